@@ -1,0 +1,254 @@
+"""ctypes plumbing shared by the tests, bench.py and __graft_entry__.smoke().
+
+Two libraries speak the same C ABI (include/aws/compression/huffman.h):
+
+  * the ORACLE  (oracle/libhuffman_oracle.so, entry points oracle_huffman_*): the CPU
+    restatement of the reference, test infrastructure only;
+  * the PRODUCT (aws-c-compression_amd/libaws-c-compression-amd.so, entry points
+    aws_huffman_*): the HIP implementation.
+
+`Codec` wraps either one behind the same Python calls so that a parity test is
+"run the same scenario on both and compare everything observable".
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(REPO, "tests", "golden")
+ORACLE_SO = os.path.join(REPO, "oracle", "libhuffman_oracle.so")
+PRODUCT_SO = os.path.join(REPO, "aws-c-compression_amd", "libaws-c-compression-amd.so")
+
+AWS_OP_SUCCESS = 0
+AWS_OP_ERR = -1
+AWS_ERROR_SHORT_BUFFER = 4
+AWS_ERROR_COMPRESSION_UNKNOWN_SYMBOL = 0x0C00
+
+
+# ----------------------------------------------------------------------------- ABI structs
+class HuffmanCode(C.Structure):  # 8 bytes
+    _fields_ = [("pattern", C.c_uint32), ("num_bits", C.c_uint8)]
+
+
+ENCODE_FN = C.CFUNCTYPE(HuffmanCode, C.c_uint8, C.c_void_p)
+DECODE_FN = C.CFUNCTYPE(C.c_uint8, C.c_uint32, C.POINTER(C.c_uint8), C.c_void_p)
+
+
+class SymbolCoder(C.Structure):  # 24 bytes
+    _fields_ = [("encode", C.c_void_p), ("decode", C.c_void_p), ("userdata", C.c_void_p)]
+
+
+class Encoder(C.Structure):  # 24 bytes
+    _fields_ = [("coder", C.POINTER(SymbolCoder)), ("eos_padding", C.c_uint8), ("overflow_bits", HuffmanCode)]
+
+
+class Decoder(C.Structure):  # 32 bytes
+    _fields_ = [
+        ("coder", C.POINTER(SymbolCoder)),
+        ("allow_growth", C.c_bool),
+        ("working_bits", C.c_uint64),
+        ("num_bits", C.c_uint8),
+    ]
+
+
+class ByteCursor(C.Structure):  # 16 bytes
+    _fields_ = [("len", C.c_size_t), ("ptr", C.c_void_p)]
+
+
+class ByteBuf(C.Structure):  # 32 bytes
+    _fields_ = [("len", C.c_size_t), ("buffer", C.c_void_p), ("capacity", C.c_size_t), ("allocator", C.c_void_p)]
+
+
+def check_abi_layout():
+    """Sizes/offsets of SURVEY.md section 8b."""
+    assert C.sizeof(HuffmanCode) == 8 and HuffmanCode.num_bits.offset == 4
+    assert C.sizeof(SymbolCoder) == 24
+    assert C.sizeof(Encoder) == 24 and Encoder.eos_padding.offset == 8 and Encoder.overflow_bits.offset == 12
+    assert C.sizeof(Decoder) == 32 and Decoder.allow_growth.offset == 8
+    assert Decoder.working_bits.offset == 16 and Decoder.num_bits.offset == 24
+    assert C.sizeof(ByteCursor) == 16 and C.sizeof(ByteBuf) == 32
+
+
+# ----------------------------------------------------------------------------- fixtures
+def load_table():
+    rows = json.load(open(os.path.join(GOLDEN, "test_coder_table.json")))["rows"]
+    patterns = (C.c_uint32 * 256)(*[r["pattern"] for r in rows])
+    lens = (C.c_uint8 * 256)(*[r["num_bits"] for r in rows])
+    return patterns, lens
+
+
+def load_json(name):
+    return json.load(open(os.path.join(GOLDEN, name)))
+
+
+def splitmix64_bytes(seed, n):
+    """numpy twin of oracle_splitmix64_fill (SURVEY.md section 8c generator)."""
+    draws = (n + 7) // 8
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, draws + 1, dtype=np.uint64)
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z.astype("<u8").view(np.uint8)[:n].copy()
+
+
+def printable_map(raw):
+    """G16KP mapping of SURVEY.md section 8c: 32 + (b % 95)."""
+    return (32 + (raw.astype(np.uint16) % 95)).astype(np.uint8)
+
+
+# ----------------------------------------------------------------------------- libraries
+_PROTOS = {
+    "huffman_encoder_init": (None, [C.POINTER(Encoder), C.POINTER(SymbolCoder)]),
+    "huffman_encoder_reset": (None, [C.POINTER(Encoder)]),
+    "huffman_decoder_init": (None, [C.POINTER(Decoder), C.POINTER(SymbolCoder)]),
+    "huffman_decoder_reset": (None, [C.POINTER(Decoder)]),
+    "huffman_decoder_allow_growth": (None, [C.POINTER(Decoder), C.c_bool]),
+    "huffman_get_encoded_length": (C.c_size_t, [C.POINTER(Encoder), ByteCursor]),
+    "huffman_encode": (C.c_int, [C.POINTER(Encoder), C.POINTER(ByteCursor), C.POINTER(ByteBuf)]),
+    "huffman_decode": (C.c_int, [C.POINTER(Decoder), C.POINTER(ByteCursor), C.POINTER(ByteBuf)]),
+}
+
+
+def _bind(lib, name, restype, argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = argtypes
+    return fn
+
+
+def load_oracle():
+    if not os.path.exists(ORACLE_SO):
+        raise RuntimeError("oracle not built: run `make -C oracle` (or __graft_entry__.build())")
+    lib = C.CDLL(ORACLE_SO)
+    for short, (res, args) in _PROTOS.items():
+        _bind(lib, "oracle_" + short, res, args)
+    _bind(lib, "oracle_last_error", C.c_int, [])
+    _bind(lib, "oracle_reset_error", None, [])
+    _bind(lib, "oracle_default_allocator", C.c_void_p, [])
+    _bind(lib, "oracle_table_coder_new", C.POINTER(SymbolCoder), [C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)])
+    _bind(lib, "oracle_table_coder_destroy", None, [C.POINTER(SymbolCoder)])
+    _bind(lib, "oracle_huffman_test_transitive", C.c_int,
+          [C.POINTER(SymbolCoder), C.c_char_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_char_p)])
+    _bind(lib, "oracle_huffman_test_transitive_chunked", C.c_int,
+          [C.POINTER(SymbolCoder), C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_char_p)])
+    _bind(lib, "oracle_splitmix64_fill", None, [C.c_void_p, C.c_size_t, C.c_uint64])
+    return lib
+
+
+def load_product():
+    """The HIP library.  Fails loudly when it is missing: there is no CPU fallback."""
+    if not os.path.exists(PRODUCT_SO):
+        raise RuntimeError("HIP library not built: %s (run __graft_entry__.build())" % PRODUCT_SO)
+    lib = C.CDLL(PRODUCT_SO, mode=C.RTLD_GLOBAL)
+    for short, (res, args) in _PROTOS.items():
+        _bind(lib, "aws_" + short, res, args)
+    _bind(lib, "aws_last_error", C.c_int, [])
+    _bind(lib, "aws_reset_error", None, [])
+    _bind(lib, "aws_default_allocator", C.c_void_p, [])
+    return lib
+
+
+class CallResult:
+    """Everything observable after one encode/decode call."""
+
+    def __init__(self, rc, err, consumed, produced, state):
+        self.rc, self.err, self.consumed, self.produced, self.state = rc, err, consumed, produced, state
+
+    def key(self):
+        return (self.rc, self.err, self.consumed, self.produced, self.state)
+
+    def __repr__(self):
+        return "CallResult(rc=%d err=%d consumed=%d produced=%d state=%s)" % self.key()
+
+
+class Codec:
+    """One of the two libraries behind a uniform Python face."""
+
+    def __init__(self, lib, prefix):
+        self.lib, self.prefix = lib, prefix
+        g = lambda n: getattr(lib, prefix + n)
+        self.encoder_init = g("huffman_encoder_init")
+        self.encoder_reset = g("huffman_encoder_reset")
+        self.decoder_init = g("huffman_decoder_init")
+        self.decoder_reset = g("huffman_decoder_reset")
+        self.decoder_allow_growth = g("huffman_decoder_allow_growth")
+        self._get_len = g("huffman_get_encoded_length")
+        self._encode = g("huffman_encode")
+        self._decode = g("huffman_decode")
+        self.last_error = getattr(lib, "oracle_last_error" if prefix == "oracle_" else "aws_last_error")
+        self.reset_error = getattr(lib, "oracle_reset_error" if prefix == "oracle_" else "aws_reset_error")
+
+    # -- state objects
+    def new_encoder(self, coder, eos_padding=None):
+        e = Encoder()
+        self.encoder_init(C.byref(e), coder)
+        if eos_padding is not None:
+            e.eos_padding = eos_padding
+        return e
+
+    def new_decoder(self, coder):
+        d = Decoder()
+        self.decoder_init(C.byref(d), coder)
+        return d
+
+    def encoded_length(self, enc, data):
+        arr = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8)) if not isinstance(data, np.ndarray) else data
+        cur = ByteCursor(arr.size, arr.ctypes.data if arr.size else None)
+        return self._get_len(C.byref(enc), cur)
+
+    # -- one call; `src`/`dst` are numpy uint8 arrays owned by the caller
+    def encode_call(self, enc, src, src_off, dst, dst_len, dst_cap):
+        """aws_huffman_encode on src[src_off:] into dst with len=dst_len, capacity=dst_cap."""
+        cur = ByteCursor(src.size - src_off, src.ctypes.data + src_off if src.size else None)
+        buf = ByteBuf(dst_len, dst.ctypes.data, dst_cap, None)
+        self.reset_error()
+        rc = self._encode(C.byref(enc), C.byref(cur), C.byref(buf))
+        err = self.last_error() if rc != 0 else 0
+        consumed = (src.size - src_off) - cur.len
+        ptr_ok = (cur.ptr or 0) == ((src.ctypes.data + src_off + consumed) if src.size else (cur.ptr or 0))
+        assert ptr_ok, "cursor pointer and length disagree"
+        nb = enc.overflow_bits.num_bits
+        # the pattern is unspecified once num_bits is 0
+        state = (nb, enc.overflow_bits.pattern if nb else 0)
+        return CallResult(rc, err, consumed, buf.len - dst_len, state)
+
+    def decode_call(self, dec, src, src_off, src_end, dst, dst_len, dst_cap):
+        """aws_huffman_decode on src[src_off:src_end] into dst with len=dst_len, capacity=dst_cap."""
+        n = src_end - src_off
+        cur = ByteCursor(n, src.ctypes.data + src_off if src.size else None)
+        buf = ByteBuf(dst_len, dst.ctypes.data, dst_cap, None)
+        self.reset_error()
+        rc = self._decode(C.byref(dec), C.byref(cur), C.byref(buf))
+        err = self.last_error() if rc != 0 else 0
+        state = (dec.num_bits, dec.working_bits)
+        return CallResult(rc, err, n - cur.len, buf.len - dst_len, state)
+
+    # -- conveniences
+    def encode_all(self, coder, data, eos_padding=None, slack=64):
+        """One-shot encode into a buffer that is certainly large enough."""
+        src = np.ascontiguousarray(data, dtype=np.uint8)
+        cap = src.size * 4 + slack
+        dst = np.zeros(cap, dtype=np.uint8)
+        enc = self.new_encoder(coder, eos_padding)
+        r = self.encode_call(enc, src, 0, dst, 0, cap)
+        assert r.rc == 0 and r.consumed == src.size, r
+        return dst[: r.produced].copy()
+
+    def decode_all(self, coder, data, out_cap):
+        src = np.ascontiguousarray(data, dtype=np.uint8)
+        dst = np.zeros(max(out_cap, 1), dtype=np.uint8)
+        dec = self.new_decoder(coder)
+        r = self.decode_call(dec, src, 0, src.size, dst, 0, out_cap)
+        return r, dst[: r.produced].copy()
+
+
+def oracle_codec():
+    return Codec(load_oracle(), "oracle_")
+
+
+def product_codec():
+    return Codec(load_product(), "aws_")
