@@ -1,0 +1,114 @@
+#ifndef HUFFMAN_AMD_DEVICE_TYPES_H
+#define HUFFMAN_AMD_DEVICE_TYPES_H
+/*
+ * Plain-C records shared by the C99 host layer (csrc/host) and the HIP shim
+ * (csrc/hip).  Everything here lives in device memory unless stated otherwise.
+ *
+ * Vocabulary
+ *   item      one independent encode or decode job (one aws_huffman_encode /
+ *             aws_huffman_decode call's worth of work)
+ *   segment   HUFD_ENC_SEG_BYTES consecutive input symbols of one encode item;
+ *             one workgroup packs one segment
+ *   chunk     HUFD_DEC_CHUNK_BYTES consecutive encoded bytes of one decode item;
+ *             one workgroup handles one chunk, one lane one sub-chunk of it
+ *   entry state  for a sub-chunk starting at stream bit B: the offset e in
+ *             [0, n_states) such that the first code that starts at or after B
+ *             starts at B + e
+ */
+#include <stdint.h>
+
+#define HUFD_ENC_SEG_BYTES 16384u
+#define HUFD_ENC_THREADS 256u
+
+#define HUFD_DEC_SUB_BYTES 128u
+#define HUFD_DEC_SUB_BITS (HUFD_DEC_SUB_BYTES * 8u)
+#define HUFD_DEC_LANES 256u
+#define HUFD_DEC_CHUNK_BYTES (HUFD_DEC_SUB_BYTES * HUFD_DEC_LANES)
+#define HUFD_DEC_MAX_STATES 16u
+#define HUFD_DEC_MAX_LUT_BITS 12u
+#define HUFD_DEC_STAGE_BYTES 40960u /* LDS bytes for a chunk's decoded symbols */
+
+#define HUFD_SCAN_SMALL_MAX 64u /* items with at most this many segments/chunks are scanned by one thread */
+#define HUFD_SCAN_LARGE_THREADS 1024u
+
+#define HUFD_NONE32 0xFFFFFFFFu
+
+/* encode item status */
+#define HUFD_ENC_OK 0u
+#define HUFD_ENC_SHORT 1u
+#define HUFD_ENC_UNKNOWN 2u
+#define HUFD_ENC_DECIDE 3u /* unknown symbol and capacity edge fall into one segment: its workgroup decides */
+
+/* why a decode walk ended */
+#define HUFD_STOP_NONE 0u
+#define HUFD_STOP_END 1u        /* all stream bits consumed */
+#define HUFD_STOP_INCOMPLETE 2u /* a code runs past the end of the stream */
+#define HUFD_STOP_INVALID 3u    /* no code matches */
+
+struct hufd_tables {
+    const uint64_t *enc_table; /* [256] low 32 bits: code masked to its length, high 32 bits: length (0 = no code) */
+    const uint16_t *dec_lut;   /* [1 << lut_bits] symbol << 8 | length, length 0 = no code; NULL when decode is unavailable */
+    uint32_t max_bits;
+    uint32_t min_bits;
+    uint32_t lut_bits;
+    uint32_t n_states; /* max(max_bits, 8) */
+};
+
+struct hufd_enc_item {
+    uint64_t in_off;
+    uint64_t in_len;
+    uint64_t out_off;
+    uint64_t out_cap;
+    uint32_t ovf_pattern; /* masked to ovf_bits */
+    uint32_t ovf_bits;
+    uint32_t eos_padding;
+    uint32_t first_seg; /* index of the item's first segment in the plan's segment numbering */
+    uint32_t n_segs;
+    uint32_t reserved;
+};
+
+/* written by the scan kernel, read by the pack kernel */
+struct hufd_enc_item_state {
+    uint64_t total_bits; /* overflow-in bits + every code bit of the item */
+    uint32_t status;     /* HUFD_ENC_* */
+    uint32_t unk_seg;    /* segment holding the first symbol without a code, or HUFD_NONE32 */
+    uint32_t unk_idx;    /* its index inside that segment */
+    uint32_t reserved;
+};
+
+struct hufd_enc_result {
+    uint32_t status; /* HUFD_ENC_OK / _SHORT / _UNKNOWN */
+    uint32_t ovf_pattern;
+    uint32_t ovf_bits;
+    uint32_t reserved;
+    uint64_t consumed;
+    uint64_t produced;
+    uint64_t total_bits; /* overflow-in bits + every code bit of the item (length queries) */
+};
+
+struct hufd_dec_item {
+    uint64_t in_off;
+    uint64_t in_len;
+    uint64_t out_off;
+    uint64_t out_cap;
+    uint32_t first_bit;
+    uint32_t first_chunk;
+    uint32_t n_chunks;
+    uint32_t reserved;
+};
+
+/* written by the scan kernel */
+struct hufd_dec_item_state {
+    uint64_t total_symbols; /* symbols on the true path before it stops */
+};
+
+/* raw record; the host layer turns it into rc / error / bits_consumed */
+struct hufd_dec_result {
+    uint64_t total_symbols; /* same as the state: how many symbols the stream holds */
+    uint64_t stop_bit;      /* stream bit (from byte 0 of the item) where the true path stopped */
+    uint64_t cap_bit;       /* start bit of symbol number out_cap, when total_symbols > out_cap */
+    uint32_t stop_kind;     /* HUFD_STOP_* */
+    uint32_t reserved;
+};
+
+#endif /* HUFFMAN_AMD_DEVICE_TYPES_H */

@@ -1,0 +1,64 @@
+#ifndef HUFFMAN_AMD_KERNELS_H
+#define HUFFMAN_AMD_KERNELS_H
+/*
+ * C interface of the kernel file: argument packs and launch wrappers.  The
+ * pointers are device pointers; the launches are asynchronous on `stream`
+ * (a hipStream_t carried as void *).  Return value: 0 or a hipError_t.
+ */
+#include <stdint.h>
+
+#include "device_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct hufk_encode_args {
+    struct hufd_tables tables;
+    const struct hufd_enc_item *items;
+    uint32_t n_items;
+    const uint32_t *seg_item; /* [n_segs] item index of every segment */
+    uint32_t n_segs;
+    const uint32_t *large_items; /* [n_large] items with more than HUFD_SCAN_SMALL_MAX segments */
+    uint32_t n_large;
+    uint32_t length_only; /* stop after the scan */
+    const void *d_in;
+    void *d_out;
+    uint32_t *seg_bits;   /* [n_segs] scratch */
+    uint32_t *seg_unk;    /* [n_segs] scratch */
+    uint64_t *seg_bitoff; /* [n_segs] scratch */
+    struct hufd_enc_item_state *states; /* [n_items] scratch */
+    struct hufd_enc_result *results;    /* [n_items] */
+};
+
+struct hufk_decode_args {
+    struct hufd_tables tables;
+    const struct hufd_dec_item *items;
+    uint32_t n_items;
+    const uint32_t *chunk_item; /* [n_chunks] */
+    uint32_t n_chunks;
+    const uint32_t *large_items;
+    uint32_t n_large;
+    const void *d_in;
+    void *d_out;
+    uint16_t *fn_tab;      /* [n_chunks][n_states][HUFD_DEC_LANES] scratch */
+    uint32_t *chunk_fn;    /* [n_chunks][n_states] scratch */
+    uint32_t *chunk_entry; /* [n_chunks] scratch */
+    uint64_t *chunk_base;  /* [n_chunks] scratch */
+    struct hufd_dec_item_state *states; /* [n_items] scratch */
+    struct hufd_dec_result *results;    /* [n_items] */
+};
+
+/* one-time per-process kernel attribute setup (dynamic LDS above 64 KiB) */
+int hufk_init(void);
+
+uint32_t hufk_enc_image_words(uint32_t max_bits);
+int hufk_encode_launch(const struct hufk_encode_args *args, void *stream);
+int hufk_decode_launch(const struct hufk_decode_args *args, void *stream);
+int hufk_fill_splitmix64(void *dst, uint64_t len, uint64_t seed, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* HUFFMAN_AMD_KERNELS_H */

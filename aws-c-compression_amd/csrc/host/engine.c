@@ -1,0 +1,904 @@
+/*
+ * Host layer (C99) of libaws-c-compression-amd: engines, plans and the
+ * translation between the reference's call semantics and the device records.
+ * All symbol work happens in the HIP kernels (csrc/hip/huffman_kernels.hip);
+ * this file tabulates coders, lays out items, launches, and reads results back.
+ * There is no CPU implementation of encode or decode here.
+ */
+#include "engine.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ small helpers */
+
+static int raise_hip(int hip_error) {
+    (void)hip_error;
+    return aws_raise_error(AWS_ERROR_UNKNOWN);
+}
+
+static void *device_upload(const void *host, size_t size, void *stream, int *err) {
+    void *d = hufs_malloc(size);
+    if (!d) {
+        *err = 2; /* hipErrorOutOfMemory */
+        return NULL;
+    }
+    *err = hufs_copy_h2d(d, host, size, stream);
+    if (!*err) {
+        *err = hufs_stream_sync(stream);
+    }
+    if (*err) {
+        hufs_free(d);
+        return NULL;
+    }
+    return d;
+}
+
+/* ------------------------------------------------------------------ engine */
+
+static int s_kernels_ready;
+
+int aws_huffman_amd_engine_new(
+    struct aws_huffman_amd_engine **out_engine,
+    struct aws_huffman_symbol_coder *coder,
+    int device) {
+
+    *out_engine = NULL;
+    if (!coder || !coder->encode) {
+        return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
+    }
+    if (hufs_device_count() <= 0) {
+        /* fail loudly: there is no CPU path to fall back to */
+        return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION);
+    }
+    if (device < 0) {
+        if (hufs_get_device(&device)) {
+            return aws_raise_error(AWS_ERROR_UNKNOWN);
+        }
+    }
+    if (hufs_set_device(device)) {
+        return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
+    }
+    if (!s_kernels_ready) {
+        const int e = hufk_init();
+        if (e) {
+            return raise_hip(e);
+        }
+        s_kernels_ready = 1;
+    }
+
+    struct aws_huffman_amd_engine *eng = calloc(1, sizeof(*eng));
+    if (!eng) {
+        return aws_raise_error(AWS_ERROR_OOM);
+    }
+    eng->device = device;
+    eng->coder = coder;
+    eng->key_encode = (void *)coder->encode;
+    eng->key_decode = (void *)coder->decode;
+    eng->key_userdata = coder->userdata;
+
+    /* encode table: one callback per symbol (reference huffman.h:37) */
+    uint32_t max_bits = 0, min_bits = 33;
+    for (int sym = 0; sym < 256; ++sym) {
+        const struct aws_huffman_code code = coder->encode((uint8_t)sym, coder->userdata);
+        if (code.num_bits > 32) {
+            free(eng);
+            return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
+        }
+        const uint32_t masked =
+            code.num_bits == 0 ? 0 : (code.num_bits == 32 ? code.pattern : code.pattern & ((1u << code.num_bits) - 1u));
+        eng->enc_table[sym] = ((uint64_t)code.num_bits << 32) | masked;
+        if (code.num_bits) {
+            max_bits = code.num_bits > max_bits ? code.num_bits : max_bits;
+            min_bits = code.num_bits < min_bits ? code.num_bits : min_bits;
+        }
+    }
+    if (max_bits == 0) {
+        min_bits = 1;
+    }
+    eng->tables.max_bits = max_bits;
+    eng->tables.min_bits = min_bits;
+    eng->tables.n_states = max_bits > 8 ? max_bits : 8;
+
+    /* decode table: the callback answers from the first max_bits bits of its window when it is
+     * the inverse of the encode table; probe every such window with zero fill and with one
+     * fill (reference huffman.h:48) and keep the table only if the fill never matters */
+    eng->can_decode = false;
+    if (coder->decode && max_bits >= 1 && max_bits <= HUFD_DEC_MAX_LUT_BITS) {
+        const uint32_t windows = 1u << max_bits;
+        const uint32_t fill = (1u << (32 - max_bits)) - 1u;
+        uint16_t *lut = malloc(windows * sizeof(uint16_t));
+        if (!lut) {
+            free(eng);
+            return aws_raise_error(AWS_ERROR_OOM);
+        }
+        bool tabular = true;
+        for (uint32_t w = 0; w < windows && tabular; ++w) {
+            uint8_t s0 = 0, s1 = 0;
+            const uint32_t bits = w << (32 - max_bits);
+            const uint8_t n0 = coder->decode(bits, &s0, coder->userdata);
+            const uint8_t n1 = coder->decode(bits | fill, &s1, coder->userdata);
+            if (n0 != n1 || n0 > max_bits || (n0 && s0 != s1)) {
+                tabular = false;
+            }
+            lut[w] = n0 ? (uint16_t)(((uint16_t)s0 << 8) | n0) : 0;
+        }
+        if (tabular) {
+            eng->dec_lut_host = lut;
+            eng->tables.lut_bits = max_bits;
+            eng->can_decode = true;
+        } else {
+            free(lut);
+        }
+    }
+
+    int err = hufs_stream_create(&eng->stream);
+    if (!err) {
+        eng->d_enc_table = device_upload(eng->enc_table, sizeof(eng->enc_table), eng->stream, &err);
+    }
+    if (!err && eng->can_decode) {
+        eng->d_dec_lut =
+            device_upload(eng->dec_lut_host, (size_t)sizeof(uint16_t) << eng->tables.lut_bits, eng->stream, &err);
+    }
+    if (err) {
+        aws_huffman_amd_engine_destroy(eng);
+        return raise_hip(err);
+    }
+    eng->tables.enc_table = eng->d_enc_table;
+    eng->tables.dec_lut = eng->d_dec_lut;
+    *out_engine = eng;
+    return AWS_OP_SUCCESS;
+}
+
+void aws_huffman_amd_engine_destroy(struct aws_huffman_amd_engine *eng) {
+    if (!eng) {
+        return;
+    }
+    hufs_set_device(eng->device);
+    if (eng->one_enc) {
+        aws_huffman_amd_encode_plan_destroy(eng->one_enc);
+    }
+    if (eng->one_dec) {
+        aws_huffman_amd_decode_plan_destroy(eng->one_dec);
+    }
+    hufs_free(eng->one_in);
+    hufs_free(eng->one_out);
+    hufs_free(eng->d_enc_table);
+    hufs_free(eng->d_dec_lut);
+    hufs_stream_destroy(eng->stream);
+    free(eng->dec_lut_host);
+    free(eng);
+}
+
+uint32_t aws_huffman_amd_engine_max_code_bits(const struct aws_huffman_amd_engine *eng) {
+    return eng->tables.max_bits;
+}
+
+bool aws_huffman_amd_engine_can_decode(const struct aws_huffman_amd_engine *eng) {
+    return eng->can_decode;
+}
+
+void *aws_huffman_amd_engine_stream(struct aws_huffman_amd_engine *eng) {
+    return eng->stream;
+}
+
+/* ------------------------------------------------------------------ encode plans */
+
+static void enc_plan_release_device(struct aws_huffman_amd_encode_plan *p) {
+    hufs_free(p->d_items);
+    hufs_free(p->d_seg_item);
+    hufs_free(p->d_large);
+    hufs_free(p->d_seg_bits);
+    hufs_free(p->d_seg_unk);
+    hufs_free(p->d_seg_bitoff);
+    hufs_free(p->d_states);
+    hufs_free(p->d_results);
+    p->d_items = NULL;
+    p->d_seg_item = NULL;
+    p->d_large = NULL;
+    p->d_seg_bits = NULL;
+    p->d_seg_unk = NULL;
+    p->d_seg_bitoff = NULL;
+    p->d_states = NULL;
+    p->d_results = NULL;
+    p->cap_items = p->cap_segs = p->cap_large = 0;
+}
+
+/* segments an item needs: at least one when there is anything to write */
+static uint64_t enc_item_segments(const struct aws_huffman_amd_encode_item *it) {
+    if (it->in_len == 0) {
+        return it->overflow_in.num_bits ? 1 : 0;
+    }
+    return (it->in_len + HUFD_ENC_SEG_BYTES - 1) / HUFD_ENC_SEG_BYTES;
+}
+
+/* (Re)fills a plan from host items, growing its device arrays when needed. */
+static int enc_plan_fill(
+    struct aws_huffman_amd_encode_plan *p,
+    const struct aws_huffman_amd_encode_item *items,
+    size_t n_items) {
+
+    struct aws_huffman_amd_engine *eng = p->engine;
+    uint64_t n_segs = 0, n_large = 0;
+    for (size_t i = 0; i < n_items; ++i) {
+        if (items[i].overflow_in.num_bits > 32) {
+            return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
+        }
+        const uint64_t segs = enc_item_segments(&items[i]);
+        n_segs += segs;
+        n_large += segs > HUFD_SCAN_SMALL_MAX;
+    }
+    if (n_segs >= 0xFFFFFFFFull || n_items >= 0xFFFFFFFFull) {
+        return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
+    }
+
+    struct hufd_enc_item *h_items = malloc((n_items ? n_items : 1) * sizeof(*h_items));
+    uint32_t *h_seg_item = malloc((n_segs ? n_segs : 1) * sizeof(uint32_t));
+    uint32_t *h_large = malloc((n_large ? n_large : 1) * sizeof(uint32_t));
+    if (!h_items || !h_seg_item || !h_large) {
+        free(h_items);
+        free(h_seg_item);
+        free(h_large);
+        return aws_raise_error(AWS_ERROR_OOM);
+    }
+    uint32_t seg = 0, large = 0;
+    for (size_t i = 0; i < n_items; ++i) {
+        const struct aws_huffman_amd_encode_item *src = &items[i];
+        struct hufd_enc_item *dst = &h_items[i];
+        const uint32_t segs = (uint32_t)enc_item_segments(src);
+        const uint32_t ob = src->overflow_in.num_bits;
+        dst->in_off = src->in_offset;
+        dst->in_len = src->in_len;
+        dst->out_off = src->out_offset;
+        dst->out_cap = src->out_capacity;
+        dst->ovf_bits = ob;
+        dst->ovf_pattern = ob == 0 ? 0 : (ob == 32 ? src->overflow_in.pattern : src->overflow_in.pattern & ((1u << ob) - 1u));
+        dst->eos_padding = src->eos_padding;
+        dst->first_seg = seg;
+        dst->n_segs = segs;
+        dst->reserved = 0;
+        for (uint32_t k = 0; k < segs; ++k) {
+            h_seg_item[seg++] = (uint32_t)i;
+        }
+        if (segs > HUFD_SCAN_SMALL_MAX) {
+            h_large[large++] = (uint32_t)i;
+        }
+    }
+
+    int err = 0;
+    hufs_set_device(eng->device);
+    if (n_items > p->cap_items || n_segs > p->cap_segs || n_large > p->cap_large) {
+        enc_plan_release_device(p);
+        const size_t ci = n_items ? n_items : 1, cs = n_segs ? n_segs : 1, cl = n_large ? n_large : 1;
+        p->d_items = hufs_malloc(ci * sizeof(struct hufd_enc_item));
+        p->d_seg_item = hufs_malloc(cs * sizeof(uint32_t));
+        p->d_large = hufs_malloc(cl * sizeof(uint32_t));
+        p->d_seg_bits = hufs_malloc(cs * sizeof(uint32_t));
+        p->d_seg_unk = hufs_malloc(cs * sizeof(uint32_t));
+        p->d_seg_bitoff = hufs_malloc(cs * sizeof(uint64_t));
+        p->d_states = hufs_malloc(ci * sizeof(struct hufd_enc_item_state));
+        p->d_results = hufs_malloc(ci * sizeof(struct hufd_enc_result));
+        if (!p->d_items || !p->d_seg_item || !p->d_large || !p->d_seg_bits || !p->d_seg_unk || !p->d_seg_bitoff ||
+            !p->d_states || !p->d_results) {
+            err = 2;
+        }
+        p->cap_items = ci;
+        p->cap_segs = cs;
+        p->cap_large = cl;
+    }
+    if (!err) {
+        err = hufs_copy_h2d(p->d_items, h_items, n_items * sizeof(*h_items), eng->stream);
+    }
+    if (!err) {
+        err = hufs_copy_h2d(p->d_seg_item, h_seg_item, n_segs * sizeof(uint32_t), eng->stream);
+    }
+    if (!err) {
+        err = hufs_copy_h2d(p->d_large, h_large, n_large * sizeof(uint32_t), eng->stream);
+    }
+    if (!err) {
+        err = hufs_stream_sync(eng->stream);
+    }
+    free(h_items);
+    free(h_seg_item);
+    free(h_large);
+    if (err) {
+        return raise_hip(err);
+    }
+    p->n_items = (uint32_t)n_items;
+    p->n_segs = (uint32_t)n_segs;
+    p->n_large = (uint32_t)n_large;
+    return AWS_OP_SUCCESS;
+}
+
+int aws_huffman_amd_encode_plan_new(
+    struct aws_huffman_amd_encode_plan **out_plan,
+    struct aws_huffman_amd_engine *eng,
+    const struct aws_huffman_amd_encode_item *items,
+    size_t item_count) {
+
+    *out_plan = NULL;
+    struct aws_huffman_amd_encode_plan *p = calloc(1, sizeof(*p));
+    if (!p) {
+        return aws_raise_error(AWS_ERROR_OOM);
+    }
+    p->engine = eng;
+    if (enc_plan_fill(p, items, item_count)) {
+        aws_huffman_amd_encode_plan_destroy(p);
+        return AWS_OP_ERR;
+    }
+    *out_plan = p;
+    return AWS_OP_SUCCESS;
+}
+
+void aws_huffman_amd_encode_plan_destroy(struct aws_huffman_amd_encode_plan *p) {
+    if (p) {
+        hufs_set_device(p->engine->device);
+        enc_plan_release_device(p);
+        free(p);
+    }
+}
+
+int aws_huffman_amd_encode_plan_launch(
+    struct aws_huffman_amd_encode_plan *p,
+    const void *device_input,
+    void *device_output,
+    bool length_only,
+    void *stream) {
+
+    struct hufk_encode_args a;
+    memset(&a, 0, sizeof(a));
+    a.tables = p->engine->tables;
+    a.items = p->d_items;
+    a.n_items = p->n_items;
+    a.seg_item = p->d_seg_item;
+    a.n_segs = p->n_segs;
+    a.large_items = p->d_large;
+    a.n_large = p->n_large;
+    a.length_only = length_only;
+    a.d_in = device_input;
+    a.d_out = device_output;
+    a.seg_bits = p->d_seg_bits;
+    a.seg_unk = p->d_seg_unk;
+    a.seg_bitoff = p->d_seg_bitoff;
+    a.states = p->d_states;
+    a.results = p->d_results;
+    hufs_set_device(p->engine->device);
+    const int err = hufk_encode_launch(&a, stream ? stream : p->engine->stream);
+    return err ? raise_hip(err) : AWS_OP_SUCCESS;
+}
+
+int aws_huffman_amd_encode_plan_raw_results(
+    struct aws_huffman_amd_encode_plan *p,
+    struct hufd_enc_result *raw,
+    void *stream) {
+    void *st = stream ? stream : p->engine->stream;
+    hufs_set_device(p->engine->device);
+    int err = hufs_copy_d2h(raw, p->d_results, (size_t)p->n_items * sizeof(*raw), st);
+    if (!err) {
+        err = hufs_stream_sync(st);
+    }
+    return err ? raise_hip(err) : AWS_OP_SUCCESS;
+}
+
+void aws_huffman_amd_encode_result_from_raw(
+    const struct hufd_enc_result *raw,
+    struct aws_huffman_amd_encode_result *out) {
+    out->consumed = raw->consumed;
+    out->produced = raw->produced;
+    out->overflow_out.pattern = raw->ovf_pattern;
+    out->overflow_out.num_bits = (uint8_t)raw->ovf_bits;
+    switch (raw->status) {
+        case HUFD_ENC_OK:
+            out->rc = AWS_OP_SUCCESS;
+            out->error = 0;
+            break;
+        case HUFD_ENC_SHORT:
+            out->rc = AWS_OP_ERR;
+            out->error = AWS_ERROR_SHORT_BUFFER;
+            break;
+        case HUFD_ENC_UNKNOWN:
+            out->rc = AWS_OP_ERR;
+            out->error = AWS_ERROR_COMPRESSION_UNKNOWN_SYMBOL;
+            break;
+        default:
+            out->rc = AWS_OP_ERR;
+            out->error = AWS_ERROR_INVALID_STATE;
+            break;
+    }
+}
+
+int aws_huffman_amd_encode_plan_results(
+    struct aws_huffman_amd_encode_plan *p,
+    struct aws_huffman_amd_encode_result *results,
+    void *stream) {
+
+    struct hufd_enc_result *raw = malloc((p->n_items ? p->n_items : 1) * sizeof(*raw));
+    if (!raw) {
+        return aws_raise_error(AWS_ERROR_OOM);
+    }
+    if (aws_huffman_amd_encode_plan_raw_results(p, raw, stream)) {
+        free(raw);
+        return AWS_OP_ERR;
+    }
+    for (uint32_t i = 0; i < p->n_items; ++i) {
+        aws_huffman_amd_encode_result_from_raw(&raw[i], &results[i]);
+    }
+    free(raw);
+    return AWS_OP_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ decode plans */
+
+static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
+    hufs_free(p->d_items);
+    hufs_free(p->d_chunk_item);
+    hufs_free(p->d_large);
+    hufs_free(p->d_fn_tab);
+    hufs_free(p->d_chunk_fn);
+    hufs_free(p->d_chunk_entry);
+    hufs_free(p->d_chunk_base);
+    hufs_free(p->d_states);
+    hufs_free(p->d_results);
+    p->d_items = NULL;
+    p->d_chunk_item = NULL;
+    p->d_large = NULL;
+    p->d_fn_tab = NULL;
+    p->d_chunk_fn = NULL;
+    p->d_chunk_entry = NULL;
+    p->d_chunk_base = NULL;
+    p->d_states = NULL;
+    p->d_results = NULL;
+    p->cap_items = p->cap_chunks = p->cap_large = 0;
+}
+
+static int dec_plan_fill(
+    struct aws_huffman_amd_decode_plan *p,
+    const struct aws_huffman_amd_decode_item *items,
+    size_t n_items) {
+
+    struct aws_huffman_amd_engine *eng = p->engine;
+    if (!eng->can_decode) {
+        return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION);
+    }
+    uint64_t n_chunks = 0, n_large = 0;
+    for (size_t i = 0; i < n_items; ++i) {
+        /* run counts in the large scan are 26-bit: 4 GiB of encoded bytes per item is the limit */
+        if (items[i].first_bit > 7 || items[i].in_len > 0xFFFFFFFFull) {
+            return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
+        }
+        const uint64_t chunks = (items[i].in_len + HUFD_DEC_CHUNK_BYTES - 1) / HUFD_DEC_CHUNK_BYTES;
+        n_chunks += chunks;
+        n_large += chunks > HUFD_SCAN_SMALL_MAX;
+    }
+    if (n_chunks >= 0xFFFFFFFFull || n_items >= 0xFFFFFFFFull) {
+        return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
+    }
+
+    struct hufd_dec_item *h_items = malloc((n_items ? n_items : 1) * sizeof(*h_items));
+    uint32_t *h_chunk_item = malloc((n_chunks ? n_chunks : 1) * sizeof(uint32_t));
+    uint32_t *h_large = malloc((n_large ? n_large : 1) * sizeof(uint32_t));
+    if (!h_items || !h_chunk_item || !h_large) {
+        free(h_items);
+        free(h_chunk_item);
+        free(h_large);
+        return aws_raise_error(AWS_ERROR_OOM);
+    }
+    uint32_t chunk = 0, large = 0;
+    for (size_t i = 0; i < n_items; ++i) {
+        const struct aws_huffman_amd_decode_item *src = &items[i];
+        struct hufd_dec_item *dst = &h_items[i];
+        const uint32_t chunks = (uint32_t)((src->in_len + HUFD_DEC_CHUNK_BYTES - 1) / HUFD_DEC_CHUNK_BYTES);
+        dst->in_off = src->in_offset;
+        dst->in_len = src->in_len;
+        dst->out_off = src->out_offset;
+        dst->out_cap = src->out_capacity;
+        dst->first_bit = src->first_bit;
+        dst->first_chunk = chunk;
+        dst->n_chunks = chunks;
+        dst->reserved = 0;
+        for (uint32_t k = 0; k < chunks; ++k) {
+            h_chunk_item[chunk++] = (uint32_t)i;
+        }
+        if (chunks > HUFD_SCAN_SMALL_MAX) {
+            h_large[large++] = (uint32_t)i;
+        }
+    }
+
+    int err = 0;
+    const uint32_t ns = eng->tables.n_states;
+    hufs_set_device(eng->device);
+    if (n_items > p->cap_items || n_chunks > p->cap_chunks || n_large > p->cap_large) {
+        dec_plan_release_device(p);
+        const size_t ci = n_items ? n_items : 1, cc = n_chunks ? n_chunks : 1, cl = n_large ? n_large : 1;
+        p->d_items = hufs_malloc(ci * sizeof(struct hufd_dec_item));
+        p->d_chunk_item = hufs_malloc(cc * sizeof(uint32_t));
+        p->d_large = hufs_malloc(cl * sizeof(uint32_t));
+        p->d_fn_tab = hufs_malloc(cc * ns * HUFD_DEC_LANES * sizeof(uint16_t));
+        p->d_chunk_fn = hufs_malloc(cc * ns * sizeof(uint32_t));
+        p->d_chunk_entry = hufs_malloc(cc * sizeof(uint32_t));
+        p->d_chunk_base = hufs_malloc(cc * sizeof(uint64_t));
+        p->d_states = hufs_malloc(ci * sizeof(struct hufd_dec_item_state));
+        p->d_results = hufs_malloc(ci * sizeof(struct hufd_dec_result));
+        if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_chunk_fn || !p->d_chunk_entry ||
+            !p->d_chunk_base || !p->d_states || !p->d_results) {
+            err = 2;
+        }
+        p->cap_items = ci;
+        p->cap_chunks = cc;
+        p->cap_large = cl;
+    }
+    if (!err) {
+        err = hufs_copy_h2d(p->d_items, h_items, n_items * sizeof(*h_items), eng->stream);
+    }
+    if (!err) {
+        err = hufs_copy_h2d(p->d_chunk_item, h_chunk_item, n_chunks * sizeof(uint32_t), eng->stream);
+    }
+    if (!err) {
+        err = hufs_copy_h2d(p->d_large, h_large, n_large * sizeof(uint32_t), eng->stream);
+    }
+    if (!err) {
+        err = hufs_stream_sync(eng->stream);
+    }
+    /* keep what the result translation needs */
+    if (!err) {
+        struct aws_huffman_amd_decode_item *keep = realloc(p->h_items, (n_items ? n_items : 1) * sizeof(*keep));
+        if (!keep) {
+            err = 2;
+        } else {
+            memcpy(keep, items, n_items * sizeof(*keep));
+            p->h_items = keep;
+        }
+    }
+    free(h_items);
+    free(h_chunk_item);
+    free(h_large);
+    if (err) {
+        return raise_hip(err);
+    }
+    p->n_items = (uint32_t)n_items;
+    p->n_chunks = (uint32_t)n_chunks;
+    p->n_large = (uint32_t)n_large;
+    return AWS_OP_SUCCESS;
+}
+
+int aws_huffman_amd_decode_plan_new(
+    struct aws_huffman_amd_decode_plan **out_plan,
+    struct aws_huffman_amd_engine *eng,
+    const struct aws_huffman_amd_decode_item *items,
+    size_t item_count) {
+
+    *out_plan = NULL;
+    struct aws_huffman_amd_decode_plan *p = calloc(1, sizeof(*p));
+    if (!p) {
+        return aws_raise_error(AWS_ERROR_OOM);
+    }
+    p->engine = eng;
+    if (dec_plan_fill(p, items, item_count)) {
+        aws_huffman_amd_decode_plan_destroy(p);
+        return AWS_OP_ERR;
+    }
+    *out_plan = p;
+    return AWS_OP_SUCCESS;
+}
+
+void aws_huffman_amd_decode_plan_destroy(struct aws_huffman_amd_decode_plan *p) {
+    if (p) {
+        hufs_set_device(p->engine->device);
+        dec_plan_release_device(p);
+        free(p->h_items);
+        free(p);
+    }
+}
+
+int aws_huffman_amd_decode_plan_launch(
+    struct aws_huffman_amd_decode_plan *p,
+    const void *device_input,
+    void *device_output,
+    void *stream) {
+
+    struct hufk_decode_args a;
+    memset(&a, 0, sizeof(a));
+    a.tables = p->engine->tables;
+    a.items = p->d_items;
+    a.n_items = p->n_items;
+    a.chunk_item = p->d_chunk_item;
+    a.n_chunks = p->n_chunks;
+    a.large_items = p->d_large;
+    a.n_large = p->n_large;
+    a.d_in = device_input;
+    a.d_out = device_output;
+    a.fn_tab = p->d_fn_tab;
+    a.chunk_fn = p->d_chunk_fn;
+    a.chunk_entry = p->d_chunk_entry;
+    a.chunk_base = p->d_chunk_base;
+    a.states = p->d_states;
+    a.results = p->d_results;
+    hufs_set_device(p->engine->device);
+    const int err = hufk_decode_launch(&a, stream ? stream : p->engine->stream);
+    return err ? raise_hip(err) : AWS_OP_SUCCESS;
+}
+
+/*
+ * Device record -> what aws_huffman_decode would have returned
+ * (reference source/huffman.c:240-268; DESIGN.md "Decode outcome").
+ */
+void aws_huffman_amd_decode_result_from_raw(
+    const struct hufd_dec_result *raw,
+    const struct aws_huffman_amd_decode_item *item,
+    struct aws_huffman_amd_decode_result *out) {
+
+    if (raw->total_symbols > item->out_capacity) {
+        /* symbol number out_capacity was recognised with nowhere to go: huffman.c:257-268 */
+        out->rc = AWS_OP_ERR;
+        out->error = AWS_ERROR_SHORT_BUFFER;
+        out->produced = item->out_capacity;
+        out->bits_consumed = raw->cap_bit - item->first_bit;
+        return;
+    }
+    out->produced = raw->total_symbols;
+    out->bits_consumed = raw->stop_bit - item->first_bit;
+    out->rc = AWS_OP_SUCCESS;
+    out->error = 0;
+    if (raw->stop_kind == HUFD_STOP_INVALID) {
+        const uint64_t left = item->in_len * 8 - raw->stop_bit;
+        if (left >= 32) { /* huffman.c:240-247 */
+            out->rc = AWS_OP_ERR;
+            out->error = AWS_ERROR_COMPRESSION_UNKNOWN_SYMBOL;
+        }
+    } else if (raw->stop_kind == HUFD_STOP_NONE) {
+        out->rc = AWS_OP_ERR;
+        out->error = AWS_ERROR_INVALID_STATE;
+    }
+}
+
+int aws_huffman_amd_decode_plan_results(
+    struct aws_huffman_amd_decode_plan *p,
+    struct aws_huffman_amd_decode_result *results,
+    void *stream) {
+
+    void *st = stream ? stream : p->engine->stream;
+    struct hufd_dec_result *raw = malloc((p->n_items ? p->n_items : 1) * sizeof(*raw));
+    if (!raw) {
+        return aws_raise_error(AWS_ERROR_OOM);
+    }
+    hufs_set_device(p->engine->device);
+    int err = hufs_copy_d2h(raw, p->d_results, (size_t)p->n_items * sizeof(*raw), st);
+    if (!err) {
+        err = hufs_stream_sync(st);
+    }
+    if (err) {
+        free(raw);
+        return raise_hip(err);
+    }
+    for (uint32_t i = 0; i < p->n_items; ++i) {
+        aws_huffman_amd_decode_result_from_raw(&raw[i], &p->h_items[i], &results[i]);
+    }
+    free(raw);
+    return AWS_OP_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ one-item helpers for the host-pointer API */
+
+static int one_shot_reserve(struct aws_huffman_amd_engine *eng, size_t in_bytes, size_t out_bytes) {
+    hufs_set_device(eng->device);
+    if (in_bytes > eng->one_in_cap) {
+        hufs_free(eng->one_in);
+        eng->one_in_cap = in_bytes + in_bytes / 4 + 4096;
+        eng->one_in = hufs_malloc(eng->one_in_cap);
+        if (!eng->one_in) {
+            eng->one_in_cap = 0;
+            return aws_raise_error(AWS_ERROR_OOM);
+        }
+    }
+    if (out_bytes > eng->one_out_cap) {
+        hufs_free(eng->one_out);
+        eng->one_out_cap = out_bytes + out_bytes / 4 + 4096;
+        eng->one_out = hufs_malloc(eng->one_out_cap);
+        if (!eng->one_out) {
+            eng->one_out_cap = 0;
+            return aws_raise_error(AWS_ERROR_OOM);
+        }
+    }
+    return AWS_OP_SUCCESS;
+}
+
+int aws_huffman_amd_engine_encode_host(
+    struct aws_huffman_amd_engine *eng,
+    const struct aws_huffman_amd_encode_item *item_in,
+    const uint8_t *host_in,
+    uint8_t *host_out,
+    bool length_only,
+    struct hufd_enc_result *raw) {
+
+    /* the device output never needs more than the worst-case encoding */
+    struct aws_huffman_amd_encode_item item = *item_in;
+    const uint64_t worst = (item.in_len * eng->tables.max_bits + item.overflow_in.num_bits + 7) / 8;
+    const uint64_t dev_out = item.out_capacity < worst ? item.out_capacity : worst;
+    item.in_offset = 0;
+    item.out_offset = 0;
+    if (one_shot_reserve(eng, item.in_len + 16, length_only ? 0 : dev_out + 16)) {
+        return AWS_OP_ERR;
+    }
+    if (!eng->one_enc) {
+        eng->one_enc = calloc(1, sizeof(*eng->one_enc));
+        if (!eng->one_enc) {
+            return aws_raise_error(AWS_ERROR_OOM);
+        }
+        eng->one_enc->engine = eng;
+    }
+    if (enc_plan_fill(eng->one_enc, &item, 1)) {
+        return AWS_OP_ERR;
+    }
+    int err = hufs_copy_h2d(eng->one_in, host_in, item.in_len, eng->stream);
+    if (err) {
+        return raise_hip(err);
+    }
+    if (aws_huffman_amd_encode_plan_launch(eng->one_enc, eng->one_in, eng->one_out, length_only, eng->stream)) {
+        return AWS_OP_ERR;
+    }
+    if (aws_huffman_amd_encode_plan_raw_results(eng->one_enc, raw, eng->stream)) {
+        return AWS_OP_ERR;
+    }
+    if (!length_only && raw->produced) {
+        err = hufs_copy_d2h(host_out, eng->one_out, raw->produced, eng->stream);
+        if (!err) {
+            err = hufs_stream_sync(eng->stream);
+        }
+        if (err) {
+            return raise_hip(err);
+        }
+    }
+    return AWS_OP_SUCCESS;
+}
+
+int aws_huffman_amd_engine_decode_host(
+    struct aws_huffman_amd_engine *eng,
+    const uint8_t *carry,
+    uint32_t carry_bytes,
+    uint32_t first_bit,
+    const uint8_t *host_in,
+    uint64_t in_len,
+    uint64_t out_capacity,
+    struct aws_huffman_amd_decode_result *result) {
+
+    if (!eng->can_decode) {
+        return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION);
+    }
+    /* the carried bytes sit right before the new bytes, which start 16-byte aligned */
+    const uint64_t stream_bits = (carry_bytes + in_len) * 8 - first_bit;
+    const uint64_t most_symbols = stream_bits / eng->tables.min_bits;
+    const uint64_t dev_out = out_capacity < most_symbols ? out_capacity : most_symbols;
+    if (one_shot_reserve(eng, 16 + in_len + 16, dev_out + 16)) {
+        return AWS_OP_ERR;
+    }
+    struct aws_huffman_amd_decode_item item;
+    memset(&item, 0, sizeof(item));
+    item.in_offset = 16 - carry_bytes;
+    item.in_len = carry_bytes + in_len;
+    item.first_bit = first_bit;
+    item.out_offset = 0;
+    item.out_capacity = dev_out;
+    if (!eng->one_dec) {
+        eng->one_dec = calloc(1, sizeof(*eng->one_dec));
+        if (!eng->one_dec) {
+            return aws_raise_error(AWS_ERROR_OOM);
+        }
+        eng->one_dec->engine = eng;
+    }
+    if (dec_plan_fill(eng->one_dec, &item, 1)) {
+        return AWS_OP_ERR;
+    }
+    int err = 0;
+    if (carry_bytes) {
+        err = hufs_copy_h2d((uint8_t *)eng->one_in + 16 - carry_bytes, carry, carry_bytes, eng->stream);
+    }
+    if (!err) {
+        err = hufs_copy_h2d((uint8_t *)eng->one_in + 16, host_in, in_len, eng->stream);
+    }
+    if (err) {
+        return raise_hip(err);
+    }
+    if (aws_huffman_amd_decode_plan_launch(eng->one_dec, eng->one_in, eng->one_out, eng->stream)) {
+        return AWS_OP_ERR;
+    }
+    if (aws_huffman_amd_decode_plan_results(eng->one_dec, result, eng->stream)) {
+        return AWS_OP_ERR;
+    }
+    /* the device capacity was clipped to what the stream can hold; undo that in the verdict */
+    if (result->error == AWS_ERROR_SHORT_BUFFER && dev_out < out_capacity) {
+        return aws_raise_error(AWS_ERROR_INVALID_STATE);
+    }
+    return AWS_OP_SUCCESS;
+}
+
+int aws_huffman_amd_engine_fetch_output(struct aws_huffman_amd_engine *eng, uint8_t *host_out, uint64_t size) {
+    int err = hufs_copy_d2h(host_out, eng->one_out, size, eng->stream);
+    if (!err) {
+        err = hufs_stream_sync(eng->stream);
+    }
+    return err ? raise_hip(err) : AWS_OP_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ device helpers */
+
+int aws_huffman_amd_device_count(void) {
+    return hufs_device_count();
+}
+
+void *aws_huffman_amd_device_alloc(struct aws_huffman_amd_engine *eng, size_t size) {
+    hufs_set_device(eng->device);
+    void *p = hufs_malloc(size);
+    if (!p) {
+        aws_raise_error(AWS_ERROR_OOM);
+    }
+    return p;
+}
+
+void aws_huffman_amd_device_free(struct aws_huffman_amd_engine *eng, void *ptr) {
+    hufs_set_device(eng->device);
+    hufs_free(ptr);
+}
+
+int aws_huffman_amd_copy_to_device(struct aws_huffman_amd_engine *eng, void *dst, const void *src, size_t size) {
+    hufs_set_device(eng->device);
+    int err = hufs_copy_h2d(dst, src, size, eng->stream);
+    if (!err) {
+        err = hufs_stream_sync(eng->stream);
+    }
+    return err ? raise_hip(err) : AWS_OP_SUCCESS;
+}
+
+int aws_huffman_amd_copy_to_host(struct aws_huffman_amd_engine *eng, void *dst, const void *src, size_t size) {
+    hufs_set_device(eng->device);
+    int err = hufs_copy_d2h(dst, src, size, eng->stream);
+    if (!err) {
+        err = hufs_stream_sync(eng->stream);
+    }
+    return err ? raise_hip(err) : AWS_OP_SUCCESS;
+}
+
+int aws_huffman_amd_device_fill(struct aws_huffman_amd_engine *eng, void *dst, int byte, size_t size) {
+    hufs_set_device(eng->device);
+    int err = hufs_memset(dst, byte, size, eng->stream);
+    if (!err) {
+        err = hufs_stream_sync(eng->stream);
+    }
+    return err ? raise_hip(err) : AWS_OP_SUCCESS;
+}
+
+int aws_huffman_amd_device_fill_splitmix64(struct aws_huffman_amd_engine *eng, void *dst, size_t size, uint64_t seed) {
+    hufs_set_device(eng->device);
+    int err = hufk_fill_splitmix64(dst, size, seed, eng->stream);
+    if (!err) {
+        err = hufs_stream_sync(eng->stream);
+    }
+    return err ? raise_hip(err) : AWS_OP_SUCCESS;
+}
+
+int aws_huffman_amd_stream_synchronize(struct aws_huffman_amd_engine *eng, void *stream) {
+    hufs_set_device(eng->device);
+    const int err = hufs_stream_sync(stream ? stream : eng->stream);
+    return err ? raise_hip(err) : AWS_OP_SUCCESS;
+}
+
+void *aws_huffman_amd_event_new(struct aws_huffman_amd_engine *eng) {
+    hufs_set_device(eng->device);
+    return hufs_event_create();
+}
+
+void aws_huffman_amd_event_destroy(struct aws_huffman_amd_engine *eng, void *event) {
+    hufs_set_device(eng->device);
+    hufs_event_destroy(event);
+}
+
+int aws_huffman_amd_event_record(struct aws_huffman_amd_engine *eng, void *event, void *stream) {
+    hufs_set_device(eng->device);
+    const int err = hufs_event_record(event, stream ? stream : eng->stream);
+    return err ? raise_hip(err) : AWS_OP_SUCCESS;
+}
+
+int aws_huffman_amd_event_elapsed_ms(struct aws_huffman_amd_engine *eng, void *start, void *stop, float *ms) {
+    hufs_set_device(eng->device);
+    const int err = hufs_event_elapsed_ms(start, stop, ms);
+    return err ? raise_hip(err) : AWS_OP_SUCCESS;
+}

@@ -1,0 +1,95 @@
+#ifndef HUFFMAN_AMD_ENGINE_H
+#define HUFFMAN_AMD_ENGINE_H
+/* Internal layout of the opaque types of huffman_amd.h and the helpers huffman.c uses. */
+#include <aws/compression/huffman_amd.h>
+
+#include "../hip/device_types.h"
+#include "../hip/hip_shim.h"
+#include "../hip/huffman_kernels.h"
+
+struct aws_huffman_amd_engine {
+    int device;
+    void *stream;
+
+    /* identity of the tabulated coder: the callbacks are assumed pure (huffman.h) */
+    struct aws_huffman_symbol_coder *coder;
+    void *key_encode;
+    void *key_decode;
+    void *key_userdata;
+
+    uint64_t enc_table[256]; /* host copy: length << 32 | masked code */
+    uint16_t *dec_lut_host;
+    bool can_decode;
+
+    void *d_enc_table;
+    void *d_dec_lut;
+    struct hufd_tables tables;
+
+    /* scratch of the host-pointer API: one item at a time */
+    void *one_in;
+    size_t one_in_cap;
+    void *one_out;
+    size_t one_out_cap;
+    struct aws_huffman_amd_encode_plan *one_enc;
+    struct aws_huffman_amd_decode_plan *one_dec;
+};
+
+struct aws_huffman_amd_encode_plan {
+    struct aws_huffman_amd_engine *engine;
+    uint32_t n_items, n_segs, n_large;
+    size_t cap_items, cap_segs, cap_large;
+    struct hufd_enc_item *d_items;
+    uint32_t *d_seg_item;
+    uint32_t *d_large;
+    uint32_t *d_seg_bits;
+    uint32_t *d_seg_unk;
+    uint64_t *d_seg_bitoff;
+    struct hufd_enc_item_state *d_states;
+    struct hufd_enc_result *d_results;
+};
+
+struct aws_huffman_amd_decode_plan {
+    struct aws_huffman_amd_engine *engine;
+    uint32_t n_items, n_chunks, n_large;
+    size_t cap_items, cap_chunks, cap_large;
+    struct aws_huffman_amd_decode_item *h_items; /* host copy for result translation */
+    struct hufd_dec_item *d_items;
+    uint32_t *d_chunk_item;
+    uint32_t *d_large;
+    uint16_t *d_fn_tab;
+    uint32_t *d_chunk_fn;
+    uint32_t *d_chunk_entry;
+    uint64_t *d_chunk_base;
+    struct hufd_dec_item_state *d_states;
+    struct hufd_dec_result *d_results;
+};
+
+int aws_huffman_amd_encode_plan_raw_results(struct aws_huffman_amd_encode_plan *plan, struct hufd_enc_result *raw, void *stream);
+void aws_huffman_amd_encode_result_from_raw(const struct hufd_enc_result *raw, struct aws_huffman_amd_encode_result *out);
+void aws_huffman_amd_decode_result_from_raw(
+    const struct hufd_dec_result *raw,
+    const struct aws_huffman_amd_decode_item *item,
+    struct aws_huffman_amd_decode_result *out);
+
+/* one item through the engine's own staging buffers; host_out receives raw->produced bytes */
+int aws_huffman_amd_engine_encode_host(
+    struct aws_huffman_amd_engine *engine,
+    const struct aws_huffman_amd_encode_item *item,
+    const uint8_t *host_in,
+    uint8_t *host_out,
+    bool length_only,
+    struct hufd_enc_result *raw);
+
+/* decodes carry bytes + new bytes; the symbols stay in the engine's output buffer until fetched */
+int aws_huffman_amd_engine_decode_host(
+    struct aws_huffman_amd_engine *engine,
+    const uint8_t *carry,
+    uint32_t carry_bytes,
+    uint32_t first_bit,
+    const uint8_t *host_in,
+    uint64_t in_len,
+    uint64_t out_capacity,
+    struct aws_huffman_amd_decode_result *result);
+int aws_huffman_amd_engine_fetch_output(struct aws_huffman_amd_engine *engine, uint8_t *host_out, uint64_t size);
+
+#endif /* HUFFMAN_AMD_ENGINE_H */

@@ -1,0 +1,304 @@
+/*
+ * The eight entry points of the reference's include/aws/compression/huffman.h,
+ * host-pointer flavour, on top of the HIP engine.
+ *
+ * Replaces reference source/huffman.c.  Same names, same argument meaning, same
+ * return codes and raised errors, same post-call contents of the caller-owned
+ * encoder/decoder structs, cursors and buffers.  What differs is where the work
+ * happens: the caller's bytes are staged into device memory, one encode or decode
+ * item runs through the kernels, and the outcome record is translated back into
+ * the reference's streaming state.  No symbol is ever coded on the host.
+ */
+#include "engine.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ engine cache */
+
+/*
+ * The structs of the reference have no room for a handle, so the staged tables
+ * are found again through the coder: one engine per (coder pointer, callbacks,
+ * userdata, current device), created on first use.
+ */
+enum { ENGINE_SLOTS = 16 };
+static struct aws_huffman_amd_engine *s_engines[ENGINE_SLOTS];
+static unsigned s_engine_clock[ENGINE_SLOTS];
+static unsigned s_clock;
+static pthread_mutex_t s_engine_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static struct aws_huffman_amd_engine *engine_for(struct aws_huffman_symbol_coder *coder) {
+    int device = 0;
+    if (hufs_device_count() <= 0 || hufs_get_device(&device)) {
+        aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION); /* no GPU: fail loudly, there is no CPU path */
+        return NULL;
+    }
+    pthread_mutex_lock(&s_engine_lock);
+    struct aws_huffman_amd_engine *found = NULL;
+    int slot = -1;
+    for (int i = 0; i < ENGINE_SLOTS && !found; ++i) {
+        struct aws_huffman_amd_engine *e = s_engines[i];
+        if (e && e->coder == coder && e->key_encode == (void *)coder->encode &&
+            e->key_decode == (void *)coder->decode && e->key_userdata == coder->userdata && e->device == device) {
+            found = e;
+            s_engine_clock[i] = ++s_clock;
+        }
+    }
+    if (!found) {
+        /* a free slot, else the least recently used one */
+        for (int i = 0; i < ENGINE_SLOTS; ++i) {
+            if (!s_engines[i]) {
+                slot = i;
+                break;
+            }
+            if (slot < 0 || s_engine_clock[i] < s_engine_clock[slot]) {
+                slot = i;
+            }
+        }
+        struct aws_huffman_amd_engine *fresh = NULL;
+        if (aws_huffman_amd_engine_new(&fresh, coder, device) == AWS_OP_SUCCESS) {
+            aws_huffman_amd_engine_destroy(s_engines[slot]);
+            s_engines[slot] = fresh;
+            s_engine_clock[slot] = ++s_clock;
+            found = fresh;
+        }
+    }
+    pthread_mutex_unlock(&s_engine_lock);
+    return found;
+}
+
+/* ------------------------------------------------------------------ init / reset */
+
+void aws_huffman_encoder_init(struct aws_huffman_encoder *encoder, struct aws_huffman_symbol_coder *coder) {
+    AWS_ASSERT(encoder);
+    AWS_ASSERT(coder);
+    memset(encoder, 0, sizeof(*encoder));
+    encoder->coder = coder;
+    encoder->eos_padding = UINT8_MAX;
+}
+
+void aws_huffman_encoder_reset(struct aws_huffman_encoder *encoder) {
+    AWS_ASSERT(encoder);
+    memset(&encoder->overflow_bits, 0, sizeof(encoder->overflow_bits));
+}
+
+void aws_huffman_decoder_init(struct aws_huffman_decoder *decoder, struct aws_huffman_symbol_coder *coder) {
+    AWS_ASSERT(decoder);
+    AWS_ASSERT(coder);
+    memset(decoder, 0, sizeof(*decoder));
+    decoder->coder = coder;
+}
+
+void aws_huffman_decoder_reset(struct aws_huffman_decoder *decoder) {
+    decoder->working_bits = 0;
+    decoder->num_bits = 0;
+}
+
+void aws_huffman_decoder_allow_growth(struct aws_huffman_decoder *decoder, bool allow_growth) {
+    decoder->allow_growth = allow_growth;
+}
+
+/* ------------------------------------------------------------------ encoded length */
+
+size_t aws_huffman_get_encoded_length(struct aws_huffman_encoder *encoder, struct aws_byte_cursor to_encode) {
+    AWS_PRECONDITION(encoder);
+    AWS_PRECONDITION(aws_byte_cursor_is_valid(&to_encode));
+    if (to_encode.len == 0) {
+        return 0;
+    }
+    struct aws_huffman_amd_engine *eng = engine_for(encoder->coder);
+    if (!eng) {
+        return 0;
+    }
+    struct aws_huffman_amd_encode_item item;
+    memset(&item, 0, sizeof(item));
+    item.in_len = to_encode.len;
+    item.out_capacity = UINT64_MAX; /* pending overflow bits are not part of the answer (huffman.c:107-129) */
+    struct hufd_enc_result raw;
+    if (aws_huffman_amd_engine_encode_host(eng, &item, to_encode.ptr, NULL, true, &raw)) {
+        return 0;
+    }
+    return (size_t)((raw.total_bits + 7) / 8);
+}
+
+/* ------------------------------------------------------------------ encode */
+
+int aws_huffman_encode(
+    struct aws_huffman_encoder *encoder,
+    struct aws_byte_cursor *to_encode,
+    struct aws_byte_buf *output) {
+
+    AWS_ASSERT(encoder);
+    AWS_ASSERT(encoder->coder);
+    AWS_ASSERT(to_encode);
+    AWS_ASSERT(output);
+
+    const size_t room = output->capacity - output->len;
+    const uint8_t carried = encoder->overflow_bits.num_bits;
+
+    /* the three outcomes that touch neither symbols nor output (huffman.c:149-152,161-164) */
+    if (carried && room == 0) {
+        return aws_raise_error(AWS_ERROR_SHORT_BUFFER);
+    }
+    if (!carried && to_encode->len == 0) {
+        return AWS_OP_SUCCESS;
+    }
+    if (!carried && room == 0) {
+        return aws_raise_error(AWS_ERROR_SHORT_BUFFER);
+    }
+
+    struct aws_huffman_amd_engine *eng = engine_for(encoder->coder);
+    if (!eng) {
+        return AWS_OP_ERR;
+    }
+
+    struct aws_huffman_amd_encode_item item;
+    memset(&item, 0, sizeof(item));
+    item.in_len = to_encode->len;
+    item.out_capacity = room;
+    item.overflow_in = encoder->overflow_bits;
+    item.eos_padding = encoder->eos_padding;
+
+    struct hufd_enc_result raw;
+    if (aws_huffman_amd_engine_encode_host(eng, &item, to_encode->ptr, output->buffer + output->len, false, &raw)) {
+        return AWS_OP_ERR;
+    }
+    struct aws_huffman_amd_encode_result res;
+    aws_huffman_amd_encode_result_from_raw(&raw, &res);
+
+    to_encode->ptr += res.consumed;
+    to_encode->len -= res.consumed;
+    output->len += res.produced;
+    /* only num_bits is ever reset by the reference; the pattern matters while num_bits > 0 */
+    encoder->overflow_bits.num_bits = res.overflow_out.num_bits;
+    if (res.overflow_out.num_bits) {
+        encoder->overflow_bits.pattern = res.overflow_out.pattern;
+    }
+    return res.rc == AWS_OP_SUCCESS ? AWS_OP_SUCCESS : aws_raise_error(res.error);
+}
+
+/* ------------------------------------------------------------------ decode */
+
+int aws_huffman_decode(
+    struct aws_huffman_decoder *decoder,
+    struct aws_byte_cursor *to_decode,
+    struct aws_byte_buf *output) {
+
+    AWS_ASSERT(decoder);
+    AWS_ASSERT(decoder->coder);
+    AWS_ASSERT(to_decode);
+    AWS_ASSERT(output);
+
+    const uint32_t held = decoder->num_bits;                 /* read-ahead bits from earlier calls */
+    const uint64_t stream_bits = held + (uint64_t)to_decode->len * 8; /* huffman.c:228 */
+
+    struct aws_huffman_amd_engine *eng = engine_for(decoder->coder);
+    if (!eng) {
+        return AWS_OP_ERR;
+    }
+    if (!eng->can_decode) {
+        return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION);
+    }
+
+    /* the held bits become up to five whole bytes in front of the new input; their first
+     * (8 * bytes - held) bits are stale and skipped via first_bit */
+    uint8_t carry[8];
+    const uint32_t carry_bytes = (held + 7) / 8;
+    const uint32_t first_bit = carry_bytes * 8 - held;
+    {
+        /* working_bits holds the held bits at its top; shift them so they END on a byte edge */
+        const uint64_t packed = held ? decoder->working_bits >> (64 - held) : 0; /* right-aligned */
+        for (uint32_t i = 0; i < carry_bytes; ++i) {
+            carry[i] = (uint8_t)(packed >> (8 * (carry_bytes - 1 - i)));
+        }
+    }
+
+    /* with growth the output is as large as it needs to be; the quirk of capacity 0 (nothing can
+     * ever be stored, huffman.c:262,275 and SURVEY.md A.3) also counts every symbol */
+    const size_t room = output->capacity - output->len;
+    const bool grow = decoder->allow_growth;
+    const uint64_t device_cap = grow ? UINT64_MAX : room;
+
+    struct aws_huffman_amd_decode_result res;
+    if (stream_bits == 0) {
+        /* nothing to look at: the reference returns success whatever the coder says (huffman.c:240-255) */
+        return AWS_OP_SUCCESS;
+    }
+    if (aws_huffman_amd_engine_decode_host(
+            eng, carry, carry_bytes, first_bit, to_decode->ptr, to_decode->len, device_cap, &res)) {
+        return AWS_OP_ERR;
+    }
+
+    /* storage for the symbols */
+    uint64_t to_store = res.produced;
+    if (grow && to_store > room) {
+        /* double until it fits, exactly as the per-symbol loop would have (huffman.c:260-264) */
+        while (output->capacity - output->len < to_store) {
+            if (output->capacity == 0) {
+                to_store = 0; /* reserve_relative(0) adds nothing and the writes are dropped */
+                break;
+            }
+            /* the reference doubles when len == capacity; replay the same sequence of sizes */
+            const size_t before = output->capacity;
+            const size_t keep_len = output->len;
+            output->len = before; /* doubling is relative to a full buffer */
+            const int rc = aws_byte_buf_reserve_relative(output, before);
+            output->len = keep_len;
+            if (rc) {
+                return AWS_OP_ERR;
+            }
+        }
+    }
+    if (to_store) {
+        if (aws_huffman_amd_engine_fetch_output(eng, output->buffer + output->len, to_store)) {
+            return AWS_OP_ERR;
+        }
+        output->len += to_store;
+    }
+
+    /*
+     * Streaming state after the call: with C stream bits consumed by
+     * the emitted symbols, the refill loop (huffman.c:196-211) has pulled the fewest bytes that
+     * leave at least 32 bits in the window, or everything.
+     */
+    const uint64_t consumed_bits = res.bits_consumed;
+    uint64_t pulled = 0;
+    if (consumed_bits + 32 > held) {
+        pulled = (consumed_bits + 32 - held + 7) / 8;
+    }
+    if (pulled > to_decode->len) {
+        pulled = to_decode->len;
+    }
+    const uint64_t left = held + pulled * 8 - consumed_bits; /* 0..39 */
+    uint64_t window = 0;
+    uint32_t filled = 0;
+    if (consumed_bits < held) {
+        window = decoder->working_bits << consumed_bits;
+        filled = held - (uint32_t)consumed_bits;
+        for (uint64_t i = 0; i < pulled; ++i) {
+            window |= (uint64_t)to_decode->ptr[i] << (56 - filled);
+            filled += 8;
+        }
+    } else {
+        const uint64_t into_new = consumed_bits - held; /* bits of the new bytes already used */
+        uint64_t i = into_new / 8;
+        const uint32_t used = (uint32_t)(into_new % 8);
+        if (i < pulled) {
+            window = (uint64_t)(uint8_t)(to_decode->ptr[i] << used) << 56;
+            filled = 8 - used;
+            for (++i; i < pulled; ++i) {
+                window |= (uint64_t)to_decode->ptr[i] << (56 - filled);
+                filled += 8;
+            }
+        }
+    }
+    AWS_ASSERT(filled == left);
+    (void)left;
+    decoder->working_bits = window;
+    decoder->num_bits = (uint8_t)filled;
+    to_decode->ptr += pulled;
+    to_decode->len -= pulled;
+
+    return res.rc == AWS_OP_SUCCESS ? AWS_OP_SUCCESS : aws_raise_error(res.error);
+}

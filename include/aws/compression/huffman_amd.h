@@ -1,0 +1,204 @@
+#ifndef AWS_COMPRESSION_HUFFMAN_AMD_H
+#define AWS_COMPRESSION_HUFFMAN_AMD_H
+/*
+ * MI355X extensions of the Huffman C ABI: device-pointer and batched entry
+ * points.  The reference has no counterpart (its API is host pointers, one
+ * stream per call); the meaning of every item processed here is defined as
+ * "what the reference function would do for that item":
+ *
+ *   encode item  ==  aws_huffman_encode   (reference source/huffman.c:131-187)
+ *                    on an encoder with the item's overflow_in / eos_padding,
+ *                    a cursor over the item's input range and a byte_buf with
+ *                    len 0 and capacity out_capacity over the item's output range;
+ *   decode item  ==  aws_huffman_decode   (reference source/huffman.c:213-286)
+ *                    on a freshly reset decoder whose stream starts `first_bit`
+ *                    bits into the item's first input byte.
+ *
+ * The host-pointer functions in huffman.h are thin wrappers over these: they
+ * stage the caller's bytes into device memory, run one item, and copy back.
+ *
+ * Plain C, plain pointers and sizes only (no HIP or torch types): `stream`
+ * arguments are a hipStream_t passed as void *, device pointers are void *.
+ * All functions return AWS_OP_SUCCESS / AWS_OP_ERR and raise through
+ * aws_raise_error like the rest of the CRT.
+ */
+
+#include <aws/compression/huffman.h>
+
+AWS_EXTERN_C_BEGIN
+
+/* One device + the tables of one symbol coder staged in its memory + a stream. */
+struct aws_huffman_amd_engine;
+
+/* A batch of encode (or decode) items laid out against one input and one output
+ * base pointer, with its segment map and scratch memory resident on the device. */
+struct aws_huffman_amd_encode_plan;
+struct aws_huffman_amd_decode_plan;
+
+struct aws_huffman_amd_encode_item {
+    uint64_t in_offset;    /* bytes from the input base pointer */
+    uint64_t in_len;       /* symbols to encode */
+    uint64_t out_offset;   /* bytes from the output base pointer */
+    uint64_t out_capacity; /* bytes the item may write */
+    struct aws_huffman_code overflow_in; /* encoder->overflow_bits on entry (num_bits 0 = none) */
+    uint8_t eos_padding;   /* encoder->eos_padding */
+};
+
+struct aws_huffman_amd_encode_result {
+    int32_t rc;        /* AWS_OP_SUCCESS or AWS_OP_ERR */
+    int32_t error;     /* 0, AWS_ERROR_SHORT_BUFFER or AWS_ERROR_COMPRESSION_UNKNOWN_SYMBOL */
+    uint64_t consumed; /* symbols the cursor would have advanced by */
+    uint64_t produced; /* bytes appended to the output */
+    struct aws_huffman_code overflow_out; /* encoder->overflow_bits on return */
+};
+
+struct aws_huffman_amd_decode_item {
+    uint64_t in_offset;
+    uint64_t in_len;       /* encoded bytes */
+    uint32_t first_bit;    /* 0..7: bits of the first byte that are already consumed */
+    uint64_t out_offset;
+    uint64_t out_capacity; /* symbols the item may write */
+};
+
+struct aws_huffman_amd_decode_result {
+    int32_t rc;
+    int32_t error;          /* 0, AWS_ERROR_SHORT_BUFFER or AWS_ERROR_COMPRESSION_UNKNOWN_SYMBOL */
+    uint64_t produced;      /* symbols written */
+    uint64_t bits_consumed; /* stream bits used by those symbols, counted from first_bit */
+};
+
+/*
+ * Tabulates `coder` (256 encode calls, 2^max_len decode calls, cross-checked for
+ * purity) and stages the tables on HIP device `device` (-1 = current device).
+ * Raises AWS_ERROR_UNSUPPORTED_OPERATION when the coder cannot be tabulated
+ * (a decode callback that disagrees with its encode callback, or codes longer
+ * than the device decode table covers: 12 bits in this release; encode-only
+ * engines accept 32).  There is no CPU path to fall back to.
+ */
+AWS_COMPRESSION_API
+int aws_huffman_amd_engine_new(
+    struct aws_huffman_amd_engine **engine,
+    struct aws_huffman_symbol_coder *coder,
+    int device);
+
+AWS_COMPRESSION_API
+void aws_huffman_amd_engine_destroy(struct aws_huffman_amd_engine *engine);
+
+/* Longest code of the staged coder, and whether the engine can decode. */
+AWS_COMPRESSION_API
+uint32_t aws_huffman_amd_engine_max_code_bits(const struct aws_huffman_amd_engine *engine);
+AWS_COMPRESSION_API
+bool aws_huffman_amd_engine_can_decode(const struct aws_huffman_amd_engine *engine);
+
+/* ---- batched encode ------------------------------------------------------ */
+
+/* Uploads the items, builds the segment map, sizes the scratch memory. */
+AWS_COMPRESSION_API
+int aws_huffman_amd_encode_plan_new(
+    struct aws_huffman_amd_encode_plan **plan,
+    struct aws_huffman_amd_engine *engine,
+    const struct aws_huffman_amd_encode_item *items,
+    size_t item_count);
+
+AWS_COMPRESSION_API
+void aws_huffman_amd_encode_plan_destroy(struct aws_huffman_amd_encode_plan *plan);
+
+/*
+ * Enqueues the encode kernels on `stream` (NULL = the engine's stream) and
+ * returns without waiting.  `length_only` stops after the length scan: nothing
+ * is written and each result's `produced` is aws_huffman_get_encoded_length
+ * (+ pending overflow bits) for the item.
+ */
+AWS_COMPRESSION_API
+int aws_huffman_amd_encode_plan_launch(
+    struct aws_huffman_amd_encode_plan *plan,
+    const void *device_input,
+    void *device_output,
+    bool length_only,
+    void *stream);
+
+/* Waits for the last launch and copies the per-item results to the host. */
+AWS_COMPRESSION_API
+int aws_huffman_amd_encode_plan_results(
+    struct aws_huffman_amd_encode_plan *plan,
+    struct aws_huffman_amd_encode_result *results,
+    void *stream);
+
+/* ---- batched decode ------------------------------------------------------ */
+
+AWS_COMPRESSION_API
+int aws_huffman_amd_decode_plan_new(
+    struct aws_huffman_amd_decode_plan **plan,
+    struct aws_huffman_amd_engine *engine,
+    const struct aws_huffman_amd_decode_item *items,
+    size_t item_count);
+
+AWS_COMPRESSION_API
+void aws_huffman_amd_decode_plan_destroy(struct aws_huffman_amd_decode_plan *plan);
+
+AWS_COMPRESSION_API
+int aws_huffman_amd_decode_plan_launch(
+    struct aws_huffman_amd_decode_plan *plan,
+    const void *device_input,
+    void *device_output,
+    void *stream);
+
+AWS_COMPRESSION_API
+int aws_huffman_amd_decode_plan_results(
+    struct aws_huffman_amd_decode_plan *plan,
+    struct aws_huffman_amd_decode_result *results,
+    void *stream);
+
+/* ---- device memory and timing helpers (so a C caller needs no HIP headers) ---- */
+
+AWS_COMPRESSION_API
+int aws_huffman_amd_device_count(void);
+AWS_COMPRESSION_API
+void *aws_huffman_amd_device_alloc(struct aws_huffman_amd_engine *engine, size_t size);
+AWS_COMPRESSION_API
+void aws_huffman_amd_device_free(struct aws_huffman_amd_engine *engine, void *ptr);
+AWS_COMPRESSION_API
+int aws_huffman_amd_copy_to_device(struct aws_huffman_amd_engine *engine, void *dst, const void *src, size_t size);
+AWS_COMPRESSION_API
+int aws_huffman_amd_copy_to_host(struct aws_huffman_amd_engine *engine, void *dst, const void *src, size_t size);
+AWS_COMPRESSION_API
+int aws_huffman_amd_device_fill(struct aws_huffman_amd_engine *engine, void *dst, int byte, size_t size);
+/* splitmix64 byte stream of BASELINE.md section 4, generated in place on the device */
+AWS_COMPRESSION_API
+int aws_huffman_amd_device_fill_splitmix64(struct aws_huffman_amd_engine *engine, void *dst, size_t size, uint64_t seed);
+/* the engine's own hipStream_t */
+AWS_COMPRESSION_API
+void *aws_huffman_amd_engine_stream(struct aws_huffman_amd_engine *engine);
+AWS_COMPRESSION_API
+int aws_huffman_amd_stream_synchronize(struct aws_huffman_amd_engine *engine, void *stream);
+
+/* HIP events on a stream: create / record / elapsed milliseconds between two recorded events */
+AWS_COMPRESSION_API
+void *aws_huffman_amd_event_new(struct aws_huffman_amd_engine *engine);
+AWS_COMPRESSION_API
+void aws_huffman_amd_event_destroy(struct aws_huffman_amd_engine *engine, void *event);
+AWS_COMPRESSION_API
+int aws_huffman_amd_event_record(struct aws_huffman_amd_engine *engine, void *event, void *stream);
+AWS_COMPRESSION_API
+int aws_huffman_amd_event_elapsed_ms(struct aws_huffman_amd_engine *engine, void *start, void *stop, float *ms);
+
+/* ---- a coder from a table (runtime counterpart of the reference's offline generator) ---- */
+
+/*
+ * Builds an aws_huffman_symbol_coder from 256 (pattern, num_bits) rows: encode is
+ * the table, decode walks the code tree one bit per level the way the C file
+ * emitted by reference source/huffman_generator/generator.c:154-214 does.
+ * Rows with num_bits 0 have no code.  NULL (+ AWS_ERROR_INVALID_ARGUMENT) when
+ * the rows are not a prefix code.
+ */
+AWS_COMPRESSION_API
+struct aws_huffman_symbol_coder *aws_huffman_amd_table_coder_new(
+    const uint32_t patterns[256],
+    const uint8_t num_bits[256]);
+
+AWS_COMPRESSION_API
+void aws_huffman_amd_table_coder_destroy(struct aws_huffman_symbol_coder *coder);
+
+AWS_EXTERN_C_END
+
+#endif /* AWS_COMPRESSION_HUFFMAN_AMD_H */

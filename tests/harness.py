@@ -139,17 +139,171 @@ def load_oracle():
     return lib
 
 
-def load_product():
+# ---- extension API of include/aws/compression/huffman_amd.h
+class AmdEncodeItem(C.Structure):
+    _fields_ = [("in_offset", C.c_uint64), ("in_len", C.c_uint64), ("out_offset", C.c_uint64),
+                ("out_capacity", C.c_uint64), ("overflow_in", HuffmanCode), ("eos_padding", C.c_uint8)]
+
+
+class AmdEncodeResult(C.Structure):
+    _fields_ = [("rc", C.c_int32), ("error", C.c_int32), ("consumed", C.c_uint64), ("produced", C.c_uint64),
+                ("overflow_out", HuffmanCode)]
+
+
+class AmdDecodeItem(C.Structure):
+    _fields_ = [("in_offset", C.c_uint64), ("in_len", C.c_uint64), ("first_bit", C.c_uint32),
+                ("out_offset", C.c_uint64), ("out_capacity", C.c_uint64)]
+
+
+class AmdDecodeResult(C.Structure):
+    _fields_ = [("rc", C.c_int32), ("error", C.c_int32), ("produced", C.c_uint64), ("bits_consumed", C.c_uint64)]
+
+
+EXPORTED_SYMBOLS = [
+    # include/aws/compression/huffman.h
+    "aws_huffman_encoder_init", "aws_huffman_encoder_reset", "aws_huffman_decoder_init", "aws_huffman_decoder_reset",
+    "aws_huffman_decoder_allow_growth", "aws_huffman_get_encoded_length", "aws_huffman_encode", "aws_huffman_decode",
+    # include/aws/compression/compression.h
+    "aws_compression_library_init", "aws_compression_library_clean_up",
+    # include/aws/compression/huffman_amd.h
+    "aws_huffman_amd_engine_new", "aws_huffman_amd_engine_destroy", "aws_huffman_amd_engine_max_code_bits",
+    "aws_huffman_amd_engine_can_decode", "aws_huffman_amd_encode_plan_new", "aws_huffman_amd_encode_plan_destroy",
+    "aws_huffman_amd_encode_plan_launch", "aws_huffman_amd_encode_plan_results", "aws_huffman_amd_decode_plan_new",
+    "aws_huffman_amd_decode_plan_destroy", "aws_huffman_amd_decode_plan_launch", "aws_huffman_amd_decode_plan_results",
+    "aws_huffman_amd_device_count", "aws_huffman_amd_device_alloc", "aws_huffman_amd_device_free",
+    "aws_huffman_amd_copy_to_device", "aws_huffman_amd_copy_to_host", "aws_huffman_amd_device_fill",
+    "aws_huffman_amd_device_fill_splitmix64", "aws_huffman_amd_engine_stream", "aws_huffman_amd_stream_synchronize",
+    "aws_huffman_amd_event_new", "aws_huffman_amd_event_destroy", "aws_huffman_amd_event_record",
+    "aws_huffman_amd_event_elapsed_ms", "aws_huffman_amd_table_coder_new", "aws_huffman_amd_table_coder_destroy",
+]
+
+
+def load_product(path=None):
     """The HIP library.  Fails loudly when it is missing: there is no CPU fallback."""
-    if not os.path.exists(PRODUCT_SO):
-        raise RuntimeError("HIP library not built: %s (run __graft_entry__.build())" % PRODUCT_SO)
-    lib = C.CDLL(PRODUCT_SO, mode=C.RTLD_GLOBAL)
+    path = path or PRODUCT_SO
+    if not os.path.exists(path):
+        raise RuntimeError("HIP library not built: %s (run __graft_entry__.build())" % path)
+    lib = C.CDLL(path)
     for short, (res, args) in _PROTOS.items():
         _bind(lib, "aws_" + short, res, args)
     _bind(lib, "aws_last_error", C.c_int, [])
     _bind(lib, "aws_reset_error", None, [])
     _bind(lib, "aws_default_allocator", C.c_void_p, [])
+    V, P = C.c_void_p, C.POINTER
+    _bind(lib, "aws_huffman_amd_table_coder_new", P(SymbolCoder), [P(C.c_uint32), P(C.c_uint8)])
+    _bind(lib, "aws_huffman_amd_table_coder_destroy", None, [P(SymbolCoder)])
+    _bind(lib, "aws_huffman_amd_engine_new", C.c_int, [P(V), P(SymbolCoder), C.c_int])
+    _bind(lib, "aws_huffman_amd_engine_destroy", None, [V])
+    _bind(lib, "aws_huffman_amd_engine_max_code_bits", C.c_uint32, [V])
+    _bind(lib, "aws_huffman_amd_engine_can_decode", C.c_bool, [V])
+    _bind(lib, "aws_huffman_amd_engine_stream", V, [V])
+    _bind(lib, "aws_huffman_amd_encode_plan_new", C.c_int, [P(V), V, P(AmdEncodeItem), C.c_size_t])
+    _bind(lib, "aws_huffman_amd_encode_plan_destroy", None, [V])
+    _bind(lib, "aws_huffman_amd_encode_plan_launch", C.c_int, [V, V, V, C.c_bool, V])
+    _bind(lib, "aws_huffman_amd_encode_plan_results", C.c_int, [V, P(AmdEncodeResult), V])
+    _bind(lib, "aws_huffman_amd_decode_plan_new", C.c_int, [P(V), V, P(AmdDecodeItem), C.c_size_t])
+    _bind(lib, "aws_huffman_amd_decode_plan_destroy", None, [V])
+    _bind(lib, "aws_huffman_amd_decode_plan_launch", C.c_int, [V, V, V, V])
+    _bind(lib, "aws_huffman_amd_decode_plan_results", C.c_int, [V, P(AmdDecodeResult), V])
+    _bind(lib, "aws_huffman_amd_device_count", C.c_int, [])
+    _bind(lib, "aws_huffman_amd_device_alloc", V, [V, C.c_size_t])
+    _bind(lib, "aws_huffman_amd_device_free", None, [V, V])
+    _bind(lib, "aws_huffman_amd_copy_to_device", C.c_int, [V, V, V, C.c_size_t])
+    _bind(lib, "aws_huffman_amd_copy_to_host", C.c_int, [V, V, V, C.c_size_t])
+    _bind(lib, "aws_huffman_amd_device_fill", C.c_int, [V, V, C.c_int, C.c_size_t])
+    _bind(lib, "aws_huffman_amd_device_fill_splitmix64", C.c_int, [V, V, C.c_size_t, C.c_uint64])
+    _bind(lib, "aws_huffman_amd_stream_synchronize", C.c_int, [V, V])
+    _bind(lib, "aws_huffman_amd_event_new", V, [V])
+    _bind(lib, "aws_huffman_amd_event_destroy", None, [V, V])
+    _bind(lib, "aws_huffman_amd_event_record", C.c_int, [V, V, V])
+    _bind(lib, "aws_huffman_amd_event_elapsed_ms", C.c_int, [V, V, V, P(C.c_float)])
     return lib
+
+
+class Engine:
+    """Device-pointer / batched face of the product library (huffman_amd.h)."""
+
+    def __init__(self, lib, coder, device=-1):
+        self.lib = lib
+        h = C.c_void_p()
+        if lib.aws_huffman_amd_engine_new(C.byref(h), coder, device) != 0:
+            raise RuntimeError("aws_huffman_amd_engine_new failed, error %d" % lib.aws_last_error())
+        self.h = h
+        self.stream = lib.aws_huffman_amd_engine_stream(h)
+
+    def close(self):
+        if self.h:
+            self.lib.aws_huffman_amd_engine_destroy(self.h)
+            self.h = None
+
+    def alloc(self, n):
+        p = self.lib.aws_huffman_amd_device_alloc(self.h, max(int(n), 1))
+        if not p:
+            raise MemoryError("device alloc of %d bytes failed" % n)
+        return p
+
+    def free(self, p):
+        self.lib.aws_huffman_amd_device_free(self.h, p)
+
+    def upload(self, dptr, arr, offset=0):
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        assert self.lib.aws_huffman_amd_copy_to_device(self.h, dptr + offset, arr.ctypes.data, arr.size) == 0
+
+    def download(self, dptr, n, offset=0):
+        out = np.empty(int(n), dtype=np.uint8)
+        assert self.lib.aws_huffman_amd_copy_to_host(self.h, out.ctypes.data, dptr + offset, out.size) == 0
+        return out
+
+    def fill(self, dptr, byte, n):
+        assert self.lib.aws_huffman_amd_device_fill(self.h, dptr, byte, int(n)) == 0
+
+    def fill_splitmix64(self, dptr, n, seed):
+        assert self.lib.aws_huffman_amd_device_fill_splitmix64(self.h, dptr, int(n), seed) == 0
+
+    def sync(self):
+        assert self.lib.aws_huffman_amd_stream_synchronize(self.h, None) == 0
+
+    # items: list of dicts / tuples
+    def encode_plan(self, items):
+        arr = (AmdEncodeItem * max(len(items), 1))()
+        for i, it in enumerate(items):
+            arr[i].in_offset, arr[i].in_len = it["in_offset"], it["in_len"]
+            arr[i].out_offset, arr[i].out_capacity = it["out_offset"], it["out_capacity"]
+            ov = it.get("overflow_in", (0, 0))
+            arr[i].overflow_in.pattern, arr[i].overflow_in.num_bits = ov
+            arr[i].eos_padding = it.get("eos_padding", 0xFF)
+        plan = C.c_void_p()
+        if self.lib.aws_huffman_amd_encode_plan_new(C.byref(plan), self.h, arr, len(items)) != 0:
+            raise RuntimeError("encode_plan_new failed, error %d" % self.lib.aws_last_error())
+        return plan
+
+    def encode_launch(self, plan, d_in, d_out, length_only=False):
+        assert self.lib.aws_huffman_amd_encode_plan_launch(plan, d_in, d_out, length_only, None) == 0
+
+    def encode_results(self, plan, n):
+        res = (AmdEncodeResult * max(n, 1))()
+        assert self.lib.aws_huffman_amd_encode_plan_results(plan, res, None) == 0
+        return [(r.rc, r.error, r.consumed, r.produced, r.overflow_out.num_bits,
+                 r.overflow_out.pattern if r.overflow_out.num_bits else 0) for r in res[:n]]
+
+    def decode_plan(self, items):
+        arr = (AmdDecodeItem * max(len(items), 1))()
+        for i, it in enumerate(items):
+            arr[i].in_offset, arr[i].in_len = it["in_offset"], it["in_len"]
+            arr[i].first_bit = it.get("first_bit", 0)
+            arr[i].out_offset, arr[i].out_capacity = it["out_offset"], it["out_capacity"]
+        plan = C.c_void_p()
+        if self.lib.aws_huffman_amd_decode_plan_new(C.byref(plan), self.h, arr, len(items)) != 0:
+            raise RuntimeError("decode_plan_new failed, error %d" % self.lib.aws_last_error())
+        return plan
+
+    def decode_launch(self, plan, d_in, d_out):
+        assert self.lib.aws_huffman_amd_decode_plan_launch(plan, d_in, d_out, None) == 0
+
+    def decode_results(self, plan, n):
+        res = (AmdDecodeResult * max(n, 1))()
+        assert self.lib.aws_huffman_amd_decode_plan_results(plan, res, None) == 0
+        return [(r.rc, r.error, r.produced, r.bits_consumed) for r in res[:n]]
 
 
 class CallResult:

@@ -1,0 +1,482 @@
+"""Parity scenarios: the product library against the CPU oracle, call by call.
+
+Every scenario runs the same calls on both libraries and compares everything a
+caller can observe: return code, raised error, how far the cursor moved, how
+many bytes were appended, the streaming state left in the encoder/decoder
+struct, the bytes written AND the bytes that must stay untouched.
+
+The scenarios are library-agnostic: tests/test_emulated_kernels.py runs them on
+the CPU-emulated build of the kernels (logic + UBSan, no GPU), and
+tests/test_gpu_parity.py runs them through the hipcc build on an MI355X.
+"""
+import ctypes as C
+import hashlib
+
+import numpy as np
+
+import harness
+from harness import AWS_ERROR_COMPRESSION_UNKNOWN_SYMBOL as UNKNOWN_SYMBOL
+from harness import AWS_ERROR_SHORT_BUFFER as SHORT_BUFFER
+
+SENTINEL = 0x5A
+VEC = harness.load_json("reference_vectors.json")
+PROBE = harness.load_json("survey_probe_records.json")
+K1_PLAIN = np.frombuffer(bytes.fromhex(VEC["K1_url"]["plain"]), dtype=np.uint8)
+K1_ENC = np.frombuffer(bytes.fromhex(VEC["K1_url"]["encoded"]), dtype=np.uint8)
+K2_PLAIN = np.frombuffer(bytes.fromhex(VEC["K2_all_codes"]["plain"]), dtype=np.uint8)
+K2_ENC = np.frombuffer(bytes.fromhex(VEC["K2_all_codes"]["encoded"]), dtype=np.uint8)
+STEPS = VEC["step_sizes"]
+
+
+class World:
+    """Both libraries, each with its own instance of the same coder."""
+
+    def __init__(self, oracle, product):
+        self.oracle, self.product = oracle, product
+        patterns, lens = harness.load_table()
+        self.table = (patterns, lens)
+        self.ocoder = oracle.lib.oracle_table_coder_new(patterns, lens)
+        self.pcoder = product.lib.aws_huffman_amd_table_coder_new(patterns, lens)
+        assert self.ocoder and self.pcoder
+        # the same table with holes: symbols 7 and 200 have no code
+        holes = (C.c_uint8 * 256)(*lens)
+        holes[7] = 0
+        holes[200] = 0
+        self.ocoder_holes = oracle.lib.oracle_table_coder_new(patterns, holes)
+        self.pcoder_holes = product.lib.aws_huffman_amd_table_coder_new(patterns, holes)
+        assert self.ocoder_holes and self.pcoder_holes
+
+
+# ----------------------------------------------------------------------------- input families
+def inputs(rng, n, kind):
+    if kind == "uniform":
+        return rng.integers(0, 256, n, dtype=np.uint8)
+    if kind == "printable":
+        return harness.printable_map(rng.integers(0, 256, n, dtype=np.uint8))
+    if kind == "short":  # only the ten 5-bit symbols: densest possible output per bit
+        alphabet = np.frombuffer(b" aeinorst", dtype=np.uint8)
+        return alphabet[rng.integers(0, alphabet.size, n)]
+    if kind == "long":  # only 10-bit symbols: no self-synchronisation between bit offsets
+        return rng.integers(128, 256, n, dtype=np.uint8)
+    if kind == "constant":
+        return np.full(n, 101, dtype=np.uint8)
+    raise ValueError(kind)
+
+
+KINDS = ["uniform", "printable", "short", "long", "constant"]
+
+
+# ----------------------------------------------------------------------------- paired calls
+def paired_encode(w, eo, ep, src, off, dst_o, dst_p, length, cap, coder_pair=None):
+    ro = w.oracle.encode_call(eo, src, off, dst_o, length, cap)
+    rp = w.product.encode_call(ep, src, off, dst_p, length, cap)
+    assert rp.key() == ro.key(), "encode call differs: product %r oracle %r (off=%d len=%d cap=%d)" % (rp, ro, off, length, cap)
+    assert np.array_equal(dst_p, dst_o), "encode output bytes differ (off=%d len=%d cap=%d)" % (off, length, cap)
+    return ro
+
+
+def paired_decode(w, do, dp, src, off, end, dst_o, dst_p, length, cap):
+    ro = w.oracle.decode_call(do, src, off, end, dst_o, length, cap)
+    rp = w.product.decode_call(dp, src, off, end, dst_p, length, cap)
+    assert rp.key() == ro.key(), "decode call differs: product %r oracle %r (off=%d end=%d len=%d cap=%d)" % (
+        rp, ro, off, end, length, cap)
+    assert np.array_equal(dst_p, dst_o), "decode output bytes differ (off=%d end=%d len=%d cap=%d)" % (off, end, length, cap)
+    return ro
+
+
+def oracle_encode(w, data, coder=None, eos=None):
+    return w.oracle.encode_all(coder or w.ocoder, data, eos_padding=eos)
+
+
+# ----------------------------------------------------------------------------- scenario: the reference's unit tests on the product
+def reference_unit_tests(codec, coder):
+    """tests/huffman_test.c:62-385 on `codec` (known answers, no oracle involved)."""
+    # huffman_encoder / _all_code_points
+    for plain, enc in ((K1_PLAIN, K1_ENC), (K2_PLAIN, K2_ENC)):
+        e = codec.new_encoder(coder)
+        assert codec.encoded_length(e, plain) == enc.size
+        dst = np.zeros(enc.size + 1, dtype=np.uint8)
+        r = codec.encode_call(e, plain, 0, dst, 0, enc.size)
+        assert (r.rc, r.consumed, r.produced) == (0, plain.size, enc.size)
+        assert dst[enc.size] == 0 and bytes(dst[: enc.size]) == bytes(enc)
+        d = codec.new_decoder(coder)
+        out = np.zeros(plain.size + 1, dtype=np.uint8)
+        r = codec.decode_call(d, enc, 0, enc.size, out, 0, plain.size)
+        assert (r.rc, r.consumed, r.produced) == (0, enc.size, plain.size)
+        assert out[plain.size] == 0 and bytes(out[: plain.size]) == bytes(plain)
+    # huffman_encoder_partial_output
+    for step in STEPS:
+        e = codec.new_encoder(coder)
+        dst = np.zeros(K2_ENC.size, dtype=np.uint8)
+        cap = length = off = 0
+        while length < K2_ENC.size:
+            cap = min(cap + step, K2_ENC.size)
+            r = codec.encode_call(e, K2_PLAIN, off, dst, length, cap)
+            assert r.produced > 0
+            length += r.produced
+            off += r.consumed
+            assert bytes(dst[:length]) == bytes(K2_ENC[:length])
+            assert (r.rc == 0) if length == K2_ENC.size else (r.rc == -1 and r.err == SHORT_BUFFER)
+    # huffman_encoder_exact_output
+    e = codec.new_encoder(coder)
+    for case in VEC["K3_exact_fit"]:
+        plain = np.frombuffer(bytes.fromhex(case["plain"]), dtype=np.uint8)
+        want = bytes.fromhex(case["encoded"])
+        dst = np.zeros(2, dtype=np.uint8)
+        r = codec.encode_call(e, plain, 0, dst, 0, len(want))
+        assert r.rc == 0 and bytes(dst[: len(want)]) == want
+    # huffman_decoder_partial_input / _partial_output
+    for step in STEPS:
+        d = codec.new_decoder(coder)
+        dst = np.zeros(150, dtype=np.uint8)
+        off = length = 0
+        while length < K2_PLAIN.size:
+            chunk = min(step, K2_ENC.size - off)
+            r = codec.decode_call(d, K2_ENC, off, off + chunk, dst, length, K2_PLAIN.size)
+            assert r.consumed == chunk
+            off += chunk
+            length += r.produced
+            assert bytes(dst[:length]) == bytes(K2_PLAIN[:length])
+        d = codec.new_decoder(coder)
+        dst = np.zeros(150, dtype=np.uint8)
+        off = length = cap = 0
+        while length < K2_PLAIN.size:
+            cap = min(cap + step, K2_PLAIN.size)
+            r = codec.decode_call(d, K2_ENC, off, K2_ENC.size, dst, length, cap)
+            assert r.produced > 0
+            off += r.consumed
+            length += r.produced
+            assert bytes(dst[:length]) == bytes(K2_PLAIN[:length])
+            assert (r.rc == 0) if length == K2_PLAIN.size else (r.rc == -1 and r.err == SHORT_BUFFER)
+    # huffman_decoder_allow_growth
+    alloc_name = "oracle_default_allocator" if codec.prefix == "oracle_" else "aws_default_allocator"
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.free.argtypes = [C.c_void_p]
+    d = codec.new_decoder(coder)
+    codec.decoder_allow_growth(d, True)
+    buf = harness.ByteBuf(0, libc.malloc(1), 1, getattr(codec.lib, alloc_name)())
+    cur = harness.ByteCursor(K1_ENC.size, K1_ENC.ctypes.data)
+    assert codec._decode(C.byref(d), C.byref(cur), C.byref(buf)) == 0
+    assert cur.len == 0 and buf.len == K1_PLAIN.size and buf.capacity == 16
+    assert C.string_at(buf.buffer, buf.len) == bytes(K1_PLAIN)
+    libc.free(buf.buffer)
+
+
+# ----------------------------------------------------------------------------- scenario: one-shot calls
+def one_shot_roundtrips(w, sizes, seed=11):
+    rng = np.random.default_rng(seed)
+    for n in sizes:
+        for kind in KINDS:
+            data = inputs(rng, n, kind)
+            cap = n * 2 + 64
+            do, dp = np.full(cap, SENTINEL, np.uint8), np.full(cap, SENTINEL, np.uint8)
+            eo, ep = w.oracle.new_encoder(w.ocoder), w.product.new_encoder(w.pcoder)
+            assert w.product.encoded_length(ep, data) == w.oracle.encoded_length(eo, data)
+            r = paired_encode(w, eo, ep, data, 0, do, dp, 0, cap)
+            enc = do[: r.produced].copy()
+            # decode: exact capacity, one byte short, and roomy
+            for out_cap in (n, max(n - 1, 0), n + 7):
+                oo, op = np.full(n + 8, SENTINEL, np.uint8), np.full(n + 8, SENTINEL, np.uint8)
+                ddo, ddp = w.oracle.new_decoder(w.ocoder), w.product.new_decoder(w.pcoder)
+                paired_decode(w, ddo, ddp, enc, 0, enc.size, oo, op, 0, out_cap)
+
+
+# ----------------------------------------------------------------------------- scenario: streaming encode (output in pieces)
+def streaming_encode(w, sizes, seed=12, coder_pair=None):
+    rng = np.random.default_rng(seed)
+    oc, pc = coder_pair or (w.ocoder, w.pcoder)
+    for n in sizes:
+        for kind in ("uniform", "printable", "short"):
+            data = inputs(rng, n, kind)
+            total = n * 2 + 64
+            do, dp = np.full(total, SENTINEL, np.uint8), np.full(total, SENTINEL, np.uint8)
+            eo, ep = w.oracle.new_encoder(oc, eos_padding=0xA7), w.product.new_encoder(pc, eos_padding=0xA7)
+            off = length = cap = 0
+            for _ in range(10000):
+                grow = int(rng.choice([0, 1, 1, 2, 3, 7, 64, 1000, 5000, 20000]))
+                cap = min(cap + grow, total)
+                r = paired_encode(w, eo, ep, data, off, do, dp, length, cap)
+                off += r.consumed
+                length += r.produced
+                if r.rc == 0:
+                    break
+                assert r.err == SHORT_BUFFER
+            else:
+                raise AssertionError("streaming encode did not finish")
+            assert off == n
+
+
+# ----------------------------------------------------------------------------- scenario: streaming decode (input and output in pieces)
+def streaming_decode(w, sizes, seed=13):
+    rng = np.random.default_rng(seed)
+    for n in sizes:
+        for kind in ("uniform", "printable", "long"):
+            data = inputs(rng, n, kind)
+            enc = oracle_encode(w, data)
+            oo, op = np.full(n + 8, SENTINEL, np.uint8), np.full(n + 8, SENTINEL, np.uint8)
+            ddo, ddp = w.oracle.new_decoder(w.ocoder), w.product.new_decoder(w.pcoder)
+            fed = length = cap = 0
+            pending_lo = 0  # start of the not-yet-consumed part of what was fed
+            for _ in range(20000):
+                # offer a few more input bytes and a little more output room
+                fed = min(fed + int(rng.choice([0, 1, 2, 3, 5, 8, 100, 3000, 40000])), enc.size)
+                cap = min(cap + int(rng.choice([0, 1, 2, 9, 200, 5000, 50000])), n)
+                r = paired_decode(w, ddo, ddp, enc, pending_lo, fed, oo, op, length, cap)
+                pending_lo += r.consumed
+                length += r.produced
+                if length == n and pending_lo == enc.size:
+                    break
+                if r.rc != 0:
+                    assert r.err == SHORT_BUFFER
+            else:
+                raise AssertionError("streaming decode did not finish")
+            assert np.array_equal(oo[:n], data)
+
+
+# ----------------------------------------------------------------------------- scenario: symbols without a code
+def unknown_symbols(w, seed=14, big=16384 * 2 + 100):
+    rng = np.random.default_rng(seed)
+    oc, pc = w.ocoder_holes, w.pcoder_holes
+    cases = []
+    for n, bad_at in ((40, [0]), (40, [39]), (300, [150, 151]), (big, [5]), (big, [16383]), (big, [16384]),
+                      (big, [16385]), (big, [big - 1]), (big, [16380, 20000])):
+        data = inputs(rng, n, "printable")
+        data[data == 7] = 8
+        data[data == 200] = 201
+        for k, b in enumerate(bad_at):
+            data[b] = 7 if k % 2 == 0 else 200
+        cases.append(data)
+    for data in cases:
+        n = data.size
+        full = w.oracle.encoded_length(w.oracle.new_encoder(oc), data)
+        first_bad = int(np.flatnonzero((data == 7) | (data == 200))[0])
+        bits_before = w.oracle.encoded_length(w.oracle.new_encoder(oc), data[:first_bad])
+        for cap in sorted({0, 1, max(bits_before - 1, 0), bits_before, bits_before + 1, bits_before + 2, full, full + 50,
+                           n * 2}):
+            do, dp = np.full(n * 2 + 64, SENTINEL, np.uint8), np.full(n * 2 + 64, SENTINEL, np.uint8)
+            eo, ep = w.oracle.new_encoder(oc), w.product.new_encoder(pc)
+            r = paired_encode(w, eo, ep, data, 0, do, dp, 0, min(cap, do.size))
+            if r.rc == -1 and r.err == SHORT_BUFFER:
+                # resume into a roomy buffer: now the bad symbol must surface identically
+                paired_encode(w, eo, ep, data, r.consumed, do, dp, r.produced, do.size)
+        assert w.product.encoded_length(w.product.new_encoder(pc), data) == full
+
+
+# ----------------------------------------------------------------------------- scenario: decode of arbitrary bytes (tests/fuzz/decode.c) + pinned error records
+def garbage_decode(w, seed=15, rounds=120, big=70000):
+    rng = np.random.default_rng(seed)
+    streams = [rng.integers(0, 256, int(rng.integers(1, 300)), dtype=np.uint8) for _ in range(rounds)]
+    streams += [np.full(k, v, np.uint8) for k in (1, 3, 4, 8, 200) for v in (0x00, 0xFF, 0x55)]
+    # valid streams with damage in the middle, across a chunk boundary
+    good = oracle_encode(w, inputs(rng, big, "uniform"))
+    for at in (0, 1000, 32767, 32768, 32769, good.size - 3):
+        bad = good.copy()
+        bad[at] ^= 0xFF
+        bad[min(at + 1, bad.size - 1)] = 0x00
+        streams.append(bad)
+    streams.append(good[: good.size - 1])
+    streams.append(good[:32768])
+    for data in streams:
+        n = data.size
+        for out_cap in (2 * n, 3):
+            oo, op = np.full(2 * n + 8, SENTINEL, np.uint8), np.full(2 * n + 8, SENTINEL, np.uint8)
+            ddo, ddp = w.oracle.new_decoder(w.ocoder), w.product.new_decoder(w.pcoder)
+            paired_decode(w, ddo, ddp, data, 0, n, oo, op, 0, out_cap)
+    for rec in PROBE["raw_bytes_as_stream_decode"]:
+        if "input" in rec:
+            s = PROBE["streams"][rec["input"]]
+            data = harness.splitmix64_bytes(s["seed"], s["len"])
+        else:
+            data = np.frombuffer(bytes.fromhex(rec["input_hex"]), dtype=np.uint8)
+        d = w.product.new_decoder(w.pcoder)
+        dst = np.zeros(rec["out_cap"], dtype=np.uint8)
+        r = w.product.decode_call(d, data, 0, data.size, dst, 0, rec["out_cap"])
+        assert (r.rc, r.err, r.consumed) == (rec["rc"], rec["error"], rec["input_pulled"]), (rec, r)
+        assert dst[: r.produced].tobytes().hex() == rec["symbols"]
+
+
+# ----------------------------------------------------------------------------- scenario: padding byte values
+def eos_padding_values(w):
+    rng = np.random.default_rng(16)
+    for eos in (0x00, 0xFF, 0x55, 0x06, 0x80, 0x7F):
+        for n in (1, 2, 3, 17, 1000):
+            data = inputs(rng, n, "printable")
+            do, dp = np.full(2 * n + 16, SENTINEL, np.uint8), np.full(2 * n + 16, SENTINEL, np.uint8)
+            eo, ep = w.oracle.new_encoder(w.ocoder, eos_padding=eos), w.product.new_encoder(w.pcoder, eos_padding=eos)
+            paired_encode(w, eo, ep, data, 0, do, dp, 0, do.size)
+    for rec in PROBE["eos_padding_probe"]:
+        plain = np.frombuffer(bytes.fromhex(rec["plain"]), dtype=np.uint8)
+        assert w.product.encode_all(w.pcoder, plain, eos_padding=rec["eos_padding"]).tobytes().hex() == rec["encoded"]
+
+
+# ----------------------------------------------------------------------------- scenario: pinned records of SURVEY.md 8c on the product
+def survey_records_on_product(w, names=("G4K", "G16K", "G16KP")):
+    for name in names:
+        rec = PROBE["streams"][name]
+        raw = harness.splitmix64_bytes(rec["seed"], rec["len"])
+        plain = harness.printable_map(raw) if rec["map"] == "printable" else raw
+        enc = w.product.encode_all(w.pcoder, plain)
+        assert enc.size == rec["encoded_len"]
+        assert hashlib.sha256(enc.tobytes()).hexdigest() == rec["sha256_encoded"]
+        r, back = w.product.decode_all(w.pcoder, enc, plain.size)
+        assert (r.rc, r.consumed, r.produced, r.state[0]) == (0, enc.size, plain.size, rec["decoder_tail_num_bits"])
+        assert np.array_equal(back, plain)
+    plain = harness.splitmix64_bytes(2, 16384)
+    for rec in PROBE["G16K_partial_encode"]:
+        e = w.product.new_encoder(w.pcoder)
+        dst = np.zeros(20000, dtype=np.uint8)
+        r = w.product.encode_call(e, plain, 0, dst, 0, rec["cap"])
+        assert (r.rc, r.consumed, r.produced) == (rec["rc"], rec["consumed"], rec["out_len"]), (rec, r)
+        if rec["rc"]:
+            assert r.err == SHORT_BUFFER and r.state == (rec["overflow_num_bits"], rec["overflow_pattern"])
+    t = PROBE["K1_encode_step1_trace"]
+    e = w.product.new_encoder(w.pcoder)
+    dst = np.zeros(12, dtype=np.uint8)
+    off = length = 0
+    for cap in range(1, 13):
+        r = w.product.encode_call(e, K1_PLAIN, off, dst, length, cap)
+        off += r.consumed
+        length += r.produced
+        assert off == t["consumed"][cap - 1] and r.state[0] == t["overflow_num_bits"][cap - 1]
+    t = PROBE["K1_decode_partial_output"]
+    d = w.product.new_decoder(w.pcoder)
+    dst = np.zeros(16, dtype=np.uint8)
+    off = length = 0
+    for cap, want_off, want_bits in zip(t["caps"], t["input_consumed"], t["num_bits"]):
+        r = w.product.decode_call(d, K1_ENC, off, K1_ENC.size, dst, length, cap)
+        off += r.consumed
+        length += r.produced
+        assert off == want_off and r.state[0] == want_bits
+    assert "%016x" % d.working_bits == t["final_working_bits"]
+
+
+# ----------------------------------------------------------------------------- scenario: foreign callbacks
+def foreign_coder_callbacks(w):
+    """The product tabulates whatever callbacks it is given: hand it the ORACLE's coder object."""
+    rng = np.random.default_rng(17)
+    data = inputs(rng, 5000, "uniform")
+    want = oracle_encode(w, data)
+    got = w.product.encode_all(w.ocoder, data)  # oracle callbacks, product engine
+    assert np.array_equal(got, want)
+    r, back = w.product.decode_all(w.ocoder, want, data.size)
+    assert r.rc == 0 and np.array_equal(back, data)
+
+
+# ----------------------------------------------------------------------------- scenario: device-pointer batched API
+def batched_device_api(w, n_items=9, seed=18, item_len=16384, engine=None):
+    """huffman_amd.h: every item must equal the oracle's result for that item alone."""
+    rng = np.random.default_rng(seed)
+    eng = engine or harness.Engine(w.product.lib, w.pcoder)
+    lens = [0, 1, 15, 16, 17, item_len - 1, item_len, item_len + 1, 3 * item_len + 5][:n_items]
+    lens += [int(rng.integers(1, 2 * item_len)) for _ in range(n_items - len(lens))]
+    blobs = [inputs(rng, n, KINDS[i % 3]) for i, n in enumerate(lens)]
+    # inputs packed back to back at odd offsets; outputs with guard gaps
+    in_offs, pos = [], 3
+    for b in blobs:
+        in_offs.append(pos)
+        pos += b.size + int(rng.integers(0, 5))
+    in_total = pos + 64
+    full = [oracle_encode(w, b) for b in blobs]
+    caps = []
+    for i, f in enumerate(full):
+        caps.append([f.size + 9, f.size, max(f.size - 1, 0), f.size // 2, 0][i % 5])
+    out_offs, pos = [], 5
+    for c in caps:
+        out_offs.append(pos)
+        pos += c + 24
+    out_total = pos + 64
+    host_in = np.zeros(in_total, np.uint8)
+    for b, o in zip(blobs, in_offs):
+        host_in[o:o + b.size] = b
+    d_in, d_out = eng.alloc(in_total), eng.alloc(out_total)
+    eng.upload(d_in, host_in)
+    eng.fill(d_out, SENTINEL, out_total)
+    items = [dict(in_offset=o, in_len=b.size, out_offset=oo, out_capacity=c, eos_padding=0xFF)
+             for b, o, oo, c in zip(blobs, in_offs, out_offs, caps)]
+    plan = eng.encode_plan(items)
+    eng.encode_launch(plan, d_in, d_out)
+    res = eng.encode_results(plan, len(items))
+    got = eng.download(d_out, out_total)
+    want = np.full(out_total, SENTINEL, np.uint8)
+    for i, (b, oo, c) in enumerate(zip(blobs, out_offs, caps)):
+        e = w.oracle.new_encoder(w.ocoder)
+        dst = np.full(c + 1, SENTINEL, np.uint8)
+        r = w.oracle.encode_call(e, b, 0, dst, 0, c)
+        want[oo:oo + c] = dst[:c]
+        assert res[i] == (r.rc, r.err, r.consumed, r.produced, r.state[0], r.state[1]), (i, res[i], r)
+    assert np.array_equal(got, want), "batched encode wrote outside its items or wrote wrong bytes"
+    # length-only launch: nothing written, totals reported
+    eng.fill(d_out, SENTINEL, out_total)
+    eng.encode_launch(plan, d_in, d_out, length_only=True)
+    eng.encode_results(plan, len(items))
+    assert np.all(eng.download(d_out, out_total) == SENTINEL)
+    eng.lib.aws_huffman_amd_encode_plan_destroy(plan)
+
+    # decode side: the full encodings packed at odd offsets, with a bit offset on some
+    enc_offs, pos = [], 1
+    for f in full:
+        enc_offs.append(pos)
+        pos += f.size + int(rng.integers(0, 4))
+    enc_total = pos + 64
+    host_enc = np.zeros(enc_total, np.uint8)
+    for f, o in zip(full, enc_offs):
+        host_enc[o:o + f.size] = f
+    dcaps = [[b.size, b.size + 3, max(b.size - 1, 0), b.size // 3][i % 4] for i, b in enumerate(blobs)]
+    sym_offs, pos = [], 7
+    for c in dcaps:
+        sym_offs.append(pos)
+        pos += c + 24
+    sym_total = pos + 64
+    d_enc, d_sym = eng.alloc(enc_total), eng.alloc(sym_total)
+    eng.upload(d_enc, host_enc)
+    eng.fill(d_sym, SENTINEL, sym_total)
+    ditems = [dict(in_offset=o, in_len=f.size, first_bit=0, out_offset=so, out_capacity=c)
+              for f, o, so, c in zip(full, enc_offs, sym_offs, dcaps)]
+    dplan = eng.decode_plan(ditems)
+    eng.decode_launch(dplan, d_enc, d_sym)
+    dres = eng.decode_results(dplan, len(ditems))
+    got = eng.download(d_sym, sym_total)
+    want = np.full(sym_total, SENTINEL, np.uint8)
+    for i, (f, so, c) in enumerate(zip(full, sym_offs, dcaps)):
+        d = w.oracle.new_decoder(w.ocoder)
+        dst = np.full(c + 1, SENTINEL, np.uint8)
+        r = w.oracle.decode_call(d, f, 0, f.size, dst, 0, c)
+        want[so:so + c] = dst[:c]
+        # bits consumed by the emitted symbols = bytes pulled * 8 - read-ahead left in the decoder
+        assert dres[i] == (r.rc, r.err, r.produced, r.consumed * 8 - r.state[0]), (i, dres[i], r)
+    assert np.array_equal(got, want), "batched decode wrote outside its items or wrote wrong bytes"
+    eng.lib.aws_huffman_amd_decode_plan_destroy(dplan)
+    for p in (d_in, d_out, d_enc, d_sym):
+        eng.free(p)
+    if engine is None:
+        eng.close()
+
+
+def first_bit_offsets(w, engine=None):
+    """Decode items that start inside their first byte (what a carried decoder state turns into)."""
+    rng = np.random.default_rng(19)
+    eng = engine or harness.Engine(w.product.lib, w.pcoder)
+    data = inputs(rng, 3000, "uniform")
+    enc = oracle_encode(w, data)
+    for skip_symbols in (1, 2, 3, 5, 8):
+        # drop the first symbols on the oracle side to learn where symbol k starts
+        d = w.oracle.new_decoder(w.ocoder)
+        dst = np.zeros(skip_symbols, np.uint8)
+        r = w.oracle.decode_call(d, enc, 0, enc.size, dst, 0, skip_symbols)
+        start_bit = r.consumed * 8 - r.state[0]
+        byte0, first_bit = start_bit // 8, start_bit % 8
+        tail = enc[byte0:]
+        d_in, d_out = eng.alloc(tail.size + 16), eng.alloc(data.size + 16)
+        eng.upload(d_in, tail)
+        plan = eng.decode_plan([dict(in_offset=0, in_len=tail.size, first_bit=first_bit, out_offset=0,
+                                     out_capacity=data.size)])
+        eng.decode_launch(plan, d_in, d_out)
+        (rc, err, produced, bits), = eng.decode_results(plan, 1)
+        assert (rc, err, produced) == (0, 0, data.size - skip_symbols)
+        assert np.array_equal(eng.download(d_out, produced), data[skip_symbols:])
+        eng.lib.aws_huffman_amd_decode_plan_destroy(plan)
+        eng.free(d_in)
+        eng.free(d_out)
+    if engine is None:
+        eng.close()

@@ -1,0 +1,74 @@
+"""CPU-only logic tests of the HIP kernels through the fiber emulator (tests/emu).
+
+The product sources are compiled unchanged against tests/emu/hip/hip_runtime.h with
+UBSan and every parity scenario is run against the oracle.  This is the "sanitizers on
+the CPU build" leg (GPU sanitizers are unavailable on the pool) and the way kernel logic
+is debugged in a container without a GPU.  It is NOT a parity claim for the GPU build:
+tests/test_gpu_parity.py makes that, on an MI355X.
+"""
+import os
+import subprocess
+
+import pytest
+
+import harness
+import parity_cases as pc
+
+EMU_DIR = os.path.join(harness.REPO, "tests", "emu")
+EMU_SO = os.path.join(EMU_DIR, "libaws-c-compression-emu.so")
+
+
+@pytest.fixture(scope="module")
+def world(oracle):
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR], stdout=subprocess.DEVNULL)
+    product = harness.Codec(harness.load_product(EMU_SO), "aws_")
+    return pc.World(oracle, product)
+
+
+def test_reference_unit_tests(world):
+    pc.reference_unit_tests(world.product, world.pcoder)
+
+
+def test_one_shot_roundtrips(world):
+    pc.one_shot_roundtrips(world, sizes=[1, 2, 15, 16, 17, 255, 4096, 16383, 16384, 16385, 40000])
+
+
+def test_streaming_encode(world):
+    pc.streaming_encode(world, sizes=[1, 40, 5000, 33000])
+
+
+def test_streaming_decode(world):
+    pc.streaming_decode(world, sizes=[1, 40, 5000, 60000])
+
+
+def test_unknown_symbols(world):
+    pc.unknown_symbols(world)
+
+
+def test_garbage_decode(world):
+    pc.garbage_decode(world)
+
+
+def test_eos_padding_values(world):
+    pc.eos_padding_values(world)
+
+
+def test_survey_records(world):
+    pc.survey_records_on_product(world)
+
+
+def test_foreign_coder_callbacks(world):
+    pc.foreign_coder_callbacks(world)
+
+
+def test_batched_device_api(world):
+    pc.batched_device_api(world)
+
+
+def test_first_bit_offsets(world):
+    pc.first_bit_offsets(world)
+
+
+def test_large_items_take_the_workgroup_scan(world):
+    """More than HUFD_SCAN_SMALL_MAX (64) segments / chunks per item."""
+    pc.one_shot_roundtrips(world, sizes=[16384 * 66 + 3, 32768 * 70], seed=21)

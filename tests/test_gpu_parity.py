@@ -1,0 +1,182 @@
+"""Parity of the HIP build against the CPU oracle, on an MI355X (`pytest -m gpu`).
+
+Everything goes through the C ABI of aws-c-compression_amd/libaws-c-compression-amd.so.
+The scenarios are the ones of tests/parity_cases.py; the sizes here reach the
+BASELINE.json configurations (1 GiB single stream, 65 536 x 16 KiB batch).
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import harness
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+PROBE = harness.load_json("survey_probe_records.json")
+
+
+@pytest.fixture(scope="module")
+def world(oracle):
+    lib = harness.load_product()
+    assert lib.aws_huffman_amd_device_count() >= 1, "no HIP device visible: the product has no CPU path"
+    return pc.World(oracle, harness.Codec(lib, "aws_"))
+
+
+@pytest.fixture(scope="module")
+def engine(world):
+    eng = harness.Engine(world.product.lib, world.pcoder)
+    yield eng
+    eng.close()
+
+
+def test_reference_unit_tests(world):
+    pc.reference_unit_tests(world.product, world.pcoder)
+
+
+def test_one_shot_roundtrips(world):
+    pc.one_shot_roundtrips(world, sizes=[1, 2, 15, 16, 17, 255, 4096, 16383, 16384, 16385, 40000, 200001])
+
+
+def test_streaming_encode(world):
+    pc.streaming_encode(world, sizes=[1, 40, 5000, 33000])
+
+
+def test_streaming_decode(world):
+    pc.streaming_decode(world, sizes=[1, 40, 5000, 60000])
+
+
+def test_unknown_symbols(world):
+    pc.unknown_symbols(world)
+
+
+def test_garbage_decode(world):
+    pc.garbage_decode(world)
+
+
+def test_eos_padding_values(world):
+    pc.eos_padding_values(world)
+
+
+def test_survey_records(world):
+    pc.survey_records_on_product(world, names=("G4K", "G16K", "G16KP", "G1M"))
+
+
+def test_foreign_coder_callbacks(world):
+    pc.foreign_coder_callbacks(world)
+
+
+def test_batched_device_api(world, engine):
+    pc.batched_device_api(world, n_items=40, engine=engine)
+
+
+def test_first_bit_offsets(world, engine):
+    pc.first_bit_offsets(world, engine=engine)
+
+
+def test_large_items_take_the_workgroup_scan(world):
+    pc.one_shot_roundtrips(world, sizes=[16384 * 66 + 3, 32768 * 70, 8 * 1024 * 1024 + 11], seed=21)
+
+
+def test_config2_config3_one_gib_stream(world, engine):
+    """BASELINE.json configs[1] and [2]: 1 GiB of splitmix64(seed 5) bytes, encode then decode.
+
+    Pinned three ways: sha256 of the device-generated input and of the encoded stream against
+    the digests SURVEY.md 8c records from the real reference, and the decoded stream against
+    the input (encode -> decode round trip at full size).
+    """
+    rec = PROBE["streams"]["G1G"]
+    n, e = rec["len"], rec["encoded_len"]
+    d_in, d_enc, d_back = engine.alloc(n), engine.alloc(e + 64), engine.alloc(n + 64)
+    engine.fill_splitmix64(d_in, n, rec["seed"])
+    engine.fill(d_enc, 0x5A, e + 64)
+    engine.fill(d_back, 0x5A, n + 64)
+    plan = engine.encode_plan([dict(in_offset=0, in_len=n, out_offset=0, out_capacity=e + 64)])
+    engine.encode_launch(plan, d_in, d_enc)
+    (rc, err, consumed, produced, ob, op), = engine.encode_results(plan, 1)
+    assert (rc, err, consumed, produced, ob) == (0, 0, n, e, 0)
+    dplan = engine.decode_plan([dict(in_offset=0, in_len=e, out_offset=0, out_capacity=n)])
+    engine.decode_launch(dplan, d_enc, d_back)
+    (rc, err, symbols, bits), = engine.decode_results(dplan, 1)
+    assert (rc, err, symbols) == (0, 0, n)
+    assert e * 8 - bits == rec["decoder_tail_num_bits"]  # padding bits left over
+
+    def digest(ptr, size):
+        h = hashlib.sha256()
+        step = 256 << 20
+        for off in range(0, size, step):
+            h.update(engine.download(ptr, min(step, size - off), offset=off).tobytes())
+        return h.hexdigest()
+
+    assert digest(d_in, n) == rec["sha256_input"]
+    assert digest(d_enc, e) == rec["sha256_encoded"]
+    assert digest(d_back, n) == rec["sha256_input"]
+    assert np.all(engine.download(d_enc, 64, offset=e) == 0x5A)  # nothing past the stream
+    assert np.all(engine.download(d_back, 64, offset=n) == 0x5A)
+    engine.lib.aws_huffman_amd_encode_plan_destroy(plan)
+    engine.lib.aws_huffman_amd_decode_plan_destroy(dplan)
+    for p in (d_in, d_enc, d_back):
+        engine.free(p)
+
+
+def test_config4_batch_of_16k_buffers(world, engine):
+    """BASELINE.json configs[3]: 65 536 buffers x 16 KiB, every fourth one capacity-limited.
+
+    Buffer i is splitmix64(seed 2 + i); buffers with i % 4 == 0 get 16 384 bytes of room and
+    must come back SHORT_BUFFER with the reference's (consumed, overflow) record -- buffer 0 is
+    the one SURVEY.md 8c pins -- then finish in a second call; the rest encode in one call.
+    A sample of buffers is compared byte for byte with the oracle, and the whole batch is
+    decoded back and compared with the input.
+    """
+    count, size = 65536, 16384
+    d_in = engine.alloc(count * size)
+    host_in = np.empty((count, size), np.uint8)
+    for i in range(count):
+        host_in[i] = harness.splitmix64_bytes(2 + i, size)
+    engine.upload(d_in, host_in.reshape(-1))
+    stride = 2 * size
+    d_out = engine.alloc(count * stride)
+    engine.fill(d_out, 0x5A, count * stride)
+    items = [dict(in_offset=i * size, in_len=size, out_offset=i * stride,
+                  out_capacity=size if i % 4 == 0 else stride) for i in range(count)]
+    plan = engine.encode_plan(items)
+    engine.encode_launch(plan, d_in, d_out)
+    res = engine.encode_results(plan, count)
+    first = PROBE["G16K_partial_encode"][2]
+    assert res[0] == (-1, harness.AWS_ERROR_SHORT_BUFFER, first["consumed"], first["out_len"],
+                      first["overflow_num_bits"], first["overflow_pattern"])
+    assert all(r[0] == 0 and r[2] == size for i, r in enumerate(res) if i % 4)
+    assert all(r[0] == -1 and r[1] == harness.AWS_ERROR_SHORT_BUFFER and r[3] == size
+               for i, r in enumerate(res) if i % 4 == 0)
+    # second call for the capacity-limited ones: the rest of the input, carried overflow, fresh room
+    resume = [dict(in_offset=i * size + res[i][2], in_len=size - res[i][2], out_offset=i * stride + size,
+                   out_capacity=size, overflow_in=(res[i][5], res[i][4])) for i in range(0, count, 4)]
+    plan2 = engine.encode_plan(resume)
+    engine.encode_launch(plan2, d_in, d_out)
+    res2 = engine.encode_results(plan2, len(resume))
+    assert all(r[0] == 0 for r in res2)
+    lengths = [res[i][3] + (res2[i // 4][3] if i % 4 == 0 else 0) for i in range(count)]
+    # a sample against the oracle, byte for byte, plus the guard bytes behind each stream
+    rng = np.random.default_rng(5)
+    for i in [0, 1, 2, 3, 4, count - 1] + [int(x) for x in rng.integers(0, count, 40)]:
+        want = world.oracle.encode_all(world.ocoder, host_in[i])
+        got = engine.download(d_out, stride, offset=i * stride)
+        assert lengths[i] == want.size and np.array_equal(got[: want.size], want), i
+        assert np.all(got[want.size:] == 0x5A), i
+    # decode everything back
+    d_back = engine.alloc(count * size)
+    ditems = [dict(in_offset=i * stride, in_len=lengths[i], out_offset=i * size, out_capacity=size)
+              for i in range(count)]
+    dplan = engine.decode_plan(ditems)
+    engine.decode_launch(dplan, d_out, d_back)
+    dres = engine.decode_results(dplan, count)
+    assert all(r[0] == 0 and r[2] == size for r in dres)
+    back = engine.download(d_back, count * size)
+    assert np.array_equal(back, host_in.reshape(-1))
+    for p in (plan, plan2):
+        engine.lib.aws_huffman_amd_encode_plan_destroy(p)
+    engine.lib.aws_huffman_amd_decode_plan_destroy(dplan)
+    for p in (d_in, d_out, d_back):
+        engine.free(p)

@@ -1,0 +1,107 @@
+"""CPU-only checks of the drop-in boundary: the shared library loads, exports every symbol
+the headers under include/ declare, keeps the reference's struct layouts, and fails loudly
+(no CPU fallback) when there is no GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+import harness
+
+
+@pytest.fixture(scope="module")
+def product_lib():
+    if not os.path.exists(harness.PRODUCT_SO):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return harness.load_product()
+
+
+def declared_symbols():
+    names = set()
+    inc = os.path.join(harness.REPO, "include", "aws", "compression")
+    for header in ("huffman.h", "huffman_amd.h", "compression.h"):
+        text = open(os.path.join(inc, header)).read()
+        for m in re.finditer(r"AWS_COMPRESSION_API\s+[^;]*?\b(aws_\w+)\s*\(", text, re.S):
+            names.add(m.group(1))
+    return names
+
+
+def test_every_declared_symbol_is_exported(product_lib):
+    declared = declared_symbols()
+    assert len(declared) >= 35
+    assert declared == set(harness.EXPORTED_SYMBOLS)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", harness.PRODUCT_SO], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    missing = declared - exported
+    assert not missing, "declared in include/ but not exported: %s" % sorted(missing)
+    # nothing from the oracle or the emulator leaks into the product
+    assert not any(s.startswith("oracle_") or "hip_emu" in s for s in exported)
+
+
+def test_abi_layout():
+    harness.check_abi_layout()
+
+
+def test_init_and_reset_need_no_gpu(product_lib):
+    codec = harness.Codec(product_lib, "aws_")
+    patterns, lens = harness.load_table()
+    coder = product_lib.aws_huffman_amd_table_coder_new(patterns, lens)
+    assert coder
+    e = codec.new_encoder(coder)
+    assert e.eos_padding == 0xFF and e.overflow_bits.num_bits == 0
+    e.overflow_bits.num_bits = 5
+    codec.encoder_reset(e)
+    assert e.overflow_bits.num_bits == 0
+    d = codec.new_decoder(coder)
+    assert not d.allow_growth and d.num_bits == 0 and d.working_bits == 0
+    codec.decoder_allow_growth(d, True)
+    d.num_bits, d.working_bits = 7, 1 << 63
+    codec.decoder_reset(d)
+    assert d.allow_growth and d.num_bits == 0 and d.working_bits == 0
+
+
+def test_table_coder_matches_the_reference_table(product_lib):
+    rows = harness.load_json("test_coder_table.json")["rows"]
+    tree = harness.load_json("test_coder_decode_tree.json")
+    patterns, lens = harness.load_table()
+    coder = product_lib.aws_huffman_amd_table_coder_new(patterns, lens)
+    enc = harness.ENCODE_FN(coder.contents.encode)
+    dec = harness.DECODE_FN(coder.contents.decode)
+    for r in rows:
+        code = enc(r["symbol"], coder.contents.userdata)
+        assert (code.pattern, code.num_bits) == (r["pattern"], r["num_bits"])
+    sym = C.c_uint8()
+    for leaf in tree["leaves"]:
+        p = leaf["prefix"]
+        for fill in (0, (1 << (32 - len(p))) - 1):
+            assert dec((int(p, 2) << (32 - len(p))) | fill, C.byref(sym), coder.contents.userdata) == leaf["num_bits"]
+            assert sym.value == leaf["symbol"]
+    for p in tree["dead_ends"]:
+        for fill in (0, (1 << (32 - len(p))) - 1):
+            assert dec((int(p, 2) << (32 - len(p))) | fill, C.byref(sym), coder.contents.userdata) == 0
+    # not a prefix code: rejected
+    bad = (C.c_uint8 * 256)(*lens)
+    bad_p = (C.c_uint32 * 256)(*patterns)
+    bad_p[1], bad[1] = bad_p[0] >> 1, bad[0] - 1  # a prefix of symbol 0's code
+    assert not product_lib.aws_huffman_amd_table_coder_new(bad_p, bad)
+
+
+def test_fails_loudly_without_a_gpu(product_lib):
+    if product_lib.aws_huffman_amd_device_count() > 0:
+        pytest.skip("a GPU is present")
+    patterns, lens = harness.load_table()
+    coder = product_lib.aws_huffman_amd_table_coder_new(patterns, lens)
+    h = C.c_void_p()
+    assert product_lib.aws_huffman_amd_engine_new(C.byref(h), coder, -1) == -1
+    assert product_lib.aws_last_error() == 6  # AWS_ERROR_UNSUPPORTED_OPERATION
+    codec = harness.Codec(product_lib, "aws_")
+    import numpy as np
+
+    src = np.frombuffer(b"abc", dtype=np.uint8)
+    dst = np.zeros(8, np.uint8)
+    r = codec.encode_call(codec.new_encoder(coder), src, 0, dst, 0, 8)
+    assert r.rc == -1 and r.err == 6 and r.consumed == 0 and r.produced == 0  # no silent CPU encode
