@@ -29,6 +29,7 @@ struct hufk_encode_args {
     uint64_t *seg_bitoff; /* [n_segs] scratch */
     struct hufd_enc_item_state *states; /* [n_items] scratch */
     struct hufd_enc_result *results;    /* [n_items] */
+    void **stage_events; /* NULL, or 4 hipEvent_t: before count, after count, after scan, after pack */
 };
 
 struct hufk_decode_args {
@@ -47,6 +48,7 @@ struct hufk_decode_args {
     uint64_t *chunk_base;  /* [n_chunks] scratch */
     struct hufd_dec_item_state *states; /* [n_items] scratch */
     struct hufd_dec_result *results;    /* [n_items] */
+    void **stage_events; /* NULL, or 4 hipEvent_t: before sync, after sync, after scan, after emit */
 };
 
 /* one-time per-process kernel attribute setup (dynamic LDS above 64 KiB) */

@@ -1243,16 +1243,24 @@ static uint32_t dec_emit_lds_bytes(const hufd_tables *tb) {
            HUFD_DEC_LANES * 8 + 16 + (2u << tb->lut_bits) + 16;
 }
 
+static void stage_mark(void **events, int index, hipStream_t st) {
+    if (events) {
+        (void)hipEventRecord((hipEvent_t)events[index], st);
+    }
+}
+
 int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a->n_segs == 0 && a->n_items == 0) {
         return 0;
     }
+    stage_mark(a->stage_events, 0, st);
     if (a->n_segs) {
         hipLaunchKernelGGL(
             enc_count_kernel, dim3(a->n_segs), dim3(HUFD_ENC_THREADS), 256 * 4 + 8 * 4, st, a->tables, a->items,
             a->seg_item, (const u8 *)a->d_in, a->seg_bits, a->seg_unk);
     }
+    stage_mark(a->stage_events, 1, st);
     hipLaunchKernelGGL(
         enc_scan_small_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, a->seg_bits,
         a->seg_unk, a->seg_bitoff, a->states, a->results);
@@ -1261,6 +1269,7 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
             enc_scan_large_kernel, dim3(a->n_large), dim3(HUFD_SCAN_LARGE_THREADS), 256, st, a->items, a->large_items,
             a->seg_bits, a->seg_unk, a->seg_bitoff, a->states, a->results);
     }
+    stage_mark(a->stage_events, 2, st);
     if (a->n_segs && !a->length_only) {
         const uint32_t img_words = hufk_enc_image_words(a->tables.max_bits);
         hipLaunchKernelGGL(
@@ -1268,6 +1277,7 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
             a->items, a->states, a->seg_item, a->seg_bits, a->seg_bitoff, (const u8 *)a->d_in, (u8 *)a->d_out,
             a->results, img_words);
     }
+    stage_mark(a->stage_events, 3, st);
     return (int)hipGetLastError();
 }
 
@@ -1277,11 +1287,13 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         return 0;
     }
     const uint32_t ns = a->tables.n_states;
+    stage_mark(a->stage_events, 0, st);
     if (a->n_chunks) {
         hipLaunchKernelGGL(
             dec_sync_kernel, dim3(a->n_chunks), dim3(HUFD_DEC_LANES), dec_sync_lds_bytes(&a->tables), st, a->tables,
             a->items, a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->chunk_fn);
     }
+    stage_mark(a->stage_events, 1, st);
     hipLaunchKernelGGL(
         dec_scan_small_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, ns, a->chunk_fn,
         a->chunk_entry, a->chunk_base, a->states, a->results);
@@ -1293,12 +1305,14 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             dec_scan_large_kernel, dim3(a->n_large), dim3(HUFD_SCAN_LARGE_THREADS), lds, st, a->items, a->large_items,
             ns, a->chunk_fn, a->chunk_entry, a->chunk_base, a->states, a->results);
     }
+    stage_mark(a->stage_events, 2, st);
     if (a->n_chunks) {
         hipLaunchKernelGGL(
             dec_emit_kernel, dim3(a->n_chunks), dim3(HUFD_DEC_LANES), dec_emit_lds_bytes(&a->tables), st, a->tables,
             a->items, a->chunk_item, (const u8 *)a->d_in, (u8 *)a->d_out, a->fn_tab, a->chunk_entry, a->chunk_base,
             a->results);
     }
+    stage_mark(a->stage_events, 3, st);
     return (int)hipGetLastError();
 }
 

@@ -344,6 +344,16 @@ int aws_huffman_amd_encode_plan_launch(
     void *device_output,
     bool length_only,
     void *stream) {
+    return aws_huffman_amd_encode_plan_launch_staged(p, device_input, device_output, length_only, stream, NULL);
+}
+
+int aws_huffman_amd_encode_plan_launch_staged(
+    struct aws_huffman_amd_encode_plan *p,
+    const void *device_input,
+    void *device_output,
+    bool length_only,
+    void *stream,
+    void **stage_events) {
 
     struct hufk_encode_args a;
     memset(&a, 0, sizeof(a));
@@ -362,6 +372,7 @@ int aws_huffman_amd_encode_plan_launch(
     a.seg_bitoff = p->d_seg_bitoff;
     a.states = p->d_states;
     a.results = p->d_results;
+    a.stage_events = stage_events;
     hufs_set_device(p->engine->device);
     const int err = hufk_encode_launch(&a, stream ? stream : p->engine->stream);
     return err ? raise_hip(err) : AWS_OP_SUCCESS;
@@ -595,6 +606,15 @@ int aws_huffman_amd_decode_plan_launch(
     const void *device_input,
     void *device_output,
     void *stream) {
+    return aws_huffman_amd_decode_plan_launch_staged(p, device_input, device_output, stream, NULL);
+}
+
+int aws_huffman_amd_decode_plan_launch_staged(
+    struct aws_huffman_amd_decode_plan *p,
+    const void *device_input,
+    void *device_output,
+    void *stream,
+    void **stage_events) {
 
     struct hufk_decode_args a;
     memset(&a, 0, sizeof(a));
@@ -613,6 +633,7 @@ int aws_huffman_amd_decode_plan_launch(
     a.chunk_base = p->d_chunk_base;
     a.states = p->d_states;
     a.results = p->d_results;
+    a.stage_events = stage_events;
     hufs_set_device(p->engine->device);
     const int err = hufk_decode_launch(&a, stream ? stream : p->engine->stream);
     return err ? raise_hip(err) : AWS_OP_SUCCESS;

@@ -117,6 +117,20 @@ int aws_huffman_amd_encode_plan_launch(
     bool length_only,
     void *stream);
 
+/*
+ * Same launch with HIP events recorded between its kernels, for per-kernel timing on the
+ * stream the kernels run on.  stage_events: 4 events from aws_huffman_amd_event_new --
+ * [0] before the length count, [1] after it, [2] after the offset scan, [3] after the pack.
+ */
+AWS_COMPRESSION_API
+int aws_huffman_amd_encode_plan_launch_staged(
+    struct aws_huffman_amd_encode_plan *plan,
+    const void *device_input,
+    void *device_output,
+    bool length_only,
+    void *stream,
+    void **stage_events);
+
 /* Waits for the last launch and copies the per-item results to the host. */
 AWS_COMPRESSION_API
 int aws_huffman_amd_encode_plan_results(
@@ -142,6 +156,15 @@ int aws_huffman_amd_decode_plan_launch(
     const void *device_input,
     void *device_output,
     void *stream);
+
+/* stage_events: [0] before the sync kernel, [1] after it, [2] after the entry scan, [3] after the emit */
+AWS_COMPRESSION_API
+int aws_huffman_amd_decode_plan_launch_staged(
+    struct aws_huffman_amd_decode_plan *plan,
+    const void *device_input,
+    void *device_output,
+    void *stream,
+    void **stage_events);
 
 AWS_COMPRESSION_API
 int aws_huffman_amd_decode_plan_results(

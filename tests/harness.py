@@ -168,8 +168,10 @@ EXPORTED_SYMBOLS = [
     # include/aws/compression/huffman_amd.h
     "aws_huffman_amd_engine_new", "aws_huffman_amd_engine_destroy", "aws_huffman_amd_engine_max_code_bits",
     "aws_huffman_amd_engine_can_decode", "aws_huffman_amd_encode_plan_new", "aws_huffman_amd_encode_plan_destroy",
-    "aws_huffman_amd_encode_plan_launch", "aws_huffman_amd_encode_plan_results", "aws_huffman_amd_decode_plan_new",
-    "aws_huffman_amd_decode_plan_destroy", "aws_huffman_amd_decode_plan_launch", "aws_huffman_amd_decode_plan_results",
+    "aws_huffman_amd_encode_plan_launch", "aws_huffman_amd_encode_plan_launch_staged",
+    "aws_huffman_amd_encode_plan_results", "aws_huffman_amd_decode_plan_new", "aws_huffman_amd_decode_plan_destroy",
+    "aws_huffman_amd_decode_plan_launch", "aws_huffman_amd_decode_plan_launch_staged",
+    "aws_huffman_amd_decode_plan_results",
     "aws_huffman_amd_device_count", "aws_huffman_amd_device_alloc", "aws_huffman_amd_device_free",
     "aws_huffman_amd_copy_to_device", "aws_huffman_amd_copy_to_host", "aws_huffman_amd_device_fill",
     "aws_huffman_amd_device_fill_splitmix64", "aws_huffman_amd_engine_stream", "aws_huffman_amd_stream_synchronize",
@@ -200,6 +202,8 @@ def load_product(path=None):
     _bind(lib, "aws_huffman_amd_encode_plan_new", C.c_int, [P(V), V, P(AmdEncodeItem), C.c_size_t])
     _bind(lib, "aws_huffman_amd_encode_plan_destroy", None, [V])
     _bind(lib, "aws_huffman_amd_encode_plan_launch", C.c_int, [V, V, V, C.c_bool, V])
+    _bind(lib, "aws_huffman_amd_encode_plan_launch_staged", C.c_int, [V, V, V, C.c_bool, V, P(V)])
+    _bind(lib, "aws_huffman_amd_decode_plan_launch_staged", C.c_int, [V, V, V, V, P(V)])
     _bind(lib, "aws_huffman_amd_encode_plan_results", C.c_int, [V, P(AmdEncodeResult), V])
     _bind(lib, "aws_huffman_amd_decode_plan_new", C.c_int, [P(V), V, P(AmdDecodeItem), C.c_size_t])
     _bind(lib, "aws_huffman_amd_decode_plan_destroy", None, [V])
@@ -277,8 +281,23 @@ class Engine:
             raise RuntimeError("encode_plan_new failed, error %d" % self.lib.aws_last_error())
         return plan
 
-    def encode_launch(self, plan, d_in, d_out, length_only=False):
-        assert self.lib.aws_huffman_amd_encode_plan_launch(plan, d_in, d_out, length_only, None) == 0
+    def encode_launch(self, plan, d_in, d_out, length_only=False, events=None):
+        assert self.lib.aws_huffman_amd_encode_plan_launch_staged(plan, d_in, d_out, length_only, None, events) == 0
+
+    def new_events(self, n):
+        arr = (C.c_void_p * n)()
+        for i in range(n):
+            arr[i] = self.lib.aws_huffman_amd_event_new(self.h)
+            assert arr[i]
+        return arr
+
+    def record(self, event):
+        assert self.lib.aws_huffman_amd_event_record(self.h, event, None) == 0
+
+    def elapsed_ms(self, start, stop):
+        ms = C.c_float()
+        assert self.lib.aws_huffman_amd_event_elapsed_ms(self.h, start, stop, C.byref(ms)) == 0
+        return ms.value
 
     def encode_results(self, plan, n):
         res = (AmdEncodeResult * max(n, 1))()
@@ -297,8 +316,8 @@ class Engine:
             raise RuntimeError("decode_plan_new failed, error %d" % self.lib.aws_last_error())
         return plan
 
-    def decode_launch(self, plan, d_in, d_out):
-        assert self.lib.aws_huffman_amd_decode_plan_launch(plan, d_in, d_out, None) == 0
+    def decode_launch(self, plan, d_in, d_out, events=None):
+        assert self.lib.aws_huffman_amd_decode_plan_launch_staged(plan, d_in, d_out, None, events) == 0
 
     def decode_results(self, plan, n):
         res = (AmdDecodeResult * max(n, 1))()
