@@ -26,7 +26,7 @@
 #define HUFD_DEC_CHUNK_BYTES (HUFD_DEC_SUB_BYTES * HUFD_DEC_LANES)
 #define HUFD_DEC_MAX_STATES 16u
 #define HUFD_DEC_MAX_LUT_BITS 12u
-#define HUFD_DEC_STAGE_BYTES 40960u /* LDS bytes for a chunk's decoded symbols */
+#define HUFD_DEC_STAGE_BYTES 36864u /* LDS bytes for a chunk's decoded symbols (two workgroups per CU) */
 
 #define HUFD_SCAN_SMALL_MAX 64u /* items with at most this many segments/chunks are scanned by one thread */
 #define HUFD_SCAN_LARGE_THREADS 1024u
@@ -64,6 +64,17 @@ struct hufd_enc_item {
     uint32_t eos_padding;
     uint32_t first_seg; /* index of the item's first segment in the plan's segment numbering */
     uint32_t n_segs;
+    uint32_t reserved;
+};
+
+/* one per segment, built with the plan: where the segment's symbols are, without pointer chasing */
+struct hufd_enc_seg {
+    uint64_t in_off;   /* bytes from the input base pointer to the segment's first symbol */
+    uint32_t len;      /* symbols in the segment (0 .. HUFD_ENC_SEG_BYTES) */
+    uint32_t item;     /* index of the owning item */
+    uint32_t index;    /* segment number inside the item */
+    uint32_t flags;    /* bit 0: first segment of the item, bit 1: last */
+    uint32_t next_len; /* symbols in the item's next segment (0 when this is the last) */
     uint32_t reserved;
 };
 

@@ -17,7 +17,7 @@ struct hufk_encode_args {
     struct hufd_tables tables;
     const struct hufd_enc_item *items;
     uint32_t n_items;
-    const uint32_t *seg_item; /* [n_segs] item index of every segment */
+    const struct hufd_enc_seg *segs; /* [n_segs] */
     uint32_t n_segs;
     const uint32_t *large_items; /* [n_large] items with more than HUFD_SCAN_SMALL_MAX segments */
     uint32_t n_large;
@@ -27,6 +27,8 @@ struct hufk_encode_args {
     uint32_t *seg_bits;   /* [n_segs] scratch */
     uint32_t *seg_unk;    /* [n_segs] scratch */
     uint64_t *seg_bitoff; /* [n_segs] scratch */
+    uint32_t *careful_list;  /* [2 * n_items] scratch: segments for the per-symbol packer */
+    uint32_t *careful_count; /* [1] scratch */
     struct hufd_enc_item_state *states; /* [n_items] scratch */
     struct hufd_enc_result *results;    /* [n_items] */
     void **stage_events; /* NULL, or 4 hipEvent_t: before count, after count, after scan, after pack */

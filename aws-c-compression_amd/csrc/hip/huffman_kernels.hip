@@ -38,6 +38,26 @@ constexpr u64 kNoBit = ~0ull;
 
 HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, dyn_lds)
 
+/*
+ * Diagnostic build only (-DHUFD_STAMPS, profiles/tools/stamps.py): wave 0 of every
+ * workgroup adds the shader clock at phase boundaries into a table of its own; differences
+ * of the sums / workgroups = average phase length.  Never compiled into the product.
+ */
+#ifdef HUFD_STAMPS
+/* one private row of 8 clocks per workgroup and kernel: plain stores, no contention */
+__device__ unsigned long long *hufd_stamp_rows; /* [3][HUFD_STAMP_MAX_WG][8], set by hufk_stamps_attach */
+#define HUFD_STAMP_MAX_WG 131072u
+#define HUFD_STAMP(kernel, phase)                                                                                      \
+    do {                                                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x < HUFD_STAMP_MAX_WG) {                                                      \
+            hufd_stamp_rows[((u64)(kernel)*HUFD_STAMP_MAX_WG + blockIdx.x) * 8 + (phase)] =                            \
+                (unsigned long long)clock64();                                                                         \
+        }                                                                                                              \
+    } while (0)
+#else
+#define HUFD_STAMP(kernel, phase)
+#endif
+
 __device__ __forceinline__ u32 round16(u32 x) {
     return (x + 15u) & ~15u;
 }
@@ -160,14 +180,26 @@ __device__ __forceinline__ void image_store(const u32 *img, u8 *gbase, u32 lo, u
         for (u32 b = lo + threadIdx.x; b < row_lo * 16; b += THREADS) {
             gbase[b] = (u8)(img[b >> 2] >> (24 - 8 * (b & 3)));
         }
-        for (u32 r = row_lo + threadIdx.x; r < row_hi; r += THREADS) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(&img[r * 4]);
-            uint4 o;
-            o.x = __builtin_bswap32(v.x);
-            o.y = __builtin_bswap32(v.y);
-            o.z = __builtin_bswap32(v.z);
-            o.w = __builtin_bswap32(v.w);
-            *reinterpret_cast<uint4 *>(gbase + (u64)r * 16) = o;
+        /* four rows per thread in flight: the LDS reads are issued together, then the stores */
+        for (u32 r = row_lo + threadIdx.x; r < row_hi; r += 4 * THREADS) {
+            uint4 v[4];
+#pragma unroll
+            for (u32 u = 0; u < 4; ++u) {
+                const u32 ru = r + u * THREADS;
+                v[u] = *reinterpret_cast<const uint4 *>(&img[(ru < row_hi ? ru : r) * 4]);
+            }
+#pragma unroll
+            for (u32 u = 0; u < 4; ++u) {
+                const u32 ru = r + u * THREADS;
+                if (ru < row_hi) {
+                    uint4 o;
+                    o.x = __builtin_bswap32(v[u].x);
+                    o.y = __builtin_bswap32(v[u].y);
+                    o.z = __builtin_bswap32(v[u].z);
+                    o.w = __builtin_bswap32(v[u].w);
+                    *reinterpret_cast<uint4 *>(gbase + (u64)ru * 16) = o;
+                }
+            }
         }
         for (u32 b = row_hi * 16 + threadIdx.x; b < hi; b += THREADS) {
             gbase[b] = (u8)(img[b >> 2] >> (24 - 8 * (b & 3)));
@@ -181,42 +213,55 @@ __device__ __forceinline__ void image_store(const u32 *img, u8 *gbase, u32 lo, u
 
 /* ------------------------------------------------------------------ encode: count */
 
+constexpr u32 kGroupsPerLane = HUFD_ENC_SEG_BYTES / (HUFD_ENC_THREADS * 16); /* 16-byte groups a lane owns per segment */
+
+/* The lane's 16-byte groups of a segment, all requested before any of them is used. */
+__device__ __forceinline__ void load_segment_groups(
+    const u8 *src, u32 seg_len, u32 (&gw)[kGroupsPerLane][4], u32 (&gvalid)[kGroupsPerLane]) {
+    const bool aligned = ((uintptr_t)src & 15u) == 0;
+#pragma unroll
+    for (u32 g = 0; g < kGroupsPerLane; ++g) {
+        const u32 base = (g * HUFD_ENC_THREADS + threadIdx.x) * 16;
+        gvalid[g] = base < seg_len ? (seg_len - base < 16 ? seg_len - base : 16) : 0;
+        gw[g][0] = gw[g][1] = gw[g][2] = gw[g][3] = 0;
+        if (gvalid[g]) {
+            load_group(src + base, gvalid[g], aligned, gw[g]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_count_kernel(
     hufd_tables tb,
-    const hufd_enc_item *items,
-    const u32 *seg_item,
+    const hufd_enc_seg *segs,
     const u8 *d_in,
     u32 *seg_bits,
-    u32 *seg_unk) {
+    u32 *seg_unk,
+    u32 *careful_count) {
 
     u32 *len_tab = reinterpret_cast<u32 *>(dyn_lds); /* [256] */
     u32 *slots = len_tab + 256;                       /* [8] */
 
     const u32 tid = threadIdx.x;
+    const u32 s = blockIdx.x;
+    if (s == 0 && tid == 0) {
+        *careful_count = 0; /* the scan kernels of this launch append to the list */
+    }
+    const hufd_enc_seg seg = segs[s];
+    u32 gw[kGroupsPerLane][4], gvalid[kGroupsPerLane];
+    load_segment_groups(d_in + seg.in_off, seg.len, gw, gvalid);
     len_tab[tid] = (u32)(tb.enc_table[tid] >> 32);
     __syncthreads();
 
-    const u32 s = blockIdx.x;
-    const hufd_enc_item it = items[seg_item[s]];
-    const u64 seg_off = (u64)(s - it.first_seg) * HUFD_ENC_SEG_BYTES;
-    const u32 seg_len = it.in_len > seg_off
-                            ? (u32)(it.in_len - seg_off < HUFD_ENC_SEG_BYTES ? it.in_len - seg_off : HUFD_ENC_SEG_BYTES)
-                            : 0u;
-    const u8 *src = d_in + it.in_off + seg_off;
-    const bool aligned = ((uintptr_t)src & 15u) == 0;
-
     u32 bits = 0, unk = HUFD_NONE32;
-    for (u32 base = tid * 16; base < seg_len; base += HUFD_ENC_THREADS * 16) {
-        const u32 valid = seg_len - base < 16 ? seg_len - base : 16;
-        u32 w[4];
-        load_group(src + base, valid, aligned, w);
+#pragma unroll
+    for (u32 g = 0; g < kGroupsPerLane; ++g) {
 #pragma unroll
         for (u32 j = 0; j < 16; ++j) {
-            if (j < valid) {
-                const u32 len = len_tab[group_byte(w, j)];
+            if (j < gvalid[g]) {
+                const u32 len = len_tab[group_byte(gw[g], j)];
                 bits += len;
                 if (len == 0 && unk == HUFD_NONE32) {
-                    unk = base + j;
+                    unk = (g * HUFD_ENC_THREADS + tid) * 16 + j;
                 }
             }
         }
@@ -255,6 +300,9 @@ __device__ void enc_finish_item(
     u32 unk_idx,
     u64 unk_seg_bitoff,
     u32 unk_seg_bits,
+    u32 edge_seg, /* segment with offset < capacity edge <= offset + bits, or HUFD_NONE32 */
+    u32 *careful_list,
+    u32 *careful_count,
     hufd_enc_item_state *state,
     hufd_enc_result *result) {
 
@@ -304,6 +352,14 @@ __device__ void enc_finish_item(
         }
         /* otherwise the lane that packs the crossing symbol fills consumed / overflow */
     }
+    /* the segments that need the per-symbol packer */
+    const bool want_short = st.status == HUFD_ENC_SHORT || st.status == HUFD_ENC_DECIDE;
+    if (want_short && edge_seg != HUFD_NONE32 && (st.unk_seg == HUFD_NONE32 || edge_seg <= st.unk_seg)) {
+        careful_list[atomicAdd(careful_count, 1u)] = edge_seg;
+    }
+    if (st.unk_seg != HUFD_NONE32 && !(want_short && edge_seg == st.unk_seg)) {
+        careful_list[atomicAdd(careful_count, 1u)] = st.unk_seg;
+    }
     *state = st;
     *result = rs;
 }
@@ -315,6 +371,8 @@ __global__ __launch_bounds__(256) void enc_scan_small_kernel(
     const u32 *seg_bits,
     const u32 *seg_unk,
     u64 *seg_bitoff,
+    u32 *careful_list,
+    u32 *careful_count,
     hufd_enc_item_state *states,
     hufd_enc_result *results) {
 
@@ -326,13 +384,17 @@ __global__ __launch_bounds__(256) void enc_scan_small_kernel(
     if (it.n_segs > HUFD_SCAN_SMALL_MAX) {
         return;
     }
+    const u64 cap_bits = it.out_cap > (~0ull >> 3) ? ~0ull : it.out_cap * 8;
     u64 at = it.ovf_bits;
-    u32 unk_seg = HUFD_NONE32, unk_idx = 0, unk_bits = 0;
+    u32 unk_seg = HUFD_NONE32, unk_idx = 0, unk_bits = 0, edge_seg = HUFD_NONE32;
     u64 unk_off = 0;
     for (u32 k = 0; k < it.n_segs; ++k) {
         const u32 s = it.first_seg + k;
         const u32 b = seg_bits[s];
         seg_bitoff[s] = at;
+        if (at < cap_bits && cap_bits <= at + b) {
+            edge_seg = s;
+        }
         if (unk_seg == HUFD_NONE32 && seg_unk[s] != HUFD_NONE32) {
             unk_seg = s;
             unk_idx = seg_unk[s];
@@ -341,62 +403,96 @@ __global__ __launch_bounds__(256) void enc_scan_small_kernel(
         }
         at += b;
     }
-    enc_finish_item(it, at, unk_seg, unk_idx, unk_off, unk_bits, &states[i], &results[i]);
+    enc_finish_item(
+        it, at, unk_seg, unk_idx, unk_off, unk_bits, edge_seg, careful_list, careful_count, &states[i], &results[i]);
 }
 
-/* one workgroup per item with many segments */
+/*
+ * One workgroup per item with many segments.  Each wave owns a contiguous range of the
+ * item's segments and reads it 64 at a time (coalesced): first pass sums the range, the 16
+ * range sums are scanned, second pass scans inside the range with a running carry.
+ */
 __global__ __launch_bounds__(HUFD_SCAN_LARGE_THREADS) void enc_scan_large_kernel(
     const hufd_enc_item *items,
     const u32 *large_items,
     const u32 *seg_bits,
     const u32 *seg_unk,
     u64 *seg_bitoff,
+    u32 *careful_list,
+    u32 *careful_count,
     hufd_enc_item_state *states,
     hufd_enc_result *results) {
 
-    u32 *slots = reinterpret_cast<u32 *>(dyn_lds);                 /* [16] wave totals */
-    u32 *first_unk = slots + 16;                                    /* [1] lowest segment with a bad symbol */
-    u64 *unk_off = reinterpret_cast<u64 *>(dyn_lds + 128);         /* [1] */
+    constexpr u32 T = HUFD_SCAN_LARGE_THREADS, W = T / kWave;
+    u64 *wave_tot = reinterpret_cast<u64 *>(dyn_lds);      /* [W] */
+    u64 *unk_off = wave_tot + W;                            /* [1] */
+    u32 *first_unk = reinterpret_cast<u32 *>(unk_off + 1);  /* [1] lowest segment with a bad symbol */
+    u32 *edge_seg = first_unk + 1;                          /* [1] segment holding the capacity edge */
 
     const u32 i = large_items[blockIdx.x];
     const hufd_enc_item it = items[i];
-    const u32 tid = threadIdx.x;
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     if (tid == 0) {
         *first_unk = HUFD_NONE32;
         *unk_off = 0;
+        *edge_seg = HUFD_NONE32;
+    }
+    const u64 cap_bits = it.out_cap > (~0ull >> 3) ? ~0ull : it.out_cap * 8;
+    /* ranges are multiples of 64 segments so that every read is a full coalesced row */
+    const u32 per = ((it.n_segs + W - 1) / W + kWave - 1) / kWave * kWave;
+    const u32 lo = wave * per < it.n_segs ? wave * per : it.n_segs;
+    const u32 hi = lo + per < it.n_segs ? lo + per : it.n_segs;
+
+    u64 mine = 0;
+    u32 my_unk = HUFD_NONE32;
+    for (u32 k = lo + lane; k < hi; k += kWave) {
+        mine += seg_bits[it.first_seg + k];
+        if (my_unk == HUFD_NONE32 && seg_unk[it.first_seg + k] != HUFD_NONE32) {
+            my_unk = it.first_seg + k;
+        }
+    }
+#pragma unroll
+    for (u32 d = kWave / 2; d > 0; d >>= 1) {
+        mine += __shfl_xor(mine, d);
+    }
+    my_unk = wave_min(my_unk);
+    if (lane == 0) {
+        wave_tot[wave] = mine;
     }
     __syncthreads();
-
-    u64 carry = it.ovf_bits;
-    for (u32 base = 0; base < it.n_segs; base += HUFD_SCAN_LARGE_THREADS) {
-        const u32 k = base + tid;
-        const bool live = k < it.n_segs;
-        const u32 b = live ? seg_bits[it.first_seg + k] : 0;
-        u32 total;
-        const u32 excl = block_exclusive_sum<HUFD_SCAN_LARGE_THREADS>(b, slots, total);
-        if (live) {
-            seg_bitoff[it.first_seg + k] = carry + excl;
-            if (seg_unk[it.first_seg + k] != HUFD_NONE32) {
-                atomicMin(first_unk, it.first_seg + k);
-            }
-        }
-        carry += total;
+    if (lane == 0 && my_unk != HUFD_NONE32) {
+        atomicMin(first_unk, my_unk);
+    }
+    u64 carry = it.ovf_bits, total = it.ovf_bits;
+    for (u32 w = 0; w < W; ++w) {
+        const u64 t = wave_tot[w];
+        carry += w < wave ? t : 0;
+        total += t;
     }
     __syncthreads();
     const u32 us = *first_unk;
-    if (us != HUFD_NONE32) {
-        /* the owner of that segment republishes its offset */
-        for (u32 base = 0; base < it.n_segs; base += HUFD_SCAN_LARGE_THREADS) {
-            if (it.first_seg + base + tid == us) {
-                *unk_off = seg_bitoff[us];
+    for (u32 base = lo; base < hi; base += kWave) {
+        const u32 k = base + lane;
+        const u32 b = k < hi ? seg_bits[it.first_seg + k] : 0;
+        const u32 incl = wave_inclusive_sum(b, lane);
+        if (k < hi) {
+            const u64 at = carry + incl - b;
+            seg_bitoff[it.first_seg + k] = at;
+            if (it.first_seg + k == us) {
+                *unk_off = at;
+            }
+            if (at < cap_bits && cap_bits <= at + b) {
+                *edge_seg = it.first_seg + k;
             }
         }
+        carry += __shfl(incl, kWave - 1);
     }
     __syncthreads();
     if (tid == 0) {
         const u32 ui = us != HUFD_NONE32 ? seg_unk[us] : 0;
         const u32 ub = us != HUFD_NONE32 ? seg_bits[us] : 0;
-        enc_finish_item(it, carry, us, ui, *unk_off, ub, &states[i], &results[i]);
+        enc_finish_item(
+            it, total, us, ui, *unk_off, ub, *edge_seg, careful_list, careful_count, &states[i], &results[i]);
     }
 }
 
@@ -411,209 +507,191 @@ struct enc_pack_shared {
     u32 halo_unknown;
 };
 
-__global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_pack_kernel(
-    hufd_tables tb,
-    const hufd_enc_item *items,
-    const hufd_enc_item_state *states,
-    const u32 *seg_item,
-    const u32 *seg_bits,
-    const u64 *seg_bitoff,
-    const u8 *d_in,
-    u8 *d_out,
-    hufd_enc_result *results,
-    u32 img_words) {
+/*
+ * Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also
+ * drains the vector-memory counter, which would stall on an LDS-DMA prefetch or on the
+ * copy-out stores that are meant to stay in flight (guide: "Pipelining across barriers").
+ */
+__device__ __forceinline__ void barrier_lds() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
 
-    u32 *img = reinterpret_cast<u32 *>(dyn_lds);
-    u64 *tab = reinterpret_cast<u64 *>(dyn_lds + round16(img_words * 4));
-    u32 *slots = reinterpret_cast<u32 *>(tab + 256);
-    enc_pack_shared *sh = reinterpret_cast<enc_pack_shared *>(slots + 8);
+/* 16 bytes global -> LDS without a register in between (global_load_lds_dwordx4) */
+__device__ __forceinline__ void lds_dma16(const void *global_src, void *lds_dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)global_src, (__attribute__((address_space(3))) void *)lds_dst,
+        16, 0, 0);
+#else
+    memcpy(lds_dst, global_src, 16);
+#endif
+}
 
-    const u32 tid = threadIdx.x;
-    const u32 s = blockIdx.x;
-    const u32 item_index = seg_item[s];
-    const hufd_enc_item it = items[item_index];
-    const hufd_enc_item_state st = states[item_index];
-    if (st.unk_seg != HUFD_NONE32 && s > st.unk_seg) {
-        return; /* past the bad symbol: the reference never gets here */
+/* OR `len` (0..64) right-aligned bits of `value` into the image at bit q: at most three words. */
+__device__ __forceinline__ void image_or_quad(u32 *img, u32 q, u64 value, u32 len) {
+    const u64 left = len ? value << (64 - len) : 0;
+    const u32 sh = q & 31, w = q >> 5;
+    const u32 w0 = (u32)(left >> (32 + sh));
+    const u32 w1 = (u32)(left >> sh);
+    const u32 w2 = (u32)(left << (32 - sh));
+    if (w0) {
+        atomicOr(&img[w], w0);
     }
+    if (w1) {
+        atomicOr(&img[w + 1], w1);
+    }
+    if (w2) {
+        atomicOr(&img[w + 2], w2);
+    }
+}
 
-    const u32 k = s - it.first_seg;
-    const u64 seg_off = (u64)k * HUFD_ENC_SEG_BYTES;
-    const u32 seg_len = it.in_len > seg_off
-                            ? (u32)(it.in_len - seg_off < HUFD_ENC_SEG_BYTES ? it.in_len - seg_off : HUFD_ENC_SEG_BYTES)
-                            : 0u;
-    const bool last_seg = k + 1 == it.n_segs;
-    const u8 *src = d_in + it.in_off + seg_off;
-    const bool aligned = ((uintptr_t)src & 15u) == 0;
+/* where a segment's bits go: shared by the two pack kernels */
+struct pack_geometry {
+    u64 p0;       /* stream bit of the segment's first code */
+    u64 pend;     /* stream bit after its last code */
+    u64 pa;       /* stream bit where the workgroup's image starts (0 for the item's first segment) */
+    u64 cap_bits; /* the item's capacity in bits */
+    u64 j0;       /* stream byte of image byte `mis` */
+    u8 *gbase;    /* output address of image byte 0, 16-byte aligned */
+    u32 mis;
+    u32 q0;       /* image bit of stream bit p0 */
+    u32 cap_rel;  /* capacity edge relative to p0; 0 disables the crossing test */
+    bool last_seg, want_short, is_unk_seg, careful, skip;
+};
 
-    const u64 p0 = seg_bitoff[s];          /* stream bit of this segment's first code */
-    const u64 pa = k == 0 ? 0 : p0;        /* stream bit where this workgroup's image starts */
-    const u64 pend = p0 + seg_bits[s];
-    const u64 cap_bits = it.out_cap > (~0ull >> 3) ? ~0ull : it.out_cap * 8;
-
+__device__ __forceinline__ pack_geometry pack_geometry_of(
+    const hufd_tables &tb,
+    const hufd_enc_seg seg,
+    u32 s,
+    const hufd_enc_item &it,
+    const hufd_enc_item_state &st,
+    u64 p0,
+    u32 bits,
+    u8 *d_out) {
+    pack_geometry g;
+    g.p0 = p0;
+    g.pend = p0 + bits;
+    g.pa = seg.index == 0 ? 0 : p0;
+    g.cap_bits = it.out_cap > (~0ull >> 3) ? ~0ull : it.out_cap * 8;
     /* image byte 0 sits on a 16-byte boundary of the output */
     u8 *out_ptr = d_out + it.out_off;
-    const u64 j0 = pa >> 3;
-    const u32 mis = (u32)((uintptr_t)(out_ptr + j0) & 15u);
-    u8 *gbase = out_ptr + j0 - mis;
-    const u32 q0 = (u32)(p0 - 8 * j0) + 8 * mis; /* image bit of stream bit p0 */
-
-    for (u32 i = tid; i < img_words; i += HUFD_ENC_THREADS) {
-        img[i] = 0;
+    g.j0 = g.pa >> 3;
+    g.mis = (u32)((uintptr_t)(out_ptr + g.j0) & 15u);
+    g.gbase = out_ptr + g.j0 - g.mis;
+    g.q0 = (u32)(p0 - 8 * g.j0) + 8 * g.mis;
+    g.last_seg = (seg.flags & 2u) != 0;
+    g.want_short = st.status == HUFD_ENC_SHORT || st.status == HUFD_ENC_DECIDE;
+    g.cap_rel = 0;
+    if (g.want_short && g.cap_bits > p0) {
+        g.cap_rel = g.cap_bits - p0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)(g.cap_bits - p0);
     }
-    tab[tid] = tb.enc_table[tid];
-    if (tid == 0) {
-        sh->unk_before = kNoBit;
-        sh->short_found = 0;
-        sh->halo_unknown = 0;
-    }
-    __syncthreads();
+    g.is_unk_seg = s == st.unk_seg;
+    /*
+     * Only the segment that holds the capacity edge or the first symbol without a code needs
+     * to look at symbols one by one; every other segment takes the branch-free path (codes of
+     * at most 16 bits: four of them always fit a 64-bit register).
+     */
+    const bool edge_here = g.want_short && g.cap_bits > p0 && g.cap_bits <= g.pend;
+    g.careful = tb.max_bits > 16 || edge_here || g.is_unk_seg;
+    /* past the item's first symbol without a code the reference never gets */
+    g.skip = st.unk_seg != HUFD_NONE32 && s > st.unk_seg;
+    return g;
+}
 
-    if (tid == 0 && k == 0 && it.ovf_bits) {
-        image_or_bits(img, 8 * mis, it.ovf_pattern, it.ovf_bits);
-    }
-
-    const bool want_short = st.status == HUFD_ENC_SHORT || st.status == HUFD_ENC_DECIDE;
-    /* capacity edge relative to p0; 0 disables the crossing test for this segment */
-    u32 cap_rel = 0;
-    if (want_short && cap_bits > p0) {
-        cap_rel = cap_bits - p0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)(cap_bits - p0);
-    }
-    const bool is_unk_seg = s == st.unk_seg;
-
-    u32 carry = 0; /* bits of this segment already placed */
-    for (u32 iter = 0; iter < HUFD_ENC_SEG_BYTES / (HUFD_ENC_THREADS * 16); ++iter) {
-        const u32 base = (iter * HUFD_ENC_THREADS + tid) * 16;
-        const u32 valid = base < seg_len ? (seg_len - base < 16 ? seg_len - base : 16) : 0;
-        u32 w[4] = {0, 0, 0, 0};
-        if (valid) {
-            load_group(src + base, valid, aligned, w);
-        }
-        u64 e[16];
-        u32 lane_bits = 0;
-#pragma unroll
-        for (u32 j = 0; j < 16; ++j) {
-            e[j] = j < valid ? tab[group_byte(w, j)] : 0;
-            lane_bits += (u32)(e[j] >> 32);
-        }
-        u32 total;
-        u32 rel = carry + block_exclusive_sum<HUFD_ENC_THREADS>(lane_bits, slots, total);
-        carry += total;
-
-        /* the lane's codes go out as whole words; its first and last word are shared
-         * with neighbours, so every word is OR-ed into the zeroed image */
-        u32 q = q0 + rel;
-        u32 wi = q >> 5, nb = q & 31;
-        u64 acc = 0;
-#pragma unroll
-        for (u32 j = 0; j < 16; ++j) {
-            const u32 len = (u32)(e[j] >> 32);
-            const u32 pat = (u32)e[j];
-            if (j < valid) {
-                if (len == 0) {
-                    if (is_unk_seg && base + j == st.unk_idx) {
-                        sh->unk_before = p0 + rel;
-                    }
-                } else {
-                    const u32 after = rel + len;
-                    if (rel < cap_rel && after >= cap_rel) {
-                        /* first symbol whose last bit reaches the capacity edge (huffman.c:88-98) */
-                        sh->short_found = 1;
-                        sh->short_consumed = seg_off + base + j + 1;
-                        sh->short_ovf_bits = after - cap_rel;
-                        sh->short_ovf_pattern = pat & (u32)((1ull << (after - cap_rel)) - 1);
-                    }
-                    acc = (acc << len) | pat;
-                    nb += len;
-                    rel = after;
-                    if (nb >= 32) {
-                        atomicOr(&img[wi], (u32)(acc >> (nb - 32)));
-                        ++wi;
-                        nb -= 32;
-                        acc &= (1ull << nb) - 1;
-                    }
-                }
+/*
+ * Completes the last byte the workgroup owns: with the head of the next segment's codes
+ * (fetched with the segment: `halo` holds its first eight symbols), or with the padding
+ * when the item ends here (huffman.c:178-184).  One lane; table work only.
+ */
+template <typename Lookup>
+__device__ __forceinline__ void pack_last_byte(
+    u32 *img,
+    enc_pack_shared *sh,
+    const pack_geometry &g,
+    const hufd_enc_seg seg,
+    const hufd_enc_item &it,
+    const hufd_enc_item_state &st,
+    const u32 (&halo)[2],
+    Lookup lookup /* symbol -> length << 32 | code */) {
+    u32 need = (u32)((8 - (g.pend & 7)) & 7);
+    u32 q = g.q0 + (u32)(g.pend - g.p0);
+    if (need && !g.last_seg) {
+        const u32 n = seg.next_len < 8 ? seg.next_len : 8;
+        for (u32 j = 0; j < n && need; ++j) {
+            const u64 ent = lookup((halo[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+            const u32 len = (u32)(ent >> 32);
+            if (len == 0) {
+                sh->halo_unknown = 1;
+                break;
             }
-        }
-        if (nb) {
-            const u32 tail = (u32)(acc << (32 - nb));
-            if (tail) {
-                atomicOr(&img[wi], tail);
-            }
+            image_or_bits(img, q, (u32)ent, len);
+            q += len;
+            need = len >= need ? 0 : need - len;
         }
     }
-    __syncthreads();
-
-    /* Complete the last byte this workgroup owns: with the head of the next segment's
-     * codes, or with the padding when the item ends here (huffman.c:178-184). */
-    if (tid == 0) {
-        u32 need = (u32)((8 - (pend & 7)) & 7);
-        u32 q = q0 + (u32)(pend - p0);
-        if (need && !last_seg) {
-            const u64 next_off = seg_off + HUFD_ENC_SEG_BYTES;
-            const u64 next_len = it.in_len > next_off ? it.in_len - next_off : 0;
-            const u8 *nxt = d_in + it.in_off + next_off;
-            for (u32 j = 0; j < 8 && j < next_len && need; ++j) {
-                const u64 ent = tab[nxt[j]];
-                const u32 len = (u32)(ent >> 32);
-                if (len == 0) {
-                    sh->halo_unknown = 1;
-                    break;
-                }
-                image_or_bits(img, q, (u32)ent, len);
-                q += len;
-                need = len >= need ? 0 : need - len;
-            }
-        }
-        if (need && !sh->halo_unknown && st.status == HUFD_ENC_OK) {
-            /* only reachable when the item's remaining symbols ran out: pad */
-            const u32 pad_bits = (u32)((8 - (st.total_bits & 7)) & 7);
-            const u32 qpad = q0 + (u32)(st.total_bits - p0);
-            if (pad_bits) {
-                image_or_bits(img, qpad, it.eos_padding & ((1u << pad_bits) - 1), pad_bits);
-            }
+    if (need && !sh->halo_unknown && st.status == HUFD_ENC_OK) {
+        /* only reachable when the item's remaining symbols ran out: pad */
+        const u32 pad_bits = (u32)((8 - (st.total_bits & 7)) & 7);
+        const u32 qpad = g.q0 + (u32)(st.total_bits - g.p0);
+        if (pad_bits) {
+            image_or_bits(img, qpad, it.eos_padding & ((1u << pad_bits) - 1), pad_bits);
         }
     }
-    __syncthreads();
+}
 
-    /* which bytes this workgroup may write */
+/* After the barrier: copy the owned bytes out and, where this segment decides it, the result. */
+__device__ __forceinline__ void pack_write_out(
+    const u32 *img,
+    const enc_pack_shared *sh,
+    const pack_geometry &g,
+    const hufd_enc_seg seg,
+    const hufd_enc_item &it,
+    const hufd_enc_item_state &st,
+    hufd_enc_result *results) {
+
     u32 status = st.status;
     if (status == HUFD_ENC_DECIDE) {
         /* only the segment holding the bad symbol can tell which stop comes first;
          * for the segments before it neither limit binds */
-        status = (is_unk_seg && sh->unk_before < cap_bits) ? HUFD_ENC_UNKNOWN : HUFD_ENC_SHORT;
+        status = (g.is_unk_seg && sh->unk_before < g.cap_bits) ? HUFD_ENC_UNKNOWN : HUFD_ENC_SHORT;
     }
     u64 limit_bytes;
     if (status == HUFD_ENC_OK) {
         limit_bytes = (st.total_bits + 7) >> 3;
-    } else if (status == HUFD_ENC_UNKNOWN && is_unk_seg) {
+    } else if (status == HUFD_ENC_UNKNOWN && g.is_unk_seg) {
         limit_bytes = sh->unk_before >> 3; /* the partial byte in flight is lost (huffman.c:62-64) */
     } else {
         limit_bytes = it.out_cap;
     }
 
     u64 jhi;
-    if (last_seg) {
-        jhi = status == HUFD_ENC_OK ? (st.total_bits + 7) >> 3 : pend >> 3;
+    if (g.last_seg) {
+        jhi = status == HUFD_ENC_OK ? (st.total_bits + 7) >> 3 : g.pend >> 3;
     } else {
-        jhi = sh->halo_unknown ? pend >> 3 : (pend + 7) >> 3;
+        jhi = sh->halo_unknown ? g.pend >> 3 : (g.pend + 7) >> 3;
     }
     if (jhi > limit_bytes) {
         jhi = limit_bytes;
     }
-    const u64 jlo = (pa + 7) >> 3;
+    const u64 jlo = (g.pa + 7) >> 3;
     if (jhi > jlo) {
-        image_store<HUFD_ENC_THREADS>(img, gbase, (u32)(jlo - j0) + mis, (u32)(jhi - j0) + mis);
+        image_store<HUFD_ENC_THREADS>(img, g.gbase, (u32)(jlo - g.j0) + g.mis, (u32)(jhi - g.j0) + g.mis);
     }
 
-    if (tid == 0) {
-        hufd_enc_result *rs = &results[item_index];
-        if (status == HUFD_ENC_UNKNOWN && is_unk_seg) {
+    if (threadIdx.x == 0) {
+        hufd_enc_result *rs = &results[seg.item];
+        if (status == HUFD_ENC_UNKNOWN && g.is_unk_seg) {
             rs->status = HUFD_ENC_UNKNOWN;
             rs->produced = limit_bytes;
             rs->ovf_bits = 0;
             rs->ovf_pattern = 0;
-        } else if (sh->short_found && (status == HUFD_ENC_SHORT)) {
+        } else if (sh->short_found && status == HUFD_ENC_SHORT) {
             rs->status = HUFD_ENC_SHORT;
             rs->produced = it.out_cap;
             rs->consumed = sh->short_consumed;
@@ -623,12 +701,394 @@ __global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_pack_kernel(
     }
 }
 
+/*
+ * The per-symbol packer: any code length up to 32, finds the symbol that crosses the
+ * capacity edge and the position of the item's first symbol without a code.  Used for
+ * every segment of a coder with codes longer than 16 bits, and otherwise only for the
+ * (at most two per item) segments listed by the scan kernel.
+ *   list == NULL : workgroup b handles segment b, b + gridDim.x, ...
+ *   list != NULL : the segments list[0 .. *list_count)
+ */
+__global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_pack_kernel(
+    hufd_tables tb,
+    const hufd_enc_item *items,
+    const hufd_enc_item_state *states,
+    const hufd_enc_seg *segs,
+    const u32 *seg_bits,
+    const u64 *seg_bitoff,
+    const u8 *d_in,
+    u8 *d_out,
+    hufd_enc_result *results,
+    u32 img_words,
+    u32 n_segs,
+    const u32 *list,
+    const u32 *list_count) {
+
+    u32 *img = reinterpret_cast<u32 *>(dyn_lds);
+    u64 *tab = reinterpret_cast<u64 *>(dyn_lds + round16(img_words * 4));
+    u32 *slots = reinterpret_cast<u32 *>(tab + 256); /* [8] */
+    enc_pack_shared *sh = reinterpret_cast<enc_pack_shared *>(slots + 8);
+
+    const u32 tid = threadIdx.x;
+    tab[tid] = tb.enc_table[tid];
+    const u32 n_work = list ? *list_count : n_segs;
+
+    for (u32 work = blockIdx.x; work < n_work; work += gridDim.x) {
+        const u32 s = list ? list[work] : work;
+        const hufd_enc_seg seg = segs[s];
+        const u8 *src = d_in + seg.in_off;
+        u32 gw[kGroupsPerLane][4], gvalid[kGroupsPerLane];
+        load_segment_groups(src, seg.len, gw, gvalid);
+        u32 halo[2] = {0, 0};
+        if (tid == 0 && seg.next_len) {
+            const u32 n = seg.next_len < 8 ? seg.next_len : 8;
+            for (u32 j = 0; j < n; ++j) {
+                halo[j >> 2] |= (u32)src[HUFD_ENC_SEG_BYTES + j] << (8 * (j & 3));
+            }
+        }
+        const hufd_enc_item it = items[seg.item];
+        const hufd_enc_item_state st = states[seg.item];
+        const pack_geometry g = pack_geometry_of(tb, seg, s, it, st, seg_bitoff[s], seg_bits[s], d_out);
+        /* with a list the stream kernel has done every segment that is not on it */
+        const bool mine = !g.skip && (list || g.careful || tb.max_bits > 16);
+
+        __syncthreads(); /* the previous segment's copy-out is done with the image */
+        {
+            const uint4 zero = {0, 0, 0, 0};
+            for (u32 i = tid; i < img_words / 4; i += HUFD_ENC_THREADS) {
+                reinterpret_cast<uint4 *>(img)[i] = zero;
+            }
+        }
+        if (tid == 0) {
+            sh->unk_before = kNoBit;
+            sh->short_found = 0;
+            sh->halo_unknown = 0;
+        }
+        __syncthreads();
+        if (!mine) {
+            continue;
+        }
+        if (tid == 0 && seg.index == 0 && it.ovf_bits) {
+            image_or_bits(img, 8 * g.mis, it.ovf_pattern, it.ovf_bits);
+        }
+
+        const u64 seg_off = (u64)seg.index * HUFD_ENC_SEG_BYTES;
+        u32 carry = 0; /* bits of this segment already placed */
+#pragma unroll
+        for (u32 iter = 0; iter < kGroupsPerLane; ++iter) {
+            const u32 base = (iter * HUFD_ENC_THREADS + tid) * 16;
+            const u32 valid = gvalid[iter];
+            u64 e[16];
+            u32 lane_bits = 0;
+#pragma unroll
+            for (u32 j = 0; j < 16; ++j) {
+                e[j] = j < valid ? tab[group_byte(gw[iter], j)] : 0;
+                lane_bits += (u32)(e[j] >> 32);
+            }
+            u32 total;
+            u32 rel = carry + block_exclusive_sum<HUFD_ENC_THREADS>(lane_bits, slots, total);
+            carry += total;
+
+            /* the lane's codes go out as whole words; its first and last word are shared
+             * with neighbours, so every word is OR-ed into the zeroed image */
+            u32 q = g.q0 + rel;
+            u32 wi = q >> 5, nb = q & 31;
+            u64 acc = 0;
+#pragma unroll
+            for (u32 j = 0; j < 16; ++j) {
+                const u32 len = (u32)(e[j] >> 32);
+                const u32 pat = (u32)e[j];
+                if (j < valid) {
+                    if (len == 0) {
+                        if (g.is_unk_seg && base + j == st.unk_idx) {
+                            sh->unk_before = g.p0 + rel;
+                        }
+                    } else {
+                        const u32 after = rel + len;
+                        if (rel < g.cap_rel && after >= g.cap_rel) {
+                            /* first symbol whose last bit reaches the capacity edge (huffman.c:88-98) */
+                            sh->short_found = 1;
+                            sh->short_consumed = seg_off + base + j + 1;
+                            sh->short_ovf_bits = after - g.cap_rel;
+                            sh->short_ovf_pattern = pat & (u32)((1ull << (after - g.cap_rel)) - 1);
+                        }
+                        acc = (acc << len) | pat;
+                        nb += len;
+                        rel = after;
+                        if (nb >= 32) {
+                            atomicOr(&img[wi], (u32)(acc >> (nb - 32)));
+                            ++wi;
+                            nb -= 32;
+                            acc &= (1ull << nb) - 1;
+                        }
+                    }
+                }
+            }
+            if (nb) {
+                const u32 tail = (u32)(acc << (32 - nb));
+                if (tail) {
+                    atomicOr(&img[wi], tail);
+                }
+            }
+        }
+        if (tid == 0) {
+            pack_last_byte(img, sh, g, seg, it, st, halo, [&](u32 sym) { return tab[sym]; });
+        }
+        __syncthreads();
+        pack_write_out(img, sh, g, seg, it, st, results);
+    }
+}
+
+/* A segment descriptor is the same in every lane: say so, and it lives in scalar registers. */
+__device__ __forceinline__ hufd_enc_seg uniform_seg(const hufd_enc_seg *p) {
+    hufd_enc_seg d = *p;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 lo = __builtin_amdgcn_readfirstlane((u32)d.in_off);
+    const u32 hi = __builtin_amdgcn_readfirstlane((u32)(d.in_off >> 32));
+    d.in_off = ((u64)hi << 32) | lo;
+    d.len = __builtin_amdgcn_readfirstlane(d.len);
+    d.item = __builtin_amdgcn_readfirstlane(d.item);
+    d.index = __builtin_amdgcn_readfirstlane(d.index);
+    d.flags = __builtin_amdgcn_readfirstlane(d.flags);
+    d.next_len = __builtin_amdgcn_readfirstlane(d.next_len);
+#endif
+    return d;
+}
+
+/* asks for a segment's symbols: 16-byte chunk c of the segment goes to inbuf + 16 c (LDS-DMA) */
+__device__ __forceinline__ void stream_request(const u8 *d_in, u8 *inbuf, u64 in_off, u32 len, u32 next_len) {
+    const u8 *src = d_in + in_off;
+    if (((uintptr_t)src & 15u) != 0) {
+        return; /* unaligned input: read with plain loads when its turn comes */
+    }
+    const u32 chunks = (len + 15) / 16 + (next_len ? 1 : 0);
+#pragma unroll
+    for (u32 j = 0; j <= kGroupsPerLane; ++j) {
+        const u32 c = j * HUFD_ENC_THREADS + threadIdx.x;
+        if (c < chunks && c <= HUFD_ENC_SEG_BYTES / 16) {
+            lds_dma16(src + 16 * c, inbuf + 16 * c);
+        }
+    }
+}
+
+/*
+ * The streaming packer for coders whose codes fit 16 bits (the reference's test coder
+ * has at most 10).  Persistent workgroups: segment blockIdx.x, + gridDim.x, ...  While a
+ * segment is packed, the symbols of the workgroup's next segment travel from HBM straight
+ * into an LDS buffer (LDS-DMA, no registers), so the memory round trip hides behind the
+ * packing.  Per segment and lane: 64 table lookups, codes merged pairwise to quads in
+ * registers, one wave scan per 32 symbols, <= 3 LDS ORs per quad -- no per-symbol branch.
+ * Segments that need the per-symbol treatment (capacity edge, symbol without a code) are
+ * left to enc_pack_kernel.
+ */
+__global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_pack_stream_kernel(
+    hufd_tables tb,
+    const hufd_enc_item *items,
+    const hufd_enc_item_state *states,
+    const hufd_enc_seg *segs,
+    const u32 *seg_bits,
+    const u64 *seg_bitoff,
+    const u8 *d_in,
+    u8 *d_out,
+    hufd_enc_result *results,
+    u32 img_words,
+    u32 n_segs) {
+
+    constexpr u32 kInBytes = HUFD_ENC_SEG_BYTES + 16; /* a segment + the chunk holding the next one's head */
+    u32 *img = reinterpret_cast<u32 *>(dyn_lds);
+    u8 *inbuf = dyn_lds + round16(img_words * 4);
+    u32 *tab32 = reinterpret_cast<u32 *>(inbuf + kInBytes); /* [256] length << 16 | code */
+    u32 *slots = tab32 + 256;                                /* [8] wave totals, first half then second half */
+    enc_pack_shared *sh = reinterpret_cast<enc_pack_shared *>(slots + 8);
+
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    {
+        const u64 ent = tb.enc_table[tid];
+        tab32[tid] = ((u32)(ent >> 32) << 16) | ((u32)ent & 0xFFFFu);
+    }
+
+    u32 s = blockIdx.x;
+    if (s >= n_segs) {
+        return;
+    }
+    hufd_enc_seg seg = uniform_seg(&segs[s]);
+    /* descriptors are read with a clamped index: a select between memory objects would push them to scratch */
+    hufd_enc_seg seg_next = uniform_seg(&segs[s + gridDim.x < n_segs ? s + gridDim.x : n_segs - 1]);
+    stream_request(d_in, inbuf, seg.in_off, seg.len, seg.next_len);
+    __syncthreads(); /* tables staged, first segment landed (the barrier drains the DMA) */
+
+    for (;;) {
+        HUFD_STAMP(2, 0);
+        const bool more = s + gridDim.x < n_segs;
+        const hufd_enc_item it = items[seg.item];
+        const hufd_enc_item_state st = states[seg.item];
+        const pack_geometry g = pack_geometry_of(tb, seg, s, it, st, seg_bitoff[s], seg_bits[s], d_out);
+        const u8 *src = d_in + seg.in_off;
+        const bool from_lds = ((uintptr_t)src & 15u) == 0;
+
+        /* symbols out of the buffer (or memory), image cleared */
+        u32 gw[kGroupsPerLane][4], gvalid[kGroupsPerLane];
+        u32 halo[2] = {0, 0};
+        if (from_lds) {
+#pragma unroll
+            for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
+                const u32 base = (gi * HUFD_ENC_THREADS + tid) * 16;
+                gvalid[gi] = base < seg.len ? (seg.len - base < 16 ? seg.len - base : 16) : 0;
+                const uint4 v = *reinterpret_cast<const uint4 *>(inbuf + base);
+                gw[gi][0] = v.x;
+                gw[gi][1] = v.y;
+                gw[gi][2] = v.z;
+                gw[gi][3] = v.w;
+                if (gvalid[gi] < 16) {
+                    /* bytes past the segment are whatever the buffer held: mask them */
+#pragma unroll
+                    for (u32 c = 0; c < 4; ++c) {
+                        const u32 keep = gvalid[gi] > 4 * c ? gvalid[gi] - 4 * c : 0;
+                        gw[gi][c] &= keep >= 4 ? 0xFFFFFFFFu : ((1u << (8 * keep)) - 1u);
+                    }
+                }
+            }
+            if (tid == 0 && seg.next_len) {
+                halo[0] = *reinterpret_cast<const u32 *>(inbuf + HUFD_ENC_SEG_BYTES);
+                halo[1] = *reinterpret_cast<const u32 *>(inbuf + HUFD_ENC_SEG_BYTES + 4);
+            }
+        } else {
+            load_segment_groups(src, seg.len, gw, gvalid);
+            if (tid == 0 && seg.next_len) {
+                const u32 n = seg.next_len < 8 ? seg.next_len : 8;
+                for (u32 j = 0; j < n; ++j) {
+                    halo[j >> 2] |= (u32)src[HUFD_ENC_SEG_BYTES + j] << (8 * (j & 3));
+                }
+            }
+        }
+        {
+            const uint4 zero = {0, 0, 0, 0};
+            for (u32 i = tid; i < img_words / 4; i += HUFD_ENC_THREADS) {
+                reinterpret_cast<uint4 *>(img)[i] = zero;
+            }
+        }
+        if (tid == 0) {
+            sh->unk_before = kNoBit;
+            sh->short_found = 0;
+            sh->halo_unknown = 0;
+        }
+        barrier_lds(); /* every lane holds its symbols: the buffer may be refilled */
+        const hufd_enc_seg seg_after = uniform_seg(&segs[s + 2 * gridDim.x < n_segs ? s + 2 * gridDim.x : n_segs - 1]);
+        if (more) {
+            stream_request(d_in, inbuf, seg_next.in_off, seg_next.len, seg_next.next_len);
+        }
+        HUFD_STAMP(2, 1);
+
+        if (!g.skip && !g.careful) {
+            if (tid == 0 && seg.index == 0 && it.ovf_bits) {
+                image_or_bits(img, 8 * g.mis, it.ovf_pattern, it.ovf_bits);
+            }
+            u32 half_base = 0; /* bits of the groups handled by the earlier half */
+#pragma unroll
+            for (u32 half = 0; half < 2; ++half) {
+                /* codes -> pairs (<= 32 bits) -> quads (<= 64 bits), two groups at a time */
+                u64 qv[2][4];
+                u32 ql[2];      /* the four quad lengths of a group, one byte each */
+                u32 packed = 0; /* the lane's bit count in its two groups, 16 bits apiece */
+#pragma unroll
+                for (u32 gg = 0; gg < 2; ++gg) {
+                    const u32 gi = 2 * half + gg;
+                    u32 group_bits = 0, lens = 0;
+#pragma unroll
+                    for (u32 m = 0; m < 4; ++m) {
+                        u32 pv[2], pl[2];
+#pragma unroll
+                        for (u32 h = 0; h < 2; ++h) {
+                            const u32 j = 4 * m + 2 * h;
+                            const u32 ea = j < gvalid[gi] ? tab32[group_byte(gw[gi], j)] : 0;
+                            const u32 eb = j + 1 < gvalid[gi] ? tab32[group_byte(gw[gi], j + 1)] : 0;
+                            const u32 lb = eb >> 16;
+                            pv[h] = ((ea & 0xFFFFu) << lb) | (eb & 0xFFFFu);
+                            pl[h] = (ea >> 16) + lb;
+                        }
+                        qv[gg][m] = ((u64)pv[0] << pl[1]) | pv[1];
+                        lens |= (pl[0] + pl[1]) << (8 * m);
+                        group_bits += pl[0] + pl[1];
+                    }
+                    ql[gg] = lens;
+                    packed |= group_bits << (16 * gg);
+                }
+                if (half == 0) {
+                    HUFD_STAMP(2, 2);
+                }
+
+                /* one wave scan for both groups (each 16-bit field stays below 2^16 across a wave) */
+                u32 incl = packed;
+#pragma unroll
+                for (u32 d = 1; d < kWave; d <<= 1) {
+                    const u32 up = __shfl_up(incl, d);
+                    if (lane >= d) {
+                        incl += up;
+                    }
+                }
+                if (lane == kWave - 1) {
+                    slots[4 * half + wave] = incl;
+                }
+                barrier_lds();
+                u32 before[2] = {0, 0}, total[2] = {0, 0};
+#pragma unroll
+                for (u32 w = 0; w < HUFD_ENC_THREADS / kWave; ++w) {
+                    const u32 t = slots[4 * half + w];
+                    before[0] += w < wave ? (t & 0xFFFFu) : 0;
+                    before[1] += w < wave ? (t >> 16) : 0;
+                    total[0] += t & 0xFFFFu;
+                    total[1] += t >> 16;
+                }
+                if (half == 0) {
+                    HUFD_STAMP(2, 3);
+                }
+#pragma unroll
+                for (u32 gg = 0; gg < 2; ++gg) {
+                    const u32 mine = (packed >> (16 * gg)) & 0xFFFFu;
+                    u32 q = g.q0 + half_base + (gg ? total[0] : 0) + before[gg] + ((incl >> (16 * gg)) & 0xFFFFu) - mine;
+#pragma unroll
+                    for (u32 m = 0; m < 4; ++m) {
+                        const u32 len = (ql[gg] >> (8 * m)) & 0xFFu;
+                        image_or_quad(img, q, qv[gg][m], len);
+                        q += len;
+                    }
+                }
+                half_base += total[0] + total[1];
+            }
+            if (tid == 0) {
+                pack_last_byte(img, sh, g, seg, it, st, halo, [&](u32 sym) {
+                    const u32 e = tab32[sym];
+                    return ((u64)(e >> 16) << 32) | (e & 0xFFFFu);
+                });
+            }
+        }
+        HUFD_STAMP(2, 4);
+        /* full barrier: the image is complete, and every wave's share of the prefetch has
+         * landed (it was issued a whole packing ago) before anybody moves on */
+        __syncthreads();
+        HUFD_STAMP(2, 5);
+        HUFD_STAMP(2, 6);
+        if (!g.skip && !g.careful) {
+            pack_write_out(img, sh, g, seg, it, st, results);
+        }
+        HUFD_STAMP(2, 7);
+        if (!more) {
+            break;
+        }
+        s += gridDim.x;
+        seg = seg_next;
+        seg_next = seg_after;
+        barrier_lds(); /* copy-out has read the image; its stores stay in flight */
+    }
+}
+
 /* ------------------------------------------------------------------ decode: shared pieces */
 
 constexpr u32 kSubWords = HUFD_DEC_SUB_BYTES / 4;    /* 32 */
-constexpr u32 kRowStride = HUFD_DEC_LANES + 1;        /* transposed chunk image, one pad column */
-constexpr u32 kChunkWords = kSubWords * kRowStride;
-constexpr u32 kMergeWords = 8;                        /* reference-path bitmap covers the first 256 bits */
+constexpr u32 kSubRows = kSubWords + 2;               /* + the first two words of the next sub-chunk */
+constexpr u32 kRowStride = HUFD_DEC_LANES + 1;        /* word r of lane i at r * 257 + i: coalesced loads transpose without bank conflicts */
+constexpr u32 kChunkWords = (kSubRows * kRowStride + 3u) & ~3u; /* what follows it in LDS stays 16-byte aligned */
+constexpr u32 kMergeWords = 7;                        /* reference-path bitmap covers the first 224 bits */
 constexpr u32 kGroupLanes = 16;
 constexpr u32 kGroups = HUFD_DEC_LANES / kGroupLanes;
 
@@ -653,9 +1113,9 @@ __device__ __forceinline__ u32 wide_count(u32 f) {
     return f & 0x03FFFFFFu;
 }
 
-/* word r (0..32) of lane's sub-chunk in the transposed image; word 32 is the next lane's word 0 */
+/* word r (0..33) of the lane's sub-chunk; words 32 and 33 are the next lane's words 0 and 1 */
 __device__ __forceinline__ u32 chunk_word(const u32 *timg, u32 lane, u32 r) {
-    return timg[(r & (kSubWords - 1)) * kRowStride + lane + (r >> 5)];
+    return timg[r * kRowStride + lane];
 }
 
 /* the 32 stream bits starting `pos` bits into the lane's sub-chunk */
@@ -665,13 +1125,50 @@ __device__ __forceinline__ u32 chunk_window(const u32 *timg, u32 lane, u32 pos) 
     return (u32)((two << (pos & 31)) >> 32);
 }
 
-/* Loads one chunk (+ one word of the next) into the transposed big-endian image. */
+/*
+ * Loads one chunk (+ two words of the next) into the transposed big-endian LDS image.
+ * Fast path: eight coalesced 16-byte loads per thread, all in flight before the first use;
+ * uint4 number q holds words 4(q&7).. of lane q>>3, and with the 257-word row stride the
+ * 32 threads of a store group land on 32 different banks.
+ */
 __device__ __forceinline__ void chunk_load(u32 *timg, const u8 *src, u64 valid_bytes) {
-    const bool aligned = ((uintptr_t)src & 3u) == 0;
-    for (u32 g = threadIdx.x; g < HUFD_DEC_CHUNK_BYTES / 4 + 1; g += HUFD_DEC_LANES) {
-        const u32 word = load_be32(src, g, valid_bytes, aligned);
-        const u32 lane = g >> 5, r = g & 31;
-        timg[r * kRowStride + lane] = word; /* g == 8192 lands on lane 256, row 0: the halo column */
+    const u32 t = threadIdx.x;
+    constexpr u32 kPerThread = HUFD_DEC_CHUNK_BYTES / 16 / HUFD_DEC_LANES; /* 8 */
+    if (((uintptr_t)src & 15u) == 0 && valid_bytes >= HUFD_DEC_CHUNK_BYTES) {
+        uint4 v[kPerThread];
+#pragma unroll
+        for (u32 j = 0; j < kPerThread; ++j) {
+            v[j] = reinterpret_cast<const uint4 *>(src)[t + HUFD_DEC_LANES * j];
+        }
+#pragma unroll
+        for (u32 j = 0; j < kPerThread; ++j) {
+            const u32 q = t + HUFD_DEC_LANES * j;
+            const u32 lane = q >> 3, r0 = 4 * (q & 7);
+            const u32 w0 = __builtin_bswap32(v[j].x), w1 = __builtin_bswap32(v[j].y);
+            u32 *col = timg + r0 * kRowStride + lane;
+            col[0] = w0;
+            col[kRowStride] = w1;
+            col[2 * kRowStride] = __builtin_bswap32(v[j].z);
+            col[3 * kRowStride] = __builtin_bswap32(v[j].w);
+            if (r0 == 0 && lane > 0) {
+                timg[kSubWords * kRowStride + lane - 1] = w0;
+                timg[(kSubWords + 1) * kRowStride + lane - 1] = w1;
+            }
+        }
+    } else {
+        const bool aligned = ((uintptr_t)src & 3u) == 0;
+        for (u32 g = t; g < HUFD_DEC_CHUNK_BYTES / 4; g += HUFD_DEC_LANES) {
+            const u32 word = load_be32(src, g, valid_bytes, aligned);
+            const u32 lane = g >> 5, r = g & 31;
+            timg[r * kRowStride + lane] = word;
+            if (r < 2 && lane > 0) {
+                timg[(kSubWords + r) * kRowStride + lane - 1] = word;
+            }
+        }
+    }
+    if (t < 2) {
+        timg[(kSubWords + t) * kRowStride + HUFD_DEC_LANES - 1] =
+            load_be32(src, (u64)HUFD_DEC_CHUNK_BYTES / 4 + t, valid_bytes, false);
     }
 }
 
@@ -686,26 +1183,64 @@ __device__ __forceinline__ void lut_load(u16 *lut, const hufd_tables &tb) {
  * sub-chunk, `remaining` stream bits left from the sub-chunk start.  Returns the code
  * length, or 0 with *why set when the walk ends here.
  */
-__device__ __forceinline__ u32 walk_step(
-    const u32 *timg, const u16 *lut, u32 lut_bits, u32 lane, u32 pos, long long remaining, u32 *symbol, u32 *why) {
-    const long long rem = remaining - (long long)pos;
-    if (rem <= 0) {
+__device__ __forceinline__ u32 code_at(
+    u32 window, const u16 *lut, u32 lut_bits, u32 pos, u32 rem, u32 *symbol, u32 *why) {
+    /* `rem` = stream bits from the sub-chunk start to the end of the item, clamped to [0, 2^30] */
+    if (pos >= rem) {
         *why = HUFD_STOP_END;
         return 0;
     }
-    const u32 entry = lut[chunk_window(timg, lane, pos) >> (32 - lut_bits)];
+    const u32 entry = lut[window >> (32 - lut_bits)];
     const u32 len = entry & 0xFFu;
     if (len == 0) {
         *why = HUFD_STOP_INVALID;
         return 0;
     }
-    if ((long long)len > rem) {
+    if (pos + len > rem) {
         *why = HUFD_STOP_INCOMPLETE;
         return 0;
     }
     *symbol = entry >> 8;
     return len;
 }
+
+__device__ __forceinline__ u32 clamp_remaining(u64 valid_bytes, u32 lane) {
+    const long long rem = (long long)(valid_bytes * 8) - (long long)lane * HUFD_DEC_SUB_BITS;
+    return rem <= 0 ? 0u : (rem > (1ll << 30) ? (1u << 30) : (u32)rem);
+}
+
+/*
+ * Sequential bit window of one lane over its sub-chunk: the next 33..64 stream bits sit
+ * at the top of `win`, refilled a word at a time from the transposed image, so a long
+ * walk costs one LDS word read per 32 bits instead of two per symbol
+ * (the register twin of the 64-bit window of source/huffman.c:196-211).
+ */
+struct bit_reader {
+    u64 win;
+    u32 nb;   /* valid bits in win, kept above 32 */
+    u32 next; /* index of the next word of the sub-chunk to append */
+
+    __device__ __forceinline__ void start(const u32 *timg, u32 lane, u32 pos) {
+        const u32 r = pos >> 5;
+        win = (((u64)chunk_word(timg, lane, r) << 32) | chunk_word(timg, lane, r + 1)) << (pos & 31);
+        nb = 64 - (pos & 31);
+        next = r + 2;
+    }
+    __device__ __forceinline__ u32 peek() const {
+        return (u32)(win >> 32);
+    }
+    __device__ __forceinline__ void skip(const u32 *timg, u32 lane, u32 len) {
+        win <<= len;
+        nb -= len;
+        if (nb <= 32) {
+            /* words past index 32 are never needed for a decision (a code starts inside the
+             * sub-chunk and is at most 32 bits long); the read only has to stay in bounds */
+            win |= (u64)chunk_word(timg, lane, next) << (32 - nb);
+            nb += 32;
+            ++next;
+        }
+    }
+};
 
 /* result of following a run of transfer functions */
 struct fold_result {
@@ -753,7 +1288,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     u16 *cnt_at = reinterpret_cast<u16 *>(bitmap + kMergeWords * HUFD_DEC_LANES); /* [kMergeWords][lanes] */
     u16 *ftab = cnt_at + kMergeWords * HUFD_DEC_LANES;                 /* [ns][lanes] */
     u32 *gtab = reinterpret_cast<u32 *>(ftab + ns * HUFD_DEC_LANES); /* [groups][ns] */
-    u16 *lut = reinterpret_cast<u16 *>(gtab + kGroups * HUFD_DEC_MAX_STATES);
+    u16 *lut = reinterpret_cast<u16 *>(gtab + kGroups * ns);
 
     const u32 lane = threadIdx.x;
     const u32 c = blockIdx.x;
@@ -761,6 +1296,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
     const u64 valid = it.in_len > chunk_off ? it.in_len - chunk_off : 0;
 
+    HUFD_STAMP(0, 0);
     chunk_load(timg, d_in + it.in_off + chunk_off, valid);
     lut_load(lut, tb);
     for (u32 w = 0; w < kMergeWords; ++w) {
@@ -769,43 +1305,71 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     }
     __syncthreads();
 
-    /* stream bits left, counted from this lane's sub-chunk start (may be <= 0) */
-    const long long remaining = (long long)(valid * 8) - (long long)lane * HUFD_DEC_SUB_BITS;
+    HUFD_STAMP(0, 1);
+    const u32 rem = clamp_remaining(valid, lane);
+    constexpr u32 kMergeBits = kMergeWords * 32;
 
-    /* Phase A: the reference path from entry state 0; remember where it stepped. */
-    u32 ref_count = 0, ref_exit = 0;
+    /*
+     * Phase A: find a reference path.  A walk from a wrong entry state usually dies on an
+     * invalid window within a few symbols, and one that survives has fallen in step with
+     * the true path; so try the entry states in order and take the first walk that is still
+     * alive after kMergeBits as the reference, remembering where it stepped.  The states
+     * that died on the way are finished (their function value is STOP).
+     */
+    u32 ref_state = ns, ref_count = 0, ref_exit = 0;
     bool ref_stop = false;
     {
-        u32 pos = 0, cur_word = 0, cur_mask = 0;
-        while (pos < HUFD_DEC_SUB_BITS) {
-            if (pos < kMergeWords * 32) {
-                const u32 w = pos >> 5;
-                if (w != cur_word) {
-                    bitmap[cur_word * HUFD_DEC_LANES + lane] = cur_mask;
-                    cur_word = w;
-                    cur_mask = 0;
-                    cnt_at[w * HUFD_DEC_LANES + lane] = (u16)ref_count;
-                }
-                cur_mask |= 1u << (pos & 31);
+        u32 cand = 0, pos = 0, steps = 0;
+        bit_reader br;
+        br.start(timg, lane, 0);
+        while (cand < ns && pos < kMergeBits) {
+            const u32 w = pos >> 5;
+            const u32 seen = bitmap[w * HUFD_DEC_LANES + lane];
+            if (seen == 0) {
+                cnt_at[w * HUFD_DEC_LANES + lane] = (u16)steps; /* symbols started before this word */
             }
+            bitmap[w * HUFD_DEC_LANES + lane] = seen | (1u << (pos & 31));
             u32 sym, why;
-            const u32 len = walk_step(timg, lut, tb.lut_bits, lane, pos, remaining, &sym, &why);
+            const u32 len = code_at(br.peek(), lut, tb.lut_bits, pos, rem, &sym, &why);
             if (!len) {
-                ref_stop = true;
-                break;
+                ftab[cand * HUFD_DEC_LANES + lane] = fn_pack(true, 0, steps);
+                for (u32 k = 0; k <= w; ++k) {
+                    bitmap[k * HUFD_DEC_LANES + lane] = 0;
+                }
+                ++cand;
+                pos = cand;
+                steps = 0;
+                br.start(timg, lane, pos);
+            } else {
+                pos += len;
+                ++steps;
+                br.skip(timg, lane, len);
             }
-            pos += len;
-            ++ref_count;
         }
-        bitmap[cur_word * HUFD_DEC_LANES + lane] = cur_mask;
-        ref_exit = ref_stop ? 0 : pos - HUFD_DEC_SUB_BITS;
-        ftab[lane] = fn_pack(ref_stop, ref_exit, ref_count);
+        if (cand < ns) {
+            ref_state = cand;
+            while (pos < HUFD_DEC_SUB_BITS) {
+                u32 sym, why;
+                const u32 len = code_at(br.peek(), lut, tb.lut_bits, pos, rem, &sym, &why);
+                if (!len) {
+                    ref_stop = true;
+                    break;
+                }
+                pos += len;
+                ++steps;
+                br.skip(timg, lane, len);
+            }
+            ref_count = steps;
+            ref_exit = ref_stop ? 0 : pos - HUFD_DEC_SUB_BITS;
+            ftab[cand * HUFD_DEC_LANES + lane] = fn_pack(ref_stop, ref_exit, ref_count);
+        }
     }
 
-    /* Phase B: the other entry states, one after another per lane, each until it falls
+    HUFD_STAMP(0, 2);
+    /* Phase B: the remaining entry states, one after another per lane, each until it falls
      * onto the reference path, dies, or leaves the sub-chunk on its own. */
     {
-        u32 state = 1, pos = 1, steps = 0;
+        u32 state = ref_state + 1, pos = ref_state + 1, steps = 0;
         while (state < ns) {
             bool done = false;
             u16 res = 0;
@@ -813,7 +1377,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
                 res = fn_pack(false, pos - HUFD_DEC_SUB_BITS, steps);
                 done = true;
             } else {
-                if (pos < kMergeWords * 32) {
+                if (pos < kMergeBits) {
                     const u32 m = bitmap[(pos >> 5) * HUFD_DEC_LANES + lane];
                     if ((m >> (pos & 31)) & 1u) {
                         const u32 before = cnt_at[(pos >> 5) * HUFD_DEC_LANES + lane] +
@@ -824,7 +1388,8 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
                 }
                 if (!done) {
                     u32 sym, why;
-                    const u32 len = walk_step(timg, lut, tb.lut_bits, lane, pos, remaining, &sym, &why);
+                    const u32 len =
+                        code_at(chunk_window(timg, lane, pos), lut, tb.lut_bits, pos, rem, &sym, &why);
                     if (!len) {
                         res = fn_pack(true, 0, steps);
                         done = true;
@@ -842,7 +1407,9 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
             }
         }
     }
+    HUFD_STAMP(0, 3);
     __syncthreads();
+    HUFD_STAMP(0, 4);
 
     /* publish the per-lane functions for dec_emit */
     for (u32 sidx = 0; sidx < ns; ++sidx) {
@@ -861,6 +1428,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
         chunk_fn[(u64)c * ns + lane] =
             wide_pack(chain_fold(kGroups, lane, [&](u32 g, u32 stt) { return gtab[g * ns + stt]; }));
     }
+    HUFD_STAMP(0, 5);
 }
 
 /* ------------------------------------------------------------------ decode: scan */
@@ -1050,7 +1618,8 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_emit_kernel(
     u32 *g_base = g_entry + kGroups;                          /* [groups] */
     u32 *l_entry = g_base + kGroups;                          /* [lanes] */
     u32 *l_base = l_entry + HUFD_DEC_LANES;                   /* [lanes] */
-    u32 *blk_count = l_base + HUFD_DEC_LANES;                 /* [4] */
+    u32 *l_cnt = l_base + HUFD_DEC_LANES;                     /* [lanes] */
+    u32 *blk_count = l_cnt + HUFD_DEC_LANES;                  /* [4] */
     u16 *lut = reinterpret_cast<u16 *>(blk_count + 4);
 
     const u32 lane = threadIdx.x;
@@ -1065,12 +1634,14 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_emit_kernel(
     const u64 valid = it.in_len > chunk_off ? it.in_len - chunk_off : 0;
     const u64 cbase = chunk_base[c];
 
+    HUFD_STAMP(1, 0);
     chunk_load(timg, d_in + it.in_off + chunk_off, valid);
     lut_load(lut, tb);
     for (u32 sidx = 0; sidx < ns; ++sidx) {
         ftab[sidx * HUFD_DEC_LANES + lane] = fn_tab[((u64)c * ns + sidx) * HUFD_DEC_LANES + lane];
     }
     __syncthreads();
+    HUFD_STAMP(1, 1);
 
     /* true entry state and output offset of every lane: groups, then lanes */
     if (lane < kGroups * ns) {
@@ -1101,14 +1672,18 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_emit_kernel(
         bool stopped = !(g_entry[lane] & 0x100u);
         for (u32 i = 0; i < kGroupLanes; ++i) {
             const u32 l = lane * kGroupLanes + i;
-            l_entry[l] = entry_pack(state, !stopped);
+            u32 ent = entry_pack(state, !stopped), cnt = 0;
             l_base[l] = total;
             if (!stopped) {
                 const u32 f = widen(ftab[state * HUFD_DEC_LANES + l]);
-                total += wide_count(f);
+                cnt = wide_count(f);
+                total += cnt;
                 stopped = wide_stop(f);
                 state = wide_state(f);
+                ent |= stopped ? 0x200u : 0u; /* the true path ends inside this sub-chunk */
             }
+            l_entry[l] = ent;
+            l_cnt[l] = cnt;
         }
     }
     __syncthreads(); /* ftab is dead from here on: the stage may be written */
@@ -1121,38 +1696,54 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_emit_kernel(
     const u64 room = it.out_cap > cbase ? it.out_cap - cbase : 0;
     const u32 writable = room < chunk_symbols ? (u32)room : chunk_symbols;
 
+    HUFD_STAMP(1, 2);
+    /*
+     * The walk proper.  dec_sync already counted the symbols of the true path that start in
+     * this sub-chunk, and every one of them is a valid, complete code, so the loop runs a
+     * fixed count with no per-symbol stop test: window -> table -> symbol byte -> shift.
+     */
     const u32 my_entry = l_entry[lane];
-    if (my_entry & 0x100u) {
-        const long long remaining = (long long)(valid * 8) - (long long)lane * HUFD_DEC_SUB_BITS;
-        const u64 sub_bit = (chunk_off + (u64)lane * HUFD_DEC_SUB_BYTES) * 8; /* stream bit of the sub-chunk start */
-        u32 pos = my_entry & 0xFFu;
-        u32 idx = l_base[lane]; /* symbol number inside the chunk */
-        while (pos < HUFD_DEC_SUB_BITS) {
-            u32 sym = 0, why = 0;
-            const u32 len = walk_step(timg, lut, tb.lut_bits, lane, pos, remaining, &sym, &why);
-            if (!len) {
-                hufd_dec_result *rs = &results[item_index];
-                rs->stop_kind = why;
-                rs->stop_bit = sub_bit + pos;
-                break;
-            }
-            if (idx < writable) {
-                if (staged) {
-                    stage[mis + idx] = (u8)sym;
-                } else {
-                    out_ptr[idx] = (u8)sym;
-                }
-            } else if (cbase + idx == it.out_cap) {
-                results[item_index].cap_bit = sub_bit + pos; /* source/huffman.c:257-268 fires on this symbol */
-                break;
-            } else {
-                break;
-            }
-            pos += len;
-            ++idx;
+    const bool reached = (my_entry & 0x100u) != 0;
+    const u32 n = reached ? l_cnt[lane] : 0;
+    const u32 base = l_base[lane];
+    const u32 n_store = base >= writable ? 0 : (writable - base < n ? writable - base : n);
+    u32 pos = my_entry & 0xFFu;
+    bit_reader br;
+    br.start(timg, lane, pos);
+    const u32 shift = 32 - tb.lut_bits;
+    if (staged) {
+        u8 *dst = stage + mis + base;
+        for (u32 k = 0; k < n_store; ++k) {
+            const u32 e = lut[br.peek() >> shift];
+            dst[k] = (u8)(e >> 8);
+            pos += e & 0xFFu;
+            br.skip(timg, lane, e & 0xFFu);
+        }
+    } else {
+        u8 *dst = out_ptr + base; /* more symbols than the stage holds: straight to memory */
+        for (u32 k = 0; k < n_store; ++k) {
+            const u32 e = lut[br.peek() >> shift];
+            dst[k] = (u8)(e >> 8);
+            pos += e & 0xFFu;
+            br.skip(timg, lane, e & 0xFFu);
         }
     }
+    if (reached) {
+        const u64 sub_bit = (chunk_off + (u64)lane * HUFD_DEC_SUB_BYTES) * 8; /* stream bit of the sub-chunk start */
+        if (n_store < n) {
+            if (cbase + base + n_store == it.out_cap) {
+                results[item_index].cap_bit = sub_bit + pos; /* source/huffman.c:257-268 fires on this symbol */
+            }
+        } else if (my_entry & 0x200u) {
+            u32 sym = 0, why = HUFD_STOP_NONE;
+            (void)code_at(br.peek(), lut, tb.lut_bits, pos, clamp_remaining(valid, lane), &sym, &why);
+            results[item_index].stop_kind = why;
+            results[item_index].stop_bit = sub_bit + pos;
+        }
+    }
+    HUFD_STAMP(1, 3);
     __syncthreads();
+    HUFD_STAMP(1, 4);
 
     if (staged && writable) {
         /* stage byte b belongs at (out_ptr - mis) + b: whole 16-byte rows go out aligned */
@@ -1175,6 +1766,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_emit_kernel(
             }
         }
     }
+    HUFD_STAMP(1, 5);
 }
 
 /* ------------------------------------------------------------------ synthetic input */
@@ -1200,11 +1792,31 @@ __global__ __launch_bounds__(256) void splitmix64_fill_kernel(u8 *dst, u64 len, 
 
 /* ------------------------------------------------------------------ launch wrappers */
 
+static int s_compute_units = 256;
+
+/* workgroups of a persistent kernel that one launch keeps resident: CUs x blocks per CU */
+template <typename Kernel>
+static uint32_t persistent_grid(Kernel kernel, uint32_t threads, uint32_t lds_bytes, uint32_t work_items) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)threads, lds_bytes) != hipSuccess ||
+        per_cu < 1) {
+        per_cu = 1;
+    }
+    const uint64_t resident = (uint64_t)s_compute_units * (uint32_t)per_cu;
+    return (uint32_t)(work_items < resident ? work_items : resident);
+}
+
 extern "C" {
 
 int hufk_init(void) {
     /* a workgroup may use up to 160 KiB of LDS on gfx950, but dynamic LDS above 64 KiB is opt-in */
     const int lds_max = 160 * 1024;
+    int device = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&device) == hipSuccess && hipGetDeviceProperties(&prop, device) == hipSuccess &&
+        prop.multiProcessorCount > 0) {
+        s_compute_units = prop.multiProcessorCount;
+    }
     hipError_t e = hipFuncSetAttribute(
         reinterpret_cast<const void *>(&dec_emit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     if (e == hipSuccess) {
@@ -1218,6 +1830,11 @@ int hufk_init(void) {
     if (e == hipSuccess) {
         e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&enc_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    }
+    if (e == hipSuccess) {
+        e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&enc_pack_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            lds_max);
     }
     return (int)e;
 }
@@ -1233,14 +1850,19 @@ static uint32_t enc_pack_lds_bytes(uint32_t img_words) {
     return ((img_words * 4 + 15) & ~15u) + 256 * 8 + 8 * 4 + (uint32_t)sizeof(enc_pack_shared) + 16;
 }
 
+static uint32_t enc_stream_lds_bytes(uint32_t img_words) {
+    return ((img_words * 4 + 15) & ~15u) + (HUFD_ENC_SEG_BYTES + 16) + 256 * 4 + 8 * 4 +
+           (uint32_t)sizeof(enc_pack_shared) + 16;
+}
+
 static uint32_t dec_sync_lds_bytes(const hufd_tables *tb) {
     return kChunkWords * 4 + kMergeWords * HUFD_DEC_LANES * 4 + kMergeWords * HUFD_DEC_LANES * 2 +
-           tb->n_states * HUFD_DEC_LANES * 2 + kGroups * HUFD_DEC_MAX_STATES * 4 + (2u << tb->lut_bits) + 16;
+           tb->n_states * HUFD_DEC_LANES * 2 + kGroups * tb->n_states * 4 + (2u << tb->lut_bits);
 }
 
 static uint32_t dec_emit_lds_bytes(const hufd_tables *tb) {
     return kChunkWords * 4 + HUFD_DEC_STAGE_BYTES + kGroups * HUFD_DEC_MAX_STATES * 4 + kGroups * 8 +
-           HUFD_DEC_LANES * 8 + 16 + (2u << tb->lut_bits) + 16;
+           HUFD_DEC_LANES * 12 + 16 + (2u << tb->lut_bits) + 16;
 }
 
 static void stage_mark(void **events, int index, hipStream_t st) {
@@ -1257,25 +1879,42 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
     stage_mark(a->stage_events, 0, st);
     if (a->n_segs) {
         hipLaunchKernelGGL(
-            enc_count_kernel, dim3(a->n_segs), dim3(HUFD_ENC_THREADS), 256 * 4 + 8 * 4, st, a->tables, a->items,
-            a->seg_item, (const u8 *)a->d_in, a->seg_bits, a->seg_unk);
+            enc_count_kernel, dim3(a->n_segs), dim3(HUFD_ENC_THREADS), 256 * 4 + 8 * 4, st, a->tables, a->segs,
+            (const u8 *)a->d_in, a->seg_bits, a->seg_unk, a->careful_count);
+    } else {
+        (void)hipMemsetAsync(a->careful_count, 0, sizeof(uint32_t), st);
     }
     stage_mark(a->stage_events, 1, st);
     hipLaunchKernelGGL(
         enc_scan_small_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, a->seg_bits,
-        a->seg_unk, a->seg_bitoff, a->states, a->results);
+        a->seg_unk, a->seg_bitoff, a->careful_list, a->careful_count, a->states, a->results);
     if (a->n_large) {
         hipLaunchKernelGGL(
             enc_scan_large_kernel, dim3(a->n_large), dim3(HUFD_SCAN_LARGE_THREADS), 256, st, a->items, a->large_items,
-            a->seg_bits, a->seg_unk, a->seg_bitoff, a->states, a->results);
+            a->seg_bits, a->seg_unk, a->seg_bitoff, a->careful_list, a->careful_count, a->states, a->results);
     }
     stage_mark(a->stage_events, 2, st);
     if (a->n_segs && !a->length_only) {
         const uint32_t img_words = hufk_enc_image_words(a->tables.max_bits);
-        hipLaunchKernelGGL(
-            enc_pack_kernel, dim3(a->n_segs), dim3(HUFD_ENC_THREADS), enc_pack_lds_bytes(img_words), st, a->tables,
-            a->items, a->states, a->seg_item, a->seg_bits, a->seg_bitoff, (const u8 *)a->d_in, (u8 *)a->d_out,
-            a->results, img_words);
+        if (a->tables.max_bits <= 16) {
+            /* streaming packer for everything but the listed segments, then those */
+            const uint32_t lds = enc_stream_lds_bytes(img_words);
+            const uint32_t grid = persistent_grid(enc_pack_stream_kernel, HUFD_ENC_THREADS, lds, a->n_segs);
+            hipLaunchKernelGGL(
+                enc_pack_stream_kernel, dim3(grid), dim3(HUFD_ENC_THREADS), lds, st, a->tables, a->items, a->states,
+                a->segs, a->seg_bits, a->seg_bitoff, (const u8 *)a->d_in, (u8 *)a->d_out, a->results, img_words,
+                a->n_segs);
+            const uint32_t most = 2 * a->n_items < 1024 ? 2 * a->n_items : 1024;
+            hipLaunchKernelGGL(
+                enc_pack_kernel, dim3(most), dim3(HUFD_ENC_THREADS), enc_pack_lds_bytes(img_words), st, a->tables,
+                a->items, a->states, a->segs, a->seg_bits, a->seg_bitoff, (const u8 *)a->d_in, (u8 *)a->d_out,
+                a->results, img_words, a->n_segs, (const u32 *)a->careful_list, (const u32 *)a->careful_count);
+        } else {
+            hipLaunchKernelGGL(
+                enc_pack_kernel, dim3(a->n_segs), dim3(HUFD_ENC_THREADS), enc_pack_lds_bytes(img_words), st, a->tables,
+                a->items, a->states, a->segs, a->seg_bits, a->seg_bitoff, (const u8 *)a->d_in, (u8 *)a->d_out,
+                a->results, img_words, a->n_segs, (const u32 *)nullptr, (const u32 *)nullptr);
+        }
     }
     stage_mark(a->stage_events, 3, st);
     return (int)hipGetLastError();
@@ -1315,6 +1954,14 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     stage_mark(a->stage_events, 3, st);
     return (int)hipGetLastError();
 }
+
+#ifdef HUFD_STAMPS
+/* diagnostic build: hand the kernels a buffer for their clock stamps (3 * 131072 * 8 u64) */
+int hufk_stamps_attach(void *device_buffer) {
+    unsigned long long *p = (unsigned long long *)device_buffer;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(hufd_stamp_rows), &p, sizeof(p));
+}
+#endif
 
 int hufk_fill_splitmix64(void *dst, uint64_t len, uint64_t seed, void *stream) {
     if (len == 0) {

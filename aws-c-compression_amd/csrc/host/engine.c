@@ -186,19 +186,21 @@ void *aws_huffman_amd_engine_stream(struct aws_huffman_amd_engine *eng) {
 
 static void enc_plan_release_device(struct aws_huffman_amd_encode_plan *p) {
     hufs_free(p->d_items);
-    hufs_free(p->d_seg_item);
+    hufs_free(p->d_segs);
     hufs_free(p->d_large);
     hufs_free(p->d_seg_bits);
     hufs_free(p->d_seg_unk);
     hufs_free(p->d_seg_bitoff);
+    hufs_free(p->d_careful);
     hufs_free(p->d_states);
     hufs_free(p->d_results);
     p->d_items = NULL;
-    p->d_seg_item = NULL;
+    p->d_segs = NULL;
     p->d_large = NULL;
     p->d_seg_bits = NULL;
     p->d_seg_unk = NULL;
     p->d_seg_bitoff = NULL;
+    p->d_careful = NULL;
     p->d_states = NULL;
     p->d_results = NULL;
     p->cap_items = p->cap_segs = p->cap_large = 0;
@@ -233,11 +235,11 @@ static int enc_plan_fill(
     }
 
     struct hufd_enc_item *h_items = malloc((n_items ? n_items : 1) * sizeof(*h_items));
-    uint32_t *h_seg_item = malloc((n_segs ? n_segs : 1) * sizeof(uint32_t));
+    struct hufd_enc_seg *h_segs = malloc((n_segs ? n_segs : 1) * sizeof(*h_segs));
     uint32_t *h_large = malloc((n_large ? n_large : 1) * sizeof(uint32_t));
-    if (!h_items || !h_seg_item || !h_large) {
+    if (!h_items || !h_segs || !h_large) {
         free(h_items);
-        free(h_seg_item);
+        free(h_segs);
         free(h_large);
         return aws_raise_error(AWS_ERROR_OOM);
     }
@@ -258,7 +260,17 @@ static int enc_plan_fill(
         dst->n_segs = segs;
         dst->reserved = 0;
         for (uint32_t k = 0; k < segs; ++k) {
-            h_seg_item[seg++] = (uint32_t)i;
+            struct hufd_enc_seg *sd = &h_segs[seg++];
+            const uint64_t off = (uint64_t)k * HUFD_ENC_SEG_BYTES;
+            const uint64_t left = src->in_len > off ? src->in_len - off : 0;
+            const uint64_t after = left > HUFD_ENC_SEG_BYTES ? left - HUFD_ENC_SEG_BYTES : 0;
+            sd->in_off = src->in_offset + off;
+            sd->len = (uint32_t)(left < HUFD_ENC_SEG_BYTES ? left : HUFD_ENC_SEG_BYTES);
+            sd->item = (uint32_t)i;
+            sd->index = k;
+            sd->flags = (k == 0 ? 1u : 0u) | (k + 1 == segs ? 2u : 0u);
+            sd->next_len = (uint32_t)(after < HUFD_ENC_SEG_BYTES ? after : HUFD_ENC_SEG_BYTES);
+            sd->reserved = 0;
         }
         if (segs > HUFD_SCAN_SMALL_MAX) {
             h_large[large++] = (uint32_t)i;
@@ -271,15 +283,16 @@ static int enc_plan_fill(
         enc_plan_release_device(p);
         const size_t ci = n_items ? n_items : 1, cs = n_segs ? n_segs : 1, cl = n_large ? n_large : 1;
         p->d_items = hufs_malloc(ci * sizeof(struct hufd_enc_item));
-        p->d_seg_item = hufs_malloc(cs * sizeof(uint32_t));
+        p->d_segs = hufs_malloc(cs * sizeof(struct hufd_enc_seg));
         p->d_large = hufs_malloc(cl * sizeof(uint32_t));
         p->d_seg_bits = hufs_malloc(cs * sizeof(uint32_t));
         p->d_seg_unk = hufs_malloc(cs * sizeof(uint32_t));
         p->d_seg_bitoff = hufs_malloc(cs * sizeof(uint64_t));
+        p->d_careful = hufs_malloc((2 * ci + 4) * sizeof(uint32_t));
         p->d_states = hufs_malloc(ci * sizeof(struct hufd_enc_item_state));
         p->d_results = hufs_malloc(ci * sizeof(struct hufd_enc_result));
-        if (!p->d_items || !p->d_seg_item || !p->d_large || !p->d_seg_bits || !p->d_seg_unk || !p->d_seg_bitoff ||
-            !p->d_states || !p->d_results) {
+        if (!p->d_items || !p->d_segs || !p->d_large || !p->d_seg_bits || !p->d_seg_unk || !p->d_seg_bitoff ||
+            !p->d_careful || !p->d_states || !p->d_results) {
             err = 2;
         }
         p->cap_items = ci;
@@ -290,7 +303,7 @@ static int enc_plan_fill(
         err = hufs_copy_h2d(p->d_items, h_items, n_items * sizeof(*h_items), eng->stream);
     }
     if (!err) {
-        err = hufs_copy_h2d(p->d_seg_item, h_seg_item, n_segs * sizeof(uint32_t), eng->stream);
+        err = hufs_copy_h2d(p->d_segs, h_segs, n_segs * sizeof(*h_segs), eng->stream);
     }
     if (!err) {
         err = hufs_copy_h2d(p->d_large, h_large, n_large * sizeof(uint32_t), eng->stream);
@@ -299,7 +312,7 @@ static int enc_plan_fill(
         err = hufs_stream_sync(eng->stream);
     }
     free(h_items);
-    free(h_seg_item);
+    free(h_segs);
     free(h_large);
     if (err) {
         return raise_hip(err);
@@ -360,7 +373,7 @@ int aws_huffman_amd_encode_plan_launch_staged(
     a.tables = p->engine->tables;
     a.items = p->d_items;
     a.n_items = p->n_items;
-    a.seg_item = p->d_seg_item;
+    a.segs = p->d_segs;
     a.n_segs = p->n_segs;
     a.large_items = p->d_large;
     a.n_large = p->n_large;
@@ -370,6 +383,8 @@ int aws_huffman_amd_encode_plan_launch_staged(
     a.seg_bits = p->d_seg_bits;
     a.seg_unk = p->d_seg_unk;
     a.seg_bitoff = p->d_seg_bitoff;
+    a.careful_list = p->d_careful;
+    a.careful_count = p->d_careful + 2 * p->cap_items + 3;
     a.states = p->d_states;
     a.results = p->d_results;
     a.stage_events = stage_events;

@@ -39,11 +39,12 @@ struct aws_huffman_amd_encode_plan {
     uint32_t n_items, n_segs, n_large;
     size_t cap_items, cap_segs, cap_large;
     struct hufd_enc_item *d_items;
-    uint32_t *d_seg_item;
+    struct hufd_enc_seg *d_segs;
     uint32_t *d_large;
     uint32_t *d_seg_bits;
     uint32_t *d_seg_unk;
     uint64_t *d_seg_bitoff;
+    uint32_t *d_careful; /* [2 * cap_items + 4]: the list, then its counter in the last word */
     struct hufd_enc_item_state *d_states;
     struct hufd_enc_result *d_results;
 };

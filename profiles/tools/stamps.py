@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Where does a workgroup of the decode kernels spend its cycles?  (diagnostic build only)
+
+Runs encode + decode of a stream through libaws-c-compression-amd-stamps.so (built with
+`make -C aws-c-compression_amd stamps`, -DHUFD_STAMPS) and prints the average number of shader
+clocks between the in-kernel stamps.  Shares only; never quote this build's run time.
+"""
+import ctypes as C
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import harness  # noqa: E402
+
+lib = harness.load_product(os.path.join(REPO, "aws-c-compression_amd", "libaws-c-compression-amd-stamps.so"))
+lib.hufk_stamps_attach.argtypes = [C.c_void_p]
+patterns, lens = harness.load_table()
+eng = harness.Engine(lib, lib.aws_huffman_amd_table_coder_new(patterns, lens))
+import numpy as np
+
+MAX_WG = 131072
+d_rows = eng.alloc(3 * MAX_WG * 8 * 8)
+assert lib.hufk_stamps_attach(d_rows) == 0
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 30
+d_in, d_enc, d_back = eng.alloc(n), eng.alloc(n * 10 // 8 + 64), eng.alloc(n + 64)
+eng.fill_splitmix64(d_in, n, 5)
+ep = eng.encode_plan([dict(in_offset=0, in_len=n, out_offset=0, out_capacity=n * 10 // 8 + 64)])
+eng.encode_launch(ep, d_in, d_enc)
+e_len = eng.encode_results(ep, 1)[0][3]
+dp = eng.decode_plan([dict(in_offset=0, in_len=e_len, out_offset=0, out_capacity=n)])
+
+
+def rows(kernel, n_wg, n_ph):
+    raw = eng.download(d_rows, n_wg * 64, offset=kernel * MAX_WG * 64).view(np.uint64).reshape(n_wg, 8)
+    return raw[:, :n_ph].astype(np.float64)
+
+
+def report(name, r, phases):
+    d = np.diff(r, axis=1)
+    life = r[:, -1] - r[:, 0]
+    print("%s: %.0f clocks per workgroup (median %.0f), wave 0" % (name, life.mean(), np.median(life)))
+    for i, ph in enumerate(phases):
+        print("   %-44s %9.0f  %5.1f %%" % (ph, d[:, i].mean(), 100 * d[:, i].mean() / life.mean()))
+
+
+for _ in range(2):
+    eng.encode_launch(ep, d_in, d_enc)
+    eng.encode_results(ep, 1)
+segs = (n + 16383) // 16384
+r = rows(2, min(segs, 4096), 8)
+r = r[(r[:, 0] > 0) & (r[:, 7] > r[:, 0])]  # persistent kernel: one row per resident workgroup (its last segment)
+report("enc_pack_stream (last segment of each resident workgroup)", r,
+       ["segment + item + input loads, zero image, barrier", "lookups + merge to quads (first half)",
+        "wave scan + barrier (first half)", "place + second half", "wait barrier", "-", "copy out"])
+for _ in range(2):
+    eng.decode_launch(dp, d_enc, d_back)
+    eng.decode_results(dp, 1)
+chunks = (e_len + 32767) // 32768
+report("dec_sync", rows(0, min(chunks, MAX_WG), 6),
+       ["load", "find ref + ref walk", "other states", "wait barrier", "publish + fold"])
+report("dec_emit", rows(1, min(chunks, MAX_WG), 6), ["load", "entry chains", "walk", "wait barrier", "copy out"])

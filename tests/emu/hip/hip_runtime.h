@@ -377,3 +377,15 @@ inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) {
 inline hipError_t hipFuncSetAttribute(const void *, int, int) {
     return hipSuccess;
 }
+struct hipDeviceProp_t {
+    int multiProcessorCount;
+};
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *prop, int) {
+    prop->multiProcessorCount = 3; /* few "CUs": persistent kernels loop several times in the tests */
+    return hipSuccess;
+}
+template <typename Kernel>
+inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *blocks, Kernel, int, size_t) {
+    *blocks = 2;
+    return hipSuccess;
+}
