@@ -1217,26 +1217,47 @@ __device__ __forceinline__ u32 clamp_remaining(u64 valid_bytes, u32 lane) {
  */
 struct bit_reader {
     u64 win;
-    u32 nb;   /* valid bits in win, kept above 32 */
-    u32 next; /* index of the next word of the sub-chunk to append */
+    u32 nb;    /* valid bits in win, kept above 32 */
+    u32 next;  /* index of the sub-chunk word that follows `ahead` */
+    u32 ahead; /* the word that will be appended next: read one refill early, never waited for */
 
+    __device__ __forceinline__ static u32 clamp_row(u32 r) {
+        /* words past index 33 are never needed for a decision (a code starts inside the
+         * sub-chunk and is at most 32 bits long); the read only has to stay in bounds */
+        return r < kSubRows ? r : kSubRows - 1;
+    }
     __device__ __forceinline__ void start(const u32 *timg, u32 lane, u32 pos) {
         const u32 r = pos >> 5;
         win = (((u64)chunk_word(timg, lane, r) << 32) | chunk_word(timg, lane, r + 1)) << (pos & 31);
         nb = 64 - (pos & 31);
-        next = r + 2;
+        ahead = chunk_word(timg, lane, clamp_row(r + 2));
+        next = r + 3;
     }
     __device__ __forceinline__ u32 peek() const {
         return (u32)(win >> 32);
+    }
+    /*
+     * skip() without a branch, for loops whose lanes stop at different times (len may be 0):
+     * the look-ahead word is re-read every step and selected in, so the only control flow
+     * left in the caller's loop is the loop itself.
+     */
+    __device__ __forceinline__ void skip_predicated(const u32 *timg, u32 lane, u32 len) {
+        win <<= len;
+        nb -= len;
+        const bool refill = nb <= 32;
+        const u64 add = (u64)ahead << ((32 - nb) & 31);
+        win |= refill ? add : 0;
+        nb += refill ? 32u : 0u;
+        next += refill ? 1u : 0u;
+        ahead = chunk_word(timg, lane, clamp_row(next - 1));
     }
     __device__ __forceinline__ void skip(const u32 *timg, u32 lane, u32 len) {
         win <<= len;
         nb -= len;
         if (nb <= 32) {
-            /* words past index 32 are never needed for a decision (a code starts inside the
-             * sub-chunk and is at most 32 bits long); the read only has to stay in bounds */
-            win |= (u64)chunk_word(timg, lane, next) << (32 - nb);
+            win |= (u64)ahead << (32 - nb);
             nb += 32;
+            ahead = chunk_word(timg, lane, clamp_row(next));
             ++next;
         }
     }
@@ -1313,97 +1334,118 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
      * Phase A: find a reference path.  A walk from a wrong entry state usually dies on an
      * invalid window within a few symbols, and one that survives has fallen in step with
      * the true path; so try the entry states in order and take the first walk that is still
-     * alive after kMergeBits as the reference, remembering where it stepped.  The states
-     * that died on the way are finished (their function value is STOP).
+     * alive at the end of the merge window as the reference, remembering where it stepped.
+     * The states that died on the way are finished (their function value is STOP).
+     * (A single pass that slides one bit past a dead window looks cheaper but leaves a short
+     * marked tail; 3 % of sub-chunks then have a state that never merges.)
      */
-    u32 ref_state = ns, ref_count = 0, ref_exit = 0;
-    bool ref_stop = false;
+    const u32 shift = 32 - tb.lut_bits;
+    u32 ref_state = 0, ref_pos = 0, ref_steps = 0;
+    bit_reader br;
+    br.start(timg, lane, 0);
     {
-        u32 cand = 0, pos = 0, steps = 0;
-        bit_reader br;
-        br.start(timg, lane, 0);
-        while (cand < ns && pos < kMergeBits) {
-            const u32 w = pos >> 5;
-            const u32 seen = bitmap[w * HUFD_DEC_LANES + lane];
-            if (seen == 0) {
-                cnt_at[w * HUFD_DEC_LANES + lane] = (u16)steps; /* symbols started before this word */
+        u32 cur_word = 0, cur_mask = 0; /* the bitmap word being filled lives in a register */
+        while (ref_state < ns && ref_pos < kMergeBits) {
+            const u32 w = ref_pos >> 5;
+            if (w != cur_word) {
+                bitmap[cur_word * HUFD_DEC_LANES + lane] = cur_mask;
+                cnt_at[w * HUFD_DEC_LANES + lane] = (u16)ref_steps; /* symbols started before word w */
+                cur_word = w;
+                cur_mask = 0;
             }
-            bitmap[w * HUFD_DEC_LANES + lane] = seen | (1u << (pos & 31));
-            u32 sym, why;
-            const u32 len = code_at(br.peek(), lut, tb.lut_bits, pos, rem, &sym, &why);
-            if (!len) {
-                ftab[cand * HUFD_DEC_LANES + lane] = fn_pack(true, 0, steps);
-                for (u32 k = 0; k <= w; ++k) {
+            cur_mask |= 1u << (ref_pos & 31);
+            const u32 len = lut[br.peek() >> shift] & 0xFFu;
+            if (ref_pos >= rem || len == 0 || ref_pos + len > rem) {
+                /* dead: this entry state is finished, the next one starts over */
+                ftab[ref_state * HUFD_DEC_LANES + lane] = fn_pack(true, 0, ref_steps);
+                for (u32 k = 0; k < cur_word; ++k) {
                     bitmap[k * HUFD_DEC_LANES + lane] = 0;
                 }
-                ++cand;
-                pos = cand;
-                steps = 0;
-                br.start(timg, lane, pos);
+                ++ref_state;
+                ref_pos = ref_state;
+                ref_steps = 0;
+                cur_word = 0;
+                cur_mask = 0;
+                br.start(timg, lane, ref_pos);
             } else {
-                pos += len;
-                ++steps;
+                ref_pos += len;
+                ++ref_steps;
                 br.skip(timg, lane, len);
             }
         }
-        if (cand < ns) {
-            ref_state = cand;
-            while (pos < HUFD_DEC_SUB_BITS) {
-                u32 sym, why;
-                const u32 len = code_at(br.peek(), lut, tb.lut_bits, pos, rem, &sym, &why);
-                if (!len) {
-                    ref_stop = true;
-                    break;
-                }
-                pos += len;
-                ++steps;
-                br.skip(timg, lane, len);
-            }
-            ref_count = steps;
-            ref_exit = ref_stop ? 0 : pos - HUFD_DEC_SUB_BITS;
-            ftab[cand * HUFD_DEC_LANES + lane] = fn_pack(ref_stop, ref_exit, ref_count);
+        if (ref_state < ns) {
+            bitmap[cur_word * HUFD_DEC_LANES + lane] = cur_mask;
         }
     }
+    const bool have_ref = ref_state < ns;
 
     HUFD_STAMP(0, 2);
-    /* Phase B: the remaining entry states, one after another per lane, each until it falls
-     * onto the reference path, dies, or leaves the sub-chunk on its own. */
-    {
-        u32 state = ref_state + 1, pos = ref_state + 1, steps = 0;
-        while (state < ns) {
-            bool done = false;
-            u16 res = 0;
-            if (pos >= HUFD_DEC_SUB_BITS) {
-                res = fn_pack(false, pos - HUFD_DEC_SUB_BITS, steps);
-                done = true;
-            } else {
-                if (pos < kMergeBits) {
-                    const u32 m = bitmap[(pos >> 5) * HUFD_DEC_LANES + lane];
-                    if ((m >> (pos & 31)) & 1u) {
-                        const u32 before = cnt_at[(pos >> 5) * HUFD_DEC_LANES + lane] +
-                                           __popc(m & ((1u << (pos & 31)) - 1u));
-                        res = fn_pack(ref_stop, ref_exit, steps + ref_count - before);
-                        done = true;
-                    }
-                }
-                if (!done) {
-                    u32 sym, why;
-                    const u32 len =
-                        code_at(chunk_window(timg, lane, pos), lut, tb.lut_bits, pos, rem, &sym, &why);
-                    if (!len) {
-                        res = fn_pack(true, 0, steps);
-                        done = true;
-                    } else {
-                        pos += len;
-                        ++steps;
-                    }
-                }
-            }
+    /*
+     * Phase B: two independent walkers per lane in ONE loop (the kernel is bound by the
+     * latency of its dependent chains, so two chains per iteration are nearly free):
+     *   R  carries the reference path from the end of the merge window to the end of the
+     *      sub-chunk -- only validity to watch;
+     *   S  takes the entry states one after another, each until it falls onto the reference
+     *      path (bitmap hit), dies, or leaves the sub-chunk on its own.
+     * A state that merged is finished once R knows the reference path's count and exit.
+     * No branch in the body; the loop condition is a wave vote.
+     */
+    const u32 end = rem < HUFD_DEC_SUB_BITS ? rem : HUFD_DEC_SUB_BITS;
+    bool ref_stop = false;
+    bool r_live = have_ref && ref_pos < end;
+    u32 state = ref_state + 1, spos = ref_state + 1, ssteps = 0, merged_mask = 0;
+    while (__any(r_live || state < ns)) {
+        /* ---- R */
+        {
+            const u32 len = lut[br.peek() >> shift] & 0xFFu;
+            const bool bad = len == 0 || ref_pos + len > rem;
+            ref_stop = ref_stop || (r_live && bad);
+            r_live = r_live && !bad;
+            const u32 step = r_live ? len : 0;
+            ref_pos += step;
+            ref_steps += r_live ? 1u : 0u;
+            br.skip_predicated(timg, lane, step);
+            r_live = r_live && ref_pos < end;
+        }
+        /* ---- S */
+        {
+            const bool s_live = state < ns;
+            const bool inside = spos < HUFD_DEC_SUB_BITS;
+            const u32 pw = spos < kMergeBits ? spos >> 5 : 0;
+            const u32 m = bitmap[pw * HUFD_DEC_LANES + lane];
+            const u32 c0 = cnt_at[pw * HUFD_DEC_LANES + lane];
+            const u32 len = lut[chunk_window(timg, lane, inside ? spos : 0) >> shift] & 0xFFu;
+            const bool hit = inside && spos < kMergeBits && ((m >> (spos & 31)) & 1u);
+            const bool dead = inside && !hit && (spos >= rem || len == 0 || spos + len > rem);
+            const bool done = s_live && (!inside || hit || dead);
+            /* provisional value: a merged state keeps (own steps - reference steps before the
+             * merge point) in the count field and is completed after the loop */
+            const u32 before = c0 + __popc(m & ((1u << (spos & 31)) - 1u));
+            const u16 res = !inside ? fn_pack(false, spos - HUFD_DEC_SUB_BITS, ssteps)
+                                    : (hit ? fn_pack(false, 0, (ssteps - before) & 0x7FFu) : fn_pack(true, 0, ssteps));
             if (done) {
                 ftab[state * HUFD_DEC_LANES + lane] = res;
-                ++state;
-                pos = state;
-                steps = 0;
+            }
+            merged_mask |= (done && inside && hit) ? (1u << state) : 0u;
+            const u32 next_state = state + (done ? 1u : 0u);
+            spos = done ? next_state : (s_live ? spos + len : spos);
+            ssteps = done ? 0u : (s_live ? ssteps + 1u : ssteps);
+            state = next_state;
+        }
+    }
+    /* the reference path is known now: complete the states that merged into it */
+    {
+        if (have_ref && ref_pos < HUFD_DEC_SUB_BITS) {
+            ref_stop = true; /* it ended on the last stream bit, or stopped on a bad window */
+        }
+        const u32 ref_exit = ref_stop ? 0 : ref_pos - HUFD_DEC_SUB_BITS;
+        if (have_ref) {
+            ftab[ref_state * HUFD_DEC_LANES + lane] = fn_pack(ref_stop, ref_exit, ref_steps);
+        }
+        for (u32 e = 0; e < ns; ++e) {
+            if ((merged_mask >> e) & 1u) {
+                const u32 delta = ftab[e * HUFD_DEC_LANES + lane] & 0x7FFu;
+                ftab[e * HUFD_DEC_LANES + lane] = fn_pack(ref_stop, ref_exit, (delta + ref_steps) & 0x7FFu);
             }
         }
     }

@@ -221,6 +221,23 @@ inline unsigned long long wave_exchange(unsigned long long mine, unsigned from_l
     return got;
 }
 
+/* one exchange for the whole wave: publish the predicate, then read every lane's */
+inline unsigned long long wave_ballot(bool predicate) {
+    State &s = state();
+    const unsigned base = s.cur->tid & ~(kWave - 1);
+    s.cur->xchg = predicate ? 1 : 0;
+    yield(Wait::kWave);
+    unsigned long long mask = 0;
+    for (unsigned l = 0; l < kWave && base + l < s.block_dim.x; ++l) {
+        /* lanes that have left the kernel count as inactive */
+        if (s.fibers[base + l].wait != Wait::kDone && s.fibers[base + l].xchg) {
+            mask |= 1ull << l;
+        }
+    }
+    yield(Wait::kWave);
+    return mask;
+}
+
 } /* namespace hip_emu */
 
 #define threadIdx (hip_emu::IdxProxy{hip_emu::state().cur->tid, 0, 0})
@@ -265,11 +282,13 @@ inline T __shfl(T v, unsigned src_lane) {
     return ok ? (T)got : v;
 }
 inline unsigned long long __ballot(int predicate) {
-    unsigned long long mask = 0;
-    for (unsigned l = 0; l < hip_emu::kWave; ++l) {
-        mask |= (unsigned long long)(__shfl(predicate ? 1u : 0u, l) & 1u) << l;
-    }
-    return mask;
+    return hip_emu::wave_ballot(predicate != 0);
+}
+inline int __any(int predicate) {
+    return __ballot(predicate) != 0;
+}
+inline int __all(int predicate) {
+    return __ballot(!predicate) == 0;
 }
 
 inline int __popc(unsigned v) {
