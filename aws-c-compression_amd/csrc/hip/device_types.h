@@ -52,6 +52,8 @@ struct hufd_tables {
     uint32_t min_bits;
     uint32_t lut_bits;
     uint32_t n_states; /* max(max_bits, 8) */
+    uint32_t all_coded; /* every one of the 256 symbols has a code */
+    uint32_t reserved;
 };
 
 struct hufd_enc_item {

@@ -29,6 +29,14 @@ struct hufk_encode_args {
     uint64_t *seg_bitoff; /* [n_segs] scratch */
     uint32_t *careful_list;  /* [2 * n_items] scratch: segments for the per-symbol packer */
     uint32_t *careful_count; /* [1] scratch */
+    /* single-pass path (codes of at most 16 bits): */
+    void *zero_block;        /* look-back granules [n_segs] u64, then ticket + error flag, then careful_count */
+    uint64_t zero_bytes;
+    uint64_t *lookback;      /* = zero_block */
+    uint32_t *ticket;        /* [2] inside zero_block */
+    uint8_t *seg_unk_seen;   /* [n_segs] scratch */
+    uint64_t *item_total;    /* [n_items] scratch */
+    uint32_t single_pass;    /* 1: fused count + look-back + pack kernel instead of count / scan / pack */
     struct hufd_enc_item_state *states; /* [n_items] scratch */
     struct hufd_enc_result *results;    /* [n_items] */
     void **stage_events; /* NULL, or 4 hipEvent_t: before count, after count, after scan, after pack */

@@ -499,6 +499,7 @@ __global__ __launch_bounds__(HUFD_SCAN_LARGE_THREADS) void enc_scan_large_kernel
 /* ------------------------------------------------------------------ encode: pack */
 
 struct enc_pack_shared {
+    u64 unk_key;       /* lowest (index in segment << 32 | bit offset in segment) of a symbol without a code */
     u64 unk_before;    /* stream bit at which the item's first bad symbol sits */
     u64 short_consumed;
     u32 short_found;
@@ -688,6 +689,7 @@ __device__ __forceinline__ void pack_write_out(
         hufd_enc_result *rs = &results[seg.item];
         if (status == HUFD_ENC_UNKNOWN && g.is_unk_seg) {
             rs->status = HUFD_ENC_UNKNOWN;
+            rs->consumed = (u64)seg.index * HUFD_ENC_SEG_BYTES + (u32)(sh->unk_key >> 32) + 1;
             rs->produced = limit_bytes;
             rs->ovf_bits = 0;
             rs->ovf_pattern = 0;
@@ -760,6 +762,7 @@ __global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_pack_kernel(
             }
         }
         if (tid == 0) {
+            sh->unk_key = kNoBit;
             sh->unk_before = kNoBit;
             sh->short_found = 0;
             sh->halo_unknown = 0;
@@ -800,8 +803,8 @@ __global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_pack_kernel(
                 const u32 pat = (u32)e[j];
                 if (j < valid) {
                     if (len == 0) {
-                        if (g.is_unk_seg && base + j == st.unk_idx) {
-                            sh->unk_before = g.p0 + rel;
+                        if (g.is_unk_seg) {
+                            atomicMin(&sh->unk_key, ((u64)(base + j) << 32) | rel);
                         }
                     } else {
                         const u32 after = rel + len;
@@ -831,7 +834,11 @@ __global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_pack_kernel(
                 }
             }
         }
+        __syncthreads();
         if (tid == 0) {
+            if (sh->unk_key != kNoBit) {
+                sh->unk_before = g.p0 + (u32)sh->unk_key;
+            }
             pack_last_byte(img, sh, g, seg, it, st, halo, [&](u32 sym) { return tab[sym]; });
         }
         __syncthreads();
@@ -1080,6 +1087,510 @@ __global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_pack_stream_kernel(
         seg_next = seg_after;
         barrier_lds(); /* copy-out has read the image; its stores stay in flight */
     }
+}
+
+/* ------------------------------------------------------------------ encode: single pass */
+
+/*
+ * Look-back granule of one segment: [63:62] flag, [61] "a symbol without a code at or before
+ * this segment", [60:0] bits.  One aligned 8-byte relaxed agent-scope store publishes it and
+ * the same kind of load polls it: the data is the flag (guide: Guideline 16, R2), so no fence
+ * and no dependence on dispatch order or XCD placement.  Zeroed before every launch.
+ */
+constexpr u64 kLbAggregate = 1ull << 62; /* bits = this segment alone */
+constexpr u64 kLbInclusive = 2ull << 62; /* bits = the item's stream up to and including this segment */
+constexpr u64 kLbUnknown = 1ull << 61;
+constexpr u64 kLbBits = (1ull << 61) - 1;
+constexpr u32 kFusedMargin = 64; /* image bit of a segment's first code: room for carried overflow bits in front */
+constexpr u32 kSpinLimit = 1u << 24;
+
+__device__ __forceinline__ void granule_store(u64 *p, u64 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ u64 granule_load(const u64 *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *p;
+#endif
+}
+
+struct fused_shared {
+    u64 lb_part[HUFD_ENC_THREADS / 64]; /* look-back mailbox: each wave's partial sum ... */
+    u32 lb_flag[HUFD_ENC_THREADS / 64]; /* ... bit 0 met an inclusive granule, bit 1 unknown seen, bit 2 timed out */
+    u64 p0;        /* stream bit of the segment's first code, from the look-back */
+    u32 unk_before; /* a symbol without a code in an earlier segment of the item */
+    u32 halo_unknown;
+    u32 failed;     /* a look-back spin ran out */
+};
+
+/*
+ * Copies stream bytes [jlo, jhi) of an item out of an image whose bit 0 is stream bit
+ * `delta` (any alignment): 16-byte rows of the output are assembled from five image words
+ * with one funnel shift that is the same for every row of the segment.
+ */
+template <u32 THREADS>
+__device__ __forceinline__ void image_store_shifted(const u32 *img, u8 *out_ptr, long long delta, u64 jlo, u64 jhi) {
+    if (jhi <= jlo) {
+        return;
+    }
+    auto byte_at = [&](u64 j) -> u8 {
+        const u32 ib = (u32)((long long)(8 * j) - delta);
+        const u64 two = ((u64)img[ib >> 5] << 32) | img[(ib >> 5) + 1];
+        return (u8)((two << (ib & 31)) >> 56);
+    };
+    const uintptr_t a_lo = (uintptr_t)(out_ptr + jlo), a_hi = (uintptr_t)(out_ptr + jhi);
+    const uintptr_t row_lo = (a_lo + 15) & ~(uintptr_t)15, row_hi = a_hi & ~(uintptr_t)15;
+    if (row_lo > row_hi) {
+        for (u64 j = jlo + threadIdx.x; j < jhi; j += THREADS) {
+            out_ptr[j] = byte_at(j);
+        }
+        return;
+    }
+    const u64 j_row_lo = jlo + (row_lo - a_lo), j_row_hi = jlo + (row_hi - a_lo);
+    for (u64 j = jlo + threadIdx.x; j < j_row_lo; j += THREADS) {
+        out_ptr[j] = byte_at(j);
+    }
+    const u32 rows = (u32)((row_hi - row_lo) >> 4);
+    const u32 ib0 = (u32)((long long)(8 * j_row_lo) - delta);
+    const u32 sh = ib0 & 31, w0 = ib0 >> 5;
+    for (u32 r = threadIdx.x; r < rows; r += THREADS) {
+        const u32 *src = img + w0 + 4 * r;
+        const u32 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3], x4 = src[4];
+        uint4 o;
+        o.x = __builtin_bswap32((u32)(((((u64)x0 << 32) | x1) << sh) >> 32));
+        o.y = __builtin_bswap32((u32)(((((u64)x1 << 32) | x2) << sh) >> 32));
+        o.z = __builtin_bswap32((u32)(((((u64)x2 << 32) | x3) << sh) >> 32));
+        o.w = __builtin_bswap32((u32)(((((u64)x3 << 32) | x4) << sh) >> 32));
+        *reinterpret_cast<uint4 *>(row_lo + (uintptr_t)r * 16) = o;
+    }
+    for (u64 j = j_row_hi + threadIdx.x; j < jhi; j += THREADS) {
+        out_ptr[j] = byte_at(j);
+    }
+}
+
+/*
+ * Encode in ONE pass over HBM for coders whose codes fit 16 bits: the segment's symbols are
+ * read once, its bits written once (no separate count and scan kernels).
+ *
+ * Persistent workgroups, static round-robin over the segments (see the comment at the loop).
+ * Per segment:
+ *   symbols arrive in LDS by DMA (requested while the previous segment was packed);
+ *   codes are merged to quads and OR-ed into an LDS image whose bit kFusedMargin is the
+ *   segment's own first bit -- nothing here needs the global offset;
+ *   the segment's bit total is published (aggregate granule); wave 0 adds up the
+ *   predecessors' granules until it meets an inclusive one, publishes its own inclusive
+ *   granule and hands the exclusive offset to the workgroup;
+ *   the copy-out applies the offset as one funnel shift.
+ * Segments that contain a symbol without a code are left to enc_pack_kernel (listed later by
+ * enc_finish_kernel), as is the (consumed, overflow) record of a capacity edge.
+ */
+template <bool HOLES> /* the coder has symbols without a code: watch for them */
+__global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_fused_kernel(
+    hufd_tables tb,
+    const hufd_enc_item *items,
+    const hufd_enc_seg *segs,
+    const u8 *d_in,
+    u8 *d_out,
+    u64 *lookback,  /* [n_segs] zeroed */
+    u32 *ticket,    /* [0] unused, [1] time-out flag; zeroed */
+    u32 *seg_bits,
+    u32 *seg_unk,
+    u64 *seg_bitoff,
+    u8 *seg_unk_seen,
+    u64 *item_total,
+    u32 img_words,
+    u32 n_segs) {
+
+    constexpr u32 kInBytes = HUFD_ENC_SEG_BYTES + 16;
+    u32 *img = reinterpret_cast<u32 *>(dyn_lds);
+    u8 *inbuf = dyn_lds + round16(img_words * 4);
+    u32 *tab32 = reinterpret_cast<u32 *>(inbuf + kInBytes);
+    u32 *slots = tab32 + 256;                     /* [8] wave totals; [8..11] first symbol without a code per wave */
+    fused_shared *sh = reinterpret_cast<fused_shared *>(slots + 16);
+
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    {
+        const u64 ent = tb.enc_table[tid];
+        tab32[tid] = ((u32)(ent >> 32) << 16) | ((u32)ent & 0xFFFFu);
+    }
+    if (tid == 0) {
+        sh->failed = 0;
+    }
+    /*
+     * Static round-robin: workgroup b takes segments b, b + gridDim.x, ...  All segments of
+     * one round are in flight together, so their aggregates appear together and a look-back
+     * only ever waits for work that is already running.  This needs every workgroup resident
+     * (the launch sizes the grid from the occupancy query; VGPR and LDS limit this kernel far
+     * below the SGPR edge where that query over-reports); every spin is bounded and a
+     * time-out makes the host redo the launch with the three-kernel path.
+     */
+    u32 s = blockIdx.x;
+    if (s >= n_segs) {
+        return;
+    }
+    hufd_enc_seg seg = uniform_seg(&segs[s]);
+    stream_request(d_in, inbuf, seg.in_off, seg.len, seg.next_len);
+    __syncthreads(); /* tables staged, first segment landed */
+
+    for (;;) {
+        const bool more = s + gridDim.x < n_segs;
+        const u32 s_next = s + gridDim.x;
+        const hufd_enc_item it = items[seg.item];
+        const u8 *src = d_in + seg.in_off;
+        const bool from_lds = ((uintptr_t)src & 15u) == 0;
+
+        u32 gw[kGroupsPerLane][4], gvalid[kGroupsPerLane];
+        u32 halo[2] = {0, 0};
+        if (from_lds) {
+#pragma unroll
+            for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
+                const u32 base = (gi * HUFD_ENC_THREADS + tid) * 16;
+                gvalid[gi] = base < seg.len ? (seg.len - base < 16 ? seg.len - base : 16) : 0;
+                const uint4 v = *reinterpret_cast<const uint4 *>(inbuf + base);
+                gw[gi][0] = v.x;
+                gw[gi][1] = v.y;
+                gw[gi][2] = v.z;
+                gw[gi][3] = v.w;
+                if (gvalid[gi] < 16) {
+#pragma unroll
+                    for (u32 c = 0; c < 4; ++c) {
+                        const u32 keep = gvalid[gi] > 4 * c ? gvalid[gi] - 4 * c : 0;
+                        gw[gi][c] &= keep >= 4 ? 0xFFFFFFFFu : ((1u << (8 * keep)) - 1u);
+                    }
+                }
+            }
+            if (tid == 0 && seg.next_len) {
+                halo[0] = *reinterpret_cast<const u32 *>(inbuf + HUFD_ENC_SEG_BYTES);
+                halo[1] = *reinterpret_cast<const u32 *>(inbuf + HUFD_ENC_SEG_BYTES + 4);
+            }
+        } else {
+            load_segment_groups(src, seg.len, gw, gvalid);
+            if (tid == 0 && seg.next_len) {
+                const u32 n = seg.next_len < 8 ? seg.next_len : 8;
+                for (u32 j = 0; j < n; ++j) {
+                    halo[j >> 2] |= (u32)src[HUFD_ENC_SEG_BYTES + j] << (8 * (j & 3));
+                }
+            }
+        }
+        {
+            const uint4 zero = {0, 0, 0, 0};
+            for (u32 i = tid; i < img_words / 4; i += HUFD_ENC_THREADS) {
+                reinterpret_cast<uint4 *>(img)[i] = zero;
+            }
+        }
+        if (tid == 0) {
+            sh->halo_unknown = 0;
+        }
+        barrier_lds(); /* every lane holds its symbols: the buffer may be refilled */
+        hufd_enc_seg seg_next = seg;
+        if (more) {
+            seg_next = uniform_seg(&segs[s_next < n_segs ? s_next : n_segs - 1]);
+            stream_request(d_in, inbuf, seg_next.in_off, seg_next.len, seg_next.next_len);
+        }
+
+        /* ---- codes -> quads -> image (relative to the segment's own first bit) */
+        u32 seg_total = 0, min_len = 0xFFFFu, seg_first_unk = HUFD_NONE32;
+#pragma unroll
+        for (u32 half = 0; half < 2; ++half) {
+            u64 qv[2][4];
+            u32 ql[2];
+            u32 packed = 0;
+#pragma unroll
+            for (u32 gg = 0; gg < 2; ++gg) {
+                const u32 gi = 2 * half + gg;
+                u32 group_bits = 0, lens = 0;
+#pragma unroll
+                for (u32 m = 0; m < 4; ++m) {
+                    u32 pv[2], pl[2];
+#pragma unroll
+                    for (u32 h = 0; h < 2; ++h) {
+                        const u32 j = 4 * m + 2 * h;
+                        const u32 ea = j < gvalid[gi] ? tab32[group_byte(gw[gi], j)] : 0xFFFF0000u;
+                        const u32 eb = j + 1 < gvalid[gi] ? tab32[group_byte(gw[gi], j + 1)] : 0xFFFF0000u;
+                        /* an absent symbol is marked with an impossible length; a real zero length
+                         * is a symbol without a code (which one is left to the per-symbol packer) */
+                        const u32 ra = ea >> 16, rb = eb >> 16;
+                        const u32 la = ra == 0xFFFFu ? 0 : ra;
+                        const u32 lb = rb == 0xFFFFu ? 0 : rb;
+                        if (HOLES) {
+                            min_len = ra < min_len ? ra : min_len;
+                            min_len = rb < min_len ? rb : min_len;
+                        }
+                        pv[h] = ((ea & 0xFFFFu) << lb) | (eb & 0xFFFFu);
+                        pl[h] = la + lb;
+                    }
+                    qv[gg][m] = ((u64)pv[0] << pl[1]) | pv[1];
+                    lens |= (pl[0] + pl[1]) << (8 * m);
+                    group_bits += pl[0] + pl[1];
+                }
+                ql[gg] = lens;
+                packed |= group_bits << (16 * gg);
+            }
+            u32 incl = packed;
+#pragma unroll
+            for (u32 d = 1; d < kWave; d <<= 1) {
+                const u32 up = __shfl_up(incl, d);
+                if (lane >= d) {
+                    incl += up;
+                }
+            }
+            if (lane == kWave - 1) {
+                slots[4 * half + wave] = incl;
+            }
+            if (half == 1) {
+                const u32 wu = wave_min(min_len);
+                if (lane == 0) {
+                    slots[8 + wave] = wu; /* 0 = this wave saw a symbol without a code */
+                }
+            }
+            barrier_lds();
+            u32 before[2] = {0, 0}, total[2] = {0, 0};
+#pragma unroll
+            for (u32 w = 0; w < HUFD_ENC_THREADS / kWave; ++w) {
+                const u32 t = slots[4 * half + w];
+                before[0] += w < wave ? (t & 0xFFFFu) : 0;
+                before[1] += w < wave ? (t >> 16) : 0;
+                total[0] += t & 0xFFFFu;
+                total[1] += t >> 16;
+            }
+            if (half == 1) {
+                /* the segment's total is known: tell the successors before placing the rest */
+#pragma unroll
+                for (u32 w = 0; w < HUFD_ENC_THREADS / kWave; ++w) {
+                    if (slots[8 + w] == 0) {
+                        seg_first_unk = 0; /* "somewhere in this segment" */
+                    }
+                }
+                if (tid == 0 && seg.index != 0) {
+                    granule_store(
+                        &lookback[s], kLbAggregate | (seg_first_unk != HUFD_NONE32 ? kLbUnknown : 0) |
+                                          (u64)(seg_total + total[0] + total[1]));
+                }
+            }
+#pragma unroll
+            for (u32 gg = 0; gg < 2; ++gg) {
+                const u32 mine = (packed >> (16 * gg)) & 0xFFFFu;
+                u32 q = kFusedMargin + seg_total + (gg ? total[0] : 0) + before[gg] + ((incl >> (16 * gg)) & 0xFFFFu) - mine;
+#pragma unroll
+                for (u32 m = 0; m < 4; ++m) {
+                    const u32 len = (ql[gg] >> (8 * m)) & 0xFFu;
+                    image_or_quad(img, q, qv[gg][m], len);
+                    q += len;
+                }
+            }
+            seg_total += total[0] + total[1];
+        }
+
+        const bool own_unknown = seg_first_unk != HUFD_NONE32;
+
+        /*
+         * ---- look back: the whole workgroup, 256 predecessors per step (wave w polls the
+         * granules 64 w + lane back).  With a 64-wide window a 1 GiB stream is 1024 sequential
+         * hops of about a microsecond -- measured: the kernel then runs at hop speed.
+         */
+        u64 excl = 0;
+        u32 unk_before = 0;
+        bool failed = false;
+        if (seg.index == 0) {
+            excl = it.ovf_bits;
+        } else {
+            u32 left = seg.index; /* predecessors inside the item not yet added */
+            u32 at = s;           /* add predecessors at-1, at-2, ... */
+            for (;;) {
+                const u32 back = wave * kWave + lane;
+                const bool has = back < left;
+                u64 g = 0;
+                u32 spins = 0;
+                bool timed_out = false;
+                do { /* poll until every predecessor in this wave's window has published something */
+                    g = has ? granule_load(&lookback[at - 1 - back]) : kLbInclusive;
+                    if (++spins > kSpinLimit) {
+                        timed_out = true;
+                        break;
+                    }
+                } while (!__all((g >> 62) != 0));
+                /* the nearest predecessor that already knows its inclusive total ends the search */
+                const u64 incl_mask = __ballot(has && (g >> 62) == 2);
+                const u32 stop = incl_mask ? (u32)__builtin_ctzll(incl_mask) : kWave;
+                const bool counts = has && lane <= stop;
+                u64 part = counts ? (g & kLbBits) : 0;
+                u32 punk = (counts && (g & kLbUnknown)) ? 1u : 0u;
+#pragma unroll
+                for (u32 d = kWave / 2; d > 0; d >>= 1) {
+                    part += __shfl_xor(part, d);
+                    punk |= __shfl_xor(punk, d);
+                }
+                if (lane == 0) {
+                    sh->lb_part[wave] = part;
+                    sh->lb_flag[wave] = (incl_mask ? 1u : 0u) | (punk << 1) | (timed_out ? 4u : 0u);
+                }
+                barrier_lds();
+                bool done = false;
+#pragma unroll
+                for (u32 w = 0; w < HUFD_ENC_THREADS / kWave; ++w) {
+                    if (!done && w * kWave < left) {
+                        excl += sh->lb_part[w];
+                        unk_before |= (sh->lb_flag[w] >> 1) & 1u;
+                        failed = failed || (sh->lb_flag[w] & 4u);
+                        done = (sh->lb_flag[w] & 1u) != 0;
+                    }
+                }
+                barrier_lds(); /* the mailbox is reused by the next step */
+                if (failed) {
+                    break;
+                }
+                if (done) {
+                    break;
+                }
+                if (left <= HUFD_ENC_THREADS) {
+                    excl += it.ovf_bits; /* reached the item's first segment through aggregates only */
+                    break;
+                }
+                left -= HUFD_ENC_THREADS;
+                at -= HUFD_ENC_THREADS;
+            }
+        }
+        if (wave == 0) {
+            const u64 incl_total = excl + seg_total;
+            const u32 unk_incl = unk_before | (own_unknown ? 1u : 0u);
+            if (lane == 0) {
+                granule_store(&lookback[s], kLbInclusive | (unk_incl ? kLbUnknown : 0) | (incl_total & kLbBits));
+                seg_bits[s] = seg_total;
+                seg_unk[s] = seg_first_unk;
+                seg_bitoff[s] = excl;
+                seg_unk_seen[s] = (u8)unk_incl;
+                sh->p0 = excl;
+                sh->unk_before = unk_before;
+                if (failed) {
+                    sh->failed = 1;
+                    ticket[1] = 1;
+                }
+                if (seg.flags & 2u) {
+                    item_total[seg.item] = incl_total;
+                }
+                /* the last byte: next segment's head, or padding when the item ends here cleanly */
+                if (!unk_before && !own_unknown) {
+                    const u64 pend = incl_total;
+                    u32 need = (u32)((8 - (pend & 7)) & 7);
+                    u32 q = kFusedMargin + seg_total;
+                    if (seg.index == 0 && it.ovf_bits) {
+                        image_or_bits(img, kFusedMargin - it.ovf_bits, it.ovf_pattern, it.ovf_bits);
+                    }
+                    if (need && !(seg.flags & 2u)) {
+                        const u32 n = seg.next_len < 8 ? seg.next_len : 8;
+                        for (u32 j = 0; j < n && need; ++j) {
+                            const u32 e = tab32[(halo[j >> 2] >> (8 * (j & 3))) & 0xFFu];
+                            const u32 len = e >> 16;
+                            if (len == 0) {
+                                sh->halo_unknown = 1;
+                                break;
+                            }
+                            image_or_bits(img, q, e & 0xFFFFu, len);
+                            q += len;
+                            need = len >= need ? 0 : need - len;
+                        }
+                    }
+                    const u64 cap_bits = it.out_cap > (~0ull >> 3) ? ~0ull : it.out_cap * 8;
+                    if (need && (seg.flags & 2u) && pend <= cap_bits) {
+                        image_or_bits(img, q, it.eos_padding & ((1u << need) - 1), need);
+                    }
+                }
+            }
+        }
+        /* full barrier: image complete, offset known, and every wave's share of the prefetch
+         * (issued a whole packing ago) has landed */
+        __syncthreads();
+
+        const u64 p0 = sh->p0;
+        const bool skip = sh->unk_before || own_unknown || sh->failed;
+        if (!skip) {
+            const u64 pend = p0 + seg_total;
+            const u64 pa = seg.index == 0 ? 0 : p0;
+            const bool last_seg = (seg.flags & 2u) != 0;
+            const u64 cap_bits = it.out_cap > (~0ull >> 3) ? ~0ull : it.out_cap * 8;
+            const bool clean_end = last_seg && pend <= cap_bits;
+            u64 jhi = last_seg ? (clean_end ? (pend + 7) >> 3 : pend >> 3)
+                               : (sh->halo_unknown ? pend >> 3 : (pend + 7) >> 3);
+            if (jhi > it.out_cap) {
+                jhi = it.out_cap;
+            }
+            const u64 jlo = (pa + 7) >> 3;
+            image_store_shifted<HUFD_ENC_THREADS>(
+                img, d_out + it.out_off, (long long)p0 - (long long)kFusedMargin, jlo, jhi);
+        }
+
+        if (!more) {
+            break;
+        }
+        s = s_next;
+        seg = seg_next;
+        barrier_lds(); /* copy-out has read the image; its stores stay in flight */
+    }
+}
+
+/*
+ * After the single pass: one thread per item turns the item's bit total and the per-segment
+ * records into the outcome of the call (enc_finish_item) and lists the segments the
+ * per-symbol packer has to visit.  The first segment with a symbol without a code and the
+ * segment holding the capacity edge are found by bisection (both records are monotone).
+ */
+__global__ __launch_bounds__(256) void enc_finish_kernel(
+    const hufd_enc_item *items,
+    u32 n_items,
+    const u32 *seg_bits,
+    const u32 *seg_unk,
+    const u64 *seg_bitoff,
+    const u8 *seg_unk_seen,
+    const u64 *item_total,
+    u32 *careful_list,
+    u32 *careful_count,
+    hufd_enc_item_state *states,
+    hufd_enc_result *results) {
+
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) {
+        return;
+    }
+    const hufd_enc_item it = items[i];
+    const u64 total = it.n_segs ? item_total[i] : it.ovf_bits;
+    const u64 cap_bits = it.out_cap > (~0ull >> 3) ? ~0ull : it.out_cap * 8;
+    u32 unk_seg = HUFD_NONE32, edge_seg = HUFD_NONE32;
+    if (it.n_segs && seg_unk_seen[it.first_seg + it.n_segs - 1]) {
+        u32 lo = 0, hi = it.n_segs - 1; /* first k with seen[k] */
+        while (lo < hi) {
+            const u32 mid = (lo + hi) / 2;
+            if (seg_unk_seen[it.first_seg + mid]) {
+                hi = mid;
+            } else {
+                lo = mid + 1;
+            }
+        }
+        unk_seg = it.first_seg + lo;
+    }
+    if (it.n_segs) {
+        /* first k whose end reaches the edge; it holds the edge if its start is below it */
+        u32 lo = 0, hi = it.n_segs;
+        while (lo < hi) {
+            const u32 mid = (lo + hi) / 2;
+            if (seg_bitoff[it.first_seg + mid] + seg_bits[it.first_seg + mid] >= cap_bits) {
+                hi = mid;
+            } else {
+                lo = mid + 1;
+            }
+        }
+        if (lo < it.n_segs && seg_bitoff[it.first_seg + lo] < cap_bits) {
+            edge_seg = it.first_seg + lo;
+        }
+    }
+    const u32 ui = unk_seg != HUFD_NONE32 ? seg_unk[unk_seg] : 0;
+    const u32 ub = unk_seg != HUFD_NONE32 ? seg_bits[unk_seg] : 0;
+    const u64 uo = unk_seg != HUFD_NONE32 ? seg_bitoff[unk_seg] : 0;
+    enc_finish_item(it, total, unk_seg, ui, uo, ub, edge_seg, careful_list, careful_count, &states[i], &results[i]);
 }
 
 /* ------------------------------------------------------------------ decode: shared pieces */
@@ -1878,6 +2389,16 @@ int hufk_init(void) {
             reinterpret_cast<const void *>(&enc_pack_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
             lds_max);
     }
+    if (e == hipSuccess) {
+        e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&enc_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            lds_max);
+    }
+    if (e == hipSuccess) {
+        e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&enc_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            lds_max);
+    }
     return (int)e;
 }
 
@@ -1895,6 +2416,11 @@ static uint32_t enc_pack_lds_bytes(uint32_t img_words) {
 static uint32_t enc_stream_lds_bytes(uint32_t img_words) {
     return ((img_words * 4 + 15) & ~15u) + (HUFD_ENC_SEG_BYTES + 16) + 256 * 4 + 8 * 4 +
            (uint32_t)sizeof(enc_pack_shared) + 16;
+}
+
+static uint32_t enc_fused_lds_bytes(uint32_t img_words) {
+    return ((img_words * 4 + 15) & ~15u) + (HUFD_ENC_SEG_BYTES + 16) + 256 * 4 + 16 * 4 + (uint32_t)sizeof(fused_shared) +
+           16;
 }
 
 static uint32_t dec_sync_lds_bytes(const hufd_tables *tb) {
@@ -1917,6 +2443,39 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a->n_segs == 0 && a->n_items == 0) {
         return 0;
+    }
+    if (a->n_segs && !a->length_only && a->single_pass && a->tables.max_bits <= 16 && a->zero_block) {
+        /* single pass: fused count + offset + pack, then the per-item outcome, then the listed segments */
+        const uint32_t img_words = hufk_enc_image_words(a->tables.max_bits);
+        (void)hipMemsetAsync(a->zero_block, 0, a->zero_bytes, st);
+        stage_mark(a->stage_events, 0, st);
+        const uint32_t lds = enc_fused_lds_bytes(img_words);
+        if (a->tables.all_coded) {
+            const uint32_t grid = persistent_grid(enc_fused_kernel<false>, HUFD_ENC_THREADS, lds, a->n_segs);
+            hipLaunchKernelGGL(
+                enc_fused_kernel<false>, dim3(grid), dim3(HUFD_ENC_THREADS), lds, st, a->tables, a->items, a->segs,
+                (const u8 *)a->d_in, (u8 *)a->d_out, a->lookback, a->ticket, a->seg_bits, a->seg_unk, a->seg_bitoff,
+                a->seg_unk_seen, a->item_total, img_words, a->n_segs);
+        } else {
+            const uint32_t grid = persistent_grid(enc_fused_kernel<true>, HUFD_ENC_THREADS, lds, a->n_segs);
+            hipLaunchKernelGGL(
+                enc_fused_kernel<true>, dim3(grid), dim3(HUFD_ENC_THREADS), lds, st, a->tables, a->items, a->segs,
+                (const u8 *)a->d_in, (u8 *)a->d_out, a->lookback, a->ticket, a->seg_bits, a->seg_unk, a->seg_bitoff,
+                a->seg_unk_seen, a->item_total, img_words, a->n_segs);
+        }
+        stage_mark(a->stage_events, 1, st);
+        hipLaunchKernelGGL(
+            enc_finish_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, a->seg_bits,
+            a->seg_unk, a->seg_bitoff, a->seg_unk_seen, a->item_total, a->careful_list, a->careful_count, a->states,
+            a->results);
+        stage_mark(a->stage_events, 2, st);
+        const uint32_t most = 2 * a->n_items < 1024 ? 2 * a->n_items : 1024;
+        hipLaunchKernelGGL(
+            enc_pack_kernel, dim3(most), dim3(HUFD_ENC_THREADS), enc_pack_lds_bytes(img_words), st, a->tables, a->items,
+            a->states, a->segs, a->seg_bits, a->seg_bitoff, (const u8 *)a->d_in, (u8 *)a->d_out, a->results,
+            img_words, a->n_segs, (const u32 *)a->careful_list, (const u32 *)a->careful_count);
+        stage_mark(a->stage_events, 3, st);
+        return (int)hipGetLastError();
     }
     stage_mark(a->stage_events, 0, st);
     if (a->n_segs) {

@@ -96,6 +96,16 @@ int aws_huffman_amd_engine_new(
     if (max_bits == 0) {
         min_bits = 1;
     }
+    eng->tables.all_coded = 1;
+    for (int sym = 0; sym < 256; ++sym) {
+        if ((eng->enc_table[sym] >> 32) == 0) {
+            eng->tables.all_coded = 0;
+        }
+    }
+    {
+        const char *mode = getenv("AWS_HUFFMAN_AMD_ENCODE");
+        eng->single_pass = mode && strcmp(mode, "single-pass") == 0;
+    }
     eng->tables.max_bits = max_bits;
     eng->tables.min_bits = min_bits;
     eng->tables.n_states = max_bits > 8 ? max_bits : 8;
@@ -192,6 +202,9 @@ static void enc_plan_release_device(struct aws_huffman_amd_encode_plan *p) {
     hufs_free(p->d_seg_unk);
     hufs_free(p->d_seg_bitoff);
     hufs_free(p->d_careful);
+    hufs_free(p->d_zero);
+    hufs_free(p->d_unk_seen);
+    hufs_free(p->d_item_total);
     hufs_free(p->d_states);
     hufs_free(p->d_results);
     p->d_items = NULL;
@@ -201,6 +214,9 @@ static void enc_plan_release_device(struct aws_huffman_amd_encode_plan *p) {
     p->d_seg_unk = NULL;
     p->d_seg_bitoff = NULL;
     p->d_careful = NULL;
+    p->d_zero = NULL;
+    p->d_unk_seen = NULL;
+    p->d_item_total = NULL;
     p->d_states = NULL;
     p->d_results = NULL;
     p->cap_items = p->cap_segs = p->cap_large = 0;
@@ -289,10 +305,13 @@ static int enc_plan_fill(
         p->d_seg_unk = hufs_malloc(cs * sizeof(uint32_t));
         p->d_seg_bitoff = hufs_malloc(cs * sizeof(uint64_t));
         p->d_careful = hufs_malloc((2 * ci + 4) * sizeof(uint32_t));
+        p->d_zero = hufs_malloc(cs * sizeof(uint64_t) + 32);
+        p->d_unk_seen = hufs_malloc(cs);
+        p->d_item_total = hufs_malloc(ci * sizeof(uint64_t));
         p->d_states = hufs_malloc(ci * sizeof(struct hufd_enc_item_state));
         p->d_results = hufs_malloc(ci * sizeof(struct hufd_enc_result));
         if (!p->d_items || !p->d_segs || !p->d_large || !p->d_seg_bits || !p->d_seg_unk || !p->d_seg_bitoff ||
-            !p->d_careful || !p->d_states || !p->d_results) {
+            !p->d_careful || !p->d_zero || !p->d_unk_seen || !p->d_item_total || !p->d_states || !p->d_results) {
             err = 2;
         }
         p->cap_items = ci;
@@ -384,7 +403,17 @@ int aws_huffman_amd_encode_plan_launch_staged(
     a.seg_unk = p->d_seg_unk;
     a.seg_bitoff = p->d_seg_bitoff;
     a.careful_list = p->d_careful;
-    a.careful_count = p->d_careful + 2 * p->cap_items + 3;
+    a.zero_block = p->d_zero;
+    a.zero_bytes = (uint64_t)p->n_segs * sizeof(uint64_t) + 32;
+    a.lookback = (uint64_t *)p->d_zero;
+    a.ticket = (uint32_t *)(p->d_zero + (uint64_t)p->n_segs * sizeof(uint64_t));
+    a.careful_count = a.ticket + 4;
+    a.seg_unk_seen = p->d_unk_seen;
+    a.item_total = p->d_item_total;
+    a.single_pass = p->engine->single_pass && !p->look_back_timed_out;
+    p->last_input = device_input;
+    p->last_output = device_output;
+    p->last_single_pass = a.single_pass && p->n_segs && !length_only && p->engine->tables.max_bits <= 16;
     a.states = p->d_states;
     a.results = p->d_results;
     a.stage_events = stage_events;
@@ -399,7 +428,27 @@ int aws_huffman_amd_encode_plan_raw_results(
     void *stream) {
     void *st = stream ? stream : p->engine->stream;
     hufs_set_device(p->engine->device);
-    int err = hufs_copy_d2h(raw, p->d_results, (size_t)p->n_items * sizeof(*raw), st);
+    int err = 0;
+    if (p->last_single_pass) {
+        /* The fused kernel's workgroups wait on each other's look-back granules. If one gave up
+         * (it raises the flag and leaves its output undefined), redo the launch with the
+         * three-kernel path, which has no cross-workgroup waits, and stay on it. */
+        uint32_t timed_out = 0;
+        const uint8_t *flag = p->d_zero + (uint64_t)p->n_segs * sizeof(uint64_t) + sizeof(uint32_t);
+        err = hufs_copy_d2h(&timed_out, flag, sizeof(timed_out), st);
+        if (!err) {
+            err = hufs_stream_sync(st);
+        }
+        if (!err && timed_out) {
+            p->look_back_timed_out = true;
+            if (aws_huffman_amd_encode_plan_launch_staged(p, p->last_input, p->last_output, false, st, NULL)) {
+                return AWS_OP_ERR;
+            }
+        }
+    }
+    if (!err) {
+        err = hufs_copy_d2h(raw, p->d_results, (size_t)p->n_items * sizeof(*raw), st);
+    }
     if (!err) {
         err = hufs_stream_sync(st);
     }

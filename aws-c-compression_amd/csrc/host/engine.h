@@ -24,6 +24,7 @@ struct aws_huffman_amd_engine {
     void *d_enc_table;
     void *d_dec_lut;
     struct hufd_tables tables;
+    bool single_pass; /* AWS_HUFFMAN_AMD_ENCODE=single-pass: fused encode kernel (measured slower) */
 
     /* scratch of the host-pointer API: one item at a time */
     void *one_in;
@@ -44,9 +45,17 @@ struct aws_huffman_amd_encode_plan {
     uint32_t *d_seg_bits;
     uint32_t *d_seg_unk;
     uint64_t *d_seg_bitoff;
-    uint32_t *d_careful; /* [2 * cap_items + 4]: the list, then its counter in the last word */
+    uint32_t *d_careful; /* [2 * cap_items + 4]: segments for the per-symbol packer */
+    uint8_t *d_zero;     /* look-back granules [cap_segs] u64 | ticket, error flag | careful count: zeroed per launch */
+    uint8_t *d_unk_seen; /* [cap_segs] */
+    uint64_t *d_item_total; /* [cap_items] */
     struct hufd_enc_item_state *d_states;
     struct hufd_enc_result *d_results;
+    /* single-pass bookkeeping: what the last launch was given, and whether look-back ever timed out */
+    const void *last_input;
+    void *last_output;
+    bool last_single_pass;
+    bool look_back_timed_out;
 };
 
 struct aws_huffman_amd_decode_plan {

@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--bytes", type=int, default=GIB, help="stream length per GPU (default 1 GiB, the BASELINE config)")
     ap.add_argument("--cpu-sample-mib", type=int, default=96, help="prefix of the stream timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--library", default=None,
+                    help="shared library to load instead of the HIP build (tests/test_multi_rank.py passes the "
+                         "CPU emulator build to exercise the rank logic where there is no GPU)")
     return ap.parse_args()
 
 
@@ -82,6 +85,14 @@ class Ranks:
         t = self.torch.tensor([x], dtype=self.torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t[0])
+
+    def gather(self, obj):
+        """obj of every rank, in rank order, on every rank."""
+        if not self.dist:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
 
     def close(self):
         if self.dist:
@@ -128,7 +139,7 @@ def main():
     ranks = Ranks(args.gpus)
     import harness  # the HIP library is loaded before anything else can pull in another HIP runtime
 
-    lib = harness.load_product()
+    lib = harness.load_product(args.library)
     if lib.aws_huffman_amd_device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible and the product has no CPU path")
     patterns, lens = harness.load_table()
@@ -204,7 +215,7 @@ def main():
         "dec_sync": e_len, "dec_scan": 0, "dec_emit": e_len + n,
     }
     dominant = max(kernel_ms, key=lambda k: kernel_ms[k])
-    achieved = algo_bytes[dominant] / (kernel_ms[dominant] * 1e-3)
+    achieved = algo_bytes[dominant] / max(kernel_ms[dominant] * 1e-3, 1e-12)
     traffic = None
     pmc_path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
@@ -212,9 +223,12 @@ def main():
 
     ms_per_step = wall / args.steps * 1e3
     total_units = ranks.sum(float(n)) / GIB  # GiB of input symbols per step, all ranks
+    per_rank = ranks.gather({"rank": ranks.rank, "device": ranks.local_rank % ndev, "seed": seed,
+                             "encoded_bytes": e_len, "sha256_encoded": enc_digest,
+                             "encode_ms": round(t_enc_ms, 4), "decode_ms": round(t_dec_ms, 4)})
     out = {
-        "metric": "GiB/s input consumed, encode+decode, 1 GiB random bytes",
-        "value": round(total_units / (wall / args.steps), 3),
+        "metric": "GiB/s input consumed, encode+decode, 1 GiB random bytes; % HBM roofline",
+        "value": round(total_units / (wall / args.steps), 6),
         "unit": "GiB/s",
         "n_gpus": ranks.world,
         "steps": args.steps,
@@ -233,12 +247,13 @@ def main():
             "bit_exact": True,
             "sha256_encoded": enc_digest,
         },
-        "encode_GiBps": round(n / GIB / (t_enc_ms * 1e-3), 2),
-        "decode_GiBps_encoded_in": round(e_len / GIB / (t_dec_ms * 1e-3), 2),
-        "decode_GiBps_symbols_out": round(n / GIB / (t_dec_ms * 1e-3), 2),
-        "encode_path_frac_of_hbm_peak": round((n + e_len) / (t_enc_ms * 1e-3) / HBM_PEAK_BYTES_PER_S, 4),
-        "encode_read_frac_of_hbm_peak": round(n / (t_enc_ms * 1e-3) / HBM_PEAK_BYTES_PER_S, 4),
-        "decode_path_frac_of_hbm_peak": round((n + e_len) / (t_dec_ms * 1e-3) / HBM_PEAK_BYTES_PER_S, 4),
+        "encode_GiBps": round(n / GIB / max(t_enc_ms * 1e-3, 1e-12), 2),
+        "decode_GiBps_encoded_in": round(e_len / GIB / max(t_dec_ms * 1e-3, 1e-12), 2),
+        "decode_GiBps_symbols_out": round(n / GIB / max(t_dec_ms * 1e-3, 1e-12), 2),
+        "encode_path_frac_of_hbm_peak": round((n + e_len) / max(t_enc_ms * 1e-3, 1e-12) / HBM_PEAK_BYTES_PER_S, 4),
+        "encode_read_frac_of_hbm_peak": round(n / max(t_enc_ms * 1e-3, 1e-12) / HBM_PEAK_BYTES_PER_S, 4),
+        "decode_path_frac_of_hbm_peak": round((n + e_len) / max(t_dec_ms * 1e-3, 1e-12) / HBM_PEAK_BYTES_PER_S, 4),
+        "ranks": per_rank,
         "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
         "roofline": {
             "kernel": dominant,

@@ -248,7 +248,7 @@ inline unsigned long long wave_ballot(bool predicate) {
 #define HIP_DYNAMIC_SHARED(type, var) static type *const var = reinterpret_cast<type *>(hip_emu::lds());
 
 #define hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, ...)                                                \
-    hip_emu::launch((grid), (block), (lds_bytes), [&]() { kernel(__VA_ARGS__); })
+    hip_emu::launch((grid), (block), (lds_bytes), [&]() { (kernel)(__VA_ARGS__); })
 
 inline void __syncthreads() {
     hip_emu::yield(hip_emu::Wait::kBlock);
@@ -400,11 +400,13 @@ struct hipDeviceProp_t {
     int multiProcessorCount;
 };
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *prop, int) {
-    prop->multiProcessorCount = 3; /* few "CUs": persistent kernels loop several times in the tests */
+    /* one "CU" with one resident workgroup: workgroups run one after another here, so a
+     * persistent kernel whose workgroups wait for each other (look-back) must fit in one */
+    prop->multiProcessorCount = 1;
     return hipSuccess;
 }
 template <typename Kernel>
 inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *blocks, Kernel, int, size_t) {
-    *blocks = 2;
+    *blocks = 1;
     return hipSuccess;
 }

@@ -72,3 +72,18 @@ def test_first_bit_offsets(world):
 def test_large_items_take_the_workgroup_scan(world):
     """More than HUFD_SCAN_SMALL_MAX (64) segments / chunks per item."""
     pc.one_shot_roundtrips(world, sizes=[16384 * 66 + 3, 32768 * 70], seed=21)
+
+
+def test_single_pass_encoder(oracle):
+    """The fused count + look-back + pack kernel (AWS_HUFFMAN_AMD_ENCODE=single-pass): same scenarios."""
+    os.environ["AWS_HUFFMAN_AMD_ENCODE"] = "single-pass"
+    try:
+        product = harness.Codec(harness.load_product(EMU_SO), "aws_")
+        w = pc.World(oracle, product)  # fresh coder objects: fresh engines that read the switch
+        pc.reference_unit_tests(w.product, w.pcoder)
+        pc.one_shot_roundtrips(w, sizes=[1, 17, 4096, 16384, 16385, 40000])
+        pc.streaming_encode(w, sizes=[40, 33000])
+        pc.unknown_symbols(w)
+        pc.batched_device_api(w)
+    finally:
+        del os.environ["AWS_HUFFMAN_AMD_ENCODE"]

@@ -180,3 +180,31 @@ def test_config4_batch_of_16k_buffers(world, engine):
     engine.lib.aws_huffman_amd_decode_plan_destroy(dplan)
     for p in (d_in, d_out, d_back):
         engine.free(p)
+
+
+def test_single_pass_encoder(oracle):
+    """The fused count + look-back + pack kernel (AWS_HUFFMAN_AMD_ENCODE=single-pass) on the GPU,
+    where its workgroups really wait for each other's look-back granules."""
+    os.environ["AWS_HUFFMAN_AMD_ENCODE"] = "single-pass"
+    try:
+        w = pc.World(oracle, harness.Codec(harness.load_product(), "aws_"))
+        pc.one_shot_roundtrips(w, sizes=[1, 17, 16384, 16385, 40000, 3 * 1024 * 1024 + 5])
+        pc.streaming_encode(w, sizes=[40, 33000])
+        pc.unknown_symbols(w)
+        eng = harness.Engine(w.product.lib, w.pcoder)
+        pc.batched_device_api(w, n_items=40, engine=eng)
+        rec = PROBE["streams"]["G1G"]
+        n, e = rec["len"], rec["encoded_len"]
+        d_in, d_enc = eng.alloc(n), eng.alloc(e + 64)
+        eng.fill_splitmix64(d_in, n, rec["seed"])
+        plan = eng.encode_plan([dict(in_offset=0, in_len=n, out_offset=0, out_capacity=e + 64)])
+        eng.encode_launch(plan, d_in, d_enc)
+        (rc, err, consumed, produced, ob, op), = eng.encode_results(plan, 1)
+        assert (rc, consumed, produced) == (0, n, e)
+        h = hashlib.sha256()
+        for off in range(0, e, 256 << 20):
+            h.update(eng.download(d_enc, min(256 << 20, e - off), offset=off).tobytes())
+        assert h.hexdigest() == rec["sha256_encoded"]
+        eng.close()
+    finally:
+        del os.environ["AWS_HUFFMAN_AMD_ENCODE"]
