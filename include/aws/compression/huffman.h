@@ -79,28 +79,24 @@ struct aws_huffman_decoder {
 AWS_EXTERN_C_BEGIN
 
 /* reference huffman.h:91-92, source/huffman.c:12-20.  Zeroes the state, eos_padding = 0xFF. */
-AWS_COMPRESSION_API
-void aws_huffman_encoder_init(struct aws_huffman_encoder *encoder, struct aws_huffman_symbol_coder *coder);
+AWS_COMPRESSION_API void aws_huffman_encoder_init(struct aws_huffman_encoder *encoder, struct aws_huffman_symbol_coder *coder);
 
 /* reference huffman.h:97-98, source/huffman.c:22-27.  Drops pending overflow bits only. */
-AWS_COMPRESSION_API
-void aws_huffman_encoder_reset(struct aws_huffman_encoder *encoder);
+AWS_COMPRESSION_API void aws_huffman_encoder_reset(struct aws_huffman_encoder *encoder);
 
 /* reference huffman.h:103-104, source/huffman.c:29-36.  Zeroes the state (allow_growth = false). */
-AWS_COMPRESSION_API
-void aws_huffman_decoder_init(struct aws_huffman_decoder *decoder, struct aws_huffman_symbol_coder *coder);
+AWS_COMPRESSION_API void aws_huffman_decoder_init(struct aws_huffman_decoder *decoder, struct aws_huffman_symbol_coder *coder);
 
 /* reference huffman.h:109-110, source/huffman.c:38-42.  Drops the read-ahead bits only. */
-AWS_COMPRESSION_API
-void aws_huffman_decoder_reset(struct aws_huffman_decoder *decoder);
+AWS_COMPRESSION_API void aws_huffman_decoder_reset(struct aws_huffman_decoder *decoder);
 
 /*
  * reference huffman.h:120-121, source/huffman.c:107-129.
  * ceil(sum of code lengths / 8) for the bytes under `to_encode`; pending
  * overflow bits are not counted.
  */
-AWS_COMPRESSION_API
-size_t aws_huffman_get_encoded_length(struct aws_huffman_encoder *encoder, struct aws_byte_cursor to_encode);
+AWS_COMPRESSION_API size_t aws_huffman_get_encoded_length(struct aws_huffman_encoder *encoder,
+                                                          struct aws_byte_cursor to_encode);
 
 /*
  * reference huffman.h:132-136, source/huffman.c:131-187.
@@ -110,11 +106,8 @@ size_t aws_huffman_get_encoded_length(struct aws_huffman_encoder *encoder, struc
  * output filled first: call again with more room, same encoder, same cursor.
  * AWS_OP_ERR + AWS_ERROR_COMPRESSION_UNKNOWN_SYMBOL for a symbol without a code.
  */
-AWS_COMPRESSION_API
-int aws_huffman_encode(
-    struct aws_huffman_encoder *encoder,
-    struct aws_byte_cursor *to_encode,
-    struct aws_byte_buf *output);
+AWS_COMPRESSION_API int aws_huffman_encode(struct aws_huffman_encoder *encoder, struct aws_byte_cursor *to_encode,
+                                           struct aws_byte_buf *output);
 
 /*
  * reference huffman.h:148-152, source/huffman.c:213-286.
@@ -125,15 +118,11 @@ int aws_huffman_encode(
  * is full and growth is off; AWS_OP_ERR + AWS_ERROR_COMPRESSION_UNKNOWN_SYMBOL
  * when 32 or more bits remain and they start with no valid code.
  */
-AWS_COMPRESSION_API
-int aws_huffman_decode(
-    struct aws_huffman_decoder *decoder,
-    struct aws_byte_cursor *to_decode,
-    struct aws_byte_buf *output);
+AWS_COMPRESSION_API int aws_huffman_decode(struct aws_huffman_decoder *decoder, struct aws_byte_cursor *to_decode,
+                                           struct aws_byte_buf *output);
 
 /* reference huffman.h:158-159, source/huffman.c:44-46.  Off by default. */
-AWS_COMPRESSION_API
-void aws_huffman_decoder_allow_growth(struct aws_huffman_decoder *decoder, bool allow_growth);
+AWS_COMPRESSION_API void aws_huffman_decoder_allow_growth(struct aws_huffman_decoder *decoder, bool allow_growth);
 
 AWS_EXTERN_C_END
 AWS_POP_SANE_WARNING_LEVEL
