@@ -1599,7 +1599,6 @@ constexpr u32 kSubWords = HUFD_DEC_SUB_BYTES / 4;    /* 32 */
 constexpr u32 kSubRows = kSubWords + 2;               /* + the first two words of the next sub-chunk */
 constexpr u32 kRowStride = HUFD_DEC_LANES + 1;        /* word r of lane i at r * 257 + i: coalesced loads transpose without bank conflicts */
 constexpr u32 kChunkWords = (kSubRows * kRowStride + 3u) & ~3u; /* what follows it in LDS stays 16-byte aligned */
-constexpr u32 kMergeWords = 7;                        /* reference-path bitmap covers the first 224 bits */
 constexpr u32 kGroupLanes = 16;
 constexpr u32 kGroups = HUFD_DEC_LANES / kGroupLanes;
 
@@ -1806,6 +1805,26 @@ __device__ __forceinline__ u32 wide_pack(const fold_result &r) {
 
 /* ------------------------------------------------------------------ decode: sync */
 
+/*
+ * The transfer function of every sub-chunk: entry state s (the first code starts s bits in)
+ * -> (exit state, symbols started, or STOP).  Two phases per lane:
+ *
+ *   U  all entry states at once.  The walks from the ns possible start bits are followed
+ *      together, lowest head first, so every stream position is looked up once however many
+ *      walks pass through it; heads never sit more than one code length apart, so the set of
+ *      heads is a small bit mask M relative to the lowest head p.  A walk that meets an
+ *      invalid or cut-off window dies (its function value is STOP).  The phase ends as soon
+ *      as ONE head is left: every surviving walk stands on that bit P0, and all that differs
+ *      between them is how many symbols they took to get there (cnt[s]).  This is the
+ *      self-synchronisation of Huffman streams; for the test coder P0 is ~40 bits in.
+ *   R  the single surviving walk from P0 to the end of the sub-chunk: count and exit state,
+ *      shared by all survivors.
+ *
+ * If the heads never collapse (possible for degenerate streams) phase U simply runs to the end
+ * of the sub-chunk and every walk keeps its own exit state.  (source/huffman.c:213-286 is the
+ * walk being reproduced; one lane's 128 bytes are one sub-chunk.)
+ */
+template <u32 NS> /* compile-time bound of tb.n_states: the per-state registers are unrolled */
 __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     hufd_tables tb,
     const hufd_dec_item *items,
@@ -1816,9 +1835,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
 
     const u32 ns = tb.n_states;
     u32 *timg = reinterpret_cast<u32 *>(dyn_lds);
-    u32 *bitmap = timg + kChunkWords;                                   /* [kMergeWords][lanes] */
-    u16 *cnt_at = reinterpret_cast<u16 *>(bitmap + kMergeWords * HUFD_DEC_LANES); /* [kMergeWords][lanes] */
-    u16 *ftab = cnt_at + kMergeWords * HUFD_DEC_LANES;                 /* [ns][lanes] */
+    u16 *ftab = reinterpret_cast<u16 *>(timg + kChunkWords);          /* [ns][lanes] */
     u32 *gtab = reinterpret_cast<u32 *>(ftab + ns * HUFD_DEC_LANES); /* [groups][ns] */
     u16 *lut = reinterpret_cast<u16 *>(gtab + kGroups * ns);
 
@@ -1831,133 +1848,80 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     HUFD_STAMP(0, 0);
     chunk_load(timg, d_in + it.in_off + chunk_off, valid);
     lut_load(lut, tb);
-    for (u32 w = 0; w < kMergeWords; ++w) {
-        bitmap[w * HUFD_DEC_LANES + lane] = 0;
-        cnt_at[w * HUFD_DEC_LANES + lane] = 0;
-    }
     __syncthreads();
 
     HUFD_STAMP(0, 1);
     const u32 rem = clamp_remaining(valid, lane);
-    constexpr u32 kMergeBits = kMergeWords * 32;
-
-    /*
-     * Phase A: find a reference path.  A walk from a wrong entry state usually dies on an
-     * invalid window within a few symbols, and one that survives has fallen in step with
-     * the true path; so try the entry states in order and take the first walk that is still
-     * alive at the end of the merge window as the reference, remembering where it stepped.
-     * The states that died on the way are finished (their function value is STOP).
-     * (A single pass that slides one bit past a dead window looks cheaper but leaves a short
-     * marked tail; 3 % of sub-chunks then have a state that never merges.)
-     */
     const u32 shift = 32 - tb.lut_bits;
-    u32 ref_state = 0, ref_pos = 0, ref_steps = 0;
+    constexpr u32 kDead = 0xFFFFFFFFu;  /* pos[] of a walk that has died */
+    constexpr u32 kNobody = 0xFFFFFFFEu; /* a head position no walk is at */
+
+    /* ---- phase U */
+    u32 pos[NS], cnt[NS];
+#pragma unroll
+    for (u32 s = 0; s < NS; ++s) {
+        pos[s] = s < ns ? s : kDead;
+        cnt[s] = 0;
+    }
+    u32 p = 0;                  /* the lowest head */
+    u32 heads = (1u << ns) - 1; /* bit j: some walk stands at p + j; bit 0 is set while any walk lives */
+    bool u_live = true;         /* several heads, the lowest inside the sub-chunk */
     bit_reader br;
     br.start(timg, lane, 0);
-    {
-        u32 cur_word = 0, cur_mask = 0; /* the bitmap word being filled lives in a register */
-        while (ref_state < ns && ref_pos < kMergeBits) {
-            const u32 w = ref_pos >> 5;
-            if (w != cur_word) {
-                bitmap[cur_word * HUFD_DEC_LANES + lane] = cur_mask;
-                cnt_at[w * HUFD_DEC_LANES + lane] = (u16)ref_steps; /* symbols started before word w */
-                cur_word = w;
-                cur_mask = 0;
-            }
-            cur_mask |= 1u << (ref_pos & 31);
-            const u32 len = lut[br.peek() >> shift] & 0xFFu;
-            if (ref_pos >= rem || len == 0 || ref_pos + len > rem) {
-                /* dead: this entry state is finished, the next one starts over */
-                ftab[ref_state * HUFD_DEC_LANES + lane] = fn_pack(true, 0, ref_steps);
-                for (u32 k = 0; k < cur_word; ++k) {
-                    bitmap[k * HUFD_DEC_LANES + lane] = 0;
-                }
-                ++ref_state;
-                ref_pos = ref_state;
-                ref_steps = 0;
-                cur_word = 0;
-                cur_mask = 0;
-                br.start(timg, lane, ref_pos);
-            } else {
-                ref_pos += len;
-                ++ref_steps;
-                br.skip(timg, lane, len);
-            }
+    while (__any(u_live)) {
+        const u32 len = lut[br.peek() >> shift] & 0xFFu;
+        const bool ok = len != 0 && p + len <= rem; /* a whole code of the stream starts at p */
+        const u32 np = ok ? p + len : kDead;
+        const u32 at = u_live ? p : kNobody;
+#pragma unroll
+        for (u32 s = 0; s < NS; ++s) {
+            const bool hit = pos[s] == at;
+            cnt[s] += hit ? 1u : 0u; /* counts the visit that kills it too: taken off below */
+            pos[s] = hit ? np : pos[s];
         }
-        if (ref_state < ns) {
-            bitmap[cur_word * HUFD_DEC_LANES + lane] = cur_mask;
-        }
+        u32 moved = (heads & ~1u) | (ok ? 1u << len : 0u);
+        moved = u_live ? moved : heads;
+        const u32 j = (u_live && moved) ? (u32)__builtin_ctz(moved | 0x80000000u) : 0u;
+        p += j;
+        heads = moved >> j;
+        br.skip_predicated(timg, lane, j);
+        u_live = u_live && (heads & (heads - 1u)) != 0 && p < HUFD_DEC_SUB_BITS;
     }
-    const bool have_ref = ref_state < ns;
-
     HUFD_STAMP(0, 2);
-    /*
-     * Phase B: two independent walkers per lane in ONE loop (the kernel is bound by the
-     * latency of its dependent chains, so two chains per iteration are nearly free):
-     *   R  carries the reference path from the end of the merge window to the end of the
-     *      sub-chunk -- only validity to watch;
-     *   S  takes the entry states one after another, each until it falls onto the reference
-     *      path (bitmap hit), dies, or leaves the sub-chunk on its own.
-     * A state that merged is finished once R knows the reference path's count and exit.
-     * No branch in the body; the loop condition is a wave vote.
-     */
+
+    /* ---- phase R */
     const u32 end = rem < HUFD_DEC_SUB_BITS ? rem : HUFD_DEC_SUB_BITS;
+    const bool have_ref = heads == 1u && p < HUFD_DEC_SUB_BITS;
+    u32 ref_pos = p, ref_steps = 0;
     bool ref_stop = false;
     bool r_live = have_ref && ref_pos < end;
-    u32 state = ref_state + 1, spos = ref_state + 1, ssteps = 0, merged_mask = 0;
-    while (__any(r_live || state < ns)) {
-        /* ---- R */
-        {
-            const u32 len = lut[br.peek() >> shift] & 0xFFu;
-            const bool bad = len == 0 || ref_pos + len > rem;
-            ref_stop = ref_stop || (r_live && bad);
-            r_live = r_live && !bad;
-            const u32 step = r_live ? len : 0;
-            ref_pos += step;
-            ref_steps += r_live ? 1u : 0u;
-            br.skip_predicated(timg, lane, step);
-            r_live = r_live && ref_pos < end;
-        }
-        /* ---- S */
-        {
-            const bool s_live = state < ns;
-            const bool inside = spos < HUFD_DEC_SUB_BITS;
-            const u32 pw = spos < kMergeBits ? spos >> 5 : 0;
-            const u32 m = bitmap[pw * HUFD_DEC_LANES + lane];
-            const u32 c0 = cnt_at[pw * HUFD_DEC_LANES + lane];
-            const u32 len = lut[chunk_window(timg, lane, inside ? spos : 0) >> shift] & 0xFFu;
-            const bool hit = inside && spos < kMergeBits && ((m >> (spos & 31)) & 1u);
-            const bool dead = inside && !hit && (spos >= rem || len == 0 || spos + len > rem);
-            const bool done = s_live && (!inside || hit || dead);
-            /* provisional value: a merged state keeps (own steps - reference steps before the
-             * merge point) in the count field and is completed after the loop */
-            const u32 before = c0 + __popc(m & ((1u << (spos & 31)) - 1u));
-            const u16 res = !inside ? fn_pack(false, spos - HUFD_DEC_SUB_BITS, ssteps)
-                                    : (hit ? fn_pack(false, 0, (ssteps - before) & 0x7FFu) : fn_pack(true, 0, ssteps));
-            if (done) {
-                ftab[state * HUFD_DEC_LANES + lane] = res;
-            }
-            merged_mask |= (done && inside && hit) ? (1u << state) : 0u;
-            const u32 next_state = state + (done ? 1u : 0u);
-            spos = done ? next_state : (s_live ? spos + len : spos);
-            ssteps = done ? 0u : (s_live ? ssteps + 1u : ssteps);
-            state = next_state;
-        }
+    while (__any(r_live)) {
+        const u32 len = lut[br.peek() >> shift] & 0xFFu;
+        const bool bad = len == 0 || ref_pos + len > rem;
+        ref_stop = ref_stop || (r_live && bad);
+        r_live = r_live && !bad;
+        const u32 step = r_live ? len : 0;
+        ref_pos += step;
+        ref_steps += r_live ? 1u : 0u;
+        br.skip_predicated(timg, lane, step);
+        r_live = r_live && ref_pos < end;
     }
-    /* the reference path is known now: complete the states that merged into it */
-    {
-        if (have_ref && ref_pos < HUFD_DEC_SUB_BITS) {
-            ref_stop = true; /* it ended on the last stream bit, or stopped on a bad window */
-        }
-        const u32 ref_exit = ref_stop ? 0 : ref_pos - HUFD_DEC_SUB_BITS;
-        if (have_ref) {
-            ftab[ref_state * HUFD_DEC_LANES + lane] = fn_pack(ref_stop, ref_exit, ref_steps);
-        }
-        for (u32 e = 0; e < ns; ++e) {
-            if ((merged_mask >> e) & 1u) {
-                const u32 delta = ftab[e * HUFD_DEC_LANES + lane] & 0x7FFu;
-                ftab[e * HUFD_DEC_LANES + lane] = fn_pack(ref_stop, ref_exit, (delta + ref_steps) & 0x7FFu);
+    if (have_ref && ref_pos < HUFD_DEC_SUB_BITS) {
+        ref_stop = true; /* it ended on the last stream bit, or stopped on a bad window */
+    }
+    const u32 ref_exit = ref_stop ? 0 : ref_pos - HUFD_DEC_SUB_BITS;
+#pragma unroll
+    for (u32 s = 0; s < NS; ++s) {
+        if (s < ns) {
+            u16 f;
+            if (pos[s] == kDead) {
+                f = fn_pack(true, 0, cnt[s] - 1u);
+            } else if (have_ref) {
+                f = fn_pack(ref_stop, ref_exit, (cnt[s] + ref_steps) & 0x7FFu);
+            } else {
+                f = fn_pack(false, pos[s] - HUFD_DEC_SUB_BITS, cnt[s]); /* it left the sub-chunk on its own */
             }
+            ftab[s * HUFD_DEC_LANES + lane] = f;
         }
     }
     HUFD_STAMP(0, 3);
@@ -2374,7 +2338,15 @@ int hufk_init(void) {
         reinterpret_cast<const void *>(&dec_emit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     if (e == hipSuccess) {
         e = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&dec_sync_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+            reinterpret_cast<const void *>(&dec_sync_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    }
+    if (e == hipSuccess) {
+        e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&dec_sync_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    }
+    if (e == hipSuccess) {
+        e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&dec_sync_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     }
     if (e == hipSuccess) {
         e = hipFuncSetAttribute(
@@ -2424,8 +2396,7 @@ static uint32_t enc_fused_lds_bytes(uint32_t img_words) {
 }
 
 static uint32_t dec_sync_lds_bytes(const hufd_tables *tb) {
-    return kChunkWords * 4 + kMergeWords * HUFD_DEC_LANES * 4 + kMergeWords * HUFD_DEC_LANES * 2 +
-           tb->n_states * HUFD_DEC_LANES * 2 + kGroups * tb->n_states * 4 + (2u << tb->lut_bits);
+    return kChunkWords * 4 + tb->n_states * HUFD_DEC_LANES * 2 + kGroups * tb->n_states * 4 + (2u << tb->lut_bits);
 }
 
 static uint32_t dec_emit_lds_bytes(const hufd_tables *tb) {
@@ -2529,9 +2500,10 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     const uint32_t ns = a->tables.n_states;
     stage_mark(a->stage_events, 0, st);
     if (a->n_chunks) {
+        const auto sync = ns <= 8 ? dec_sync_kernel<8> : (ns <= 10 ? dec_sync_kernel<10> : dec_sync_kernel<12>);
         hipLaunchKernelGGL(
-            dec_sync_kernel, dim3(a->n_chunks), dim3(HUFD_DEC_LANES), dec_sync_lds_bytes(&a->tables), st, a->tables,
-            a->items, a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->chunk_fn);
+            sync, dim3(a->n_chunks), dim3(HUFD_DEC_LANES), dec_sync_lds_bytes(&a->tables), st, a->tables, a->items,
+            a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->chunk_fn);
     }
     stage_mark(a->stage_events, 1, st);
     hipLaunchKernelGGL(
