@@ -1773,6 +1773,41 @@ struct bit_reader {
     }
 };
 
+/*
+ * The same window for loops whose lanes stop at different times, kept as two words and a bit
+ * offset so that a step is a handful of 32-bit operations and no branch: the 32 stream bits
+ * at the cursor are a funnel shift of (hi:lo); crossing into the next word moves lo up and
+ * takes the word that was requested one step earlier.
+ */
+struct lane_window {
+    u32 hi, lo; /* the word the cursor is in, and the one after it */
+    u32 k;      /* cursor, bits into hi: 0..31 */
+    u32 next;   /* sub-chunk word index of `ahead` */
+    u32 ahead;  /* word `next`, re-read every step so that it is there when the cursor crosses */
+
+    __device__ __forceinline__ void start(const u32 *timg, u32 lane, u32 pos) {
+        const u32 r = pos >> 5;
+        hi = chunk_word(timg, lane, r);
+        lo = chunk_word(timg, lane, r + 1);
+        k = pos & 31u;
+        next = r + 2;
+        ahead = chunk_word(timg, lane, bit_reader::clamp_row(next));
+    }
+    __device__ __forceinline__ u32 peek() const {
+        return (u32)(((((u64)hi << 32) | lo) << k) >> 32);
+    }
+    /* advance by len <= 32 bits (0 = stay) */
+    __device__ __forceinline__ void skip(const u32 *timg, u32 lane, u32 len) {
+        k += len;
+        const bool cross = k >= 32u;
+        hi = cross ? lo : hi;
+        lo = cross ? ahead : lo;
+        next += cross ? 1u : 0u;
+        k &= 31u;
+        ahead = chunk_word(timg, lane, bit_reader::clamp_row(next));
+    }
+};
+
 /* result of following a run of transfer functions */
 struct fold_result {
     bool stop;
@@ -1835,8 +1870,8 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
 
     const u32 ns = tb.n_states;
     u32 *timg = reinterpret_cast<u32 *>(dyn_lds);
-    u16 *ftab = reinterpret_cast<u16 *>(timg + kChunkWords);          /* [ns][lanes] */
-    u32 *gtab = reinterpret_cast<u32 *>(ftab + ns * HUFD_DEC_LANES); /* [groups][ns] */
+    u16 *ftab = reinterpret_cast<u16 *>(timg);                       /* [ns][lanes], over the image once the walks are done */
+    u32 *gtab = timg + kChunkWords;                                  /* [groups][ns] */
     u16 *lut = reinterpret_cast<u16 *>(gtab + kGroups * ns);
 
     const u32 lane = threadIdx.x;
@@ -1858,17 +1893,29 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
 
     /* ---- phase U */
     u32 pos[NS], cnt[NS];
+    u32 p = kDead; /* the lowest head */
+    {
+        /* the first code of every entry state at once: independent lookups in the first 64 bits */
+        const u64 first = ((u64)chunk_word(timg, lane, 0) << 32) | chunk_word(timg, lane, 1);
+#pragma unroll
+        for (u32 s = 0; s < NS; ++s) {
+            const u32 len = lut[(u32)((first << s) >> 32) >> shift] & 0xFFu;
+            const bool ok = s < ns && len != 0 && s + len <= rem;
+            pos[s] = ok ? s + len : kDead;
+            cnt[s] = 1; /* a walk that dies has counted the visit that killed it: taken off below */
+            p = pos[s] < p ? pos[s] : p;
+        }
+    }
+    u32 heads = 0; /* bit j: some walk stands at p + j; bit 0 is set while any walk lives */
 #pragma unroll
     for (u32 s = 0; s < NS; ++s) {
-        pos[s] = s < ns ? s : kDead;
-        cnt[s] = 0;
+        heads |= pos[s] != kDead ? 1u << (pos[s] - p) : 0u; /* all within 9 + max_bits of each other */
     }
-    u32 p = 0;                  /* the lowest head */
-    u32 heads = (1u << ns) - 1; /* bit j: some walk stands at p + j; bit 0 is set while any walk lives */
-    bool u_live = true;         /* several heads, the lowest inside the sub-chunk */
-    bit_reader br;
-    br.start(timg, lane, 0);
-    while (__any(u_live)) {
+    p = heads ? p : 0;
+    bool u_live = (heads & (heads - 1u)) != 0; /* several heads, the lowest inside the sub-chunk */
+    lane_window br;
+    br.start(timg, lane, p);
+    if (__any(u_live)) do {
         const u32 len = lut[br.peek() >> shift] & 0xFFu;
         const bool ok = len != 0 && p + len <= rem; /* a whole code of the stream starts at p */
         const u32 np = ok ? p + len : kDead;
@@ -1876,7 +1923,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
 #pragma unroll
         for (u32 s = 0; s < NS; ++s) {
             const bool hit = pos[s] == at;
-            cnt[s] += hit ? 1u : 0u; /* counts the visit that kills it too: taken off below */
+            cnt[s] += hit ? 1u : 0u;
             pos[s] = hit ? np : pos[s];
         }
         u32 moved = (heads & ~1u) | (ok ? 1u << len : 0u);
@@ -1884,9 +1931,9 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
         const u32 j = (u_live && moved) ? (u32)__builtin_ctz(moved | 0x80000000u) : 0u;
         p += j;
         heads = moved >> j;
-        br.skip_predicated(timg, lane, j);
+        br.skip(timg, lane, j);
         u_live = u_live && (heads & (heads - 1u)) != 0 && p < HUFD_DEC_SUB_BITS;
-    }
+    } while (__any(u_live));
     HUFD_STAMP(0, 2);
 
     /* ---- phase R */
@@ -1895,7 +1942,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     u32 ref_pos = p, ref_steps = 0;
     bool ref_stop = false;
     bool r_live = have_ref && ref_pos < end;
-    while (__any(r_live)) {
+    if (__any(r_live)) do {
         const u32 len = lut[br.peek() >> shift] & 0xFFu;
         const bool bad = len == 0 || ref_pos + len > rem;
         ref_stop = ref_stop || (r_live && bad);
@@ -1903,35 +1950,35 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
         const u32 step = r_live ? len : 0;
         ref_pos += step;
         ref_steps += r_live ? 1u : 0u;
-        br.skip_predicated(timg, lane, step);
+        br.skip(timg, lane, step);
         r_live = r_live && ref_pos < end;
-    }
+    } while (__any(r_live));
     if (have_ref && ref_pos < HUFD_DEC_SUB_BITS) {
         ref_stop = true; /* it ended on the last stream bit, or stopped on a bad window */
     }
     const u32 ref_exit = ref_stop ? 0 : ref_pos - HUFD_DEC_SUB_BITS;
+    u16 fn[NS];
 #pragma unroll
     for (u32 s = 0; s < NS; ++s) {
-        if (s < ns) {
-            u16 f;
-            if (pos[s] == kDead) {
-                f = fn_pack(true, 0, cnt[s] - 1u);
-            } else if (have_ref) {
-                f = fn_pack(ref_stop, ref_exit, (cnt[s] + ref_steps) & 0x7FFu);
-            } else {
-                f = fn_pack(false, pos[s] - HUFD_DEC_SUB_BITS, cnt[s]); /* it left the sub-chunk on its own */
-            }
-            ftab[s * HUFD_DEC_LANES + lane] = f;
+        if (pos[s] == kDead) {
+            fn[s] = fn_pack(true, 0, cnt[s] - 1u);
+        } else if (have_ref) {
+            fn[s] = fn_pack(ref_stop, ref_exit, (cnt[s] + ref_steps) & 0x7FFu);
+        } else {
+            fn[s] = fn_pack(false, pos[s] - HUFD_DEC_SUB_BITS, cnt[s]); /* it left the sub-chunk on its own */
         }
     }
     HUFD_STAMP(0, 3);
-    __syncthreads();
+    __syncthreads(); /* every lane is done with the image: its first rows become the function table */
     HUFD_STAMP(0, 4);
-
-    /* publish the per-lane functions for dec_emit */
-    for (u32 sidx = 0; sidx < ns; ++sidx) {
-        fn_tab[((u64)c * ns + sidx) * HUFD_DEC_LANES + lane] = ftab[sidx * HUFD_DEC_LANES + lane];
+#pragma unroll
+    for (u32 s = 0; s < NS; ++s) {
+        if (s < ns) {
+            ftab[s * HUFD_DEC_LANES + lane] = fn[s];
+            fn_tab[((u64)c * ns + s) * HUFD_DEC_LANES + lane] = fn[s]; /* for dec_emit */
+        }
     }
+    __syncthreads();
 
     /* fold 16 lanes per group, then the 16 groups: the chunk's own transfer function */
     if (lane < kGroups * ns) {
@@ -2396,7 +2443,7 @@ static uint32_t enc_fused_lds_bytes(uint32_t img_words) {
 }
 
 static uint32_t dec_sync_lds_bytes(const hufd_tables *tb) {
-    return kChunkWords * 4 + tb->n_states * HUFD_DEC_LANES * 2 + kGroups * tb->n_states * 4 + (2u << tb->lut_bits);
+    return kChunkWords * 4 + kGroups * tb->n_states * 4 + (2u << tb->lut_bits);
 }
 
 static uint32_t dec_emit_lds_bytes(const hufd_tables *tb) {

@@ -58,5 +58,5 @@ for _ in range(2):
     eng.decode_results(dp, 1)
 chunks = (e_len + 32767) // 32768
 report("dec_sync", rows(0, min(chunks, MAX_WG), 6),
-       ["load", "find ref + ref walk", "other states", "wait barrier", "publish + fold"])
+       ["load", "phase U (all entry states to one head)", "phase R (walk to the end)", "wait barrier", "publish + fold"])
 report("dec_emit", rows(1, min(chunks, MAX_WG), 6), ["load", "entry chains", "walk", "wait barrier", "copy out"])

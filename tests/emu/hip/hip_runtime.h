@@ -291,6 +291,11 @@ inline int __all(int predicate) {
     return __ballot(!predicate) == 0;
 }
 
+/* ((hi:lo) << (shift & 31)) >> 32, as the HIP device function of the same name */
+inline unsigned __funnelshift_l(unsigned lo, unsigned hi, unsigned shift) {
+    const unsigned k = shift & 31u;
+    return k ? (hi << k) | (lo >> (32u - k)) : hi;
+}
 inline int __popc(unsigned v) {
     return __builtin_popcount(v);
 }
