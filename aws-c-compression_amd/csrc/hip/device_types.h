@@ -25,6 +25,7 @@
 #define HUFD_DEC_LANES 256u
 #define HUFD_DEC_CHUNK_BYTES (HUFD_DEC_SUB_BYTES * HUFD_DEC_LANES)
 #define HUFD_DEC_MAX_STATES 16u
+#define HUFD_DEC_CP_ROWS 4u /* per sub-chunk: three checkpoints of the walk + the merged-state mask */
 #define HUFD_DEC_MAX_LUT_BITS 12u
 #define HUFD_DEC_STAGE_BYTES 36864u /* LDS bytes for a chunk's decoded symbols (two workgroups per CU) */
 

@@ -53,6 +53,7 @@ struct hufk_decode_args {
     const void *d_in;
     void *d_out;
     uint16_t *fn_tab;      /* [n_chunks][n_states][HUFD_DEC_LANES] scratch */
+    uint16_t *cp_tab;      /* [n_chunks][HUFD_DEC_CP_ROWS][HUFD_DEC_LANES] scratch: walk checkpoints */
     uint32_t *chunk_fn;    /* [n_chunks][n_states] scratch */
     uint32_t *chunk_entry; /* [n_chunks] scratch */
     uint64_t *chunk_base;  /* [n_chunks] scratch */

@@ -1601,6 +1601,10 @@ constexpr u32 kRowStride = HUFD_DEC_LANES + 1;        /* word r of lane i at r *
 constexpr u32 kChunkWords = (kSubRows * kRowStride + 3u) & ~3u; /* what follows it in LDS stays 16-byte aligned */
 constexpr u32 kGroupLanes = 16;
 constexpr u32 kGroups = HUFD_DEC_LANES / kGroupLanes;
+constexpr u32 kQuarters = 4;                          /* dec_emit walks a sub-chunk with this many threads */
+constexpr u32 kQuarterBits = HUFD_DEC_SUB_BITS / kQuarters;
+constexpr u32 kCpRows = HUFD_DEC_CP_ROWS;                    /* kQuarters - 1 checkpoints + the merged-state mask */
+constexpr u32 kEmitThreads = HUFD_DEC_LANES * kQuarters;
 
 /* narrow transfer-function entry (per sub-chunk): [15] stop, [14:11] exit state, [10:0] symbols */
 __device__ __forceinline__ u16 fn_pack(bool stop, u32 exit_state, u32 count) {
@@ -1641,18 +1645,19 @@ __device__ __forceinline__ u32 chunk_window(const u32 *timg, u32 lane, u32 pos) 
  * uint4 number q holds words 4(q&7).. of lane q>>3, and with the 257-word row stride the
  * 32 threads of a store group land on 32 different banks.
  */
+template <u32 THREADS = HUFD_DEC_LANES>
 __device__ __forceinline__ void chunk_load(u32 *timg, const u8 *src, u64 valid_bytes) {
     const u32 t = threadIdx.x;
-    constexpr u32 kPerThread = HUFD_DEC_CHUNK_BYTES / 16 / HUFD_DEC_LANES; /* 8 */
+    constexpr u32 kPerThread = HUFD_DEC_CHUNK_BYTES / 16 / THREADS; /* 8 for 256 threads */
     if (((uintptr_t)src & 15u) == 0 && valid_bytes >= HUFD_DEC_CHUNK_BYTES) {
         uint4 v[kPerThread];
 #pragma unroll
         for (u32 j = 0; j < kPerThread; ++j) {
-            v[j] = reinterpret_cast<const uint4 *>(src)[t + HUFD_DEC_LANES * j];
+            v[j] = reinterpret_cast<const uint4 *>(src)[t + THREADS * j];
         }
 #pragma unroll
         for (u32 j = 0; j < kPerThread; ++j) {
-            const u32 q = t + HUFD_DEC_LANES * j;
+            const u32 q = t + THREADS * j;
             const u32 lane = q >> 3, r0 = 4 * (q & 7);
             const u32 w0 = __builtin_bswap32(v[j].x), w1 = __builtin_bswap32(v[j].y);
             u32 *col = timg + r0 * kRowStride + lane;
@@ -1667,7 +1672,7 @@ __device__ __forceinline__ void chunk_load(u32 *timg, const u8 *src, u64 valid_b
         }
     } else {
         const bool aligned = ((uintptr_t)src & 3u) == 0;
-        for (u32 g = t; g < HUFD_DEC_CHUNK_BYTES / 4; g += HUFD_DEC_LANES) {
+        for (u32 g = t; g < HUFD_DEC_CHUNK_BYTES / 4; g += THREADS) {
             const u32 word = load_be32(src, g, valid_bytes, aligned);
             const u32 lane = g >> 5, r = g & 31;
             timg[r * kRowStride + lane] = word;
@@ -1682,8 +1687,9 @@ __device__ __forceinline__ void chunk_load(u32 *timg, const u8 *src, u64 valid_b
     }
 }
 
+template <u32 THREADS = HUFD_DEC_LANES>
 __device__ __forceinline__ void lut_load(u16 *lut, const hufd_tables &tb) {
-    for (u32 i = threadIdx.x; i < (1u << tb.lut_bits); i += HUFD_DEC_LANES) {
+    for (u32 i = threadIdx.x; i < (1u << tb.lut_bits); i += THREADS) {
         lut[i] = tb.dec_lut[i];
     }
 }
@@ -1866,6 +1872,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     const u32 *chunk_item,
     const u8 *d_in,
     u16 *fn_tab,   /* [chunk][state][lane] */
+    u16 *cp_tab,   /* [chunk][kCpRows][lane]: checkpoints of the reference walk + merged-state mask */
     u32 *chunk_fn) /* [chunk][state] */ {
 
     const u32 ns = tb.n_states;
@@ -1942,17 +1949,36 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     u32 ref_pos = p, ref_steps = 0;
     bool ref_stop = false;
     bool r_live = have_ref && ref_pos < end;
-    if (__any(r_live)) do {
-        const u32 len = lut[br.peek() >> shift] & 0xFFu;
-        const bool bad = len == 0 || ref_pos + len > rem;
-        ref_stop = ref_stop || (r_live && bad);
-        r_live = r_live && !bad;
-        const u32 step = r_live ? len : 0;
-        ref_pos += step;
-        ref_steps += r_live ? 1u : 0u;
-        br.skip(timg, lane, step);
-        r_live = r_live && ref_pos < end;
-    } while (__any(r_live));
+    /*
+     * One bounded loop per quarter of the sub-chunk.  Where the walk stands when it enters a
+     * quarter is a checkpoint: dec_emit starts an extra thread there, so its walks are a
+     * quarter as long.  (Recorded between the loops, so the loop body does not pay for it.)
+     */
+    u32 cp_pos[kQuarters - 1], cp_steps[kQuarters - 1];
+    bool cp_ok[kQuarters - 1];
+#pragma unroll
+    for (u32 qq = 0; qq < kQuarters; ++qq) {
+        const u32 bound = (qq + 1) * kQuarterBits;
+        const u32 lim = bound < end ? bound : end;
+        bool act = r_live && ref_pos < lim;
+        if (__any(act)) do {
+            const u32 len = lut[br.peek() >> shift] & 0xFFu;
+            const bool bad = len == 0 || ref_pos + len > rem;
+            ref_stop = ref_stop || (act && bad);
+            act = act && !bad;
+            const u32 step = act ? len : 0;
+            ref_pos += step;
+            ref_steps += act ? 1u : 0u;
+            br.skip(timg, lane, step);
+            act = act && ref_pos < lim;
+        } while (__any(act));
+        r_live = r_live && !ref_stop && ref_pos < end;
+        if (qq + 1 < kQuarters) {
+            cp_ok[qq] = r_live && ref_pos - bound < 16u; /* the walk goes on, from a code start just past the boundary */
+            cp_pos[qq] = ref_pos;
+            cp_steps[qq] = ref_steps;
+        }
+    }
     if (have_ref && ref_pos < HUFD_DEC_SUB_BITS) {
         ref_stop = true; /* it ended on the last stream bit, or stopped on a bad window */
     }
@@ -1977,6 +2003,22 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
             ftab[s * HUFD_DEC_LANES + lane] = fn[s];
             fn_tab[((u64)c * ns + s) * HUFD_DEC_LANES + lane] = fn[s]; /* for dec_emit */
         }
+    }
+    {
+        /* checkpoint: [15] usable, [14:11] bits past the quarter boundary, [10:0] symbols from it to the end of the walk */
+        u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
+#pragma unroll
+        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+            const u32 tail = ref_steps - cp_steps[qq];
+            cp[qq * HUFD_DEC_LANES] =
+                (u16)(cp_ok[qq] ? 0x8000u | ((cp_pos[qq] - (qq + 1) * kQuarterBits) << 11) | tail : 0u);
+        }
+        u32 merged = 0; /* entry states whose walk runs into the reference walk */
+#pragma unroll
+        for (u32 s = 0; s < NS; ++s) {
+            merged |= (have_ref && pos[s] != kDead) ? 1u << s : 0u;
+        }
+        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)merged;
     }
     __syncthreads();
 
@@ -2162,13 +2204,19 @@ __global__ __launch_bounds__(HUFD_SCAN_LARGE_THREADS) void dec_scan_large_kernel
 
 /* ------------------------------------------------------------------ decode: emit */
 
-__global__ __launch_bounds__(HUFD_DEC_LANES) void dec_emit_kernel(
+/*
+ * kEmitThreads threads per chunk: thread (lane, q) walks the part of lane's sub-chunk between
+ * checkpoint q and the next usable one (q = 0: from the true entry state).  The waves of one
+ * q run the same number of steps, a quarter of what one thread per sub-chunk would.
+ */
+__global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_kernel(
     hufd_tables tb,
     const hufd_dec_item *items,
     const u32 *chunk_item,
     const u8 *d_in,
     u8 *d_out,
     const u16 *fn_tab,
+    const u16 *cp_tab,
     const u32 *chunk_entry,
     const u64 *chunk_base,
     hufd_dec_result *results) {
@@ -2184,9 +2232,11 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_emit_kernel(
     u32 *l_base = l_entry + HUFD_DEC_LANES;                   /* [lanes] */
     u32 *l_cnt = l_base + HUFD_DEC_LANES;                     /* [lanes] */
     u32 *blk_count = l_cnt + HUFD_DEC_LANES;                  /* [4] */
-    u16 *lut = reinterpret_cast<u16 *>(blk_count + 4);
+    u16 *cpt = reinterpret_cast<u16 *>(blk_count + 4);        /* [kCpRows][lanes] */
+    u16 *lut = cpt + kCpRows * HUFD_DEC_LANES;
 
-    const u32 lane = threadIdx.x;
+    const u32 t = threadIdx.x;
+    const u32 lane = t % HUFD_DEC_LANES, q = t / HUFD_DEC_LANES;
     const u32 c = blockIdx.x;
     const u32 entry = chunk_entry[c];
     if (!(entry & 0x100u)) {
@@ -2199,23 +2249,36 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_emit_kernel(
     const u64 cbase = chunk_base[c];
 
     HUFD_STAMP(1, 0);
-    chunk_load(timg, d_in + it.in_off + chunk_off, valid);
-    lut_load(lut, tb);
-    for (u32 sidx = 0; sidx < ns; ++sidx) {
-        ftab[sidx * HUFD_DEC_LANES + lane] = fn_tab[((u64)c * ns + sidx) * HUFD_DEC_LANES + lane];
+    /* the two small tables first, so that their latency hides behind the chunk itself */
+    const u16 my_cp = cp_tab[(u64)c * kCpRows * HUFD_DEC_LANES + t]; /* kCpRows * lanes == threads */
+    u16 my_fn[(HUFD_DEC_MAX_STATES * HUFD_DEC_LANES + kEmitThreads - 1) / kEmitThreads];
+#pragma unroll
+    for (u32 j = 0; j < sizeof(my_fn) / sizeof(my_fn[0]); ++j) {
+        const u32 i = t + j * kEmitThreads;
+        my_fn[j] = i < ns * HUFD_DEC_LANES ? fn_tab[(u64)c * ns * HUFD_DEC_LANES + i] : (u16)0;
+    }
+    chunk_load<kEmitThreads>(timg, d_in + it.in_off + chunk_off, valid);
+    lut_load<kEmitThreads>(lut, tb);
+    cpt[t] = my_cp;
+#pragma unroll
+    for (u32 j = 0; j < sizeof(my_fn) / sizeof(my_fn[0]); ++j) {
+        const u32 i = t + j * kEmitThreads;
+        if (i < ns * HUFD_DEC_LANES) {
+            ftab[i] = my_fn[j];
+        }
     }
     __syncthreads();
     HUFD_STAMP(1, 1);
 
     /* true entry state and output offset of every lane: groups, then lanes */
-    if (lane < kGroups * ns) {
-        const u32 g = lane / ns, start = lane % ns;
+    if (t < kGroups * ns) {
+        const u32 g = t / ns, start = t % ns;
         gtab[g * ns + start] = wide_pack(chain_fold(kGroupLanes, start, [&](u32 i, u32 stt) {
             return widen(ftab[stt * HUFD_DEC_LANES + g * kGroupLanes + i]);
         }));
     }
     __syncthreads();
-    if (lane == 0) {
+    if (t == 0) {
         u32 state = entry & 0xFFu, total = 0;
         bool stopped = false;
         for (u32 g = 0; g < kGroups; ++g) {
@@ -2231,11 +2294,11 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_emit_kernel(
         blk_count[0] = total;
     }
     __syncthreads();
-    if (lane < kGroups) {
-        u32 state = g_entry[lane] & 0xFFu, total = g_base[lane];
-        bool stopped = !(g_entry[lane] & 0x100u);
+    if (t < kGroups) {
+        u32 state = g_entry[t] & 0xFFu, total = g_base[t];
+        bool stopped = !(g_entry[t] & 0x100u);
         for (u32 i = 0; i < kGroupLanes; ++i) {
-            const u32 l = lane * kGroupLanes + i;
+            const u32 l = t * kGroupLanes + i;
             u32 ent = entry_pack(state, !stopped), cnt = 0;
             l_base[l] = total;
             if (!stopped) {
@@ -2265,14 +2328,36 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_emit_kernel(
      * The walk proper.  dec_sync already counted the symbols of the true path that start in
      * this sub-chunk, and every one of them is a valid, complete code, so the loop runs a
      * fixed count with no per-symbol stop test: window -> table -> symbol byte -> shift.
+     * This thread's share: from its checkpoint (q = 0: the lane's entry state) to the next
+     * usable checkpoint.  Checkpoints lie on the reference walk, so they only apply when the
+     * lane's true entry state merged into it.
      */
     const u32 my_entry = l_entry[lane];
     const bool reached = (my_entry & 0x100u) != 0;
-    const u32 n = reached ? l_cnt[lane] : 0;
-    const u32 base = l_base[lane];
+    const u32 lane_n = reached ? l_cnt[lane] : 0;
+    const bool on_ref = ((cpt[(kQuarters - 1) * HUFD_DEC_LANES + lane] >> (my_entry & 0xFFu)) & 1u) != 0;
+    u32 first = 0, pos = my_entry & 0xFFu; /* index of my first symbol within the lane, and its bit */
+    bool mine = reached;
+    if (q > 0) {
+        const u32 cp = cpt[(q - 1) * HUFD_DEC_LANES + lane];
+        mine = reached && on_ref && (cp & 0x8000u) != 0;
+        first = lane_n - (cp & 0x7FFu);
+        pos = q * kQuarterBits + ((cp >> 11) & 15u);
+    }
+    u32 beyond = lane_n; /* index of the first symbol that is no longer mine */
+    bool last_part = true;
+#pragma unroll
+    for (u32 k = kQuarters - 1; k >= 1; --k) {
+        const u32 cp = cpt[(k - 1) * HUFD_DEC_LANES + lane];
+        if (k > q && on_ref && (cp & 0x8000u)) {
+            beyond = lane_n - (cp & 0x7FFu);
+            last_part = false;
+        }
+    }
+    const u32 n = mine ? beyond - first : 0;
+    const u32 base = l_base[lane] + first;
     const u32 n_store = base >= writable ? 0 : (writable - base < n ? writable - base : n);
-    u32 pos = my_entry & 0xFFu;
-    bit_reader br;
+    lane_window br;
     br.start(timg, lane, pos);
     const u32 shift = 32 - tb.lut_bits;
     if (staged) {
@@ -2292,13 +2377,13 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_emit_kernel(
             br.skip(timg, lane, e & 0xFFu);
         }
     }
-    if (reached) {
+    if (mine) {
         const u64 sub_bit = (chunk_off + (u64)lane * HUFD_DEC_SUB_BYTES) * 8; /* stream bit of the sub-chunk start */
         if (n_store < n) {
             if (cbase + base + n_store == it.out_cap) {
                 results[item_index].cap_bit = sub_bit + pos; /* source/huffman.c:257-268 fires on this symbol */
             }
-        } else if (my_entry & 0x200u) {
+        } else if (last_part && (my_entry & 0x200u)) {
             u32 sym = 0, why = HUFD_STOP_NONE;
             (void)code_at(br.peek(), lut, tb.lut_bits, pos, clamp_remaining(valid, lane), &sym, &why);
             results[item_index].stop_kind = why;
@@ -2315,17 +2400,17 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_emit_kernel(
         const u32 lo = mis, hi = mis + writable;
         const u32 row_lo = (lo + 15) >> 4, row_hi = hi >> 4;
         if (row_lo <= row_hi) {
-            for (u32 b = lo + lane; b < row_lo * 16; b += HUFD_DEC_LANES) {
+            for (u32 b = lo + t; b < row_lo * 16; b += kEmitThreads) {
                 gbase[b] = stage[b];
             }
-            for (u32 r = row_lo + lane; r < row_hi; r += HUFD_DEC_LANES) {
+            for (u32 r = row_lo + t; r < row_hi; r += kEmitThreads) {
                 *reinterpret_cast<uint4 *>(gbase + (u64)r * 16) = *reinterpret_cast<const uint4 *>(stage + r * 16);
             }
-            for (u32 b = row_hi * 16 + lane; b < hi; b += HUFD_DEC_LANES) {
+            for (u32 b = row_hi * 16 + t; b < hi; b += kEmitThreads) {
                 gbase[b] = stage[b];
             }
         } else {
-            for (u32 b = lo + lane; b < hi; b += HUFD_DEC_LANES) {
+            for (u32 b = lo + t; b < hi; b += kEmitThreads) {
                 gbase[b] = stage[b];
             }
         }
@@ -2448,7 +2533,7 @@ static uint32_t dec_sync_lds_bytes(const hufd_tables *tb) {
 
 static uint32_t dec_emit_lds_bytes(const hufd_tables *tb) {
     return kChunkWords * 4 + HUFD_DEC_STAGE_BYTES + kGroups * HUFD_DEC_MAX_STATES * 4 + kGroups * 8 +
-           HUFD_DEC_LANES * 12 + 16 + (2u << tb->lut_bits) + 16;
+           HUFD_DEC_LANES * 12 + 16 + kCpRows * HUFD_DEC_LANES * 2 + (2u << tb->lut_bits) + 16;
 }
 
 static void stage_mark(void **events, int index, hipStream_t st) {
@@ -2550,7 +2635,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         const auto sync = ns <= 8 ? dec_sync_kernel<8> : (ns <= 10 ? dec_sync_kernel<10> : dec_sync_kernel<12>);
         hipLaunchKernelGGL(
             sync, dim3(a->n_chunks), dim3(HUFD_DEC_LANES), dec_sync_lds_bytes(&a->tables), st, a->tables, a->items,
-            a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->chunk_fn);
+            a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn);
     }
     stage_mark(a->stage_events, 1, st);
     hipLaunchKernelGGL(
@@ -2567,9 +2652,9 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     stage_mark(a->stage_events, 2, st);
     if (a->n_chunks) {
         hipLaunchKernelGGL(
-            dec_emit_kernel, dim3(a->n_chunks), dim3(HUFD_DEC_LANES), dec_emit_lds_bytes(&a->tables), st, a->tables,
-            a->items, a->chunk_item, (const u8 *)a->d_in, (u8 *)a->d_out, a->fn_tab, a->chunk_entry, a->chunk_base,
-            a->results);
+            dec_emit_kernel, dim3(a->n_chunks), dim3(kEmitThreads), dec_emit_lds_bytes(&a->tables), st, a->tables,
+            a->items, a->chunk_item, (const u8 *)a->d_in, (u8 *)a->d_out, a->fn_tab, a->cp_tab, a->chunk_entry,
+            a->chunk_base, a->results);
     }
     stage_mark(a->stage_events, 3, st);
     return (int)hipGetLastError();

@@ -509,6 +509,7 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     hufs_free(p->d_chunk_item);
     hufs_free(p->d_large);
     hufs_free(p->d_fn_tab);
+    hufs_free(p->d_cp_tab);
     hufs_free(p->d_chunk_fn);
     hufs_free(p->d_chunk_entry);
     hufs_free(p->d_chunk_base);
@@ -518,6 +519,7 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     p->d_chunk_item = NULL;
     p->d_large = NULL;
     p->d_fn_tab = NULL;
+    p->d_cp_tab = NULL;
     p->d_chunk_fn = NULL;
     p->d_chunk_entry = NULL;
     p->d_chunk_base = NULL;
@@ -589,12 +591,13 @@ static int dec_plan_fill(
         p->d_chunk_item = hufs_malloc(cc * sizeof(uint32_t));
         p->d_large = hufs_malloc(cl * sizeof(uint32_t));
         p->d_fn_tab = hufs_malloc(cc * ns * HUFD_DEC_LANES * sizeof(uint16_t));
+        p->d_cp_tab = hufs_malloc(cc * HUFD_DEC_CP_ROWS * HUFD_DEC_LANES * sizeof(uint16_t));
         p->d_chunk_fn = hufs_malloc(cc * ns * sizeof(uint32_t));
         p->d_chunk_entry = hufs_malloc(cc * sizeof(uint32_t));
         p->d_chunk_base = hufs_malloc(cc * sizeof(uint64_t));
         p->d_states = hufs_malloc(ci * sizeof(struct hufd_dec_item_state));
         p->d_results = hufs_malloc(ci * sizeof(struct hufd_dec_result));
-        if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_chunk_fn || !p->d_chunk_entry ||
+        if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_cp_tab || !p->d_chunk_fn || !p->d_chunk_entry ||
             !p->d_chunk_base || !p->d_states || !p->d_results) {
             err = 2;
         }
@@ -692,6 +695,7 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.d_in = device_input;
     a.d_out = device_output;
     a.fn_tab = p->d_fn_tab;
+    a.cp_tab = p->d_cp_tab;
     a.chunk_fn = p->d_chunk_fn;
     a.chunk_entry = p->d_chunk_entry;
     a.chunk_base = p->d_chunk_base;

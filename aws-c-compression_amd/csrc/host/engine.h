@@ -67,6 +67,7 @@ struct aws_huffman_amd_decode_plan {
     uint32_t *d_chunk_item;
     uint32_t *d_large;
     uint16_t *d_fn_tab;
+    uint16_t *d_cp_tab;
     uint32_t *d_chunk_fn;
     uint32_t *d_chunk_entry;
     uint64_t *d_chunk_base;
