@@ -1605,6 +1605,7 @@ constexpr u32 kQuarters = 4;                          /* dec_emit walks a sub-ch
 constexpr u32 kQuarterBits = HUFD_DEC_SUB_BITS / kQuarters;
 constexpr u32 kCpRows = HUFD_DEC_CP_ROWS;                    /* kQuarters - 1 checkpoints + the merged-state mask */
 constexpr u32 kEmitThreads = HUFD_DEC_LANES * kQuarters;
+constexpr u32 kExitStop = 15, kExitNoRef = 14;        /* top nibble of the merged-state row (states are < 13) */
 
 /* narrow transfer-function entry (per sub-chunk): [15] stop, [14:11] exit state, [10:0] symbols */
 __device__ __forceinline__ u16 fn_pack(bool stop, u32 exit_state, u32 count) {
@@ -2018,7 +2019,9 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
         for (u32 s = 0; s < NS; ++s) {
             merged |= (have_ref && pos[s] != kDead) ? 1u << s : 0u;
         }
-        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)merged;
+        /* [15:12] where every merged state comes out: exit state, kExitStop, or kExitNoRef without a reference walk */
+        const u32 common = have_ref ? (ref_stop ? kExitStop : ref_exit) : kExitNoRef;
+        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(merged | (common << 12));
     }
     __syncthreads();
 
@@ -2270,47 +2273,107 @@ __global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_kernel(
     __syncthreads();
     HUFD_STAMP(1, 1);
 
-    /* true entry state and output offset of every lane: groups, then lanes */
-    if (t < kGroups * ns) {
-        const u32 g = t / ns, start = t % ns;
-        gtab[g * ns + start] = wide_pack(chain_fold(kGroupLanes, start, [&](u32 i, u32 stt) {
-            return widen(ftab[stt * HUFD_DEC_LANES + g * kGroupLanes + i]);
-        }));
+    /*
+     * True entry state and output offset of every lane.  Nearly always every lane's true entry
+     * state merges into the lane's reference walk, and then the lane's exit does not depend on
+     * its entry: lane i enters in the state lane i-1's reference walk leaves in.  Assume that
+     * for all lanes at once, check it for all lanes at once, and only walk the chain lane by
+     * lane (the general case below) when some lane does not fit.
+     */
+    const u32 merged_row = (kQuarters - 1) * HUFD_DEC_LANES;
+    bool lane_reached = false;
+    u32 lane_state = 0, lane_count = 0, lane_stop = 0, lane_incl = 0;
+    if (t < HUFD_DEC_LANES) {
+        /* a stop shows as kExitStop in the lane after it */
+        lane_state = t ? (u32)(cpt[merged_row + t - 1] >> 12) : (entry & 0xFFu);
+        l_entry[t] = lane_state == kExitStop ? 1u : 0u; /* borrowed: flags for the search below */
+    }
+    if (t == 0) {
+        blk_count[1] = 0; /* set by any lane that does not fit */
     }
     __syncthreads();
-    if (t == 0) {
-        u32 state = entry & 0xFFu, total = 0;
-        bool stopped = false;
-        for (u32 g = 0; g < kGroups; ++g) {
-            g_entry[g] = entry_pack(state, !stopped);
-            g_base[g] = total;
-            if (!stopped) {
-                const u32 f = gtab[g * ns + state];
-                total += wide_count(f);
-                stopped = wide_stop(f);
-                state = wide_state(f);
+    if (t < HUFD_DEC_LANES) {
+        /* first lane that follows a stop: lanes from there on are not reached */
+        u32 first_unreached = HUFD_DEC_LANES;
+        for (u32 w = HUFD_DEC_LANES / kWave; w-- > 0;) {
+            const u64 b = __ballot(l_entry[w * kWave + (t & (kWave - 1))] != 0);
+            first_unreached = b ? w * kWave + (u32)__builtin_ctzll(b) : first_unreached;
+        }
+        lane_reached = t < first_unreached;
+        const u32 mine_row = cpt[merged_row + t];
+        lane_stop = (mine_row >> 12) == kExitStop ? 1u : 0u;
+        const bool fits = !lane_reached || (lane_state < kExitNoRef && ((mine_row >> lane_state) & 1u));
+        if (!fits) {
+            blk_count[1] = 1;
+        }
+        lane_state = (fits && lane_reached) ? lane_state : 0;
+        lane_count = lane_reached ? (u32)(ftab[lane_state * HUFD_DEC_LANES + t] & 0x7FFu) : 0u;
+        lane_incl = wave_inclusive_sum(lane_count, t & (kWave - 1));
+        if ((t & (kWave - 1)) == kWave - 1) {
+            g_base[t / kWave] = lane_incl;
+        }
+    }
+    __syncthreads();
+    const bool all_fit = blk_count[1] == 0;
+    if (all_fit) {
+        if (t < HUFD_DEC_LANES) {
+            u32 before = 0, total = 0;
+#pragma unroll
+            for (u32 w = 0; w < HUFD_DEC_LANES / kWave; ++w) {
+                const u32 sum = g_base[w];
+                before += w < t / kWave ? sum : 0;
+                total += sum;
+            }
+            l_base[t] = before + lane_incl - lane_count;
+            l_cnt[t] = lane_count;
+            l_entry[t] = entry_pack(lane_reached ? lane_state : 0u, lane_reached) | ((lane_reached && lane_stop) ? 0x200u : 0u);
+            if (t == 0) {
+                blk_count[0] = total;
             }
         }
-        blk_count[0] = total;
-    }
-    __syncthreads();
-    if (t < kGroups) {
-        u32 state = g_entry[t] & 0xFFu, total = g_base[t];
-        bool stopped = !(g_entry[t] & 0x100u);
-        for (u32 i = 0; i < kGroupLanes; ++i) {
-            const u32 l = t * kGroupLanes + i;
-            u32 ent = entry_pack(state, !stopped), cnt = 0;
-            l_base[l] = total;
-            if (!stopped) {
-                const u32 f = widen(ftab[state * HUFD_DEC_LANES + l]);
-                cnt = wide_count(f);
-                total += cnt;
-                stopped = wide_stop(f);
-                state = wide_state(f);
-                ent |= stopped ? 0x200u : 0u; /* the true path ends inside this sub-chunk */
+    } else {
+        /* the general case: fold 16 lanes per group, walk the groups, then the lanes of each group */
+        if (t < kGroups * ns) {
+            const u32 g = t / ns, start = t % ns;
+            gtab[g * ns + start] = wide_pack(chain_fold(kGroupLanes, start, [&](u32 i, u32 stt) {
+                return widen(ftab[stt * HUFD_DEC_LANES + g * kGroupLanes + i]);
+            }));
+        }
+        __syncthreads();
+        if (t == 0) {
+            u32 state = entry & 0xFFu, total = 0;
+            bool stopped = false;
+            for (u32 g = 0; g < kGroups; ++g) {
+                g_entry[g] = entry_pack(state, !stopped);
+                g_base[g] = total;
+                if (!stopped) {
+                    const u32 f = gtab[g * ns + state];
+                    total += wide_count(f);
+                    stopped = wide_stop(f);
+                    state = wide_state(f);
+                }
             }
-            l_entry[l] = ent;
-            l_cnt[l] = cnt;
+            blk_count[0] = total;
+        }
+        __syncthreads();
+        if (t < kGroups) {
+            u32 state = g_entry[t] & 0xFFu, total = g_base[t];
+            bool stopped = !(g_entry[t] & 0x100u);
+            for (u32 i = 0; i < kGroupLanes; ++i) {
+                const u32 l = t * kGroupLanes + i;
+                u32 ent = entry_pack(state, !stopped), cnt = 0;
+                l_base[l] = total;
+                if (!stopped) {
+                    const u32 f = widen(ftab[state * HUFD_DEC_LANES + l]);
+                    cnt = wide_count(f);
+                    total += cnt;
+                    stopped = wide_stop(f);
+                    state = wide_state(f);
+                    ent |= stopped ? 0x200u : 0u; /* the true path ends inside this sub-chunk */
+                }
+                l_entry[l] = ent;
+                l_cnt[l] = cnt;
+            }
         }
     }
     __syncthreads(); /* ftab is dead from here on: the stage may be written */
