@@ -1845,6 +1845,102 @@ __device__ __forceinline__ u32 wide_pack(const fold_result &r) {
     return wide_pack(r.stop, r.state, (u32)r.count);
 }
 
+/* ------------------------------------------------------------------ decode: row-synchronous walk */
+
+/*
+ * Every decode kernel is bound by its vector-instruction count (measured: ~4 cycles per wave
+ * instruction and SIMD, profiles/r01_d_*), so the walk below is written for the fewest of them
+ * per symbol.  All lanes of a wave stand in the SAME 32-bit word ("row") of their sub-chunks at
+ * the same time: the two words a window can touch are loaded once per row at a compile-time
+ * offset, nothing is shifted between registers, and a step is
+ *
+ *      offset = (row pair >> s) & mask;   entry = walk_lut[offset];   state += entry;
+ *
+ * `state` keeps the shift amount for the next window in its low half and the symbols counted so
+ * far in its high half; the table entry is 0x10000 - length, so one add moves both.  The low half
+ * is 64 + (bits from the code start to the end of the pair) - (index width) - 2: the hardware
+ * uses the low six bits of a shift amount, which takes the 64 off again, and the - 2 makes the
+ * masked window a byte offset into the table of 32-bit entries.  A window without a code has
+ * length 48 in this table: the walk leaves the row at once and lands below every position a real
+ * code can produce, which is how a dead walk is told from a live one (once per row, not per step).
+ *
+ * Only for sub-chunks that lie wholly inside the stream with at least 8 bytes after them (every
+ * code that starts in them is whole): no end-of-stream tests anywhere.
+ */
+constexpr u32 kWalkDeadLen = 48;
+
+struct row_walk {
+    u32 thr;    /* a code starts in the current row while (u16)state > thr */
+    u32 mask;   /* index mask, times four */
+    u32 floor;  /* (u16)state after a row is at least this unless the walk died */
+
+    __device__ __forceinline__ row_walk(u32 lut_bits, u32 max_bits) {
+        thr = 64 + (32 - lut_bits) - 2;
+        mask = ((1u << lut_bits) - 1u) << 2;
+        floor = thr - max_bits + 1;
+    }
+    /* state of a walk whose next code starts `k` bits into the current row, `count` symbols so far */
+    __device__ __forceinline__ u32 state_at(u32 k, u32 count) const {
+        return (count << 16) | (thr + 32 - k);
+    }
+    __device__ __forceinline__ u32 offset_of(u32 state) const { /* bits into the current row */
+        return thr + 32 - (state & 0xFFFFu);
+    }
+    /* all codes of the walk that start in the row whose words are hi:lo */
+    __device__ __forceinline__ u32 row(u32 state, u32 hi, u32 lo, const u32 *wlut) const {
+        const u64 pair = ((u64)hi << 32) | lo;
+        while ((state & 0xFFFFu) > thr) {
+            const u32 off = (u32)(pair >> (state & 63u)) & mask;
+            state += *reinterpret_cast<const u32 *>(reinterpret_cast<const u8 *>(wlut) + off);
+        }
+        return state;
+    }
+    __device__ __forceinline__ bool died(u32 state) const {
+        return (state & 0xFFFFu) < floor;
+    }
+    __device__ __forceinline__ u32 next_row(u32 state) const {
+        return state + 32u;
+    }
+};
+
+/* walk table for counting: 0x10000 - length, length 48 where no code matches */
+template <u32 THREADS = HUFD_DEC_LANES>
+__device__ __forceinline__ void walk_lut_load(u32 *wlut, const hufd_tables &tb) {
+    for (u32 i = threadIdx.x; i < (1u << tb.lut_bits); i += THREADS) {
+        const u32 len = tb.dec_lut[i] & 0xFFu;
+        wlut[i] = 0x10000u - (len ? len : kWalkDeadLen);
+    }
+}
+
+/*
+ * The walks from all `ns` entry states of a sub-chunk at once, one row: `heads` bit j = some walk
+ * stands j bits into the row (bits 32.. = already in the next row).  Lowest head first, so every
+ * stream position is looked up once however many walks pass through it; a walk on a window
+ * without a code just disappears.  Which walk is which is not tracked: the point is the bit where
+ * ONE head is left, because every walk that is still alive stands there.
+ */
+__device__ __forceinline__ u64 union_row(u64 heads, u32 hi, u32 lo, const u16 *lut, u32 lut_bits) {
+    const u64 pair = ((u64)hi << 32) | lo;
+    const u32 top = 63u - lut_bits;                 /* window of bit j as a byte offset into the u16 table: pair >> (top - j) */
+    const u32 mask = ((1u << lut_bits) - 1u) << 1;
+    while ((u32)heads) {
+        const u32 j = (u32)__builtin_ctz((u32)heads);
+        const u32 off = (u32)(pair >> (top - j)) & mask;
+        const u32 len = *reinterpret_cast<const u16 *>(reinterpret_cast<const u8 *>(lut) + off) & 0xFFu;
+        heads &= heads - 1;
+        heads |= len ? 1ull << (j + len) : 0ull;
+    }
+    return heads >> 32;
+}
+
+struct spec_shared {
+    u32 exit_state[HUFD_DEC_LANES];
+    u32 wave_sum[HUFD_DEC_LANES / 64];
+    u32 lane0_fn[HUFD_DEC_MAX_STATES]; /* bit 31: the walk from this entry state of sub-chunk 0 dies; low bits: its symbols up to the meeting bit */
+    u32 lane0_meet;                     /* row << 8 | bits into the row: where sub-chunk 0's walks have become one */
+    u32 bad;
+};
+
 /* ------------------------------------------------------------------ decode: sync */
 
 /*
@@ -1891,11 +1987,168 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     HUFD_STAMP(0, 0);
     chunk_load(timg, d_in + it.in_off + chunk_off, valid);
     lut_load(lut, tb);
-    __syncthreads();
-
-    HUFD_STAMP(0, 1);
-    const u32 rem = clamp_remaining(valid, lane);
     const u32 shift = 32 - tb.lut_bits;
+
+    /*
+     * ---- the short way (DESIGN.md "Decode: regular chunks").  Inside the stream a chunk is
+     * nearly always REGULAR: in every sub-chunk the walks from all entry states become ONE walk
+     * after a few rows (the ones on a wrong phase die or fall in step), and that walk reaches the
+     * end of the sub-chunk.  Then a sub-chunk's exit state does not depend on its entry state, so
+     * lane i's true entry state simply IS lane i-1's exit state, and what is left to find is how
+     * many symbols the walk from that entry state takes to reach the meeting bit.  Per lane:
+     *   U  rows 0 .. m-1: all entry states together (union_row) until every lane of the wave is
+     *      down to one head (m is the same for the wave, ~5 rows);
+     *   R  rows m .. 31: the one walk, counting (row_walk);
+     *   H  rows 0 .. m-1 again: the walk from the true entry state, counting, which must land on
+     *      the lane's meeting bit.  Threads 0 .. ns-1 do the same for every entry state of
+     *      sub-chunk 0, whose true entry state only dec_scan can know.
+     * Anything else -- all heads dead, no meeting, a walk that dies, the chunk holding the end of
+     * the stream -- takes the long way below, which assumes nothing.  Same tables out either way.
+     */
+    const bool interior = valid >= (u64)HUFD_DEC_CHUNK_BYTES + 8u;
+    if (interior) {
+        u32 *wlut = reinterpret_cast<u32 *>(lut + (1u << tb.lut_bits));
+        spec_shared *sp = reinterpret_cast<spec_shared *>(wlut + (1u << tb.lut_bits));
+        walk_lut_load(wlut, tb);
+        if (lane == 0) {
+            sp->bad = 0;
+        }
+        __syncthreads();
+        HUFD_STAMP(0, 1);
+
+        const row_walk rw(tb.lut_bits, tb.max_bits);
+        const u32 *col = timg + lane;
+
+        /* U */
+        u64 heads = (1ull << ns) - 1ull;
+        u32 r = 0;
+        u32 hi = col[0];
+        bool one = false;
+        do {
+            const u32 lo = col[(r + 1) * kRowStride];
+            heads = union_row(heads, hi, lo, lut, tb.lut_bits);
+            hi = lo;
+            ++r;
+            one = heads != 0 && (heads & (heads - 1)) == 0;
+        } while (r < kSubWords && !__all(one || heads == 0));
+        const u32 meet_row = r;                                      /* the same for the whole wave */
+        const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
+        bool ok = one && meet_row < kSubWords;
+        HUFD_STAMP(0, 2);
+
+        /* R */
+        u32 state = rw.state_at(meet_bit, 0);
+        u32 cp_state[kQuarters - 1] = {0, 0, 0};
+        bool dead = false;
+        for (; r < kSubWords; ++r) {
+#pragma unroll
+            for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+                if (r == (qq + 1) * (kSubWords / kQuarters)) {
+                    cp_state[qq] = state;
+                }
+            }
+            const u32 lo = col[(r + 1) * kRowStride];
+            state = rw.row(state, hi, lo, wlut);
+            dead = dead || rw.died(state);
+            state = rw.next_row(state);
+            hi = lo;
+        }
+        const u32 ref_count = state >> 16;         /* symbols from the meeting bit to the end of the sub-chunk */
+        const u32 ref_exit = rw.offset_of(state);
+        ok = ok && !dead && ref_exit < ns;
+        sp->exit_state[lane] = ref_exit;
+        __syncthreads();
+        HUFD_STAMP(0, 3);
+
+        /* H */
+        const u32 entry = lane ? sp->exit_state[lane - 1] : 0u;
+        /* the walk over rows 0 .. meet_row-1 of column `hc` from `start` bits in: symbols counted, or where it died */
+        auto head_walk = [&](const u32 *hc, u32 start, u32 target, u32 *symbols, u32 *dead_symbols) -> bool {
+            u32 st = rw.state_at(start, 0);
+            u32 dead_count = 0;
+            bool dd = false;
+            u32 h = hc[0];
+            for (u32 rr = 0; rr < meet_row; ++rr) {
+                const u32 l = hc[(rr + 1) * kRowStride];
+                st = rw.row(st, h, l, wlut);
+                const bool now = rw.died(st) && !dd;
+                dead_count = now ? (st >> 16) - 1u : dead_count; /* the step that found no code is not a symbol */
+                dd = dd || now;
+                st = rw.next_row(st);
+                h = l;
+            }
+            *symbols = st >> 16;
+            *dead_symbols = dead_count;
+            return !dd && rw.offset_of(st) == target;
+        };
+        u32 head_count = 0, unused = 0;
+        const bool reached = head_walk(col, entry, meet_bit, &head_count, &unused);
+        ok = ok && (lane == 0 || reached);
+        const u32 count = head_count + ref_count; /* symbols of the true path that start in my sub-chunk (lanes >= 1) */
+
+        /* sub-chunk 0 for every entry state the chunk may be entered in: threads 0 .. ns-1 */
+        u32 cand_count = 0, cand_dead = 0;
+        bool cand_reached = false;
+        u64 cand_alive = 0;
+        if (lane < kWave) {
+            cand_reached = head_walk(timg, lane < ns ? lane : 0u, __shfl(meet_bit, 0), &cand_count, &cand_dead);
+            cand_reached = cand_reached && lane < ns;
+            cand_alive = __ballot(cand_reached);
+            cand_count += __shfl(ref_count, 0);
+        }
+
+        const u32 wsum = wave_sum(lane ? count : 0u);
+        if ((lane & (kWave - 1)) == 0) {
+            sp->wave_sum[lane / kWave] = wsum;
+        }
+        if (!ok) {
+            sp->bad = 1;
+#if defined(HUFD_EMU_TRACE)
+            fprintf(stderr, "chunk %u lane %u irregular: one %d meet %u.%u dead %d exit %u entry %u reached %d\n", c, lane,
+                    (int)one, meet_row, meet_bit, (int)dead, ref_exit, entry, (int)reached);
+#endif
+        }
+        __syncthreads();
+        HUFD_STAMP(0, 4);
+        if (!sp->bad) {
+            /* the tables dec_scan and dec_emit read, in the format of the long way; only the rows they will look at */
+            u16 *fn_out = fn_tab + (u64)c * ns * HUFD_DEC_LANES;
+            u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
+            if (lane) {
+                fn_out[(u64)entry * HUFD_DEC_LANES + lane] = fn_pack(false, ref_exit, count & 0x7FFu);
+            }
+#pragma unroll
+            for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+                /* a checkpoint in front of the meeting row is not on the one walk */
+                const bool usable = (qq + 1) * (kSubWords / kQuarters) >= meet_row;
+                const u32 tail = ref_count - (cp_state[qq] >> 16);
+                cp[qq * HUFD_DEC_LANES] = (u16)(usable ? 0x8000u | (rw.offset_of(cp_state[qq]) << 11) | tail : 0u);
+            }
+            const u32 merged = lane ? 1u << entry : (u32)cand_alive;
+            cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(merged | (ref_exit << 12));
+            if (lane < ns) {
+                u32 rest = 0;
+#pragma unroll
+                for (u32 w = 0; w < HUFD_DEC_LANES / kWave; ++w) {
+                    rest += sp->wave_sum[w];
+                }
+                const u32 first_exit = sp->exit_state[0];
+                const u32 last_exit = sp->exit_state[HUFD_DEC_LANES - 1];
+                fn_out[(u64)lane * HUFD_DEC_LANES] =
+                    cand_reached ? fn_pack(false, first_exit, cand_count & 0x7FFu) : fn_pack(true, 0, cand_dead);
+                chunk_fn[(u64)c * ns + lane] =
+                    cand_reached ? wide_pack(false, last_exit, cand_count + rest) : wide_pack(true, 0, cand_dead);
+            }
+            HUFD_STAMP(0, 5);
+            return;
+        }
+        __syncthreads(); /* everybody has read the verdict; the long way starts from the loaded image and table */
+    } else {
+        __syncthreads();
+        HUFD_STAMP(0, 1);
+    }
+
+    const u32 rem = clamp_remaining(valid, lane);
     constexpr u32 kDead = 0xFFFFFFFFu;  /* pos[] of a walk that has died */
     constexpr u32 kNobody = 0xFFFFFFFEu; /* a head position no walk is at */
 
@@ -2591,7 +2844,9 @@ static uint32_t enc_fused_lds_bytes(uint32_t img_words) {
 }
 
 static uint32_t dec_sync_lds_bytes(const hufd_tables *tb) {
-    return kChunkWords * 4 + kGroups * tb->n_states * 4 + (2u << tb->lut_bits);
+    /* image, group functions, decode table, walk table, scratch of the short way */
+    return kChunkWords * 4 + kGroups * tb->n_states * 4 + (2u << tb->lut_bits) + (4u << tb->lut_bits) +
+           (uint32_t)sizeof(spec_shared) + 16;
 }
 
 static uint32_t dec_emit_lds_bytes(const hufd_tables *tb) {
