@@ -55,6 +55,8 @@ struct hufk_decode_args {
     uint16_t *fn_tab;      /* [n_chunks][n_states][HUFD_DEC_LANES] scratch */
     uint16_t *cp_tab;      /* [n_chunks][HUFD_DEC_CP_ROWS][HUFD_DEC_LANES] scratch: walk checkpoints */
     uint32_t *chunk_fn;    /* [n_chunks][n_states] scratch */
+    uint32_t *slow_list;   /* [n_chunks] scratch: chunks that take the long way through dec_sync */
+    uint32_t *slow_count;  /* [1] */
     uint32_t *chunk_entry; /* [n_chunks] scratch */
     uint64_t *chunk_base;  /* [n_chunks] scratch */
     struct hufd_dec_item_state *states; /* [n_items] scratch */

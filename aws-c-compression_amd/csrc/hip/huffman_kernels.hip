@@ -1903,44 +1903,6 @@ struct row_walk {
     }
 };
 
-/* walk table for counting: 0x10000 - length, length 48 where no code matches */
-template <u32 THREADS = HUFD_DEC_LANES>
-__device__ __forceinline__ void walk_lut_load(u32 *wlut, const hufd_tables &tb) {
-    for (u32 i = threadIdx.x; i < (1u << tb.lut_bits); i += THREADS) {
-        const u32 len = tb.dec_lut[i] & 0xFFu;
-        wlut[i] = 0x10000u - (len ? len : kWalkDeadLen);
-    }
-}
-
-/*
- * The walks from all `ns` entry states of a sub-chunk at once, one row: `heads` bit j = some walk
- * stands j bits into the row (bits 32.. = already in the next row).  Lowest head first, so every
- * stream position is looked up once however many walks pass through it; a walk on a window
- * without a code just disappears.  Which walk is which is not tracked: the point is the bit where
- * ONE head is left, because every walk that is still alive stands there.
- */
-__device__ __forceinline__ u64 union_row(u64 heads, u32 hi, u32 lo, const u16 *lut, u32 lut_bits) {
-    const u64 pair = ((u64)hi << 32) | lo;
-    const u32 top = 63u - lut_bits;                 /* window of bit j as a byte offset into the u16 table: pair >> (top - j) */
-    const u32 mask = ((1u << lut_bits) - 1u) << 1;
-    while ((u32)heads) {
-        const u32 j = (u32)__builtin_ctz((u32)heads);
-        const u32 off = (u32)(pair >> (top - j)) & mask;
-        const u32 len = *reinterpret_cast<const u16 *>(reinterpret_cast<const u8 *>(lut) + off) & 0xFFu;
-        heads &= heads - 1;
-        heads |= len ? 1ull << (j + len) : 0ull;
-    }
-    return heads >> 32;
-}
-
-struct spec_shared {
-    u32 exit_state[HUFD_DEC_LANES];
-    u32 wave_sum[HUFD_DEC_LANES / 64];
-    u32 lane0_fn[HUFD_DEC_MAX_STATES]; /* bit 31: the walk from this entry state of sub-chunk 0 dies; low bits: its symbols up to the meeting bit */
-    u32 lane0_meet;                     /* row << 8 | bits into the row: where sub-chunk 0's walks have become one */
-    u32 bad;
-};
-
 /* ------------------------------------------------------------------ decode: sync */
 
 /*
@@ -1970,7 +1932,9 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     const u8 *d_in,
     u16 *fn_tab,   /* [chunk][state][lane] */
     u16 *cp_tab,   /* [chunk][kCpRows][lane]: checkpoints of the reference walk + merged-state mask */
-    u32 *chunk_fn) /* [chunk][state] */ {
+    u32 *chunk_fn, /* [chunk][state] */
+    const u32 *list,        /* NULL: workgroup b handles chunk b; else the chunks list[0 .. *list_count) */
+    const u32 *list_count) {
 
     const u32 ns = tb.n_states;
     u32 *timg = reinterpret_cast<u32 *>(dyn_lds);
@@ -1979,7 +1943,10 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     u16 *lut = reinterpret_cast<u16 *>(gtab + kGroups * ns);
 
     const u32 lane = threadIdx.x;
-    const u32 c = blockIdx.x;
+    if (list && blockIdx.x >= *list_count) {
+        return;
+    }
+    const u32 c = list ? list[blockIdx.x] : blockIdx.x;
     const hufd_dec_item it = items[chunk_item[c]];
     const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
     const u64 valid = it.in_len > chunk_off ? it.in_len - chunk_off : 0;
@@ -1989,164 +1956,8 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     lut_load(lut, tb);
     const u32 shift = 32 - tb.lut_bits;
 
-    /*
-     * ---- the short way (DESIGN.md "Decode: regular chunks").  Inside the stream a chunk is
-     * nearly always REGULAR: in every sub-chunk the walks from all entry states become ONE walk
-     * after a few rows (the ones on a wrong phase die or fall in step), and that walk reaches the
-     * end of the sub-chunk.  Then a sub-chunk's exit state does not depend on its entry state, so
-     * lane i's true entry state simply IS lane i-1's exit state, and what is left to find is how
-     * many symbols the walk from that entry state takes to reach the meeting bit.  Per lane:
-     *   U  rows 0 .. m-1: all entry states together (union_row) until every lane of the wave is
-     *      down to one head (m is the same for the wave, ~5 rows);
-     *   R  rows m .. 31: the one walk, counting (row_walk);
-     *   H  rows 0 .. m-1 again: the walk from the true entry state, counting, which must land on
-     *      the lane's meeting bit.  Threads 0 .. ns-1 do the same for every entry state of
-     *      sub-chunk 0, whose true entry state only dec_scan can know.
-     * Anything else -- all heads dead, no meeting, a walk that dies, the chunk holding the end of
-     * the stream -- takes the long way below, which assumes nothing.  Same tables out either way.
-     */
-    const bool interior = valid >= (u64)HUFD_DEC_CHUNK_BYTES + 8u;
-    if (interior) {
-        u32 *wlut = reinterpret_cast<u32 *>(lut + (1u << tb.lut_bits));
-        spec_shared *sp = reinterpret_cast<spec_shared *>(wlut + (1u << tb.lut_bits));
-        walk_lut_load(wlut, tb);
-        if (lane == 0) {
-            sp->bad = 0;
-        }
-        __syncthreads();
-        HUFD_STAMP(0, 1);
-
-        const row_walk rw(tb.lut_bits, tb.max_bits);
-        const u32 *col = timg + lane;
-
-        /* U */
-        u64 heads = (1ull << ns) - 1ull;
-        u32 r = 0;
-        u32 hi = col[0];
-        bool one = false;
-        do {
-            const u32 lo = col[(r + 1) * kRowStride];
-            heads = union_row(heads, hi, lo, lut, tb.lut_bits);
-            hi = lo;
-            ++r;
-            one = heads != 0 && (heads & (heads - 1)) == 0;
-        } while (r < kSubWords && !__all(one || heads == 0));
-        const u32 meet_row = r;                                      /* the same for the whole wave */
-        const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
-        bool ok = one && meet_row < kSubWords;
-        HUFD_STAMP(0, 2);
-
-        /* R */
-        u32 state = rw.state_at(meet_bit, 0);
-        u32 cp_state[kQuarters - 1] = {0, 0, 0};
-        bool dead = false;
-        for (; r < kSubWords; ++r) {
-#pragma unroll
-            for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-                if (r == (qq + 1) * (kSubWords / kQuarters)) {
-                    cp_state[qq] = state;
-                }
-            }
-            const u32 lo = col[(r + 1) * kRowStride];
-            state = rw.row(state, hi, lo, wlut);
-            dead = dead || rw.died(state);
-            state = rw.next_row(state);
-            hi = lo;
-        }
-        const u32 ref_count = state >> 16;         /* symbols from the meeting bit to the end of the sub-chunk */
-        const u32 ref_exit = rw.offset_of(state);
-        ok = ok && !dead && ref_exit < ns;
-        sp->exit_state[lane] = ref_exit;
-        __syncthreads();
-        HUFD_STAMP(0, 3);
-
-        /* H */
-        const u32 entry = lane ? sp->exit_state[lane - 1] : 0u;
-        /* the walk over rows 0 .. meet_row-1 of column `hc` from `start` bits in: symbols counted, or where it died */
-        auto head_walk = [&](const u32 *hc, u32 start, u32 target, u32 *symbols, u32 *dead_symbols) -> bool {
-            u32 st = rw.state_at(start, 0);
-            u32 dead_count = 0;
-            bool dd = false;
-            u32 h = hc[0];
-            for (u32 rr = 0; rr < meet_row; ++rr) {
-                const u32 l = hc[(rr + 1) * kRowStride];
-                st = rw.row(st, h, l, wlut);
-                const bool now = rw.died(st) && !dd;
-                dead_count = now ? (st >> 16) - 1u : dead_count; /* the step that found no code is not a symbol */
-                dd = dd || now;
-                st = rw.next_row(st);
-                h = l;
-            }
-            *symbols = st >> 16;
-            *dead_symbols = dead_count;
-            return !dd && rw.offset_of(st) == target;
-        };
-        u32 head_count = 0, unused = 0;
-        const bool reached = head_walk(col, entry, meet_bit, &head_count, &unused);
-        ok = ok && (lane == 0 || reached);
-        const u32 count = head_count + ref_count; /* symbols of the true path that start in my sub-chunk (lanes >= 1) */
-
-        /* sub-chunk 0 for every entry state the chunk may be entered in: threads 0 .. ns-1 */
-        u32 cand_count = 0, cand_dead = 0;
-        bool cand_reached = false;
-        u64 cand_alive = 0;
-        if (lane < kWave) {
-            cand_reached = head_walk(timg, lane < ns ? lane : 0u, __shfl(meet_bit, 0), &cand_count, &cand_dead);
-            cand_reached = cand_reached && lane < ns;
-            cand_alive = __ballot(cand_reached);
-            cand_count += __shfl(ref_count, 0);
-        }
-
-        const u32 wsum = wave_sum(lane ? count : 0u);
-        if ((lane & (kWave - 1)) == 0) {
-            sp->wave_sum[lane / kWave] = wsum;
-        }
-        if (!ok) {
-            sp->bad = 1;
-#if defined(HUFD_EMU_TRACE)
-            fprintf(stderr, "chunk %u lane %u irregular: one %d meet %u.%u dead %d exit %u entry %u reached %d\n", c, lane,
-                    (int)one, meet_row, meet_bit, (int)dead, ref_exit, entry, (int)reached);
-#endif
-        }
-        __syncthreads();
-        HUFD_STAMP(0, 4);
-        if (!sp->bad) {
-            /* the tables dec_scan and dec_emit read, in the format of the long way; only the rows they will look at */
-            u16 *fn_out = fn_tab + (u64)c * ns * HUFD_DEC_LANES;
-            u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
-            if (lane) {
-                fn_out[(u64)entry * HUFD_DEC_LANES + lane] = fn_pack(false, ref_exit, count & 0x7FFu);
-            }
-#pragma unroll
-            for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-                /* a checkpoint in front of the meeting row is not on the one walk */
-                const bool usable = (qq + 1) * (kSubWords / kQuarters) >= meet_row;
-                const u32 tail = ref_count - (cp_state[qq] >> 16);
-                cp[qq * HUFD_DEC_LANES] = (u16)(usable ? 0x8000u | (rw.offset_of(cp_state[qq]) << 11) | tail : 0u);
-            }
-            const u32 merged = lane ? 1u << entry : (u32)cand_alive;
-            cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(merged | (ref_exit << 12));
-            if (lane < ns) {
-                u32 rest = 0;
-#pragma unroll
-                for (u32 w = 0; w < HUFD_DEC_LANES / kWave; ++w) {
-                    rest += sp->wave_sum[w];
-                }
-                const u32 first_exit = sp->exit_state[0];
-                const u32 last_exit = sp->exit_state[HUFD_DEC_LANES - 1];
-                fn_out[(u64)lane * HUFD_DEC_LANES] =
-                    cand_reached ? fn_pack(false, first_exit, cand_count & 0x7FFu) : fn_pack(true, 0, cand_dead);
-                chunk_fn[(u64)c * ns + lane] =
-                    cand_reached ? wide_pack(false, last_exit, cand_count + rest) : wide_pack(true, 0, cand_dead);
-            }
-            HUFD_STAMP(0, 5);
-            return;
-        }
-        __syncthreads(); /* everybody has read the verdict; the long way starts from the loaded image and table */
-    } else {
-        __syncthreads();
-        HUFD_STAMP(0, 1);
-    }
+    __syncthreads();
+    HUFD_STAMP(0, 1);
 
     const u32 rem = clamp_remaining(valid, lane);
     constexpr u32 kDead = 0xFFFFFFFFu;  /* pos[] of a walk that has died */
@@ -2289,6 +2100,247 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     if (lane < ns) {
         chunk_fn[(u64)c * ns + lane] =
             wide_pack(chain_fold(kGroups, lane, [&](u32 g, u32 stt) { return gtab[g * ns + stt]; }));
+    }
+    HUFD_STAMP(0, 5);
+}
+
+/* ------------------------------------------------------------------ decode: sync, regular chunks */
+
+/*
+ * dec_sync for chunks that lie inside the stream (DESIGN.md "Decode: regular chunks"); every
+ * other chunk, and every chunk that turns out not to be regular, is put on a list for
+ * dec_sync_kernel (the long way, which assumes nothing).  Same tables out.
+ *
+ * Inside the stream a chunk is nearly always REGULAR: in every sub-chunk the walks from all
+ * entry states become ONE walk after a few rows (those on a wrong phase die or fall in step),
+ * and that walk reaches the end of the sub-chunk.  Then a sub-chunk's exit state does not depend
+ * on its entry state, so lane i's true entry state simply IS lane i-1's exit state, and what is
+ * left to find is how many symbols the walk from that entry state takes to the meeting bit:
+ *   U  rows 0 .. m-1: all entry states together (head mask) until every lane of the wave is down
+ *      to one head (m is the same for the wave, ~5 rows);
+ *   R  rows m .. 31: the one walk, counting (row_walk: shift, mask, table, add);
+ *   H  rows 0 .. m-1 again: the walk from the true entry state, counting, which must land on the
+ *      lane's meeting bit.  Threads 0 .. ns-1 do the same for every entry state of sub-chunk 0,
+ *      whose true entry state only dec_scan can know.
+ *
+ * The walks are one dependent chain per lane (window -> table -> add -> test), a couple of
+ * hundred cycles a step, so what counts is how many chains a SIMD holds.  A sub-chunk therefore
+ * lives in its lane's REGISTERS (33 words, loaded as the lane's own 128-byte line) and not in an
+ * LDS image: eight waves per SIMD instead of four, rows at compile-time register numbers, and
+ * the LDS holds only the two small tables.
+ */
+constexpr u32 kFastRows = kSubWords + 1;  /* a window of the last row reaches into the next sub-chunk's first word */
+constexpr u32 kFastMaxMeet = 16;          /* no single head after this many rows: not regular */
+
+template <u32 LB>
+struct fast_shared {
+    u32 wlut[1u << LB];                  /* 0x10000 - length; length 48 = no code */
+    u32 exit_state[HUFD_DEC_LANES];
+    u32 sub0[kFastMaxMeet + 4];          /* the first rows of sub-chunk 0, for the threads that try its entry states */
+    u32 wave_sum[HUFD_DEC_LANES / 64];
+    u32 bad;
+    u32 pad[3];
+    u8 lens[1u << LB];                   /* code length of a window, 0 = no code */
+};
+
+template <u32 LB>
+__device__ __forceinline__ u64 union_row_fast(u64 heads, u32 hi, u32 lo, const u8 *lens) {
+    const u64 pair = ((u64)hi << 32) | lo;
+    while ((u32)heads) {
+        const u32 j = (u32)__builtin_ctz((u32)heads);
+        const u32 len = lens[(u32)(pair >> (64u - LB - j)) & ((1u << LB) - 1u)];
+        heads &= heads - 1;
+        heads |= len ? 1ull << (j + len) : 0ull;
+    }
+    return heads >> 32;
+}
+
+template <u32 LB>
+__global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
+    hufd_tables tb,
+    const hufd_dec_item *items,
+    const u32 *chunk_item,
+    const u8 *d_in,
+    u16 *fn_tab,
+    u16 *cp_tab,
+    u32 *chunk_fn,
+    u32 *slow_list,   /* chunks left to dec_sync_kernel */
+    u32 *slow_count) {
+
+    fast_shared<LB> &sh = *reinterpret_cast<fast_shared<LB> *>(dyn_lds);
+
+    const u32 ns = tb.n_states;
+    const u32 lane = threadIdx.x;
+    const u32 c = blockIdx.x;
+    const hufd_dec_item it = items[chunk_item[c]];
+    const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
+    const u64 valid = it.in_len > chunk_off ? it.in_len - chunk_off : 0;
+    const u8 *src = d_in + it.in_off + chunk_off;
+    /* whole codes only, rows as aligned 16-byte loads */
+    const bool eligible = valid >= (u64)HUFD_DEC_CHUNK_BYTES + 8u && ((uintptr_t)src & 15u) == 0 &&
+                          tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS;
+    if (!eligible) {
+        if (lane == 0) {
+            slow_list[atomicAdd(slow_count, 1u)] = c;
+        }
+        return;
+    }
+
+    HUFD_STAMP(0, 0);
+    u32 w[kFastRows];
+    {
+        const uint4 *line = reinterpret_cast<const uint4 *>(src + (u64)lane * HUFD_DEC_SUB_BYTES);
+#pragma unroll
+        for (u32 q = 0; q < kSubWords / 4; ++q) {
+            const uint4 v = line[q];
+            w[4 * q + 0] = __builtin_bswap32(v.x);
+            w[4 * q + 1] = __builtin_bswap32(v.y);
+            w[4 * q + 2] = __builtin_bswap32(v.z);
+            w[4 * q + 3] = __builtin_bswap32(v.w);
+        }
+        w[kSubWords] = __builtin_bswap32(*reinterpret_cast<const u32 *>(src + (u64)(lane + 1) * HUFD_DEC_SUB_BYTES));
+    }
+    for (u32 i = lane; i < (1u << LB); i += HUFD_DEC_LANES) {
+        const u32 len = tb.dec_lut[i >> (LB - tb.lut_bits)] & 0xFFu;
+        sh.wlut[i] = 0x10000u - (len ? len : kWalkDeadLen);
+        sh.lens[i] = (u8)len;
+    }
+    if (lane == 0) {
+        sh.bad = 0;
+#pragma unroll
+        for (u32 r = 0; r <= kFastMaxMeet; ++r) {
+            sh.sub0[r] = w[r];
+        }
+    }
+    __syncthreads();
+    HUFD_STAMP(0, 1);
+
+    const row_walk rw(LB, tb.max_bits);
+
+    /* U */
+    u64 heads = (1ull << ns) - 1ull;
+    u32 meet_row = 0; /* the same for the whole wave */
+    bool one = false, settled = false;
+#pragma unroll
+    for (u32 r = 0; r < kFastMaxMeet; ++r) {
+        if (!settled) {
+            heads = union_row_fast<LB>(heads, w[r], w[r + 1], sh.lens);
+            one = heads != 0 && (heads & (heads - 1)) == 0;
+            meet_row = r + 1;
+            settled = __all(one || heads == 0);
+        }
+    }
+    const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
+    bool ok = one && settled;
+    HUFD_STAMP(0, 2);
+
+    /* R */
+    u32 state = rw.state_at(meet_bit, 0);
+    u32 cp_state[kQuarters - 1] = {0, 0, 0};
+    bool dead = false;
+#pragma unroll
+    for (u32 r = 1; r < kSubWords; ++r) {
+        if (r >= meet_row) {
+            if (r % (kSubWords / kQuarters) == 0) {
+                cp_state[r / (kSubWords / kQuarters) - 1] = state;
+            }
+            state = rw.row(state, w[r], w[r + 1], sh.wlut);
+            dead = dead || rw.died(state);
+            state = rw.next_row(state);
+        }
+    }
+    const u32 ref_count = state >> 16; /* symbols from the meeting bit to the end of the sub-chunk */
+    const u32 ref_exit = rw.offset_of(state);
+    ok = ok && !dead && ref_exit < ns;
+    sh.exit_state[lane] = ref_exit;
+    __syncthreads();
+    HUFD_STAMP(0, 3);
+
+    /* H: my own sub-chunk from my true entry state */
+    const u32 entry = lane ? sh.exit_state[lane - 1] : 0u;
+    u32 count;
+    {
+        u32 st = rw.state_at(entry, 0);
+        bool dd = false;
+#pragma unroll
+        for (u32 r = 0; r < kFastMaxMeet; ++r) {
+            if (r < meet_row) {
+                st = rw.row(st, w[r], w[r + 1], sh.wlut);
+                dd = dd || rw.died(st);
+                st = rw.next_row(st);
+            }
+        }
+        const bool reached = !dd && rw.offset_of(st) == meet_bit;
+        ok = ok && (lane == 0 || reached);
+        count = (st >> 16) + ref_count; /* symbols of the true path that start in my sub-chunk (lanes >= 1) */
+    }
+
+    /* H: sub-chunk 0 from every entry state the chunk may be entered in (threads 0 .. ns-1) */
+    u32 cand_count = 0, cand_dead = 0;
+    bool cand_reached = false;
+    u64 cand_alive = 0;
+    if (lane < kWave) {
+        const u32 target = __shfl(meet_bit, 0), tail0 = __shfl(ref_count, 0); /* sub-chunk 0 is lane 0's */
+        u32 st = rw.state_at(lane < ns ? lane : 0u, 0);
+        bool dd = false;
+        u32 hi = sh.sub0[0];
+        for (u32 r = 0; r < meet_row; ++r) {
+            const u32 lo = sh.sub0[r + 1];
+            st = rw.row(st, hi, lo, sh.wlut);
+            const bool now = rw.died(st) && !dd;
+            cand_dead = now ? (st >> 16) - 1u : cand_dead; /* the step that found no code is not a symbol */
+            dd = dd || now;
+            st = rw.next_row(st);
+            hi = lo;
+        }
+        cand_reached = !dd && lane < ns && rw.offset_of(st) == target;
+        cand_alive = __ballot(cand_reached);
+        cand_count = (st >> 16) + tail0;
+    }
+
+    const u32 wsum = wave_sum(lane ? count : 0u);
+    if ((lane & (kWave - 1)) == 0) {
+        sh.wave_sum[lane / kWave] = wsum;
+    }
+    if (!ok) {
+        sh.bad = 1;
+    }
+    __syncthreads();
+    HUFD_STAMP(0, 4);
+    if (sh.bad) {
+        if (lane == 0) {
+            slow_list[atomicAdd(slow_count, 1u)] = c;
+        }
+        return;
+    }
+
+    /* the tables dec_scan and dec_emit read, in the format of the long way; only the rows they will look at */
+    u16 *fn_out = fn_tab + (u64)c * ns * HUFD_DEC_LANES;
+    u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
+    if (lane) {
+        fn_out[(u64)entry * HUFD_DEC_LANES + lane] = fn_pack(false, ref_exit, count & 0x7FFu);
+    }
+#pragma unroll
+    for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+        /* a checkpoint in front of the meeting row is not on the one walk */
+        const bool usable = (qq + 1) * (kSubWords / kQuarters) >= meet_row;
+        const u32 tail = ref_count - (cp_state[qq] >> 16);
+        cp[qq * HUFD_DEC_LANES] = (u16)(usable ? 0x8000u | (rw.offset_of(cp_state[qq]) << 11) | tail : 0u);
+    }
+    const u32 merged = lane ? 1u << entry : (u32)cand_alive;
+    cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(merged | (ref_exit << 12));
+    if (lane < ns) {
+        u32 rest = 0;
+#pragma unroll
+        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
+            rest += sh.wave_sum[wv];
+        }
+        const u32 first_exit = sh.exit_state[0];
+        const u32 last_exit = sh.exit_state[HUFD_DEC_LANES - 1];
+        fn_out[(u64)lane * HUFD_DEC_LANES] =
+            cand_reached ? fn_pack(false, first_exit, cand_count & 0x7FFu) : fn_pack(true, 0, cand_dead);
+        chunk_fn[(u64)c * ns + lane] =
+            cand_reached ? wide_pack(false, last_exit, cand_count + rest) : wide_pack(true, 0, cand_dead);
     }
     HUFD_STAMP(0, 5);
 }
@@ -2844,9 +2896,7 @@ static uint32_t enc_fused_lds_bytes(uint32_t img_words) {
 }
 
 static uint32_t dec_sync_lds_bytes(const hufd_tables *tb) {
-    /* image, group functions, decode table, walk table, scratch of the short way */
-    return kChunkWords * 4 + kGroups * tb->n_states * 4 + (2u << tb->lut_bits) + (4u << tb->lut_bits) +
-           (uint32_t)sizeof(spec_shared) + 16;
+    return kChunkWords * 4 + kGroups * tb->n_states * 4 + (2u << tb->lut_bits);
 }
 
 static uint32_t dec_emit_lds_bytes(const hufd_tables *tb) {
@@ -2950,10 +3000,24 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     const uint32_t ns = a->tables.n_states;
     stage_mark(a->stage_events, 0, st);
     if (a->n_chunks) {
+        /* chunks inside the stream the short way; the rest, and those that turn out irregular, through the list */
         const auto sync = ns <= 8 ? dec_sync_kernel<8> : (ns <= 10 ? dec_sync_kernel<10> : dec_sync_kernel<12>);
+        (void)hipMemsetAsync(a->slow_count, 0, sizeof(uint32_t), st);
+        if (a->tables.lut_bits <= 10) {
+            hipLaunchKernelGGL(
+                dec_sync_fast_kernel<10>, dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<10>), st,
+                a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn,
+                a->slow_list, a->slow_count);
+        } else {
+            hipLaunchKernelGGL(
+                dec_sync_fast_kernel<12>, dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<12>), st,
+                a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn,
+                a->slow_list, a->slow_count);
+        }
         hipLaunchKernelGGL(
             sync, dim3(a->n_chunks), dim3(HUFD_DEC_LANES), dec_sync_lds_bytes(&a->tables), st, a->tables, a->items,
-            a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn);
+            a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, (const u32 *)a->slow_list,
+            (const u32 *)a->slow_count);
     }
     stage_mark(a->stage_events, 1, st);
     hipLaunchKernelGGL(

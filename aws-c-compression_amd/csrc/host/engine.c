@@ -511,6 +511,7 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     hufs_free(p->d_fn_tab);
     hufs_free(p->d_cp_tab);
     hufs_free(p->d_chunk_fn);
+    hufs_free(p->d_slow_list);
     hufs_free(p->d_chunk_entry);
     hufs_free(p->d_chunk_base);
     hufs_free(p->d_states);
@@ -521,6 +522,7 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     p->d_fn_tab = NULL;
     p->d_cp_tab = NULL;
     p->d_chunk_fn = NULL;
+    p->d_slow_list = NULL;
     p->d_chunk_entry = NULL;
     p->d_chunk_base = NULL;
     p->d_states = NULL;
@@ -593,11 +595,12 @@ static int dec_plan_fill(
         p->d_fn_tab = hufs_malloc(cc * ns * HUFD_DEC_LANES * sizeof(uint16_t));
         p->d_cp_tab = hufs_malloc(cc * HUFD_DEC_CP_ROWS * HUFD_DEC_LANES * sizeof(uint16_t));
         p->d_chunk_fn = hufs_malloc(cc * ns * sizeof(uint32_t));
+        p->d_slow_list = hufs_malloc((cc + 1) * sizeof(uint32_t)); /* [0] count, [1..] chunks */
         p->d_chunk_entry = hufs_malloc(cc * sizeof(uint32_t));
         p->d_chunk_base = hufs_malloc(cc * sizeof(uint64_t));
         p->d_states = hufs_malloc(ci * sizeof(struct hufd_dec_item_state));
         p->d_results = hufs_malloc(ci * sizeof(struct hufd_dec_result));
-        if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_cp_tab || !p->d_chunk_fn || !p->d_chunk_entry ||
+        if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_cp_tab || !p->d_chunk_fn || !p->d_slow_list || !p->d_chunk_entry ||
             !p->d_chunk_base || !p->d_states || !p->d_results) {
             err = 2;
         }
@@ -697,6 +700,8 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.fn_tab = p->d_fn_tab;
     a.cp_tab = p->d_cp_tab;
     a.chunk_fn = p->d_chunk_fn;
+    a.slow_count = p->d_slow_list;
+    a.slow_list = p->d_slow_list + 1;
     a.chunk_entry = p->d_chunk_entry;
     a.chunk_base = p->d_chunk_base;
     a.states = p->d_states;
