@@ -31,6 +31,8 @@
 
 #define HUFD_SCAN_SMALL_MAX 64u /* items with at most this many segments/chunks are scanned by one thread */
 #define HUFD_SCAN_LARGE_THREADS 1024u
+#define HUFD_SCAN_RUN_CHUNKS 256u /* a large decode item is scanned in runs of this many chunks, one workgroup per run */
+#define HUFD_SCAN_SUB_CHUNKS 16u  /* ... each folded in sub-runs of this many */
 
 #define HUFD_NONE32 0xFFFFFFFFu
 

@@ -48,8 +48,13 @@ struct hufk_decode_args {
     uint32_t n_items;
     const uint32_t *chunk_item; /* [n_chunks] */
     uint32_t n_chunks;
-    const uint32_t *large_items;
+    const uint32_t *large_items; /* per item with more than HUFD_SCAN_SMALL_MAX chunks: item index, its first run */
     uint32_t n_large;
+    const uint32_t *runs;        /* per run of HUFD_SCAN_RUN_CHUNKS chunks of a large item: item index, run number */
+    uint32_t n_runs;
+    uint32_t *run_fn;            /* [n_runs][n_states] scratch */
+    uint32_t *run_entry;         /* [n_runs] scratch */
+    uint64_t *run_base;          /* [n_runs] scratch */
     const void *d_in;
     void *d_out;
     uint16_t *fn_tab;      /* [n_chunks][n_states][HUFD_DEC_LANES] scratch */

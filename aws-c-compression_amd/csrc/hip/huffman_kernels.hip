@@ -2408,80 +2408,124 @@ __global__ __launch_bounds__(256) void dec_scan_small_kernel(
 }
 
 /*
- * One workgroup per item with many chunks.  Thread t owns a run of consecutive
- * chunks; run functions are folded 32 at a time, the true path is followed through
- * the 32 groups, then through each group's threads, then through each run.
+ * Items with many chunks are scanned in RUNS of HUFD_SCAN_RUN_CHUNKS chunks, one workgroup per
+ * run, in three short launches (the walk along an item is a chain of dependent table look-ups:
+ * what matters is that every look-up is an LDS read and every chain is short):
+ *   dec_scan_runs   the run's chunk functions into LDS, folded 16 at a time and then once more:
+ *                   the run's own transfer function
+ *   dec_scan_top    per item: the true path through its run functions (in LDS) -> entry state and
+ *                   symbol offset of every run, outcome of the item
+ *   dec_scan_apply  per run: the same fold again, then the true path through the 16 sub-runs and
+ *                   through the chunks of each -> entry state and symbol offset of every chunk
  */
-__global__ __launch_bounds__(HUFD_SCAN_LARGE_THREADS) void dec_scan_large_kernel(
+constexpr u32 kRunChunks = HUFD_SCAN_RUN_CHUNKS, kSubRun = HUFD_SCAN_SUB_CHUNKS, kSubRuns = kRunChunks / kSubRun;
+
+/* chunk functions of run `k` of item `it` -> fn[chunk][state]; sub-run functions -> sub[sub-run][state].  Returns the run's chunk count. */
+__device__ __forceinline__ u32 scan_run_load(const hufd_dec_item &it, u32 k, u32 ns, const u32 *chunk_fn, u32 *fn, u32 *sub) {
+    const u32 lo = k * kRunChunks;
+    const u32 n = it.n_chunks - lo < kRunChunks ? it.n_chunks - lo : kRunChunks;
+    const u32 *src = chunk_fn + (u64)(it.first_chunk + lo) * ns;
+    for (u32 i = threadIdx.x; i < n * ns; i += blockDim.x) {
+        fn[i] = src[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < kSubRuns * ns) {
+        const u32 j = threadIdx.x / ns, start = threadIdx.x % ns;
+        const u32 first = j * kSubRun;
+        const u32 cnt = first < n ? (n - first < kSubRun ? n - first : kSubRun) : 0;
+        sub[j * ns + start] =
+            wide_pack(chain_fold(cnt, start, [&](u32 i, u32 stt) { return fn[(first + i) * ns + stt]; }));
+    }
+    __syncthreads();
+    return n;
+}
+
+static uint32_t scan_run_lds_bytes(uint32_t ns) {
+    return kRunChunks * ns * 4 + kSubRuns * ns * 4 + kSubRuns * 4 + kSubRuns * 8 + 16;
+}
+
+__global__ __launch_bounds__(256) void dec_scan_runs_kernel(
+    const hufd_dec_item *items, const u32 *runs, u32 ns, const u32 *chunk_fn, u32 *run_fn) {
+    u32 *fn = reinterpret_cast<u32 *>(dyn_lds);
+    u32 *sub = fn + kRunChunks * ns;
+    const u32 run = blockIdx.x;
+    const hufd_dec_item it = items[runs[2 * run]];
+    (void)scan_run_load(it, runs[2 * run + 1], ns, chunk_fn, fn, sub);
+    if (threadIdx.x < ns) {
+        run_fn[(u64)run * ns + threadIdx.x] = wide_pack(
+            chain_fold(kSubRuns, threadIdx.x, [&](u32 j, u32 stt) { return sub[j * ns + stt]; }));
+    }
+}
+
+constexpr u32 kTopTile = 1024; /* run functions of an item held in LDS at a time */
+
+__global__ __launch_bounds__(256) void dec_scan_top_kernel(
     const hufd_dec_item *items,
     const u32 *large_items,
     u32 ns,
-    const u32 *chunk_fn,
-    u32 *chunk_entry,
-    u64 *chunk_base,
+    const u32 *run_fn,
+    u32 *run_entry,
+    u64 *run_base,
     hufd_dec_item_state *states,
     hufd_dec_result *results) {
-
-    constexpr u32 T = HUFD_SCAN_LARGE_THREADS, G = 32, PER = T / G;
-    u64 *grp_cnt = reinterpret_cast<u64 *>(dyn_lds);          /* [G][ns] symbols of a group of runs */
-    u64 *t_base = grp_cnt + G * HUFD_DEC_MAX_STATES;           /* [T] */
-    u64 *g_base = t_base + T;                                  /* [G] */
-    u64 *fin_total = g_base + G;                               /* [2] */
-    u32 *run_fn = reinterpret_cast<u32 *>(fin_total + 2);      /* [T][ns] wide entries, counts < 2^26 */
-    u32 *grp_st = run_fn + T * HUFD_DEC_MAX_STATES;            /* [G][ns] entry_pack(exit state, !stop) */
-    u32 *t_entry = grp_st + G * HUFD_DEC_MAX_STATES;           /* [T] */
-    u32 *g_entry = t_entry + T;                                /* [G] */
-    u32 *fin_stop = g_entry + G;                               /* [1] */
-
-    const u32 i = large_items[blockIdx.x];
+    u32 *fn = reinterpret_cast<u32 *>(dyn_lds); /* [kTopTile][ns] */
+    const u32 i = large_items[2 * blockIdx.x], run0 = large_items[2 * blockIdx.x + 1];
     const hufd_dec_item it = items[i];
-    const u32 tid = threadIdx.x;
-    const u32 per_thread = (it.n_chunks + T - 1) / T;
-    const u32 run_lo = tid * per_thread < it.n_chunks ? tid * per_thread : it.n_chunks;
-    const u32 run_hi = run_lo + per_thread < it.n_chunks ? run_lo + per_thread : it.n_chunks;
-
-    for (u32 start = 0; start < ns; ++start) {
-        run_fn[tid * ns + start] = wide_pack(chain_fold(run_hi - run_lo, start, [&](u32 k, u32 stt) {
-            return chunk_fn[(u64)(it.first_chunk + run_lo + k) * ns + stt];
-        }));
-    }
-    __syncthreads();
-    if (tid < G * ns) {
-        const u32 g = tid / ns, start = tid % ns;
-        const fold_result r =
-            chain_fold(PER, start, [&](u32 k, u32 stt) { return run_fn[(g * PER + k) * ns + stt]; });
-        grp_cnt[g * ns + start] = r.count;
-        grp_st[g * ns + start] = entry_pack(r.state, !r.stop);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        u32 state = it.first_bit;
-        u64 total = 0;
-        bool stopped = false;
-        for (u32 g = 0; g < G; ++g) {
-            g_entry[g] = entry_pack(state, !stopped);
-            g_base[g] = total;
-            if (!stopped) {
-                const u32 f = grp_st[g * ns + state];
-                total += grp_cnt[g * ns + state];
-                stopped = !(f & 0x100u);
-                state = f & 0xFFu;
+    const u32 n_runs = (it.n_chunks + kRunChunks - 1) / kRunChunks;
+    u32 state = it.first_bit;
+    u64 total = 0;
+    bool stopped = false;
+    for (u32 base = 0; base < n_runs; base += kTopTile) {
+        const u32 n = n_runs - base < kTopTile ? n_runs - base : kTopTile;
+        __syncthreads();
+        for (u32 k = threadIdx.x; k < n * ns; k += blockDim.x) {
+            fn[k] = run_fn[(u64)(run0 + base) * ns + k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (u32 k = 0; k < n; ++k) {
+                run_entry[run0 + base + k] = entry_pack(state, !stopped);
+                run_base[run0 + base + k] = total;
+                if (!stopped) {
+                    const u32 f = fn[k * ns + state];
+                    total += wide_count(f);
+                    stopped = wide_stop(f);
+                    state = wide_state(f);
+                }
             }
         }
-        *fin_total = total;
-        *fin_stop = stopped;
     }
-    __syncthreads();
-    if (tid < G) {
-        u32 state = g_entry[tid] & 0xFFu;
-        bool stopped = !(g_entry[tid] & 0x100u);
-        u64 total = g_base[tid];
-        for (u32 k = 0; k < PER; ++k) {
-            const u32 t = tid * PER + k;
-            t_entry[t] = entry_pack(state, !stopped);
-            t_base[t] = total;
+    if (threadIdx.x == 0) {
+        dec_finish_item(it, total, stopped, &states[i], &results[i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void dec_scan_apply_kernel(
+    const hufd_dec_item *items,
+    const u32 *runs,
+    u32 ns,
+    const u32 *chunk_fn,
+    const u32 *run_entry,
+    const u64 *run_base,
+    u32 *chunk_entry,
+    u64 *chunk_base) {
+    u32 *fn = reinterpret_cast<u32 *>(dyn_lds);
+    u32 *sub = fn + kRunChunks * ns;
+    u32 *sub_entry = sub + kSubRuns * ns;                           /* [kSubRuns] */
+    u64 *sub_base = reinterpret_cast<u64 *>(sub_entry + kSubRuns);  /* [kSubRuns] */
+    const u32 run = blockIdx.x;
+    const hufd_dec_item it = items[runs[2 * run]];
+    const u32 k = runs[2 * run + 1];
+    const u32 n = scan_run_load(it, k, ns, chunk_fn, fn, sub);
+    if (threadIdx.x == 0) {
+        u32 state = run_entry[run] & 0xFFu;
+        bool stopped = !(run_entry[run] & 0x100u);
+        u64 total = run_base[run];
+        for (u32 j = 0; j < kSubRuns; ++j) {
+            sub_entry[j] = entry_pack(state, !stopped);
+            sub_base[j] = total;
             if (!stopped) {
-                const u32 f = run_fn[t * ns + state];
+                const u32 f = sub[j * ns + state];
                 total += wide_count(f);
                 stopped = wide_stop(f);
                 state = wide_state(f);
@@ -2489,24 +2533,24 @@ __global__ __launch_bounds__(HUFD_SCAN_LARGE_THREADS) void dec_scan_large_kernel
         }
     }
     __syncthreads();
-    {
-        u32 state = t_entry[tid] & 0xFFu;
-        bool stopped = !(t_entry[tid] & 0x100u);
-        u64 total = t_base[tid];
-        for (u32 k = run_lo; k < run_hi; ++k) {
-            const u32 c = it.first_chunk + k;
+    if (threadIdx.x < kSubRuns) {
+        const u32 j = threadIdx.x;
+        u32 state = sub_entry[j] & 0xFFu;
+        bool stopped = !(sub_entry[j] & 0x100u);
+        u64 total = sub_base[j];
+        const u32 first = j * kSubRun;
+        const u32 cnt = first < n ? (n - first < kSubRun ? n - first : kSubRun) : 0;
+        for (u32 q = 0; q < cnt; ++q) {
+            const u32 c = it.first_chunk + k * kRunChunks + first + q;
             chunk_entry[c] = entry_pack(state, !stopped);
             chunk_base[c] = total;
             if (!stopped) {
-                const u32 f = chunk_fn[(u64)c * ns + state];
+                const u32 f = fn[(first + q) * ns + state];
                 total += wide_count(f);
                 stopped = wide_stop(f);
                 state = wide_state(f);
             }
         }
-    }
-    if (tid == 0) {
-        dec_finish_item(it, *fin_total, *fin_stop != 0, &states[i], &results[i]);
     }
 }
 
@@ -2850,10 +2894,6 @@ int hufk_init(void) {
     }
     if (e == hipSuccess) {
         e = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&dec_scan_large_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    }
-    if (e == hipSuccess) {
-        e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&enc_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     }
     if (e == hipSuccess) {
@@ -3024,12 +3064,15 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         dec_scan_small_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, ns, a->chunk_fn,
         a->chunk_entry, a->chunk_base, a->states, a->results);
     if (a->n_large) {
-        const uint32_t T = HUFD_SCAN_LARGE_THREADS, G = 32;
-        const uint32_t lds = G * HUFD_DEC_MAX_STATES * 8 + T * 8 + G * 8 + 16 + T * HUFD_DEC_MAX_STATES * 4 +
-                             G * HUFD_DEC_MAX_STATES * 4 + T * 4 + G * 4 + 16;
+        const uint32_t lds = scan_run_lds_bytes(ns);
         hipLaunchKernelGGL(
-            dec_scan_large_kernel, dim3(a->n_large), dim3(HUFD_SCAN_LARGE_THREADS), lds, st, a->items, a->large_items,
-            ns, a->chunk_fn, a->chunk_entry, a->chunk_base, a->states, a->results);
+            dec_scan_runs_kernel, dim3(a->n_runs), dim3(256), lds, st, a->items, a->runs, ns, a->chunk_fn, a->run_fn);
+        hipLaunchKernelGGL(
+            dec_scan_top_kernel, dim3(a->n_large), dim3(256), kTopTile * ns * 4, st, a->items, a->large_items, ns,
+            (const u32 *)a->run_fn, a->run_entry, a->run_base, a->states, a->results);
+        hipLaunchKernelGGL(
+            dec_scan_apply_kernel, dim3(a->n_runs), dim3(256), lds, st, a->items, a->runs, ns, a->chunk_fn,
+            (const u32 *)a->run_entry, (const u64 *)a->run_base, a->chunk_entry, a->chunk_base);
     }
     stage_mark(a->stage_events, 2, st);
     if (a->n_chunks) {

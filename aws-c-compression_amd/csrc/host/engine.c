@@ -508,6 +508,10 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     hufs_free(p->d_items);
     hufs_free(p->d_chunk_item);
     hufs_free(p->d_large);
+    hufs_free(p->d_runs);
+    hufs_free(p->d_run_fn);
+    hufs_free(p->d_run_entry);
+    hufs_free(p->d_run_base);
     hufs_free(p->d_fn_tab);
     hufs_free(p->d_cp_tab);
     hufs_free(p->d_chunk_fn);
@@ -519,6 +523,10 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     p->d_items = NULL;
     p->d_chunk_item = NULL;
     p->d_large = NULL;
+    p->d_runs = NULL;
+    p->d_run_fn = NULL;
+    p->d_run_entry = NULL;
+    p->d_run_base = NULL;
     p->d_fn_tab = NULL;
     p->d_cp_tab = NULL;
     p->d_chunk_fn = NULL;
@@ -527,7 +535,7 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     p->d_chunk_base = NULL;
     p->d_states = NULL;
     p->d_results = NULL;
-    p->cap_items = p->cap_chunks = p->cap_large = 0;
+    p->cap_items = p->cap_chunks = p->cap_large = p->cap_runs = 0;
 }
 
 static int dec_plan_fill(
@@ -539,15 +547,16 @@ static int dec_plan_fill(
     if (!eng->can_decode) {
         return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION);
     }
-    uint64_t n_chunks = 0, n_large = 0;
+    uint64_t n_chunks = 0, n_large = 0, n_runs = 0;
     for (size_t i = 0; i < n_items; ++i) {
-        /* run counts in the large scan are 26-bit: 4 GiB of encoded bytes per item is the limit */
+        /* symbol counts in the scan's function entries are 26-bit; 4 GiB of encoded bytes per item is the limit */
         if (items[i].first_bit > 7 || items[i].in_len > 0xFFFFFFFFull) {
             return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
         }
         const uint64_t chunks = (items[i].in_len + HUFD_DEC_CHUNK_BYTES - 1) / HUFD_DEC_CHUNK_BYTES;
         n_chunks += chunks;
         n_large += chunks > HUFD_SCAN_SMALL_MAX;
+        n_runs += chunks > HUFD_SCAN_SMALL_MAX ? (chunks + HUFD_SCAN_RUN_CHUNKS - 1) / HUFD_SCAN_RUN_CHUNKS : 0;
     }
     if (n_chunks >= 0xFFFFFFFFull || n_items >= 0xFFFFFFFFull) {
         return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
@@ -555,14 +564,16 @@ static int dec_plan_fill(
 
     struct hufd_dec_item *h_items = malloc((n_items ? n_items : 1) * sizeof(*h_items));
     uint32_t *h_chunk_item = malloc((n_chunks ? n_chunks : 1) * sizeof(uint32_t));
-    uint32_t *h_large = malloc((n_large ? n_large : 1) * sizeof(uint32_t));
-    if (!h_items || !h_chunk_item || !h_large) {
+    uint32_t *h_large = malloc((n_large ? n_large : 1) * 2 * sizeof(uint32_t));
+    uint32_t *h_runs = malloc((n_runs ? n_runs : 1) * 2 * sizeof(uint32_t));
+    if (!h_items || !h_chunk_item || !h_large || !h_runs) {
+        free(h_runs);
         free(h_items);
         free(h_chunk_item);
         free(h_large);
         return aws_raise_error(AWS_ERROR_OOM);
     }
-    uint32_t chunk = 0, large = 0;
+    uint32_t chunk = 0, large = 0, run = 0;
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_decode_item *src = &items[i];
         struct hufd_dec_item *dst = &h_items[i];
@@ -579,19 +590,31 @@ static int dec_plan_fill(
             h_chunk_item[chunk++] = (uint32_t)i;
         }
         if (chunks > HUFD_SCAN_SMALL_MAX) {
-            h_large[large++] = (uint32_t)i;
+            h_large[2 * large] = (uint32_t)i;
+            h_large[2 * large + 1] = run;
+            ++large;
+            for (uint32_t k = 0; k * HUFD_SCAN_RUN_CHUNKS < chunks; ++k) {
+                h_runs[2 * run] = (uint32_t)i;
+                h_runs[2 * run + 1] = k;
+                ++run;
+            }
         }
     }
 
     int err = 0;
     const uint32_t ns = eng->tables.n_states;
     hufs_set_device(eng->device);
-    if (n_items > p->cap_items || n_chunks > p->cap_chunks || n_large > p->cap_large) {
+    if (n_items > p->cap_items || n_chunks > p->cap_chunks || n_large > p->cap_large || n_runs > p->cap_runs) {
         dec_plan_release_device(p);
         const size_t ci = n_items ? n_items : 1, cc = n_chunks ? n_chunks : 1, cl = n_large ? n_large : 1;
+        const size_t cr = n_runs ? n_runs : 1;
         p->d_items = hufs_malloc(ci * sizeof(struct hufd_dec_item));
         p->d_chunk_item = hufs_malloc(cc * sizeof(uint32_t));
-        p->d_large = hufs_malloc(cl * sizeof(uint32_t));
+        p->d_large = hufs_malloc(cl * 2 * sizeof(uint32_t));
+        p->d_runs = hufs_malloc(cr * 2 * sizeof(uint32_t));
+        p->d_run_fn = hufs_malloc(cr * ns * sizeof(uint32_t));
+        p->d_run_entry = hufs_malloc(cr * sizeof(uint32_t));
+        p->d_run_base = hufs_malloc(cr * sizeof(uint64_t));
         p->d_fn_tab = hufs_malloc(cc * ns * HUFD_DEC_LANES * sizeof(uint16_t));
         p->d_cp_tab = hufs_malloc(cc * HUFD_DEC_CP_ROWS * HUFD_DEC_LANES * sizeof(uint16_t));
         p->d_chunk_fn = hufs_malloc(cc * ns * sizeof(uint32_t));
@@ -601,21 +624,26 @@ static int dec_plan_fill(
         p->d_states = hufs_malloc(ci * sizeof(struct hufd_dec_item_state));
         p->d_results = hufs_malloc(ci * sizeof(struct hufd_dec_result));
         if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_cp_tab || !p->d_chunk_fn || !p->d_slow_list || !p->d_chunk_entry ||
+            !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
             !p->d_chunk_base || !p->d_states || !p->d_results) {
             err = 2;
         }
         p->cap_items = ci;
         p->cap_chunks = cc;
         p->cap_large = cl;
+        p->cap_runs = cr;
     }
     if (!err) {
         err = hufs_copy_h2d(p->d_items, h_items, n_items * sizeof(*h_items), eng->stream);
     }
     if (!err) {
+        err = hufs_copy_h2d(p->d_runs, h_runs, n_runs * 2 * sizeof(uint32_t), eng->stream);
+    }
+    if (!err) {
         err = hufs_copy_h2d(p->d_chunk_item, h_chunk_item, n_chunks * sizeof(uint32_t), eng->stream);
     }
     if (!err) {
-        err = hufs_copy_h2d(p->d_large, h_large, n_large * sizeof(uint32_t), eng->stream);
+        err = hufs_copy_h2d(p->d_large, h_large, n_large * 2 * sizeof(uint32_t), eng->stream);
     }
     if (!err) {
         err = hufs_stream_sync(eng->stream);
@@ -633,12 +661,14 @@ static int dec_plan_fill(
     free(h_items);
     free(h_chunk_item);
     free(h_large);
+    free(h_runs);
     if (err) {
         return raise_hip(err);
     }
     p->n_items = (uint32_t)n_items;
     p->n_chunks = (uint32_t)n_chunks;
     p->n_large = (uint32_t)n_large;
+    p->n_runs = (uint32_t)n_runs;
     return AWS_OP_SUCCESS;
 }
 
@@ -695,6 +725,11 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.n_chunks = p->n_chunks;
     a.large_items = p->d_large;
     a.n_large = p->n_large;
+    a.runs = p->d_runs;
+    a.n_runs = p->n_runs;
+    a.run_fn = p->d_run_fn;
+    a.run_entry = p->d_run_entry;
+    a.run_base = p->d_run_base;
     a.d_in = device_input;
     a.d_out = device_output;
     a.fn_tab = p->d_fn_tab;
