@@ -62,6 +62,10 @@ struct hufk_decode_args {
     uint32_t *chunk_fn;    /* [n_chunks][n_states] scratch */
     uint32_t *slow_list;   /* [n_chunks] scratch: chunks that take the long way through dec_sync */
     uint32_t *slow_count;  /* [1] */
+    uint32_t *emit_list;   /* [n_chunks] scratch: chunks left to dec_emit by dec_emit_fast */
+    uint32_t *emit_count;  /* [1] */
+    uint16_t *lane_count;  /* [n_chunks][HUFD_DEC_LANES] scratch */
+    uint8_t *chunk_regular; /* [n_chunks] scratch */
     uint32_t *chunk_entry; /* [n_chunks] scratch */
     uint64_t *chunk_base;  /* [n_chunks] scratch */
     struct hufd_dec_item_state *states; /* [n_items] scratch */

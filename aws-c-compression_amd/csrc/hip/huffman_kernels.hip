@@ -1933,6 +1933,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     u16 *fn_tab,   /* [chunk][state][lane] */
     u16 *cp_tab,   /* [chunk][kCpRows][lane]: checkpoints of the reference walk + merged-state mask */
     u32 *chunk_fn, /* [chunk][state] */
+    u8 *chunk_regular,      /* [chunk]: cleared here */
     const u32 *list,        /* NULL: workgroup b handles chunk b; else the chunks list[0 .. *list_count) */
     const u32 *list_count) {
 
@@ -1950,6 +1951,9 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     const hufd_dec_item it = items[chunk_item[c]];
     const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
     const u64 valid = it.in_len > chunk_off ? it.in_len - chunk_off : 0;
+    if (lane == 0) {
+        chunk_regular[c] = 0;
+    }
 
     HUFD_STAMP(0, 0);
     chunk_load(timg, d_in + it.in_off + chunk_off, valid);
@@ -2164,6 +2168,8 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
     u16 *fn_tab,
     u16 *cp_tab,
     u32 *chunk_fn,
+    u16 *lane_count,  /* [chunk][lane]: symbols of the true path that start in the sub-chunk (lane 0: from the meeting bit on) */
+    u8 *chunk_regular, /* [chunk]: 1 = these tables come from here and dec_emit_fast may use them */
     u32 *slow_list,   /* chunks left to dec_sync_kernel */
     u32 *slow_count) {
 
@@ -2259,12 +2265,17 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
     /* H: my own sub-chunk from my true entry state */
     const u32 entry = lane ? sh.exit_state[lane - 1] : 0u;
     u32 count;
+    u32 head_cp = 0;         /* the head walk where it enters the second quarter, when the meeting row lies behind that */
+    const bool late = meet_row > kSubWords / kQuarters;
     {
         u32 st = rw.state_at(entry, 0);
         bool dd = false;
 #pragma unroll
         for (u32 r = 0; r < kFastMaxMeet; ++r) {
             if (r < meet_row) {
+                if (r == kSubWords / kQuarters) {
+                    head_cp = st;
+                }
                 st = rw.row(st, w[r], w[r + 1], sh.wlut);
                 dd = dd || rw.died(st);
                 st = rw.next_row(st);
@@ -2322,10 +2333,21 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
     }
 #pragma unroll
     for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-        /* a checkpoint in front of the meeting row is not on the one walk */
+        /* a checkpoint in front of the meeting row is not on the one walk: the first one is then taken from
+         * the head walk (not for lane 0, whose head is only known to dec_scan) */
         const bool usable = (qq + 1) * (kSubWords / kQuarters) >= meet_row;
-        const u32 tail = ref_count - (cp_state[qq] >> 16);
-        cp[qq * HUFD_DEC_LANES] = (u16)(usable ? 0x8000u | (rw.offset_of(cp_state[qq]) << 11) | tail : 0u);
+        u32 tail = ref_count - (cp_state[qq] >> 16), bits = rw.offset_of(cp_state[qq]);
+        bool have = usable;
+        if (qq == 0 && late && lane != 0) {
+            tail = count - (head_cp >> 16);
+            bits = rw.offset_of(head_cp);
+            have = true;
+        }
+        cp[qq * HUFD_DEC_LANES] = (u16)(have ? 0x8000u | (bits << 11) | tail : 0u);
+    }
+    lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)(lane ? count : ref_count);
+    if (lane == 0) {
+        chunk_regular[c] = 1;
     }
     const u32 merged = lane ? 1u << entry : (u32)cand_alive;
     cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(merged | (ref_exit << 12));
@@ -2571,7 +2593,9 @@ __global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_kernel(
     const u16 *cp_tab,
     const u32 *chunk_entry,
     const u64 *chunk_base,
-    hufd_dec_result *results) {
+    hufd_dec_result *results,
+    const u32 *list,        /* NULL: workgroup b handles chunk b; else the chunks list[0 .. *list_count) */
+    const u32 *list_count) {
 
     const u32 ns = tb.n_states;
     u32 *timg = reinterpret_cast<u32 *>(dyn_lds);
@@ -2589,7 +2613,10 @@ __global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_kernel(
 
     const u32 t = threadIdx.x;
     const u32 lane = t % HUFD_DEC_LANES, q = t / HUFD_DEC_LANES;
-    const u32 c = blockIdx.x;
+    if (list && blockIdx.x >= *list_count) {
+        return;
+    }
+    const u32 c = list ? list[blockIdx.x] : blockIdx.x;
     const u32 entry = chunk_entry[c];
     if (!(entry & 0x100u)) {
         return; /* the stream ended before this chunk */
@@ -2830,6 +2857,194 @@ __global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_kernel(
     HUFD_STAMP(1, 5);
 }
 
+/* ------------------------------------------------------------------ decode: emit, regular chunks */
+
+/*
+ * dec_emit for the chunks dec_sync_fast found regular, when the whole chunk fits the output and
+ * the LDS stage; every other chunk is put on a list for dec_emit_kernel.  Four threads per
+ * sub-chunk as there (thread (lane, q) starts at checkpoint q), but each holds its quarter of the
+ * sub-chunk in registers (nine words of the lane's own 128-byte line) and walks it row by row like
+ * dec_sync_fast: shift, mask, table, byte store, two adds a symbol.  The table entry is
+ * symbol << 16 | (0x10000 - length) & 0xFFFF; only the low half of the walk state is ever looked
+ * at, so the symbol may ride along in the add.
+ */
+template <u32 LB>
+struct emit_shared {
+    u32 wlut[1u << LB];
+    u32 lane_base[HUFD_DEC_LANES]; /* index of the sub-chunk's first symbol within the chunk */
+    u32 wave_tot[HUFD_DEC_LANES / 64];
+    u32 pad[4];
+    u8 stage[HUFD_DEC_STAGE_BYTES + 32];
+};
+
+template <u32 LB>
+__global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_fast_kernel(
+    hufd_tables tb,
+    const hufd_dec_item *items,
+    const u32 *chunk_item,
+    const u8 *d_in,
+    u8 *d_out,
+    const u16 *cp_tab,
+    const u16 *lane_count,
+    const u8 *chunk_regular,
+    const u32 *chunk_fn,
+    const u32 *chunk_entry,
+    const u64 *chunk_base,
+    u32 *slow_list, /* chunks left to dec_emit_kernel */
+    u32 *slow_count) {
+
+    emit_shared<LB> &sh = *reinterpret_cast<emit_shared<LB> *>(dyn_lds);
+    const u32 ns = tb.n_states;
+    const u32 t = threadIdx.x;
+    const u32 lane = t % HUFD_DEC_LANES, q = t / HUFD_DEC_LANES;
+    const u32 c = blockIdx.x;
+    const u32 centry = chunk_entry[c];
+    if (!(centry & 0x100u)) {
+        return; /* the stream ended before this chunk */
+    }
+    const u32 s0 = centry & 0xFFu;
+    const hufd_dec_item it = items[chunk_item[c]];
+    const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
+    const u64 cbase = chunk_base[c];
+    const u16 *cpt = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES;
+    const u32 merged_row = (kQuarters - 1) * HUFD_DEC_LANES;
+    const u32 f0 = chunk_fn[(u64)c * ns + s0];
+    const u32 chunk_symbols = wide_count(f0);
+    /* all the same for the whole workgroup */
+    const bool fast = chunk_regular[c] != 0 && !wide_stop(f0) && ((cpt[merged_row] >> s0) & 1u) != 0 &&
+                      cbase + chunk_symbols <= it.out_cap && chunk_symbols + 16 <= HUFD_DEC_STAGE_BYTES;
+    if (!fast) {
+        if (t == 0) {
+            slow_list[atomicAdd(slow_count, 1u)] = c;
+#if defined(HUFD_EMU_TRACE)
+            fprintf(stderr, "emit: chunk %u slow: regular %d stop %d alive %d fits %d stage %d\n", c, (int)chunk_regular[c],
+                    (int)wide_stop(f0), (int)((cpt[merged_row] >> s0) & 1u), (int)(cbase + chunk_symbols <= it.out_cap),
+                    (int)(chunk_symbols + 16 <= HUFD_DEC_STAGE_BYTES));
+#endif
+        }
+        return;
+    }
+
+    HUFD_STAMP(1, 0);
+    /* my quarter: rows 8q .. 8q+7 and the word after them */
+    constexpr u32 kRows = kSubWords / kQuarters;
+    const u8 *sub = d_in + it.in_off + chunk_off + (u64)lane * HUFD_DEC_SUB_BYTES;
+    u32 w[kRows + 1];
+    {
+        const uint4 *p = reinterpret_cast<const uint4 *>(sub + q * kRows * 4);
+#pragma unroll
+        for (u32 j = 0; j < kRows / 4; ++j) {
+            const uint4 v = p[j];
+            w[4 * j + 0] = __builtin_bswap32(v.x);
+            w[4 * j + 1] = __builtin_bswap32(v.y);
+            w[4 * j + 2] = __builtin_bswap32(v.z);
+            w[4 * j + 3] = __builtin_bswap32(v.w);
+        }
+        w[kRows] = __builtin_bswap32(*reinterpret_cast<const u32 *>(sub + (q + 1) * kRows * 4));
+    }
+    const u32 my_cp = q ? cpt[(q - 1) * HUFD_DEC_LANES + lane] : 0u;
+    const u32 next_cp = q + 1 < kQuarters ? cpt[q * HUFD_DEC_LANES + lane] : 0u;
+    const u32 entry_state = lane ? (u32)(cpt[merged_row + lane - 1] >> 12) : s0;
+    const u32 cnt = lane_count[(u64)c * HUFD_DEC_LANES + lane];
+    for (u32 i = t; i < (1u << LB); i += kEmitThreads) {
+        const u32 e = tb.dec_lut[i >> (LB - tb.lut_bits)];
+        const u32 len = e & 0xFFu;
+        sh.wlut[i] = ((e >> 8) << 16) | ((0x10000u - (len ? len : kWalkDeadLen)) & 0xFFFFu);
+    }
+    /* where every sub-chunk's symbols go: lane 0's count follows from the chunk's total */
+    u32 incl = 0;
+    if (q == 0) {
+        incl = wave_inclusive_sum(lane ? cnt : 0u, lane & (kWave - 1));
+        if ((lane & (kWave - 1)) == kWave - 1) {
+            sh.wave_tot[lane / kWave] = incl;
+        }
+    }
+    __syncthreads();
+    u32 rest = 0, before = 0;
+#pragma unroll
+    for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
+        const u32 tot = sh.wave_tot[wv];
+        rest += tot;
+        before += wv < lane / kWave ? tot : 0u;
+    }
+    const u32 first_count = chunk_symbols - rest; /* sub-chunk 0, entered in state s0 */
+    if (q == 0) {
+        sh.lane_base[lane] = lane ? first_count + before + incl - cnt : 0u;
+    }
+    __syncthreads();
+    HUFD_STAMP(1, 1);
+
+    const u32 lane_n = lane ? cnt : first_count;
+    /* my share: from my checkpoint (q = 0: the entry state) to the next usable one */
+    const bool mine = q == 0 || (my_cp & 0x8000u) != 0;
+    const u32 first = q ? lane_n - (my_cp & 0x7FFu) : 0u;
+    const u32 start_bit = q ? (my_cp >> 11) & 15u : entry_state;
+    /* only sub-chunk 0's first checkpoint can be missing (its head is not known when dec_sync_fast runs) */
+    const bool extend = q == 0 && !(next_cp & 0x8000u);
+
+    u8 *out_ptr = d_out + it.out_off + cbase;
+    const u32 mis = (u32)((uintptr_t)out_ptr & 15u);
+    u8 *dst = sh.stage + mis + sh.lane_base[lane] + first;
+    const row_walk rw(LB, tb.max_bits);
+    HUFD_STAMP(1, 2);
+    if (mine) {
+        u32 st = rw.state_at(start_bit, 0);
+#pragma unroll
+        for (u32 r = 0; r < kRows; ++r) {
+            const u64 pair = ((u64)w[r] << 32) | w[r + 1];
+            while ((st & 0xFFFFu) > rw.thr) {
+                const u32 off = (u32)(pair >> (st & 63u)) & rw.mask;
+                const u32 e = *reinterpret_cast<const u32 *>(reinterpret_cast<const u8 *>(sh.wlut) + off);
+                *dst++ = (u8)(e >> 16);
+                st += e;
+            }
+            st += 32u;
+        }
+        if (extend) {
+            /* rare: on through the second quarter, words straight from memory */
+            u32 hi = w[kRows];
+            for (u32 r = kRows; r < 2 * kRows; ++r) {
+                const u32 lo = __builtin_bswap32(*reinterpret_cast<const u32 *>(sub + (r + 1) * 4));
+                const u64 pair = ((u64)hi << 32) | lo;
+                while ((st & 0xFFFFu) > rw.thr) {
+                    const u32 off = (u32)(pair >> (st & 63u)) & rw.mask;
+                    const u32 e = *reinterpret_cast<const u32 *>(reinterpret_cast<const u8 *>(sh.wlut) + off);
+                    *dst++ = (u8)(e >> 16);
+                    st += e;
+                }
+                st += 32u;
+                hi = lo;
+            }
+        }
+    }
+    HUFD_STAMP(1, 3);
+    __syncthreads();
+    HUFD_STAMP(1, 4);
+
+    {
+        /* stage byte b belongs at (out_ptr - mis) + b: whole 16-byte rows go out aligned */
+        u8 *gbase = out_ptr - mis;
+        const u32 lo = mis, hi = mis + chunk_symbols;
+        const u32 row_lo = (lo + 15) >> 4, row_hi = hi >> 4;
+        if (row_lo <= row_hi) {
+            for (u32 b = lo + t; b < row_lo * 16; b += kEmitThreads) {
+                gbase[b] = sh.stage[b];
+            }
+            for (u32 r = row_lo + t; r < row_hi; r += kEmitThreads) {
+                *reinterpret_cast<uint4 *>(gbase + (u64)r * 16) = *reinterpret_cast<const uint4 *>(sh.stage + r * 16);
+            }
+            for (u32 b = row_hi * 16 + t; b < hi; b += kEmitThreads) {
+                gbase[b] = sh.stage[b];
+            }
+        } else {
+            for (u32 b = lo + t; b < hi; b += kEmitThreads) {
+                gbase[b] = sh.stage[b];
+            }
+        }
+    }
+    HUFD_STAMP(1, 5);
+}
+
 /* ------------------------------------------------------------------ synthetic input */
 
 __global__ __launch_bounds__(256) void splitmix64_fill_kernel(u8 *dst, u64 len, u64 seed) {
@@ -2880,6 +3095,14 @@ int hufk_init(void) {
     }
     hipError_t e = hipFuncSetAttribute(
         reinterpret_cast<const void *>(&dec_emit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    if (e == hipSuccess) {
+        e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&dec_emit_fast_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    }
+    if (e == hipSuccess) {
+        e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&dec_emit_fast_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    }
     if (e == hipSuccess) {
         e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&dec_sync_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -3047,17 +3270,17 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             hipLaunchKernelGGL(
                 dec_sync_fast_kernel<10>, dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<10>), st,
                 a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn,
-                a->slow_list, a->slow_count);
+                a->lane_count, a->chunk_regular, a->slow_list, a->slow_count);
         } else {
             hipLaunchKernelGGL(
                 dec_sync_fast_kernel<12>, dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<12>), st,
                 a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn,
-                a->slow_list, a->slow_count);
+                a->lane_count, a->chunk_regular, a->slow_list, a->slow_count);
         }
         hipLaunchKernelGGL(
             sync, dim3(a->n_chunks), dim3(HUFD_DEC_LANES), dec_sync_lds_bytes(&a->tables), st, a->tables, a->items,
-            a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, (const u32 *)a->slow_list,
-            (const u32 *)a->slow_count);
+            a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular,
+            (const u32 *)a->slow_list, (const u32 *)a->slow_count);
     }
     stage_mark(a->stage_events, 1, st);
     hipLaunchKernelGGL(
@@ -3076,10 +3299,25 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     }
     stage_mark(a->stage_events, 2, st);
     if (a->n_chunks) {
+        /* regular chunks that fit their output the short way; the rest through the list */
+        (void)hipMemsetAsync(a->emit_count, 0, sizeof(uint32_t), st);
+        if (a->tables.lut_bits <= 10) {
+            hipLaunchKernelGGL(
+                dec_emit_fast_kernel<10>, dim3(a->n_chunks), dim3(kEmitThreads), (uint32_t)sizeof(emit_shared<10>), st,
+                a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab,
+                (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn,
+                (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->emit_list, a->emit_count);
+        } else {
+            hipLaunchKernelGGL(
+                dec_emit_fast_kernel<12>, dim3(a->n_chunks), dim3(kEmitThreads), (uint32_t)sizeof(emit_shared<12>), st,
+                a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab,
+                (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn,
+                (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->emit_list, a->emit_count);
+        }
         hipLaunchKernelGGL(
             dec_emit_kernel, dim3(a->n_chunks), dim3(kEmitThreads), dec_emit_lds_bytes(&a->tables), st, a->tables,
             a->items, a->chunk_item, (const u8 *)a->d_in, (u8 *)a->d_out, a->fn_tab, a->cp_tab, a->chunk_entry,
-            a->chunk_base, a->results);
+            a->chunk_base, a->results, (const u32 *)a->emit_list, (const u32 *)a->emit_count);
     }
     stage_mark(a->stage_events, 3, st);
     return (int)hipGetLastError();

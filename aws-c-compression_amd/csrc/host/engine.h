@@ -74,6 +74,9 @@ struct aws_huffman_amd_decode_plan {
     uint16_t *d_cp_tab;
     uint32_t *d_chunk_fn;
     uint32_t *d_slow_list; /* [0] how many, [1..] the chunks dec_sync_fast left to dec_sync */
+    uint32_t *d_emit_list; /* the same for dec_emit_fast / dec_emit */
+    uint16_t *d_lane_count;
+    uint8_t *d_chunk_regular;
     uint32_t *d_chunk_entry;
     uint64_t *d_chunk_base;
     struct hufd_dec_item_state *d_states;

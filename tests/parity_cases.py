@@ -296,6 +296,32 @@ def garbage_decode(w, seed=15, rounds=120, big=70000):
         assert dst[: r.produced].tobytes().hex() == rec["symbols"]
 
 
+# ----------------------------------------------------------------------------- scenario: long streams with damage / short output (several scan runs)
+def damaged_long_streams(w, seed=19, big=10_000_000):
+    """Streams of several hundred chunks (more than one scan run of 256 chunks): damage inside a
+    sub-chunk, at chunk and run boundaries, and output capacities that end in either run."""
+    rng = np.random.default_rng(seed)
+    plain = inputs(rng, big, "uniform")
+    good = oracle_encode(w, plain)
+    run_bytes = 256 * 32768
+    assert good.size > run_bytes + 4 * 32768
+    cases = []
+    for at in (5 * 32768 + 777, run_bytes - 1, run_bytes, run_bytes + 32768 * 3 + 129, good.size - 40000):
+        bad = good.copy()
+        bad[at] ^= 0xFF
+        bad[at + 1] = 0x00
+        bad[at + 2] = 0x00
+        cases.append((bad, 2 * big))
+    for cap in (big, big - 1, 7_000_000, 8_000_001, 3):
+        cases.append((good, cap))
+    cases.append((good[: run_bytes + 5], 2 * big))
+    for data, out_cap in cases:
+        n = data.size
+        oo, op = np.full(out_cap + 8, SENTINEL, np.uint8), np.full(out_cap + 8, SENTINEL, np.uint8)
+        ddo, ddp = w.oracle.new_decoder(w.ocoder), w.product.new_decoder(w.pcoder)
+        paired_decode(w, ddo, ddp, data, 0, n, oo, op, 0, out_cap)
+
+
 # ----------------------------------------------------------------------------- scenario: padding byte values
 def eos_padding_values(w):
     rng = np.random.default_rng(16)

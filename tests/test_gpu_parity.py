@@ -56,6 +56,10 @@ def test_garbage_decode(world):
     pc.garbage_decode(world)
 
 
+def test_damaged_long_streams(world):
+    pc.damaged_long_streams(world)
+
+
 def test_eos_padding_values(world):
     pc.eos_padding_values(world)
 
