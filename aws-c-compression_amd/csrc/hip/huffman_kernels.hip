@@ -230,59 +230,128 @@ __device__ __forceinline__ void load_segment_groups(
     }
 }
 
+/* A segment descriptor is the same in every lane: say so, and it lives in scalar registers. */
+__device__ __forceinline__ hufd_enc_seg uniform_seg(const hufd_enc_seg *p) {
+    hufd_enc_seg d = *p;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 lo = __builtin_amdgcn_readfirstlane((u32)d.in_off);
+    const u32 hi = __builtin_amdgcn_readfirstlane((u32)(d.in_off >> 32));
+    d.in_off = ((u64)hi << 32) | lo;
+    d.len = __builtin_amdgcn_readfirstlane(d.len);
+    d.item = __builtin_amdgcn_readfirstlane(d.item);
+    d.index = __builtin_amdgcn_readfirstlane(d.index);
+    d.flags = __builtin_amdgcn_readfirstlane(d.flags);
+    d.next_len = __builtin_amdgcn_readfirstlane(d.next_len);
+#endif
+    return d;
+}
+
+/*
+ * Bits per segment and its first symbol without a code.  The kernel is a stream of table
+ * look-ups, and a 256-entry table read by 64 lanes at random is served at a third of the LDS rate
+ * (bank conflicts), which made this kernel LDS-bound.  So every entry is kept 32 times, one copy
+ * per bank: lane l reads entry b at word 32 b + (l & 31) and never shares a bank with another
+ * lane.  32 KiB of table per workgroup, hence persistent workgroups (segment blockIdx.x,
+ * + gridDim.x, ...) that build it once.  Entry = length | (length == 0) << 20, so one add per
+ * symbol counts the bits and the symbols without a code together.
+ */
+constexpr u32 kCountLdsBytes = 256 * 32 * 4 + 64;
+
 __global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_count_kernel(
     hufd_tables tb,
     const hufd_enc_seg *segs,
     const u8 *d_in,
     u32 *seg_bits,
     u32 *seg_unk,
-    u32 *careful_count) {
+    u32 *careful_count,
+    u32 n_segs) {
 
-    u32 *len_tab = reinterpret_cast<u32 *>(dyn_lds); /* [256] */
-    u32 *slots = len_tab + 256;                       /* [8] */
+    u32 *tab = reinterpret_cast<u32 *>(dyn_lds); /* [256][32] */
+    u32 *slots = tab + 256 * 32;                  /* [16] */
 
     const u32 tid = threadIdx.x;
-    const u32 s = blockIdx.x;
-    if (s == 0 && tid == 0) {
+    const u32 lane = tid & (kWave - 1), wave = tid / kWave;
+    if (blockIdx.x == 0 && tid == 0) {
         *careful_count = 0; /* the scan kernels of this launch append to the list */
     }
-    const hufd_enc_seg seg = segs[s];
-    u32 gw[kGroupsPerLane][4], gvalid[kGroupsPerLane];
-    load_segment_groups(d_in + seg.in_off, seg.len, gw, gvalid);
-    len_tab[tid] = (u32)(tb.enc_table[tid] >> 32);
+    {
+        const u32 len = (u32)(tb.enc_table[tid] >> 32);
+        const u32 e = len | (len == 0 ? 1u << 20 : 0u);
+#pragma unroll
+        for (u32 k = 0; k < 32; ++k) {
+            tab[tid * 32 + ((k + tid) & 31u)] = e; /* rotated so that the 32 stores of a group hit 32 banks */
+        }
+    }
     __syncthreads();
+    const u8 *mine = reinterpret_cast<const u8 *>(tab) + (lane & 31u) * 4u;
 
-    u32 bits = 0, unk = HUFD_NONE32;
+    for (u32 s = blockIdx.x; s < n_segs; s += gridDim.x) {
+        const hufd_enc_seg seg = uniform_seg(&segs[s]);
+        const u8 *src = d_in + seg.in_off;
+        u32 sum = 0;
+        if (seg.len == HUFD_ENC_SEG_BYTES && ((uintptr_t)src & 15u) == 0) {
+            uint4 v[kGroupsPerLane];
 #pragma unroll
-    for (u32 g = 0; g < kGroupsPerLane; ++g) {
+            for (u32 g = 0; g < kGroupsPerLane; ++g) {
+                v[g] = reinterpret_cast<const uint4 *>(src)[g * HUFD_ENC_THREADS + tid];
+            }
 #pragma unroll
-        for (u32 j = 0; j < 16; ++j) {
-            if (j < gvalid[g]) {
-                const u32 len = len_tab[group_byte(gw[g], j)];
-                bits += len;
-                if (len == 0 && unk == HUFD_NONE32) {
-                    unk = (g * HUFD_ENC_THREADS + tid) * 16 + j;
+            for (u32 g = 0; g < kGroupsPerLane; ++g) {
+                const u32 wd[4] = {v[g].x, v[g].y, v[g].z, v[g].w};
+#pragma unroll
+                for (u32 j = 0; j < 16; ++j) {
+                    const u32 b = (wd[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                    sum += *reinterpret_cast<const u32 *>(mine + b * 128u);
+                }
+            }
+        } else {
+            /* a ragged or unaligned segment: symbol by symbol */
+            u32 gw[kGroupsPerLane][4], gvalid[kGroupsPerLane];
+            load_segment_groups(src, seg.len, gw, gvalid);
+#pragma unroll
+            for (u32 g = 0; g < kGroupsPerLane; ++g) {
+                for (u32 j = 0; j < gvalid[g]; ++j) {
+                    sum += *reinterpret_cast<const u32 *>(mine + group_byte(gw[g], j) * 128u);
                 }
             }
         }
-    }
-
-    bits = wave_sum(bits);
-    unk = wave_min(unk);
-    const u32 lane = tid & (kWave - 1), wave = tid / kWave;
-    if (lane == 0) {
-        slots[wave] = bits;
-        slots[4 + wave] = unk;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        u32 b = 0, u = HUFD_NONE32;
-        for (u32 w = 0; w < HUFD_ENC_THREADS / kWave; ++w) {
-            b += slots[w];
-            u = slots[4 + w] < u ? slots[4 + w] : u;
+        u32 bits = wave_sum(sum & 0xFFFFFu);
+        u32 holes = wave_sum(sum >> 20);
+        if (lane == 0) {
+            slots[wave] = bits;
+            slots[4 + wave] = holes;
         }
-        seg_bits[s] = b;
-        seg_unk[s] = u;
+        __syncthreads();
+        bits = slots[0] + slots[1] + slots[2] + slots[3];
+        holes = slots[4] + slots[5] + slots[6] + slots[7];
+        u32 unk = HUFD_NONE32;
+        if (holes) {
+            /* rare: which symbol is the first without a code */
+            for (u32 g = 0; g < kGroupsPerLane && unk == HUFD_NONE32; ++g) {
+                const u32 base = (g * HUFD_ENC_THREADS + tid) * 16;
+                for (u32 j = 0; j < 16 && base + j < seg.len; ++j) {
+                    if ((*reinterpret_cast<const u32 *>(mine + (u32)src[base + j] * 128u) >> 20) != 0) {
+                        unk = base + j;
+                        break;
+                    }
+                }
+            }
+            unk = wave_min(unk);
+            if (lane == 0) {
+                slots[8 + wave] = unk;
+            }
+            __syncthreads();
+            unk = slots[8];
+#pragma unroll
+            for (u32 wv = 1; wv < HUFD_ENC_THREADS / kWave; ++wv) {
+                unk = slots[8 + wv] < unk ? slots[8 + wv] : unk;
+            }
+        }
+        if (tid == 0) {
+            seg_bits[s] = bits;
+            seg_unk[s] = unk;
+        }
+        __syncthreads(); /* slots are reused by the next segment */
     }
 }
 
@@ -844,22 +913,6 @@ __global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_pack_kernel(
         __syncthreads();
         pack_write_out(img, sh, g, seg, it, st, results);
     }
-}
-
-/* A segment descriptor is the same in every lane: say so, and it lives in scalar registers. */
-__device__ __forceinline__ hufd_enc_seg uniform_seg(const hufd_enc_seg *p) {
-    hufd_enc_seg d = *p;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const u32 lo = __builtin_amdgcn_readfirstlane((u32)d.in_off);
-    const u32 hi = __builtin_amdgcn_readfirstlane((u32)(d.in_off >> 32));
-    d.in_off = ((u64)hi << 32) | lo;
-    d.len = __builtin_amdgcn_readfirstlane(d.len);
-    d.item = __builtin_amdgcn_readfirstlane(d.item);
-    d.index = __builtin_amdgcn_readfirstlane(d.index);
-    d.flags = __builtin_amdgcn_readfirstlane(d.flags);
-    d.next_len = __builtin_amdgcn_readfirstlane(d.next_len);
-#endif
-    return d;
 }
 
 /* asks for a segment's symbols: 16-byte chunk c of the segment goes to inbuf + 16 c (LDS-DMA) */
@@ -3213,9 +3266,10 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
     }
     stage_mark(a->stage_events, 0, st);
     if (a->n_segs) {
+        const uint32_t grid = persistent_grid(enc_count_kernel, HUFD_ENC_THREADS, kCountLdsBytes, a->n_segs);
         hipLaunchKernelGGL(
-            enc_count_kernel, dim3(a->n_segs), dim3(HUFD_ENC_THREADS), 256 * 4 + 8 * 4, st, a->tables, a->segs,
-            (const u8 *)a->d_in, a->seg_bits, a->seg_unk, a->careful_count);
+            enc_count_kernel, dim3(grid), dim3(HUFD_ENC_THREADS), kCountLdsBytes, st, a->tables, a->segs,
+            (const u8 *)a->d_in, a->seg_bits, a->seg_unk, a->careful_count, a->n_segs);
     } else {
         (void)hipMemsetAsync(a->careful_count, 0, sizeof(uint32_t), st);
     }
