@@ -25,6 +25,7 @@ struct hufk_encode_args {
     const void *d_in;
     void *d_out;
     uint32_t *seg_bits;   /* [n_segs] scratch */
+    uint32_t *wave_bits;  /* [n_segs][4] scratch: bits of each quarter (4 KiB of symbols) of a segment */
     uint32_t *seg_unk;    /* [n_segs] scratch */
     uint64_t *seg_bitoff; /* [n_segs] scratch */
     uint32_t *careful_list;  /* [2 * n_items] scratch: segments for the per-symbol packer */

@@ -75,6 +75,22 @@ __device__ __forceinline__ u32 wave_inclusive_sum(u32 v, u32 lane) {
     return v;
 }
 
+/* the same sum with data-parallel-primitive moves instead of LDS permutes: six adds, no LDS traffic */
+__device__ __forceinline__ u32 wave_inclusive_sum_dpp(u32 v, u32 lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)lane;
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); /* row_shr:1 */
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false); /* row_shr:2 */
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false); /* row_shr:4 */
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false); /* row_shr:8 */
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); /* row_bcast:15 into rows 1 and 3 */
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); /* row_bcast:31 into rows 2 and 3 */
+    return v;
+#else
+    return wave_inclusive_sum(v, lane);
+#endif
+}
+
 __device__ __forceinline__ u32 wave_min(u32 v) {
 #pragma unroll
     for (u32 d = kWave / 2; d > 0; d >>= 1) {
@@ -262,6 +278,7 @@ __global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_count_kernel(
     const hufd_enc_seg *segs,
     const u8 *d_in,
     u32 *seg_bits,
+    u32 *wave_bits, /* [seg][4]: bits of each quarter of the segment (wave w of enc_pack_wave packs quarter w) */
     u32 *seg_unk,
     u32 *careful_count,
     u32 n_segs) {
@@ -293,7 +310,8 @@ __global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_count_kernel(
             uint4 v[kGroupsPerLane];
 #pragma unroll
             for (u32 g = 0; g < kGroupsPerLane; ++g) {
-                v[g] = reinterpret_cast<const uint4 *>(src)[g * HUFD_ENC_THREADS + tid];
+                /* wave w counts the w-th quarter of the segment: the unit enc_pack_wave packs */
+                v[g] = reinterpret_cast<const uint4 *>(src)[(wave * kGroupsPerLane + g) * kWave + lane];
             }
 #pragma unroll
             for (u32 g = 0; g < kGroupsPerLane; ++g) {
@@ -320,6 +338,7 @@ __global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_count_kernel(
         if (lane == 0) {
             slots[wave] = bits;
             slots[4 + wave] = holes;
+            wave_bits[4 * s + wave] = bits; /* only meaningful for whole, aligned segments: the others are packed symbol by symbol */
         }
         __syncthreads();
         bits = slots[0] + slots[1] + slots[2] + slots[3];
@@ -1139,6 +1158,335 @@ __global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_pack_stream_kernel(
         seg = seg_next;
         seg_next = seg_after;
         barrier_lds(); /* copy-out has read the image; its stores stay in flight */
+    }
+}
+
+/* ------------------------------------------------------------------ encode: pack, one wave per tile */
+
+/*
+ * The packer for whole, aligned segments of coders with codes of 4 .. 15 bits (the reference's
+ * test coder: 5 .. 10).  Written around three measurements of the packer before it
+ * (profiles/r01_d_*): ~16 vector instructions a symbol at ~4 cycles each were the bound, a
+ * third of the LDS time went into bank conflicts of the table look-ups, and LDS atomics into a
+ * zeroed image cost a zeroing pass and returned nothing.
+ *
+ *  - One WAVE packs one TILE: a quarter segment, 4 KiB of symbols, whose bit offset comes from
+ *    enc_count's per-quarter totals.  A wave owns the output bytes whose first bit lies in its
+ *    tile and completes its last byte with the first codes of the next tile (which it looks up
+ *    itself), so waves share nothing: no workgroup barrier after the table is built.
+ *  - The code table is kept once per LDS bank (entry b for lane l at word 32 b + l % 32): no bank
+ *    conflicts.  Entry = code left-aligned in the high half | length.
+ *  - A lane merges its 16 symbols pairwise in registers: codes -> pairs -> quads -> two "octs" of
+ *    eight symbols (up to 120 bits, left-aligned).  One wave scan per two groups places them.
+ *  - An oct becomes NW whole words at the lane's bit offset (funnel shifts), stored with PLAIN
+ *    stores: an oct is at least 32 bits long, so the word a unit starts in is the only one it
+ *    shares with its predecessor.  All units of a group store word k before any stores word
+ *    k - 1: whatever a unit writes past its own end (zeros) is overwritten by the unit that owns
+ *    that word, whose store comes later; word 0 is OR-ed in last, onto the predecessor's tail.
+ *    No zeroing of the image, no atomics but that one OR.
+ */
+constexpr u32 kTileBytes = HUFD_ENC_SEG_BYTES / 4;
+constexpr u32 kTilesPerSeg = 4;
+constexpr u32 kPackWaves = 8; /* waves (= independent tiles in flight) per workgroup */
+constexpr u32 kPackThreads = kPackWaves * kWave;
+constexpr u32 kPackTabBytes = 256 * 32 * 4;
+
+/* lanes of a wave take turns in program order: nothing on the GPU, a rendezvous of the wave's fibers under tests/emu */
+__device__ __forceinline__ void wave_step() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_wave_barrier();
+#else
+    (void)__ballot(1);
+#endif
+}
+
+__device__ __forceinline__ u32 funnel(u32 hi, u32 lo, u32 shift /* 0..31 */) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, shift);
+#else
+    return (u32)(((((u64)hi) << 32) | lo) >> shift);
+#endif
+}
+
+/* bytes of LDS one tile's bit image needs: the tile's bits, 16 bytes of alignment in front, the words a last unit spills */
+__device__ __host__ inline u32 pack_region_bytes(u32 max_bits) {
+    return ((kTileBytes * max_bits + 7) / 8 + 16 + 8 * 4 + 15) & ~15u;
+}
+
+/* copies region bytes [lo, hi) to gbase + b (gbase 16-byte aligned), one wave */
+__device__ __forceinline__ void region_store(const u32 *img, u8 *gbase, u32 lo, u32 hi, u32 lane) {
+    if (hi <= lo) {
+        return;
+    }
+    const u32 row_lo = (lo + 15) >> 4, row_hi = hi >> 4;
+    if (row_lo <= row_hi) {
+        for (u32 b = lo + lane; b < row_lo * 16; b += kWave) {
+            gbase[b] = (u8)(img[b >> 2] >> (24 - 8 * (b & 3)));
+        }
+        uint4 *rows = reinterpret_cast<uint4 *>(__builtin_assume_aligned(gbase, 16));
+        for (u32 r = row_lo + lane; r < row_hi; r += kWave) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&img[r * 4]);
+            uint4 o;
+            o.x = __builtin_bswap32(v.x);
+            o.y = __builtin_bswap32(v.y);
+            o.z = __builtin_bswap32(v.z);
+            o.w = __builtin_bswap32(v.w);
+            rows[r] = o;
+        }
+        for (u32 b = row_hi * 16 + lane; b < hi; b += kWave) {
+            gbase[b] = (u8)(img[b >> 2] >> (24 - 8 * (b & 3)));
+        }
+    } else {
+        for (u32 b = lo + lane; b < hi; b += kWave) {
+            gbase[b] = (u8)(img[b >> 2] >> (24 - 8 * (b & 3)));
+        }
+    }
+}
+
+/* plain read-modify-write of the low `nbits` (1..32) bits of `pattern` into the image at bit q: one lane */
+__device__ __forceinline__ void region_put_bits(u32 *img, u32 q, u32 pattern, u32 nbits) {
+    const u64 left = ((u64)pattern << (64 - nbits)) >> (q & 31);
+    img[q >> 5] |= (u32)(left >> 32);
+    if ((u32)left) {
+        img[(q >> 5) + 1] |= (u32)left;
+    }
+}
+
+template <u32 NW> /* words an oct can touch: 4 for codes of at most 12 bits, 5 up to 15 */
+__global__ __launch_bounds__(kPackThreads) void enc_pack_wave_kernel(
+    hufd_tables tb,
+    const hufd_enc_item *items,
+    const hufd_enc_item_state *states,
+    const hufd_enc_seg *segs,
+    const u32 *seg_bits,
+    const u32 *wave_bits,
+    const u64 *seg_bitoff,
+    const u8 *d_in,
+    u8 *d_out,
+    u32 region_bytes,
+    u32 n_segs,
+    u32 *careful_list,   /* segments this kernel leaves to enc_pack_kernel are added */
+    u32 *careful_count) {
+
+    u32 *tab = reinterpret_cast<u32 *>(dyn_lds); /* [256][32] */
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    u32 *img = reinterpret_cast<u32 *>(dyn_lds + kPackTabBytes + wave * region_bytes);
+
+    if (tid < 256) {
+        const u64 ent = tb.enc_table[tid];
+        const u32 len = (u32)(ent >> 32);
+        const u32 e = len ? ((((u32)ent << (16 - len)) & 0xFFFFu) << 16) | len : 0u;
+#pragma unroll
+        for (u32 k = 0; k < 32; ++k) {
+            tab[tid * 32 + ((k + tid) & 31u)] = e;
+        }
+    }
+    __syncthreads();
+    const u8 *mine = reinterpret_cast<const u8 *>(tab) + (lane & 31u) * 4u;
+    const bool coder_ok = tb.max_bits <= (NW == 4 ? 12u : 15u) && tb.min_bits >= 4;
+
+    const u32 n_tiles = n_segs * kTilesPerSeg;
+    uint4 v[kGroupsPerLane], vn[kGroupsPerLane]; /* this tile's symbols and the next one's, asked for a tile ahead */
+    bool fetched = false;
+#pragma unroll
+    for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
+        v[gi] = vn[gi] = uint4{0, 0, 0, 0};
+    }
+    for (u32 tile = blockIdx.x * kPackWaves + wave; tile < n_tiles; tile += gridDim.x * kPackWaves) {
+        const u32 s = tile / kTilesPerSeg, w4 = tile % kTilesPerSeg;
+        const bool had = fetched;
+        if (had) {
+#pragma unroll
+            for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
+                v[gi] = vn[gi];
+            }
+        }
+        fetched = false;
+        {
+            /* the wave's next tile: on its way while this one is packed (whole, aligned segments only: the others are not packed here) */
+            const u32 next = tile + gridDim.x * kPackWaves;
+            if (next < n_tiles) {
+                const hufd_enc_seg nseg = uniform_seg(&segs[next / kTilesPerSeg]);
+                const u8 *nsrc = d_in + nseg.in_off + (next % kTilesPerSeg) * kTileBytes;
+                if (nseg.len == HUFD_ENC_SEG_BYTES && ((uintptr_t)nsrc & 15u) == 0) {
+#pragma unroll
+                    for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
+                        vn[gi] = reinterpret_cast<const uint4 *>(nsrc)[gi * kWave + lane];
+                    }
+                    fetched = true;
+                }
+            }
+        }
+        const hufd_enc_seg seg = uniform_seg(&segs[s]);
+        const hufd_enc_item it = items[seg.item];
+        const hufd_enc_item_state st = states[seg.item];
+        const pack_geometry g = pack_geometry_of(tb, seg, s, it, st, seg_bitoff[s], seg_bits[s], d_out);
+        const u8 *src = d_in + seg.in_off;
+        if (g.skip || g.careful) {
+            continue; /* nothing to write, or already on the list */
+        }
+        const bool shaped = coder_ok && seg.len == HUFD_ENC_SEG_BYTES && ((uintptr_t)src & 15u) == 0 &&
+                            !(seg.index == 0 && it.ovf_bits);
+        if (!shaped) {
+            if (w4 == 0 && lane == 0) {
+                careful_list[atomicAdd(careful_count, 1u)] = s;
+            }
+            continue;
+        }
+
+        /* where the tile's bits go */
+        u64 bw = g.p0;
+        for (u32 k = 0; k < w4; ++k) {
+            bw += wave_bits[kTilesPerSeg * s + k];
+        }
+        const u32 tile_bits = wave_bits[kTilesPerSeg * s + w4];
+        const u64 bn = bw + tile_bits;
+        const bool first_tile = seg.index == 0 && w4 == 0;
+        const bool last_tile = (seg.flags & 2u) != 0 && w4 == kTilesPerSeg - 1;
+        u8 *out_ptr = d_out + it.out_off;
+        const u64 jb = bw >> 3;                                       /* stream byte holding the tile's first bit */
+        const u32 mis = (u32)((uintptr_t)(out_ptr + jb) & 15u);
+        u8 *gbase = out_ptr + jb - mis;                               /* output address of image byte 0, 16-byte aligned */
+        const u32 q0 = (u32)(bw - 8 * jb) + 8 * mis;                  /* image bit of the tile's first code */
+
+        /* the tile's symbols: wave-contiguous, 16 per lane and group */
+        const u8 *tsrc = src + w4 * kTileBytes;
+        if (!had) {
+#pragma unroll
+            for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
+                v[gi] = reinterpret_cast<const uint4 *>(tsrc)[gi * kWave + lane];
+            }
+        }
+        /* the next tile's first two symbols complete my last byte (a code is at least 4 bits, the byte lacks at most 7) */
+        u32 halo_n = 0, halo0 = 0, halo1 = 0;
+        if (!last_tile) {
+            halo_n = w4 + 1 < kTilesPerSeg ? 2u : (seg.next_len < 2 ? seg.next_len : 2u);
+            halo0 = halo_n > 0 ? tsrc[kTileBytes] : 0u;
+            halo1 = halo_n > 1 ? tsrc[kTileBytes + 1] : 0u;
+        }
+        if (lane == 0) {
+            img[q0 >> 5] = 0; /* the word the first unit ORs its head into */
+        }
+
+        /* codes -> pairs -> quads -> octs */
+        u64 ohi[kGroupsPerLane][2], olo[kGroupsPerLane][2];
+        u32 olen[kGroupsPerLane]; /* the two oct lengths of a group, 16 bits each */
+#pragma unroll
+        for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
+            const u32 wd[4] = {v[gi].x, v[gi].y, v[gi].z, v[gi].w};
+            u32 both = 0;
+#pragma unroll
+            for (u32 o = 0; o < 2; ++o) {
+                u64 quad[2];
+                u32 qlen[2];
+#pragma unroll
+                for (u32 h = 0; h < 2; ++h) {
+                    u32 pair[2], plen[2];
+#pragma unroll
+                    for (u32 m = 0; m < 2; ++m) {
+                        const u32 wdv = wd[2 * o + h];
+                        const u32 ea = *reinterpret_cast<const u32 *>(mine + ((wdv >> (16 * m)) & 0xFFu) * 128u);
+                        const u32 eb = *reinterpret_cast<const u32 *>(mine + ((wdv >> (16 * m + 8)) & 0xFFu) * 128u);
+                        pair[m] = (ea & 0xFFFF0000u) | ((eb & 0xFFFF0000u) >> (ea & 31u));
+                        plen[m] = ea + eb; /* the lengths add up in the low half; what the high half holds is never looked at */
+                    }
+                    quad[h] = ((u64)pair[0] << 32) | (((u64)pair[1] << 32) >> (plen[0] & 63u));
+                    qlen[h] = plen[0] + plen[1];
+                }
+                const u64 x = quad[1] >> (qlen[0] & 63u);
+                ohi[gi][o] = quad[0] | x;
+                olo[gi][o] = quad[1] << ((64u - qlen[0]) & 63u); /* a quad is 16 .. 60 bits */
+                both |= ((qlen[0] + qlen[1]) & 0xFFFFu) << (16 * o);
+            }
+            olen[gi] = both;
+        }
+
+        /* bit offset of every lane's group: one wave scan for two groups (16-bit fields, < 2^16 across a wave) */
+        u32 gq[kGroupsPerLane];
+        {
+            u32 at = q0;
+#pragma unroll
+            for (u32 half = 0; half < kGroupsPerLane / 2; ++half) {
+                const u32 a = (olen[2 * half] & 0xFFFFu) + (olen[2 * half] >> 16);
+                const u32 b = (olen[2 * half + 1] & 0xFFFFu) + (olen[2 * half + 1] >> 16);
+                const u32 packed = a | (b << 16);
+                const u32 incl = wave_inclusive_sum_dpp(packed, lane);
+                const u32 tot = __shfl(incl, kWave - 1);
+                gq[2 * half] = at + (incl & 0xFFFFu) - a;
+                gq[2 * half + 1] = at + (tot & 0xFFFFu) + (incl >> 16) - b;
+                at += (tot & 0xFFFFu) + (tot >> 16);
+            }
+        }
+        wave_step(); /* img[q0 >> 5] = 0 is in place */
+
+        /* octs -> words, highest word first */
+#pragma unroll
+        for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
+            u32 wds[2][NW], base[2];
+#pragma unroll
+            for (u32 o = 0; o < 2; ++o) {
+                const u32 q = gq[gi] + (o ? olen[gi] & 0xFFFFu : 0u);
+                const u32 sh = q & 31u;
+                base[o] = q >> 5;
+                const u32 w0 = (u32)(ohi[gi][o] >> 32), w1 = (u32)ohi[gi][o], w2 = (u32)(olo[gi][o] >> 32),
+                          w3 = (u32)olo[gi][o];
+                wds[o][0] = w0 >> sh;
+                wds[o][1] = funnel(w0, w1, sh);
+                wds[o][2] = funnel(w1, w2, sh);
+                if (NW == 4) {
+                    wds[o][3] = funnel(w2, 0, sh);
+                } else {
+                    wds[o][3] = funnel(w2, w3, sh);
+                    wds[o][NW - 1] = funnel(w3, 0, sh);
+                }
+            }
+#pragma unroll
+            for (u32 k = NW - 1; k >= 1; --k) {
+#pragma unroll
+                for (u32 o = 0; o < 2; ++o) {
+                    img[base[o] + k] = wds[o][k];
+                    wave_step();
+                }
+            }
+#pragma unroll
+            for (u32 o = 0; o < 2; ++o) {
+                atomicOr(&img[base[o]], wds[o][0]);
+                wave_step();
+            }
+        }
+
+        /* the last byte: the next tile's head, or the padding when the item ends here (huffman.c:178-184) */
+        bool halo_unknown = false;
+        {
+            const u32 need = (u32)((8 - (bn & 7)) & 7);
+            const u32 e0 = halo_n > 0 ? *reinterpret_cast<const u32 *>(mine + halo0 * 128u) : 0u;
+            const u32 e1 = halo_n > 1 ? *reinterpret_cast<const u32 *>(mine + halo1 * 128u) : 0u;
+            const u32 l0 = e0 & 0xFFFFu, l1 = e1 & 0xFFFFu;
+            /* the codes that follow, left-aligned; behind the item's last symbol the padding (ones above the low bits are masked off below) */
+            u32 head = (e0 & 0xFFFF0000u) | ((e1 & 0xFFFF0000u) >> l0);
+            u32 have = l0 + l1;
+            halo_unknown = (halo_n > 0 && l0 == 0) || (halo_n > 1 && l0 < need && l1 == 0);
+            if (have < need && halo_n < 2 && st.status == HUFD_ENC_OK) {
+                const u32 pad_bits = need - have;
+                head |= ((it.eos_padding & ((1u << pad_bits) - 1u)) << (32 - need));
+                have = need;
+            }
+            if (lane == 0 && need && have >= need && !halo_unknown) {
+                region_put_bits(img, q0 + tile_bits, head >> (32 - need), need);
+            }
+        }
+        wave_step();
+
+        /* the bytes this tile owns, within what the call may write (pack_write_out's rules) */
+        const u64 limit_bytes = st.status == HUFD_ENC_OK ? (st.total_bits + 7) >> 3 : it.out_cap;
+        u64 jhi = last_tile ? (st.status == HUFD_ENC_OK ? (st.total_bits + 7) >> 3 : bn >> 3)
+                            : (halo_unknown ? bn >> 3 : (bn + 7) >> 3);
+        jhi = jhi > limit_bytes ? limit_bytes : jhi;
+        const u64 jlo = first_tile ? 0 : (bw + 7) >> 3;
+        if (jhi > jlo) {
+            region_store(img, gbase, (u32)(jlo - jb) + mis, (u32)(jhi - jb) + mis, lane);
+        }
+        wave_step(); /* the image is free for the next tile */
     }
 }
 
@@ -3179,6 +3527,14 @@ int hufk_init(void) {
     }
     if (e == hipSuccess) {
         e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&enc_pack_wave_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    }
+    if (e == hipSuccess) {
+        e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&enc_pack_wave_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    }
+    if (e == hipSuccess) {
+        e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&enc_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
             lds_max);
     }
@@ -3269,7 +3625,7 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
         const uint32_t grid = persistent_grid(enc_count_kernel, HUFD_ENC_THREADS, kCountLdsBytes, a->n_segs);
         hipLaunchKernelGGL(
             enc_count_kernel, dim3(grid), dim3(HUFD_ENC_THREADS), kCountLdsBytes, st, a->tables, a->segs,
-            (const u8 *)a->d_in, a->seg_bits, a->seg_unk, a->careful_count, a->n_segs);
+            (const u8 *)a->d_in, a->seg_bits, a->wave_bits, a->seg_unk, a->careful_count, a->n_segs);
     } else {
         (void)hipMemsetAsync(a->careful_count, 0, sizeof(uint32_t), st);
     }
@@ -3285,7 +3641,29 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
     stage_mark(a->stage_events, 2, st);
     if (a->n_segs && !a->length_only) {
         const uint32_t img_words = hufk_enc_image_words(a->tables.max_bits);
-        if (a->tables.max_bits <= 16) {
+        if (a->tables.max_bits <= 15 && a->tables.min_bits >= 4) {
+            /* one wave per quarter segment for whole, aligned segments; it lists the others for the per-symbol packer */
+            const uint32_t region = pack_region_bytes(a->tables.max_bits);
+            const uint32_t lds = kPackTabBytes + kPackWaves * region;
+            if (a->tables.max_bits <= 12) {
+                const uint32_t grid = persistent_grid(enc_pack_wave_kernel<4>, kPackThreads, lds, (a->n_segs * kTilesPerSeg + kPackWaves - 1) / kPackWaves);
+                hipLaunchKernelGGL(
+                    enc_pack_wave_kernel<4>, dim3(grid), dim3(kPackThreads), lds, st, a->tables, a->items, a->states,
+                    a->segs, a->seg_bits, a->wave_bits, a->seg_bitoff, (const u8 *)a->d_in, (u8 *)a->d_out, region,
+                    a->n_segs, a->careful_list, a->careful_count);
+            } else {
+                const uint32_t grid = persistent_grid(enc_pack_wave_kernel<5>, kPackThreads, lds, (a->n_segs * kTilesPerSeg + kPackWaves - 1) / kPackWaves);
+                hipLaunchKernelGGL(
+                    enc_pack_wave_kernel<5>, dim3(grid), dim3(kPackThreads), lds, st, a->tables, a->items, a->states,
+                    a->segs, a->seg_bits, a->wave_bits, a->seg_bitoff, (const u8 *)a->d_in, (u8 *)a->d_out, region,
+                    a->n_segs, a->careful_list, a->careful_count);
+            }
+            const uint32_t most = a->n_segs < 1024 ? a->n_segs : 1024;
+            hipLaunchKernelGGL(
+                enc_pack_kernel, dim3(most), dim3(HUFD_ENC_THREADS), enc_pack_lds_bytes(img_words), st, a->tables,
+                a->items, a->states, a->segs, a->seg_bits, a->seg_bitoff, (const u8 *)a->d_in, (u8 *)a->d_out,
+                a->results, img_words, a->n_segs, (const u32 *)a->careful_list, (const u32 *)a->careful_count);
+        } else if (a->tables.max_bits <= 16) {
             /* streaming packer for everything but the listed segments, then those */
             const uint32_t lds = enc_stream_lds_bytes(img_words);
             const uint32_t grid = persistent_grid(enc_pack_stream_kernel, HUFD_ENC_THREADS, lds, a->n_segs);

@@ -199,6 +199,7 @@ static void enc_plan_release_device(struct aws_huffman_amd_encode_plan *p) {
     hufs_free(p->d_segs);
     hufs_free(p->d_large);
     hufs_free(p->d_seg_bits);
+    hufs_free(p->d_wave_bits);
     hufs_free(p->d_seg_unk);
     hufs_free(p->d_seg_bitoff);
     hufs_free(p->d_careful);
@@ -211,6 +212,7 @@ static void enc_plan_release_device(struct aws_huffman_amd_encode_plan *p) {
     p->d_segs = NULL;
     p->d_large = NULL;
     p->d_seg_bits = NULL;
+    p->d_wave_bits = NULL;
     p->d_seg_unk = NULL;
     p->d_seg_bitoff = NULL;
     p->d_careful = NULL;
@@ -302,15 +304,16 @@ static int enc_plan_fill(
         p->d_segs = hufs_malloc(cs * sizeof(struct hufd_enc_seg));
         p->d_large = hufs_malloc(cl * sizeof(uint32_t));
         p->d_seg_bits = hufs_malloc(cs * sizeof(uint32_t));
+        p->d_wave_bits = hufs_malloc(cs * 4 * sizeof(uint32_t));
         p->d_seg_unk = hufs_malloc(cs * sizeof(uint32_t));
         p->d_seg_bitoff = hufs_malloc(cs * sizeof(uint64_t));
-        p->d_careful = hufs_malloc((2 * ci + 4) * sizeof(uint32_t));
+        p->d_careful = hufs_malloc((2 * ci + cs + 4) * sizeof(uint32_t)); /* the scan lists up to two segments an item, the wave packer any segment it leaves */
         p->d_zero = hufs_malloc(cs * sizeof(uint64_t) + 32);
         p->d_unk_seen = hufs_malloc(cs);
         p->d_item_total = hufs_malloc(ci * sizeof(uint64_t));
         p->d_states = hufs_malloc(ci * sizeof(struct hufd_enc_item_state));
         p->d_results = hufs_malloc(ci * sizeof(struct hufd_enc_result));
-        if (!p->d_items || !p->d_segs || !p->d_large || !p->d_seg_bits || !p->d_seg_unk || !p->d_seg_bitoff ||
+        if (!p->d_items || !p->d_segs || !p->d_large || !p->d_seg_bits || !p->d_wave_bits || !p->d_seg_unk || !p->d_seg_bitoff ||
             !p->d_careful || !p->d_zero || !p->d_unk_seen || !p->d_item_total || !p->d_states || !p->d_results) {
             err = 2;
         }
@@ -400,6 +403,7 @@ int aws_huffman_amd_encode_plan_launch_staged(
     a.d_in = device_input;
     a.d_out = device_output;
     a.seg_bits = p->d_seg_bits;
+    a.wave_bits = p->d_wave_bits;
     a.seg_unk = p->d_seg_unk;
     a.seg_bitoff = p->d_seg_bitoff;
     a.careful_list = p->d_careful;

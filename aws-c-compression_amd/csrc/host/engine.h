@@ -43,6 +43,7 @@ struct aws_huffman_amd_encode_plan {
     struct hufd_enc_seg *d_segs;
     uint32_t *d_large;
     uint32_t *d_seg_bits;
+    uint32_t *d_wave_bits; /* [n_segs][4]: bits of each quarter of a segment */
     uint32_t *d_seg_unk;
     uint64_t *d_seg_bitoff;
     uint32_t *d_careful; /* [2 * cap_items + 4]: segments for the per-symbol packer */
