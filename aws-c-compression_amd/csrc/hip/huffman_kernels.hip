@@ -496,9 +496,10 @@ __global__ __launch_bounds__(256) void enc_scan_small_kernel(
 }
 
 /*
- * One workgroup per item with many segments.  Each wave owns a contiguous range of the
- * item's segments and reads it 64 at a time (coalesced): first pass sums the range, the 16
- * range sums are scanned, second pass scans inside the range with a running carry.
+ * One workgroup per item with many segments.  Each wave owns a contiguous range of the item's
+ * segments and reads it 64 x 8 at a time, all eight loads of a lane in flight together (one load
+ * per trip left this kernel waiting a memory round trip per 64 segments): first pass sums the
+ * range, the 16 range sums are scanned, second pass scans inside the range with a running carry.
  */
 __global__ __launch_bounds__(HUFD_SCAN_LARGE_THREADS) void enc_scan_large_kernel(
     const hufd_enc_item *items,
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(HUFD_SCAN_LARGE_THREADS) void enc_scan_large_kernel
     hufd_enc_item_state *states,
     hufd_enc_result *results) {
 
-    constexpr u32 T = HUFD_SCAN_LARGE_THREADS, W = T / kWave;
+    constexpr u32 T = HUFD_SCAN_LARGE_THREADS, W = T / kWave, U = 8; /* U independent loads a lane and trip */
     u64 *wave_tot = reinterpret_cast<u64 *>(dyn_lds);      /* [W] */
     u64 *unk_off = wave_tot + W;                            /* [1] */
     u32 *first_unk = reinterpret_cast<u32 *>(unk_off + 1);  /* [1] lowest segment with a bad symbol */
@@ -526,17 +527,28 @@ __global__ __launch_bounds__(HUFD_SCAN_LARGE_THREADS) void enc_scan_large_kernel
         *edge_seg = HUFD_NONE32;
     }
     const u64 cap_bits = it.out_cap > (~0ull >> 3) ? ~0ull : it.out_cap * 8;
-    /* ranges are multiples of 64 segments so that every read is a full coalesced row */
-    const u32 per = ((it.n_segs + W - 1) / W + kWave - 1) / kWave * kWave;
+    /* ranges are multiples of 64 * U segments so that every read is a full coalesced row */
+    const u32 per = ((it.n_segs + W - 1) / W + kWave * U - 1) / (kWave * U) * (kWave * U);
     const u32 lo = wave * per < it.n_segs ? wave * per : it.n_segs;
     const u32 hi = lo + per < it.n_segs ? lo + per : it.n_segs;
+    const u32 *bits_in = seg_bits + it.first_seg, *unk_in = seg_unk + it.first_seg;
 
     u64 mine = 0;
     u32 my_unk = HUFD_NONE32;
-    for (u32 k = lo + lane; k < hi; k += kWave) {
-        mine += seg_bits[it.first_seg + k];
-        if (my_unk == HUFD_NONE32 && seg_unk[it.first_seg + k] != HUFD_NONE32) {
-            my_unk = it.first_seg + k;
+    for (u32 base = lo; base < hi; base += kWave * U) {
+        u32 b[U], u[U];
+#pragma unroll
+        for (u32 j = 0; j < U; ++j) {
+            const u32 k = base + j * kWave + lane;
+            b[j] = k < hi ? bits_in[k] : 0u;
+            u[j] = k < hi ? unk_in[k] : HUFD_NONE32;
+        }
+#pragma unroll
+        for (u32 j = 0; j < U; ++j) {
+            mine += b[j];
+            if (my_unk == HUFD_NONE32 && u[j] != HUFD_NONE32) {
+                my_unk = it.first_seg + base + j * kWave + lane;
+            }
         }
     }
 #pragma unroll
@@ -559,21 +571,29 @@ __global__ __launch_bounds__(HUFD_SCAN_LARGE_THREADS) void enc_scan_large_kernel
     }
     __syncthreads();
     const u32 us = *first_unk;
-    for (u32 base = lo; base < hi; base += kWave) {
-        const u32 k = base + lane;
-        const u32 b = k < hi ? seg_bits[it.first_seg + k] : 0;
-        const u32 incl = wave_inclusive_sum(b, lane);
-        if (k < hi) {
-            const u64 at = carry + incl - b;
-            seg_bitoff[it.first_seg + k] = at;
-            if (it.first_seg + k == us) {
-                *unk_off = at;
-            }
-            if (at < cap_bits && cap_bits <= at + b) {
-                *edge_seg = it.first_seg + k;
-            }
+    for (u32 base = lo; base < hi; base += kWave * U) {
+        u32 b[U];
+#pragma unroll
+        for (u32 j = 0; j < U; ++j) {
+            const u32 k = base + j * kWave + lane;
+            b[j] = k < hi ? bits_in[k] : 0u;
         }
-        carry += __shfl(incl, kWave - 1);
+#pragma unroll
+        for (u32 j = 0; j < U; ++j) {
+            const u32 k = base + j * kWave + lane;
+            const u32 incl = wave_inclusive_sum_dpp(b[j], lane);
+            if (k < hi) {
+                const u64 at = carry + incl - b[j];
+                seg_bitoff[it.first_seg + k] = at;
+                if (it.first_seg + k == us) {
+                    *unk_off = at;
+                }
+                if (at < cap_bits && cap_bits <= at + b[j]) {
+                    *edge_seg = it.first_seg + k;
+                }
+            }
+            carry += __shfl(incl, kWave - 1);
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -1213,31 +1233,33 @@ __device__ __host__ inline u32 pack_region_bytes(u32 max_bits) {
     return ((kTileBytes * max_bits + 7) / 8 + 16 + 8 * 4 + 15) & ~15u;
 }
 
-/* copies region bytes [lo, hi) to gbase + b (gbase 16-byte aligned), one wave */
+/* copies region bytes [lo, hi) to gbase + b (gbase 16-byte aligned), one wave: aligned 16-byte rows, and at most 15 single bytes at either end */
 __device__ __forceinline__ void region_store(const u32 *img, u8 *gbase, u32 lo, u32 hi, u32 lane) {
     if (hi <= lo) {
         return;
     }
     const u32 row_lo = (lo + 15) >> 4, row_hi = hi >> 4;
-    if (row_lo <= row_hi) {
-        for (u32 b = lo + lane; b < row_lo * 16; b += kWave) {
+    const u32 head_end = row_lo * 16 < hi ? row_lo * 16 : hi;          /* bytes [lo, head_end) in front of the first whole row */
+    const u32 tail_at = row_hi > row_lo ? row_hi * 16 : head_end;       /* bytes [tail_at, hi) behind the last whole row */
+    {
+        const u32 b = lo + lane;
+        if (b < head_end) {
             gbase[b] = (u8)(img[b >> 2] >> (24 - 8 * (b & 3)));
         }
-        uint4 *rows = reinterpret_cast<uint4 *>(__builtin_assume_aligned(gbase, 16));
-        for (u32 r = row_lo + lane; r < row_hi; r += kWave) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(&img[r * 4]);
-            uint4 o;
-            o.x = __builtin_bswap32(v.x);
-            o.y = __builtin_bswap32(v.y);
-            o.z = __builtin_bswap32(v.z);
-            o.w = __builtin_bswap32(v.w);
-            rows[r] = o;
-        }
-        for (u32 b = row_hi * 16 + lane; b < hi; b += kWave) {
-            gbase[b] = (u8)(img[b >> 2] >> (24 - 8 * (b & 3)));
-        }
-    } else {
-        for (u32 b = lo + lane; b < hi; b += kWave) {
+    }
+    uint4 *rows = reinterpret_cast<uint4 *>(__builtin_assume_aligned(gbase, 16));
+    for (u32 r = row_lo + lane; r < row_hi; r += kWave) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(&img[r * 4]);
+        uint4 o;
+        o.x = __builtin_bswap32(v.x);
+        o.y = __builtin_bswap32(v.y);
+        o.z = __builtin_bswap32(v.z);
+        o.w = __builtin_bswap32(v.w);
+        rows[r] = o;
+    }
+    {
+        const u32 b = tail_at + lane;
+        if (b < hi) {
             gbase[b] = (u8)(img[b >> 2] >> (24 - 8 * (b & 3)));
         }
     }
@@ -1387,7 +1409,8 @@ __global__ __launch_bounds__(kPackThreads) void enc_pack_wave_kernel(
                         const u32 wdv = wd[2 * o + h];
                         const u32 ea = *reinterpret_cast<const u32 *>(mine + ((wdv >> (16 * m)) & 0xFFu) * 128u);
                         const u32 eb = *reinterpret_cast<const u32 *>(mine + ((wdv >> (16 * m + 8)) & 0xFFu) * 128u);
-                        pair[m] = (ea & 0xFFFF0000u) | ((eb & 0xFFFF0000u) >> (ea & 31u));
+                        /* eb's length field (< 16) falls off the low end: the shift is by at least 4 */
+                        pair[m] = (ea & 0xFFFF0000u) | (eb >> (ea & 31u));
                         plen[m] = ea + eb; /* the lengths add up in the low half; what the high half holds is never looked at */
                     }
                     quad[h] = ((u64)pair[0] << 32) | (((u64)pair[1] << 32) >> (plen[0] & 63u));
