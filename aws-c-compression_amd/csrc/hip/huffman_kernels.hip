@@ -1317,26 +1317,11 @@ __global__ __launch_bounds__(kPackThreads) void enc_pack_wave_kernel(
     for (u32 tile = blockIdx.x * kPackWaves + wave; tile < n_tiles; tile += gridDim.x * kPackWaves) {
         const u32 s = tile / kTilesPerSeg, w4 = tile % kTilesPerSeg;
         const bool had = fetched;
+        fetched = false;
         if (had) {
 #pragma unroll
             for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
                 v[gi] = vn[gi];
-            }
-        }
-        fetched = false;
-        {
-            /* the wave's next tile: on its way while this one is packed (whole, aligned segments only: the others are not packed here) */
-            const u32 next = tile + gridDim.x * kPackWaves;
-            if (next < n_tiles) {
-                const hufd_enc_seg nseg = uniform_seg(&segs[next / kTilesPerSeg]);
-                const u8 *nsrc = d_in + nseg.in_off + (next % kTilesPerSeg) * kTileBytes;
-                if (nseg.len == HUFD_ENC_SEG_BYTES && ((uintptr_t)nsrc & 15u) == 0) {
-#pragma unroll
-                    for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
-                        vn[gi] = reinterpret_cast<const uint4 *>(nsrc)[gi * kWave + lane];
-                    }
-                    fetched = true;
-                }
             }
         }
         const hufd_enc_seg seg = uniform_seg(&segs[s]);
@@ -1385,6 +1370,22 @@ __global__ __launch_bounds__(kPackThreads) void enc_pack_wave_kernel(
             halo_n = w4 + 1 < kTilesPerSeg ? 2u : (seg.next_len < 2 ? seg.next_len : 2u);
             halo0 = halo_n > 0 ? tsrc[kTileBytes] : 0u;
             halo1 = halo_n > 1 ? tsrc[kTileBytes + 1] : 0u;
+        }
+        /* (asked for after the halo bytes: loads return in order, and the halo is needed first) */
+        {
+            /* the wave's next tile: on its way while this one is packed (whole, aligned segments only: the others are not packed here) */
+            const u32 next = tile + gridDim.x * kPackWaves;
+            if (next < n_tiles) {
+                const hufd_enc_seg nseg = uniform_seg(&segs[next / kTilesPerSeg]);
+                const u8 *nsrc = d_in + nseg.in_off + (next % kTilesPerSeg) * kTileBytes;
+                if (nseg.len == HUFD_ENC_SEG_BYTES && ((uintptr_t)nsrc & 15u) == 0) {
+#pragma unroll
+                    for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
+                        vn[gi] = reinterpret_cast<const uint4 *>(nsrc)[gi * kWave + lane];
+                    }
+                    fetched = true;
+                }
+            }
         }
         if (lane == 0) {
             img[q0 >> 5] = 0; /* the word the first unit ORs its head into */

@@ -27,11 +27,11 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 
 GROUPS = [  # bench kernel name <- substrings of the device kernel names it covers
     ("enc_count", ["enc_count_kernel"]),
-    ("enc_scan", ["enc_scan_small_kernel", "enc_scan_large_kernel", "enc_scan_"]),
-    ("enc_pack", ["enc_pack_stream_kernel", "enc_pack_kernel", "enc_fused_kernel", "enc_finish_kernel", "enc_onepass"]),
-    ("dec_sync", ["dec_sync_kernel"]),
-    ("dec_scan", ["dec_scan_small_kernel", "dec_scan_large_kernel", "dec_scan_"]),
-    ("dec_emit", ["dec_emit_kernel"]),
+    ("enc_scan", ["enc_scan_small_kernel", "enc_scan_large_kernel"]),
+    ("enc_pack", ["enc_pack_wave_kernel", "enc_pack_stream_kernel", "enc_pack_kernel", "enc_fused_kernel", "enc_finish_kernel"]),
+    ("dec_sync", ["dec_sync_fast_kernel", "dec_sync_kernel"]),
+    ("dec_scan", ["dec_scan_small_kernel", "dec_scan_runs_kernel", "dec_scan_top_kernel", "dec_scan_apply_kernel"]),
+    ("dec_emit", ["dec_emit_fast_kernel", "dec_emit_kernel"]),
 ]
 
 
