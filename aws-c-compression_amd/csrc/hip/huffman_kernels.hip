@@ -2350,8 +2350,8 @@ struct row_walk {
  * walk being reproduced; one lane's 128 bytes are one sub-chunk.)
  */
 template <u32 NS> /* compile-time bound of tb.n_states: the per-state registers are unrolled */
-__global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
-    hufd_tables tb,
+__device__ __forceinline__ void dec_sync_chunk(
+    const hufd_tables &tb,
     const hufd_dec_item *items,
     const u32 *chunk_item,
     const u8 *d_in,
@@ -2359,8 +2359,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     u16 *cp_tab,   /* [chunk][kCpRows][lane]: checkpoints of the reference walk + merged-state mask */
     u32 *chunk_fn, /* [chunk][state] */
     u8 *chunk_regular,      /* [chunk]: cleared here */
-    const u32 *list,        /* NULL: workgroup b handles chunk b; else the chunks list[0 .. *list_count) */
-    const u32 *list_count) {
+    u32 c) {
 
     const u32 ns = tb.n_states;
     u32 *timg = reinterpret_cast<u32 *>(dyn_lds);
@@ -2369,10 +2368,6 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     u16 *lut = reinterpret_cast<u16 *>(gtab + kGroups * ns);
 
     const u32 lane = threadIdx.x;
-    if (list && blockIdx.x >= *list_count) {
-        return;
-    }
-    const u32 c = list ? list[blockIdx.x] : blockIdx.x;
     const hufd_dec_item it = items[chunk_item[c]];
     const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
     const u64 valid = it.in_len > chunk_off ? it.in_len - chunk_off : 0;
@@ -2531,6 +2526,27 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
             wide_pack(chain_fold(kGroups, lane, [&](u32 g, u32 stt) { return gtab[g * ns + stt]; }));
     }
     HUFD_STAMP(0, 5);
+}
+
+/* the chunks list[0 .. *list_count), a few workgroups taking turns (list == NULL: every chunk) */
+template <u32 NS>
+__global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
+    hufd_tables tb,
+    const hufd_dec_item *items,
+    const u32 *chunk_item,
+    u32 n_chunks,
+    const u8 *d_in,
+    u16 *fn_tab,
+    u16 *cp_tab,
+    u32 *chunk_fn,
+    u8 *chunk_regular,
+    const u32 *list,
+    const u32 *list_count) {
+    const u32 n = list ? *list_count : n_chunks;
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+        dec_sync_chunk<NS>(tb, items, chunk_item, d_in, fn_tab, cp_tab, chunk_fn, chunk_regular, list ? list[i] : i);
+        __syncthreads(); /* the image is loaded anew for the next chunk */
+    }
 }
 
 /* ------------------------------------------------------------------ decode: sync, regular chunks */
@@ -3008,8 +3024,8 @@ __global__ __launch_bounds__(256) void dec_scan_apply_kernel(
  * checkpoint q and the next usable one (q = 0: from the true entry state).  The waves of one
  * q run the same number of steps, a quarter of what one thread per sub-chunk would.
  */
-__global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_kernel(
-    hufd_tables tb,
+__device__ __forceinline__ void dec_emit_chunk(
+    const hufd_tables &tb,
     const hufd_dec_item *items,
     const u32 *chunk_item,
     const u8 *d_in,
@@ -3019,8 +3035,7 @@ __global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_kernel(
     const u32 *chunk_entry,
     const u64 *chunk_base,
     hufd_dec_result *results,
-    const u32 *list,        /* NULL: workgroup b handles chunk b; else the chunks list[0 .. *list_count) */
-    const u32 *list_count) {
+    u32 c) {
 
     const u32 ns = tb.n_states;
     u32 *timg = reinterpret_cast<u32 *>(dyn_lds);
@@ -3038,10 +3053,6 @@ __global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_kernel(
 
     const u32 t = threadIdx.x;
     const u32 lane = t % HUFD_DEC_LANES, q = t / HUFD_DEC_LANES;
-    if (list && blockIdx.x >= *list_count) {
-        return;
-    }
-    const u32 c = list ? list[blockIdx.x] : blockIdx.x;
     const u32 entry = chunk_entry[c];
     if (!(entry & 0x100u)) {
         return; /* the stream ended before this chunk */
@@ -3280,6 +3291,28 @@ __global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_kernel(
         }
     }
     HUFD_STAMP(1, 5);
+}
+
+/* the chunks list[0 .. *list_count), a few workgroups taking turns (list == NULL: every chunk) */
+__global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_kernel(
+    hufd_tables tb,
+    const hufd_dec_item *items,
+    const u32 *chunk_item,
+    u32 n_chunks,
+    const u8 *d_in,
+    u8 *d_out,
+    const u16 *fn_tab,
+    const u16 *cp_tab,
+    const u32 *chunk_entry,
+    const u64 *chunk_base,
+    hufd_dec_result *results,
+    const u32 *list,
+    const u32 *list_count) {
+    const u32 n = list ? *list_count : n_chunks;
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+        dec_emit_chunk(tb, items, chunk_item, d_in, d_out, fn_tab, cp_tab, chunk_entry, chunk_base, results, list ? list[i] : i);
+        __syncthreads(); /* image and stage are reused by the next chunk */
+    }
 }
 
 /* ------------------------------------------------------------------ decode: emit, regular chunks */
@@ -3734,9 +3767,10 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
                 a->lane_count, a->chunk_regular, a->slow_list, a->slow_count);
         }
         hipLaunchKernelGGL(
-            sync, dim3(a->n_chunks), dim3(HUFD_DEC_LANES), dec_sync_lds_bytes(&a->tables), st, a->tables, a->items,
-            a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular,
-            (const u32 *)a->slow_list, (const u32 *)a->slow_count);
+            sync, dim3(persistent_grid(sync, HUFD_DEC_LANES, dec_sync_lds_bytes(&a->tables), a->n_chunks)),
+            dim3(HUFD_DEC_LANES), dec_sync_lds_bytes(&a->tables), st, a->tables, a->items, a->chunk_item, a->n_chunks,
+            (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, (const u32 *)a->slow_list,
+            (const u32 *)a->slow_count);
     }
     stage_mark(a->stage_events, 1, st);
     hipLaunchKernelGGL(
@@ -3771,9 +3805,11 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
                 (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->emit_list, a->emit_count);
         }
         hipLaunchKernelGGL(
-            dec_emit_kernel, dim3(a->n_chunks), dim3(kEmitThreads), dec_emit_lds_bytes(&a->tables), st, a->tables,
-            a->items, a->chunk_item, (const u8 *)a->d_in, (u8 *)a->d_out, a->fn_tab, a->cp_tab, a->chunk_entry,
-            a->chunk_base, a->results, (const u32 *)a->emit_list, (const u32 *)a->emit_count);
+            dec_emit_kernel,
+            dim3(persistent_grid(dec_emit_kernel, kEmitThreads, dec_emit_lds_bytes(&a->tables), a->n_chunks)),
+            dim3(kEmitThreads), dec_emit_lds_bytes(&a->tables), st, a->tables, a->items, a->chunk_item, a->n_chunks,
+            (const u8 *)a->d_in, (u8 *)a->d_out, a->fn_tab, a->cp_tab, a->chunk_entry, a->chunk_base, a->results,
+            (const u32 *)a->emit_list, (const u32 *)a->emit_count);
     }
     stage_mark(a->stage_events, 3, st);
     return (int)hipGetLastError();
