@@ -302,17 +302,45 @@ __global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_count_kernel(
     __syncthreads();
     const u8 *mine = reinterpret_cast<const u8 *>(tab) + (lane & 31u) * 4u;
 
+    /* the next segment's symbols are asked for before this one's are counted */
+    uint4 v[kGroupsPerLane], vn[kGroupsPerLane];
+    bool fetched = false;
+#pragma unroll
+    for (u32 g = 0; g < kGroupsPerLane; ++g) {
+        v[g] = vn[g] = uint4{0, 0, 0, 0};
+    }
     for (u32 s = blockIdx.x; s < n_segs; s += gridDim.x) {
         const hufd_enc_seg seg = uniform_seg(&segs[s]);
         const u8 *src = d_in + seg.in_off;
         u32 sum = 0;
-        if (seg.len == HUFD_ENC_SEG_BYTES && ((uintptr_t)src & 15u) == 0) {
-            uint4 v[kGroupsPerLane];
+        const bool had = fetched;
+        fetched = false;
+        if (had) {
+#pragma unroll
+            for (u32 g = 0; g < kGroupsPerLane; ++g) {
+                v[g] = vn[g];
+            }
+        }
+        const bool whole = seg.len == HUFD_ENC_SEG_BYTES && ((uintptr_t)src & 15u) == 0;
+        if (whole && !had) {
 #pragma unroll
             for (u32 g = 0; g < kGroupsPerLane; ++g) {
                 /* wave w counts the w-th quarter of the segment: the unit enc_pack_wave packs */
                 v[g] = reinterpret_cast<const uint4 *>(src)[(wave * kGroupsPerLane + g) * kWave + lane];
             }
+        }
+        if (s + gridDim.x < n_segs) {
+            const hufd_enc_seg nseg = uniform_seg(&segs[s + gridDim.x]);
+            const u8 *nsrc = d_in + nseg.in_off;
+            if (nseg.len == HUFD_ENC_SEG_BYTES && ((uintptr_t)nsrc & 15u) == 0) {
+#pragma unroll
+                for (u32 g = 0; g < kGroupsPerLane; ++g) {
+                    vn[g] = reinterpret_cast<const uint4 *>(nsrc)[(wave * kGroupsPerLane + g) * kWave + lane];
+                }
+                fetched = true;
+            }
+        }
+        if (whole) {
 #pragma unroll
             for (u32 g = 0; g < kGroupsPerLane; ++g) {
                 const u32 wd[4] = {v[g].x, v[g].y, v[g].z, v[g].w};
@@ -510,9 +538,10 @@ __global__ __launch_bounds__(HUFD_SCAN_LARGE_THREADS) void enc_scan_large_kernel
     u32 *careful_list,
     u32 *careful_count,
     hufd_enc_item_state *states,
-    hufd_enc_result *results) {
+    hufd_enc_result *results,
+    u32 all_coded /* every symbol has a code: seg_unk need not be read */) {
 
-    constexpr u32 T = HUFD_SCAN_LARGE_THREADS, W = T / kWave, U = 8; /* U independent loads a lane and trip */
+    constexpr u32 T = HUFD_SCAN_LARGE_THREADS, W = T / kWave, U = 16; /* U independent loads a lane and trip */
     u64 *wave_tot = reinterpret_cast<u64 *>(dyn_lds);      /* [W] */
     u64 *unk_off = wave_tot + W;                            /* [1] */
     u32 *first_unk = reinterpret_cast<u32 *>(unk_off + 1);  /* [1] lowest segment with a bad symbol */
@@ -541,7 +570,7 @@ __global__ __launch_bounds__(HUFD_SCAN_LARGE_THREADS) void enc_scan_large_kernel
         for (u32 j = 0; j < U; ++j) {
             const u32 k = base + j * kWave + lane;
             b[j] = k < hi ? bits_in[k] : 0u;
-            u[j] = k < hi ? unk_in[k] : HUFD_NONE32;
+            u[j] = (k < hi && !all_coded) ? unk_in[k] : HUFD_NONE32;
         }
 #pragma unroll
         for (u32 j = 0; j < U; ++j) {
@@ -3693,7 +3722,8 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
     if (a->n_large) {
         hipLaunchKernelGGL(
             enc_scan_large_kernel, dim3(a->n_large), dim3(HUFD_SCAN_LARGE_THREADS), 256, st, a->items, a->large_items,
-            a->seg_bits, a->seg_unk, a->seg_bitoff, a->careful_list, a->careful_count, a->states, a->results);
+            a->seg_bits, a->seg_unk, a->seg_bitoff, a->careful_list, a->careful_count, a->states, a->results,
+            a->tables.all_coded);
     }
     stage_mark(a->stage_events, 2, st);
     if (a->n_segs && !a->length_only) {
