@@ -2327,11 +2327,16 @@ struct row_walk {
     u32 thr;    /* a code starts in the current row while (u16)state > thr */
     u32 mask;   /* index mask, times four */
     u32 floor;  /* (u16)state after a row is at least this unless the walk died */
+    u32 sure;   /* codes that are certain to start in a row: taken without asking (no compare, no branch, no lane mask) */
 
     __device__ __forceinline__ row_walk(u32 lut_bits, u32 max_bits) {
-        thr = 64 + (32 - lut_bits) - 2;
+        /* 512 = a multiple of 64 that keeps the low half positive through `sure` steps of a dead walk (48 bits each) */
+        thr = 512 + (32 - lut_bits) - 2;
         mask = ((1u << lut_bits) - 1u) << 2;
         floor = thr - max_bits + 1;
+        /* a row's first code starts at most max(max_bits - 1, 7) bits in (entry states go up to 7), the others max_bits apart */
+        const u32 late = max_bits - 1 > 7 ? max_bits - 1 : 7;
+        sure = (31 - late) / max_bits + 1;
     }
     /* state of a walk whose next code starts `k` bits into the current row, `count` symbols so far */
     __device__ __forceinline__ u32 state_at(u32 k, u32 count) const {
@@ -2341,8 +2346,13 @@ struct row_walk {
         return thr + 32 - (state & 0xFFFFu);
     }
     /* all codes of the walk that start in the row whose words are hi:lo */
+    template <bool STEP_BY_STEP = false> /* true: ask before every step, for a walk whose count must be right even if it dies */
     __device__ __forceinline__ u32 row(u32 state, u32 hi, u32 lo, const u32 *wlut) const {
         const u64 pair = ((u64)hi << 32) | lo;
+        for (u32 i = 0; !STEP_BY_STEP && i < sure; ++i) {
+            const u32 off = (u32)(pair >> (state & 63u)) & mask;
+            state += *reinterpret_cast<const u32 *>(reinterpret_cast<const u8 *>(wlut) + off);
+        }
         while ((state & 0xFFFFu) > thr) {
             const u32 off = (u32)(pair >> (state & 63u)) & mask;
             state += *reinterpret_cast<const u32 *>(reinterpret_cast<const u8 *>(wlut) + off);
@@ -2352,8 +2362,9 @@ struct row_walk {
     __device__ __forceinline__ bool died(u32 state) const {
         return (state & 0xFFFFu) < floor;
     }
-    __device__ __forceinline__ u32 next_row(u32 state) const {
-        return state + 32u;
+    /* on to the next row; a walk that has died is put back on a row start so that its state stays in range */
+    __device__ __forceinline__ u32 next_row(u32 state, bool dead = false) const {
+        return dead ? state_at(0, 0) : state + 32u;
     }
 };
 
@@ -2722,7 +2733,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
             }
             state = rw.row(state, w[r], w[r + 1], sh.wlut);
             dead = dead || rw.died(state);
-            state = rw.next_row(state);
+            state = rw.next_row(state, dead);
         }
     }
     const u32 ref_count = state >> 16; /* symbols from the meeting bit to the end of the sub-chunk */
@@ -2748,7 +2759,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
                 }
                 st = rw.row(st, w[r], w[r + 1], sh.wlut);
                 dd = dd || rw.died(st);
-                st = rw.next_row(st);
+                st = rw.next_row(st, dd);
             }
         }
         const bool reached = !dd && rw.offset_of(st) == meet_bit;
@@ -2767,11 +2778,11 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
         u32 hi = sh.sub0[0];
         for (u32 r = 0; r < meet_row; ++r) {
             const u32 lo = sh.sub0[r + 1];
-            st = rw.row(st, hi, lo, sh.wlut);
+            st = rw.row<true>(st, hi, lo, sh.wlut);
             const bool now = rw.died(st) && !dd;
             cand_dead = now ? (st >> 16) - 1u : cand_dead; /* the step that found no code is not a symbol */
             dd = dd || now;
-            st = rw.next_row(st);
+            st = rw.next_row(st, dd);
             hi = lo;
         }
         cand_reached = !dd && lane < ns && rw.offset_of(st) == target;
@@ -3479,6 +3490,12 @@ __global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_fast_kernel(
 #pragma unroll
         for (u32 r = 0; r < kRows; ++r) {
             const u64 pair = ((u64)w[r] << 32) | w[r + 1];
+            for (u32 i = 0; i < rw.sure; ++i) { /* the codes that are certain to start in this row */
+                const u32 off = (u32)(pair >> (st & 63u)) & rw.mask;
+                const u32 e = *reinterpret_cast<const u32 *>(reinterpret_cast<const u8 *>(sh.wlut) + off);
+                *dst++ = (u8)(e >> 16);
+                st += e;
+            }
             while ((st & 0xFFFFu) > rw.thr) {
                 const u32 off = (u32)(pair >> (st & 63u)) & rw.mask;
                 const u32 e = *reinterpret_cast<const u32 *>(reinterpret_cast<const u8 *>(sh.wlut) + off);
