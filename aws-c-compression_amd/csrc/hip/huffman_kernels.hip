@@ -2625,19 +2625,22 @@ struct fast_shared {
     u32 wave_sum[HUFD_DEC_LANES / 64];
     u32 bad;
     u32 pad[3];
-    u8 lens[1u << LB];                   /* code length of a window, 0 = no code */
+    u16 hops[1u << LB];                  /* 1 << code length of a window (the head it sends on), 0 = no code */
 };
 
 template <u32 LB>
-__device__ __forceinline__ u64 union_row_fast(u64 heads, u32 hi, u32 lo, const u8 *lens) {
+__device__ __forceinline__ u64 union_row_fast(u64 heads, u32 hi, u32 lo, const u16 *hops) {
     const u64 pair = ((u64)hi << 32) | lo;
-    while ((u32)heads) {
-        const u32 j = (u32)__builtin_ctz((u32)heads);
-        const u32 len = lens[(u32)(pair >> (64u - LB - j)) & ((1u << LB) - 1u)];
-        heads &= heads - 1;
-        heads |= len ? 1ull << (j + len) : 0ull;
+    u32 here = (u32)heads, next = (u32)(heads >> 32); /* heads in this row / already in the next one */
+    while (here) {
+        const u32 j = (u32)__builtin_ctz(here);
+        const u32 off = (u32)(pair >> (63u - LB - j)) & (((1u << LB) - 1u) << 1); /* byte offset into the u16 table */
+        const u64 sent = (u64)*reinterpret_cast<const u16 *>(reinterpret_cast<const u8 *>(hops) + off) << j;
+        here &= here - 1;
+        here |= (u32)sent; /* no code: nothing is sent on, the walk is gone */
+        next |= (u32)(sent >> 32);
     }
-    return heads >> 32;
+    return next;
 }
 
 template <u32 LB>
@@ -2690,7 +2693,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
     for (u32 i = lane; i < (1u << LB); i += HUFD_DEC_LANES) {
         const u32 len = tb.dec_lut[i >> (LB - tb.lut_bits)] & 0xFFu;
         sh.wlut[i] = 0x10000u - (len ? len : kWalkDeadLen);
-        sh.lens[i] = (u8)len;
+        sh.hops[i] = (u16)(len ? 1u << len : 0u);
     }
     if (lane == 0) {
         sh.bad = 0;
@@ -2711,7 +2714,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
 #pragma unroll
     for (u32 r = 0; r < kFastMaxMeet; ++r) {
         if (!settled) {
-            heads = union_row_fast<LB>(heads, w[r], w[r + 1], sh.lens);
+            heads = union_row_fast<LB>(heads, w[r], w[r + 1], sh.hops);
             one = heads != 0 && (heads & (heads - 1)) == 0;
             meet_row = r + 1;
             settled = __all(one || heads == 0);
