@@ -3369,6 +3369,10 @@ __global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_kernel(
  * symbol << 16 | (0x10000 - length) & 0xFFFF; only the low half of the walk state is ever looked
  * at, so the symbol may ride along in the add.
  */
+constexpr u32 kEmitChains = 2; /* quarters of sub-chunks a thread walks side by side: two independent chains per lane hide the table latency */
+constexpr u32 kEmitFastThreads = kEmitThreads / kEmitChains;
+constexpr u32 kEmitHalf = HUFD_DEC_LANES / kEmitChains;
+
 template <u32 LB>
 struct emit_shared {
     u32 wlut[1u << LB];
@@ -3376,10 +3380,11 @@ struct emit_shared {
     u32 wave_tot[HUFD_DEC_LANES / 64];
     u32 pad[4];
     u8 stage[HUFD_DEC_STAGE_BYTES + 32];
+    u8 dump[128]; /* where a chain that has nothing to emit writes */
 };
 
 template <u32 LB>
-__global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_fast_kernel(
+__global__ __launch_bounds__(kEmitFastThreads, 6) void dec_emit_fast_kernel(
     hufd_tables tb,
     const hufd_dec_item *items,
     const u32 *chunk_item,
@@ -3397,7 +3402,8 @@ __global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_fast_kernel(
     emit_shared<LB> &sh = *reinterpret_cast<emit_shared<LB> *>(dyn_lds);
     const u32 ns = tb.n_states;
     const u32 t = threadIdx.x;
-    const u32 lane = t % HUFD_DEC_LANES, q = t / HUFD_DEC_LANES;
+    const u32 q = t / kEmitHalf;                 /* my quarter of ... */
+    const u32 lanes[kEmitChains] = {t % kEmitHalf, t % kEmitHalf + kEmitHalf}; /* ... these two sub-chunks */
     const u32 c = blockIdx.x;
     const u32 centry = chunk_entry[c];
     if (!(centry & 0x100u)) {
@@ -3417,111 +3423,135 @@ __global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_fast_kernel(
     if (!fast) {
         if (t == 0) {
             slow_list[atomicAdd(slow_count, 1u)] = c;
-#if defined(HUFD_EMU_TRACE)
-            fprintf(stderr, "emit: chunk %u slow: regular %d stop %d alive %d fits %d stage %d\n", c, (int)chunk_regular[c],
-                    (int)wide_stop(f0), (int)((cpt[merged_row] >> s0) & 1u), (int)(cbase + chunk_symbols <= it.out_cap),
-                    (int)(chunk_symbols + 16 <= HUFD_DEC_STAGE_BYTES));
-#endif
         }
         return;
     }
 
     HUFD_STAMP(1, 0);
-    /* my quarter: rows 8q .. 8q+7 and the word after them */
+    /* my quarters: rows 8q .. 8q+7 and the word after them */
     constexpr u32 kRows = kSubWords / kQuarters;
-    const u8 *sub = d_in + it.in_off + chunk_off + (u64)lane * HUFD_DEC_SUB_BYTES;
-    u32 w[kRows + 1];
-    {
-        const uint4 *p = reinterpret_cast<const uint4 *>(sub + q * kRows * 4);
+    const u8 *sub[kEmitChains];
+    u32 w[kEmitChains][kRows + 1];
+    u32 my_cp[kEmitChains], next_cp[kEmitChains], entry_state[kEmitChains], cnt[kEmitChains];
+#pragma unroll
+    for (u32 ch = 0; ch < kEmitChains; ++ch) {
+        sub[ch] = d_in + it.in_off + chunk_off + (u64)lanes[ch] * HUFD_DEC_SUB_BYTES;
+        const uint4 *p = reinterpret_cast<const uint4 *>(sub[ch] + q * kRows * 4);
 #pragma unroll
         for (u32 j = 0; j < kRows / 4; ++j) {
             const uint4 v = p[j];
-            w[4 * j + 0] = __builtin_bswap32(v.x);
-            w[4 * j + 1] = __builtin_bswap32(v.y);
-            w[4 * j + 2] = __builtin_bswap32(v.z);
-            w[4 * j + 3] = __builtin_bswap32(v.w);
+            w[ch][4 * j + 0] = __builtin_bswap32(v.x);
+            w[ch][4 * j + 1] = __builtin_bswap32(v.y);
+            w[ch][4 * j + 2] = __builtin_bswap32(v.z);
+            w[ch][4 * j + 3] = __builtin_bswap32(v.w);
         }
-        w[kRows] = __builtin_bswap32(*reinterpret_cast<const u32 *>(sub + (q + 1) * kRows * 4));
+        w[ch][kRows] = __builtin_bswap32(*reinterpret_cast<const u32 *>(sub[ch] + (q + 1) * kRows * 4));
+        my_cp[ch] = q ? cpt[(q - 1) * HUFD_DEC_LANES + lanes[ch]] : 0u;
+        next_cp[ch] = q + 1 < kQuarters ? cpt[q * HUFD_DEC_LANES + lanes[ch]] : 0u;
+        entry_state[ch] = lanes[ch] ? (u32)(cpt[merged_row + lanes[ch] - 1] >> 12) : s0;
+        cnt[ch] = lane_count[(u64)c * HUFD_DEC_LANES + lanes[ch]];
     }
-    const u32 my_cp = q ? cpt[(q - 1) * HUFD_DEC_LANES + lane] : 0u;
-    const u32 next_cp = q + 1 < kQuarters ? cpt[q * HUFD_DEC_LANES + lane] : 0u;
-    const u32 entry_state = lane ? (u32)(cpt[merged_row + lane - 1] >> 12) : s0;
-    const u32 cnt = lane_count[(u64)c * HUFD_DEC_LANES + lane];
-    for (u32 i = t; i < (1u << LB); i += kEmitThreads) {
+    for (u32 i = t; i < (1u << LB); i += kEmitFastThreads) {
         const u32 e = tb.dec_lut[i >> (LB - tb.lut_bits)];
         const u32 len = e & 0xFFu;
         sh.wlut[i] = ((e >> 8) << 16) | ((0x10000u - (len ? len : kWalkDeadLen)) & 0xFFFFu);
     }
     /* where every sub-chunk's symbols go: lane 0's count follows from the chunk's total */
-    u32 incl = 0;
+    u32 incl[kEmitChains] = {0, 0};
+    const u32 wl = t & (kWave - 1), half_wave = (t / kWave) & (kEmitHalf / kWave - 1);
     if (q == 0) {
-        incl = wave_inclusive_sum(lane ? cnt : 0u, lane & (kWave - 1));
-        if ((lane & (kWave - 1)) == kWave - 1) {
-            sh.wave_tot[lane / kWave] = incl;
+#pragma unroll
+        for (u32 ch = 0; ch < kEmitChains; ++ch) {
+            incl[ch] = wave_inclusive_sum(lanes[ch] ? cnt[ch] : 0u, wl);
+            if (wl == kWave - 1) {
+                sh.wave_tot[ch * (kEmitHalf / kWave) + half_wave] = incl[ch]; /* = lanes[ch] / 64 */
+            }
         }
     }
     __syncthreads();
-    u32 rest = 0, before = 0;
+    u32 rest = 0;
 #pragma unroll
     for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
-        const u32 tot = sh.wave_tot[wv];
-        rest += tot;
-        before += wv < lane / kWave ? tot : 0u;
+        rest += sh.wave_tot[wv];
     }
     const u32 first_count = chunk_symbols - rest; /* sub-chunk 0, entered in state s0 */
     if (q == 0) {
-        sh.lane_base[lane] = lane ? first_count + before + incl - cnt : 0u;
+#pragma unroll
+        for (u32 ch = 0; ch < kEmitChains; ++ch) {
+            u32 before = 0;
+#pragma unroll
+            for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
+                before += wv < lanes[ch] / kWave ? sh.wave_tot[wv] : 0u;
+            }
+            sh.lane_base[lanes[ch]] = lanes[ch] ? first_count + before + incl[ch] - cnt[ch] : 0u;
+        }
     }
     __syncthreads();
     HUFD_STAMP(1, 1);
 
-    const u32 lane_n = lane ? cnt : first_count;
-    /* my share: from my checkpoint (q = 0: the entry state) to the next usable one */
-    const bool mine = q == 0 || (my_cp & 0x8000u) != 0;
-    const u32 first = q ? lane_n - (my_cp & 0x7FFu) : 0u;
-    const u32 start_bit = q ? (my_cp >> 11) & 15u : entry_state;
-    /* only sub-chunk 0's first checkpoint can be missing (its head is not known when dec_sync_fast runs) */
-    const bool extend = q == 0 && !(next_cp & 0x8000u);
-
     u8 *out_ptr = d_out + it.out_off + cbase;
     const u32 mis = (u32)((uintptr_t)out_ptr & 15u);
-    u8 *dst = sh.stage + mis + sh.lane_base[lane] + first;
     const row_walk rw(LB, tb.max_bits);
-    HUFD_STAMP(1, 2);
-    if (mine) {
-        u32 st = rw.state_at(start_bit, 0);
+    u32 st[kEmitChains];
+    u8 *dst[kEmitChains];
+    bool extend = false;
 #pragma unroll
-        for (u32 r = 0; r < kRows; ++r) {
-            const u64 pair = ((u64)w[r] << 32) | w[r + 1];
-            for (u32 i = 0; i < rw.sure; ++i) { /* the codes that are certain to start in this row */
-                const u32 off = (u32)(pair >> (st & 63u)) & rw.mask;
-                const u32 e = *reinterpret_cast<const u32 *>(reinterpret_cast<const u8 *>(sh.wlut) + off);
-                *dst++ = (u8)(e >> 16);
-                st += e;
-            }
-            while ((st & 0xFFFFu) > rw.thr) {
-                const u32 off = (u32)(pair >> (st & 63u)) & rw.mask;
-                const u32 e = *reinterpret_cast<const u32 *>(reinterpret_cast<const u8 *>(sh.wlut) + off);
-                *dst++ = (u8)(e >> 16);
-                st += e;
-            }
-            st += 32u;
+    for (u32 ch = 0; ch < kEmitChains; ++ch) {
+        const u32 lane_n = lanes[ch] ? cnt[ch] : first_count;
+        /* my share: from my checkpoint (q = 0: the entry state) to the next usable one */
+        const bool mine = q == 0 || (my_cp[ch] & 0x8000u) != 0;
+        const u32 first = q ? lane_n - (my_cp[ch] & 0x7FFu) : 0u;
+        st[ch] = rw.state_at(q ? (my_cp[ch] >> 11) & 15u : entry_state[ch], 0);
+        dst[ch] = mine ? sh.stage + mis + sh.lane_base[lanes[ch]] + first : sh.dump;
+        /* only sub-chunk 0's first checkpoint can be missing (its head is not known when dec_sync_fast runs) */
+        if (ch == 0) {
+            extend = q == 0 && !(next_cp[ch] & 0x8000u);
         }
-        if (extend) {
-            /* rare: on through the second quarter, words straight from memory */
-            u32 hi = w[kRows];
-            for (u32 r = kRows; r < 2 * kRows; ++r) {
-                const u32 lo = __builtin_bswap32(*reinterpret_cast<const u32 *>(sub + (r + 1) * 4));
-                const u64 pair = ((u64)hi << 32) | lo;
-                while ((st & 0xFFFFu) > rw.thr) {
-                    const u32 off = (u32)(pair >> (st & 63u)) & rw.mask;
-                    const u32 e = *reinterpret_cast<const u32 *>(reinterpret_cast<const u8 *>(sh.wlut) + off);
-                    *dst++ = (u8)(e >> 16);
-                    st += e;
-                }
-                st += 32u;
-                hi = lo;
+    }
+    HUFD_STAMP(1, 2);
+    const u8 *lut = reinterpret_cast<const u8 *>(sh.wlut);
+#pragma unroll
+    for (u32 r = 0; r < kRows; ++r) {
+        u64 pair[kEmitChains];
+#pragma unroll
+        for (u32 ch = 0; ch < kEmitChains; ++ch) {
+            pair[ch] = ((u64)w[ch][r] << 32) | w[ch][r + 1];
+        }
+        for (u32 i = 0; i < rw.sure; ++i) { /* the codes that are certain to start in this row, the two chains in turn */
+            u32 e[kEmitChains];
+#pragma unroll
+            for (u32 ch = 0; ch < kEmitChains; ++ch) {
+                e[ch] = *reinterpret_cast<const u32 *>(lut + ((u32)(pair[ch] >> (st[ch] & 63u)) & rw.mask));
             }
+#pragma unroll
+            for (u32 ch = 0; ch < kEmitChains; ++ch) {
+                *dst[ch]++ = (u8)(e[ch] >> 16);
+                st[ch] += e[ch];
+            }
+        }
+#pragma unroll
+        for (u32 ch = 0; ch < kEmitChains; ++ch) {
+            while ((st[ch] & 0xFFFFu) > rw.thr) {
+                const u32 e = *reinterpret_cast<const u32 *>(lut + ((u32)(pair[ch] >> (st[ch] & 63u)) & rw.mask));
+                *dst[ch]++ = (u8)(e >> 16);
+                st[ch] += e;
+            }
+            st[ch] += 32u;
+        }
+    }
+    if (extend) {
+        /* rare: sub-chunk 0 on through the second quarter, words straight from memory */
+        u32 hi = w[0][kRows];
+        for (u32 r = kRows; r < 2 * kRows; ++r) {
+            const u32 lo = __builtin_bswap32(*reinterpret_cast<const u32 *>(sub[0] + (r + 1) * 4));
+            const u64 pair = ((u64)hi << 32) | lo;
+            while ((st[0] & 0xFFFFu) > rw.thr) {
+                const u32 e = *reinterpret_cast<const u32 *>(lut + ((u32)(pair >> (st[0] & 63u)) & rw.mask));
+                *dst[0]++ = (u8)(e >> 16);
+                st[0] += e;
+            }
+            st[0] += 32u;
+            hi = lo;
         }
     }
     HUFD_STAMP(1, 3);
@@ -3534,17 +3564,17 @@ __global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_fast_kernel(
         const u32 lo = mis, hi = mis + chunk_symbols;
         const u32 row_lo = (lo + 15) >> 4, row_hi = hi >> 4;
         if (row_lo <= row_hi) {
-            for (u32 b = lo + t; b < row_lo * 16; b += kEmitThreads) {
+            for (u32 b = lo + t; b < row_lo * 16; b += kEmitFastThreads) {
                 gbase[b] = sh.stage[b];
             }
-            for (u32 r = row_lo + t; r < row_hi; r += kEmitThreads) {
+            for (u32 r = row_lo + t; r < row_hi; r += kEmitFastThreads) {
                 *reinterpret_cast<uint4 *>(gbase + (u64)r * 16) = *reinterpret_cast<const uint4 *>(sh.stage + r * 16);
             }
-            for (u32 b = row_hi * 16 + t; b < hi; b += kEmitThreads) {
+            for (u32 b = row_hi * 16 + t; b < hi; b += kEmitFastThreads) {
                 gbase[b] = sh.stage[b];
             }
         } else {
-            for (u32 b = lo + t; b < hi; b += kEmitThreads) {
+            for (u32 b = lo + t; b < hi; b += kEmitFastThreads) {
                 gbase[b] = sh.stage[b];
             }
         }
@@ -3843,13 +3873,13 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         (void)hipMemsetAsync(a->emit_count, 0, sizeof(uint32_t), st);
         if (a->tables.lut_bits <= 10) {
             hipLaunchKernelGGL(
-                dec_emit_fast_kernel<10>, dim3(a->n_chunks), dim3(kEmitThreads), (uint32_t)sizeof(emit_shared<10>), st,
+                dec_emit_fast_kernel<10>, dim3(a->n_chunks), dim3(kEmitFastThreads), (uint32_t)sizeof(emit_shared<10>), st,
                 a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab,
                 (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn,
                 (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->emit_list, a->emit_count);
         } else {
             hipLaunchKernelGGL(
-                dec_emit_fast_kernel<12>, dim3(a->n_chunks), dim3(kEmitThreads), (uint32_t)sizeof(emit_shared<12>), st,
+                dec_emit_fast_kernel<12>, dim3(a->n_chunks), dim3(kEmitFastThreads), (uint32_t)sizeof(emit_shared<12>), st,
                 a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab,
                 (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn,
                 (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->emit_list, a->emit_count);
