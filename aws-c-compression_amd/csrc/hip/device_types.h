@@ -27,7 +27,7 @@
 #define HUFD_DEC_MAX_STATES 16u
 #define HUFD_DEC_CP_ROWS 4u /* per sub-chunk: three checkpoints of the walk + the merged-state mask */
 #define HUFD_DEC_MAX_LUT_BITS 12u
-#define HUFD_DEC_STAGE_BYTES 36864u /* LDS bytes for a chunk's decoded symbols (two workgroups per CU) */
+#define HUFD_DEC_STAGE_BYTES 34304u /* LDS bytes for a chunk's decoded symbols (dec_emit_fast: four workgroups per CU) */
 
 #define HUFD_SCAN_SMALL_MAX 64u /* items with at most this many segments/chunks are scanned by one thread */
 #define HUFD_SCAN_LARGE_THREADS 1024u

@@ -3384,7 +3384,7 @@ struct emit_shared {
 };
 
 template <u32 LB>
-__global__ __launch_bounds__(kEmitFastThreads, 6) void dec_emit_fast_kernel(
+__global__ __launch_bounds__(kEmitFastThreads, 8) void dec_emit_fast_kernel(
     hufd_tables tb,
     const hufd_dec_item *items,
     const u32 *chunk_item,
