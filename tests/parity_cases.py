@@ -322,6 +322,69 @@ def damaged_long_streams(w, seed=19, big=10_000_000):
         paired_decode(w, ddo, ddp, data, 0, n, oo, op, 0, out_cap)
 
 
+# ----------------------------------------------------------------------------- scenario: other coders (every kernel variant, not only the reference's test table)
+def canonical_code(lengths):
+    """patterns[256], lens[256] of the canonical prefix code with these code lengths (Kraft sum <= 1)."""
+    assert sum(2.0 ** -l for l in lengths if l) <= 1.0 + 1e-12
+    order = sorted((l, s) for s, l in enumerate(lengths) if l)
+    patterns = [0] * 256
+    code, prev = 0, order[0][0]
+    for l, s in order:
+        code <<= l - prev
+        patterns[s] = code
+        code += 1
+        prev = l
+    return patterns, list(lengths)
+
+
+CODER_PROFILES = {
+    # name: [(how many symbols, code length), ...] in symbol order
+    "len4to12": [(8, 4), (16, 6), (32, 8), (64, 10), (136, 12)],      # wave packer with 4-word octs; decode tables of 12 bits
+    "len4to15": [(4, 4), (8, 5), (16, 7), (32, 9), (64, 12), (132, 15)],  # wave packer with 5-word octs; no decode (> 12 bits)
+    "len1to16": [(1, 1), (1, 2), (2, 4), (4, 7), (8, 9), (240, 16)],      # codes shorter than 4 bits: the streaming packer
+    "len2to12": [(2, 2), (4, 4), (8, 6), (16, 8), (226, 12)],            # short codes and decode: > 255 symbols a sub-chunk
+    "len2to30": [(2, 2), (4, 5), (10, 8), (240, 30)],                    # long codes: the per-symbol packer
+    "len8": [(256, 8)],                                                  # fixed length, decode table of 8 bits
+}
+
+
+def other_coders(w, n=60000, seed=23):
+    import ctypes as C
+
+    rng = np.random.default_rng(seed)
+    for name, profile in CODER_PROFILES.items():
+        lengths = [l for count, l in profile for _ in range(count)]
+        assert len(lengths) == 256
+        patterns, lens = canonical_code(lengths)
+        pat_arr = (C.c_uint32 * 256)(*patterns)
+        len_arr = (C.c_uint8 * 256)(*lens)
+        oc = w.oracle.lib.oracle_table_coder_new(pat_arr, len_arr)
+        pc = w.product.lib.aws_huffman_amd_table_coder_new(pat_arr, len_arr)
+        prob = np.array([2.0 ** -l for l in lengths])
+        prob /= prob.sum()
+        for kind in ("matched", "uniform"):
+            data = (rng.choice(256, size=n, p=prob) if kind == "matched" else rng.integers(0, 256, n)).astype(np.uint8)
+            want = w.oracle.encode_all(oc, data, slack=64 + n)
+            got = w.product.encode_all(pc, data, slack=64 + n)
+            assert np.array_equal(got, want), "encode differs for coder %s on %s data" % (name, kind)
+            # short output, then the rest: the capacity edge inside a whole segment
+            eo, ep = w.oracle.new_encoder(oc), w.product.new_encoder(pc)
+            do, dp = np.full(want.size + 8, SENTINEL, np.uint8), np.full(want.size + 8, SENTINEL, np.uint8)
+            r = paired_encode(w, eo, ep, data, 0, do, dp, 0, want.size // 2)
+            paired_encode(w, eo, ep, data, r.consumed, do, dp, r.produced, want.size)
+            if max(lengths) <= 12:
+                ddo, ddp = w.oracle.new_decoder(oc), w.product.new_decoder(pc)
+                oo, op = np.full(n + 8, SENTINEL, np.uint8), np.full(n + 8, SENTINEL, np.uint8)
+                paired_decode(w, ddo, ddp, want, 0, want.size, oo, op, 0, n)
+                assert np.array_equal(op[:n], data)
+                # damage: the same answer as the oracle, whatever it is
+                bad = want.copy()
+                bad[bad.size // 3] ^= 0x5A
+                ddo, ddp = w.oracle.new_decoder(oc), w.product.new_decoder(pc)
+                oo, op = np.full(2 * n + 8, SENTINEL, np.uint8), np.full(2 * n + 8, SENTINEL, np.uint8)
+                paired_decode(w, ddo, ddp, bad, 0, bad.size, oo, op, 0, 2 * n)
+
+
 # ----------------------------------------------------------------------------- scenario: padding byte values
 def eos_padding_values(w):
     rng = np.random.default_rng(16)

@@ -60,6 +60,10 @@ def test_damaged_long_streams(world):
     pc.damaged_long_streams(world)
 
 
+def test_other_coders(world):
+    pc.other_coders(world, n=1_500_000)
+
+
 def test_eos_padding_values(world):
     pc.eos_padding_values(world)
 
