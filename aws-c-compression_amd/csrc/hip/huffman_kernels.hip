@@ -2624,7 +2624,11 @@ struct fast_shared {
     u32 sub0[kFastMaxMeet + 4];          /* the first rows of sub-chunk 0, for the threads that try its entry states */
     u32 wave_sum[HUFD_DEC_LANES / 64];
     u32 bad;
-    u32 pad[3];
+    u32 tail_entry;    /* the end of the stream: entry state of the first lane behind the whole ones, ... */
+    u32 tail_count[2]; /* ... symbols that start in its sub-chunk / in the next one, ... */
+    u32 tail_exit;     /* ... entry state of the next one, */
+    u32 tail_stop;     /* ... and where the true path stops: 0 there, 1 in the next one, 2 not in this chunk */
+    u32 pad[2];
     u16 hops[1u << LB];                  /* 1 << code length of a window (the head it sends on), 0 = no code */
 };
 
@@ -2666,9 +2670,18 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
     const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
     const u64 valid = it.in_len > chunk_off ? it.in_len - chunk_off : 0;
     const u8 *src = d_in + it.in_off + chunk_off;
-    /* whole codes only, rows as aligned 16-byte loads */
-    const bool eligible = valid >= (u64)HUFD_DEC_CHUNK_BYTES + 8u && ((uintptr_t)src & 15u) == 0 &&
-                          tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS;
+    /*
+     * Lanes whose sub-chunk and the 8 bytes after it lie inside the stream walk as described (every code that
+     * starts in them is whole).  In the chunk that holds the end of the stream the lanes behind them are idle,
+     * except for the first one: it follows the true path from where the last such lane leaves it to where the
+     * stream stops, symbol by symbol with the end-of-stream tests of source/huffman.c:232-255 -- through its own
+     * sub-chunk and, if a few more bytes follow, the next one.
+     */
+    const u32 n_full = valid >= (u64)HUFD_DEC_CHUNK_BYTES + 8u ? HUFD_DEC_LANES : (valid >= 8u ? (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES) : 0u);
+    const bool tail_chunk = n_full < HUFD_DEC_LANES;
+    const bool eligible = n_full >= 1 && ((uintptr_t)src & 15u) == 0 && tb.lut_bits <= LB &&
+                          tb.max_bits <= HUFD_DEC_MAX_LUT_BITS;
+    const bool active = lane < n_full;
     if (!eligible) {
         if (lane == 0) {
             slow_list[atomicAdd(slow_count, 1u)] = c;
@@ -2678,7 +2691,11 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
 
     HUFD_STAMP(0, 0);
     u32 w[kFastRows];
-    {
+#pragma unroll
+    for (u32 r = 0; r < kFastRows; ++r) {
+        w[r] = 0;
+    }
+    if (active) {
         const uint4 *line = reinterpret_cast<const uint4 *>(src + (u64)lane * HUFD_DEC_SUB_BYTES);
 #pragma unroll
         for (u32 q = 0; q < kSubWords / 4; ++q) {
@@ -2708,7 +2725,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
     const row_walk rw(LB, tb.max_bits);
 
     /* U */
-    u64 heads = (1ull << ns) - 1ull;
+    u64 heads = active ? (1ull << ns) - 1ull : 0ull;
     u32 meet_row = 0; /* the same for the whole wave */
     bool one = false, settled = false;
 #pragma unroll
@@ -2721,7 +2738,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
         }
     }
     const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
-    bool ok = one && settled;
+    bool ok = !active || (one && settled);
     HUFD_STAMP(0, 2);
 
     /* R */
@@ -2741,7 +2758,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
     }
     const u32 ref_count = state >> 16; /* symbols from the meeting bit to the end of the sub-chunk */
     const u32 ref_exit = rw.offset_of(state);
-    ok = ok && !dead && ref_exit < ns;
+    ok = ok && (!active || (!dead && ref_exit < ns));
     sh.exit_state[lane] = ref_exit;
     __syncthreads();
     HUFD_STAMP(0, 3);
@@ -2766,8 +2783,46 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
             }
         }
         const bool reached = !dd && rw.offset_of(st) == meet_bit;
-        ok = ok && (lane == 0 || reached);
-        count = (st >> 16) + ref_count; /* symbols of the true path that start in my sub-chunk (lanes >= 1) */
+        ok = ok && (lane == 0 || !active || reached);
+        count = active ? (st >> 16) + ref_count : 0u; /* symbols of the true path that start in my sub-chunk (lanes >= 1) */
+    }
+
+    /* the end of the stream: the first lane behind the whole ones follows the true path to where it stops,
+     * through its own sub-chunk and the next one of this chunk (a few bytes at most: then the stream is over) */
+    const bool careful = tail_chunk && lane == n_full;
+    if (careful) {
+        const u32 tail_entry = sh.exit_state[n_full - 1];
+        const u8 *tsrc = src + (u64)n_full * HUFD_DEC_SUB_BYTES;
+        const u64 tail_bytes = valid - (u64)n_full * HUFD_DEC_SUB_BYTES; /* 8 .. 135 */
+        const u32 rem = (u32)(tail_bytes * 8);
+        const u32 limit = (n_full + 1 < HUFD_DEC_LANES ? 2u : 1u) * HUFD_DEC_SUB_BITS; /* the last lane's walk ends with the chunk */
+        u32 pos = tail_entry, why = HUFD_STOP_NONE, tail_exit = 0, n0 = 0, n1 = 0;
+        while (pos < limit) {
+            const u32 wi = pos >> 5;
+            const u64 two = ((u64)load_be32(tsrc, wi, tail_bytes, true) << 32) | load_be32(tsrc, wi + 1, tail_bytes, true);
+            u32 sym = 0;
+            const u32 len = code_at((u32)((two << (pos & 31u)) >> 32), tb.dec_lut, tb.lut_bits, pos, rem, &sym, &why);
+            if (!len) {
+                break;
+            }
+            /* a symbol belongs to the sub-chunk its code starts in */
+            if (pos < HUFD_DEC_SUB_BITS) {
+                ++n0;
+                if (pos + len >= HUFD_DEC_SUB_BITS) {
+                    tail_exit = pos + len - HUFD_DEC_SUB_BITS; /* on into the next sub-chunk */
+                }
+            } else {
+                ++n1;
+            }
+            pos += len;
+        }
+        count = n0 + n1;
+        sh.tail_entry = tail_entry;
+        sh.tail_count[0] = n0;
+        sh.tail_count[1] = n1;
+        sh.tail_exit = tail_exit;
+        /* where the true path stops: 0 in this lane's sub-chunk, 1 in the next one, 2 not in this chunk */
+        sh.tail_stop = why == HUFD_STOP_NONE ? 2u : (pos < HUFD_DEC_SUB_BITS ? 0u : 1u);
     }
 
     /* H: sub-chunk 0 from every entry state the chunk may be entered in (threads 0 .. ns-1) */
@@ -2812,29 +2867,50 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
     /* the tables dec_scan and dec_emit read, in the format of the long way; only the rows they will look at */
     u16 *fn_out = fn_tab + (u64)c * ns * HUFD_DEC_LANES;
     u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
-    if (lane) {
-        fn_out[(u64)entry * HUFD_DEC_LANES + lane] = fn_pack(false, ref_exit, count & 0x7FFu);
-    }
-#pragma unroll
-    for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-        /* a checkpoint in front of the meeting row is not on the one walk: the first one is then taken from
-         * the head walk (not for lane 0, whose head is only known to dec_scan) */
-        const bool usable = (qq + 1) * (kSubWords / kQuarters) >= meet_row;
-        u32 tail = ref_count - (cp_state[qq] >> 16), bits = rw.offset_of(cp_state[qq]);
-        bool have = usable;
-        if (qq == 0 && late && lane != 0) {
-            tail = count - (head_cp >> 16);
-            bits = rw.offset_of(head_cp);
-            have = true;
+    if (active) {
+        if (lane) {
+            fn_out[(u64)entry * HUFD_DEC_LANES + lane] = fn_pack(false, ref_exit, count & 0x7FFu);
         }
-        cp[qq * HUFD_DEC_LANES] = (u16)(have ? 0x8000u | (bits << 11) | tail : 0u);
+#pragma unroll
+        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+            /* a checkpoint in front of the meeting row is not on the one walk: the first one is then taken from
+             * the head walk (not for lane 0, whose head is only known to dec_scan) */
+            const bool usable = (qq + 1) * (kSubWords / kQuarters) >= meet_row;
+            u32 tail = ref_count - (cp_state[qq] >> 16), bits = rw.offset_of(cp_state[qq]);
+            bool have = usable;
+            if (qq == 0 && late && lane != 0) {
+                tail = count - (head_cp >> 16);
+                bits = rw.offset_of(head_cp);
+                have = true;
+            }
+            cp[qq * HUFD_DEC_LANES] = (u16)(have ? 0x8000u | (bits << 11) | tail : 0u);
+        }
+        lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)(lane ? count : ref_count);
+        const u32 merged = lane ? 1u << entry : (u32)cand_alive;
+        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(merged | (ref_exit << 12));
+    } else {
+        /* behind the whole lanes: the one or two sub-chunks the true path ends in, then lanes it never reaches */
+        const u32 k = lane - n_full; /* 0: the careful lane's own sub-chunk, 1: the next one */
+        const u32 stop_at = sh.tail_stop;
+        const bool reached = k == 0 || (k == 1 && stop_at != 0);
+        const u32 my_entry = k == 0 ? sh.tail_entry : sh.tail_exit;
+        const bool stops_here = reached && stop_at == k;
+        const u32 my_count = reached ? sh.tail_count[k] : 0u;
+#pragma unroll
+        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+            cp[qq * HUFD_DEC_LANES] = 0; /* no checkpoints: one thread walks these few symbols */
+        }
+        lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)my_count;
+        if (reached) {
+            fn_out[(u64)my_entry * HUFD_DEC_LANES + lane] =
+                stops_here ? fn_pack(true, 0, my_count & 0x7FFu) : fn_pack(false, sh.tail_exit, my_count & 0x7FFu);
+        }
+        const u32 common = !reached || stops_here ? kExitStop : sh.tail_exit;
+        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((reached ? 1u << my_entry : 0u) | (common << 12));
     }
-    lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)(lane ? count : ref_count);
     if (lane == 0) {
-        chunk_regular[c] = 1;
+        chunk_regular[c] = tail_chunk ? 2 : 1;
     }
-    const u32 merged = lane ? 1u << entry : (u32)cand_alive;
-    cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(merged | (ref_exit << 12));
     if (lane < ns) {
         u32 rest = 0;
 #pragma unroll
@@ -2845,8 +2921,11 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
         const u32 last_exit = sh.exit_state[HUFD_DEC_LANES - 1];
         fn_out[(u64)lane * HUFD_DEC_LANES] =
             cand_reached ? fn_pack(false, first_exit, cand_count & 0x7FFu) : fn_pack(true, 0, cand_dead);
+        /* in the chunk that holds the end of the stream every walk that gets through sub-chunk 0 stops at that end */
+        const bool stops = tail_chunk && sh.tail_stop != 2u;
+        const u32 leaves_in = !tail_chunk ? last_exit : sh.tail_exit;
         chunk_fn[(u64)c * ns + lane] =
-            cand_reached ? wide_pack(false, last_exit, cand_count + rest) : wide_pack(true, 0, cand_dead);
+            cand_reached ? wide_pack(stops, stops ? 0u : leaves_in, cand_count + rest) : wide_pack(true, 0, cand_dead);
     }
     HUFD_STAMP(0, 5);
 }
@@ -3418,7 +3497,7 @@ __global__ __launch_bounds__(kEmitFastThreads, 8) void dec_emit_fast_kernel(
     const u32 f0 = chunk_fn[(u64)c * ns + s0];
     const u32 chunk_symbols = wide_count(f0);
     /* all the same for the whole workgroup */
-    const bool fast = chunk_regular[c] != 0 && !wide_stop(f0) && ((cpt[merged_row] >> s0) & 1u) != 0 &&
+    const bool fast = chunk_regular[c] == 1 && !wide_stop(f0) && ((cpt[merged_row] >> s0) & 1u) != 0 &&
                       cbase + chunk_symbols <= it.out_cap && chunk_symbols + 16 <= HUFD_DEC_STAGE_BYTES;
     if (!fast) {
         if (t == 0) {

@@ -276,7 +276,9 @@ def garbage_decode(w, seed=15, rounds=120, big=70000):
         bad[min(at + 1, bad.size - 1)] = 0x00
         streams.append(bad)
     streams.append(good[: good.size - 1])
-    streams.append(good[:32768])
+    # cut around a chunk boundary: the last whole lane, the careful lane and the next chunk's first bytes
+    for cut in (32768 - 140, 32768 - 9, 32768 - 3, 32768, 32768 + 3, 32768 + 5, 32768 + 7, 32768 + 8, 32768 + 135, 32768 + 137):
+        streams.append(good[:cut])
     for data in streams:
         n = data.size
         for out_cap in (2 * n, 3):
