@@ -2614,6 +2614,48 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
  * LDS image: eight waves per SIMD instead of four, rows at compile-time register numbers, and
  * the LDS holds only the two small tables.
  */
+/*
+ * The words of the one or two sub-chunks that hold the end of a stream, zero-filled past its last byte, into
+ * LDS: all loads in flight together, so that the symbol-by-symbol walk over them reads LDS and not memory.
+ */
+constexpr u32 kTailWords = 2 * kSubWords + 4;
+__device__ __forceinline__ void tail_words_load(u32 *dst, const u8 *src, u64 bytes) {
+    u32 tmp[kTailWords];
+#pragma unroll
+    for (u32 i = 0; i < kTailWords; ++i) {
+        tmp[i] = load_be32(src, i, bytes, true);
+    }
+#pragma unroll
+    for (u32 i = 0; i < kTailWords; ++i) {
+        dst[i] = tmp[i];
+    }
+}
+__device__ __forceinline__ u32 tail_window(const u32 *words, u32 pos) {
+    const u32 wi = pos >> 5;
+    const u64 two = ((u64)words[wi] << 32) | words[wi + 1];
+    return (u32)((two << (pos & 31u)) >> 32);
+}
+/* code_at() with the length taken from a walk table in LDS (low half of an entry = 0x10000 - length, 48 = no code) */
+template <u32 LB>
+__device__ __forceinline__ u32 code_at_walk(u32 window, const u32 *wlut, u32 pos, u32 rem, u32 *entry, u32 *why) {
+    if (pos >= rem) {
+        *why = HUFD_STOP_END;
+        return 0;
+    }
+    const u32 e = wlut[window >> (32u - LB)];
+    const u32 len = (0x10000u - (e & 0xFFFFu)) & 0xFFFFu;
+    if (len == kWalkDeadLen) {
+        *why = HUFD_STOP_INVALID;
+        return 0;
+    }
+    if (pos + len > rem) {
+        *why = HUFD_STOP_INCOMPLETE;
+        return 0;
+    }
+    *entry = e;
+    return len;
+}
+
 constexpr u32 kFastRows = kSubWords + 1;  /* a window of the last row reaches into the next sub-chunk's first word */
 constexpr u32 kFastMaxMeet = 16;          /* no single head after this many rows: not regular */
 
@@ -2628,6 +2670,7 @@ struct fast_shared {
     u32 tail_count[2]; /* ... symbols that start in its sub-chunk / in the next one, ... */
     u32 tail_exit;     /* ... entry state of the next one, */
     u32 tail_stop;     /* ... and where the true path stops: 0 there, 1 in the next one, 2 not in this chunk */
+    u32 tail_words[kTailWords]; /* the stream's last words, for the careful lane */
     u32 pad[2];
     u16 hops[1u << LB];                  /* 1 << code length of a window (the head it sends on), 0 = no code */
 };
@@ -2647,11 +2690,12 @@ __device__ __forceinline__ u64 union_row_fast(u64 heads, u32 hi, u32 lo, const u
     return next;
 }
 
-template <u32 LB>
-__global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
+template <u32 LB, bool TAIL> /* TAIL: the chunks that hold the end of a stream (listed in tail_chunks); else all the others */
+__global__ __launch_bounds__(HUFD_DEC_LANES, TAIL ? 4 : 8) void dec_sync_fast_kernel(
     hufd_tables tb,
     const hufd_dec_item *items,
     const u32 *chunk_item,
+    const u32 *tail_chunks,
     const u8 *d_in,
     u16 *fn_tab,
     u16 *cp_tab,
@@ -2665,11 +2709,14 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
 
     const u32 ns = tb.n_states;
     const u32 lane = threadIdx.x;
-    const u32 c = blockIdx.x;
+    const u32 c = TAIL ? tail_chunks[blockIdx.x] : blockIdx.x;
     const hufd_dec_item it = items[chunk_item[c]];
     const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
     const u64 valid = it.in_len > chunk_off ? it.in_len - chunk_off : 0;
     const u8 *src = d_in + it.in_off + chunk_off;
+    if (!TAIL && valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
+        return; /* the other instantiation's */
+    }
     /*
      * Lanes whose sub-chunk and the 8 bytes after it lie inside the stream walk as described (every code that
      * starts in them is whole).  In the chunk that holds the end of the stream the lanes behind them are idle,
@@ -2677,11 +2724,11 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
      * stream stops, symbol by symbol with the end-of-stream tests of source/huffman.c:232-255 -- through its own
      * sub-chunk and, if a few more bytes follow, the next one.
      */
-    const u32 n_full = valid >= (u64)HUFD_DEC_CHUNK_BYTES + 8u ? HUFD_DEC_LANES : (valid >= 8u ? (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES) : 0u);
-    const bool tail_chunk = n_full < HUFD_DEC_LANES;
+    const u32 n_full = !TAIL ? HUFD_DEC_LANES : (valid >= 8u ? (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES) : 0u);
+    const bool tail_chunk = TAIL;
     const bool eligible = n_full >= 1 && ((uintptr_t)src & 15u) == 0 && tb.lut_bits <= LB &&
                           tb.max_bits <= HUFD_DEC_MAX_LUT_BITS;
-    const bool active = lane < n_full;
+    const bool active = !TAIL || lane < n_full;
     if (!eligible) {
         if (lane == 0) {
             slow_list[atomicAdd(slow_count, 1u)] = c;
@@ -2789,19 +2836,18 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
 
     /* the end of the stream: the first lane behind the whole ones follows the true path to where it stops,
      * through its own sub-chunk and the next one of this chunk (a few bytes at most: then the stream is over) */
-    const bool careful = tail_chunk && lane == n_full;
-    if (careful) {
+    const bool careful = TAIL && lane == n_full;
+    if (TAIL && careful) {
         const u32 tail_entry = sh.exit_state[n_full - 1];
         const u8 *tsrc = src + (u64)n_full * HUFD_DEC_SUB_BYTES;
         const u64 tail_bytes = valid - (u64)n_full * HUFD_DEC_SUB_BYTES; /* 8 .. 135 */
         const u32 rem = (u32)(tail_bytes * 8);
         const u32 limit = (n_full + 1 < HUFD_DEC_LANES ? 2u : 1u) * HUFD_DEC_SUB_BITS; /* the last lane's walk ends with the chunk */
         u32 pos = tail_entry, why = HUFD_STOP_NONE, tail_exit = 0, n0 = 0, n1 = 0;
+        tail_words_load(sh.tail_words, tsrc, tail_bytes);
         while (pos < limit) {
-            const u32 wi = pos >> 5;
-            const u64 two = ((u64)load_be32(tsrc, wi, tail_bytes, true) << 32) | load_be32(tsrc, wi + 1, tail_bytes, true);
             u32 sym = 0;
-            const u32 len = code_at((u32)((two << (pos & 31u)) >> 32), tb.dec_lut, tb.lut_bits, pos, rem, &sym, &why);
+            const u32 len = code_at_walk<LB>(tail_window(sh.tail_words, pos), sh.wlut, pos, rem, &sym, &why);
             if (!len) {
                 break;
             }
@@ -2888,7 +2934,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
         lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)(lane ? count : ref_count);
         const u32 merged = lane ? 1u << entry : (u32)cand_alive;
         cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(merged | (ref_exit << 12));
-    } else {
+    } else if (TAIL) {
         /* behind the whole lanes: the one or two sub-chunks the true path ends in, then lanes it never reaches */
         const u32 k = lane - n_full; /* 0: the careful lane's own sub-chunk, 1: the next one */
         const u32 stop_at = sh.tail_stop;
@@ -2922,8 +2968,8 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_fast_kernel(
         fn_out[(u64)lane * HUFD_DEC_LANES] =
             cand_reached ? fn_pack(false, first_exit, cand_count & 0x7FFu) : fn_pack(true, 0, cand_dead);
         /* in the chunk that holds the end of the stream every walk that gets through sub-chunk 0 stops at that end */
-        const bool stops = tail_chunk && sh.tail_stop != 2u;
-        const u32 leaves_in = !tail_chunk ? last_exit : sh.tail_exit;
+        const bool stops = TAIL && sh.tail_stop != 2u;
+        const u32 leaves_in = !TAIL ? last_exit : sh.tail_exit;
         chunk_fn[(u64)c * ns + lane] =
             cand_reached ? wide_pack(stops, stops ? 0u : leaves_in, cand_count + rest) : wide_pack(true, 0, cand_dead);
     }
@@ -3459,14 +3505,16 @@ struct emit_shared {
     u32 wave_tot[HUFD_DEC_LANES / 64];
     u32 pad[4];
     u8 stage[HUFD_DEC_STAGE_BYTES + 32];
-    u8 dump[128]; /* where a chain that has nothing to emit writes */
+    u8 dump[512]; /* where a chain that has nothing to emit writes (at most 8 rows x 32 codes) */
+    u32 tail_words[2][kTailWords]; /* TAIL: the stream's last words, for the one or two careful lanes */
 };
 
-template <u32 LB>
-__global__ __launch_bounds__(kEmitFastThreads, 8) void dec_emit_fast_kernel(
+template <u32 LB, bool TAIL> /* TAIL: the chunks listed in tail_chunks (they may hold the end of a stream); else all the others */
+__global__ __launch_bounds__(kEmitFastThreads, TAIL ? 4 : 8) void dec_emit_fast_kernel(
     hufd_tables tb,
     const hufd_dec_item *items,
     const u32 *chunk_item,
+    const u32 *tail_chunks,
     const u8 *d_in,
     u8 *d_out,
     const u16 *cp_tab,
@@ -3475,6 +3523,7 @@ __global__ __launch_bounds__(kEmitFastThreads, 8) void dec_emit_fast_kernel(
     const u32 *chunk_fn,
     const u32 *chunk_entry,
     const u64 *chunk_base,
+    hufd_dec_result *results,
     u32 *slow_list, /* chunks left to dec_emit_kernel */
     u32 *slow_count) {
 
@@ -3483,21 +3532,29 @@ __global__ __launch_bounds__(kEmitFastThreads, 8) void dec_emit_fast_kernel(
     const u32 t = threadIdx.x;
     const u32 q = t / kEmitHalf;                 /* my quarter of ... */
     const u32 lanes[kEmitChains] = {t % kEmitHalf, t % kEmitHalf + kEmitHalf}; /* ... these two sub-chunks */
-    const u32 c = blockIdx.x;
+    const u32 c = TAIL ? tail_chunks[blockIdx.x] : blockIdx.x;
     const u32 centry = chunk_entry[c];
     if (!(centry & 0x100u)) {
         return; /* the stream ended before this chunk */
     }
     const u32 s0 = centry & 0xFFu;
-    const hufd_dec_item it = items[chunk_item[c]];
+    const u32 item_index = chunk_item[c];
+    const hufd_dec_item it = items[item_index];
     const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
+    const u64 valid = it.in_len > chunk_off ? it.in_len - chunk_off : 0;
+    /* lanes whose sub-chunk and the 8 bytes after it lie inside the stream (dec_sync_fast: the others are idle or "careful") */
+    if (!TAIL && valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
+        return; /* the other instantiation's */
+    }
+    const u32 n_full = !TAIL ? HUFD_DEC_LANES : (valid >= 8u ? (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES) : 0u);
     const u64 cbase = chunk_base[c];
     const u16 *cpt = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES;
     const u32 merged_row = (kQuarters - 1) * HUFD_DEC_LANES;
     const u32 f0 = chunk_fn[(u64)c * ns + s0];
     const u32 chunk_symbols = wide_count(f0);
     /* all the same for the whole workgroup */
-    const bool fast = chunk_regular[c] == 1 && !wide_stop(f0) && ((cpt[merged_row] >> s0) & 1u) != 0 &&
+    const u32 regular = chunk_regular[c]; /* 1: all lanes whole; 2: the chunk that holds the end of the stream */
+    const bool fast = regular != 0 && (regular == 2 || !wide_stop(f0)) && ((cpt[merged_row] >> s0) & 1u) != 0 &&
                       cbase + chunk_symbols <= it.out_cap && chunk_symbols + 16 <= HUFD_DEC_STAGE_BYTES;
     if (!fast) {
         if (t == 0) {
@@ -3511,20 +3568,29 @@ __global__ __launch_bounds__(kEmitFastThreads, 8) void dec_emit_fast_kernel(
     constexpr u32 kRows = kSubWords / kQuarters;
     const u8 *sub[kEmitChains];
     u32 w[kEmitChains][kRows + 1];
-    u32 my_cp[kEmitChains], next_cp[kEmitChains], entry_state[kEmitChains], cnt[kEmitChains];
+    u32 my_cp[kEmitChains], next_cp[kEmitChains], entry_state[kEmitChains], cnt[kEmitChains], own_row[kEmitChains];
+    bool whole[kEmitChains];
 #pragma unroll
     for (u32 ch = 0; ch < kEmitChains; ++ch) {
         sub[ch] = d_in + it.in_off + chunk_off + (u64)lanes[ch] * HUFD_DEC_SUB_BYTES;
-        const uint4 *p = reinterpret_cast<const uint4 *>(sub[ch] + q * kRows * 4);
+        whole[ch] = !TAIL || lanes[ch] < n_full;
 #pragma unroll
-        for (u32 j = 0; j < kRows / 4; ++j) {
-            const uint4 v = p[j];
-            w[ch][4 * j + 0] = __builtin_bswap32(v.x);
-            w[ch][4 * j + 1] = __builtin_bswap32(v.y);
-            w[ch][4 * j + 2] = __builtin_bswap32(v.z);
-            w[ch][4 * j + 3] = __builtin_bswap32(v.w);
+        for (u32 j = 0; j <= kRows; ++j) {
+            w[ch][j] = 0;
         }
-        w[ch][kRows] = __builtin_bswap32(*reinterpret_cast<const u32 *>(sub[ch] + (q + 1) * kRows * 4));
+        if (whole[ch]) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(sub[ch] + q * kRows * 4);
+#pragma unroll
+            for (u32 j = 0; j < kRows / 4; ++j) {
+                const uint4 v = p[j];
+                w[ch][4 * j + 0] = __builtin_bswap32(v.x);
+                w[ch][4 * j + 1] = __builtin_bswap32(v.y);
+                w[ch][4 * j + 2] = __builtin_bswap32(v.z);
+                w[ch][4 * j + 3] = __builtin_bswap32(v.w);
+            }
+            w[ch][kRows] = __builtin_bswap32(*reinterpret_cast<const u32 *>(sub[ch] + (q + 1) * kRows * 4));
+        }
+        own_row[ch] = cpt[merged_row + lanes[ch]];
         my_cp[ch] = q ? cpt[(q - 1) * HUFD_DEC_LANES + lanes[ch]] : 0u;
         next_cp[ch] = q + 1 < kQuarters ? cpt[q * HUFD_DEC_LANES + lanes[ch]] : 0u;
         entry_state[ch] = lanes[ch] ? (u32)(cpt[merged_row + lanes[ch] - 1] >> 12) : s0;
@@ -3573,18 +3639,21 @@ __global__ __launch_bounds__(kEmitFastThreads, 8) void dec_emit_fast_kernel(
     const row_walk rw(LB, tb.max_bits);
     u32 st[kEmitChains];
     u8 *dst[kEmitChains];
+    bool idle[kEmitChains]; /* a chain with nothing to emit still walks (the two go in step): over zeros, into the dump */
     bool extend = false;
 #pragma unroll
     for (u32 ch = 0; ch < kEmitChains; ++ch) {
         const u32 lane_n = lanes[ch] ? cnt[ch] : first_count;
-        /* my share: from my checkpoint (q = 0: the entry state) to the next usable one */
-        const bool mine = q == 0 || (my_cp[ch] & 0x8000u) != 0;
+        /* my share: from my checkpoint (q = 0: the entry state) to the next usable one; the lanes behind the whole
+         * ones are not walked here */
+        const bool mine = whole[ch] && (q == 0 || (my_cp[ch] & 0x8000u) != 0);
         const u32 first = q ? lane_n - (my_cp[ch] & 0x7FFu) : 0u;
         st[ch] = rw.state_at(q ? (my_cp[ch] >> 11) & 15u : entry_state[ch], 0);
         dst[ch] = mine ? sh.stage + mis + sh.lane_base[lanes[ch]] + first : sh.dump;
+        idle[ch] = !mine;
         /* only sub-chunk 0's first checkpoint can be missing (its head is not known when dec_sync_fast runs) */
         if (ch == 0) {
-            extend = q == 0 && !(next_cp[ch] & 0x8000u);
+            extend = q == 0 && lanes[0] == 0 && !(next_cp[ch] & 0x8000u);
         }
     }
     HUFD_STAMP(1, 2);
@@ -3616,6 +3685,9 @@ __global__ __launch_bounds__(kEmitFastThreads, 8) void dec_emit_fast_kernel(
                 st[ch] += e;
             }
             st[ch] += 32u;
+            /* an idle chain starts every row afresh: whatever it decodes, its state and its writes stay in bounds */
+            st[ch] = idle[ch] ? rw.state_at(0, 0) : st[ch];
+            dst[ch] = idle[ch] ? sh.dump : dst[ch];
         }
     }
     if (extend) {
@@ -3631,6 +3703,35 @@ __global__ __launch_bounds__(kEmitFastThreads, 8) void dec_emit_fast_kernel(
             }
             st[0] += 32u;
             hi = lo;
+        }
+    }
+    if (TAIL && q == 0 && regular == 2) {
+        /* the end of the stream: the one or two sub-chunks behind the whole lanes, a thread each, symbol by symbol */
+#pragma unroll
+        for (u32 ch = 0; ch < kEmitChains; ++ch) {
+            if (!whole[ch] && (own_row[ch] & 0xFFFu) != 0) { /* the true path gets here */
+                const u32 lane = lanes[ch];
+                const u64 bytes = valid - (u64)lane * HUFD_DEC_SUB_BYTES;
+                const u32 shift = 32 - tb.lut_bits;
+                u8 *d = sh.stage + mis + sh.lane_base[lane];
+                u32 pos = entry_state[ch];
+                u32 *words = sh.tail_words[lane - n_full < 2 ? lane - n_full : 0];
+                tail_words_load(words, sub[ch], bytes);
+                auto window_at = [&](u32 at) -> u32 { return tail_window(words, at); };
+                (void)shift;
+                for (u32 k = 0; k < cnt[ch]; ++k) { /* dec_sync_fast counted them: every one is a whole, valid code */
+                    const u32 e = sh.wlut[window_at(pos) >> (32u - LB)]; /* symbol << 16 | -length */
+                    *d++ = (u8)(e >> 16);
+                    pos += (0x10000u - (e & 0xFFFFu)) & 0xFFFFu;
+                }
+                if ((own_row[ch] >> 12) == kExitStop) {
+                    /* the true path ends here: where, and why (source/huffman.c:240-255) */
+                    u32 sym = 0, why = HUFD_STOP_NONE;
+                    (void)code_at_walk<LB>(window_at(pos), sh.wlut, pos, clamp_remaining(valid, lane), &sym, &why);
+                    results[item_index].stop_kind = why;
+                    results[item_index].stop_bit = (chunk_off + (u64)lane * HUFD_DEC_SUB_BYTES) * 8 + pos;
+                }
+            }
         }
     }
     HUFD_STAMP(1, 3);
@@ -3713,11 +3814,11 @@ int hufk_init(void) {
         reinterpret_cast<const void *>(&dec_emit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     if (e == hipSuccess) {
         e = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&dec_emit_fast_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+            reinterpret_cast<const void *>(&dec_emit_fast_kernel<10, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     }
     if (e == hipSuccess) {
         e = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&dec_emit_fast_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+            reinterpret_cast<const void *>(&dec_emit_fast_kernel<12, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     }
     if (e == hipSuccess) {
         e = hipFuncSetAttribute(
@@ -3916,14 +4017,26 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         (void)hipMemsetAsync(a->slow_count, 0, sizeof(uint32_t), st);
         if (a->tables.lut_bits <= 10) {
             hipLaunchKernelGGL(
-                dec_sync_fast_kernel<10>, dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<10>), st,
-                a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn,
-                a->lane_count, a->chunk_regular, a->slow_list, a->slow_count);
+                (dec_sync_fast_kernel<10, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<10>),
+                st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
+                a->chunk_fn, a->lane_count, a->chunk_regular, a->slow_list, a->slow_count);
+            if (a->n_tail) {
+                hipLaunchKernelGGL(
+                    (dec_sync_fast_kernel<10, true>), dim3(a->n_tail), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<10>),
+                    st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
+                    a->chunk_fn, a->lane_count, a->chunk_regular, a->slow_list, a->slow_count);
+            }
         } else {
             hipLaunchKernelGGL(
-                dec_sync_fast_kernel<12>, dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<12>), st,
-                a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn,
-                a->lane_count, a->chunk_regular, a->slow_list, a->slow_count);
+                (dec_sync_fast_kernel<12, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<12>),
+                st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
+                a->chunk_fn, a->lane_count, a->chunk_regular, a->slow_list, a->slow_count);
+            if (a->n_tail) {
+                hipLaunchKernelGGL(
+                    (dec_sync_fast_kernel<12, true>), dim3(a->n_tail), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<12>),
+                    st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
+                    a->chunk_fn, a->lane_count, a->chunk_regular, a->slow_list, a->slow_count);
+            }
         }
         hipLaunchKernelGGL(
             sync, dim3(persistent_grid(sync, HUFD_DEC_LANES, dec_sync_lds_bytes(&a->tables), a->n_chunks)),
@@ -3950,19 +4063,24 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     if (a->n_chunks) {
         /* regular chunks that fit their output the short way; the rest through the list */
         (void)hipMemsetAsync(a->emit_count, 0, sizeof(uint32_t), st);
+#define HUFK_LAUNCH_EMIT_FAST(LBV, TAILV, GRID)                                                                          \
+    hipLaunchKernelGGL(                                                                                                \
+        (dec_emit_fast_kernel<LBV, TAILV>), dim3(GRID), dim3(kEmitFastThreads), (uint32_t)sizeof(emit_shared<LBV>), st, \
+        a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, (u8 *)a->d_out,                       \
+        (const u16 *)a->cp_tab, (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn,    \
+        (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results, a->emit_list, a->emit_count)
         if (a->tables.lut_bits <= 10) {
-            hipLaunchKernelGGL(
-                dec_emit_fast_kernel<10>, dim3(a->n_chunks), dim3(kEmitFastThreads), (uint32_t)sizeof(emit_shared<10>), st,
-                a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab,
-                (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn,
-                (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->emit_list, a->emit_count);
+            HUFK_LAUNCH_EMIT_FAST(10, false, a->n_chunks);
+            if (a->n_tail) {
+                HUFK_LAUNCH_EMIT_FAST(10, true, a->n_tail);
+            }
         } else {
-            hipLaunchKernelGGL(
-                dec_emit_fast_kernel<12>, dim3(a->n_chunks), dim3(kEmitFastThreads), (uint32_t)sizeof(emit_shared<12>), st,
-                a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab,
-                (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn,
-                (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->emit_list, a->emit_count);
+            HUFK_LAUNCH_EMIT_FAST(12, false, a->n_chunks);
+            if (a->n_tail) {
+                HUFK_LAUNCH_EMIT_FAST(12, true, a->n_tail);
+            }
         }
+#undef HUFK_LAUNCH_EMIT_FAST
         hipLaunchKernelGGL(
             dec_emit_kernel,
             dim3(persistent_grid(dec_emit_kernel, kEmitThreads, dec_emit_lds_bytes(&a->tables), a->n_chunks)),

@@ -511,6 +511,7 @@ int aws_huffman_amd_encode_plan_results(
 static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     hufs_free(p->d_items);
     hufs_free(p->d_chunk_item);
+    hufs_free(p->d_tail);
     hufs_free(p->d_large);
     hufs_free(p->d_runs);
     hufs_free(p->d_run_fn);
@@ -529,6 +530,7 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     hufs_free(p->d_results);
     p->d_items = NULL;
     p->d_chunk_item = NULL;
+    p->d_tail = NULL;
     p->d_large = NULL;
     p->d_runs = NULL;
     p->d_run_fn = NULL;
@@ -576,14 +578,16 @@ static int dec_plan_fill(
     uint32_t *h_chunk_item = malloc((n_chunks ? n_chunks : 1) * sizeof(uint32_t));
     uint32_t *h_large = malloc((n_large ? n_large : 1) * 2 * sizeof(uint32_t));
     uint32_t *h_runs = malloc((n_runs ? n_runs : 1) * 2 * sizeof(uint32_t));
-    if (!h_items || !h_chunk_item || !h_large || !h_runs) {
+    uint32_t *h_tail = malloc((n_items ? n_items : 1) * 2 * sizeof(uint32_t));
+    if (!h_items || !h_chunk_item || !h_large || !h_runs || !h_tail) {
+        free(h_tail);
         free(h_runs);
         free(h_items);
         free(h_chunk_item);
         free(h_large);
         return aws_raise_error(AWS_ERROR_OOM);
     }
-    uint32_t chunk = 0, large = 0, run = 0;
+    uint32_t chunk = 0, large = 0, run = 0, tail = 0;
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_decode_item *src = &items[i];
         struct hufd_dec_item *dst = &h_items[i];
@@ -597,6 +601,10 @@ static int dec_plan_fill(
         dst->n_chunks = chunks;
         dst->reserved = 0;
         for (uint32_t k = 0; k < chunks; ++k) {
+            /* fewer than a chunk + 8 bytes left: the end of the stream is in (or just behind) this chunk */
+            if (src->in_len - (uint64_t)k * HUFD_DEC_CHUNK_BYTES < (uint64_t)HUFD_DEC_CHUNK_BYTES + 8u) {
+                h_tail[tail++] = chunk;
+            }
             h_chunk_item[chunk++] = (uint32_t)i;
         }
         if (chunks > HUFD_SCAN_SMALL_MAX) {
@@ -620,6 +628,7 @@ static int dec_plan_fill(
         const size_t cr = n_runs ? n_runs : 1;
         p->d_items = hufs_malloc(ci * sizeof(struct hufd_dec_item));
         p->d_chunk_item = hufs_malloc(cc * sizeof(uint32_t));
+        p->d_tail = hufs_malloc(ci * 2 * sizeof(uint32_t));
         p->d_large = hufs_malloc(cl * 2 * sizeof(uint32_t));
         p->d_runs = hufs_malloc(cr * 2 * sizeof(uint32_t));
         p->d_run_fn = hufs_malloc(cr * ns * sizeof(uint32_t));
@@ -637,7 +646,7 @@ static int dec_plan_fill(
         p->d_states = hufs_malloc(ci * sizeof(struct hufd_dec_item_state));
         p->d_results = hufs_malloc(ci * sizeof(struct hufd_dec_result));
         if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_cp_tab || !p->d_chunk_fn || !p->d_slow_list || !p->d_chunk_entry ||
-            !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
+            !p->d_tail || !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
             !p->d_chunk_base || !p->d_states || !p->d_results) {
             err = 2;
         }
@@ -651,6 +660,9 @@ static int dec_plan_fill(
     }
     if (!err) {
         err = hufs_copy_h2d(p->d_runs, h_runs, n_runs * 2 * sizeof(uint32_t), eng->stream);
+    }
+    if (!err) {
+        err = hufs_copy_h2d(p->d_tail, h_tail, tail * sizeof(uint32_t), eng->stream);
     }
     if (!err) {
         err = hufs_copy_h2d(p->d_chunk_item, h_chunk_item, n_chunks * sizeof(uint32_t), eng->stream);
@@ -675,6 +687,7 @@ static int dec_plan_fill(
     free(h_chunk_item);
     free(h_large);
     free(h_runs);
+    free(h_tail);
     if (err) {
         return raise_hip(err);
     }
@@ -682,6 +695,7 @@ static int dec_plan_fill(
     p->n_chunks = (uint32_t)n_chunks;
     p->n_large = (uint32_t)n_large;
     p->n_runs = (uint32_t)n_runs;
+    p->n_tail = tail;
     return AWS_OP_SUCCESS;
 }
 
@@ -736,6 +750,8 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.n_items = p->n_items;
     a.chunk_item = p->d_chunk_item;
     a.n_chunks = p->n_chunks;
+    a.tail_chunks = p->d_tail;
+    a.n_tail = p->n_tail;
     a.large_items = p->d_large;
     a.n_large = p->n_large;
     a.runs = p->d_runs;
