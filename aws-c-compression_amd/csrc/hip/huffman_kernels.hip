@@ -4015,7 +4015,9 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         /* chunks inside the stream the short way; the rest, and those that turn out irregular, through the list */
         const auto sync = ns <= 8 ? dec_sync_kernel<8> : (ns <= 10 ? dec_sync_kernel<10> : dec_sync_kernel<12>);
         (void)hipMemsetAsync(a->slow_count, 0, sizeof(uint32_t), st);
+        const bool some_inside = a->n_tail < a->n_chunks; /* chunks with a whole chunk + 8 bytes of stream left */
         if (a->tables.lut_bits <= 10) {
+            if (some_inside)
             hipLaunchKernelGGL(
                 (dec_sync_fast_kernel<10, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<10>),
                 st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
@@ -4027,6 +4029,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
                     a->chunk_fn, a->lane_count, a->chunk_regular, a->slow_list, a->slow_count);
             }
         } else {
+            if (some_inside)
             hipLaunchKernelGGL(
                 (dec_sync_fast_kernel<12, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<12>),
                 st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
@@ -4069,13 +4072,18 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, (u8 *)a->d_out,                       \
         (const u16 *)a->cp_tab, (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn,    \
         (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results, a->emit_list, a->emit_count)
+        const bool some_inside = a->n_tail < a->n_chunks;
         if (a->tables.lut_bits <= 10) {
-            HUFK_LAUNCH_EMIT_FAST(10, false, a->n_chunks);
+            if (some_inside) {
+                HUFK_LAUNCH_EMIT_FAST(10, false, a->n_chunks);
+            }
             if (a->n_tail) {
                 HUFK_LAUNCH_EMIT_FAST(10, true, a->n_tail);
             }
         } else {
-            HUFK_LAUNCH_EMIT_FAST(12, false, a->n_chunks);
+            if (some_inside) {
+                HUFK_LAUNCH_EMIT_FAST(12, false, a->n_chunks);
+            }
             if (a->n_tail) {
                 HUFK_LAUNCH_EMIT_FAST(12, true, a->n_tail);
             }
