@@ -2914,9 +2914,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, TAIL ? 4 : 8) void dec_sync_fast_ke
     u16 *fn_out = fn_tab + (u64)c * ns * HUFD_DEC_LANES;
     u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
     if (active) {
-        if (lane) {
-            fn_out[(u64)entry * HUFD_DEC_LANES + lane] = fn_pack(false, ref_exit, count & 0x7FFu);
-        }
+        /* (lanes >= 1 have no row in fn_tab: their one count that matters is in lane_count) */
 #pragma unroll
         for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
             /* a checkpoint in front of the meeting row is not on the one walk: the first one is then taken from
@@ -2947,10 +2945,6 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, TAIL ? 4 : 8) void dec_sync_fast_ke
             cp[qq * HUFD_DEC_LANES] = 0; /* no checkpoints: one thread walks these few symbols */
         }
         lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)my_count;
-        if (reached) {
-            fn_out[(u64)my_entry * HUFD_DEC_LANES + lane] =
-                stops_here ? fn_pack(true, 0, my_count & 0x7FFu) : fn_pack(false, sh.tail_exit, my_count & 0x7FFu);
-        }
         const u32 common = !reached || stops_here ? kExitStop : sh.tail_exit;
         cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((reached ? 1u << my_entry : 0u) | (common << 12));
     }
@@ -3200,6 +3194,8 @@ __device__ __forceinline__ void dec_emit_chunk(
     u8 *d_out,
     const u16 *fn_tab,
     const u16 *cp_tab,
+    const u16 *lane_count_tab, /* chunks from dec_sync_fast: the symbol counts of lanes >= 1 are here, not in fn_tab */
+    const u8 *chunk_regular,
     const u32 *chunk_entry,
     const u64 *chunk_base,
     hufd_dec_result *results,
@@ -3287,7 +3283,9 @@ __device__ __forceinline__ void dec_emit_chunk(
             blk_count[1] = 1;
         }
         lane_state = (fits && lane_reached) ? lane_state : 0;
-        lane_count = lane_reached ? (u32)(ftab[lane_state * HUFD_DEC_LANES + t] & 0x7FFu) : 0u;
+        lane_count = !lane_reached ? 0u
+                     : (t != 0 && chunk_regular[c] != 0) ? (u32)lane_count_tab[(u64)c * HUFD_DEC_LANES + t]
+                                                         : (u32)(ftab[lane_state * HUFD_DEC_LANES + t] & 0x7FFu);
         lane_incl = wave_inclusive_sum(lane_count, t & (kWave - 1));
         if ((t & (kWave - 1)) == kWave - 1) {
             g_base[t / kWave] = lane_incl;
@@ -3471,6 +3469,8 @@ __global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_kernel(
     u8 *d_out,
     const u16 *fn_tab,
     const u16 *cp_tab,
+    const u16 *lane_count_tab,
+    const u8 *chunk_regular,
     const u32 *chunk_entry,
     const u64 *chunk_base,
     hufd_dec_result *results,
@@ -3478,7 +3478,7 @@ __global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_kernel(
     const u32 *list_count) {
     const u32 n = list ? *list_count : n_chunks;
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
-        dec_emit_chunk(tb, items, chunk_item, d_in, d_out, fn_tab, cp_tab, chunk_entry, chunk_base, results, list ? list[i] : i);
+        dec_emit_chunk(tb, items, chunk_item, d_in, d_out, fn_tab, cp_tab, lane_count_tab, chunk_regular, chunk_entry, chunk_base, results, list ? list[i] : i);
         __syncthreads(); /* image and stage are reused by the next chunk */
     }
 }
@@ -4093,8 +4093,9 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             dec_emit_kernel,
             dim3(persistent_grid(dec_emit_kernel, kEmitThreads, dec_emit_lds_bytes(&a->tables), a->n_chunks)),
             dim3(kEmitThreads), dec_emit_lds_bytes(&a->tables), st, a->tables, a->items, a->chunk_item, a->n_chunks,
-            (const u8 *)a->d_in, (u8 *)a->d_out, a->fn_tab, a->cp_tab, a->chunk_entry, a->chunk_base, a->results,
-            (const u32 *)a->emit_list, (const u32 *)a->emit_count);
+            (const u8 *)a->d_in, (u8 *)a->d_out, a->fn_tab, a->cp_tab, (const u16 *)a->lane_count,
+            (const u8 *)a->chunk_regular, a->chunk_entry, a->chunk_base, a->results, (const u32 *)a->emit_list,
+            (const u32 *)a->emit_count);
     }
     stage_mark(a->stage_events, 3, st);
     return (int)hipGetLastError();
