@@ -3533,6 +3533,14 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 4 : 8) void dec_emit_fast_
     const u32 q = t / kEmitHalf;                 /* my quarter of ... */
     const u32 lanes[kEmitChains] = {t % kEmitHalf, t % kEmitHalf + kEmitHalf}; /* ... these two sub-chunks */
     const u32 c = TAIL ? tail_chunks[blockIdx.x] : blockIdx.x;
+    /* the table entries this thread will put into LDS: asked for first, they depend on nothing */
+    constexpr u32 kLutPerThread = ((1u << LB) + kEmitFastThreads - 1) / kEmitFastThreads;
+    u32 lut_raw[kLutPerThread];
+#pragma unroll
+    for (u32 j = 0; j < kLutPerThread; ++j) {
+        const u32 i = t + j * kEmitFastThreads;
+        lut_raw[j] = i < (1u << LB) ? tb.dec_lut[i >> (LB - tb.lut_bits)] : 0u;
+    }
     const u32 centry = chunk_entry[c];
     if (!(centry & 0x100u)) {
         return; /* the stream ended before this chunk */
@@ -3596,10 +3604,14 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 4 : 8) void dec_emit_fast_
         entry_state[ch] = lanes[ch] ? (u32)(cpt[merged_row + lanes[ch] - 1] >> 12) : s0;
         cnt[ch] = lane_count[(u64)c * HUFD_DEC_LANES + lanes[ch]];
     }
-    for (u32 i = t; i < (1u << LB); i += kEmitFastThreads) {
-        const u32 e = tb.dec_lut[i >> (LB - tb.lut_bits)];
+#pragma unroll
+    for (u32 j = 0; j < kLutPerThread; ++j) {
+        const u32 i = t + j * kEmitFastThreads;
+        const u32 e = lut_raw[j];
         const u32 len = e & 0xFFu;
-        sh.wlut[i] = ((e >> 8) << 16) | ((0x10000u - (len ? len : kWalkDeadLen)) & 0xFFFFu);
+        if (i < (1u << LB)) {
+            sh.wlut[i] = ((e >> 8) << 16) | ((0x10000u - (len ? len : kWalkDeadLen)) & 0xFFFFu);
+        }
     }
     /* where every sub-chunk's symbols go: lane 0's count follows from the chunk's total */
     u32 incl[kEmitChains] = {0, 0};
