@@ -387,6 +387,30 @@ def other_coders(w, n=60000, seed=23):
                 paired_decode(w, ddo, ddp, bad, 0, bad.size, oo, op, 0, 2 * n)
 
 
+# ----------------------------------------------------------------------------- scenario: streams cut at every kind of place (end-of-stream handling of the chunked decoder)
+def cut_streams(w, seed=29, chunks=(1, 2, 5), step=7, span=140, n=200_000):
+    """A valid stream cut short at byte positions all around chunk and sub-chunk boundaries: the decoder must
+    stop where the oracle stops (END / incomplete code / padding-like garbage), with every output capacity."""
+    rng = np.random.default_rng(seed)
+    plain = inputs(rng, n, "uniform")
+    good = oracle_encode(w, plain)
+    cuts = set()
+    for k in chunks:
+        base = k * 32768
+        if base + span >= good.size:
+            continue
+        cuts.update(range(base - span, base + span + 1, step))
+        cuts.update((base - 129, base - 128, base - 127, base - 9, base - 8, base - 7, base - 1, base, base + 1,
+                     base + 7, base + 8, base + 9, base + 127, base + 128, base + 129, base + 135, base + 136, base + 137))
+    cuts.update((135, 136, 137, 263, 264, 265, 1000, 4095, 4096, 4097))
+    for cut in sorted(c for c in cuts if 0 < c < good.size):
+        data = good[:cut]
+        for out_cap in (n, max(int(cut / 1.3), 1)):
+            oo, op = np.full(n + 8, SENTINEL, np.uint8), np.full(n + 8, SENTINEL, np.uint8)
+            ddo, ddp = w.oracle.new_decoder(w.ocoder), w.product.new_decoder(w.pcoder)
+            paired_decode(w, ddo, ddp, data, 0, cut, oo, op, 0, out_cap)
+
+
 # ----------------------------------------------------------------------------- scenario: padding byte values
 def eos_padding_values(w):
     rng = np.random.default_rng(16)

@@ -64,6 +64,10 @@ def test_other_coders(world):
     pc.other_coders(world, n=1_500_000)
 
 
+def test_cut_streams(world):
+    pc.cut_streams(world)
+
+
 def test_eos_padding_values(world):
     pc.eos_padding_values(world)
 
