@@ -67,6 +67,8 @@ struct hufk_decode_args {
     uint32_t *slow_count;  /* [1] */
     uint32_t *emit_list;   /* [n_chunks] scratch: chunks left to dec_emit by dec_emit_fast */
     uint32_t *emit_count;  /* [1] */
+    uint32_t *dense_list;  /* [n_chunks] scratch: chunks dec_emit_fast leaves to dec_emit_dense */
+    uint32_t *dense_count; /* [1] */
     uint16_t *lane_count;  /* [n_chunks][HUFD_DEC_LANES] scratch */
     uint8_t *chunk_regular; /* [n_chunks] scratch */
     uint32_t *chunk_entry; /* [n_chunks] scratch */

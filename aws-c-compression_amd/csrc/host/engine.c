@@ -522,6 +522,7 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     hufs_free(p->d_chunk_fn);
     hufs_free(p->d_slow_list);
     hufs_free(p->d_emit_list);
+    hufs_free(p->d_dense_list);
     hufs_free(p->d_lane_count);
     hufs_free(p->d_chunk_regular);
     hufs_free(p->d_chunk_entry);
@@ -541,6 +542,7 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     p->d_chunk_fn = NULL;
     p->d_slow_list = NULL;
     p->d_emit_list = NULL;
+    p->d_dense_list = NULL;
     p->d_lane_count = NULL;
     p->d_chunk_regular = NULL;
     p->d_chunk_entry = NULL;
@@ -639,6 +641,7 @@ static int dec_plan_fill(
         p->d_chunk_fn = hufs_malloc(cc * ns * sizeof(uint32_t));
         p->d_slow_list = hufs_malloc((cc + 1) * sizeof(uint32_t)); /* [0] count, [1..] chunks */
         p->d_emit_list = hufs_malloc((cc + 1) * sizeof(uint32_t));
+        p->d_dense_list = hufs_malloc((cc + 1) * sizeof(uint32_t));
         p->d_lane_count = hufs_malloc(cc * HUFD_DEC_LANES * sizeof(uint16_t));
         p->d_chunk_regular = hufs_malloc(cc);
         p->d_chunk_entry = hufs_malloc(cc * sizeof(uint32_t));
@@ -646,7 +649,7 @@ static int dec_plan_fill(
         p->d_states = hufs_malloc(ci * sizeof(struct hufd_dec_item_state));
         p->d_results = hufs_malloc(ci * sizeof(struct hufd_dec_result));
         if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_cp_tab || !p->d_chunk_fn || !p->d_slow_list || !p->d_chunk_entry ||
-            !p->d_tail || !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
+            !p->d_tail || !p->d_dense_list || !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
             !p->d_chunk_base || !p->d_states || !p->d_results) {
             err = 2;
         }
@@ -768,6 +771,8 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.slow_list = p->d_slow_list + 1;
     a.emit_count = p->d_emit_list;
     a.emit_list = p->d_emit_list + 1;
+    a.dense_count = p->d_dense_list;
+    a.dense_list = p->d_dense_list + 1;
     a.lane_count = p->d_lane_count;
     a.chunk_regular = p->d_chunk_regular;
     a.chunk_entry = p->d_chunk_entry;

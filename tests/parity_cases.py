@@ -411,6 +411,25 @@ def cut_streams(w, seed=29, chunks=(1, 2, 5), step=7, span=140, n=200_000):
             paired_decode(w, ddo, ddp, data, 0, cut, oo, op, 0, out_cap)
 
 
+# ----------------------------------------------------------------------------- scenario: streams of short codes (more symbols in a chunk than the emit stage holds)
+def dense_symbols(w, n=200_000, seed=31):
+    rng = np.random.default_rng(seed)
+    lens = np.array([w.table[1][i] for i in range(256)])
+    short = np.flatnonzero(lens == lens[lens > 0].min())  # the symbols with the shortest codes
+    cases = [np.full(n, short[0], np.uint8), short[rng.integers(0, short.size, n)].astype(np.uint8)]
+    mixed = short[rng.integers(0, short.size, n)].astype(np.uint8)
+    mixed[rng.integers(0, n, n // 50)] = rng.integers(0, 256, n // 50)  # a few long codes in between
+    cases.append(mixed)
+    for data in cases:
+        enc = oracle_encode(w, data)
+        got = w.product.encode_all(w.pcoder, data)
+        assert np.array_equal(got, enc)
+        for out_cap in (n, n - 1, n // 3):
+            oo, op = np.full(n + 8, SENTINEL, np.uint8), np.full(n + 8, SENTINEL, np.uint8)
+            ddo, ddp = w.oracle.new_decoder(w.ocoder), w.product.new_decoder(w.pcoder)
+            paired_decode(w, ddo, ddp, enc, 0, enc.size, oo, op, 0, out_cap)
+
+
 # ----------------------------------------------------------------------------- scenario: padding byte values
 def eos_padding_values(w):
     rng = np.random.default_rng(16)

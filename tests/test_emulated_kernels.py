@@ -73,6 +73,10 @@ def test_other_coders(world):
     pc.other_coders(world, n=60000)
 
 
+def test_dense_symbols(world):
+    pc.dense_symbols(world, n=200_000)
+
+
 def test_cut_streams(world):
     pc.cut_streams(world, chunks=(1,), step=23, n=40_000)
 

@@ -68,6 +68,10 @@ def test_cut_streams(world):
     pc.cut_streams(world)
 
 
+def test_dense_symbols(world):
+    pc.dense_symbols(world, n=3_000_000)
+
+
 def test_eos_padding_values(world):
     pc.eos_padding_values(world)
 
