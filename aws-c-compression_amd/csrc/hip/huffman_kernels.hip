@@ -2690,6 +2690,12 @@ __device__ __forceinline__ u64 union_row_fast(u64 heads, u32 hi, u32 lo, const u
     return next;
 }
 
+/*
+ * (The TAIL instantiation must not spill vector registers: with a cap of 80 -- four spills to scratch -- about
+ * one chunk in a thousand of BASELINE config 4 got a wrong symbol count, a different one every run: a value
+ * that is live across the one-lane "careful" region came back from scratch with other lanes' slots never
+ * written.  At four waves per SIMD it needs 85 registers and spills nothing.)
+ */
 template <u32 LB, bool TAIL> /* TAIL: the chunks that hold the end of a stream (listed in tail_chunks); else all the others */
 __global__ __launch_bounds__(HUFD_DEC_LANES, TAIL ? 4 : 8) void dec_sync_fast_kernel(
     hufd_tables tb,
