@@ -3719,7 +3719,8 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 4 : 8) void dec_emit_fast_
         /* rare: sub-chunk 0 on through the second quarter, words straight from memory */
         u32 hi = w[0][kRows];
         for (u32 r = kRows; r < 2 * kRows; ++r) {
-            const u32 lo = __builtin_bswap32(*reinterpret_cast<const u32 *>(sub[0] + (r + 1) * 4));
+            /* (sub-chunk 0: the address is rebuilt from the chunk's, so that no pointer has to stay in registers for this) */
+            const u32 lo = __builtin_bswap32(*reinterpret_cast<const u32 *>(d_in + it.in_off + chunk_off + (r + 1) * 4));
             const u64 pair = ((u64)hi << 32) | lo;
             while ((st[0] & 0xFFFFu) > rw.thr) {
                 const u32 e = *reinterpret_cast<const u32 *>(lut + ((u32)(pair >> (st[0] & 63u)) & rw.mask));
