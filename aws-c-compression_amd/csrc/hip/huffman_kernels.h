@@ -71,6 +71,7 @@ struct hufk_decode_args {
     uint32_t *dense_count; /* [1] */
     uint16_t *lane_count;  /* [n_chunks][HUFD_DEC_LANES] scratch */
     uint8_t *chunk_regular; /* [n_chunks] scratch */
+    uint32_t *tail_entry;   /* [n_chunks] scratch: state in which the last whole lane of an end-of-stream chunk leaves */
     uint32_t *chunk_entry; /* [n_chunks] scratch */
     uint64_t *chunk_base;  /* [n_chunks] scratch */
     struct hufd_dec_item_state *states; /* [n_items] scratch */

@@ -2635,6 +2635,42 @@ __device__ __forceinline__ u32 tail_window(const u32 *words, u32 pos) {
     const u64 two = ((u64)words[wi] << 32) | words[wi + 1];
     return (u32)((two << (pos & 31u)) >> 32);
 }
+/*
+ * The 32 stream bits at the careful walk's position, out of a 64-bit register window that is topped up a word
+ * at a time; the word that will be needed next is read one refill early, so that the only LDS read a step has
+ * to wait for is the table look-up (the register twin of the window of source/huffman.c:196-211).
+ */
+struct tail_reader {
+    const u32 *words;
+    u64 win;
+    u32 nb, next, ahead;
+
+    __device__ __forceinline__ u32 word(u32 i) const {
+        return words[i < kTailWords ? i : kTailWords - 1]; /* words past the end are zero anyway */
+    }
+    __device__ __forceinline__ void start(const u32 *w, u32 pos) {
+        words = w;
+        const u32 r = pos >> 5;
+        win = (((u64)word(r) << 32) | word(r + 1)) << (pos & 31u);
+        nb = 64 - (pos & 31u);
+        ahead = word(r + 2);
+        next = r + 3;
+    }
+    __device__ __forceinline__ u32 peek() const {
+        return (u32)(win >> 32);
+    }
+    __device__ __forceinline__ void skip(u32 len) {
+        win <<= len;
+        nb -= len;
+        if (nb <= 32) {
+            win |= (u64)ahead << (32 - nb);
+            nb += 32;
+            ahead = word(next);
+            ++next;
+        }
+    }
+};
+
 /* code_at() with the length taken from a walk table in LDS (low half of an entry = 0x10000 - length, 48 = no code) */
 template <u32 LB>
 __device__ __forceinline__ u32 code_at_walk(u32 window, const u32 *wlut, u32 pos, u32 rem, u32 *entry, u32 *why) {
@@ -2666,12 +2702,7 @@ struct fast_shared {
     u32 sub0[kFastMaxMeet + 4];          /* the first rows of sub-chunk 0, for the threads that try its entry states */
     u32 wave_sum[HUFD_DEC_LANES / 64];
     u32 bad;
-    u32 tail_entry;    /* the end of the stream: entry state of the first lane behind the whole ones, ... */
-    u32 tail_count[2]; /* ... symbols that start in its sub-chunk / in the next one, ... */
-    u32 tail_exit;     /* ... entry state of the next one, */
-    u32 tail_stop;     /* ... and where the true path stops: 0 there, 1 in the next one, 2 not in this chunk */
-    u32 tail_words[kTailWords]; /* the stream's last words, for the careful lane */
-    u32 pad[2];
+    u32 pad[3];
     u16 hops[1u << LB];                  /* 1 << code length of a window (the head it sends on), 0 = no code */
 };
 
@@ -2697,7 +2728,7 @@ __device__ __forceinline__ u64 union_row_fast(u64 heads, u32 hi, u32 lo, const u
  * written.  At four waves per SIMD it needs 85 registers and spills nothing.)
  */
 template <u32 LB, bool TAIL> /* TAIL: the chunks that hold the end of a stream (listed in tail_chunks); else all the others */
-__global__ __launch_bounds__(HUFD_DEC_LANES, TAIL ? 4 : 8) void dec_sync_fast_kernel(
+__global__ __launch_bounds__(HUFD_DEC_LANES, TAIL ? (LB <= 10 ? 6 : 4) : 8) void dec_sync_fast_kernel(
     hufd_tables tb,
     const hufd_dec_item *items,
     const u32 *chunk_item,
@@ -2708,6 +2739,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, TAIL ? 4 : 8) void dec_sync_fast_ke
     u32 *chunk_fn,
     u16 *lane_count,  /* [chunk][lane]: symbols of the true path that start in the sub-chunk (lane 0: from the meeting bit on) */
     u8 *chunk_regular, /* [chunk]: 1 = these tables come from here and dec_emit_fast may use them */
+    u32 *tail_entry,  /* [chunk] TAIL: the state in which the last whole lane leaves (dec_sync_tail picks it up) */
     u32 *slow_list,   /* chunks left to dec_sync_kernel */
     u32 *slow_count) {
 
@@ -2737,6 +2769,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, TAIL ? 4 : 8) void dec_sync_fast_ke
     const bool active = !TAIL || lane < n_full;
     if (!eligible) {
         if (lane == 0) {
+            chunk_regular[c] = 0;
             slow_list[atomicAdd(slow_count, 1u)] = c;
         }
         return;
@@ -2840,43 +2873,6 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, TAIL ? 4 : 8) void dec_sync_fast_ke
         count = active ? (st >> 16) + ref_count : 0u; /* symbols of the true path that start in my sub-chunk (lanes >= 1) */
     }
 
-    /* the end of the stream: the first lane behind the whole ones follows the true path to where it stops,
-     * through its own sub-chunk and the next one of this chunk (a few bytes at most: then the stream is over) */
-    const bool careful = TAIL && lane == n_full;
-    if (TAIL && careful) {
-        const u32 tail_entry = sh.exit_state[n_full - 1];
-        const u8 *tsrc = src + (u64)n_full * HUFD_DEC_SUB_BYTES;
-        const u64 tail_bytes = valid - (u64)n_full * HUFD_DEC_SUB_BYTES; /* 8 .. 135 */
-        const u32 rem = (u32)(tail_bytes * 8);
-        const u32 limit = (n_full + 1 < HUFD_DEC_LANES ? 2u : 1u) * HUFD_DEC_SUB_BITS; /* the last lane's walk ends with the chunk */
-        u32 pos = tail_entry, why = HUFD_STOP_NONE, tail_exit = 0, n0 = 0, n1 = 0;
-        tail_words_load(sh.tail_words, tsrc, tail_bytes);
-        while (pos < limit) {
-            u32 sym = 0;
-            const u32 len = code_at_walk<LB>(tail_window(sh.tail_words, pos), sh.wlut, pos, rem, &sym, &why);
-            if (!len) {
-                break;
-            }
-            /* a symbol belongs to the sub-chunk its code starts in */
-            if (pos < HUFD_DEC_SUB_BITS) {
-                ++n0;
-                if (pos + len >= HUFD_DEC_SUB_BITS) {
-                    tail_exit = pos + len - HUFD_DEC_SUB_BITS; /* on into the next sub-chunk */
-                }
-            } else {
-                ++n1;
-            }
-            pos += len;
-        }
-        count = n0 + n1;
-        sh.tail_entry = tail_entry;
-        sh.tail_count[0] = n0;
-        sh.tail_count[1] = n1;
-        sh.tail_exit = tail_exit;
-        /* where the true path stops: 0 in this lane's sub-chunk, 1 in the next one, 2 not in this chunk */
-        sh.tail_stop = why == HUFD_STOP_NONE ? 2u : (pos < HUFD_DEC_SUB_BITS ? 0u : 1u);
-    }
-
     /* H: sub-chunk 0 from every entry state the chunk may be entered in (threads 0 .. ns-1) */
     u32 cand_count = 0, cand_dead = 0;
     bool cand_reached = false;
@@ -2911,6 +2907,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, TAIL ? 4 : 8) void dec_sync_fast_ke
     HUFD_STAMP(0, 4);
     if (sh.bad) {
         if (lane == 0) {
+            chunk_regular[c] = 0;
             slow_list[atomicAdd(slow_count, 1u)] = c;
         }
         return;
@@ -2939,20 +2936,17 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, TAIL ? 4 : 8) void dec_sync_fast_ke
         const u32 merged = lane ? 1u << entry : (u32)cand_alive;
         cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(merged | (ref_exit << 12));
     } else if (TAIL) {
-        /* behind the whole lanes: the one or two sub-chunks the true path ends in, then lanes it never reaches */
-        const u32 k = lane - n_full; /* 0: the careful lane's own sub-chunk, 1: the next one */
-        const u32 stop_at = sh.tail_stop;
-        const bool reached = k == 0 || (k == 1 && stop_at != 0);
-        const u32 my_entry = k == 0 ? sh.tail_entry : sh.tail_exit;
-        const bool stops_here = reached && stop_at == k;
-        const u32 my_count = reached ? sh.tail_count[k] : 0u;
+        /* behind the whole lanes: never reached, as far as this kernel knows -- dec_sync_tail follows the true path
+         * through the one or two sub-chunks the stream ends in and rewrites their records */
 #pragma unroll
         for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-            cp[qq * HUFD_DEC_LANES] = 0; /* no checkpoints: one thread walks these few symbols */
+            cp[qq * HUFD_DEC_LANES] = 0;
         }
-        lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)my_count;
-        const u32 common = !reached || stops_here ? kExitStop : sh.tail_exit;
-        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((reached ? 1u << my_entry : 0u) | (common << 12));
+        lane_count[(u64)c * HUFD_DEC_LANES + lane] = 0;
+        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(kExitStop << 12);
+    }
+    if (TAIL && lane + 1 == n_full) {
+        tail_entry[c] = ref_exit;
     }
     if (lane == 0) {
         chunk_regular[c] = tail_chunk ? 2 : 1;
@@ -2967,13 +2961,138 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, TAIL ? 4 : 8) void dec_sync_fast_ke
         const u32 last_exit = sh.exit_state[HUFD_DEC_LANES - 1];
         fn_out[(u64)lane * HUFD_DEC_LANES] =
             cand_reached ? fn_pack(false, first_exit, cand_count & 0x7FFu) : fn_pack(true, 0, cand_dead);
-        /* in the chunk that holds the end of the stream every walk that gets through sub-chunk 0 stops at that end */
-        const bool stops = TAIL && sh.tail_stop != 2u;
-        const u32 leaves_in = !TAIL ? last_exit : sh.tail_exit;
+        /* (TAIL: symbols of the whole lanes only, and no exit yet: dec_sync_tail adds the stream's last symbols and how it ends) */
         chunk_fn[(u64)c * ns + lane] =
-            cand_reached ? wide_pack(stops, stops ? 0u : leaves_in, cand_count + rest) : wide_pack(true, 0, cand_dead);
+            cand_reached ? wide_pack(false, TAIL ? 0u : last_exit, cand_count + rest) : wide_pack(true, 0, cand_dead);
     }
     HUFD_STAMP(0, 5);
+}
+
+/* ------------------------------------------------------------------ decode: the end of a stream */
+
+/*
+ * One THREAD per chunk that holds the end of a stream (after dec_sync_fast<TAIL>, which took its whole lanes):
+ * follows the true path from where the last whole lane leaves it to where the stream stops, symbol by symbol
+ * with the end-of-stream tests of source/huffman.c:232-255, through the first sub-chunk behind the whole lanes
+ * and the few bytes of the next one.  Then completes the chunk's tables: records of those one or two lanes,
+ * and symbols + stop (or exit state) in the chunk function.  A walk of ~100 dependent steps is slow for one
+ * thread and nothing for 65 536 of them side by side; inside dec_sync_fast it held a workgroup up and cost
+ * the kernel its occupancy.
+ */
+constexpr u32 kTailThreads = 128;
+
+struct tail_walk {
+    u32 count[2]; /* symbols that start in the first / the second sub-chunk behind the whole lanes */
+    u32 exit;     /* entry state of the second one */
+    u32 stop;     /* where the true path stops: 0 in the first, 1 in the second, 2 not in this chunk */
+};
+
+/* words: this thread's LDS copy of the stream's last bytes; lut: the u16 decode table in LDS */
+__device__ __forceinline__ tail_walk tail_follow(
+    const u32 *words, const u16 *lut, u32 lut_bits, u32 entry, u32 rem, u32 limit, u8 *out /* NULL: only count */,
+    u32 *stop_pos, u32 *stop_why) {
+    tail_walk r = {{0, 0}, 0, 2};
+    tail_reader tr;
+    tr.start(words, entry);
+    u32 pos = entry, why = HUFD_STOP_NONE;
+    while (pos < limit) {
+        u32 sym = 0;
+        const u32 len = code_at(tr.peek(), lut, lut_bits, pos, rem, &sym, &why);
+        if (!len) {
+            break;
+        }
+        tr.skip(len);
+        if (out) {
+            *out++ = (u8)sym;
+        }
+        if (pos < HUFD_DEC_SUB_BITS) { /* a symbol belongs to the sub-chunk its code starts in */
+            ++r.count[0];
+            if (pos + len >= HUFD_DEC_SUB_BITS) {
+                r.exit = pos + len - HUFD_DEC_SUB_BITS;
+            }
+        } else {
+            ++r.count[1];
+        }
+        pos += len;
+    }
+    r.stop = why == HUFD_STOP_NONE ? 2u : (pos < HUFD_DEC_SUB_BITS ? 0u : 1u);
+    *stop_pos = pos;
+    *stop_why = why;
+    return r;
+}
+
+struct tail_lds {
+    u32 words[kTailThreads][kTailWords + 1]; /* + 1: odd stride, the threads' copies start in different banks */
+};
+
+__global__ __launch_bounds__(kTailThreads) void dec_sync_tail_kernel(
+    hufd_tables tb,
+    const hufd_dec_item *items,
+    const u32 *chunk_item,
+    const u32 *tail_chunks,
+    u32 n_tail,
+    const u8 *d_in,
+    const u8 *chunk_regular,
+    const u32 *tail_entry,
+    u16 *fn_tab,
+    u16 *cp_tab,
+    u32 *chunk_fn,
+    u16 *lane_count) {
+
+    tail_lds &sh = *reinterpret_cast<tail_lds *>(dyn_lds);
+    u16 *lut = reinterpret_cast<u16 *>(dyn_lds + sizeof(tail_lds));
+    for (u32 i = threadIdx.x; i < (1u << tb.lut_bits); i += kTailThreads) {
+        lut[i] = tb.dec_lut[i];
+    }
+    __syncthreads();
+    const u32 i = blockIdx.x * kTailThreads + threadIdx.x;
+    if (i >= n_tail) {
+        return;
+    }
+    const u32 c = tail_chunks[i];
+    if (chunk_regular[c] != 2) {
+        return; /* not taken by dec_sync_fast: the long way does all of it */
+    }
+    const u32 ns = tb.n_states;
+    const hufd_dec_item it = items[chunk_item[c]];
+    const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
+    const u64 valid = it.in_len - chunk_off;
+    const u32 n_full = (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES); /* >= 1 and < HUFD_DEC_LANES here */
+    const u8 *tsrc = d_in + it.in_off + chunk_off + (u64)n_full * HUFD_DEC_SUB_BYTES;
+    const u64 tail_bytes = valid - (u64)n_full * HUFD_DEC_SUB_BYTES; /* 8 .. 135 */
+    u32 *words = sh.words[threadIdx.x];
+    for (u32 k = 0; k < kTailWords; ++k) {
+        words[k] = load_be32(tsrc, k, tail_bytes, true);
+    }
+    const u32 entry = tail_entry[c];
+    const u32 limit = (n_full + 1 < HUFD_DEC_LANES ? 2u : 1u) * HUFD_DEC_SUB_BITS; /* the last lane's walk ends with the chunk */
+    u32 stop_pos = 0, stop_why = 0;
+    const tail_walk tw = tail_follow(words, lut, tb.lut_bits, entry, (u32)(tail_bytes * 8), limit, nullptr, &stop_pos, &stop_why);
+
+    /* the records of the one or two lanes the true path gets to */
+    u16 *fn_out = fn_tab + (u64)c * ns * HUFD_DEC_LANES;
+    u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES;
+    for (u32 k = 0; k < 2; ++k) {
+        const u32 lane = n_full + k;
+        const bool reached = k == 0 || tw.stop != 0;
+        if (lane >= HUFD_DEC_LANES || !reached) {
+            break;
+        }
+        const u32 my_entry = k == 0 ? entry : tw.exit;
+        const bool stops_here = tw.stop == k;
+        lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)tw.count[k];
+        fn_out[(u64)my_entry * HUFD_DEC_LANES + lane] =
+            stops_here ? fn_pack(true, 0, tw.count[k] & 0x7FFu) : fn_pack(false, tw.exit, tw.count[k] & 0x7FFu);
+        cp[(kQuarters - 1) * HUFD_DEC_LANES + lane] = (u16)((1u << my_entry) | ((stops_here ? kExitStop : tw.exit) << 12));
+    }
+    /* the chunk function: every walk that gets through sub-chunk 0 goes on to the end of the stream */
+    const bool stops = tw.stop != 2u;
+    for (u32 st = 0; st < ns; ++st) {
+        const u32 f = chunk_fn[(u64)c * ns + st];
+        if (!wide_stop(f)) {
+            chunk_fn[(u64)c * ns + st] = wide_pack(stops, stops ? 0u : tw.exit, wide_count(f) + tw.count[0] + tw.count[1]);
+        }
+    }
 }
 
 /* ------------------------------------------------------------------ decode: scan */
@@ -3745,10 +3864,14 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 4 : 8) void dec_emit_fast_
                 tail_words_load(words, sub[ch], bytes);
                 auto window_at = [&](u32 at) -> u32 { return tail_window(words, at); };
                 (void)shift;
+                tail_reader tr;
+                tr.start(words, pos);
                 for (u32 k = 0; k < cnt[ch]; ++k) { /* dec_sync_fast counted them: every one is a whole, valid code */
-                    const u32 e = sh.wlut[window_at(pos) >> (32u - LB)]; /* symbol << 16 | -length */
+                    const u32 e = sh.wlut[tr.peek() >> (32u - LB)]; /* symbol << 16 | -length */
+                    const u32 len = (0x10000u - (e & 0xFFFFu)) & 0xFFFFu;
                     *d++ = (u8)(e >> 16);
-                    pos += (0x10000u - (e & 0xFFFFu)) & 0xFFFFu;
+                    pos += len;
+                    tr.skip(len);
                 }
                 if ((own_row[ch] >> 12) == kExitStop) {
                     /* the true path ends here: where, and why (source/huffman.c:240-255) */
@@ -4034,10 +4157,14 @@ __device__ __forceinline__ void dec_emit_dense_chunk(
                     u32 *words = sh.tail_words[lane - n_full < 2 ? lane - n_full : 0];
                     tail_words_load(words, sub[ch], bytes);
                     auto window_at = [&](u32 at) -> u32 { return tail_window(words, at); };
+                    tail_reader tr;
+                    tr.start(words, pos);
                     for (u32 k = 0; k < cnt[ch]; ++k) { /* dec_sync_fast counted them: every one is a whole, valid code */
-                        const u32 e = sh.wlut[window_at(pos) >> (32u - LB)]; /* symbol << 16 | -length */
+                        const u32 e = sh.wlut[tr.peek() >> (32u - LB)]; /* symbol << 16 | -length */
+                        const u32 len = (0x10000u - (e & 0xFFFFu)) & 0xFFFFu;
                         *d++ = (u8)(e >> 16);
-                        pos += (0x10000u - (e & 0xFFFFu)) & 0xFFFFu;
+                        pos += len;
+                        tr.skip(len);
                     }
                     if ((own_row[ch] >> 12) == kExitStop) {
                         /* the true path ends here: where, and why (source/huffman.c:240-255) */
@@ -4365,25 +4492,33 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             hipLaunchKernelGGL(
                 (dec_sync_fast_kernel<10, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<10>),
                 st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
-                a->chunk_fn, a->lane_count, a->chunk_regular, a->slow_list, a->slow_count);
+                a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry, a->slow_list, a->slow_count);
             if (a->n_tail) {
                 hipLaunchKernelGGL(
                     (dec_sync_fast_kernel<10, true>), dim3(a->n_tail), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<10>),
                     st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
-                    a->chunk_fn, a->lane_count, a->chunk_regular, a->slow_list, a->slow_count);
+                    a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry, a->slow_list, a->slow_count);
             }
         } else {
             if (some_inside)
             hipLaunchKernelGGL(
                 (dec_sync_fast_kernel<12, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<12>),
                 st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
-                a->chunk_fn, a->lane_count, a->chunk_regular, a->slow_list, a->slow_count);
+                a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry, a->slow_list, a->slow_count);
             if (a->n_tail) {
                 hipLaunchKernelGGL(
                     (dec_sync_fast_kernel<12, true>), dim3(a->n_tail), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<12>),
                     st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
-                    a->chunk_fn, a->lane_count, a->chunk_regular, a->slow_list, a->slow_count);
+                    a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry, a->slow_list, a->slow_count);
             }
+        }
+        if (a->n_tail) {
+            /* the last symbols of every stream, a thread each; then the chunk functions are complete */
+            const uint32_t lds = (uint32_t)sizeof(tail_lds) + (2u << a->tables.lut_bits);
+            hipLaunchKernelGGL(
+                dec_sync_tail_kernel, dim3((a->n_tail + kTailThreads - 1) / kTailThreads), dim3(kTailThreads), lds, st,
+                a->tables, a->items, a->chunk_item, a->tail_chunks, a->n_tail, (const u8 *)a->d_in,
+                (const u8 *)a->chunk_regular, (const u32 *)a->tail_entry, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count);
         }
         hipLaunchKernelGGL(
             sync, dim3(persistent_grid(sync, HUFD_DEC_LANES, dec_sync_lds_bytes(&a->tables), a->n_chunks)),

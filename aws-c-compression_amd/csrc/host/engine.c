@@ -525,6 +525,7 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     hufs_free(p->d_dense_list);
     hufs_free(p->d_lane_count);
     hufs_free(p->d_chunk_regular);
+    hufs_free(p->d_tail_entry);
     hufs_free(p->d_chunk_entry);
     hufs_free(p->d_chunk_base);
     hufs_free(p->d_states);
@@ -545,6 +546,7 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     p->d_dense_list = NULL;
     p->d_lane_count = NULL;
     p->d_chunk_regular = NULL;
+    p->d_tail_entry = NULL;
     p->d_chunk_entry = NULL;
     p->d_chunk_base = NULL;
     p->d_states = NULL;
@@ -644,12 +646,13 @@ static int dec_plan_fill(
         p->d_dense_list = hufs_malloc((cc + 1) * sizeof(uint32_t));
         p->d_lane_count = hufs_malloc(cc * HUFD_DEC_LANES * sizeof(uint16_t));
         p->d_chunk_regular = hufs_malloc(cc);
+        p->d_tail_entry = hufs_malloc(cc * sizeof(uint32_t));
         p->d_chunk_entry = hufs_malloc(cc * sizeof(uint32_t));
         p->d_chunk_base = hufs_malloc(cc * sizeof(uint64_t));
         p->d_states = hufs_malloc(ci * sizeof(struct hufd_dec_item_state));
         p->d_results = hufs_malloc(ci * sizeof(struct hufd_dec_result));
         if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_cp_tab || !p->d_chunk_fn || !p->d_slow_list || !p->d_chunk_entry ||
-            !p->d_tail || !p->d_dense_list || !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
+            !p->d_tail || !p->d_dense_list || !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_tail_entry || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
             !p->d_chunk_base || !p->d_states || !p->d_results) {
             err = 2;
         }
@@ -775,6 +778,7 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.dense_list = p->d_dense_list + 1;
     a.lane_count = p->d_lane_count;
     a.chunk_regular = p->d_chunk_regular;
+    a.tail_entry = p->d_tail_entry;
     a.chunk_entry = p->d_chunk_entry;
     a.chunk_base = p->d_chunk_base;
     a.states = p->d_states;

@@ -80,6 +80,7 @@ struct aws_huffman_amd_decode_plan {
     uint32_t *d_dense_list; /* [0] how many, [1..] chunks with more symbols than one emit stage */
     uint16_t *d_lane_count;
     uint8_t *d_chunk_regular;
+    uint32_t *d_tail_entry;
     uint32_t *d_chunk_entry;
     uint64_t *d_chunk_base;
     struct hufd_dec_item_state *d_states;
