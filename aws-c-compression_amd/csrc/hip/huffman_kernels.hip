@@ -3635,7 +3635,7 @@ struct emit_shared {
 };
 
 template <u32 LB, bool TAIL> /* TAIL: the chunks listed in tail_chunks (they may hold the end of a stream); else all the others */
-__global__ __launch_bounds__(kEmitFastThreads, TAIL ? 4 : 8) void dec_emit_fast_kernel(
+__global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_kernel(
     hufd_tables tb,
     const hufd_dec_item *items,
     const u32 *chunk_item,
@@ -3708,7 +3708,7 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 4 : 8) void dec_emit_fast_
     constexpr u32 kRows = kSubWords / kQuarters;
     const u8 *sub[kEmitChains];
     u32 w[kEmitChains][kRows + 1];
-    u32 my_cp[kEmitChains], next_cp[kEmitChains], entry_state[kEmitChains], cnt[kEmitChains], own_row[kEmitChains];
+    u32 my_cp[kEmitChains], next_cp[kEmitChains], entry_state[kEmitChains], cnt[kEmitChains];
     bool whole[kEmitChains];
 #pragma unroll
     for (u32 ch = 0; ch < kEmitChains; ++ch) {
@@ -3730,7 +3730,6 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 4 : 8) void dec_emit_fast_
             }
             w[ch][kRows] = __builtin_bswap32(*reinterpret_cast<const u32 *>(sub[ch] + (q + 1) * kRows * 4));
         }
-        own_row[ch] = cpt[merged_row + lanes[ch]];
         my_cp[ch] = q ? cpt[(q - 1) * HUFD_DEC_LANES + lanes[ch]] : 0u;
         next_cp[ch] = q + 1 < kQuarters ? cpt[q * HUFD_DEC_LANES + lanes[ch]] : 0u;
         entry_state[ch] = lanes[ch] ? (u32)(cpt[merged_row + lanes[ch] - 1] >> 12) : s0;
@@ -3850,39 +3849,7 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 4 : 8) void dec_emit_fast_
             hi = lo;
         }
     }
-    if (TAIL && q == 0 && regular == 2) {
-        /* the end of the stream: the one or two sub-chunks behind the whole lanes, a thread each, symbol by symbol */
-#pragma unroll
-        for (u32 ch = 0; ch < kEmitChains; ++ch) {
-            if (!whole[ch] && (own_row[ch] & 0xFFFu) != 0) { /* the true path gets here */
-                const u32 lane = lanes[ch];
-                const u64 bytes = valid - (u64)lane * HUFD_DEC_SUB_BYTES;
-                const u32 shift = 32 - tb.lut_bits;
-                u8 *d = sh.stage + mis + sh.lane_base[lane];
-                u32 pos = entry_state[ch];
-                u32 *words = sh.tail_words[lane - n_full < 2 ? lane - n_full : 0];
-                tail_words_load(words, sub[ch], bytes);
-                auto window_at = [&](u32 at) -> u32 { return tail_window(words, at); };
-                (void)shift;
-                tail_reader tr;
-                tr.start(words, pos);
-                for (u32 k = 0; k < cnt[ch]; ++k) { /* dec_sync_fast counted them: every one is a whole, valid code */
-                    const u32 e = sh.wlut[tr.peek() >> (32u - LB)]; /* symbol << 16 | -length */
-                    const u32 len = (0x10000u - (e & 0xFFFFu)) & 0xFFFFu;
-                    *d++ = (u8)(e >> 16);
-                    pos += len;
-                    tr.skip(len);
-                }
-                if ((own_row[ch] >> 12) == kExitStop) {
-                    /* the true path ends here: where, and why (source/huffman.c:240-255) */
-                    u32 sym = 0, why = HUFD_STOP_NONE;
-                    (void)code_at_walk<LB>(window_at(pos), sh.wlut, pos, clamp_remaining(valid, lane), &sym, &why);
-                    results[item_index].stop_kind = why;
-                    results[item_index].stop_bit = (chunk_off + (u64)lane * HUFD_DEC_SUB_BYTES) * 8 + pos;
-                }
-            }
-        }
-    }
+    /* (TAIL: the symbols of the one or two sub-chunks behind the whole lanes are dec_emit_tail's, straight to memory) */
     HUFD_STAMP(1, 3);
     __syncthreads();
     HUFD_STAMP(1, 4);
@@ -3890,7 +3857,7 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 4 : 8) void dec_emit_fast_
     {
         /* stage byte b belongs at (out_ptr - mis) + b: whole 16-byte rows go out aligned */
         u8 *gbase = out_ptr - mis;
-        const u32 lo = mis, hi = mis + chunk_symbols;
+        const u32 lo = mis, hi = mis + (TAIL && n_full < HUFD_DEC_LANES ? sh.lane_base[n_full] : chunk_symbols);
         const u32 row_lo = (lo + 15) >> 4, row_hi = hi >> 4;
         if (row_lo <= row_hi) {
             for (u32 b = lo + t; b < row_lo * 16; b += kEmitFastThreads) {
@@ -3909,6 +3876,78 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 4 : 8) void dec_emit_fast_
         }
     }
     HUFD_STAMP(1, 5);
+}
+
+/*
+ * The symbols of the one or two sub-chunks a stream ends in, for the chunks dec_emit_fast<TAIL> took: one THREAD
+ * per chunk, straight to memory (dec_sync_tail's walk again, this time keeping the symbols), and the record of
+ * where and why the true path stops (source/huffman.c:240-255).
+ */
+__global__ __launch_bounds__(kTailThreads) void dec_emit_tail_kernel(
+    hufd_tables tb,
+    const hufd_dec_item *items,
+    const u32 *chunk_item,
+    const u32 *tail_chunks,
+    u32 n_tail,
+    const u8 *d_in,
+    u8 *d_out,
+    const u16 *cp_tab,
+    const u16 *lane_count,
+    const u8 *chunk_regular,
+    const u32 *chunk_fn,
+    const u32 *chunk_entry,
+    const u64 *chunk_base,
+    hufd_dec_result *results) {
+
+    tail_lds &sh = *reinterpret_cast<tail_lds *>(dyn_lds);
+    u16 *lut = reinterpret_cast<u16 *>(dyn_lds + sizeof(tail_lds));
+    for (u32 i = threadIdx.x; i < (1u << tb.lut_bits); i += kTailThreads) {
+        lut[i] = tb.dec_lut[i];
+    }
+    __syncthreads();
+    const u32 i = blockIdx.x * kTailThreads + threadIdx.x;
+    if (i >= n_tail) {
+        return;
+    }
+    const u32 c = tail_chunks[i];
+    const u32 centry = chunk_entry[c];
+    if (!(centry & 0x100u) || chunk_regular[c] != 2) {
+        return;
+    }
+    const u32 ns = tb.n_states, s0 = centry & 0xFFu;
+    const u32 item_index = chunk_item[c];
+    const hufd_dec_item it = items[item_index];
+    const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
+    const u64 valid = it.in_len - chunk_off;
+    const u64 cbase = chunk_base[c];
+    const u16 *cpt = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES;
+    const u32 merged_row = (kQuarters - 1) * HUFD_DEC_LANES;
+    const u32 f0 = chunk_fn[(u64)c * ns + s0];
+    const u32 chunk_symbols = wide_count(f0);
+    /* exactly the chunks dec_emit_fast<TAIL> emitted in one pass (the two-pass and the long way do their own ends) */
+    if (((cpt[merged_row] >> s0) & 1u) == 0 || cbase + chunk_symbols > it.out_cap ||
+        chunk_symbols + 16 > HUFD_DEC_STAGE_BYTES) {
+        return;
+    }
+    const u32 n_full = (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES);
+    const u32 first = n_full, second = n_full + 1;
+    const u32 n_first = lane_count[(u64)c * HUFD_DEC_LANES + first];
+    const u32 n_second = second < HUFD_DEC_LANES ? lane_count[(u64)c * HUFD_DEC_LANES + second] : 0u;
+    const u32 entry = cpt[merged_row + first - 1] >> 12;
+    const u8 *tsrc = d_in + it.in_off + chunk_off + (u64)n_full * HUFD_DEC_SUB_BYTES;
+    const u64 tail_bytes = valid - (u64)n_full * HUFD_DEC_SUB_BYTES;
+    u32 *words = sh.words[threadIdx.x];
+    for (u32 k = 0; k < kTailWords; ++k) {
+        words[k] = load_be32(tsrc, k, tail_bytes, true);
+    }
+    const u32 limit = (second < HUFD_DEC_LANES ? 2u : 1u) * HUFD_DEC_SUB_BITS;
+    u8 *out = d_out + it.out_off + cbase + (chunk_symbols - n_first - n_second);
+    u32 stop_pos = 0, stop_why = HUFD_STOP_NONE;
+    (void)tail_follow(words, lut, tb.lut_bits, entry, (u32)(tail_bytes * 8), limit, out, &stop_pos, &stop_why);
+    if (stop_why != HUFD_STOP_NONE) {
+        results[item_index].stop_kind = stop_why;
+        results[item_index].stop_bit = (chunk_off + (u64)n_full * HUFD_DEC_SUB_BYTES) * 8 + stop_pos;
+    }
 }
 
 /*
@@ -4570,6 +4609,14 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             }
         }
 #undef HUFK_LAUNCH_EMIT_FAST
+        if (a->n_tail) {
+            const uint32_t lds = (uint32_t)sizeof(tail_lds) + (2u << a->tables.lut_bits);
+            hipLaunchKernelGGL(
+                dec_emit_tail_kernel, dim3((a->n_tail + kTailThreads - 1) / kTailThreads), dim3(kTailThreads), lds, st,
+                a->tables, a->items, a->chunk_item, a->tail_chunks, a->n_tail, (const u8 *)a->d_in, (u8 *)a->d_out,
+                (const u16 *)a->cp_tab, (const u16 *)a->lane_count, (const u8 *)a->chunk_regular,
+                (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results);
+        }
         /* chunks of short codes (more symbols than one stage): a resident grid takes turns over their list */
         if (a->tables.lut_bits <= 10) {
             const uint32_t lds = (uint32_t)sizeof(emit_shared<10>);
