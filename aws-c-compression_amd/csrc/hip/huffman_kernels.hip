@@ -2767,6 +2767,13 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, TAIL ? (LB <= 10 ? 6 : 4) : 8) void
     const bool eligible = n_full >= 1 && ((uintptr_t)src & 15u) == 0 && tb.lut_bits <= LB &&
                           tb.max_bits <= HUFD_DEC_MAX_LUT_BITS;
     const bool active = !TAIL || lane < n_full;
+    if (TAIL && n_full == 0 && tb.lut_bits <= HUFD_DEC_MAX_LUT_BITS) {
+        /* fewer than 136 bytes: no lane is whole, and the whole chunk is one thread's work in dec_sync_tail / dec_emit_tail */
+        if (lane == 0) {
+            chunk_regular[c] = 3;
+        }
+        return;
+    }
     if (!eligible) {
         if (lane == 0) {
             chunk_regular[c] = 0;
@@ -3050,13 +3057,27 @@ __global__ __launch_bounds__(kTailThreads) void dec_sync_tail_kernel(
         return;
     }
     const u32 c = tail_chunks[i];
-    if (chunk_regular[c] != 2) {
+    const u32 kind = chunk_regular[c];
+    if (kind != 2 && kind != 3) {
         return; /* not taken by dec_sync_fast: the long way does all of it */
     }
     const u32 ns = tb.n_states;
     const hufd_dec_item it = items[chunk_item[c]];
     const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
     const u64 valid = it.in_len - chunk_off;
+    if (kind == 3) {
+        /* a chunk of fewer than 136 bytes (a short item, or the last bytes of a long one): its whole transfer function */
+        u32 *tiny = sh.words[threadIdx.x];
+        for (u32 k = 0; k < kTailWords; ++k) {
+            tiny[k] = load_be32(d_in + it.in_off + chunk_off, k, valid, false);
+        }
+        for (u32 st = 0; st < ns; ++st) {
+            u32 stop_pos = 0, stop_why = 0;
+            const tail_walk tw = tail_follow(tiny, lut, tb.lut_bits, st, (u32)(valid * 8), 2 * HUFD_DEC_SUB_BITS, nullptr, &stop_pos, &stop_why);
+            chunk_fn[(u64)c * ns + st] = wide_pack(true, 0, tw.count[0] + tw.count[1]); /* the stream ends here whatever the entry */
+        }
+        return;
+    }
     const u32 n_full = (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES); /* >= 1 and < HUFD_DEC_LANES here */
     const u8 *tsrc = d_in + it.in_off + chunk_off + (u64)n_full * HUFD_DEC_SUB_BYTES;
     const u64 tail_bytes = valid - (u64)n_full * HUFD_DEC_SUB_BYTES; /* 8 .. 135 */
@@ -3689,6 +3710,9 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
     const u32 chunk_symbols = wide_count(f0);
     /* all the same for the whole workgroup */
     const u32 regular = chunk_regular[c]; /* 1: all lanes whole; 2: the chunk that holds the end of the stream */
+    if (TAIL && regular == 3) {
+        return; /* fewer than 136 bytes: dec_emit_tail does the whole chunk */
+    }
     const bool fits = regular != 0 && (regular == 2 || !wide_stop(f0)) && ((cpt[merged_row] >> s0) & 1u) != 0 &&
                       cbase + chunk_symbols <= it.out_cap;
     const bool fast = fits && chunk_symbols + 16 <= HUFD_DEC_STAGE_BYTES;
@@ -3911,7 +3935,8 @@ __global__ __launch_bounds__(kTailThreads) void dec_emit_tail_kernel(
     }
     const u32 c = tail_chunks[i];
     const u32 centry = chunk_entry[c];
-    if (!(centry & 0x100u) || chunk_regular[c] != 2) {
+    const u32 kind = chunk_regular[c];
+    if (!(centry & 0x100u) || (kind != 2 && kind != 3)) {
         return;
     }
     const u32 ns = tb.n_states, s0 = centry & 0xFFu;
@@ -3920,6 +3945,38 @@ __global__ __launch_bounds__(kTailThreads) void dec_emit_tail_kernel(
     const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
     const u64 valid = it.in_len - chunk_off;
     const u64 cbase = chunk_base[c];
+    if (kind == 3) {
+        /* the whole chunk: symbols while there is room, the start bit of the one that finds none
+         * (source/huffman.c:257-268), else where and why the stream stops (:240-255) */
+        u32 *tiny = sh.words[threadIdx.x];
+        for (u32 k = 0; k < kTailWords; ++k) {
+            tiny[k] = load_be32(d_in + it.in_off + chunk_off, k, valid, false);
+        }
+        const u64 room = it.out_cap > cbase ? it.out_cap - cbase : 0;
+        u8 *out = d_out + it.out_off + cbase;
+        const u32 rem = (u32)(valid * 8);
+        tail_reader tr;
+        tr.start(tiny, s0);
+        u32 pos = s0, why = HUFD_STOP_NONE;
+        u64 n = 0;
+        for (;;) {
+            u32 sym = 0;
+            const u32 len = code_at(tr.peek(), lut, tb.lut_bits, pos, rem, &sym, &why);
+            if (!len) {
+                results[item_index].stop_kind = why;
+                results[item_index].stop_bit = chunk_off * 8 + pos;
+                break;
+            }
+            if (n == room) {
+                results[item_index].cap_bit = chunk_off * 8 + pos;
+                break;
+            }
+            out[n++] = (u8)sym;
+            tr.skip(len);
+            pos += len;
+        }
+        return;
+    }
     const u16 *cpt = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES;
     const u32 merged_row = (kQuarters - 1) * HUFD_DEC_LANES;
     const u32 f0 = chunk_fn[(u64)c * ns + s0];
