@@ -19,6 +19,7 @@
 
 #define HUFD_ENC_SEG_BYTES 16384u
 #define HUFD_ENC_THREADS 256u
+#define HUFD_ENC_TINY_BYTES 512u /* encode items up to this long are one thread's work (enc_tiny): no segments */
 
 #define HUFD_DEC_SUB_BYTES 128u
 #define HUFD_DEC_SUB_BITS (HUFD_DEC_SUB_BYTES * 8u)
@@ -69,7 +70,7 @@ struct hufd_enc_item {
     uint32_t eos_padding;
     uint32_t first_seg; /* index of the item's first segment in the plan's segment numbering */
     uint32_t n_segs;
-    uint32_t reserved;
+    uint32_t tiny; /* 1: the item has no segments, enc_tiny encodes it */
 };
 
 /* one per segment, built with the plan: where the segment's symbols are, without pointer chasing */

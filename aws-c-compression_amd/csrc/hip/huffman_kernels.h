@@ -21,6 +21,8 @@ struct hufk_encode_args {
     uint32_t n_segs;
     const uint32_t *large_items; /* [n_large] items with more than HUFD_SCAN_SMALL_MAX segments */
     uint32_t n_large;
+    const uint32_t *tiny_items;  /* [n_tiny] items of at most HUFD_ENC_TINY_BYTES symbols: no segments, one thread each */
+    uint32_t n_tiny;
     uint32_t length_only; /* stop after the scan */
     const void *d_in;
     void *d_out;

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void enc_scan_small_kernel(
         return;
     }
     const hufd_enc_item it = items[i];
-    if (it.n_segs > HUFD_SCAN_SMALL_MAX) {
+    if (it.n_segs > HUFD_SCAN_SMALL_MAX || it.tiny) {
         return;
     }
     const u64 cap_bits = it.out_cap > (~0ull >> 3) ? ~0ull : it.out_cap * 8;
@@ -521,6 +521,166 @@ __global__ __launch_bounds__(256) void enc_scan_small_kernel(
     }
     enc_finish_item(
         it, at, unk_seg, unk_idx, unk_off, unk_bits, edge_seg, careful_list, careful_count, &states[i], &results[i]);
+}
+
+/*
+ * Items of at most HUFD_ENC_TINY_BYTES symbols (header-field sized strings): one THREAD per item
+ * replays the reference loop (source/huffman.c:149-184) as it stands -- carried overflow first, a
+ * symbol only while the output has a free byte, whatever of a code does not fit becomes the
+ * overflow, the last byte completed with the low bits of eos_padding -- with the code bits
+ * gathered in a 64-bit accumulator and stored a byte at a time, or a word at a time once the
+ * output address is word aligned.  Segments, counts, offsets and output images cost such items
+ * far more than their symbols do.
+ */
+constexpr u32 kTinyThreads = 256;
+
+struct tiny_sink {
+    u8 *out;
+    u64 cap;
+    u64 produced;
+    u64 acc;  /* low nacc bits: code bits not yet stored, oldest highest */
+    u32 nacc;
+
+    /* stores every whole byte gathered; true when the output filled with bits of the last code left over */
+    __device__ bool drain(bool writing) {
+        if (writing && nacc >= 32 && cap - produced > 4 && ((reinterpret_cast<uintptr_t>(out) + produced) & 3) == 0) {
+            const u32 w = (u32)(acc >> (nacc - 32));
+            *reinterpret_cast<u32 *>(out + produced) = __builtin_bswap32(w);
+            produced += 4;
+            nacc -= 32;
+        }
+        while (nacc >= 8) {
+            if (writing) {
+                out[produced] = (u8)(acc >> (nacc - 8));
+            }
+            nacc -= 8;
+            ++produced;
+            if (produced == cap) {
+                return nacc != 0;
+            }
+        }
+        return false;
+    }
+};
+
+__global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
+    hufd_tables tb,
+    const hufd_enc_item *items,
+    const u32 *tiny_items,
+    u32 n_tiny,
+    const u8 *d_in,
+    u8 *d_out,
+    hufd_enc_result *results,
+    u32 length_only) {
+
+    u64 *tab = reinterpret_cast<u64 *>(dyn_lds); /* [256] low half: code, high half: length */
+    for (u32 i = threadIdx.x; i < 256; i += kTinyThreads) {
+        tab[i] = tb.enc_table[i];
+    }
+    __syncthreads();
+    const u32 t = blockIdx.x * kTinyThreads + threadIdx.x;
+    if (t >= n_tiny) {
+        return;
+    }
+    const u32 item = tiny_items[t];
+    const hufd_enc_item it = items[item];
+    const u8 *in = d_in + it.in_off;
+    const u32 n = (u32)it.in_len;
+
+    hufd_enc_result rs;
+    rs.status = HUFD_ENC_OK;
+    rs.ovf_pattern = 0;
+    rs.ovf_bits = 0;
+    rs.reserved = 0;
+    rs.consumed = n;
+    rs.produced = 0;
+    rs.total_bits = it.ovf_bits;
+
+    /* aligned eight-byte reads of the symbols, one at a time */
+    const uintptr_t in_addr = reinterpret_cast<uintptr_t>(in);
+    u64 word = 0;
+    auto symbol = [&](u32 k) -> u32 {
+        const uintptr_t a = in_addr + k;
+        if (k == 0 || (a & 7) == 0) {
+            word = *reinterpret_cast<const u64 *>(a & ~(uintptr_t)7);
+        }
+        return (u32)(word >> ((a & 7) * 8)) & 0xFFu;
+    };
+
+    if (length_only) {
+        u64 bits = it.ovf_bits;
+        for (u32 k = 0; k < n; ++k) {
+            bits += (u32)(tab[symbol(k)] >> 32);
+        }
+        rs.total_bits = bits;
+        rs.produced = (bits + 7) >> 3;
+        results[item] = rs;
+        return;
+    }
+
+    tiny_sink sink;
+    sink.out = d_out + it.out_off;
+    sink.cap = it.out_cap;
+    sink.produced = 0;
+    sink.acc = 0;
+    sink.nacc = 0;
+    bool stopped = false;
+    if (it.ovf_bits) {
+        if (sink.cap == 0) {
+            /* no byte to put the carried bits in (source/huffman.c:150-152): they stay carried */
+            rs.status = HUFD_ENC_SHORT;
+            rs.consumed = 0;
+            rs.ovf_bits = it.ovf_bits;
+            rs.ovf_pattern = it.ovf_pattern;
+            stopped = true;
+        } else {
+            sink.acc = it.ovf_pattern;
+            sink.nacc = it.ovf_bits;
+            if (sink.drain(true)) {
+                rs.status = HUFD_ENC_SHORT;
+                rs.consumed = 0;
+                rs.ovf_bits = sink.nacc;
+                rs.ovf_pattern = (u32)(sink.acc & ((1ull << sink.nacc) - 1));
+                stopped = true;
+            }
+        }
+    }
+    u64 bits = it.ovf_bits;
+    for (u32 k = 0; k < n && !stopped; ++k) {
+        if (sink.produced == sink.cap) { /* source/huffman.c:162-164 */
+            rs.status = HUFD_ENC_SHORT;
+            rs.consumed = k;
+            stopped = true;
+            break;
+        }
+        const u64 ent = tab[symbol(k)];
+        const u32 len = (u32)(ent >> 32);
+        if (len == 0) { /* source/huffman.c:62-64: the symbol is consumed, the byte under construction is not written */
+            rs.status = HUFD_ENC_UNKNOWN;
+            rs.consumed = k + 1;
+            stopped = true;
+            break;
+        }
+        bits += len;
+        sink.acc = (sink.acc << len) | (u32)ent;
+        sink.nacc += len;
+        if (sink.drain(true)) { /* source/huffman.c:88-100 */
+            rs.status = HUFD_ENC_SHORT;
+            rs.consumed = k + 1;
+            rs.ovf_bits = sink.nacc;
+            rs.ovf_pattern = (u32)(sink.acc & ((1ull << sink.nacc) - 1));
+            stopped = true;
+            break;
+        }
+    }
+    if (!stopped && sink.nacc) { /* source/huffman.c:178-184 */
+        const u32 room = 8 - sink.nacc;
+        sink.out[sink.produced] = (u8)((sink.acc << room) | (it.eos_padding & ((1u << room) - 1)));
+        ++sink.produced;
+    }
+    rs.produced = sink.produced;
+    rs.total_bits = bits;
+    results[item] = rs;
 }
 
 /*
@@ -2011,6 +2171,9 @@ __global__ __launch_bounds__(256) void enc_finish_kernel(
         return;
     }
     const hufd_enc_item it = items[i];
+    if (it.tiny) {
+        return; /* enc_tiny's */
+    }
     const u64 total = it.n_segs ? item_total[i] : it.ovf_bits;
     const u64 cap_bits = it.out_cap > (~0ull >> 3) ? ~0ull : it.out_cap * 8;
     u32 unk_seg = HUFD_NONE32, edge_seg = HUFD_NONE32;
@@ -4495,6 +4658,12 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
             a->seg_unk, a->seg_bitoff, a->seg_unk_seen, a->item_total, a->careful_list, a->careful_count, a->states,
             a->results);
         stage_mark(a->stage_events, 2, st);
+        if (a->n_tiny) {
+            hipLaunchKernelGGL(
+            enc_tiny_kernel, dim3((a->n_tiny + kTinyThreads - 1) / kTinyThreads), dim3(kTinyThreads), 256 * sizeof(u64), st,
+            a->tables, a->items, a->tiny_items, a->n_tiny, (const u8 *)a->d_in, (u8 *)a->d_out, a->results,
+            a->length_only);
+        }
         const uint32_t most = 2 * a->n_items < 1024 ? 2 * a->n_items : 1024;
         hipLaunchKernelGGL(
             enc_pack_kernel, dim3(most), dim3(HUFD_ENC_THREADS), enc_pack_lds_bytes(img_words), st, a->tables, a->items,
@@ -4521,6 +4690,12 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
             enc_scan_large_kernel, dim3(a->n_large), dim3(HUFD_SCAN_LARGE_THREADS), 256, st, a->items, a->large_items,
             a->seg_bits, a->seg_unk, a->seg_bitoff, a->careful_list, a->careful_count, a->states, a->results,
             a->tables.all_coded);
+    }
+    if (a->n_tiny) {
+        hipLaunchKernelGGL(
+            enc_tiny_kernel, dim3((a->n_tiny + kTinyThreads - 1) / kTinyThreads), dim3(kTinyThreads), 256 * sizeof(u64), st,
+            a->tables, a->items, a->tiny_items, a->n_tiny, (const u8 *)a->d_in, (u8 *)a->d_out, a->results,
+            a->length_only);
     }
     stage_mark(a->stage_events, 2, st);
     if (a->n_segs && !a->length_only) {

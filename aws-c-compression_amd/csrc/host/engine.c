@@ -198,6 +198,7 @@ static void enc_plan_release_device(struct aws_huffman_amd_encode_plan *p) {
     hufs_free(p->d_items);
     hufs_free(p->d_segs);
     hufs_free(p->d_large);
+    hufs_free(p->d_tiny);
     hufs_free(p->d_seg_bits);
     hufs_free(p->d_wave_bits);
     hufs_free(p->d_seg_unk);
@@ -211,6 +212,7 @@ static void enc_plan_release_device(struct aws_huffman_amd_encode_plan *p) {
     p->d_items = NULL;
     p->d_segs = NULL;
     p->d_large = NULL;
+    p->d_tiny = NULL;
     p->d_seg_bits = NULL;
     p->d_wave_bits = NULL;
     p->d_seg_unk = NULL;
@@ -221,13 +223,18 @@ static void enc_plan_release_device(struct aws_huffman_amd_encode_plan *p) {
     p->d_item_total = NULL;
     p->d_states = NULL;
     p->d_results = NULL;
-    p->cap_items = p->cap_segs = p->cap_large = 0;
+    p->cap_items = p->cap_segs = p->cap_large = p->cap_tiny = 0;
 }
 
-/* segments an item needs: at least one when there is anything to write */
+/* short items with anything to write (symbols or carried bits) are one thread's work, without segments */
+static bool enc_item_is_tiny(const struct aws_huffman_amd_encode_item *it) {
+    return it->in_len <= HUFD_ENC_TINY_BYTES && (it->in_len > 0 || it->overflow_in.num_bits);
+}
+
+/* segments the other items need */
 static uint64_t enc_item_segments(const struct aws_huffman_amd_encode_item *it) {
-    if (it->in_len == 0) {
-        return it->overflow_in.num_bits ? 1 : 0;
+    if (enc_item_is_tiny(it)) {
+        return 0; /* one thread encodes it (enc_tiny) */
     }
     return (it->in_len + HUFD_ENC_SEG_BYTES - 1) / HUFD_ENC_SEG_BYTES;
 }
@@ -239,7 +246,7 @@ static int enc_plan_fill(
     size_t n_items) {
 
     struct aws_huffman_amd_engine *eng = p->engine;
-    uint64_t n_segs = 0, n_large = 0;
+    uint64_t n_segs = 0, n_large = 0, n_tiny = 0;
     for (size_t i = 0; i < n_items; ++i) {
         if (items[i].overflow_in.num_bits > 32) {
             return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
@@ -247,6 +254,7 @@ static int enc_plan_fill(
         const uint64_t segs = enc_item_segments(&items[i]);
         n_segs += segs;
         n_large += segs > HUFD_SCAN_SMALL_MAX;
+        n_tiny += enc_item_is_tiny(&items[i]);
     }
     if (n_segs >= 0xFFFFFFFFull || n_items >= 0xFFFFFFFFull) {
         return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
@@ -255,13 +263,15 @@ static int enc_plan_fill(
     struct hufd_enc_item *h_items = malloc((n_items ? n_items : 1) * sizeof(*h_items));
     struct hufd_enc_seg *h_segs = malloc((n_segs ? n_segs : 1) * sizeof(*h_segs));
     uint32_t *h_large = malloc((n_large ? n_large : 1) * sizeof(uint32_t));
-    if (!h_items || !h_segs || !h_large) {
+    uint32_t *h_tiny = malloc((n_tiny ? n_tiny : 1) * sizeof(uint32_t));
+    if (!h_items || !h_segs || !h_large || !h_tiny) {
         free(h_items);
         free(h_segs);
         free(h_large);
+        free(h_tiny);
         return aws_raise_error(AWS_ERROR_OOM);
     }
-    uint32_t seg = 0, large = 0;
+    uint32_t seg = 0, large = 0, tiny = 0;
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_encode_item *src = &items[i];
         struct hufd_enc_item *dst = &h_items[i];
@@ -276,7 +286,10 @@ static int enc_plan_fill(
         dst->eos_padding = src->eos_padding;
         dst->first_seg = seg;
         dst->n_segs = segs;
-        dst->reserved = 0;
+        dst->tiny = enc_item_is_tiny(src) ? 1u : 0u;
+        if (dst->tiny) {
+            h_tiny[tiny++] = (uint32_t)i;
+        }
         for (uint32_t k = 0; k < segs; ++k) {
             struct hufd_enc_seg *sd = &h_segs[seg++];
             const uint64_t off = (uint64_t)k * HUFD_ENC_SEG_BYTES;
@@ -297,12 +310,13 @@ static int enc_plan_fill(
 
     int err = 0;
     hufs_set_device(eng->device);
-    if (n_items > p->cap_items || n_segs > p->cap_segs || n_large > p->cap_large) {
+    if (n_items > p->cap_items || n_segs > p->cap_segs || n_large > p->cap_large || n_tiny > p->cap_tiny) {
         enc_plan_release_device(p);
-        const size_t ci = n_items ? n_items : 1, cs = n_segs ? n_segs : 1, cl = n_large ? n_large : 1;
+        const size_t ci = n_items ? n_items : 1, cs = n_segs ? n_segs : 1, cl = n_large ? n_large : 1, ct = n_tiny ? n_tiny : 1;
         p->d_items = hufs_malloc(ci * sizeof(struct hufd_enc_item));
         p->d_segs = hufs_malloc(cs * sizeof(struct hufd_enc_seg));
         p->d_large = hufs_malloc(cl * sizeof(uint32_t));
+        p->d_tiny = hufs_malloc(ct * sizeof(uint32_t));
         p->d_seg_bits = hufs_malloc(cs * sizeof(uint32_t));
         p->d_wave_bits = hufs_malloc(cs * 4 * sizeof(uint32_t));
         p->d_seg_unk = hufs_malloc(cs * sizeof(uint32_t));
@@ -313,13 +327,14 @@ static int enc_plan_fill(
         p->d_item_total = hufs_malloc(ci * sizeof(uint64_t));
         p->d_states = hufs_malloc(ci * sizeof(struct hufd_enc_item_state));
         p->d_results = hufs_malloc(ci * sizeof(struct hufd_enc_result));
-        if (!p->d_items || !p->d_segs || !p->d_large || !p->d_seg_bits || !p->d_wave_bits || !p->d_seg_unk || !p->d_seg_bitoff ||
+        if (!p->d_items || !p->d_segs || !p->d_large || !p->d_tiny || !p->d_seg_bits || !p->d_wave_bits || !p->d_seg_unk || !p->d_seg_bitoff ||
             !p->d_careful || !p->d_zero || !p->d_unk_seen || !p->d_item_total || !p->d_states || !p->d_results) {
             err = 2;
         }
         p->cap_items = ci;
         p->cap_segs = cs;
         p->cap_large = cl;
+        p->cap_tiny = ct;
     }
     if (!err) {
         err = hufs_copy_h2d(p->d_items, h_items, n_items * sizeof(*h_items), eng->stream);
@@ -331,17 +346,22 @@ static int enc_plan_fill(
         err = hufs_copy_h2d(p->d_large, h_large, n_large * sizeof(uint32_t), eng->stream);
     }
     if (!err) {
+        err = hufs_copy_h2d(p->d_tiny, h_tiny, n_tiny * sizeof(uint32_t), eng->stream);
+    }
+    if (!err) {
         err = hufs_stream_sync(eng->stream);
     }
     free(h_items);
     free(h_segs);
     free(h_large);
+    free(h_tiny);
     if (err) {
         return raise_hip(err);
     }
     p->n_items = (uint32_t)n_items;
     p->n_segs = (uint32_t)n_segs;
     p->n_large = (uint32_t)n_large;
+    p->n_tiny = (uint32_t)n_tiny;
     return AWS_OP_SUCCESS;
 }
 
@@ -398,6 +418,8 @@ int aws_huffman_amd_encode_plan_launch_staged(
     a.segs = p->d_segs;
     a.n_segs = p->n_segs;
     a.large_items = p->d_large;
+    a.tiny_items = p->d_tiny;
+    a.n_tiny = p->n_tiny;
     a.n_large = p->n_large;
     a.length_only = length_only;
     a.d_in = device_input;

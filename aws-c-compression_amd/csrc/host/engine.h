@@ -42,6 +42,9 @@ struct aws_huffman_amd_encode_plan {
     struct hufd_enc_item *d_items;
     struct hufd_enc_seg *d_segs;
     uint32_t *d_large;
+    uint32_t *d_tiny; /* items of at most HUFD_ENC_TINY_BYTES symbols */
+    uint32_t n_tiny;
+    size_t cap_tiny;
     uint32_t *d_seg_bits;
     uint32_t *d_wave_bits; /* [n_segs][4]: bits of each quarter of a segment */
     uint32_t *d_seg_unk;

@@ -587,6 +587,78 @@ def batched_device_api(w, n_items=9, seed=18, item_len=16384, engine=None):
         eng.close()
 
 
+def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False):
+    """Items either side of HUFD_ENC_TINY_BYTES (512 symbols; one thread each below it), with every kind
+    of stop: roomy, exact, one byte short, cut anywhere, no room at all, carried overflow bits that fit,
+    fill the output exactly or do not fit, symbols without a code."""
+    rng = np.random.default_rng(seed)
+    own = engine is None or holes
+    eng = harness.Engine(w.product.lib, w.pcoder_holes if holes else w.pcoder) if own else engine
+    oc = w.ocoder_holes if holes else w.ocoder
+    lens = [0, 0, 1, 2, 3, 511, 512, 513, 600] + [int(rng.integers(0, 560)) for _ in range(n_items - 9)]
+    blobs = []
+    for i, n in enumerate(lens):
+        b = inputs(rng, n, KINDS[i % 4])
+        if holes:
+            b[b == 7] = 8
+            b[b == 200] = 201
+            if n and i % 3 == 0:
+                b[int(rng.integers(0, n))] = 7 if i % 2 else 200
+        blobs.append(b)
+    in_offs, pos = [], 1
+    for b in blobs:
+        in_offs.append(pos)
+        pos += b.size + int(rng.integers(0, 3))
+    in_total = pos + 64
+    host_in = np.zeros(in_total, np.uint8)
+    for b, o in zip(blobs, in_offs):
+        host_in[o:o + b.size] = b
+    items, out_offs, pos = [], [], 3
+    for i, b in enumerate(blobs):
+        ov = (0, 0)
+        if i % 4 == 1:
+            nb = int(rng.integers(1, 33))
+            ov = (int(rng.integers(0, 1 << nb)), nb)
+        full = (ov[1] + 10 * b.size + 7) // 8 + 2
+        cap = [full, int(rng.integers(0, full + 1)), max(b.size * 5 // 8, 0), 0, int(rng.integers(0, 6))][int(rng.integers(0, 5))]
+        if i % 7 == 3:  # the exact size, and one less
+            e = w.oracle.new_encoder(oc)
+            e.overflow_bits.pattern, e.overflow_bits.num_bits = ov
+            dst = np.zeros(full + 8, np.uint8)
+            r = w.oracle.encode_call(e, b, 0, dst, 0, full + 8)
+            cap = max(r.produced - (i % 2), 0)
+        out_offs.append(pos)
+        items.append(dict(in_offset=in_offs[i], in_len=b.size, out_offset=pos, out_capacity=cap, overflow_in=ov,
+                          eos_padding=[0xFF, 0x00, 0xA5][i % 3]))
+        pos += cap + int(rng.integers(1, 9))
+    out_total = pos + 64
+    d_in, d_out = eng.alloc(in_total), eng.alloc(out_total)
+    eng.upload(d_in, host_in)
+    eng.fill(d_out, SENTINEL, out_total)
+    plan = eng.encode_plan(items)
+    eng.encode_launch(plan, d_in, d_out)
+    res = eng.encode_results(plan, len(items))
+    got = eng.download(d_out, out_total)
+    want = np.full(out_total, SENTINEL, np.uint8)
+    kinds = set()
+    for i, (b, it) in enumerate(zip(blobs, items)):
+        e = w.oracle.new_encoder(oc, eos_padding=it["eos_padding"])
+        e.overflow_bits.pattern, e.overflow_bits.num_bits = it["overflow_in"]
+        c = it["out_capacity"]
+        dst = np.full(c + 1, SENTINEL, np.uint8)
+        r = w.oracle.encode_call(e, b, 0, dst, 0, c)
+        want[it["out_offset"]:it["out_offset"] + c] = dst[:c]
+        assert res[i] == (r.rc, r.err, r.consumed, r.produced, r.state[0], r.state[1]), (i, it, res[i], r)
+        kinds.add((r.rc, r.err))
+    assert np.array_equal(got, want), "tiny items: wrong bytes, or bytes outside an item"
+    assert len(kinds) >= (3 if holes else 2)
+    eng.lib.aws_huffman_amd_encode_plan_destroy(plan)
+    eng.free(d_in)
+    eng.free(d_out)
+    if own:
+        eng.close()
+
+
 def first_bit_offsets(w, engine=None):
     """Decode items that start inside their first byte (what a carried decoder state turns into)."""
     rng = np.random.default_rng(19)

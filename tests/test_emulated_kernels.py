@@ -65,6 +65,11 @@ def test_batched_device_api(world):
     pc.batched_device_api(world)
 
 
+def test_tiny_encode_items(world):
+    pc.tiny_encode_items(world, n_items=400)
+    pc.tiny_encode_items(world, n_items=400, seed=38, holes=True)
+
+
 def test_first_bit_offsets(world):
     pc.first_bit_offsets(world)
 

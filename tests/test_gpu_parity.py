@@ -88,6 +88,11 @@ def test_batched_device_api(world, engine):
     pc.batched_device_api(world, n_items=40, engine=engine)
 
 
+def test_tiny_encode_items(world, engine):
+    pc.tiny_encode_items(world, engine=engine)
+    pc.tiny_encode_items(world, seed=38, holes=True)
+
+
 def test_first_bit_offsets(world, engine):
     pc.first_bit_offsets(world, engine=engine)
 
