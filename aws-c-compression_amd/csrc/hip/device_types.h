@@ -28,6 +28,7 @@
 #define HUFD_DEC_MAX_STATES 16u
 #define HUFD_DEC_CP_ROWS 4u /* per sub-chunk: three checkpoints of the walk + the merged-state mask */
 #define HUFD_DEC_MAX_LUT_BITS 12u
+#define HUFD_DEC_TINY_BYTES 512u /* decode items up to this long are one thread's work (dec_tiny): no chunks */
 #define HUFD_DEC_STAGE_BYTES 34304u /* LDS bytes for a chunk's decoded symbols (dec_emit_fast: four workgroups per CU) */
 
 #define HUFD_SCAN_SMALL_MAX 64u /* items with at most this many segments/chunks are scanned by one thread */
@@ -111,7 +112,7 @@ struct hufd_dec_item {
     uint32_t first_bit;
     uint32_t first_chunk;
     uint32_t n_chunks;
-    uint32_t reserved;
+    uint32_t tiny; /* 1: the item has no chunks, dec_tiny decodes it */
 };
 
 /* written by the scan kernel */

@@ -3234,7 +3234,9 @@ __global__ __launch_bounds__(kTailThreads) void dec_sync_tail_kernel(
         for (u32 k = 0; k < kTailWords; ++k) {
             tiny[k] = load_be32(d_in + it.in_off + chunk_off, k, valid, false);
         }
-        for (u32 st = 0; st < ns; ++st) {
+        /* (an item's first chunk is only ever entered at the item's first bit) */
+        const bool only = c == it.first_chunk;
+        for (u32 st = only ? it.first_bit : 0u; st < (only ? it.first_bit + 1u : ns); ++st) {
             u32 stop_pos = 0, stop_why = 0;
             const tail_walk tw = tail_follow(tiny, lut, tb.lut_bits, st, (u32)(valid * 8), 2 * HUFD_DEC_SUB_BITS, nullptr, &stop_pos, &stop_why);
             chunk_fn[(u64)c * ns + st] = wide_pack(true, 0, tw.count[0] + tw.count[1]); /* the stream ends here whatever the entry */
@@ -3279,6 +3281,123 @@ __global__ __launch_bounds__(kTailThreads) void dec_sync_tail_kernel(
     }
 }
 
+/*
+ * Items of at most HUFD_DEC_TINY_BYTES encoded bytes (header-field sized strings): one THREAD per item does
+ * all of source/huffman.c:228-268 for it -- from the item's first bit, a symbol per code while there is room,
+ * the start bit of the first symbol that finds none, how many symbols the stream holds, where and why it
+ * stops -- reading the stream from memory in aligned 8-byte words.  No chunks, transfer functions or scan: for
+ * such items they cost far more than the symbols.
+ */
+constexpr u32 kTinyDecThreads = 128;
+
+struct stream_reader {
+    uintptr_t base; /* 8-byte aligned address at or in front of the item's first byte */
+    u32 end;        /* bytes from base to the end of the item: bytes behind it read as zero */
+    u64 cur;        /* aligned word cur_index, big endian */
+    u32 cur_index;
+    u64 win;
+    u32 nb, next, ahead;
+
+    __device__ __forceinline__ u64 word64(u32 i) const {
+        if (i * 8 >= end) {
+            return 0;
+        }
+        u64 v = __builtin_bswap64(*reinterpret_cast<const u64 *>(base + (uintptr_t)i * 8));
+        const u32 keep = end - i * 8;
+        if (keep < 8) {
+            v &= ~0ull << (8 * (8 - keep));
+        }
+        return v;
+    }
+    __device__ __forceinline__ u32 word(u32 i) {
+        if ((i >> 1) != cur_index) {
+            cur_index = i >> 1;
+            cur = word64(cur_index);
+        }
+        return (i & 1) ? (u32)cur : (u32)(cur >> 32);
+    }
+    /* pos: bits from base */
+    __device__ __forceinline__ void start(uintptr_t b, u32 end_bytes, u32 pos) {
+        base = b;
+        end = end_bytes;
+        cur_index = ~0u;
+        cur = 0;
+        const u32 r = pos >> 5;
+        const u32 w0 = word(r), w1 = word(r + 1);
+        win = (((u64)w0 << 32) | w1) << (pos & 31u);
+        nb = 64 - (pos & 31u);
+        ahead = word(r + 2);
+        next = r + 3;
+    }
+    __device__ __forceinline__ u32 peek() const {
+        return (u32)(win >> 32);
+    }
+    __device__ __forceinline__ void skip(u32 len) {
+        win <<= len;
+        nb -= len;
+        if (nb <= 32) {
+            win |= (u64)ahead << (32 - nb);
+            nb += 32;
+            ahead = word(next);
+            ++next;
+        }
+    }
+};
+
+__global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
+    hufd_tables tb,
+    const hufd_dec_item *items,
+    const u32 *tiny_items,
+    u32 n_tiny,
+    const u8 *d_in,
+    u8 *d_out,
+    hufd_dec_item_state *states,
+    hufd_dec_result *results) {
+
+    u16 *lut = reinterpret_cast<u16 *>(dyn_lds);
+    for (u32 i = threadIdx.x; i < (1u << tb.lut_bits); i += kTinyDecThreads) {
+        lut[i] = tb.dec_lut[i];
+    }
+    __syncthreads();
+    const u32 t = blockIdx.x * kTinyDecThreads + threadIdx.x;
+    if (t >= n_tiny) {
+        return;
+    }
+    const u32 item = tiny_items[t];
+    const hufd_dec_item it = items[item];
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(d_in + it.in_off);
+    const u32 lead = (u32)(addr & 7);
+    stream_reader sr;
+    sr.start(addr - lead, lead + (u32)it.in_len, lead * 8 + it.first_bit);
+    u8 *out = d_out + it.out_off;
+    const u32 rem = (u32)it.in_len * 8;
+    u32 pos = it.first_bit, why = HUFD_STOP_NONE;
+    u64 n = 0, cap_bit = kNoBit;
+    for (;;) {
+        u32 sym = 0;
+        const u32 len = code_at(sr.peek(), lut, tb.lut_bits, pos, rem, &sym, &why);
+        if (!len) {
+            break;
+        }
+        if (n < it.out_cap) {
+            out[n] = (u8)sym;
+        } else if (n == it.out_cap) {
+            cap_bit = pos; /* source/huffman.c:257-268: this symbol is not consumed */
+        }
+        ++n;
+        sr.skip(len);
+        pos += len;
+    }
+    hufd_dec_result rs;
+    rs.total_symbols = n;
+    rs.stop_bit = pos;
+    rs.cap_bit = cap_bit;
+    rs.stop_kind = why;
+    rs.reserved = 0;
+    results[item] = rs;
+    states[item].total_symbols = n;
+}
+
 /* ------------------------------------------------------------------ decode: scan */
 
 /* chunk entry record: [7:0] entry state, [8] reached */
@@ -3321,7 +3440,7 @@ __global__ __launch_bounds__(256) void dec_scan_small_kernel(
         return;
     }
     const hufd_dec_item it = items[i];
-    if (it.n_chunks > HUFD_SCAN_SMALL_MAX) {
+    if (it.n_chunks > HUFD_SCAN_SMALL_MAX || it.tiny) {
         return;
     }
     u32 state = it.first_bit;
@@ -4801,6 +4920,12 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     hipLaunchKernelGGL(
         dec_scan_small_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, ns, a->chunk_fn,
         a->chunk_entry, a->chunk_base, a->states, a->results);
+    if (a->n_tiny) {
+        hipLaunchKernelGGL(
+            dec_tiny_kernel, dim3((a->n_tiny + kTinyDecThreads - 1) / kTinyDecThreads), dim3(kTinyDecThreads),
+            (1u << a->tables.lut_bits) * sizeof(u16), st, a->tables, a->items, a->tiny_items, a->n_tiny, (const u8 *)a->d_in,
+            (u8 *)a->d_out, a->states, a->results);
+    }
     if (a->n_large) {
         const uint32_t lds = scan_run_lds_bytes(ns);
         hipLaunchKernelGGL(

@@ -535,6 +535,7 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     hufs_free(p->d_chunk_item);
     hufs_free(p->d_tail);
     hufs_free(p->d_large);
+    hufs_free(p->d_tiny);
     hufs_free(p->d_runs);
     hufs_free(p->d_run_fn);
     hufs_free(p->d_run_entry);
@@ -556,6 +557,7 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     p->d_chunk_item = NULL;
     p->d_tail = NULL;
     p->d_large = NULL;
+    p->d_tiny = NULL;
     p->d_runs = NULL;
     p->d_run_fn = NULL;
     p->d_run_entry = NULL;
@@ -576,6 +578,18 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     p->cap_items = p->cap_chunks = p->cap_large = p->cap_runs = 0;
 }
 
+/* short items are one thread's work, without chunks */
+static bool dec_item_is_tiny(const struct aws_huffman_amd_decode_item *it) {
+    return it->in_len > 0 && it->in_len <= HUFD_DEC_TINY_BYTES;
+}
+
+static uint64_t dec_item_chunks(const struct aws_huffman_amd_decode_item *it) {
+    if (dec_item_is_tiny(it)) {
+        return 0;
+    }
+    return (it->in_len + HUFD_DEC_CHUNK_BYTES - 1) / HUFD_DEC_CHUNK_BYTES;
+}
+
 static int dec_plan_fill(
     struct aws_huffman_amd_decode_plan *p,
     const struct aws_huffman_amd_decode_item *items,
@@ -591,7 +605,7 @@ static int dec_plan_fill(
         if (items[i].first_bit > 7 || items[i].in_len > 0xFFFFFFFFull) {
             return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
         }
-        const uint64_t chunks = (items[i].in_len + HUFD_DEC_CHUNK_BYTES - 1) / HUFD_DEC_CHUNK_BYTES;
+        const uint64_t chunks = dec_item_chunks(&items[i]);
         n_chunks += chunks;
         n_large += chunks > HUFD_SCAN_SMALL_MAX;
         n_runs += chunks > HUFD_SCAN_SMALL_MAX ? (chunks + HUFD_SCAN_RUN_CHUNKS - 1) / HUFD_SCAN_RUN_CHUNKS : 0;
@@ -605,19 +619,21 @@ static int dec_plan_fill(
     uint32_t *h_large = malloc((n_large ? n_large : 1) * 2 * sizeof(uint32_t));
     uint32_t *h_runs = malloc((n_runs ? n_runs : 1) * 2 * sizeof(uint32_t));
     uint32_t *h_tail = malloc((n_items ? n_items : 1) * 2 * sizeof(uint32_t));
-    if (!h_items || !h_chunk_item || !h_large || !h_runs || !h_tail) {
+    uint32_t *h_tiny = malloc((n_items ? n_items : 1) * sizeof(uint32_t));
+    if (!h_items || !h_chunk_item || !h_large || !h_runs || !h_tail || !h_tiny) {
         free(h_tail);
+        free(h_tiny);
         free(h_runs);
         free(h_items);
         free(h_chunk_item);
         free(h_large);
         return aws_raise_error(AWS_ERROR_OOM);
     }
-    uint32_t chunk = 0, large = 0, run = 0, tail = 0;
+    uint32_t chunk = 0, large = 0, run = 0, tail = 0, tiny = 0;
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_decode_item *src = &items[i];
         struct hufd_dec_item *dst = &h_items[i];
-        const uint32_t chunks = (uint32_t)((src->in_len + HUFD_DEC_CHUNK_BYTES - 1) / HUFD_DEC_CHUNK_BYTES);
+        const uint32_t chunks = (uint32_t)dec_item_chunks(src);
         dst->in_off = src->in_offset;
         dst->in_len = src->in_len;
         dst->out_off = src->out_offset;
@@ -625,7 +641,10 @@ static int dec_plan_fill(
         dst->first_bit = src->first_bit;
         dst->first_chunk = chunk;
         dst->n_chunks = chunks;
-        dst->reserved = 0;
+        dst->tiny = dec_item_is_tiny(src) ? 1u : 0u;
+        if (dst->tiny) {
+            h_tiny[tiny++] = (uint32_t)i;
+        }
         for (uint32_t k = 0; k < chunks; ++k) {
             /* fewer than a chunk + 8 bytes left: the end of the stream is in (or just behind) this chunk */
             if (src->in_len - (uint64_t)k * HUFD_DEC_CHUNK_BYTES < (uint64_t)HUFD_DEC_CHUNK_BYTES + 8u) {
@@ -655,6 +674,7 @@ static int dec_plan_fill(
         p->d_items = hufs_malloc(ci * sizeof(struct hufd_dec_item));
         p->d_chunk_item = hufs_malloc(cc * sizeof(uint32_t));
         p->d_tail = hufs_malloc(ci * 2 * sizeof(uint32_t));
+        p->d_tiny = hufs_malloc(ci * sizeof(uint32_t));
         p->d_large = hufs_malloc(cl * 2 * sizeof(uint32_t));
         p->d_runs = hufs_malloc(cr * 2 * sizeof(uint32_t));
         p->d_run_fn = hufs_malloc(cr * ns * sizeof(uint32_t));
@@ -674,7 +694,7 @@ static int dec_plan_fill(
         p->d_states = hufs_malloc(ci * sizeof(struct hufd_dec_item_state));
         p->d_results = hufs_malloc(ci * sizeof(struct hufd_dec_result));
         if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_cp_tab || !p->d_chunk_fn || !p->d_slow_list || !p->d_chunk_entry ||
-            !p->d_tail || !p->d_dense_list || !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_tail_entry || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
+            !p->d_tail || !p->d_tiny || !p->d_dense_list || !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_tail_entry || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
             !p->d_chunk_base || !p->d_states || !p->d_results) {
             err = 2;
         }
@@ -691,6 +711,9 @@ static int dec_plan_fill(
     }
     if (!err) {
         err = hufs_copy_h2d(p->d_tail, h_tail, tail * sizeof(uint32_t), eng->stream);
+    }
+    if (!err) {
+        err = hufs_copy_h2d(p->d_tiny, h_tiny, tiny * sizeof(uint32_t), eng->stream);
     }
     if (!err) {
         err = hufs_copy_h2d(p->d_chunk_item, h_chunk_item, n_chunks * sizeof(uint32_t), eng->stream);
@@ -716,6 +739,7 @@ static int dec_plan_fill(
     free(h_large);
     free(h_runs);
     free(h_tail);
+    free(h_tiny);
     if (err) {
         return raise_hip(err);
     }
@@ -724,6 +748,7 @@ static int dec_plan_fill(
     p->n_large = (uint32_t)n_large;
     p->n_runs = (uint32_t)n_runs;
     p->n_tail = tail;
+    p->n_tiny = tiny;
     return AWS_OP_SUCCESS;
 }
 
@@ -780,6 +805,8 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.n_chunks = p->n_chunks;
     a.tail_chunks = p->d_tail;
     a.n_tail = p->n_tail;
+    a.tiny_items = p->d_tiny;
+    a.n_tiny = p->n_tiny;
     a.large_items = p->d_large;
     a.n_large = p->n_large;
     a.runs = p->d_runs;

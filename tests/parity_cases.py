@@ -659,6 +659,77 @@ def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False):
         eng.close()
 
 
+def tiny_decode_items(w, n_items=1500, seed=41, engine=None):
+    """Streams either side of HUFD_DEC_TINY_BYTES (512 bytes; one thread each below it): whole encodings, cut
+    ones, arbitrary bytes, starting inside their first byte, with room for all, some or none of their symbols."""
+    rng = np.random.default_rng(seed)
+    eng = engine or harness.Engine(w.product.lib, w.pcoder)
+    streams = []
+    for i in range(n_items):
+        kind = i % 5
+        if kind == 4:
+            enc = rng.integers(0, 256, int(rng.integers(1, 540)), dtype=np.uint8)
+        else:
+            n = [0, 1, 2, 409, 410, 420][i // 5] if i < 30 else int(rng.integers(0, 460))
+            enc = oracle_encode(w, inputs(rng, n, KINDS[i % 3]), eos=[None, 0x00, 0x5A][i % 3])
+            if kind == 3 and enc.size:
+                enc = enc[:int(rng.integers(0, enc.size + 1))]
+        streams.append(enc)
+    offs, pos = [], 1
+    for e in streams:
+        offs.append(pos)
+        pos += e.size + int(rng.integers(0, 4))
+    enc_total = pos + 64
+    host_enc = np.zeros(enc_total, np.uint8)
+    for e, o in zip(streams, offs):
+        host_enc[o:o + e.size] = e
+    items, expect, pos = [], [], 5
+    for i, e in enumerate(streams):
+        fb = int(rng.integers(0, 8)) if (i % 4 == 2 and e.size) else 0
+        # the oracle's view: the rest of the first byte is what a previous call left in the decoder
+        d = w.oracle.new_decoder(w.ocoder)
+        start = 0
+        if fb:
+            d.working_bits = (int(e[0]) & (0xFF >> fb)) << (56 + fb)
+            d.num_bits = 8 - fb
+            start = 1
+        probe = np.zeros(e.size * 2 + 8, np.uint8)
+        r_all = w.oracle.decode_call(d, e, start, e.size, probe, 0, probe.size)
+        n = r_all.produced
+        cap = [n, n + 3, max(n - 1, 0), n // 3, 0][int(rng.integers(0, 5))]
+        d = w.oracle.new_decoder(w.ocoder)
+        if fb:
+            d.working_bits = (int(e[0]) & (0xFF >> fb)) << (56 + fb)
+            d.num_bits = 8 - fb
+        dst = np.full(cap + 1, SENTINEL, np.uint8)
+        r = w.oracle.decode_call(d, e, start, e.size, dst, 0, cap)
+        bits = (8 - fb if fb else 0) + r.consumed * 8 - r.state[0]
+        expect.append(((r.rc, r.err, r.produced, bits), dst[:cap].copy()))
+        items.append(dict(in_offset=offs[i], in_len=e.size, first_bit=fb, out_offset=pos, out_capacity=cap))
+        pos += cap + int(rng.integers(1, 9))
+    sym_total = pos + 64
+    d_enc, d_sym = eng.alloc(enc_total), eng.alloc(sym_total)
+    eng.upload(d_enc, host_enc)
+    eng.fill(d_sym, SENTINEL, sym_total)
+    plan = eng.decode_plan(items)
+    eng.decode_launch(plan, d_enc, d_sym)
+    res = eng.decode_results(plan, len(items))
+    got = eng.download(d_sym, sym_total)
+    want = np.full(sym_total, SENTINEL, np.uint8)
+    kinds = set()
+    for i, (it, (key, sym)) in enumerate(zip(items, expect)):
+        want[it["out_offset"]:it["out_offset"] + it["out_capacity"]] = sym
+        assert res[i] == key, (i, it, res[i], key)
+        kinds.add(key[:2])
+    assert np.array_equal(got, want), "tiny items: wrong symbols, or bytes outside an item"
+    assert len(kinds) >= 3
+    eng.lib.aws_huffman_amd_decode_plan_destroy(plan)
+    eng.free(d_enc)
+    eng.free(d_sym)
+    if engine is None:
+        eng.close()
+
+
 def first_bit_offsets(w, engine=None):
     """Decode items that start inside their first byte (what a carried decoder state turns into)."""
     rng = np.random.default_rng(19)

@@ -70,6 +70,10 @@ def test_tiny_encode_items(world):
     pc.tiny_encode_items(world, n_items=400, seed=38, holes=True)
 
 
+def test_tiny_decode_items(world):
+    pc.tiny_decode_items(world, n_items=400)
+
+
 def test_first_bit_offsets(world):
     pc.first_bit_offsets(world)
 

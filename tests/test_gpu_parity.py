@@ -93,6 +93,10 @@ def test_tiny_encode_items(world, engine):
     pc.tiny_encode_items(world, seed=38, holes=True)
 
 
+def test_tiny_decode_items(world, engine):
+    pc.tiny_decode_items(world, engine=engine)
+
+
 def test_first_bit_offsets(world, engine):
     pc.first_bit_offsets(world, engine=engine)
 
