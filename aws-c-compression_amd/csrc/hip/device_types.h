@@ -28,6 +28,11 @@
 #define HUFD_DEC_MAX_STATES 16u
 #define HUFD_DEC_CP_ROWS 4u /* per sub-chunk: three checkpoints of the walk + the merged-state mask */
 #define HUFD_DEC_MAX_LUT_BITS 12u
+/* coders with longer codes (HPACK: 30 bits) decode through a tree of tables, one thread per item */
+#define HUFD_DEEP_ROOT_BITS 10u
+#define HUFD_DEEP_SUB_BITS 8u
+#define HUFD_DEEP_MAX_ENTRIES 16384u
+#define HUFD_DEEP_LINK 0x80000000u /* entry is a link: [15:0] first entry of the next table, [23:16] its index width */
 #define HUFD_DEC_TINY_BYTES 512u /* decode items up to this long are one thread's work (dec_tiny): no chunks */
 #define HUFD_DEC_STAGE_BYTES 34304u /* LDS bytes for a chunk's decoded symbols (dec_emit_fast: four workgroups per CU) */
 
@@ -58,7 +63,9 @@ struct hufd_tables {
     uint32_t lut_bits;
     uint32_t n_states; /* max(max_bits, 8) */
     uint32_t all_coded; /* every one of the 256 symbols has a code */
-    uint32_t reserved;
+    uint32_t deep_entries; /* != 0: codes longer than HUFD_DEC_MAX_LUT_BITS, decode walks deep_lut instead of dec_lut */
+    const uint32_t *deep_lut; /* [deep_entries] root table of 1 << HUFD_DEEP_ROOT_BITS entries, then the linked ones;
+                               * an entry is symbol << 8 | length, 0 = no code, or a link */
 };
 
 struct hufd_enc_item {

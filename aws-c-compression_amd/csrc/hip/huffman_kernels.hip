@@ -3292,18 +3292,18 @@ constexpr u32 kTinyDecThreads = 128;
 
 struct stream_reader {
     uintptr_t base; /* 8-byte aligned address at or in front of the item's first byte */
-    u32 end;        /* bytes from base to the end of the item: bytes behind it read as zero */
+    u64 end;        /* bytes from base to the end of the item: bytes behind it read as zero */
     u64 cur;        /* aligned word cur_index, big endian */
     u32 cur_index;
     u64 win;
     u32 nb, next, ahead;
 
     __device__ __forceinline__ u64 word64(u32 i) const {
-        if (i * 8 >= end) {
+        if ((u64)i * 8 >= end) {
             return 0;
         }
         u64 v = __builtin_bswap64(*reinterpret_cast<const u64 *>(base + (uintptr_t)i * 8));
-        const u32 keep = end - i * 8;
+        const u64 keep = end - (u64)i * 8;
         if (keep < 8) {
             v &= ~0ull << (8 * (8 - keep));
         }
@@ -3317,7 +3317,7 @@ struct stream_reader {
         return (i & 1) ? (u32)cur : (u32)(cur >> 32);
     }
     /* pos: bits from base */
-    __device__ __forceinline__ void start(uintptr_t b, u32 end_bytes, u32 pos) {
+    __device__ __forceinline__ void start(uintptr_t b, u64 end_bytes, u32 pos) {
         base = b;
         end = end_bytes;
         cur_index = ~0u;
@@ -3344,6 +3344,18 @@ struct stream_reader {
     }
 };
 
+/* the entry (symbol << 8 | length, 0 = no code) for a window, out of the linked tables of a coder with long codes */
+__device__ __forceinline__ u32 deep_entry(const u32 *deep, u32 window) {
+    u32 e = deep[window >> (32 - HUFD_DEEP_ROOT_BITS)], used = HUFD_DEEP_ROOT_BITS;
+    while (e & HUFD_DEEP_LINK) {
+        const u32 width = (e >> 16) & 0xFFu;
+        e = deep[(e & 0xFFFFu) + ((window << used) >> (32 - width))];
+        used += width;
+    }
+    return e;
+}
+
+template <bool DEEP> /* codes of more than HUFD_DEC_MAX_LUT_BITS bits: linked tables, and items of any size */
 __global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
     hufd_tables tb,
     const hufd_dec_item *items,
@@ -3355,8 +3367,15 @@ __global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
     hufd_dec_result *results) {
 
     u16 *lut = reinterpret_cast<u16 *>(dyn_lds);
-    for (u32 i = threadIdx.x; i < (1u << tb.lut_bits); i += kTinyDecThreads) {
-        lut[i] = tb.dec_lut[i];
+    u32 *deep = reinterpret_cast<u32 *>(dyn_lds);
+    if (DEEP) {
+        for (u32 i = threadIdx.x; i < tb.deep_entries; i += kTinyDecThreads) {
+            deep[i] = tb.deep_lut[i];
+        }
+    } else {
+        for (u32 i = threadIdx.x; i < (1u << tb.lut_bits); i += kTinyDecThreads) {
+            lut[i] = tb.dec_lut[i];
+        }
     }
     __syncthreads();
     const u32 t = blockIdx.x * kTinyDecThreads + threadIdx.x;
@@ -3368,19 +3387,31 @@ __global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
     const uintptr_t addr = reinterpret_cast<uintptr_t>(d_in + it.in_off);
     const u32 lead = (u32)(addr & 7);
     stream_reader sr;
-    sr.start(addr - lead, lead + (u32)it.in_len, lead * 8 + it.first_bit);
+    sr.start(addr - lead, lead + it.in_len, lead * 8 + it.first_bit);
     u8 *out = d_out + it.out_off;
-    const u32 rem = (u32)it.in_len * 8;
-    u32 pos = it.first_bit, why = HUFD_STOP_NONE;
+    const u64 rem = it.in_len * 8;
+    u64 pos = it.first_bit;
+    u32 why = HUFD_STOP_NONE;
     u64 n = 0, cap_bit = kNoBit;
     for (;;) {
-        u32 sym = 0;
-        const u32 len = code_at(sr.peek(), lut, tb.lut_bits, pos, rem, &sym, &why);
-        if (!len) {
+        /* one symbol of source/huffman.c:232-255 */
+        if (pos >= rem) {
+            why = HUFD_STOP_END;
+            break;
+        }
+        const u32 window = sr.peek();
+        const u32 entry = DEEP ? deep_entry(deep, window) : lut[window >> (32 - tb.lut_bits)];
+        const u32 len = entry & 0xFFu;
+        if (len == 0) {
+            why = HUFD_STOP_INVALID;
+            break;
+        }
+        if (pos + len > rem) {
+            why = HUFD_STOP_INCOMPLETE;
             break;
         }
         if (n < it.out_cap) {
-            out[n] = (u8)sym;
+            out[n] = (u8)(entry >> 8);
         } else if (n == it.out_cap) {
             cap_bit = pos; /* source/huffman.c:257-268: this symbol is not consumed */
         }
@@ -4920,9 +4951,14 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     hipLaunchKernelGGL(
         dec_scan_small_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, ns, a->chunk_fn,
         a->chunk_entry, a->chunk_base, a->states, a->results);
-    if (a->n_tiny) {
+    if (a->n_tiny && a->tables.deep_entries) {
         hipLaunchKernelGGL(
-            dec_tiny_kernel, dim3((a->n_tiny + kTinyDecThreads - 1) / kTinyDecThreads), dim3(kTinyDecThreads),
+            dec_tiny_kernel<true>, dim3((a->n_tiny + kTinyDecThreads - 1) / kTinyDecThreads), dim3(kTinyDecThreads),
+            a->tables.deep_entries * sizeof(u32), st, a->tables, a->items, a->tiny_items, a->n_tiny, (const u8 *)a->d_in,
+            (u8 *)a->d_out, a->states, a->results);
+    } else if (a->n_tiny) {
+        hipLaunchKernelGGL(
+            dec_tiny_kernel<false>, dim3((a->n_tiny + kTinyDecThreads - 1) / kTinyDecThreads), dim3(kTinyDecThreads),
             (1u << a->tables.lut_bits) * sizeof(u16), st, a->tables, a->items, a->tiny_items, a->n_tiny, (const u8 *)a->d_in,
             (u8 *)a->d_out, a->states, a->results);
     }

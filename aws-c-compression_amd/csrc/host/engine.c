@@ -38,6 +38,83 @@ static void *device_upload(const void *host, size_t size, void *stream, int *err
 
 static int s_kernels_ready;
 
+/*
+ * Decode tables for a coder with codes of more than HUFD_DEC_MAX_LUT_BITS bits: a root table indexed by the
+ * first HUFD_DEEP_ROOT_BITS bits of the window, whose entries either answer (symbol, length / no code) or
+ * link to a table indexed by the next few bits, and so on down to bit 32.  Filled by asking the decode
+ * callback (reference huffman.h:48) about every index with the bits below it all zero and all one: the same
+ * answer, no longer than the bits looked at, is an entry; anything else depends on later bits and gets a
+ * table of its own.  Every code of the encode table must then come back out of the tables.
+ */
+struct deep_builder {
+    struct aws_huffman_symbol_coder *coder;
+    uint32_t *tab;
+    uint32_t used;
+    bool ok;
+};
+
+static void deep_table_fill(struct deep_builder *b, uint32_t base, uint32_t prefix, uint32_t depth, uint32_t width) {
+    const uint32_t low = 32 - depth - width; /* window bits below this table's index */
+    const uint32_t fill = low ? (uint32_t)((1ull << low) - 1) : 0;
+    for (uint32_t w = 0; w < (1u << width) && b->ok; ++w) {
+        const uint32_t bits = prefix | (uint32_t)((uint64_t)w << low);
+        uint8_t s0 = 0, s1 = 0;
+        const uint8_t n0 = b->coder->decode(bits, &s0, b->coder->userdata);
+        const uint8_t n1 = b->coder->decode(bits | fill, &s1, b->coder->userdata);
+        if (n0 == n1 && n0 <= depth + width && (n0 == 0 || s0 == s1)) {
+            b->tab[base + w] = n0 ? ((uint32_t)s0 << 8) | n0 : 0;
+        } else if (low == 0) {
+            b->ok = false; /* an answer longer than the window */
+        } else {
+            const uint32_t sub = low < HUFD_DEEP_SUB_BITS ? low : HUFD_DEEP_SUB_BITS;
+            if (b->used + (1u << sub) > HUFD_DEEP_MAX_ENTRIES) {
+                b->ok = false;
+                return;
+            }
+            const uint32_t at = b->used;
+            b->used += 1u << sub;
+            b->tab[base + w] = HUFD_DEEP_LINK | (sub << 16) | at;
+            deep_table_fill(b, at, bits, depth + width, sub);
+        }
+    }
+}
+
+static uint32_t deep_table_lookup(const uint32_t *tab, uint32_t window) {
+    uint32_t e = tab[window >> (32 - HUFD_DEEP_ROOT_BITS)], used = HUFD_DEEP_ROOT_BITS;
+    while (e & HUFD_DEEP_LINK) {
+        const uint32_t width = (e >> 16) & 0xFFu;
+        e = tab[(e & 0xFFFFu) + ((window << used) >> (32 - width))];
+        used += width;
+    }
+    return e;
+}
+
+static int deep_table_build(struct aws_huffman_amd_engine *eng, struct aws_huffman_symbol_coder *coder) {
+    struct deep_builder b = {coder, malloc(HUFD_DEEP_MAX_ENTRIES * sizeof(uint32_t)), 1u << HUFD_DEEP_ROOT_BITS, true};
+    if (!b.tab) {
+        return aws_raise_error(AWS_ERROR_OOM);
+    }
+    deep_table_fill(&b, 0, 0, 0, HUFD_DEEP_ROOT_BITS);
+    for (int sym = 0; sym < 256 && b.ok; ++sym) {
+        const uint32_t len = (uint32_t)(eng->enc_table[sym] >> 32);
+        if (len) {
+            const uint32_t code = (uint32_t)eng->enc_table[sym] << (32 - len);
+            const uint32_t fill = len < 32 ? (1u << (32 - len)) - 1u : 0u;
+            const uint32_t want = ((uint32_t)sym << 8) | len;
+            b.ok = deep_table_lookup(b.tab, code) == want && deep_table_lookup(b.tab, code | fill) == want;
+        }
+    }
+    if (!b.ok) {
+        free(b.tab); /* not a table-shaped decoder: decode stays unavailable */
+        return AWS_OP_SUCCESS;
+    }
+    eng->deep_lut_host = b.tab;
+    eng->tables.deep_entries = b.used;
+    eng->tables.lut_bits = 0;
+    eng->can_decode = true;
+    return AWS_OP_SUCCESS;
+}
+
 int aws_huffman_amd_engine_new(
     struct aws_huffman_amd_engine **out_engine,
     struct aws_huffman_symbol_coder *coder,
@@ -142,11 +219,22 @@ int aws_huffman_amd_engine_new(
         }
     }
 
+    if (!eng->can_decode && coder->decode && max_bits > HUFD_DEC_MAX_LUT_BITS) {
+        if (deep_table_build(eng, coder)) {
+            free(eng);
+            return AWS_OP_ERR;
+        }
+    }
+
     int err = hufs_stream_create(&eng->stream);
+    if (!err && eng->deep_lut_host) {
+        eng->d_deep_lut =
+            device_upload(eng->deep_lut_host, (size_t)eng->tables.deep_entries * sizeof(uint32_t), eng->stream, &err);
+    }
     if (!err) {
         eng->d_enc_table = device_upload(eng->enc_table, sizeof(eng->enc_table), eng->stream, &err);
     }
-    if (!err && eng->can_decode) {
+    if (!err && eng->dec_lut_host) {
         eng->d_dec_lut =
             device_upload(eng->dec_lut_host, (size_t)sizeof(uint16_t) << eng->tables.lut_bits, eng->stream, &err);
     }
@@ -156,6 +244,7 @@ int aws_huffman_amd_engine_new(
     }
     eng->tables.enc_table = eng->d_enc_table;
     eng->tables.dec_lut = eng->d_dec_lut;
+    eng->tables.deep_lut = eng->d_deep_lut;
     *out_engine = eng;
     return AWS_OP_SUCCESS;
 }
@@ -175,8 +264,10 @@ void aws_huffman_amd_engine_destroy(struct aws_huffman_amd_engine *eng) {
     hufs_free(eng->one_out);
     hufs_free(eng->d_enc_table);
     hufs_free(eng->d_dec_lut);
+    hufs_free(eng->d_deep_lut);
     hufs_stream_destroy(eng->stream);
     free(eng->dec_lut_host);
+    free(eng->deep_lut_host);
     free(eng);
 }
 
@@ -579,12 +670,13 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
 }
 
 /* short items are one thread's work, without chunks */
-static bool dec_item_is_tiny(const struct aws_huffman_amd_decode_item *it) {
-    return it->in_len > 0 && it->in_len <= HUFD_DEC_TINY_BYTES;
+static bool dec_item_is_tiny(const struct aws_huffman_amd_engine *eng, const struct aws_huffman_amd_decode_item *it) {
+    /* (with codes too long for the chunked decoder's tables, every item goes that way) */
+    return it->in_len > 0 && (it->in_len <= HUFD_DEC_TINY_BYTES || eng->tables.deep_entries);
 }
 
-static uint64_t dec_item_chunks(const struct aws_huffman_amd_decode_item *it) {
-    if (dec_item_is_tiny(it)) {
+static uint64_t dec_item_chunks(const struct aws_huffman_amd_engine *eng, const struct aws_huffman_amd_decode_item *it) {
+    if (dec_item_is_tiny(eng, it)) {
         return 0;
     }
     return (it->in_len + HUFD_DEC_CHUNK_BYTES - 1) / HUFD_DEC_CHUNK_BYTES;
@@ -605,7 +697,7 @@ static int dec_plan_fill(
         if (items[i].first_bit > 7 || items[i].in_len > 0xFFFFFFFFull) {
             return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
         }
-        const uint64_t chunks = dec_item_chunks(&items[i]);
+        const uint64_t chunks = dec_item_chunks(eng, &items[i]);
         n_chunks += chunks;
         n_large += chunks > HUFD_SCAN_SMALL_MAX;
         n_runs += chunks > HUFD_SCAN_SMALL_MAX ? (chunks + HUFD_SCAN_RUN_CHUNKS - 1) / HUFD_SCAN_RUN_CHUNKS : 0;
@@ -633,7 +725,7 @@ static int dec_plan_fill(
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_decode_item *src = &items[i];
         struct hufd_dec_item *dst = &h_items[i];
-        const uint32_t chunks = (uint32_t)dec_item_chunks(src);
+        const uint32_t chunks = (uint32_t)dec_item_chunks(eng, src);
         dst->in_off = src->in_offset;
         dst->in_len = src->in_len;
         dst->out_off = src->out_offset;
@@ -641,7 +733,7 @@ static int dec_plan_fill(
         dst->first_bit = src->first_bit;
         dst->first_chunk = chunk;
         dst->n_chunks = chunks;
-        dst->tiny = dec_item_is_tiny(src) ? 1u : 0u;
+        dst->tiny = dec_item_is_tiny(eng, src) ? 1u : 0u;
         if (dst->tiny) {
             h_tiny[tiny++] = (uint32_t)i;
         }

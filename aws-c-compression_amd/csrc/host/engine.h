@@ -19,6 +19,8 @@ struct aws_huffman_amd_engine {
 
     uint64_t enc_table[256]; /* host copy: length << 32 | masked code */
     uint16_t *dec_lut_host;
+    uint32_t *deep_lut_host; /* codes longer than HUFD_DEC_MAX_LUT_BITS */
+    void *d_deep_lut;
     bool can_decode;
 
     void *d_enc_table;

@@ -72,6 +72,7 @@ def test_tiny_encode_items(world):
 
 def test_tiny_decode_items(world):
     pc.tiny_decode_items(world, n_items=400)
+    pc.tiny_decode_items(world, n_items=400, seed=42, profile="hpack_lengths")
 
 
 def test_first_bit_offsets(world):

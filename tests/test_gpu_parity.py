@@ -95,6 +95,7 @@ def test_tiny_encode_items(world, engine):
 
 def test_tiny_decode_items(world, engine):
     pc.tiny_decode_items(world, engine=engine)
+    pc.tiny_decode_items(world, seed=42, profile="hpack_lengths")
 
 
 def test_first_bit_offsets(world, engine):
