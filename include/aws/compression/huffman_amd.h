@@ -68,12 +68,14 @@ struct aws_huffman_amd_decode_result {
 };
 
 /*
- * Tabulates `coder` (256 encode calls, 2^max_len decode calls, cross-checked for
- * purity) and stages the tables on HIP device `device` (-1 = current device).
- * Raises AWS_ERROR_UNSUPPORTED_OPERATION when the coder cannot be tabulated
- * (a decode callback that disagrees with its encode callback, or codes longer
- * than the device decode table covers: 12 bits in this release; encode-only
- * engines accept 32).  There is no CPU path to fall back to.
+ * Tabulates `coder` (256 encode calls; decode calls for every index of the
+ * decode tables with zero and one fill, cross-checked against the encode
+ * table) and stages the tables on HIP device `device` (-1 = current device).
+ * Codes of up to 32 bits either way; up to 12 bits decode through the chunked
+ * kernels, longer ones one thread per item.  A decode callback that is not
+ * table-shaped leaves the engine encode-only
+ * (aws_huffman_amd_engine_can_decode() == false; decode entry points raise
+ * AWS_ERROR_UNSUPPORTED_OPERATION).  There is no CPU path to fall back to.
  */
 AWS_COMPRESSION_API
 int aws_huffman_amd_engine_new(
