@@ -572,6 +572,22 @@ int aws_huffman_amd_encode_plan_raw_results(
     return err ? raise_hip(err) : AWS_OP_SUCCESS;
 }
 
+int aws_huffman_amd_encode_plan_encoded_lengths(struct aws_huffman_amd_encode_plan *p, uint64_t *lengths, void *stream) {
+    struct hufd_enc_result *raw = malloc((p->n_items ? p->n_items : 1) * sizeof(*raw));
+    if (!raw) {
+        return aws_raise_error(AWS_ERROR_OOM);
+    }
+    if (aws_huffman_amd_encode_plan_raw_results(p, raw, stream)) {
+        free(raw);
+        return AWS_OP_ERR;
+    }
+    for (uint32_t i = 0; i < p->n_items; ++i) {
+        lengths[i] = (raw[i].total_bits + 7) / 8; /* source/huffman.c:121-128 */
+    }
+    free(raw);
+    return AWS_OP_SUCCESS;
+}
+
 void aws_huffman_amd_encode_result_from_raw(
     const struct hufd_enc_result *raw,
     struct aws_huffman_amd_encode_result *out) {

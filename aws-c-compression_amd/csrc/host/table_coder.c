@@ -105,6 +105,139 @@ struct aws_huffman_symbol_coder *aws_huffman_amd_table_coder_new(
     return &tc->coder;
 }
 
+/* ------------------------------------------------------------------ a coder from the text of a table .def file */
+
+/* skips blanks, comments and preprocessor lines; returns the position of the next token or `end` */
+static const char *def_skip(const char *at, const char *end, bool *line_start) {
+    while (at < end) {
+        if (*at == '\n') {
+            *line_start = true;
+            ++at;
+        } else if (*at == ' ' || *at == '\t' || *at == '\r') {
+            ++at;
+        } else if (*line_start && *at == '#') {
+            while (at < end && *at != '\n') {
+                ++at;
+            }
+        } else if (at + 1 < end && at[0] == '/' && at[1] == '*') {
+            at += 2;
+            while (at + 1 < end && !(at[0] == '*' && at[1] == '/')) {
+                ++at;
+            }
+            at = at + 1 < end ? at + 2 : end;
+        } else if (at + 1 < end && at[0] == '/' && at[1] == '/') {
+            while (at < end && *at != '\n') {
+                ++at;
+            }
+        } else {
+            break;
+        }
+    }
+    return at;
+}
+
+/* one unsigned number, decimal or 0x-hex (`hex`: hex even without the prefix, as the reference reads patterns) */
+static bool def_number(const char **at, const char *end, bool hex, uint64_t *out) {
+    const char *p = *at;
+    uint64_t v = 0;
+    int digits = 0;
+    if (p + 1 < end && p[0] == '0' && (p[1] == 'x' || p[1] == 'X')) {
+        hex = true;
+        p += 2;
+    }
+    for (; p < end; ++p, ++digits) {
+        int d;
+        if (*p >= '0' && *p <= '9') {
+            d = *p - '0';
+        } else if (hex && *p >= 'a' && *p <= 'f') {
+            d = *p - 'a' + 10;
+        } else if (hex && *p >= 'A' && *p <= 'F') {
+            d = *p - 'A' + 10;
+        } else {
+            break;
+        }
+        v = v * (hex ? 16u : 10u) + (uint64_t)d;
+        if (v > 0xFFFFFFFFull) {
+            return false;
+        }
+    }
+    *at = p;
+    *out = v;
+    return digits > 0;
+}
+
+static bool def_expect(const char **at, const char *end, char c, bool *line_start) {
+    *at = def_skip(*at, end, line_start);
+    if (*at < end && **at == c) {
+        ++*at;
+        *line_start = false;
+        return true;
+    }
+    return false;
+}
+
+struct aws_huffman_symbol_coder *aws_huffman_amd_table_coder_from_def(const char *text, size_t length) {
+    static const char keyword[] = "HUFFMAN_CODE";
+    const size_t keyword_len = sizeof(keyword) - 1;
+    uint32_t patterns[256];
+    uint8_t num_bits[256];
+    bool seen[256];
+    memset(patterns, 0, sizeof(patterns));
+    memset(num_bits, 0, sizeof(num_bits));
+    memset(seen, 0, sizeof(seen));
+
+    const char *at = text, *end = text + length;
+    bool line_start = true;
+    size_t rows = 0;
+    for (;;) {
+        at = def_skip(at, end, &line_start);
+        if (at >= end) {
+            break;
+        }
+        if ((size_t)(end - at) < keyword_len || memcmp(at, keyword, keyword_len) != 0) {
+            ++at; /* not a row: the #ifndef guard's body, stray text */
+            line_start = false;
+            continue;
+        }
+        at += keyword_len;
+        line_start = false;
+        uint64_t symbol = 0, pattern = 0, bits = 0;
+        bool ok = def_expect(&at, end, '(', &line_start);
+        at = def_skip(at, end, &line_start);
+        ok = ok && def_number(&at, end, false, &symbol) && def_expect(&at, end, ',', &line_start);
+        /* the bit string is for the reader: the pattern and the length are what counts (reference generator.c:84-85) */
+        ok = ok && def_expect(&at, end, '"', &line_start);
+        while (ok && at < end && *at != '"') {
+            ++at;
+        }
+        ok = ok && def_expect(&at, end, '"', &line_start) && def_expect(&at, end, ',', &line_start);
+        at = def_skip(at, end, &line_start);
+        ok = ok && def_number(&at, end, true, &pattern) && def_expect(&at, end, ',', &line_start);
+        at = def_skip(at, end, &line_start);
+        ok = ok && def_number(&at, end, false, &bits) && def_expect(&at, end, ')', &line_start);
+        if (!ok || bits > 32) {
+            aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
+            return NULL;
+        }
+        if (symbol > 255) {
+            continue; /* HPACK's EOS (256) and the like: not a byte symbol, no row in the 256-entry coder */
+        }
+        if (seen[symbol]) {
+            aws_raise_error(AWS_ERROR_INVALID_ARGUMENT); /* "Symbol already found!" (generator.c:78) */
+            return NULL;
+        }
+        seen[symbol] = true;
+        patterns[symbol] = (uint32_t)pattern;
+        num_bits[symbol] = (uint8_t)bits;
+        ++rows;
+    }
+    if (rows == 0) {
+        aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
+        return NULL;
+    }
+    return aws_huffman_amd_table_coder_new(patterns, num_bits);
+}
+
 void aws_huffman_amd_table_coder_destroy(struct aws_huffman_symbol_coder *coder) {
     if (coder) {
         free(coder->userdata);

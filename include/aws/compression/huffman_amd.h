@@ -140,6 +140,18 @@ int aws_huffman_amd_encode_plan_results(
     struct aws_huffman_amd_encode_result *results,
     void *stream);
 
+/*
+ * Capacity planning (aws_huffman_get_encoded_length, reference source/huffman.c:107-129,
+ * for every item of a plan): after a launch with length_only = true, lengths[i] = bytes item
+ * i appends when it has room for all of them -- ceil((carried overflow bits + code bits) / 8);
+ * symbols without a code count as 0 bits, as in the reference.
+ */
+AWS_COMPRESSION_API
+int aws_huffman_amd_encode_plan_encoded_lengths(
+    struct aws_huffman_amd_encode_plan *plan,
+    uint64_t *lengths,
+    void *stream);
+
 /* ---- batched decode ------------------------------------------------------ */
 
 AWS_COMPRESSION_API
@@ -220,6 +232,20 @@ AWS_COMPRESSION_API
 struct aws_huffman_symbol_coder *aws_huffman_amd_table_coder_new(
     const uint32_t patterns[256],
     const uint8_t num_bits[256]);
+
+/*
+ * The same from the text of a table .def file -- rows of
+ *     HUFFMAN_CODE(symbol, "bit string", 0xpattern, num_bits)
+ * between comments and preprocessor lines -- the input format of the reference's
+ * generator (source/huffman_generator/generator.c:42-104; e.g.
+ * tests/test_huffman_static_table.def, aws-c-http's HPACK table).  No C file is
+ * generated and compiled: the coder exists at once, and an engine tabulates it for
+ * the device.  Symbols missing from the file have no code; rows for symbols above
+ * 255 (HPACK's EOS) are skipped.  NULL + AWS_ERROR_INVALID_ARGUMENT for a malformed
+ * row, a symbol listed twice, or rows that are not a prefix code.
+ */
+AWS_COMPRESSION_API
+struct aws_huffman_symbol_coder *aws_huffman_amd_table_coder_from_def(const char *text, size_t length);
 
 AWS_COMPRESSION_API
 void aws_huffman_amd_table_coder_destroy(struct aws_huffman_symbol_coder *coder);

@@ -177,7 +177,10 @@ EXPORTED_SYMBOLS = [
     "aws_huffman_amd_device_fill_splitmix64", "aws_huffman_amd_engine_stream", "aws_huffman_amd_stream_synchronize",
     "aws_huffman_amd_event_new", "aws_huffman_amd_event_destroy", "aws_huffman_amd_event_record",
     "aws_huffman_amd_event_elapsed_ms", "aws_huffman_amd_table_coder_new", "aws_huffman_amd_table_coder_destroy",
+    "aws_huffman_amd_table_coder_from_def", "aws_huffman_amd_encode_plan_encoded_lengths",
 ]
+# include/aws/compression/private/huffman_testing.h (the reference's names: no aws_ prefix)
+TESTING_SYMBOLS = ["huffman_test_transitive", "huffman_test_transitive_chunked"]
 
 
 def load_product(path=None):
@@ -194,6 +197,11 @@ def load_product(path=None):
     V, P = C.c_void_p, C.POINTER
     _bind(lib, "aws_huffman_amd_table_coder_new", P(SymbolCoder), [P(C.c_uint32), P(C.c_uint8)])
     _bind(lib, "aws_huffman_amd_table_coder_destroy", None, [P(SymbolCoder)])
+    _bind(lib, "aws_huffman_amd_table_coder_from_def", P(SymbolCoder), [C.c_char_p, C.c_size_t])
+    _bind(lib, "aws_huffman_amd_encode_plan_encoded_lengths", C.c_int, [V, P(C.c_uint64), V])
+    _bind(lib, "huffman_test_transitive", C.c_int, [P(SymbolCoder), C.c_char_p, C.c_size_t, C.c_size_t, P(C.c_char_p)])
+    _bind(lib, "huffman_test_transitive_chunked", C.c_int,
+          [P(SymbolCoder), C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t, P(C.c_char_p)])
     _bind(lib, "aws_huffman_amd_engine_new", C.c_int, [P(V), P(SymbolCoder), C.c_int])
     _bind(lib, "aws_huffman_amd_engine_destroy", None, [V])
     _bind(lib, "aws_huffman_amd_engine_max_code_bits", C.c_uint32, [V])
@@ -304,6 +312,11 @@ class Engine:
         assert self.lib.aws_huffman_amd_encode_plan_results(plan, res, None) == 0
         return [(r.rc, r.error, r.consumed, r.produced, r.overflow_out.num_bits,
                  r.overflow_out.pattern if r.overflow_out.num_bits else 0) for r in res[:n]]
+
+    def encoded_lengths(self, plan, n):
+        out = (C.c_uint64 * max(n, 1))()
+        assert self.lib.aws_huffman_amd_encode_plan_encoded_lengths(plan, out, None) == 0
+        return list(out[:n])
 
     def decode_plan(self, items):
         arr = (AmdDecodeItem * max(len(items), 1))()

@@ -207,6 +207,32 @@ def streaming_encode(w, sizes, seed=12, coder_pair=None):
             assert off == n
 
 
+# ----------------------------------------------------------------------------- scenario: the reference's coder-testing helpers, exported by the product
+def transitive_helpers(w):
+    """include/aws/compression/private/huffman_testing.h on the product: tests/huffman_test.c:387-446 as the
+    reference runs them, plus a coder with HPACK's code lengths."""
+    import ctypes as C
+
+    lib = w.product.lib
+    msg = C.c_char_p()
+    k4 = VEC["K4_even_bytes"]
+    cases = [(bytes(K1_PLAIN), K1_ENC.size), (bytes.fromhex(k4["plain"]), k4["encoded_len"]), (bytes(K2_PLAIN), K2_ENC.size)]
+    for plain, enc_len in cases:
+        assert lib.huffman_test_transitive(w.pcoder, plain, len(plain), enc_len, C.byref(msg)) == 0, msg.value
+    for step in STEPS:
+        rc = lib.huffman_test_transitive_chunked(w.pcoder, bytes(K2_PLAIN), K2_PLAIN.size, K2_ENC.size, step, C.byref(msg))
+        assert rc == 0, (step, msg.value)
+    assert lib.huffman_test_transitive(w.pcoder, bytes(K1_PLAIN), 15, 13, C.byref(msg)) == -1
+    assert msg.value == b"encoded length is incorrect"
+    assert lib.huffman_test_transitive_chunked(w.pcoder, bytes(K1_PLAIN), 15, 11, 3, C.byref(msg)) == -1
+    assert msg.value == b"encoded length is incorrect"
+    # what a downstream user does with its own table: here HPACK's code lengths, printable text
+    _, hp, _ = profile_coders(w, "hpack_lengths")
+    text = bytes(inputs(np.random.default_rng(5), 700, "printable"))
+    assert lib.huffman_test_transitive(hp, text, len(text), 0, C.byref(msg)) == 0, msg.value
+    assert lib.huffman_test_transitive_chunked(hp, text[:90], 90, 0, 7, C.byref(msg)) == 0, msg.value
+
+
 # ----------------------------------------------------------------------------- scenario: streaming decode (input and output in pieces)
 def streaming_decode(w, sizes, seed=13):
     rng = np.random.default_rng(seed)
@@ -560,7 +586,7 @@ def batched_device_api(w, n_items=9, seed=18, item_len=16384, engine=None):
     # length-only launch: nothing written, totals reported
     eng.fill(d_out, SENTINEL, out_total)
     eng.encode_launch(plan, d_in, d_out, length_only=True)
-    eng.encode_results(plan, len(items))
+    assert eng.encoded_lengths(plan, len(items)) == [f.size for f in full]  # capacity planning: whatever the item's own capacity
     assert np.all(eng.download(d_out, out_total) == SENTINEL)
     eng.lib.aws_huffman_amd_encode_plan_destroy(plan)
 
@@ -669,6 +695,13 @@ def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False):
         kinds.add((r.rc, r.err))
     assert np.array_equal(got, want), "tiny items: wrong bytes, or bytes outside an item"
     assert len(kinds) >= (3 if holes else 2)
+    eng.encode_launch(plan, d_in, d_out, length_only=True)
+    lens_of = [int(w.table[1][b]) for b in range(256)]
+    if holes:
+        lens_of[7] = lens_of[200] = 0
+    want_lens = [(it["overflow_in"][1] + sum(lens_of[int(x)] for x in b) + 7) // 8 for b, it in zip(blobs, items)]
+    assert eng.encoded_lengths(plan, len(items)) == want_lens
+    assert np.array_equal(eng.download(d_out, out_total), want), "a length-only launch wrote something"
     eng.lib.aws_huffman_amd_encode_plan_destroy(plan)
     eng.free(d_in)
     eng.free(d_out)

@@ -57,6 +57,10 @@ def test_survey_records(world):
     pc.survey_records_on_product(world)
 
 
+def test_transitive_helpers(world):
+    pc.transitive_helpers(world)
+
+
 def test_foreign_coder_callbacks(world):
     pc.foreign_coder_callbacks(world)
 

@@ -80,6 +80,10 @@ def test_survey_records(world):
     pc.survey_records_on_product(world, names=("G4K", "G16K", "G16KP", "G1M"))
 
 
+def test_transitive_helpers(world):
+    pc.transitive_helpers(world)
+
+
 def test_foreign_coder_callbacks(world):
     pc.foreign_coder_callbacks(world)
 

@@ -38,6 +38,10 @@ def test_every_declared_symbol_is_exported(product_lib):
     exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
     missing = declared - exported
     assert not missing, "declared in include/ but not exported: %s" % sorted(missing)
+    # the reference's coder-testing helpers (include/aws/compression/private/huffman_testing.h) keep their names
+    text = open(os.path.join(harness.REPO, "include", "aws", "compression", "private", "huffman_testing.h")).read()
+    helpers = set(re.findall(r"AWS_COMPRESSION_API\s+int\s+(huffman_\w+)\s*\(", text))
+    assert helpers == set(harness.TESTING_SYMBOLS) and helpers <= exported
     # nothing from the oracle or the emulator leaks into the product
     assert not any(s.startswith("oracle_") or "hip_emu" in s for s in exported)
 
@@ -88,6 +92,44 @@ def test_table_coder_matches_the_reference_table(product_lib):
     bad_p = (C.c_uint32 * 256)(*patterns)
     bad_p[1], bad[1] = bad_p[0] >> 1, bad[0] - 1  # a prefix of symbol 0's code
     assert not product_lib.aws_huffman_amd_table_coder_new(bad_p, bad)
+
+
+def def_text(rows, extra=""):
+    """The text of a table .def file for these rows, laid out the way the reference's tables are."""
+    lines = ["/**", " * a table", " */", "", "#ifndef HUFFMAN_CODE", '#error "Macro HUFFMAN_CODE must be defined before including this header file!"',
+             "#endif", "", "/*           sym          bits   code len */"]
+    for sym, pattern, n in rows:
+        bits = format(pattern, "0%db" % n) if n else ""
+        lines.append('HUFFMAN_CODE(%3d, %20s, 0x%x, %d)' % (sym, '"%s"' % bits, pattern, n))
+    return ("\n".join(lines) + "\n" + extra).encode()
+
+
+def test_table_coder_from_def_text(product_lib):
+    """huffman_amd.h aws_huffman_amd_table_coder_from_def: the generator's input format (generator.c:42-104)."""
+    rows = [(r["symbol"], r["pattern"], r["num_bits"]) for r in harness.load_json("test_coder_table.json")["rows"]]
+    text = def_text(rows, extra="// HUFFMAN_CODE(1, \"0\", 0x0, 1) in a comment is not a row\nHUFFMAN_CODE(256, \"1\", 0x3fffffff, 30)\n")
+    coder = product_lib.aws_huffman_amd_table_coder_from_def(text, len(text))
+    assert coder
+    enc = harness.ENCODE_FN(coder.contents.encode)
+    dec = harness.DECODE_FN(coder.contents.decode)
+    sym = C.c_uint8()
+    for s_, pattern, n in rows:
+        code = enc(s_, coder.contents.userdata)
+        assert (code.pattern, code.num_bits) == (pattern, n)
+        assert dec(pattern << (32 - n), C.byref(sym), coder.contents.userdata) == n and sym.value == s_
+    product_lib.aws_huffman_amd_table_coder_destroy(coder)
+    # a symbol listed twice, a malformed row, no rows at all, not a prefix code
+    for bad in (def_text(rows + [rows[3]]), def_text(rows)[:-9], b"/* nothing */\n",
+                def_text([(0, 0b0, 1), (1, 0b01, 2)])):
+        product_lib.aws_reset_error()
+        assert not product_lib.aws_huffman_amd_table_coder_from_def(bad, len(bad))
+        assert product_lib.aws_last_error() == 34  # AWS_ERROR_INVALID_ARGUMENT
+    # symbols missing from the file have no code
+    some = def_text(rows[:100])
+    coder = product_lib.aws_huffman_amd_table_coder_from_def(some, len(some))
+    enc = harness.ENCODE_FN(coder.contents.encode)
+    assert enc(99, coder.contents.userdata).num_bits == rows[99][2] and enc(100, coder.contents.userdata).num_bits == 0
+    product_lib.aws_huffman_amd_table_coder_destroy(coder)
 
 
 def test_fails_loudly_without_a_gpu(product_lib):
