@@ -55,6 +55,8 @@ struct hufk_decode_args {
     uint32_t n_tail;
     const uint32_t *tiny_items;  /* [n_tiny] items of at most HUFD_DEC_TINY_BYTES encoded bytes: no chunks, one thread each */
     uint32_t n_tiny;
+    const uint32_t *deep_items;  /* [n_deep] longer items of a coder with codes of more than HUFD_DEC_MAX_LUT_BITS bits: no chunks, one workgroup each */
+    uint32_t n_deep;
     const uint32_t *large_items; /* per item with more than HUFD_SCAN_SMALL_MAX chunks: item index, its first run */
     uint32_t n_large;
     const uint32_t *runs;        /* per run of HUFD_SCAN_RUN_CHUNKS chunks of a large item: item index, run number */

@@ -3429,6 +3429,196 @@ __global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
     states[item].total_symbols = n;
 }
 
+/*
+ * Items of more than HUFD_DEC_TINY_BYTES encoded bytes of a coder with long codes: one WORKGROUP per item, the
+ * stream taken 32 KiB (256 lanes x 128 bytes) at a time.  The chunked decoder's transfer functions need a state
+ * per possible entry offset (up to 32 here); this road needs none: every lane walks its 128 bytes from a guessed
+ * entry (bit 0), then again from where the lane in front of it really leaves, until no lane's entry changes --
+ * walks from different entries fall into step within a few codes, so that is two or three rounds, and it is
+ * exact whatever the stream does, because lane 0's entry is the true one and every round settles at least one
+ * more lane.  A walk that stops (end of stream, no code, code cut off: source/huffman.c:232-255) leaves the lanes
+ * behind it unreached.  Then a scan of the lanes' symbol counts and one more walk that writes the symbols.
+ */
+constexpr u32 kDeepThreads = 256;
+constexpr u32 kDeepLaneBytes = 128;
+constexpr u32 kDeepLaneBits = kDeepLaneBytes * 8;
+constexpr u32 kDeepBlockBytes = kDeepThreads * kDeepLaneBytes;
+constexpr u32 kDeepStop = 0xFFu; /* a lane's exit: its walk stopped, or the lane is never reached */
+
+struct deep_shared {
+    u32 exit_of[kDeepThreads];
+    u32 scan[kDeepThreads];
+    u32 changed;
+    u32 stop_kind;
+    u64 stop_bit;
+    u64 cap_bit;
+};
+
+struct deep_walked {
+    u64 pos;   /* where the walk ended: the first code start at or behind `to`, or where it stopped */
+    u32 count; /* symbols whose codes start in [from, to) */
+    u32 why;   /* HUFD_STOP_NONE: reached `to` */
+};
+
+/* follows the codes from stream bit `from` to the first code start at or behind `to`; writes symbol number
+ * index + k to out[index + k] while that is below out_cap (out == NULL: count only) */
+__device__ __forceinline__ deep_walked deep_walk(
+    const u32 *deep, const u8 *in, u64 in_len, u64 from, u64 to, u8 *out, u64 index, u64 out_cap, u64 *cap_bit) {
+    const u64 rem = in_len * 8;
+    stream_reader sr = {};
+    if (from < rem) {
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(in) + (uintptr_t)(from >> 3);
+        const u32 lead = (u32)(addr & 7);
+        sr.start(addr - lead, lead + (in_len - (from >> 3)), lead * 8 + (u32)(from & 7));
+    }
+    deep_walked r;
+    r.pos = from;
+    r.count = 0;
+    r.why = HUFD_STOP_NONE;
+    while (r.pos < to) {
+        if (r.pos >= rem) {
+            r.why = HUFD_STOP_END;
+            break;
+        }
+        const u32 entry = deep_entry(deep, sr.peek());
+        const u32 len = entry & 0xFFu;
+        if (len == 0) {
+            r.why = HUFD_STOP_INVALID;
+            break;
+        }
+        if (r.pos + len > rem) {
+            r.why = HUFD_STOP_INCOMPLETE;
+            break;
+        }
+        if (out) {
+            const u64 k = index + r.count;
+            if (k < out_cap) {
+                out[k] = (u8)(entry >> 8);
+            } else if (k == out_cap) {
+                *cap_bit = r.pos; /* source/huffman.c:257-268: this symbol is not consumed */
+            }
+        }
+        ++r.count;
+        sr.skip(len);
+        r.pos += len;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(kDeepThreads) void dec_deep_kernel(
+    hufd_tables tb,
+    const hufd_dec_item *items,
+    const u32 *deep_items,
+    const u8 *d_in,
+    u8 *d_out,
+    hufd_dec_item_state *states,
+    hufd_dec_result *results) {
+
+    deep_shared &sh = *reinterpret_cast<deep_shared *>(dyn_lds);
+    u32 *deep = reinterpret_cast<u32 *>(dyn_lds + sizeof(deep_shared));
+    const u32 l = threadIdx.x;
+    for (u32 i = l; i < tb.deep_entries; i += kDeepThreads) {
+        deep[i] = tb.deep_lut[i];
+    }
+    if (l == 0) {
+        sh.stop_kind = HUFD_STOP_NONE;
+        sh.stop_bit = kNoBit;
+        sh.cap_bit = kNoBit;
+    }
+    __syncthreads();
+    const u32 item = deep_items[blockIdx.x];
+    const hufd_dec_item it = items[item];
+    const u8 *in = d_in + it.in_off;
+    u8 *out = d_out + it.out_off;
+    const u64 n_blocks = (it.in_len + kDeepBlockBytes - 1) / kDeepBlockBytes;
+    u64 symbols = 0; /* on the true path in front of this block */
+    u32 entry = it.first_bit;
+    for (u64 b = 0; b < n_blocks && entry != kDeepStop; ++b) {
+        const u64 block_bytes = it.in_len - b * kDeepBlockBytes < kDeepBlockBytes ? it.in_len - b * kDeepBlockBytes : kDeepBlockBytes;
+        const u32 n_lanes = (u32)((block_bytes + kDeepLaneBytes - 1) / kDeepLaneBytes);
+        const bool active = l < n_lanes;
+        const u64 lane_from = (b * kDeepBlockBytes + (u64)l * kDeepLaneBytes) * 8, lane_to = lane_from + kDeepLaneBits;
+        u32 start = l == 0 ? entry : 0u, my_exit = kDeepStop, my_count = 0;
+        bool reached = true, walk = active;
+        for (;;) {
+            if (walk) {
+                const deep_walked r = deep_walk(deep, in, it.in_len, lane_from + start, lane_to, nullptr, 0, 0, nullptr);
+                my_exit = r.why == HUFD_STOP_NONE ? (u32)(r.pos - lane_to) : kDeepStop;
+                my_count = r.count;
+            }
+            sh.exit_of[l] = active && reached ? my_exit : kDeepStop;
+            if (l == 0) {
+                sh.changed = 0;
+            }
+            __syncthreads();
+            walk = false;
+            if (active && l > 0) {
+                const u32 prev = sh.exit_of[l - 1];
+                if (prev == kDeepStop) {
+                    if (reached) {
+                        reached = false;
+                        sh.changed = 1;
+                    }
+                } else if (!reached || prev != start) {
+                    reached = true;
+                    start = prev;
+                    walk = true;
+                    sh.changed = 1;
+                }
+            }
+            __syncthreads();
+            const bool again = sh.changed != 0;
+            __syncthreads(); /* everyone has seen the flag and the exits before they are written again */
+            if (!again) {
+                break;
+            }
+        }
+        /* where each lane's symbols go: an exclusive scan of the counts of the lanes on the true path */
+        const u32 mine = active && reached ? my_count : 0u;
+        sh.scan[l] = mine;
+        __syncthreads();
+        for (u32 d = 1; d < kDeepThreads; d *= 2) {
+            const u32 add = l >= d ? sh.scan[l - d] : 0u;
+            __syncthreads();
+            sh.scan[l] += add;
+            __syncthreads();
+        }
+        const u32 before = sh.scan[l] - mine, block_symbols = sh.scan[kDeepThreads - 1];
+        const u32 last_exit = sh.exit_of[n_lanes - 1];
+        if (active && reached) {
+            u64 cap_bit = kNoBit;
+            const deep_walked r = deep_walk(deep, in, it.in_len, lane_from + start, lane_to, out, symbols + before, it.out_cap, &cap_bit);
+            if (cap_bit != kNoBit) {
+                sh.cap_bit = cap_bit;
+            }
+            if (r.why != HUFD_STOP_NONE) {
+                sh.stop_kind = r.why;
+                sh.stop_bit = r.pos;
+            }
+        }
+        __syncthreads(); /* exit_of and scan are free for the next block */
+        symbols += block_symbols;
+        entry = last_exit;
+    }
+    __syncthreads();
+    if (l == 0) {
+        hufd_dec_result rs;
+        rs.total_symbols = symbols;
+        rs.cap_bit = sh.cap_bit;
+        rs.reserved = 0;
+        if (sh.stop_kind != HUFD_STOP_NONE) {
+            rs.stop_kind = sh.stop_kind;
+            rs.stop_bit = sh.stop_bit;
+        } else {
+            /* the last code ended on the last bit of the stream */
+            rs.stop_kind = HUFD_STOP_END;
+            rs.stop_bit = it.in_len * 8;
+        }
+        results[item] = rs;
+        states[item].total_symbols = symbols;
+    }
+}
+
 /* ------------------------------------------------------------------ decode: scan */
 
 /* chunk entry record: [7:0] entry state, [8] reached */
@@ -4961,6 +5151,11 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             dec_tiny_kernel<false>, dim3((a->n_tiny + kTinyDecThreads - 1) / kTinyDecThreads), dim3(kTinyDecThreads),
             (1u << a->tables.lut_bits) * sizeof(u16), st, a->tables, a->items, a->tiny_items, a->n_tiny, (const u8 *)a->d_in,
             (u8 *)a->d_out, a->states, a->results);
+    }
+    if (a->n_deep) {
+        hipLaunchKernelGGL(
+            dec_deep_kernel, dim3(a->n_deep), dim3(kDeepThreads), sizeof(deep_shared) + a->tables.deep_entries * sizeof(u32),
+            st, a->tables, a->items, a->deep_items, (const u8 *)a->d_in, (u8 *)a->d_out, a->states, a->results);
     }
     if (a->n_large) {
         const uint32_t lds = scan_run_lds_bytes(ns);

@@ -686,13 +686,18 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
 }
 
 /* short items are one thread's work, without chunks */
-static bool dec_item_is_tiny(const struct aws_huffman_amd_engine *eng, const struct aws_huffman_amd_decode_item *it) {
-    /* (with codes too long for the chunked decoder's tables, every item goes that way) */
-    return it->in_len > 0 && (it->in_len <= HUFD_DEC_TINY_BYTES || eng->tables.deep_entries);
+/* short items are one thread's work, without chunks; with codes too long for the chunked decoder's tables the
+ * longer items are one workgroup's, without chunks either */
+static bool dec_item_is_tiny(const struct aws_huffman_amd_decode_item *it) {
+    return it->in_len > 0 && it->in_len <= HUFD_DEC_TINY_BYTES;
+}
+
+static bool dec_item_is_deep(const struct aws_huffman_amd_engine *eng, const struct aws_huffman_amd_decode_item *it) {
+    return eng->tables.deep_entries && it->in_len > HUFD_DEC_TINY_BYTES;
 }
 
 static uint64_t dec_item_chunks(const struct aws_huffman_amd_engine *eng, const struct aws_huffman_amd_decode_item *it) {
-    if (dec_item_is_tiny(eng, it)) {
+    if (dec_item_is_tiny(it) || dec_item_is_deep(eng, it)) {
         return 0;
     }
     return (it->in_len + HUFD_DEC_CHUNK_BYTES - 1) / HUFD_DEC_CHUNK_BYTES;
@@ -737,7 +742,7 @@ static int dec_plan_fill(
         free(h_large);
         return aws_raise_error(AWS_ERROR_OOM);
     }
-    uint32_t chunk = 0, large = 0, run = 0, tail = 0, tiny = 0;
+    uint32_t chunk = 0, large = 0, run = 0, tail = 0, tiny = 0, deep = 0;
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_decode_item *src = &items[i];
         struct hufd_dec_item *dst = &h_items[i];
@@ -749,9 +754,13 @@ static int dec_plan_fill(
         dst->first_bit = src->first_bit;
         dst->first_chunk = chunk;
         dst->n_chunks = chunks;
-        dst->tiny = dec_item_is_tiny(eng, src) ? 1u : 0u;
-        if (dst->tiny) {
+        dst->tiny = 0;
+        if (dec_item_is_tiny(src)) {
+            dst->tiny = 1;
             h_tiny[tiny++] = (uint32_t)i;
+        } else if (dec_item_is_deep(eng, src)) {
+            dst->tiny = 1;
+            h_tiny[n_items - ++deep] = (uint32_t)i;
         }
         for (uint32_t k = 0; k < chunks; ++k) {
             /* fewer than a chunk + 8 bytes left: the end of the stream is in (or just behind) this chunk */
@@ -821,7 +830,7 @@ static int dec_plan_fill(
         err = hufs_copy_h2d(p->d_tail, h_tail, tail * sizeof(uint32_t), eng->stream);
     }
     if (!err) {
-        err = hufs_copy_h2d(p->d_tiny, h_tiny, tiny * sizeof(uint32_t), eng->stream);
+        err = hufs_copy_h2d(p->d_tiny, h_tiny, (tiny || deep ? n_items : 0) * sizeof(uint32_t), eng->stream);
     }
     if (!err) {
         err = hufs_copy_h2d(p->d_chunk_item, h_chunk_item, n_chunks * sizeof(uint32_t), eng->stream);
@@ -857,6 +866,7 @@ static int dec_plan_fill(
     p->n_runs = (uint32_t)n_runs;
     p->n_tail = tail;
     p->n_tiny = tiny;
+    p->n_deep = deep;
     return AWS_OP_SUCCESS;
 }
 
@@ -913,6 +923,8 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.n_chunks = p->n_chunks;
     a.tail_chunks = p->d_tail;
     a.n_tail = p->n_tail;
+    a.deep_items = p->d_tiny + (p->n_items - p->n_deep);
+    a.n_deep = p->n_deep;
     a.tiny_items = p->d_tiny;
     a.n_tiny = p->n_tiny;
     a.large_items = p->d_large;

@@ -66,12 +66,12 @@ struct aws_huffman_amd_encode_plan {
 
 struct aws_huffman_amd_decode_plan {
     struct aws_huffman_amd_engine *engine;
-    uint32_t n_items, n_chunks, n_large, n_runs, n_tail, n_tiny;
+    uint32_t n_items, n_chunks, n_large, n_runs, n_tail, n_tiny, n_deep;
     size_t cap_items, cap_chunks, cap_large, cap_runs;
     struct aws_huffman_amd_decode_item *h_items; /* host copy for result translation */
     struct hufd_dec_item *d_items;
     uint32_t *d_chunk_item;
-    uint32_t *d_tiny;      /* items of at most HUFD_DEC_TINY_BYTES encoded bytes (room for every item) */
+    uint32_t *d_tiny;      /* [n_items]: from the front the items of at most HUFD_DEC_TINY_BYTES encoded bytes, from the back the longer ones of a coder with long codes */
     uint32_t *d_tail;      /* chunks that may hold the end of their stream (room for 2 per item) */
     uint32_t *d_large;     /* per large item: item index, its first run */
     uint32_t *d_runs;      /* per run: item index, run number inside the item */

@@ -72,7 +72,7 @@ struct aws_huffman_amd_decode_result {
  * decode tables with zero and one fill, cross-checked against the encode
  * table) and stages the tables on HIP device `device` (-1 = current device).
  * Codes of up to 32 bits either way; up to 12 bits decode through the chunked
- * kernels, longer ones one thread per item.  A decode callback that is not
+ * kernels, longer ones one thread or one workgroup per item.  A decode callback that is not
  * table-shaped leaves the engine encode-only
  * (aws_huffman_amd_engine_can_decode() == false; decode entry points raise
  * AWS_ERROR_UNSUPPORTED_OPERATION).  There is no CPU path to fall back to.

@@ -428,6 +428,12 @@ def other_coders(w, n=60000, seed=23):
             r = paired_decode(w, ddo, ddp, want, 0, want.size, oo, op, 0, n // 3)
             paired_decode(w, ddo, ddp, want, r.consumed, want.size, oo, op, r.produced, n)
             assert np.array_equal(op[:n], data)
+            # the stream cut short in a few places (long codes: around the lanes and blocks of dec_deep)
+            for cut in (513, 640, 32768, 32769, 32768 + 127, want.size // 2, want.size - 1):
+                if cut < want.size:
+                    ddo, ddp = w.oracle.new_decoder(oc), w.product.new_decoder(pc)
+                    oo, op = np.full(n + 8, SENTINEL, np.uint8), np.full(n + 8, SENTINEL, np.uint8)
+                    paired_decode(w, ddo, ddp, want, 0, cut, oo, op, 0, n)
 
 
 # ----------------------------------------------------------------------------- scenario: streams cut at every kind of place (end-of-stream handling of the chunked decoder)
