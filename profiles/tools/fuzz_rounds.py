@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""The parity scenarios of tests/parity_cases.py again and again with fresh seeds, on the GPU, for as long as asked:
+every result is compared with the CPU oracle, bit for bit.  Not part of the timed or graded runs: a soak for the
+paths the seeded tests visit once.
+
+  usage: fuzz_rounds.py [seconds=240] [first_seed=1000]
+"""
+import os
+import sys
+import time
+import traceback
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import harness  # noqa: E402
+import parity_cases as pc  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+lib = harness.load_product()
+assert lib.aws_huffman_amd_device_count() >= 1
+w = pc.World(harness.oracle_codec(), harness.Codec(lib, "aws_"))
+eng = harness.Engine(lib, w.pcoder)
+rounds = [
+    ("tiny_encode_items", lambda s: pc.tiny_encode_items(w, n_items=600, seed=s, engine=eng)),
+    ("tiny_encode_items holes", lambda s: pc.tiny_encode_items(w, n_items=600, seed=s, holes=True)),
+    ("tiny_decode_items", lambda s: pc.tiny_decode_items(w, n_items=600, seed=s, engine=eng)),
+    ("tiny_decode_items hpack", lambda s: pc.tiny_decode_items(w, n_items=600, seed=s, profile="hpack_lengths")),
+    ("batched_device_api", lambda s: pc.batched_device_api(w, n_items=24, seed=s, engine=eng)),
+    ("batched_device_api 3000", lambda s: pc.batched_device_api(w, n_items=14, seed=s, item_len=3000, engine=eng)),
+    ("garbage_decode", lambda s: pc.garbage_decode(w, seed=s, rounds=40)),
+    ("streaming_encode", lambda s: pc.streaming_encode(w, [700, 40000], seed=s)),
+    ("streaming_decode", lambda s: pc.streaming_decode(w, [700, 40000], seed=s)),
+    ("one_shot_roundtrips", lambda s: pc.one_shot_roundtrips(w, [1, 513, 16385, 100001], seed=s)),
+    ("cut_streams", lambda s: pc.cut_streams(w, seed=s, chunks=(1, 3), step=13, span=70, n=120_000)),
+    ("other_coders", lambda s: pc.other_coders(w, n=30000, seed=s)),
+    ("damaged_long_streams", lambda s: pc.damaged_long_streams(w, seed=s) if s % 8 == 0 else None),  # 10 M symbols: now and then
+]
+t0 = time.time()
+done = failed = 0
+while time.time() - t0 < budget:
+    for name, run in rounds:
+        try:
+            run(seed)
+        except Exception:  # noqa: BLE001
+            failed += 1
+            print("FAILED %s seed %d" % (name, seed))
+            traceback.print_exc()
+        done += 1
+        if time.time() - t0 >= budget:
+            break
+    seed += 1
+print("%d scenario runs, %d failed, seeds up to %d, %.0f s" % (done, failed, seed, time.time() - t0))
+sys.exit(1 if failed else 0)
