@@ -25,6 +25,8 @@
 #define HUFD_DEC_SUB_BITS (HUFD_DEC_SUB_BYTES * 8u)
 #define HUFD_DEC_LANES 256u
 #define HUFD_DEC_CHUNK_BYTES (HUFD_DEC_SUB_BYTES * HUFD_DEC_LANES)
+#define HUFD_TINY_MANY_BYTES 2048u  /* one thread per item up to this many symbols (encode), or encoded bytes x 2 / 3 (decode), when a plan holds at least ... */
+#define HUFD_TINY_MANY_ITEMS 65536u /* ... this many items that short: enough threads to fill the chip */
 #define HUFD_DEC_MAX_STATES 16u
 #define HUFD_DEC_CP_ROWS 4u /* per sub-chunk: three checkpoints of the walk + the merged-state mask */
 #define HUFD_DEC_MAX_LUT_BITS 12u
@@ -34,6 +36,7 @@
 #define HUFD_DEEP_MAX_ENTRIES 16384u
 #define HUFD_DEEP_LINK 0x80000000u /* entry is a link: [15:0] first entry of the next table, [23:16] its index width */
 #define HUFD_DEC_TINY_BYTES 512u /* decode items up to this long are one thread's work (dec_tiny): no chunks */
+#define HUFD_DEC_COOP_BYTES 768u /* ... and up to this long one wave's (dec_deep<false>): no chunks either */
 #define HUFD_DEC_STAGE_BYTES 34304u /* LDS bytes for a chunk's decoded symbols (dec_emit_fast: four workgroups per CU) */
 
 #define HUFD_SCAN_SMALL_MAX 64u /* items with at most this many segments/chunks are scanned by one thread */

@@ -3285,44 +3285,43 @@ __global__ __launch_bounds__(kTailThreads) void dec_sync_tail_kernel(
  * Items of at most HUFD_DEC_TINY_BYTES encoded bytes (header-field sized strings): one THREAD per item does
  * all of source/huffman.c:228-268 for it -- from the item's first bit, a symbol per code while there is room,
  * the start bit of the first symbol that finds none, how many symbols the stream holds, where and why it
- * stops -- reading the stream from memory in aligned 8-byte words.  No chunks, transfer functions or scan: for
+ * stops -- reading the stream from memory in aligned 16-byte blocks.  No chunks, transfer functions or scan: for
  * such items they cost far more than the symbols.
  */
 constexpr u32 kTinyDecThreads = 128;
 
 struct stream_reader {
-    uintptr_t base; /* 8-byte aligned address at or in front of the item's first byte */
-    u64 end;        /* bytes from base to the end of the item: bytes behind it read as zero */
-    u64 cur;        /* aligned word cur_index, big endian */
-    u32 cur_index;
+    /* the stream 16 aligned bytes at a time: what limits these one-lane-one-stream walks is the number of
+     * memory requests (every lane of a load touches a line of its own), not the bytes */
+    const uint4 *blocks; /* 16-byte aligned, at or in front of the first byte looked at */
+    u64 end;             /* bytes from there to the end of the item: what follows reads as zero */
+    uint4 cur;
+    u32 cur_block;
     u64 win;
     u32 nb, next, ahead;
 
-    __device__ __forceinline__ u64 word64(u32 i) const {
-        if ((u64)i * 8 >= end) {
-            return 0;
-        }
-        u64 v = __builtin_bswap64(*reinterpret_cast<const u64 *>(base + (uintptr_t)i * 8));
-        const u64 keep = end - (u64)i * 8;
-        if (keep < 8) {
-            v &= ~0ull << (8 * (8 - keep));
-        }
-        return v;
-    }
     __device__ __forceinline__ u32 word(u32 i) {
-        if ((i >> 1) != cur_index) {
-            cur_index = i >> 1;
-            cur = word64(cur_index);
+        const u32 b = i >> 2;
+        if (b != cur_block) {
+            cur_block = b;
+            cur = (u64)b * 16 < end ? blocks[b] : uint4{0, 0, 0, 0};
         }
-        return (i & 1) ? (u32)cur : (u32)(cur >> 32);
+        const u32 k = i & 3u;
+        const u32 raw = k == 0 ? cur.x : (k == 1 ? cur.y : (k == 2 ? cur.z : cur.w));
+        const u64 at = (u64)i * 4;
+        if (at + 4 <= end) {
+            return __builtin_bswap32(raw);
+        }
+        return at < end ? __builtin_bswap32(raw) & (~0u << (8 * (4 - (u32)(end - at)))) : 0u;
     }
-    /* pos: bits from base */
-    __device__ __forceinline__ void start(uintptr_t b, u64 end_bytes, u32 pos) {
-        base = b;
-        end = end_bytes;
-        cur_index = ~0u;
-        cur = 0;
-        const u32 r = pos >> 5;
+    /* from bit `bit` (0..7) of *first, with bytes_left bytes of the item at and behind first */
+    __device__ __forceinline__ void start(const u8 *first, u64 bytes_left, u32 bit) {
+        const u32 lead = (u32)(reinterpret_cast<uintptr_t>(first) & 15u);
+        blocks = reinterpret_cast<const uint4 *>(first - lead);
+        end = lead + bytes_left;
+        cur_block = ~0u;
+        cur = uint4{0, 0, 0, 0};
+        const u32 pos = lead * 8 + bit, r = pos >> 5;
         const u32 w0 = word(r), w1 = word(r + 1);
         win = (((u64)w0 << 32) | w1) << (pos & 31u);
         nb = 64 - (pos & 31u);
@@ -3341,6 +3340,40 @@ struct stream_reader {
             ahead = word(next);
             ++next;
         }
+    }
+};
+
+/* decoded symbols on their way to memory: single bytes up to a 4-byte boundary, whole words from there
+ * (a one-lane-one-stream walk pays per store, not per byte) */
+struct symbol_sink {
+    u8 *at; /* where the next flushed symbol goes */
+    u32 acc, have;
+
+    __device__ __forceinline__ void begin(u8 *first) {
+        at = first;
+        acc = 0;
+        have = 0;
+    }
+    __device__ __forceinline__ void put(u32 symbol) {
+        if (have == 0 && (reinterpret_cast<uintptr_t>(at) & 3u) != 0) {
+            *at++ = (u8)symbol;
+            return;
+        }
+        acc |= symbol << (8 * have);
+        if (++have == 4) {
+            *reinterpret_cast<u32 *>(at) = acc;
+            at += 4;
+            acc = 0;
+            have = 0;
+        }
+    }
+    __device__ __forceinline__ void flush() {
+        for (u32 k = 0; k < have; ++k) {
+            at[k] = (u8)(acc >> (8 * k));
+        }
+        at += have;
+        have = 0;
+        acc = 0;
     }
 };
 
@@ -3384,11 +3417,10 @@ __global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
     }
     const u32 item = tiny_items[t];
     const hufd_dec_item it = items[item];
-    const uintptr_t addr = reinterpret_cast<uintptr_t>(d_in + it.in_off);
-    const u32 lead = (u32)(addr & 7);
     stream_reader sr;
-    sr.start(addr - lead, lead + it.in_len, lead * 8 + it.first_bit);
-    u8 *out = d_out + it.out_off;
+    sr.start(d_in + it.in_off, it.in_len, it.first_bit);
+    symbol_sink sink;
+    sink.begin(d_out + it.out_off);
     const u64 rem = it.in_len * 8;
     u64 pos = it.first_bit;
     u32 why = HUFD_STOP_NONE;
@@ -3411,7 +3443,7 @@ __global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
             break;
         }
         if (n < it.out_cap) {
-            out[n] = (u8)(entry >> 8);
+            sink.put(entry >> 8);
         } else if (n == it.out_cap) {
             cap_bit = pos; /* source/huffman.c:257-268: this symbol is not consumed */
         }
@@ -3419,6 +3451,7 @@ __global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
         sr.skip(len);
         pos += len;
     }
+    sink.flush();
     hufd_dec_result rs;
     rs.total_symbols = n;
     rs.stop_bit = pos;
@@ -3430,19 +3463,21 @@ __global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
 }
 
 /*
- * Items of more than HUFD_DEC_TINY_BYTES encoded bytes of a coder with long codes: one WORKGROUP per item, the
- * stream taken 32 KiB (256 lanes x 128 bytes) at a time.  The chunked decoder's transfer functions need a state
- * per possible entry offset (up to 32 here); this road needs none: every lane walks its 128 bytes from a guessed
+ * One small WORKGROUP per item, the stream taken (lanes x lane_bytes) at a time, for two kinds of item:
+ *   - HUFD_DEC_TINY_BYTES < encoded bytes <= HUFD_DEC_COOP_BYTES, any coder: one wave, the item split evenly over
+ *     its 64 lanes.  A chunk's workgroup, tables and three more launches cost such an item tens of times its symbols.
+ *   - longer items of a coder with long codes (DEEP): 256 lanes x 128 bytes a round.  The chunked decoder's transfer
+ *     functions need a state per possible entry offset (up to 32 there).
+ * This road needs no entry states: every lane walks its bytes from a guessed
  * entry (bit 0), then again from where the lane in front of it really leaves, until no lane's entry changes --
  * walks from different entries fall into step within a few codes, so that is two or three rounds, and it is
  * exact whatever the stream does, because lane 0's entry is the true one and every round settles at least one
  * more lane.  A walk that stops (end of stream, no code, code cut off: source/huffman.c:232-255) leaves the lanes
  * behind it unreached.  Then a scan of the lanes' symbol counts and one more walk that writes the symbols.
  */
-constexpr u32 kDeepThreads = 256;
+constexpr u32 kDeepThreads = 256; /* at most */
 constexpr u32 kDeepLaneBytes = 128;
-constexpr u32 kDeepLaneBits = kDeepLaneBytes * 8;
-constexpr u32 kDeepBlockBytes = kDeepThreads * kDeepLaneBytes;
+constexpr u32 kCoopThreads = 64; /* the one-wave variant for items of up to HUFD_DEC_COOP_BYTES */
 constexpr u32 kDeepStop = 0xFFu; /* a lane's exit: its walk stopped, or the lane is never reached */
 
 struct deep_shared {
@@ -3462,15 +3497,16 @@ struct deep_walked {
 
 /* follows the codes from stream bit `from` to the first code start at or behind `to`; writes symbol number
  * index + k to out[index + k] while that is below out_cap (out == NULL: count only) */
+template <bool DEEP>
 __device__ __forceinline__ deep_walked deep_walk(
-    const u32 *deep, const u8 *in, u64 in_len, u64 from, u64 to, u8 *out, u64 index, u64 out_cap, u64 *cap_bit) {
+    const u32 *deep, const u16 *lut, u32 lut_bits, const u8 *in, u64 in_len, u64 from, u64 to, u8 *out, u64 index, u64 out_cap, u64 *cap_bit) {
     const u64 rem = in_len * 8;
     stream_reader sr = {};
     if (from < rem) {
-        const uintptr_t addr = reinterpret_cast<uintptr_t>(in) + (uintptr_t)(from >> 3);
-        const u32 lead = (u32)(addr & 7);
-        sr.start(addr - lead, lead + (in_len - (from >> 3)), lead * 8 + (u32)(from & 7));
+        sr.start(in + (from >> 3), in_len - (from >> 3), (u32)(from & 7));
     }
+    symbol_sink sink;
+    sink.begin(out ? out + index : nullptr);
     deep_walked r;
     r.pos = from;
     r.count = 0;
@@ -3480,7 +3516,7 @@ __device__ __forceinline__ deep_walked deep_walk(
             r.why = HUFD_STOP_END;
             break;
         }
-        const u32 entry = deep_entry(deep, sr.peek());
+        const u32 entry = DEEP ? deep_entry(deep, sr.peek()) : lut[sr.peek() >> (32 - lut_bits)];
         const u32 len = entry & 0xFFu;
         if (len == 0) {
             r.why = HUFD_STOP_INVALID;
@@ -3493,7 +3529,7 @@ __device__ __forceinline__ deep_walked deep_walk(
         if (out) {
             const u64 k = index + r.count;
             if (k < out_cap) {
-                out[k] = (u8)(entry >> 8);
+                sink.put(entry >> 8);
             } else if (k == out_cap) {
                 *cap_bit = r.pos; /* source/huffman.c:257-268: this symbol is not consumed */
             }
@@ -3502,13 +3538,16 @@ __device__ __forceinline__ deep_walked deep_walk(
         sr.skip(len);
         r.pos += len;
     }
+    sink.flush();
     return r;
 }
 
+template <bool DEEP>
 __global__ __launch_bounds__(kDeepThreads) void dec_deep_kernel(
     hufd_tables tb,
     const hufd_dec_item *items,
     const u32 *deep_items,
+    u32 fixed_lane_bytes, /* 0: the item split evenly over the lanes */
     const u8 *d_in,
     u8 *d_out,
     hufd_dec_item_state *states,
@@ -3516,9 +3555,16 @@ __global__ __launch_bounds__(kDeepThreads) void dec_deep_kernel(
 
     deep_shared &sh = *reinterpret_cast<deep_shared *>(dyn_lds);
     u32 *deep = reinterpret_cast<u32 *>(dyn_lds + sizeof(deep_shared));
-    const u32 l = threadIdx.x;
-    for (u32 i = l; i < tb.deep_entries; i += kDeepThreads) {
-        deep[i] = tb.deep_lut[i];
+    u16 *lut = reinterpret_cast<u16 *>(dyn_lds + sizeof(deep_shared));
+    const u32 l = threadIdx.x, lanes = blockDim.x;
+    if (DEEP) {
+        for (u32 i = l; i < tb.deep_entries; i += lanes) {
+            deep[i] = tb.deep_lut[i];
+        }
+    } else {
+        for (u32 i = l; i < (1u << tb.lut_bits); i += lanes) {
+            lut[i] = tb.dec_lut[i];
+        }
     }
     if (l == 0) {
         sh.stop_kind = HUFD_STOP_NONE;
@@ -3530,19 +3576,26 @@ __global__ __launch_bounds__(kDeepThreads) void dec_deep_kernel(
     const hufd_dec_item it = items[item];
     const u8 *in = d_in + it.in_off;
     u8 *out = d_out + it.out_off;
-    const u64 n_blocks = (it.in_len + kDeepBlockBytes - 1) / kDeepBlockBytes;
+    u32 lane_bytes = fixed_lane_bytes;
+    if (lane_bytes == 0) {
+        lane_bytes = (u32)(((it.in_len + lanes - 1) / lanes + 7) & ~7ull);
+        lane_bytes = lane_bytes < 16 ? 16u : lane_bytes;
+    }
+    const u32 lane_bits = lane_bytes * 8;
+    const u64 round_bytes = (u64)lanes * lane_bytes;
+    const u64 n_blocks = (it.in_len + round_bytes - 1) / round_bytes;
     u64 symbols = 0; /* on the true path in front of this block */
     u32 entry = it.first_bit;
     for (u64 b = 0; b < n_blocks && entry != kDeepStop; ++b) {
-        const u64 block_bytes = it.in_len - b * kDeepBlockBytes < kDeepBlockBytes ? it.in_len - b * kDeepBlockBytes : kDeepBlockBytes;
-        const u32 n_lanes = (u32)((block_bytes + kDeepLaneBytes - 1) / kDeepLaneBytes);
+        const u64 block_bytes = it.in_len - b * round_bytes < round_bytes ? it.in_len - b * round_bytes : round_bytes;
+        const u32 n_lanes = (u32)((block_bytes + lane_bytes - 1) / lane_bytes);
         const bool active = l < n_lanes;
-        const u64 lane_from = (b * kDeepBlockBytes + (u64)l * kDeepLaneBytes) * 8, lane_to = lane_from + kDeepLaneBits;
+        const u64 lane_from = (b * round_bytes + (u64)l * lane_bytes) * 8, lane_to = lane_from + lane_bits;
         u32 start = l == 0 ? entry : 0u, my_exit = kDeepStop, my_count = 0;
         bool reached = true, walk = active;
         for (;;) {
             if (walk) {
-                const deep_walked r = deep_walk(deep, in, it.in_len, lane_from + start, lane_to, nullptr, 0, 0, nullptr);
+                const deep_walked r = deep_walk<DEEP>(deep, lut, tb.lut_bits, in, it.in_len, lane_from + start, lane_to, nullptr, 0, 0, nullptr);
                 my_exit = r.why == HUFD_STOP_NONE ? (u32)(r.pos - lane_to) : kDeepStop;
                 my_count = r.count;
             }
@@ -3577,17 +3630,17 @@ __global__ __launch_bounds__(kDeepThreads) void dec_deep_kernel(
         const u32 mine = active && reached ? my_count : 0u;
         sh.scan[l] = mine;
         __syncthreads();
-        for (u32 d = 1; d < kDeepThreads; d *= 2) {
+        for (u32 d = 1; d < lanes; d *= 2) {
             const u32 add = l >= d ? sh.scan[l - d] : 0u;
             __syncthreads();
             sh.scan[l] += add;
             __syncthreads();
         }
-        const u32 before = sh.scan[l] - mine, block_symbols = sh.scan[kDeepThreads - 1];
+        const u32 before = sh.scan[l] - mine, block_symbols = sh.scan[lanes - 1];
         const u32 last_exit = sh.exit_of[n_lanes - 1];
         if (active && reached) {
             u64 cap_bit = kNoBit;
-            const deep_walked r = deep_walk(deep, in, it.in_len, lane_from + start, lane_to, out, symbols + before, it.out_cap, &cap_bit);
+            const deep_walked r = deep_walk<DEEP>(deep, lut, tb.lut_bits, in, it.in_len, lane_from + start, lane_to, out, symbols + before, it.out_cap, &cap_bit);
             if (cap_bit != kNoBit) {
                 sh.cap_bit = cap_bit;
             }
@@ -5152,10 +5205,14 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             (1u << a->tables.lut_bits) * sizeof(u16), st, a->tables, a->items, a->tiny_items, a->n_tiny, (const u8 *)a->d_in,
             (u8 *)a->d_out, a->states, a->results);
     }
-    if (a->n_deep) {
+    if (a->n_deep && a->tables.deep_entries) {
         hipLaunchKernelGGL(
-            dec_deep_kernel, dim3(a->n_deep), dim3(kDeepThreads), sizeof(deep_shared) + a->tables.deep_entries * sizeof(u32),
-            st, a->tables, a->items, a->deep_items, (const u8 *)a->d_in, (u8 *)a->d_out, a->states, a->results);
+            dec_deep_kernel<true>, dim3(a->n_deep), dim3(kDeepThreads), sizeof(deep_shared) + a->tables.deep_entries * sizeof(u32),
+            st, a->tables, a->items, a->deep_items, kDeepLaneBytes, (const u8 *)a->d_in, (u8 *)a->d_out, a->states, a->results);
+    } else if (a->n_deep) {
+        hipLaunchKernelGGL(
+            dec_deep_kernel<false>, dim3(a->n_deep), dim3(kCoopThreads), sizeof(deep_shared) + (1u << a->tables.lut_bits) * sizeof(u16),
+            st, a->tables, a->items, a->deep_items, 0u, (const u8 *)a->d_in, (u8 *)a->d_out, a->states, a->results);
     }
     if (a->n_large) {
         const uint32_t lds = scan_run_lds_bytes(ns);

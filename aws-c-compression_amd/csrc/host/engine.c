@@ -318,13 +318,22 @@ static void enc_plan_release_device(struct aws_huffman_amd_encode_plan *p) {
 }
 
 /* short items with anything to write (symbols or carried bits) are one thread's work, without segments */
-static bool enc_item_is_tiny(const struct aws_huffman_amd_encode_item *it) {
-    return it->in_len <= HUFD_ENC_TINY_BYTES && (it->in_len > 0 || it->overflow_in.num_bits);
+static bool enc_item_is_tiny(const struct aws_huffman_amd_encode_item *it, uint64_t limit) {
+    return it->in_len <= limit && (it->in_len > 0 || it->overflow_in.num_bits);
+}
+
+/* one thread per item pays for longer items too when there are enough of them to fill the chip with threads */
+static uint64_t enc_tiny_limit(const struct aws_huffman_amd_encode_item *items, size_t n_items) {
+    size_t many = 0;
+    for (size_t i = 0; i < n_items; ++i) {
+        many += items[i].in_len <= HUFD_TINY_MANY_BYTES;
+    }
+    return many >= HUFD_TINY_MANY_ITEMS ? HUFD_TINY_MANY_BYTES : HUFD_ENC_TINY_BYTES;
 }
 
 /* segments the other items need */
-static uint64_t enc_item_segments(const struct aws_huffman_amd_encode_item *it) {
-    if (enc_item_is_tiny(it)) {
+static uint64_t enc_item_segments(const struct aws_huffman_amd_encode_item *it, uint64_t tiny_limit) {
+    if (enc_item_is_tiny(it, tiny_limit)) {
         return 0; /* one thread encodes it (enc_tiny) */
     }
     return (it->in_len + HUFD_ENC_SEG_BYTES - 1) / HUFD_ENC_SEG_BYTES;
@@ -337,15 +346,16 @@ static int enc_plan_fill(
     size_t n_items) {
 
     struct aws_huffman_amd_engine *eng = p->engine;
+    const uint64_t tiny_limit = enc_tiny_limit(items, n_items);
     uint64_t n_segs = 0, n_large = 0, n_tiny = 0;
     for (size_t i = 0; i < n_items; ++i) {
         if (items[i].overflow_in.num_bits > 32) {
             return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
         }
-        const uint64_t segs = enc_item_segments(&items[i]);
+        const uint64_t segs = enc_item_segments(&items[i], tiny_limit);
         n_segs += segs;
         n_large += segs > HUFD_SCAN_SMALL_MAX;
-        n_tiny += enc_item_is_tiny(&items[i]);
+        n_tiny += enc_item_is_tiny(&items[i], tiny_limit);
     }
     if (n_segs >= 0xFFFFFFFFull || n_items >= 0xFFFFFFFFull) {
         return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
@@ -366,7 +376,7 @@ static int enc_plan_fill(
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_encode_item *src = &items[i];
         struct hufd_enc_item *dst = &h_items[i];
-        const uint32_t segs = (uint32_t)enc_item_segments(src);
+        const uint32_t segs = (uint32_t)enc_item_segments(src, tiny_limit);
         const uint32_t ob = src->overflow_in.num_bits;
         dst->in_off = src->in_offset;
         dst->in_len = src->in_len;
@@ -377,7 +387,7 @@ static int enc_plan_fill(
         dst->eos_padding = src->eos_padding;
         dst->first_seg = seg;
         dst->n_segs = segs;
-        dst->tiny = enc_item_is_tiny(src) ? 1u : 0u;
+        dst->tiny = enc_item_is_tiny(src, tiny_limit) ? 1u : 0u;
         if (dst->tiny) {
             h_tiny[tiny++] = (uint32_t)i;
         }
@@ -688,16 +698,28 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
 /* short items are one thread's work, without chunks */
 /* short items are one thread's work, without chunks; with codes too long for the chunked decoder's tables the
  * longer items are one workgroup's, without chunks either */
-static bool dec_item_is_tiny(const struct aws_huffman_amd_decode_item *it) {
-    return it->in_len > 0 && it->in_len <= HUFD_DEC_TINY_BYTES;
+static bool dec_item_is_tiny(const struct aws_huffman_amd_decode_item *it, uint64_t limit) {
+    return it->in_len > 0 && it->in_len <= limit;
 }
 
-static bool dec_item_is_deep(const struct aws_huffman_amd_engine *eng, const struct aws_huffman_amd_decode_item *it) {
-    return eng->tables.deep_entries && it->in_len > HUFD_DEC_TINY_BYTES;
+/* (longer ones too when there are enough of them to fill the chip with threads) */
+static uint64_t dec_tiny_limit(const struct aws_huffman_amd_decode_item *items, size_t n_items) {
+    size_t many = 0;
+    for (size_t i = 0; i < n_items; ++i) {
+        many += items[i].in_len <= (HUFD_TINY_MANY_BYTES * 3 / 2);
+    }
+    return many >= HUFD_TINY_MANY_ITEMS ? HUFD_TINY_MANY_BYTES : HUFD_DEC_TINY_BYTES;
 }
 
-static uint64_t dec_item_chunks(const struct aws_huffman_amd_engine *eng, const struct aws_huffman_amd_decode_item *it) {
-    if (dec_item_is_tiny(it) || dec_item_is_deep(eng, it)) {
+static bool dec_item_is_deep(
+    const struct aws_huffman_amd_engine *eng, const struct aws_huffman_amd_decode_item *it, uint64_t tiny_limit) {
+    /* (the same kernel, as one wave, takes every coder's items that are too short to be worth a chunk's workgroup) */
+    return it->in_len > tiny_limit && (eng->tables.deep_entries || it->in_len <= HUFD_DEC_COOP_BYTES);
+}
+
+static uint64_t dec_item_chunks(
+    const struct aws_huffman_amd_engine *eng, const struct aws_huffman_amd_decode_item *it, uint64_t tiny_limit) {
+    if (dec_item_is_tiny(it, tiny_limit) || dec_item_is_deep(eng, it, tiny_limit)) {
         return 0;
     }
     return (it->in_len + HUFD_DEC_CHUNK_BYTES - 1) / HUFD_DEC_CHUNK_BYTES;
@@ -712,13 +734,14 @@ static int dec_plan_fill(
     if (!eng->can_decode) {
         return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION);
     }
+    const uint64_t tiny_limit = dec_tiny_limit(items, n_items);
     uint64_t n_chunks = 0, n_large = 0, n_runs = 0;
     for (size_t i = 0; i < n_items; ++i) {
         /* symbol counts in the scan's function entries are 26-bit; 4 GiB of encoded bytes per item is the limit */
         if (items[i].first_bit > 7 || items[i].in_len > 0xFFFFFFFFull) {
             return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
         }
-        const uint64_t chunks = dec_item_chunks(eng, &items[i]);
+        const uint64_t chunks = dec_item_chunks(eng, &items[i], tiny_limit);
         n_chunks += chunks;
         n_large += chunks > HUFD_SCAN_SMALL_MAX;
         n_runs += chunks > HUFD_SCAN_SMALL_MAX ? (chunks + HUFD_SCAN_RUN_CHUNKS - 1) / HUFD_SCAN_RUN_CHUNKS : 0;
@@ -746,7 +769,7 @@ static int dec_plan_fill(
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_decode_item *src = &items[i];
         struct hufd_dec_item *dst = &h_items[i];
-        const uint32_t chunks = (uint32_t)dec_item_chunks(eng, src);
+        const uint32_t chunks = (uint32_t)dec_item_chunks(eng, src, tiny_limit);
         dst->in_off = src->in_offset;
         dst->in_len = src->in_len;
         dst->out_off = src->out_offset;
@@ -755,10 +778,10 @@ static int dec_plan_fill(
         dst->first_chunk = chunk;
         dst->n_chunks = chunks;
         dst->tiny = 0;
-        if (dec_item_is_tiny(src)) {
+        if (dec_item_is_tiny(src, tiny_limit)) {
             dst->tiny = 1;
             h_tiny[tiny++] = (uint32_t)i;
-        } else if (dec_item_is_deep(eng, src)) {
+        } else if (dec_item_is_deep(eng, src, tiny_limit)) {
             dst->tiny = 1;
             h_tiny[n_items - ++deep] = (uint32_t)i;
         }

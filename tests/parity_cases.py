@@ -636,7 +636,7 @@ def batched_device_api(w, n_items=9, seed=18, item_len=16384, engine=None):
         eng.close()
 
 
-def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False):
+def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False, max_len=560):
     """Items either side of HUFD_ENC_TINY_BYTES (512 symbols; one thread each below it), with every kind
     of stop: roomy, exact, one byte short, cut anywhere, no room at all, carried overflow bits that fit,
     fill the output exactly or do not fit, symbols without a code."""
@@ -644,7 +644,7 @@ def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False):
     own = engine is None or holes
     eng = harness.Engine(w.product.lib, w.pcoder_holes if holes else w.pcoder) if own else engine
     oc = w.ocoder_holes if holes else w.ocoder
-    lens = [0, 0, 1, 2, 3, 511, 512, 513, 600] + [int(rng.integers(0, 560)) for _ in range(n_items - 9)]
+    lens = [0, 0, 1, 2, 3, 511, 512, 513, 600] + [int(rng.integers(0, max_len)) for _ in range(n_items - 9)]
     blobs = []
     for i, n in enumerate(lens):
         b = inputs(rng, n, KINDS[i % 4])
@@ -705,7 +705,8 @@ def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False):
     lens_of = [int(w.table[1][b]) for b in range(256)]
     if holes:
         lens_of[7] = lens_of[200] = 0
-    want_lens = [(it["overflow_in"][1] + sum(lens_of[int(x)] for x in b) + 7) // 8 for b, it in zip(blobs, items)]
+    lens_arr = np.asarray(lens_of, dtype=np.int64)
+    want_lens = [(it["overflow_in"][1] + int(lens_arr[b].sum()) + 7) // 8 for b, it in zip(blobs, items)]
     assert eng.encoded_lengths(plan, len(items)) == want_lens
     assert np.array_equal(eng.download(d_out, out_total), want), "a length-only launch wrote something"
     eng.lib.aws_huffman_amd_encode_plan_destroy(plan)
@@ -715,7 +716,7 @@ def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False):
         eng.close()
 
 
-def tiny_decode_items(w, n_items=1500, seed=41, engine=None, profile=None):
+def tiny_decode_items(w, n_items=1500, seed=41, engine=None, profile=None, max_len=460):
     """Streams either side of HUFD_DEC_TINY_BYTES (512 bytes; one thread each below it): whole encodings, cut
     ones, arbitrary bytes, starting inside their first byte, with room for all, some or none of their symbols."""
     rng = np.random.default_rng(seed)
@@ -728,9 +729,9 @@ def tiny_decode_items(w, n_items=1500, seed=41, engine=None, profile=None):
     for i in range(n_items):
         kind = i % 5
         if kind == 4:
-            enc = rng.integers(0, 256, int(rng.integers(1, 540)), dtype=np.uint8)
+            enc = rng.integers(0, 256, int(rng.integers(1, max_len + 80)), dtype=np.uint8)
         else:
-            n = [0, 1, 2, 409, 410, 420][i // 5] if i < 30 else int(rng.integers(0, 460))
+            n = [0, 1, 2, 409, 410, 420][i // 5] if i < 30 else int(rng.integers(0, max_len))
             enc = oracle_encode(w, inputs(rng, n, KINDS[i % 3]), coder=ocoder, eos=[None, 0x00, 0x5A][i % 3])
             if kind == 3 and enc.size:
                 enc = enc[:int(rng.integers(0, enc.size + 1))]
