@@ -541,25 +541,38 @@ struct tiny_sink {
     u64 acc;  /* low nacc bits: code bits not yet stored, oldest highest */
     u32 nacc;
 
-    /* stores every whole byte gathered; true when the output filled with bits of the last code left over */
-    __device__ bool drain(bool writing) {
-        if (writing && nacc >= 32 && cap - produced > 4 && ((reinterpret_cast<uintptr_t>(out) + produced) & 3) == 0) {
-            const u32 w = (u32)(acc >> (nacc - 32));
-            *reinterpret_cast<u32 *>(out + produced) = __builtin_bswap32(w);
-            produced += 4;
-            nacc -= 32;
-        }
-        while (nacc >= 8) {
-            if (writing) {
+    /* stores what has gathered -- whole words once the output address is word aligned and four bytes still fit
+     * (fewer than 32 gathered bits then wait: a one-lane walk pays per store), single bytes otherwise; true when
+     * the output filled with bits of the last code left over */
+    __device__ bool drain() {
+        for (;;) {
+            const bool wordy = cap - produced >= 4 && ((reinterpret_cast<uintptr_t>(out) + produced) & 3) == 0;
+            if (wordy) {
+                if (nacc < 32) {
+                    return false;
+                }
+                *reinterpret_cast<u32 *>(out + produced) = __builtin_bswap32((u32)(acc >> (nacc - 32)));
+                produced += 4;
+                nacc -= 32;
+            } else {
+                if (nacc < 8) {
+                    return false;
+                }
                 out[produced] = (u8)(acc >> (nacc - 8));
+                nacc -= 8;
+                ++produced;
             }
-            nacc -= 8;
-            ++produced;
             if (produced == cap) {
                 return nacc != 0;
             }
         }
-        return false;
+    }
+    /* the whole bytes still waiting (there is room for them: they only wait while four bytes fit) */
+    __device__ void finish() {
+        while (nacc >= 8) {
+            out[produced++] = (u8)(acc >> (nacc - 8));
+            nacc -= 8;
+        }
     }
 };
 
@@ -596,15 +609,17 @@ __global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
     rs.produced = 0;
     rs.total_bits = it.ovf_bits;
 
-    /* aligned eight-byte reads of the symbols, one at a time */
+    /* aligned 16-byte reads of the symbols, handed out one at a time (what counts is the number of requests) */
     const uintptr_t in_addr = reinterpret_cast<uintptr_t>(in);
-    u64 word = 0;
+    uint4 block = uint4{0, 0, 0, 0};
     auto symbol = [&](u32 k) -> u32 {
         const uintptr_t a = in_addr + k;
-        if (k == 0 || (a & 7) == 0) {
-            word = *reinterpret_cast<const u64 *>(a & ~(uintptr_t)7);
+        if (k == 0 || (a & 15) == 0) {
+            block = *reinterpret_cast<const uint4 *>(a & ~(uintptr_t)15);
         }
-        return (u32)(word >> ((a & 7) * 8)) & 0xFFu;
+        const u32 w = (u32)(a >> 2) & 3u;
+        const u32 word = w == 0 ? block.x : (w == 1 ? block.y : (w == 2 ? block.z : block.w));
+        return (word >> ((a & 3) * 8)) & 0xFFu;
     };
 
     if (length_only) {
@@ -636,7 +651,7 @@ __global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
         } else {
             sink.acc = it.ovf_pattern;
             sink.nacc = it.ovf_bits;
-            if (sink.drain(true)) {
+            if (sink.drain()) {
                 rs.status = HUFD_ENC_SHORT;
                 rs.consumed = 0;
                 rs.ovf_bits = sink.nacc;
@@ -664,7 +679,7 @@ __global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
         bits += len;
         sink.acc = (sink.acc << len) | (u32)ent;
         sink.nacc += len;
-        if (sink.drain(true)) { /* source/huffman.c:88-100 */
+        if (sink.drain()) { /* source/huffman.c:88-100 */
             rs.status = HUFD_ENC_SHORT;
             rs.consumed = k + 1;
             rs.ovf_bits = sink.nacc;
@@ -672,6 +687,9 @@ __global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
             stopped = true;
             break;
         }
+    }
+    if (rs.status != HUFD_ENC_SHORT) {
+        sink.finish(); /* (before a symbol without a code too: the reference had written those bytes) */
     }
     if (!stopped && sink.nacc) { /* source/huffman.c:178-184 */
         const u32 room = 8 - sink.nacc;

@@ -708,7 +708,7 @@ static uint64_t dec_tiny_limit(const struct aws_huffman_amd_decode_item *items, 
     for (size_t i = 0; i < n_items; ++i) {
         many += items[i].in_len <= (HUFD_TINY_MANY_BYTES * 3 / 2);
     }
-    return many >= HUFD_TINY_MANY_ITEMS ? HUFD_TINY_MANY_BYTES : HUFD_DEC_TINY_BYTES;
+    return many >= HUFD_TINY_MANY_ITEMS ? (HUFD_TINY_MANY_BYTES * 3 / 2) : HUFD_DEC_TINY_BYTES;
 }
 
 static bool dec_item_is_deep(
