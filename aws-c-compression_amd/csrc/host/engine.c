@@ -324,14 +324,18 @@ static bool enc_item_is_tiny(const struct aws_huffman_amd_encode_item *it, uint6
 
 /* one thread per item pays for longer items too when there are enough of them to fill the chip with threads */
 static uint64_t enc_tiny_limit(const struct aws_huffman_amd_encode_item *items, size_t n_items) {
-    size_t many = 0;
+    size_t many = 0, tiny = 0;
     for (size_t i = 0; i < n_items; ++i) {
         many += items[i].in_len <= HUFD_TINY_MANY_BYTES;
+        tiny += items[i].in_len <= HUFD_ENC_TINY_BYTES;
     }
-    return many >= HUFD_TINY_MANY_ITEMS ? HUFD_TINY_MANY_BYTES : HUFD_ENC_TINY_BYTES;
+    if (many >= HUFD_TINY_MANY_ITEMS) {
+        return HUFD_TINY_MANY_BYTES;
+    }
+    /* a handful of items is about latency, and a lone thread is slow: it only gets the shortest ones */
+    return tiny < HUFD_TINY_FEW_ITEMS ? HUFD_TINY_FEW_BYTES : HUFD_ENC_TINY_BYTES;
 }
 
-/* segments the other items need */
 static uint64_t enc_item_segments(const struct aws_huffman_amd_encode_item *it, uint64_t tiny_limit) {
     if (enc_item_is_tiny(it, tiny_limit)) {
         return 0; /* one thread encodes it (enc_tiny) */
@@ -704,11 +708,16 @@ static bool dec_item_is_tiny(const struct aws_huffman_amd_decode_item *it, uint6
 
 /* (longer ones too when there are enough of them to fill the chip with threads) */
 static uint64_t dec_tiny_limit(const struct aws_huffman_amd_decode_item *items, size_t n_items) {
-    size_t many = 0;
+    size_t many = 0, tiny = 0;
     for (size_t i = 0; i < n_items; ++i) {
         many += items[i].in_len <= (HUFD_TINY_MANY_BYTES * 3 / 2);
+        tiny += items[i].in_len <= HUFD_DEC_TINY_BYTES;
     }
-    return many >= HUFD_TINY_MANY_ITEMS ? (HUFD_TINY_MANY_BYTES * 3 / 2) : HUFD_DEC_TINY_BYTES;
+    if (many >= HUFD_TINY_MANY_ITEMS) {
+        return HUFD_TINY_MANY_BYTES * 3 / 2;
+    }
+    /* a handful of items is about latency: a wave (dec_deep) takes over from the lone thread early */
+    return tiny < HUFD_TINY_FEW_ITEMS ? HUFD_TINY_FEW_BYTES : HUFD_DEC_TINY_BYTES;
 }
 
 static bool dec_item_is_deep(
