@@ -148,6 +148,7 @@ int aws_huffman_amd_engine_new(
     if (!eng) {
         return aws_raise_error(AWS_ERROR_OOM);
     }
+    pthread_mutex_init(&eng->one_lock, NULL);
     eng->device = device;
     eng->coder = coder;
     eng->key_encode = (void *)coder->encode;
@@ -268,6 +269,7 @@ void aws_huffman_amd_engine_destroy(struct aws_huffman_amd_engine *eng) {
     hufs_stream_destroy(eng->stream);
     free(eng->dec_lut_host);
     free(eng->deep_lut_host);
+    pthread_mutex_destroy(&eng->one_lock);
     free(eng);
 }
 

@@ -3,6 +3,8 @@
 /* Internal layout of the opaque types of huffman_amd.h and the helpers huffman.c uses. */
 #include <aws/compression/huffman_amd.h>
 
+#include <pthread.h>
+
 #include "../hip/device_types.h"
 #include "../hip/hip_shim.h"
 #include "../hip/huffman_kernels.h"
@@ -28,7 +30,10 @@ struct aws_huffman_amd_engine {
     struct hufd_tables tables;
     bool single_pass; /* AWS_HUFFMAN_AMD_ENCODE=single-pass: fused encode kernel (measured slower) */
 
-    /* scratch of the host-pointer API: one item at a time */
+    /* scratch of the host-pointer API: one item at a time, one caller at a time (`one_lock`); `users` keeps the
+     * engine cache of huffman.c from retiring an engine somebody is inside of */
+    pthread_mutex_t one_lock;
+    int users;
     void *one_in;
     size_t one_in_cap;
     void *one_out;

@@ -28,7 +28,10 @@ static unsigned s_engine_clock[ENGINE_SLOTS];
 static unsigned s_clock;
 static pthread_mutex_t s_engine_lock = PTHREAD_MUTEX_INITIALIZER;
 
-static struct aws_huffman_amd_engine *engine_for(struct aws_huffman_symbol_coder *coder) {
+/* the engine of a coder, held for one call: counted (so that it is not retired under the caller) and locked (its
+ * staging buffers and one-item plans serve one call at a time; different threads may share a coder, as the
+ * reference allows for its function-static generated coders) */
+static struct aws_huffman_amd_engine *engine_acquire(struct aws_huffman_symbol_coder *coder) {
     int device = 0;
     if (hufs_device_count() <= 0 || hufs_get_device(&device)) {
         aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION); /* no GPU: fail loudly, there is no CPU path */
@@ -46,26 +49,41 @@ static struct aws_huffman_amd_engine *engine_for(struct aws_huffman_symbol_coder
         }
     }
     if (!found) {
-        /* a free slot, else the least recently used one */
+        /* a free slot, else the least recently used engine nobody is inside of */
         for (int i = 0; i < ENGINE_SLOTS; ++i) {
             if (!s_engines[i]) {
                 slot = i;
                 break;
             }
-            if (slot < 0 || s_engine_clock[i] < s_engine_clock[slot]) {
+            if (s_engines[i]->users == 0 && (slot < 0 || s_engine_clock[i] < s_engine_clock[slot])) {
                 slot = i;
             }
         }
         struct aws_huffman_amd_engine *fresh = NULL;
-        if (aws_huffman_amd_engine_new(&fresh, coder, device) == AWS_OP_SUCCESS) {
+        if (slot < 0) {
+            aws_raise_error(AWS_ERROR_INVALID_STATE); /* ENGINE_SLOTS different coders in use at this very moment */
+        } else if (aws_huffman_amd_engine_new(&fresh, coder, device) == AWS_OP_SUCCESS) {
             aws_huffman_amd_engine_destroy(s_engines[slot]);
             s_engines[slot] = fresh;
             s_engine_clock[slot] = ++s_clock;
             found = fresh;
         }
     }
+    if (found) {
+        ++found->users;
+    }
     pthread_mutex_unlock(&s_engine_lock);
+    if (found) {
+        pthread_mutex_lock(&found->one_lock);
+    }
     return found;
+}
+
+static void engine_release(struct aws_huffman_amd_engine *eng) {
+    pthread_mutex_unlock(&eng->one_lock);
+    pthread_mutex_lock(&s_engine_lock);
+    --eng->users;
+    pthread_mutex_unlock(&s_engine_lock);
 }
 
 /* ------------------------------------------------------------------ init / reset */
@@ -107,7 +125,7 @@ size_t aws_huffman_get_encoded_length(struct aws_huffman_encoder *encoder, struc
     if (to_encode.len == 0) {
         return 0;
     }
-    struct aws_huffman_amd_engine *eng = engine_for(encoder->coder);
+    struct aws_huffman_amd_engine *eng = engine_acquire(encoder->coder);
     if (!eng) {
         return 0;
     }
@@ -116,7 +134,9 @@ size_t aws_huffman_get_encoded_length(struct aws_huffman_encoder *encoder, struc
     item.in_len = to_encode.len;
     item.out_capacity = UINT64_MAX; /* pending overflow bits are not part of the answer (huffman.c:107-129) */
     struct hufd_enc_result raw;
-    if (aws_huffman_amd_engine_encode_host(eng, &item, to_encode.ptr, NULL, true, &raw)) {
+    const int failed = aws_huffman_amd_engine_encode_host(eng, &item, to_encode.ptr, NULL, true, &raw);
+    engine_release(eng);
+    if (failed) {
         return 0;
     }
     return (size_t)((raw.total_bits + 7) / 8);
@@ -148,7 +168,7 @@ int aws_huffman_encode(
         return aws_raise_error(AWS_ERROR_SHORT_BUFFER);
     }
 
-    struct aws_huffman_amd_engine *eng = engine_for(encoder->coder);
+    struct aws_huffman_amd_engine *eng = engine_acquire(encoder->coder);
     if (!eng) {
         return AWS_OP_ERR;
     }
@@ -161,7 +181,9 @@ int aws_huffman_encode(
     item.eos_padding = encoder->eos_padding;
 
     struct hufd_enc_result raw;
-    if (aws_huffman_amd_engine_encode_host(eng, &item, to_encode->ptr, output->buffer + output->len, false, &raw)) {
+    const int failed = aws_huffman_amd_engine_encode_host(eng, &item, to_encode->ptr, output->buffer + output->len, false, &raw);
+    engine_release(eng);
+    if (failed) {
         return AWS_OP_ERR;
     }
     struct aws_huffman_amd_encode_result res;
@@ -193,11 +215,16 @@ int aws_huffman_decode(
     const uint32_t held = decoder->num_bits;                 /* read-ahead bits from earlier calls */
     const uint64_t stream_bits = held + (uint64_t)to_decode->len * 8; /* huffman.c:228 */
 
-    struct aws_huffman_amd_engine *eng = engine_for(decoder->coder);
+    if (stream_bits == 0) {
+        /* nothing to look at: the reference returns success whatever the coder says (huffman.c:240-255) */
+        return AWS_OP_SUCCESS;
+    }
+    struct aws_huffman_amd_engine *eng = engine_acquire(decoder->coder);
     if (!eng) {
         return AWS_OP_ERR;
     }
     if (!eng->can_decode) {
+        engine_release(eng);
         return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION);
     }
 
@@ -221,12 +248,9 @@ int aws_huffman_decode(
     const uint64_t device_cap = grow ? UINT64_MAX : room;
 
     struct aws_huffman_amd_decode_result res;
-    if (stream_bits == 0) {
-        /* nothing to look at: the reference returns success whatever the coder says (huffman.c:240-255) */
-        return AWS_OP_SUCCESS;
-    }
     if (aws_huffman_amd_engine_decode_host(
             eng, carry, carry_bytes, first_bit, to_decode->ptr, to_decode->len, device_cap, &res)) {
+        engine_release(eng);
         return AWS_OP_ERR;
     }
 
@@ -246,16 +270,19 @@ int aws_huffman_decode(
             const int rc = aws_byte_buf_reserve_relative(output, before);
             output->len = keep_len;
             if (rc) {
+                engine_release(eng);
                 return AWS_OP_ERR;
             }
         }
     }
     if (to_store) {
         if (aws_huffman_amd_engine_fetch_output(eng, output->buffer + output->len, to_store)) {
+            engine_release(eng);
             return AWS_OP_ERR;
         }
         output->len += to_store;
     }
+    engine_release(eng); /* the symbols are out of its staging buffer */
 
     /*
      * Streaming state after the call: with C stream bits consumed by

@@ -233,6 +233,40 @@ def transitive_helpers(w):
     assert lib.huffman_test_transitive_chunked(hp, text[:90], 90, 0, 7, C.byref(msg)) == 0, msg.value
 
 
+# ----------------------------------------------------------------------------- scenario: threads sharing a coder
+def shared_coder_threads(w, n_threads=4, calls=60, seed=47):
+    """Distinct encoders/decoders on different threads with the SAME coder (the reference's generated coders are
+    function-static, so every connection of a process shares one): the calls meet inside one engine."""
+    import threading
+
+    rng = np.random.default_rng(seed)
+    jobs = []
+    for t in range(n_threads):
+        mine = []
+        for _ in range(calls):
+            data = inputs(rng, int(rng.choice([1, 15, 100, 700, 5000, 40000])), KINDS[t % 3])
+            mine.append((data, oracle_encode(w, data)))
+        jobs.append(mine)
+    errors = []
+
+    def run(mine):
+        try:
+            for data, want in mine:
+                got = w.product.encode_all(w.pcoder, data)
+                assert np.array_equal(got, want), "encode differs under threads"
+                r, back = w.product.decode_all(w.pcoder, want, data.size)
+                assert r.rc == 0 and np.array_equal(back, data), "decode differs under threads"
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(mine,)) for mine in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[0]
+
+
 # ----------------------------------------------------------------------------- scenario: streaming decode (input and output in pieces)
 def streaming_decode(w, sizes, seed=13):
     rng = np.random.default_rng(seed)

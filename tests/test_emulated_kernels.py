@@ -61,6 +61,10 @@ def test_transitive_helpers(world):
     pc.transitive_helpers(world)
 
 
+def test_shared_coder_threads(world):
+    pc.shared_coder_threads(world, calls=12)
+
+
 def test_foreign_coder_callbacks(world):
     pc.foreign_coder_callbacks(world)
 
