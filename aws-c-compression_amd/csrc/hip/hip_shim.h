@@ -19,6 +19,8 @@ const char *hufs_error_string(int error);
 
 void *hufs_malloc(size_t size); /* NULL on failure */
 void hufs_free(void *ptr);
+void *hufs_host_alloc(size_t size); /* page-locked host memory, NULL on failure */
+void hufs_host_free(void *ptr);
 int hufs_copy_h2d(void *dst, const void *src, size_t size, void *stream);
 int hufs_copy_d2h(void *dst, const void *src, size_t size, void *stream);
 int hufs_memset(void *dst, int byte, size_t size, void *stream);

@@ -36,6 +36,20 @@ void hufs_free(void *ptr) {
     }
 }
 
+void *hufs_host_alloc(size_t size) {
+    void *p = NULL;
+    if (hipHostMalloc(&p, size ? size : 1, 0) != hipSuccess) {
+        return NULL;
+    }
+    return p;
+}
+
+void hufs_host_free(void *ptr) {
+    if (ptr) {
+        (void)hipHostFree(ptr);
+    }
+}
+
 int hufs_copy_h2d(void *dst, const void *src, size_t size, void *stream) {
     if (size == 0) {
         return 0;

@@ -91,6 +91,13 @@ int hufk_init(void);
 uint32_t hufk_enc_image_words(uint32_t max_bits);
 int hufk_encode_launch(const struct hufk_encode_args *args, void *stream);
 int hufk_decode_launch(const struct hufk_decode_args *args, void *stream);
+/* one short item whose record already sits in device memory (the host-pointer calls' small-input road): one launch */
+int hufk_encode_one_tiny(
+    const struct hufd_tables *tables, const struct hufd_enc_item *item, const uint32_t *zero, const void *d_in, void *d_out,
+    struct hufd_enc_result *result, uint32_t length_only, void *stream);
+int hufk_decode_one_tiny(
+    const struct hufd_tables *tables, const struct hufd_dec_item *item, const uint32_t *zero, const void *d_in, void *d_out,
+    struct hufd_dec_item_state *state, struct hufd_dec_result *result, void *stream);
 int hufk_fill_splitmix64(void *dst, uint64_t len, uint64_t seed, void *stream);
 
 #ifdef __cplusplus

@@ -5157,6 +5157,30 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
     return (int)hipGetLastError();
 }
 
+int hufk_encode_one_tiny(
+    const struct hufd_tables *tables, const struct hufd_enc_item *item, const uint32_t *zero, const void *d_in, void *d_out,
+    struct hufd_enc_result *result, uint32_t length_only, void *stream) {
+    hipLaunchKernelGGL(
+        enc_tiny_kernel, dim3(1), dim3(kTinyThreads), 256 * sizeof(u64), (hipStream_t)stream, *tables, item, zero, 1u,
+        (const u8 *)d_in, (u8 *)d_out, result, length_only);
+    return (int)hipGetLastError();
+}
+
+int hufk_decode_one_tiny(
+    const struct hufd_tables *tables, const struct hufd_dec_item *item, const uint32_t *zero, const void *d_in, void *d_out,
+    struct hufd_dec_item_state *state, struct hufd_dec_result *result, void *stream) {
+    if (tables->deep_entries) {
+        hipLaunchKernelGGL(
+            dec_tiny_kernel<true>, dim3(1), dim3(kTinyDecThreads), tables->deep_entries * sizeof(u32), (hipStream_t)stream,
+            *tables, item, zero, 1u, (const u8 *)d_in, (u8 *)d_out, state, result);
+    } else {
+        hipLaunchKernelGGL(
+            dec_tiny_kernel<false>, dim3(1), dim3(kTinyDecThreads), (1u << tables->lut_bits) * sizeof(u16),
+            (hipStream_t)stream, *tables, item, zero, 1u, (const u8 *)d_in, (u8 *)d_out, state, result);
+    }
+    return (int)hipGetLastError();
+}
+
 int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a->n_items == 0) {

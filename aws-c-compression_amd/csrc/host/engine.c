@@ -263,6 +263,8 @@ void aws_huffman_amd_engine_destroy(struct aws_huffman_amd_engine *eng) {
     }
     hufs_free(eng->one_in);
     hufs_free(eng->one_out);
+    hufs_free(eng->mini_dev);
+    hufs_host_free(eng->mini_host);
     hufs_free(eng->d_enc_table);
     hufs_free(eng->d_dec_lut);
     hufs_free(eng->d_deep_lut);
@@ -1076,6 +1078,88 @@ static int one_shot_reserve(struct aws_huffman_amd_engine *eng, size_t in_bytes,
     return AWS_OP_SUCCESS;
 }
 
+/*
+ * Header-sized inputs (what the reference's HPACK consumer passes, one call per field): the item record and
+ * the input go up in ONE copy from a page-locked block, ONE thread does the work (enc_tiny / dec_tiny), the
+ * result record and the output come back in ONE copy.  The general road costs a plan upload, four small
+ * pageable copies, two or three launches and two synchronisations for the same call.
+ */
+enum {
+    MINI_MAX_IN = 128,     /* symbols to encode / encoded bytes to decode (carried bytes included) */
+    MINI_IN_AT = 64,       /* block layout: [0] item record, [64] input, [1024] zero word, [1088] scratch, */
+    MINI_ZERO_AT = 1024,
+    MINI_SCRATCH_AT = 1088,
+    MINI_RESULT_AT = 2048, /* [2048] result record, [2112] output */
+    MINI_OUT_AT = 2112,
+    MINI_BLOCK = 4096,
+    MINI_MAX_OUT = MINI_BLOCK - MINI_OUT_AT
+};
+
+static bool mini_ready(struct aws_huffman_amd_engine *eng) {
+    if (eng->mini_host && eng->mini_dev) {
+        return true;
+    }
+    hufs_set_device(eng->device);
+    if (!eng->mini_host) {
+        eng->mini_host = hufs_host_alloc(MINI_BLOCK);
+    }
+    if (!eng->mini_dev) {
+        eng->mini_dev = hufs_malloc(MINI_BLOCK);
+        if (eng->mini_dev && (hufs_memset(eng->mini_dev, 0, MINI_BLOCK, eng->stream) || hufs_stream_sync(eng->stream))) {
+            hufs_free(eng->mini_dev);
+            eng->mini_dev = NULL;
+        }
+    }
+    return eng->mini_host && eng->mini_dev;
+}
+
+static int mini_encode(
+    struct aws_huffman_amd_engine *eng,
+    const struct aws_huffman_amd_encode_item *item,
+    uint64_t dev_out,
+    const uint8_t *host_in,
+    uint8_t *host_out,
+    bool length_only,
+    struct hufd_enc_result *raw) {
+
+    struct hufd_enc_item rec;
+    memset(&rec, 0, sizeof(rec));
+    rec.in_off = MINI_IN_AT;
+    rec.in_len = item->in_len;
+    rec.out_off = MINI_OUT_AT;
+    rec.out_cap = dev_out;
+    rec.ovf_bits = item->overflow_in.num_bits;
+    rec.ovf_pattern = rec.ovf_bits >= 32 ? item->overflow_in.pattern
+                                         : item->overflow_in.pattern & ((1u << rec.ovf_bits) - 1u);
+    rec.eos_padding = item->eos_padding;
+    rec.tiny = 1;
+    memcpy(eng->mini_host, &rec, sizeof(rec));
+    memcpy(eng->mini_host + MINI_IN_AT, host_in, item->in_len);
+    hufs_set_device(eng->device);
+    int err = hufs_copy_h2d(eng->mini_dev, eng->mini_host, MINI_IN_AT + item->in_len, eng->stream);
+    if (!err) {
+        err = hufk_encode_one_tiny(
+            &eng->tables, (const struct hufd_enc_item *)eng->mini_dev, (const uint32_t *)(eng->mini_dev + MINI_ZERO_AT),
+            eng->mini_dev, eng->mini_dev, (struct hufd_enc_result *)(eng->mini_dev + MINI_RESULT_AT), length_only,
+            eng->stream);
+    }
+    if (!err) {
+        const size_t back = (MINI_OUT_AT - MINI_RESULT_AT) + (length_only ? 0 : dev_out);
+        err = hufs_copy_d2h(eng->mini_host + MINI_RESULT_AT, eng->mini_dev + MINI_RESULT_AT, back, eng->stream);
+    }
+    if (!err) {
+        err = hufs_stream_sync(eng->stream);
+    }
+    if (err) {
+        return raise_hip(err);
+    }
+    memcpy(raw, eng->mini_host + MINI_RESULT_AT, sizeof(*raw));
+    if (!length_only && raw->produced) {
+        memcpy(host_out, eng->mini_host + MINI_OUT_AT, raw->produced);
+    }
+    return AWS_OP_SUCCESS;
+}
+
 int aws_huffman_amd_engine_encode_host(
     struct aws_huffman_amd_engine *eng,
     const struct aws_huffman_amd_encode_item *item_in,
@@ -1090,6 +1174,10 @@ int aws_huffman_amd_engine_encode_host(
     const uint64_t dev_out = item.out_capacity < worst ? item.out_capacity : worst;
     item.in_offset = 0;
     item.out_offset = 0;
+    if (item.in_len <= MINI_MAX_IN && (item.in_len || item.overflow_in.num_bits) && item.overflow_in.num_bits <= 32 &&
+        dev_out <= MINI_MAX_OUT && mini_ready(eng)) {
+        return mini_encode(eng, &item, dev_out, host_in, host_out, length_only, raw);
+    }
     if (one_shot_reserve(eng, item.in_len + 16, length_only ? 0 : dev_out + 16)) {
         return AWS_OP_ERR;
     }
@@ -1142,6 +1230,52 @@ int aws_huffman_amd_engine_decode_host(
     const uint64_t stream_bits = (carry_bytes + in_len) * 8 - first_bit;
     const uint64_t most_symbols = stream_bits / eng->tables.min_bits;
     const uint64_t dev_out = out_capacity < most_symbols ? out_capacity : most_symbols;
+    eng->mini_output = false;
+    if (carry_bytes + in_len <= MINI_MAX_IN && carry_bytes + in_len > 0 && dev_out <= MINI_MAX_OUT && mini_ready(eng)) {
+        struct hufd_dec_item rec;
+        memset(&rec, 0, sizeof(rec));
+        rec.in_off = MINI_IN_AT + 16 - carry_bytes;
+        rec.in_len = carry_bytes + in_len;
+        rec.out_off = MINI_OUT_AT;
+        rec.out_cap = dev_out;
+        rec.first_bit = first_bit;
+        rec.tiny = 1;
+        memcpy(eng->mini_host, &rec, sizeof(rec));
+        memcpy(eng->mini_host + MINI_IN_AT + 16 - carry_bytes, carry, carry_bytes);
+        memcpy(eng->mini_host + MINI_IN_AT + 16, host_in, in_len);
+        hufs_set_device(eng->device);
+        int e = hufs_copy_h2d(eng->mini_dev, eng->mini_host, MINI_IN_AT + 16 + in_len, eng->stream);
+        if (!e) {
+            e = hufk_decode_one_tiny(
+                &eng->tables, (const struct hufd_dec_item *)eng->mini_dev, (const uint32_t *)(eng->mini_dev + MINI_ZERO_AT),
+                eng->mini_dev, eng->mini_dev, (struct hufd_dec_item_state *)(eng->mini_dev + MINI_SCRATCH_AT),
+                (struct hufd_dec_result *)(eng->mini_dev + MINI_RESULT_AT), eng->stream);
+        }
+        if (!e) {
+            e = hufs_copy_d2h(
+                eng->mini_host + MINI_RESULT_AT, eng->mini_dev + MINI_RESULT_AT, (MINI_OUT_AT - MINI_RESULT_AT) + dev_out,
+                eng->stream);
+        }
+        if (!e) {
+            e = hufs_stream_sync(eng->stream);
+        }
+        if (e) {
+            return raise_hip(e);
+        }
+        struct hufd_dec_result raw;
+        memcpy(&raw, eng->mini_host + MINI_RESULT_AT, sizeof(raw));
+        struct aws_huffman_amd_decode_item as_item;
+        memset(&as_item, 0, sizeof(as_item));
+        as_item.in_len = carry_bytes + in_len;
+        as_item.first_bit = first_bit;
+        as_item.out_capacity = dev_out;
+        aws_huffman_amd_decode_result_from_raw(&raw, &as_item, result);
+        eng->mini_output = true;
+        if (result->error == AWS_ERROR_SHORT_BUFFER && dev_out < out_capacity) {
+            return aws_raise_error(AWS_ERROR_INVALID_STATE);
+        }
+        return AWS_OP_SUCCESS;
+    }
     if (one_shot_reserve(eng, 16 + in_len + 16, dev_out + 16)) {
         return AWS_OP_ERR;
     }
@@ -1186,6 +1320,10 @@ int aws_huffman_amd_engine_decode_host(
 }
 
 int aws_huffman_amd_engine_fetch_output(struct aws_huffman_amd_engine *eng, uint8_t *host_out, uint64_t size) {
+    if (eng->mini_output) {
+        memcpy(host_out, eng->mini_host + MINI_OUT_AT, size); /* came back with the result record */
+        return AWS_OP_SUCCESS;
+    }
     int err = hufs_copy_d2h(host_out, eng->one_out, size, eng->stream);
     if (!err) {
         err = hufs_stream_sync(eng->stream);

@@ -40,6 +40,10 @@ struct aws_huffman_amd_engine {
     size_t one_out_cap;
     struct aws_huffman_amd_encode_plan *one_enc;
     struct aws_huffman_amd_decode_plan *one_dec;
+    /* ... and of its road for header-sized inputs: one block up, one launch, one block back (MINI_* in engine.c) */
+    uint8_t *mini_host; /* page-locked */
+    uint8_t *mini_dev;
+    bool mini_output; /* the last decode left its symbols in mini_host */
 };
 
 struct aws_huffman_amd_encode_plan {

@@ -362,6 +362,14 @@ inline hipError_t hipFree(void *p) {
     std::free(p);
     return hipSuccess;
 }
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) {
+    *p = std::malloc(n ? n : 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+inline hipError_t hipHostFree(void *p) {
+    std::free(p);
+    return hipSuccess;
+}
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) {
     std::memcpy(d, s, n);
     return hipSuccess;
