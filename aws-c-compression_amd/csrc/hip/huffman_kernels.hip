@@ -5181,6 +5181,21 @@ int hufk_decode_one_tiny(
     return (int)hipGetLastError();
 }
 
+int hufk_decode_one_coop(
+    const struct hufd_tables *tables, const struct hufd_dec_item *item, const uint32_t *zero, const void *d_in, void *d_out,
+    struct hufd_dec_item_state *state, struct hufd_dec_result *result, void *stream) {
+    if (tables->deep_entries) {
+        hipLaunchKernelGGL(
+            dec_deep_kernel<true>, dim3(1), dim3(kDeepThreads), sizeof(deep_shared) + tables->deep_entries * sizeof(u32),
+            (hipStream_t)stream, *tables, item, zero, kDeepLaneBytes, (const u8 *)d_in, (u8 *)d_out, state, result);
+    } else {
+        hipLaunchKernelGGL(
+            dec_deep_kernel<false>, dim3(1), dim3(kCoopThreads), sizeof(deep_shared) + (1u << tables->lut_bits) * sizeof(u16),
+            (hipStream_t)stream, *tables, item, zero, 0u, (const u8 *)d_in, (u8 *)d_out, state, result);
+    }
+    return (int)hipGetLastError();
+}
+
 int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a->n_items == 0) {

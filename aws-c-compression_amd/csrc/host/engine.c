@@ -1085,7 +1085,7 @@ static int one_shot_reserve(struct aws_huffman_amd_engine *eng, size_t in_bytes,
  * pageable copies, two or three launches and two synchronisations for the same call.
  */
 enum {
-    MINI_MAX_IN = 128,     /* symbols to encode / encoded bytes to decode (carried bytes included) */
+    MINI_MAX_IN = 128,     /* symbols to encode; encoded bytes (carried ones included) one thread decodes: HUFD_DEC_COOP_BYTES go this way */
     MINI_IN_AT = 64,       /* block layout: [0] item record, [64] input, [1024] zero word, [1088] scratch, */
     MINI_ZERO_AT = 1024,
     MINI_SCRATCH_AT = 1088,
@@ -1231,7 +1231,7 @@ int aws_huffman_amd_engine_decode_host(
     const uint64_t most_symbols = stream_bits / eng->tables.min_bits;
     const uint64_t dev_out = out_capacity < most_symbols ? out_capacity : most_symbols;
     eng->mini_output = false;
-    if (carry_bytes + in_len <= MINI_MAX_IN && carry_bytes + in_len > 0 && dev_out <= MINI_MAX_OUT && mini_ready(eng)) {
+    if (carry_bytes + in_len <= HUFD_DEC_COOP_BYTES && carry_bytes + in_len > 0 && dev_out <= MINI_MAX_OUT && mini_ready(eng)) {
         struct hufd_dec_item rec;
         memset(&rec, 0, sizeof(rec));
         rec.in_off = MINI_IN_AT + 16 - carry_bytes;
@@ -1246,7 +1246,8 @@ int aws_huffman_amd_engine_decode_host(
         hufs_set_device(eng->device);
         int e = hufs_copy_h2d(eng->mini_dev, eng->mini_host, MINI_IN_AT + 16 + in_len, eng->stream);
         if (!e) {
-            e = hufk_decode_one_tiny(
+            /* a lone thread up to MINI_MAX_IN bytes, a wave (a workgroup with long codes) above */
+            e = (carry_bytes + in_len <= MINI_MAX_IN ? hufk_decode_one_tiny : hufk_decode_one_coop)(
                 &eng->tables, (const struct hufd_dec_item *)eng->mini_dev, (const uint32_t *)(eng->mini_dev + MINI_ZERO_AT),
                 eng->mini_dev, eng->mini_dev, (struct hufd_dec_item_state *)(eng->mini_dev + MINI_SCRATCH_AT),
                 (struct hufd_dec_result *)(eng->mini_dev + MINI_RESULT_AT), eng->stream);
