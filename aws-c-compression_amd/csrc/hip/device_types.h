@@ -26,7 +26,7 @@
 #define HUFD_DEC_LANES 256u
 #define HUFD_DEC_CHUNK_BYTES (HUFD_DEC_SUB_BYTES * HUFD_DEC_LANES)
 #define HUFD_TINY_MANY_BYTES 2048u  /* one thread per item up to this many symbols (encode), or encoded bytes x 2 / 3 (decode), when a plan holds at least ... */
-#define HUFD_TINY_MANY_ITEMS 65536u /* ... this many items that short: enough threads to fill the chip */
+#define HUFD_TINY_MANY_ITEMS 16384u /* ... this many items that short: enough threads to fill the chip */
 #define HUFD_TINY_FEW_ITEMS 1024u   /* with fewer items than this up to HUFD_*_TINY_BYTES a plan is about latency: one thread ... */
 #define HUFD_TINY_FEW_BYTES 128u    /* ... only walks items up to this long (a lone thread takes ~0.4 us a symbol) */
 #define HUFD_DEC_MAX_STATES 16u
