@@ -25,10 +25,13 @@
 #define HUFD_DEC_SUB_BITS (HUFD_DEC_SUB_BYTES * 8u)
 #define HUFD_DEC_LANES 256u
 #define HUFD_DEC_CHUNK_BYTES (HUFD_DEC_SUB_BYTES * HUFD_DEC_LANES)
-#define HUFD_TINY_MANY_BYTES 2048u  /* one thread per item up to this many symbols (encode), or encoded bytes x 2 / 3 (decode), when a plan holds at least ... */
-#define HUFD_TINY_MANY_ITEMS 16384u /* ... this many items that short: enough threads to fill the chip */
-#define HUFD_TINY_FEW_ITEMS 1024u   /* with fewer items than this up to HUFD_*_TINY_BYTES a plan is about latency: one thread ... */
-#define HUFD_TINY_FEW_BYTES 128u    /* ... only walks items up to this long (a lone thread takes ~0.4 us a symbol) */
+/* One thread per item pays when the walk of the longest such item (a lone thread needs ~0.5 us a symbol) is
+ * shorter than the segments / chunks of all of them (~33 / ~74 ns an item): the plan takes the largest of these
+ * length classes that holds at least HUFD_*_TINY_PER_BYTE items per byte of its longest item. */
+#define HUFD_TINY_MANY_BYTES 2048u /* symbols (encode); encoded bytes x 2 / 3 (decode) */
+#define HUFD_ENC_TINY_PER_BYTE 18u
+#define HUFD_DEC_TINY_PER_BYTE 6u
+#define HUFD_TINY_FEW_BYTES 128u   /* the class that always goes to a thread */
 #define HUFD_DEC_MAX_STATES 16u
 #define HUFD_DEC_CP_ROWS 4u /* per sub-chunk: three checkpoints of the walk + the merged-state mask */
 #define HUFD_DEC_MAX_LUT_BITS 12u

@@ -326,18 +326,22 @@ static bool enc_item_is_tiny(const struct aws_huffman_amd_encode_item *it, uint6
     return it->in_len <= limit && (it->in_len > 0 || it->overflow_in.num_bits);
 }
 
-/* one thread per item pays for longer items too when there are enough of them to fill the chip with threads */
+/* the longest item a lone thread takes in this plan: see HUFD_ENC_TINY_PER_BYTE */
 static uint64_t enc_tiny_limit(const struct aws_huffman_amd_encode_item *items, size_t n_items) {
-    size_t many = 0, tiny = 0;
-    for (size_t i = 0; i < n_items; ++i) {
-        many += items[i].in_len <= HUFD_TINY_MANY_BYTES;
-        tiny += items[i].in_len <= HUFD_ENC_TINY_BYTES;
+    static const uint64_t classes[2] = {HUFD_TINY_MANY_BYTES, HUFD_ENC_TINY_BYTES};
+    for (int c = 0; c < 2; ++c) {
+        uint64_t count = 0, longest = 0;
+        for (size_t i = 0; i < n_items; ++i) {
+            if (items[i].in_len <= classes[c]) {
+                ++count;
+                longest = items[i].in_len > longest ? items[i].in_len : longest;
+            }
+        }
+        if (longest > HUFD_TINY_FEW_BYTES && count >= HUFD_ENC_TINY_PER_BYTE * longest) {
+            return classes[c];
+        }
     }
-    if (many >= HUFD_TINY_MANY_ITEMS) {
-        return HUFD_TINY_MANY_BYTES;
-    }
-    /* a handful of items is about latency, and a lone thread is slow: it only gets the shortest ones */
-    return tiny < HUFD_TINY_FEW_ITEMS ? HUFD_TINY_FEW_BYTES : HUFD_ENC_TINY_BYTES;
+    return HUFD_TINY_FEW_BYTES;
 }
 
 static uint64_t enc_item_segments(const struct aws_huffman_amd_encode_item *it, uint64_t tiny_limit) {
@@ -710,18 +714,22 @@ static bool dec_item_is_tiny(const struct aws_huffman_amd_decode_item *it, uint6
     return it->in_len > 0 && it->in_len <= limit;
 }
 
-/* (longer ones too when there are enough of them to fill the chip with threads) */
+/* the longest item a lone thread takes in this plan: see HUFD_DEC_TINY_PER_BYTE */
 static uint64_t dec_tiny_limit(const struct aws_huffman_amd_decode_item *items, size_t n_items) {
-    size_t many = 0, tiny = 0;
-    for (size_t i = 0; i < n_items; ++i) {
-        many += items[i].in_len <= (HUFD_TINY_MANY_BYTES * 3 / 2);
-        tiny += items[i].in_len <= HUFD_DEC_TINY_BYTES;
+    static const uint64_t classes[2] = {HUFD_TINY_MANY_BYTES * 3 / 2, HUFD_DEC_TINY_BYTES};
+    for (int c = 0; c < 2; ++c) {
+        uint64_t count = 0, longest = 0;
+        for (size_t i = 0; i < n_items; ++i) {
+            if (items[i].in_len <= classes[c]) {
+                ++count;
+                longest = items[i].in_len > longest ? items[i].in_len : longest;
+            }
+        }
+        if (longest > HUFD_TINY_FEW_BYTES && count >= HUFD_DEC_TINY_PER_BYTE * longest) {
+            return classes[c];
+        }
     }
-    if (many >= HUFD_TINY_MANY_ITEMS) {
-        return HUFD_TINY_MANY_BYTES * 3 / 2;
-    }
-    /* a handful of items is about latency: a wave (dec_deep) takes over from the lone thread early */
-    return tiny < HUFD_TINY_FEW_ITEMS ? HUFD_TINY_FEW_BYTES : HUFD_DEC_TINY_BYTES;
+    return HUFD_TINY_FEW_BYTES;
 }
 
 static bool dec_item_is_deep(

@@ -670,7 +670,7 @@ def batched_device_api(w, n_items=9, seed=18, item_len=16384, engine=None):
         eng.close()
 
 
-def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False, max_len=560):
+def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False, max_len=560, edge_lens=True):
     """Items either side of HUFD_ENC_TINY_BYTES (512 symbols; one thread each below it), with every kind
     of stop: roomy, exact, one byte short, cut anywhere, no room at all, carried overflow bits that fit,
     fill the output exactly or do not fit, symbols without a code."""
@@ -678,7 +678,8 @@ def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False, max_le
     own = engine is None or holes
     eng = harness.Engine(w.product.lib, w.pcoder_holes if holes else w.pcoder) if own else engine
     oc = w.ocoder_holes if holes else w.ocoder
-    lens = [0, 0, 1, 2, 3, 511, 512, 513, 600] + [int(rng.integers(0, max_len)) for _ in range(n_items - 9)]
+    lens = ([0, 0, 1, 2, 3, 511, 512, 513, 600] if edge_lens else [0, 0, 1, 2, 3, 127, 128, 129, max_len - 1]) + [
+        int(rng.integers(0, max_len)) for _ in range(n_items - 9)]
     blobs = []
     for i, n in enumerate(lens):
         b = inputs(rng, n, KINDS[i % 4])

@@ -75,13 +75,14 @@ def test_batched_device_api(world):
 
 def test_tiny_encode_items(world):
     pc.tiny_encode_items(world, n_items=400)  # a handful: one thread only up to 128 symbols, segments above
-    pc.tiny_encode_items(world, n_items=1100, seed=40)  # many: one thread up to 512
+    # 18 items per byte of the longest: one thread each (the GPU tests do this with items of up to 512 and 1200 symbols)
+    pc.tiny_encode_items(world, n_items=3700, seed=40, max_len=200, edge_lens=False)
     pc.tiny_encode_items(world, n_items=400, seed=38, holes=True)
 
 
 def test_tiny_decode_items(world):
     pc.tiny_decode_items(world, n_items=400)  # a handful: one thread up to 128 bytes, one wave up to 768, chunks above
-    pc.tiny_decode_items(world, n_items=1100, seed=44)  # many: one thread up to 512
+    pc.tiny_decode_items(world, n_items=3300, seed=44)  # 6 items per byte of the longest: one thread up to 512
     pc.tiny_decode_items(world, n_items=400, seed=42, profile="hpack_lengths")
 
 

@@ -97,18 +97,21 @@ def test_batched_device_api(world, engine):
 
 
 def test_tiny_encode_items(world, engine):
-    pc.tiny_encode_items(world, engine=engine)
+    pc.tiny_encode_items(world, engine=engine)  # a handful: one thread up to 128 symbols, segments above
     pc.tiny_encode_items(world, seed=38, holes=True)
+    pc.tiny_encode_items(world, n_items=11000, seed=36, engine=engine)  # one thread up to 512
+    pc.tiny_encode_items(world, n_items=11000, seed=35, holes=True)
 
 
 def test_many_short_items_take_one_thread_each(world, engine):
-    """HUFD_TINY_MANY_ITEMS items of at most HUFD_TINY_MANY_BYTES: the plan gives all of them a thread each."""
+    """Enough items of at most HUFD_TINY_MANY_BYTES (HUFD_*_TINY_PER_BYTE per byte of the longest): a thread each."""
     pc.tiny_encode_items(world, n_items=66000, seed=39, engine=engine, max_len=1200)
     pc.tiny_decode_items(world, n_items=66000, seed=43, engine=engine, max_len=1000)
 
 
 def test_tiny_decode_items(world, engine):
-    pc.tiny_decode_items(world, engine=engine)
+    pc.tiny_decode_items(world, engine=engine)  # a handful: one thread up to 128 bytes, one wave up to 768
+    pc.tiny_decode_items(world, n_items=4000, seed=45, engine=engine)  # one thread up to 512
     pc.tiny_decode_items(world, seed=42, profile="hpack_lengths")
 
 
