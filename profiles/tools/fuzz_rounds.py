@@ -26,6 +26,8 @@ rounds = [
     ("tiny_encode_items holes", lambda s: pc.tiny_encode_items(w, n_items=600, seed=s, holes=True)),
     ("tiny_decode_items", lambda s: pc.tiny_decode_items(w, n_items=600, seed=s, engine=eng)),
     ("tiny_decode_items hpack", lambda s: pc.tiny_decode_items(w, n_items=600, seed=s, profile="hpack_lengths")),
+    ("tiny_encode_items many", lambda s: pc.tiny_encode_items(w, n_items=11000, seed=s, engine=eng) if s % 4 == 0 else None),
+    ("tiny_decode_items many", lambda s: pc.tiny_decode_items(w, n_items=4000, seed=s, engine=eng) if s % 4 == 1 else None),
     ("batched_device_api", lambda s: pc.batched_device_api(w, n_items=24, seed=s, engine=eng)),
     ("batched_device_api 3000", lambda s: pc.batched_device_api(w, n_items=14, seed=s, item_len=3000, engine=eng)),
     ("garbage_decode", lambda s: pc.garbage_decode(w, seed=s, rounds=40)),
