@@ -4379,7 +4379,11 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
     const u32 mis = (u32)((uintptr_t)out_ptr & 15u);
     const row_walk rw(LB, tb.max_bits);
     u32 st[kEmitChains];
-    u8 *dst[kEmitChains];
+    /* where a chain's next symbol goes, as a byte offset into the workgroup's LDS record: a pointer here turns
+     * the stores into flat ones with 64-bit address arithmetic */
+    u8 *const lds_bytes = reinterpret_cast<u8 *>(&sh);
+    const u32 stage_at = (u32)(reinterpret_cast<u8 *>(sh.stage) - lds_bytes), dump_at = (u32)(sh.dump - lds_bytes);
+    u32 dst[kEmitChains];
     bool idle[kEmitChains]; /* a chain with nothing to emit still walks (the two go in step): over zeros, into the dump */
     bool extend = false;
 #pragma unroll
@@ -4390,7 +4394,7 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
         const bool mine = whole[ch] && (q == 0 || (my_cp[ch] & 0x8000u) != 0);
         const u32 first = q ? lane_n - (my_cp[ch] & 0x7FFu) : 0u;
         st[ch] = rw.state_at(q ? (my_cp[ch] >> 11) & 15u : entry_state[ch], 0);
-        dst[ch] = mine ? sh.stage + mis + sh.lane_base[lanes[ch]] + first : sh.dump;
+        dst[ch] = mine ? stage_at + mis + sh.lane_base[lanes[ch]] + first : dump_at;
         idle[ch] = !mine;
         /* only sub-chunk 0's first checkpoint can be missing (its head is not known when dec_sync_fast runs) */
         if (ch == 0) {
@@ -4414,7 +4418,7 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
             }
 #pragma unroll
             for (u32 ch = 0; ch < kEmitChains; ++ch) {
-                *dst[ch]++ = (u8)(e[ch] >> 16);
+                lds_bytes[dst[ch]++] = (u8)(e[ch] >> 16);
                 st[ch] += e[ch];
             }
         }
@@ -4422,13 +4426,13 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
         for (u32 ch = 0; ch < kEmitChains; ++ch) {
             while ((st[ch] & 0xFFFFu) > rw.thr) {
                 const u32 e = *reinterpret_cast<const u32 *>(lut + ((u32)(pair[ch] >> (st[ch] & 63u)) & rw.mask));
-                *dst[ch]++ = (u8)(e >> 16);
+                lds_bytes[dst[ch]++] = (u8)(e >> 16);
                 st[ch] += e;
             }
             st[ch] += 32u;
             /* an idle chain starts every row afresh: whatever it decodes, its state and its writes stay in bounds */
             st[ch] = idle[ch] ? rw.state_at(0, 0) : st[ch];
-            dst[ch] = idle[ch] ? sh.dump : dst[ch];
+            dst[ch] = idle[ch] ? dump_at : dst[ch];
         }
     }
     if (extend) {
@@ -4440,7 +4444,7 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
             const u64 pair = ((u64)hi << 32) | lo;
             while ((st[0] & 0xFFFFu) > rw.thr) {
                 const u32 e = *reinterpret_cast<const u32 *>(lut + ((u32)(pair >> (st[0] & 63u)) & rw.mask));
-                *dst[0]++ = (u8)(e >> 16);
+                lds_bytes[dst[0]++] = (u8)(e >> 16);
                 st[0] += e;
             }
             st[0] += 32u;
@@ -4748,7 +4752,10 @@ __device__ __forceinline__ void dec_emit_dense_chunk(
         u8 *out_ptr = d_out + it.out_off + cbase + base_sym;
         const u32 mis = (u32)((uintptr_t)out_ptr & 15u);
         u32 st[kEmitChains];
-        u8 *dst[kEmitChains];
+        /* (byte offsets into the workgroup's LDS record, as in dec_emit_fast: LDS stores, 32-bit arithmetic) */
+        u8 *const lds_bytes = reinterpret_cast<u8 *>(&sh);
+        const u32 stage_at = (u32)(reinterpret_cast<u8 *>(sh.stage) - lds_bytes), dump_at = (u32)(sh.dump - lds_bytes);
+        u32 dst[kEmitChains];
         bool idle[kEmitChains]; /* a chain with nothing to emit still walks (the two go in step), into the dump */
         bool in_pass[kEmitChains];
         bool extend = false;
@@ -4761,7 +4768,7 @@ __device__ __forceinline__ void dec_emit_dense_chunk(
             const bool mine = in_pass[ch] && whole[ch] && (q == 0 || (my_cp[ch] & 0x8000u) != 0);
             const u32 first = q ? lane_n - (my_cp[ch] & 0x7FFu) : 0u;
             st[ch] = rw.state_at(q ? (my_cp[ch] >> 11) & 15u : entry_state[ch], 0);
-            dst[ch] = mine ? sh.stage + mis + (sh.lane_base[lanes[ch]] - base_sym) + first : sh.dump;
+            dst[ch] = mine ? stage_at + mis + (sh.lane_base[lanes[ch]] - base_sym) + first : dump_at;
             idle[ch] = !mine;
             /* only sub-chunk 0's first checkpoint can be missing (its head is not known when dec_sync_fast runs) */
             if (ch == 0) {
@@ -4783,7 +4790,7 @@ __device__ __forceinline__ void dec_emit_dense_chunk(
                 }
 #pragma unroll
                 for (u32 ch = 0; ch < kEmitChains; ++ch) {
-                    *dst[ch]++ = (u8)(e[ch] >> 16);
+                    lds_bytes[dst[ch]++] = (u8)(e[ch] >> 16);
                     st[ch] += e[ch];
                 }
             }
@@ -4791,13 +4798,13 @@ __device__ __forceinline__ void dec_emit_dense_chunk(
             for (u32 ch = 0; ch < kEmitChains; ++ch) {
                 while ((st[ch] & 0xFFFFu) > rw.thr) {
                     const u32 e = *reinterpret_cast<const u32 *>(lut + ((u32)(pair[ch] >> (st[ch] & 63u)) & rw.mask));
-                    *dst[ch]++ = (u8)(e >> 16);
+                    lds_bytes[dst[ch]++] = (u8)(e >> 16);
                     st[ch] += e;
                 }
                 st[ch] += 32u;
                 /* an idle chain starts every row afresh: whatever it decodes, its state and its writes stay in bounds */
                 st[ch] = idle[ch] ? rw.state_at(0, 0) : st[ch];
-                dst[ch] = idle[ch] ? sh.dump : dst[ch];
+                dst[ch] = idle[ch] ? dump_at : dst[ch];
             }
         }
         if (extend) {
@@ -4808,7 +4815,7 @@ __device__ __forceinline__ void dec_emit_dense_chunk(
                 const u64 pair = ((u64)hi << 32) | lo;
                 while ((st[0] & 0xFFFFu) > rw.thr) {
                     const u32 e = *reinterpret_cast<const u32 *>(lut + ((u32)(pair >> (st[0] & 63u)) & rw.mask));
-                    *dst[0]++ = (u8)(e >> 16);
+                    lds_bytes[dst[0]++] = (u8)(e >> 16);
                     st[0] += e;
                 }
                 st[0] += 32u;
