@@ -610,16 +610,17 @@ __global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
     rs.total_bits = it.ovf_bits;
 
     /* aligned 16-byte reads of the symbols, handed out one at a time (what counts is the number of requests) */
-    const uintptr_t in_addr = reinterpret_cast<uintptr_t>(in);
+    const u32 lead = (u32)(reinterpret_cast<uintptr_t>(in) & 15u);
+    const uint4 *blocks = reinterpret_cast<const uint4 *>(in - lead);
     uint4 block = uint4{0, 0, 0, 0};
     auto symbol = [&](u32 k) -> u32 {
-        const uintptr_t a = in_addr + k;
-        if (k == 0 || (a & 15) == 0) {
-            block = *reinterpret_cast<const uint4 *>(a & ~(uintptr_t)15);
+        const u32 a = lead + k;
+        if (k == 0 || (a & 15u) == 0) {
+            block = blocks[a >> 4];
         }
-        const u32 w = (u32)(a >> 2) & 3u;
+        const u32 w = (a >> 2) & 3u;
         const u32 word = w == 0 ? block.x : (w == 1 ? block.y : (w == 2 ? block.z : block.w));
-        return (word >> ((a & 3) * 8)) & 0xFFu;
+        return (word >> ((a & 3u) * 8)) & 0xFFu;
     };
 
     if (length_only) {

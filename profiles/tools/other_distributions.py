@@ -40,14 +40,19 @@ for kind in ("printable", "short-codes", "one-symbol", "two-symbols"):
     (rc, err, symbols, _), = eng.decode_results(dp, 1)
     assert rc == 0 and symbols == n, (rc, err, symbols)
     assert np.array_equal(eng.download(d_back, n), data)
-    t0 = time.perf_counter()
+    # HIP events around the launches (host clocks around a few launches after a long host-side check pick up
+    # whatever the GPU's clocks are doing at that moment)
+    ev = eng.new_events(4)
+    t_enc = t_dec = 0.0
     for _ in range(5):
-        eng.encode_launch(ep, d_in, d_enc)
-    eng.sync()
-    t1 = time.perf_counter()
+        eng.encode_launch(ep, d_in, d_enc, events=ev)
+        eng.sync()
+        t_enc += eng.elapsed_ms(ev[0], ev[3]) / 5e3
     for _ in range(5):
-        eng.decode_launch(dp, d_enc, d_back)
-    eng.sync()
-    t2 = time.perf_counter()
+        eng.decode_launch(dp, d_enc, d_back, events=ev)
+        eng.sync()
+        t_dec += eng.elapsed_ms(ev[0], ev[3]) / 5e3
     print("%-12s %d MiB -> %.2f bits/symbol: encode %.0f GiB/s, decode %.0f GiB/s of symbols" % (
-        kind, n >> 20, e_len * 8 / n, n / 2**30 / ((t1 - t0) / 5), n / 2**30 / ((t2 - t1) / 5)))
+        kind, n >> 20, e_len * 8 / n, n / 2**30 / t_enc, n / 2**30 / t_dec), flush=True)
+    for p in (d_in, d_enc, d_back):
+        eng.free(p)
