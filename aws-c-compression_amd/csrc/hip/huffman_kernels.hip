@@ -4463,19 +4463,19 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
         const u32 lo = mis, hi = mis + (TAIL && n_full < HUFD_DEC_LANES ? sh.lane_base[n_full] : chunk_symbols);
         const u32 row_lo = (lo + 15) >> 4, row_hi = hi >> 4;
         if (row_lo <= row_hi) {
-            for (u32 b = lo + t; b < row_lo * 16; b += kEmitFastThreads) {
-                gbase[b] = sh.stage[b];
+            /* (fewer than 16 bytes in front of the first whole row and behind the last: one byte a thread at most) */
+            if (lo + t < row_lo * 16) {
+                gbase[lo + t] = sh.stage[lo + t];
             }
+#pragma unroll 2
             for (u32 r = row_lo + t; r < row_hi; r += kEmitFastThreads) {
                 *reinterpret_cast<uint4 *>(gbase + (u64)r * 16) = *reinterpret_cast<const uint4 *>(sh.stage + r * 16);
             }
-            for (u32 b = row_hi * 16 + t; b < hi; b += kEmitFastThreads) {
-                gbase[b] = sh.stage[b];
+            if (row_hi * 16 + t < hi) {
+                gbase[row_hi * 16 + t] = sh.stage[row_hi * 16 + t];
             }
-        } else {
-            for (u32 b = lo + t; b < hi; b += kEmitFastThreads) {
-                gbase[b] = sh.stage[b];
-            }
+        } else if (lo + t < hi) {
+            gbase[lo + t] = sh.stage[lo + t]; /* no whole row: fewer than 31 bytes */
         }
     }
     HUFD_STAMP(1, 5);
