@@ -49,6 +49,18 @@
 #define HUFD_SCAN_RUN_CHUNKS 256u /* a large decode item is scanned in runs of this many chunks, one workgroup per run */
 #define HUFD_SCAN_SUB_CHUNKS 16u  /* ... each folded in sub-runs of this many */
 
+/* look-back of the one-pass encoder: tiles per group, groups per round (the emulator build of tests/emu
+ * makes them small so that a short input crosses many boundaries) */
+#ifndef HUFD_OP_GROUP_TILES
+#define HUFD_OP_GROUP_TILES 64u
+#endif
+#ifndef HUFD_OP_ROUND_GROUPS
+#define HUFD_OP_ROUND_GROUPS 64u
+#endif
+#ifndef HUFD_OP_GROUP_STRIDE
+#define HUFD_OP_GROUP_STRIDE 8u /* u64 words from one group's counter to the next */
+#endif
+
 #define HUFD_NONE32 0xFFFFFFFFu
 
 /* encode item status */

@@ -32,14 +32,14 @@ struct hufk_encode_args {
     uint64_t *seg_bitoff; /* [n_segs] scratch */
     uint32_t *careful_list;  /* [2 * n_items] scratch: segments for the per-symbol packer */
     uint32_t *careful_count; /* [1] scratch */
-    /* single-pass path (codes of at most 16 bits): */
-    void *zero_block;        /* look-back granules [n_segs] u64, then ticket + error flag, then careful_count */
-    uint64_t zero_bytes;
-    uint64_t *lookback;      /* = zero_block */
-    uint32_t *ticket;        /* [2] inside zero_block */
+    /* one-pass path (every symbol coded, codes of 4 .. 15 bits): */
+    void *zero_block;        /* hufk_encode_zero_bytes(n_segs, n_items) bytes, zeroed by the launch: word 0 ticket,
+                              * word 1 "a wait ran out", word 2 careful_count, then the look-back tables */
     uint8_t *seg_unk_seen;   /* [n_segs] scratch */
     uint64_t *item_total;    /* [n_items] scratch */
-    uint32_t single_pass;    /* 1: fused count + look-back + pack kernel instead of count / scan / pack */
+    uint32_t single_pass;    /* 1: one kernel reads the symbols once (enc_onepass) instead of count / scan / pack */
+    uint32_t maybe_unshaped; /* the plan holds segments that are ragged, start with carried bits or lie at an input offset
+                              * that is no multiple of 16: the one-pass path counts those in a kernel of their own first */
     struct hufd_enc_item_state *states; /* [n_items] scratch */
     struct hufd_enc_result *results;    /* [n_items] */
     void **stage_events; /* NULL, or 4 hipEvent_t: before count, after count, after scan, after pack */
@@ -89,6 +89,9 @@ struct hufk_decode_args {
 int hufk_init(void);
 
 uint32_t hufk_enc_image_words(uint32_t max_bits);
+/* whether the one-pass encoder takes this coder, and the size of the block it wants zeroed per launch */
+int hufk_encode_one_pass_applies(const struct hufd_tables *tables);
+uint64_t hufk_encode_zero_bytes(uint32_t n_segs, uint32_t n_items);
 int hufk_encode_launch(const struct hufk_encode_args *args, void *stream);
 int hufk_decode_launch(const struct hufk_decode_args *args, void *stream);
 /* one short item whose record already sits in device memory (the host-pointer calls' small-input road): one launch */

@@ -54,8 +54,46 @@ __device__ unsigned long long *hufd_stamp_rows; /* [3][HUFD_STAMP_MAX_WG][8], se
                 (unsigned long long)clock64();                                                                         \
         }                                                                                                              \
     } while (0)
+/* the same, summed over the turns of a persistent workgroup: kept in LDS (a stamp must not add a memory round trip to
+ * the phase it measures), written out once by HUFD_STAMP_FLUSH */
+#define HUFD_STAMP_DECL __shared__ unsigned long long hufd_stamp_acc[8];
+#define HUFD_STAMP_ZERO                                                                                                \
+    do {                                                                                                               \
+        if (threadIdx.x < 8) {                                                                                         \
+            hufd_stamp_acc[threadIdx.x] = 0;                                                                           \
+        }                                                                                                              \
+    } while (0)
+#ifdef HUFD_STAMPS_WHY /* slots 3 .. 5 count events instead of clocks */
+#define HUFD_STAMP_TIMED(phase) ((phase) < 3 || (phase) > 5)
+#else
+#define HUFD_STAMP_TIMED(phase) true
+#endif
+#define HUFD_STAMP_ADD(kernel, phase)                                                                                  \
+    do {                                                                                                               \
+        if (threadIdx.x == 0 && HUFD_STAMP_TIMED(phase)) {                                                             \
+            hufd_stamp_acc[phase] += (unsigned long long)clock64();                                                    \
+        }                                                                                                              \
+    } while (0)
+#define HUFD_STAMP_COUNT(phase, n)                                                                                     \
+    do {                                                                                                               \
+        if (threadIdx.x == 0) {                                                                                        \
+            hufd_stamp_acc[phase] += (unsigned long long)(n);                                                          \
+        }                                                                                                              \
+    } while (0)
+#define HUFD_STAMP_FLUSH(kernel)                                                                                       \
+    do {                                                                                                               \
+        if (threadIdx.x < 8 && blockIdx.x < HUFD_STAMP_MAX_WG) {                                                       \
+            hufd_stamp_rows[((u64)(kernel)*HUFD_STAMP_MAX_WG + blockIdx.x) * 8 + threadIdx.x] =                        \
+                hufd_stamp_acc[threadIdx.x];                                                                           \
+        }                                                                                                              \
+    } while (0)
 #else
 #define HUFD_STAMP(kernel, phase)
+#define HUFD_STAMP_ADD(kernel, phase)
+#define HUFD_STAMP_DECL
+#define HUFD_STAMP_ZERO
+#define HUFD_STAMP_COUNT(phase, n)
+#define HUFD_STAMP_FLUSH(kernel)
 #endif
 
 __device__ __forceinline__ u32 round16(u32 x) {
@@ -1722,452 +1760,686 @@ __global__ __launch_bounds__(kPackThreads) void enc_pack_wave_kernel(
     }
 }
 
-/* ------------------------------------------------------------------ encode: single pass */
+/* ------------------------------------------------------------------ encode: one pass */
 
 /*
- * Look-back granule of one segment: [63:62] flag, [61] "a symbol without a code at or before
- * this segment", [60:0] bits.  One aligned 8-byte relaxed agent-scope store publishes it and
- * the same kind of load polls it: the data is the flag (guide: Guideline 16, R2), so no fence
- * and no dependence on dispatch order or XCD placement.  Zeroed before every launch.
+ * Encode in ONE pass over HBM (coders whose every symbol has a code of 4 .. 15 bits): a tile's
+ * symbols are read once, its bits written once -- no count kernel that reads the input a second
+ * time, no scan kernel.  What a tile needs from the tiles in front of it is the number of bits they
+ * hold; what this kernel is built around is that nobody waits for that number:
+ *
+ *  - Persistent waves take tiles (quarter segments, as enc_pack_wave) in turn: wave w of the grid
+ *    packs tiles w, w + W, ...  A tile only depends on lower tiles, which are in the same turn or
+ *    an earlier one; the grid is sized to be resident as a whole, every wait is bounded, and a
+ *    wait that runs out sends the launch to the three-kernel path.  (Tickets from one counter
+ *    would drop the residency assumption, but one word hands out ~90 tickets a microsecond --
+ *    measured: 8.8 ms for the 262 144 tiles of 1 GiB.)
+ *  - A wave looks a tile's symbols up, merges them to octs and scans the lane lengths exactly as
+ *    enc_pack_wave does -- which gives the tile's bit total long before the tile is finished -- and
+ *    publishes the total at once.  The octs then wait in registers while the wave finishes its
+ *    PREVIOUS tile: only now does it ask for the offsets in front of that one, which were published
+ *    a whole turn ago by waves that ran beside it (asking in the same turn made every turn a
+ *    chip-wide rendezvous: the slowest of 4 096 waves set the pace and the waiting ones' polls took
+ *    the memory system from the rest -- measured: 7.5 ms instead of 0.5).  Then the fresh octs go
+ *    into the LDS image, at image bit 0: where the tile lies in the stream is found out a turn later.
+ *  - Totals are kept on three levels so that a wave reads a few hundred bytes, not the history:
+ *    tile_agg[t] (one word, flagged), group_acc[t / 64] (sum and arrival count of 64 tiles, one
+ *    atomic add each, nothing returned) and round_base[r] = bits in front of round r (64 groups),
+ *    stored by one wave of the grid that does nothing else.  A tile's offset = round_base + the
+ *    complete groups of its round in front of it + the tiles of its group in front of it: three
+ *    loads of at most 64 lanes, polled until every value is there (in the steady state: at once).
+ *    item_base[item] = the same number for the item's first tile turns it into an offset inside
+ *    the item.  All of it through agent-scope relaxed atomics: the data is the flag (guide:
+ *    Guideline 16, R2).
+ *  - The copy-out moves the image to where the offset says with one funnel shift that is the same
+ *    for the whole tile (region_store_shifted).
+ *
+ * Segments that are ragged, unaligned or start with carried overflow bits are counted here (symbol
+ * by symbol) and listed for enc_pack_kernel, as is -- by enc_finish_kernel -- the segment that holds
+ * the capacity edge.  Every spin is bounded; a wave that gives up raises ctl[1] and the host layer
+ * redoes the launch with the three-kernel path (which has no waits between workgroups).
  */
-constexpr u64 kLbAggregate = 1ull << 62; /* bits = this segment alone */
-constexpr u64 kLbInclusive = 2ull << 62; /* bits = the item's stream up to and including this segment */
-constexpr u64 kLbUnknown = 1ull << 61;
-constexpr u64 kLbBits = (1ull << 61) - 1;
-constexpr u32 kFusedMargin = 64; /* image bit of a segment's first code: room for carried overflow bits in front */
-constexpr u32 kSpinLimit = 1u << 24;
+constexpr u32 kOpGroupTiles = HUFD_OP_GROUP_TILES;   /* at most 64: a lane per tile */
+constexpr u32 kOpRoundGroups = HUFD_OP_ROUND_GROUPS; /* at most 64: a lane per group */
+constexpr u32 kOpRoundTiles = kOpGroupTiles * kOpRoundGroups;
+constexpr u64 kOpArrive = 1ull << 40; /* group_acc: arrivals above, sum of bits below */
+constexpr u64 kOpSum = kOpArrive - 1;
+constexpr u64 kOpReady = 1ull << 63;  /* round_base / item_base */
+constexpr u32 kOpTileReady = 1u << 31; /* tile_agg */
+constexpr u32 kOpSpinLimit = 1u << 20;
+constexpr u32 kOpGroupStride = HUFD_OP_GROUP_STRIDE; /* u64 words from one group's counter to the next: a memory line each (the adds are done at the memory side, a line at a time) */
 
 __device__ __forceinline__ void granule_store(u64 *p, u64 v) {
-#if defined(__HIP_DEVICE_COMPILE__)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    *p = v;
-#endif
 }
 __device__ __forceinline__ u64 granule_load(const u64 *p) {
-#if defined(__HIP_DEVICE_COMPILE__)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void word_store(u32 *p, u32 v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u32 word_load(const u32 *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+/*
+ * The same loads for a poll loop: load and wait in one piece of assembly, so that the compiler sees a value, not a
+ * load in flight.  (A load it knows of inside the loop makes every wait behind the loop a wait for everything --
+ * among it the next tile's symbols, which are meant to stay in flight.)  Polling with atomics (which are carried out
+ * at the memory side and cannot be served from a cache) was tried: 2 000 waves asking for one word that way take
+ * turns at ~12 ns each -- 18 ms instead of 0.6.
+ */
+__device__ __forceinline__ u32 word_load_now(const u32 *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
 #else
     return *p;
 #endif
 }
+__device__ __forceinline__ u64 granule_load_now(const u64 *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+#else
+    return *p;
+#endif
+}
+/*
+ * A tile's arrival (flagged word + add to its group), issued without the compiler knowing of a store in flight: with
+ * loads and a store outstanding together it makes every wait a wait for everything (it has to assume that the two
+ * kinds complete in any order), and the wait behind this is for the old tile's offsets only -- the next tile's symbols
+ * are meant to stay in flight.  A counted wait that does not count these two still covers the loads it is for: at
+ * most two of the operations it lets stand are these, the others are loads, which complete in order.
+ */
+__device__ __forceinline__ void arrival_quiet(u32 *flag_word, u32 flagged, u64 *group, u64 add) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_store_dword %0, %1, off sc1\n\tglobal_atomic_add_x2 %2, %3, off"
+                 :
+                 : "v"(flag_word), "v"(flagged), "v"(group), "v"(add)
+                 : "memory");
+#else
+    *flag_word = flagged;
+    *group += add;
+#endif
+}
+__device__ __forceinline__ u64 granule_add(u64 *p, u64 v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
-struct fused_shared {
-    u64 lb_part[HUFD_ENC_THREADS / 64]; /* look-back mailbox: each wave's partial sum ... */
-    u32 lb_flag[HUFD_ENC_THREADS / 64]; /* ... bit 0 met an inclusive granule, bit 1 unknown seen, bit 2 timed out */
-    u64 p0;        /* stream bit of the segment's first code, from the look-back */
-    u32 unk_before; /* a symbol without a code in an earlier segment of the item */
-    u32 halo_unknown;
-    u32 failed;     /* a look-back spin ran out */
-};
+/* a value that is the same in every lane, as a scalar */
+__device__ __forceinline__ u32 uniform32(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readfirstlane(x);
+#else
+    return __shfl(x, 0);
+#endif
+}
+__device__ __forceinline__ u64 uniform64(u64 x) {
+    return ((u64)uniform32((u32)(x >> 32)) << 32) | uniform32((u32)x);
+}
 
 /*
- * Copies stream bytes [jlo, jhi) of an item out of an image whose bit 0 is stream bit
- * `delta` (any alignment): 16-byte rows of the output are assembled from five image words
- * with one funnel shift that is the same for every row of the segment.
+ * Copies stream bytes [jlo, jhi) of an item out of a tile image whose bit 0 is stream bit `bit0`
+ * (any alignment), one wave: stream byte j is image bits 8 j - bit0 ...; whole 16-byte rows of
+ * the output are assembled from five image words with a funnel shift that is the same for every
+ * row of the tile, at most 15 single bytes at either end.
  */
-template <u32 THREADS>
-__device__ __forceinline__ void image_store_shifted(const u32 *img, u8 *out_ptr, long long delta, u64 jlo, u64 jhi) {
+__device__ __forceinline__ void region_store_shifted(const u32 *img, u8 *out_ptr, u64 bit0, u64 jlo, u64 jhi, u32 lane) {
     if (jhi <= jlo) {
         return;
     }
     auto byte_at = [&](u64 j) -> u8 {
-        const u32 ib = (u32)((long long)(8 * j) - delta);
+        const u32 ib = (u32)(8 * j - bit0);
         const u64 two = ((u64)img[ib >> 5] << 32) | img[(ib >> 5) + 1];
-        return (u8)((two << (ib & 31)) >> 56);
+        return (u8)((two << (ib & 31u)) >> 56);
     };
     const uintptr_t a_lo = (uintptr_t)(out_ptr + jlo), a_hi = (uintptr_t)(out_ptr + jhi);
     const uintptr_t row_lo = (a_lo + 15) & ~(uintptr_t)15, row_hi = a_hi & ~(uintptr_t)15;
-    if (row_lo > row_hi) {
-        for (u64 j = jlo + threadIdx.x; j < jhi; j += THREADS) {
-            out_ptr[j] = byte_at(j);
+    if (row_lo >= row_hi) {
+        /* no whole row: fewer than 31 bytes */
+        if (jlo + lane < jhi) {
+            out_ptr[jlo + lane] = byte_at(jlo + lane);
         }
         return;
     }
     const u64 j_row_lo = jlo + (row_lo - a_lo), j_row_hi = jlo + (row_hi - a_lo);
-    for (u64 j = jlo + threadIdx.x; j < j_row_lo; j += THREADS) {
-        out_ptr[j] = byte_at(j);
+    if (jlo + lane < j_row_lo) {
+        out_ptr[jlo + lane] = byte_at(jlo + lane);
     }
-    const u32 rows = (u32)((row_hi - row_lo) >> 4);
-    const u32 ib0 = (u32)((long long)(8 * j_row_lo) - delta);
-    const u32 sh = ib0 & 31, w0 = ib0 >> 5;
-    for (u32 r = threadIdx.x; r < rows; r += THREADS) {
-        const u32 *src = img + w0 + 4 * r;
-        const u32 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3], x4 = src[4];
-        uint4 o;
-        o.x = __builtin_bswap32((u32)(((((u64)x0 << 32) | x1) << sh) >> 32));
-        o.y = __builtin_bswap32((u32)(((((u64)x1 << 32) | x2) << sh) >> 32));
-        o.z = __builtin_bswap32((u32)(((((u64)x2 << 32) | x3) << sh) >> 32));
-        o.w = __builtin_bswap32((u32)(((((u64)x3 << 32) | x4) << sh) >> 32));
-        *reinterpret_cast<uint4 *>(row_lo + (uintptr_t)r * 16) = o;
+    {
+        /* bits [ib0 + 128 r, + 128) of the image are row r.  With the shift written as a right shift of the
+         * word pair (k - 1, k) a shift of zero needs no case of its own: it takes the pair one word down */
+        const u32 ib0 = (u32)(8 * j_row_lo - bit0);
+        const u32 sh = ib0 & 31u;
+        const u32 rs = (32u - sh) & 31u;
+        const u32 *words = img + (ib0 >> 5) - (sh == 0 ? 1u : 0u);
+        const u32 rows = (u32)((row_hi - row_lo) >> 4);
+        uint4 *dst = reinterpret_cast<uint4 *>(row_lo);
+        for (u32 r = lane; r < rows; r += kWave) {
+            const u32 *src = words + 4 * r;
+            const u32 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3], x4 = src[4];
+            uint4 o;
+            o.x = __builtin_bswap32(funnel(x0, x1, rs));
+            o.y = __builtin_bswap32(funnel(x1, x2, rs));
+            o.z = __builtin_bswap32(funnel(x2, x3, rs));
+            o.w = __builtin_bswap32(funnel(x3, x4, rs));
+            dst[r] = o;
+        }
     }
-    for (u64 j = j_row_hi + threadIdx.x; j < jhi; j += THREADS) {
-        out_ptr[j] = byte_at(j);
+    if (j_row_hi + lane < jhi) {
+        out_ptr[j_row_hi + lane] = byte_at(j_row_hi + lane);
     }
 }
 
+/* a segment the one-pass kernel packs itself: whole, 16-byte aligned, no carried bits in front of it */
+__device__ __forceinline__ bool op_shaped(const hufd_enc_seg &seg, const u8 *d_in, u32 carried) {
+    return seg.len == HUFD_ENC_SEG_BYTES && ((uintptr_t)(d_in + seg.in_off) & 15u) == 0 && !(seg.index == 0 && carried);
+}
+
 /*
- * Encode in ONE pass over HBM for coders whose codes fit 16 bits: the segment's symbols are
- * read once, its bits written once (no separate count and scan kernels).
- *
- * Persistent workgroups, static round-robin over the segments (see the comment at the loop).
- * Per segment:
- *   symbols arrive in LDS by DMA (requested while the previous segment was packed);
- *   codes are merged to quads and OR-ed into an LDS image whose bit kFusedMargin is the
- *   segment's own first bit -- nothing here needs the global offset;
- *   the segment's bit total is published (aggregate granule); wave 0 adds up the
- *   predecessors' granules until it meets an inclusive one, publishes its own inclusive
- *   granule and hands the exclusive offset to the workgroup;
- *   the copy-out applies the offset as one funnel shift.
- * Segments that contain a symbol without a code are left to enc_pack_kernel (listed later by
- * enc_finish_kernel), as is the (consumed, overflow) record of a capacity edge.
+ * The other segments (ragged ends of items, unaligned input, carried bits in front) are only COUNTED for the
+ * look-back, symbol by symbol, here -- before enc_onepass_kernel starts, which then finds their tiles arrived and
+ * has no loop of loads in its turn (a wait in it can then be a counted one) -- and packed by enc_pack_kernel.
+ * One workgroup per segment, a wave per tile; launched only when the plan may hold such segments.
  */
-template <bool HOLES> /* the coder has symbols without a code: watch for them */
-__global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_fused_kernel(
+__global__ __launch_bounds__(256) void enc_ragged_count_kernel(
     hufd_tables tb,
-    const hufd_enc_item *items,
-    const hufd_enc_seg *segs,
-    const u8 *d_in,
-    u8 *d_out,
-    u64 *lookback,  /* [n_segs] zeroed */
-    u32 *ticket,    /* [0] unused, [1] time-out flag; zeroed */
-    u32 *seg_bits,
-    u32 *seg_unk,
-    u64 *seg_bitoff,
-    u8 *seg_unk_seen,
-    u64 *item_total,
-    u32 img_words,
-    u32 n_segs) {
+    const hufd_enc_item *__restrict__ items,
+    const hufd_enc_seg *__restrict__ segs,
+    const u8 *__restrict__ d_in,
+    u32 *tile_agg,
+    u64 *group_acc) {
 
-    constexpr u32 kInBytes = HUFD_ENC_SEG_BYTES + 16;
-    u32 *img = reinterpret_cast<u32 *>(dyn_lds);
-    u8 *inbuf = dyn_lds + round16(img_words * 4);
-    u32 *tab32 = reinterpret_cast<u32 *>(inbuf + kInBytes);
-    u32 *slots = tab32 + 256;                     /* [8] wave totals; [8..11] first symbol without a code per wave */
-    fused_shared *sh = reinterpret_cast<fused_shared *>(slots + 16);
-
-    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    {
-        const u64 ent = tb.enc_table[tid];
-        tab32[tid] = ((u32)(ent >> 32) << 16) | ((u32)ent & 0xFFFFu);
-    }
-    if (tid == 0) {
-        sh->failed = 0;
-    }
-    /*
-     * Static round-robin: workgroup b takes segments b, b + gridDim.x, ...  All segments of
-     * one round are in flight together, so their aggregates appear together and a look-back
-     * only ever waits for work that is already running.  This needs every workgroup resident
-     * (the launch sizes the grid from the occupancy query; VGPR and LDS limit this kernel far
-     * below the SGPR edge where that query over-reports); every spin is bounded and a
-     * time-out makes the host redo the launch with the three-kernel path.
-     */
-    u32 s = blockIdx.x;
-    if (s >= n_segs) {
+    const u32 s = blockIdx.x, lane = threadIdx.x & (kWave - 1), w4 = threadIdx.x / kWave;
+    const hufd_enc_seg seg = segs[s];
+    if (op_shaped(seg, d_in, items[seg.item].ovf_bits)) {
         return;
     }
-    hufd_enc_seg seg = uniform_seg(&segs[s]);
-    stream_request(d_in, inbuf, seg.in_off, seg.len, seg.next_len);
-    __syncthreads(); /* tables staged, first segment landed */
-
-    for (;;) {
-        const bool more = s + gridDim.x < n_segs;
-        const u32 s_next = s + gridDim.x;
-        const hufd_enc_item it = items[seg.item];
-        const u8 *src = d_in + seg.in_off;
-        const bool from_lds = ((uintptr_t)src & 15u) == 0;
-
-        u32 gw[kGroupsPerLane][4], gvalid[kGroupsPerLane];
-        u32 halo[2] = {0, 0};
-        if (from_lds) {
-#pragma unroll
-            for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
-                const u32 base = (gi * HUFD_ENC_THREADS + tid) * 16;
-                gvalid[gi] = base < seg.len ? (seg.len - base < 16 ? seg.len - base : 16) : 0;
-                const uint4 v = *reinterpret_cast<const uint4 *>(inbuf + base);
-                gw[gi][0] = v.x;
-                gw[gi][1] = v.y;
-                gw[gi][2] = v.z;
-                gw[gi][3] = v.w;
-                if (gvalid[gi] < 16) {
-#pragma unroll
-                    for (u32 c = 0; c < 4; ++c) {
-                        const u32 keep = gvalid[gi] > 4 * c ? gvalid[gi] - 4 * c : 0;
-                        gw[gi][c] &= keep >= 4 ? 0xFFFFFFFFu : ((1u << (8 * keep)) - 1u);
-                    }
-                }
-            }
-            if (tid == 0 && seg.next_len) {
-                halo[0] = *reinterpret_cast<const u32 *>(inbuf + HUFD_ENC_SEG_BYTES);
-                halo[1] = *reinterpret_cast<const u32 *>(inbuf + HUFD_ENC_SEG_BYTES + 4);
-            }
-        } else {
-            load_segment_groups(src, seg.len, gw, gvalid);
-            if (tid == 0 && seg.next_len) {
-                const u32 n = seg.next_len < 8 ? seg.next_len : 8;
-                for (u32 j = 0; j < n; ++j) {
-                    halo[j >> 2] |= (u32)src[HUFD_ENC_SEG_BYTES + j] << (8 * (j & 3));
-                }
-            }
-        }
-        {
-            const uint4 zero = {0, 0, 0, 0};
-            for (u32 i = tid; i < img_words / 4; i += HUFD_ENC_THREADS) {
-                reinterpret_cast<uint4 *>(img)[i] = zero;
-            }
-        }
-        if (tid == 0) {
-            sh->halo_unknown = 0;
-        }
-        barrier_lds(); /* every lane holds its symbols: the buffer may be refilled */
-        hufd_enc_seg seg_next = seg;
-        if (more) {
-            seg_next = uniform_seg(&segs[s_next < n_segs ? s_next : n_segs - 1]);
-            stream_request(d_in, inbuf, seg_next.in_off, seg_next.len, seg_next.next_len);
-        }
-
-        /* ---- codes -> quads -> image (relative to the segment's own first bit) */
-        u32 seg_total = 0, min_len = 0xFFFFu, seg_first_unk = HUFD_NONE32;
-#pragma unroll
-        for (u32 half = 0; half < 2; ++half) {
-            u64 qv[2][4];
-            u32 ql[2];
-            u32 packed = 0;
-#pragma unroll
-            for (u32 gg = 0; gg < 2; ++gg) {
-                const u32 gi = 2 * half + gg;
-                u32 group_bits = 0, lens = 0;
-#pragma unroll
-                for (u32 m = 0; m < 4; ++m) {
-                    u32 pv[2], pl[2];
-#pragma unroll
-                    for (u32 h = 0; h < 2; ++h) {
-                        const u32 j = 4 * m + 2 * h;
-                        const u32 ea = j < gvalid[gi] ? tab32[group_byte(gw[gi], j)] : 0xFFFF0000u;
-                        const u32 eb = j + 1 < gvalid[gi] ? tab32[group_byte(gw[gi], j + 1)] : 0xFFFF0000u;
-                        /* an absent symbol is marked with an impossible length; a real zero length
-                         * is a symbol without a code (which one is left to the per-symbol packer) */
-                        const u32 ra = ea >> 16, rb = eb >> 16;
-                        const u32 la = ra == 0xFFFFu ? 0 : ra;
-                        const u32 lb = rb == 0xFFFFu ? 0 : rb;
-                        if (HOLES) {
-                            min_len = ra < min_len ? ra : min_len;
-                            min_len = rb < min_len ? rb : min_len;
-                        }
-                        pv[h] = ((ea & 0xFFFFu) << lb) | (eb & 0xFFFFu);
-                        pl[h] = la + lb;
-                    }
-                    qv[gg][m] = ((u64)pv[0] << pl[1]) | pv[1];
-                    lens |= (pl[0] + pl[1]) << (8 * m);
-                    group_bits += pl[0] + pl[1];
-                }
-                ql[gg] = lens;
-                packed |= group_bits << (16 * gg);
-            }
-            u32 incl = packed;
-#pragma unroll
-            for (u32 d = 1; d < kWave; d <<= 1) {
-                const u32 up = __shfl_up(incl, d);
-                if (lane >= d) {
-                    incl += up;
-                }
-            }
-            if (lane == kWave - 1) {
-                slots[4 * half + wave] = incl;
-            }
-            if (half == 1) {
-                const u32 wu = wave_min(min_len);
-                if (lane == 0) {
-                    slots[8 + wave] = wu; /* 0 = this wave saw a symbol without a code */
-                }
-            }
-            barrier_lds();
-            u32 before[2] = {0, 0}, total[2] = {0, 0};
-#pragma unroll
-            for (u32 w = 0; w < HUFD_ENC_THREADS / kWave; ++w) {
-                const u32 t = slots[4 * half + w];
-                before[0] += w < wave ? (t & 0xFFFFu) : 0;
-                before[1] += w < wave ? (t >> 16) : 0;
-                total[0] += t & 0xFFFFu;
-                total[1] += t >> 16;
-            }
-            if (half == 1) {
-                /* the segment's total is known: tell the successors before placing the rest */
-#pragma unroll
-                for (u32 w = 0; w < HUFD_ENC_THREADS / kWave; ++w) {
-                    if (slots[8 + w] == 0) {
-                        seg_first_unk = 0; /* "somewhere in this segment" */
-                    }
-                }
-                if (tid == 0 && seg.index != 0) {
-                    granule_store(
-                        &lookback[s], kLbAggregate | (seg_first_unk != HUFD_NONE32 ? kLbUnknown : 0) |
-                                          (u64)(seg_total + total[0] + total[1]));
-                }
-            }
-#pragma unroll
-            for (u32 gg = 0; gg < 2; ++gg) {
-                const u32 mine = (packed >> (16 * gg)) & 0xFFFFu;
-                u32 q = kFusedMargin + seg_total + (gg ? total[0] : 0) + before[gg] + ((incl >> (16 * gg)) & 0xFFFFu) - mine;
-#pragma unroll
-                for (u32 m = 0; m < 4; ++m) {
-                    const u32 len = (ql[gg] >> (8 * m)) & 0xFFu;
-                    image_or_quad(img, q, qv[gg][m], len);
-                    q += len;
-                }
-            }
-            seg_total += total[0] + total[1];
-        }
-
-        const bool own_unknown = seg_first_unk != HUFD_NONE32;
-
-        /*
-         * ---- look back: the whole workgroup, 256 predecessors per step (wave w polls the
-         * granules 64 w + lane back).  With a 64-wide window a 1 GiB stream is 1024 sequential
-         * hops of about a microsecond -- measured: the kernel then runs at hop speed.
-         */
-        u64 excl = 0;
-        u32 unk_before = 0;
-        bool failed = false;
-        if (seg.index == 0) {
-            excl = it.ovf_bits;
-        } else {
-            u32 left = seg.index; /* predecessors inside the item not yet added */
-            u32 at = s;           /* add predecessors at-1, at-2, ... */
-            for (;;) {
-                const u32 back = wave * kWave + lane;
-                const bool has = back < left;
-                u64 g = 0;
-                u32 spins = 0;
-                bool timed_out = false;
-                do { /* poll until every predecessor in this wave's window has published something */
-                    g = has ? granule_load(&lookback[at - 1 - back]) : kLbInclusive;
-                    if (++spins > kSpinLimit) {
-                        timed_out = true;
-                        break;
-                    }
-                } while (!__all((g >> 62) != 0));
-                /* the nearest predecessor that already knows its inclusive total ends the search */
-                const u64 incl_mask = __ballot(has && (g >> 62) == 2);
-                const u32 stop = incl_mask ? (u32)__builtin_ctzll(incl_mask) : kWave;
-                const bool counts = has && lane <= stop;
-                u64 part = counts ? (g & kLbBits) : 0;
-                u32 punk = (counts && (g & kLbUnknown)) ? 1u : 0u;
-#pragma unroll
-                for (u32 d = kWave / 2; d > 0; d >>= 1) {
-                    part += __shfl_xor(part, d);
-                    punk |= __shfl_xor(punk, d);
-                }
-                if (lane == 0) {
-                    sh->lb_part[wave] = part;
-                    sh->lb_flag[wave] = (incl_mask ? 1u : 0u) | (punk << 1) | (timed_out ? 4u : 0u);
-                }
-                barrier_lds();
-                bool done = false;
-#pragma unroll
-                for (u32 w = 0; w < HUFD_ENC_THREADS / kWave; ++w) {
-                    if (!done && w * kWave < left) {
-                        excl += sh->lb_part[w];
-                        unk_before |= (sh->lb_flag[w] >> 1) & 1u;
-                        failed = failed || (sh->lb_flag[w] & 4u);
-                        done = (sh->lb_flag[w] & 1u) != 0;
-                    }
-                }
-                barrier_lds(); /* the mailbox is reused by the next step */
-                if (failed) {
-                    break;
-                }
-                if (done) {
-                    break;
-                }
-                if (left <= HUFD_ENC_THREADS) {
-                    excl += it.ovf_bits; /* reached the item's first segment through aggregates only */
-                    break;
-                }
-                left -= HUFD_ENC_THREADS;
-                at -= HUFD_ENC_THREADS;
-            }
-        }
-        if (wave == 0) {
-            const u64 incl_total = excl + seg_total;
-            const u32 unk_incl = unk_before | (own_unknown ? 1u : 0u);
-            if (lane == 0) {
-                granule_store(&lookback[s], kLbInclusive | (unk_incl ? kLbUnknown : 0) | (incl_total & kLbBits));
-                seg_bits[s] = seg_total;
-                seg_unk[s] = seg_first_unk;
-                seg_bitoff[s] = excl;
-                seg_unk_seen[s] = (u8)unk_incl;
-                sh->p0 = excl;
-                sh->unk_before = unk_before;
-                if (failed) {
-                    sh->failed = 1;
-                    ticket[1] = 1;
-                }
-                if (seg.flags & 2u) {
-                    item_total[seg.item] = incl_total;
-                }
-                /* the last byte: next segment's head, or padding when the item ends here cleanly */
-                if (!unk_before && !own_unknown) {
-                    const u64 pend = incl_total;
-                    u32 need = (u32)((8 - (pend & 7)) & 7);
-                    u32 q = kFusedMargin + seg_total;
-                    if (seg.index == 0 && it.ovf_bits) {
-                        image_or_bits(img, kFusedMargin - it.ovf_bits, it.ovf_pattern, it.ovf_bits);
-                    }
-                    if (need && !(seg.flags & 2u)) {
-                        const u32 n = seg.next_len < 8 ? seg.next_len : 8;
-                        for (u32 j = 0; j < n && need; ++j) {
-                            const u32 e = tab32[(halo[j >> 2] >> (8 * (j & 3))) & 0xFFu];
-                            const u32 len = e >> 16;
-                            if (len == 0) {
-                                sh->halo_unknown = 1;
-                                break;
-                            }
-                            image_or_bits(img, q, e & 0xFFFFu, len);
-                            q += len;
-                            need = len >= need ? 0 : need - len;
-                        }
-                    }
-                    const u64 cap_bits = it.out_cap > (~0ull >> 3) ? ~0ull : it.out_cap * 8;
-                    if (need && (seg.flags & 2u) && pend <= cap_bits) {
-                        image_or_bits(img, q, it.eos_padding & ((1u << need) - 1), need);
-                    }
-                }
-            }
-        }
-        /* full barrier: image complete, offset known, and every wave's share of the prefetch
-         * (issued a whole packing ago) has landed */
-        __syncthreads();
-
-        const u64 p0 = sh->p0;
-        const bool skip = sh->unk_before || own_unknown || sh->failed;
-        if (!skip) {
-            const u64 pend = p0 + seg_total;
-            const u64 pa = seg.index == 0 ? 0 : p0;
-            const bool last_seg = (seg.flags & 2u) != 0;
-            const u64 cap_bits = it.out_cap > (~0ull >> 3) ? ~0ull : it.out_cap * 8;
-            const bool clean_end = last_seg && pend <= cap_bits;
-            u64 jhi = last_seg ? (clean_end ? (pend + 7) >> 3 : pend >> 3)
-                               : (sh->halo_unknown ? pend >> 3 : (pend + 7) >> 3);
-            if (jhi > it.out_cap) {
-                jhi = it.out_cap;
-            }
-            const u64 jlo = (pa + 7) >> 3;
-            image_store_shifted<HUFD_ENC_THREADS>(
-                img, d_out + it.out_off, (long long)p0 - (long long)kFusedMargin, jlo, jhi);
-        }
-
-        if (!more) {
-            break;
-        }
-        s = s_next;
-        seg = seg_next;
-        barrier_lds(); /* copy-out has read the image; its stores stay in flight */
+    const u32 from = w4 * kTileBytes;
+    const u32 n = seg.len > from ? (seg.len - from < kTileBytes ? seg.len - from : kTileBytes) : 0u;
+    const u8 *src = d_in + seg.in_off + from;
+    u32 sum = 0;
+    for (u32 i = lane; i < n; i += kWave) {
+        sum += (u32)(tb.enc_table[src[i]] >> 32);
+    }
+    const u32 bits = wave_sum(sum);
+    if (lane == 0) {
+        const u32 t = s * kTilesPerSeg + w4;
+        word_store(&tile_agg[t], kOpTileReady | bits);
+        granule_add(&group_acc[(u64)(t / kOpGroupTiles) * kOpGroupStride], kOpArrive | bits);
     }
 }
 
+/* what a wave knows about a tile (everything here is the same in all lanes) */
+struct op_tile {
+    hufd_enc_seg seg;
+    u32 t, s, w4;
+    u32 n_sym;      /* symbols of the segment that lie in this tile */
+    u32 carried;    /* the item's carried overflow bits */
+    u32 bits;       /* the tile's code bits, once counted */
+    u32 halo_n;     /* how many symbols behind the tile its last byte may need (their values are per-lane registers) */
+    bool shaped;    /* a whole, aligned segment without carried bits in front: packed here */
+    bool first_tile, last_tile; /* of its item */
+    const u8 *tsrc;
+};
+
+template <u32 NW> /* words an oct can touch: 4 for codes of at most 12 bits, 5 up to 15 */
+__global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
+    hufd_tables tb,
+    const hufd_enc_item *__restrict__ items,
+    const hufd_enc_seg *__restrict__ segs,
+    const u8 *__restrict__ d_in,
+    u8 *__restrict__ d_out,
+    u32 region_bytes,
+    u32 n_segs,
+    u32 *ctl,          /* [1] a spin ran out, [2] careful_count */
+    u32 *tile_agg,     /* [4 n_segs] zeroed */
+    u64 *group_acc,    /* zeroed */
+    u64 *round_base,   /* [rounds + 1] zeroed */
+    u64 *item_base,    /* [n_items] zeroed */
+    u32 *__restrict__ seg_bits,
+    u32 *__restrict__ seg_unk,
+    u64 *__restrict__ seg_bitoff,
+    u8 *__restrict__ seg_unk_seen,
+    u64 *__restrict__ item_total,
+    u32 *__restrict__ careful_list,
+    const u8 *__restrict__ null_tile, /* kTileBytes readable bytes: what a wave "prefetches" when no tile follows */
+    const u32 *__restrict__ tile_agg_early /* = tile_agg, for the words enc_ragged_count_kernel wrote before this launch */) {
+
+    HUFD_STAMP_DECL
+    HUFD_STAMP_ZERO;
+    u32 *tab = reinterpret_cast<u32 *>(dyn_lds); /* [256][32] */
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = uniform32(tid / kWave);
+    u32 *img = reinterpret_cast<u32 *>(dyn_lds + kPackTabBytes + wave * region_bytes);
+
+    if (tid < 256) {
+        const u64 ent = tb.enc_table[tid];
+        const u32 len = (u32)(ent >> 32);
+        const u32 e = len ? ((((u32)ent << (16 - len)) & 0xFFFFu) << 16) | len : 0u;
+#pragma unroll
+        for (u32 k = 0; k < 32; ++k) {
+            tab[tid * 32 + ((k + tid) & 31u)] = e;
+        }
+    }
+    __syncthreads();
+    const u8 *mine = reinterpret_cast<const u8 *>(tab) + (lane & 31u) * 4u;
+    const u32 n_tiles = n_segs * kTilesPerSeg;
+
+    /* (t is a scalar, the descriptor arrays are read-only: these are scalar loads, no vector registers, no vector-memory wait) */
+    auto describe = [&](u32 t) -> op_tile {
+        op_tile d;
+        const u32 tc = t < n_tiles ? t : n_tiles - 1; /* (a tile past the end is never worked on) */
+        d.t = t;
+        d.s = tc / kTilesPerSeg;
+        d.w4 = tc % kTilesPerSeg;
+        d.seg = segs[d.s];
+        const u8 *src = d_in + d.seg.in_off;
+        d.carried = items[d.seg.item].ovf_bits;
+        d.shaped = op_shaped(d.seg, d_in, d.carried);
+        d.tsrc = src + d.w4 * kTileBytes;
+        const u32 from = d.w4 * kTileBytes;
+        d.n_sym = d.seg.len > from ? (d.seg.len - from < kTileBytes ? d.seg.len - from : kTileBytes) : 0u;
+        d.first_tile = d.seg.index == 0 && d.w4 == 0;
+        d.last_tile = (d.seg.flags & 2u) != 0 && d.w4 == kTilesPerSeg - 1;
+        d.bits = 0;
+        d.halo_n = 0;
+        return d;
+    };
+
+    /*
+     * One wave of the grid packs nothing: it watches the groups of a round arrive and publishes the next round's
+     * base the moment the last one is there (a packing wave would get to it half a turn to a turn later -- measured:
+     * then 9 of 10 tiles found their round's base missing at the first look and every wave polled a third of its
+     * time, in step with the one wave that held the round's last tile).
+     */
+    if (blockIdx.x == 0 && wave == kPackWaves - 1) {
+        const u32 full_rounds = n_tiles / kOpRoundTiles; /* (nobody asks for the base behind a round that is not full) */
+        u64 base = 0;
+        if (lane == 0) {
+            granule_store(&round_base[0], kOpReady);
+        }
+        for (u32 r = 0; r < full_rounds; ++r) {
+            u64 b = 0;
+            u32 spins = 0;
+            for (;;) {
+                b = lane < kOpRoundGroups ? granule_load(&group_acc[(u64)(r * kOpRoundGroups + lane) * kOpGroupStride])
+                                          : kOpGroupTiles * kOpArrive;
+                if (__all((b >> 40) == kOpGroupTiles)) {
+                    break;
+                }
+                if (++spins > kOpSpinLimit) {
+                    if (lane == 0) {
+                        ctl[1] = 1; /* (the waves that wait for this base give up in their turn) */
+                    }
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            u64 sum = lane < kOpRoundGroups ? (b & kOpSum) : 0;
+#pragma unroll
+            for (u32 d = kWave / 2; d > 0; d >>= 1) {
+                sum += __shfl_xor(sum, d);
+            }
+            base += sum;
+            if (lane == 0) {
+                granule_store(&round_base[r + 1], kOpReady | base);
+#ifdef HUFD_STAMPS_WHY
+                hufd_stamp_rows[((u64)1 * HUFD_STAMP_MAX_WG + r + 1) * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+#endif
+            }
+        }
+        return;
+    }
+    /* tiles in turn over the packing waves of the grid: the tiles a tile waits for belong to this turn or an earlier
+     * one, so to the running waves as long as the whole grid is resident (the launch sizes it so) */
+    const u32 stride = gridDim.x * kPackWaves - 1;
+    u32 t_new = blockIdx.x * kPackWaves + wave - (blockIdx.x ? 1u : 0u);
+    if (t_new >= n_tiles) {
+        return;
+    }
+    op_tile fresh = describe(t_new); /* the tile whose symbols are looked up in this turn ... */
+    op_tile old = fresh;             /* ... and the one before it, whose image is copied out in this turn */
+    bool have_old = false;
+    uint4 v[kGroupsPerLane], vn[kGroupsPerLane];
+#pragma unroll
+    for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
+        v[gi] = vn[gi] = uint4{0, 0, 0, 0};
+    }
+    if (fresh.shaped) {
+#pragma unroll
+        for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
+            v[gi] = reinterpret_cast<const uint4 *>(fresh.tsrc)[gi * kWave + lane];
+        }
+    }
+    u32 base_item = HUFD_NONE32; /* the item whose base this wave has read ... */
+    u64 base_value = 0;          /* ... and that base (item_base[base_item]) */
+    u32 halo0 = 0, halo1 = 0, old_halo0 = 0, old_halo1 = 0; /* the first two symbols behind the fresh / the old tile */
+
+    /* the old tile's offsets, as they stand in memory: its round's base, the complete groups of its round in front of
+     * it, the tiles of its group in front of it, its item's base.  Every lane, no branch: the compiler then knows how
+     * many younger loads a wait for these may leave in flight. */
+    auto ask_offsets = [&](u32 &a_raw, u64 &b_raw, u64 &rb_raw, u64 &ib_raw) {
+        const u32 g = old.t / kOpGroupTiles, p = old.t % kOpGroupTiles, r = g / kOpRoundGroups, gi_r = g % kOpRoundGroups;
+        a_raw = word_load(&tile_agg[g * kOpGroupTiles + (lane < p ? lane : 0u)]);
+        b_raw = granule_load(&group_acc[(u64)(r * kOpRoundGroups + (lane < gi_r ? lane : 0u)) * kOpGroupStride]);
+        rb_raw = granule_load(&round_base[r]);
+        ib_raw = granule_load(&item_base[old.seg.item]);
+    };
+
+    /* the old tile, from the look at its offsets to the copy-out of its image; false: a wait ran out */
+    auto finish_old = [&](u32 a_raw, u64 b_raw, u64 rb_raw, u64 ib_raw) -> bool {
+        const u32 g = old.t / kOpGroupTiles, p = old.t % kOpGroupTiles, r = g / kOpRoundGroups, gi_r = g % kOpRoundGroups;
+        /* ---- the bits in front of the old tile are there (asked for at the top of the turn); if not, ask again */
+        const hufd_enc_seg seg = old.seg;
+        /* (the wait for these leaves the younger loads -- the next tile's symbols -- and the arrival atomic in flight) */
+        u32 a = lane < p ? a_raw : kOpTileReady;
+        u64 b = lane < gi_r ? b_raw : kOpGroupTiles * kOpArrive;
+        u64 rb = rb_raw;
+        u64 ib = old.first_tile ? kOpReady : (seg.item == base_item ? base_value : ib_raw); /* an item's base is read once per wave */
+        bool gave_up = false;
+        for (u32 spins = 0;; ++spins) {
+            const bool there = (a & kOpTileReady) != 0 && (b >> 40) == kOpGroupTiles && (rb & kOpReady) != 0 &&
+                               (ib & kOpReady) != 0;
+            if (spins == 0) {
+#ifdef HUFD_STAMPS_WHY
+                if ((threadIdx.x & 63u) == 0 && blockIdx.x >= 1 && blockIdx.x <= 7 && threadIdx.x == 0) {
+                    hufd_stamp_rows[((u64)1 * HUFD_STAMP_MAX_WG + r) * 8 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+                }
+#endif
+                HUFD_STAMP_ADD(2, 7); /* the values asked for at the top of the turn are in registers */
+#ifdef HUFD_STAMPS_WHY
+                HUFD_STAMP_COUNT(3, __all((a & kOpTileReady) != 0) ? 0 : 1);
+                HUFD_STAMP_COUNT(4, __all((b >> 40) == kOpGroupTiles) ? 0 : 1);
+                HUFD_STAMP_COUNT(5, __all((rb & kOpReady) != 0) ? 0 : 1);
+#endif
+            }
+            if (__all(there)) {
+                HUFD_STAMP_COUNT(6, spins);
+                break;
+            }
+            if (spins > kOpSpinLimit) {
+                gave_up = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8); /* a poll is traffic for everybody: rarely needed, then not in a tight loop */
+            if (lane < p && !(a & kOpTileReady)) {
+                a = word_load_now(&tile_agg[g * kOpGroupTiles + lane]);
+            }
+            if (lane < gi_r && (b >> 40) != kOpGroupTiles) {
+                b = granule_load_now(&group_acc[(u64)(r * kOpRoundGroups + lane) * kOpGroupStride]);
+            }
+            if (!(rb & kOpReady)) {
+                rb = granule_load_now(&round_base[r]);
+            }
+            if (!(ib & kOpReady)) {
+                ib = granule_load_now(&item_base[seg.item]);
+            }
+        }
+        if (gave_up) {
+            if (lane == 0) {
+                ctl[1] = 1; /* the host layer redoes the launch without waits between workgroups */
+            }
+            return false;
+        }
+        HUFD_STAMP_ADD(2, 2);
+        a &= ~kOpTileReady;
+        const u32 part = (lane < p ? a : 0u) + (lane < gi_r ? (u32)(b & kOpSum) : 0u);
+        const u32 in_round = __shfl(wave_inclusive_sum_dpp(part, lane), kWave - 1);
+        const u64 before = uniform64((rb & ~kOpReady) + in_round); /* bits of every tile of the plan in front of this one */
+        u64 bw; /* stream bit (inside the item) of the tile's first code */
+        if (old.first_tile) {
+            bw = old.carried;
+            base_value = kOpReady | before;
+            if (lane == 0) {
+                granule_store(&item_base[seg.item], base_value);
+            }
+        } else {
+            base_value = uniform64(ib);
+            bw = before - (base_value & ~kOpReady) + old.carried;
+        }
+        base_item = seg.item;
+        const u64 bn = bw + old.bits;
+
+        /* ---- the records enc_finish_kernel and enc_pack_kernel read */
+        {
+            /* (w4 == 3: lanes p - 3 .. p - 1 hold the segment's other three tiles) */
+            const u32 a1 = __shfl(a, (p + kWave - 1) & (kWave - 1)), a2 = __shfl(a, (p + kWave - 2) & (kWave - 1)),
+                      a3 = __shfl(a, (p + kWave - 3) & (kWave - 1));
+            if (lane == 0) {
+                if (old.w4 == 0) {
+                    seg_bitoff[old.s] = bw;
+                    if (!old.shaped) {
+                        careful_list[atomicAdd(&ctl[2], 1u)] = old.s;
+                    }
+                }
+                if (old.w4 == kTilesPerSeg - 1) {
+                    seg_bits[old.s] = old.bits + a1 + a2 + a3;
+                    seg_unk[old.s] = HUFD_NONE32;
+                    seg_unk_seen[old.s] = 0;
+                    if (seg.flags & 2u) {
+                        item_total[seg.item] = bn;
+                    }
+                }
+            }
+        }
+
+        if (old.shaped) {
+            const u64 out_cap = uniform64(items[seg.item].out_cap);
+            const u64 cap_bits = out_cap > (~0ull >> 3) ? ~0ull : out_cap * 8;
+            u8 *out_ptr = d_out + uniform64(items[seg.item].out_off);
+            /* the last byte: the next tile's head, or the padding when the item ends here (huffman.c:178-184) */
+            {
+                const u32 need = (u32)((8 - (bn & 7)) & 7);
+                const u32 e0 = old.halo_n > 0 ? *reinterpret_cast<const u32 *>(mine + old_halo0 * 128u) : 0u;
+                const u32 e1 = old.halo_n > 1 ? *reinterpret_cast<const u32 *>(mine + old_halo1 * 128u) : 0u;
+                const u32 l0 = e0 & 0xFFFFu, l1 = e1 & 0xFFFFu;
+                u32 head = (e0 & 0xFFFF0000u) | ((e1 & 0xFFFF0000u) >> l0);
+                u32 have = l0 + l1;
+                /* fewer than two symbols behind the tile: the item ends inside its last byte, and whether it ends
+                 * well (padding) is a matter of its total, which is then known here */
+                if (have < need && old.halo_n < 2 && bn + have <= cap_bits) {
+                    const u32 eos = uniform32(items[seg.item].eos_padding);
+                    const u32 pad_bits = need - have;
+                    head |= ((eos & ((1u << pad_bits) - 1u)) << (32 - need));
+                    have = need;
+                }
+                if (lane == 0 && need && have >= need) {
+                    /* behind the tile's last bit the image holds nothing yet (the word the bits start in was
+                     * written whole by the last unit, zeros behind its end): the word after it is stored, not OR-ed */
+                    const u32 q = old.bits;
+                    const u64 left = ((u64)(head >> (32 - need)) << (64 - need)) >> (q & 31u);
+                    img[q >> 5] |= (u32)(left >> 32);
+                    img[(q >> 5) + 1] = (u32)left;
+                }
+            }
+            wave_step();
+            u64 jhi = old.last_tile ? (bn <= cap_bits ? (bn + 7) >> 3 : bn >> 3) : (bn + 7) >> 3;
+            jhi = jhi > out_cap ? out_cap : jhi;
+            const u64 jlo = old.first_tile ? 0 : (bw + 7) >> 3;
+            region_store_shifted(img, out_ptr, bw, jlo, jhi, lane);
+        }
+        wave_step(); /* the image is free for the fresh tile */
+        return true;
+    };
+
+    /*
+     * One turn: look up and merge the FRESH tile's symbols; then finish the OLD tile (offsets in front of it --
+     * published a whole turn ago --, last byte, copy-out of the image), publishing the fresh tile's bit total on the
+     * way; then place the fresh tile's octs in the image.  The fresh octs wait in registers meanwhile.  The last tile
+     * is finished behind the loop, so that every turn inside it asks for the same loads (see ask_offsets).
+     */
+    while (t_new < n_tiles) {
+        HUFD_STAMP_ADD(2, 0);
+        u64 ohi[kGroupsPerLane][2], olo[kGroupsPerLane][2];
+        u32 olen[kGroupsPerLane];
+        u32 gq[kGroupsPerLane];
+        op_tile nxt = fresh;
+        /* Everything the last turn asked for has had a turn to land: this tile's symbols, the copy-out stores.  Saying so
+         * here (instead of leaving it to the first use) lets the wait further down be a counted one that leaves this
+         * turn's own loads in flight. */
+        __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) */
+        u32 a_raw;
+        u64 b_raw, rb_raw, ib_raw;
+        ask_offsets(a_raw, b_raw, rb_raw, ib_raw); /* (in the first turn: of the fresh tile, never looked at) */
+        /* the next tile's first two symbols complete this tile's last byte (a code is at least 4 bits, the byte lacks at most 7) */
+        if (fresh.shaped && !fresh.last_tile) {
+            fresh.halo_n = fresh.w4 + 1 < kTilesPerSeg ? 2u : (fresh.seg.next_len < 2 ? fresh.seg.next_len : 2u);
+        }
+        const u8 *seg_first = d_in + fresh.seg.in_off; /* (a segment holds at least one symbol) */
+        halo0 = *(fresh.halo_n > 0 ? fresh.tsrc + kTileBytes : seg_first);
+        halo1 = *(fresh.halo_n > 1 ? fresh.tsrc + kTileBytes + 1 : seg_first);
+        /* the tile after it: its symbols are on their way while this one is packed */
+        nxt = describe(t_new + stride);
+        {
+            const u8 *nsrc = (t_new + stride < n_tiles && nxt.shaped) ? nxt.tsrc : null_tile;
+#pragma unroll
+            for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
+                vn[gi] = reinterpret_cast<const uint4 *>(nsrc)[gi * kWave + lane];
+            }
+        }
+
+        /* ---- the fresh tile's bits: codes -> pairs -> quads -> octs, one wave scan per two groups */
+        if (fresh.shaped) {
+#pragma unroll
+            for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
+                const u32 wd[4] = {v[gi].x, v[gi].y, v[gi].z, v[gi].w};
+                u32 both = 0;
+#pragma unroll
+                for (u32 o = 0; o < 2; ++o) {
+                    u64 quad[2];
+                    u32 qlen[2];
+#pragma unroll
+                    for (u32 h = 0; h < 2; ++h) {
+                        u32 pair[2], plen[2];
+#pragma unroll
+                        for (u32 m = 0; m < 2; ++m) {
+                            const u32 wdv = wd[2 * o + h];
+                            const u32 ea = *reinterpret_cast<const u32 *>(mine + ((wdv >> (16 * m)) & 0xFFu) * 128u);
+                            const u32 eb = *reinterpret_cast<const u32 *>(mine + ((wdv >> (16 * m + 8)) & 0xFFu) * 128u);
+                            /* eb's length field (< 16) falls off the low end: the shift is by at least 4 */
+                            pair[m] = (ea & 0xFFFF0000u) | (eb >> (ea & 31u));
+                            plen[m] = ea + eb; /* the lengths add up in the low half; what the high half holds is never looked at */
+                        }
+                        quad[h] = ((u64)pair[0] << 32) | (((u64)pair[1] << 32) >> (plen[0] & 63u));
+                        qlen[h] = plen[0] + plen[1];
+                    }
+                    const u64 x = quad[1] >> (qlen[0] & 63u);
+                    ohi[gi][o] = quad[0] | x;
+                    olo[gi][o] = quad[1] << ((64u - qlen[0]) & 63u); /* a quad is 16 .. 60 bits */
+                    both |= ((qlen[0] + qlen[1]) & 0xFFFFu) << (16 * o);
+                }
+                olen[gi] = both;
+            }
+            u32 at = 0; /* the image starts at the tile's own first bit */
+#pragma unroll
+            for (u32 half = 0; half < kGroupsPerLane / 2; ++half) {
+                const u32 la = (olen[2 * half] & 0xFFFFu) + (olen[2 * half] >> 16);
+                const u32 lb = (olen[2 * half + 1] & 0xFFFFu) + (olen[2 * half + 1] >> 16);
+                const u32 packed = la | (lb << 16);
+                const u32 incl = wave_inclusive_sum_dpp(packed, lane);
+                const u32 tot = __shfl(incl, kWave - 1);
+                gq[2 * half] = at + (incl & 0xFFFFu) - la;
+                gq[2 * half + 1] = at + (tot & 0xFFFFu) + (incl >> 16) - lb;
+                at += (tot & 0xFFFFu) + (tot >> 16);
+            }
+            fresh.bits = uniform32(at);
+        } else {
+            /* ragged, unaligned or behind carried bits: counted (and its arrival told) by enc_ragged_count_kernel
+             * before this kernel started, packed by enc_pack_kernel after it; a scalar read */
+            fresh.bits = tile_agg_early[fresh.t] & ~kOpTileReady;
+        }
+        HUFD_STAMP_ADD(2, 1);
+
+        /* tell the tiles behind the fresh one (see arrival_quiet) */
+        if (fresh.shaped && lane == 0) {
+            arrival_quiet(&tile_agg[fresh.t], kOpTileReady | fresh.bits, &group_acc[(u64)(fresh.t / kOpGroupTiles) * kOpGroupStride], kOpArrive | fresh.bits);
+        }
+        if (have_old) {
+            if (!finish_old(a_raw, b_raw, rb_raw, ib_raw)) {
+                return;
+            }
+        } else {
+            HUFD_STAMP_ADD(2, 7);
+            HUFD_STAMP_ADD(2, 2);
+        }
+        HUFD_STAMP_ADD(2, 3);
+
+        /* ---- the fresh octs -> words of the image, highest word first */
+        if (fresh.shaped) {
+            if (lane == 0) {
+                img[0] = 0; /* the word the first unit ORs its head into */
+            }
+            wave_step();
+#pragma unroll
+            for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
+                u32 wds[2][NW], base[2];
+#pragma unroll
+                for (u32 o = 0; o < 2; ++o) {
+                    const u32 q = gq[gi] + (o ? olen[gi] & 0xFFFFu : 0u);
+                    const u32 sh = q & 31u;
+                    base[o] = q >> 5;
+                    const u32 w0 = (u32)(ohi[gi][o] >> 32), w1 = (u32)ohi[gi][o], w2 = (u32)(olo[gi][o] >> 32),
+                              w3 = (u32)olo[gi][o];
+                    wds[o][0] = w0 >> sh;
+                    wds[o][1] = funnel(w0, w1, sh);
+                    wds[o][2] = funnel(w1, w2, sh);
+                    if (NW == 4) {
+                        wds[o][3] = funnel(w2, 0, sh);
+                    } else {
+                        wds[o][3] = funnel(w2, w3, sh);
+                        wds[o][NW - 1] = funnel(w3, 0, sh);
+                    }
+                }
+#pragma unroll
+                for (u32 k = NW - 1; k >= 1; --k) {
+#pragma unroll
+                    for (u32 o = 0; o < 2; ++o) {
+                        img[base[o] + k] = wds[o][k];
+                        wave_step();
+                    }
+                }
+#pragma unroll
+                for (u32 o = 0; o < 2; ++o) {
+                    atomicOr(&img[base[o]], wds[o][0]);
+                    wave_step();
+                }
+            }
+        }
+        HUFD_STAMP_ADD(2, 4);
+        HUFD_STAMP_ADD(2, 5);
+
+        old = fresh;
+        old_halo0 = halo0;
+        old_halo1 = halo1;
+        have_old = true;
+        fresh = nxt;
+        t_new += stride;
+#pragma unroll
+        for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
+            v[gi] = vn[gi];
+        }
+    }
+    /* the last tile */
+    HUFD_STAMP_ADD(2, 0);
+    {
+        u32 a_raw;
+        u64 b_raw, rb_raw, ib_raw;
+        ask_offsets(a_raw, b_raw, rb_raw, ib_raw);
+        HUFD_STAMP_ADD(2, 1);
+        if (!finish_old(a_raw, b_raw, rb_raw, ib_raw)) {
+            return;
+        }
+    }
+    HUFD_STAMP_ADD(2, 3);
+    HUFD_STAMP_ADD(2, 4);
+    HUFD_STAMP_ADD(2, 5);
+    HUFD_STAMP_FLUSH(2); /* (wave 0's own sums) */
+}
+
 /*
- * After the single pass: one thread per item turns the item's bit total and the per-segment
+ * After the one pass: one thread per item turns the item's bit total and the per-segment
  * records into the outcome of the call (enc_finish_item) and lists the segments the
  * per-symbol packer has to visit.  The first segment with a symbol without a code and the
  * segment holding the capacity edge are found by bisection (both records are monotone).
@@ -4948,11 +5220,35 @@ static uint32_t persistent_grid(Kernel kernel, uint32_t threads, uint32_t lds_by
     return (uint32_t)(work_items < resident ? work_items : resident);
 }
 
+/* layout of the block the one-pass encoder wants zeroed before every launch (all offsets multiples of 8) */
+struct onepass_layout {
+    uint64_t ctl, tile_agg, group_acc, round_base, item_base, null_tile, bytes;
+};
+
+static onepass_layout onepass_layout_of(uint64_t n_segs, uint64_t n_items) {
+    const uint64_t tiles = n_segs * kTilesPerSeg;
+    const uint64_t groups = (tiles + kOpGroupTiles - 1) / kOpGroupTiles;
+    const uint64_t rounds = (groups + kOpRoundGroups - 1) / kOpRoundGroups;
+    onepass_layout l;
+    l.ctl = 0;
+    l.tile_agg = 32;
+    l.group_acc = l.tile_agg + ((tiles * 4 + 7) & ~7ull);
+    l.round_base = l.group_acc + groups * 8 * kOpGroupStride;
+    l.item_base = l.round_base + (rounds + 1) * 8;
+    l.null_tile = (l.item_base + n_items * 8 + 15) & ~15ull;
+    l.bytes = l.null_tile + kTileBytes;
+    return l;
+}
+
 extern "C" {
 
 int hufk_init(void) {
     /* a workgroup may use up to 160 KiB of LDS on gfx950, but dynamic LDS above 64 KiB is opt-in */
+#ifdef HUFD_STAMPS
+    const int lds_max = 160 * 1024 - 1024; /* the diagnostic build keeps its stamp sums in static LDS */
+#else
     const int lds_max = 160 * 1024;
+#endif
     int device = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&device) == hipSuccess && hipGetDeviceProperties(&prop, device) == hipSuccess &&
@@ -5000,15 +5296,22 @@ int hufk_init(void) {
     }
     if (e == hipSuccess) {
         e = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&enc_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-            lds_max);
+            reinterpret_cast<const void *>(&enc_onepass_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     }
     if (e == hipSuccess) {
         e = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&enc_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-            lds_max);
+            reinterpret_cast<const void *>(&enc_onepass_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     }
     return (int)e;
+}
+
+int hufk_encode_one_pass_applies(const struct hufd_tables *tb) {
+    /* every symbol has a code (no stop inside a stream to look for), octs of 4 .. 15-bit codes */
+    return tb->all_coded && tb->max_bits <= 15 && tb->min_bits >= 4;
+}
+
+uint64_t hufk_encode_zero_bytes(uint32_t n_segs, uint32_t n_items) {
+    return onepass_layout_of(n_segs, n_items).bytes;
 }
 
 uint32_t hufk_enc_image_words(uint32_t max_bits) {
@@ -5025,11 +5328,6 @@ static uint32_t enc_pack_lds_bytes(uint32_t img_words) {
 static uint32_t enc_stream_lds_bytes(uint32_t img_words) {
     return ((img_words * 4 + 15) & ~15u) + (HUFD_ENC_SEG_BYTES + 16) + 256 * 4 + 8 * 4 +
            (uint32_t)sizeof(enc_pack_shared) + 16;
-}
-
-static uint32_t enc_fused_lds_bytes(uint32_t img_words) {
-    return ((img_words * 4 + 15) & ~15u) + (HUFD_ENC_SEG_BYTES + 16) + 256 * 4 + 16 * 4 + (uint32_t)sizeof(fused_shared) +
-           16;
 }
 
 static uint32_t dec_sync_lds_bytes(const hufd_tables *tb) {
@@ -5052,25 +5350,34 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
     if (a->n_segs == 0 && a->n_items == 0) {
         return 0;
     }
-    if (a->n_segs && !a->length_only && a->single_pass && a->tables.max_bits <= 16 && a->zero_block) {
-        /* single pass: fused count + offset + pack, then the per-item outcome, then the listed segments */
+    if (a->n_segs && !a->length_only && a->single_pass && hufk_encode_one_pass_applies(&a->tables) && a->zero_block) {
+        /* one pass: count + offsets + pack in one kernel, then the per-item outcome, then the listed segments */
         const uint32_t img_words = hufk_enc_image_words(a->tables.max_bits);
-        (void)hipMemsetAsync(a->zero_block, 0, a->zero_bytes, st);
+        const onepass_layout l = onepass_layout_of(a->n_segs, a->n_items);
+        uint8_t *z = (uint8_t *)a->zero_block;
+        (void)hipMemsetAsync(a->zero_block, 0, l.bytes, st);
         stage_mark(a->stage_events, 0, st);
-        const uint32_t lds = enc_fused_lds_bytes(img_words);
-        if (a->tables.all_coded) {
-            const uint32_t grid = persistent_grid(enc_fused_kernel<false>, HUFD_ENC_THREADS, lds, a->n_segs);
+        const uint32_t region = pack_region_bytes(a->tables.max_bits);
+        const uint32_t lds = kPackTabBytes + kPackWaves * region;
+        const uint32_t work = (a->n_segs * kTilesPerSeg + kPackWaves - 1) / kPackWaves;
+        if (a->maybe_unshaped || ((uintptr_t)a->d_in & 15u) != 0) {
             hipLaunchKernelGGL(
-                enc_fused_kernel<false>, dim3(grid), dim3(HUFD_ENC_THREADS), lds, st, a->tables, a->items, a->segs,
-                (const u8 *)a->d_in, (u8 *)a->d_out, a->lookback, a->ticket, a->seg_bits, a->seg_unk, a->seg_bitoff,
-                a->seg_unk_seen, a->item_total, img_words, a->n_segs);
-        } else {
-            const uint32_t grid = persistent_grid(enc_fused_kernel<true>, HUFD_ENC_THREADS, lds, a->n_segs);
-            hipLaunchKernelGGL(
-                enc_fused_kernel<true>, dim3(grid), dim3(HUFD_ENC_THREADS), lds, st, a->tables, a->items, a->segs,
-                (const u8 *)a->d_in, (u8 *)a->d_out, a->lookback, a->ticket, a->seg_bits, a->seg_unk, a->seg_bitoff,
-                a->seg_unk_seen, a->item_total, img_words, a->n_segs);
+                enc_ragged_count_kernel, dim3(a->n_segs), dim3(256), 0, st, a->tables, a->items, a->segs,
+                (const u8 *)a->d_in, (u32 *)(z + l.tile_agg), (u64 *)(z + l.group_acc));
         }
+#define HUFK_LAUNCH_ONEPASS(NWV)                                                                                      \
+    hipLaunchKernelGGL(                                                                                                \
+        enc_onepass_kernel<NWV>, dim3(persistent_grid(enc_onepass_kernel<NWV>, kPackThreads, lds, work)),              \
+        dim3(kPackThreads), lds, st, a->tables, a->items, a->segs, (const u8 *)a->d_in, (u8 *)a->d_out, region,        \
+        a->n_segs, (u32 *)(z + l.ctl), (u32 *)(z + l.tile_agg), (u64 *)(z + l.group_acc),                              \
+        (u64 *)(z + l.round_base), (u64 *)(z + l.item_base), a->seg_bits, a->seg_unk, a->seg_bitoff, a->seg_unk_seen,  \
+        a->item_total, a->careful_list, (const u8 *)(z + l.null_tile), (const u32 *)(z + l.tile_agg))
+        if (a->tables.max_bits <= 12) {
+            HUFK_LAUNCH_ONEPASS(4);
+        } else {
+            HUFK_LAUNCH_ONEPASS(5);
+        }
+#undef HUFK_LAUNCH_ONEPASS
         stage_mark(a->stage_events, 1, st);
         hipLaunchKernelGGL(
             enc_finish_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, a->seg_bits,

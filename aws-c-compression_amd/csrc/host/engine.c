@@ -182,7 +182,9 @@ int aws_huffman_amd_engine_new(
     }
     {
         const char *mode = getenv("AWS_HUFFMAN_AMD_ENCODE");
-        eng->single_pass = mode && strcmp(mode, "single-pass") == 0;
+        /* one pass over the input where the coder allows it (hufk_encode_one_pass_applies); "three-kernel"
+         * forces count / scan / pack, the road every other coder takes */
+        eng->single_pass = !(mode && strcmp(mode, "three-kernel") == 0);
     }
     eng->tables.max_bits = max_bits;
     eng->tables.min_bits = min_bits;
@@ -385,6 +387,7 @@ static int enc_plan_fill(
         return aws_raise_error(AWS_ERROR_OOM);
     }
     uint32_t seg = 0, large = 0, tiny = 0;
+    bool maybe_unshaped = false;
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_encode_item *src = &items[i];
         struct hufd_enc_item *dst = &h_items[i];
@@ -415,6 +418,9 @@ static int enc_plan_fill(
             sd->flags = (k == 0 ? 1u : 0u) | (k + 1 == segs ? 2u : 0u);
             sd->next_len = (uint32_t)(after < HUFD_ENC_SEG_BYTES ? after : HUFD_ENC_SEG_BYTES);
             sd->reserved = 0;
+            if (sd->len != HUFD_ENC_SEG_BYTES || (sd->in_off & 15u) != 0 || (k == 0 && ob)) {
+                maybe_unshaped = true;
+            }
         }
         if (segs > HUFD_SCAN_SMALL_MAX) {
             h_large[large++] = (uint32_t)i;
@@ -435,7 +441,7 @@ static int enc_plan_fill(
         p->d_seg_unk = hufs_malloc(cs * sizeof(uint32_t));
         p->d_seg_bitoff = hufs_malloc(cs * sizeof(uint64_t));
         p->d_careful = hufs_malloc((2 * ci + cs + 4) * sizeof(uint32_t)); /* the scan lists up to two segments an item, the wave packer any segment it leaves */
-        p->d_zero = hufs_malloc(cs * sizeof(uint64_t) + 32);
+        p->d_zero = hufs_malloc(hufk_encode_zero_bytes((uint32_t)cs, (uint32_t)ci));
         p->d_unk_seen = hufs_malloc(cs);
         p->d_item_total = hufs_malloc(ci * sizeof(uint64_t));
         p->d_states = hufs_malloc(ci * sizeof(struct hufd_enc_item_state));
@@ -475,6 +481,7 @@ static int enc_plan_fill(
     p->n_segs = (uint32_t)n_segs;
     p->n_large = (uint32_t)n_large;
     p->n_tiny = (uint32_t)n_tiny;
+    p->maybe_unshaped = maybe_unshaped;
     return AWS_OP_SUCCESS;
 }
 
@@ -543,16 +550,14 @@ int aws_huffman_amd_encode_plan_launch_staged(
     a.seg_bitoff = p->d_seg_bitoff;
     a.careful_list = p->d_careful;
     a.zero_block = p->d_zero;
-    a.zero_bytes = (uint64_t)p->n_segs * sizeof(uint64_t) + 32;
-    a.lookback = (uint64_t *)p->d_zero;
-    a.ticket = (uint32_t *)(p->d_zero + (uint64_t)p->n_segs * sizeof(uint64_t));
-    a.careful_count = a.ticket + 4;
+    a.careful_count = (uint32_t *)p->d_zero + 2;
     a.seg_unk_seen = p->d_unk_seen;
     a.item_total = p->d_item_total;
     a.single_pass = p->engine->single_pass && !p->look_back_timed_out;
+    a.maybe_unshaped = p->maybe_unshaped;
     p->last_input = device_input;
     p->last_output = device_output;
-    p->last_single_pass = a.single_pass && p->n_segs && !length_only && p->engine->tables.max_bits <= 16;
+    p->last_single_pass = a.single_pass && p->n_segs && !length_only && hufk_encode_one_pass_applies(&p->engine->tables);
     a.states = p->d_states;
     a.results = p->d_results;
     a.stage_events = stage_events;
@@ -573,7 +578,7 @@ int aws_huffman_amd_encode_plan_raw_results(
          * (it raises the flag and leaves its output undefined), redo the launch with the
          * three-kernel path, which has no cross-workgroup waits, and stay on it. */
         uint32_t timed_out = 0;
-        const uint8_t *flag = p->d_zero + (uint64_t)p->n_segs * sizeof(uint64_t) + sizeof(uint32_t);
+        const uint8_t *flag = p->d_zero + sizeof(uint32_t);
         err = hufs_copy_d2h(&timed_out, flag, sizeof(timed_out), st);
         if (!err) {
             err = hufs_stream_sync(st);

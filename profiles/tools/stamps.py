@@ -44,15 +44,24 @@ def report(name, r, phases):
         print("   %-44s %9.0f  %5.1f %%" % (ph, d[:, i].mean(), 100 * d[:, i].mean() / life.mean()))
 
 
-for _ in range(2):
-    eng.encode_launch(ep, d_in, d_enc)
-    eng.encode_results(ep, 1)
-segs = (n + 16383) // 16384
-r = rows(2, min(segs, 4096), 8)
-r = r[(r[:, 0] > 0) & (r[:, 7] > r[:, 0])]  # persistent kernel: one row per resident workgroup (its last segment)
-report("enc_pack_stream (last segment of each resident workgroup)", r,
-       ["segment + item + input loads, zero image, barrier", "lookups + merge to quads (first half)",
-        "wave scan + barrier (first half)", "place + second half", "wait barrier", "-", "copy out"])
+def zero_rows():
+    z = np.zeros(3 * MAX_WG * 8, dtype=np.uint64)
+    eng.upload(d_rows, z.view(np.uint8))
+
+
+zero_rows()
+eng.encode_launch(ep, d_in, d_enc)
+eng.encode_results(ep, 1)
+r = rows(2, 4096, 8)
+r = r[r[:, 0] > 0]  # persistent kernel: one row per resident workgroup, sums over its tiles
+tiles = (n + 4095) // 4096
+per = tiles / 8.0 / max(len(r), 1)  # iterations of a workgroup's wave 0
+print("enc_onepass: %d resident workgroups, %.1f tiles per wave" % (len(r), per))
+rr = np.stack([r[:, 0], r[:, 1], r[:, 7], r[:, 2], r[:, 3], r[:, 4], r[:, 5]], axis=1)
+report("enc_onepass (sum over the tiles of wave 0 of each workgroup)", rr,
+       ["fresh tile: descriptors, loads, look-ups, octs, scan, publish", "old tile: wait for the offsets asked for at the top of the turn",
+        "old tile: polls (offsets not there yet)", "old tile: records, last byte, shifted copy-out", "fresh tile: octs into the image", "-"])
+print("   polls per tile: %.2f" % (r[:, 6].mean() / per))
 for _ in range(2):
     eng.decode_launch(dp, d_enc, d_back)
     eng.decode_results(dp, 1)

@@ -328,6 +328,26 @@ inline T atomicMax(T *p, T v) {
     return old;
 }
 
+/* clang's scoped atomic builtins, as the kernels spell their agent-scope hand-offs: one workgroup runs at a
+ * time here and its work-items are fibers of one thread, so a plain access is what they come to */
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(n) ((void)0)
+template <typename T>
+inline T __hip_atomic_load(const T *p, int, int) {
+    return *p;
+}
+template <typename T, typename V>
+inline void __hip_atomic_store(T *p, V v, int, int) {
+    *p = (T)v;
+}
+template <typename T, typename V>
+inline T __hip_atomic_fetch_add(T *p, V v, int, int) {
+    const T old = *p;
+    *p = old + (T)v;
+    return old;
+}
+
 /* ------------------------------------------------------------------ runtime API: host memory stands in for device memory */
 
 inline hipError_t hipGetDeviceCount(int *n) {

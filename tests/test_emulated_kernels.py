@@ -107,9 +107,11 @@ def test_large_items_take_the_workgroup_scan(world):
     pc.one_shot_roundtrips(world, sizes=[16384 * 66 + 3, 32768 * 70], seed=21)
 
 
-def test_single_pass_encoder(oracle):
-    """The fused count + look-back + pack kernel (AWS_HUFFMAN_AMD_ENCODE=single-pass): same scenarios."""
-    os.environ["AWS_HUFFMAN_AMD_ENCODE"] = "single-pass"
+def test_three_kernel_encoder(oracle):
+    """Coders the one-pass encoder takes (every symbol coded, codes of 4..15 bits -- the test coder) also have the
+    count / scan / pack road (AWS_HUFFMAN_AMD_ENCODE=three-kernel): it is what the library falls back to when a
+    look-back wait runs out, and what every other coder takes.  Same scenarios."""
+    os.environ["AWS_HUFFMAN_AMD_ENCODE"] = "three-kernel"
     try:
         product = harness.Codec(harness.load_product(EMU_SO), "aws_")
         w = pc.World(oracle, product)  # fresh coder objects: fresh engines that read the switch
@@ -120,3 +122,9 @@ def test_single_pass_encoder(oracle):
         pc.batched_device_api(w)
     finally:
         del os.environ["AWS_HUFFMAN_AMD_ENCODE"]
+
+
+def test_one_pass_encoder_across_rounds(world):
+    """The emulator build keeps 4 tiles a look-back group and 4 groups a round (tests/emu/Makefile), so that a few
+    hundred KiB cross many group and round boundaries of the one-pass encoder."""
+    pc.one_shot_roundtrips(world, sizes=[16384 * 40, 16384 * 37 + 4097], seed=33)
