@@ -55,7 +55,10 @@ void aws_compression_library_init(struct aws_allocator *alloc) {
     set_up(1, alloc);
 }
 
+void aws_huffman_amd_forget_all(void); /* huffman.c: the engines behind the eight reference entry points */
+
 void aws_compression_library_clean_up(void) {
+    aws_huffman_amd_forget_all(); /* the device tables and staging buffers cached per coder */
     set_up(0, 0);
 }
 

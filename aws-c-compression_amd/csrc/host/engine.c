@@ -154,6 +154,7 @@ int aws_huffman_amd_engine_new(
     eng->key_encode = (void *)coder->encode;
     eng->key_decode = (void *)coder->decode;
     eng->key_userdata = coder->userdata;
+    eng->fingerprint = aws_huffman_amd_coder_fingerprint(coder);
 
     /* encode table: one callback per symbol (reference huffman.h:37) */
     uint32_t max_bits = 0, min_bits = 33;

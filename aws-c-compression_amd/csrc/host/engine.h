@@ -18,6 +18,7 @@ struct aws_huffman_amd_engine {
     void *key_encode;
     void *key_decode;
     void *key_userdata;
+    uint64_t fingerprint; /* aws_huffman_amd_coder_fingerprint(coder) when the tables were made */
 
     uint64_t enc_table[256]; /* host copy: length << 32 | masked code */
     uint16_t *dec_lut_host;
@@ -102,6 +103,11 @@ struct aws_huffman_amd_decode_plan {
     struct hufd_dec_item_state *d_states;
     struct hufd_dec_result *d_results;
 };
+
+/* the engine cache of huffman.c: what an engine is recognised by besides the coder's address, and the two ways out of it */
+uint64_t aws_huffman_amd_coder_fingerprint(struct aws_huffman_symbol_coder *coder);
+void aws_huffman_amd_forget_coder(struct aws_huffman_symbol_coder *coder);
+void aws_huffman_amd_forget_all(void);
 
 int aws_huffman_amd_encode_plan_raw_results(struct aws_huffman_amd_encode_plan *plan, struct hufd_enc_result *raw, void *stream);
 void aws_huffman_amd_encode_result_from_raw(const struct hufd_enc_result *raw, struct aws_huffman_amd_encode_result *out);

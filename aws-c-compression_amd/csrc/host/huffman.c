@@ -21,12 +21,69 @@
  * The structs of the reference have no room for a handle, so the staged tables
  * are found again through the coder: one engine per (coder pointer, callbacks,
  * userdata, current device), created on first use.
+ *
+ * A pointer says nothing about what it points to: a coder may be freed and another one
+ * allocated at the same address, or its table changed behind the same userdata.  So an
+ * engine also remembers a fingerprint of the 256 answers of the encode callback it was
+ * tabulated from, and every look-up asks the callback again (256 calls, well under a
+ * microsecond -- a call through this library costs tens) and retires an engine whose
+ * fingerprint no longer matches.  aws_huffman_amd_table_coder_destroy and
+ * aws_compression_library_clean_up drop what they can (aws_huffman_amd_forget_coder / _all).
  */
 enum { ENGINE_SLOTS = 16 };
 static struct aws_huffman_amd_engine *s_engines[ENGINE_SLOTS];
 static unsigned s_engine_clock[ENGINE_SLOTS];
 static unsigned s_clock;
 static pthread_mutex_t s_engine_lock = PTHREAD_MUTEX_INITIALIZER;
+
+uint64_t aws_huffman_amd_coder_fingerprint(struct aws_huffman_symbol_coder *coder) {
+    uint64_t h = 0xCBF29CE484222325ull; /* FNV-1a over (pattern masked to its length, length) of every symbol */
+    if (!coder->encode) {
+        return h;
+    }
+    for (int sym = 0; sym < 256; ++sym) {
+        const struct aws_huffman_code c = coder->encode((uint8_t)sym, coder->userdata);
+        const uint32_t n = c.num_bits;
+        const uint32_t pat = n == 0 ? 0 : (n >= 32 ? c.pattern : c.pattern & ((1u << n) - 1u));
+        h = (h ^ pat) * 0x100000001B3ull;
+        h = (h ^ n) * 0x100000001B3ull;
+    }
+    return h;
+}
+
+/* retires slot i if nobody is inside its engine; otherwise makes sure it is never handed out again
+ * (its turn comes when a slot is needed and its last user has left) */
+static void engine_retire_locked(int i) {
+    struct aws_huffman_amd_engine *e = s_engines[i];
+    if (!e) {
+        return;
+    }
+    if (e->users == 0) {
+        aws_huffman_amd_engine_destroy(e);
+        s_engines[i] = NULL;
+    } else {
+        e->coder = NULL;
+        s_engine_clock[i] = 0;
+    }
+}
+
+void aws_huffman_amd_forget_coder(struct aws_huffman_symbol_coder *coder) {
+    pthread_mutex_lock(&s_engine_lock);
+    for (int i = 0; i < ENGINE_SLOTS; ++i) {
+        if (s_engines[i] && s_engines[i]->coder == coder) {
+            engine_retire_locked(i);
+        }
+    }
+    pthread_mutex_unlock(&s_engine_lock);
+}
+
+void aws_huffman_amd_forget_all(void) {
+    pthread_mutex_lock(&s_engine_lock);
+    for (int i = 0; i < ENGINE_SLOTS; ++i) {
+        engine_retire_locked(i);
+    }
+    pthread_mutex_unlock(&s_engine_lock);
+}
 
 /* the engine of a coder, held for one call: counted (so that it is not retired under the caller) and locked (its
  * staging buffers and one-item plans serve one call at a time; different threads may share a coder, as the
@@ -37,6 +94,7 @@ static struct aws_huffman_amd_engine *engine_acquire(struct aws_huffman_symbol_c
         aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION); /* no GPU: fail loudly, there is no CPU path */
         return NULL;
     }
+    const uint64_t fingerprint = aws_huffman_amd_coder_fingerprint(coder);
     pthread_mutex_lock(&s_engine_lock);
     struct aws_huffman_amd_engine *found = NULL;
     int slot = -1;
@@ -44,8 +102,12 @@ static struct aws_huffman_amd_engine *engine_acquire(struct aws_huffman_symbol_c
         struct aws_huffman_amd_engine *e = s_engines[i];
         if (e && e->coder == coder && e->key_encode == (void *)coder->encode &&
             e->key_decode == (void *)coder->decode && e->key_userdata == coder->userdata && e->device == device) {
-            found = e;
-            s_engine_clock[i] = ++s_clock;
+            if (e->fingerprint == fingerprint) {
+                found = e;
+                s_engine_clock[i] = ++s_clock;
+            } else {
+                engine_retire_locked(i); /* same address, another table */
+            }
         }
     }
     if (!found) {

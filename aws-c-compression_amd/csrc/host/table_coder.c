@@ -238,8 +238,13 @@ struct aws_huffman_symbol_coder *aws_huffman_amd_table_coder_from_def(const char
     return aws_huffman_amd_table_coder_new(patterns, num_bits);
 }
 
+/* (huffman.c: retires the engines tabulated from this coder, so that neither their device memory nor -- should the
+ * allocator hand the address out again -- their tables outlive it) */
+void aws_huffman_amd_forget_coder(struct aws_huffman_symbol_coder *coder);
+
 void aws_huffman_amd_table_coder_destroy(struct aws_huffman_symbol_coder *coder) {
     if (coder) {
+        aws_huffman_amd_forget_coder(coder);
         free(coder->userdata);
     }
 }

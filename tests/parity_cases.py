@@ -470,6 +470,44 @@ def other_coders(w, n=60000, seed=23):
                     paired_decode(w, ddo, ddp, want, 0, cut, oo, op, 0, n)
 
 
+# ----------------------------------------------------------------------------- scenario: a coder destroyed and another one made (often at the same address)
+def recreated_coders(w, rounds=6, n=3000, seed=61):
+    """The product finds its device tables again through the coder's address.  An address says nothing about the
+    table behind it: destroy a coder, make one with another table -- malloc likes to hand the same block out
+    again -- and the next call must encode with the NEW table (checked against the oracle's coder of that table).
+    Also: the library's clean-up in between, which drops every cached engine."""
+    import ctypes as C
+
+    rng = np.random.default_rng(seed)
+    names = ["len4to12", "len8", "len4to15", "len2to12"]
+    seen = set()
+    for k in range(rounds):
+        name = names[k % len(names)]
+        lengths = [l for count, l in CODER_PROFILES[name] for _ in range(count)]
+        patterns, lens = canonical_code(lengths)
+        if k % 2:
+            # a permutation of the same lengths: same callbacks, same sizes, different codes per symbol
+            perm = rng.permutation(256)
+            patterns, lens = [patterns[i] for i in perm], [lens[i] for i in perm]
+        pat_arr, len_arr = (C.c_uint32 * 256)(*patterns), (C.c_uint8 * 256)(*lens)
+        oc = w.oracle.lib.oracle_table_coder_new(pat_arr, len_arr)
+        pc = w.product.lib.aws_huffman_amd_table_coder_new(pat_arr, len_arr)
+        seen.add(C.addressof(pc.contents))
+        data = rng.integers(0, 256, n).astype(np.uint8)
+        want = w.oracle.encode_all(oc, data, slack=64 + 3 * n)
+        got = w.product.encode_all(pc, data, slack=64 + 3 * n)
+        assert np.array_equal(got, want), "round %d (%s): encoded with a stale table" % (k, name)
+        r, back = w.product.decode_all(pc, want, n)
+        assert r.rc == 0 and np.array_equal(back, data), "round %d (%s): decoded with a stale table" % (k, name)
+        if k == rounds // 2:
+            w.product.lib.aws_compression_library_clean_up()
+            got = w.product.encode_all(pc, data, slack=64 + 3 * n)  # engines are made again on demand
+            assert np.array_equal(got, want)
+        w.product.lib.aws_huffman_amd_table_coder_destroy(pc)
+        w.oracle.lib.oracle_table_coder_destroy(oc)
+    return len(seen)  # (how many distinct addresses the coders had: fewer than `rounds` means addresses came back)
+
+
 # ----------------------------------------------------------------------------- scenario: streams cut at every kind of place (end-of-stream handling of the chunked decoder)
 def cut_streams(w, seed=29, chunks=(1, 2, 5), step=7, span=140, n=200_000):
     """A valid stream cut short at byte positions all around chunk and sub-chunk boundaries: the decoder must

@@ -69,6 +69,10 @@ def test_foreign_coder_callbacks(world):
     pc.foreign_coder_callbacks(world)
 
 
+def test_recreated_coders(world):
+    pc.recreated_coders(world)
+
+
 def test_batched_device_api(world):
     pc.batched_device_api(world)
 

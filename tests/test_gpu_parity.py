@@ -92,6 +92,10 @@ def test_foreign_coder_callbacks(world):
     pc.foreign_coder_callbacks(world)
 
 
+def test_recreated_coders(world):
+    pc.recreated_coders(world, rounds=8, n=40000)
+
+
 def test_batched_device_api(world, engine):
     pc.batched_device_api(world, n_items=40, engine=engine)
 
