@@ -481,6 +481,7 @@ def recreated_coders(w, rounds=6, n=3000, seed=61):
     rng = np.random.default_rng(seed)
     names = ["len4to12", "len8", "len4to15", "len2to12"]
     seen = set()
+    previous = None
     for k in range(rounds):
         name = names[k % len(names)]
         lengths = [l for count, l in CODER_PROFILES[name] for _ in range(count)]
@@ -490,8 +491,11 @@ def recreated_coders(w, rounds=6, n=3000, seed=61):
             perm = rng.permutation(256)
             patterns, lens = [patterns[i] for i in perm], [lens[i] for i in perm]
         pat_arr, len_arr = (C.c_uint32 * 256)(*patterns), (C.c_uint8 * 256)(*lens)
-        oc = w.oracle.lib.oracle_table_coder_new(pat_arr, len_arr)
+        if previous is not None:
+            w.product.lib.aws_huffman_amd_table_coder_destroy(previous)  # ... and at once a new one of the same size
         pc = w.product.lib.aws_huffman_amd_table_coder_new(pat_arr, len_arr)
+        previous = pc
+        oc = w.oracle.lib.oracle_table_coder_new(pat_arr, len_arr)
         seen.add(C.addressof(pc.contents))
         data = rng.integers(0, 256, n).astype(np.uint8)
         want = w.oracle.encode_all(oc, data, slack=64 + 3 * n)
@@ -503,8 +507,8 @@ def recreated_coders(w, rounds=6, n=3000, seed=61):
             w.product.lib.aws_compression_library_clean_up()
             got = w.product.encode_all(pc, data, slack=64 + 3 * n)  # engines are made again on demand
             assert np.array_equal(got, want)
-        w.product.lib.aws_huffman_amd_table_coder_destroy(pc)
         w.oracle.lib.oracle_table_coder_destroy(oc)
+    w.product.lib.aws_huffman_amd_table_coder_destroy(previous)
     return len(seen)  # (how many distinct addresses the coders had: fewer than `rounds` means addresses came back)
 
 
