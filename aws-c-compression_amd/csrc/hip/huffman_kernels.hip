@@ -2783,7 +2783,7 @@ struct row_walk {
     u32 floor;  /* (u16)state after a row is at least this unless the walk died */
     u32 sure;   /* codes that are certain to start in a row: taken without asking (no compare, no branch, no lane mask) */
 
-    __device__ __forceinline__ row_walk(u32 lut_bits, u32 max_bits) {
+    __device__ __host__ __forceinline__ row_walk(u32 lut_bits, u32 max_bits) {
         /* 512 = a multiple of 64 that keeps the low half positive through `sure` steps of a dead walk (48 bits each) */
         thr = 512 + (32 - lut_bits) - 2;
         mask = ((1u << lut_bits) - 1u) << 2;
@@ -3427,6 +3427,271 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, TAIL ? (LB <= 10 ? 6 : 4) : 8) void
             cand_reached ? wide_pack(false, TAIL ? 0u : last_exit, cand_count + rest) : wide_pack(true, 0, cand_dead);
     }
     HUFD_STAMP(0, 5);
+}
+
+/* ------------------------------------------------------------------ decode: sync, regular chunks, fewer instructions */
+
+/*
+ * An LDS address as a number, and a word read at such a number: a walk-table entry is then read at
+ * (window & mask) | table, ONE instruction for the address where pointer arithmetic gives two (and + add), given a
+ * table that starts at a multiple of its size.
+ */
+__device__ __forceinline__ u32 lds_offset_of(const void *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (u32)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+#else
+    return (u32)(reinterpret_cast<const u8 *>(p) - dyn_lds);
+#endif
+}
+__device__ __forceinline__ u32 lds_word_at(u32 byte_offset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const __attribute__((address_space(3))) u32 *)(uintptr_t)byte_offset;
+#else
+    return *reinterpret_cast<const u32 *>(dyn_lds + byte_offset);
+#endif
+}
+
+/* a value the compiler is to keep as computed (it otherwise swaps a word's bytes again at every use to save a register) */
+__device__ __forceinline__ u32 settled_value(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+
+template <u32 LB>
+struct lean_shared {
+    u32 wlut[1u << LB]; /* 0x10000 - length, length 48 = no code; at a multiple of its own size */
+    u32 exit_state[HUFD_DEC_LANES];
+    u32 sub0[kFastMaxMeet + 4]; /* the first rows of sub-chunk 0, for the threads that try its entry states */
+    u32 wave_sum[HUFD_DEC_LANES / 64];
+    u32 bad;
+    u32 pad[3];
+    u16 hops[1u << LB]; /* 1 << code length of a window (the head it sends on), 0 = no code */
+};
+
+/* row_walk::row with the number of certain steps known to the compiler and the table given as an LDS offset */
+template <u32 SURE, bool STEP_BY_STEP = false>
+__device__ __forceinline__ u32 lean_row(u32 state, u32 hi, u32 lo, u32 table, const row_walk &rw) {
+    const u64 pair = ((u64)hi << 32) | lo;
+    if (!STEP_BY_STEP) {
+#pragma unroll
+        for (u32 i = 0; i < SURE; ++i) {
+            state += lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
+        }
+    }
+    while ((state & 0xFFFFu) > rw.thr) {
+        state += lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
+    }
+    return state;
+}
+
+/*
+ * dec_sync_fast for the chunks inside a stream with fewer instructions (it was bound by them: 297 M vector
+ * instructions per GiB, 17.7 per symbol, at one per 4 cycles and SIMD).  Same phases, same tables out; what is
+ * different is what a step of a walk costs: the number of certain steps a row is known to the compiler (no loop
+ * around them), a table entry's address is one instruction (lean_row), the words are byte-swapped once.
+ */
+template <u32 LB, u32 SURE>
+__global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
+    hufd_tables tb,
+    const hufd_dec_item *items,
+    const u32 *chunk_item,
+    const u8 *d_in,
+    u16 *fn_tab,
+    u16 *cp_tab,
+    u32 *chunk_fn,
+    u16 *lane_count,
+    u8 *chunk_regular,
+    u32 *slow_list,
+    u32 *slow_count) {
+
+    lean_shared<LB> &sh = *reinterpret_cast<lean_shared<LB> *>(dyn_lds);
+    const u32 ns = tb.n_states;
+    const u32 lane = threadIdx.x;
+    const u32 c = blockIdx.x;
+    const hufd_dec_item it = items[chunk_item[c]];
+    const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
+    const u64 valid = it.in_len > chunk_off ? it.in_len - chunk_off : 0;
+    const u8 *src = d_in + it.in_off + chunk_off;
+    if (valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
+        return; /* holds the end of its stream: dec_sync_fast<LB, true>'s */
+    }
+    const row_walk rw(LB, tb.max_bits);
+    const u32 table = lds_offset_of(sh.wlut);
+    const bool eligible = ((uintptr_t)src & 15u) == 0 && tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS &&
+                          rw.sure == SURE && (table & ((4u << LB) - 1u)) == 0;
+    if (!eligible) {
+        if (lane == 0) {
+            chunk_regular[c] = 0;
+            slow_list[atomicAdd(slow_count, 1u)] = c;
+        }
+        return;
+    }
+
+    u32 w[kFastRows];
+    {
+        const uint4 *line = reinterpret_cast<const uint4 *>(src + (u64)lane * HUFD_DEC_SUB_BYTES);
+#pragma unroll
+        for (u32 q = 0; q < kSubWords / 4; ++q) {
+            const uint4 v = line[q];
+            w[4 * q + 0] = __builtin_bswap32(v.x);
+            w[4 * q + 1] = __builtin_bswap32(v.y);
+            w[4 * q + 2] = __builtin_bswap32(v.z);
+            w[4 * q + 3] = __builtin_bswap32(v.w);
+        }
+        w[kSubWords] = __builtin_bswap32(*reinterpret_cast<const u32 *>(src + (u64)(lane + 1) * HUFD_DEC_SUB_BYTES));
+    }
+    for (u32 i = lane; i < (1u << LB); i += HUFD_DEC_LANES) {
+        const u32 len = tb.dec_lut[i >> (LB - tb.lut_bits)] & 0xFFu;
+        sh.wlut[i] = 0x10000u - (len ? len : kWalkDeadLen);
+        sh.hops[i] = (u16)(len ? 1u << len : 0u);
+    }
+    if (lane == 0) {
+        sh.bad = 0;
+#pragma unroll
+        for (u32 r = 0; r <= kFastMaxMeet; ++r) {
+            sh.sub0[r] = w[r];
+        }
+    }
+    __syncthreads();
+
+    /* U: all entry states as one mask of heads per row, until every lane of the wave is down to one */
+    u64 heads = (1ull << ns) - 1ull;
+    u32 meet_row = 0; /* the same for the whole wave */
+    bool one = false, settled = false;
+#pragma unroll
+    for (u32 r = 0; r < kFastMaxMeet; ++r) {
+        if (!settled) {
+            heads = union_row_fast<LB>(heads, w[r], w[r + 1], sh.hops);
+            one = heads != 0 && (heads & (heads - 1)) == 0;
+            meet_row = r + 1;
+            settled = __all(one || heads == 0);
+        }
+    }
+    const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
+    bool ok = one && settled;
+
+    /* R: the one walk from the meeting bit to the end of the sub-chunk */
+    u32 state = rw.state_at(meet_bit, 0);
+    u32 cp_state[kQuarters - 1] = {0, 0, 0};
+    bool dead = false;
+#pragma unroll
+    for (u32 r = 1; r < kSubWords; ++r) {
+        if (r >= meet_row) {
+            if (r % (kSubWords / kQuarters) == 0) {
+                cp_state[r / (kSubWords / kQuarters) - 1] = state;
+            }
+            state = lean_row<SURE>(state, w[r], w[r + 1], table, rw);
+            dead = dead || rw.died(state);
+            state += 32u; /* (a walk that has died drifts, in bounds: the chunk is not regular then and nothing of this is kept) */
+        }
+    }
+    const u32 ref_count = state >> 16; /* symbols from the meeting bit to the end of the sub-chunk */
+    const u32 ref_exit = rw.offset_of(state);
+    ok = ok && !dead && ref_exit < ns;
+    sh.exit_state[lane] = ref_exit;
+    __syncthreads();
+
+    /* H: my own sub-chunk from my true entry state, to the meeting bit */
+    const u32 entry = lane ? sh.exit_state[lane - 1] : 0u;
+    u32 count;
+    u32 head_cp = 0; /* the head walk where it enters the second quarter, when the meeting row lies behind that */
+    const bool late = meet_row > kSubWords / kQuarters;
+    {
+        u32 st = rw.state_at(entry < ns ? entry : 0u, 0);
+        bool dd = false;
+#pragma unroll
+        for (u32 r = 0; r < kFastMaxMeet; ++r) {
+            if (r < meet_row) {
+                if (r == kSubWords / kQuarters) {
+                    head_cp = st;
+                }
+                st = lean_row<SURE>(st, w[r], w[r + 1], table, rw);
+                dd = dd || rw.died(st);
+                st += 32u;
+            }
+        }
+        const bool reached = !dd && rw.offset_of(st) == meet_bit;
+        ok = ok && (lane == 0 || reached);
+        count = (st >> 16) + ref_count; /* symbols of the true path that start in my sub-chunk (lanes >= 1) */
+    }
+
+    /* H: sub-chunk 0 from every entry state the chunk may be entered in (threads 0 .. ns-1), step by step: the count
+     * of a walk that dies has to be right */
+    u32 cand_count = 0, cand_dead = 0;
+    bool cand_reached = false;
+    u64 cand_alive = 0;
+    if (lane < kWave) {
+        const u32 target = __shfl(meet_bit, 0), tail0 = __shfl(ref_count, 0); /* sub-chunk 0 is lane 0's */
+        u32 st = rw.state_at(lane < ns ? lane : 0u, 0);
+        bool dd = false;
+        u32 hi = sh.sub0[0];
+        for (u32 r = 0; r < meet_row; ++r) {
+            const u32 lo = sh.sub0[r + 1];
+            st = lean_row<SURE, true>(st, hi, lo, table, rw);
+            const bool now = rw.died(st) && !dd;
+            cand_dead = now ? (st >> 16) - 1u : cand_dead; /* the step that found no code is not a symbol */
+            dd = dd || now;
+            st = rw.next_row(st, dd);
+            hi = lo;
+        }
+        cand_reached = !dd && lane < ns && rw.offset_of(st) == target;
+        cand_alive = __ballot(cand_reached);
+        cand_count = (st >> 16) + tail0;
+    }
+
+    const u32 wsum = wave_sum(lane ? count : 0u);
+    if ((lane & (kWave - 1)) == 0) {
+        sh.wave_sum[lane / kWave] = wsum;
+    }
+    if (!ok) {
+        sh.bad = 1;
+    }
+    __syncthreads();
+    if (sh.bad) {
+        if (lane == 0) {
+            chunk_regular[c] = 0;
+            slow_list[atomicAdd(slow_count, 1u)] = c;
+        }
+        return;
+    }
+
+    /* the tables dec_scan and dec_emit read (dec_sync_fast's) */
+    u16 *fn_out = fn_tab + (u64)c * ns * HUFD_DEC_LANES;
+    u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
+#pragma unroll
+    for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+        /* a checkpoint in front of the meeting row is not on the one walk: the first one is then taken from the head
+         * walk (not for lane 0, whose head is only known to dec_scan) */
+        const bool usable = (qq + 1) * (kSubWords / kQuarters) >= meet_row;
+        u32 tail = ref_count - (cp_state[qq] >> 16), bits = rw.offset_of(cp_state[qq]);
+        bool have = usable;
+        if (qq == 0 && late && lane != 0) {
+            tail = count - (head_cp >> 16);
+            bits = rw.offset_of(head_cp);
+            have = true;
+        }
+        cp[qq * HUFD_DEC_LANES] = (u16)(have ? 0x8000u | (bits << 11) | tail : 0u);
+    }
+    lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)(lane ? count : ref_count);
+    cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((lane ? 1u << entry : (u32)cand_alive) | (ref_exit << 12));
+    if (lane == 0) {
+        chunk_regular[c] = 1;
+    }
+    if (lane < ns) {
+        u32 rest = 0;
+#pragma unroll
+        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
+            rest += sh.wave_sum[wv];
+        }
+        const u32 first_exit = sh.exit_state[0];
+        const u32 last_exit = sh.exit_state[HUFD_DEC_LANES - 1];
+        fn_out[(u64)lane * HUFD_DEC_LANES] =
+            cand_reached ? fn_pack(false, first_exit, cand_count & 0x7FFu) : fn_pack(true, 0, cand_dead);
+        chunk_fn[(u64)c * ns + lane] =
+            cand_reached ? wide_pack(false, last_exit, cand_count + rest) : wide_pack(true, 0, cand_dead);
+    }
 }
 
 /* ------------------------------------------------------------------ decode: the end of a stream */
@@ -4502,7 +4767,8 @@ struct emit_shared {
     u32 tail_words[2][kTailWords]; /* TAIL: the stream's last words, for the one or two careful lanes */
 };
 
-template <u32 LB, bool TAIL> /* TAIL: the chunks listed in tail_chunks (they may hold the end of a stream); else all the others */
+template <u32 LB, bool TAIL, u32 SURE = 0> /* TAIL: the chunks listed in tail_chunks (they may hold the end of a stream); else all the others.
+                                             * SURE: the codes that are certain to start in a row, when the launch knows (0: asked of the coder at run time) */
 __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_kernel(
     hufd_tables tb,
     const hufd_dec_item *items,
@@ -4562,7 +4828,8 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
     }
     const bool fits = regular != 0 && (regular == 2 || !wide_stop(f0)) && ((cpt[merged_row] >> s0) & 1u) != 0 &&
                       cbase + chunk_symbols <= it.out_cap;
-    const bool fast = fits && chunk_symbols + 16 <= HUFD_DEC_STAGE_BYTES;
+    const bool fast = fits && chunk_symbols + 16 <= HUFD_DEC_STAGE_BYTES &&
+                      (lds_offset_of(sh.wlut) & ((4u << LB) - 1u)) == 0 && (SURE == 0 || SURE == row_walk(LB, tb.max_bits).sure);
     if (!fast) {
         if (t == 0) {
             if (fits && chunk_symbols + 32 <= 2 * HUFD_DEC_STAGE_BYTES) {
@@ -4676,6 +4943,9 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
     }
     HUFD_STAMP(1, 2);
     const u8 *lut = reinterpret_cast<const u8 *>(sh.wlut);
+    /* (the table sits at a multiple of its size: an entry's address is (window & mask) | table, one instruction) */
+    const u32 table = lds_offset_of(sh.wlut);
+    const u32 sure = SURE ? SURE : rw.sure;
 #pragma unroll
     for (u32 r = 0; r < kRows; ++r) {
         u64 pair[kEmitChains];
@@ -4683,11 +4953,12 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
         for (u32 ch = 0; ch < kEmitChains; ++ch) {
             pair[ch] = ((u64)w[ch][r] << 32) | w[ch][r + 1];
         }
-        for (u32 i = 0; i < rw.sure; ++i) { /* the codes that are certain to start in this row, the two chains in turn */
+#pragma unroll
+        for (u32 i = 0; i < sure; ++i) { /* the codes that are certain to start in this row, the two chains in turn */
             u32 e[kEmitChains];
 #pragma unroll
             for (u32 ch = 0; ch < kEmitChains; ++ch) {
-                e[ch] = *reinterpret_cast<const u32 *>(lut + ((u32)(pair[ch] >> (st[ch] & 63u)) & rw.mask));
+                e[ch] = lds_word_at(((u32)(pair[ch] >> (st[ch] & 63u)) & rw.mask) | table);
             }
 #pragma unroll
             for (u32 ch = 0; ch < kEmitChains; ++ch) {
@@ -4698,7 +4969,7 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
 #pragma unroll
         for (u32 ch = 0; ch < kEmitChains; ++ch) {
             while ((st[ch] & 0xFFFFu) > rw.thr) {
-                const u32 e = *reinterpret_cast<const u32 *>(lut + ((u32)(pair[ch] >> (st[ch] & 63u)) & rw.mask));
+                const u32 e = lds_word_at(((u32)(pair[ch] >> (st[ch] & 63u)) & rw.mask) | table);
                 lds_bytes[dst[ch]++] = (u8)(e >> 16);
                 st[ch] += e;
             }
@@ -5523,8 +5794,35 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         const auto sync = ns <= 8 ? dec_sync_kernel<8> : (ns <= 10 ? dec_sync_kernel<10> : dec_sync_kernel<12>);
         (void)hipMemsetAsync(a->slow_count, 0, sizeof(uint32_t), st);
         const bool some_inside = a->n_tail < a->n_chunks; /* chunks with a whole chunk + 8 bytes of stream left */
+        /* chunks inside a stream: the lean kernel where it is compiled for this coder's number of certain steps a row */
+        const uint32_t sure = row_walk(a->tables.lut_bits <= 10 ? 10u : 12u, a->tables.max_bits).sure;
+        bool lean = false;
+#define HUFK_LAUNCH_SYNC_LEAN(LBV, SUREV)                                                                               \
+    hipLaunchKernelGGL(                                                                                                \
+        (dec_sync_lean_kernel<LBV, SUREV>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(lean_shared<LBV>), \
+        st, a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count,  \
+        a->chunk_regular, a->slow_list, a->slow_count)
+        if (some_inside && !a->old_sync && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS) {
+            lean = true;
+            if (a->tables.lut_bits <= 10) {
+                switch (sure) {
+                    case 2: HUFK_LAUNCH_SYNC_LEAN(10, 2); break;
+                    case 3: HUFK_LAUNCH_SYNC_LEAN(10, 3); break;
+                    case 4: HUFK_LAUNCH_SYNC_LEAN(10, 4); break;
+                    case 5: HUFK_LAUNCH_SYNC_LEAN(10, 5); break;
+                    default: lean = false; break;
+                }
+            } else {
+                switch (sure) {
+                    case 2: HUFK_LAUNCH_SYNC_LEAN(12, 2); break;
+                    case 3: HUFK_LAUNCH_SYNC_LEAN(12, 3); break;
+                    default: lean = false; break;
+                }
+            }
+        }
+#undef HUFK_LAUNCH_SYNC_LEAN
         if (a->tables.lut_bits <= 10) {
-            if (some_inside)
+            if (some_inside && !lean)
             hipLaunchKernelGGL(
                 (dec_sync_fast_kernel<10, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<10>),
                 st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
@@ -5536,7 +5834,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
                     a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry, a->slow_list, a->slow_count);
             }
         } else {
-            if (some_inside)
+            if (some_inside && !lean)
             hipLaunchKernelGGL(
                 (dec_sync_fast_kernel<12, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<12>),
                 st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
@@ -5602,27 +5900,39 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         /* regular chunks that fit their output the short way; the rest through the list */
         (void)hipMemsetAsync(a->emit_count, 0, sizeof(uint32_t), st);
         (void)hipMemsetAsync(a->dense_count, 0, sizeof(uint32_t), st);
-#define HUFK_LAUNCH_EMIT_FAST(LBV, TAILV, GRID)                                                                          \
+#define HUFK_LAUNCH_EMIT_FAST(LBV, TAILV, SUREV, GRID)                                                                   \
     hipLaunchKernelGGL(                                                                                                \
-        (dec_emit_fast_kernel<LBV, TAILV>), dim3(GRID), dim3(kEmitFastThreads), (uint32_t)sizeof(emit_shared<LBV>), st, \
-        a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, (u8 *)a->d_out,                       \
+        (dec_emit_fast_kernel<LBV, TAILV, SUREV>), dim3(GRID), dim3(kEmitFastThreads), (uint32_t)sizeof(emit_shared<LBV>), \
+        st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, (u8 *)a->d_out,                   \
         (const u16 *)a->cp_tab, (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn,    \
         (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results, a->emit_list, a->emit_count,              \
         a->dense_list, a->dense_count)
         const bool some_inside = a->n_tail < a->n_chunks;
+        /* (chunks inside a stream: with the coder's number of certain steps a row compiled in, where there is such a build) */
+        const uint32_t emit_sure = a->old_sync ? 0u : row_walk(a->tables.lut_bits <= 10 ? 10u : 12u, a->tables.max_bits).sure;
         if (a->tables.lut_bits <= 10) {
             if (some_inside) {
-                HUFK_LAUNCH_EMIT_FAST(10, false, a->n_chunks);
+                switch (emit_sure) {
+                    case 2: HUFK_LAUNCH_EMIT_FAST(10, false, 2, a->n_chunks); break;
+                    case 3: HUFK_LAUNCH_EMIT_FAST(10, false, 3, a->n_chunks); break;
+                    case 4: HUFK_LAUNCH_EMIT_FAST(10, false, 4, a->n_chunks); break;
+                    case 5: HUFK_LAUNCH_EMIT_FAST(10, false, 5, a->n_chunks); break;
+                    default: HUFK_LAUNCH_EMIT_FAST(10, false, 0, a->n_chunks); break;
+                }
             }
             if (a->n_tail) {
-                HUFK_LAUNCH_EMIT_FAST(10, true, a->n_tail);
+                HUFK_LAUNCH_EMIT_FAST(10, true, 0, a->n_tail);
             }
         } else {
             if (some_inside) {
-                HUFK_LAUNCH_EMIT_FAST(12, false, a->n_chunks);
+                switch (emit_sure) {
+                    case 2: HUFK_LAUNCH_EMIT_FAST(12, false, 2, a->n_chunks); break;
+                    case 3: HUFK_LAUNCH_EMIT_FAST(12, false, 3, a->n_chunks); break;
+                    default: HUFK_LAUNCH_EMIT_FAST(12, false, 0, a->n_chunks); break;
+                }
             }
             if (a->n_tail) {
-                HUFK_LAUNCH_EMIT_FAST(12, true, a->n_tail);
+                HUFK_LAUNCH_EMIT_FAST(12, true, 0, a->n_tail);
             }
         }
 #undef HUFK_LAUNCH_EMIT_FAST

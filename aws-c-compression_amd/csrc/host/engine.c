@@ -1002,6 +1002,10 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.chunk_base = p->d_chunk_base;
     a.states = p->d_states;
     a.results = p->d_results;
+    {
+        const char *mode = getenv("AWS_HUFFMAN_AMD_DECODE");
+        a.old_sync = mode && strcmp(mode, "old-sync") == 0; /* the kernel dec_sync_lean replaced, for comparison and tests */
+    }
     a.stage_events = stage_events;
     hufs_set_device(p->engine->device);
     const int err = hufk_decode_launch(&a, stream ? stream : p->engine->stream);
