@@ -21,6 +21,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <pthread.h>
 #include <stdint.h>
 
 #include "device_types.h"
@@ -5477,7 +5478,19 @@ __global__ __launch_bounds__(256) void splitmix64_fill_kernel(u8 *dst, u64 len, 
 
 /* ------------------------------------------------------------------ launch wrappers */
 
-static int s_compute_units = 256;
+/* per device: compute units (sizes the grids of the persistent kernels) and whether hufk_init has run there */
+constexpr int kMaxDevices = 64;
+static int s_compute_units[kMaxDevices];
+static bool s_device_ready[kMaxDevices];
+static pthread_mutex_t s_init_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static int current_compute_units() {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMaxDevices || s_compute_units[device] <= 0) {
+        return 256;
+    }
+    return s_compute_units[device];
+}
 
 /* workgroups of a persistent kernel that one launch keeps resident: CUs x blocks per CU */
 template <typename Kernel>
@@ -5487,7 +5500,7 @@ static uint32_t persistent_grid(Kernel kernel, uint32_t threads, uint32_t lds_by
         per_cu < 1) {
         per_cu = 1;
     }
-    const uint64_t resident = (uint64_t)s_compute_units * (uint32_t)per_cu;
+    const uint64_t resident = (uint64_t)current_compute_units() * (uint32_t)per_cu;
     return (uint32_t)(work_items < resident ? work_items : resident);
 }
 
@@ -5513,6 +5526,8 @@ static onepass_layout onepass_layout_of(uint64_t n_segs, uint64_t n_items) {
 
 extern "C" {
 
+/* for the calling thread's current device; every device an engine is made on gets its own call (the opt-ins below are
+ * per device, and so is the number of compute units), threads may race here */
 int hufk_init(void) {
     /* a workgroup may use up to 160 KiB of LDS on gfx950, but dynamic LDS above 64 KiB is opt-in */
 #ifdef HUFD_STAMPS
@@ -5521,10 +5536,18 @@ int hufk_init(void) {
     const int lds_max = 160 * 1024;
 #endif
     int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMaxDevices) {
+        return (int)hipErrorInvalidDevice;
+    }
+    pthread_mutex_lock(&s_init_lock);
+    if (s_device_ready[device]) {
+        pthread_mutex_unlock(&s_init_lock);
+        return 0;
+    }
     hipDeviceProp_t prop;
-    if (hipGetDevice(&device) == hipSuccess && hipGetDeviceProperties(&prop, device) == hipSuccess &&
-        prop.multiProcessorCount > 0) {
-        s_compute_units = prop.multiProcessorCount;
+    s_compute_units[device] = 256;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+        s_compute_units[device] = prop.multiProcessorCount;
     }
     hipError_t e = hipFuncSetAttribute(
         reinterpret_cast<const void *>(&dec_emit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -5573,6 +5596,8 @@ int hufk_init(void) {
         e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&enc_onepass_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     }
+    s_device_ready[device] = e == hipSuccess;
+    pthread_mutex_unlock(&s_init_lock);
     return (int)e;
 }
 

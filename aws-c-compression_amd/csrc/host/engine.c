@@ -36,7 +36,6 @@ static void *device_upload(const void *host, size_t size, void *stream, int *err
 
 /* ------------------------------------------------------------------ engine */
 
-static int s_kernels_ready;
 
 /*
  * Decode tables for a coder with codes of more than HUFD_DEC_MAX_LUT_BITS bits: a root table indexed by the
@@ -136,12 +135,11 @@ int aws_huffman_amd_engine_new(
     if (hufs_set_device(device)) {
         return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
     }
-    if (!s_kernels_ready) {
-        const int e = hufk_init();
+    {
+        const int e = hufk_init(); /* per device, once; safe from several threads */
         if (e) {
             return raise_hip(e);
         }
-        s_kernels_ready = 1;
     }
 
     struct aws_huffman_amd_engine *eng = calloc(1, sizeof(*eng));
@@ -484,6 +482,10 @@ static int enc_plan_fill(
     p->n_tiny = (uint32_t)n_tiny;
     p->maybe_unshaped = maybe_unshaped;
     return AWS_OP_SUCCESS;
+}
+
+bool aws_huffman_amd_engine_encodes_in_one_pass(const struct aws_huffman_amd_engine *eng) {
+    return eng->single_pass && hufk_encode_one_pass_applies(&eng->tables);
 }
 
 int aws_huffman_amd_encode_plan_new(

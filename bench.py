@@ -1,31 +1,41 @@
 #!/usr/bin/env python3
-"""Benchmark of the Huffman hot path on MI355X: encode + decode of 1 GiB of random bytes.
+"""Benchmark of the Huffman hot path on MI355X.
 
 Contract (one JSON line on stdout from rank 0):
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--workload stream|cfg4|host-abi]
 
-  * workload = BASELINE.json configs[1]+[2]: one 1 GiB stream of splitmix64 bytes per GPU
-    (seed 5 + rank), encoded with the test coder of the reference
-    (tests/test_huffman_static_table.def) and decoded back.  One STEP = one encode of the
-    stream + one decode of the result, inputs and outputs resident in HBM.
+  * --workload stream (default) = BASELINE.json configs[1]+[2], the configuration the metric is quoted on: one
+    1 GiB stream of splitmix64 bytes per GPU (seed 5 + rank), encoded with the test coder of the reference
+    (tests/test_huffman_static_table.def) and decoded back.  One STEP = one encode of the stream + one decode
+    of the result, inputs and outputs resident in HBM.  Weak scaling: every GPU has its own stream.
+  * --workload cfg4 = configs[3]: 65 536 buffers of 16 KiB (buffer i = splitmix64 seed 2 + i), every fourth one
+    capacity-limited (SHORT_BUFFER with the reference's record, then a resume call), decoded back; with N ranks
+    buffer i goes to rank i mod N (strong scaling: the batch is fixed).
+  * --workload host-abi = the eight reference entry points on HOST pointers (aws_huffman_encode / _decode of one
+    256 MiB buffer): PCIe-inclusive, never the headline value.
   * value = GiB of input symbols pushed through encode+decode per second, whole job:
-    N_gpus * 2^30 B / (t_encode + t_decode) / 2^30, time = max over ranks between barriers.
-  * roofline = the kernel with the largest share of the step, its algorithmic bytes
-    (DESIGN.md "Kernels") over its average duration measured with HIP events recorded on the
-    stream between the kernels of every timed step, against 8 TB/s of HBM.
-  * cpu_baseline = the CPU oracle (a port of the reference's scalar loop; the reference itself
-    needs aws-c-common and cannot be built here) timed on one host core on a bounded prefix.
+    sum over ranks of the symbols / (t_encode + t_decode), time = max over ranks between barriers.
+  * roofline = the slower of the two PATHS (encode, decode), its algorithmic bytes N + E (every input byte read
+    once, every output byte written once: SURVEY.md 8d) over the sum of its kernels' durations -- medians over the
+    timed steps of HIP events recorded on the stream between the kernels -- against 8 TB/s of HBM.
+    roofline_encode / roofline_decode give both paths, roofline_kernel the single longest kernel.
+  * cpu_baseline = the CPU oracle (a port of the reference's scalar loop; the reference itself needs aws-c-common
+    and cannot be built here) on the host: the same stream on ONE core (the reference is single-threaded per
+    stream) on a bounded prefix, and the configs[3] batch on ALL cores (one thread per core), CPU model stated.
 
-For N > 1 the driver launches one process per GPU through torch.distributed.run; ranks share
-nothing but a barrier and a max-reduction of the step time (no collective on the data path:
-the streams are independent, DESIGN.md "Multi-GPU").
+For N > 1 the driver launches one process per GPU through torch.distributed.run; ranks share nothing but a barrier
+and a max-reduction of the step time (no collective on the data path: the items are independent, DESIGN.md
+"Multi-GPU").
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import statistics
 import sys
+import threading
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -33,6 +43,8 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 
 GIB = 1 << 30
 HBM_PEAK_BYTES_PER_S = 8.0e12  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+PCIE_PEAK_BYTES_PER_S = 63.0e9  # PCIe Gen5 x16 (spec), same guide
+METRIC = "GiB/s input consumed, encode+decode, 1 GiB random bytes; % HBM roofline"
 
 
 def parse_args():
@@ -40,7 +52,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--bytes", type=int, default=GIB, help="stream length per GPU (default 1 GiB, the BASELINE config)")
+    ap.add_argument("--workload", choices=("stream", "cfg4", "host-abi"), default="stream")
+    ap.add_argument("--bytes", type=int, default=GIB, help="stream: bytes per GPU (default 1 GiB, the BASELINE config); host-abi: bytes per call (default 256 MiB)")
+    ap.add_argument("--buffers", type=int, default=65536, help="cfg4: buffers in the batch")
+    ap.add_argument("--buffer-bytes", type=int, default=16384, help="cfg4: bytes per buffer")
     ap.add_argument("--cpu-sample-mib", type=int, default=96, help="prefix of the stream timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--library", default=None,
@@ -72,19 +87,18 @@ class Ranks:
         if self.dist:
             self.dist.barrier()
 
-    def max(self, x):
+    def _reduce(self, x, op):
         if not self.dist:
             return x
         t = self.torch.tensor([x], dtype=self.torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        self.dist.all_reduce(t, op=op)
         return float(t[0])
 
+    def max(self, x):
+        return self._reduce(x, self.dist.ReduceOp.MAX if self.dist else None)
+
     def sum(self, x):
-        if not self.dist:
-            return x
-        t = self.torch.tensor([x], dtype=self.torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return float(t[0])
+        return self._reduce(x, self.dist.ReduceOp.SUM if self.dist else None)
 
     def gather(self, obj):
         """obj of every rank, in rank order, on every rank."""
@@ -99,8 +113,20 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
-def cpu_baseline(sample_bytes, seed):
-    """Oracle encode + decode of a prefix of the same stream on one host core."""
+# ----------------------------------------------------------------------------- CPU baseline
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sample_bytes, seed, batch_seconds=8.0, buffer_bytes=16384):
+    """The oracle on the host: the stream on one core (bounded prefix), the configs[3] batch on all cores."""
     import numpy as np
 
     import harness
@@ -122,30 +148,139 @@ def cpu_baseline(sample_bytes, seed):
     t3 = time.perf_counter()
     assert r2.rc == 0 and np.array_equal(back, data)
     t_enc, t_dec = t1 - t0, t3 - t2
+
+    # configs[3] on all host cores: one thread per core, each encodes + decodes 16 KiB buffers of its own for a
+    # bounded time (the oracle's calls release the interpreter lock: they are plain C through ctypes)
+    cores = os.cpu_count() or 1
+    done = [0] * cores
+    deadline = time.perf_counter() + batch_seconds
+
+    def worker(k):
+        buf = harness.splitmix64_bytes(2 + k, buffer_bytes)
+        out = np.zeros(buffer_bytes * 2 + 64, dtype=np.uint8)
+        again = np.zeros(buffer_bytes, dtype=np.uint8)
+        n = 0
+        while time.perf_counter() < deadline:
+            e = oracle.new_encoder(coder)
+            rr = oracle.encode_call(e, buf, 0, out, 0, out.size)
+            d = oracle.new_decoder(coder)
+            oracle.decode_call(d, out, 0, rr.produced, again, 0, buffer_bytes)
+            n += 1
+        done[k] = n
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(cores)]
+    tb0 = time.perf_counter()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    tb = time.perf_counter() - tb0
     return {
         "value": round(sample_bytes / GIB / (t_enc + t_dec), 5),
         "unit": "GiB/s",
         "cores": 1,
         "kind": "port",
         "sample": "first %d MiB of the same splitmix64 stream, encode %.2f s + decode %.2f s, C oracle -O2 "
-                  "(scalar per-symbol callbacks like reference source/huffman.c)" % (sample_bytes >> 20, t_enc, t_dec),
+                  "(scalar per-symbol callbacks like reference source/huffman.c), one core: the reference is "
+                  "single-threaded per stream" % (sample_bytes >> 20, t_enc, t_dec),
         "encode_GiBps": round(sample_bytes / GIB / t_enc, 5),
         "decode_GiBps": round(sample_bytes / GIB / t_dec, 5),
+        "cpu_model": cpu_model(),
+        "host_cores": cores,
+        "all_cores_cfg4": {
+            "value": round(sum(done) * buffer_bytes / GIB / tb, 5),
+            "unit": "GiB/s",
+            "cores": cores,
+            "sample": "%d x %d B buffers (BASELINE configs[3] shape) encoded + decoded in %.1f s by %d threads, one per "
+                      "host core" % (sum(done), buffer_bytes, tb, cores),
+        },
     }
 
 
-def main():
-    args = parse_args()
-    ranks = Ranks(args.gpus)
-    import harness  # the HIP library is loaded before anything else can pull in another HIP runtime
+# ----------------------------------------------------------------------------- timing helpers
 
-    lib = harness.load_product(args.library)
-    if lib.aws_huffman_amd_device_count() < 1:
-        raise SystemExit("bench.py: no HIP device visible and the product has no CPU path")
-    patterns, lens = harness.load_table()
-    coder = lib.aws_huffman_amd_table_coder_new(patterns, lens)
-    ndev = lib.aws_huffman_amd_device_count()
-    eng = harness.Engine(lib, coder, device=ranks.local_rank % ndev)
+class Stages:
+    """HIP events between the kernels of every timed step; medians per stage afterwards."""
+
+    def __init__(self, eng, steps, names_e, names_d, plans_e=1):
+        self.eng, self.steps = eng, steps
+        self.names_e, self.names_d = names_e, names_d
+        self.ev_e = [[eng.new_events(4) for _ in range(plans_e)] for _ in range(steps)]
+        self.ev_d = [eng.new_events(4) for _ in range(steps)]
+
+    def medians(self):
+        per_step = {k: [] for k in self.names_e + self.names_d}
+        t_enc, t_dec = [], []
+        for k in range(self.steps):
+            e_sum = 0.0
+            for i, name in enumerate(self.names_e):
+                ms = sum(self.eng.elapsed_ms(ev[i], ev[i + 1]) for ev in self.ev_e[k])
+                per_step[name].append(ms)
+                e_sum += ms
+            d_sum = 0.0
+            for i, name in enumerate(self.names_d):
+                ms = self.eng.elapsed_ms(self.ev_d[k][i], self.ev_d[k][i + 1])
+                per_step[name].append(ms)
+                d_sum += ms
+            t_enc.append(e_sum)
+            t_dec.append(d_sum)
+        kernel_ms = {k: statistics.median(v) for k, v in per_step.items()}
+        return kernel_ms, statistics.median(t_enc), statistics.median(t_dec)
+
+
+def roofline_of(label, kernels, algo_bytes, ms, traffic_table):
+    achieved = algo_bytes / max(ms * 1e-3, 1e-12)
+    traffic = None
+    if traffic_table and all(k in traffic_table for k in kernels):
+        parts = [traffic_table[k].get("hbm_bytes_per_launch") for k in kernels]
+        traffic = sum(parts) if all(p is not None for p in parts) else None
+    return {
+        "path": label,
+        "kernels": kernels,
+        "bound": "hbm",
+        "achieved": round(achieved / 1e9, 2),
+        "peak": HBM_PEAK_BYTES_PER_S / 1e9,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4),
+        "traffic": traffic,
+        "algorithmic_bytes_per_launch": algo_bytes,
+        "ms": round(ms, 4),
+    }
+
+
+def load_traffic():
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    return json.load(open(path)) if os.path.exists(path) else None
+
+
+def stage_names(lib, eng):
+    one_pass = bool(lib.aws_huffman_amd_engine_encodes_in_one_pass(eng.h))
+    names_e = ["enc_onepass", "enc_finish", "enc_pack_listed"] if one_pass else ["enc_count", "enc_scan", "enc_pack"]
+    return names_e, ["dec_sync", "dec_scan", "dec_emit"]
+
+
+def digest_of(eng, ptr, size):
+    h = hashlib.sha256()
+    for off in range(0, size, 256 << 20):
+        h.update(eng.download(ptr, min(256 << 20, size - off), offset=off).tobytes())
+    return h.hexdigest()
+
+
+def rooflines(out, names_e, names_d, kernel_ms, t_enc_ms, t_dec_ms, n, e_len, algo_per_kernel):
+    traffic = load_traffic()
+    enc = roofline_of("encode", names_e, n + e_len, t_enc_ms, traffic)
+    dec = roofline_of("decode", names_d, n + e_len, t_dec_ms, traffic)
+    out["roofline_encode"], out["roofline_decode"] = enc, dec
+    out["roofline"] = dec if t_dec_ms >= t_enc_ms else enc
+    dominant = max(kernel_ms, key=lambda k: kernel_ms[k])
+    out["roofline_kernel"] = roofline_of(dominant, [dominant], algo_per_kernel[dominant], kernel_ms[dominant], traffic)
+    out["encode_read_frac_of_hbm_peak"] = round(n / max(t_enc_ms * 1e-3, 1e-12) / HBM_PEAK_BYTES_PER_S, 4)
+
+
+# ----------------------------------------------------------------------------- workloads
+
+def run_stream(args, ranks, lib, eng):
+    import harness
 
     n = args.bytes
     seed = 5 + ranks.rank  # SURVEY.md 8d: cfg5 = seed 5 + g
@@ -162,72 +297,217 @@ def main():
     eng.decode_launch(dec_plan, d_enc, d_back)
     (rc, err, symbols, _), = eng.decode_results(dec_plan, 1)
     assert rc == 0 and symbols == n, (rc, err, symbols)
-    import hashlib
-
-    def digest(ptr, size):
-        h = hashlib.sha256()
-        for off in range(0, size, 256 << 20):
-            h.update(eng.download(ptr, min(256 << 20, size - off), offset=off).tobytes())
-        return h.hexdigest()
-
-    in_digest = digest(d_in, n)
-    assert digest(d_back, n) == in_digest, "round trip is not bit-exact"
-    enc_digest = digest(d_enc, e_len)
+    in_digest = digest_of(eng, d_in, n)
+    assert digest_of(eng, d_back, n) == in_digest, "round trip is not bit-exact"
+    enc_digest = digest_of(eng, d_enc, e_len)
     if n == GIB and seed == 5:
         pinned = harness.load_json("survey_probe_records.json")["streams"]["G1G"]
         assert (e_len, enc_digest) == (pinned["encoded_len"], pinned["sha256_encoded"]), "encoded stream differs from the reference's"
 
-    def step(events_e=None, events_d=None):
-        eng.encode_launch(enc_plan, d_in, d_enc, events=events_e)
-        eng.decode_launch(dec_plan, d_enc, d_back, events=events_d)
+    names_e, names_d = stage_names(lib, eng)
+    stages = Stages(eng, args.steps, names_e, names_d)
+
+    def step(k=None):
+        eng.encode_launch(enc_plan, d_in, d_enc, events=stages.ev_e[k][0] if k is not None else None)
+        eng.decode_launch(dec_plan, d_enc, d_back, events=stages.ev_d[k] if k is not None else None)
 
     for _ in range(args.warmup):
         step()
     eng.sync()
-
-    ev_e = [eng.new_events(4) for _ in range(args.steps)]
-    ev_d = [eng.new_events(4) for _ in range(args.steps)]
     ranks.barrier()
     eng.sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(ev_e[k], ev_d[k])
+        step(k)
     eng.sync()
     ranks.barrier()
-    t1 = time.perf_counter()
-    wall = ranks.max(t1 - t0)
+    wall = ranks.max(time.perf_counter() - t0)
 
-    # per-kernel durations from the events recorded inside the timed region
-    names_e = ["enc_count", "enc_scan", "enc_pack"]
-    names_d = ["dec_sync", "dec_scan", "dec_emit"]
-    kernel_ms = {k: 0.0 for k in names_e + names_d}
-    for k in range(args.steps):
-        for i, name in enumerate(names_e):
-            kernel_ms[name] += eng.elapsed_ms(ev_e[k][i], ev_e[k][i + 1]) / args.steps
-        for i, name in enumerate(names_d):
-            kernel_ms[name] += eng.elapsed_ms(ev_d[k][i], ev_d[k][i + 1]) / args.steps
-    t_enc_ms = sum(kernel_ms[k] for k in names_e)
-    t_dec_ms = sum(kernel_ms[k] for k in names_d)
-
-    # algorithmic bytes per launch (DESIGN.md "Kernels"): every input byte read once, every output byte written once
-    algo_bytes = {
-        "enc_count": n, "enc_scan": 0, "enc_pack": n + e_len,
-        "dec_sync": e_len, "dec_scan": 0, "dec_emit": e_len + n,
+    kernel_ms, t_enc_ms, t_dec_ms = stages.medians()
+    out = {
+        "config": {
+            "workload": "1 GiB splitmix64 bytes per GPU (seed 5+rank), test_huffman_static_table coder: "
+                        "encode (BASELINE configs[1]) then decode back (configs[2]), HBM-resident",
+            "stream_bytes": n, "encoded_bytes": e_len, "bit_exact": True, "sha256_encoded": enc_digest,
+        },
+        "scaling": "weak",
     }
-    dominant = max(kernel_ms, key=lambda k: kernel_ms[k])
-    achieved = algo_bytes[dominant] / max(kernel_ms[dominant] * 1e-3, 1e-12)
-    traffic = None
-    pmc_path = os.path.join(REPO, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        traffic = json.load(open(pmc_path)).get(dominant, {}).get("hbm_bytes_per_launch")
+    algo = {names_e[0]: n + e_len if names_e[0] == "enc_onepass" else n, names_e[1]: 0, names_e[2]: 0 if names_e[0] == "enc_onepass" else n + e_len,
+            "dec_sync": e_len, "dec_scan": 0, "dec_emit": e_len + n}
+    rooflines(out, names_e, names_d, kernel_ms, t_enc_ms, t_dec_ms, n, e_len, algo)
+    per_rank = {"rank": ranks.rank, "seed": seed, "encoded_bytes": e_len, "sha256_encoded": enc_digest,
+                "encode_ms": round(t_enc_ms, 4), "decode_ms": round(t_dec_ms, 4)}
+    return out, n, e_len, wall, kernel_ms, t_enc_ms, t_dec_ms, per_rank, seed
+
+
+def run_cfg4(args, ranks, lib, eng):
+    import numpy as np
+
+    import harness
+
+    count_all, size = args.buffers, args.buffer_bytes
+    mine = list(range(ranks.rank, count_all, ranks.world))  # buffer i -> rank i mod N
+    count = len(mine)
+    stride = 2 * size
+    d_in, d_out, d_back = eng.alloc(count * size), eng.alloc(count * stride), eng.alloc(count * size)
+    for k, i in enumerate(mine):
+        assert lib.aws_huffman_amd_device_fill_splitmix64(eng.h, d_in + k * size, size, 2 + i) == 0
+    eng.fill(d_out, 0x5A, count * stride)
+    # every fourth buffer of the BATCH has room for 16 384 bytes only: SHORT_BUFFER, then a second call
+    items = [dict(in_offset=k * size, in_len=size, out_offset=k * stride, out_capacity=size if i % 4 == 0 else stride)
+             for k, i in enumerate(mine)]
+    plan = eng.encode_plan(items)
+    eng.encode_launch(plan, d_in, d_out)
+    res = eng.encode_results(plan, count)
+    short = [k for k, i in enumerate(mine) if i % 4 == 0]
+    assert all(res[k][0] == -1 and res[k][1] == harness.AWS_ERROR_SHORT_BUFFER and res[k][3] == size for k in short)
+    assert all(res[k][0] == 0 and res[k][2] == size for k in range(count) if k not in set(short))
+    if mine and mine[0] == 0 and size == 16384:
+        first = harness.load_json("survey_probe_records.json")["G16K_partial_encode"][2]
+        assert res[0] == (-1, harness.AWS_ERROR_SHORT_BUFFER, first["consumed"], first["out_len"],
+                          first["overflow_num_bits"], first["overflow_pattern"]), "buffer 0 differs from the reference's record"
+    resume = [dict(in_offset=k * size + res[k][2], in_len=size - res[k][2], out_offset=k * stride + size,
+                   out_capacity=size, overflow_in=(res[k][5], res[k][4])) for k in short]
+    plan2 = eng.encode_plan(resume) if resume else None
+    lengths = [r[3] for r in res]
+    if plan2:
+        eng.encode_launch(plan2, d_in, d_out)
+        res2 = eng.encode_results(plan2, len(resume))
+        assert all(r[0] == 0 for r in res2)
+        for k, r in zip(short, res2):
+            lengths[k] += r[3]
+    dplan = eng.decode_plan([dict(in_offset=k * stride, in_len=lengths[k], out_offset=k * size, out_capacity=size)
+                             for k in range(count)])
+    eng.decode_launch(dplan, d_out, d_back)
+    dres = eng.decode_results(dplan, count)
+    assert all(r[0] == 0 and r[2] == size for r in dres)
+    assert digest_of(eng, d_back, count * size) == digest_of(eng, d_in, count * size), "round trip is not bit-exact"
+    h = hashlib.sha256()
+    enc_all = eng.download(d_out, count * stride)
+    for k in range(count):
+        h.update(enc_all[k * stride:k * stride + lengths[k]].tobytes())
+    enc_digest = h.hexdigest()
+    n, e_len = count * size, int(sum(lengths))
+
+    names_e, names_d = stage_names(lib, eng)
+    stages = Stages(eng, args.steps, names_e, names_d, plans_e=2 if plan2 else 1)
+
+    def step(k=None):
+        eng.encode_launch(plan, d_in, d_out, events=stages.ev_e[k][0] if k is not None else None)
+        if plan2:
+            eng.encode_launch(plan2, d_in, d_out, events=stages.ev_e[k][1] if k is not None else None)
+        eng.decode_launch(dplan, d_out, d_back, events=stages.ev_d[k] if k is not None else None)
+
+    for _ in range(args.warmup):
+        step()
+    eng.sync()
+    ranks.barrier()
+    eng.sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    eng.sync()
+    ranks.barrier()
+    wall = ranks.max(time.perf_counter() - t0)
+    kernel_ms, t_enc_ms, t_dec_ms = stages.medians()
+    out = {
+        "config": {
+            "workload": "BASELINE configs[3]: %d buffers x %d B (buffer i = splitmix64 seed 2+i, rank r takes i = r mod N), "
+                        "every fourth one capacity-limited (SHORT_BUFFER record, then a resume call), all decoded back, "
+                        "HBM-resident" % (count_all, size),
+            "buffers": count_all, "buffer_bytes": size, "bit_exact": True,
+        },
+        "scaling": "strong",
+    }
+    algo = {names_e[0]: n + e_len if names_e[0] == "enc_onepass" else n, names_e[1]: 0, names_e[2]: 0 if names_e[0] == "enc_onepass" else n + e_len,
+            "dec_sync": e_len, "dec_scan": 0, "dec_emit": e_len + n}
+    rooflines(out, names_e, names_d, kernel_ms, t_enc_ms, t_dec_ms, n, e_len, algo)
+    per_rank = {"rank": ranks.rank, "buffers": count, "encoded_bytes": e_len, "sha256_encoded_streams": enc_digest,
+                "encode_ms": round(t_enc_ms, 4), "decode_ms": round(t_dec_ms, 4)}
+    return out, n, e_len, wall, kernel_ms, t_enc_ms, t_dec_ms, per_rank, 2
+
+
+def run_host_abi(args, ranks, lib, eng, coder):
+    """aws_huffman_encode / aws_huffman_decode on host memory: what a caller of the reference's API gets."""
+    import numpy as np
+
+    import harness
+
+    n = args.bytes if args.bytes != GIB else 256 << 20
+    seed = 5 + ranks.rank
+    codec = harness.Codec(lib, "aws_")
+    data = harness.splitmix64_bytes(seed, n)
+    dst = np.zeros(n * 10 // 8 + 64, dtype=np.uint8)
+    back = np.zeros(n, dtype=np.uint8)
+
+    def step():
+        enc = codec.new_encoder(coder)
+        t0 = time.perf_counter()
+        r = codec.encode_call(enc, data, 0, dst, 0, dst.size)
+        t1 = time.perf_counter()
+        dec = codec.new_decoder(coder)
+        r2 = codec.decode_call(dec, dst, 0, r.produced, back, 0, n)
+        t2 = time.perf_counter()
+        assert r.rc == 0 and r.consumed == n and r2.rc == 0 and r2.produced == n
+        return r.produced, (t1 - t0) * 1e3, (t2 - t1) * 1e3
+
+    e_len = 0
+    for _ in range(max(args.warmup, 1)):
+        e_len, _, _ = step()
+    assert np.array_equal(back, data), "round trip is not bit-exact"
+    ranks.barrier()
+    t0 = time.perf_counter()
+    enc_ms, dec_ms = [], []
+    for _ in range(args.steps):
+        _, a, b = step()
+        enc_ms.append(a)
+        dec_ms.append(b)
+    ranks.barrier()
+    wall = ranks.max(time.perf_counter() - t0)
+    t_enc_ms, t_dec_ms = statistics.median(enc_ms), statistics.median(dec_ms)
+    link = (n + e_len) / max(min(t_enc_ms, t_dec_ms) * 1e-3, 1e-12)
+    out = {
+        "config": {
+            "workload": "aws_huffman_encode + aws_huffman_decode of one %d MiB buffer in pageable HOST memory (the "
+                        "reference's own entry points): H2D + kernels + D2H per call" % (n >> 20),
+            "stream_bytes": n, "encoded_bytes": e_len, "bit_exact": True,
+        },
+        "scaling": "weak",
+        "roofline": {"path": "host link", "bound": "pcie", "achieved": round(link / 1e9, 2),
+                     "peak": PCIE_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s", "frac": round(link / PCIE_PEAK_BYTES_PER_S, 4),
+                     "traffic": None, "note": "bytes over the host link (N + E) / the faster of the two calls; not an HBM figure"},
+    }
+    kernel_ms = {"aws_huffman_encode": t_enc_ms, "aws_huffman_decode": t_dec_ms}
+    per_rank = {"rank": ranks.rank, "seed": seed, "encoded_bytes": e_len,
+                "encode_ms": round(t_enc_ms, 4), "decode_ms": round(t_dec_ms, 4)}
+    return out, n, e_len, wall, kernel_ms, t_enc_ms, t_dec_ms, per_rank, seed
+
+
+def main():
+    args = parse_args()
+    ranks = Ranks(args.gpus)
+    import harness  # the HIP library is loaded before anything else can pull in another HIP runtime
+
+    lib = harness.load_product(args.library)
+    if lib.aws_huffman_amd_device_count() < 1:
+        raise SystemExit("bench.py: no HIP device visible and the product has no CPU path")
+    patterns, lens = harness.load_table()
+    coder = lib.aws_huffman_amd_table_coder_new(patterns, lens)
+    ndev = lib.aws_huffman_amd_device_count()
+    eng = harness.Engine(lib, coder, device=ranks.local_rank % ndev)
+
+    if args.workload == "stream":
+        out, n, e_len, wall, kernel_ms, t_enc_ms, t_dec_ms, per_rank, seed = run_stream(args, ranks, lib, eng)
+    elif args.workload == "cfg4":
+        out, n, e_len, wall, kernel_ms, t_enc_ms, t_dec_ms, per_rank, seed = run_cfg4(args, ranks, lib, eng)
+    else:
+        out, n, e_len, wall, kernel_ms, t_enc_ms, t_dec_ms, per_rank, seed = run_host_abi(args, ranks, lib, eng, coder)
+    per_rank["device"] = ranks.local_rank % ndev
 
     ms_per_step = wall / args.steps * 1e3
     total_units = ranks.sum(float(n)) / GIB  # GiB of input symbols per step, all ranks
-    per_rank = ranks.gather({"rank": ranks.rank, "device": ranks.local_rank % ndev, "seed": seed,
-                             "encoded_bytes": e_len, "sha256_encoded": enc_digest,
-                             "encode_ms": round(t_enc_ms, 4), "decode_ms": round(t_dec_ms, 4)})
-    out = {
-        "metric": "GiB/s input consumed, encode+decode, 1 GiB random bytes; % HBM roofline",
+    line = {
+        "metric": METRIC,
         "value": round(total_units / (wall / args.steps), 6),
         "unit": "GiB/s",
         "n_gpus": ranks.world,
@@ -235,44 +515,30 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": out.pop("scaling"),
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {
-            "workload": "1 GiB splitmix64 bytes per GPU (seed 5+rank), test_huffman_static_table coder: "
-                        "encode (BASELINE configs[1]) then decode back (configs[2]), HBM-resident",
-            "stream_bytes": n,
-            "encoded_bytes": e_len,
-            "bit_exact": True,
-            "sha256_encoded": enc_digest,
-        },
+        "workload": args.workload,
+    }
+    line.update(out)
+    line.update({
         "encode_GiBps": round(n / GIB / max(t_enc_ms * 1e-3, 1e-12), 2),
         "decode_GiBps_encoded_in": round(e_len / GIB / max(t_dec_ms * 1e-3, 1e-12), 2),
         "decode_GiBps_symbols_out": round(n / GIB / max(t_dec_ms * 1e-3, 1e-12), 2),
         "encode_path_frac_of_hbm_peak": round((n + e_len) / max(t_enc_ms * 1e-3, 1e-12) / HBM_PEAK_BYTES_PER_S, 4),
-        "encode_read_frac_of_hbm_peak": round(n / max(t_enc_ms * 1e-3, 1e-12) / HBM_PEAK_BYTES_PER_S, 4),
         "decode_path_frac_of_hbm_peak": round((n + e_len) / max(t_dec_ms * 1e-3, 1e-12) / HBM_PEAK_BYTES_PER_S, 4),
-        "ranks": per_rank,
+        "timing": "kernel_ms and the path times are medians over the %d timed steps (HIP events on the engine's stream); "
+                  "value and ms_per_step are the wall clock of all of them between barriers" % args.steps,
+        "ranks": ranks.gather(per_rank),
         "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
-        "roofline": {
-            "kernel": dominant,
-            "bound": "hbm",
-            "achieved": round(achieved / 1e9, 2),
-            "peak": HBM_PEAK_BYTES_PER_S / 1e9,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_BYTES_PER_S, 4),
-            "traffic": traffic,
-            "algorithmic_bytes_per_launch": algo_bytes[dominant],
-            "avg_launch_ms": round(kernel_ms[dominant], 4),
-        },
-    }
+    })
     if ranks.rank == 0 and ranks.world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_mib << 20, n), seed)
+        line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_mib << 20, n), seed)
     else:
-        out["cpu_baseline"] = None
+        line["cpu_baseline"] = None
     if ranks.rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(line), flush=True)
     ranks.close()
 
 

@@ -92,6 +92,12 @@ uint32_t aws_huffman_amd_engine_max_code_bits(const struct aws_huffman_amd_engin
 AWS_COMPRESSION_API
 bool aws_huffman_amd_engine_can_decode(const struct aws_huffman_amd_engine *engine);
 
+/* Whether encode plans of this engine run as one kernel that reads the symbols once (coders whose 256 symbols all have
+ * codes of 4 .. 15 bits, unless AWS_HUFFMAN_AMD_ENCODE=three-kernel) or as count / scan / pack: which kernels the
+ * stage events of aws_huffman_amd_encode_plan_launch_staged bracket depends on it. */
+AWS_COMPRESSION_API
+bool aws_huffman_amd_engine_encodes_in_one_pass(const struct aws_huffman_amd_engine *engine);
+
 /* ---- batched encode ------------------------------------------------------ */
 
 /* Uploads the items, builds the segment map, sizes the scratch memory. */
@@ -122,7 +128,9 @@ int aws_huffman_amd_encode_plan_launch(
 /*
  * Same launch with HIP events recorded between its kernels, for per-kernel timing on the
  * stream the kernels run on.  stage_events: 4 events from aws_huffman_amd_event_new --
- * [0] before the length count, [1] after it, [2] after the offset scan, [3] after the pack.
+ * [0] before the length count, [1] after it, [2] after the offset scan, [3] after the pack;
+ * for an engine that encodes in one pass: [0] before the one-pass kernel, [1] after it,
+ * [2] after the per-item outcomes, [3] after the segments left to the per-symbol packer.
  */
 AWS_COMPRESSION_API
 int aws_huffman_amd_encode_plan_launch_staged(
@@ -185,6 +193,59 @@ int aws_huffman_amd_decode_plan_results(
     struct aws_huffman_amd_decode_plan *plan,
     struct aws_huffman_amd_decode_result *results,
     void *stream);
+
+/* ---- several GPUs: independent items sharded over the devices of one node ---- */
+
+/*
+ * Items are independent (each has its own encoder / decoder state and its own padded output), so they shard with no
+ * exchange between devices: item i of a call goes to shard i mod G.  A shard = one device with the coder's tables
+ * staged on it, one engine and stream, and -- inside a call -- one host thread that builds the plan of its items,
+ * launches it and fetches their result records; the call returns when every shard has, with the records gathered in
+ * item order.  Inputs and outputs stay on the shard's device: an item's offsets are relative to that shard's base
+ * pointers (`io[i mod G]`).  No collective, no peer traffic.  (BASELINE.json configs[3] split over G GPUs is one
+ * such call; configs[4], one stream per GPU, is G items.)  The same device may be listed more than once.
+ */
+struct aws_huffman_amd_shards;
+
+struct aws_huffman_amd_shard_io {
+    const void *device_input; /* base pointers on the shard's device */
+    void *device_output;
+};
+
+AWS_COMPRESSION_API
+int aws_huffman_amd_shards_new(
+    struct aws_huffman_amd_shards **shards,
+    struct aws_huffman_symbol_coder *coder,
+    const int *devices,
+    size_t device_count);
+
+AWS_COMPRESSION_API
+void aws_huffman_amd_shards_destroy(struct aws_huffman_amd_shards *shards);
+
+AWS_COMPRESSION_API
+size_t aws_huffman_amd_shards_count(const struct aws_huffman_amd_shards *shards);
+
+/* the engine of shard g: for its device memory (aws_huffman_amd_device_alloc, copies, fills) */
+AWS_COMPRESSION_API
+struct aws_huffman_amd_engine *aws_huffman_amd_shards_engine(struct aws_huffman_amd_shards *shards, size_t g);
+
+/* items[i] on shard i mod G against io[i mod G]; results[i] as aws_huffman_amd_encode_plan_results would give them.
+ * AWS_OP_ERR if any shard failed (the error raised is the first failing shard's). */
+AWS_COMPRESSION_API
+int aws_huffman_amd_shards_encode(
+    struct aws_huffman_amd_shards *shards,
+    const struct aws_huffman_amd_encode_item *items,
+    size_t item_count,
+    const struct aws_huffman_amd_shard_io *io,
+    struct aws_huffman_amd_encode_result *results);
+
+AWS_COMPRESSION_API
+int aws_huffman_amd_shards_decode(
+    struct aws_huffman_amd_shards *shards,
+    const struct aws_huffman_amd_decode_item *items,
+    size_t item_count,
+    const struct aws_huffman_amd_shard_io *io,
+    struct aws_huffman_amd_decode_result *results);
 
 /* ---- device memory and timing helpers (so a C caller needs no HIP headers) ---- */
 

@@ -18,6 +18,9 @@ if [ "${2:-}" != "skip-tests" ]; then
 fi
 timeout 600 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 600 "$OUT/bench.json"
+timeout 600 python3 bench.py --workload cfg4 --no-cpu-baseline > "$OUT/bench_cfg4.json" 2> "$OUT/bench_cfg4.err"
+timeout 600 python3 bench.py --workload host-abi --no-cpu-baseline > "$OUT/bench_host_abi.json" 2> "$OUT/bench_host_abi.err"
+tail -c 300 "$OUT/bench_cfg4.json"; tail -c 300 "$OUT/bench_host_abi.json"
 BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $BENCH > "$OUT/stats.json" 2> "$OUT/stats.err"

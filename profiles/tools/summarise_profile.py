@@ -26,16 +26,25 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 GROUPS = [  # bench kernel name <- substrings of the device kernel names it covers
+    ("enc_onepass", ["enc_onepass_kernel", "enc_ragged_count_kernel"]),
+    ("enc_finish", ["enc_finish_kernel"]),
+    ("enc_pack_listed", ["enc_tiny_kernel"]),  # (+ enc_pack_kernel when the one-pass road is taken: see group_of)
     ("enc_count", ["enc_count_kernel"]),
     ("enc_scan", ["enc_scan_small_kernel", "enc_scan_large_kernel"]),
-    ("enc_pack", ["enc_pack_wave_kernel", "enc_pack_stream_kernel", "enc_pack_kernel", "enc_fused_kernel", "enc_finish_kernel"]),
-    ("dec_sync", ["dec_sync_fast_kernel", "dec_sync_kernel"]),
-    ("dec_scan", ["dec_scan_small_kernel", "dec_scan_runs_kernel", "dec_scan_top_kernel", "dec_scan_apply_kernel"]),
-    ("dec_emit", ["dec_emit_fast_kernel", "dec_emit_kernel"]),
+    ("enc_pack", ["enc_pack_wave_kernel", "enc_pack_stream_kernel", "enc_pack_kernel"]),
+    ("dec_sync", ["dec_sync_lean_kernel", "dec_sync_fast_kernel", "dec_sync_tail_kernel", "dec_sync_kernel"]),
+    ("dec_scan", ["dec_scan_small_kernel", "dec_scan_runs_kernel", "dec_scan_top_kernel", "dec_scan_apply_kernel",
+                  "dec_tiny_kernel", "dec_deep_kernel"]),
+    ("dec_emit", ["dec_emit_fast_kernel", "dec_emit_tail_kernel", "dec_emit_dense_kernel", "dec_emit_kernel"]),
 ]
 
 
+ONE_PASS = False  # set by counter_sums: the profile holds enc_onepass_kernel dispatches
+
+
 def group_of(kernel_name):
+    if ONE_PASS and "enc_pack_kernel" in kernel_name:
+        return "enc_pack_listed"  # the segments the one-pass kernel leaves to the per-symbol packer
     for g, subs in GROUPS:
         if any(s in kernel_name for s in subs):
             return g
@@ -46,7 +55,10 @@ def counter_sums(directory):
     """{group: {counter: sum over dispatches}}, {group: dispatches of its first kernel}"""
     sums = collections.defaultdict(lambda: collections.defaultdict(float))
     calls = collections.Counter()
-    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+    global ONE_PASS
+    files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
+    ONE_PASS = any("enc_onepass_kernel" in r["Kernel_Name"] for f in files for r in csv.DictReader(open(f)))
+    for f in files:
         seen = set()
         for r in csv.DictReader(open(f)):
             g = group_of(r["Kernel_Name"])
@@ -72,7 +84,7 @@ def main():
     steps = None
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         sums, calls = counter_sums(os.path.join(src, sub))
-        n_steps = max([v for k, v in calls.items() if "enc_count_kernel" in k or "dec_sync_kernel" in k] or [0])
+        n_steps = max([v for k, v in calls.items() if "dec_scan_small_kernel" in k] or [0])  # one per decode launch
         if not n_steps:
             continue
         steps = n_steps

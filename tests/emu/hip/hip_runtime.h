@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <random>
 #include <vector>
 
@@ -51,7 +52,7 @@ struct uint4 {
 typedef int hipError_t;
 typedef void *hipStream_t;
 typedef struct hip_emu_event *hipEvent_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorInvalidDevice = 101 };
 enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 enum { hipStreamNonBlocking = 1 };
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
@@ -185,6 +186,10 @@ inline void run_block(unsigned threads) {
 }
 
 inline void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body) {
+    /* one launch at a time: the fibers, the LDS and the block index are one global state, and host threads with an
+     * engine each (the sharded driver) may launch side by side */
+    static std::mutex one_launch;
+    std::lock_guard<std::mutex> hold(one_launch);
     State &s = state();
     if (lds_bytes > kLdsBytes || block.x * block.y * block.z > 1024) {
         s.last_error = hipErrorInvalidValue;

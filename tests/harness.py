@@ -159,6 +159,10 @@ class AmdDecodeResult(C.Structure):
     _fields_ = [("rc", C.c_int32), ("error", C.c_int32), ("produced", C.c_uint64), ("bits_consumed", C.c_uint64)]
 
 
+class ShardIo(C.Structure):
+    _fields_ = [("device_input", C.c_void_p), ("device_output", C.c_void_p)]
+
+
 EXPORTED_SYMBOLS = [
     # include/aws/compression/huffman.h
     "aws_huffman_encoder_init", "aws_huffman_encoder_reset", "aws_huffman_decoder_init", "aws_huffman_decoder_reset",
@@ -178,6 +182,9 @@ EXPORTED_SYMBOLS = [
     "aws_huffman_amd_event_new", "aws_huffman_amd_event_destroy", "aws_huffman_amd_event_record",
     "aws_huffman_amd_event_elapsed_ms", "aws_huffman_amd_table_coder_new", "aws_huffman_amd_table_coder_destroy",
     "aws_huffman_amd_table_coder_from_def", "aws_huffman_amd_encode_plan_encoded_lengths",
+    "aws_huffman_amd_engine_encodes_in_one_pass",
+    "aws_huffman_amd_shards_new", "aws_huffman_amd_shards_destroy", "aws_huffman_amd_shards_count",
+    "aws_huffman_amd_shards_engine", "aws_huffman_amd_shards_encode", "aws_huffman_amd_shards_decode",
 ]
 # include/aws/compression/private/huffman_testing.h (the reference's names: no aws_ prefix)
 TESTING_SYMBOLS = ["huffman_test_transitive", "huffman_test_transitive_chunked"]
@@ -207,6 +214,13 @@ def load_product(path=None):
     _bind(lib, "aws_huffman_amd_engine_max_code_bits", C.c_uint32, [V])
     _bind(lib, "aws_huffman_amd_engine_can_decode", C.c_bool, [V])
     _bind(lib, "aws_huffman_amd_engine_stream", V, [V])
+    _bind(lib, "aws_huffman_amd_engine_encodes_in_one_pass", C.c_bool, [V])
+    _bind(lib, "aws_huffman_amd_shards_new", C.c_int, [P(V), P(SymbolCoder), P(C.c_int), C.c_size_t])
+    _bind(lib, "aws_huffman_amd_shards_destroy", None, [V])
+    _bind(lib, "aws_huffman_amd_shards_count", C.c_size_t, [V])
+    _bind(lib, "aws_huffman_amd_shards_engine", V, [V, C.c_size_t])
+    _bind(lib, "aws_huffman_amd_shards_encode", C.c_int, [V, P(AmdEncodeItem), C.c_size_t, P(ShardIo), P(AmdEncodeResult)])
+    _bind(lib, "aws_huffman_amd_shards_decode", C.c_int, [V, P(AmdDecodeItem), C.c_size_t, P(ShardIo), P(AmdDecodeResult)])
     _bind(lib, "aws_huffman_amd_encode_plan_new", C.c_int, [P(V), V, P(AmdEncodeItem), C.c_size_t])
     _bind(lib, "aws_huffman_amd_encode_plan_destroy", None, [V])
     _bind(lib, "aws_huffman_amd_encode_plan_launch", C.c_int, [V, V, V, C.c_bool, V])
@@ -336,6 +350,61 @@ class Engine:
         res = (AmdDecodeResult * max(n, 1))()
         assert self.lib.aws_huffman_amd_decode_plan_results(plan, res, None) == 0
         return [(r.rc, r.error, r.produced, r.bits_consumed) for r in res[:n]]
+
+
+class Shards:
+    """huffman_amd.h "several GPUs": item i on shard i mod G, one engine and one host thread per shard."""
+
+    def __init__(self, lib, coder, devices):
+        self.lib, self.G = lib, len(devices)
+        h = C.c_void_p()
+        devs = (C.c_int * self.G)(*devices)
+        if lib.aws_huffman_amd_shards_new(C.byref(h), coder, devs, self.G) != 0:
+            raise RuntimeError("aws_huffman_amd_shards_new failed, error %d" % lib.aws_last_error())
+        self.h = h
+        assert lib.aws_huffman_amd_shards_count(h) == self.G
+        self.engines = []
+        for g in range(self.G):
+            e = Engine.__new__(Engine)
+            e.lib, e.h = lib, C.c_void_p(lib.aws_huffman_amd_shards_engine(h, g))
+            e.stream = lib.aws_huffman_amd_engine_stream(e.h)
+            self.engines.append(e)
+
+    def close(self):
+        if self.h:
+            self.lib.aws_huffman_amd_shards_destroy(self.h)
+            self.h = None
+
+    def _io(self, bases):
+        io = (ShardIo * self.G)()
+        for g, (d_in, d_out) in enumerate(bases):
+            io[g].device_input, io[g].device_output = d_in, d_out
+        return io
+
+    def encode(self, items, bases):
+        arr = (AmdEncodeItem * max(len(items), 1))()
+        for i, it in enumerate(items):
+            arr[i].in_offset, arr[i].in_len = it["in_offset"], it["in_len"]
+            arr[i].out_offset, arr[i].out_capacity = it["out_offset"], it["out_capacity"]
+            ov = it.get("overflow_in", (0, 0))
+            arr[i].overflow_in.pattern, arr[i].overflow_in.num_bits = ov
+            arr[i].eos_padding = it.get("eos_padding", 0xFF)
+        res = (AmdEncodeResult * max(len(items), 1))()
+        rc = self.lib.aws_huffman_amd_shards_encode(self.h, arr, len(items), self._io(bases), res)
+        assert rc == 0, "shards_encode failed, error %d" % self.lib.aws_last_error()
+        return [(r.rc, r.error, r.consumed, r.produced, r.overflow_out.num_bits,
+                 r.overflow_out.pattern if r.overflow_out.num_bits else 0) for r in res[:len(items)]]
+
+    def decode(self, items, bases):
+        arr = (AmdDecodeItem * max(len(items), 1))()
+        for i, it in enumerate(items):
+            arr[i].in_offset, arr[i].in_len = it["in_offset"], it["in_len"]
+            arr[i].first_bit = it.get("first_bit", 0)
+            arr[i].out_offset, arr[i].out_capacity = it["out_offset"], it["out_capacity"]
+        res = (AmdDecodeResult * max(len(items), 1))()
+        rc = self.lib.aws_huffman_amd_shards_decode(self.h, arr, len(items), self._io(bases), res)
+        assert rc == 0, "shards_decode failed, error %d" % self.lib.aws_last_error()
+        return [(r.rc, r.error, r.produced, r.bits_consumed) for r in res[:len(items)]]
 
 
 class CallResult:

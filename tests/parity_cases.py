@@ -470,6 +470,79 @@ def other_coders(w, n=60000, seed=23):
                     paired_decode(w, ddo, ddp, want, 0, cut, oo, op, 0, n)
 
 
+# ----------------------------------------------------------------------------- scenario: items sharded over several engines (one per GPU)
+def sharded_items(w, devices=(0, 0, 0), n_items=23, seed=71, item_len=16384):
+    """huffman_amd.h "several GPUs": item i runs on shard i mod G (the split of BASELINE configs[3]),
+    every shard with its own engine, stream, host thread and device buffers; the records come back in item order
+    and every item must equal the oracle's result for that item alone -- whole buffers, capacity-limited ones
+    (SHORT_BUFFER with the reference's record), ragged ones, an empty one.  Then everything is decoded back the
+    same way.  (The same device may be listed several times: that is how one GPU, or the emulator, runs this.)"""
+    rng = np.random.default_rng(seed)
+    G = len(devices)
+    sh = harness.Shards(w.product.lib, w.pcoder, list(devices))
+    lens = [item_len, item_len, 0, 1, item_len + 17, 3 * item_len + 5, 15][:n_items]
+    lens += [int(rng.integers(1, 2 * item_len)) for _ in range(n_items - len(lens))]
+    blobs = [inputs(rng, n, KINDS[i % 3]) for i, n in enumerate(lens)]
+    full = [oracle_encode(w, b) for b in blobs]
+    caps = [[f.size + 9, f.size, max(f.size - 1, 0), f.size // 2][i % 4] for i, f in enumerate(full)]
+    # per shard: its items' inputs back to back, outputs with guard gaps
+    in_off, out_off = [0] * n_items, [0] * n_items
+    in_pos, out_pos = [3] * G, [5] * G
+    for i in range(n_items):
+        g = i % G
+        in_off[i], out_off[i] = in_pos[g], out_pos[g]
+        in_pos[g] += blobs[i].size + int(rng.integers(0, 5))
+        out_pos[g] += caps[i] + 24
+    bases = []
+    for g in range(G):
+        eng = sh.engines[g]
+        host_in = np.zeros(in_pos[g] + 64, np.uint8)
+        for i in range(g, n_items, G):
+            host_in[in_off[i]:in_off[i] + blobs[i].size] = blobs[i]
+        d_in, d_out = eng.alloc(host_in.size), eng.alloc(out_pos[g] + 64)
+        eng.upload(d_in, host_in)
+        eng.fill(d_out, SENTINEL, out_pos[g] + 64)
+        bases.append((d_in, d_out))
+    items = [dict(in_offset=in_off[i], in_len=blobs[i].size, out_offset=out_off[i], out_capacity=caps[i]) for i in range(n_items)]
+    res = sh.encode(items, bases)
+    outs = [sh.engines[g].download(bases[g][1], out_pos[g] + 64) for g in range(G)]
+    for i in range(n_items):
+        eo = w.oracle.new_encoder(w.ocoder)
+        want = np.full(caps[i] + 8, SENTINEL, np.uint8)
+        r = w.oracle.encode_call(eo, blobs[i], 0, want, 0, caps[i])
+        assert res[i] == (r.rc, r.err, r.consumed, r.produced, r.state[0], r.state[1]), (i, res[i], r)
+        got = outs[i % G][out_off[i]:out_off[i] + caps[i] + 8]
+        assert np.array_equal(got[:r.produced], want[:r.produced]), "item %d bytes" % i
+        assert np.all(got[r.produced:caps[i] + 8] == SENTINEL), "item %d wrote past what the call produced" % i
+    # decode the complete streams back, sharded the same way
+    dbases, dn = [], [0] * G
+    d_items = []
+    for g in range(G):
+        eng = sh.engines[g]
+        pos_in, pos_out = 0, 0
+        blob_in = []
+        for i in range(g, n_items, G):
+            d_items.append((i, dict(in_offset=pos_in, in_len=full[i].size, out_offset=pos_out, out_capacity=blobs[i].size)))
+            blob_in.append(full[i])
+            pos_in += full[i].size
+            pos_out += blobs[i].size
+        host = np.concatenate(blob_in + [np.zeros(64, np.uint8)])
+        d_in, d_out = eng.alloc(host.size), eng.alloc(pos_out + 64)
+        eng.upload(d_in, host)
+        dbases.append((d_in, d_out))
+        dn[g] = pos_out
+    d_items.sort(key=lambda t: t[0])
+    dres = sh.decode([it for _, it in d_items], dbases)
+    backs = [sh.engines[g].download(dbases[g][1], dn[g] + 64) for g in range(G)]
+    for i, it in d_items:
+        assert dres[i][0] == 0 and dres[i][2] == blobs[i].size, (i, dres[i])
+        assert np.array_equal(backs[i % G][it["out_offset"]:it["out_offset"] + blobs[i].size], blobs[i]), "item %d round trip" % i
+    for g in range(G):
+        for ptr in bases[g] + dbases[g]:
+            sh.engines[g].free(ptr)
+    sh.close()
+
+
 # ----------------------------------------------------------------------------- scenario: a coder destroyed and another one made (often at the same address)
 def recreated_coders(w, rounds=6, n=3000, seed=61):
     """The product finds its device tables again through the coder's address.  An address says nothing about the

@@ -73,6 +73,10 @@ def test_recreated_coders(world):
     pc.recreated_coders(world)
 
 
+def test_sharded_items(world):
+    pc.sharded_items(world, devices=(0, 0, 0), n_items=14, item_len=4096)
+
+
 def test_batched_device_api(world):
     pc.batched_device_api(world)
 

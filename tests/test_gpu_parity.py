@@ -96,6 +96,13 @@ def test_recreated_coders(world):
     pc.recreated_coders(world, rounds=8, n=40000)
 
 
+def test_sharded_items(world):
+    """The in-library multi-GPU driver, here with every shard on this box's one GPU: three engines, three host
+    threads, the configs[3] split i mod G (on an 8-GPU node: devices=range(8))."""
+    ndev = world.product.lib.aws_huffman_amd_device_count()
+    pc.sharded_items(world, devices=tuple(g % ndev for g in range(3)), n_items=60)
+
+
 def test_batched_device_api(world, engine):
     pc.batched_device_api(world, n_items=40, engine=engine)
 

@@ -70,9 +70,13 @@ def check_line(out, world):
     # whole-job value: every rank's bytes over the slowest rank's time per step
     per_step_s = out["ms_per_step"] * 1e-3
     assert out["value"] == pytest.approx(world * STREAM_BYTES / 2**30 / per_step_s, rel=2e-2)
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert key in out["roofline"]
-    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["peak"] == 8000.0
+    for name in ("roofline", "roofline_encode", "roofline_decode", "roofline_kernel"):
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert key in out[name], (name, key)
+        assert out[name]["bound"] == "hbm" and out[name]["peak"] == 8000.0
+    # the headline roofline is a PATH: all its kernels, N + E bytes
+    assert out["roofline"]["path"] in ("encode", "decode") and len(out["roofline"]["kernels"]) == 3
+    assert out["roofline"]["algorithmic_bytes_per_launch"] == STREAM_BYTES + out["ranks"][0]["encoded_bytes"]
 
 
 def test_two_ranks_independent_streams(emulator, oracle):
@@ -85,6 +89,30 @@ def test_two_ranks_independent_streams(emulator, oracle):
         assert (r["encoded_bytes"], r["sha256_encoded"]) == (e_len, digest), "rank %d stream differs from the oracle" % r["rank"]
     assert out["ranks"][0]["sha256_encoded"] != out["ranks"][1]["sha256_encoded"]
     assert out["cpu_baseline"] is None  # reported at N = 1 only
+
+
+def expected_batch(oracle, rank, world, buffers, size):
+    """sha256 over the complete encoded streams of the buffers rank `rank` takes (i = rank mod world), in order."""
+    coder = oracle.lib.oracle_table_coder_new(*harness.load_table())
+    h, total = hashlib.sha256(), 0
+    for i in range(rank, buffers, world):
+        enc = oracle.encode_all(coder, harness.splitmix64_bytes(2 + i, size))
+        h.update(enc.tobytes())
+        total += enc.size
+    return total, h.hexdigest()
+
+
+def test_two_ranks_split_the_batch(emulator, oracle):
+    """BASELINE configs[3] over two ranks: buffer i on rank i mod 2, every fourth buffer of the batch
+    capacity-limited and resumed; each rank's encoded streams against the oracle's."""
+    buffers, size = 22, 16384
+    out = run_bench(emulator, 2, extra=("--workload", "cfg4", "--buffers", str(buffers), "--buffer-bytes", str(size)))
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["workload"] == "cfg4"
+    assert out["value"] == pytest.approx(buffers * size / 2**30 / (out["ms_per_step"] * 1e-3), rel=2e-2)
+    assert [r["buffers"] for r in out["ranks"]] == [11, 11]
+    for r in out["ranks"]:
+        e_len, digest = expected_batch(oracle, r["rank"], 2, buffers, size)
+        assert (r["encoded_bytes"], r["sha256_encoded_streams"]) == (e_len, digest), "rank %d differs from the oracle" % r["rank"]
 
 
 def test_single_rank_line(emulator, oracle):
