@@ -1979,6 +1979,7 @@ struct op_tile {
     u32 t, s, w4;
     u32 n_sym;      /* symbols of the segment that lie in this tile */
     u32 carried;    /* the item's carried overflow bits */
+    u32 item_first_tile; /* the item's first tile */
     u32 bits;       /* the tile's code bits, once counted */
     u32 halo_n;     /* how many symbols behind the tile its last byte may need (their values are per-lane registers) */
     bool shaped;    /* a whole, aligned segment without carried bits in front: packed here */
@@ -2038,6 +2039,7 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         d.seg = segs[d.s];
         const u8 *src = d_in + d.seg.in_off;
         d.carried = items[d.seg.item].ovf_bits;
+        d.item_first_tile = items[d.seg.item].first_seg * kTilesPerSeg;
         d.shaped = op_shaped(d.seg, d_in, d.carried);
         d.tsrc = src + d.w4 * kTileBytes;
         const u32 from = d.w4 * kTileBytes;
@@ -2138,7 +2140,11 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         u32 a = lane < p ? a_raw : kOpTileReady;
         u64 b = lane < gi_r ? b_raw : kOpGroupTiles * kOpArrive;
         u64 rb = rb_raw;
-        u64 ib = old.first_tile ? kOpReady : (seg.item == base_item ? base_value : ib_raw); /* an item's base is read once per wave */
+        /* an item that starts inside my group needs no base: its tiles in front of me are among the group's (lanes
+         * p - since .. p - 1); otherwise the base, read once per wave and item */
+        const u32 since = old.t - old.item_first_tile; /* tiles of my item in front of me */
+        const bool near = since <= p;
+        u64 ib = (old.first_tile || near) ? kOpReady : (seg.item == base_item ? base_value : ib_raw);
         bool gave_up = false;
         for (u32 spins = 0;; ++spins) {
             const bool there = (a & kOpTileReady) != 0 && (b >> 40) == kOpGroupTiles && (rb & kOpReady) != 0 &&
@@ -2186,21 +2192,32 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         }
         HUFD_STAMP_ADD(2, 2);
         a &= ~kOpTileReady;
-        const u32 part = (lane < p ? a : 0u) + (lane < gi_r ? (u32)(b & kOpSum) : 0u);
-        const u32 in_round = __shfl(wave_inclusive_sum_dpp(part, lane), kWave - 1);
+        /* (two sums in one scan: everything in front of me in the low half-words' place, my own item's tiles of this
+         * group above bit 32 -- a group holds less than 2^22 bits) */
+        const u64 part = (u64)((lane < p ? a : 0u) + (lane < gi_r ? (u32)(b & kOpSum) : 0u)) |
+                         ((u64)((near && lane < p && lane + since >= p) ? a : 0u) << 32);
+        u64 sums = part;
+#pragma unroll
+        for (u32 d = kWave / 2; d > 0; d >>= 1) {
+            sums += __shfl_xor(sums, d);
+        }
+        const u32 in_round = (u32)sums, in_item = (u32)(sums >> 32);
         const u64 before = uniform64((rb & ~kOpReady) + in_round); /* bits of every tile of the plan in front of this one */
         u64 bw; /* stream bit (inside the item) of the tile's first code */
         if (old.first_tile) {
             bw = old.carried;
             base_value = kOpReady | before;
+            base_item = seg.item;
             if (lane == 0) {
                 granule_store(&item_base[seg.item], base_value);
             }
+        } else if (near) {
+            bw = (u64)uniform32(in_item) + old.carried;
         } else {
             base_value = uniform64(ib);
+            base_item = seg.item;
             bw = before - (base_value & ~kOpReady) + old.carried;
         }
-        base_item = seg.item;
         const u64 bn = bw + old.bits;
 
         /* ---- the records enc_finish_kernel and enc_pack_kernel read */

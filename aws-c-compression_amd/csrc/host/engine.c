@@ -1188,8 +1188,25 @@ int aws_huffman_amd_engine_encode_host(
     bool length_only,
     struct hufd_enc_result *raw) {
 
-    /* the device output never needs more than the worst-case encoding */
     struct aws_huffman_amd_encode_item item = *item_in;
+    /*
+     * Only the symbols this call can consume are staged.  The reference reads symbol k only while the output has a
+     * free byte (source/huffman.c:162-164), i.e. while the bits in front of it -- carried ones + at least min_bits
+     * per earlier symbol -- are fewer than 8 * room: at most ceil((8 * room - carried) / min_bits) symbols, one more
+     * here so that a call that fills its room exactly still sees input behind it (and says SHORT_BUFFER, as the
+     * reference would at the top of its next turn).  A caller that offers its output a few bytes at a time
+     * (huffman_test_transitive_chunked, HPACK's SHORT_BUFFER resumption) otherwise pays for the whole rest of its
+     * input in every call: O(n^2 / chunk) bytes over the bus and through the count.
+     */
+    if (!length_only && eng->tables.min_bits && item.out_capacity < (UINT64_MAX >> 4)) {
+        const uint64_t room_bits = item.out_capacity * 8;
+        const uint64_t carried = item.overflow_in.num_bits;
+        const uint64_t fit = room_bits > carried ? (room_bits - carried + eng->tables.min_bits - 1) / eng->tables.min_bits : 0;
+        if (fit + 1 < item.in_len) {
+            item.in_len = fit + 1;
+        }
+    }
+    /* the device output never needs more than the worst-case encoding */
     const uint64_t worst = (item.in_len * eng->tables.max_bits + item.overflow_in.num_bits + 7) / 8;
     const uint64_t dev_out = item.out_capacity < worst ? item.out_capacity : worst;
     item.in_offset = 0;
@@ -1245,6 +1262,20 @@ int aws_huffman_amd_engine_decode_host(
 
     if (!eng->can_decode) {
         return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION);
+    }
+    /*
+     * Only the bytes this call can get through are staged: with room for r symbols the reference stops at the latest
+     * when it has recognised symbol r + 1 (source/huffman.c:257-268), which lies within (r + 1) * max_bits bits of
+     * the stream's first one; eight bytes more keep a code without a match "at least 32 bits from the end" exactly
+     * when it is so in the whole stream (source/huffman.c:240-247).  (The caller's cursor and the decoder's window
+     * are worked out from the bits consumed and the real length, in huffman.c.)
+     */
+    if (out_capacity < (UINT64_MAX >> 8) && eng->tables.max_bits) {
+        const uint64_t need_bits = first_bit + (out_capacity + 1) * (eng->tables.max_bits ? eng->tables.max_bits : 32);
+        const uint64_t need_bytes = (need_bits + 7) / 8 + 8;
+        if (need_bytes < carry_bytes + in_len) {
+            in_len = need_bytes > carry_bytes ? need_bytes - carry_bytes : 0;
+        }
     }
     /* the carried bytes sit right before the new bytes, which start 16-byte aligned */
     const uint64_t stream_bits = (carry_bytes + in_len) * 8 - first_bit;

@@ -81,14 +81,34 @@ struct aws_allocator {
     void *impl;
 };
 
+/* The error-string registry: a package hands a list of its codes' names to aws-c-common at library init
+ * (reference source/compression.c:13-33) and anybody can ask for a code's name. */
+struct aws_error_info {
+    int error_code;
+    const char *literal_name;
+    const char *error_str;
+    const char *lib_name;
+    const char *formatted_name;
+};
+struct aws_error_info_list {
+    const struct aws_error_info *error_list;
+    uint16_t count;
+};
+
 AWS_EXTERN_C_BEGIN
 
-/* Thread-local last-error, exported by libaws-c-compression-amd when the real
- * aws-c-common is absent. */
+/* Thread-local last-error and the error-name registry, exported by libaws-c-compression-amd when the
+ * real aws-c-common is absent. */
 int aws_raise_error(int err);
 int aws_last_error(void);
 void aws_reset_error(void);
 struct aws_allocator *aws_default_allocator(void);
+void aws_register_error_info(const struct aws_error_info_list *error_info);
+void aws_unregister_error_info(const struct aws_error_info_list *error_info);
+const char *aws_error_name(int err);  /* "Unknown Error Code" for a code nobody registered */
+const char *aws_error_str(int err);
+void aws_common_library_init(struct aws_allocator *allocator);
+void aws_common_library_clean_up(void);
 
 AWS_EXTERN_C_END
 

@@ -500,3 +500,94 @@ void oracle_splitmix64_fill(uint8_t *dst, size_t len, uint64_t seed) {
         }
     }
 }
+
+/* ------------------------------------------------------------------ all-core baseline (bench.py) */
+
+#include <pthread.h>
+#include <time.h>
+
+struct batch_worker {
+    struct aws_huffman_symbol_coder *coder;
+    uint32_t buffer_bytes;
+    uint64_t seed;
+    double deadline;
+    uint64_t done;
+    int bad;
+};
+
+static double now_seconds(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *batch_run(void *arg) {
+    struct batch_worker *w = arg;
+    const size_t n = w->buffer_bytes;
+    uint8_t *in = malloc(n + 8), *enc = malloc(2 * n + 64), *back = malloc(n + 8);
+    if (!in || !enc || !back) {
+        w->bad = 1;
+        return NULL;
+    }
+    oracle_splitmix64_fill(in, n, w->seed);
+    while (now_seconds() < w->deadline) {
+        struct aws_huffman_encoder e;
+        struct aws_huffman_decoder d;
+        oracle_huffman_encoder_init(&e, w->coder);
+        oracle_huffman_decoder_init(&d, w->coder);
+        struct aws_byte_cursor src = {n, in};
+        struct aws_byte_buf out = {0, enc, 2 * n + 64, NULL};
+        if (oracle_huffman_encode(&e, &src, &out) != AWS_OP_SUCCESS) {
+            w->bad = 1;
+            break;
+        }
+        struct aws_byte_cursor stream = {out.len, enc};
+        struct aws_byte_buf plain = {0, back, n, NULL};
+        if (oracle_huffman_decode(&d, &stream, &plain) != AWS_OP_SUCCESS || plain.len != n || memcmp(back, in, n) != 0) {
+            w->bad = 1;
+            break;
+        }
+        ++w->done;
+    }
+    free(in);
+    free(enc);
+    free(back);
+    return NULL;
+}
+
+uint64_t oracle_batch_round_trips(
+    struct aws_huffman_symbol_coder *coder, uint32_t threads, double seconds, uint32_t buffer_bytes, double *elapsed_seconds) {
+    struct batch_worker *w = calloc(threads ? threads : 1, sizeof(*w));
+    pthread_t *t = calloc(threads ? threads : 1, sizeof(*t));
+    if (!w || !t || threads == 0) {
+        free(w);
+        free(t);
+        return 0;
+    }
+    const double start = now_seconds();
+    for (uint32_t k = 0; k < threads; ++k) {
+        w[k].coder = coder;
+        w[k].buffer_bytes = buffer_bytes;
+        w[k].seed = 2 + k;
+        w[k].deadline = start + seconds;
+        if (pthread_create(&t[k], NULL, batch_run, &w[k]) != 0) {
+            w[k].bad = 1;
+            t[k] = 0;
+        }
+    }
+    uint64_t total = 0;
+    int bad = 0;
+    for (uint32_t k = 0; k < threads; ++k) {
+        if (t[k]) {
+            pthread_join(t[k], NULL);
+        }
+        total += w[k].done;
+        bad |= w[k].bad;
+    }
+    if (elapsed_seconds) {
+        *elapsed_seconds = now_seconds() - start;
+    }
+    free(w);
+    free(t);
+    return bad ? 0 : total;
+}

@@ -87,6 +87,15 @@ int oracle_huffman_test_transitive_chunked(
     size_t output_chunk_size,
     const char **error_string);
 
+/*
+ * bench.py's all-core CPU baseline: `threads` threads, each encoding and decoding
+ * buffers of `buffer_bytes` symbols of its own (splitmix64, seed 2 + thread) through oracle_huffman_encode /
+ * oracle_huffman_decode for `seconds`; returns how many buffers made the round trip in all (0 on a mismatch).
+ * Plain pthreads, no shared state but the coder's read-only tables.
+ */
+uint64_t oracle_batch_round_trips(
+    struct aws_huffman_symbol_coder *coder, uint32_t threads, double seconds, uint32_t buffer_bytes, double *elapsed_seconds);
+
 /* splitmix64 byte stream of SURVEY.md section 8c: draw i (0-based) mixes seed + (i+1)*0x9E3779B97F4A7C15,
  * 8 bytes little-endian per draw. */
 void oracle_splitmix64_fill(uint8_t *dst, size_t len, uint64_t seed);

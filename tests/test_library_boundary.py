@@ -68,6 +68,27 @@ def test_init_and_reset_need_no_gpu(product_lib):
     assert d.allow_growth and d.num_bits == 0 and d.working_bits == 0
 
 
+def test_library_init_registers_the_error_name(product_lib):
+    """reference tests/library_test.c:9-22: after aws_compression_library_init, aws_error_name of
+    AWS_ERROR_COMPRESSION_UNKNOWN_SYMBOL is that very string -- stand-alone too, through the registry of
+    csrc/host/common_compat.c; after clean-up the name is gone again, and both calls are idempotent."""
+    lib = product_lib
+    lib.aws_error_name.restype, lib.aws_error_name.argtypes = C.c_char_p, [C.c_int]
+    lib.aws_error_str.restype, lib.aws_error_str.argtypes = C.c_char_p, [C.c_int]
+    code = harness.AWS_ERROR_COMPRESSION_UNKNOWN_SYMBOL
+    assert code == 0x0C00
+    lib.aws_compression_library_clean_up()
+    assert lib.aws_error_name(code) == b"Unknown Error Code"
+    lib.aws_compression_library_init(lib.aws_default_allocator())
+    lib.aws_compression_library_init(lib.aws_default_allocator())
+    assert lib.aws_error_name(code) == b"AWS_ERROR_COMPRESSION_UNKNOWN_SYMBOL"
+    assert lib.aws_error_str(code) == b"Compression encountered an unknown symbol."
+    assert lib.aws_error_name(harness.AWS_ERROR_SHORT_BUFFER) == b"AWS_ERROR_SHORT_BUFFER"
+    lib.aws_compression_library_clean_up()
+    lib.aws_compression_library_clean_up()
+    assert lib.aws_error_name(code) == b"Unknown Error Code"
+
+
 def test_table_coder_matches_the_reference_table(product_lib):
     rows = harness.load_json("test_coder_table.json")["rows"]
     tree = harness.load_json("test_coder_decode_tree.json")
