@@ -105,7 +105,11 @@ int hufk_decode_one_tiny(
 /* the same for an item of up to HUFD_DEC_COOP_BYTES encoded bytes (any size with long codes): dec_deep, one launch */
 int hufk_decode_one_coop(
     const struct hufd_tables *tables, const struct hufd_dec_item *item, const uint32_t *zero, const void *d_in, void *d_out,
-    struct hufd_dec_item_state *state, struct hufd_dec_result *result, void *stream);
+    struct hufd_dec_item_state *state, struct hufd_dec_result *result, uint32_t wide /* a workgroup, not one wave */, void *stream);
+/* one item of up to HUFD_ENC_BLOCK_BYTES symbols, one workgroup, one launch (enc_block_kernel) */
+int hufk_encode_one_block(
+    const struct hufd_tables *tables, const struct hufd_enc_item *item, const void *d_in, void *d_out,
+    struct hufd_enc_result *result, uint32_t length_only, void *stream);
 int hufk_fill_splitmix64(void *dst, uint64_t len, uint64_t seed, void *stream);
 
 #ifdef __cplusplus

@@ -742,6 +742,168 @@ __global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
 }
 
 /*
+ * One item of at most HUFD_ENC_BLOCK_BYTES symbols, one workgroup, ONE launch: count, offsets, outcome and bits in
+ * one go (the host-pointer calls' road for inputs beyond a header field: with segments the same call is a plan
+ * upload and four or five launches).  A thread takes 16 symbols; the outcome is the reference's, in closed form as
+ * in enc_finish_item: with `o` carried bits, T bits in all, room for A bytes, first symbol without a code `u` at bit
+ * `before_u`: UNKNOWN_SYMBOL iff before_u < 8A (source/huffman.c:62-64: whole bytes in front of it stay, the byte
+ * in flight is lost), else SUCCESS iff no such symbol and T <= 8A (padded, :178-184), else SHORT_BUFFER with the
+ * symbol whose last bit reaches bit 8A consumed and what of its code lies behind that bit carried (:88-100).
+ */
+constexpr u32 kBlockEncThreads = 256;
+
+struct enc_block_shared {
+    u64 unk_key;   /* lowest (index << 32 | bits in front) of a symbol without a code */
+    u32 short_consumed, short_ovf_bits, short_ovf_pattern, pad;
+    u32 slots[8];
+};
+
+__global__ __launch_bounds__(kBlockEncThreads) void enc_block_kernel(
+    hufd_tables tb,
+    const hufd_enc_item *item_ptr,
+    const u8 *d_in,
+    u8 *d_out,
+    hufd_enc_result *result,
+    u32 img_words,
+    u32 length_only) {
+
+    u32 *img = reinterpret_cast<u32 *>(dyn_lds);
+    u64 *tab = reinterpret_cast<u64 *>(dyn_lds + round16(img_words * 4));
+    enc_block_shared *sh = reinterpret_cast<enc_block_shared *>(tab + 256);
+    const u32 tid = threadIdx.x;
+    tab[tid] = tb.enc_table[tid];
+    const hufd_enc_item it = *item_ptr;
+    const u32 n = (u32)it.in_len;
+    const u8 *src = d_in + it.in_off;
+    u8 *out = d_out + it.out_off;
+    const u64 cap_bits = it.out_cap > (~0ull >> 3) ? ~0ull : it.out_cap * 8;
+    {
+        const uint4 zero = {0, 0, 0, 0};
+        for (u32 i = tid; i < img_words / 4; i += kBlockEncThreads) {
+            reinterpret_cast<uint4 *>(img)[i] = zero;
+        }
+    }
+    if (tid == 0) {
+        sh->unk_key = kNoBit;
+        sh->short_consumed = 0;
+        sh->short_ovf_bits = 0;
+        sh->short_ovf_pattern = 0;
+    }
+    const u32 base = tid * 16;
+    const u32 valid = base < n ? (n - base < 16 ? n - base : 16) : 0;
+    u32 gw[4] = {0, 0, 0, 0};
+    if (valid) {
+        load_group(src + base, valid, ((uintptr_t)src & 15u) == 0, gw);
+    }
+    __syncthreads();
+
+    u64 e[16];
+    u32 lane_bits = 0;
+#pragma unroll
+    for (u32 j = 0; j < 16; ++j) {
+        e[j] = j < valid ? tab[group_byte(gw, j)] : 0;
+        lane_bits += (u32)(e[j] >> 32);
+    }
+    u32 symbols_bits;
+    const u32 rel0 = it.ovf_bits + block_exclusive_sum<kBlockEncThreads>(lane_bits, sh->slots, symbols_bits);
+    const u64 total = (u64)it.ovf_bits + symbols_bits;
+
+    /* the image's bit 8 * mis is the stream's first bit: whole 16-byte rows of the output leave aligned */
+    const u32 mis = (u32)((uintptr_t)out & 15u);
+    u8 *gbase = out - mis;
+    if (tid == 0 && it.ovf_bits && !length_only) {
+        image_or_bits(img, 8 * mis, it.ovf_pattern, it.ovf_bits);
+    }
+    {
+        u32 rel = rel0;
+        u32 wi = (8 * mis + rel) >> 5, nb = (8 * mis + rel) & 31;
+        u64 acc = 0;
+#pragma unroll
+        for (u32 j = 0; j < 16; ++j) {
+            const u32 len = (u32)(e[j] >> 32);
+            const u32 pat = (u32)e[j];
+            if (j < valid) {
+                if (len == 0) {
+                    atomicMin(&sh->unk_key, ((u64)(base + j) << 32) | rel);
+                } else {
+                    const u32 after = rel + len;
+                    if (rel < cap_bits && after >= cap_bits) {
+                        /* the symbol whose last bit reaches the capacity edge (source/huffman.c:88-98): only one can */
+                        sh->short_consumed = base + j + 1;
+                        sh->short_ovf_bits = (u32)(after - cap_bits);
+                        sh->short_ovf_pattern = pat & (u32)((1ull << (after - cap_bits)) - 1);
+                    }
+                    if (!length_only) {
+                        acc = (acc << len) | pat;
+                        nb += len;
+                        if (nb >= 32) {
+                            atomicOr(&img[wi], (u32)(acc >> (nb - 32)));
+                            ++wi;
+                            nb -= 32;
+                            acc &= (1ull << nb) - 1;
+                        }
+                    }
+                    rel = after;
+                }
+            }
+        }
+        if (nb && !length_only) {
+            const u32 tail = (u32)(acc << (32 - nb));
+            if (tail) {
+                atomicOr(&img[wi], tail);
+            }
+        }
+    }
+    __syncthreads();
+
+    const u64 unk_key = sh->unk_key;
+    const bool has_unk = unk_key != kNoBit;
+    const u32 unk_idx = (u32)(unk_key >> 32), unk_before = (u32)unk_key;
+    hufd_enc_result rs;
+    rs.reserved = 0;
+    rs.ovf_pattern = 0;
+    rs.ovf_bits = 0;
+    rs.total_bits = total;
+    if (length_only) {
+        rs.status = HUFD_ENC_OK;
+        rs.consumed = n;
+        rs.produced = (total + 7) >> 3;
+    } else if (has_unk && unk_before < cap_bits) {
+        rs.status = HUFD_ENC_UNKNOWN;
+        rs.consumed = unk_idx + 1;
+        rs.produced = unk_before >> 3;
+    } else if (!has_unk && total <= cap_bits) {
+        rs.status = HUFD_ENC_OK;
+        rs.consumed = n;
+        rs.produced = (total + 7) >> 3;
+        const u32 pad_bits = (u32)((8 - (total & 7)) & 7);
+        if (tid == 0 && pad_bits) {
+            image_or_bits(img, 8 * mis + (u32)total, it.eos_padding & ((1u << pad_bits) - 1), pad_bits);
+        }
+    } else {
+        rs.status = HUFD_ENC_SHORT;
+        rs.produced = it.out_cap;
+        if (it.ovf_bits >= cap_bits) {
+            /* the carried bits alone fill the room (source/huffman.c:149-156) */
+            rs.consumed = 0;
+            rs.ovf_bits = (u32)(it.ovf_bits - cap_bits);
+            rs.ovf_pattern = rs.ovf_bits ? (it.ovf_pattern & (u32)((1ull << rs.ovf_bits) - 1)) : 0;
+        } else {
+            rs.consumed = sh->short_consumed;
+            rs.ovf_bits = sh->short_ovf_bits;
+            rs.ovf_pattern = sh->short_ovf_pattern;
+        }
+    }
+    __syncthreads();
+    if (!length_only && rs.produced) {
+        image_store<kBlockEncThreads>(img, gbase, mis, mis + (u32)rs.produced);
+    }
+    if (tid == 0) {
+        *result = rs;
+    }
+}
+
+/*
  * One workgroup per item with many segments.  Each wave owns a contiguous range of the item's
  * segments and reads it 64 x 8 at a time, all eight loads of a lane in flight together (one load
  * per trip left this kernel waiting a memory round trip per 64 segments): first pass sums the
@@ -5794,6 +5956,19 @@ int hufk_encode_one_tiny(
     return (int)hipGetLastError();
 }
 
+int hufk_encode_one_block(
+    const struct hufd_tables *tables, const struct hufd_enc_item *item, const void *d_in, void *d_out,
+    struct hufd_enc_result *result, uint32_t length_only, void *stream) {
+    /* (the image: HUFD_ENC_BLOCK_BYTES symbols of the longest code, carried bits, alignment, padding) */
+    const uint32_t bits = HUFD_ENC_BLOCK_BYTES * tables->max_bits + 32 + 128 + 64;
+    const uint32_t img_words = ((bits + 31) / 32 + 3) & ~3u;
+    const uint32_t lds = ((img_words * 4 + 15) & ~15u) + 256 * 8 + (uint32_t)sizeof(enc_block_shared);
+    hipLaunchKernelGGL(
+        enc_block_kernel, dim3(1), dim3(kBlockEncThreads), lds, (hipStream_t)stream, *tables, item, (const u8 *)d_in,
+        (u8 *)d_out, result, img_words, length_only);
+    return (int)hipGetLastError();
+}
+
 int hufk_decode_one_tiny(
     const struct hufd_tables *tables, const struct hufd_dec_item *item, const uint32_t *zero, const void *d_in, void *d_out,
     struct hufd_dec_item_state *state, struct hufd_dec_result *result, void *stream) {
@@ -5811,15 +5986,17 @@ int hufk_decode_one_tiny(
 
 int hufk_decode_one_coop(
     const struct hufd_tables *tables, const struct hufd_dec_item *item, const uint32_t *zero, const void *d_in, void *d_out,
-    struct hufd_dec_item_state *state, struct hufd_dec_result *result, void *stream) {
+    struct hufd_dec_item_state *state, struct hufd_dec_result *result, uint32_t wide, void *stream) {
     if (tables->deep_entries) {
         hipLaunchKernelGGL(
             dec_deep_kernel<true>, dim3(1), dim3(kDeepThreads), sizeof(deep_shared) + tables->deep_entries * sizeof(u32),
             (hipStream_t)stream, *tables, item, zero, kDeepLaneBytes, (const u8 *)d_in, (u8 *)d_out, state, result);
     } else {
+        /* (one wave up to HUFD_DEC_COOP_BYTES; beyond, the workgroup the kernel allows: the lanes share the item evenly) */
         hipLaunchKernelGGL(
-            dec_deep_kernel<false>, dim3(1), dim3(kCoopThreads), sizeof(deep_shared) + (1u << tables->lut_bits) * sizeof(u16),
-            (hipStream_t)stream, *tables, item, zero, 0u, (const u8 *)d_in, (u8 *)d_out, state, result);
+            dec_deep_kernel<false>, dim3(1), dim3(wide ? kDeepThreads : kCoopThreads),
+            sizeof(deep_shared) + (1u << tables->lut_bits) * sizeof(u16), (hipStream_t)stream, *tables, item, zero, 0u,
+            (const u8 *)d_in, (u8 *)d_out, state, result);
     }
     return (int)hipGetLastError();
 }

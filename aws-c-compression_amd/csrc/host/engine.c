@@ -576,28 +576,29 @@ int aws_huffman_amd_encode_plan_raw_results(
     void *st = stream ? stream : p->engine->stream;
     hufs_set_device(p->engine->device);
     int err = 0;
+    /* The one-pass kernel's waves wait for each other's totals; every wait is bounded, and one that ran out raises a
+     * flag (and leaves the output undefined).  The flag comes back with the results, in the same synchronisation; if it
+     * is up, the launch is redone with the three-kernel path, which has no waits between workgroups, and the plan stays
+     * on it. */
+    uint32_t timed_out = 0;
     if (p->last_single_pass) {
-        /* The fused kernel's workgroups wait on each other's look-back granules. If one gave up
-         * (it raises the flag and leaves its output undefined), redo the launch with the
-         * three-kernel path, which has no cross-workgroup waits, and stay on it. */
-        uint32_t timed_out = 0;
-        const uint8_t *flag = p->d_zero + sizeof(uint32_t);
-        err = hufs_copy_d2h(&timed_out, flag, sizeof(timed_out), st);
-        if (!err) {
-            err = hufs_stream_sync(st);
-        }
-        if (!err && timed_out) {
-            p->look_back_timed_out = true;
-            if (aws_huffman_amd_encode_plan_launch_staged(p, p->last_input, p->last_output, false, st, NULL)) {
-                return AWS_OP_ERR;
-            }
-        }
+        err = hufs_copy_d2h(&timed_out, p->d_zero + sizeof(uint32_t), sizeof(timed_out), st);
     }
     if (!err) {
         err = hufs_copy_d2h(raw, p->d_results, (size_t)p->n_items * sizeof(*raw), st);
     }
     if (!err) {
         err = hufs_stream_sync(st);
+    }
+    if (!err && timed_out) {
+        p->look_back_timed_out = true;
+        if (aws_huffman_amd_encode_plan_launch_staged(p, p->last_input, p->last_output, false, st, NULL)) {
+            return AWS_OP_ERR;
+        }
+        err = hufs_copy_d2h(raw, p->d_results, (size_t)p->n_items * sizeof(*raw), st);
+        if (!err) {
+            err = hufs_stream_sync(st);
+        }
     }
     return err ? raise_hip(err) : AWS_OP_SUCCESS;
 }
@@ -1099,19 +1100,20 @@ static int one_shot_reserve(struct aws_huffman_amd_engine *eng, size_t in_bytes,
 }
 
 /*
- * Header-sized inputs (what the reference's HPACK consumer passes, one call per field): the item record and
- * the input go up in ONE copy from a page-locked block, ONE thread does the work (enc_tiny / dec_tiny), the
- * result record and the output come back in ONE copy.  The general road costs a plan upload, four small
- * pageable copies, two or three launches and two synchronisations for the same call.
+ * Inputs of up to a few KiB (what the reference's HPACK consumer passes is tens of bytes, one call per header field):
+ * the item record and the input go up in ONE copy from a page-locked block, ONE launch does the work -- one thread
+ * (enc_tiny / dec_tiny) up to MINI_MAX_IN bytes, beyond that one wave (dec_deep) or one workgroup (enc_block,
+ * dec_deep) --, the result record and the output come back in ONE copy.  The general road costs a plan upload, four
+ * small pageable copies, four or five launches and two synchronisations for the same call.
  */
 enum {
-    MINI_MAX_IN = 128,     /* symbols to encode; encoded bytes (carried ones included) one thread decodes: HUFD_DEC_COOP_BYTES go this way */
-    MINI_IN_AT = 64,       /* block layout: [0] item record, [64] input, [1024] zero word, [1088] scratch, */
-    MINI_ZERO_AT = 1024,
-    MINI_SCRATCH_AT = 1088,
-    MINI_RESULT_AT = 2048, /* [2048] result record, [2112] output */
-    MINI_OUT_AT = 2112,
-    MINI_BLOCK = 4096,
+    MINI_MAX_IN = 128,     /* symbols to encode / encoded bytes (carried ones included) that are ONE THREAD's work */
+    MINI_IN_AT = 64,       /* block layout: [0] item record, [64] input (decode: 16 bytes for the carried ones first), */
+    MINI_ZERO_AT = 6208,   /* [6208] zero word, [6272] scratch, */
+    MINI_SCRATCH_AT = 6272,
+    MINI_RESULT_AT = 6336, /* [6336] result record, [6400] output */
+    MINI_OUT_AT = 6400,
+    MINI_BLOCK = 16384,
     MINI_MAX_OUT = MINI_BLOCK - MINI_OUT_AT
 };
 
@@ -1153,15 +1155,20 @@ static int mini_encode(
                                          : item->overflow_in.pattern & ((1u << rec.ovf_bits) - 1u);
     rec.eos_padding = item->eos_padding;
     rec.tiny = 1;
+    rec.n_segs = 0;
     memcpy(eng->mini_host, &rec, sizeof(rec));
     memcpy(eng->mini_host + MINI_IN_AT, host_in, item->in_len);
     hufs_set_device(eng->device);
     int err = hufs_copy_h2d(eng->mini_dev, eng->mini_host, MINI_IN_AT + item->in_len, eng->stream);
-    if (!err) {
+    if (!err && item->in_len <= MINI_MAX_IN) {
         err = hufk_encode_one_tiny(
             &eng->tables, (const struct hufd_enc_item *)eng->mini_dev, (const uint32_t *)(eng->mini_dev + MINI_ZERO_AT),
             eng->mini_dev, eng->mini_dev, (struct hufd_enc_result *)(eng->mini_dev + MINI_RESULT_AT), length_only,
             eng->stream);
+    } else if (!err) {
+        err = hufk_encode_one_block(
+            &eng->tables, (const struct hufd_enc_item *)eng->mini_dev, eng->mini_dev, eng->mini_dev,
+            (struct hufd_enc_result *)(eng->mini_dev + MINI_RESULT_AT), length_only, eng->stream);
     }
     if (!err) {
         const size_t back = (MINI_OUT_AT - MINI_RESULT_AT) + (length_only ? 0 : dev_out);
@@ -1211,8 +1218,8 @@ int aws_huffman_amd_engine_encode_host(
     const uint64_t dev_out = item.out_capacity < worst ? item.out_capacity : worst;
     item.in_offset = 0;
     item.out_offset = 0;
-    if (item.in_len <= MINI_MAX_IN && (item.in_len || item.overflow_in.num_bits) && item.overflow_in.num_bits <= 32 &&
-        dev_out <= MINI_MAX_OUT && mini_ready(eng)) {
+    if (item.in_len <= HUFD_ENC_BLOCK_BYTES && (item.in_len || item.overflow_in.num_bits) && item.overflow_in.num_bits <= 32 &&
+        (length_only || dev_out <= MINI_MAX_OUT) && mini_ready(eng)) {
         return mini_encode(eng, &item, dev_out, host_in, host_out, length_only, raw);
     }
     if (one_shot_reserve(eng, item.in_len + 16, length_only ? 0 : dev_out + 16)) {
@@ -1282,6 +1289,8 @@ int aws_huffman_amd_engine_decode_host(
     const uint64_t most_symbols = stream_bits / eng->tables.min_bits;
     const uint64_t dev_out = out_capacity < most_symbols ? out_capacity : most_symbols;
     eng->mini_output = false;
+    /* (decode: one thread, or one wave up to HUFD_DEC_COOP_BYTES; a workgroup of dec_deep's lanes was tried for a few
+     * KiB -- 1.5 ms for 4 KiB: lanes of 24 bytes rarely settle in one round -- the chunk kernels take those) */
     if (carry_bytes + in_len <= HUFD_DEC_COOP_BYTES && carry_bytes + in_len > 0 && dev_out <= MINI_MAX_OUT && mini_ready(eng)) {
         struct hufd_dec_item rec;
         memset(&rec, 0, sizeof(rec));
@@ -1298,10 +1307,18 @@ int aws_huffman_amd_engine_decode_host(
         int e = hufs_copy_h2d(eng->mini_dev, eng->mini_host, MINI_IN_AT + 16 + in_len, eng->stream);
         if (!e) {
             /* a lone thread up to MINI_MAX_IN bytes, a wave (a workgroup with long codes) above */
-            e = (carry_bytes + in_len <= MINI_MAX_IN ? hufk_decode_one_tiny : hufk_decode_one_coop)(
-                &eng->tables, (const struct hufd_dec_item *)eng->mini_dev, (const uint32_t *)(eng->mini_dev + MINI_ZERO_AT),
-                eng->mini_dev, eng->mini_dev, (struct hufd_dec_item_state *)(eng->mini_dev + MINI_SCRATCH_AT),
-                (struct hufd_dec_result *)(eng->mini_dev + MINI_RESULT_AT), eng->stream);
+            if (carry_bytes + in_len <= MINI_MAX_IN) {
+                e = hufk_decode_one_tiny(
+                    &eng->tables, (const struct hufd_dec_item *)eng->mini_dev, (const uint32_t *)(eng->mini_dev + MINI_ZERO_AT),
+                    eng->mini_dev, eng->mini_dev, (struct hufd_dec_item_state *)(eng->mini_dev + MINI_SCRATCH_AT),
+                    (struct hufd_dec_result *)(eng->mini_dev + MINI_RESULT_AT), eng->stream);
+            } else {
+                e = hufk_decode_one_coop(
+                    &eng->tables, (const struct hufd_dec_item *)eng->mini_dev, (const uint32_t *)(eng->mini_dev + MINI_ZERO_AT),
+                    eng->mini_dev, eng->mini_dev, (struct hufd_dec_item_state *)(eng->mini_dev + MINI_SCRATCH_AT),
+                    (struct hufd_dec_result *)(eng->mini_dev + MINI_RESULT_AT), carry_bytes + in_len > HUFD_DEC_COOP_BYTES,
+                    eng->stream);
+            }
         }
         if (!e) {
             e = hufs_copy_d2h(
