@@ -30,6 +30,7 @@
  * shorter than the segments / chunks of all of them (~33 / ~74 ns an item): the plan takes the largest of these
  * length classes that holds at least HUFD_*_TINY_PER_BYTE items per byte of its longest item. */
 #define HUFD_TINY_MANY_BYTES 2048u /* symbols (encode); encoded bytes x 2 / 3 (decode) */
+#define HUFD_ENC_TINY_WAVE_BYTES 1024u /* the same class for encode where the one-pass kernel is used */
 #define HUFD_ENC_TINY_PER_BYTE 18u
 #define HUFD_DEC_TINY_PER_BYTE 6u
 #define HUFD_TINY_FEW_BYTES 128u   /* the class that always goes to a thread */

@@ -38,8 +38,6 @@ struct hufk_encode_args {
     uint8_t *seg_unk_seen;   /* [n_segs] scratch */
     uint64_t *item_total;    /* [n_items] scratch */
     uint32_t single_pass;    /* 1: one kernel reads the symbols once (enc_onepass) instead of count / scan / pack */
-    uint32_t maybe_unshaped; /* the plan holds segments that are ragged, start with carried bits or lie at an input offset
-                              * that is no multiple of 16: the one-pass path counts those in a kernel of their own first */
     struct hufd_enc_item_state *states; /* [n_items] scratch */
     struct hufd_enc_result *results;    /* [n_items] */
     void **stage_events; /* NULL, or 4 hipEvent_t: before count, after count, after scan, after pack */

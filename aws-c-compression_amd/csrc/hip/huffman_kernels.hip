@@ -2053,10 +2053,16 @@ __device__ __forceinline__ void region_store_shifted(const u32 *img, u8 *out_ptr
     if (jhi <= jlo) {
         return;
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* (the lane number as a value the compiler cannot trace: what is derived from it -- the lane's place in the image --
+     * is then worked out here, two instructions, instead of being kept in registers, or spilled, across the turn) */
+    asm volatile("" : "+v"(lane));
+#endif
+    /* (an item's carried bits lie in front of image bit 0, in img[-1]: image bit numbers may be negative down to -32) */
     auto byte_at = [&](u64 j) -> u8 {
-        const u32 ib = (u32)(8 * j - bit0);
+        const int ib = (int)(u32)(8 * j - bit0);
         const u64 two = ((u64)img[ib >> 5] << 32) | img[(ib >> 5) + 1];
-        return (u8)((two << (ib & 31u)) >> 56);
+        return (u8)((two << ((u32)ib & 31u)) >> 56);
     };
     const uintptr_t a_lo = (uintptr_t)(out_ptr + jlo), a_hi = (uintptr_t)(out_ptr + jhi);
     const uintptr_t row_lo = (a_lo + 15) & ~(uintptr_t)15, row_hi = a_hi & ~(uintptr_t)15;
@@ -2074,10 +2080,10 @@ __device__ __forceinline__ void region_store_shifted(const u32 *img, u8 *out_ptr
     {
         /* bits [ib0 + 128 r, + 128) of the image are row r.  With the shift written as a right shift of the
          * word pair (k - 1, k) a shift of zero needs no case of its own: it takes the pair one word down */
-        const u32 ib0 = (u32)(8 * j_row_lo - bit0);
-        const u32 sh = ib0 & 31u;
+        const int ib0 = (int)(u32)(8 * j_row_lo - bit0);
+        const u32 sh = (u32)ib0 & 31u;
         const u32 rs = (32u - sh) & 31u;
-        const u32 *words = img + (ib0 >> 5) - (sh == 0 ? 1u : 0u);
+        const u32 *words = img + (ib0 >> 5) - (sh == 0 ? 1 : 0);
         const u32 rows = (u32)((row_hi - row_lo) >> 4);
         uint4 *dst = reinterpret_cast<uint4 *>(row_lo);
         for (u32 r = lane; r < rows; r += kWave) {
@@ -2096,44 +2102,13 @@ __device__ __forceinline__ void region_store_shifted(const u32 *img, u8 *out_ptr
     }
 }
 
-/* a segment the one-pass kernel packs itself: whole, 16-byte aligned, no carried bits in front of it */
-__device__ __forceinline__ bool op_shaped(const hufd_enc_seg &seg, const u8 *d_in, u32 carried) {
-    return seg.len == HUFD_ENC_SEG_BYTES && ((uintptr_t)(d_in + seg.in_off) & 15u) == 0 && !(seg.index == 0 && carried);
-}
-
-/*
- * The other segments (ragged ends of items, unaligned input, carried bits in front) are only COUNTED for the
- * look-back, symbol by symbol, here -- before enc_onepass_kernel starts, which then finds their tiles arrived and
- * has no loop of loads in its turn (a wait in it can then be a counted one) -- and packed by enc_pack_kernel.
- * One workgroup per segment, a wave per tile; launched only when the plan may hold such segments.
- */
-__global__ __launch_bounds__(256) void enc_ragged_count_kernel(
-    hufd_tables tb,
-    const hufd_enc_item *__restrict__ items,
-    const hufd_enc_seg *__restrict__ segs,
-    const u8 *__restrict__ d_in,
-    u32 *tile_agg,
-    u64 *group_acc) {
-
-    const u32 s = blockIdx.x, lane = threadIdx.x & (kWave - 1), w4 = threadIdx.x / kWave;
-    const hufd_enc_seg seg = segs[s];
-    if (op_shaped(seg, d_in, items[seg.item].ovf_bits)) {
-        return;
-    }
-    const u32 from = w4 * kTileBytes;
-    const u32 n = seg.len > from ? (seg.len - from < kTileBytes ? seg.len - from : kTileBytes) : 0u;
-    const u8 *src = d_in + seg.in_off + from;
-    u32 sum = 0;
-    for (u32 i = lane; i < n; i += kWave) {
-        sum += (u32)(tb.enc_table[src[i]] >> 32);
-    }
-    const u32 bits = wave_sum(sum);
-    if (lane == 0) {
-        const u32 t = s * kTilesPerSeg + w4;
-        word_store(&tile_agg[t], kOpTileReady | bits);
-        granule_add(&group_acc[(u64)(t / kOpGroupTiles) * kOpGroupStride], kOpArrive | bits);
-    }
-}
+/* 16 bytes at any address (one load: the memory system takes any alignment) */
+struct __attribute__((packed, aligned(1))) unaligned_uint4 {
+    u32 x, y, z, w;
+};
+template <bool B> struct op_flag {
+    static constexpr bool value = B;
+};
 
 /* what a wave knows about a tile (everything here is the same in all lanes) */
 struct op_tile {
@@ -2144,8 +2119,9 @@ struct op_tile {
     u32 item_first_tile; /* the item's first tile */
     u32 bits;       /* the tile's code bits, once counted */
     u32 halo_n;     /* how many symbols behind the tile its last byte may need (their values are per-lane registers) */
-    bool shaped;    /* a whole, aligned segment without carried bits in front: packed here */
-    bool first_tile, last_tile; /* of its item */
+    u32 carried_pattern; /* the carried bits themselves (an item's first tile puts them in front of its image) */
+    bool first_tile; /* of its item */
+    bool ends_item;  /* holds the item's last symbol */
     const u8 *tsrc;
 };
 
@@ -2163,20 +2139,17 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
     u64 *group_acc,    /* zeroed */
     u64 *round_base,   /* [rounds + 1] zeroed */
     u64 *item_base,    /* [n_items] zeroed */
-    u32 *__restrict__ seg_bits,
-    u32 *__restrict__ seg_unk,
-    u64 *__restrict__ seg_bitoff,
-    u8 *__restrict__ seg_unk_seen,
     u64 *__restrict__ item_total,
-    u32 *__restrict__ careful_list,
-    const u8 *__restrict__ null_tile, /* kTileBytes readable bytes: what a wave "prefetches" when no tile follows */
-    const u32 *__restrict__ tile_agg_early /* = tile_agg, for the words enc_ragged_count_kernel wrote before this launch */) {
+    hufd_enc_result *__restrict__ results, /* the tile with the capacity edge leaves a note for enc_finish_kernel here */
+    const u8 *__restrict__ null_tile /* kTileBytes readable bytes: what a wave "prefetches" when no tile follows */) {
 
     HUFD_STAMP_DECL
     HUFD_STAMP_ZERO;
     u32 *tab = reinterpret_cast<u32 *>(dyn_lds); /* [256][32] */
     const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = uniform32(tid / kWave);
-    u32 *img = reinterpret_cast<u32 *>(dyn_lds + kPackTabBytes + wave * region_bytes);
+    /* image bit 0 = the tile's first code; the four words in front of it: img[-1] = an item's carried bits (first
+     * tile, right-aligned), the others only ever read along with it */
+    u32 *img = reinterpret_cast<u32 *>(dyn_lds + kPackTabBytes + wave * region_bytes) + 4;
 
     if (tid < 256) {
         const u64 ent = tb.enc_table[tid];
@@ -2186,6 +2159,9 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         for (u32 k = 0; k < 32; ++k) {
             tab[tid * 32 + ((k + tid) & 31u)] = e;
         }
+    }
+    if (lane < 4) {
+        img[(int)lane - 4] = 0;
     }
     __syncthreads();
     const u8 *mine = reinterpret_cast<const u8 *>(tab) + (lane & 31u) * 4u;
@@ -2201,15 +2177,17 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         d.seg = segs[d.s];
         const u8 *src = d_in + d.seg.in_off;
         d.carried = items[d.seg.item].ovf_bits;
+        d.carried_pattern = items[d.seg.item].ovf_pattern;
         d.item_first_tile = items[d.seg.item].first_seg * kTilesPerSeg;
-        d.shaped = op_shaped(d.seg, d_in, d.carried);
         d.tsrc = src + d.w4 * kTileBytes;
         const u32 from = d.w4 * kTileBytes;
-        d.n_sym = d.seg.len > from ? (d.seg.len - from < kTileBytes ? d.seg.len - from : kTileBytes) : 0u;
+        d.n_sym = (t < n_tiles && d.seg.len > from) ? (d.seg.len - from < kTileBytes ? d.seg.len - from : kTileBytes) : 0u;
         d.first_tile = d.seg.index == 0 && d.w4 == 0;
-        d.last_tile = (d.seg.flags & 2u) != 0 && d.w4 == kTilesPerSeg - 1;
+        d.ends_item = (d.seg.flags & 2u) != 0 && d.n_sym != 0 && from + d.n_sym == d.seg.len;
         d.bits = 0;
-        d.halo_n = 0;
+        /* the symbols of the item behind the tile: the first two complete its last byte (a code is at least 4 bits, the byte lacks at most 7) */
+        const u32 behind = d.n_sym ? (d.seg.len - from - d.n_sym) + d.seg.next_len : 0u;
+        d.halo_n = behind < 2 ? behind : 2u;
         return d;
     };
 
@@ -2272,12 +2250,41 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
     for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
         v[gi] = vn[gi] = uint4{0, 0, 0, 0};
     }
-    if (fresh.shaped) {
+    /*
+     * A tile's symbols, 16 per lane and group, from any address (the loads need no alignment).  Every lane loads (no
+     * branch around a load: see ask_offsets): where a ragged tile ends inside a group, the 16 bytes that END with the
+     * tile's last symbol (an item with segments is longer than 16 bytes, so they are the item's; ragged_groups shifts
+     * them into place), behind that a harmless address.
+     */
+    auto tile_loads = [&](const op_tile &d, uint4 (&into)[kGroupsPerLane]) {
+        const u8 *spare = d.n_sym >= 16 ? d.tsrc : null_tile;
 #pragma unroll
         for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
-            v[gi] = reinterpret_cast<const uint4 *>(fresh.tsrc)[gi * kWave + lane];
+            const u32 base = (gi * kWave + lane) * 16;
+            const u8 *at = base + 16 <= d.n_sym ? d.tsrc + base : (base < d.n_sym ? d.tsrc + d.n_sym - 16 : spare);
+            const unaligned_uint4 got = *reinterpret_cast<const unaligned_uint4 *>(at);
+            into[gi] = uint4{got.x, got.y, got.z, got.w};
         }
-    }
+    };
+    /* how many of a lane's 16 symbols of group gi the tile holds; and its words put right where it holds only some
+     * (loaded as the 16 bytes that end with the tile: down by 16 - valid bytes) */
+    auto group_valid = [&](const op_tile &d, u32 gi) -> u32 {
+        const u32 base = (gi * kWave + lane) * 16;
+        return d.n_sym > base ? (d.n_sym - base < 16 ? d.n_sym - base : 16u) : 0u;
+    };
+    auto group_in_place = [&](u32 (&wd)[4], u32 valid) {
+        const u32 sb = 16 - valid, ws = sb >> 2, bs8 = (sb & 3u) * 8;
+        const u32 y0 = ws == 0 ? wd[0] : ws == 1 ? wd[1] : ws == 2 ? wd[2] : wd[3];
+        const u32 y1 = ws == 0 ? wd[1] : ws == 1 ? wd[2] : ws == 2 ? wd[3] : 0u;
+        const u32 y2 = ws == 0 ? wd[2] : ws == 1 ? wd[3] : 0u;
+        const u32 y3 = ws == 0 ? wd[3] : 0u;
+        const bool part = valid > 0 && valid < 16;
+        wd[0] = part ? (u32)((((u64)y1 << 32) | y0) >> bs8) : wd[0];
+        wd[1] = part ? (u32)((((u64)y2 << 32) | y1) >> bs8) : wd[1];
+        wd[2] = part ? (u32)((((u64)y3 << 32) | y2) >> bs8) : wd[2];
+        wd[3] = part ? (y3 >> bs8) : wd[3];
+    };
+    tile_loads(fresh, v);
     u32 base_item = HUFD_NONE32; /* the item whose base this wave has read ... */
     u64 base_value = 0;          /* ... and that base (item_base[base_item]) */
     u32 halo0 = 0, halo1 = 0, old_halo0 = 0, old_halo1 = 0; /* the first two symbols behind the fresh / the old tile */
@@ -2382,32 +2389,22 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         }
         const u64 bn = bw + old.bits;
 
-        /* ---- the records enc_finish_kernel and enc_pack_kernel read */
-        {
-            /* (w4 == 3: lanes p - 3 .. p - 1 hold the segment's other three tiles) */
-            const u32 a1 = __shfl(a, (p + kWave - 1) & (kWave - 1)), a2 = __shfl(a, (p + kWave - 2) & (kWave - 1)),
-                      a3 = __shfl(a, (p + kWave - 3) & (kWave - 1));
-            if (lane == 0) {
-                if (old.w4 == 0) {
-                    seg_bitoff[old.s] = bw;
-                    if (!old.shaped) {
-                        careful_list[atomicAdd(&ctl[2], 1u)] = old.s;
-                    }
-                }
-                if (old.w4 == kTilesPerSeg - 1) {
-                    seg_bits[old.s] = old.bits + a1 + a2 + a3;
-                    seg_unk[old.s] = HUFD_NONE32;
-                    seg_unk_seen[old.s] = 0;
-                    if (seg.flags & 2u) {
-                        item_total[seg.item] = bn;
-                    }
-                }
-            }
+        const u64 out_cap = uniform64(items[seg.item].out_cap);
+        const u64 cap_bits = out_cap > (~0ull >> 3) ? ~0ull : out_cap * 8;
+        /* ---- what enc_finish_kernel turns into the call's outcome: the item's bit total ... */
+        if (lane == 0 && old.w4 == kTilesPerSeg - 1 && (seg.flags & 2u)) {
+            item_total[seg.item] = bn; /* (tiles behind the item's last symbol hold no bits) */
+        }
+        /* ... and, when the output is too short, which tile holds the symbol whose last bit reaches the capacity edge (exactly
+         * one does) and where that tile's bits start: enc_finish_kernel looks the symbol up */
+        if (lane == 0 && bw < cap_bits && cap_bits <= bn) {
+            hufd_enc_result *r = &results[seg.item];
+            r->consumed = (u64)seg.index * HUFD_ENC_SEG_BYTES + old.w4 * kTileBytes; /* the item's symbols in front of the tile */
+            r->total_bits = bw;
+            r->ovf_bits = old.n_sym;
         }
 
-        if (old.shaped) {
-            const u64 out_cap = uniform64(items[seg.item].out_cap);
-            const u64 cap_bits = out_cap > (~0ull >> 3) ? ~0ull : out_cap * 8;
+        {
             u8 *out_ptr = d_out + uniform64(items[seg.item].out_off);
             /* the last byte: the next tile's head, or the padding when the item ends here (huffman.c:178-184) */
             {
@@ -2435,7 +2432,7 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
                 }
             }
             wave_step();
-            u64 jhi = old.last_tile ? (bn <= cap_bits ? (bn + 7) >> 3 : bn >> 3) : (bn + 7) >> 3;
+            u64 jhi = old.ends_item ? (bn <= cap_bits ? (bn + 7) >> 3 : bn >> 3) : (bn + 7) >> 3;
             jhi = jhi > out_cap ? out_cap : jhi;
             const u64 jlo = old.first_tile ? 0 : (bw + 7) >> 3;
             region_store_shifted(img, out_ptr, bw, jlo, jhi, lane);
@@ -2463,28 +2460,27 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         u32 a_raw;
         u64 b_raw, rb_raw, ib_raw;
         ask_offsets(a_raw, b_raw, rb_raw, ib_raw); /* (in the first turn: of the fresh tile, never looked at) */
-        /* the next tile's first two symbols complete this tile's last byte (a code is at least 4 bits, the byte lacks at most 7) */
-        if (fresh.shaped && !fresh.last_tile) {
-            fresh.halo_n = fresh.w4 + 1 < kTilesPerSeg ? 2u : (fresh.seg.next_len < 2 ? fresh.seg.next_len : 2u);
-        }
+        /* the first two symbols behind the tile (they complete its last byte): always asked for, from a harmless
+         * address when there are none */
         const u8 *seg_first = d_in + fresh.seg.in_off; /* (a segment holds at least one symbol) */
-        halo0 = *(fresh.halo_n > 0 ? fresh.tsrc + kTileBytes : seg_first);
-        halo1 = *(fresh.halo_n > 1 ? fresh.tsrc + kTileBytes + 1 : seg_first);
+        halo0 = *(fresh.halo_n > 0 ? fresh.tsrc + fresh.n_sym : seg_first);
+        halo1 = *(fresh.halo_n > 1 ? fresh.tsrc + fresh.n_sym + 1 : seg_first);
         /* the tile after it: its symbols are on their way while this one is packed */
         nxt = describe(t_new + stride);
-        {
-            const u8 *nsrc = (t_new + stride < n_tiles && nxt.shaped) ? nxt.tsrc : null_tile;
-#pragma unroll
-            for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
-                vn[gi] = reinterpret_cast<const uint4 *>(nsrc)[gi * kWave + lane];
-            }
-        }
+        tile_loads(nxt, vn);
 
-        /* ---- the fresh tile's bits: codes -> pairs -> quads -> octs, one wave scan per two groups */
-        if (fresh.shaped) {
+        /* ---- the fresh tile's bits: codes -> pairs -> quads -> octs, one wave scan per two groups.  A ragged tile takes
+         * the same way with the entries behind its last symbol set to nothing (a code of no bits). */
+        auto pyramid = [&](auto ragged_tag) {
+            constexpr bool RAGGED = decltype(ragged_tag)::value;
 #pragma unroll
             for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
-                const u32 wd[4] = {v[gi].x, v[gi].y, v[gi].z, v[gi].w};
+                u32 wd[4] = {v[gi].x, v[gi].y, v[gi].z, v[gi].w};
+                u32 valid = 16;
+                if (RAGGED) {
+                    valid = group_valid(fresh, gi);
+                    group_in_place(wd, valid);
+                }
                 u32 both = 0;
 #pragma unroll
                 for (u32 o = 0; o < 2; ++o) {
@@ -2496,9 +2492,14 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
 #pragma unroll
                         for (u32 m = 0; m < 2; ++m) {
                             const u32 wdv = wd[2 * o + h];
-                            const u32 ea = *reinterpret_cast<const u32 *>(mine + ((wdv >> (16 * m)) & 0xFFu) * 128u);
-                            const u32 eb = *reinterpret_cast<const u32 *>(mine + ((wdv >> (16 * m + 8)) & 0xFFu) * 128u);
-                            /* eb's length field (< 16) falls off the low end: the shift is by at least 4 */
+                            u32 ea = *reinterpret_cast<const u32 *>(mine + ((wdv >> (16 * m)) & 0xFFu) * 128u);
+                            u32 eb = *reinterpret_cast<const u32 *>(mine + ((wdv >> (16 * m + 8)) & 0xFFu) * 128u);
+                            if (RAGGED) {
+                                const u32 k = 4 * (2 * o + h) + 2 * m; /* the symbols in front of ea in its group */
+                                ea = k < valid ? ea : 0u;
+                                eb = k + 1 < valid ? eb : 0u;
+                            }
+                            /* eb's length field (< 16) falls off the low end: the shift is by at least 4 (or eb is nothing) */
                             pair[m] = (ea & 0xFFFF0000u) | (eb >> (ea & 31u));
                             plen[m] = ea + eb; /* the lengths add up in the low half; what the high half holds is never looked at */
                         }
@@ -2507,7 +2508,7 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
                     }
                     const u64 x = quad[1] >> (qlen[0] & 63u);
                     ohi[gi][o] = quad[0] | x;
-                    olo[gi][o] = quad[1] << ((64u - qlen[0]) & 63u); /* a quad is 16 .. 60 bits */
+                    olo[gi][o] = quad[1] << ((64u - qlen[0]) & 63u); /* a quad is 16 .. 60 bits (ragged: or quad[1] is nothing) */
                     both |= ((qlen[0] + qlen[1]) & 0xFFFFu) << (16 * o);
                 }
                 olen[gi] = both;
@@ -2525,15 +2526,20 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
                 at += (tot & 0xFFFFu) + (tot >> 16);
             }
             fresh.bits = uniform32(at);
+        };
+        /* (a segment that is not full has tiles without symbols: they only tell that they hold no bits) */
+        const bool whole = fresh.n_sym == kTileBytes, empty = fresh.n_sym == 0;
+        if (whole) {
+            pyramid(op_flag<false>{});
+        } else if (!empty) {
+            pyramid(op_flag<true>{});
         } else {
-            /* ragged, unaligned or behind carried bits: counted (and its arrival told) by enc_ragged_count_kernel
-             * before this kernel started, packed by enc_pack_kernel after it; a scalar read */
-            fresh.bits = tile_agg_early[fresh.t] & ~kOpTileReady;
+            fresh.bits = 0;
         }
         HUFD_STAMP_ADD(2, 1);
 
         /* tell the tiles behind the fresh one (see arrival_quiet) */
-        if (fresh.shaped && lane == 0) {
+        if (lane == 0) {
             arrival_quiet(&tile_agg[fresh.t], kOpTileReady | fresh.bits, &group_acc[(u64)(fresh.t / kOpGroupTiles) * kOpGroupStride], kOpArrive | fresh.bits);
         }
         if (have_old) {
@@ -2546,31 +2552,39 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         }
         HUFD_STAMP_ADD(2, 3);
 
-        /* ---- the fresh octs -> words of the image, highest word first */
-        if (fresh.shaped) {
-            if (lane == 0) {
-                img[0] = 0; /* the word the first unit ORs its head into */
+        /* ---- the fresh octs -> words of the image */
+        if (lane == 0) {
+            img[0] = 0; /* the word the first unit ORs its head into */
+            if (fresh.first_tile) {
+                img[-1] = fresh.carried_pattern; /* stream bits 0 .. carried - 1 of the item */
             }
+        }
+        auto oct_words = [&](u32 gi, u32 o, u32 (&wds)[NW]) -> u32 {
+            const u32 q = gq[gi] + (o ? olen[gi] & 0xFFFFu : 0u);
+            const u32 sh = q & 31u;
+            const u32 w0 = (u32)(ohi[gi][o] >> 32), w1 = (u32)ohi[gi][o], w2 = (u32)(olo[gi][o] >> 32),
+                      w3 = (u32)olo[gi][o];
+            wds[0] = w0 >> sh;
+            wds[1] = funnel(w0, w1, sh);
+            wds[2] = funnel(w1, w2, sh);
+            if (NW == 4) {
+                wds[3] = funnel(w2, 0, sh);
+            } else {
+                wds[3] = funnel(w2, w3, sh);
+                wds[NW - 1] = funnel(w3, 0, sh);
+            }
+            return q >> 5;
+        };
+        if (whole) {
+            /* highest word first: a unit's words behind its first are stored (whoever else has bits there comes later
+             * in the stream and later in this order), its first word is OR-ed in at the end */
             wave_step();
 #pragma unroll
             for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
                 u32 wds[2][NW], base[2];
 #pragma unroll
                 for (u32 o = 0; o < 2; ++o) {
-                    const u32 q = gq[gi] + (o ? olen[gi] & 0xFFFFu : 0u);
-                    const u32 sh = q & 31u;
-                    base[o] = q >> 5;
-                    const u32 w0 = (u32)(ohi[gi][o] >> 32), w1 = (u32)ohi[gi][o], w2 = (u32)(olo[gi][o] >> 32),
-                              w3 = (u32)olo[gi][o];
-                    wds[o][0] = w0 >> sh;
-                    wds[o][1] = funnel(w0, w1, sh);
-                    wds[o][2] = funnel(w1, w2, sh);
-                    if (NW == 4) {
-                        wds[o][3] = funnel(w2, 0, sh);
-                    } else {
-                        wds[o][3] = funnel(w2, w3, sh);
-                        wds[o][NW - 1] = funnel(w3, 0, sh);
-                    }
+                    base[o] = oct_words(gi, o, wds[o]);
                 }
 #pragma unroll
                 for (u32 k = NW - 1; k >= 1; --k) {
@@ -2586,6 +2600,29 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
                     wave_step();
                 }
             }
+        } else if (!empty) {
+            /* a ragged tile has units of no bits, which own no word: the image is cleared first and every unit ORs */
+            const u32 used = (fresh.bits >> 5) + NW + 2;
+            for (u32 w = lane; w < used; w += kWave) {
+                img[w] = 0;
+            }
+            wave_step();
+#pragma unroll
+            for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
+#pragma unroll
+                for (u32 o = 0; o < 2; ++o) {
+                    u32 wds[NW];
+                    const u32 base = oct_words(gi, o, wds);
+                    const u32 len = o ? olen[gi] >> 16 : olen[gi] & 0xFFFFu;
+                    if (len) {
+#pragma unroll
+                        for (u32 k = 0; k < NW; ++k) {
+                            atomicOr(&img[base + k], wds[k]);
+                        }
+                    }
+                }
+            }
+            wave_step();
         }
         HUFD_STAMP_ADD(2, 4);
         HUFD_STAMP_ADD(2, 5);
@@ -2619,66 +2656,109 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
 }
 
 /*
- * After the one pass: one thread per item turns the item's bit total and the per-segment
- * records into the outcome of the call (enc_finish_item) and lists the segments the
- * per-symbol packer has to visit.  The first segment with a symbol without a code and the
- * segment holding the capacity edge are found by bisection (both records are monotone).
+ * After the one pass: one thread per item turns the item's bit total into the outcome of the call
+ * (enc_finish_item; every symbol has a code here).  For a call that ran out of room the tile holding
+ * the capacity edge has left a note in the item's result record -- the item's symbols in front of
+ * the tile (consumed), the stream bit its codes start at (total_bits), its symbols (ovf_bits) -- and
+ * a wave of this workgroup reads that tile again to find the symbol whose last bit reaches the edge:
+ * `consumed` counts up to and with it, the overflow is what of its code did not fit
+ * (source/huffman.c:88-98).
  */
+constexpr u32 kFinishItems = 64; /* per workgroup of 256: a wave of it per 16 items that may each need a tile read again */
+constexpr u32 kFinishLdsBytes = 256 * (8 + 8 + 4 + 4 + 4) + 16;
 __global__ __launch_bounds__(256) void enc_finish_kernel(
+    hufd_tables tb,
     const hufd_enc_item *items,
     u32 n_items,
-    const u32 *seg_bits,
-    const u32 *seg_unk,
-    const u64 *seg_bitoff,
-    const u8 *seg_unk_seen,
     const u64 *item_total,
+    const u8 *d_in,
     u32 *careful_list,
     u32 *careful_count,
     hufd_enc_item_state *states,
     hufd_enc_result *results) {
 
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_items) {
-        return;
+    u64 *note_first = reinterpret_cast<u64 *>(dyn_lds), *note_bit = note_first + 256; /* kFinishLdsBytes */
+    u32 *code_len = reinterpret_cast<u32 *>(note_bit + 256), *noted = code_len + 256, *note_syms = noted + 256;
+    u32 &n_noted = note_syms[256];
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const u32 i = blockIdx.x * kFinishItems + tid;
+    if (tid == 0) {
+        n_noted = 0;
     }
-    const hufd_enc_item it = items[i];
-    if (it.tiny) {
-        return; /* enc_tiny's */
+    code_len[tid] = (u32)(tb.enc_table[tid] >> 32);
+    __syncthreads();
+    if (tid < kFinishItems && i < n_items && !items[i].tiny /* enc_tiny's */) {
+        const hufd_enc_item it = items[i];
+        const u64 total = it.n_segs ? item_total[i] : it.ovf_bits;
+        const u64 cap_bits = it.out_cap > (~0ull >> 3) ? ~0ull : it.out_cap * 8;
+        const hufd_enc_result note = results[i];
+        hufd_enc_result rs;
+        /* (no segment is named as the edge's: nothing is listed for enc_pack_kernel) */
+        enc_finish_item(it, total, HUFD_NONE32, 0, 0, 0, HUFD_NONE32, careful_list, careful_count, &states[i], &rs);
+        results[i] = rs;
+        if (rs.status == HUFD_ENC_SHORT && it.ovf_bits < cap_bits) {
+            const u32 k = atomicAdd(&n_noted, 1u);
+            noted[k] = i;
+            note_first[k] = note.consumed;
+            note_bit[k] = note.total_bits;
+            note_syms[k] = note.ovf_bits;
+        }
     }
-    const u64 total = it.n_segs ? item_total[i] : it.ovf_bits;
-    const u64 cap_bits = it.out_cap > (~0ull >> 3) ? ~0ull : it.out_cap * 8;
-    u32 unk_seg = HUFD_NONE32, edge_seg = HUFD_NONE32;
-    if (it.n_segs && seg_unk_seen[it.first_seg + it.n_segs - 1]) {
-        u32 lo = 0, hi = it.n_segs - 1; /* first k with seen[k] */
-        while (lo < hi) {
-            const u32 mid = (lo + hi) / 2;
-            if (seg_unk_seen[it.first_seg + mid]) {
-                hi = mid;
-            } else {
-                lo = mid + 1;
+    __syncthreads();
+    for (u32 k = wave; k < n_noted; k += blockDim.x / kWave) {
+        const hufd_enc_item it = items[noted[k]];
+        const u8 *src = d_in + it.in_off + note_first[k];
+        const u32 n_sym = note_syms[k];
+        const u32 target = (u32)(it.out_cap * 8 - note_bit[k]); /* the edge, in bits from the tile's first code: 1 .. the tile's bits */
+        /* lane l counts symbols 64 l .. 64 l + 63 (four loads, all on their way before the first look-up), the lane that
+         * holds the edge walks them once more */
+        const u32 from = lane * 64 < n_sym ? lane * 64 : n_sym, to = from + 64 < n_sym ? from + 64 : n_sym;
+        u32 wd[16];
+        if (to - from == 64) {
+#pragma unroll
+            for (u32 g = 0; g < 4; ++g) {
+                const unaligned_uint4 q = *reinterpret_cast<const unaligned_uint4 *>(src + from + 16 * g);
+                wd[4 * g] = q.x, wd[4 * g + 1] = q.y, wd[4 * g + 2] = q.z, wd[4 * g + 3] = q.w;
+            }
+        } else {
+            /* the tile's last symbols: one by one (nothing behind the item is read) */
+#pragma unroll
+            for (u32 g = 0; g < 16; ++g) {
+                wd[g] = 0;
+            }
+            for (u32 j = from; j < to; ++j) {
+                const u32 at = j - from;
+                const u32 v = (u32)src[j] << (8 * (at & 3u));
+#pragma unroll
+                for (u32 g = 0; g < 16; ++g) {
+                    wd[g] |= g == (at >> 2) ? v : 0u;
+                }
             }
         }
-        unk_seg = it.first_seg + lo;
-    }
-    if (it.n_segs) {
-        /* first k whose end reaches the edge; it holds the edge if its start is below it */
-        u32 lo = 0, hi = it.n_segs;
-        while (lo < hi) {
-            const u32 mid = (lo + hi) / 2;
-            if (seg_bitoff[it.first_seg + mid] + seg_bits[it.first_seg + mid] >= cap_bits) {
-                hi = mid;
-            } else {
-                lo = mid + 1;
+        const u32 mine_n = to - from;
+        u32 sum = 0;
+#pragma unroll
+        for (u32 b = 0; b < 64; ++b) {
+            sum += b < mine_n ? code_len[(wd[b >> 2] >> (8 * (b & 3u))) & 0xFFu] : 0u;
+        }
+        const u32 incl = wave_inclusive_sum_dpp(sum, lane);
+        u32 rel = incl - sum;
+        if (rel < target && target <= incl) {
+#pragma unroll
+            for (u32 b = 0; b < 64; ++b) {
+                const u32 sym = (wd[b >> 2] >> (8 * (b & 3u))) & 0xFFu;
+                const u32 len = b < mine_n ? code_len[sym] : 0u;
+                if (rel < target && target <= rel + len) {
+                    const u32 left = rel + len - target;
+                    hufd_enc_result *r = &results[noted[k]];
+                    r->consumed = note_first[k] + from + b + 1;
+                    r->ovf_bits = left;
+                    r->ovf_pattern = left ? ((u32)tb.enc_table[sym] & ((1u << left) - 1u)) : 0u;
+                }
+                rel += len;
             }
         }
-        if (lo < it.n_segs && seg_bitoff[it.first_seg + lo] < cap_bits) {
-            edge_seg = it.first_seg + lo;
-        }
     }
-    const u32 ui = unk_seg != HUFD_NONE32 ? seg_unk[unk_seg] : 0;
-    const u32 ub = unk_seg != HUFD_NONE32 ? seg_bits[unk_seg] : 0;
-    const u64 uo = unk_seg != HUFD_NONE32 ? seg_bitoff[unk_seg] : 0;
-    enc_finish_item(it, total, unk_seg, ui, uo, ub, edge_seg, careful_list, careful_count, &states[i], &results[i]);
 }
 
 /* ------------------------------------------------------------------ decode: shared pieces */
@@ -5826,8 +5906,7 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
         return 0;
     }
     if (a->n_segs && !a->length_only && a->single_pass && hufk_encode_one_pass_applies(&a->tables) && a->zero_block) {
-        /* one pass: count + offsets + pack in one kernel, then the per-item outcome, then the listed segments */
-        const uint32_t img_words = hufk_enc_image_words(a->tables.max_bits);
+        /* one pass: count + offsets + pack in one kernel, then the per-item outcome */
         const onepass_layout l = onepass_layout_of(a->n_segs, a->n_items);
         uint8_t *z = (uint8_t *)a->zero_block;
         (void)hipMemsetAsync(a->zero_block, 0, l.bytes, st);
@@ -5835,18 +5914,12 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
         const uint32_t region = pack_region_bytes(a->tables.max_bits);
         const uint32_t lds = kPackTabBytes + kPackWaves * region;
         const uint32_t work = (a->n_segs * kTilesPerSeg + kPackWaves - 1) / kPackWaves;
-        if (a->maybe_unshaped || ((uintptr_t)a->d_in & 15u) != 0) {
-            hipLaunchKernelGGL(
-                enc_ragged_count_kernel, dim3(a->n_segs), dim3(256), 0, st, a->tables, a->items, a->segs,
-                (const u8 *)a->d_in, (u32 *)(z + l.tile_agg), (u64 *)(z + l.group_acc));
-        }
 #define HUFK_LAUNCH_ONEPASS(NWV)                                                                                      \
     hipLaunchKernelGGL(                                                                                                \
         enc_onepass_kernel<NWV>, dim3(persistent_grid(enc_onepass_kernel<NWV>, kPackThreads, lds, work)),              \
         dim3(kPackThreads), lds, st, a->tables, a->items, a->segs, (const u8 *)a->d_in, (u8 *)a->d_out, region,        \
         a->n_segs, (u32 *)(z + l.ctl), (u32 *)(z + l.tile_agg), (u64 *)(z + l.group_acc),                              \
-        (u64 *)(z + l.round_base), (u64 *)(z + l.item_base), a->seg_bits, a->seg_unk, a->seg_bitoff, a->seg_unk_seen,  \
-        a->item_total, a->careful_list, (const u8 *)(z + l.null_tile), (const u32 *)(z + l.tile_agg))
+        (u64 *)(z + l.round_base), (u64 *)(z + l.item_base), a->item_total, a->results, (const u8 *)(z + l.null_tile))
         if (a->tables.max_bits <= 12) {
             HUFK_LAUNCH_ONEPASS(4);
         } else {
@@ -5855,9 +5928,8 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
 #undef HUFK_LAUNCH_ONEPASS
         stage_mark(a->stage_events, 1, st);
         hipLaunchKernelGGL(
-            enc_finish_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, a->seg_bits,
-            a->seg_unk, a->seg_bitoff, a->seg_unk_seen, a->item_total, a->careful_list, a->careful_count, a->states,
-            a->results);
+            enc_finish_kernel, dim3((a->n_items + kFinishItems - 1) / kFinishItems), dim3(256), kFinishLdsBytes, st, a->tables, a->items, a->n_items,
+            a->item_total, (const u8 *)a->d_in, a->careful_list, a->careful_count, a->states, a->results);
         stage_mark(a->stage_events, 2, st);
         if (a->n_tiny) {
             hipLaunchKernelGGL(
@@ -5865,11 +5937,7 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
             a->tables, a->items, a->tiny_items, a->n_tiny, (const u8 *)a->d_in, (u8 *)a->d_out, a->results,
             a->length_only);
         }
-        const uint32_t most = 2 * a->n_items < 1024 ? 2 * a->n_items : 1024;
-        hipLaunchKernelGGL(
-            enc_pack_kernel, dim3(most), dim3(HUFD_ENC_THREADS), enc_pack_lds_bytes(img_words), st, a->tables, a->items,
-            a->states, a->segs, a->seg_bits, a->seg_bitoff, (const u8 *)a->d_in, (u8 *)a->d_out, a->results,
-            img_words, a->n_segs, (const u32 *)a->careful_list, (const u32 *)a->careful_count);
+        /* (nothing is left for the per-symbol packer: every segment was packed by a wave, the capacity edge found by one) */
         stage_mark(a->stage_events, 3, st);
         return (int)hipGetLastError();
     }

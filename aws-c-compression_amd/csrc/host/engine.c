@@ -328,8 +328,10 @@ static bool enc_item_is_tiny(const struct aws_huffman_amd_encode_item *it, uint6
 }
 
 /* the longest item a lone thread takes in this plan: see HUFD_ENC_TINY_PER_BYTE */
-static uint64_t enc_tiny_limit(const struct aws_huffman_amd_encode_item *items, size_t n_items) {
-    static const uint64_t classes[2] = {HUFD_TINY_MANY_BYTES, HUFD_ENC_TINY_BYTES};
+static uint64_t enc_tiny_limit(const struct aws_huffman_amd_engine *eng, const struct aws_huffman_amd_encode_item *items, size_t n_items) {
+    /* (the one-pass kernel packs ragged tiles at full speed: measured, a wave beats a thread from about 1 KiB an item) */
+    const uint64_t classes[2] = {
+        aws_huffman_amd_engine_encodes_in_one_pass(eng) ? HUFD_ENC_TINY_WAVE_BYTES : HUFD_TINY_MANY_BYTES, HUFD_ENC_TINY_BYTES};
     for (int c = 0; c < 2; ++c) {
         uint64_t count = 0, longest = 0;
         for (size_t i = 0; i < n_items; ++i) {
@@ -359,7 +361,7 @@ static int enc_plan_fill(
     size_t n_items) {
 
     struct aws_huffman_amd_engine *eng = p->engine;
-    const uint64_t tiny_limit = enc_tiny_limit(items, n_items);
+    const uint64_t tiny_limit = enc_tiny_limit(eng, items, n_items);
     uint64_t n_segs = 0, n_large = 0, n_tiny = 0;
     for (size_t i = 0; i < n_items; ++i) {
         if (items[i].overflow_in.num_bits > 32) {
@@ -386,7 +388,6 @@ static int enc_plan_fill(
         return aws_raise_error(AWS_ERROR_OOM);
     }
     uint32_t seg = 0, large = 0, tiny = 0;
-    bool maybe_unshaped = false;
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_encode_item *src = &items[i];
         struct hufd_enc_item *dst = &h_items[i];
@@ -417,9 +418,6 @@ static int enc_plan_fill(
             sd->flags = (k == 0 ? 1u : 0u) | (k + 1 == segs ? 2u : 0u);
             sd->next_len = (uint32_t)(after < HUFD_ENC_SEG_BYTES ? after : HUFD_ENC_SEG_BYTES);
             sd->reserved = 0;
-            if (sd->len != HUFD_ENC_SEG_BYTES || (sd->in_off & 15u) != 0 || (k == 0 && ob)) {
-                maybe_unshaped = true;
-            }
         }
         if (segs > HUFD_SCAN_SMALL_MAX) {
             h_large[large++] = (uint32_t)i;
@@ -480,7 +478,6 @@ static int enc_plan_fill(
     p->n_segs = (uint32_t)n_segs;
     p->n_large = (uint32_t)n_large;
     p->n_tiny = (uint32_t)n_tiny;
-    p->maybe_unshaped = maybe_unshaped;
     return AWS_OP_SUCCESS;
 }
 
@@ -557,7 +554,6 @@ int aws_huffman_amd_encode_plan_launch_staged(
     a.seg_unk_seen = p->d_unk_seen;
     a.item_total = p->d_item_total;
     a.single_pass = p->engine->single_pass && !p->look_back_timed_out;
-    a.maybe_unshaped = p->maybe_unshaped;
     p->last_input = device_input;
     p->last_output = device_output;
     p->last_single_pass = a.single_pass && p->n_segs && !length_only && hufk_encode_one_pass_applies(&p->engine->tables);

@@ -72,7 +72,6 @@ struct aws_huffman_amd_encode_plan {
     void *last_output;
     bool last_single_pass;
     bool look_back_timed_out;
-    bool maybe_unshaped; /* some segment is ragged, starts with carried bits or lies at an offset that is no multiple of 16 */
 };
 
 struct aws_huffman_amd_decode_plan {

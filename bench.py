@@ -239,7 +239,7 @@ def load_traffic():
 
 def stage_names(lib, eng):
     one_pass = bool(lib.aws_huffman_amd_engine_encodes_in_one_pass(eng.h))
-    names_e = ["enc_onepass", "enc_finish", "enc_pack_listed"] if one_pass else ["enc_count", "enc_scan", "enc_pack"]
+    names_e = ["enc_onepass", "enc_finish", "enc_tiny"] if one_pass else ["enc_count", "enc_scan", "enc_pack"]
     return names_e, ["dec_sync", "dec_scan", "dec_emit"]
 
 

@@ -26,9 +26,9 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 GROUPS = [  # bench kernel name <- substrings of the device kernel names it covers
-    ("enc_onepass", ["enc_onepass_kernel", "enc_ragged_count_kernel"]),
+    ("enc_onepass", ["enc_onepass_kernel"]),
     ("enc_finish", ["enc_finish_kernel"]),
-    ("enc_pack_listed", ["enc_tiny_kernel"]),  # (+ enc_pack_kernel when the one-pass road is taken: see group_of)
+    ("enc_tiny", ["enc_tiny_kernel"]),
     ("enc_count", ["enc_count_kernel"]),
     ("enc_scan", ["enc_scan_small_kernel", "enc_scan_large_kernel"]),
     ("enc_pack", ["enc_pack_wave_kernel", "enc_pack_stream_kernel", "enc_pack_kernel"]),
@@ -43,8 +43,6 @@ ONE_PASS = False  # set by counter_sums: the profile holds enc_onepass_kernel di
 
 
 def group_of(kernel_name):
-    if ONE_PASS and "enc_pack_kernel" in kernel_name:
-        return "enc_pack_listed"  # the segments the one-pass kernel leaves to the per-symbol packer
     for g, subs in GROUPS:
         if any(s in kernel_name for s in subs):
             return g
