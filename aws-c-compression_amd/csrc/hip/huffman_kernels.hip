@@ -3548,13 +3548,14 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, TAIL ? (LB <= 10 ? 6 : 4) : 8) void
     bool ok = !active || (one && settled);
     HUFD_STAMP(0, 2);
 
-    /* R */
+    /* R (not for a wave behind the stream's whole lanes: it would walk zeros for as long as the others walk codes) */
     u32 state = rw.state_at(meet_bit, 0);
     u32 cp_state[kQuarters - 1] = {0, 0, 0};
     bool dead = false;
+    const bool wave_on = !TAIL || (lane & ~(kWave - 1)) < n_full;
 #pragma unroll
     for (u32 r = 1; r < kSubWords; ++r) {
-        if (r >= meet_row) {
+        if (r >= meet_row && wave_on) {
             if (r % (kSubWords / kQuarters) == 0) {
                 cp_state[r / (kSubWords / kQuarters) - 1] = state;
             }
@@ -5051,8 +5052,13 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
     emit_shared<LB> &sh = *reinterpret_cast<emit_shared<LB> *>(dyn_lds);
     const u32 ns = tb.n_states;
     const u32 t = threadIdx.x;
-    const u32 q = t / kEmitHalf;                 /* my quarter of ... */
-    const u32 lanes[kEmitChains] = {t % kEmitHalf, t % kEmitHalf + kEmitHalf}; /* ... these two sub-chunks */
+    /* my quarter of two sub-chunks.  In a chunk that holds the end of a stream only the first lanes have data: there a
+     * thread takes two NEIGHBOURING sub-chunks and the threads are numbered sub-chunks first, so that the idle ones fill
+     * whole waves, which then skip the walk (the kernel is bound by instruction issue: an idle wave's slots go to the
+     * other workgroups of the CU) */
+    const u32 q = TAIL ? t % kQuarters : t / kEmitHalf;
+    const u32 lanes[kEmitChains] = {TAIL ? 2 * (t / kQuarters) : t % kEmitHalf,
+                                    TAIL ? 2 * (t / kQuarters) + 1 : t % kEmitHalf + kEmitHalf};
     const u32 c = TAIL ? tail_chunks[blockIdx.x] : blockIdx.x;
     /* the table entries this thread will put into LDS: asked for first, they depend on nothing */
     constexpr u32 kLutPerThread = ((1u << LB) + kEmitFastThreads - 1) / kEmitFastThreads;
@@ -5145,7 +5151,16 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
     /* where every sub-chunk's symbols go: lane 0's count follows from the chunk's total */
     u32 incl[kEmitChains] = {0, 0};
     const u32 wl = t & (kWave - 1), half_wave = (t / kWave) & (kEmitHalf / kWave - 1);
-    if (q == 0) {
+    u32 own_cnt = 0; /* TAIL: thread t < 256 does this for sub-chunk t, whoever walks it */
+    if (TAIL) {
+        if (t < HUFD_DEC_LANES) {
+            own_cnt = lane_count[(u64)c * HUFD_DEC_LANES + t];
+            incl[0] = wave_inclusive_sum(t ? own_cnt : 0u, wl);
+            if (wl == kWave - 1) {
+                sh.wave_tot[t / kWave] = incl[0];
+            }
+        }
+    } else if (q == 0) {
 #pragma unroll
         for (u32 ch = 0; ch < kEmitChains; ++ch) {
             incl[ch] = wave_inclusive_sum(lanes[ch] ? cnt[ch] : 0u, wl);
@@ -5161,7 +5176,16 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
         rest += sh.wave_tot[wv];
     }
     const u32 first_count = chunk_symbols - rest; /* sub-chunk 0, entered in state s0 */
-    if (q == 0) {
+    if (TAIL) {
+        if (t < HUFD_DEC_LANES) {
+            u32 before = 0;
+#pragma unroll
+            for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
+                before += wv < t / kWave ? sh.wave_tot[wv] : 0u;
+            }
+            sh.lane_base[t] = t ? first_count + before + incl[0] - own_cnt : 0u;
+        }
+    } else if (q == 0) {
 #pragma unroll
         for (u32 ch = 0; ch < kEmitChains; ++ch) {
             u32 before = 0;
@@ -5206,6 +5230,8 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
     /* (the table sits at a multiple of its size: an entry's address is (window & mask) | table, one instruction) */
     const u32 table = lds_offset_of(sh.wlut);
     const u32 sure = SURE ? SURE : rw.sure;
+    const bool wave_idle = TAIL && __all(idle[0] && idle[1]);
+    if (!wave_idle) {
 #pragma unroll
     for (u32 r = 0; r < kRows; ++r) {
         u64 pair[kEmitChains];
@@ -5238,6 +5264,7 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
             st[ch] = idle[ch] ? rw.state_at(0, 0) : st[ch];
             dst[ch] = idle[ch] ? dump_at : dst[ch];
         }
+    }
     }
     if (extend) {
         /* rare: sub-chunk 0 on through the second quarter, words straight from memory */
