@@ -3753,34 +3753,46 @@ __device__ __forceinline__ u32 lean_row(u32 state, u32 hi, u32 lo, u32 table, co
  * different is what a step of a walk costs: the number of certain steps a row is known to the compiler (no loop
  * around them), a table entry's address is one instruction (lean_row), the words are byte-swapped once.
  */
-template <u32 LB, u32 SURE>
+template <u32 LB, u32 SURE, bool TAIL = false> /* TAIL: the chunks listed in tail_chunks (a stream ends in them): see dec_sync_fast */
 __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     hufd_tables tb,
     const hufd_dec_item *items,
     const u32 *chunk_item,
+    const u32 *tail_chunks,
     const u8 *d_in,
     u16 *fn_tab,
     u16 *cp_tab,
     u32 *chunk_fn,
     u16 *lane_count,
     u8 *chunk_regular,
+    u32 *tail_entry, /* [chunk] TAIL: the state in which the last whole lane leaves (dec_sync_tail picks it up) */
     u32 *slow_list,
     u32 *slow_count) {
 
     lean_shared<LB> &sh = *reinterpret_cast<lean_shared<LB> *>(dyn_lds);
     const u32 ns = tb.n_states;
     const u32 lane = threadIdx.x;
-    const u32 c = blockIdx.x;
+    const u32 c = TAIL ? tail_chunks[blockIdx.x] : blockIdx.x;
     const hufd_dec_item it = items[chunk_item[c]];
     const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
     const u64 valid = it.in_len > chunk_off ? it.in_len - chunk_off : 0;
     const u8 *src = d_in + it.in_off + chunk_off;
-    if (valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
-        return; /* holds the end of its stream: dec_sync_fast<LB, true>'s */
+    if (!TAIL && valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
+        return; /* holds the end of its stream: the other instantiation's */
+    }
+    /* the lanes whose sub-chunk and the 8 bytes behind it lie inside the stream (dec_sync_fast) */
+    const u32 n_full = !TAIL ? HUFD_DEC_LANES : (valid >= 8u ? (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES) : 0u);
+    const bool active = !TAIL || lane < n_full;
+    if (TAIL && n_full == 0 && tb.lut_bits <= HUFD_DEC_MAX_LUT_BITS) {
+        /* fewer than 136 bytes: no lane is whole, and the whole chunk is one thread's work in dec_sync_tail / dec_emit_tail */
+        if (lane == 0) {
+            chunk_regular[c] = 3;
+        }
+        return;
     }
     const row_walk rw(LB, tb.max_bits);
     const u32 table = lds_offset_of(sh.wlut);
-    const bool eligible = ((uintptr_t)src & 15u) == 0 && tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS &&
+    const bool eligible = n_full >= 1 && ((uintptr_t)src & 15u) == 0 && tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS &&
                           rw.sure == SURE && (table & ((4u << LB) - 1u)) == 0;
     if (!eligible) {
         if (lane == 0) {
@@ -3789,10 +3801,18 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         }
         return;
     }
+    u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
+    /* a wave wholly behind the stream's whole lanes walks nothing: it only keeps the barriers company (the kernel is
+     * bound by instruction issue: what it does not issue, the other workgroups of the CU do).  Leaving the kernel
+     * instead was tried: the barriers then took ~20 times as long -- 16.6 ms for config 4's 65 536 chunks. */
+    const bool wave_off = TAIL && lane >= kWave && (lane & ~(kWave - 1)) >= n_full;
 
     u32 w[kFastRows];
     {
-        const uint4 *line = reinterpret_cast<const uint4 *>(src + (u64)lane * HUFD_DEC_SUB_BYTES);
+        /* (TAIL: a lane behind the stream's whole lanes reads sub-chunk 0 again -- no branch, no second set of
+         * registers for "nothing", and words that are codes; what it makes of them is never looked at) */
+        const u32 mine = active ? lane : 0u;
+        const uint4 *line = reinterpret_cast<const uint4 *>(src + (u64)mine * HUFD_DEC_SUB_BYTES);
 #pragma unroll
         for (u32 q = 0; q < kSubWords / 4; ++q) {
             const uint4 v = line[q];
@@ -3801,7 +3821,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
             w[4 * q + 2] = __builtin_bswap32(v.z);
             w[4 * q + 3] = __builtin_bswap32(v.w);
         }
-        w[kSubWords] = __builtin_bswap32(*reinterpret_cast<const u32 *>(src + (u64)(lane + 1) * HUFD_DEC_SUB_BYTES));
+        w[kSubWords] = __builtin_bswap32(*reinterpret_cast<const u32 *>(src + (u64)(mine + 1) * HUFD_DEC_SUB_BYTES));
     }
     for (u32 i = lane; i < (1u << LB); i += HUFD_DEC_LANES) {
         const u32 len = tb.dec_lut[i >> (LB - tb.lut_bits)] & 0xFFu;
@@ -3814,11 +3834,15 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         for (u32 r = 0; r <= kFastMaxMeet; ++r) {
             sh.sub0[r] = w[r];
         }
+#pragma unroll
+        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
+            sh.wave_sum[wv] = 0; /* (TAIL: of the waves that have left) */
+        }
     }
     __syncthreads();
 
     /* U: all entry states as one mask of heads per row, until every lane of the wave is down to one */
-    u64 heads = (1ull << ns) - 1ull;
+    u64 heads = active ? (1ull << ns) - 1ull : 0ull;
     u32 meet_row = 0; /* the same for the whole wave */
     bool one = false, settled = false;
 #pragma unroll
@@ -3831,7 +3855,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         }
     }
     const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
-    bool ok = one && settled;
+    bool ok = !active || (one && settled);
 
     /* R: the one walk from the meeting bit to the end of the sub-chunk */
     u32 state = rw.state_at(meet_bit, 0);
@@ -3839,18 +3863,21 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     bool dead = false;
 #pragma unroll
     for (u32 r = 1; r < kSubWords; ++r) {
-        if (r >= meet_row) {
+        if (r >= meet_row && !wave_off) {
             if (r % (kSubWords / kQuarters) == 0) {
                 cp_state[r / (kSubWords / kQuarters) - 1] = state;
             }
             state = lean_row<SURE>(state, w[r], w[r + 1], table, rw);
             dead = dead || rw.died(state);
-            state += 32u; /* (a walk that has died drifts, in bounds: the chunk is not regular then and nothing of this is kept) */
+            /* (a walk that has died drifts: the chunk is not regular then and nothing of this is kept.  TAIL: the lanes
+             * behind the stream walk zeros, which need not be a code -- drifting, their state would wrap and the row
+             * loop run for thousands of steps: they are put back on a row start) */
+            state = TAIL ? rw.next_row(state, dead) : state + 32u;
         }
     }
     const u32 ref_count = state >> 16; /* symbols from the meeting bit to the end of the sub-chunk */
     const u32 ref_exit = rw.offset_of(state);
-    ok = ok && !dead && ref_exit < ns;
+    ok = ok && (!active || (!dead && ref_exit < ns));
     sh.exit_state[lane] = ref_exit;
     __syncthreads();
 
@@ -3870,12 +3897,12 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
                 }
                 st = lean_row<SURE>(st, w[r], w[r + 1], table, rw);
                 dd = dd || rw.died(st);
-                st += 32u;
+                st = TAIL ? rw.next_row(st, dd) : st + 32u;
             }
         }
         const bool reached = !dd && rw.offset_of(st) == meet_bit;
-        ok = ok && (lane == 0 || reached);
-        count = (st >> 16) + ref_count; /* symbols of the true path that start in my sub-chunk (lanes >= 1) */
+        ok = ok && (lane == 0 || !active || reached);
+        count = active ? (st >> 16) + ref_count : 0u; /* symbols of the true path that start in my sub-chunk (lanes >= 1) */
     }
 
     /* H: sub-chunk 0 from every entry state the chunk may be entered in (threads 0 .. ns-1), step by step: the count
@@ -3920,7 +3947,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
 
     /* the tables dec_scan and dec_emit read (dec_sync_fast's) */
     u16 *fn_out = fn_tab + (u64)c * ns * HUFD_DEC_LANES;
-    u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
+    if (active) {
 #pragma unroll
     for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
         /* a checkpoint in front of the meeting row is not on the one walk: the first one is then taken from the head
@@ -3937,8 +3964,20 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     }
     lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)(lane ? count : ref_count);
     cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((lane ? 1u << entry : (u32)cand_alive) | (ref_exit << 12));
+    } else {
+        /* (TAIL) behind the whole lanes, in a wave that has some: as for the waves that left */
+#pragma unroll
+        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+            cp[qq * HUFD_DEC_LANES] = 0;
+        }
+        lane_count[(u64)c * HUFD_DEC_LANES + lane] = 0;
+        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(kExitStop << 12);
+    }
+    if (TAIL && lane + 1 == n_full) {
+        tail_entry[c] = ref_exit;
+    }
     if (lane == 0) {
-        chunk_regular[c] = 1;
+        chunk_regular[c] = TAIL ? 2 : 1;
     }
     if (lane < ns) {
         u32 rest = 0;
@@ -3950,8 +3989,9 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         const u32 last_exit = sh.exit_state[HUFD_DEC_LANES - 1];
         fn_out[(u64)lane * HUFD_DEC_LANES] =
             cand_reached ? fn_pack(false, first_exit, cand_count & 0x7FFu) : fn_pack(true, 0, cand_dead);
+        /* (TAIL: symbols of the whole lanes only, and no exit yet: dec_sync_tail adds the stream's last symbols and how it ends) */
         chunk_fn[(u64)c * ns + lane] =
-            cand_reached ? wide_pack(false, last_exit, cand_count + rest) : wide_pack(true, 0, cand_dead);
+            cand_reached ? wide_pack(false, TAIL ? 0u : last_exit, cand_count + rest) : wide_pack(true, 0, cand_dead);
     }
 }
 
@@ -6112,11 +6152,21 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         const uint32_t sure = row_walk(a->tables.lut_bits <= 10 ? 10u : 12u, a->tables.max_bits).sure;
         bool lean = false;
 #define HUFK_LAUNCH_SYNC_LEAN(LBV, SUREV)                                                                               \
-    hipLaunchKernelGGL(                                                                                                \
-        (dec_sync_lean_kernel<LBV, SUREV>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(lean_shared<LBV>), \
-        st, a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count,  \
-        a->chunk_regular, a->slow_list, a->slow_count)
-        if (some_inside && !a->old_sync && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS) {
+    if (some_inside) {                                                                                                 \
+        hipLaunchKernelGGL(                                                                                            \
+            (dec_sync_lean_kernel<LBV, SUREV, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES),                         \
+            (uint32_t)sizeof(lean_shared<LBV>), st, a->tables, a->items, a->chunk_item, a->tail_chunks,                 \
+            (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
+            a->slow_list, a->slow_count);                                                                              \
+    }                                                                                                                  \
+    if (a->n_tail) {                                                                                                   \
+        hipLaunchKernelGGL(                                                                                            \
+            (dec_sync_lean_kernel<LBV, SUREV, true>), dim3(a->n_tail), dim3(HUFD_DEC_LANES),                            \
+            (uint32_t)sizeof(lean_shared<LBV>), st, a->tables, a->items, a->chunk_item, a->tail_chunks,                 \
+            (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
+            a->slow_list, a->slow_count);                                                                              \
+    }
+        if (!a->old_sync && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS) {
             lean = true;
             if (a->tables.lut_bits <= 10) {
                 switch (sure) {
@@ -6141,7 +6191,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
                 (dec_sync_fast_kernel<10, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<10>),
                 st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
                 a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry, a->slow_list, a->slow_count);
-            if (a->n_tail) {
+            if (a->n_tail && !lean) {
                 hipLaunchKernelGGL(
                     (dec_sync_fast_kernel<10, true>), dim3(a->n_tail), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<10>),
                     st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
@@ -6153,7 +6203,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
                 (dec_sync_fast_kernel<12, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<12>),
                 st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
                 a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry, a->slow_list, a->slow_count);
-            if (a->n_tail) {
+            if (a->n_tail && !lean) {
                 hipLaunchKernelGGL(
                     (dec_sync_fast_kernel<12, true>), dim3(a->n_tail), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<12>),
                     st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
