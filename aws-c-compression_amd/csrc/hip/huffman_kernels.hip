@@ -3802,10 +3802,18 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         return;
     }
     u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
-    /* a wave wholly behind the stream's whole lanes walks nothing: it only keeps the barriers company (the kernel is
-     * bound by instruction issue: what it does not issue, the other workgroups of the CU do).  Leaving the kernel
-     * instead was tried: the barriers then took ~20 times as long -- 16.6 ms for config 4's 65 536 chunks. */
-    const bool wave_off = TAIL && lane >= kWave && (lane & ~(kWave - 1)) >= n_full;
+    if (TAIL && lane >= kWave && (lane & ~(kWave - 1)) >= n_full) {
+        /* a wave wholly behind the stream's whole lanes: never reached, as far as this kernel knows (dec_sync_tail follows
+         * the true path through the one or two sub-chunks the stream ends in and rewrites their records).  It leaves at
+         * once -- the barriers below count the waves that are still there -- and its slots go to another workgroup. */
+#pragma unroll
+        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+            cp[qq * HUFD_DEC_LANES] = 0;
+        }
+        lane_count[(u64)c * HUFD_DEC_LANES + lane] = 0;
+        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(kExitStop << 12);
+        return;
+    }
 
     u32 w[kFastRows];
     {
@@ -3823,7 +3831,9 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         }
         w[kSubWords] = __builtin_bswap32(*reinterpret_cast<const u32 *>(src + (u64)(mine + 1) * HUFD_DEC_SUB_BYTES));
     }
-    for (u32 i = lane; i < (1u << LB); i += HUFD_DEC_LANES) {
+    /* (the threads that are still there: wave 0 and the waves with whole lanes) */
+    const u32 live = !TAIL ? HUFD_DEC_LANES : (n_full + kWave - 1) / kWave * kWave;
+    for (u32 i = lane; i < (1u << LB); i += live) {
         const u32 len = tb.dec_lut[i >> (LB - tb.lut_bits)] & 0xFFu;
         sh.wlut[i] = 0x10000u - (len ? len : kWalkDeadLen);
         sh.hops[i] = (u16)(len ? 1u << len : 0u);
@@ -3863,7 +3873,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     bool dead = false;
 #pragma unroll
     for (u32 r = 1; r < kSubWords; ++r) {
-        if (r >= meet_row && !wave_off) {
+        if (r >= meet_row) {
             if (r % (kSubWords / kQuarters) == 0) {
                 cp_state[r / (kSubWords / kQuarters) - 1] = state;
             }
@@ -6285,7 +6295,13 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
                 }
             }
             if (a->n_tail) {
-                HUFK_LAUNCH_EMIT_FAST(10, true, 0, a->n_tail);
+                switch (emit_sure) {
+                    case 2: HUFK_LAUNCH_EMIT_FAST(10, true, 2, a->n_tail); break;
+                    case 3: HUFK_LAUNCH_EMIT_FAST(10, true, 3, a->n_tail); break;
+                    case 4: HUFK_LAUNCH_EMIT_FAST(10, true, 4, a->n_tail); break;
+                    case 5: HUFK_LAUNCH_EMIT_FAST(10, true, 5, a->n_tail); break;
+                    default: HUFK_LAUNCH_EMIT_FAST(10, true, 0, a->n_tail); break;
+                }
             }
         } else {
             if (some_inside) {
@@ -6296,7 +6312,11 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
                 }
             }
             if (a->n_tail) {
-                HUFK_LAUNCH_EMIT_FAST(12, true, 0, a->n_tail);
+                switch (emit_sure) {
+                    case 2: HUFK_LAUNCH_EMIT_FAST(12, true, 2, a->n_tail); break;
+                    case 3: HUFK_LAUNCH_EMIT_FAST(12, true, 3, a->n_tail); break;
+                    default: HUFK_LAUNCH_EMIT_FAST(12, true, 0, a->n_tail); break;
+                }
             }
         }
 #undef HUFK_LAUNCH_EMIT_FAST
