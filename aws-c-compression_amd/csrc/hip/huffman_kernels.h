@@ -80,6 +80,7 @@ struct hufk_decode_args {
     uint64_t *chunk_base;  /* [n_chunks] scratch */
     struct hufd_dec_item_state *states; /* [n_items] scratch */
     struct hufd_dec_result *results;    /* [n_items] */
+    uint32_t tail_stage_bytes; /* the most symbols a chunk that holds the end of a stream can decode to, +32 (0: unknown) */
     uint32_t old_sync; /* 1: dec_sync_fast for every chunk (AWS_HUFFMAN_AMD_DECODE=old-sync), not dec_sync_lean for those inside a stream */
     void **stage_events; /* NULL, or 4 hipEvent_t: before sync, after sync, after scan, after emit */
 };

@@ -5073,10 +5073,17 @@ struct emit_shared {
     u32 lane_base[HUFD_DEC_LANES]; /* index of the sub-chunk's first symbol within the chunk */
     u32 wave_tot[HUFD_DEC_LANES / 64];
     u32 pad[4];
-    u8 stage[HUFD_DEC_STAGE_BYTES + 32];
     u8 dump[512]; /* where a chain that has nothing to emit writes (at most 8 rows x 32 codes) */
     u32 tail_words[2][kTailWords]; /* TAIL: the stream's last words, for the one or two careful lanes */
+    /* last: a launch for chunks that cannot hold that many symbols asks for less of it (emit_lds_bytes) */
+    u8 stage[HUFD_DEC_STAGE_BYTES + 32];
 };
+
+/* LDS of dec_emit_fast with room for `stage_bytes` symbols in the stage */
+template <u32 LB>
+__host__ __device__ constexpr u32 emit_lds_bytes(u32 stage_bytes) {
+    return (u32)sizeof(emit_shared<LB>) - HUFD_DEC_STAGE_BYTES + stage_bytes;
+}
 
 template <u32 LB, bool TAIL, u32 SURE = 0> /* TAIL: the chunks listed in tail_chunks (they may hold the end of a stream); else all the others.
                                              * SURE: the codes that are certain to start in a row, when the launch knows (0: asked of the coder at run time) */
@@ -5097,7 +5104,8 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
     u32 *slow_list, /* chunks left to dec_emit_kernel */
     u32 *slow_count,
     u32 *dense_list, /* chunks with more symbols than the stage holds: left to dec_emit_dense_kernel */
-    u32 *dense_count) {
+    u32 *dense_count,
+    u32 stage_limit /* symbols the stage of this launch holds (HUFD_DEC_STAGE_BYTES, or less: emit_lds_bytes) */) {
 
     emit_shared<LB> &sh = *reinterpret_cast<emit_shared<LB> *>(dyn_lds);
     const u32 ns = tb.n_states;
@@ -5144,7 +5152,7 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
     }
     const bool fits = regular != 0 && (regular == 2 || !wide_stop(f0)) && ((cpt[merged_row] >> s0) & 1u) != 0 &&
                       cbase + chunk_symbols <= it.out_cap;
-    const bool fast = fits && chunk_symbols + 16 <= HUFD_DEC_STAGE_BYTES &&
+    const bool fast = fits && chunk_symbols + 16 <= stage_limit &&
                       (lds_offset_of(sh.wlut) & ((4u << LB) - 1u)) == 0 && (SURE == 0 || SURE == row_walk(LB, tb.max_bits).sure);
     if (!fast) {
         if (t == 0) {
@@ -5197,6 +5205,18 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
         if (i < (1u << LB)) {
             sh.wlut[i] = ((e >> 8) << 16) | ((0x10000u - (len ? len : kWalkDeadLen)) & 0xFFFFu);
         }
+    }
+    /* TAIL: the waves whose threads all stand behind the stream's whole lanes have done their share of the table and
+     * leave; their slots (and, with a stage sized for what such chunks can hold, the LDS) let more workgroups onto the CU --
+     * a workgroup's time is the latency of its walks, so that is what the rate follows.  Threads 0 .. 255 stay for the
+     * scan below. */
+    const u32 live_t = !TAIL ? kEmitFastThreads
+                             : (4 * ((n_full + 1) / 2) + kWave - 1) / kWave * kWave < HUFD_DEC_LANES
+                                   ? HUFD_DEC_LANES
+                                   : (4 * ((n_full + 1) / 2) + kWave - 1) / kWave * kWave;
+    if (TAIL && t >= live_t) {
+        __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): the table entries are in LDS */
+        return;
     }
     /* where every sub-chunk's symbols go: lane 0's count follows from the chunk's total */
     u32 incl[kEmitChains] = {0, 0};
@@ -5348,7 +5368,7 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
                 gbase[lo + t] = sh.stage[lo + t];
             }
 #pragma unroll 2
-            for (u32 r = row_lo + t; r < row_hi; r += kEmitFastThreads) {
+            for (u32 r = row_lo + t; r < row_hi; r += live_t) {
                 *reinterpret_cast<uint4 *>(gbase + (u64)r * 16) = *reinterpret_cast<const uint4 *>(sh.stage + r * 16);
             }
             if (row_hi * 16 + t < hi) {
@@ -6276,12 +6296,17 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         (void)hipMemsetAsync(a->dense_count, 0, sizeof(uint32_t), st);
 #define HUFK_LAUNCH_EMIT_FAST(LBV, TAILV, SUREV, GRID)                                                                   \
     hipLaunchKernelGGL(                                                                                                \
-        (dec_emit_fast_kernel<LBV, TAILV, SUREV>), dim3(GRID), dim3(kEmitFastThreads), (uint32_t)sizeof(emit_shared<LBV>), \
-        st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, (u8 *)a->d_out,                   \
-        (const u16 *)a->cp_tab, (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn,    \
-        (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results, a->emit_list, a->emit_count,              \
-        a->dense_list, a->dense_count)
+        (dec_emit_fast_kernel<LBV, TAILV, SUREV>), dim3(GRID), dim3(kEmitFastThreads),                                  \
+        emit_lds_bytes<LBV>(TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES), st, a->tables, a->items, a->chunk_item,        \
+        a->tail_chunks, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab, (const u16 *)a->lane_count,       \
+        (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry,                           \
+        (const u64 *)a->chunk_base, a->results, a->emit_list, a->emit_count, a->dense_list, a->dense_count,            \
+        TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES)
         const bool some_inside = a->n_tail < a->n_chunks;
+        /* the stage of the launch for the chunks streams end in: what the plan says such a chunk can hold at most */
+        const uint32_t tail_stage = a->tail_stage_bytes >= 4096 && a->tail_stage_bytes < HUFD_DEC_STAGE_BYTES
+                                        ? (a->tail_stage_bytes + 255u) & ~255u
+                                        : HUFD_DEC_STAGE_BYTES;
         /* (chunks inside a stream: with the coder's number of certain steps a row compiled in, where there is such a build) */
         const uint32_t emit_sure = a->old_sync ? 0u : row_walk(a->tables.lut_bits <= 10 ? 10u : 12u, a->tables.max_bits).sure;
         if (a->tables.lut_bits <= 10) {

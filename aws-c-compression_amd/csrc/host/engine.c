@@ -792,6 +792,7 @@ static int dec_plan_fill(
         return aws_raise_error(AWS_ERROR_OOM);
     }
     uint32_t chunk = 0, large = 0, run = 0, tail = 0, tiny = 0, deep = 0;
+    uint64_t tail_stage = 0; /* the most symbols a chunk that holds the end of a stream can decode to */
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_decode_item *src = &items[i];
         struct hufd_dec_item *dst = &h_items[i];
@@ -815,6 +816,11 @@ static int dec_plan_fill(
             /* fewer than a chunk + 8 bytes left: the end of the stream is in (or just behind) this chunk */
             if (src->in_len - (uint64_t)k * HUFD_DEC_CHUNK_BYTES < (uint64_t)HUFD_DEC_CHUNK_BYTES + 8u) {
                 h_tail[tail++] = chunk;
+                const uint64_t left = src->in_len - (uint64_t)k * HUFD_DEC_CHUNK_BYTES;
+                const uint32_t shortest = eng->tables.min_bits ? eng->tables.min_bits : 1;
+                uint64_t holds = left * 8 / shortest + 1;
+                holds = holds < src->out_capacity ? holds : src->out_capacity;
+                tail_stage = holds > tail_stage ? holds : tail_stage;
             }
             h_chunk_item[chunk++] = (uint32_t)i;
         }
@@ -914,6 +920,7 @@ static int dec_plan_fill(
     p->n_large = (uint32_t)n_large;
     p->n_runs = (uint32_t)n_runs;
     p->n_tail = tail;
+    p->tail_stage_bytes = tail_stage + 32 < 0xFFFFFFFFu ? (uint32_t)tail_stage + 32u : 0u;
     p->n_tiny = tiny;
     p->n_deep = deep;
     return AWS_OP_SUCCESS;
@@ -972,6 +979,7 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.n_chunks = p->n_chunks;
     a.tail_chunks = p->d_tail;
     a.n_tail = p->n_tail;
+    a.tail_stage_bytes = p->tail_stage_bytes;
     a.deep_items = p->d_tiny + (p->n_items - p->n_deep);
     a.n_deep = p->n_deep;
     a.tiny_items = p->d_tiny;
