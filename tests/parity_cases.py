@@ -731,13 +731,43 @@ def batched_device_api(w, n_items=9, seed=18, item_len=16384, engine=None):
     res = eng.encode_results(plan, len(items))
     got = eng.download(d_out, out_total)
     want = np.full(out_total, SENTINEL, np.uint8)
+    carried = []  # the oracle's encoders of the items that ran out of room, for the resume pass below
     for i, (b, oo, c) in enumerate(zip(blobs, out_offs, caps)):
         e = w.oracle.new_encoder(w.ocoder)
         dst = np.full(c + 1, SENTINEL, np.uint8)
         r = w.oracle.encode_call(e, b, 0, dst, 0, c)
         want[oo:oo + c] = dst[:c]
         assert res[i] == (r.rc, r.err, r.consumed, r.produced, r.state[0], r.state[1]), (i, res[i], r)
+        if r.rc != 0 and r.err == SHORT_BUFFER:
+            carried.append((i, e, r))
     assert np.array_equal(got, want), "batched encode wrote outside its items or wrote wrong bytes"
+    # the items that ran out of room, taken up where they stopped: the rest of the input (at whatever address that
+    # is) with the bits that did not fit carried in, each into an output of its own
+    if carried:
+        rest_caps = [full[i].size - r.produced + [5, 0, 1][k % 3] for k, (i, e, r) in enumerate(carried)]
+        rest_offs, pos = [], 11
+        for c in rest_caps:
+            rest_offs.append(pos)
+            pos += c + 24
+        rest_total = pos + 64
+        d_rest = eng.alloc(rest_total)
+        eng.fill(d_rest, SENTINEL, rest_total)
+        ritems = [dict(in_offset=in_offs[i] + r.consumed, in_len=blobs[i].size - r.consumed, out_offset=ro, out_capacity=rc_,
+                       overflow_in=(r.state[1], r.state[0]), eos_padding=0xFF)
+                  for (i, e, r), ro, rc_ in zip(carried, rest_offs, rest_caps)]
+        rplan = eng.encode_plan(ritems)
+        eng.encode_launch(rplan, d_in, d_rest)
+        rres = eng.encode_results(rplan, len(ritems))
+        got = eng.download(d_rest, rest_total)
+        want = np.full(rest_total, SENTINEL, np.uint8)
+        for k, ((i, e, r), ro, rc_) in enumerate(zip(carried, rest_offs, rest_caps)):
+            dst = np.full(rc_ + 1, SENTINEL, np.uint8)
+            r2 = w.oracle.encode_call(e, blobs[i], r.consumed, dst, 0, rc_)
+            want[ro:ro + rc_] = dst[:rc_]
+            assert rres[k] == (r2.rc, r2.err, r2.consumed, r2.produced, r2.state[0], r2.state[1]), (k, rres[k], r2)
+        assert np.array_equal(got, want), "resumed batched encode wrote outside its items or wrote wrong bytes"
+        eng.lib.aws_huffman_amd_encode_plan_destroy(rplan)
+        eng.free(d_rest)
     # length-only launch: nothing written, totals reported
     eng.fill(d_out, SENTINEL, out_total)
     eng.encode_launch(plan, d_in, d_out, length_only=True)
