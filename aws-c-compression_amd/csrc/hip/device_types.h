@@ -158,4 +158,14 @@ struct hufd_dec_result {
     uint32_t reserved;
 };
 
+/* one per chunk, built with the plan: what the chunk kernels need of the chunk's item, without following
+ * chunk -> item -> record (a workgroup's time is mostly the latency of what it loads before its first walk) */
+struct hufd_chunk_rec {
+    uint64_t src_off; /* bytes from the input base pointer to the chunk */
+    uint64_t out_off; /* bytes from the output base pointer to the item's first symbol */
+    uint64_t out_cap; /* the item's output capacity */
+    uint32_t valid;   /* bytes of the item from the chunk's first on (saturated) */
+    uint32_t item;
+};
+
 #endif /* HUFFMAN_AMD_DEVICE_TYPES_H */

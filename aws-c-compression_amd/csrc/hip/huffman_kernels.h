@@ -78,6 +78,7 @@ struct hufk_decode_args {
     uint32_t *tail_entry;   /* [n_chunks] scratch: state in which the last whole lane of an end-of-stream chunk leaves */
     uint32_t *chunk_entry; /* [n_chunks] scratch */
     uint64_t *chunk_base;  /* [n_chunks] scratch */
+    const struct hufd_chunk_rec *chunk_rec; /* [n_chunks] built with the plan */
     struct hufd_dec_item_state *states; /* [n_items] scratch */
     struct hufd_dec_result *results;    /* [n_items] */
     uint32_t tail_stage_bytes; /* the most symbols a chunk that holds the end of a stream can decode to, +32 (0: unknown) */

@@ -3756,8 +3756,7 @@ __device__ __forceinline__ u32 lean_row(u32 state, u32 hi, u32 lo, u32 table, co
 template <u32 LB, u32 SURE, bool TAIL = false> /* TAIL: the chunks listed in tail_chunks (a stream ends in them): see dec_sync_fast */
 __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     hufd_tables tb,
-    const hufd_dec_item *items,
-    const u32 *chunk_item,
+    const hufd_chunk_rec *chunk_rec,
     const u32 *tail_chunks,
     const u8 *d_in,
     u16 *fn_tab,
@@ -3773,10 +3772,9 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     const u32 ns = tb.n_states;
     const u32 lane = threadIdx.x;
     const u32 c = TAIL ? tail_chunks[blockIdx.x] : blockIdx.x;
-    const hufd_dec_item it = items[chunk_item[c]];
-    const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
-    const u64 valid = it.in_len > chunk_off ? it.in_len - chunk_off : 0;
-    const u8 *src = d_in + it.in_off + chunk_off;
+    const hufd_chunk_rec rec = chunk_rec[c]; /* (one load: not chunk -> item -> its record) */
+    const u64 valid = rec.valid;
+    const u8 *src = d_in + rec.src_off;
     if (!TAIL && valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
         return; /* holds the end of its stream: the other instantiation's */
     }
@@ -5089,8 +5087,7 @@ template <u32 LB, bool TAIL, u32 SURE = 0> /* TAIL: the chunks listed in tail_ch
                                              * SURE: the codes that are certain to start in a row, when the launch knows (0: asked of the coder at run time) */
 __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_kernel(
     hufd_tables tb,
-    const hufd_dec_item *items,
-    const u32 *chunk_item,
+    const hufd_chunk_rec *chunk_rec,
     const u32 *tail_chunks,
     const u8 *d_in,
     u8 *d_out,
@@ -5131,10 +5128,8 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
         return; /* the stream ended before this chunk */
     }
     const u32 s0 = centry & 0xFFu;
-    const u32 item_index = chunk_item[c];
-    const hufd_dec_item it = items[item_index];
-    const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
-    const u64 valid = it.in_len > chunk_off ? it.in_len - chunk_off : 0;
+    const hufd_chunk_rec rec = chunk_rec[c]; /* (asked for with the chunk's entry: not chunk -> item -> its record) */
+    const u64 valid = rec.valid;
     /* lanes whose sub-chunk and the 8 bytes after it lie inside the stream (dec_sync_fast: the others are idle or "careful") */
     if (!TAIL && valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
         return; /* the other instantiation's */
@@ -5151,7 +5146,7 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
         return; /* fewer than 136 bytes: dec_emit_tail does the whole chunk */
     }
     const bool fits = regular != 0 && (regular == 2 || !wide_stop(f0)) && ((cpt[merged_row] >> s0) & 1u) != 0 &&
-                      cbase + chunk_symbols <= it.out_cap;
+                      cbase + chunk_symbols <= rec.out_cap;
     const bool fast = fits && chunk_symbols + 16 <= stage_limit &&
                       (lds_offset_of(sh.wlut) & ((4u << LB) - 1u)) == 0 && (SURE == 0 || SURE == row_walk(LB, tb.max_bits).sure);
     if (!fast) {
@@ -5174,7 +5169,7 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
     bool whole[kEmitChains];
 #pragma unroll
     for (u32 ch = 0; ch < kEmitChains; ++ch) {
-        sub[ch] = d_in + it.in_off + chunk_off + (u64)lanes[ch] * HUFD_DEC_SUB_BYTES;
+        sub[ch] = d_in + rec.src_off + (u64)lanes[ch] * HUFD_DEC_SUB_BYTES;
         whole[ch] = !TAIL || lanes[ch] < n_full;
 #pragma unroll
         for (u32 j = 0; j <= kRows; ++j) {
@@ -5269,7 +5264,7 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
     __syncthreads();
     HUFD_STAMP(1, 1);
 
-    u8 *out_ptr = d_out + it.out_off + cbase;
+    u8 *out_ptr = d_out + rec.out_off + cbase;
     const u32 mis = (u32)((uintptr_t)out_ptr & 15u);
     const row_walk rw(LB, tb.max_bits);
     u32 st[kEmitChains];
@@ -5341,7 +5336,7 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
         u32 hi = w[0][kRows];
         for (u32 r = kRows; r < 2 * kRows; ++r) {
             /* (sub-chunk 0: the address is rebuilt from the chunk's, so that no pointer has to stay in registers for this) */
-            const u32 lo = __builtin_bswap32(*reinterpret_cast<const u32 *>(d_in + it.in_off + chunk_off + (r + 1) * 4));
+            const u32 lo = __builtin_bswap32(*reinterpret_cast<const u32 *>(d_in + rec.src_off + (r + 1) * 4));
             const u64 pair = ((u64)hi << 32) | lo;
             while ((st[0] & 0xFFFFu) > rw.thr) {
                 const u32 e = *reinterpret_cast<const u32 *>(lut + ((u32)(pair >> (st[0] & 63u)) & rw.mask));
@@ -6185,14 +6180,14 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     if (some_inside) {                                                                                                 \
         hipLaunchKernelGGL(                                                                                            \
             (dec_sync_lean_kernel<LBV, SUREV, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES),                         \
-            (uint32_t)sizeof(lean_shared<LBV>), st, a->tables, a->items, a->chunk_item, a->tail_chunks,                 \
+            (uint32_t)sizeof(lean_shared<LBV>), st, a->tables, a->chunk_rec, a->tail_chunks,                            \
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
             a->slow_list, a->slow_count);                                                                              \
     }                                                                                                                  \
     if (a->n_tail) {                                                                                                   \
         hipLaunchKernelGGL(                                                                                            \
             (dec_sync_lean_kernel<LBV, SUREV, true>), dim3(a->n_tail), dim3(HUFD_DEC_LANES),                            \
-            (uint32_t)sizeof(lean_shared<LBV>), st, a->tables, a->items, a->chunk_item, a->tail_chunks,                 \
+            (uint32_t)sizeof(lean_shared<LBV>), st, a->tables, a->chunk_rec, a->tail_chunks,                            \
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
             a->slow_list, a->slow_count);                                                                              \
     }
@@ -6297,7 +6292,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
 #define HUFK_LAUNCH_EMIT_FAST(LBV, TAILV, SUREV, GRID)                                                                   \
     hipLaunchKernelGGL(                                                                                                \
         (dec_emit_fast_kernel<LBV, TAILV, SUREV>), dim3(GRID), dim3(kEmitFastThreads),                                  \
-        emit_lds_bytes<LBV>(TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES), st, a->tables, a->items, a->chunk_item,        \
+        emit_lds_bytes<LBV>(TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES), st, a->tables, a->chunk_rec,                   \
         a->tail_chunks, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab, (const u16 *)a->lane_count,       \
         (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry,                           \
         (const u64 *)a->chunk_base, a->results, a->emit_list, a->emit_count, a->dense_list, a->dense_count,            \

@@ -685,6 +685,7 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     hufs_free(p->d_tail_entry);
     hufs_free(p->d_chunk_entry);
     hufs_free(p->d_chunk_base);
+    hufs_free(p->d_chunk_rec);
     hufs_free(p->d_states);
     hufs_free(p->d_results);
     p->d_items = NULL;
@@ -707,6 +708,7 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     p->d_tail_entry = NULL;
     p->d_chunk_entry = NULL;
     p->d_chunk_base = NULL;
+    p->d_chunk_rec = NULL;
     p->d_states = NULL;
     p->d_results = NULL;
     p->cap_items = p->cap_chunks = p->cap_large = p->cap_runs = 0;
@@ -778,11 +780,13 @@ static int dec_plan_fill(
 
     struct hufd_dec_item *h_items = malloc((n_items ? n_items : 1) * sizeof(*h_items));
     uint32_t *h_chunk_item = malloc((n_chunks ? n_chunks : 1) * sizeof(uint32_t));
+    struct hufd_chunk_rec *h_chunk_rec = malloc((n_chunks ? n_chunks : 1) * sizeof(*h_chunk_rec));
     uint32_t *h_large = malloc((n_large ? n_large : 1) * 2 * sizeof(uint32_t));
     uint32_t *h_runs = malloc((n_runs ? n_runs : 1) * 2 * sizeof(uint32_t));
     uint32_t *h_tail = malloc((n_items ? n_items : 1) * 2 * sizeof(uint32_t));
     uint32_t *h_tiny = malloc((n_items ? n_items : 1) * sizeof(uint32_t));
-    if (!h_items || !h_chunk_item || !h_large || !h_runs || !h_tail || !h_tiny) {
+    if (!h_items || !h_chunk_item || !h_chunk_rec || !h_large || !h_runs || !h_tail || !h_tiny) {
+        free(h_chunk_rec);
         free(h_tail);
         free(h_tiny);
         free(h_runs);
@@ -821,6 +825,15 @@ static int dec_plan_fill(
                 uint64_t holds = left * 8 / shortest + 1;
                 holds = holds < src->out_capacity ? holds : src->out_capacity;
                 tail_stage = holds > tail_stage ? holds : tail_stage;
+            }
+            {
+                const uint64_t off = (uint64_t)k * HUFD_DEC_CHUNK_BYTES, left = src->in_len - off;
+                struct hufd_chunk_rec *cr = &h_chunk_rec[chunk];
+                cr->src_off = src->in_offset + off;
+                cr->out_off = src->out_offset;
+                cr->out_cap = src->out_capacity;
+                cr->valid = left < 0xFFFFFFFFull ? (uint32_t)left : 0xFFFFFFFFu;
+                cr->item = (uint32_t)i;
             }
             h_chunk_item[chunk++] = (uint32_t)i;
         }
@@ -863,11 +876,12 @@ static int dec_plan_fill(
         p->d_tail_entry = hufs_malloc(cc * sizeof(uint32_t));
         p->d_chunk_entry = hufs_malloc(cc * sizeof(uint32_t));
         p->d_chunk_base = hufs_malloc(cc * sizeof(uint64_t));
+        p->d_chunk_rec = hufs_malloc(cc * sizeof(struct hufd_chunk_rec));
         p->d_states = hufs_malloc(ci * sizeof(struct hufd_dec_item_state));
         p->d_results = hufs_malloc(ci * sizeof(struct hufd_dec_result));
         if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_cp_tab || !p->d_chunk_fn || !p->d_slow_list || !p->d_chunk_entry ||
             !p->d_tail || !p->d_tiny || !p->d_dense_list || !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_tail_entry || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
-            !p->d_chunk_base || !p->d_states || !p->d_results) {
+            !p->d_chunk_base || !p->d_chunk_rec || !p->d_states || !p->d_results) {
             err = 2;
         }
         p->cap_items = ci;
@@ -889,6 +903,9 @@ static int dec_plan_fill(
     }
     if (!err) {
         err = hufs_copy_h2d(p->d_chunk_item, h_chunk_item, n_chunks * sizeof(uint32_t), eng->stream);
+        if (!err) {
+            err = hufs_copy_h2d(p->d_chunk_rec, h_chunk_rec, n_chunks * sizeof(*h_chunk_rec), eng->stream);
+        }
     }
     if (!err) {
         err = hufs_copy_h2d(p->d_large, h_large, n_large * 2 * sizeof(uint32_t), eng->stream);
@@ -908,6 +925,7 @@ static int dec_plan_fill(
     }
     free(h_items);
     free(h_chunk_item);
+    free(h_chunk_rec);
     free(h_large);
     free(h_runs);
     free(h_tail);
@@ -1007,6 +1025,7 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.tail_entry = p->d_tail_entry;
     a.chunk_entry = p->d_chunk_entry;
     a.chunk_base = p->d_chunk_base;
+    a.chunk_rec = p->d_chunk_rec;
     a.states = p->d_states;
     a.results = p->d_results;
     {

@@ -100,6 +100,7 @@ struct aws_huffman_amd_decode_plan {
     uint32_t *d_tail_entry;
     uint32_t *d_chunk_entry;
     uint64_t *d_chunk_base;
+    struct hufd_chunk_rec *d_chunk_rec;
     struct hufd_dec_item_state *d_states;
     struct hufd_dec_result *d_results;
 };
