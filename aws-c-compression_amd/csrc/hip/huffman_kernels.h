@@ -79,6 +79,9 @@ struct hufk_decode_args {
     uint32_t *chunk_entry; /* [n_chunks] scratch */
     uint64_t *chunk_base;  /* [n_chunks] scratch */
     const struct hufd_chunk_rec *chunk_rec; /* [n_chunks] built with the plan */
+    void *side_stream;  /* NULL, or a stream of the engine's for the kernels of the chunks streams end in ... */
+    void *fork_event;   /* ... and two events to fork it off the launch's stream and join it again */
+    void *join_event;
     struct hufd_dec_item_state *states; /* [n_items] scratch */
     struct hufd_dec_result *results;    /* [n_items] */
     uint32_t tail_stage_bytes; /* the most symbols a chunk that holds the end of a stream can decode to, +32 (0: unknown) */

@@ -6173,20 +6173,30 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         const auto sync = ns <= 8 ? dec_sync_kernel<8> : (ns <= 10 ? dec_sync_kernel<10> : dec_sync_kernel<12>);
         (void)hipMemsetAsync(a->slow_count, 0, sizeof(uint32_t), st);
         const bool some_inside = a->n_tail < a->n_chunks; /* chunks with a whole chunk + 8 bytes of stream left */
+        /* A few chunks that streams end in beside many inside streams (one long stream: ONE): their kernels are tiny
+         * and, one after the other behind the big ones, cost a tenth of the decode time in launch and drain.  They run on
+         * a second stream of the engine's, beside the big kernels, forked off and joined with events. */
+        const bool beside = some_inside && a->n_tail && a->side_stream && a->fork_event && a->join_event &&
+                            (uint64_t)a->n_tail * 8 <= a->n_chunks;
+        hipStream_t tst = beside ? (hipStream_t)a->side_stream : st;
+        if (beside) {
+            (void)hipEventRecord((hipEvent_t)a->fork_event, st);
+            (void)hipStreamWaitEvent(tst, (hipEvent_t)a->fork_event, 0);
+        }
         /* chunks inside a stream: the lean kernel where it is compiled for this coder's number of certain steps a row */
         const uint32_t sure = row_walk(a->tables.lut_bits <= 10 ? 10u : 12u, a->tables.max_bits).sure;
         bool lean = false;
 #define HUFK_LAUNCH_SYNC_LEAN(LBV, SUREV)                                                                               \
-    if (some_inside) {                                                                                                 \
-        hipLaunchKernelGGL(                                                                                            \
-            (dec_sync_lean_kernel<LBV, SUREV, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES),                         \
-            (uint32_t)sizeof(lean_shared<LBV>), st, a->tables, a->chunk_rec, a->tail_chunks,                            \
-            (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
-            a->slow_list, a->slow_count);                                                                              \
-    }                                                                                                                  \
     if (a->n_tail) {                                                                                                   \
         hipLaunchKernelGGL(                                                                                            \
             (dec_sync_lean_kernel<LBV, SUREV, true>), dim3(a->n_tail), dim3(HUFD_DEC_LANES),                            \
+            (uint32_t)sizeof(lean_shared<LBV>), tst, a->tables, a->chunk_rec, a->tail_chunks,                           \
+            (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
+            a->slow_list, a->slow_count);                                                                              \
+    }                                                                                                                  \
+    if (some_inside) {                                                                                                 \
+        hipLaunchKernelGGL(                                                                                            \
+            (dec_sync_lean_kernel<LBV, SUREV, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES),                         \
             (uint32_t)sizeof(lean_shared<LBV>), st, a->tables, a->chunk_rec, a->tail_chunks,                            \
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
             a->slow_list, a->slow_count);                                                                              \
@@ -6219,7 +6229,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             if (a->n_tail && !lean) {
                 hipLaunchKernelGGL(
                     (dec_sync_fast_kernel<10, true>), dim3(a->n_tail), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<10>),
-                    st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
+                    tst, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
                     a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry, a->slow_list, a->slow_count);
             }
         } else {
@@ -6231,7 +6241,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             if (a->n_tail && !lean) {
                 hipLaunchKernelGGL(
                     (dec_sync_fast_kernel<12, true>), dim3(a->n_tail), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<12>),
-                    st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
+                    tst, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
                     a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry, a->slow_list, a->slow_count);
             }
         }
@@ -6239,9 +6249,13 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             /* the last symbols of every stream, a thread each; then the chunk functions are complete */
             const uint32_t lds = (uint32_t)sizeof(tail_lds) + (2u << a->tables.lut_bits);
             hipLaunchKernelGGL(
-                dec_sync_tail_kernel, dim3((a->n_tail + kTailThreads - 1) / kTailThreads), dim3(kTailThreads), lds, st,
+                dec_sync_tail_kernel, dim3((a->n_tail + kTailThreads - 1) / kTailThreads), dim3(kTailThreads), lds, tst,
                 a->tables, a->items, a->chunk_item, a->tail_chunks, a->n_tail, (const u8 *)a->d_in,
                 (const u8 *)a->chunk_regular, (const u32 *)a->tail_entry, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count);
+        }
+        if (beside) {
+            (void)hipEventRecord((hipEvent_t)a->join_event, tst);
+            (void)hipStreamWaitEvent(st, (hipEvent_t)a->join_event, 0);
         }
         hipLaunchKernelGGL(
             sync, dim3(persistent_grid(sync, HUFD_DEC_LANES, dec_sync_lds_bytes(&a->tables), a->n_chunks)),
@@ -6289,15 +6303,23 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         /* regular chunks that fit their output the short way; the rest through the list */
         (void)hipMemsetAsync(a->emit_count, 0, sizeof(uint32_t), st);
         (void)hipMemsetAsync(a->dense_count, 0, sizeof(uint32_t), st);
-#define HUFK_LAUNCH_EMIT_FAST(LBV, TAILV, SUREV, GRID)                                                                   \
+#define HUFK_LAUNCH_EMIT_FAST(LBV, TAILV, SUREV, GRID, STREAMV)                                                          \
     hipLaunchKernelGGL(                                                                                                \
         (dec_emit_fast_kernel<LBV, TAILV, SUREV>), dim3(GRID), dim3(kEmitFastThreads),                                  \
-        emit_lds_bytes<LBV>(TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES), st, a->tables, a->chunk_rec,                   \
+        emit_lds_bytes<LBV>(TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES), STREAMV, a->tables, a->chunk_rec,              \
         a->tail_chunks, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab, (const u16 *)a->lane_count,       \
         (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry,                           \
         (const u64 *)a->chunk_base, a->results, a->emit_list, a->emit_count, a->dense_list, a->dense_count,            \
         TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES)
         const bool some_inside = a->n_tail < a->n_chunks;
+        /* (the few chunks streams end in beside the many inside streams: see the sync kernels above) */
+        const bool beside = some_inside && a->n_tail && a->side_stream && a->fork_event && a->join_event &&
+                            (uint64_t)a->n_tail * 8 <= a->n_chunks;
+        hipStream_t tst = beside ? (hipStream_t)a->side_stream : st;
+        if (beside) {
+            (void)hipEventRecord((hipEvent_t)a->fork_event, st);
+            (void)hipStreamWaitEvent(tst, (hipEvent_t)a->fork_event, 0);
+        }
         /* the stage of the launch for the chunks streams end in: what the plan says such a chunk can hold at most */
         const uint32_t tail_stage = a->tail_stage_bytes >= 4096 && a->tail_stage_bytes < HUFD_DEC_STAGE_BYTES
                                         ? (a->tail_stage_bytes + 255u) & ~255u
@@ -6305,37 +6327,37 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         /* (chunks inside a stream: with the coder's number of certain steps a row compiled in, where there is such a build) */
         const uint32_t emit_sure = a->old_sync ? 0u : row_walk(a->tables.lut_bits <= 10 ? 10u : 12u, a->tables.max_bits).sure;
         if (a->tables.lut_bits <= 10) {
-            if (some_inside) {
-                switch (emit_sure) {
-                    case 2: HUFK_LAUNCH_EMIT_FAST(10, false, 2, a->n_chunks); break;
-                    case 3: HUFK_LAUNCH_EMIT_FAST(10, false, 3, a->n_chunks); break;
-                    case 4: HUFK_LAUNCH_EMIT_FAST(10, false, 4, a->n_chunks); break;
-                    case 5: HUFK_LAUNCH_EMIT_FAST(10, false, 5, a->n_chunks); break;
-                    default: HUFK_LAUNCH_EMIT_FAST(10, false, 0, a->n_chunks); break;
-                }
-            }
             if (a->n_tail) {
                 switch (emit_sure) {
-                    case 2: HUFK_LAUNCH_EMIT_FAST(10, true, 2, a->n_tail); break;
-                    case 3: HUFK_LAUNCH_EMIT_FAST(10, true, 3, a->n_tail); break;
-                    case 4: HUFK_LAUNCH_EMIT_FAST(10, true, 4, a->n_tail); break;
-                    case 5: HUFK_LAUNCH_EMIT_FAST(10, true, 5, a->n_tail); break;
-                    default: HUFK_LAUNCH_EMIT_FAST(10, true, 0, a->n_tail); break;
+                    case 2: HUFK_LAUNCH_EMIT_FAST(10, true, 2, a->n_tail, tst); break;
+                    case 3: HUFK_LAUNCH_EMIT_FAST(10, true, 3, a->n_tail, tst); break;
+                    case 4: HUFK_LAUNCH_EMIT_FAST(10, true, 4, a->n_tail, tst); break;
+                    case 5: HUFK_LAUNCH_EMIT_FAST(10, true, 5, a->n_tail, tst); break;
+                    default: HUFK_LAUNCH_EMIT_FAST(10, true, 0, a->n_tail, tst); break;
+                }
+            }
+            if (some_inside) {
+                switch (emit_sure) {
+                    case 2: HUFK_LAUNCH_EMIT_FAST(10, false, 2, a->n_chunks, st); break;
+                    case 3: HUFK_LAUNCH_EMIT_FAST(10, false, 3, a->n_chunks, st); break;
+                    case 4: HUFK_LAUNCH_EMIT_FAST(10, false, 4, a->n_chunks, st); break;
+                    case 5: HUFK_LAUNCH_EMIT_FAST(10, false, 5, a->n_chunks, st); break;
+                    default: HUFK_LAUNCH_EMIT_FAST(10, false, 0, a->n_chunks, st); break;
                 }
             }
         } else {
-            if (some_inside) {
-                switch (emit_sure) {
-                    case 2: HUFK_LAUNCH_EMIT_FAST(12, false, 2, a->n_chunks); break;
-                    case 3: HUFK_LAUNCH_EMIT_FAST(12, false, 3, a->n_chunks); break;
-                    default: HUFK_LAUNCH_EMIT_FAST(12, false, 0, a->n_chunks); break;
-                }
-            }
             if (a->n_tail) {
                 switch (emit_sure) {
-                    case 2: HUFK_LAUNCH_EMIT_FAST(12, true, 2, a->n_tail); break;
-                    case 3: HUFK_LAUNCH_EMIT_FAST(12, true, 3, a->n_tail); break;
-                    default: HUFK_LAUNCH_EMIT_FAST(12, true, 0, a->n_tail); break;
+                    case 2: HUFK_LAUNCH_EMIT_FAST(12, true, 2, a->n_tail, tst); break;
+                    case 3: HUFK_LAUNCH_EMIT_FAST(12, true, 3, a->n_tail, tst); break;
+                    default: HUFK_LAUNCH_EMIT_FAST(12, true, 0, a->n_tail, tst); break;
+                }
+            }
+            if (some_inside) {
+                switch (emit_sure) {
+                    case 2: HUFK_LAUNCH_EMIT_FAST(12, false, 2, a->n_chunks, st); break;
+                    case 3: HUFK_LAUNCH_EMIT_FAST(12, false, 3, a->n_chunks, st); break;
+                    default: HUFK_LAUNCH_EMIT_FAST(12, false, 0, a->n_chunks, st); break;
                 }
             }
         }
@@ -6343,10 +6365,14 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         if (a->n_tail) {
             const uint32_t lds = (uint32_t)sizeof(tail_lds) + (2u << a->tables.lut_bits);
             hipLaunchKernelGGL(
-                dec_emit_tail_kernel, dim3((a->n_tail + kTailThreads - 1) / kTailThreads), dim3(kTailThreads), lds, st,
+                dec_emit_tail_kernel, dim3((a->n_tail + kTailThreads - 1) / kTailThreads), dim3(kTailThreads), lds, tst,
                 a->tables, a->items, a->chunk_item, a->tail_chunks, a->n_tail, (const u8 *)a->d_in, (u8 *)a->d_out,
                 (const u16 *)a->cp_tab, (const u16 *)a->lane_count, (const u8 *)a->chunk_regular,
                 (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results);
+        }
+        if (beside) {
+            (void)hipEventRecord((hipEvent_t)a->join_event, tst);
+            (void)hipStreamWaitEvent(st, (hipEvent_t)a->join_event, 0);
         }
         /* chunks of short codes (more symbols than one stage): a resident grid takes turns over their list */
         if (a->tables.lut_bits <= 10) {

@@ -229,6 +229,19 @@ int aws_huffman_amd_engine_new(
     }
 
     int err = hufs_stream_create(&eng->stream);
+    if (!err && hufs_stream_create(&eng->side_stream) == 0) {
+        eng->fork_event = hufs_event_create();
+        eng->join_event = hufs_event_create();
+        if (!eng->fork_event || !eng->join_event) {
+            /* (no overlap then: the kernels run one after the other on the one stream) */
+            hufs_event_destroy(eng->fork_event);
+            hufs_event_destroy(eng->join_event);
+            hufs_stream_destroy(eng->side_stream);
+            eng->fork_event = eng->join_event = eng->side_stream = NULL;
+        }
+    } else {
+        eng->side_stream = NULL;
+    }
     if (!err && eng->deep_lut_host) {
         eng->d_deep_lut =
             device_upload(eng->deep_lut_host, (size_t)eng->tables.deep_entries * sizeof(uint32_t), eng->stream, &err);
@@ -269,6 +282,11 @@ void aws_huffman_amd_engine_destroy(struct aws_huffman_amd_engine *eng) {
     hufs_free(eng->d_enc_table);
     hufs_free(eng->d_dec_lut);
     hufs_free(eng->d_deep_lut);
+    hufs_event_destroy(eng->fork_event);
+    hufs_event_destroy(eng->join_event);
+    if (eng->side_stream) {
+        hufs_stream_destroy(eng->side_stream);
+    }
     hufs_stream_destroy(eng->stream);
     free(eng->dec_lut_host);
     free(eng->deep_lut_host);
@@ -1026,6 +1044,9 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.chunk_entry = p->d_chunk_entry;
     a.chunk_base = p->d_chunk_base;
     a.chunk_rec = p->d_chunk_rec;
+    a.side_stream = p->engine->side_stream;
+    a.fork_event = p->engine->fork_event;
+    a.join_event = p->engine->join_event;
     a.states = p->d_states;
     a.results = p->d_results;
     {

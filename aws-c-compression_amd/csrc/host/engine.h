@@ -12,6 +12,10 @@
 struct aws_huffman_amd_engine {
     int device;
     void *stream;
+    /* a second stream and two events: the few kernels for the chunks streams end in run beside the big ones for the
+     * chunks inside the streams (hufk_decode_launch forks and joins; NULL: one after the other) */
+    void *side_stream;
+    void *fork_event, *join_event;
 
     /* identity of the tabulated coder: the callbacks are assumed pure (huffman.h) */
     struct aws_huffman_symbol_coder *coder;
