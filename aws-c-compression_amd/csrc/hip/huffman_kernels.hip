@@ -1957,10 +1957,12 @@ __global__ __launch_bounds__(kPackThreads) void enc_pack_wave_kernel(
  *  - The copy-out moves the image to where the offset says with one funnel shift that is the same
  *    for the whole tile (region_store_shifted).
  *
- * Segments that are ragged, unaligned or start with carried overflow bits are counted here (symbol
- * by symbol) and listed for enc_pack_kernel, as is -- by enc_finish_kernel -- the segment that holds
- * the capacity edge.  Every spin is bounded; a wave that gives up raises ctl[1] and the host layer
- * redoes the launch with the three-kernel path (which has no waits between workgroups).
+ * Every segment is packed here: a ragged tile takes the same pyramid with the entries behind its last
+ * symbol set to no bits, the loads take any alignment, an item's carried overflow bits sit in the word
+ * in front of image bit 0.  The tile that holds the capacity edge of an item whose output is too
+ * short leaves a note for enc_finish_kernel, which finds the symbol at the edge.  Every spin is
+ * bounded; a wave that gives up raises ctl[1] and the host layer redoes the launch with the
+ * three-kernel path (which has no waits between workgroups).
  */
 constexpr u32 kOpGroupTiles = HUFD_OP_GROUP_TILES;   /* at most 64: a lane per tile */
 constexpr u32 kOpRoundGroups = HUFD_OP_ROUND_GROUPS; /* at most 64: a lane per group */
@@ -3710,14 +3712,6 @@ __device__ __forceinline__ u32 lds_word_at(u32 byte_offset) {
 #else
     return *reinterpret_cast<const u32 *>(dyn_lds + byte_offset);
 #endif
-}
-
-/* a value the compiler is to keep as computed (it otherwise swaps a word's bytes again at every use to save a register) */
-__device__ __forceinline__ u32 settled_value(u32 x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(x));
-#endif
-    return x;
 }
 
 template <u32 LB>
