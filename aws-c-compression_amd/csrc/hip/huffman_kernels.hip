@@ -5995,8 +5995,8 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
         /* one pass: count + offsets + pack in one kernel, then the per-item outcome */
         const onepass_layout l = onepass_layout_of(a->n_segs, a->n_items);
         uint8_t *z = (uint8_t *)a->zero_block;
+        stage_mark(a->stage_events, 0, st); /* (the clearing of the look-back words is part of what is timed) */
         (void)hipMemsetAsync(a->zero_block, 0, l.bytes, st);
-        stage_mark(a->stage_events, 0, st);
         const uint32_t region = pack_region_bytes(a->tables.max_bits);
         const uint32_t lds = kPackTabBytes + kPackWaves * region;
         const uint32_t work = (a->n_segs * kTilesPerSeg + kPackWaves - 1) / kPackWaves;
