@@ -6306,13 +6306,17 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         (const u64 *)a->chunk_base, a->results, a->emit_list, a->emit_count, a->dense_list, a->dense_count,            \
         TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES)
         const bool some_inside = a->n_tail < a->n_chunks;
-        /* (the few chunks streams end in beside the many inside streams: see the sync kernels above) */
-        const bool beside = some_inside && a->n_tail && a->side_stream && a->fork_event && a->join_event &&
-                            (uint64_t)a->n_tail * 8 <= a->n_chunks;
+        /* (the few chunks streams end in beside the many inside streams: see the sync kernels above.  And in any case
+         * dec_emit_tail beside dec_emit_fast<TAIL>: it works out for itself which chunks that kernel takes, reads
+         * nothing it writes and writes other bytes) */
+        const bool have_side = a->n_tail && a->side_stream && a->fork_event && a->join_event;
+        const bool beside = some_inside && have_side && (uint64_t)a->n_tail * 8 <= a->n_chunks;
         hipStream_t tst = beside ? (hipStream_t)a->side_stream : st;
-        if (beside) {
+        hipStream_t ends_st = have_side ? (hipStream_t)a->side_stream : st;
+        (void)ends_st;
+        if (have_side) {
             (void)hipEventRecord((hipEvent_t)a->fork_event, st);
-            (void)hipStreamWaitEvent(tst, (hipEvent_t)a->fork_event, 0);
+            (void)hipStreamWaitEvent((hipStream_t)a->side_stream, (hipEvent_t)a->fork_event, 0);
         }
         /* the stage of the launch for the chunks streams end in: what the plan says such a chunk can hold at most */
         const uint32_t tail_stage = a->tail_stage_bytes >= 4096 && a->tail_stage_bytes < HUFD_DEC_STAGE_BYTES
@@ -6359,13 +6363,13 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         if (a->n_tail) {
             const uint32_t lds = (uint32_t)sizeof(tail_lds) + (2u << a->tables.lut_bits);
             hipLaunchKernelGGL(
-                dec_emit_tail_kernel, dim3((a->n_tail + kTailThreads - 1) / kTailThreads), dim3(kTailThreads), lds, tst,
+                dec_emit_tail_kernel, dim3((a->n_tail + kTailThreads - 1) / kTailThreads), dim3(kTailThreads), lds, ends_st,
                 a->tables, a->items, a->chunk_item, a->tail_chunks, a->n_tail, (const u8 *)a->d_in, (u8 *)a->d_out,
                 (const u16 *)a->cp_tab, (const u16 *)a->lane_count, (const u8 *)a->chunk_regular,
                 (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results);
         }
-        if (beside) {
-            (void)hipEventRecord((hipEvent_t)a->join_event, tst);
+        if (have_side) {
+            (void)hipEventRecord((hipEvent_t)a->join_event, (hipStream_t)a->side_stream);
             (void)hipStreamWaitEvent(st, (hipEvent_t)a->join_event, 0);
         }
         /* chunks of short codes (more symbols than one stage): a resident grid takes turns over their list */
