@@ -6313,6 +6313,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         const bool beside = some_inside && have_side && (uint64_t)a->n_tail * 8 <= a->n_chunks;
         hipStream_t tst = beside ? (hipStream_t)a->side_stream : st;
         hipStream_t ends_st = have_side ? (hipStream_t)a->side_stream : st;
+        (void)tst;
         (void)ends_st;
         if (have_side) {
             (void)hipEventRecord((hipEvent_t)a->fork_event, st);
