@@ -6155,6 +6155,8 @@ int hufk_decode_one_coop(
     return (int)hipGetLastError();
 }
 
+constexpr uint32_t kBesideMinChunks = 1024; /* launches of fewer chunks keep to one stream */
+
 int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a->n_items == 0) {
@@ -6170,8 +6172,9 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         /* A few chunks that streams end in beside many inside streams (one long stream: ONE): their kernels are tiny
          * and, one after the other behind the big ones, cost a tenth of the decode time in launch and drain.  They run on
          * a second stream of the engine's, beside the big kernels, forked off and joined with events. */
+        /* (not for a launch of a few chunks: the fork and the join are four commands, ~30 us of a small call) */
         const bool beside = some_inside && a->n_tail && a->side_stream && a->fork_event && a->join_event &&
-                            (uint64_t)a->n_tail * 8 <= a->n_chunks;
+                            (uint64_t)a->n_tail * 8 <= a->n_chunks && a->n_chunks >= kBesideMinChunks;
         hipStream_t tst = beside ? (hipStream_t)a->side_stream : st;
         if (beside) {
             (void)hipEventRecord((hipEvent_t)a->fork_event, st);
@@ -6309,7 +6312,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         /* (the few chunks streams end in beside the many inside streams: see the sync kernels above.  And in any case
          * dec_emit_tail beside dec_emit_fast<TAIL>: it works out for itself which chunks that kernel takes, reads
          * nothing it writes and writes other bytes) */
-        const bool have_side = a->n_tail && a->side_stream && a->fork_event && a->join_event;
+        const bool have_side = a->n_tail && a->side_stream && a->fork_event && a->join_event && a->n_chunks >= kBesideMinChunks;
         const bool beside = some_inside && have_side && (uint64_t)a->n_tail * 8 <= a->n_chunks;
         hipStream_t tst = beside ? (hipStream_t)a->side_stream : st;
         hipStream_t ends_st = have_side ? (hipStream_t)a->side_stream : st;
