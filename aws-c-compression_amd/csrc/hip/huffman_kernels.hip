@@ -97,6 +97,14 @@ __device__ unsigned long long *hufd_stamp_rows; /* [3][HUFD_STAMP_MAX_WG][8], se
 #define HUFD_STAMP_FLUSH(kernel)
 #endif
 
+/* 16 / 4 bytes at any address (one load: the memory system takes any alignment) */
+struct __attribute__((packed, aligned(1))) unaligned_uint4 {
+    u32 x, y, z, w;
+};
+struct __attribute__((packed, aligned(1))) unaligned_u32 {
+    u32 x;
+};
+
 __device__ __forceinline__ u32 round16(u32 x) {
     return (x + 15u) & ~15u;
 }
@@ -196,7 +204,7 @@ __device__ __forceinline__ u32 group_byte(const u32 (&w)[4], u32 j) {
 __device__ __forceinline__ u32 load_be32(const u8 *base, u64 index, u64 valid_bytes, bool aligned) {
     const u64 at = index * 4;
     if (aligned && at + 4 <= valid_bytes) {
-        return __builtin_bswap32(*reinterpret_cast<const u32 *>(base + at));
+        return __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(base + at)->x); /* (whole words: one load, at any address) */
     }
     u32 v = 0;
 #pragma unroll
@@ -2104,10 +2112,6 @@ __device__ __forceinline__ void region_store_shifted(const u32 *img, u8 *out_ptr
     }
 }
 
-/* 16 bytes at any address (one load: the memory system takes any alignment) */
-struct __attribute__((packed, aligned(1))) unaligned_uint4 {
-    u32 x, y, z, w;
-};
 template <bool B> struct op_flag {
     static constexpr bool value = B;
 };
@@ -3784,7 +3788,8 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     }
     const row_walk rw(LB, tb.max_bits);
     const u32 table = lds_offset_of(sh.wlut);
-    const bool eligible = n_full >= 1 && ((uintptr_t)src & 15u) == 0 && tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS &&
+    /* (a chunk may lie at any address: the loads need no alignment) */
+    const bool eligible = n_full >= 1 && tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS &&
                           rw.sure == SURE && (table & ((4u << LB) - 1u)) == 0;
     if (!eligible) {
         if (lane == 0) {
@@ -3812,16 +3817,16 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         /* (TAIL: a lane behind the stream's whole lanes reads sub-chunk 0 again -- no branch, no second set of
          * registers for "nothing", and words that are codes; what it makes of them is never looked at) */
         const u32 mine = active ? lane : 0u;
-        const uint4 *line = reinterpret_cast<const uint4 *>(src + (u64)mine * HUFD_DEC_SUB_BYTES);
+        const unaligned_uint4 *line = reinterpret_cast<const unaligned_uint4 *>(src + (u64)mine * HUFD_DEC_SUB_BYTES);
 #pragma unroll
         for (u32 q = 0; q < kSubWords / 4; ++q) {
-            const uint4 v = line[q];
+            const unaligned_uint4 v = line[q];
             w[4 * q + 0] = __builtin_bswap32(v.x);
             w[4 * q + 1] = __builtin_bswap32(v.y);
             w[4 * q + 2] = __builtin_bswap32(v.z);
             w[4 * q + 3] = __builtin_bswap32(v.w);
         }
-        w[kSubWords] = __builtin_bswap32(*reinterpret_cast<const u32 *>(src + (u64)(mine + 1) * HUFD_DEC_SUB_BYTES));
+        w[kSubWords] = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(src + (u64)(mine + 1) * HUFD_DEC_SUB_BYTES)->x);
     }
     /* (the threads that are still there: wave 0 and the waves with whole lanes) */
     const u32 live = !TAIL ? HUFD_DEC_LANES : (n_full + kWave - 1) / kWave * kWave;
@@ -5170,16 +5175,16 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
             w[ch][j] = 0;
         }
         if (whole[ch]) {
-            const uint4 *p = reinterpret_cast<const uint4 *>(sub[ch] + q * kRows * 4);
+            const unaligned_uint4 *p = reinterpret_cast<const unaligned_uint4 *>(sub[ch] + q * kRows * 4);
 #pragma unroll
             for (u32 j = 0; j < kRows / 4; ++j) {
-                const uint4 v = p[j];
+                const unaligned_uint4 v = p[j];
                 w[ch][4 * j + 0] = __builtin_bswap32(v.x);
                 w[ch][4 * j + 1] = __builtin_bswap32(v.y);
                 w[ch][4 * j + 2] = __builtin_bswap32(v.z);
                 w[ch][4 * j + 3] = __builtin_bswap32(v.w);
             }
-            w[ch][kRows] = __builtin_bswap32(*reinterpret_cast<const u32 *>(sub[ch] + (q + 1) * kRows * 4));
+            w[ch][kRows] = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(sub[ch] + (q + 1) * kRows * 4)->x);
         }
         my_cp[ch] = q ? cpt[(q - 1) * HUFD_DEC_LANES + lanes[ch]] : 0u;
         next_cp[ch] = q + 1 < kQuarters ? cpt[q * HUFD_DEC_LANES + lanes[ch]] : 0u;
@@ -5330,7 +5335,7 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
         u32 hi = w[0][kRows];
         for (u32 r = kRows; r < 2 * kRows; ++r) {
             /* (sub-chunk 0: the address is rebuilt from the chunk's, so that no pointer has to stay in registers for this) */
-            const u32 lo = __builtin_bswap32(*reinterpret_cast<const u32 *>(d_in + rec.src_off + (r + 1) * 4));
+            const u32 lo = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(d_in + rec.src_off + (r + 1) * 4)->x);
             const u64 pair = ((u64)hi << 32) | lo;
             while ((st[0] & 0xFFFFu) > rw.thr) {
                 const u32 e = *reinterpret_cast<const u32 *>(lut + ((u32)(pair >> (st[0] & 63u)) & rw.mask));
@@ -5559,16 +5564,16 @@ __device__ __forceinline__ void dec_emit_dense_chunk(
             w[ch][j] = 0;
         }
         if (whole[ch]) {
-            const uint4 *p = reinterpret_cast<const uint4 *>(sub[ch] + q * kRows * 4);
+            const unaligned_uint4 *p = reinterpret_cast<const unaligned_uint4 *>(sub[ch] + q * kRows * 4);
 #pragma unroll
             for (u32 j = 0; j < kRows / 4; ++j) {
-                const uint4 v = p[j];
+                const unaligned_uint4 v = p[j];
                 w[ch][4 * j + 0] = __builtin_bswap32(v.x);
                 w[ch][4 * j + 1] = __builtin_bswap32(v.y);
                 w[ch][4 * j + 2] = __builtin_bswap32(v.z);
                 w[ch][4 * j + 3] = __builtin_bswap32(v.w);
             }
-            w[ch][kRows] = __builtin_bswap32(*reinterpret_cast<const u32 *>(sub[ch] + (q + 1) * kRows * 4));
+            w[ch][kRows] = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(sub[ch] + (q + 1) * kRows * 4)->x);
         }
         own_row[ch] = cpt[merged_row + lanes[ch]];
         my_cp[ch] = q ? cpt[(q - 1) * HUFD_DEC_LANES + lanes[ch]] : 0u;
