@@ -5082,12 +5082,12 @@ __host__ __device__ constexpr u32 emit_lds_bytes(u32 stage_bytes) {
     return (u32)sizeof(emit_shared<LB>) - HUFD_DEC_STAGE_BYTES + stage_bytes;
 }
 
-template <u32 LB, bool TAIL, u32 SURE = 0> /* TAIL: the chunks listed in tail_chunks (they may hold the end of a stream); else all the others.
+template <u32 LB, bool TAIL, u32 SURE = 0> /* TAIL: a chunk that may hold the end of a stream; else one inside a stream.
                                              * SURE: the codes that are certain to start in a row, when the launch knows (0: asked of the coder at run time) */
-__global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_kernel(
-    hufd_tables tb,
+__device__ __forceinline__ void dec_emit_fast_chunk(
+    const u32 c,
+    const hufd_tables &tb,
     const hufd_chunk_rec *chunk_rec,
-    const u32 *tail_chunks,
     const u8 *d_in,
     u8 *d_out,
     const u16 *cp_tab,
@@ -5113,7 +5113,6 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
     const u32 q = TAIL ? t % kQuarters : t / kEmitHalf;
     const u32 lanes[kEmitChains] = {TAIL ? 2 * (t / kQuarters) : t % kEmitHalf,
                                     TAIL ? 2 * (t / kQuarters) + 1 : t % kEmitHalf + kEmitHalf};
-    const u32 c = TAIL ? tail_chunks[blockIdx.x] : blockIdx.x;
     /* the table entries this thread will put into LDS: asked for first, they depend on nothing */
     constexpr u32 kLutPerThread = ((1u << LB) + kEmitFastThreads - 1) / kEmitFastThreads;
     u32 lut_raw[kLutPerThread];
@@ -5373,6 +5372,68 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
         }
     }
     HUFD_STAMP(1, 5);
+}
+
+template <u32 LB, bool TAIL, u32 SURE = 0> /* TAIL: the chunks listed in tail_chunks (they may hold the end of a stream); else all the others */
+__global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_kernel(
+    hufd_tables tb,
+    const hufd_chunk_rec *chunk_rec,
+    const u32 *tail_chunks,
+    const u8 *d_in,
+    u8 *d_out,
+    const u16 *cp_tab,
+    const u16 *lane_count,
+    const u8 *chunk_regular,
+    const u32 *chunk_fn,
+    const u32 *chunk_entry,
+    const u64 *chunk_base,
+    hufd_dec_result *results,
+    u32 *slow_list, /* chunks left to dec_emit_kernel */
+    u32 *slow_count,
+    u32 *dense_list, /* chunks with more symbols than the stage holds: left to dec_emit_big_kernel */
+    u32 *dense_count,
+    u32 stage_limit /* symbols the stage of this launch holds (HUFD_DEC_STAGE_BYTES, or less: emit_lds_bytes) */) {
+    dec_emit_fast_chunk<LB, TAIL, SURE>(
+        TAIL ? tail_chunks[blockIdx.x] : blockIdx.x, tb, chunk_rec, d_in, d_out, cp_tab, lane_count, chunk_regular, chunk_fn,
+        chunk_entry, chunk_base, results, slow_list, slow_count, dense_list, dense_count, stage_limit);
+}
+
+/*
+ * The chunks dec_emit_fast left because they hold more symbols than its stage (short codes: up to 2 x the stage's worth):
+ * the same walk in ONE pass with a stage twice as long -- two workgroups per CU instead of four -- by resident workgroups
+ * that take turns over the list.  (Two passes over the small stage, dec_emit_dense, cost 4.7 times dec_emit_fast's time
+ * per symbol: 660 us for 256 MiB of 5.5-bit symbols.)
+ */
+constexpr u32 kEmitBigStage = 2 * HUFD_DEC_STAGE_BYTES;
+
+template <u32 LB, u32 SURE>
+__global__ __launch_bounds__(kEmitFastThreads, 4) void dec_emit_big_kernel(
+    hufd_tables tb,
+    const hufd_chunk_rec *chunk_rec,
+    const u8 *d_in,
+    u8 *d_out,
+    const u16 *cp_tab,
+    const u16 *lane_count,
+    const u8 *chunk_regular,
+    const u32 *chunk_fn,
+    const u32 *chunk_entry,
+    const u64 *chunk_base,
+    hufd_dec_result *results,
+    u32 *slow_list,
+    u32 *slow_count,
+    const u32 *big_list,
+    const u32 *big_count) {
+    const u32 n = *big_count;
+    for (u32 k = blockIdx.x; k < n; k += gridDim.x) {
+        if (chunk_rec[big_list[k]].valid < HUFD_DEC_CHUNK_BYTES + 8u) {
+            continue; /* holds the end of its stream: dec_emit_dense's, which walks the stream's last symbols too */
+        }
+        /* (a chunk that does not go through here after all is left to the long way, not listed for this kernel again) */
+        dec_emit_fast_chunk<LB, false, SURE>(
+            big_list[k], tb, chunk_rec, d_in, d_out, cp_tab, lane_count, chunk_regular, chunk_fn, chunk_entry, chunk_base, results,
+            slow_list, slow_count, slow_list, slow_count, kEmitBigStage);
+        __syncthreads(); /* the table and the stage are written again */
+    }
 }
 
 /*
@@ -5796,8 +5857,12 @@ __global__ __launch_bounds__(kEmitFastThreads, 2) void dec_emit_dense_kernel(
     const u32 *list,
     const u32 *list_count,
     u32 *slow_list,
-    u32 *slow_count) {
+    u32 *slow_count,
+    const hufd_chunk_rec *only_ends /* not NULL: only the chunks that hold the end of a stream (dec_emit_big took the others) */) {
     for (u32 i = blockIdx.x; i < *list_count; i += gridDim.x) {
+        if (only_ends && only_ends[list[i]].valid >= HUFD_DEC_CHUNK_BYTES + 8u) {
+            continue;
+        }
         dec_emit_dense_chunk<LB>(
             tb, items, chunk_item, d_in, d_out, cp_tab, lane_count, chunk_regular, chunk_fn, chunk_entry, chunk_base, results,
             slow_list, slow_count, list[i]);
@@ -5909,6 +5974,19 @@ int hufk_init(void) {
         e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&dec_emit_fast_kernel<12, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     }
+#define HUFK_ALLOW_BIG_LDS(LBV, SUREV)                                                                                  \
+    if (e == hipSuccess) {                                                                                             \
+        e = hipFuncSetAttribute(                                                                                       \
+            reinterpret_cast<const void *>(&dec_emit_big_kernel<LBV, SUREV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+            lds_max);                                                                                                  \
+    }
+    HUFK_ALLOW_BIG_LDS(10, 2)
+    HUFK_ALLOW_BIG_LDS(10, 3)
+    HUFK_ALLOW_BIG_LDS(10, 4)
+    HUFK_ALLOW_BIG_LDS(10, 5)
+    HUFK_ALLOW_BIG_LDS(12, 2)
+    HUFK_ALLOW_BIG_LDS(12, 3)
+#undef HUFK_ALLOW_BIG_LDS
     if (e == hipSuccess) {
         e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&dec_sync_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -6381,7 +6459,40 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             (void)hipEventRecord((hipEvent_t)a->join_event, (hipStream_t)a->side_stream);
             (void)hipStreamWaitEvent(st, (hipEvent_t)a->join_event, 0);
         }
-        /* chunks of short codes (more symbols than one stage): a resident grid takes turns over their list */
+        /* chunks of short codes (more symbols than one stage): resident workgroups with a stage twice as long take turns
+         * over their list */
+        bool big = false;
+#define HUFK_LAUNCH_EMIT_BIG(LBV, SUREV)                                                                                \
+    do {                                                                                                               \
+        const uint32_t lds = emit_lds_bytes<LBV>(kEmitBigStage);                                                       \
+        hipLaunchKernelGGL(                                                                                            \
+            (dec_emit_big_kernel<LBV, SUREV>),                                                                         \
+            dim3(persistent_grid(dec_emit_big_kernel<LBV, SUREV>, kEmitFastThreads, lds, a->n_chunks)),                 \
+            dim3(kEmitFastThreads), lds, st, a->tables, a->chunk_rec, (const u8 *)a->d_in, (u8 *)a->d_out,             \
+            (const u16 *)a->cp_tab, (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn, \
+            (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results, a->emit_list, a->emit_count,          \
+            (const u32 *)a->dense_list, (const u32 *)a->dense_count);                                                  \
+        big = true;                                                                                                    \
+    } while (0)
+        if (a->tables.lut_bits <= 10) {
+            switch (emit_sure) {
+                case 2: HUFK_LAUNCH_EMIT_BIG(10, 2); break;
+                case 3: HUFK_LAUNCH_EMIT_BIG(10, 3); break;
+                case 4: HUFK_LAUNCH_EMIT_BIG(10, 4); break;
+                case 5: HUFK_LAUNCH_EMIT_BIG(10, 5); break;
+                default: break;
+            }
+        } else {
+            switch (emit_sure) {
+                case 2: HUFK_LAUNCH_EMIT_BIG(12, 2); break;
+                case 3: HUFK_LAUNCH_EMIT_BIG(12, 3); break;
+                default: break;
+            }
+        }
+#undef HUFK_LAUNCH_EMIT_BIG
+        /* the two-pass kernel: the listed chunks that hold the end of a stream -- or all of them, where there is no
+         * build of the other for this coder's number of certain steps */
+        const hufd_chunk_rec *only_ends = big ? a->chunk_rec : nullptr;
         if (a->tables.lut_bits <= 10) {
             const uint32_t lds = (uint32_t)sizeof(emit_shared<10>);
             hipLaunchKernelGGL(
@@ -6389,7 +6500,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
                 dim3(kEmitFastThreads), lds, st, a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, (u8 *)a->d_out,
                 (const u16 *)a->cp_tab, (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn,
                 (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results, (const u32 *)a->dense_list,
-                (const u32 *)a->dense_count, a->emit_list, a->emit_count);
+                (const u32 *)a->dense_count, a->emit_list, a->emit_count, only_ends);
         } else {
             const uint32_t lds = (uint32_t)sizeof(emit_shared<12>);
             hipLaunchKernelGGL(
@@ -6397,7 +6508,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
                 dim3(kEmitFastThreads), lds, st, a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, (u8 *)a->d_out,
                 (const u16 *)a->cp_tab, (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn,
                 (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results, (const u32 *)a->dense_list,
-                (const u32 *)a->dense_count, a->emit_list, a->emit_count);
+                (const u32 *)a->dense_count, a->emit_list, a->emit_count, only_ends);
         }
         hipLaunchKernelGGL(
             dec_emit_kernel,
