@@ -3763,8 +3763,11 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     u16 *lane_count,
     u8 *chunk_regular,
     u32 *tail_entry, /* [chunk] TAIL: the state in which the last whole lane leaves (dec_sync_tail picks it up) */
-    u32 *slow_list,
-    u32 *slow_count) {
+    u32 *slow_list, /* chunks inside a stream that are not regular by this kernel's rules but whose first sub-chunk's walks
+                     * do meet: dec_sync_guess tries them its way */
+    u32 *slow_count,
+    u32 *long_list, /* the others that are not regular: dec_sync's (may be the same list as slow_list) */
+    u32 *long_count) {
 
     lean_shared<LB> &sh = *reinterpret_cast<lean_shared<LB> *>(dyn_lds);
     const u32 ns = tb.n_states;
@@ -3794,7 +3797,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     if (!eligible) {
         if (lane == 0) {
             chunk_regular[c] = 0;
-            slow_list[atomicAdd(slow_count, 1u)] = c;
+            long_list[atomicAdd(long_count, 1u)] = c;
         }
         return;
     }
@@ -3863,6 +3866,9 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     }
     const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
     bool ok = !active || (one && settled);
+    if (lane == 0) {
+        sh.pad[2] = one; /* sub-chunk 0's own walks have met (whatever the wave's other lanes' have): what dec_sync_guess needs of a chunk */
+    }
 
     /* R: the one walk from the meeting bit to the end of the sub-chunk */
     u32 state = rw.state_at(meet_bit, 0);
@@ -3947,7 +3953,11 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     if (sh.bad) {
         if (lane == 0) {
             chunk_regular[c] = 0;
-            slow_list[atomicAdd(slow_count, 1u)] = c;
+            if (TAIL || !sh.pad[2]) {
+                long_list[atomicAdd(long_count, 1u)] = c;
+            } else {
+                slow_list[atomicAdd(slow_count, 1u)] = c;
+            }
         }
         return;
     }
@@ -3999,6 +4009,321 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         /* (TAIL: symbols of the whole lanes only, and no exit yet: dec_sync_tail adds the stream's last symbols and how it ends) */
         chunk_fn[(u64)c * ns + lane] =
             cand_reached ? wide_pack(false, TAIL ? 0u : last_exit, cand_count + rest) : wide_pack(true, 0, cand_dead);
+    }
+}
+
+/* ------------------------------------------------------------------ decode: sync, second chance for chunks inside a stream */
+
+/*
+ * dec_sync_lean wants ALL entry states of EVERY sub-chunk to fall into one walk within 16 rows.  The test coder does
+ * that; a coder that synchronises slowly on its own kind of data does not (codes of 4 .. 12 bits on symbols drawn to
+ * match them: a quarter of the sub-chunks still have several heads after 16 rows), so none of its chunks is regular
+ * and all of them take the long way at a tenth of the speed.  This kernel takes the chunks dec_sync_lean gave up on
+ * (its list) and asks less: only sub-chunk 0, whose entry state nobody in the chunk can know, goes through phase U
+ * and the candidates' walks as there.  Every other lane starts ONE walk kGuessRows rows in front of its sub-chunk
+ * (a window without a code moves it one bit on), takes where that walk crosses into the sub-chunk as its entry state
+ * -- a guess -- and walks on to the end, counting.  Then lane j's guess is checked against lane j - 1's exit state,
+ * true by induction from lane 0; who guessed wrong walks again from the true state (its exit may change: the check
+ * is repeated).  Exact: at the end every lane's walk starts where its neighbour's ends.  What is not settled after
+ * kGuessRounds, or not regular for another reason, goes on the next list, for dec_sync.  Same tables out.  (As the
+ * FIRST kernel for every chunk this was measured slower than dec_sync_lean on the test coder: 0.63 against 0.44 ms.)
+ */
+constexpr u32 kGuessRows = 8;
+constexpr u32 kGuessRounds = 6;
+/* a window without a code: one bit on, and a mark above the count that is looked at once a row (counts stay below 512) */
+constexpr u32 kGuessDeadMark = 1u << 25;
+constexpr u32 kGuessDeadEntry = kGuessDeadMark + 0x10000u - 1u;
+
+template <u32 LB, u32 SURE>
+__device__ __forceinline__ void dec_sync_guess_chunk(
+    const u32 c,
+    const hufd_tables &tb,
+    const hufd_chunk_rec *chunk_rec,
+    const u8 *d_in,
+    u16 *fn_tab,
+    u16 *cp_tab,
+    u32 *chunk_fn,
+    u16 *lane_count,
+    u8 *chunk_regular,
+    u32 *slow_list,
+    u32 *slow_count) {
+
+    lean_shared<LB> &sh = *reinterpret_cast<lean_shared<LB> *>(dyn_lds);
+    u32 *again = sh.pad; /* [2]: somebody walks again, one flag for the even rounds, one for the odd ones */
+    const u32 ns = tb.n_states;
+    const u32 lane = threadIdx.x;
+    const hufd_chunk_rec rec = chunk_rec[c];
+    const u8 *src = d_in + rec.src_off;
+    const row_walk rw(LB, tb.max_bits);
+    const u32 table = lds_offset_of(sh.wlut);
+    const bool eligible = tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS && tb.min_bits >= 3 && rw.sure == SURE &&
+                          (table & ((4u << LB) - 1u)) == 0;
+    if (!eligible) {
+        if (lane == 0) {
+            slow_list[atomicAdd(slow_count, 1u)] = c;
+        }
+        return;
+    }
+
+    /* First what decides whether the chunk can be regular at all, and only that: U for sub-chunk 0 -- all entry states
+     * as one mask of heads per row, until one is left -- by wave 0 on words it loads for this alone.  If its walks do not
+     * meet, nothing the other lanes find out helps: the chunk goes on at once, having cost a table and sixteen rows (a
+     * stream that never synchronises gets here with every chunk). */
+    for (u32 i = lane; i < (1u << LB); i += HUFD_DEC_LANES) {
+        const u32 len = tb.dec_lut[i >> (LB - tb.lut_bits)] & 0xFFu;
+        sh.wlut[i] = len ? 0x10000u - len : kGuessDeadEntry;
+        sh.hops[i] = (u16)(len ? 1u << len : 0u);
+    }
+    if (lane == 0) {
+        sh.bad = 0;
+        again[0] = 0;
+    }
+    __syncthreads();
+    u32 meet_row = 0, meet_bit = 0; /* wave 0: where sub-chunk 0's walks meet */
+    if (lane < kWave) {
+        u32 w0[kFastMaxMeet + 1];
+#pragma unroll
+        for (u32 r = 0; r <= kFastMaxMeet; ++r) {
+            w0[r] = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(src + 4 * r)->x);
+        }
+        u64 heads = lane == 0 ? (1ull << ns) - 1ull : 0ull;
+        bool one = false, settled = false;
+#pragma unroll
+        for (u32 r = 0; r < kFastMaxMeet; ++r) {
+            if (!settled) {
+                heads = union_row_fast<LB>(heads, w0[r], w0[r + 1], sh.hops);
+                one = heads != 0 && (heads & (heads - 1)) == 0;
+                meet_row = r + 1;
+                settled = __all(one || heads == 0);
+            }
+        }
+        meet_bit = __shfl(one ? (u32)__builtin_ctzll(heads) : 0u, 0); /* bits into row meet_row */
+        if (lane == 0) {
+            if (!(one && settled)) {
+                sh.bad = 1;
+            }
+#pragma unroll
+            for (u32 r = 0; r <= kFastMaxMeet; ++r) {
+                sh.sub0[r] = w0[r];
+            }
+        }
+    }
+    __syncthreads();
+    if (sh.bad) {
+        if (lane == 0) {
+            slow_list[atomicAdd(slow_count, 1u)] = c;
+        }
+        return;
+    }
+
+    u32 w[kFastRows], pw[kGuessRows];
+    {
+        const unaligned_uint4 *line = reinterpret_cast<const unaligned_uint4 *>(src + (u64)lane * HUFD_DEC_SUB_BYTES);
+        /* (lane 0 reads its own first rows here: never looked at, and inside the chunk) */
+        const unaligned_uint4 *front =
+            reinterpret_cast<const unaligned_uint4 *>(src + (u64)lane * HUFD_DEC_SUB_BYTES - (lane ? kGuessRows * 4 : 0u));
+#pragma unroll
+        for (u32 q = 0; q < kGuessRows / 4; ++q) {
+            const unaligned_uint4 v = front[q];
+            pw[4 * q + 0] = __builtin_bswap32(v.x);
+            pw[4 * q + 1] = __builtin_bswap32(v.y);
+            pw[4 * q + 2] = __builtin_bswap32(v.z);
+            pw[4 * q + 3] = __builtin_bswap32(v.w);
+        }
+#pragma unroll
+        for (u32 q = 0; q < kSubWords / 4; ++q) {
+            const unaligned_uint4 v = line[q];
+            w[4 * q + 0] = __builtin_bswap32(v.x);
+            w[4 * q + 1] = __builtin_bswap32(v.y);
+            w[4 * q + 2] = __builtin_bswap32(v.z);
+            w[4 * q + 3] = __builtin_bswap32(v.w);
+        }
+        w[kSubWords] = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(src + (u64)(lane + 1) * HUFD_DEC_SUB_BYTES)->x);
+    }
+
+    /* the walk in front of the sub-chunk (lanes >= 1): where it crosses into the sub-chunk is the guess */
+    u32 guess = 0;
+    bool guess_ok = true;
+    if (lane) {
+        u32 st = rw.state_at(0, 0);
+#pragma unroll
+        for (u32 r = 0; r < kGuessRows; ++r) {
+            st = lean_row<SURE>(st, pw[r], r + 1 < kGuessRows ? pw[r + 1] : w[0], table, rw);
+            st += 32u;
+        }
+        guess = rw.offset_of(st);
+        guess_ok = guess < ns;
+        guess = guess_ok ? guess : 0u;
+    }
+
+    /* the one walk of a sub-chunk from its entry state (lane 0: from the meeting bit in row meet_row), then the guesses
+     * against the exit states; whoever guessed wrong walks again, from the true entry state (the others stand by) */
+    u32 cp_state[kQuarters - 1] = {0, 0, 0};
+    u32 state = 0, exit_bit = 0, entry = 0;
+    bool ok = true;
+    bool walking = true;
+    u32 from_bit = lane ? guess : meet_bit;
+    const u32 first_row = lane ? 0u : meet_row; /* (meet_row >= 1) */
+    for (u32 round = 0;; ++round) {
+        if (__any(walking)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            /* (the words as values the compiler cannot trace through the rounds: it otherwise builds every row's 64-bit
+             * window register pair once, in front of the loop -- twice the registers, and a value spilled inside this
+             * divergent loop has come back wrong on this toolchain) */
+#pragma unroll
+            for (u32 r = 0; r < kFastRows; ++r) {
+                asm volatile("" : "+v"(w[r]));
+            }
+#endif
+            u32 st = rw.state_at(from_bit, 0);
+            bool dd = false;
+#pragma unroll
+            for (u32 r = 0; r < kSubWords; ++r) {
+                if (walking && r >= first_row) {
+                    if (r && r % (kSubWords / kQuarters) == 0) {
+                        cp_state[r / (kSubWords / kQuarters) - 1] = st;
+                    }
+                    st = lean_row<SURE>(st, w[r], w[r + 1], table, rw);
+                    dd = dd || st >= kGuessDeadMark; /* (it walks on, a bit at a time: nothing of it is kept) */
+                    st += 32u;
+                }
+            }
+            if (walking) {
+                state = st & (kGuessDeadMark - 1u);
+                exit_bit = rw.offset_of(st);
+                ok = !dd && exit_bit < ns;
+                sh.exit_state[lane] = ok ? exit_bit : 0xFFu;
+            }
+        }
+        __syncthreads();
+        entry = lane ? sh.exit_state[lane - 1] : 0u;
+        walking = lane != 0 && entry < ns && (!guess_ok || entry != guess);
+        if (walking) {
+            again[round & 1u] = 1;
+            from_bit = guess = entry;
+            guess_ok = true;
+        }
+        if (lane == 0) {
+            again[(round & 1u) ^ 1u] = 0; /* (the next round's: last read a round ago, in front of this round's barrier) */
+        }
+        __syncthreads();
+        if (!again[round & 1u]) {
+            break;
+        }
+        if (round == kGuessRounds) {
+            ok = false; /* (every lane leaves the loop in the same round) */
+            break;
+        }
+    }
+    ok = ok && (lane == 0 || entry < ns);
+    const u32 count = state >> 16; /* symbols of the true path that start in my sub-chunk (lane 0: from the meeting bit on) */
+
+    /* sub-chunk 0 from every entry state the chunk may be entered in (threads 0 .. ns-1), step by step to the meeting
+     * row: the count of a walk that dies has to be right */
+    u32 cand_count = 0, cand_dead = 0;
+    bool cand_reached = false;
+    u64 cand_alive = 0;
+    if (lane < kWave) {
+        const u32 target = meet_bit, tail0 = __shfl(count, 0); /* sub-chunk 0 is lane 0's */
+        u32 st = rw.state_at(lane < ns ? lane : 0u, 0);
+        bool dd = false;
+        u32 hi = sh.sub0[0];
+        for (u32 r = 0; r < meet_row; ++r) {
+            const u32 lo = sh.sub0[r + 1];
+            const u64 pair = ((u64)hi << 32) | lo;
+            while (!dd && (st & 0xFFFFu) > rw.thr) {
+                const u32 e = lds_word_at(((u32)(pair >> (st & 63u)) & rw.mask) | table);
+                if (e & kGuessDeadMark) {
+                    dd = true;
+                    cand_dead = st >> 16; /* the symbols in front of the window without a code */
+                } else {
+                    st += e;
+                }
+            }
+            st = rw.next_row(st, dd);
+            hi = lo;
+        }
+        cand_reached = !dd && lane < ns && rw.offset_of(st) == target;
+        cand_alive = __ballot(cand_reached);
+        cand_count = (st >> 16) + tail0;
+    }
+
+    const u32 wsum = wave_sum(lane ? count : 0u);
+    if ((lane & (kWave - 1)) == 0) {
+        sh.wave_sum[lane / kWave] = wsum;
+    }
+    if (!ok) {
+        sh.bad = 1;
+    }
+    __syncthreads();
+    if (sh.bad) {
+        if (lane == 0) {
+            slow_list[atomicAdd(slow_count, 1u)] = c; /* (chunk_regular[c] is 0 already: dec_sync_lean's) */
+        }
+        return;
+    }
+
+    /* the tables dec_scan and dec_emit read (dec_sync_fast's).  (The lane number as a value the compiler cannot trace:
+     * where the records go is worked out here, not in front of the walks where the registers are needed.) */
+    u32 lane_o = lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(lane_o));
+#endif
+    u16 *fn_out = fn_tab + (u64)c * ns * HUFD_DEC_LANES;
+    u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane_o;
+#pragma unroll
+    for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+        /* lane 0: a checkpoint in front of the meeting row is not on its walk (dec_emit_fast goes on from the chunk's entry) */
+        const bool have = lane != 0 || (qq + 1) * (kSubWords / kQuarters) >= meet_row;
+        const u32 tail = count - (cp_state[qq] >> 16), bits = rw.offset_of(cp_state[qq]);
+        cp[qq * HUFD_DEC_LANES] = (u16)(have ? 0x8000u | (bits << 11) | tail : 0u);
+    }
+    lane_count[(u64)c * HUFD_DEC_LANES + lane_o] = (u16)count;
+    cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((lane ? 1u << entry : (u32)cand_alive) | (exit_bit << 12));
+    if (lane == 0) {
+        chunk_regular[c] = 1;
+    }
+    if (lane < ns) {
+        u32 rest = 0;
+#pragma unroll
+        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
+            rest += sh.wave_sum[wv];
+        }
+        const u32 first_exit = sh.exit_state[0];
+        const u32 last_exit = sh.exit_state[HUFD_DEC_LANES - 1];
+        fn_out[(u64)lane_o * HUFD_DEC_LANES] =
+            cand_reached ? fn_pack(false, first_exit, cand_count & 0x7FFu) : fn_pack(true, 0, cand_dead);
+        chunk_fn[(u64)c * ns + lane_o] =
+            cand_reached ? wide_pack(false, last_exit, cand_count + rest) : wide_pack(true, 0, cand_dead);
+    }
+}
+
+template <u32 LB, u32 SURE>
+__global__ __launch_bounds__(HUFD_DEC_LANES, 4) void dec_sync_guess_kernel(
+    hufd_tables tb,
+    const hufd_chunk_rec *chunk_rec,
+    const u8 *d_in,
+    u16 *fn_tab,
+    u16 *cp_tab,
+    u32 *chunk_fn,
+    u16 *lane_count,
+    u8 *chunk_regular,
+    const u32 *given_up,       /* dec_sync_lean's list ... */
+    const u32 *given_up_count,
+    u32 *slow_list,            /* ... and the one dec_sync works through */
+    u32 *slow_count) {
+    const u32 n = *given_up_count;
+    for (u32 k = blockIdx.x; k < n; k += gridDim.x) {
+        const u32 c = given_up[k];
+        if (chunk_rec[c].valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
+            /* holds the end of its stream: not this kernel's */
+            if (threadIdx.x == 0) {
+                slow_list[atomicAdd(slow_count, 1u)] = c;
+            }
+            continue;
+        }
+        dec_sync_guess_chunk<LB, SURE>(c, tb, chunk_rec, d_in, fn_tab, cp_tab, chunk_fn, lane_count, chunk_regular, slow_list, slow_count);
+        __syncthreads(); /* the tables in LDS are written again */
     }
 }
 
@@ -6252,6 +6577,18 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         const auto sync = ns <= 8 ? dec_sync_kernel<8> : (ns <= 10 ? dec_sync_kernel<10> : dec_sync_kernel<12>);
         (void)hipMemsetAsync(a->slow_count, 0, sizeof(uint32_t), st);
         const bool some_inside = a->n_tail < a->n_chunks; /* chunks with a whole chunk + 8 bytes of stream left */
+        /* two lists of chunks that are not regular by dec_sync_lean's rules: the ones dec_sync_guess may still take
+         * (inside a stream, first sub-chunk's walks meet) and the ones for the long way.  The second is the emit stage's
+         * list, free until then; one list where there is no dec_sync_guess for the launch. */
+        const uint32_t sure_of_launch = row_walk(a->tables.lut_bits <= 10 ? 10u : 12u, a->tables.max_bits).sure;
+        const bool guessing = some_inside && a->old_sync == 0 && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS &&
+                              (a->tables.lut_bits <= 10 ? sure_of_launch >= 2 && sure_of_launch <= 5
+                                                        : sure_of_launch >= 2 && sure_of_launch <= 3);
+        u32 *lean_long_list = guessing ? a->emit_list : a->slow_list;
+        u32 *lean_long_count = guessing ? a->emit_count : a->slow_count;
+        if (guessing) {
+            (void)hipMemsetAsync(a->emit_count, 0, sizeof(uint32_t), st);
+        }
         /* A few chunks that streams end in beside many inside streams (one long stream: ONE): their kernels are tiny
          * and, one after the other behind the big ones, cost a tenth of the decode time in launch and drain.  They run on
          * a second stream of the engine's, beside the big kernels, forked off and joined with events. */
@@ -6272,14 +6609,14 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             (dec_sync_lean_kernel<LBV, SUREV, true>), dim3(a->n_tail), dim3(HUFD_DEC_LANES),                            \
             (uint32_t)sizeof(lean_shared<LBV>), tst, a->tables, a->chunk_rec, a->tail_chunks,                           \
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
-            a->slow_list, a->slow_count);                                                                              \
+            a->slow_list, a->slow_count, lean_long_list, lean_long_count);                                             \
     }                                                                                                                  \
     if (some_inside) {                                                                                                 \
         hipLaunchKernelGGL(                                                                                            \
             (dec_sync_lean_kernel<LBV, SUREV, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES),                         \
             (uint32_t)sizeof(lean_shared<LBV>), st, a->tables, a->chunk_rec, a->tail_chunks,                            \
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
-            a->slow_list, a->slow_count);                                                                              \
+            a->slow_list, a->slow_count, lean_long_list, lean_long_count);                                             \
     }
         if (!a->old_sync && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS) {
             lean = true;
@@ -6337,11 +6674,44 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             (void)hipEventRecord((hipEvent_t)a->join_event, tst);
             (void)hipStreamWaitEvent(st, (hipEvent_t)a->join_event, 0);
         }
+        /* the chunks inside streams that dec_sync_lean gave up on: a second chance that asks less of the coder
+         * (dec_sync_guess); what that gives up on goes on a second list (the emit stage's, free until then) */
+        const u32 *long_list = a->slow_list, *long_count = a->slow_count;
+        if (lean && guessing) {
+            bool guessed = true;
+#define HUFK_LAUNCH_SYNC_GUESS(LBV, SUREV)                                                                              \
+    hipLaunchKernelGGL(                                                                                                \
+        (dec_sync_guess_kernel<LBV, SUREV>),                                                                           \
+        dim3(persistent_grid(dec_sync_guess_kernel<LBV, SUREV>, HUFD_DEC_LANES, (uint32_t)sizeof(lean_shared<LBV>),     \
+                             a->n_chunks)),                                                                            \
+        dim3(HUFD_DEC_LANES), (uint32_t)sizeof(lean_shared<LBV>), st, a->tables, a->chunk_rec, (const u8 *)a->d_in,     \
+        a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, (const u32 *)a->slow_list,                 \
+        (const u32 *)a->slow_count, a->emit_list, a->emit_count)
+            if (a->tables.lut_bits <= 10) {
+                switch (sure) {
+                    case 2: HUFK_LAUNCH_SYNC_GUESS(10, 2); break;
+                    case 3: HUFK_LAUNCH_SYNC_GUESS(10, 3); break;
+                    case 4: HUFK_LAUNCH_SYNC_GUESS(10, 4); break;
+                    case 5: HUFK_LAUNCH_SYNC_GUESS(10, 5); break;
+                    default: guessed = false; break;
+                }
+            } else {
+                switch (sure) {
+                    case 2: HUFK_LAUNCH_SYNC_GUESS(12, 2); break;
+                    case 3: HUFK_LAUNCH_SYNC_GUESS(12, 3); break;
+                    default: guessed = false; break;
+                }
+            }
+#undef HUFK_LAUNCH_SYNC_GUESS
+            if (guessed) {
+                long_list = a->emit_list;
+                long_count = a->emit_count;
+            }
+        }
         hipLaunchKernelGGL(
             sync, dim3(persistent_grid(sync, HUFD_DEC_LANES, dec_sync_lds_bytes(&a->tables), a->n_chunks)),
             dim3(HUFD_DEC_LANES), dec_sync_lds_bytes(&a->tables), st, a->tables, a->items, a->chunk_item, a->n_chunks,
-            (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, (const u32 *)a->slow_list,
-            (const u32 *)a->slow_count);
+            (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, long_list, long_count);
     }
     stage_mark(a->stage_events, 1, st);
     hipLaunchKernelGGL(
