@@ -1,4 +1,4 @@
-# GPU box: the -m gpu suite, the stream and cfg4 bench lines, and the mid-size item batches (also with items above 128 / 512 bytes going to waves instead of single threads)
+# GPU box: the -m gpu suite, the stream and cfg4 bench lines, and the mid-size item batches
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1; tail -3 gpurun_out/gpu_tests.log
 timeout 300 python bench.py --no-cpu-baseline > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -3 gpurun_out/bench.err
@@ -8,5 +8,3 @@ timeout 300 python bench.py --no-cpu-baseline --workload cfg4 > gpurun_out/bench
 python -c "
 import json; d=json.load(open('gpurun_out/bench_cfg4.json')); print('cfg4', d['value'], d['kernel_ms'])"
 timeout 300 python profiles/tools/mid_items.py 2>&1 | tail -8
-echo "tiny limit 512"; AWS_HUFFMAN_AMD_TUNE_ENC_TINY=512 timeout 300 python profiles/tools/mid_items.py 600 1024 2048 2>&1 | tail -8
-echo "tiny limit 128"; AWS_HUFFMAN_AMD_TUNE_ENC_TINY=128 timeout 300 python profiles/tools/mid_items.py 600 1024 2048 2>&1 | tail -8

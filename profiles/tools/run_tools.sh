@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG/tools
 mkdir -p "$OUT"
 cd "$ROOT"
-for tool in other_distributions tiny_items mid_items host_path_rate small_call_latency long_code_stream; do
-    timeout 600 python3 profiles/tools/$tool.py > "$OUT/$tool.txt" 2> "$OUT/$tool.err"
+for tool in other_distributions tiny_items mid_items host_path_rate small_call_latency long_code_stream coder_survey; do
+    timeout 900 python3 profiles/tools/$tool.py > "$OUT/$tool.txt" 2> "$OUT/$tool.err"
     echo "== $tool"; tail -4 "$OUT/$tool.txt"
 done
