@@ -76,6 +76,11 @@ struct aws_huffman_amd_decode_result {
  * table-shaped leaves the engine encode-only
  * (aws_huffman_amd_engine_can_decode() == false; decode entry points raise
  * AWS_ERROR_UNSUPPORTED_OPERATION).  There is no CPU path to fall back to.
+ *
+ * An engine (its plans included) is one host thread's at a time: launches of one
+ * engine's plans are made one after the other -- they share the engine's second
+ * stream and its events.  Threads that work side by side take an engine each
+ * (aws_huffman_amd_shards does that per device).
  */
 AWS_COMPRESSION_API
 int aws_huffman_amd_engine_new(
