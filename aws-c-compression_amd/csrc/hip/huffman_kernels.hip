@@ -3767,8 +3767,12 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
                      * do meet: dec_sync_guess tries them its way */
     u32 *slow_count,
     u32 *long_list, /* the others that are not regular: dec_sync's (may be the same list as slow_list) */
-    u32 *long_count) {
+    u32 *long_count,
+    const u32 *gate /* NULL, or dec_onepass's ctl: the chunks inside streams are this kernel's only if that one gave up */) {
 
+    if (!TAIL && gate && gate[0] == 0) {
+        return;
+    }
     lean_shared<LB> &sh = *reinterpret_cast<lean_shared<LB> *>(dyn_lds);
     const u32 ns = tb.n_states;
     const u32 lane = threadIdx.x;
@@ -4896,20 +4900,31 @@ __global__ __launch_bounds__(256) void dec_scan_small_kernel(
     u32 *chunk_entry,
     u64 *chunk_base,
     hufd_dec_item_state *states,
-    hufd_dec_result *results) {
+    hufd_dec_result *results,
+    const u32 *fuse_ctl /* NULL, or dec_onepass's ctl: [0] == 0 says that kernel has decoded every chunk inside a stream */) {
 
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) {
         return;
     }
     const hufd_dec_item it = items[i];
-    if (it.n_chunks > HUFD_SCAN_SMALL_MAX || it.tiny) {
+    if (it.tiny) {
+        return;
+    }
+    /* the chunks in front of the one(s) the stream ends in: with dec_onepass done, the scan starts behind them, from what
+     * the last of them left (and then takes an item of any length: there are at most two chunks to go) */
+    const u32 inside = fuse_ctl && fuse_ctl[0] == 0 && it.in_len >= 8 ? (u32)((it.in_len - 8) / HUFD_DEC_CHUNK_BYTES) : 0u;
+    if (it.n_chunks > HUFD_SCAN_SMALL_MAX && inside == 0) {
         return;
     }
     u32 state = it.first_bit;
     u64 total = 0;
     bool stopped = false;
-    for (u32 k = 0; k < it.n_chunks; ++k) {
+    if (inside) {
+        state = chunk_entry[it.first_chunk + inside] & 0xFFu;
+        total = chunk_base[it.first_chunk + inside];
+    }
+    for (u32 k = inside; k < it.n_chunks; ++k) {
         const u32 c = it.first_chunk + k;
         chunk_entry[c] = entry_pack(state, !stopped);
         chunk_base[c] = total;
@@ -4961,7 +4976,10 @@ static uint32_t scan_run_lds_bytes(uint32_t ns) {
 }
 
 __global__ __launch_bounds__(256) void dec_scan_runs_kernel(
-    const hufd_dec_item *items, const u32 *runs, u32 ns, const u32 *chunk_fn, u32 *run_fn) {
+    const hufd_dec_item *items, const u32 *runs, u32 ns, const u32 *chunk_fn, u32 *run_fn, const u32 *gate) {
+    if (gate && gate[0] == 0) {
+        return; /* dec_onepass has done the chunks inside the streams: dec_scan_small goes on from there */
+    }
     u32 *fn = reinterpret_cast<u32 *>(dyn_lds);
     u32 *sub = fn + kRunChunks * ns;
     const u32 run = blockIdx.x;
@@ -4983,7 +5001,11 @@ __global__ __launch_bounds__(256) void dec_scan_top_kernel(
     u32 *run_entry,
     u64 *run_base,
     hufd_dec_item_state *states,
-    hufd_dec_result *results) {
+    hufd_dec_result *results,
+    const u32 *gate) {
+    if (gate && gate[0] == 0) {
+        return;
+    }
     u32 *fn = reinterpret_cast<u32 *>(dyn_lds); /* [kTopTile][ns] */
     const u32 i = large_items[2 * blockIdx.x], run0 = large_items[2 * blockIdx.x + 1];
     const hufd_dec_item it = items[i];
@@ -5024,7 +5046,11 @@ __global__ __launch_bounds__(256) void dec_scan_apply_kernel(
     const u32 *run_entry,
     const u64 *run_base,
     u32 *chunk_entry,
-    u64 *chunk_base) {
+    u64 *chunk_base,
+    const u32 *gate) {
+    if (gate && gate[0] == 0) {
+        return;
+    }
     u32 *fn = reinterpret_cast<u32 *>(dyn_lds);
     u32 *sub = fn + kRunChunks * ns;
     u32 *sub_entry = sub + kSubRuns * ns;                           /* [kSubRuns] */
@@ -5068,6 +5094,466 @@ __global__ __launch_bounds__(256) void dec_scan_apply_kernel(
             }
         }
     }
+}
+
+/* ------------------------------------------------------------------ decode: one pass for the chunks inside a stream */
+
+/*
+ * dec_sync_lean + dec_scan + dec_emit_fast read every encoded byte twice and walk every code twice (count, then emit):
+ * 1.65 x the algorithmic HBM traffic and ~33 vector instructions a symbol.  This kernel reads a chunk once and walks
+ * it once.  What makes that possible: the symbols of a walk do not have to wait for their place in the output --
+ * they go to a SLOT of the lane's in LDS while the walk counts them, and the slots are moved to the output when the
+ * counts are known.
+ *
+ *   U   as dec_sync_lean: all entry states of the lane's sub-chunk as one mask of heads per row until one is left
+ *       (meeting row m, the same for the wave; meeting bit per lane);
+ *   R   the one walk from the meeting bit to the end of the sub-chunk, every symbol stored to the lane's slot
+ *       (table entry = symbol << 16 | 0x10000 - length: shift, mask-or, look-up, byte store, two adds a symbol);
+ *       exit state and slot fill of every lane to LDS;
+ *   H   rows 0 .. m-1 again from the true entry state (the neighbour's exit state), symbols stored BEHIND the
+ *       neighbour's R symbols in the neighbour's slot: slot j then holds, in stream order and without a gap, the
+ *       symbols from sub-chunk j's meeting bit to sub-chunk j+1's.  Sub-chunk 0's entry state is the previous
+ *       chunk's exit state, which that chunk publishes the moment its R phase is over (it does not depend on how
+ *       that chunk was entered); until it is read, lanes 0 .. ns-1 of wave 0 walk sub-chunk 0's first rows from every
+ *       entry state into small candidate slots;
+ *   a scan of the slot fills gives every slot its place in the chunk; the chunk's symbol count goes into a
+ *   decoupled look-back over the chunks of the item (one flagged 64-bit word a chunk: exit state, count, inclusive
+ *   prefix) which gives the chunk its place in the item's output; then the slots leave for HBM, eight lanes a slot,
+ *   16 bytes each (the memory system takes any alignment).
+ *
+ * Exactness: the same argument as dec_sync_lean -- every lane's H walk must land on its own meeting bit, no walk may
+ * die, every count must fit its slot, the output must fit the item's capacity.  Whatever is not so (a damaged or cut
+ * stream, a stream that does not synchronise, symbol-dense data, a short output buffer) raises ctl[0] and marks the
+ * chunk's word FAILED; chunks behind it give up when they see either, nothing wrong has been written (a chunk writes
+ * only once every chunk in front of it has published a count), and the kernels of the two-pass road, which are
+ * queued behind this one and look at ctl[0] first, then do the whole launch.  Every wait is bounded the same way.
+ * (source/huffman.c:213-286 is what is reproduced; this is the road of BASELINE configs[2].)
+ */
+constexpr u32 kFuseSlotBytes = 136; /* 34 words: neighbouring lanes' slots two banks apart (a two-way conflict costs a byte store nothing) */
+constexpr u32 kFuseRowMax = 10;     /* more bytes than the codes of one row can be (codes of at least 4 bits), dead walks included */
+constexpr u32 kFuseSlotFill = kFuseSlotBytes - kFuseRowMax; /* a slot that ends up at least this full is not trusted */
+constexpr u32 kFuseCandBytes = 128; /* (16 rows of codes of 5 bits and more, and the slack of a slot) */
+constexpr u64 kFuseIncl = 1ull << 63, kFuseAgg = 1ull << 62, kFuseExit = 1ull << 61, kFuseFail = 1ull << 60;
+constexpr u32 kFuseExitShift = 52;
+constexpr u64 kFuseValue = (1ull << 48) - 1;
+constexpr u32 kFuseSpinLimit = 1u << 13;
+
+template <u32 LB>
+struct fuse_shared {
+    u32 wlut[1u << LB]; /* symbol << 16 | (0x10000 - length) & 0xFFFF, length 48 = no code; at a multiple of its own size */
+    u16 hops[1u << LB]; /* 1 << code length of a window (the head it sends on), 0 = no code */
+    u32 link[HUFD_DEC_LANES]; /* after R: exit state | symbols in the slot << 8 */
+    u32 pos[HUFD_DEC_LANES];  /* where the slot's symbols go, from the chunk's first R symbol */
+    u16 hcnt[HUFD_DEC_LANES]; /* symbols the next lane's H walk added to the slot */
+    u32 sub0[kFastMaxMeet + 4];
+    u32 wave_tot[HUFD_DEC_LANES / 64];
+    u32 wave_meet[HUFD_DEC_LANES / 64];
+    u32 cand_cnt[HUFD_DEC_MAX_STATES]; /* symbols of sub-chunk 0 in front of its meeting bit per entry state, HUFD_NONE32: that walk dies */
+    u32 bad, entry, n0, why;
+    u64 base;
+    u8 cand[HUFD_DEC_MAX_STATES][kFuseCandBytes];
+    u8 dump[64];
+    __attribute__((aligned(16))) u8 slots[HUFD_DEC_LANES * kFuseSlotBytes + 16];
+};
+
+/* lean_row that keeps the symbols: entry = symbol << 16 | -length, the symbol to LDS byte `dst` */
+template <u32 SURE, bool STEP_BY_STEP = false, bool KEEP = true> /* KEEP false: the walk only, no symbol is stored */
+__device__ __forceinline__ u32 fuse_row(u32 state, u32 hi, u32 lo, u32 table, const row_walk &rw, u8 *lds_bytes, u32 &dst) {
+    const u64 pair = ((u64)hi << 32) | lo;
+    if (!STEP_BY_STEP) {
+#pragma unroll
+        for (u32 i = 0; i < SURE; ++i) {
+            const u32 e = lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
+            if (KEEP) {
+                lds_bytes[dst++] = (u8)(e >> 16);
+            }
+            state += e;
+        }
+    }
+    while ((state & 0xFFFFu) > rw.thr) {
+        const u32 e = lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
+        if (KEEP) {
+            lds_bytes[dst++] = (u8)(e >> 16);
+        }
+        state += e;
+    }
+    return state;
+}
+
+template <u32 LB, u32 SURE>
+__global__ __launch_bounds__(HUFD_DEC_LANES, 3) void dec_onepass_kernel(
+    hufd_tables tb,
+    const hufd_chunk_rec *chunk_rec,
+    const hufd_dec_item *items,
+    const u8 *d_in,
+    u8 *d_out,
+    u64 *status,      /* [n_chunks] zeroed before the launch */
+    u32 *ctl,         /* [0] raised by the first chunk that cannot go this way; zeroed before the launch */
+    u32 *chunk_entry, /* of the chunk behind an item's last chunk inside the stream: what dec_scan_small goes on from */
+    u64 *chunk_base,
+    u32 fail_chunk /* a chunk that is to give up (tests of the way back); HUFD_NONE32: none */) {
+
+    fuse_shared<LB> &sh = *reinterpret_cast<fuse_shared<LB> *>(dyn_lds);
+    u8 *const lds_bytes = reinterpret_cast<u8 *>(&sh);
+    const u32 ns = tb.n_states;
+    const u32 lane = threadIdx.x, wl = lane & (kWave - 1);
+    const u32 c = blockIdx.x;
+    const hufd_chunk_rec rec = chunk_rec[c];
+    if (rec.valid < HUFD_DEC_CHUNK_BYTES + 8u) {
+        return; /* holds the end of its stream: the kernels for those */
+    }
+    const u32 prev_item = c ? chunk_rec[c - 1].item : HUFD_NONE32;
+    const bool first = prev_item != rec.item; /* the item's first chunk: entered at its first bit, nothing in front */
+    HUFD_STAMP(0, 0);
+    const u8 *src = d_in + rec.src_off;
+    const row_walk rw(LB, tb.max_bits);
+    const u32 table = lds_offset_of(sh.wlut);
+    const bool eligible = tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS && tb.min_bits >= 4 && rw.sure == SURE &&
+                          (table & ((4u << LB) - 1u)) == 0 && c != fail_chunk;
+
+    u32 w[kFastRows];
+    {
+        const unaligned_uint4 *line = reinterpret_cast<const unaligned_uint4 *>(src + (u64)lane * HUFD_DEC_SUB_BYTES);
+#pragma unroll
+        for (u32 q = 0; q < kSubWords / 4; ++q) {
+            const unaligned_uint4 v = line[q];
+            w[4 * q + 0] = __builtin_bswap32(v.x);
+            w[4 * q + 1] = __builtin_bswap32(v.y);
+            w[4 * q + 2] = __builtin_bswap32(v.z);
+            w[4 * q + 3] = __builtin_bswap32(v.w);
+        }
+        w[kSubWords] = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(src + (u64)(lane + 1) * HUFD_DEC_SUB_BYTES)->x);
+    }
+    for (u32 i = lane; i < (1u << LB); i += HUFD_DEC_LANES) {
+        const u32 e = tb.dec_lut[i >> (LB - tb.lut_bits)];
+        const u32 len = e & 0xFFu;
+        sh.wlut[i] = ((e >> 8) << 16) | ((0x10000u - (len ? len : kWalkDeadLen)) & 0xFFFFu);
+        sh.hops[i] = (u16)(len ? 1u << len : 0u);
+    }
+    if (lane == 0) {
+        /* (one lane looks whether the launch has gone the other way already: the whole workgroup must see the same answer) */
+        sh.bad = !eligible ? 2u : (word_load(&ctl[0]) != 0 ? 1u : 0u);
+        sh.why = 0;
+#pragma unroll
+        for (u32 r = 0; r <= kFastMaxMeet; ++r) {
+            sh.sub0[r] = w[r];
+        }
+    }
+    __syncthreads();
+    if (sh.bad) { /* (nobody writes this word again before everybody has passed two more barriers) */
+        if (lane == 0 && sh.bad == 2u) {
+            ctl[1] = (c << 8) | (c == fail_chunk ? 11u : 1u);
+            word_store(&ctl[0], 1u);
+            granule_store(&status[c], kFuseFail);
+        }
+        return;
+    }
+
+    HUFD_STAMP(0, 1);
+    /* U: all entry states as one mask of heads per row, until every lane of the wave is down to one */
+    u64 heads = (1ull << ns) - 1ull;
+    u32 meet_row = 0; /* the same for the whole wave */
+    bool one = false, settled = false;
+#pragma unroll
+    for (u32 r = 0; r < kFastMaxMeet; ++r) {
+        if (!settled) {
+            heads = union_row_fast<LB>(heads, w[r], w[r + 1], sh.hops);
+            one = heads != 0 && (heads & (heads - 1)) == 0;
+            meet_row = r + 1;
+            settled = __all(one || heads == 0);
+        }
+    }
+    u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
+    bool ok = one && settled;
+    u32 why = ok ? 0u : 2u; /* (diagnostics: the first reason this lane has for giving up) */
+    const u32 slots_at = (u32)(sh.slots - lds_bytes), dump_at = (u32)(sh.dump - lds_bytes);
+
+    /* One meeting row for the whole chunk (the last of its waves'): a slot then holds what lies between the same row
+     * of two neighbouring sub-chunks -- a sub-chunk's worth of symbols -- also where two waves meet.  A wave that was
+     * down to one head earlier follows that head to the common row (rows that its H walks take again below). */
+    HUFD_STAMP(0, 2);
+    if (wl == 0) {
+        sh.wave_meet[lane / kWave] = meet_row;
+    }
+    __syncthreads();
+    {
+        u32 common = 0;
+#pragma unroll
+        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
+            common = sh.wave_meet[wv] > common ? sh.wave_meet[wv] : common;
+        }
+        if (meet_row < common) {
+            u32 state = rw.state_at(meet_bit, 0), none = 0;
+            bool dead = false;
+#pragma unroll
+            for (u32 r = 1; r < kFastMaxMeet; ++r) {
+                if (r >= meet_row && r < common) {
+                    state = fuse_row<SURE, false, false>(state, w[r], w[r + 1], table, rw, lds_bytes, none);
+                    dead = dead || rw.died(state);
+                    state = rw.next_row(state, dead);
+                }
+            }
+            meet_bit = rw.offset_of(state);
+            why = why ? why : (dead || meet_bit >= 32u ? 16u : 0u);
+            ok = ok && !dead && meet_bit < 32u;
+            meet_bit = meet_bit < 32u ? meet_bit : 0u;
+            meet_row = common;
+        }
+    }
+
+    /* R: the one walk from the meeting bit to the end of the sub-chunk, symbols to my slot */
+    const u32 my_slot = slots_at + lane * kFuseSlotBytes;
+    u32 ref_exit, slot_fill;
+    {
+        const u32 lim = my_slot + kFuseSlotFill;
+        u32 dst = my_slot;
+        u32 state = rw.state_at(meet_bit, 0);
+        bool dead = false;
+#pragma unroll
+        for (u32 r = 1; r < kSubWords; ++r) {
+            if (r >= meet_row) {
+                state = fuse_row<SURE>(state, w[r], w[r + 1], table, rw, lds_bytes, dst);
+                dead = dead || rw.died(state);
+                state = rw.next_row(state, dead); /* (a dead walk is put back on a row start: its state and its stores stay in bounds) */
+                dst = dst < lim ? dst : lim;
+            }
+        }
+        ref_exit = rw.offset_of(state);
+        slot_fill = dst - my_slot;
+        why = why ? why : (dead ? 3u : (ref_exit >= ns ? 12u : (dst >= lim ? 13u : 0u)));
+        ok = ok && !dead && ref_exit < ns && dst < lim;
+        sh.link[lane] = (ref_exit & 0xFFu) | (slot_fill << 8);
+    }
+    HUFD_STAMP(0, 3);
+    __syncthreads();
+    if (lane == 0) {
+        /* how the chunk is left does not depend on how it is entered: the next chunk may start on its first sub-chunk
+         * (lane 0 writes every version of the chunk's word: one wave's stores to one address stay in order) */
+        granule_store(&status[c], kFuseExit | ((u64)(sh.link[HUFD_DEC_LANES - 1] & 0xFFu) << kFuseExitShift));
+    }
+
+    /* H: my own sub-chunk from my true entry state to the meeting bit, symbols behind my neighbour's in its slot
+     * (lane 0, whose entry state the previous chunk knows, walks into the dump; its rows are the candidates' below) */
+    {
+        const u32 prev = lane ? sh.link[lane - 1] : 0u;
+        const u32 entry = prev & 0xFFu;
+        const u32 at = lane ? my_slot - kFuseSlotBytes : dump_at;
+        const u32 dst0 = lane ? at + (prev >> 8) : at;
+        const u32 lim = lane ? at + kFuseSlotFill : at + (u32)sizeof(sh.dump) - kFuseRowMax;
+        u32 dst = dst0;
+        u32 st = rw.state_at(entry < ns ? entry : 0u, 0);
+        bool dd = false;
+#pragma unroll
+        for (u32 r = 0; r < kFastMaxMeet; ++r) {
+            if (r < meet_row) {
+                st = fuse_row<SURE>(st, w[r], w[r + 1], table, rw, lds_bytes, dst);
+                dd = dd || rw.died(st);
+                st = rw.next_row(st, dd);
+                dst = dst < lim ? dst : lim;
+            }
+        }
+        const bool reached = !dd && rw.offset_of(st) == meet_bit && dst < lim;
+        ok = ok && (lane == 0 || reached);
+        why = why ? why : (lane == 0 || reached ? 0u : 4u);
+        if (lane) {
+            sh.hcnt[lane - 1] = (u16)(dst - dst0);
+        }
+        if (lane == HUFD_DEC_LANES - 1) {
+            sh.hcnt[lane] = 0; /* (the next chunk's first sub-chunk is the next chunk's) */
+        }
+    }
+    /* sub-chunk 0 from every entry state the chunk may be entered in (lanes 0 .. ns-1 of wave 0), step by step */
+    if (lane < kWave) {
+        const u32 target = __shfl(meet_bit, 0);
+        const bool mine = lane < ns && lane < HUFD_DEC_MAX_STATES;
+        const u32 dst0 = mine ? (u32)(sh.cand[lane] - lds_bytes) : dump_at;
+        const u32 lim = dst0 + (mine ? kFuseCandBytes : (u32)sizeof(sh.dump)) - kFuseRowMax;
+        u32 dst = dst0;
+        u32 st = rw.state_at(mine ? lane : 0u, 0);
+        bool dd = false;
+        u32 hi = sh.sub0[0];
+        for (u32 r = 0; r < meet_row; ++r) {
+            const u32 lo = sh.sub0[r + 1];
+            st = fuse_row<SURE, true>(st, hi, lo, table, rw, lds_bytes, dst);
+            dd = dd || rw.died(st);
+            st = rw.next_row(st, dd);
+            dst = dst < lim ? dst : lim;
+            hi = lo;
+        }
+        const bool reached = !dd && mine && rw.offset_of(st) == target && dst < lim;
+        if (lane < HUFD_DEC_MAX_STATES) {
+            sh.cand_cnt[lane] = reached ? dst - dst0 : HUFD_NONE32;
+        }
+    }
+    HUFD_STAMP(0, 4);
+    __syncthreads();
+
+    /* what every slot holds, and where it goes */
+    const u32 len = (sh.link[lane] >> 8) + sh.hcnt[lane];
+    ok = ok && len >= 16u && len < kFuseSlotFill;
+    why = why ? why : (ok ? 0u : 5u);
+    const u32 incl = wave_inclusive_sum_dpp(len, wl);
+    if (wl == kWave - 1) {
+        sh.wave_tot[lane / kWave] = incl;
+    }
+    if (!ok) {
+        sh.bad = 1;
+        sh.why = why;
+    }
+    __syncthreads();
+    u32 body = 0; /* symbols from sub-chunk 0's meeting bit to the end of the chunk */
+    {
+        u32 before = 0;
+#pragma unroll
+        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
+            before += wv < lane / kWave ? sh.wave_tot[wv] : 0u;
+            body += sh.wave_tot[wv];
+        }
+        sh.pos[lane] = before + incl - len;
+    }
+    bool failed = sh.bad != 0;
+    HUFD_STAMP(0, 5);
+
+    /* wave 0: the chunk's entry state, its count to the chunks behind, its place from the chunks in front */
+    const u32 exit_state = sh.link[HUFD_DEC_LANES - 1] & 0xFFu;
+    if (lane < kWave) {
+        u32 e = 0, n0 = 0;
+        u64 base = 0;
+        u32 late = 0; /* (diagnostics: why wave 0 gives up) */
+        if (!failed) {
+            if (first) {
+                e = items[rec.item].first_bit;
+            } else {
+                u64 st = 0;
+                for (u32 spins = 0;; ++spins) {
+                    st = granule_load_now(&status[c - 1]);
+                    if (st & (kFuseExit | kFuseFail)) {
+                        break;
+                    }
+                    if (spins > kFuseSpinLimit || word_load_now(&ctl[0]) != 0) {
+                        late = spins > kFuseSpinLimit ? 6u : 14u;
+                        st = kFuseFail;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                failed = (st & kFuseFail) != 0;
+                late = failed && !late ? 15u : late;
+                e = (u32)(st >> kFuseExitShift) & 0xFFu;
+            }
+            n0 = e < ns && e < HUFD_DEC_MAX_STATES ? sh.cand_cnt[e] : HUFD_NONE32;
+            late = !failed && n0 == HUFD_NONE32 ? 7u : late;
+            failed = failed || n0 == HUFD_NONE32; /* the true path dies in front of the meeting bit: the stream is damaged */
+        }
+        const u64 count = (u64)n0 + body;
+        if (!failed) {
+            if (lane == 0) {
+                granule_store(&status[c], (first ? kFuseIncl : kFuseAgg) | kFuseExit | ((u64)exit_state << kFuseExitShift) | count);
+            }
+            if (!first) {
+                /* symbols of my item in front of me: the chunks in front, 64 at a time, back to one that knows its own answer */
+                const u32 item_first = items[rec.item].first_chunk;
+                u32 idx = c - 1;
+                for (;;) {
+                    const bool inside = idx >= lane && idx - lane >= item_first;
+                    u64 st = inside ? granule_load_now(&status[idx - lane]) : kFuseIncl;
+                    u64 need = 0;
+                    bool known = false;
+                    for (u32 spins = 0;; ++spins) {
+                        const u64 have_incl = __ballot((st & kFuseIncl) != 0);
+                        const u64 have_any = __ballot((st & (kFuseIncl | kFuseAgg | kFuseFail)) != 0);
+                        known = have_incl != 0;
+                        const u32 upto = known ? (u32)__builtin_ctzll(have_incl) : kWave - 1;
+                        need = upto == 63 ? ~0ull : (1ull << (upto + 1)) - 1ull;
+                        if ((have_any & need) == need) {
+                            break;
+                        }
+                        if (spins > kFuseSpinLimit || word_load_now(&ctl[0]) != 0) {
+                            late = spins > kFuseSpinLimit ? 8u : 14u;
+                            failed = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                        if (inside && !(st & (kFuseIncl | kFuseAgg | kFuseFail))) {
+                            st = granule_load_now(&status[idx - lane]);
+                        }
+                    }
+                    if (failed) {
+                        break;
+                    }
+                    const bool mine = ((need >> wl) & 1ull) != 0;
+                    if (__any(mine && (st & kFuseFail) != 0)) {
+                        late = 9u;
+                        failed = true;
+                        break;
+                    }
+                    u64 part = mine ? (st & kFuseValue) : 0ull;
+#pragma unroll
+                    for (u32 d = kWave / 2; d > 0; d >>= 1) {
+                        part += __shfl_xor(part, d);
+                    }
+                    base += part;
+                    if (known) {
+                        break;
+                    }
+                    idx -= kWave; /* (no chunk of the item in the window knew: the item has at least 64 more in front) */
+                }
+            }
+            late = !failed && base + count > rec.out_cap ? 10u : late;
+            failed = failed || base + count > rec.out_cap; /* the output is too short for this chunk: the other road finds the edge */
+        }
+        if (lane == 0) {
+            if (failed) {
+                if (word_load_now(&ctl[0]) == 0) {
+                    ctl[1] = (c << 8) | (late ? late : sh.why); /* (diagnostics; who is first is not decided exactly) */
+                }
+                word_store(&ctl[0], 1u);
+                granule_store(&status[c], kFuseFail);
+            } else {
+                if (!first) {
+                    granule_store(&status[c], kFuseIncl | kFuseExit | ((u64)exit_state << kFuseExitShift) | (base + count));
+                }
+                if (rec.valid - HUFD_DEC_CHUNK_BYTES < HUFD_DEC_CHUNK_BYTES + 8u) {
+                    /* the item's last chunk inside the stream: the chunk(s) the stream ends in start here */
+                    chunk_entry[c + 1] = entry_pack(exit_state, true);
+                    chunk_base[c + 1] = base + count;
+                }
+            }
+            sh.bad = failed ? 1u : 0u;
+            sh.entry = e;
+            sh.n0 = n0;
+            sh.base = base;
+        }
+        HUFD_STAMP(0, 6);
+    }
+    __syncthreads();
+    if (sh.bad) {
+        return;
+    }
+
+    /* the slots to HBM: sub-chunk 0's first symbols a byte a lane, then eight lanes a slot, 16 bytes each, the last
+     * 16 of a slot as they lie (any alignment; they overlap the row in front with the same bytes) */
+    {
+        const u32 n0 = sh.n0;
+        u8 *out = d_out + rec.out_off + sh.base;
+        if (lane < n0) {
+            out[lane] = sh.cand[sh.entry][lane];
+        }
+        u8 *body_out = out + n0;
+        const u32 row = lane & 7u;
+#pragma unroll
+        for (u32 it = 0; it < HUFD_DEC_LANES / 32; ++it) {
+            const u32 s = it * 32 + (lane >> 3);
+            const u32 n = (sh.link[s] >> 8) + sh.hcnt[s];
+            const u32 p = sh.pos[s];
+            const u32 from = 16 * row + 16 <= n ? 16 * row : n - 16;
+            if (16 * row < n) {
+                const unaligned_uint4 v = *reinterpret_cast<const unaligned_uint4 *>(sh.slots + s * kFuseSlotBytes + from);
+                *reinterpret_cast<unaligned_uint4 *>(body_out + p + from) = v;
+            }
+        }
+    }
+    HUFD_STAMP(0, 7);
 }
 
 /* ------------------------------------------------------------------ decode: emit */
@@ -5717,7 +6203,11 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
     u32 *slow_count,
     u32 *dense_list, /* chunks with more symbols than the stage holds: left to dec_emit_big_kernel */
     u32 *dense_count,
-    u32 stage_limit /* symbols the stage of this launch holds (HUFD_DEC_STAGE_BYTES, or less: emit_lds_bytes) */) {
+    u32 stage_limit /* symbols the stage of this launch holds (HUFD_DEC_STAGE_BYTES, or less: emit_lds_bytes) */,
+    const u32 *gate /* NULL, or dec_onepass's ctl: the chunks inside streams are this kernel's only if that one gave up */) {
+    if (!TAIL && gate && gate[0] == 0) {
+        return;
+    }
     dec_emit_fast_chunk<LB, TAIL, SURE>(
         TAIL ? tail_chunks[blockIdx.x] : blockIdx.x, tb, chunk_rec, d_in, d_out, cp_tab, lane_count, chunk_regular, chunk_fn,
         chunk_entry, chunk_base, results, slow_list, slow_count, dense_list, dense_count, stage_limit);
@@ -6314,6 +6804,14 @@ int hufk_init(void) {
 #undef HUFK_ALLOW_BIG_LDS
     if (e == hipSuccess) {
         e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&dec_onepass_kernel<12, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    }
+    if (e == hipSuccess) {
+        e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&dec_onepass_kernel<12, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    }
+    if (e == hipSuccess) {
+        e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&dec_sync_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     }
     if (e == hipSuccess) {
@@ -6357,6 +6855,17 @@ int hufk_init(void) {
 int hufk_encode_one_pass_applies(const struct hufd_tables *tb) {
     /* every symbol has a code (no stop inside a stream to look for), octs of 4 .. 15-bit codes */
     return tb->all_coded && tb->max_bits <= 15 && tb->min_bits >= 4;
+}
+
+int hufk_decode_one_pass_applies(const struct hufd_tables *tb) {
+    /* the chunked decoder's tables, slots sized for codes of at least 4 bits, and a build for the coder's number of
+     * certain steps a row (the instantiations hufk_decode_launch picks from) */
+    if (!tb->dec_lut || tb->deep_entries || tb->max_bits > HUFD_DEC_MAX_LUT_BITS || tb->min_bits < 4) {
+        return 0;
+    }
+    const uint32_t lb = tb->lut_bits <= 10 ? 10u : 12u;
+    const uint32_t sure = row_walk(lb, tb->max_bits).sure;
+    return lb == 10 ? sure >= 2 && sure <= 5 : sure >= 2 && sure <= 3;
 }
 
 uint64_t hufk_encode_zero_bytes(uint32_t n_segs, uint32_t n_items) {
@@ -6572,6 +7081,40 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     }
     const uint32_t ns = a->tables.n_states;
     stage_mark(a->stage_events, 0, st);
+    /* The chunks inside streams in ONE pass (dec_onepass) where the coder allows: the kernels of the two-pass road for
+     * those chunks are queued behind it all the same and look at its ctl word first -- they run only if it gave up. */
+    const u32 *gate = nullptr;
+    if (a->n_chunks && a->n_tail < a->n_chunks && a->fuse_status && a->fuse_ctl && a->fuse_mode != 1 && !a->old_sync &&
+        hufk_decode_one_pass_applies(&a->tables)) {
+        const uint32_t lb = a->tables.lut_bits <= 10 ? 10u : 12u;
+        const uint32_t sure = row_walk(lb, a->tables.max_bits).sure;
+        const u32 fail_chunk = a->fuse_mode == 2 ? a->n_chunks / 2 : HUFD_NONE32;
+        bool launched = true;
+#define HUFK_LAUNCH_ONEPASS_DEC(LBV, SUREV)                                                                            \
+    hipLaunchKernelGGL(                                                                                                \
+        (dec_onepass_kernel<LBV, SUREV>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fuse_shared<LBV>), \
+        st, a->tables, a->chunk_rec, a->items, (const u8 *)a->d_in, (u8 *)a->d_out, a->fuse_status, a->fuse_ctl,       \
+        a->chunk_entry, a->chunk_base, fail_chunk)
+        (void)hipMemsetAsync(a->fuse_status, 0, (size_t)a->n_chunks * sizeof(u64), st);
+        (void)hipMemsetAsync(a->fuse_ctl, 0, 2 * sizeof(u32), st);
+        if (lb == 10) {
+            switch (sure) {
+                case 2: HUFK_LAUNCH_ONEPASS_DEC(10, 2); break;
+                case 3: HUFK_LAUNCH_ONEPASS_DEC(10, 3); break;
+                case 4: HUFK_LAUNCH_ONEPASS_DEC(10, 4); break;
+                case 5: HUFK_LAUNCH_ONEPASS_DEC(10, 5); break;
+                default: launched = false; break;
+            }
+        } else {
+            switch (sure) {
+                case 2: HUFK_LAUNCH_ONEPASS_DEC(12, 2); break;
+                case 3: HUFK_LAUNCH_ONEPASS_DEC(12, 3); break;
+                default: launched = false; break;
+            }
+        }
+#undef HUFK_LAUNCH_ONEPASS_DEC
+        gate = launched ? a->fuse_ctl : nullptr;
+    }
     if (a->n_chunks) {
         /* chunks inside the stream the short way; the rest, and those that turn out irregular, through the list */
         const auto sync = ns <= 8 ? dec_sync_kernel<8> : (ns <= 10 ? dec_sync_kernel<10> : dec_sync_kernel<12>);
@@ -6609,14 +7152,14 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             (dec_sync_lean_kernel<LBV, SUREV, true>), dim3(a->n_tail), dim3(HUFD_DEC_LANES),                            \
             (uint32_t)sizeof(lean_shared<LBV>), tst, a->tables, a->chunk_rec, a->tail_chunks,                           \
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
-            a->slow_list, a->slow_count, lean_long_list, lean_long_count);                                             \
+            a->slow_list, a->slow_count, lean_long_list, lean_long_count, (const u32 *)nullptr);                        \
     }                                                                                                                  \
     if (some_inside) {                                                                                                 \
         hipLaunchKernelGGL(                                                                                            \
             (dec_sync_lean_kernel<LBV, SUREV, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES),                         \
             (uint32_t)sizeof(lean_shared<LBV>), st, a->tables, a->chunk_rec, a->tail_chunks,                            \
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
-            a->slow_list, a->slow_count, lean_long_list, lean_long_count);                                             \
+            a->slow_list, a->slow_count, lean_long_list, lean_long_count, gate);                                       \
     }
         if (!a->old_sync && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS) {
             lean = true;
@@ -6716,7 +7259,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     stage_mark(a->stage_events, 1, st);
     hipLaunchKernelGGL(
         dec_scan_small_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, ns, a->chunk_fn,
-        a->chunk_entry, a->chunk_base, a->states, a->results);
+        a->chunk_entry, a->chunk_base, a->states, a->results, gate);
     if (a->n_tiny && a->tables.deep_entries) {
         hipLaunchKernelGGL(
             dec_tiny_kernel<true>, dim3((a->n_tiny + kTinyDecThreads - 1) / kTinyDecThreads), dim3(kTinyDecThreads),
@@ -6740,13 +7283,13 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     if (a->n_large) {
         const uint32_t lds = scan_run_lds_bytes(ns);
         hipLaunchKernelGGL(
-            dec_scan_runs_kernel, dim3(a->n_runs), dim3(256), lds, st, a->items, a->runs, ns, a->chunk_fn, a->run_fn);
+            dec_scan_runs_kernel, dim3(a->n_runs), dim3(256), lds, st, a->items, a->runs, ns, a->chunk_fn, a->run_fn, gate);
         hipLaunchKernelGGL(
             dec_scan_top_kernel, dim3(a->n_large), dim3(256), kTopTile * ns * 4, st, a->items, a->large_items, ns,
-            (const u32 *)a->run_fn, a->run_entry, a->run_base, a->states, a->results);
+            (const u32 *)a->run_fn, a->run_entry, a->run_base, a->states, a->results, gate);
         hipLaunchKernelGGL(
             dec_scan_apply_kernel, dim3(a->n_runs), dim3(256), lds, st, a->items, a->runs, ns, a->chunk_fn,
-            (const u32 *)a->run_entry, (const u64 *)a->run_base, a->chunk_entry, a->chunk_base);
+            (const u32 *)a->run_entry, (const u64 *)a->run_base, a->chunk_entry, a->chunk_base, gate);
     }
     stage_mark(a->stage_events, 2, st);
     if (a->n_chunks) {
@@ -6760,7 +7303,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         a->tail_chunks, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab, (const u16 *)a->lane_count,       \
         (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry,                           \
         (const u64 *)a->chunk_base, a->results, a->emit_list, a->emit_count, a->dense_list, a->dense_count,            \
-        TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES)
+        TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES, TAILV ? (const u32 *)nullptr : gate)
         const bool some_inside = a->n_tail < a->n_chunks;
         /* (the few chunks streams end in beside the many inside streams: see the sync kernels above.  And in any case
          * dec_emit_tail beside dec_emit_fast<TAIL>: it works out for itself which chunks that kernel takes, reads

@@ -704,6 +704,7 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     hufs_free(p->d_chunk_entry);
     hufs_free(p->d_chunk_base);
     hufs_free(p->d_chunk_rec);
+    hufs_free(p->d_fuse_status);
     hufs_free(p->d_states);
     hufs_free(p->d_results);
     p->d_items = NULL;
@@ -727,6 +728,7 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     p->d_chunk_entry = NULL;
     p->d_chunk_base = NULL;
     p->d_chunk_rec = NULL;
+    p->d_fuse_status = NULL;
     p->d_states = NULL;
     p->d_results = NULL;
     p->cap_items = p->cap_chunks = p->cap_large = p->cap_runs = 0;
@@ -895,11 +897,12 @@ static int dec_plan_fill(
         p->d_chunk_entry = hufs_malloc(cc * sizeof(uint32_t));
         p->d_chunk_base = hufs_malloc(cc * sizeof(uint64_t));
         p->d_chunk_rec = hufs_malloc(cc * sizeof(struct hufd_chunk_rec));
+        p->d_fuse_status = hufs_malloc((cc + 1) * sizeof(uint64_t));
         p->d_states = hufs_malloc(ci * sizeof(struct hufd_dec_item_state));
         p->d_results = hufs_malloc(ci * sizeof(struct hufd_dec_result));
         if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_cp_tab || !p->d_chunk_fn || !p->d_slow_list || !p->d_chunk_entry ||
             !p->d_tail || !p->d_tiny || !p->d_dense_list || !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_tail_entry || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
-            !p->d_chunk_base || !p->d_chunk_rec || !p->d_states || !p->d_results) {
+            !p->d_chunk_base || !p->d_chunk_rec || !p->d_fuse_status || !p->d_states || !p->d_results) {
             err = 2;
         }
         p->cap_items = ci;
@@ -1052,7 +1055,13 @@ int aws_huffman_amd_decode_plan_launch_staged(
     {
         const char *mode = getenv("AWS_HUFFMAN_AMD_DECODE");
         a.old_sync = mode && strcmp(mode, "old-sync") == 0; /* the kernel dec_sync_lean replaced, for comparison and tests */
+        /* the chunks inside streams: in one pass (dec_onepass) unless told otherwise; "one-pass-fails" makes one chunk
+         * of the launch give up, so that the way back to the two-pass kernels can be tested */
+        a.fuse_mode = mode && strcmp(mode, "two-pass") == 0 ? 1u : (mode && strcmp(mode, "one-pass-fails") == 0 ? 2u : 0u);
     }
+    a.fuse_status = p->d_fuse_status;
+    a.fuse_ctl = (uint32_t *)(p->d_fuse_status + p->cap_chunks);
+    p->one_pass_tried = a.fuse_mode != 1 && !a.old_sync && p->n_tail < p->n_chunks && hufk_decode_one_pass_applies(&a.tables);
     a.stage_events = stage_events;
     hufs_set_device(p->engine->device);
     const int err = hufk_decode_launch(&a, stream ? stream : p->engine->stream);
@@ -1090,6 +1099,31 @@ void aws_huffman_amd_decode_result_from_raw(
         out->rc = AWS_OP_ERR;
         out->error = AWS_ERROR_INVALID_STATE;
     }
+}
+
+int aws_huffman_amd_decode_plan_road(struct aws_huffman_amd_decode_plan *p, void *stream, uint32_t *road, uint32_t *detail) {
+    *road = AWS_HUFFMAN_AMD_ROAD_TWO_PASS;
+    if (detail) {
+        *detail = 0;
+    }
+    if (!p->one_pass_tried) {
+        return AWS_OP_SUCCESS;
+    }
+    void *st = stream ? stream : p->engine->stream;
+    uint32_t ctl[2] = {0, 0};
+    hufs_set_device(p->engine->device);
+    int err = hufs_copy_d2h(ctl, p->d_fuse_status + p->cap_chunks, sizeof(ctl), st);
+    if (!err) {
+        err = hufs_stream_sync(st);
+    }
+    if (err) {
+        return raise_hip(err);
+    }
+    *road = ctl[0] ? AWS_HUFFMAN_AMD_ROAD_ONE_PASS_GAVE_UP : AWS_HUFFMAN_AMD_ROAD_ONE_PASS;
+    if (detail && ctl[0]) {
+        *detail = ctl[1];
+    }
+    return AWS_OP_SUCCESS;
 }
 
 int aws_huffman_amd_decode_plan_results(

@@ -105,6 +105,8 @@ struct aws_huffman_amd_decode_plan {
     uint32_t *d_chunk_entry;
     uint64_t *d_chunk_base;
     struct hufd_chunk_rec *d_chunk_rec;
+    uint32_t one_pass_tried; /* the last launch queued dec_onepass for the chunks inside streams */
+    uint64_t *d_fuse_status; /* [cap_chunks + 1] dec_onepass: a flagged word per chunk, then its ctl words */
     struct hufd_dec_item_state *d_states;
     struct hufd_dec_result *d_results;
 };

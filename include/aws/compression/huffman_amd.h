@@ -199,6 +199,25 @@ int aws_huffman_amd_decode_plan_results(
     struct aws_huffman_amd_decode_result *results,
     void *stream);
 
+/*
+ * Which kernels decoded the chunks inside the streams of the plan's last launch (a chunk = 32 KiB of one item's
+ * encoded bytes; the chunks streams END in always take the kernels written for them).  Diagnostics and tests: the
+ * results are the same either way.  Waits for the stream.
+ *   TWO_PASS           sync + scan + emit (every coder; selected for all launches by AWS_HUFFMAN_AMD_DECODE=two-pass)
+ *   ONE_PASS           dec_onepass: every encoded byte read once, every code walked once (coders with codes of 4..12 bits)
+ *   ONE_PASS_GAVE_UP   dec_onepass met a chunk it does not take (damaged, cut or non-synchronising stream, symbol-dense
+ *                      data, short output) and the two-pass kernels queued behind it on the same stream did the launch
+ */
+#define AWS_HUFFMAN_AMD_ROAD_TWO_PASS 0u
+#define AWS_HUFFMAN_AMD_ROAD_ONE_PASS 1u
+#define AWS_HUFFMAN_AMD_ROAD_ONE_PASS_GAVE_UP 2u
+AWS_COMPRESSION_API
+int aws_huffman_amd_decode_plan_road(
+    struct aws_huffman_amd_decode_plan *plan,
+    void *stream,
+    uint32_t *road,
+    uint32_t *detail /* NULL, or (ONE_PASS_GAVE_UP) chunk << 8 | reason code of one of the chunks that gave up: diagnostics */);
+
 /* ---- several GPUs: independent items sharded over the devices of one node ---- */
 
 /*

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Where does a workgroup of dec_onepass spend its cycles?  (diagnostic build only: `make -C aws-c-compression_amd stamps`)
+
+Shader clocks between the in-kernel stamps of wave 0, averaged over the chunks of a 1 GiB stream.  Shares only; never
+quote this build's run time."""
+import ctypes as C
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import harness  # noqa: E402
+import numpy as np  # noqa: E402
+
+lib = harness.load_product(os.path.join(REPO, "aws-c-compression_amd", "libaws-c-compression-amd-stamps.so"))
+lib.hufk_stamps_attach.argtypes = [C.c_void_p]
+patterns, lens = harness.load_table()
+eng = harness.Engine(lib, lib.aws_huffman_amd_table_coder_new(patterns, lens))
+MAX_WG = 131072
+d_rows = eng.alloc(3 * MAX_WG * 8 * 8)
+assert lib.hufk_stamps_attach(d_rows) == 0
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 30
+d_in, d_enc, d_back = eng.alloc(n), eng.alloc(n * 10 // 8 + 64), eng.alloc(n + 64)
+eng.fill_splitmix64(d_in, n, 5)
+ep = eng.encode_plan([dict(in_offset=0, in_len=n, out_offset=0, out_capacity=n * 10 // 8 + 64)])
+eng.encode_launch(ep, d_in, d_enc)
+e_len = eng.encode_results(ep, 1)[0][3]
+dp = eng.decode_plan([dict(in_offset=0, in_len=e_len, out_offset=0, out_capacity=n)])
+eng.upload(d_rows, np.zeros(3 * MAX_WG * 8, dtype=np.uint64).view(np.uint8))
+for _ in range(2):
+    eng.decode_launch(dp, d_enc, d_back)
+    eng.decode_results(dp, 1)
+print("road", eng.decode_road(dp), eng.last_road_detail)
+chunks = min((e_len - 8) // 32768, MAX_WG)
+r = eng.download(d_rows, chunks * 64, offset=0).view(np.uint64).reshape(chunks, 8).astype(np.float64)
+r = r[(r[:, 0] > 0) & (r[:, 7] > r[:, 0])]
+d = np.diff(r, axis=1)
+life = r[:, 7] - r[:, 0]
+print("dec_onepass: %d chunks, %.0f clocks per workgroup (median %.0f), wave 0" % (len(r), life.mean(), np.median(life)))
+names = ["load the sub-chunks, build the tables", "U: all entry states to one head", "common row, R: walk to the end (symbols to slots)",
+         "wait for the other waves, H + candidates", "wait, slot lengths, scan", "entry state + look-back (wave 0)", "wait, slots to HBM"]
+for i, ph in enumerate(names):
+    print("   %-52s %9.0f  %5.1f %%   (median %.0f, p99 %.0f)" % (ph, d[:, i].mean(), 100 * d[:, i].mean() / life.mean(),
+                                                            np.median(d[:, i]), np.percentile(d[:, i], 99)))
+t0 = r[:, 0].min()
+print("kernel span %.0f clocks; starts of chunks 0 / 10%% / 50%% / 90%% / last: %s" % (
+    r[:, 7].max() - t0, [int(r[int(q * (len(r) - 1)), 0] - t0) for q in (0, 0.1, 0.5, 0.9, 1.0)]))

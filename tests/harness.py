@@ -175,7 +175,7 @@ EXPORTED_SYMBOLS = [
     "aws_huffman_amd_encode_plan_launch", "aws_huffman_amd_encode_plan_launch_staged",
     "aws_huffman_amd_encode_plan_results", "aws_huffman_amd_decode_plan_new", "aws_huffman_amd_decode_plan_destroy",
     "aws_huffman_amd_decode_plan_launch", "aws_huffman_amd_decode_plan_launch_staged",
-    "aws_huffman_amd_decode_plan_results",
+    "aws_huffman_amd_decode_plan_results", "aws_huffman_amd_decode_plan_road",
     "aws_huffman_amd_device_count", "aws_huffman_amd_device_alloc", "aws_huffman_amd_device_free",
     "aws_huffman_amd_copy_to_device", "aws_huffman_amd_copy_to_host", "aws_huffman_amd_device_fill",
     "aws_huffman_amd_device_fill_splitmix64", "aws_huffman_amd_engine_stream", "aws_huffman_amd_stream_synchronize",
@@ -231,6 +231,7 @@ def load_product(path=None):
     _bind(lib, "aws_huffman_amd_decode_plan_destroy", None, [V])
     _bind(lib, "aws_huffman_amd_decode_plan_launch", C.c_int, [V, V, V, V])
     _bind(lib, "aws_huffman_amd_decode_plan_results", C.c_int, [V, P(AmdDecodeResult), V])
+    _bind(lib, "aws_huffman_amd_decode_plan_road", C.c_int, [V, V, P(C.c_uint32), P(C.c_uint32)])
     _bind(lib, "aws_huffman_amd_device_count", C.c_int, [])
     _bind(lib, "aws_huffman_amd_device_alloc", V, [V, C.c_size_t])
     _bind(lib, "aws_huffman_amd_device_free", None, [V, V])
@@ -345,6 +346,13 @@ class Engine:
 
     def decode_launch(self, plan, d_in, d_out, events=None):
         assert self.lib.aws_huffman_amd_decode_plan_launch_staged(plan, d_in, d_out, None, events) == 0
+
+    def decode_road(self, plan):
+        """0: two-pass kernels only, 1: one pass (dec_onepass), 2: dec_onepass gave up and the two-pass kernels took over."""
+        road, detail = C.c_uint32(99), C.c_uint32(0)
+        assert self.lib.aws_huffman_amd_decode_plan_road(plan, None, C.byref(road), C.byref(detail)) == 0
+        self.last_road_detail = (detail.value >> 8, detail.value & 0xFF)  # (chunk, reason) of a chunk that gave up
+        return road.value
 
     def decode_results(self, plan, n):
         res = (AmdDecodeResult * max(n, 1))()

@@ -11,6 +11,7 @@ tests/test_gpu_parity.py runs them through the hipcc build on an MI355X.
 """
 import ctypes as C
 import hashlib
+import os
 
 import numpy as np
 
@@ -997,4 +998,79 @@ def first_bit_offsets(w, engine=None):
         eng.free(d_in)
         eng.free(d_out)
     if engine is None:
+        eng.close()
+
+
+# ----------------------------------------------------------------------------- scenario: which kernels decode the chunks inside a stream
+ROAD_TWO_PASS, ROAD_ONE_PASS, ROAD_GAVE_UP = 0, 1, 2
+
+
+def decode_roads(w, engine=None, sizes=(40_000, 300_000, 1_100_000), seed=53):
+    """The chunks inside a stream (32 KiB of encoded bytes with at least 8 more behind them) are decoded in ONE pass by
+    dec_onepass; the two-pass kernels stay queued behind it and take the launch over when it gives up.  Every road
+    must give the oracle's result: plans of several streams (sizes in symbols) are launched
+      as they come                               -> ONE_PASS
+      with AWS_HUFFMAN_AMD_DECODE=two-pass       -> TWO_PASS
+      with AWS_HUFFMAN_AMD_DECODE=one-pass-fails -> GAVE_UP   (a chunk in the middle of the plan made to give up)
+      with a damaged stream / a short output     -> GAVE_UP   (the stop is found by the two-pass kernels)
+    and records, output bytes and guard bytes are compared with the oracle's decode of the same streams."""
+    own = engine is None
+    eng = engine or harness.Engine(w.product.lib, w.pcoder)
+    rng = np.random.default_rng(seed)
+    plains = [inputs(rng, n, "uniform") for n in sizes]
+    streams = [oracle_encode(w, p) for p in plains]
+
+    def run(mode, damage=None, short=None, want_road=None):
+        encs = [s.copy() for s in streams]
+        if damage is not None:
+            k, at = damage
+            encs[k][at:at + 4] = 0xFF  # the test coder has no code of ten one bits: an invalid window
+        caps = [p.size for p in plains]
+        if short is not None:
+            k, cap = short
+            caps[k] = cap
+        in_offs = np.cumsum([0] + [e.size + 5 for e in encs])   # odd gaps: chunks at any alignment
+        out_offs = np.cumsum([0] + [c + 16 for c in caps])
+        blob = np.full(int(in_offs[-1]) + 64, 0xA5, np.uint8)
+        for e, o in zip(encs, in_offs):
+            blob[o:o + e.size] = e
+        d_in, d_out = eng.alloc(blob.size), eng.alloc(int(out_offs[-1]) + 64)
+        eng.upload(d_in, blob)
+        eng.fill(d_out, SENTINEL, int(out_offs[-1]) + 64)
+        items = [dict(in_offset=int(in_offs[i]), in_len=int(encs[i].size), out_offset=int(out_offs[i]),
+                      out_capacity=int(caps[i])) for i in range(len(encs))]
+        plan = eng.decode_plan(items)
+        if mode:
+            os.environ["AWS_HUFFMAN_AMD_DECODE"] = mode
+        try:
+            eng.decode_launch(plan, d_in, d_out)
+        finally:
+            if mode:
+                del os.environ["AWS_HUFFMAN_AMD_DECODE"]
+        road = eng.decode_road(plan)
+        got = eng.decode_results(plan, len(items))
+        back = eng.download(d_out, int(out_offs[-1]) + 64)
+        for i, e in enumerate(encs):
+            dec = w.oracle.new_decoder(w.ocoder)
+            want_out = np.full(caps[i] + 16, SENTINEL, np.uint8)
+            r = w.oracle.decode_call(dec, e, 0, e.size, want_out, 0, caps[i])
+            assert got[i][0] == r.rc and got[i][1] == r.err and got[i][2] == r.produced, (mode, i, got[i], r)
+            mine = back[out_offs[i]:out_offs[i] + caps[i] + 16]
+            assert np.array_equal(mine, want_out), (mode, i, int(np.flatnonzero(mine != want_out)[0]))
+        eng.lib.aws_huffman_amd_decode_plan_destroy(plan)
+        eng.free(d_in)
+        eng.free(d_out)
+        if want_road is not None:
+            assert road == want_road, (mode, damage, short, road, eng.last_road_detail)
+        return road
+
+    run(None, want_road=ROAD_ONE_PASS)
+    run("two-pass", want_road=ROAD_TWO_PASS)
+    run("one-pass-fails", want_road=ROAD_GAVE_UP)
+    big = int(np.argmax([s.size for s in streams]))
+    run(None, damage=(big, streams[big].size // 2), want_road=ROAD_GAVE_UP)
+    run(None, damage=(big, 40), want_road=ROAD_GAVE_UP)
+    run(None, short=(big, plains[big].size // 2), want_road=ROAD_GAVE_UP)
+    run(None, short=(big, plains[big].size - 1))  # the edge lies in the stream's last chunk: either road
+    if own:
         eng.close()

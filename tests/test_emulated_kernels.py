@@ -110,6 +110,11 @@ def test_cut_streams(world):
     pc.cut_streams(world, chunks=(1,), step=23, n=40_000)
 
 
+def test_decode_roads(world):
+    """dec_onepass for the chunks inside streams, the two-pass kernels when told so or when it gives up."""
+    pc.decode_roads(world, sizes=(40_000, 90_000, 160_000))
+
+
 def test_large_items_take_the_workgroup_scan(world):
     """More than HUFD_SCAN_SMALL_MAX (64) segments / chunks per item."""
     pc.one_shot_roundtrips(world, sizes=[16384 * 66 + 3, 32768 * 70], seed=21)

@@ -130,6 +130,13 @@ def test_first_bit_offsets(world, engine):
     pc.first_bit_offsets(world, engine=engine)
 
 
+def test_decode_roads(world, engine):
+    """dec_onepass for the chunks inside streams; the two-pass kernels when told so and when it gives up (forced,
+    damaged stream, short output): same records, same bytes, nothing written that should not be."""
+    pc.decode_roads(world, engine=engine)
+    pc.decode_roads(world, engine=engine, sizes=(5_000_000, 33_000, 12_000_000, 70_000), seed=54)
+
+
 def test_large_items_take_the_workgroup_scan(world):
     pc.one_shot_roundtrips(world, sizes=[16384 * 66 + 3, 32768 * 70, 8 * 1024 * 1024 + 11], seed=21)
 
@@ -156,6 +163,7 @@ def test_config2_config3_one_gib_stream(world, engine):
     (rc, err, symbols, bits), = engine.decode_results(dplan, 1)
     assert (rc, err, symbols) == (0, 0, n)
     assert e * 8 - bits == rec["decoder_tail_num_bits"]  # padding bits left over
+    assert engine.decode_road(dplan) == pc.ROAD_ONE_PASS  # every encoded byte read once (dec_onepass)
 
     def digest(ptr, size):
         h = hashlib.sha256()
@@ -169,6 +177,18 @@ def test_config2_config3_one_gib_stream(world, engine):
     assert digest(d_back, n) == rec["sha256_input"]
     assert np.all(engine.download(d_enc, 64, offset=e) == 0x5A)  # nothing past the stream
     assert np.all(engine.download(d_back, 64, offset=n) == 0x5A)
+    # the same stream through the two-pass kernels, and through them after dec_onepass gave up half-way
+    for mode, road in (("two-pass", pc.ROAD_TWO_PASS), ("one-pass-fails", pc.ROAD_GAVE_UP)):
+        engine.fill(d_back, 0x5A, n + 64)
+        os.environ["AWS_HUFFMAN_AMD_DECODE"] = mode
+        try:
+            engine.decode_launch(dplan, d_enc, d_back)
+        finally:
+            del os.environ["AWS_HUFFMAN_AMD_DECODE"]
+        (rc, err, symbols, bits), = engine.decode_results(dplan, 1)
+        assert (rc, err, symbols) == (0, 0, n) and engine.decode_road(dplan) == road, mode
+        assert digest(d_back, n) == rec["sha256_input"], mode
+        assert np.all(engine.download(d_back, 64, offset=n) == 0x5A)
     engine.lib.aws_huffman_amd_encode_plan_destroy(plan)
     engine.lib.aws_huffman_amd_decode_plan_destroy(dplan)
     for p in (d_in, d_enc, d_back):
