@@ -168,4 +168,19 @@ struct hufd_chunk_rec {
     uint32_t item;
 };
 
+/* one per tile of dec_onepass, built with the plan.  A tile = up to 64 neighbouring sub-chunks of one item that lie inside
+ * its stream (with at least 8 more bytes behind them), one wave's work; but for an item's first tile, lane 0 is the last
+ * sub-chunk of the tile in front (walked again only to learn how it is left): tiles advance by 63 sub-chunks. */
+struct hufd_tile_rec {
+    uint64_t src_off;    /* bytes from the input base pointer to the sub-chunk of lane 0 */
+    uint64_t out_off;    /* bytes from the output base pointer to the item's first symbol */
+    uint64_t out_cap;    /* the item's output capacity */
+    uint32_t item;
+    uint16_t n_lanes;    /* sub-chunks of the tile, lane 0 included */
+    uint16_t flags;      /* bit 0: the item's first tile, bit 1: its last, bits 8..10: the item's first bit */
+    uint32_t tail_chunk; /* (last tile) the item's first chunk that is not wholly inside the stream */
+    uint32_t reserved;
+};
+#define HUFD_TILE_LANES 64u
+
 #endif /* HUFFMAN_AMD_DEVICE_TYPES_H */

@@ -87,8 +87,10 @@ struct hufk_decode_args {
     uint32_t tail_stage_bytes; /* the most symbols a chunk that holds the end of a stream can decode to, +32 (0: unknown) */
     uint32_t old_sync; /* 1: dec_sync_fast for every chunk (AWS_HUFFMAN_AMD_DECODE=old-sync), not dec_sync_lean for those inside a stream */
     void **stage_events; /* NULL, or 4 hipEvent_t: before sync, after sync, after scan, after emit */
-    uint64_t *fuse_status; /* [n_chunks] scratch of dec_onepass (the chunks inside streams in one pass): a flagged word per chunk */
-    uint32_t *fuse_ctl;    /* [2] [0]: dec_onepass gave up, the two-pass kernels behind it take every chunk */
+    const struct hufd_tile_rec *tiles; /* [n_tiles] dec_onepass (the chunks inside streams in one pass): built with the plan */
+    uint32_t n_tiles;
+    void *fuse_block;      /* hufk_decode_zero_bytes(n_tiles, n_items) bytes of scratch for dec_onepass, zeroed by the launch;
+                            * its first word: dec_onepass gave up, the two-pass kernels behind it take every chunk */
     uint32_t fuse_mode;    /* 0: dec_onepass where the coder allows; 1: never (AWS_HUFFMAN_AMD_DECODE=two-pass);
                             * 2: with one chunk made to give up (=one-pass-fails: the way back, for tests) */
 };
@@ -104,6 +106,7 @@ int hufk_encode_launch(const struct hufk_encode_args *args, void *stream);
 int hufk_decode_launch(const struct hufk_decode_args *args, void *stream);
 /* whether the chunks inside streams of this coder are decoded in one pass (dec_onepass), given fuse_mode != 1 */
 int hufk_decode_one_pass_applies(const struct hufd_tables *tables);
+uint64_t hufk_decode_zero_bytes(uint32_t n_tiles, uint32_t n_items);
 /* one short item whose record already sits in device memory (the host-pointer calls' small-input road): one launch */
 int hufk_encode_one_tiny(
     const struct hufd_tables *tables, const struct hufd_enc_item *item, const uint32_t *zero, const void *d_in, void *d_out,

@@ -5100,460 +5100,503 @@ __global__ __launch_bounds__(256) void dec_scan_apply_kernel(
 
 /*
  * dec_sync_lean + dec_scan + dec_emit_fast read every encoded byte twice and walk every code twice (count, then emit):
- * 1.65 x the algorithmic HBM traffic and ~33 vector instructions a symbol.  This kernel reads a chunk once and walks
- * it once.  What makes that possible: the symbols of a walk do not have to wait for their place in the output --
- * they go to a SLOT of the lane's in LDS while the walk counts them, and the slots are moved to the output when the
- * counts are known.
+ * 1.65 x the algorithmic HBM traffic and ~33 vector instructions a symbol.  This kernel reads the stream once and
+ * walks it once.  Two things make that possible:
  *
- *   U   as dec_sync_lean: all entry states of the lane's sub-chunk as one mask of heads per row until one is left
- *       (meeting row m, the same for the wave; meeting bit per lane);
- *   R   the one walk from the meeting bit to the end of the sub-chunk, every symbol stored to the lane's slot
- *       (table entry = symbol << 16 | 0x10000 - length: shift, mask-or, look-up, byte store, two adds a symbol);
- *       exit state and slot fill of every lane to LDS;
- *   H   rows 0 .. m-1 again from the true entry state (the neighbour's exit state), symbols stored BEHIND the
- *       neighbour's R symbols in the neighbour's slot: slot j then holds, in stream order and without a gap, the
- *       symbols from sub-chunk j's meeting bit to sub-chunk j+1's.  Sub-chunk 0's entry state is the previous
- *       chunk's exit state, which that chunk publishes the moment its R phase is over (it does not depend on how
- *       that chunk was entered); until it is read, lanes 0 .. ns-1 of wave 0 walk sub-chunk 0's first rows from every
- *       entry state into small candidate slots;
- *   a scan of the slot fills gives every slot its place in the chunk; the chunk's symbol count goes into a
- *   decoupled look-back over the chunks of the item (one flagged 64-bit word a chunk: exit state, count, inclusive
- *   prefix) which gives the chunk its place in the item's output; then the slots leave for HBM, eight lanes a slot,
- *   16 bytes each (the memory system takes any alignment).
+ *  - a walk's symbols do not have to wait for their place in the output: all lanes of a wave stand in the same row
+ *    (32-bit word) of their sub-chunks, a row holds at most eight codes, and the k-th code of a row goes to byte k
+ *    of a register pair -- a compile-time place (the steps of a row are unrolled: the codes that are certain to
+ *    start in it, then nested conditions).  The table entry is symbol << 24 | 4096 - length: one add moves the
+ *    shift amount (low 12 bits) and the symbol count (next 12), one v_perm_b32 keeps the symbol.  At the end of a
+ *    row the pair goes to the lane's SLOT in LDS with one 8-byte store at the count so far (what lies behind the
+ *    row's codes is overwritten by the next row's).  When the counts of a tile are known the slots leave for HBM,
+ *    eight lanes a slot, 16 bytes each (the memory system takes any alignment);
+ *  - nothing waits for an entry state.  A TILE is one wave's work: 64 neighbouring sub-chunks of 128 bytes.  Every
+ *    lane first follows ONE walk through the last rows of its own sub-chunk, started on a row boundary (a window
+ *    without a code moves it one bit on): where that walk leaves is a guess of the NEXT lane's entry state
+ *    (Huffman streams synchronise themselves: after a few rows such a walk is on the true path).  Lanes then walk
+ *    their sub-chunks from the guesses, and each guess is checked against the exit state of the lane in front;
+ *    who guessed wrong walks again from the true state (rare; the check is repeated).  Lane 0 of a tile is the
+ *    LAST sub-chunk of the tile in front, there only for the guess of lane 1's entry state (its symbols are the other
+ *    tile's).  How a tile is LEFT is then a function of its own bytes: it is published as soon as the tile's own
+ *    guesses are settled, and all the tile behind does with it is check lane 1's guess (and walk lane 1 again if it
+ *    was wrong, which must not change how that tile is left in turn: a sub-chunk's walks from different entry
+ *    states fall into step long before its end).  True by induction from the item's first tile, which is entered at
+ *    the item's first bit.  No tile waits for more than one word of the tile beside it.
  *
- * Exactness: the same argument as dec_sync_lean -- every lane's H walk must land on its own meeting bit, no walk may
- * die, every count must fit its slot, the output must fit the item's capacity.  Whatever is not so (a damaged or cut
- * stream, a stream that does not synchronise, symbol-dense data, a short output buffer) raises ctl[0] and marks the
- * chunk's word FAILED; chunks behind it give up when they see either, nothing wrong has been written (a chunk writes
- * only once every chunk in front of it has published a count), and the kernels of the two-pass road, which are
- * queued behind this one and look at ctl[0] first, then do the whole launch.  Every wait is bounded the same way.
- * (source/huffman.c:213-286 is what is reproduced; this is the road of BASELINE configs[2].)
+ * A tile's place in the output is the sum of the counts in front of it: the look-back of enc_onepass (a flagged word
+ * per tile, a memory-side sum + arrival count per group of 64 tiles, the bits in front of every round of 64 groups
+ * from one wave that does nothing else).
+ *
+ * Exactness: no walk of a tile's own sub-chunks may meet a window without a code, every guess must be confirmed,
+ * lane 0 must leave its sub-chunk as the tile in front says, a sub-chunk's symbols must fit its slot (128), the output
+ * must fit the item's capacity.  Whatever is not so (a damaged or cut stream, one that does not synchronise,
+ * symbol-dense data, a short output buffer) raises ctl[0]; tiles behind
+ * give up when they see it, nothing wrong has been written (a tile writes only once every tile in front of it has
+ * published a count), and the kernels of the two-pass road, queued behind this one, look at ctl[0] first and then do
+ * the whole launch.  Every wait is bounded the same way.  (source/huffman.c:213-286 is what is reproduced; this is
+ * the road of BASELINE configs[2].)
  */
-constexpr u32 kFuseSlotBytes = 136; /* 34 words: neighbouring lanes' slots two banks apart (a two-way conflict costs a byte store nothing) */
-constexpr u32 kFuseRowMax = 10;     /* more bytes than the codes of one row can be (codes of at least 4 bits), dead walks included */
-constexpr u32 kFuseSlotFill = kFuseSlotBytes - kFuseRowMax; /* a slot that ends up at least this full is not trusted */
-constexpr u32 kFuseCandBytes = 128; /* (16 rows of codes of 5 bits and more, and the slack of a slot) */
-constexpr u64 kFuseIncl = 1ull << 63, kFuseAgg = 1ull << 62, kFuseExit = 1ull << 61, kFuseFail = 1ull << 60;
-constexpr u32 kFuseExitShift = 52;
-constexpr u64 kFuseValue = (1ull << 48) - 1;
-constexpr u32 kFuseSpinLimit = 1u << 13;
+constexpr u32 kFuseWaves = 8;
+constexpr u32 kFuseThreads = kFuseWaves * kWave;
+constexpr u32 kFuseGuessRows = 12;    /* rows of a sub-chunk the walk that guesses the next lane's entry state runs through */
+constexpr u32 kFuseRowSyms = 8;      /* codes that can start in a row (at least 4 bits each) */
+constexpr u32 kFuseSlotBytes = 136;  /* 34 words: neighbouring lanes' slots two banks apart */
+constexpr u32 kFuseSlotFill = 128;   /* symbols a slot takes (a row's eight bytes may lie behind them) */
+constexpr u32 kFuseRepairRounds = 3;
+constexpr u32 kFuseField = 12;       /* bits of a walk state that hold the shift amount; the symbol count is the 12 above */
+constexpr u32 kFuseFieldMask = (1u << kFuseField) - 1u;
+constexpr u32 kFuseSpinLimit = 1u << 14;
+constexpr u32 kFuseReady = 1u << 31; /* tile_agg: [31] published, [23:0] symbols; tile_exit: [31] published, [3:0] exit state */
+
+struct fuse_walk {
+    u32 thr, mask, floor;
+    __device__ __host__ __forceinline__ fuse_walk(u32 lut_bits, u32 max_bits) {
+        thr = 512 + (32 - lut_bits) - 2; /* (row_walk's: 512 keeps the field positive through the certain steps of a dead walk) */
+        mask = ((1u << lut_bits) - 1u) << 2;
+        floor = thr - max_bits + 1;
+    }
+    __device__ __forceinline__ u32 state_at(u32 k) const { /* next code starts k bits into the current row, no symbols yet */
+        return thr + 32 - k;
+    }
+    __device__ __forceinline__ u32 offset_of(u32 state) const {
+        return thr + 32 - (state & kFuseFieldMask);
+    }
+    __device__ __forceinline__ bool open(u32 state) const { /* a code starts in the current row */
+        return (state & kFuseFieldMask) > thr;
+    }
+    __device__ __forceinline__ bool died(u32 state) const {
+        return (state & kFuseFieldMask) < floor;
+    }
+    __device__ __forceinline__ u32 count_of(u32 state) const {
+        return (state >> kFuseField) & kFuseFieldMask;
+    }
+};
 
 template <u32 LB>
 struct fuse_shared {
-    u32 wlut[1u << LB]; /* symbol << 16 | (0x10000 - length) & 0xFFFF, length 48 = no code; at a multiple of its own size */
-    u16 hops[1u << LB]; /* 1 << code length of a window (the head it sends on), 0 = no code */
-    u32 link[HUFD_DEC_LANES]; /* after R: exit state | symbols in the slot << 8 */
-    u32 pos[HUFD_DEC_LANES];  /* where the slot's symbols go, from the chunk's first R symbol */
-    u16 hcnt[HUFD_DEC_LANES]; /* symbols the next lane's H walk added to the slot */
-    u32 sub0[kFastMaxMeet + 4];
-    u32 wave_tot[HUFD_DEC_LANES / 64];
-    u32 wave_meet[HUFD_DEC_LANES / 64];
-    u32 cand_cnt[HUFD_DEC_MAX_STATES]; /* symbols of sub-chunk 0 in front of its meeting bit per entry state, HUFD_NONE32: that walk dies */
-    u32 bad, entry, n0, why;
-    u64 base;
-    u8 cand[HUFD_DEC_MAX_STATES][kFuseCandBytes];
-    u8 dump[64];
-    __attribute__((aligned(16))) u8 slots[HUFD_DEC_LANES * kFuseSlotBytes + 16];
+    u32 wlut[1u << LB]; /* symbol << 24 | 4096 - length, length 48 = no code; at a multiple of its own size */
+    u32 glut[1u << LB]; /* 4096 - length, no code: length 1 (the guessing walk moves a bit on) */
+    __attribute__((aligned(16))) u8 slots[kFuseWaves][kWave * kFuseSlotBytes + 16];
 };
 
-/* lean_row that keeps the symbols: entry = symbol << 16 | -length, the symbol to LDS byte `dst` */
-template <u32 SURE, bool STEP_BY_STEP = false, bool KEEP = true> /* KEEP false: the walk only, no symbol is stored */
-__device__ __forceinline__ u32 fuse_row(u32 state, u32 hi, u32 lo, u32 table, const row_walk &rw, u8 *lds_bytes, u32 &dst) {
-    const u64 pair = ((u64)hi << 32) | lo;
-    if (!STEP_BY_STEP) {
-#pragma unroll
-        for (u32 i = 0; i < SURE; ++i) {
-            const u32 e = lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
-            if (KEEP) {
-                lds_bytes[dst++] = (u8)(e >> 16);
-            }
-            state += e;
-        }
-    }
-    while ((state & 0xFFFFu) > rw.thr) {
-        const u32 e = lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
-        if (KEEP) {
-            lds_bytes[dst++] = (u8)(e >> 16);
-        }
-        state += e;
-    }
-    return state;
+/* byte POS of a row's register := the symbol of table entry e */
+template <u32 POS>
+__device__ __forceinline__ u32 fuse_put(u32 e, u32 acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr u32 sel = (0x03020100u & ~(0xFFu << (8 * POS))) | (7u << (8 * POS));
+    return __builtin_amdgcn_perm(e, acc, sel);
+#else
+    return (acc & ~(0xFFu << (8 * POS))) | ((e >> 24) << (8 * POS));
+#endif
 }
 
+template <u32 POS>
+__device__ __forceinline__ void fuse_step(u32 &state, u64 pair, u32 table, const fuse_walk &fw, u32 &alo, u32 &ahi) {
+    const u32 e = lds_word_at(((u32)(pair >> (state & 63u)) & fw.mask) | table);
+    if (POS < 4) {
+        alo = fuse_put<POS & 3u>(e, alo);
+    } else {
+        ahi = fuse_put<POS & 3u>(e, ahi);
+    }
+    state += e;
+}
+/* the codes of a row behind the certain ones: nested, so that a lane's k-th code has a compile-time place */
+template <u32 POS>
+__device__ __forceinline__ void fuse_more(u32 &state, u64 pair, u32 table, const fuse_walk &fw, u32 &alo, u32 &ahi) {
+    if constexpr (POS < kFuseRowSyms) {
+        if (fw.open(state)) {
+            fuse_step<POS>(state, pair, table, fw, alo, ahi);
+            fuse_more<POS + 1>(state, pair, table, fw, alo, ahi);
+        }
+    }
+}
+template <u32 POS, u32 SURE>
+__device__ __forceinline__ void fuse_sure(u32 &state, u64 pair, u32 table, const fuse_walk &fw, u32 &alo, u32 &ahi) {
+    if constexpr (POS < SURE) {
+        fuse_step<POS>(state, pair, table, fw, alo, ahi);
+        fuse_sure<POS + 1, SURE>(state, pair, table, fw, alo, ahi);
+    }
+}
+
+/* layout of the block the kernel wants zeroed before every launch (all offsets multiples of 8) */
+struct dec_onepass_layout {
+    uint64_t ctl, tile_agg, tile_exit, group_acc, round_base, item_base, bytes;
+};
+static dec_onepass_layout dec_onepass_layout_of(uint64_t n_tiles, uint64_t n_items) {
+    const uint64_t groups = (n_tiles + kOpGroupTiles - 1) / kOpGroupTiles;
+    const uint64_t rounds = (groups + kOpRoundGroups - 1) / kOpRoundGroups;
+    dec_onepass_layout l;
+    l.ctl = 0;
+    l.tile_agg = 32;
+    l.tile_exit = l.tile_agg + ((n_tiles * 4 + 7) & ~7ull);
+    l.group_acc = l.tile_exit + ((n_tiles * 4 + 7) & ~7ull);
+    l.round_base = l.group_acc + (groups ? groups : 1) * 8 * kOpGroupStride;
+    l.item_base = l.round_base + (rounds + 1) * 8;
+    l.bytes = l.item_base + (n_items ? n_items : 1) * 8;
+    return l;
+}
+
+struct __attribute__((packed, aligned(1))) two_words {
+    u32 lo, hi;
+};
+
+/* (diagnostic build: this kernel keeps its stamp sums in registers -- static LDS in front of the tables would move them
+ * off the multiple of their size that the walk's addressing wants) */
+#ifdef HUFD_STAMPS
+#define FUSE_STAMP_DECL unsigned long long fuse_stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define FUSE_STAMP_ADD(phase)                                                                                          \
+    do {                                                                                                               \
+        if (threadIdx.x == 0) {                                                                                        \
+            fuse_stamp_acc[phase] += (unsigned long long)clock64();                                                    \
+        }                                                                                                              \
+    } while (0)
+#define FUSE_STAMP_COUNT(phase, n)                                                                                     \
+    do {                                                                                                               \
+        if (threadIdx.x == 0) {                                                                                        \
+            fuse_stamp_acc[phase] += (unsigned long long)(n);                                                          \
+        }                                                                                                              \
+    } while (0)
+#define FUSE_STAMP_FLUSH                                                                                               \
+    do {                                                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x < HUFD_STAMP_MAX_WG) {                                                      \
+            for (u32 i = 0; i < 8; ++i) {                                                                              \
+                hufd_stamp_rows[(u64)blockIdx.x * 8 + i] = fuse_stamp_acc[i];                                          \
+            }                                                                                                          \
+        }                                                                                                              \
+    } while (0)
+#else
+#define FUSE_STAMP_DECL
+#define FUSE_STAMP_ADD(phase)
+#define FUSE_STAMP_COUNT(phase, n)
+#define FUSE_STAMP_FLUSH
+#endif
+
 template <u32 LB, u32 SURE>
-__global__ __launch_bounds__(HUFD_DEC_LANES, 3) void dec_onepass_kernel(
+__global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
     hufd_tables tb,
-    const hufd_chunk_rec *chunk_rec,
-    const hufd_dec_item *items,
-    const u8 *d_in,
-    u8 *d_out,
-    u64 *status,      /* [n_chunks] zeroed before the launch */
-    u32 *ctl,         /* [0] raised by the first chunk that cannot go this way; zeroed before the launch */
+    const hufd_tile_rec *__restrict__ tiles,
+    u32 n_tiles,
+    const u8 *__restrict__ d_in,
+    u8 *__restrict__ d_out,
+    u32 *ctl,        /* [0] raised by the first tile that cannot go this way, [1] which and why, [2] lanes that walked twice; zeroed */
+    u32 *tile_agg,   /* [n_tiles] zeroed */
+    u32 *tile_exit,  /* [n_tiles] zeroed */
+    u64 *group_acc,  /* zeroed */
+    u64 *round_base, /* [rounds + 1] zeroed */
+    u64 *item_base,  /* [n_items] zeroed */
     u32 *chunk_entry, /* of the chunk behind an item's last chunk inside the stream: what dec_scan_small goes on from */
     u64 *chunk_base,
-    u32 fail_chunk /* a chunk that is to give up (tests of the way back); HUFD_NONE32: none */) {
+    u32 fail_tile /* a tile that is to give up (tests of the way back); HUFD_NONE32: none */) {
 
+    FUSE_STAMP_DECL
     fuse_shared<LB> &sh = *reinterpret_cast<fuse_shared<LB> *>(dyn_lds);
-    u8 *const lds_bytes = reinterpret_cast<u8 *>(&sh);
-    const u32 ns = tb.n_states;
-    const u32 lane = threadIdx.x, wl = lane & (kWave - 1);
-    const u32 c = blockIdx.x;
-    const hufd_chunk_rec rec = chunk_rec[c];
-    if (rec.valid < HUFD_DEC_CHUNK_BYTES + 8u) {
-        return; /* holds the end of its stream: the kernels for those */
-    }
-    const u32 prev_item = c ? chunk_rec[c - 1].item : HUFD_NONE32;
-    const bool first = prev_item != rec.item; /* the item's first chunk: entered at its first bit, nothing in front */
-    HUFD_STAMP(0, 0);
-    const u8 *src = d_in + rec.src_off;
-    const row_walk rw(LB, tb.max_bits);
-    const u32 table = lds_offset_of(sh.wlut);
-    const bool eligible = tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS && tb.min_bits >= 4 && rw.sure == SURE &&
-                          (table & ((4u << LB) - 1u)) == 0 && c != fail_chunk;
-
-    u32 w[kFastRows];
-    {
-        const unaligned_uint4 *line = reinterpret_cast<const unaligned_uint4 *>(src + (u64)lane * HUFD_DEC_SUB_BYTES);
-#pragma unroll
-        for (u32 q = 0; q < kSubWords / 4; ++q) {
-            const unaligned_uint4 v = line[q];
-            w[4 * q + 0] = __builtin_bswap32(v.x);
-            w[4 * q + 1] = __builtin_bswap32(v.y);
-            w[4 * q + 2] = __builtin_bswap32(v.z);
-            w[4 * q + 3] = __builtin_bswap32(v.w);
-        }
-        w[kSubWords] = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(src + (u64)(lane + 1) * HUFD_DEC_SUB_BYTES)->x);
-    }
-    for (u32 i = lane; i < (1u << LB); i += HUFD_DEC_LANES) {
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = uniform32(tid / kWave);
+    for (u32 i = tid; i < (1u << LB); i += kFuseThreads) {
         const u32 e = tb.dec_lut[i >> (LB - tb.lut_bits)];
         const u32 len = e & 0xFFu;
-        sh.wlut[i] = ((e >> 8) << 16) | ((0x10000u - (len ? len : kWalkDeadLen)) & 0xFFFFu);
-        sh.hops[i] = (u16)(len ? 1u << len : 0u);
-    }
-    if (lane == 0) {
-        /* (one lane looks whether the launch has gone the other way already: the whole workgroup must see the same answer) */
-        sh.bad = !eligible ? 2u : (word_load(&ctl[0]) != 0 ? 1u : 0u);
-        sh.why = 0;
-#pragma unroll
-        for (u32 r = 0; r <= kFastMaxMeet; ++r) {
-            sh.sub0[r] = w[r];
-        }
+        sh.wlut[i] = ((e >> 8) << 24) | ((1u << kFuseField) - (len ? len : kWalkDeadLen));
+        sh.glut[i] = (1u << kFuseField) - (len ? len : 1u);
     }
     __syncthreads();
-    if (sh.bad) { /* (nobody writes this word again before everybody has passed two more barriers) */
-        if (lane == 0 && sh.bad == 2u) {
-            ctl[1] = (c << 8) | (c == fail_chunk ? 11u : 1u);
+    const fuse_walk fw(LB, tb.max_bits);
+    const u32 ns = tb.n_states;
+    const u32 wlut_at = lds_offset_of(sh.wlut), glut_at = lds_offset_of(sh.glut);
+
+    /* one wave of the grid only watches the groups of a round arrive and publishes the next round's base (enc_onepass) */
+    if (blockIdx.x == 0 && wave == kFuseWaves - 1) {
+        const u32 full_rounds = n_tiles / kOpRoundTiles;
+        u64 base = 0;
+        if (lane == 0) {
+            granule_store(&round_base[0], kOpReady);
+        }
+        for (u32 r = 0; r < full_rounds; ++r) {
+            u64 b = 0;
+            for (u32 spins = 0;; ++spins) {
+                b = lane < kOpRoundGroups ? granule_load(&group_acc[(u64)(r * kOpRoundGroups + lane) * kOpGroupStride])
+                                          : kOpGroupTiles * kOpArrive;
+                if (__all((b >> 40) == kOpGroupTiles)) {
+                    break;
+                }
+                if (spins > kFuseSpinLimit * 16u || word_load(&ctl[0]) != 0) {
+                    return; /* (the tiles that wait for this base give up in their turn, or have) */
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            u64 sum = lane < kOpRoundGroups ? (b & kOpSum) : 0;
+#pragma unroll
+            for (u32 d = kWave / 2; d > 0; d >>= 1) {
+                sum += __shfl_xor(sum, d);
+            }
+            base += sum;
+            if (lane == 0) {
+                granule_store(&round_base[r + 1], kOpReady | base);
+            }
+        }
+        return;
+    }
+    if ((wlut_at & ((4u << LB) - 1u)) != 0 || (glut_at & ((4u << LB) - 1u)) != 0) {
+        if (lane == 0) {
+            ctl[1] = 1u;
             word_store(&ctl[0], 1u);
-            granule_store(&status[c], kFuseFail);
         }
         return;
     }
 
-    HUFD_STAMP(0, 1);
-    /* U: all entry states as one mask of heads per row, until every lane of the wave is down to one */
-    u64 heads = (1ull << ns) - 1ull;
-    u32 meet_row = 0; /* the same for the whole wave */
-    bool one = false, settled = false;
-#pragma unroll
-    for (u32 r = 0; r < kFastMaxMeet; ++r) {
-        if (!settled) {
-            heads = union_row_fast<LB>(heads, w[r], w[r + 1], sh.hops);
-            one = heads != 0 && (heads & (heads - 1)) == 0;
-            meet_row = r + 1;
-            settled = __all(one || heads == 0);
+    /* tiles in turn over the waves of the grid: the tiles a tile waits for belong to this turn or an earlier one, so to
+     * running waves as long as the whole grid is resident (the launch sizes it so; every wait is bounded anyway) */
+    const u32 stride = gridDim.x * kFuseWaves - 1;
+    u8 *const lds_bytes = reinterpret_cast<u8 *>(&sh);
+    const u32 slot_at = (u32)(sh.slots[wave] - lds_bytes) + lane * kFuseSlotBytes; /* my slot, as an LDS byte offset */
+    for (u32 t = blockIdx.x * kFuseWaves + wave - (blockIdx.x ? 1u : 0u); t < n_tiles; t += stride) {
+        if (uniform32(word_load(&ctl[0])) != 0) {
+            return; /* the launch has gone the other way */
         }
-    }
-    u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
-    bool ok = one && settled;
-    u32 why = ok ? 0u : 2u; /* (diagnostics: the first reason this lane has for giving up) */
-    const u32 slots_at = (u32)(sh.slots - lds_bytes), dump_at = (u32)(sh.dump - lds_bytes);
-
-    /* One meeting row for the whole chunk (the last of its waves'): a slot then holds what lies between the same row
-     * of two neighbouring sub-chunks -- a sub-chunk's worth of symbols -- also where two waves meet.  A wave that was
-     * down to one head earlier follows that head to the common row (rows that its H walks take again below). */
-    HUFD_STAMP(0, 2);
-    if (wl == 0) {
-        sh.wave_meet[lane / kWave] = meet_row;
-    }
-    __syncthreads();
-    {
-        u32 common = 0;
+        FUSE_STAMP_ADD(0);
+        const hufd_tile_rec rec = tiles[t];
+        const u32 n_lanes = rec.n_lanes;
+        const bool first_tile = (rec.flags & 1u) != 0; /* of its item: lane 0 is entered at the item's first bit and its symbols are the tile's */
+        const bool active = lane < n_lanes;
+        const bool payload = active && (first_tile || lane != 0);
+        const u8 *src = d_in + rec.src_off + (u64)(active ? lane : 0u) * HUFD_DEC_SUB_BYTES;
+        u32 w[kFastRows];
+        auto load_rows = [&]() {
+            const unaligned_uint4 *line = reinterpret_cast<const unaligned_uint4 *>(src);
 #pragma unroll
-        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
-            common = sh.wave_meet[wv] > common ? sh.wave_meet[wv] : common;
-        }
-        if (meet_row < common) {
-            u32 state = rw.state_at(meet_bit, 0), none = 0;
-            bool dead = false;
-#pragma unroll
-            for (u32 r = 1; r < kFastMaxMeet; ++r) {
-                if (r >= meet_row && r < common) {
-                    state = fuse_row<SURE, false, false>(state, w[r], w[r + 1], table, rw, lds_bytes, none);
-                    dead = dead || rw.died(state);
-                    state = rw.next_row(state, dead);
-                }
+            for (u32 q = 0; q < kSubWords / 4; ++q) {
+                const unaligned_uint4 v = line[q];
+                w[4 * q + 0] = __builtin_bswap32(v.x);
+                w[4 * q + 1] = __builtin_bswap32(v.y);
+                w[4 * q + 2] = __builtin_bswap32(v.z);
+                w[4 * q + 3] = __builtin_bswap32(v.w);
             }
-            meet_bit = rw.offset_of(state);
-            why = why ? why : (dead || meet_bit >= 32u ? 16u : 0u);
-            ok = ok && !dead && meet_bit < 32u;
-            meet_bit = meet_bit < 32u ? meet_bit : 0u;
-            meet_row = common;
-        }
-    }
+            w[kSubWords] = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(src + HUFD_DEC_SUB_BYTES)->x);
+        };
+        load_rows();
 
-    /* R: the one walk from the meeting bit to the end of the sub-chunk, symbols to my slot */
-    const u32 my_slot = slots_at + lane * kFuseSlotBytes;
-    u32 ref_exit, slot_fill;
-    {
-        const u32 lim = my_slot + kFuseSlotFill;
-        u32 dst = my_slot;
-        u32 state = rw.state_at(meet_bit, 0);
+        /* G: where a walk started on row 24's first bit leaves my sub-chunk = a guess of the next lane's entry state */
+        u32 entry;
+        {
+            u32 state = fw.state_at(0);
+#pragma unroll
+            for (u32 r = kSubWords - kFuseGuessRows; r < kSubWords; ++r) {
+                const u64 pair = ((u64)w[r] << 32) | w[r + 1];
+                while (fw.open(state)) {
+                    state += lds_word_at(((u32)(pair >> (state & 63u)) & fw.mask) | glut_at);
+                }
+                state += 32u;
+            }
+            const u32 guess = __shfl_up(fw.offset_of(state), 1);
+            /* (lane 0 of a tile that is not its item's first has nothing of its own to walk: what it does below is never looked at) */
+            entry = lane ? guess : (first_tile ? (u32)(rec.flags >> 8) & 7u : 0u);
+        }
+
+        FUSE_STAMP_ADD(1);
+        /* R: my sub-chunk from `from`, the k-th code of a row to byte k of a register pair, the pair to my slot at the
+         * count so far.  A walk that meets a window without a code is put on the next row's first bit and goes on, so
+         * that its state and its stores stay in bounds; `dead` says so. */
+        u32 exit_state = 0, count = 0;
         bool dead = false;
+        auto walk = [&](bool go, u32 from) {
+            if (go) {
+                u32 state = fw.state_at(from);
+                bool dd = false;
+                u32 at = slot_at;
 #pragma unroll
-        for (u32 r = 1; r < kSubWords; ++r) {
-            if (r >= meet_row) {
-                state = fuse_row<SURE>(state, w[r], w[r + 1], table, rw, lds_bytes, dst);
-                dead = dead || rw.died(state);
-                state = rw.next_row(state, dead); /* (a dead walk is put back on a row start: its state and its stores stay in bounds) */
-                dst = dst < lim ? dst : lim;
-            }
-        }
-        ref_exit = rw.offset_of(state);
-        slot_fill = dst - my_slot;
-        why = why ? why : (dead ? 3u : (ref_exit >= ns ? 12u : (dst >= lim ? 13u : 0u)));
-        ok = ok && !dead && ref_exit < ns && dst < lim;
-        sh.link[lane] = (ref_exit & 0xFFu) | (slot_fill << 8);
-    }
-    HUFD_STAMP(0, 3);
-    __syncthreads();
-    if (lane == 0) {
-        /* how the chunk is left does not depend on how it is entered: the next chunk may start on its first sub-chunk
-         * (lane 0 writes every version of the chunk's word: one wave's stores to one address stay in order) */
-        granule_store(&status[c], kFuseExit | ((u64)(sh.link[HUFD_DEC_LANES - 1] & 0xFFu) << kFuseExitShift));
-    }
-
-    /* H: my own sub-chunk from my true entry state to the meeting bit, symbols behind my neighbour's in its slot
-     * (lane 0, whose entry state the previous chunk knows, walks into the dump; its rows are the candidates' below) */
-    {
-        const u32 prev = lane ? sh.link[lane - 1] : 0u;
-        const u32 entry = prev & 0xFFu;
-        const u32 at = lane ? my_slot - kFuseSlotBytes : dump_at;
-        const u32 dst0 = lane ? at + (prev >> 8) : at;
-        const u32 lim = lane ? at + kFuseSlotFill : at + (u32)sizeof(sh.dump) - kFuseRowMax;
-        u32 dst = dst0;
-        u32 st = rw.state_at(entry < ns ? entry : 0u, 0);
-        bool dd = false;
-#pragma unroll
-        for (u32 r = 0; r < kFastMaxMeet; ++r) {
-            if (r < meet_row) {
-                st = fuse_row<SURE>(st, w[r], w[r + 1], table, rw, lds_bytes, dst);
-                dd = dd || rw.died(st);
-                st = rw.next_row(st, dd);
-                dst = dst < lim ? dst : lim;
-            }
-        }
-        const bool reached = !dd && rw.offset_of(st) == meet_bit && dst < lim;
-        ok = ok && (lane == 0 || reached);
-        why = why ? why : (lane == 0 || reached ? 0u : 4u);
-        if (lane) {
-            sh.hcnt[lane - 1] = (u16)(dst - dst0);
-        }
-        if (lane == HUFD_DEC_LANES - 1) {
-            sh.hcnt[lane] = 0; /* (the next chunk's first sub-chunk is the next chunk's) */
-        }
-    }
-    /* sub-chunk 0 from every entry state the chunk may be entered in (lanes 0 .. ns-1 of wave 0), step by step */
-    if (lane < kWave) {
-        const u32 target = __shfl(meet_bit, 0);
-        const bool mine = lane < ns && lane < HUFD_DEC_MAX_STATES;
-        const u32 dst0 = mine ? (u32)(sh.cand[lane] - lds_bytes) : dump_at;
-        const u32 lim = dst0 + (mine ? kFuseCandBytes : (u32)sizeof(sh.dump)) - kFuseRowMax;
-        u32 dst = dst0;
-        u32 st = rw.state_at(mine ? lane : 0u, 0);
-        bool dd = false;
-        u32 hi = sh.sub0[0];
-        for (u32 r = 0; r < meet_row; ++r) {
-            const u32 lo = sh.sub0[r + 1];
-            st = fuse_row<SURE, true>(st, hi, lo, table, rw, lds_bytes, dst);
-            dd = dd || rw.died(st);
-            st = rw.next_row(st, dd);
-            dst = dst < lim ? dst : lim;
-            hi = lo;
-        }
-        const bool reached = !dd && mine && rw.offset_of(st) == target && dst < lim;
-        if (lane < HUFD_DEC_MAX_STATES) {
-            sh.cand_cnt[lane] = reached ? dst - dst0 : HUFD_NONE32;
-        }
-    }
-    HUFD_STAMP(0, 4);
-    __syncthreads();
-
-    /* what every slot holds, and where it goes */
-    const u32 len = (sh.link[lane] >> 8) + sh.hcnt[lane];
-    ok = ok && len >= 16u && len < kFuseSlotFill;
-    why = why ? why : (ok ? 0u : 5u);
-    const u32 incl = wave_inclusive_sum_dpp(len, wl);
-    if (wl == kWave - 1) {
-        sh.wave_tot[lane / kWave] = incl;
-    }
-    if (!ok) {
-        sh.bad = 1;
-        sh.why = why;
-    }
-    __syncthreads();
-    u32 body = 0; /* symbols from sub-chunk 0's meeting bit to the end of the chunk */
-    {
-        u32 before = 0;
-#pragma unroll
-        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
-            before += wv < lane / kWave ? sh.wave_tot[wv] : 0u;
-            body += sh.wave_tot[wv];
-        }
-        sh.pos[lane] = before + incl - len;
-    }
-    bool failed = sh.bad != 0;
-    HUFD_STAMP(0, 5);
-
-    /* wave 0: the chunk's entry state, its count to the chunks behind, its place from the chunks in front */
-    const u32 exit_state = sh.link[HUFD_DEC_LANES - 1] & 0xFFu;
-    if (lane < kWave) {
-        u32 e = 0, n0 = 0;
-        u64 base = 0;
-        u32 late = 0; /* (diagnostics: why wave 0 gives up) */
-        if (!failed) {
-            if (first) {
-                e = items[rec.item].first_bit;
-            } else {
-                u64 st = 0;
-                for (u32 spins = 0;; ++spins) {
-                    st = granule_load_now(&status[c - 1]);
-                    if (st & (kFuseExit | kFuseFail)) {
-                        break;
-                    }
-                    if (spins > kFuseSpinLimit || word_load_now(&ctl[0]) != 0) {
-                        late = spins > kFuseSpinLimit ? 6u : 14u;
-                        st = kFuseFail;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
+                for (u32 r = 0; r < kSubWords; ++r) {
+                    const u64 pair = ((u64)w[r] << 32) | w[r + 1];
+                    u32 lo_acc = 0, hi_acc = 0;
+                    fuse_sure<0, SURE>(state, pair, wlut_at, fw, lo_acc, hi_acc);
+                    fuse_more<SURE>(state, pair, wlut_at, fw, lo_acc, hi_acc);
+                    const bool now = fw.died(state) || fw.open(state);
+                    dd = dd || now;
+                    state = now ? (state & ~kFuseFieldMask) | fw.state_at(0) : state + 32u;
+                    *reinterpret_cast<two_words *>(lds_bytes + at) = two_words{lo_acc, hi_acc};
+                    const u32 sofar = fw.count_of(state);
+                    at = slot_at + (sofar < kFuseSlotFill ? sofar : kFuseSlotFill); /* (a slot that is full stays full: the tile gives up below) */
                 }
-                failed = (st & kFuseFail) != 0;
-                late = failed && !late ? 15u : late;
-                e = (u32)(st >> kFuseExitShift) & 0xFFu;
+                exit_state = fw.offset_of(state);
+                count = fw.count_of(state);
+                dead = dd;
             }
-            n0 = e < ns && e < HUFD_DEC_MAX_STATES ? sh.cand_cnt[e] : HUFD_NONE32;
-            late = !failed && n0 == HUFD_NONE32 ? 7u : late;
-            failed = failed || n0 == HUFD_NONE32; /* the true path dies in front of the meeting bit: the stream is damaged */
+        };
+        walk(true, entry < ns ? entry : 0u);
+        entry = entry < ns ? entry : HUFD_NONE32;
+        FUSE_STAMP_ADD(2);
+
+        /* every guess against the exit state of the lane in front; who guessed wrong walks again from there.  Lane 1 of a tile
+         * that is not its item's first has the tile in front to ask (`front_exit`, once that tile has said how it is left). */
+        u32 front_exit = HUFD_NONE32, walked_twice = 0, said_exit = HUFD_NONE32, why = 0;
+        bool asked_front = first_tile;
+        for (;;) {
+            u32 in_front = __shfl_up(exit_state, 1);
+            in_front = (!first_tile && lane == 1) ? (front_exit != HUFD_NONE32 ? front_exit : entry) : in_front;
+            bool wrong = active && lane != 0 && in_front != entry;
+            for (u32 round = 0; round < kFuseRepairRounds && __any(wrong); ++round) {
+                walked_twice += (u32)__builtin_popcountll(__ballot(wrong));
+                load_rows();
+                walk(wrong && in_front < ns, in_front);
+                entry = wrong ? in_front : entry;
+                in_front = __shfl_up(exit_state, 1);
+                in_front = (!first_tile && lane == 1) ? (front_exit != HUFD_NONE32 ? front_exit : entry) : in_front;
+                wrong = active && lane != 0 && in_front != entry;
+            }
+            if (__any(wrong)) {
+                why = 2u;
+                break;
+            }
+            const u32 leaves = __shfl(exit_state, n_lanes - 1);
+            if (said_exit == HUFD_NONE32) {
+                /* how the tile is left: a function of its own bytes, said at once */
+                said_exit = leaves;
+                if (lane == 0) {
+                    word_store(&tile_exit[t], kFuseReady | (leaves & 15u));
+                }
+            } else if (leaves != said_exit) {
+                why = 5u; /* lane 1, walked again from its true entry state, did not fall into step: the tile is left otherwise than said */
+                break;
+            }
+            if (asked_front) {
+                break;
+            }
+            /* how the tile in front is left = lane 1's true entry state */
+            u32 pe = 0;
+            for (u32 spins = 0;; ++spins) {
+                pe = uniform32(word_load_now(&tile_exit[t - 1]));
+                if (pe & kFuseReady) {
+                    break;
+                }
+                if (spins > kFuseSpinLimit || uniform32(word_load_now(&ctl[0])) != 0) {
+                    why = spins > kFuseSpinLimit ? 6u : 14u;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (why) {
+                break;
+            }
+            asked_front = true;
+            front_exit = pe & 15u;
+            if (__shfl(entry, 1) == front_exit) {
+                break;
+            }
         }
-        const u64 count = (u64)n0 + body;
-        if (!failed) {
+        FUSE_STAMP_ADD(3);
+        FUSE_STAMP_COUNT(7, 1);
+        why = !why && __any(payload && dead) ? 3u : why;
+        why = !why && __any(payload && exit_state >= ns) ? 4u : why;
+        why = !why && __any(payload && (count > kFuseSlotFill || count < 16u)) ? 7u : why; /* symbol-dense data: more than a slot holds */
+        why = t == fail_tile ? 11u : why;
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(HUFD_FUSE_DEBUG)
+        if (why == 3u || why == 2u) {
+            printf("tile %u why %u lane %2u active %d payload %d entry %u front %u exit %u dead %d count %u twice %u\n", t, why, lane, (int)active,
+                   (int)payload, entry, front_exit, exit_state, (int)dead, count, walked_twice);
+        }
+#endif
+
+        /* where every lane's symbols go; the tile's count and exit state to the tiles behind */
+        const u32 n = payload ? count : 0u;
+        const u32 incl = wave_inclusive_sum_dpp(n, lane);
+        const u32 pos = incl - n;
+        const u32 total = __shfl(incl, kWave - 1);
+        const u32 leaves = __shfl(exit_state, n_lanes - 1) & 15u;
+        const u32 g = t / kOpGroupTiles, p = t % kOpGroupTiles, rr = g / kOpRoundGroups, gi = g % kOpRoundGroups;
+        u32 a = kFuseReady;
+        u64 b = kOpGroupTiles * kOpArrive, rb = 0, ib = kOpReady;
+        if (!why) {
             if (lane == 0) {
-                granule_store(&status[c], (first ? kFuseIncl : kFuseAgg) | kFuseExit | ((u64)exit_state << kFuseExitShift) | count);
-            }
-            if (!first) {
-                /* symbols of my item in front of me: the chunks in front, 64 at a time, back to one that knows its own answer */
-                const u32 item_first = items[rec.item].first_chunk;
-                u32 idx = c - 1;
-                for (;;) {
-                    const bool inside = idx >= lane && idx - lane >= item_first;
-                    u64 st = inside ? granule_load_now(&status[idx - lane]) : kFuseIncl;
-                    u64 need = 0;
-                    bool known = false;
-                    for (u32 spins = 0;; ++spins) {
-                        const u64 have_incl = __ballot((st & kFuseIncl) != 0);
-                        const u64 have_any = __ballot((st & (kFuseIncl | kFuseAgg | kFuseFail)) != 0);
-                        known = have_incl != 0;
-                        const u32 upto = known ? (u32)__builtin_ctzll(have_incl) : kWave - 1;
-                        need = upto == 63 ? ~0ull : (1ull << (upto + 1)) - 1ull;
-                        if ((have_any & need) == need) {
-                            break;
-                        }
-                        if (spins > kFuseSpinLimit || word_load_now(&ctl[0]) != 0) {
-                            late = spins > kFuseSpinLimit ? 8u : 14u;
-                            failed = true;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(2);
-                        if (inside && !(st & (kFuseIncl | kFuseAgg | kFuseFail))) {
-                            st = granule_load_now(&status[idx - lane]);
-                        }
-                    }
-                    if (failed) {
-                        break;
-                    }
-                    const bool mine = ((need >> wl) & 1ull) != 0;
-                    if (__any(mine && (st & kFuseFail) != 0)) {
-                        late = 9u;
-                        failed = true;
-                        break;
-                    }
-                    u64 part = mine ? (st & kFuseValue) : 0ull;
-#pragma unroll
-                    for (u32 d = kWave / 2; d > 0; d >>= 1) {
-                        part += __shfl_xor(part, d);
-                    }
-                    base += part;
-                    if (known) {
-                        break;
-                    }
-                    idx -= kWave; /* (no chunk of the item in the window knew: the item has at least 64 more in front) */
+                arrival_quiet(&tile_agg[t], kFuseReady | total, &group_acc[(u64)g * kOpGroupStride], kOpArrive + total);
+                if (walked_twice) {
+                    atomicAdd(&ctl[2], walked_twice);
                 }
             }
-            late = !failed && base + count > rec.out_cap ? 10u : late;
-            failed = failed || base + count > rec.out_cap; /* the output is too short for this chunk: the other road finds the edge */
+            /* asked for now, looked at when the first batch is staged */
+            a = lane < p ? word_load(&tile_agg[g * kOpGroupTiles + lane]) : kFuseReady;
+            b = lane < gi ? granule_load(&group_acc[(u64)(rr * kOpRoundGroups + lane) * kOpGroupStride]) : kOpGroupTiles * kOpArrive;
+            rb = granule_load(&round_base[rr]);
+            ib = first_tile ? kOpReady : granule_load(&item_base[rec.item]);
         }
-        if (lane == 0) {
-            if (failed) {
+
+        FUSE_STAMP_ADD(4);
+        u64 item_off = 0;
+        if (!why) {
+            /* ---- the symbols in front of the tile: asked for above; if not there yet, ask again */
+            for (u32 spins = 0;; ++spins) {
+                const bool there = (a & kFuseReady) != 0 && (b >> 40) == kOpGroupTiles && (rb & kOpReady) != 0 && (ib & kOpReady) != 0;
+                if (__all(there)) {
+                    break;
+                }
+                if (spins > kFuseSpinLimit || uniform32(word_load_now(&ctl[0])) != 0) {
+                    why = spins > kFuseSpinLimit ? 8u : 14u;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+                if (lane < p && !(a & kFuseReady)) {
+                    a = word_load_now(&tile_agg[g * kOpGroupTiles + lane]);
+                }
+                if (lane < gi && (b >> 40) != kOpGroupTiles) {
+                    b = granule_load_now(&group_acc[(u64)(rr * kOpRoundGroups + lane) * kOpGroupStride]);
+                }
+                if (!(rb & kOpReady)) {
+                    rb = granule_load_now(&round_base[rr]);
+                }
+                if (!(ib & kOpReady)) {
+                    ib = granule_load_now(&item_base[rec.item]);
+                }
+            }
+        }
+        if (!why) {
+            u64 front = (lane < p ? (u64)(a & 0xFFFFFFu) : 0ull) + (lane < gi ? (b & kOpSum) : 0ull);
+#pragma unroll
+            for (u32 d = kWave / 2; d > 0; d >>= 1) {
+                front += __shfl_xor(front, d);
+            }
+            front += rb & ~kOpReady;
+            if (first_tile) {
+                if (lane == 0) {
+                    granule_store(&item_base[rec.item], kOpReady | front);
+                }
+            } else {
+                item_off = front - (ib & ~kOpReady);
+            }
+            why = !why && item_off + total > rec.out_cap ? 10u : why; /* the output is too short: the other road finds the edge */
+        }
+        FUSE_STAMP_ADD(5);
+        if (!why) {
+            /* ---- the slots to HBM: eight lanes a slot, 16 bytes each, the last 16 of a slot as they lie (they overlap
+             * the row in front with the same bytes) */
+            u8 *dst = d_out + rec.out_off + item_off;
+            const u32 row = lane & 7u;
+#pragma unroll
+            for (u32 it = 0; it < kWave / 8; ++it) {
+                const u32 s = it * 8 + (lane >> 3);
+                const u32 ns_ = __shfl(n, s), ps = __shfl(pos, s);
+                const u32 from = 16 * row + 16 <= ns_ ? 16 * row : ns_ - 16;
+                if (16 * row < ns_) {
+                    const unaligned_uint4 v =
+                        *reinterpret_cast<const unaligned_uint4 *>(sh.slots[wave] + s * kFuseSlotBytes + from);
+                    *reinterpret_cast<unaligned_uint4 *>(dst + ps + from) = v;
+                }
+            }
+            wave_step(); /* the slots are free for the next tile */
+        }
+        FUSE_STAMP_ADD(6);
+        if (why) {
+            if (lane == 0) {
                 if (word_load_now(&ctl[0]) == 0) {
-                    ctl[1] = (c << 8) | (late ? late : sh.why); /* (diagnostics; who is first is not decided exactly) */
+                    ctl[1] = (t << 8) | why; /* (diagnostics; who is first is not decided exactly) */
                 }
                 word_store(&ctl[0], 1u);
-                granule_store(&status[c], kFuseFail);
-            } else {
-                if (!first) {
-                    granule_store(&status[c], kFuseIncl | kFuseExit | ((u64)exit_state << kFuseExitShift) | (base + count));
-                }
-                if (rec.valid - HUFD_DEC_CHUNK_BYTES < HUFD_DEC_CHUNK_BYTES + 8u) {
-                    /* the item's last chunk inside the stream: the chunk(s) the stream ends in start here */
-                    chunk_entry[c + 1] = entry_pack(exit_state, true);
-                    chunk_base[c + 1] = base + count;
-                }
             }
-            sh.bad = failed ? 1u : 0u;
-            sh.entry = e;
-            sh.n0 = n0;
-            sh.base = base;
+            return;
         }
-        HUFD_STAMP(0, 6);
-    }
-    __syncthreads();
-    if (sh.bad) {
-        return;
-    }
-
-    /* the slots to HBM: sub-chunk 0's first symbols a byte a lane, then eight lanes a slot, 16 bytes each, the last
-     * 16 of a slot as they lie (any alignment; they overlap the row in front with the same bytes) */
-    {
-        const u32 n0 = sh.n0;
-        u8 *out = d_out + rec.out_off + sh.base;
-        if (lane < n0) {
-            out[lane] = sh.cand[sh.entry][lane];
-        }
-        u8 *body_out = out + n0;
-        const u32 row = lane & 7u;
-#pragma unroll
-        for (u32 it = 0; it < HUFD_DEC_LANES / 32; ++it) {
-            const u32 s = it * 32 + (lane >> 3);
-            const u32 n = (sh.link[s] >> 8) + sh.hcnt[s];
-            const u32 p = sh.pos[s];
-            const u32 from = 16 * row + 16 <= n ? 16 * row : n - 16;
-            if (16 * row < n) {
-                const unaligned_uint4 v = *reinterpret_cast<const unaligned_uint4 *>(sh.slots + s * kFuseSlotBytes + from);
-                *reinterpret_cast<unaligned_uint4 *>(body_out + p + from) = v;
-            }
+        if ((rec.flags & 2u) != 0 && lane == 0) {
+            /* the item's last tile inside the stream: the chunk(s) the stream ends in start here */
+            chunk_entry[rec.tail_chunk] = entry_pack(leaves, true);
+            chunk_base[rec.tail_chunk] = item_off + total;
         }
     }
-    HUFD_STAMP(0, 7);
+    FUSE_STAMP_FLUSH;
 }
 
 /* ------------------------------------------------------------------ decode: emit */
@@ -6868,6 +6911,10 @@ int hufk_decode_one_pass_applies(const struct hufd_tables *tb) {
     return lb == 10 ? sure >= 2 && sure <= 5 : sure >= 2 && sure <= 3;
 }
 
+uint64_t hufk_decode_zero_bytes(uint32_t n_tiles, uint32_t n_items) {
+    return dec_onepass_layout_of(n_tiles, n_items).bytes;
+}
+
 uint64_t hufk_encode_zero_bytes(uint32_t n_segs, uint32_t n_items) {
     return onepass_layout_of(n_segs, n_items).bytes;
 }
@@ -7084,19 +7131,24 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     /* The chunks inside streams in ONE pass (dec_onepass) where the coder allows: the kernels of the two-pass road for
      * those chunks are queued behind it all the same and look at its ctl word first -- they run only if it gave up. */
     const u32 *gate = nullptr;
-    if (a->n_chunks && a->n_tail < a->n_chunks && a->fuse_status && a->fuse_ctl && a->fuse_mode != 1 && !a->old_sync &&
+    if (a->n_chunks && a->n_tiles && a->tiles && a->fuse_block && a->fuse_mode != 1 && !a->old_sync &&
         hufk_decode_one_pass_applies(&a->tables)) {
         const uint32_t lb = a->tables.lut_bits <= 10 ? 10u : 12u;
         const uint32_t sure = row_walk(lb, a->tables.max_bits).sure;
-        const u32 fail_chunk = a->fuse_mode == 2 ? a->n_chunks / 2 : HUFD_NONE32;
+        const u32 fail_tile = a->fuse_mode == 2 ? a->n_tiles / 2 : HUFD_NONE32;
+        const dec_onepass_layout l = dec_onepass_layout_of(a->n_tiles, a->n_items);
+        u8 *blk = (u8 *)a->fuse_block;
         bool launched = true;
 #define HUFK_LAUNCH_ONEPASS_DEC(LBV, SUREV)                                                                            \
     hipLaunchKernelGGL(                                                                                                \
-        (dec_onepass_kernel<LBV, SUREV>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fuse_shared<LBV>), \
-        st, a->tables, a->chunk_rec, a->items, (const u8 *)a->d_in, (u8 *)a->d_out, a->fuse_status, a->fuse_ctl,       \
-        a->chunk_entry, a->chunk_base, fail_chunk)
-        (void)hipMemsetAsync(a->fuse_status, 0, (size_t)a->n_chunks * sizeof(u64), st);
-        (void)hipMemsetAsync(a->fuse_ctl, 0, 2 * sizeof(u32), st);
+        (dec_onepass_kernel<LBV, SUREV>),                                                                              \
+        dim3(persistent_grid(dec_onepass_kernel<LBV, SUREV>, kFuseThreads, (uint32_t)sizeof(fuse_shared<LBV>),          \
+                             (a->n_tiles + 1 + kFuseWaves - 1) / kFuseWaves)),                                         \
+        dim3(kFuseThreads), (uint32_t)sizeof(fuse_shared<LBV>), st, a->tables, a->tiles, a->n_tiles,                   \
+        (const u8 *)a->d_in, (u8 *)a->d_out, (u32 *)(blk + l.ctl), (u32 *)(blk + l.tile_agg), (u32 *)(blk + l.tile_exit), \
+        (u64 *)(blk + l.group_acc),                                                                                    \
+        (u64 *)(blk + l.round_base), (u64 *)(blk + l.item_base), a->chunk_entry, a->chunk_base, fail_tile)
+        (void)hipMemsetAsync(blk, 0, l.bytes, st);
         if (lb == 10) {
             switch (sure) {
                 case 2: HUFK_LAUNCH_ONEPASS_DEC(10, 2); break;
@@ -7113,7 +7165,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             }
         }
 #undef HUFK_LAUNCH_ONEPASS_DEC
-        gate = launched ? a->fuse_ctl : nullptr;
+        gate = launched ? (const u32 *)(blk + l.ctl) : nullptr;
     }
     if (a->n_chunks) {
         /* chunks inside the stream the short way; the rest, and those that turn out irregular, through the list */

@@ -704,7 +704,8 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     hufs_free(p->d_chunk_entry);
     hufs_free(p->d_chunk_base);
     hufs_free(p->d_chunk_rec);
-    hufs_free(p->d_fuse_status);
+    hufs_free(p->d_tiles);
+    hufs_free(p->d_fuse_block);
     hufs_free(p->d_states);
     hufs_free(p->d_results);
     p->d_items = NULL;
@@ -728,7 +729,9 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     p->d_chunk_entry = NULL;
     p->d_chunk_base = NULL;
     p->d_chunk_rec = NULL;
-    p->d_fuse_status = NULL;
+    p->d_tiles = NULL;
+    p->d_fuse_block = NULL;
+    p->cap_tiles = p->cap_fuse_block = 0;
     p->d_states = NULL;
     p->d_results = NULL;
     p->cap_items = p->cap_chunks = p->cap_large = p->cap_runs = 0;
@@ -773,6 +776,17 @@ static uint64_t dec_item_chunks(
     return (it->in_len + HUFD_DEC_CHUNK_BYTES - 1) / HUFD_DEC_CHUNK_BYTES;
 }
 
+/* sub-chunks of an item that dec_onepass takes: those of its chunks that lie inside the stream with 8 more bytes behind */
+static uint64_t dec_item_inside_subs(uint64_t chunks, uint64_t in_len) {
+    const uint64_t inside = chunks && in_len >= 8 ? (in_len - 8) / HUFD_DEC_CHUNK_BYTES : 0;
+    return (inside < chunks ? inside : chunks) * HUFD_DEC_LANES;
+}
+/* ... as tiles: the first of 64 sub-chunks, the others of 63 and the last one of the tile in front */
+static uint64_t dec_item_tiles(uint64_t chunks, uint64_t in_len) {
+    const uint64_t subs = dec_item_inside_subs(chunks, in_len);
+    return subs == 0 ? 0 : (subs <= HUFD_TILE_LANES ? 1 : 1 + (subs - HUFD_TILE_LANES + HUFD_TILE_LANES - 2) / (HUFD_TILE_LANES - 1));
+}
+
 static int dec_plan_fill(
     struct aws_huffman_amd_decode_plan *p,
     const struct aws_huffman_amd_decode_item *items,
@@ -783,7 +797,7 @@ static int dec_plan_fill(
         return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION);
     }
     const uint64_t tiny_limit = dec_tiny_limit(items, n_items);
-    uint64_t n_chunks = 0, n_large = 0, n_runs = 0;
+    uint64_t n_chunks = 0, n_large = 0, n_runs = 0, n_tiles = 0;
     for (size_t i = 0; i < n_items; ++i) {
         /* symbol counts in the scan's function entries are 26-bit; 4 GiB of encoded bytes per item is the limit */
         if (items[i].first_bit > 7 || items[i].in_len > 0xFFFFFFFFull) {
@@ -793,8 +807,9 @@ static int dec_plan_fill(
         n_chunks += chunks;
         n_large += chunks > HUFD_SCAN_SMALL_MAX;
         n_runs += chunks > HUFD_SCAN_SMALL_MAX ? (chunks + HUFD_SCAN_RUN_CHUNKS - 1) / HUFD_SCAN_RUN_CHUNKS : 0;
+        n_tiles += dec_item_tiles(chunks, items[i].in_len);
     }
-    if (n_chunks >= 0xFFFFFFFFull || n_items >= 0xFFFFFFFFull) {
+    if (n_chunks >= 0xFFFFFFFFull || n_items >= 0xFFFFFFFFull || n_tiles >= 0x00FFFFFFull) {
         return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
     }
 
@@ -805,17 +820,19 @@ static int dec_plan_fill(
     uint32_t *h_runs = malloc((n_runs ? n_runs : 1) * 2 * sizeof(uint32_t));
     uint32_t *h_tail = malloc((n_items ? n_items : 1) * 2 * sizeof(uint32_t));
     uint32_t *h_tiny = malloc((n_items ? n_items : 1) * sizeof(uint32_t));
-    if (!h_items || !h_chunk_item || !h_chunk_rec || !h_large || !h_runs || !h_tail || !h_tiny) {
+    struct hufd_tile_rec *h_tiles = malloc((n_tiles ? n_tiles : 1) * sizeof(*h_tiles));
+    if (!h_tiles || !h_items || !h_chunk_item || !h_chunk_rec || !h_large || !h_runs || !h_tail || !h_tiny) {
         free(h_chunk_rec);
         free(h_tail);
         free(h_tiny);
+        free(h_tiles);
         free(h_runs);
         free(h_items);
         free(h_chunk_item);
         free(h_large);
         return aws_raise_error(AWS_ERROR_OOM);
     }
-    uint32_t chunk = 0, large = 0, run = 0, tail = 0, tiny = 0, deep = 0;
+    uint32_t chunk = 0, large = 0, run = 0, tail = 0, tiny = 0, deep = 0, tile = 0;
     uint64_t tail_stage = 0; /* the most symbols a chunk that holds the end of a stream can decode to */
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_decode_item *src = &items[i];
@@ -835,6 +852,24 @@ static int dec_plan_fill(
         } else if (dec_item_is_deep(eng, src, tiny_limit)) {
             dst->tiny = 1;
             h_tiny[n_items - ++deep] = (uint32_t)i;
+        }
+        {
+            const uint64_t subs = dec_item_inside_subs(chunks, src->in_len);
+            const uint64_t tiles_here = dec_item_tiles(chunks, src->in_len);
+            for (uint64_t k = 0; k < tiles_here; ++k) {
+                /* tile 0: sub-chunks 0 .. 63; tile k: sub-chunk 63 k (again) and 63 k + 1 .. 63 k + 63 */
+                const uint64_t first_sub = k * (HUFD_TILE_LANES - 1);
+                const uint64_t left = subs - first_sub;
+                struct hufd_tile_rec *tr = &h_tiles[tile++];
+                tr->src_off = src->in_offset + first_sub * HUFD_DEC_SUB_BYTES;
+                tr->out_off = src->out_offset;
+                tr->out_cap = src->out_capacity;
+                tr->item = (uint32_t)i;
+                tr->n_lanes = (uint16_t)(left < HUFD_TILE_LANES ? left : HUFD_TILE_LANES);
+                tr->flags = (uint16_t)((k == 0 ? 1u : 0u) | (k + 1 == tiles_here ? 2u : 0u) | ((uint32_t)src->first_bit << 8));
+                tr->tail_chunk = chunk + (uint32_t)(subs / HUFD_DEC_LANES);
+                tr->reserved = 0;
+            }
         }
         for (uint32_t k = 0; k < chunks; ++k) {
             /* fewer than a chunk + 8 bytes left: the end of the stream is in (or just behind) this chunk */
@@ -897,18 +932,35 @@ static int dec_plan_fill(
         p->d_chunk_entry = hufs_malloc(cc * sizeof(uint32_t));
         p->d_chunk_base = hufs_malloc(cc * sizeof(uint64_t));
         p->d_chunk_rec = hufs_malloc(cc * sizeof(struct hufd_chunk_rec));
-        p->d_fuse_status = hufs_malloc((cc + 1) * sizeof(uint64_t));
         p->d_states = hufs_malloc(ci * sizeof(struct hufd_dec_item_state));
         p->d_results = hufs_malloc(ci * sizeof(struct hufd_dec_result));
         if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_cp_tab || !p->d_chunk_fn || !p->d_slow_list || !p->d_chunk_entry ||
             !p->d_tail || !p->d_tiny || !p->d_dense_list || !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_tail_entry || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
-            !p->d_chunk_base || !p->d_chunk_rec || !p->d_fuse_status || !p->d_states || !p->d_results) {
+            !p->d_chunk_base || !p->d_chunk_rec || !p->d_states || !p->d_results) {
             err = 2;
         }
         p->cap_items = ci;
         p->cap_chunks = cc;
         p->cap_large = cl;
         p->cap_runs = cr;
+    }
+    {
+        const size_t zero_bytes = (size_t)hufk_decode_zero_bytes((uint32_t)n_tiles, (uint32_t)n_items);
+        if (!err && n_tiles > p->cap_tiles) {
+            hufs_free(p->d_tiles);
+            p->d_tiles = hufs_malloc(n_tiles * sizeof(struct hufd_tile_rec));
+            p->cap_tiles = p->d_tiles ? n_tiles : 0;
+            err = p->d_tiles ? 0 : 2;
+        }
+        if (!err && zero_bytes > p->cap_fuse_block) {
+            hufs_free(p->d_fuse_block);
+            p->d_fuse_block = hufs_malloc(zero_bytes);
+            p->cap_fuse_block = p->d_fuse_block ? zero_bytes : 0;
+            err = p->d_fuse_block ? 0 : 2;
+        }
+        if (!err && n_tiles) {
+            err = hufs_copy_h2d(p->d_tiles, h_tiles, n_tiles * sizeof(*h_tiles), eng->stream);
+        }
     }
     if (!err) {
         err = hufs_copy_h2d(p->d_items, h_items, n_items * sizeof(*h_items), eng->stream);
@@ -951,6 +1003,7 @@ static int dec_plan_fill(
     free(h_runs);
     free(h_tail);
     free(h_tiny);
+    free(h_tiles);
     if (err) {
         return raise_hip(err);
     }
@@ -959,6 +1012,7 @@ static int dec_plan_fill(
     p->n_large = (uint32_t)n_large;
     p->n_runs = (uint32_t)n_runs;
     p->n_tail = tail;
+    p->n_tiles = (uint32_t)n_tiles;
     p->tail_stage_bytes = tail_stage + 32 < 0xFFFFFFFFu ? (uint32_t)tail_stage + 32u : 0u;
     p->n_tiny = tiny;
     p->n_deep = deep;
@@ -1059,9 +1113,10 @@ int aws_huffman_amd_decode_plan_launch_staged(
          * of the launch give up, so that the way back to the two-pass kernels can be tested */
         a.fuse_mode = mode && strcmp(mode, "two-pass") == 0 ? 1u : (mode && strcmp(mode, "one-pass-fails") == 0 ? 2u : 0u);
     }
-    a.fuse_status = p->d_fuse_status;
-    a.fuse_ctl = (uint32_t *)(p->d_fuse_status + p->cap_chunks);
-    p->one_pass_tried = a.fuse_mode != 1 && !a.old_sync && p->n_tail < p->n_chunks && hufk_decode_one_pass_applies(&a.tables);
+    a.tiles = p->d_tiles;
+    a.n_tiles = p->n_tiles;
+    a.fuse_block = p->d_fuse_block;
+    p->one_pass_tried = a.fuse_mode != 1 && !a.old_sync && p->n_tiles && hufk_decode_one_pass_applies(&a.tables);
     a.stage_events = stage_events;
     hufs_set_device(p->engine->device);
     const int err = hufk_decode_launch(&a, stream ? stream : p->engine->stream);
@@ -1104,15 +1159,15 @@ void aws_huffman_amd_decode_result_from_raw(
 int aws_huffman_amd_decode_plan_road(struct aws_huffman_amd_decode_plan *p, void *stream, uint32_t *road, uint32_t *detail) {
     *road = AWS_HUFFMAN_AMD_ROAD_TWO_PASS;
     if (detail) {
-        *detail = 0;
+        detail[0] = detail[1] = 0;
     }
     if (!p->one_pass_tried) {
         return AWS_OP_SUCCESS;
     }
     void *st = stream ? stream : p->engine->stream;
-    uint32_t ctl[2] = {0, 0};
+    uint32_t ctl[4] = {0, 0, 0, 0};
     hufs_set_device(p->engine->device);
-    int err = hufs_copy_d2h(ctl, p->d_fuse_status + p->cap_chunks, sizeof(ctl), st);
+    int err = hufs_copy_d2h(ctl, p->d_fuse_block, sizeof(ctl), st);
     if (!err) {
         err = hufs_stream_sync(st);
     }
@@ -1120,8 +1175,9 @@ int aws_huffman_amd_decode_plan_road(struct aws_huffman_amd_decode_plan *p, void
         return raise_hip(err);
     }
     *road = ctl[0] ? AWS_HUFFMAN_AMD_ROAD_ONE_PASS_GAVE_UP : AWS_HUFFMAN_AMD_ROAD_ONE_PASS;
-    if (detail && ctl[0]) {
-        *detail = ctl[1];
+    if (detail) {
+        detail[0] = ctl[0] ? ctl[1] : 0;
+        detail[1] = ctl[2];
     }
     return AWS_OP_SUCCESS;
 }

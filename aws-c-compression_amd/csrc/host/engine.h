@@ -106,7 +106,10 @@ struct aws_huffman_amd_decode_plan {
     uint64_t *d_chunk_base;
     struct hufd_chunk_rec *d_chunk_rec;
     uint32_t one_pass_tried; /* the last launch queued dec_onepass for the chunks inside streams */
-    uint64_t *d_fuse_status; /* [cap_chunks + 1] dec_onepass: a flagged word per chunk, then its ctl words */
+    struct hufd_tile_rec *d_tiles; /* [n_tiles] dec_onepass: the chunks inside streams as tiles of 64 sub-chunks, one wave each */
+    void *d_fuse_block;            /* its look-back words, zeroed by every launch; first: its ctl words */
+    uint32_t n_tiles;
+    size_t cap_tiles, cap_fuse_block;
     struct hufd_dec_item_state *d_states;
     struct hufd_dec_result *d_results;
 };

@@ -216,7 +216,8 @@ int aws_huffman_amd_decode_plan_road(
     struct aws_huffman_amd_decode_plan *plan,
     void *stream,
     uint32_t *road,
-    uint32_t *detail /* NULL, or (ONE_PASS_GAVE_UP) chunk << 8 | reason code of one of the chunks that gave up: diagnostics */);
+    uint32_t *detail /* NULL, or two words of diagnostics: [0] (ONE_PASS_GAVE_UP) tile << 8 | reason code of one of the tiles
+                      * that gave up, [1] sub-chunks whose entry state was guessed wrong and that were walked a second time */);
 
 /* ---- several GPUs: independent items sharded over the devices of one node ---- */
 

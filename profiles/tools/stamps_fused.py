@@ -31,17 +31,16 @@ for _ in range(2):
     eng.decode_launch(dp, d_enc, d_back)
     eng.decode_results(dp, 1)
 print("road", eng.decode_road(dp), eng.last_road_detail)
-chunks = min((e_len - 8) // 32768, MAX_WG)
-r = eng.download(d_rows, chunks * 64, offset=0).view(np.uint64).reshape(chunks, 8).astype(np.float64)
-r = r[(r[:, 0] > 0) & (r[:, 7] > r[:, 0])]
-d = np.diff(r, axis=1)
-life = r[:, 7] - r[:, 0]
-print("dec_onepass: %d chunks, %.0f clocks per workgroup (median %.0f), wave 0" % (len(r), life.mean(), np.median(life)))
-names = ["load the sub-chunks, build the tables", "U: all entry states to one head", "common row, R: walk to the end (symbols to slots)",
-         "wait for the other waves, H + candidates", "wait, slot lengths, scan", "entry state + look-back (wave 0)", "wait, slots to HBM"]
+r = eng.download(d_rows, 4096 * 64, offset=0).view(np.uint64).reshape(4096, 8).astype(np.float64)
+r = r[r[:, 7] > 0]  # persistent kernel: one row per resident workgroup, sums over the tiles of its wave 0 (both launches)
+tiles = r[:, 7]
+d = np.diff(r[:, :7], axis=1)
+per_tile = d / tiles[:, None]
+life = per_tile.sum(axis=1)
+print("dec_onepass: %d resident workgroups, %.1f tiles per wave; %.0f clocks per tile (median %.0f), wave 0 of each" % (
+    len(r), tiles.mean() / 2, life.mean(), np.median(life)))
+names = ["tile record, loads issued, G: the guess of the next lane's entry state", "R: the walk, symbols to the slot",
+         "guesses settled, exit said, the tile in front asked", "count published, offsets asked for",
+         "wait for the offsets in front", "slots to HBM"]
 for i, ph in enumerate(names):
-    print("   %-52s %9.0f  %5.1f %%   (median %.0f, p99 %.0f)" % (ph, d[:, i].mean(), 100 * d[:, i].mean() / life.mean(),
-                                                            np.median(d[:, i]), np.percentile(d[:, i], 99)))
-t0 = r[:, 0].min()
-print("kernel span %.0f clocks; starts of chunks 0 / 10%% / 50%% / 90%% / last: %s" % (
-    r[:, 7].max() - t0, [int(r[int(q * (len(r) - 1)), 0] - t0) for q in (0, 0.1, 0.5, 0.9, 1.0)]))
+    print("   %-72s %9.0f  %5.1f %%" % (ph, per_tile[:, i].mean(), 100 * per_tile[:, i].mean() / life.mean()))

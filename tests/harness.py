@@ -349,9 +349,10 @@ class Engine:
 
     def decode_road(self, plan):
         """0: two-pass kernels only, 1: one pass (dec_onepass), 2: dec_onepass gave up and the two-pass kernels took over."""
-        road, detail = C.c_uint32(99), C.c_uint32(0)
-        assert self.lib.aws_huffman_amd_decode_plan_road(plan, None, C.byref(road), C.byref(detail)) == 0
-        self.last_road_detail = (detail.value >> 8, detail.value & 0xFF)  # (chunk, reason) of a chunk that gave up
+        road, detail = C.c_uint32(99), (C.c_uint32 * 2)()
+        assert self.lib.aws_huffman_amd_decode_plan_road(plan, None, C.byref(road), detail) == 0
+        # (tile, reason) of a tile that gave up; sub-chunks walked twice (wrong guess of the entry state)
+        self.last_road_detail = (detail[0] >> 8, detail[0] & 0xFF, detail[1])
         return road.value
 
     def decode_results(self, plan, n):
