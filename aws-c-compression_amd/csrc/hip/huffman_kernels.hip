@@ -5103,14 +5103,15 @@ __global__ __launch_bounds__(256) void dec_scan_apply_kernel(
  * 1.65 x the algorithmic HBM traffic and ~33 vector instructions a symbol.  This kernel reads the stream once and
  * walks it once.  Two things make that possible:
  *
- *  - a walk's symbols do not have to wait for their place in the output: all lanes of a wave stand in the same row
- *    (32-bit word) of their sub-chunks, a row holds at most eight codes, and the k-th code of a row goes to byte k
- *    of a register pair -- a compile-time place (the steps of a row are unrolled: the codes that are certain to
- *    start in it, then nested conditions).  The table entry is symbol << 24 | 4096 - length: one add moves the
- *    shift amount (low 12 bits) and the symbol count (next 12), one v_perm_b32 keeps the symbol.  At the end of a
- *    row the pair goes to the lane's SLOT in LDS with one 8-byte store at the count so far (what lies behind the
- *    row's codes is overwritten by the next row's).  When the counts of a tile are known the slots leave for HBM,
- *    eight lanes a slot, 16 bytes each (the memory system takes any alignment);
+ *  - a walk's symbols do not have to wait for their place in the output: they go to the lane's SLOT in LDS as they
+ *    are found.  All lanes of a wave stand in the same row (32-bit word) of their sub-chunks, a row holds at most
+ *    eight codes, and the steps of a row are unrolled (the codes that are certain to start in it, then nested
+ *    conditions): the k-th code of a row is stored at (slot + symbols before the row) + k, k in the instruction.  The
+ *    table entry is symbol << 16 | 4096 - length: one add moves the shift amount (low 12 bits) and a symbol count
+ *    modulo 16 (the next four), which is what the row's end needs to move the slot address on; one byte store keeps
+ *    the symbol.  (An 8-byte store per row of a register pair filled by v_perm_b32 was measured first: LDS stores
+ *    that are not aligned cost several times their aligned price, 2.3 ms against this.)  When the counts of a tile
+ *    are known the slots leave for HBM, eight lanes a slot, 16 bytes each (the memory system takes any alignment);
  *  - nothing waits for an entry state.  A TILE is one wave's work: 64 neighbouring sub-chunks of 128 bytes.  Every
  *    lane first follows ONE walk through the last rows of its own sub-chunk, started on a row boundary (a window
  *    without a code moves it one bit on): where that walk leaves is a guess of the NEXT lane's entry state
@@ -5142,9 +5143,9 @@ constexpr u32 kFuseThreads = kFuseWaves * kWave;
 constexpr u32 kFuseGuessRows = 12;    /* rows of a sub-chunk the walk that guesses the next lane's entry state runs through */
 constexpr u32 kFuseRowSyms = 8;      /* codes that can start in a row (at least 4 bits each) */
 constexpr u32 kFuseSlotBytes = 136;  /* 34 words: neighbouring lanes' slots two banks apart */
-constexpr u32 kFuseSlotFill = 128;   /* symbols a slot takes (a row's eight bytes may lie behind them) */
+constexpr u32 kFuseSlotFill = 128;   /* a slot that fills up to here is not trusted (a row's eight bytes may lie behind) */
 constexpr u32 kFuseRepairRounds = 3;
-constexpr u32 kFuseField = 12;       /* bits of a walk state that hold the shift amount; the symbol count is the 12 above */
+constexpr u32 kFuseField = 12;       /* bits of a walk state that hold the shift amount; the symbol count modulo 16 is the 4 above */
 constexpr u32 kFuseFieldMask = (1u << kFuseField) - 1u;
 constexpr u32 kFuseSpinLimit = 1u << 14;
 constexpr u32 kFuseReady = 1u << 31; /* tile_agg: [31] published, [23:0] symbols; tile_exit: [31] published, [3:0] exit state */
@@ -5168,55 +5169,76 @@ struct fuse_walk {
     __device__ __forceinline__ bool died(u32 state) const {
         return (state & kFuseFieldMask) < floor;
     }
-    __device__ __forceinline__ u32 count_of(u32 state) const {
-        return (state >> kFuseField) & kFuseFieldMask;
+    __device__ __forceinline__ u32 count16_of(u32 state) const { /* symbols so far, modulo 16 */
+        return (state >> kFuseField) & 15u;
     }
 };
 
 template <u32 LB>
 struct fuse_shared {
-    u32 wlut[1u << LB]; /* symbol << 24 | 4096 - length, length 48 = no code; at a multiple of its own size */
+    u32 wlut[1u << LB]; /* symbol << 16 | 4096 - length, length 48 = no code; at a multiple of its own size */
     u32 glut[1u << LB]; /* 4096 - length, no code: length 1 (the guessing walk moves a bit on) */
     __attribute__((aligned(16))) u8 slots[kFuseWaves][kWave * kFuseSlotBytes + 16];
 };
 
-/* byte POS of a row's register := the symbol of table entry e */
 template <u32 POS>
-__device__ __forceinline__ u32 fuse_put(u32 e, u32 acc) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr u32 sel = (0x03020100u & ~(0xFFu << (8 * POS))) | (7u << (8 * POS));
-    return __builtin_amdgcn_perm(e, acc, sel);
-#else
-    return (acc & ~(0xFFu << (8 * POS))) | ((e >> 24) << (8 * POS));
-#endif
-}
-
-template <u32 POS>
-__device__ __forceinline__ void fuse_step(u32 &state, u64 pair, u32 table, const fuse_walk &fw, u32 &alo, u32 &ahi) {
+__device__ __forceinline__ void fuse_step(u32 &state, u64 pair, u32 table, const fuse_walk &fw, u8 *lds_bytes, u32 at) {
     const u32 e = lds_word_at(((u32)(pair >> (state & 63u)) & fw.mask) | table);
-    if (POS < 4) {
-        alo = fuse_put<POS & 3u>(e, alo);
-    } else {
-        ahi = fuse_put<POS & 3u>(e, ahi);
-    }
+    lds_bytes[at + POS] = (u8)(e >> 16);
     state += e;
 }
 /* the codes of a row behind the certain ones: nested, so that a lane's k-th code has a compile-time place */
 template <u32 POS>
-__device__ __forceinline__ void fuse_more(u32 &state, u64 pair, u32 table, const fuse_walk &fw, u32 &alo, u32 &ahi) {
+__device__ __forceinline__ void fuse_more(u32 &state, u64 pair, u32 table, const fuse_walk &fw, u8 *lds_bytes, u32 at) {
     if constexpr (POS < kFuseRowSyms) {
         if (fw.open(state)) {
-            fuse_step<POS>(state, pair, table, fw, alo, ahi);
-            fuse_more<POS + 1>(state, pair, table, fw, alo, ahi);
+            fuse_step<POS>(state, pair, table, fw, lds_bytes, at);
+            fuse_more<POS + 1>(state, pair, table, fw, lds_bytes, at);
         }
     }
 }
 template <u32 POS, u32 SURE>
-__device__ __forceinline__ void fuse_sure(u32 &state, u64 pair, u32 table, const fuse_walk &fw, u32 &alo, u32 &ahi) {
+__device__ __forceinline__ void fuse_sure(u32 &state, u64 pair, u32 table, const fuse_walk &fw, u8 *lds_bytes, u32 at) {
     if constexpr (POS < SURE) {
-        fuse_step<POS>(state, pair, table, fw, alo, ahi);
-        fuse_sure<POS + 1, SURE>(state, pair, table, fw, alo, ahi);
+        fuse_step<POS>(state, pair, table, fw, lds_bytes, at);
+        fuse_sure<POS + 1, SURE>(state, pair, table, fw, lds_bytes, at);
     }
+}
+
+/* what a tile waits for, asked for together and waited for once (a poll costs a trip to memory: five of them one after
+ * the other made a missed first look cost five trips) */
+__device__ __forceinline__ void fuse_ask_all(
+    const u32 *pa, const u64 *pb, const u64 *prb, const u64 *pib, const u32 *pctl, u32 &a, u64 &b, u64 &rb, u64 &ib, u32 &gave_up) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_load_dword %0, %5, off sc1\n\t"
+                 "global_load_dwordx2 %1, %6, off sc1\n\t"
+                 "global_load_dwordx2 %2, %7, off sc1\n\t"
+                 "global_load_dwordx2 %3, %8, off sc1\n\t"
+                 "global_load_dword %4, %9, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(rb), "=&v"(ib), "=&v"(gave_up)
+                 : "v"(pa), "v"(pb), "v"(prb), "v"(pib), "v"(pctl)
+                 : "memory");
+#else
+    a = *pa;
+    b = *pb;
+    rb = *prb;
+    ib = *pib;
+    gave_up = *pctl;
+#endif
+}
+__device__ __forceinline__ void fuse_ask_two(const u32 *p0, const u32 *p1, u32 &v0, u32 &v1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_load_dword %0, %2, off sc1\n\t"
+                 "global_load_dword %1, %3, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1)
+                 : "v"(p0), "v"(p1)
+                 : "memory");
+#else
+    v0 = *p0;
+    v1 = *p1;
+#endif
 }
 
 /* layout of the block the kernel wants zeroed before every launch (all offsets multiples of 8) */
@@ -5236,10 +5258,6 @@ static dec_onepass_layout dec_onepass_layout_of(uint64_t n_tiles, uint64_t n_ite
     l.bytes = l.item_base + (n_items ? n_items : 1) * 8;
     return l;
 }
-
-struct __attribute__((packed, aligned(1))) two_words {
-    u32 lo, hi;
-};
 
 /* (diagnostic build: this kernel keeps its stamp sums in registers -- static LDS in front of the tables would move them
  * off the multiple of their size that the walk's addressing wants) */
@@ -5295,7 +5313,7 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
     for (u32 i = tid; i < (1u << LB); i += kFuseThreads) {
         const u32 e = tb.dec_lut[i >> (LB - tb.lut_bits)];
         const u32 len = e & 0xFFu;
-        sh.wlut[i] = ((e >> 8) << 24) | ((1u << kFuseField) - (len ? len : kWalkDeadLen));
+        sh.wlut[i] = ((e >> 8) << 16) | ((1u << kFuseField) - (len ? len : kWalkDeadLen));
         sh.glut[i] = (1u << kFuseField) - (len ? len : 1u);
     }
     __syncthreads();
@@ -5392,8 +5410,7 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
         }
 
         FUSE_STAMP_ADD(1);
-        /* R: my sub-chunk from `from`, the k-th code of a row to byte k of a register pair, the pair to my slot at the
-         * count so far.  A walk that meets a window without a code is put on the next row's first bit and goes on, so
+        /* R: my sub-chunk from `from`, the k-th code of a row to my slot at the count before the row + k.  A walk that meets a window without a code is put on the next row's first bit and goes on, so
          * that its state and its stores stay in bounds; `dead` says so. */
         u32 exit_state = 0, count = 0;
         bool dead = false;
@@ -5401,22 +5418,23 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
             if (go) {
                 u32 state = fw.state_at(from);
                 bool dd = false;
-                u32 at = slot_at;
+                u32 at = slot_at, c16 = 0;
+                const u32 full = slot_at + kFuseSlotFill;
 #pragma unroll
                 for (u32 r = 0; r < kSubWords; ++r) {
                     const u64 pair = ((u64)w[r] << 32) | w[r + 1];
-                    u32 lo_acc = 0, hi_acc = 0;
-                    fuse_sure<0, SURE>(state, pair, wlut_at, fw, lo_acc, hi_acc);
-                    fuse_more<SURE>(state, pair, wlut_at, fw, lo_acc, hi_acc);
+                    fuse_sure<0, SURE>(state, pair, wlut_at, fw, lds_bytes, at);
+                    fuse_more<SURE>(state, pair, wlut_at, fw, lds_bytes, at);
                     const bool now = fw.died(state) || fw.open(state);
                     dd = dd || now;
+                    const u32 now16 = fw.count16_of(state);
+                    at += (now16 - c16) & 15u; /* (a row holds at most eight codes) */
+                    at = at < full ? at : full; /* (a slot that is full stays full: the tile gives up below) */
+                    c16 = now16;
                     state = now ? (state & ~kFuseFieldMask) | fw.state_at(0) : state + 32u;
-                    *reinterpret_cast<two_words *>(lds_bytes + at) = two_words{lo_acc, hi_acc};
-                    const u32 sofar = fw.count_of(state);
-                    at = slot_at + (sofar < kFuseSlotFill ? sofar : kFuseSlotFill); /* (a slot that is full stays full: the tile gives up below) */
                 }
                 exit_state = fw.offset_of(state);
-                count = fw.count_of(state);
+                count = at - slot_at;
                 dead = dd;
             }
         };
@@ -5462,11 +5480,13 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
             /* how the tile in front is left = lane 1's true entry state */
             u32 pe = 0;
             for (u32 spins = 0;; ++spins) {
-                pe = uniform32(word_load_now(&tile_exit[t - 1]));
+                u32 gave_up = 0;
+                fuse_ask_two(&tile_exit[t - 1], &ctl[0], pe, gave_up);
+                pe = uniform32(pe);
                 if (pe & kFuseReady) {
                     break;
                 }
-                if (spins > kFuseSpinLimit || uniform32(word_load_now(&ctl[0])) != 0) {
+                if (spins > kFuseSpinLimit || uniform32(gave_up) != 0) {
                     why = spins > kFuseSpinLimit ? 6u : 14u;
                     break;
                 }
@@ -5485,7 +5505,7 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
         FUSE_STAMP_COUNT(7, 1);
         why = !why && __any(payload && dead) ? 3u : why;
         why = !why && __any(payload && exit_state >= ns) ? 4u : why;
-        why = !why && __any(payload && (count > kFuseSlotFill || count < 16u)) ? 7u : why; /* symbol-dense data: more than a slot holds */
+        why = !why && __any(payload && (count >= kFuseSlotFill || count < 16u)) ? 7u : why; /* symbol-dense data: more than a slot holds */
         why = t == fail_tile ? 11u : why;
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(HUFD_FUSE_DEBUG)
         if (why == 3u || why == 2u) {
@@ -5511,38 +5531,30 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
                 }
             }
             /* asked for now, looked at when the first batch is staged */
-            a = lane < p ? word_load(&tile_agg[g * kOpGroupTiles + lane]) : kFuseReady;
-            b = lane < gi ? granule_load(&group_acc[(u64)(rr * kOpRoundGroups + lane) * kOpGroupStride]) : kOpGroupTiles * kOpArrive;
-            rb = granule_load(&round_base[rr]);
-            ib = first_tile ? kOpReady : granule_load(&item_base[rec.item]);
         }
 
         FUSE_STAMP_ADD(4);
         u64 item_off = 0;
         if (!why) {
             /* ---- the symbols in front of the tile: asked for above; if not there yet, ask again */
+            /* (every lane asks for something every time, the words it does not need among them: one wait for all) */
+            const u32 *pa = &tile_agg[g * kOpGroupTiles + (lane < p ? lane : 0u)];
+            const u64 *pb = &group_acc[(u64)(rr * kOpRoundGroups + (lane < gi ? lane : 0u)) * kOpGroupStride];
             for (u32 spins = 0;; ++spins) {
+                u32 gave_up = 0;
+                fuse_ask_all(pa, pb, &round_base[rr], &item_base[rec.item], &ctl[0], a, b, rb, ib, gave_up);
+                a = lane < p ? a : kFuseReady;
+                b = lane < gi ? b : kOpGroupTiles * kOpArrive;
+                ib = first_tile ? kOpReady : ib;
                 const bool there = (a & kFuseReady) != 0 && (b >> 40) == kOpGroupTiles && (rb & kOpReady) != 0 && (ib & kOpReady) != 0;
                 if (__all(there)) {
                     break;
                 }
-                if (spins > kFuseSpinLimit || uniform32(word_load_now(&ctl[0])) != 0) {
+                if (spins > kFuseSpinLimit || uniform32(gave_up) != 0) {
                     why = spins > kFuseSpinLimit ? 8u : 14u;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(8);
-                if (lane < p && !(a & kFuseReady)) {
-                    a = word_load_now(&tile_agg[g * kOpGroupTiles + lane]);
-                }
-                if (lane < gi && (b >> 40) != kOpGroupTiles) {
-                    b = granule_load_now(&group_acc[(u64)(rr * kOpRoundGroups + lane) * kOpGroupStride]);
-                }
-                if (!(rb & kOpReady)) {
-                    rb = granule_load_now(&round_base[rr]);
-                }
-                if (!(ib & kOpReady)) {
-                    ib = granule_load_now(&item_base[rec.item]);
-                }
+                __builtin_amdgcn_s_sleep(4);
             }
         }
         if (!why) {
@@ -5572,7 +5584,13 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
                 const u32 s = it * 8 + (lane >> 3);
                 const u32 ns_ = __shfl(n, s), ps = __shfl(pos, s);
                 const u32 from = 16 * row + 16 <= ns_ ? 16 * row : ns_ - 16;
-                if (16 * row < ns_) {
+                if (16 * row + 16 <= ns_) {
+                    /* (a slot starts on a multiple of 8: two aligned reads) */
+                    const u64 *q = reinterpret_cast<const u64 *>(sh.slots[wave] + s * kFuseSlotBytes + from);
+                    const u64 v0 = q[0], v1 = q[1];
+                    *reinterpret_cast<unaligned_uint4 *>(dst + ps + from) =
+                        unaligned_uint4{(u32)v0, (u32)(v0 >> 32), (u32)v1, (u32)(v1 >> 32)};
+                } else if (16 * row < ns_) {
                     const unaligned_uint4 v =
                         *reinterpret_cast<const unaligned_uint4 *>(sh.slots[wave] + s * kFuseSlotBytes + from);
                     *reinterpret_cast<unaligned_uint4 *>(dst + ps + from) = v;
