@@ -5112,26 +5112,26 @@ __global__ __launch_bounds__(256) void dec_scan_apply_kernel(
  *    the symbol.  (An 8-byte store per row of a register pair filled by v_perm_b32 was measured first: LDS stores
  *    that are not aligned cost several times their aligned price, 2.3 ms against this.)  When the counts of a tile
  *    are known the slots leave for HBM, eight lanes a slot, 16 bytes each (the memory system takes any alignment);
- *  - nothing waits for an entry state.  A TILE is one wave's work: 64 neighbouring sub-chunks of 128 bytes.  Every
- *    lane first follows ONE walk through the last rows of its own sub-chunk, started on a row boundary (a window
- *    without a code moves it one bit on): where that walk leaves is a guess of the NEXT lane's entry state
- *    (Huffman streams synchronise themselves: after a few rows such a walk is on the true path).  Lanes then walk
- *    their sub-chunks from the guesses, and each guess is checked against the exit state of the lane in front;
- *    who guessed wrong walks again from the true state (rare; the check is repeated).  Lane 0 of a tile is the
- *    LAST sub-chunk of the tile in front, there only for the guess of lane 1's entry state (its symbols are the other
- *    tile's).  How a tile is LEFT is then a function of its own bytes: it is published as soon as the tile's own
- *    guesses are settled, and all the tile behind does with it is check lane 1's guess (and walk lane 1 again if it
- *    was wrong, which must not change how that tile is left in turn: a sub-chunk's walks from different entry
- *    states fall into step long before its end).  True by induction from the item's first tile, which is entered at
- *    the item's first bit.  No tile waits for more than one word of the tile beside it.
+ *  - nothing waits for an entry state.  A TILE is one wave's work: 64 neighbouring sub-chunks of 128 bytes, and the
+ *    three phases of dec_sync_lean per lane: U, all entry states of the sub-chunk as one mask of heads per row until
+ *    one head is left (meeting row m, the same for the wave; meeting bit per lane) -- from there on the sub-chunk is
+ *    walked the same way however it was entered; R, the one walk from the meeting bit to the end of the sub-chunk,
+ *    symbols to the lane's slot; H, rows 0 .. m-1 again from the true entry state -- the exit state of the lane in
+ *    front, one shuffle away -- symbols BEHIND that lane's R symbols in ITS slot: slot j then holds, in stream
+ *    order and without a gap, the symbols from sub-chunk j's meeting bit to sub-chunk j+1's.  Lane 0 of a tile is
+ *    the LAST sub-chunk of the tile in front, walked again only to tell lane 1 how it is left (its symbols are the
+ *    other tile's): everything a tile computes is a function of its own bytes alone, and every tile costs the same
+ *    (a first version that GUESSED entry states from a walk through the rows in front and walked again where the
+ *    guess was wrong had 4 % of the tiles take twice the time -- and every tile behind them wait for their counts:
+ *    2.3 ms).  The item's first tile is entered at the item's first bit.
  *
  * A tile's place in the output is the sum of the counts in front of it: the look-back of enc_onepass (a flagged word
  * per tile, a memory-side sum + arrival count per group of 64 tiles, the bits in front of every round of 64 groups
  * from one wave that does nothing else).
  *
- * Exactness: no walk of a tile's own sub-chunks may meet a window without a code, every guess must be confirmed,
- * lane 0 must leave its sub-chunk as the tile in front says, a sub-chunk's symbols must fit its slot (128), the output
- * must fit the item's capacity.  Whatever is not so (a damaged or cut stream, one that does not synchronise,
+ * Exactness: as dec_sync_lean -- the heads of every sub-chunk must fall into one within 16 rows, every H walk must land on
+ * its own meeting bit, no walk may meet a window without a code, a slot's symbols must fit it (128), the output must
+ * fit the item's capacity.  Whatever is not so (a damaged or cut stream, one that does not synchronise,
  * symbol-dense data, a short output buffer) raises ctl[0]; tiles behind
  * give up when they see it, nothing wrong has been written (a tile writes only once every tile in front of it has
  * published a count), and the kernels of the two-pass road, queued behind this one, look at ctl[0] first and then do
@@ -5140,15 +5140,14 @@ __global__ __launch_bounds__(256) void dec_scan_apply_kernel(
  */
 constexpr u32 kFuseWaves = 8;
 constexpr u32 kFuseThreads = kFuseWaves * kWave;
-constexpr u32 kFuseGuessRows = 12;    /* rows of a sub-chunk the walk that guesses the next lane's entry state runs through */
 constexpr u32 kFuseRowSyms = 8;      /* codes that can start in a row (at least 4 bits each) */
 constexpr u32 kFuseSlotBytes = 136;  /* 34 words: neighbouring lanes' slots two banks apart */
 constexpr u32 kFuseSlotFill = 128;   /* a slot that fills up to here is not trusted (a row's eight bytes may lie behind) */
-constexpr u32 kFuseRepairRounds = 3;
+constexpr u32 kFuseHeadBytes = 144;  /* an item's first symbols: its first sub-chunk in front of its meeting bit (16 rows of eight) */
 constexpr u32 kFuseField = 12;       /* bits of a walk state that hold the shift amount; the symbol count modulo 16 is the 4 above */
 constexpr u32 kFuseFieldMask = (1u << kFuseField) - 1u;
 constexpr u32 kFuseSpinLimit = 1u << 14;
-constexpr u32 kFuseReady = 1u << 31; /* tile_agg: [31] published, [23:0] symbols; tile_exit: [31] published, [3:0] exit state */
+constexpr u32 kFuseReady = 1u << 31; /* tile_agg: [31] published, [23:0] symbols */
 
 struct fuse_walk {
     u32 thr, mask, floor;
@@ -5177,8 +5176,9 @@ struct fuse_walk {
 template <u32 LB>
 struct fuse_shared {
     u32 wlut[1u << LB]; /* symbol << 16 | 4096 - length, length 48 = no code; at a multiple of its own size */
-    u32 glut[1u << LB]; /* 4096 - length, no code: length 1 (the guessing walk moves a bit on) */
-    __attribute__((aligned(16))) u8 slots[kFuseWaves][kWave * kFuseSlotBytes + 16];
+    u16 hops[1u << LB]; /* 1 << code length of a window (the head it sends on), 0 = no code */
+    /* per wave: the lanes' slots, then room for an item's first symbols (what any other tile's lane 0 writes there is never read) */
+    __attribute__((aligned(16))) u8 slots[kFuseWaves][kWave * kFuseSlotBytes + kFuseHeadBytes];
 };
 
 template <u32 POS>
@@ -5227,23 +5227,9 @@ __device__ __forceinline__ void fuse_ask_all(
     gave_up = *pctl;
 #endif
 }
-__device__ __forceinline__ void fuse_ask_two(const u32 *p0, const u32 *p1, u32 &v0, u32 &v1) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("global_load_dword %0, %2, off sc1\n\t"
-                 "global_load_dword %1, %3, off sc1\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(v0), "=&v"(v1)
-                 : "v"(p0), "v"(p1)
-                 : "memory");
-#else
-    v0 = *p0;
-    v1 = *p1;
-#endif
-}
-
 /* layout of the block the kernel wants zeroed before every launch (all offsets multiples of 8) */
 struct dec_onepass_layout {
-    uint64_t ctl, tile_agg, tile_exit, group_acc, round_base, item_base, bytes;
+    uint64_t ctl, tile_agg, group_acc, round_base, item_base, bytes;
 };
 static dec_onepass_layout dec_onepass_layout_of(uint64_t n_tiles, uint64_t n_items) {
     const uint64_t groups = (n_tiles + kOpGroupTiles - 1) / kOpGroupTiles;
@@ -5251,8 +5237,7 @@ static dec_onepass_layout dec_onepass_layout_of(uint64_t n_tiles, uint64_t n_ite
     dec_onepass_layout l;
     l.ctl = 0;
     l.tile_agg = 32;
-    l.tile_exit = l.tile_agg + ((n_tiles * 4 + 7) & ~7ull);
-    l.group_acc = l.tile_exit + ((n_tiles * 4 + 7) & ~7ull);
+    l.group_acc = l.tile_agg + ((n_tiles * 4 + 7) & ~7ull);
     l.round_base = l.group_acc + (groups ? groups : 1) * 8 * kOpGroupStride;
     l.item_base = l.round_base + (rounds + 1) * 8;
     l.bytes = l.item_base + (n_items ? n_items : 1) * 8;
@@ -5297,9 +5282,8 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
     u32 n_tiles,
     const u8 *__restrict__ d_in,
     u8 *__restrict__ d_out,
-    u32 *ctl,        /* [0] raised by the first tile that cannot go this way, [1] which and why, [2] lanes that walked twice; zeroed */
+    u32 *ctl,        /* [0] raised by the first tile that cannot go this way, [1] which and why; zeroed */
     u32 *tile_agg,   /* [n_tiles] zeroed */
-    u32 *tile_exit,  /* [n_tiles] zeroed */
     u64 *group_acc,  /* zeroed */
     u64 *round_base, /* [rounds + 1] zeroed */
     u64 *item_base,  /* [n_items] zeroed */
@@ -5314,12 +5298,12 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
         const u32 e = tb.dec_lut[i >> (LB - tb.lut_bits)];
         const u32 len = e & 0xFFu;
         sh.wlut[i] = ((e >> 8) << 16) | ((1u << kFuseField) - (len ? len : kWalkDeadLen));
-        sh.glut[i] = (1u << kFuseField) - (len ? len : 1u);
+        sh.hops[i] = (u16)(len ? 1u << len : 0u);
     }
     __syncthreads();
     const fuse_walk fw(LB, tb.max_bits);
     const u32 ns = tb.n_states;
-    const u32 wlut_at = lds_offset_of(sh.wlut), glut_at = lds_offset_of(sh.glut);
+    const u32 wlut_at = lds_offset_of(sh.wlut);
 
     /* one wave of the grid only watches the groups of a round arrive and publishes the next round's base (enc_onepass) */
     if (blockIdx.x == 0 && wave == kFuseWaves - 1) {
@@ -5353,7 +5337,7 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
         }
         return;
     }
-    if ((wlut_at & ((4u << LB) - 1u)) != 0 || (glut_at & ((4u << LB) - 1u)) != 0) {
+    if ((wlut_at & ((4u << LB) - 1u)) != 0) {
         if (lane == 0) {
             ctl[1] = 1u;
             word_store(&ctl[0], 1u);
@@ -5366,6 +5350,7 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
     const u32 stride = gridDim.x * kFuseWaves - 1;
     u8 *const lds_bytes = reinterpret_cast<u8 *>(&sh);
     const u32 slot_at = (u32)(sh.slots[wave] - lds_bytes) + lane * kFuseSlotBytes; /* my slot, as an LDS byte offset */
+    const u32 head_at = (u32)(sh.slots[wave] - lds_bytes) + kWave * kFuseSlotBytes;
     for (u32 t = blockIdx.x * kFuseWaves + wave - (blockIdx.x ? 1u : 0u); t < n_tiles; t += stride) {
         if (uniform32(word_load(&ctl[0])) != 0) {
             return; /* the launch has gone the other way */
@@ -5378,7 +5363,7 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
         const bool payload = active && (first_tile || lane != 0);
         const u8 *src = d_in + rec.src_off + (u64)(active ? lane : 0u) * HUFD_DEC_SUB_BYTES;
         u32 w[kFastRows];
-        auto load_rows = [&]() {
+        {
             const unaligned_uint4 *line = reinterpret_cast<const unaligned_uint4 *>(src);
 #pragma unroll
             for (u32 q = 0; q < kSubWords / 4; ++q) {
@@ -5389,136 +5374,101 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
                 w[4 * q + 3] = __builtin_bswap32(v.w);
             }
             w[kSubWords] = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(src + HUFD_DEC_SUB_BYTES)->x);
-        };
-        load_rows();
-
-        /* G: where a walk started on row 24's first bit leaves my sub-chunk = a guess of the next lane's entry state */
-        u32 entry;
-        {
-            u32 state = fw.state_at(0);
-#pragma unroll
-            for (u32 r = kSubWords - kFuseGuessRows; r < kSubWords; ++r) {
-                const u64 pair = ((u64)w[r] << 32) | w[r + 1];
-                while (fw.open(state)) {
-                    state += lds_word_at(((u32)(pair >> (state & 63u)) & fw.mask) | glut_at);
-                }
-                state += 32u;
-            }
-            const u32 guess = __shfl_up(fw.offset_of(state), 1);
-            /* (lane 0 of a tile that is not its item's first has nothing of its own to walk: what it does below is never looked at) */
-            entry = lane ? guess : (first_tile ? (u32)(rec.flags >> 8) & 7u : 0u);
         }
 
-        FUSE_STAMP_ADD(1);
-        /* R: my sub-chunk from `from`, the k-th code of a row to my slot at the count before the row + k.  A walk that meets a window without a code is put on the next row's first bit and goes on, so
-         * that its state and its stores stay in bounds; `dead` says so. */
-        u32 exit_state = 0, count = 0;
-        bool dead = false;
-        auto walk = [&](bool go, u32 from) {
-            if (go) {
-                u32 state = fw.state_at(from);
-                bool dd = false;
-                u32 at = slot_at, c16 = 0;
-                const u32 full = slot_at + kFuseSlotFill;
+        /* U: all entry states as one mask of heads per row, until every lane of the wave is down to one */
+        u64 heads = active ? (1ull << ns) - 1ull : 0ull;
+        u32 meet_row = 0; /* the same for the whole wave */
+        bool one = false, settled = false;
 #pragma unroll
-                for (u32 r = 0; r < kSubWords; ++r) {
+        for (u32 r = 0; r < kFastMaxMeet; ++r) {
+            if (!settled) {
+                heads = union_row_fast<LB>(heads, w[r], w[r + 1], sh.hops);
+                one = heads != 0 && (heads & (heads - 1)) == 0;
+                meet_row = r + 1;
+                settled = __all(one || heads == 0);
+            }
+        }
+        const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
+        u32 why = __any(active && !(one && settled)) ? 2u : 0u; /* (diagnostics: the first reason the tile has for giving up) */
+        FUSE_STAMP_ADD(1);
+
+        /* R: the one walk from the meeting bit to the end of the sub-chunk, the k-th code of a row to my slot at the count
+         * before the row + k.  A walk that meets a window without a code is put on the next row's first bit and goes on,
+         * so that its state and its stores stay in bounds; `dead` says so. */
+        const u32 full = slot_at + kFuseSlotFill;
+        u32 exit_state, in_slot;
+        bool dead = false;
+        {
+            u32 state = fw.state_at(meet_bit);
+            u32 at = slot_at, c16 = 0;
+#pragma unroll
+            for (u32 r = 1; r < kSubWords; ++r) {
+                if (r >= meet_row) {
                     const u64 pair = ((u64)w[r] << 32) | w[r + 1];
                     fuse_sure<0, SURE>(state, pair, wlut_at, fw, lds_bytes, at);
                     fuse_more<SURE>(state, pair, wlut_at, fw, lds_bytes, at);
                     const bool now = fw.died(state) || fw.open(state);
-                    dd = dd || now;
+                    dead = dead || now;
                     const u32 now16 = fw.count16_of(state);
                     at += (now16 - c16) & 15u; /* (a row holds at most eight codes) */
                     at = at < full ? at : full; /* (a slot that is full stays full: the tile gives up below) */
                     c16 = now16;
                     state = now ? (state & ~kFuseFieldMask) | fw.state_at(0) : state + 32u;
                 }
-                exit_state = fw.offset_of(state);
-                count = at - slot_at;
-                dead = dd;
             }
-        };
-        walk(true, entry < ns ? entry : 0u);
-        entry = entry < ns ? entry : HUFD_NONE32;
+            exit_state = fw.offset_of(state);
+            in_slot = at - slot_at;
+        }
         FUSE_STAMP_ADD(2);
 
-        /* every guess against the exit state of the lane in front; who guessed wrong walks again from there.  Lane 1 of a tile
-         * that is not its item's first has the tile in front to ask (`front_exit`, once that tile has said how it is left). */
-        u32 front_exit = HUFD_NONE32, walked_twice = 0, said_exit = HUFD_NONE32, why = 0;
-        bool asked_front = first_tile;
-        for (;;) {
-            u32 in_front = __shfl_up(exit_state, 1);
-            in_front = (!first_tile && lane == 1) ? (front_exit != HUFD_NONE32 ? front_exit : entry) : in_front;
-            bool wrong = active && lane != 0 && in_front != entry;
-            for (u32 round = 0; round < kFuseRepairRounds && __any(wrong); ++round) {
-                walked_twice += (u32)__builtin_popcountll(__ballot(wrong));
-                load_rows();
-                walk(wrong && in_front < ns, in_front);
-                entry = wrong ? in_front : entry;
-                in_front = __shfl_up(exit_state, 1);
-                in_front = (!first_tile && lane == 1) ? (front_exit != HUFD_NONE32 ? front_exit : entry) : in_front;
-                wrong = active && lane != 0 && in_front != entry;
-            }
-            if (__any(wrong)) {
-                why = 2u;
-                break;
-            }
-            const u32 leaves = __shfl(exit_state, n_lanes - 1);
-            if (said_exit == HUFD_NONE32) {
-                /* how the tile is left: a function of its own bytes, said at once */
-                said_exit = leaves;
-                if (lane == 0) {
-                    word_store(&tile_exit[t], kFuseReady | (leaves & 15u));
+        /* H: my own sub-chunk from my true entry state (how the lane in front leaves; the item's first bit) to the meeting
+         * bit, symbols behind that lane's in its slot (lane 0: to the room behind the slots) */
+        u32 head_n; /* symbols of my sub-chunk in front of its meeting bit */
+        {
+            const u32 front_exit = __shfl_up(exit_state, 1), front_fill = __shfl_up(in_slot, 1);
+            const u32 entry = lane ? front_exit : (u32)(rec.flags >> 8) & 7u;
+            const u32 at0 = lane ? slot_at - kFuseSlotBytes + front_fill : head_at;
+            const u32 lim = lane ? slot_at - kFuseSlotBytes + kFuseSlotFill : head_at + kFuseHeadBytes - 16u;
+            u32 state = fw.state_at(entry < ns ? entry : 0u);
+            u32 at = at0, c16 = 0;
+            bool dd = false;
+#pragma unroll
+            for (u32 r = 0; r < kFastMaxMeet; ++r) {
+                if (r < meet_row) {
+                    const u64 pair = ((u64)w[r] << 32) | w[r + 1];
+                    fuse_sure<0, SURE>(state, pair, wlut_at, fw, lds_bytes, at);
+                    fuse_more<SURE>(state, pair, wlut_at, fw, lds_bytes, at);
+                    const bool now = fw.died(state) || fw.open(state);
+                    dd = dd || now;
+                    const u32 now16 = fw.count16_of(state);
+                    at += (now16 - c16) & 15u;
+                    at = at < lim ? at : lim;
+                    c16 = now16;
+                    state = now ? (state & ~kFuseFieldMask) | fw.state_at(0) : state + 32u;
                 }
-            } else if (leaves != said_exit) {
-                why = 5u; /* lane 1, walked again from its true entry state, did not fall into step: the tile is left otherwise than said */
-                break;
             }
-            if (asked_front) {
-                break;
-            }
-            /* how the tile in front is left = lane 1's true entry state */
-            u32 pe = 0;
-            for (u32 spins = 0;; ++spins) {
-                u32 gave_up = 0;
-                fuse_ask_two(&tile_exit[t - 1], &ctl[0], pe, gave_up);
-                pe = uniform32(pe);
-                if (pe & kFuseReady) {
-                    break;
-                }
-                if (spins > kFuseSpinLimit || uniform32(gave_up) != 0) {
-                    why = spins > kFuseSpinLimit ? 6u : 14u;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (why) {
-                break;
-            }
-            asked_front = true;
-            front_exit = pe & 15u;
-            if (__shfl(entry, 1) == front_exit) {
-                break;
-            }
+            head_n = at - at0;
+            /* (lane 0 of a tile that is not its item's first has no entry state to start from, and nothing of this is its own) */
+            const bool mine = payload;
+            const bool landed = !dd && fw.offset_of(state) == meet_bit && at < lim && entry < ns;
+            why = !why && __any(mine && !landed) ? 3u : why;
         }
         FUSE_STAMP_ADD(3);
         FUSE_STAMP_COUNT(7, 1);
-        why = !why && __any(payload && dead) ? 3u : why;
-        why = !why && __any(payload && exit_state >= ns) ? 4u : why;
-        why = !why && __any(payload && (count >= kFuseSlotFill || count < 16u)) ? 7u : why; /* symbol-dense data: more than a slot holds */
+        why = !why && __any(active && (dead || exit_state >= ns)) ? 4u : why;
         why = t == fail_tile ? 11u : why;
-#if !defined(__HIP_DEVICE_COMPILE__) && defined(HUFD_FUSE_DEBUG)
-        if (why == 3u || why == 2u) {
-            printf("tile %u why %u lane %2u active %d payload %d entry %u front %u exit %u dead %d count %u twice %u\n", t, why, lane, (int)active,
-                   (int)payload, entry, front_exit, exit_state, (int)dead, count, walked_twice);
-        }
-#endif
 
-        /* where every lane's symbols go; the tile's count and exit state to the tiles behind */
-        const u32 n = payload ? count : 0u;
+        /* what every slot holds: its lane's R symbols (not lane 0's, unless the item starts here) and the next lane's H
+         * symbols (not behind the tile's last lane: those are the next tile's); in front of slot 0 an item's first symbols */
+        const u32 next_head = __shfl_down(head_n, 1);
+        const u32 skip = payload ? 0u : in_slot; /* (lane 0 of a tile that is not its item's first: only what lane 1 put behind its symbols) */
+        const u32 n = active ? (payload ? in_slot : 0u) + (lane + 1 < n_lanes ? next_head : 0u) : 0u;
+        why = !why && __any(active && (skip + n >= kFuseSlotFill || (payload && n < 16u))) ? 7u : why; /* symbol-dense data: more than a slot holds */
+        const u32 first_n = first_tile ? __shfl(head_n, 0) : 0u;
         const u32 incl = wave_inclusive_sum_dpp(n, lane);
-        const u32 pos = incl - n;
-        const u32 total = __shfl(incl, kWave - 1);
+        const u32 pos = first_n + incl - n;
+        const u32 total = first_n + __shfl(incl, kWave - 1);
         const u32 leaves = __shfl(exit_state, n_lanes - 1) & 15u;
         const u32 g = t / kOpGroupTiles, p = t % kOpGroupTiles, rr = g / kOpRoundGroups, gi = g % kOpRoundGroups;
         u32 a = kFuseReady;
@@ -5526,9 +5476,6 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
         if (!why) {
             if (lane == 0) {
                 arrival_quiet(&tile_agg[t], kFuseReady | total, &group_acc[(u64)g * kOpGroupStride], kOpArrive + total);
-                if (walked_twice) {
-                    atomicAdd(&ctl[2], walked_twice);
-                }
             }
             /* asked for now, looked at when the first batch is staged */
         }
@@ -5578,22 +5525,36 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
             /* ---- the slots to HBM: eight lanes a slot, 16 bytes each, the last 16 of a slot as they lie (they overlap
              * the row in front with the same bytes) */
             u8 *dst = d_out + rec.out_off + item_off;
+            if (lane < first_n) {
+                dst[lane] = lds_bytes[head_at + lane]; /* an item's first symbols (at most 128: 16 rows of eight) */
+            }
+            if (lane + kWave < first_n) {
+                dst[lane + kWave] = lds_bytes[head_at + lane + kWave];
+            }
             const u32 row = lane & 7u;
 #pragma unroll
             for (u32 it = 0; it < kWave / 8; ++it) {
                 const u32 s = it * 8 + (lane >> 3);
-                const u32 ns_ = __shfl(n, s), ps = __shfl(pos, s);
-                const u32 from = 16 * row + 16 <= ns_ ? 16 * row : ns_ - 16;
-                if (16 * row + 16 <= ns_) {
+                const u32 ns_ = __shfl(n, s), ps = __shfl(pos, s), ks = __shfl(skip, s);
+                const u8 *slot = sh.slots[wave] + s * kFuseSlotBytes + ks;
+                if (16 * row + 16 <= ns_ && ks == 0) {
                     /* (a slot starts on a multiple of 8: two aligned reads) */
-                    const u64 *q = reinterpret_cast<const u64 *>(sh.slots[wave] + s * kFuseSlotBytes + from);
+                    const u64 *q = reinterpret_cast<const u64 *>(slot + 16 * row);
                     const u64 v0 = q[0], v1 = q[1];
-                    *reinterpret_cast<unaligned_uint4 *>(dst + ps + from) =
+                    *reinterpret_cast<unaligned_uint4 *>(dst + ps + 16 * row) =
                         unaligned_uint4{(u32)v0, (u32)(v0 >> 32), (u32)v1, (u32)(v1 >> 32)};
-                } else if (16 * row < ns_) {
-                    const unaligned_uint4 v =
-                        *reinterpret_cast<const unaligned_uint4 *>(sh.slots[wave] + s * kFuseSlotBytes + from);
+                } else if (16 * row < ns_ && ns_ >= 16) {
+                    const u32 from = 16 * row + 16 <= ns_ ? 16 * row : ns_ - 16;
+                    const unaligned_uint4 v = *reinterpret_cast<const unaligned_uint4 *>(slot + from);
                     *reinterpret_cast<unaligned_uint4 *>(dst + ps + from) = v;
+                } else if (ns_ < 16) {
+                    /* (slot 0 of a tile that is not its item's first may hold fewer than 16 symbols: a byte a lane, two trips) */
+                    if (row < ns_) {
+                        dst[ps + row] = slot[row];
+                    }
+                    if (row + 8 < ns_) {
+                        dst[ps + row + 8] = slot[row + 8];
+                    }
                 }
             }
             wave_step(); /* the slots are free for the next tile */
@@ -7163,8 +7124,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         dim3(persistent_grid(dec_onepass_kernel<LBV, SUREV>, kFuseThreads, (uint32_t)sizeof(fuse_shared<LBV>),          \
                              (a->n_tiles + 1 + kFuseWaves - 1) / kFuseWaves)),                                         \
         dim3(kFuseThreads), (uint32_t)sizeof(fuse_shared<LBV>), st, a->tables, a->tiles, a->n_tiles,                   \
-        (const u8 *)a->d_in, (u8 *)a->d_out, (u32 *)(blk + l.ctl), (u32 *)(blk + l.tile_agg), (u32 *)(blk + l.tile_exit), \
-        (u64 *)(blk + l.group_acc),                                                                                    \
+        (const u8 *)a->d_in, (u8 *)a->d_out, (u32 *)(blk + l.ctl), (u32 *)(blk + l.tile_agg), (u64 *)(blk + l.group_acc), \
         (u64 *)(blk + l.round_base), (u64 *)(blk + l.item_base), a->chunk_entry, a->chunk_base, fail_tile)
         (void)hipMemsetAsync(blk, 0, l.bytes, st);
         if (lb == 10) {

@@ -39,8 +39,8 @@ per_tile = d / tiles[:, None]
 life = per_tile.sum(axis=1)
 print("dec_onepass: %d resident workgroups, %.1f tiles per wave; %.0f clocks per tile (median %.0f), wave 0 of each" % (
     len(r), tiles.mean() / 2, life.mean(), np.median(life)))
-names = ["tile record, loads issued, G: the guess of the next lane's entry state", "R: the walk, symbols to the slot",
-         "guesses settled, exit said, the tile in front asked", "count published, offsets asked for",
+names = ["tile record, loads, U: all entry states to one head", "R: the walk from the meeting bit, symbols to the slot",
+         "H: the first rows again from the true entry state", "counts, count published",
          "wait for the offsets in front", "slots to HBM"]
 for i, ph in enumerate(names):
     print("   %-72s %9.0f  %5.1f %%" % (ph, per_tile[:, i].mean(), 100 * per_tile[:, i].mean() / life.mean()))
