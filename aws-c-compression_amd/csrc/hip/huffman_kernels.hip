@@ -5351,18 +5351,17 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
     u8 *const lds_bytes = reinterpret_cast<u8 *>(&sh);
     const u32 slot_at = (u32)(sh.slots[wave] - lds_bytes) + lane * kFuseSlotBytes; /* my slot, as an LDS byte offset */
     const u32 head_at = (u32)(sh.slots[wave] - lds_bytes) + kWave * kFuseSlotBytes;
-    for (u32 t = blockIdx.x * kFuseWaves + wave - (blockIdx.x ? 1u : 0u); t < n_tiles; t += stride) {
-        if (uniform32(word_load(&ctl[0])) != 0) {
-            return; /* the launch has gone the other way */
-        }
-        FUSE_STAMP_ADD(0);
-        const hufd_tile_rec rec = tiles[t];
-        const u32 n_lanes = rec.n_lanes;
-        const bool first_tile = (rec.flags & 1u) != 0; /* of its item: lane 0 is entered at the item's first bit and its symbols are the tile's */
-        const bool active = lane < n_lanes;
-        const bool payload = active && (first_tile || lane != 0);
+    /* The FRONT of a tile -- its rows into registers and phase U -- needs no slot: it is done for the NEXT tile between
+     * the publishing of this tile's count and the look at the counts in front of it, which have that long to arrive
+     * (asked for at once, every wave of the chip polled for half a tile's time, and the polls slowed everything down:
+     * 1.67 ms). */
+    hufd_tile_rec rec;
+    u32 w[kFastRows];
+    u32 meet_row = 0, meet_bit = 0, why = 0;
+    auto front = [&](u32 t) {
+        rec = tiles[t];
+        const bool active = lane < rec.n_lanes;
         const u8 *src = d_in + rec.src_off + (u64)(active ? lane : 0u) * HUFD_DEC_SUB_BYTES;
-        u32 w[kFastRows];
         {
             const unaligned_uint4 *line = reinterpret_cast<const unaligned_uint4 *>(src);
 #pragma unroll
@@ -5378,8 +5377,8 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
 
         /* U: all entry states as one mask of heads per row, until every lane of the wave is down to one */
         u64 heads = active ? (1ull << ns) - 1ull : 0ull;
-        u32 meet_row = 0; /* the same for the whole wave */
         bool one = false, settled = false;
+        meet_row = 0; /* the same for the whole wave */
 #pragma unroll
         for (u32 r = 0; r < kFastMaxMeet; ++r) {
             if (!settled) {
@@ -5389,9 +5388,24 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
                 settled = __all(one || heads == 0);
             }
         }
-        const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
-        u32 why = __any(active && !(one && settled)) ? 2u : 0u; /* (diagnostics: the first reason the tile has for giving up) */
-        FUSE_STAMP_ADD(1);
+        meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
+        why = __any(active && !(one && settled)) ? 2u : 0u; /* (diagnostics: the first reason the tile has for giving up) */
+    };
+
+    u32 t = blockIdx.x * kFuseWaves + wave - (blockIdx.x ? 1u : 0u);
+    if (t >= n_tiles || uniform32(word_load(&ctl[0])) != 0) {
+        return;
+    }
+    front(t);
+    for (;;) {
+        FUSE_STAMP_ADD(0);
+        const u32 n_lanes = rec.n_lanes;
+        const bool first_tile = (rec.flags & 1u) != 0; /* of its item: lane 0 is entered at the item's first bit and its symbols are the tile's */
+        const bool active = lane < n_lanes;
+        const bool payload = active && (first_tile || lane != 0);
+        /* (what the end of the tile needs of its record: the record itself is the next tile's by then) */
+        const u64 my_out_off = rec.out_off, my_out_cap = rec.out_cap;
+        const u32 my_item = rec.item, my_flags = rec.flags, my_tail_chunk = rec.tail_chunk;
 
         /* R: the one walk from the meeting bit to the end of the sub-chunk, the k-th code of a row to my slot at the count
          * before the row + k.  A walk that meets a window without a code is put on the next row's first bit and goes on,
@@ -5420,14 +5434,14 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
             exit_state = fw.offset_of(state);
             in_slot = at - slot_at;
         }
-        FUSE_STAMP_ADD(2);
+        FUSE_STAMP_ADD(1);
 
         /* H: my own sub-chunk from my true entry state (how the lane in front leaves; the item's first bit) to the meeting
          * bit, symbols behind that lane's in its slot (lane 0: to the room behind the slots) */
         u32 head_n; /* symbols of my sub-chunk in front of its meeting bit */
         {
             const u32 front_exit = __shfl_up(exit_state, 1), front_fill = __shfl_up(in_slot, 1);
-            const u32 entry = lane ? front_exit : (u32)(rec.flags >> 8) & 7u;
+            const u32 entry = lane ? front_exit : (u32)(my_flags >> 8) & 7u;
             const u32 at0 = lane ? slot_at - kFuseSlotBytes + front_fill : head_at;
             const u32 lim = lane ? slot_at - kFuseSlotBytes + kFuseSlotFill : head_at + kFuseHeadBytes - 16u;
             u32 state = fw.state_at(entry < ns ? entry : 0u);
@@ -5454,7 +5468,7 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
             const bool landed = !dd && fw.offset_of(state) == meet_bit && at < lim && entry < ns;
             why = !why && __any(mine && !landed) ? 3u : why;
         }
-        FUSE_STAMP_ADD(3);
+        FUSE_STAMP_ADD(2);
         FUSE_STAMP_COUNT(7, 1);
         why = !why && __any(active && (dead || exit_state >= ns)) ? 4u : why;
         why = t == fail_tile ? 11u : why;
@@ -5477,19 +5491,30 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
             if (lane == 0) {
                 arrival_quiet(&tile_agg[t], kFuseReady | total, &group_acc[(u64)g * kOpGroupStride], kOpArrive + total);
             }
-            /* asked for now, looked at when the first batch is staged */
         }
+        FUSE_STAMP_ADD(3);
 
+        /* ---- the next tile's front, while this tile's count travels */
+        const u32 t_mine = t;
+        u32 why_mine = why;
+        t += stride;
+        const bool more = t < n_tiles && uniform32(word_load(&ctl[0])) == 0;
+        if (more) {
+            front(t);
+        }
+        const u32 why_next = why;
+        why = why_mine;
         FUSE_STAMP_ADD(4);
+
         u64 item_off = 0;
         if (!why) {
-            /* ---- the symbols in front of the tile: asked for above; if not there yet, ask again */
+            /* ---- the symbols in front of the tile */
             /* (every lane asks for something every time, the words it does not need among them: one wait for all) */
             const u32 *pa = &tile_agg[g * kOpGroupTiles + (lane < p ? lane : 0u)];
             const u64 *pb = &group_acc[(u64)(rr * kOpRoundGroups + (lane < gi ? lane : 0u)) * kOpGroupStride];
             for (u32 spins = 0;; ++spins) {
                 u32 gave_up = 0;
-                fuse_ask_all(pa, pb, &round_base[rr], &item_base[rec.item], &ctl[0], a, b, rb, ib, gave_up);
+                fuse_ask_all(pa, pb, &round_base[rr], &item_base[my_item], &ctl[0], a, b, rb, ib, gave_up);
                 a = lane < p ? a : kFuseReady;
                 b = lane < gi ? b : kOpGroupTiles * kOpArrive;
                 ib = first_tile ? kOpReady : ib;
@@ -5513,18 +5538,18 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
             front += rb & ~kOpReady;
             if (first_tile) {
                 if (lane == 0) {
-                    granule_store(&item_base[rec.item], kOpReady | front);
+                    granule_store(&item_base[my_item], kOpReady | front);
                 }
             } else {
                 item_off = front - (ib & ~kOpReady);
             }
-            why = !why && item_off + total > rec.out_cap ? 10u : why; /* the output is too short: the other road finds the edge */
+            why = !why && item_off + total > my_out_cap ? 10u : why; /* the output is too short: the other road finds the edge */
         }
         FUSE_STAMP_ADD(5);
         if (!why) {
             /* ---- the slots to HBM: eight lanes a slot, 16 bytes each, the last 16 of a slot as they lie (they overlap
              * the row in front with the same bytes) */
-            u8 *dst = d_out + rec.out_off + item_off;
+            u8 *dst = d_out + my_out_off + item_off;
             if (lane < first_n) {
                 dst[lane] = lds_bytes[head_at + lane]; /* an item's first symbols (at most 128: 16 rows of eight) */
             }
@@ -5563,17 +5588,21 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
         if (why) {
             if (lane == 0) {
                 if (word_load_now(&ctl[0]) == 0) {
-                    ctl[1] = (t << 8) | why; /* (diagnostics; who is first is not decided exactly) */
+                    ctl[1] = (t_mine << 8) | why; /* (diagnostics; who is first is not decided exactly) */
                 }
                 word_store(&ctl[0], 1u);
             }
             return;
         }
-        if ((rec.flags & 2u) != 0 && lane == 0) {
+        if ((my_flags & 2u) != 0 && lane == 0) {
             /* the item's last tile inside the stream: the chunk(s) the stream ends in start here */
-            chunk_entry[rec.tail_chunk] = entry_pack(leaves, true);
-            chunk_base[rec.tail_chunk] = item_off + total;
+            chunk_entry[my_tail_chunk] = entry_pack(leaves, true);
+            chunk_base[my_tail_chunk] = item_off + total;
         }
+        if (!more) {
+            break;
+        }
+        why = why_next;
     }
     FUSE_STAMP_FLUSH;
 }

@@ -39,8 +39,16 @@ per_tile = d / tiles[:, None]
 life = per_tile.sum(axis=1)
 print("dec_onepass: %d resident workgroups, %.1f tiles per wave; %.0f clocks per tile (median %.0f), wave 0 of each" % (
     len(r), tiles.mean() / 2, life.mean(), np.median(life)))
-names = ["tile record, loads, U: all entry states to one head", "R: the walk from the meeting bit, symbols to the slot",
-         "H: the first rows again from the true entry state", "counts, count published",
+names = ["R: the walk from the meeting bit, symbols to the slot", "H: the first rows again from the true entry state",
+         "counts, count published", "the NEXT tile's record, rows and U (all entry states to one head)",
          "wait for the offsets in front", "slots to HBM"]
 for i, ph in enumerate(names):
     print("   %-72s %9.0f  %5.1f %%" % (ph, per_tile[:, i].mean(), 100 * per_tile[:, i].mean() / life.mean()))
+compute = per_tile[:, [0, 1, 2, 3, 5]].sum(axis=1)
+wait = per_tile[:, 4]
+q = [0, 1, 10, 50, 90, 99, 100]
+print("compute clocks per tile over the workgroups, percentiles %s: %s" % (q, [int(x) for x in np.percentile(compute, q)]))
+print("wait    clocks per tile over the workgroups, percentiles %s: %s" % (q, [int(x) for x in np.percentile(wait, q)]))
+idx = np.flatnonzero(r0_mask) if 'r0_mask' in globals() else np.arange(len(compute))
+for lo in range(0, len(compute), 64):
+    print("  workgroups %3d..%3d: compute %6.0f wait %6.0f" % (lo, min(lo + 63, len(compute) - 1), compute[lo:lo + 64].mean(), wait[lo:lo + 64].mean()))
