@@ -5179,6 +5179,7 @@ struct fuse_shared {
     u16 hops[1u << LB]; /* 1 << code length of a window (the head it sends on), 0 = no code */
     /* per wave: the lanes' slots, then room for an item's first symbols (what any other tile's lane 0 writes there is never read) */
     __attribute__((aligned(16))) u8 slots[kFuseWaves][kWave * kFuseSlotBytes + kFuseHeadBytes];
+    u32 meta[kFuseWaves][kWave]; /* per slot: where its symbols go in the tile [15:0], how many [31:16] */
 };
 
 template <u32 POS>
@@ -5227,6 +5228,26 @@ __device__ __forceinline__ void fuse_ask_all(
     gave_up = *pctl;
 #endif
 }
+/*
+ * Phase U's first row.  The ns entry states are ns look-ups that do not wait for each other (the general loop takes a
+ * head at a time, lowest first, because a head may send another into the same row): their windows lie in the row's own
+ * word, where they land is an OR.  What lands on an entry state is followed already; the general loop goes on with the
+ * rest of the row.
+ */
+template <u32 LB>
+__device__ __forceinline__ u64 union_first_row(u32 ns, bool active, u32 hi, u32 lo, const u16 *hops) {
+    u32 landed = 0;
+#pragma unroll
+    for (u32 j = 0; j < HUFD_DEC_MAX_LUT_BITS; ++j) {
+        if (j < ns) {
+            const u32 off = (hi >> (31u - LB - j)) & (((1u << LB) - 1u) << 1); /* byte offset into the u16 table */
+            landed |= (u32)*reinterpret_cast<const u16 *>(reinterpret_cast<const u8 *>(hops) + off) << j;
+        }
+    }
+    const u64 heads = active ? landed & ~((1u << ns) - 1u) : 0u;
+    return union_row_fast<LB>(heads, hi, lo, hops);
+}
+
 /* layout of the block the kernel wants zeroed before every launch (all offsets multiples of 8) */
 struct dec_onepass_layout {
     uint64_t ctl, tile_agg, group_acc, round_base, item_base, bytes;
@@ -5305,38 +5326,6 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
     const u32 ns = tb.n_states;
     const u32 wlut_at = lds_offset_of(sh.wlut);
 
-    /* one wave of the grid only watches the groups of a round arrive and publishes the next round's base (enc_onepass) */
-    if (blockIdx.x == 0 && wave == kFuseWaves - 1) {
-        const u32 full_rounds = n_tiles / kOpRoundTiles;
-        u64 base = 0;
-        if (lane == 0) {
-            granule_store(&round_base[0], kOpReady);
-        }
-        for (u32 r = 0; r < full_rounds; ++r) {
-            u64 b = 0;
-            for (u32 spins = 0;; ++spins) {
-                b = lane < kOpRoundGroups ? granule_load(&group_acc[(u64)(r * kOpRoundGroups + lane) * kOpGroupStride])
-                                          : kOpGroupTiles * kOpArrive;
-                if (__all((b >> 40) == kOpGroupTiles)) {
-                    break;
-                }
-                if (spins > kFuseSpinLimit * 16u || word_load(&ctl[0]) != 0) {
-                    return; /* (the tiles that wait for this base give up in their turn, or have) */
-                }
-                __builtin_amdgcn_s_sleep(4);
-            }
-            u64 sum = lane < kOpRoundGroups ? (b & kOpSum) : 0;
-#pragma unroll
-            for (u32 d = kWave / 2; d > 0; d >>= 1) {
-                sum += __shfl_xor(sum, d);
-            }
-            base += sum;
-            if (lane == 0) {
-                granule_store(&round_base[r + 1], kOpReady | base);
-            }
-        }
-        return;
-    }
     if ((wlut_at & ((4u << LB) - 1u)) != 0) {
         if (lane == 0) {
             ctl[1] = 1u;
@@ -5347,7 +5336,7 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
 
     /* tiles in turn over the waves of the grid: the tiles a tile waits for belong to this turn or an earlier one, so to
      * running waves as long as the whole grid is resident (the launch sizes it so; every wait is bounded anyway) */
-    const u32 stride = gridDim.x * kFuseWaves - 1;
+    const u32 stride = gridDim.x * kFuseWaves;
     u8 *const lds_bytes = reinterpret_cast<u8 *>(&sh);
     const u32 slot_at = (u32)(sh.slots[wave] - lds_bytes) + lane * kFuseSlotBytes; /* my slot, as an LDS byte offset */
     const u32 head_at = (u32)(sh.slots[wave] - lds_bytes) + kWave * kFuseSlotBytes;
@@ -5358,7 +5347,13 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
     hufd_tile_rec rec;
     u32 w[kFastRows];
     u32 meet_row = 0, meet_bit = 0, why = 0;
-    auto front = [&](u32 t) {
+    /* what the tile whose count has just been published will want to know: asked for in the middle of the next tile's
+     * phase U (not at once: the counts of the tiles beside it are on their way at the same moment), looked at after it */
+    const u32 *ask_a = nullptr;
+    const u64 *ask_b = nullptr, *ask_rb = nullptr, *ask_ib = nullptr;
+    u32 a = 0;
+    u64 b = 0, rb = 0, ib = 0;
+    auto front = [&](u32 t, bool ask) {
         rec = tiles[t];
         const bool active = lane < rec.n_lanes;
         const u8 *src = d_in + rec.src_off + (u64)(active ? lane : 0u) * HUFD_DEC_SUB_BYTES;
@@ -5381,8 +5376,14 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
         meet_row = 0; /* the same for the whole wave */
 #pragma unroll
         for (u32 r = 0; r < kFastMaxMeet; ++r) {
+            if (r == 2 && ask) {
+                a = word_load(ask_a);
+                b = granule_load(ask_b);
+                rb = granule_load(ask_rb);
+                ib = granule_load(ask_ib);
+            }
             if (!settled) {
-                heads = union_row_fast<LB>(heads, w[r], w[r + 1], sh.hops);
+                heads = r == 0 ? union_first_row<LB>(ns, active, w[0], w[1], sh.hops) : union_row_fast<LB>(heads, w[r], w[r + 1], sh.hops);
                 one = heads != 0 && (heads & (heads - 1)) == 0;
                 meet_row = r + 1;
                 settled = __all(one || heads == 0);
@@ -5392,11 +5393,14 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
         why = __any(active && !(one && settled)) ? 2u : 0u; /* (diagnostics: the first reason the tile has for giving up) */
     };
 
-    u32 t = blockIdx.x * kFuseWaves + wave - (blockIdx.x ? 1u : 0u);
+    u32 t = blockIdx.x * kFuseWaves + wave;
+    if (lane == 0 && t == 0) {
+        granule_store(&round_base[0], kOpReady);
+    }
     if (t >= n_tiles || uniform32(word_load(&ctl[0])) != 0) {
         return;
     }
-    front(t);
+    front(t, false);
     for (;;) {
         FUSE_STAMP_ADD(0);
         const u32 n_lanes = rec.n_lanes;
@@ -5485,11 +5489,46 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
         const u32 total = first_n + __shfl(incl, kWave - 1);
         const u32 leaves = __shfl(exit_state, n_lanes - 1) & 15u;
         const u32 g = t / kOpGroupTiles, p = t % kOpGroupTiles, rr = g / kOpRoundGroups, gi = g % kOpRoundGroups;
-        u32 a = kFuseReady;
-        u64 b = kOpGroupTiles * kOpArrive, rb = 0, ib = kOpReady;
+        /* (every lane asks for something, the words it does not need among them) */
+        ask_a = &tile_agg[g * kOpGroupTiles + (lane < p ? lane : 0u)];
+        ask_b = &group_acc[(u64)(rr * kOpRoundGroups + (lane < gi ? lane : 0u)) * kOpGroupStride];
+        ask_rb = &round_base[rr];
+        ask_ib = &item_base[my_item];
         if (!why) {
             if (lane == 0) {
                 arrival_quiet(&tile_agg[t], kFuseReady | total, &group_acc[(u64)g * kOpGroupStride], kOpArrive + total);
+            }
+            /* The wave with a round's last tile watches the round's groups arrive and says how many symbols lie in front of
+             * the next round.  (The grid is 4096 waves on an MI355X, a round 4096 tiles: a round is what the grid does in
+             * one turn, so that nobody but this wave waits for more of the turn than the tiles in front of its own -- with
+             * one wave of the grid set aside for this, as in enc_onepass, a turn was 4095 tiles, every round's first
+             * tiles lay in the next turn and every tile of that turn waited for them by way of the round's base.) */
+            if ((t + 1) % kOpRoundTiles == 0) {
+                const u32 r = t / kOpRoundTiles;
+                u64 rb0 = 0, gb = 0;
+                for (u32 spins = 0;; ++spins) {
+                    gb = lane < kOpRoundGroups ? granule_load_now(&group_acc[(u64)(r * kOpRoundGroups + lane) * kOpGroupStride])
+                                               : kOpGroupTiles * kOpArrive;
+                    rb0 = granule_load_now(&round_base[r]);
+                    if (__all((gb >> 40) == kOpGroupTiles && (rb0 & kOpReady) != 0)) {
+                        break;
+                    }
+                    if (spins > kFuseSpinLimit || uniform32(word_load_now(&ctl[0])) != 0) {
+                        why = spins > kFuseSpinLimit ? 9u : 14u;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (!why) {
+                    u64 sum = lane < kOpRoundGroups ? (gb & kOpSum) : 0;
+#pragma unroll
+                    for (u32 d = kWave / 2; d > 0; d >>= 1) {
+                        sum += __shfl_xor(sum, d);
+                    }
+                    if (lane == 0) {
+                        granule_store(&round_base[r + 1], kOpReady | ((rb0 & ~kOpReady) + sum));
+                    }
+                }
             }
         }
         FUSE_STAMP_ADD(3);
@@ -5500,7 +5539,12 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
         t += stride;
         const bool more = t < n_tiles && uniform32(word_load(&ctl[0])) == 0;
         if (more) {
-            front(t);
+            front(t, true);
+        } else {
+            a = word_load(ask_a);
+            b = granule_load(ask_b);
+            rb = granule_load(ask_rb);
+            ib = granule_load(ask_ib);
         }
         const u32 why_next = why;
         why = why_mine;
@@ -5508,13 +5552,9 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
 
         u64 item_off = 0;
         if (!why) {
-            /* ---- the symbols in front of the tile */
-            /* (every lane asks for something every time, the words it does not need among them: one wait for all) */
-            const u32 *pa = &tile_agg[g * kOpGroupTiles + (lane < p ? lane : 0u)];
-            const u64 *pb = &group_acc[(u64)(rr * kOpRoundGroups + (lane < gi ? lane : 0u)) * kOpGroupStride];
+            /* ---- the symbols in front of the tile: asked for above; what is not there yet is asked for again, all of
+             * it together and waited for once */
             for (u32 spins = 0;; ++spins) {
-                u32 gave_up = 0;
-                fuse_ask_all(pa, pb, &round_base[rr], &item_base[my_item], &ctl[0], a, b, rb, ib, gave_up);
                 a = lane < p ? a : kFuseReady;
                 b = lane < gi ? b : kOpGroupTiles * kOpArrive;
                 ib = first_tile ? kOpReady : ib;
@@ -5522,11 +5562,13 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
                 if (__all(there)) {
                     break;
                 }
+                u32 gave_up = 0;
+                __builtin_amdgcn_s_sleep(4);
+                fuse_ask_all(ask_a, ask_b, ask_rb, ask_ib, &ctl[0], a, b, rb, ib, gave_up);
                 if (spins > kFuseSpinLimit || uniform32(gave_up) != 0) {
                     why = spins > kFuseSpinLimit ? 8u : 14u;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(4);
             }
         }
         if (!why) {
@@ -5556,30 +5598,36 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
             if (lane + kWave < first_n) {
                 dst[lane + kWave] = lds_bytes[head_at + lane + kWave];
             }
+            /* (slot 0 of a tile that is not its item's first holds only what lane 1 put behind lane 0's symbols, often
+             * fewer than 16: a byte a lane; every other slot holds at least 16) */
+            if (!first_tile) {
+                const u32 n0 = __shfl(n, 0), k0 = __shfl(skip, 0);
+                if (lane < n0) {
+                    dst[lane] = sh.slots[wave][k0 + lane];
+                }
+                if (lane + kWave < n0) {
+                    dst[lane + kWave] = sh.slots[wave][k0 + lane + kWave];
+                }
+            }
             const u32 row = lane & 7u;
+            sh.meta[wave][lane] = pos | ((!first_tile && lane == 0 ? 0u : n) << 16);
+            wave_step();
+            /* all the reads, then all the stores: a store behind every read had the wave wait for LDS eight times */
+            unaligned_uint4 v[kWave / 8];
+            u32 to[kWave / 8];
 #pragma unroll
             for (u32 it = 0; it < kWave / 8; ++it) {
                 const u32 s = it * 8 + (lane >> 3);
-                const u32 ns_ = __shfl(n, s), ps = __shfl(pos, s), ks = __shfl(skip, s);
-                const u8 *slot = sh.slots[wave] + s * kFuseSlotBytes + ks;
-                if (16 * row + 16 <= ns_ && ks == 0) {
-                    /* (a slot starts on a multiple of 8: two aligned reads) */
-                    const u64 *q = reinterpret_cast<const u64 *>(slot + 16 * row);
-                    const u64 v0 = q[0], v1 = q[1];
-                    *reinterpret_cast<unaligned_uint4 *>(dst + ps + 16 * row) =
-                        unaligned_uint4{(u32)v0, (u32)(v0 >> 32), (u32)v1, (u32)(v1 >> 32)};
-                } else if (16 * row < ns_ && ns_ >= 16) {
-                    const u32 from = 16 * row + 16 <= ns_ ? 16 * row : ns_ - 16;
-                    const unaligned_uint4 v = *reinterpret_cast<const unaligned_uint4 *>(slot + from);
-                    *reinterpret_cast<unaligned_uint4 *>(dst + ps + from) = v;
-                } else if (ns_ < 16) {
-                    /* (slot 0 of a tile that is not its item's first may hold fewer than 16 symbols: a byte a lane, two trips) */
-                    if (row < ns_) {
-                        dst[ps + row] = slot[row];
-                    }
-                    if (row + 8 < ns_) {
-                        dst[ps + row + 8] = slot[row + 8];
-                    }
+                const u32 m = sh.meta[wave][s];
+                const u32 ns_ = m >> 16, ps = m & 0xFFFFu;
+                const u32 from = 16 * row + 16 <= ns_ ? 16 * row : (ns_ >= 16 ? ns_ - 16 : 0u);
+                v[it] = *reinterpret_cast<const unaligned_uint4 *>(sh.slots[wave] + s * kFuseSlotBytes + from);
+                to[it] = 16 * row < ns_ ? ps + from : HUFD_NONE32;
+            }
+#pragma unroll
+            for (u32 it = 0; it < kWave / 8; ++it) {
+                if (to[it] != HUFD_NONE32) {
+                    *reinterpret_cast<unaligned_uint4 *>(dst + to[it]) = v[it];
                 }
             }
             wave_step(); /* the slots are free for the next tile */
@@ -7151,7 +7199,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     hipLaunchKernelGGL(                                                                                                \
         (dec_onepass_kernel<LBV, SUREV>),                                                                              \
         dim3(persistent_grid(dec_onepass_kernel<LBV, SUREV>, kFuseThreads, (uint32_t)sizeof(fuse_shared<LBV>),          \
-                             (a->n_tiles + 1 + kFuseWaves - 1) / kFuseWaves)),                                         \
+                             (a->n_tiles + kFuseWaves - 1) / kFuseWaves)),                                             \
         dim3(kFuseThreads), (uint32_t)sizeof(fuse_shared<LBV>), st, a->tables, a->tiles, a->n_tiles,                   \
         (const u8 *)a->d_in, (u8 *)a->d_out, (u32 *)(blk + l.ctl), (u32 *)(blk + l.tile_agg), (u64 *)(blk + l.group_acc), \
         (u64 *)(blk + l.round_base), (u64 *)(blk + l.item_base), a->chunk_entry, a->chunk_base, fail_tile)
