@@ -168,7 +168,7 @@ struct hufd_chunk_rec {
     uint32_t item;
 };
 
-/* one per tile of dec_onepass, built with the plan.  A tile = up to 64 neighbouring sub-chunks of one item that lie inside
+/* one per tile of dec_onepass, built with the plan.  A tile = up to 64 neighbouring sub-chunks (of HUFD_FUSE_SUB_BYTES) of one item that lie inside
  * its stream (with at least 8 more bytes behind them), one wave's work; but for an item's first tile, lane 0 is the last
  * sub-chunk of the tile in front (walked again only to learn how it is left): tiles advance by 63 sub-chunks. */
 struct hufd_tile_rec {
@@ -182,5 +182,6 @@ struct hufd_tile_rec {
     uint32_t reserved;
 };
 #define HUFD_TILE_LANES 64u
+#define HUFD_FUSE_SUB_BYTES 128u /* a lane's sub-chunk in dec_onepass */
 
 #endif /* HUFFMAN_AMD_DEVICE_TYPES_H */

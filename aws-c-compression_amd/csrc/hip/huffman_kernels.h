@@ -91,8 +91,8 @@ struct hufk_decode_args {
     uint32_t n_tiles;
     void *fuse_block;      /* hufk_decode_zero_bytes(n_tiles, n_items) bytes of scratch for dec_onepass, zeroed by the launch;
                             * its first word: dec_onepass gave up, the two-pass kernels behind it take every chunk */
-    uint32_t fuse_mode;    /* 0: dec_onepass where the coder allows; 1: never (AWS_HUFFMAN_AMD_DECODE=two-pass);
-                            * 2: with one chunk made to give up (=one-pass-fails: the way back, for tests) */
+    uint32_t fuse_mode;    /* 1: the two-pass kernels only (the default); 0: dec_onepass in front of them where the coder allows
+                            * (AWS_HUFFMAN_AMD_DECODE=one-pass); 2: the same with one tile made to give up (=one-pass-fails) */
 };
 
 /* one-time per-process kernel attribute setup (dynamic LDS above 64 KiB) */

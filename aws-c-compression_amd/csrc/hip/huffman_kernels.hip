@@ -20,9 +20,11 @@
  * All LDS lives in the dynamic region with 16-byte carves (guide: Guideline 17).
  */
 #include <hip/hip_runtime.h>
+#include <numeric>
 
 #include <pthread.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "device_types.h"
 #include "huffman_kernels.h"
@@ -5139,6 +5141,10 @@ __global__ __launch_bounds__(256) void dec_scan_apply_kernel(
  * the road of BASELINE configs[2].)
  */
 constexpr u32 kFuseWaves = 8;
+constexpr u32 kFuseSubBytes = HUFD_FUSE_SUB_BYTES; /* a lane's sub-chunk: 128 bytes as in the two-pass kernels.  (64 bytes -- half the LDS a lane holds, so
+                                                     * 6 waves a SIMD instead of 4 -- was measured: a tile's front is then too short to cover the time its
+                                                     * neighbours' counts need to arrive, every wave polls, and the polls slow everything down: 4 ms and more.) */
+constexpr u32 kFuseSubWords = kFuseSubBytes / 4;
 constexpr u32 kFuseThreads = kFuseWaves * kWave;
 constexpr u32 kFuseRowSyms = 8;      /* codes that can start in a row (at least 4 bits each) */
 constexpr u32 kFuseSlotBytes = 136;  /* 34 words: neighbouring lanes' slots two banks apart */
@@ -5209,25 +5215,52 @@ __device__ __forceinline__ void fuse_sure(u32 &state, u64 pair, u32 table, const
 /* what a tile waits for, asked for together and waited for once (a poll costs a trip to memory: five of them one after
  * the other made a missed first look cost five trips) */
 __device__ __forceinline__ void fuse_ask_all(
-    const u32 *pa, const u64 *pb, const u64 *prb, const u64 *pib, const u32 *pctl, u32 &a, u64 &b, u64 &rb, u64 &ib, u32 &gave_up) {
+    const u32 *pa, const u64 *pb, const u64 *pb2, const u64 *prb, const u64 *pib, const u32 *pctl, u32 &a, u64 &b, u64 &b2, u64 &rb,
+    u64 &ib, u32 &gave_up) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("global_load_dword %0, %5, off sc1\n\t"
-                 "global_load_dwordx2 %1, %6, off sc1\n\t"
-                 "global_load_dwordx2 %2, %7, off sc1\n\t"
-                 "global_load_dwordx2 %3, %8, off sc1\n\t"
-                 "global_load_dword %4, %9, off sc1\n\t"
+    asm volatile("global_load_dword %0, %6, off sc1\n\t"
+                 "global_load_dwordx2 %1, %7, off sc1\n\t"
+                 "global_load_dwordx2 %2, %8, off sc1\n\t"
+                 "global_load_dwordx2 %3, %9, off sc1\n\t"
+                 "global_load_dwordx2 %4, %10, off sc1\n\t"
+                 "global_load_dword %5, %11, off sc1\n\t"
                  "s_waitcnt vmcnt(0)"
-                 : "=&v"(a), "=&v"(b), "=&v"(rb), "=&v"(ib), "=&v"(gave_up)
-                 : "v"(pa), "v"(pb), "v"(prb), "v"(pib), "v"(pctl)
+                 : "=&v"(a), "=&v"(b), "=&v"(b2), "=&v"(rb), "=&v"(ib), "=&v"(gave_up)
+                 : "v"(pa), "v"(pb), "v"(pb2), "v"(prb), "v"(pib), "v"(pctl)
                  : "memory");
 #else
     a = *pa;
     b = *pb;
+    b2 = *pb2;
     rb = *prb;
     ib = *pib;
     gave_up = *pctl;
 #endif
 }
+/* the value of the lane in front / behind (lane 0 / lane 63: its own), and of a lane every lane names alike: data-parallel
+ * moves and a scalar read, no LDS permute and no index register kept for it */
+__device__ __forceinline__ u32 wave_from_front(u32 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false); /* wave_shr:1 */
+#else
+    return __shfl_up(v, 1);
+#endif
+}
+__device__ __forceinline__ u32 wave_from_behind(u32 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xF, 0xF, false); /* wave_shl:1 */
+#else
+    return __shfl_down(v, 1);
+#endif
+}
+__device__ __forceinline__ u32 wave_read(u32 v, u32 lane_same_everywhere) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (u32)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)lane_same_everywhere));
+#else
+    return __shfl(v, lane_same_everywhere);
+#endif
+}
+
 /*
  * Phase U's first row.  The ns entry states are ns look-ups that do not wait for each other (the general loop takes a
  * head at a time, lowest first, because a head may send another into the same row): their windows lie in the row's own
@@ -5254,7 +5287,7 @@ struct dec_onepass_layout {
 };
 static dec_onepass_layout dec_onepass_layout_of(uint64_t n_tiles, uint64_t n_items) {
     const uint64_t groups = (n_tiles + kOpGroupTiles - 1) / kOpGroupTiles;
-    const uint64_t rounds = (groups + kOpRoundGroups - 1) / kOpRoundGroups;
+    const uint64_t rounds = groups; /* (a round is what the grid does in one turn, at least a group: no more rounds than groups) */
     dec_onepass_layout l;
     l.ctl = 0;
     l.tile_agg = 32;
@@ -5310,7 +5343,8 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
     u64 *item_base,  /* [n_items] zeroed */
     u32 *chunk_entry, /* of the chunk behind an item's last chunk inside the stream: what dec_scan_small goes on from */
     u64 *chunk_base,
-    u32 fail_tile /* a tile that is to give up (tests of the way back); HUFD_NONE32: none */) {
+    u32 fail_tile /* a tile that is to give up (tests of the way back); HUFD_NONE32: none */,
+    u32 round_groups /* groups of kOpGroupTiles tiles that the grid takes in one turn = a round of the look-back (at most 128) */) {
 
     FUSE_STAMP_DECL
     fuse_shared<LB> &sh = *reinterpret_cast<fuse_shared<LB> *>(dyn_lds);
@@ -5345,29 +5379,33 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
      * (asked for at once, every wave of the chip polled for half a tile's time, and the polls slowed everything down:
      * 1.67 ms). */
     hufd_tile_rec rec;
-    u32 w[kFastRows];
+    u32 w[kFuseSubWords + 1];
     u32 meet_row = 0, meet_bit = 0, why = 0;
     /* what the tile whose count has just been published will want to know: asked for in the middle of the next tile's
      * phase U (not at once: the counts of the tiles beside it are on their way at the same moment), looked at after it */
-    const u32 *ask_a = nullptr;
-    const u64 *ask_b = nullptr, *ask_rb = nullptr, *ask_ib = nullptr;
+    u32 ask_g = 0, ask_p = 0, ask_rr = 0, ask_gi = 0, ask_item = 0; /* (the same in every lane: the addresses are worked out when they are used) */
+    auto ask_a = [&]() { return &tile_agg[ask_g * kOpGroupTiles + (lane < ask_p ? lane : 0u)]; };
+    auto ask_b = [&]() { return &group_acc[(u64)(ask_rr * round_groups + (lane < ask_gi ? lane : 0u)) * kOpGroupStride]; };
+    auto ask_b2 = [&]() { return &group_acc[(u64)(ask_rr * round_groups + (lane + kWave < ask_gi ? lane + kWave : 0u)) * kOpGroupStride]; };
+    auto ask_rb = [&]() { return &round_base[ask_rr]; };
+    auto ask_ib = [&]() { return &item_base[ask_item]; };
     u32 a = 0;
-    u64 b = 0, rb = 0, ib = 0;
+    u64 b = 0, b2 = 0, rb = 0, ib = 0;
     auto front = [&](u32 t, bool ask) {
         rec = tiles[t];
         const bool active = lane < rec.n_lanes;
-        const u8 *src = d_in + rec.src_off + (u64)(active ? lane : 0u) * HUFD_DEC_SUB_BYTES;
+        const u8 *src = d_in + rec.src_off + (u64)(active ? lane : 0u) * kFuseSubBytes;
         {
             const unaligned_uint4 *line = reinterpret_cast<const unaligned_uint4 *>(src);
 #pragma unroll
-            for (u32 q = 0; q < kSubWords / 4; ++q) {
+            for (u32 q = 0; q < kFuseSubWords / 4; ++q) {
                 const unaligned_uint4 v = line[q];
                 w[4 * q + 0] = __builtin_bswap32(v.x);
                 w[4 * q + 1] = __builtin_bswap32(v.y);
                 w[4 * q + 2] = __builtin_bswap32(v.z);
                 w[4 * q + 3] = __builtin_bswap32(v.w);
             }
-            w[kSubWords] = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(src + HUFD_DEC_SUB_BYTES)->x);
+            w[kFuseSubWords] = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(src + kFuseSubBytes)->x);
         }
 
         /* U: all entry states as one mask of heads per row, until every lane of the wave is down to one */
@@ -5377,10 +5415,11 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
 #pragma unroll
         for (u32 r = 0; r < kFastMaxMeet; ++r) {
             if (r == 2 && ask) {
-                a = word_load(ask_a);
-                b = granule_load(ask_b);
-                rb = granule_load(ask_rb);
-                ib = granule_load(ask_ib);
+                a = word_load(ask_a());
+                b = granule_load(ask_b());
+                b2 = granule_load(ask_b2());
+                rb = granule_load(ask_rb());
+                ib = granule_load(ask_ib());
             }
             if (!settled) {
                 heads = r == 0 ? union_first_row<LB>(ns, active, w[0], w[1], sh.hops) : union_row_fast<LB>(heads, w[r], w[r + 1], sh.hops);
@@ -5421,7 +5460,7 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
             u32 state = fw.state_at(meet_bit);
             u32 at = slot_at, c16 = 0;
 #pragma unroll
-            for (u32 r = 1; r < kSubWords; ++r) {
+            for (u32 r = 1; r < kFuseSubWords; ++r) {
                 if (r >= meet_row) {
                     const u64 pair = ((u64)w[r] << 32) | w[r + 1];
                     fuse_sure<0, SURE>(state, pair, wlut_at, fw, lds_bytes, at);
@@ -5444,7 +5483,7 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
          * bit, symbols behind that lane's in its slot (lane 0: to the room behind the slots) */
         u32 head_n; /* symbols of my sub-chunk in front of its meeting bit */
         {
-            const u32 front_exit = __shfl_up(exit_state, 1), front_fill = __shfl_up(in_slot, 1);
+            const u32 front_exit = wave_from_front(exit_state), front_fill = wave_from_front(in_slot);
             const u32 entry = lane ? front_exit : (u32)(my_flags >> 8) & 7u;
             const u32 at0 = lane ? slot_at - kFuseSlotBytes + front_fill : head_at;
             const u32 lim = lane ? slot_at - kFuseSlotBytes + kFuseSlotFill : head_at + kFuseHeadBytes - 16u;
@@ -5479,38 +5518,45 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
 
         /* what every slot holds: its lane's R symbols (not lane 0's, unless the item starts here) and the next lane's H
          * symbols (not behind the tile's last lane: those are the next tile's); in front of slot 0 an item's first symbols */
-        const u32 next_head = __shfl_down(head_n, 1);
+        const u32 next_head = wave_from_behind(head_n);
         const u32 skip = payload ? 0u : in_slot; /* (lane 0 of a tile that is not its item's first: only what lane 1 put behind its symbols) */
         const u32 n = active ? (payload ? in_slot : 0u) + (lane + 1 < n_lanes ? next_head : 0u) : 0u;
-        why = !why && __any(active && (skip + n >= kFuseSlotFill || (payload && n < 16u))) ? 7u : why; /* symbol-dense data: more than a slot holds */
-        const u32 first_n = first_tile ? __shfl(head_n, 0) : 0u;
+        why = !why && __any(active && skip + n >= kFuseSlotFill) ? 7u : why; /* symbol-dense data: more than a slot holds */
+        const u32 first_n = first_tile ? wave_read(head_n, 0) : 0u;
         const u32 incl = wave_inclusive_sum_dpp(n, lane);
         const u32 pos = first_n + incl - n;
-        const u32 total = first_n + __shfl(incl, kWave - 1);
-        const u32 leaves = __shfl(exit_state, n_lanes - 1) & 15u;
-        const u32 g = t / kOpGroupTiles, p = t % kOpGroupTiles, rr = g / kOpRoundGroups, gi = g % kOpRoundGroups;
+        const u32 total = first_n + wave_read(incl, kWave - 1);
+        const u32 leaves = wave_read(exit_state, n_lanes - 1) & 15u;
+        const u32 g = t / kOpGroupTiles, p = t % kOpGroupTiles, rr = g / round_groups, gi = g % round_groups;
         /* (every lane asks for something, the words it does not need among them) */
-        ask_a = &tile_agg[g * kOpGroupTiles + (lane < p ? lane : 0u)];
-        ask_b = &group_acc[(u64)(rr * kOpRoundGroups + (lane < gi ? lane : 0u)) * kOpGroupStride];
-        ask_rb = &round_base[rr];
-        ask_ib = &item_base[my_item];
+        ask_g = g;
+        ask_p = p;
+        ask_rr = rr;
+        ask_gi = gi;
+        ask_item = my_item;
         if (!why) {
             if (lane == 0) {
-                arrival_quiet(&tile_agg[t], kFuseReady | total, &group_acc[(u64)g * kOpGroupStride], kOpArrive + total);
+                u32 arrive_hi = (u32)(kOpArrive >> 32); /* (made here, not kept in a register pair -- or spilled -- across the turn) */
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(arrive_hi));
+#endif
+                arrival_quiet(&tile_agg[t], kFuseReady | total, &group_acc[(u64)g * kOpGroupStride], ((u64)arrive_hi << 32) | total);
             }
             /* The wave with a round's last tile watches the round's groups arrive and says how many symbols lie in front of
              * the next round.  (The grid is 4096 waves on an MI355X, a round 4096 tiles: a round is what the grid does in
              * one turn, so that nobody but this wave waits for more of the turn than the tiles in front of its own -- with
              * one wave of the grid set aside for this, as in enc_onepass, a turn was 4095 tiles, every round's first
              * tiles lay in the next turn and every tile of that turn waited for them by way of the round's base.) */
-            if ((t + 1) % kOpRoundTiles == 0) {
-                const u32 r = t / kOpRoundTiles;
-                u64 rb0 = 0, gb = 0;
+            if ((t + 1) % (round_groups * kOpGroupTiles) == 0) {
+                const u32 r = t / (round_groups * kOpGroupTiles);
+                u64 rb0 = 0, gb = 0, gb2 = 0;
                 for (u32 spins = 0;; ++spins) {
-                    gb = lane < kOpRoundGroups ? granule_load_now(&group_acc[(u64)(r * kOpRoundGroups + lane) * kOpGroupStride])
-                                               : kOpGroupTiles * kOpArrive;
+                    gb = lane < round_groups ? granule_load_now(&group_acc[(u64)(r * round_groups + lane) * kOpGroupStride])
+                                             : kOpGroupTiles * kOpArrive;
+                    gb2 = lane + kWave < round_groups ? granule_load_now(&group_acc[(u64)(r * round_groups + lane + kWave) * kOpGroupStride])
+                                                      : kOpGroupTiles * kOpArrive;
                     rb0 = granule_load_now(&round_base[r]);
-                    if (__all((gb >> 40) == kOpGroupTiles && (rb0 & kOpReady) != 0)) {
+                    if (__all((gb >> 40) == kOpGroupTiles && (gb2 >> 40) == kOpGroupTiles && (rb0 & kOpReady) != 0)) {
                         break;
                     }
                     if (spins > kFuseSpinLimit || uniform32(word_load_now(&ctl[0])) != 0) {
@@ -5520,11 +5566,9 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
                     __builtin_amdgcn_s_sleep(8);
                 }
                 if (!why) {
-                    u64 sum = lane < kOpRoundGroups ? (gb & kOpSum) : 0;
-#pragma unroll
-                    for (u32 d = kWave / 2; d > 0; d >>= 1) {
-                        sum += __shfl_xor(sum, d);
-                    }
+                    const u64 mine_g = (lane < round_groups ? (gb & kOpSum) : 0) + (lane + kWave < round_groups ? (gb2 & kOpSum) : 0);
+                    const u64 sum = (u64)wave_read(wave_inclusive_sum_dpp((u32)(mine_g & 0xFFFFFu), lane), kWave - 1) +
+                                    ((u64)wave_read(wave_inclusive_sum_dpp((u32)(mine_g >> 20), lane), kWave - 1) << 20);
                     if (lane == 0) {
                         granule_store(&round_base[r + 1], kOpReady | ((rb0 & ~kOpReady) + sum));
                     }
@@ -5541,10 +5585,11 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
         if (more) {
             front(t, true);
         } else {
-            a = word_load(ask_a);
-            b = granule_load(ask_b);
-            rb = granule_load(ask_rb);
-            ib = granule_load(ask_ib);
+            a = word_load(ask_a());
+            b = granule_load(ask_b());
+            b2 = granule_load(ask_b2());
+            rb = granule_load(ask_rb());
+            ib = granule_load(ask_ib());
         }
         const u32 why_next = why;
         why = why_mine;
@@ -5557,14 +5602,16 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
             for (u32 spins = 0;; ++spins) {
                 a = lane < p ? a : kFuseReady;
                 b = lane < gi ? b : kOpGroupTiles * kOpArrive;
+                b2 = lane + kWave < gi ? b2 : kOpGroupTiles * kOpArrive;
                 ib = first_tile ? kOpReady : ib;
-                const bool there = (a & kFuseReady) != 0 && (b >> 40) == kOpGroupTiles && (rb & kOpReady) != 0 && (ib & kOpReady) != 0;
+                const bool there = (a & kFuseReady) != 0 && (b >> 40) == kOpGroupTiles && (b2 >> 40) == kOpGroupTiles &&
+                                   (rb & kOpReady) != 0 && (ib & kOpReady) != 0;
                 if (__all(there)) {
                     break;
                 }
                 u32 gave_up = 0;
                 __builtin_amdgcn_s_sleep(4);
-                fuse_ask_all(ask_a, ask_b, ask_rb, ask_ib, &ctl[0], a, b, rb, ib, gave_up);
+                fuse_ask_all(ask_a(), ask_b(), ask_b2(), ask_rb(), ask_ib(), &ctl[0], a, b, b2, rb, ib, gave_up);
                 if (spins > kFuseSpinLimit || uniform32(gave_up) != 0) {
                     why = spins > kFuseSpinLimit ? 8u : 14u;
                     break;
@@ -5572,11 +5619,12 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
             }
         }
         if (!why) {
-            u64 front = (lane < p ? (u64)(a & 0xFFFFFFu) : 0ull) + (lane < gi ? (b & kOpSum) : 0ull);
-#pragma unroll
-            for (u32 d = kWave / 2; d > 0; d >>= 1) {
-                front += __shfl_xor(front, d);
-            }
+            /* (sums of 40-bit numbers as two sums of 20-bit halves: data-parallel moves, no LDS permutes, no index registers) */
+            const u64 mine_b = (lane < gi ? (b & kOpSum) : 0ull) + (lane + kWave < gi ? (b2 & kOpSum) : 0ull);
+            const u32 part_lo = (lane < p ? a & 0xFFFFFFu : 0u) + (u32)(mine_b & 0xFFFFFu);
+            const u32 part_hi = (u32)(mine_b >> 20);
+            u64 front = (u64)wave_read(wave_inclusive_sum_dpp(part_lo, lane), kWave - 1) +
+                        ((u64)wave_read(wave_inclusive_sum_dpp(part_hi, lane), kWave - 1) << 20);
             front += rb & ~kOpReady;
             if (first_tile) {
                 if (lane == 0) {
@@ -5592,42 +5640,59 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
             /* ---- the slots to HBM: eight lanes a slot, 16 bytes each, the last 16 of a slot as they lie (they overlap
              * the row in front with the same bytes) */
             u8 *dst = d_out + my_out_off + item_off;
-            if (lane < first_n) {
-                dst[lane] = lds_bytes[head_at + lane]; /* an item's first symbols (at most 128: 16 rows of eight) */
+            /* (the lane number as a value the compiler cannot trace: what is derived from it in this block is then worked
+             * out here, not kept in registers across the whole turn -- or spilled: this kernel must not spill, a reload
+             * waits for every load and atomic in flight) */
+            u32 lane_o = lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(lane_o));
+#endif
+            const u32 slot_o = (u32)(sh.slots[wave] - lds_bytes) + lane_o * kFuseSlotBytes;
+            if (lane_o < first_n) {
+                dst[lane_o] = lds_bytes[head_at + lane_o]; /* an item's first symbols (at most 128: 16 rows of eight) */
             }
-            if (lane + kWave < first_n) {
-                dst[lane + kWave] = lds_bytes[head_at + lane + kWave];
+            if (lane_o + kWave < first_n) {
+                dst[lane_o + kWave] = lds_bytes[head_at + lane_o + kWave];
             }
             /* (slot 0 of a tile that is not its item's first holds only what lane 1 put behind lane 0's symbols, often
-             * fewer than 16: a byte a lane; every other slot holds at least 16) */
+             * fewer than 16: a byte a lane; the other slots in 16-byte rows, and the rare one with fewer than 16 symbols --
+             * a late meeting row leaves the tile's last lane few -- by its own lane, byte by byte) */
             if (!first_tile) {
-                const u32 n0 = __shfl(n, 0), k0 = __shfl(skip, 0);
-                if (lane < n0) {
-                    dst[lane] = sh.slots[wave][k0 + lane];
+                const u32 n0 = wave_read(n, 0), k0 = wave_read(skip, 0);
+                if (lane_o < n0) {
+                    dst[lane_o] = sh.slots[wave][k0 + lane_o];
                 }
-                if (lane + kWave < n0) {
-                    dst[lane + kWave] = sh.slots[wave][k0 + lane + kWave];
+                if (lane_o + kWave < n0) {
+                    dst[lane_o + kWave] = sh.slots[wave][k0 + lane_o + kWave];
                 }
             }
-            const u32 row = lane & 7u;
-            sh.meta[wave][lane] = pos | ((!first_tile && lane == 0 ? 0u : n) << 16);
+            constexpr u32 kSlotRows = kFuseSlotFill / 16, kTrips = kSlotRows; /* 16-byte rows a slot can hold: that many lanes a slot */
+            const u32 row = lane_o % kSlotRows;
+            sh.meta[wave][lane_o] = pos | ((!first_tile && lane_o == 0 ? 0u : n) << 16);
             wave_step();
-            /* all the reads, then all the stores: a store behind every read had the wave wait for LDS eight times */
-            unaligned_uint4 v[kWave / 8];
-            u32 to[kWave / 8];
+            /* all the reads, then all the stores: a store behind every read had the wave wait for LDS every time */
+            unaligned_uint4 v[kTrips];
+            u32 to[kTrips];
 #pragma unroll
-            for (u32 it = 0; it < kWave / 8; ++it) {
-                const u32 s = it * 8 + (lane >> 3);
+            for (u32 it = 0; it < kTrips; ++it) {
+                const u32 s = it * (kWave / kSlotRows) + lane_o / kSlotRows;
                 const u32 m = sh.meta[wave][s];
                 const u32 ns_ = m >> 16, ps = m & 0xFFFFu;
                 const u32 from = 16 * row + 16 <= ns_ ? 16 * row : (ns_ >= 16 ? ns_ - 16 : 0u);
                 v[it] = *reinterpret_cast<const unaligned_uint4 *>(sh.slots[wave] + s * kFuseSlotBytes + from);
-                to[it] = 16 * row < ns_ ? ps + from : HUFD_NONE32;
+                to[it] = 16 * row < ns_ && ns_ >= 16 ? ps + from : HUFD_NONE32;
             }
 #pragma unroll
-            for (u32 it = 0; it < kWave / 8; ++it) {
+            for (u32 it = 0; it < kTrips; ++it) {
                 if (to[it] != HUFD_NONE32) {
                     *reinterpret_cast<unaligned_uint4 *>(dst + to[it]) = v[it];
+                }
+            }
+            if (__any(n != 0 && n < 16u && (first_tile || lane_o != 0))) {
+                if (n < 16u && (first_tile || lane_o != 0)) {
+                    for (u32 i = 0; i < n; ++i) {
+                        dst[pos + i] = lds_bytes[slot_o + skip + i];
+                    }
                 }
             }
             wave_step(); /* the slots are free for the next tile */
@@ -7196,26 +7261,36 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         u8 *blk = (u8 *)a->fuse_block;
         bool launched = true;
 #define HUFK_LAUNCH_ONEPASS_DEC(LBV, SUREV)                                                                            \
+    /* a turn of the grid = a round of the look-back: whole groups of tiles, at most 128 of them */                  \
+    const uint32_t resident = persistent_grid(dec_onepass_kernel<LBV, SUREV>, kFuseThreads, (uint32_t)sizeof(fuse_shared<LBV>), 1u << 20); \
+    const uint32_t want = (a->n_tiles + kFuseWaves - 1) / kFuseWaves;                                                  \
+    const uint32_t unit = kOpGroupTiles / std::gcd(kOpGroupTiles, kFuseWaves); /* workgroups that make whole groups */ \
+    uint32_t grid = want < resident ? (want + unit - 1) / unit * unit : resident / unit * unit;                        \
+    grid = grid > 128u * kOpGroupTiles / kFuseWaves ? 128u * kOpGroupTiles / kFuseWaves / unit * unit : grid;           \
+    grid = grid ? grid : unit;                                                                                         \
+    if (getenv("AWS_HUFFMAN_AMD_ONEPASS_GRID")) { /* (experiments) */                                                 \
+        grid = (uint32_t)atoi(getenv("AWS_HUFFMAN_AMD_ONEPASS_GRID")) / unit * unit;                                   \
+        grid = grid ? grid : unit;                                                                                     \
+    }                                                                                                                  \
     hipLaunchKernelGGL(                                                                                                \
-        (dec_onepass_kernel<LBV, SUREV>),                                                                              \
-        dim3(persistent_grid(dec_onepass_kernel<LBV, SUREV>, kFuseThreads, (uint32_t)sizeof(fuse_shared<LBV>),          \
-                             (a->n_tiles + kFuseWaves - 1) / kFuseWaves)),                                             \
+        (dec_onepass_kernel<LBV, SUREV>), dim3(grid),                                                                  \
         dim3(kFuseThreads), (uint32_t)sizeof(fuse_shared<LBV>), st, a->tables, a->tiles, a->n_tiles,                   \
         (const u8 *)a->d_in, (u8 *)a->d_out, (u32 *)(blk + l.ctl), (u32 *)(blk + l.tile_agg), (u64 *)(blk + l.group_acc), \
-        (u64 *)(blk + l.round_base), (u64 *)(blk + l.item_base), a->chunk_entry, a->chunk_base, fail_tile)
+        (u64 *)(blk + l.round_base), (u64 *)(blk + l.item_base), a->chunk_entry, a->chunk_base, fail_tile,           \
+        grid * kFuseWaves / kOpGroupTiles)
         (void)hipMemsetAsync(blk, 0, l.bytes, st);
         if (lb == 10) {
             switch (sure) {
-                case 2: HUFK_LAUNCH_ONEPASS_DEC(10, 2); break;
-                case 3: HUFK_LAUNCH_ONEPASS_DEC(10, 3); break;
-                case 4: HUFK_LAUNCH_ONEPASS_DEC(10, 4); break;
-                case 5: HUFK_LAUNCH_ONEPASS_DEC(10, 5); break;
+                case 2: { HUFK_LAUNCH_ONEPASS_DEC(10, 2); } break;
+                case 3: { HUFK_LAUNCH_ONEPASS_DEC(10, 3); } break;
+                case 4: { HUFK_LAUNCH_ONEPASS_DEC(10, 4); } break;
+                case 5: { HUFK_LAUNCH_ONEPASS_DEC(10, 5); } break;
                 default: launched = false; break;
             }
         } else {
             switch (sure) {
-                case 2: HUFK_LAUNCH_ONEPASS_DEC(12, 2); break;
-                case 3: HUFK_LAUNCH_ONEPASS_DEC(12, 3); break;
+                case 2: { HUFK_LAUNCH_ONEPASS_DEC(12, 2); } break;
+                case 3: { HUFK_LAUNCH_ONEPASS_DEC(12, 3); } break;
                 default: launched = false; break;
             }
         }

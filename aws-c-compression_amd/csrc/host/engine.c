@@ -779,7 +779,7 @@ static uint64_t dec_item_chunks(
 /* sub-chunks of an item that dec_onepass takes: those of its chunks that lie inside the stream with 8 more bytes behind */
 static uint64_t dec_item_inside_subs(uint64_t chunks, uint64_t in_len) {
     const uint64_t inside = chunks && in_len >= 8 ? (in_len - 8) / HUFD_DEC_CHUNK_BYTES : 0;
-    return (inside < chunks ? inside : chunks) * HUFD_DEC_LANES;
+    return (inside < chunks ? inside : chunks) * (HUFD_DEC_CHUNK_BYTES / HUFD_FUSE_SUB_BYTES);
 }
 /* ... as tiles: the first of 64 sub-chunks, the others of 63 and the last one of the tile in front */
 static uint64_t dec_item_tiles(uint64_t chunks, uint64_t in_len) {
@@ -861,13 +861,13 @@ static int dec_plan_fill(
                 const uint64_t first_sub = k * (HUFD_TILE_LANES - 1);
                 const uint64_t left = subs - first_sub;
                 struct hufd_tile_rec *tr = &h_tiles[tile++];
-                tr->src_off = src->in_offset + first_sub * HUFD_DEC_SUB_BYTES;
+                tr->src_off = src->in_offset + first_sub * HUFD_FUSE_SUB_BYTES;
                 tr->out_off = src->out_offset;
                 tr->out_cap = src->out_capacity;
                 tr->item = (uint32_t)i;
                 tr->n_lanes = (uint16_t)(left < HUFD_TILE_LANES ? left : HUFD_TILE_LANES);
                 tr->flags = (uint16_t)((k == 0 ? 1u : 0u) | (k + 1 == tiles_here ? 2u : 0u) | ((uint32_t)src->first_bit << 8));
-                tr->tail_chunk = chunk + (uint32_t)(subs / HUFD_DEC_LANES);
+                tr->tail_chunk = chunk + (uint32_t)(subs / (HUFD_DEC_CHUNK_BYTES / HUFD_FUSE_SUB_BYTES));
                 tr->reserved = 0;
             }
         }
@@ -1109,9 +1109,11 @@ int aws_huffman_amd_decode_plan_launch_staged(
     {
         const char *mode = getenv("AWS_HUFFMAN_AMD_DECODE");
         a.old_sync = mode && strcmp(mode, "old-sync") == 0; /* the kernel dec_sync_lean replaced, for comparison and tests */
-        /* the chunks inside streams: in one pass (dec_onepass) unless told otherwise; "one-pass-fails" makes one chunk
-         * of the launch give up, so that the way back to the two-pass kernels can be tested */
-        a.fuse_mode = mode && strcmp(mode, "two-pass") == 0 ? 1u : (mode && strcmp(mode, "one-pass-fails") == 0 ? 2u : 0u);
+        /* the chunks inside streams: sync + scan + emit (two passes over the stream) unless told otherwise.  "one-pass"
+         * puts dec_onepass in front of them (every encoded byte read once; on an MI355X it takes as long as the two
+         * passes, DESIGN.md 4 "One pass": not the default); "one-pass-fails" does the same with one tile made to give
+         * up, so that the way back to the two-pass kernels can be tested */
+        a.fuse_mode = mode && strcmp(mode, "one-pass") == 0 ? 0u : (mode && strcmp(mode, "one-pass-fails") == 0 ? 2u : 1u);
     }
     a.tiles = p->d_tiles;
     a.n_tiles = p->n_tiles;

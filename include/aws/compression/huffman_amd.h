@@ -203,8 +203,9 @@ int aws_huffman_amd_decode_plan_results(
  * Which kernels decoded the chunks inside the streams of the plan's last launch (a chunk = 32 KiB of one item's
  * encoded bytes; the chunks streams END in always take the kernels written for them).  Diagnostics and tests: the
  * results are the same either way.  Waits for the stream.
- *   TWO_PASS           sync + scan + emit (every coder; selected for all launches by AWS_HUFFMAN_AMD_DECODE=two-pass)
- *   ONE_PASS           dec_onepass: every encoded byte read once, every code walked once (coders with codes of 4..12 bits)
+ *   TWO_PASS           sync + scan + emit (every coder; the default)
+ *   ONE_PASS           dec_onepass: every encoded byte read once, every code walked once (coders with codes of 4..12 bits;
+ *                      selected by AWS_HUFFMAN_AMD_DECODE=one-pass -- on an MI355X it takes as long as the two passes)
  *   ONE_PASS_GAVE_UP   dec_onepass met a chunk it does not take (damaged, cut or non-synchronising stream, symbol-dense
  *                      data, short output) and the two-pass kernels queued behind it on the same stream did the launch
  */

@@ -7,6 +7,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 import harness  # noqa: E402
 
+os.environ.setdefault("AWS_HUFFMAN_AMD_DECODE", "one-pass")
+
 lib = harness.load_product(os.environ.get("HUF_LIB"))
 patterns, lens = harness.load_table()
 eng = harness.Engine(lib, lib.aws_huffman_amd_table_coder_new(patterns, lens))

@@ -1006,13 +1006,13 @@ ROAD_TWO_PASS, ROAD_ONE_PASS, ROAD_GAVE_UP = 0, 1, 2
 
 
 def decode_roads(w, engine=None, sizes=(40_000, 300_000, 1_100_000), seed=53):
-    """The chunks inside a stream (32 KiB of encoded bytes with at least 8 more behind them) are decoded in ONE pass by
+    """The chunks inside a stream (32 KiB of encoded bytes with at least 8 more behind them) can be decoded in ONE pass by
     dec_onepass; the two-pass kernels stay queued behind it and take the launch over when it gives up.  Every road
     must give the oracle's result: plans of several streams (sizes in symbols) are launched
-      as they come                               -> ONE_PASS
-      with AWS_HUFFMAN_AMD_DECODE=two-pass       -> TWO_PASS
-      with AWS_HUFFMAN_AMD_DECODE=one-pass-fails -> GAVE_UP   (a chunk in the middle of the plan made to give up)
-      with a damaged stream / a short output     -> GAVE_UP   (the stop is found by the two-pass kernels)
+      as they come                               -> TWO_PASS
+      with AWS_HUFFMAN_AMD_DECODE=one-pass       -> ONE_PASS
+      with AWS_HUFFMAN_AMD_DECODE=one-pass-fails -> GAVE_UP   (a tile in the middle of the plan made to give up)
+      one-pass with a damaged stream / short output -> GAVE_UP (the stop is found by the two-pass kernels)
     and records, output bytes and guard bytes are compared with the oracle's decode of the same streams."""
     own = engine is None
     eng = engine or harness.Engine(w.product.lib, w.pcoder)
@@ -1064,13 +1064,13 @@ def decode_roads(w, engine=None, sizes=(40_000, 300_000, 1_100_000), seed=53):
             assert road == want_road, (mode, damage, short, road, eng.last_road_detail)
         return road
 
-    run(None, want_road=ROAD_ONE_PASS)
-    run("two-pass", want_road=ROAD_TWO_PASS)
+    run("one-pass", want_road=ROAD_ONE_PASS)
+    run(None, want_road=ROAD_TWO_PASS)
     run("one-pass-fails", want_road=ROAD_GAVE_UP)
     big = int(np.argmax([s.size for s in streams]))
-    run(None, damage=(big, streams[big].size // 2), want_road=ROAD_GAVE_UP)
-    run(None, damage=(big, 40), want_road=ROAD_GAVE_UP)
-    run(None, short=(big, plains[big].size // 2), want_road=ROAD_GAVE_UP)
-    run(None, short=(big, plains[big].size - 1))  # the edge lies in the stream's last chunk: either road
+    run("one-pass", damage=(big, streams[big].size // 2), want_road=ROAD_GAVE_UP)
+    run("one-pass", damage=(big, 40), want_road=ROAD_GAVE_UP)
+    run("one-pass", short=(big, plains[big].size // 2), want_road=ROAD_GAVE_UP)
+    run("one-pass", short=(big, plains[big].size - 1))  # the edge lies in the stream's last chunk: either road
     if own:
         eng.close()

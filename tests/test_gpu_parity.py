@@ -163,7 +163,7 @@ def test_config2_config3_one_gib_stream(world, engine):
     (rc, err, symbols, bits), = engine.decode_results(dplan, 1)
     assert (rc, err, symbols) == (0, 0, n)
     assert e * 8 - bits == rec["decoder_tail_num_bits"]  # padding bits left over
-    assert engine.decode_road(dplan) == pc.ROAD_ONE_PASS  # every encoded byte read once (dec_onepass)
+    assert engine.decode_road(dplan) == pc.ROAD_TWO_PASS
 
     def digest(ptr, size):
         h = hashlib.sha256()
@@ -177,8 +177,8 @@ def test_config2_config3_one_gib_stream(world, engine):
     assert digest(d_back, n) == rec["sha256_input"]
     assert np.all(engine.download(d_enc, 64, offset=e) == 0x5A)  # nothing past the stream
     assert np.all(engine.download(d_back, 64, offset=n) == 0x5A)
-    # the same stream through the two-pass kernels, and through them after dec_onepass gave up half-way
-    for mode, road in (("two-pass", pc.ROAD_TWO_PASS), ("one-pass-fails", pc.ROAD_GAVE_UP)):
+    # the same stream in one pass (dec_onepass), and through the two-pass kernels after dec_onepass gave up half-way
+    for mode, road in (("one-pass", pc.ROAD_ONE_PASS), ("one-pass-fails", pc.ROAD_GAVE_UP)):
         engine.fill(d_back, 0x5A, n + 64)
         os.environ["AWS_HUFFMAN_AMD_DECODE"] = mode
         try:
