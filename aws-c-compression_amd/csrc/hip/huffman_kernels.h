@@ -38,6 +38,7 @@ struct hufk_encode_args {
     uint8_t *seg_unk_seen;   /* [n_segs] scratch */
     uint64_t *item_total;    /* [n_items] scratch */
     uint32_t single_pass;    /* 1: one kernel reads the symbols once (enc_onepass) instead of count / scan / pack */
+    uint32_t fail_tile;      /* 1: a wave of enc_onepass is made to give up (AWS_HUFFMAN_AMD_ENCODE=one-pass-fails: the way back, for tests) */
     struct hufd_enc_item_state *states; /* [n_items] scratch */
     struct hufd_enc_result *results;    /* [n_items] */
     void **stage_events; /* NULL, or 4 hipEvent_t: before count, after count, after scan, after pack */

@@ -330,7 +330,11 @@ __global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_count_kernel(
     u32 *wave_bits, /* [seg][4]: bits of each quarter of the segment (wave w of enc_pack_wave packs quarter w) */
     u32 *seg_unk,
     u32 *careful_count,
-    u32 n_segs) {
+    u32 n_segs,
+    const u32 *gate /* NULL, or the word enc_onepass raises when a look-back wait ran out: this kernel runs only then */) {
+    if (gate && gate[0] == 0) {
+        return;
+    }
 
     u32 *tab = reinterpret_cast<u32 *>(dyn_lds); /* [256][32] */
     u32 *slots = tab + 256 * 32;                  /* [16] */
@@ -539,7 +543,11 @@ __global__ __launch_bounds__(256) void enc_scan_small_kernel(
     u32 *careful_list,
     u32 *careful_count,
     hufd_enc_item_state *states,
-    hufd_enc_result *results) {
+    hufd_enc_result *results,
+    const u32 *gate /* NULL, or the word enc_onepass raises when a look-back wait ran out: this kernel runs only then */) {
+    if (gate && gate[0] == 0) {
+        return;
+    }
 
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) {
@@ -929,7 +937,11 @@ __global__ __launch_bounds__(HUFD_SCAN_LARGE_THREADS) void enc_scan_large_kernel
     u32 *careful_count,
     hufd_enc_item_state *states,
     hufd_enc_result *results,
-    u32 all_coded /* every symbol has a code: seg_unk need not be read */) {
+    u32 all_coded /* every symbol has a code: seg_unk need not be read */,
+    const u32 *gate /* NULL, or the word enc_onepass raises when a look-back wait ran out: this kernel runs only then */) {
+    if (gate && gate[0] == 0) {
+        return;
+    }
 
     constexpr u32 T = HUFD_SCAN_LARGE_THREADS, W = T / kWave, U = 16; /* U independent loads a lane and trip */
     u64 *wave_tot = reinterpret_cast<u64 *>(dyn_lds);      /* [W] */
@@ -1251,7 +1263,11 @@ __global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_pack_kernel(
     u32 img_words,
     u32 n_segs,
     const u32 *list,
-    const u32 *list_count) {
+    const u32 *list_count,
+    const u32 *gate /* NULL, or the word enc_onepass raises when a look-back wait ran out: this kernel runs only then */) {
+    if (gate && gate[0] == 0) {
+        return;
+    }
 
     u32 *img = reinterpret_cast<u32 *>(dyn_lds);
     u64 *tab = reinterpret_cast<u64 *>(dyn_lds + round16(img_words * 4));
@@ -1410,7 +1426,11 @@ __global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_pack_stream_kernel(
     u8 *d_out,
     hufd_enc_result *results,
     u32 img_words,
-    u32 n_segs) {
+    u32 n_segs,
+    const u32 *gate /* NULL, or the word enc_onepass raises when a look-back wait ran out: this kernel runs only then */) {
+    if (gate && gate[0] == 0) {
+        return;
+    }
 
     constexpr u32 kInBytes = HUFD_ENC_SEG_BYTES + 16; /* a segment + the chunk holding the next one's head */
     u32 *img = reinterpret_cast<u32 *>(dyn_lds);
@@ -1707,7 +1727,11 @@ __global__ __launch_bounds__(kPackThreads) void enc_pack_wave_kernel(
     u32 region_bytes,
     u32 n_segs,
     u32 *careful_list,   /* segments this kernel leaves to enc_pack_kernel are added */
-    u32 *careful_count) {
+    u32 *careful_count,
+    const u32 *gate /* NULL, or the word enc_onepass raises when a look-back wait ran out: this kernel runs only then */) {
+    if (gate && gate[0] == 0) {
+        return;
+    }
 
     u32 *tab = reinterpret_cast<u32 *>(dyn_lds); /* [256][32] */
     const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -1981,7 +2005,7 @@ constexpr u64 kOpArrive = 1ull << 40; /* group_acc: arrivals above, sum of bits 
 constexpr u64 kOpSum = kOpArrive - 1;
 constexpr u64 kOpReady = 1ull << 63;  /* round_base / item_base */
 constexpr u32 kOpTileReady = 1u << 31; /* tile_agg */
-constexpr u32 kOpSpinLimit = 1u << 20;
+constexpr u32 kOpSpinLimit = 1u << 13; /* polls (each a trip to memory and a sleep): milliseconds */
 constexpr u32 kOpGroupStride = HUFD_OP_GROUP_STRIDE; /* u64 words from one group's counter to the next: a memory line each (the adds are done at the memory side, a line at a time) */
 
 __device__ __forceinline__ void granule_store(u64 *p, u64 v) {
@@ -2149,7 +2173,8 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
     u64 *item_base,    /* [n_items] zeroed */
     u64 *__restrict__ item_total,
     hufd_enc_result *__restrict__ results, /* the tile with the capacity edge leaves a note for enc_finish_kernel here */
-    const u8 *__restrict__ null_tile /* kTileBytes readable bytes: what a wave "prefetches" when no tile follows */) {
+    const u8 *__restrict__ null_tile /* kTileBytes readable bytes: what a wave "prefetches" when no tile follows */,
+    u32 fail_tile /* a tile whose wave is to give up (tests of the way back); HUFD_NONE32: none */) {
 
     HUFD_STAMP_DECL
     HUFD_STAMP_ZERO;
@@ -2220,7 +2245,7 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
                 if (__all((b >> 40) == kOpGroupTiles)) {
                     break;
                 }
-                if (++spins > kOpSpinLimit) {
+                if (++spins > kOpSpinLimit || uniform32(word_load_now(&ctl[1])) != 0) {
                     if (lane == 0) {
                         ctl[1] = 1; /* (the waves that wait for this base give up in their turn) */
                     }
@@ -2322,8 +2347,8 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         const u32 since = old.t - old.item_first_tile; /* tiles of my item in front of me */
         const bool near = since <= p;
         u64 ib = (old.first_tile || near) ? kOpReady : (seg.item == base_item ? base_value : ib_raw);
-        bool gave_up = false;
-        for (u32 spins = 0;; ++spins) {
+        bool gave_up = old.t == fail_tile;
+        for (u32 spins = 0; !gave_up; ++spins) {
             const bool there = (a & kOpTileReady) != 0 && (b >> 40) == kOpGroupTiles && (rb & kOpReady) != 0 &&
                                (ib & kOpReady) != 0;
             if (spins == 0) {
@@ -2343,8 +2368,8 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
                 HUFD_STAMP_COUNT(6, spins);
                 break;
             }
-            if (spins > kOpSpinLimit) {
-                gave_up = true;
+            if (spins > kOpSpinLimit || uniform32(word_load_now(&ctl[1])) != 0) {
+                gave_up = true; /* (or somebody else has: the launch is redone anyway) */
                 break;
             }
             __builtin_amdgcn_s_sleep(8); /* a poll is traffic for everybody: rarely needed, then not in a tight loop */
@@ -2363,7 +2388,7 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         }
         if (gave_up) {
             if (lane == 0) {
-                ctl[1] = 1; /* the host layer redoes the launch without waits between workgroups */
+                ctl[1] = 1; /* the kernels of the three-kernel road, queued behind this one, see it and do the launch over */
             }
             return false;
         }
@@ -2683,8 +2708,13 @@ __global__ __launch_bounds__(256) void enc_finish_kernel(
     u32 *careful_list,
     u32 *careful_count,
     hufd_enc_item_state *states,
-    hufd_enc_result *results) {
+    hufd_enc_result *results,
+    const u32 *gave_up /* the word enc_onepass raises when a look-back wait ran out: totals and notes are not whole then, and
+                        * the three-kernel road behind this kernel does the launch over, records included */) {
 
+    if (gave_up[0] != 0) {
+        return;
+    }
     u64 *note_first = reinterpret_cast<u64 *>(dyn_lds), *note_bit = note_first + 256; /* kFinishLdsBytes */
     u32 *code_len = reinterpret_cast<u32 *>(note_bit + 256), *noted = code_len + 256, *note_syms = noted + 256;
     u32 &n_noted = note_syms[256];
@@ -3432,15 +3462,43 @@ template <u32 LB>
 __device__ __forceinline__ u64 union_row_fast(u64 heads, u32 hi, u32 lo, const u16 *hops) {
     const u64 pair = ((u64)hi << 32) | lo;
     u32 here = (u32)heads, next = (u32)(heads >> 32); /* heads in this row / already in the next one */
+    /* the two lowest heads a trip: two look-ups that do not wait for each other (a head that the first sends onto the
+     * second, or in between the two, is simply taken again on a later trip: the heads are a set) */
     while (here) {
-        const u32 j = (u32)__builtin_ctz(here);
-        const u32 off = (u32)(pair >> (63u - LB - j)) & (((1u << LB) - 1u) << 1); /* byte offset into the u16 table */
-        const u64 sent = (u64)*reinterpret_cast<const u16 *>(reinterpret_cast<const u8 *>(hops) + off) << j;
+        const u32 j0 = (u32)__builtin_ctz(here);
         here &= here - 1;
+        const bool two = here != 0;
+        const u32 j1 = two ? (u32)__builtin_ctz(here) : j0;
+        here &= here - 1;
+        const u32 off0 = (u32)(pair >> (63u - LB - j0)) & (((1u << LB) - 1u) << 1); /* byte offset into the u16 table */
+        const u32 off1 = (u32)(pair >> (63u - LB - j1)) & (((1u << LB) - 1u) << 1);
+        const u64 sent0 = (u64)*reinterpret_cast<const u16 *>(reinterpret_cast<const u8 *>(hops) + off0) << j0;
+        const u64 sent1 = (u64)*reinterpret_cast<const u16 *>(reinterpret_cast<const u8 *>(hops) + off1) << j1;
+        const u64 sent = sent0 | (two ? sent1 : 0ull);
         here |= (u32)sent; /* no code: nothing is sent on, the walk is gone */
         next |= (u32)(sent >> 32);
     }
     return next;
+}
+
+/*
+ * Phase U's first row.  The ns entry states are ns look-ups that do not wait for each other (the general loop takes a
+ * head at a time, lowest first, because a head may send another into the same row): their windows lie in the row's own
+ * word, where they land is an OR.  What lands on an entry state is followed already; the general loop goes on with the
+ * rest of the row.
+ */
+template <u32 LB>
+__device__ __forceinline__ u64 union_first_row(u32 ns, bool active, u32 hi, u32 lo, const u16 *hops) {
+    u32 landed = 0;
+#pragma unroll
+    for (u32 j = 0; j < HUFD_DEC_MAX_LUT_BITS; ++j) {
+        if (j < ns) {
+            const u32 off = (hi >> (31u - LB - j)) & (((1u << LB) - 1u) << 1); /* byte offset into the u16 table */
+            landed |= (u32)*reinterpret_cast<const u16 *>(reinterpret_cast<const u8 *>(hops) + off) << j;
+        }
+    }
+    const u64 heads = active ? landed & ~((1u << ns) - 1u) : 0u;
+    return union_row_fast<LB>(heads, hi, lo, hops);
 }
 
 /*
@@ -3864,7 +3922,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
 #pragma unroll
     for (u32 r = 0; r < kFastMaxMeet; ++r) {
         if (!settled) {
-            heads = union_row_fast<LB>(heads, w[r], w[r + 1], sh.hops);
+            heads = r == 0 ? union_first_row<LB>(ns, active, w[0], w[1], sh.hops) : union_row_fast<LB>(heads, w[r], w[r + 1], sh.hops);
             one = heads != 0 && (heads & (heads - 1)) == 0;
             meet_row = r + 1;
             settled = __all(one || heads == 0);
@@ -5259,26 +5317,6 @@ __device__ __forceinline__ u32 wave_read(u32 v, u32 lane_same_everywhere) {
 #else
     return __shfl(v, lane_same_everywhere);
 #endif
-}
-
-/*
- * Phase U's first row.  The ns entry states are ns look-ups that do not wait for each other (the general loop takes a
- * head at a time, lowest first, because a head may send another into the same row): their windows lie in the row's own
- * word, where they land is an OR.  What lands on an entry state is followed already; the general loop goes on with the
- * rest of the row.
- */
-template <u32 LB>
-__device__ __forceinline__ u64 union_first_row(u32 ns, bool active, u32 hi, u32 lo, const u16 *hops) {
-    u32 landed = 0;
-#pragma unroll
-    for (u32 j = 0; j < HUFD_DEC_MAX_LUT_BITS; ++j) {
-        if (j < ns) {
-            const u32 off = (hi >> (31u - LB - j)) & (((1u << LB) - 1u) << 1); /* byte offset into the u16 table */
-            landed |= (u32)*reinterpret_cast<const u16 *>(reinterpret_cast<const u8 *>(hops) + off) << j;
-        }
-    }
-    const u64 heads = active ? landed & ~((1u << ns) - 1u) : 0u;
-    return union_row_fast<LB>(heads, hi, lo, hops);
 }
 
 /* layout of the block the kernel wants zeroed before every launch (all offsets multiples of 8) */
@@ -7071,6 +7109,10 @@ static void stage_mark(void **events, int index, hipStream_t st) {
     }
 }
 
+} /* extern "C" */
+static void encode_three_kernels(const struct hufk_encode_args *a, hipStream_t st, const u32 *gate);
+extern "C" {
+
 int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a->n_segs == 0 && a->n_items == 0) {
@@ -7090,7 +7132,8 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
         enc_onepass_kernel<NWV>, dim3(persistent_grid(enc_onepass_kernel<NWV>, kPackThreads, lds, work)),              \
         dim3(kPackThreads), lds, st, a->tables, a->items, a->segs, (const u8 *)a->d_in, (u8 *)a->d_out, region,        \
         a->n_segs, (u32 *)(z + l.ctl), (u32 *)(z + l.tile_agg), (u64 *)(z + l.group_acc),                              \
-        (u64 *)(z + l.round_base), (u64 *)(z + l.item_base), a->item_total, a->results, (const u8 *)(z + l.null_tile))
+        (u64 *)(z + l.round_base), (u64 *)(z + l.item_base), a->item_total, a->results, (const u8 *)(z + l.null_tile),  \
+        a->fail_tile ? a->n_segs * kTilesPerSeg / 2 : HUFD_NONE32)
         if (a->tables.max_bits <= 12) {
             HUFK_LAUNCH_ONEPASS(4);
         } else {
@@ -7100,7 +7143,8 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
         stage_mark(a->stage_events, 1, st);
         hipLaunchKernelGGL(
             enc_finish_kernel, dim3((a->n_items + kFinishItems - 1) / kFinishItems), dim3(256), kFinishLdsBytes, st, a->tables, a->items, a->n_items,
-            a->item_total, (const u8 *)a->d_in, a->careful_list, a->careful_count, a->states, a->results);
+            a->item_total, (const u8 *)a->d_in, a->careful_list, a->careful_count, a->states, a->results,
+            (const u32 *)(z + l.ctl) + 1);
         stage_mark(a->stage_events, 2, st);
         if (a->n_tiny) {
             hipLaunchKernelGGL(
@@ -7109,35 +7153,50 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
             a->length_only);
         }
         /* (nothing is left for the per-symbol packer: every segment was packed by a wave, the capacity edge found by one) */
+        /* The way back, on the same stream: the three-kernel road (no waits between workgroups) queued behind the one
+         * pass, every kernel of it looking first at the word a wave raises when a look-back wait runs out -- whoever
+         * works on the output behind this launch finds it whole either way, without the host in between. */
+        encode_three_kernels(a, st, (const u32 *)(z + l.ctl) + 1);
         stage_mark(a->stage_events, 3, st);
         return (int)hipGetLastError();
     }
     stage_mark(a->stage_events, 0, st);
+    encode_three_kernels(a, st, nullptr);
+    stage_mark(a->stage_events, 3, st);
+    return (int)hipGetLastError();
+}
+
+} /* extern "C" */
+
+/* count + scan + pack; `gate`: NULL, or the word that says whether the kernels are to run at all (stage events: the
+ * caller's, when it times them) */
+static void encode_three_kernels(const struct hufk_encode_args *a, hipStream_t st, const u32 *gate) {
+    void **events = gate ? nullptr : a->stage_events;
     if (a->n_segs) {
         const uint32_t grid = persistent_grid(enc_count_kernel, HUFD_ENC_THREADS, kCountLdsBytes, a->n_segs);
         hipLaunchKernelGGL(
             enc_count_kernel, dim3(grid), dim3(HUFD_ENC_THREADS), kCountLdsBytes, st, a->tables, a->segs,
-            (const u8 *)a->d_in, a->seg_bits, a->wave_bits, a->seg_unk, a->careful_count, a->n_segs);
-    } else {
+            (const u8 *)a->d_in, a->seg_bits, a->wave_bits, a->seg_unk, a->careful_count, a->n_segs, gate);
+    } else if (!gate) {
         (void)hipMemsetAsync(a->careful_count, 0, sizeof(uint32_t), st);
     }
-    stage_mark(a->stage_events, 1, st);
+    stage_mark(events, 1, st);
     hipLaunchKernelGGL(
         enc_scan_small_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, a->seg_bits,
-        a->seg_unk, a->seg_bitoff, a->careful_list, a->careful_count, a->states, a->results);
+        a->seg_unk, a->seg_bitoff, a->careful_list, a->careful_count, a->states, a->results, gate);
     if (a->n_large) {
         hipLaunchKernelGGL(
             enc_scan_large_kernel, dim3(a->n_large), dim3(HUFD_SCAN_LARGE_THREADS), 256, st, a->items, a->large_items,
             a->seg_bits, a->seg_unk, a->seg_bitoff, a->careful_list, a->careful_count, a->states, a->results,
-            a->tables.all_coded);
+            a->tables.all_coded, gate);
     }
-    if (a->n_tiny) {
+    if (a->n_tiny && !gate) { /* (on the way back the short items are done: they wait for nobody) */
         hipLaunchKernelGGL(
             enc_tiny_kernel, dim3((a->n_tiny + kTinyThreads - 1) / kTinyThreads), dim3(kTinyThreads), 256 * sizeof(u64), st,
             a->tables, a->items, a->tiny_items, a->n_tiny, (const u8 *)a->d_in, (u8 *)a->d_out, a->results,
             a->length_only);
     }
-    stage_mark(a->stage_events, 2, st);
+    stage_mark(events, 2, st);
     if (a->n_segs && !a->length_only) {
         const uint32_t img_words = hufk_enc_image_words(a->tables.max_bits);
         if (a->tables.max_bits <= 15 && a->tables.min_bits >= 4) {
@@ -7149,19 +7208,19 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
                 hipLaunchKernelGGL(
                     enc_pack_wave_kernel<4>, dim3(grid), dim3(kPackThreads), lds, st, a->tables, a->items, a->states,
                     a->segs, a->seg_bits, a->wave_bits, a->seg_bitoff, (const u8 *)a->d_in, (u8 *)a->d_out, region,
-                    a->n_segs, a->careful_list, a->careful_count);
+                    a->n_segs, a->careful_list, a->careful_count, gate);
             } else {
                 const uint32_t grid = persistent_grid(enc_pack_wave_kernel<5>, kPackThreads, lds, (a->n_segs * kTilesPerSeg + kPackWaves - 1) / kPackWaves);
                 hipLaunchKernelGGL(
                     enc_pack_wave_kernel<5>, dim3(grid), dim3(kPackThreads), lds, st, a->tables, a->items, a->states,
                     a->segs, a->seg_bits, a->wave_bits, a->seg_bitoff, (const u8 *)a->d_in, (u8 *)a->d_out, region,
-                    a->n_segs, a->careful_list, a->careful_count);
+                    a->n_segs, a->careful_list, a->careful_count, gate);
             }
             const uint32_t most = a->n_segs < 1024 ? a->n_segs : 1024;
             hipLaunchKernelGGL(
                 enc_pack_kernel, dim3(most), dim3(HUFD_ENC_THREADS), enc_pack_lds_bytes(img_words), st, a->tables,
                 a->items, a->states, a->segs, a->seg_bits, a->seg_bitoff, (const u8 *)a->d_in, (u8 *)a->d_out,
-                a->results, img_words, a->n_segs, (const u32 *)a->careful_list, (const u32 *)a->careful_count);
+                a->results, img_words, a->n_segs, (const u32 *)a->careful_list, (const u32 *)a->careful_count, gate);
         } else if (a->tables.max_bits <= 16) {
             /* streaming packer for everything but the listed segments, then those */
             const uint32_t lds = enc_stream_lds_bytes(img_words);
@@ -7169,22 +7228,22 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
             hipLaunchKernelGGL(
                 enc_pack_stream_kernel, dim3(grid), dim3(HUFD_ENC_THREADS), lds, st, a->tables, a->items, a->states,
                 a->segs, a->seg_bits, a->seg_bitoff, (const u8 *)a->d_in, (u8 *)a->d_out, a->results, img_words,
-                a->n_segs);
+                a->n_segs, gate);
             const uint32_t most = 2 * a->n_items < 1024 ? 2 * a->n_items : 1024;
             hipLaunchKernelGGL(
                 enc_pack_kernel, dim3(most), dim3(HUFD_ENC_THREADS), enc_pack_lds_bytes(img_words), st, a->tables,
                 a->items, a->states, a->segs, a->seg_bits, a->seg_bitoff, (const u8 *)a->d_in, (u8 *)a->d_out,
-                a->results, img_words, a->n_segs, (const u32 *)a->careful_list, (const u32 *)a->careful_count);
+                a->results, img_words, a->n_segs, (const u32 *)a->careful_list, (const u32 *)a->careful_count, gate);
         } else {
             hipLaunchKernelGGL(
                 enc_pack_kernel, dim3(a->n_segs), dim3(HUFD_ENC_THREADS), enc_pack_lds_bytes(img_words), st, a->tables,
                 a->items, a->states, a->segs, a->seg_bits, a->seg_bitoff, (const u8 *)a->d_in, (u8 *)a->d_out,
-                a->results, img_words, a->n_segs, (const u32 *)nullptr, (const u32 *)nullptr);
+                a->results, img_words, a->n_segs, (const u32 *)nullptr, (const u32 *)nullptr, gate);
         }
     }
-    stage_mark(a->stage_events, 3, st);
-    return (int)hipGetLastError();
 }
+
+extern "C" {
 
 int hufk_encode_one_tiny(
     const struct hufd_tables *tables, const struct hufd_enc_item *item, const uint32_t *zero, const void *d_in, void *d_out,

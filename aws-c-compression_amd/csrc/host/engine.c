@@ -184,6 +184,9 @@ int aws_huffman_amd_engine_new(
         /* one pass over the input where the coder allows it (hufk_encode_one_pass_applies); "three-kernel"
          * forces count / scan / pack, the road every other coder takes */
         eng->single_pass = !(mode && strcmp(mode, "three-kernel") == 0);
+        /* "one-pass-fails": a wave of the one-pass kernel is made to give up, as if a look-back wait had run out: the
+         * three-kernel road queued behind it on the stream does the launch over (tests) */
+        eng->encode_fails = mode && strcmp(mode, "one-pass-fails") == 0;
     }
     eng->tables.max_bits = max_bits;
     eng->tables.min_bits = min_bits;
@@ -572,6 +575,7 @@ int aws_huffman_amd_encode_plan_launch_staged(
     a.seg_unk_seen = p->d_unk_seen;
     a.item_total = p->d_item_total;
     a.single_pass = p->engine->single_pass && !p->look_back_timed_out;
+    a.fail_tile = p->engine->encode_fails;
     p->last_input = device_input;
     p->last_output = device_output;
     p->last_single_pass = a.single_pass && p->n_segs && !length_only && hufk_encode_one_pass_applies(&p->engine->tables);
@@ -591,9 +595,11 @@ int aws_huffman_amd_encode_plan_raw_results(
     hufs_set_device(p->engine->device);
     int err = 0;
     /* The one-pass kernel's waves wait for each other's totals; every wait is bounded, and one that ran out raises a
-     * flag (and leaves the output undefined).  The flag comes back with the results, in the same synchronisation; if it
-     * is up, the launch is redone with the three-kernel path, which has no waits between workgroups, and the plan stays
-     * on it. */
+     * flag.  The kernels of the three-kernel road (no waits between workgroups) are queued behind it on the same
+     * stream and look at that flag first: the output and these records are whole when the stream gets here, whichever
+     * road made them.  The flag comes back with the results only so that the plan stays on the three-kernel road
+     * from then on (a wait that ran out once -- the grid was not resident as a whole: another kernel on the device --
+     * is likely to run out again, and costs milliseconds). */
     uint32_t timed_out = 0;
     if (p->last_single_pass) {
         err = hufs_copy_d2h(&timed_out, p->d_zero + sizeof(uint32_t), sizeof(timed_out), st);
@@ -604,17 +610,17 @@ int aws_huffman_amd_encode_plan_raw_results(
     if (!err) {
         err = hufs_stream_sync(st);
     }
-    if (!err && timed_out) {
+    if (!err && timed_out && !p->engine->encode_fails) {
         p->look_back_timed_out = true;
-        if (aws_huffman_amd_encode_plan_launch_staged(p, p->last_input, p->last_output, false, st, NULL)) {
-            return AWS_OP_ERR;
-        }
-        err = hufs_copy_d2h(raw, p->d_results, (size_t)p->n_items * sizeof(*raw), st);
-        if (!err) {
-            err = hufs_stream_sync(st);
-        }
     }
+    p->last_timed_out = !err && timed_out;
     return err ? raise_hip(err) : AWS_OP_SUCCESS;
+}
+
+int aws_huffman_amd_encode_plan_road(const struct aws_huffman_amd_encode_plan *p, uint32_t *road) {
+    *road = !p->last_single_pass ? AWS_HUFFMAN_AMD_ROAD_TWO_PASS
+                                 : (p->last_timed_out ? AWS_HUFFMAN_AMD_ROAD_ONE_PASS_GAVE_UP : AWS_HUFFMAN_AMD_ROAD_ONE_PASS);
+    return AWS_OP_SUCCESS;
 }
 
 int aws_huffman_amd_encode_plan_encoded_lengths(struct aws_huffman_amd_encode_plan *p, uint64_t *lengths, void *stream) {

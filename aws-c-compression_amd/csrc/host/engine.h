@@ -33,7 +33,8 @@ struct aws_huffman_amd_engine {
     void *d_enc_table;
     void *d_dec_lut;
     struct hufd_tables tables;
-    bool single_pass; /* AWS_HUFFMAN_AMD_ENCODE=single-pass: fused encode kernel (measured slower) */
+    bool single_pass; /* enc_onepass where the coder allows it (not with AWS_HUFFMAN_AMD_ENCODE=three-kernel) */
+    bool encode_fails; /* AWS_HUFFMAN_AMD_ENCODE=one-pass-fails: a wave of enc_onepass is made to give up (tests of the way back) */
 
     /* scratch of the host-pointer API: one item at a time, one caller at a time (`one_lock`); `users` keeps the
      * engine cache of huffman.c from retiring an engine somebody is inside of */
@@ -75,6 +76,7 @@ struct aws_huffman_amd_encode_plan {
     const void *last_input;
     void *last_output;
     bool last_single_pass;
+    bool last_timed_out; /* the last launch whose results were fetched was done over by the three-kernel road */
     bool look_back_timed_out;
 };
 

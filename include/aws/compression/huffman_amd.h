@@ -199,6 +199,9 @@ int aws_huffman_amd_decode_plan_results(
     struct aws_huffman_amd_decode_result *results,
     void *stream);
 
+#define AWS_HUFFMAN_AMD_ROAD_TWO_PASS 0u
+#define AWS_HUFFMAN_AMD_ROAD_ONE_PASS 1u
+#define AWS_HUFFMAN_AMD_ROAD_ONE_PASS_GAVE_UP 2u
 /*
  * Which kernels decoded the chunks inside the streams of the plan's last launch (a chunk = 32 KiB of one item's
  * encoded bytes; the chunks streams END in always take the kernels written for them).  Diagnostics and tests: the
@@ -209,9 +212,16 @@ int aws_huffman_amd_decode_plan_results(
  *   ONE_PASS_GAVE_UP   dec_onepass met a chunk it does not take (damaged, cut or non-synchronising stream, symbol-dense
  *                      data, short output) and the two-pass kernels queued behind it on the same stream did the launch
  */
-#define AWS_HUFFMAN_AMD_ROAD_TWO_PASS 0u
-#define AWS_HUFFMAN_AMD_ROAD_ONE_PASS 1u
-#define AWS_HUFFMAN_AMD_ROAD_ONE_PASS_GAVE_UP 2u
+/* The same question for the encoder, of the plan's last launch whose results were fetched (no wait of its own):
+ *   TWO_PASS           here: count + scan + pack, the three-kernel road (every coder; AWS_HUFFMAN_AMD_ENCODE=three-kernel)
+ *   ONE_PASS           enc_onepass: every symbol read once (coders with codes of 4..15 bits for all 256 symbols; the default)
+ *   ONE_PASS_GAVE_UP   a look-back wait of enc_onepass ran out (the grid was not resident as a whole) and the three-kernel
+ *                      kernels queued behind it on the same stream did the launch over; the plan stays on that road
+ * Output and records are whole when the stream reaches the end of the launch, whichever road made them: work queued on
+ * the stream behind a launch may use them without the host in between. */
+AWS_COMPRESSION_API
+int aws_huffman_amd_encode_plan_road(const struct aws_huffman_amd_encode_plan *plan, uint32_t *road);
+
 AWS_COMPRESSION_API
 int aws_huffman_amd_decode_plan_road(
     struct aws_huffman_amd_decode_plan *plan,

@@ -175,7 +175,7 @@ EXPORTED_SYMBOLS = [
     "aws_huffman_amd_encode_plan_launch", "aws_huffman_amd_encode_plan_launch_staged",
     "aws_huffman_amd_encode_plan_results", "aws_huffman_amd_decode_plan_new", "aws_huffman_amd_decode_plan_destroy",
     "aws_huffman_amd_decode_plan_launch", "aws_huffman_amd_decode_plan_launch_staged",
-    "aws_huffman_amd_decode_plan_results", "aws_huffman_amd_decode_plan_road",
+    "aws_huffman_amd_decode_plan_results", "aws_huffman_amd_decode_plan_road", "aws_huffman_amd_encode_plan_road",
     "aws_huffman_amd_device_count", "aws_huffman_amd_device_alloc", "aws_huffman_amd_device_free",
     "aws_huffman_amd_copy_to_device", "aws_huffman_amd_copy_to_host", "aws_huffman_amd_device_fill",
     "aws_huffman_amd_device_fill_splitmix64", "aws_huffman_amd_engine_stream", "aws_huffman_amd_stream_synchronize",
@@ -232,6 +232,7 @@ def load_product(path=None):
     _bind(lib, "aws_huffman_amd_decode_plan_launch", C.c_int, [V, V, V, V])
     _bind(lib, "aws_huffman_amd_decode_plan_results", C.c_int, [V, P(AmdDecodeResult), V])
     _bind(lib, "aws_huffman_amd_decode_plan_road", C.c_int, [V, V, P(C.c_uint32), P(C.c_uint32)])
+    _bind(lib, "aws_huffman_amd_encode_plan_road", C.c_int, [V, P(C.c_uint32)])
     _bind(lib, "aws_huffman_amd_device_count", C.c_int, [])
     _bind(lib, "aws_huffman_amd_device_alloc", V, [V, C.c_size_t])
     _bind(lib, "aws_huffman_amd_device_free", None, [V, V])
@@ -327,6 +328,12 @@ class Engine:
         assert self.lib.aws_huffman_amd_encode_plan_results(plan, res, None) == 0
         return [(r.rc, r.error, r.consumed, r.produced, r.overflow_out.num_bits,
                  r.overflow_out.pattern if r.overflow_out.num_bits else 0) for r in res[:n]]
+
+    def encode_road(self, plan):
+        """Of the last launch whose results were fetched.  0: count / scan / pack, 1: one pass, 2: one pass gave up, done over."""
+        road = C.c_uint32(99)
+        assert self.lib.aws_huffman_amd_encode_plan_road(plan, C.byref(road)) == 0
+        return road.value
 
     def encoded_lengths(self, plan, n):
         out = (C.c_uint64 * max(n, 1))()

@@ -1074,3 +1074,56 @@ def decode_roads(w, engine=None, sizes=(40_000, 300_000, 1_100_000), seed=53):
     run("one-pass", short=(big, plains[big].size - 1))  # the edge lies in the stream's last chunk: either road
     if own:
         eng.close()
+
+
+# ----------------------------------------------------------------------------- scenario: which kernels encode
+def encode_roads(w, sizes=(200_000, 16384, 40_000, 3_000_000), seed=57):
+    """The one-pass encoder (enc_onepass) waits between workgroups, with bounds; when a wait runs out the three-kernel
+    road, queued behind it on the same stream, does the launch over.  Every road must give the oracle's bytes and
+    records: one plan of several streams (one with a short output: SHORT_BUFFER with the reference's consumed /
+    overflow) through engines made
+      as they come                                  -> ONE_PASS
+      with AWS_HUFFMAN_AMD_ENCODE=three-kernel      -> TWO_PASS (count / scan / pack)
+      with AWS_HUFFMAN_AMD_ENCODE=one-pass-fails    -> GAVE_UP  (a wave in the middle of the plan made to give up)
+    and the output is read straight after the launch, before the records are fetched: it must be whole by then."""
+    rng = np.random.default_rng(seed)
+    plains = [inputs(rng, n, "uniform") for n in sizes]
+    wants = [oracle_encode(w, p) for p in plains]
+    caps = [e.size + 9 for e in wants]
+    caps[1] = wants[1].size // 2  # a short output
+    in_offs = np.cumsum([0] + [p.size + 3 for p in plains])
+    out_offs = np.cumsum([0] + [c + 16 for c in caps])
+    blob = np.concatenate([np.concatenate([p, np.zeros(3, np.uint8)]) for p in plains])
+    for mode, want_road in ((None, ROAD_ONE_PASS), ("three-kernel", ROAD_TWO_PASS), ("one-pass-fails", ROAD_GAVE_UP)):
+        if mode:
+            os.environ["AWS_HUFFMAN_AMD_ENCODE"] = mode
+        try:
+            coder = w.product.lib.aws_huffman_amd_table_coder_new(*w.table)  # a fresh coder: a fresh engine that reads the switch
+            eng = harness.Engine(w.product.lib, coder)
+        finally:
+            if mode:
+                del os.environ["AWS_HUFFMAN_AMD_ENCODE"]
+        d_in, d_out = eng.alloc(blob.size + 64), eng.alloc(int(out_offs[-1]) + 64)
+        eng.upload(d_in, blob)
+        eng.fill(d_out, SENTINEL, int(out_offs[-1]) + 64)
+        items = [dict(in_offset=int(in_offs[i]), in_len=int(plains[i].size), out_offset=int(out_offs[i]),
+                      out_capacity=int(caps[i])) for i in range(len(plains))]
+        plan = eng.encode_plan(items)
+        eng.encode_launch(plan, d_in, d_out)
+        got = eng.download(d_out, int(out_offs[-1]) + 64)  # (behind the launch on the stream, before any record is read)
+        res = eng.encode_results(plan, len(items))
+        assert eng.encode_road(plan) == want_road, (mode, eng.encode_road(plan))
+        for i, e in enumerate(wants):
+            enc = w.oracle.new_encoder(w.ocoder)
+            ref_out = np.full(caps[i] + 16, SENTINEL, np.uint8)
+            r = w.oracle.encode_call(enc, plains[i], 0, ref_out, 0, caps[i])
+            rc, err, consumed, produced, ob, op = res[i]
+            assert (rc, err, consumed, produced) == (r.rc, r.err, r.consumed, r.produced), (mode, i, res[i], r)
+            assert (ob, op if ob else 0) == r.state, (mode, i, res[i], r)
+            mine = got[out_offs[i]:out_offs[i] + caps[i] + 16]
+            assert np.array_equal(mine, ref_out), (mode, i, int(np.flatnonzero(mine != ref_out)[0]))
+        eng.lib.aws_huffman_amd_encode_plan_destroy(plan)
+        eng.free(d_in)
+        eng.free(d_out)
+        eng.close()
+        w.product.lib.aws_huffman_amd_table_coder_destroy(coder)

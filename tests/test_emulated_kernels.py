@@ -110,6 +110,11 @@ def test_cut_streams(world):
     pc.cut_streams(world, chunks=(1,), step=23, n=40_000)
 
 
+def test_encode_roads(world):
+    """enc_onepass, the three-kernel road when told so, and the three-kernel road behind a one-pass launch that gave up."""
+    pc.encode_roads(world, sizes=(70_000, 16384, 40_000, 300_000))
+
+
 def test_decode_roads(world):
     """dec_onepass for the chunks inside streams, the two-pass kernels when told so or when it gives up."""
     pc.decode_roads(world, sizes=(40_000, 90_000, 160_000))

@@ -256,16 +256,18 @@ def test_config4_batch_of_16k_buffers(world, engine):
         engine.free(p)
 
 
-def test_single_pass_encoder(oracle):
-    """The fused count + look-back + pack kernel (AWS_HUFFMAN_AMD_ENCODE=single-pass) on the GPU,
-    where its workgroups really wait for each other's look-back granules."""
-    os.environ["AWS_HUFFMAN_AMD_ENCODE"] = "single-pass"
+def test_three_kernel_encoder(oracle):
+    """The count / scan / pack road (AWS_HUFFMAN_AMD_ENCODE=three-kernel) on the GPU: what every coder outside the
+    one-pass kernel's range takes, and what is queued behind every one-pass launch in case a look-back wait runs out.
+    Same scenarios as the default road, and the 1 GiB stream's digest."""
+    os.environ["AWS_HUFFMAN_AMD_ENCODE"] = "three-kernel"
     try:
         w = pc.World(oracle, harness.Codec(harness.load_product(), "aws_"))
         pc.one_shot_roundtrips(w, sizes=[1, 17, 16384, 16385, 40000, 3 * 1024 * 1024 + 5])
         pc.streaming_encode(w, sizes=[40, 33000])
         pc.unknown_symbols(w)
         eng = harness.Engine(w.product.lib, w.pcoder)
+        assert not eng.lib.aws_huffman_amd_engine_encodes_in_one_pass(eng.h)
         pc.batched_device_api(w, n_items=40, engine=eng)
         rec = PROBE["streams"]["G1G"]
         n, e = rec["len"], rec["encoded_len"]
@@ -275,6 +277,7 @@ def test_single_pass_encoder(oracle):
         eng.encode_launch(plan, d_in, d_enc)
         (rc, err, consumed, produced, ob, op), = eng.encode_results(plan, 1)
         assert (rc, consumed, produced) == (0, n, e)
+        assert eng.encode_road(plan) == pc.ROAD_TWO_PASS
         h = hashlib.sha256()
         for off in range(0, e, 256 << 20):
             h.update(eng.download(d_enc, min(256 << 20, e - off), offset=off).tobytes())
@@ -282,3 +285,49 @@ def test_single_pass_encoder(oracle):
         eng.close()
     finally:
         del os.environ["AWS_HUFFMAN_AMD_ENCODE"]
+
+
+def test_encode_roads(world):
+    """enc_onepass; count / scan / pack when told so; and count / scan / pack queued behind an enc_onepass launch in
+    which a wave gave up (a look-back wait that ran out is what it stands for): the output is read on the stream right
+    behind the launch, before any record is fetched, and must be whole."""
+    pc.encode_roads(world)
+    pc.encode_roads(world, sizes=(33_000_000, 16384, 5_000_000, 70_000), seed=58)
+
+
+def test_one_gib_stream_when_the_one_pass_encoder_gives_up(oracle):
+    """The 1 GiB stream with a wave of enc_onepass made to give up half-way: the three-kernel road behind it on the
+    stream must leave the pinned stream."""
+    os.environ["AWS_HUFFMAN_AMD_ENCODE"] = "one-pass-fails"
+    try:
+        w = pc.World(oracle, harness.Codec(harness.load_product(), "aws_"))
+        eng = harness.Engine(w.product.lib, w.pcoder)
+    finally:
+        del os.environ["AWS_HUFFMAN_AMD_ENCODE"]
+    rec = PROBE["streams"]["G1G"]
+    n, e = rec["len"], rec["encoded_len"]
+    d_in, d_enc = eng.alloc(n), eng.alloc(e + 64)
+    eng.fill_splitmix64(d_in, n, rec["seed"])
+    eng.fill(d_enc, 0x5A, e + 64)
+    plan = eng.encode_plan([dict(in_offset=0, in_len=n, out_offset=0, out_capacity=e + 64)])
+    eng.encode_launch(plan, d_in, d_enc)
+    h = hashlib.sha256()  # (the stream, read behind the launch, before the records)
+    for off in range(0, e, 256 << 20):
+        h.update(eng.download(d_enc, min(256 << 20, e - off), offset=off).tobytes())
+    (rc, err, consumed, produced, ob, op), = eng.encode_results(plan, 1)
+    assert (rc, consumed, produced) == (0, n, e) and eng.encode_road(plan) == pc.ROAD_GAVE_UP
+    assert h.hexdigest() == rec["sha256_encoded"]
+    assert np.all(eng.download(d_enc, 64, offset=e) == 0x5A)
+    eng.close()
+
+
+def test_decode_with_the_first_sync_kernel(world, engine):
+    """AWS_HUFFMAN_AMD_DECODE=old-sync: dec_sync_fast for every chunk instead of dec_sync_lean (kept for coders and
+    comparisons; the end-of-stream chunks of other launches take it where dec_sync_lean has no build)."""
+    os.environ["AWS_HUFFMAN_AMD_DECODE"] = "old-sync"
+    try:
+        pc.one_shot_roundtrips(world, sizes=[40000, 200001, 3 * 1024 * 1024 + 5])
+        pc.cut_streams(world, chunks=(1, 2), step=31)
+        pc.garbage_decode(world)
+    finally:
+        del os.environ["AWS_HUFFMAN_AMD_DECODE"]
