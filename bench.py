@@ -58,6 +58,8 @@ def parse_args():
     ap.add_argument("--buffer-bytes", type=int, default=16384, help="cfg4: bytes per buffer")
     ap.add_argument("--cpu-sample-mib", type=int, default=96, help="prefix of the stream timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="stream, one GPU: leave out the short cfg4 and host-abi legs that ride along as extra keys")
     ap.add_argument("--library", default=None,
                     help="shared library to load instead of the HIP build (tests/test_multi_rank.py passes the "
                          "CPU emulator build to exercise the rank logic where there is no GPU)")
@@ -164,6 +166,11 @@ def cpu_baseline(sample_bytes, seed, batch_seconds=8.0, buffer_bytes=16384):
         "unit": "GiB/s",
         "cores": 1,
         "kind": "port",
+        "calibration": "none against the real reference: source/huffman.c needs aws-c-common's headers, which this image "
+                       "lacks (stand-ins are not allowed for a reference build), so oracle/_ref holds only the "
+                       "reference's generator tool.  The port (oracle/huffman_oracle.c) restates source/huffman.c line "
+                       "by line -- one callback per symbol, one byte store per output byte -- and is pinned to the "
+                       "reference's own vectors (tests/test_oracle_pins.py)",
         "sample": "first %d MiB of the same splitmix64 stream, encode %.2f s + decode %.2f s, C oracle -O2 "
                   "(scalar per-symbol callbacks like reference source/huffman.c), one core: the reference is "
                   "single-threaded per stream" % (sample_bytes >> 20, t_enc, t_dec),
@@ -218,6 +225,10 @@ def roofline_of(label, kernels, algo_bytes, ms, traffic_table):
     if traffic_table and all(k in traffic_table for k in kernels):
         parts = [traffic_table[k].get("hbm_bytes_per_launch") for k in kernels]
         traffic = sum(parts) if all(p is not None for p in parts) else None
+    elif traffic_table and any(k in traffic_table for k in kernels):
+        # (a stage without an entry of its own moves nothing worth a counter pass: a few result records)
+        parts = [traffic_table[k].get("hbm_bytes_per_launch") for k in kernels if k in traffic_table]
+        traffic = sum(parts) if all(p is not None for p in parts) else None
     return {
         "path": label,
         "kernels": kernels,
@@ -256,6 +267,8 @@ def rooflines(out, names_e, names_d, kernel_ms, t_enc_ms, t_dec_ms, n, e_len, al
     dec = roofline_of("decode", names_d, n + e_len, t_dec_ms, traffic)
     out["roofline_encode"], out["roofline_decode"] = enc, dec
     out["roofline"] = dec if t_dec_ms >= t_enc_ms else enc
+    out["traffic_source"] = (traffic or {}).get("_source", "profiles/pmc_traffic.json: HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, "
+                                                "separate rocprofv3 --pmc passes of this command, committed profile), not this run")
     dominant = max(kernel_ms, key=lambda k: kernel_ms[k])
     out["roofline_kernel"] = roofline_of(dominant, [dominant], algo_per_kernel[dominant], kernel_ms[dominant], traffic)
     out["encode_read_frac_of_hbm_peak"] = round(n / max(t_enc_ms * 1e-3, 1e-12) / HBM_PEAK_BYTES_PER_S, 4)
@@ -307,12 +320,23 @@ def run_stream(args, ranks, lib, eng):
     ranks.barrier()
     wall = ranks.max(time.perf_counter() - t0)
 
+    # what the TIMED steps left behind: both record sets, both digests, the roads taken (untimed)
+    (rc, err, consumed, e_after, _, _), = eng.encode_results(enc_plan, 1)
+    (rc2, err2, symbols, _), = eng.decode_results(dec_plan, 1)
+    bit_exact = ((rc, consumed, e_after) == (0, n, e_len) and (rc2, symbols) == (0, n) and
+                 digest_of(eng, d_enc, e_len) == enc_digest and digest_of(eng, d_back, n) == in_digest)
+    assert bit_exact, "the timed steps did not leave the pinned stream and its round trip"
+    roads = {0: "two-pass", 1: "one-pass", 2: "one-pass gave up, two-pass did the launch over"}
+
     kernel_ms, t_enc_ms, t_dec_ms = stages.medians()
     out = {
         "config": {
             "workload": "1 GiB splitmix64 bytes per GPU (seed 5+rank), test_huffman_static_table coder: "
                         "encode (BASELINE configs[1]) then decode back (configs[2]), HBM-resident",
-            "stream_bytes": n, "encoded_bytes": e_len, "bit_exact": True, "sha256_encoded": enc_digest,
+            "stream_bytes": n, "encoded_bytes": e_len, "bit_exact": bit_exact, "sha256_encoded": enc_digest,
+            "bit_exact_checked": "records and sha256 of the encoded stream and of the decoded bytes after the last timed step",
+            "encode_road": roads[eng.encode_road(enc_plan)].replace("two-pass", "three-kernel"),
+            "decode_road": roads[eng.decode_road(dec_plan)],
         },
         "scaling": "weak",
     }
@@ -393,13 +417,16 @@ def run_cfg4(args, ranks, lib, eng):
     eng.sync()
     ranks.barrier()
     wall = ranks.max(time.perf_counter() - t0)
+    dres = eng.decode_results(dplan, count)
+    bit_exact = all(r[0] == 0 and r[2] == size for r in dres) and digest_of(eng, d_back, count * size) == digest_of(eng, d_in, count * size)
+    assert bit_exact, "the timed steps did not leave the batch's round trip"
     kernel_ms, t_enc_ms, t_dec_ms = stages.medians()
     out = {
         "config": {
             "workload": "BASELINE configs[3]: %d buffers x %d B (buffer i = splitmix64 seed 2+i, rank r takes i = r mod N), "
                         "every fourth one capacity-limited (SHORT_BUFFER record, then a resume call), all decoded back, "
                         "HBM-resident" % (count_all, size),
-            "buffers": count_all, "buffer_bytes": size, "bit_exact": True,
+            "buffers": count_all, "buffer_bytes": size, "bit_exact": bit_exact,
         },
         "scaling": "strong",
     }
@@ -417,7 +444,7 @@ def run_host_abi(args, ranks, lib, eng, coder):
 
     import harness
 
-    n = args.bytes if args.bytes != GIB else 256 << 20
+    n = min(args.bytes, 256 << 20) if args.workload == "stream" else (args.bytes if args.bytes != GIB else 256 << 20)
     seed = 5 + ranks.rank
     codec = harness.Codec(lib, "aws_")
     data = harness.splitmix64_bytes(seed, n)
@@ -469,10 +496,10 @@ def run_host_abi(args, ranks, lib, eng, coder):
 
 def main():
     args = parse_args()
-    ranks = Ranks(args.gpus)
-    import harness  # the HIP library is loaded before anything else can pull in another HIP runtime
+    import harness  # the HIP library is loaded before anything else (torch, in Ranks) can pull in another HIP runtime
 
     lib = harness.load_product(args.library)
+    ranks = Ranks(args.gpus)
     if lib.aws_huffman_amd_device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible and the product has no CPU path")
     patterns, lens = harness.load_table()
@@ -517,6 +544,26 @@ def main():
         "ranks": ranks.gather(per_rank),
         "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
     })
+    if args.workload == "stream" and ranks.world == 1 and not args.no_extra_legs:
+        # BASELINE configs[3] and the reference's own entry points on host memory ride along as extra keys (short legs,
+        # never `value`): what the driver's default run would otherwise never measure
+        def leg(fn, *more):
+            o, ln, le, w, kms, te, td, _, _ = fn(*more)
+            return {"workload": o["config"]["workload"], "bit_exact": o["config"]["bit_exact"], "steps": more[0].steps,
+                    "value_GiBps": round(ln / GIB / max((te + td) * 1e-3, 1e-12), 2),
+                    "encode_ms": round(te, 4), "decode_ms": round(td, 4),
+                    "encode_path_frac_of_hbm_peak": round((ln + le) / max(te * 1e-3, 1e-12) / HBM_PEAK_BYTES_PER_S, 4),
+                    "decode_path_frac_of_hbm_peak": round((ln + le) / max(td * 1e-3, 1e-12) / HBM_PEAK_BYTES_PER_S, 4),
+                    "kernel_ms": {k: round(v, 4) for k, v in kms.items()}, "roofline": o.get("roofline")}
+        short = argparse.Namespace(**vars(args))
+        short.steps, short.warmup = 5, 2
+        try:
+            line["cfg4"] = leg(run_cfg4, short, ranks, lib, eng)
+            short.steps, short.warmup = 3, 1  # (one 256 MiB buffer, or the stream's size when that was given and is smaller)
+            line["host_abi"] = leg(run_host_abi, short, ranks, lib, eng, coder)
+            line["host_abi"].pop("encode_path_frac_of_hbm_peak"), line["host_abi"].pop("decode_path_frac_of_hbm_peak")
+        except MemoryError as exc:  # (a host without room for the legs: the headline line stands)
+            line["extra_legs_error"] = repr(exc)
     if ranks.rank == 0 and ranks.world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_mib << 20, n), seed)
     else:

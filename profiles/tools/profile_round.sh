@@ -21,7 +21,7 @@ tail -c 600 "$OUT/bench.json"
 timeout 600 python3 bench.py --workload cfg4 --no-cpu-baseline > "$OUT/bench_cfg4.json" 2> "$OUT/bench_cfg4.err"
 timeout 600 python3 bench.py --workload host-abi --no-cpu-baseline > "$OUT/bench_host_abi.json" 2> "$OUT/bench_host_abi.err"
 tail -c 300 "$OUT/bench_cfg4.json"; tail -c 300 "$OUT/bench_host_abi.json"
-BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $BENCH > "$OUT/stats.json" 2> "$OUT/stats.err"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o run -- $BENCH > /dev/null 2> "$OUT/pmc_fetch.err"

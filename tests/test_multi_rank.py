@@ -116,7 +116,14 @@ def test_two_ranks_split_the_batch(emulator, oracle):
 
 
 def test_single_rank_line(emulator, oracle):
-    out = run_bench(emulator, 1)
+    """The default line of one GPU: the stream, verified after the timed steps, with BASELINE configs[3] and the
+    reference's entry points on host memory riding along as extra keys (here with a small batch)."""
+    out = run_bench(emulator, 1, extra=("--buffers", "12", "--buffer-bytes", "16384"))
     check_line(out, 1)
     e_len, digest = expected_stream(oracle, 0)
     assert (out["config"]["encoded_bytes"], out["config"]["sha256_encoded"]) == (e_len, digest)
+    assert out["config"]["bit_exact"] is True and "after the last timed step" in out["config"]["bit_exact_checked"]
+    assert out["config"]["encode_road"] in ("one-pass", "three-kernel") and out["config"]["decode_road"] == "two-pass"
+    for leg in ("cfg4", "host_abi"):
+        assert out[leg]["bit_exact"] is True and "value_GiBps" in out[leg] and "encode_ms" in out[leg], leg  # (the emulator has no clock for events)
+    assert "configs[3]" in out["cfg4"]["workload"] and "HOST memory" in out["host_abi"]["workload"]
