@@ -94,7 +94,17 @@ static int deep_table_build(struct aws_huffman_amd_engine *eng, struct aws_huffm
         return aws_raise_error(AWS_ERROR_OOM);
     }
     deep_table_fill(&b, 0, 0, 0, HUFD_DEEP_ROOT_BITS);
-    for (int sym = 0; sym < 256 && b.ok; ++sym) {
+    /* the longest and the shortest code the decoder knows (an encoder may know fewer, or none) */
+    for (uint32_t i = 0; i < b.used && b.ok; ++i) {
+        const uint32_t e = b.tab[i];
+        if (!(e & HUFD_DEEP_LINK) && (e & 0xFFu)) {
+            const uint32_t len = e & 0xFFu;
+            eng->tables.max_bits = len > eng->tables.max_bits ? len : eng->tables.max_bits;
+            eng->tables.min_bits = len < eng->tables.min_bits ? len : eng->tables.min_bits;
+        }
+    }
+    eng->tables.n_states = eng->tables.max_bits > 8 ? eng->tables.max_bits : 8;
+    for (int sym = 0; sym < 256 && b.ok && coder->encode; ++sym) {
         const uint32_t len = (uint32_t)(eng->enc_table[sym] >> 32);
         if (len) {
             const uint32_t code = (uint32_t)eng->enc_table[sym] << (32 - len);
@@ -120,7 +130,9 @@ int aws_huffman_amd_engine_new(
     int device) {
 
     *out_engine = NULL;
-    if (!coder || !coder->encode) {
+    /* (a coder may lack one of its two callbacks: the reference's encoder only ever calls `encode`, its decoder only
+     * `decode` -- source/huffman.c:60,235 -- and an engine is then good for that half) */
+    if (!coder || (!coder->encode && !coder->decode)) {
         return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
     }
     if (hufs_device_count() <= 0) {
@@ -156,7 +168,8 @@ int aws_huffman_amd_engine_new(
 
     /* encode table: one callback per symbol (reference huffman.h:37) */
     uint32_t max_bits = 0, min_bits = 33;
-    for (int sym = 0; sym < 256; ++sym) {
+    eng->can_encode = coder->encode != NULL;
+    for (int sym = 0; sym < 256 && coder->encode; ++sym) {
         const struct aws_huffman_code code = coder->encode((uint8_t)sym, coder->userdata);
         if (code.num_bits > 32) {
             free(eng);
@@ -169,9 +182,6 @@ int aws_huffman_amd_engine_new(
             max_bits = code.num_bits > max_bits ? code.num_bits : max_bits;
             min_bits = code.num_bits < min_bits ? code.num_bits : min_bits;
         }
-    }
-    if (max_bits == 0) {
-        min_bits = 1;
     }
     eng->tables.all_coded = 1;
     for (int sym = 0; sym < 256; ++sym) {
@@ -188,47 +198,90 @@ int aws_huffman_amd_engine_new(
          * three-kernel road queued behind it on the stream does the launch over (tests) */
         eng->encode_fails = mode && strcmp(mode, "one-pass-fails") == 0;
     }
-    eng->tables.max_bits = max_bits;
-    eng->tables.min_bits = min_bits;
-    eng->tables.n_states = max_bits > 8 ? max_bits : 8;
-
-    /* decode table: the callback answers from the first max_bits bits of its window when it is
-     * the inverse of the encode table; probe every such window with zero fill and with one
-     * fill (reference huffman.h:48) and keep the table only if the fill never matters */
+    /* decode tables from the DECODE callback alone (the reference's decoder knows nothing else: source/huffman.c:235-238;
+     * reference huffman.h:48).  Every window of HUFD_DEC_MAX_LUT_BITS bits is asked twice, the bits behind it all zero
+     * and all one: the same answer both times, no longer than the window, for every window = a coder whose codes have at
+     * most that many bits, and its table (exhaustive: nothing is inferred).  Otherwise codes are longer: the linked
+     * tables (deep_table_build), checked against the encode table where there is one. */
     eng->can_decode = false;
-    if (coder->decode && max_bits >= 1 && max_bits <= HUFD_DEC_MAX_LUT_BITS) {
-        const uint32_t windows = 1u << max_bits;
-        const uint32_t fill = (1u << (32 - max_bits)) - 1u;
-        uint16_t *lut = malloc(windows * sizeof(uint16_t));
-        if (!lut) {
+    uint32_t dec_max = 0, dec_min = 33;
+    if (coder->decode) {
+        const uint32_t wide = HUFD_DEC_MAX_LUT_BITS, windows = 1u << wide;
+        const uint32_t fill = (1u << (32 - wide)) - 1u;
+        uint16_t *probe = malloc(windows * sizeof(uint16_t));
+        if (!probe) {
             free(eng);
             return aws_raise_error(AWS_ERROR_OOM);
         }
         bool tabular = true;
         for (uint32_t w = 0; w < windows && tabular; ++w) {
             uint8_t s0 = 0, s1 = 0;
-            const uint32_t bits = w << (32 - max_bits);
+            const uint32_t bits = w << (32 - wide);
             const uint8_t n0 = coder->decode(bits, &s0, coder->userdata);
             const uint8_t n1 = coder->decode(bits | fill, &s1, coder->userdata);
-            if (n0 != n1 || n0 > max_bits || (n0 && s0 != s1)) {
+            if (n0 != n1 || n0 > wide || (n0 && s0 != s1)) {
                 tabular = false;
             }
-            lut[w] = n0 ? (uint16_t)(((uint16_t)s0 << 8) | n0) : 0;
+            probe[w] = n0 ? (uint16_t)(((uint16_t)s0 << 8) | n0) : 0;
+            if (n0) {
+                dec_max = n0 > dec_max ? n0 : dec_max;
+                dec_min = n0 < dec_min ? n0 : dec_min;
+            }
         }
-        if (tabular) {
+        /* (a code of n bits must own all windows that start with it: a callback that answers from more bits than it
+         * says is not a prefix code's) */
+        for (uint32_t w = 0; w < windows && tabular; ++w) {
+            const uint32_t n = probe[w] & 0xFFu;
+            if (n && n < wide) {
+                const uint32_t first = w >> (wide - n) << (wide - n);
+                tabular = probe[first] == probe[w] && probe[first + (1u << (wide - n)) - 1u] == probe[w];
+            }
+        }
+        if (tabular && dec_max >= 1) {
+            uint16_t *lut = malloc(((size_t)1 << dec_max) * sizeof(uint16_t));
+            if (!lut) {
+                free(probe);
+                free(eng);
+                return aws_raise_error(AWS_ERROR_OOM);
+            }
+            for (uint32_t w = 0; w < (1u << dec_max); ++w) {
+                lut[w] = probe[w << (wide - dec_max)];
+            }
             eng->dec_lut_host = lut;
-            eng->tables.lut_bits = max_bits;
+            eng->tables.lut_bits = dec_max;
             eng->can_decode = true;
-        } else {
-            free(lut);
+        } else if (tabular) {
+            dec_min = 33; /* a decoder without a single code: every stream stops at its first window, as the reference's would */
+            uint16_t *lut = calloc(2, sizeof(uint16_t));
+            if (!lut) {
+                free(probe);
+                free(eng);
+                return aws_raise_error(AWS_ERROR_OOM);
+            }
+            eng->dec_lut_host = lut;
+            eng->tables.lut_bits = 1;
+            eng->can_decode = true;
         }
+        free(probe);
     }
+    /* one set of code-length bounds for both halves: what sizes images, stages and entry states must hold for the longest
+     * and the shortest code either callback knows */
+    if (eng->can_decode && dec_max) {
+        max_bits = dec_max > max_bits ? dec_max : max_bits;
+        min_bits = dec_min < min_bits ? dec_min : min_bits;
+    }
+    eng->tables.max_bits = max_bits;
+    eng->tables.min_bits = min_bits; /* (33: no code known yet) */
+    eng->tables.n_states = max_bits > 8 ? max_bits : 8;
 
-    if (!eng->can_decode && coder->decode && max_bits > HUFD_DEC_MAX_LUT_BITS) {
+    if (!eng->can_decode && coder->decode) {
         if (deep_table_build(eng, coder)) {
             free(eng);
             return AWS_OP_ERR;
         }
+    }
+    if (eng->tables.min_bits > 32) {
+        eng->tables.min_bits = 1;
     }
 
     int err = hufs_stream_create(&eng->stream);
@@ -382,6 +435,9 @@ static int enc_plan_fill(
     size_t n_items) {
 
     struct aws_huffman_amd_engine *eng = p->engine;
+    if (!eng->can_encode) {
+        return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION); /* a coder without an encode callback: good for decoding only */
+    }
     const uint64_t tiny_limit = enc_tiny_limit(eng, items, n_items);
     uint64_t n_segs = 0, n_large = 0, n_tiny = 0;
     for (size_t i = 0; i < n_items; ++i) {

@@ -28,6 +28,7 @@ struct aws_huffman_amd_engine {
     uint16_t *dec_lut_host;
     uint32_t *deep_lut_host; /* codes longer than HUFD_DEC_MAX_LUT_BITS */
     void *d_deep_lut;
+    bool can_encode; /* the coder has an encode callback */
     bool can_decode;
 
     void *d_enc_table;

@@ -37,7 +37,18 @@ static unsigned s_clock;
 static pthread_mutex_t s_engine_lock = PTHREAD_MUTEX_INITIALIZER;
 
 uint64_t aws_huffman_amd_coder_fingerprint(struct aws_huffman_symbol_coder *coder) {
-    uint64_t h = 0xCBF29CE484222325ull; /* FNV-1a over (pattern masked to its length, length) of every symbol */
+    uint64_t h = 0xCBF29CE484222325ull; /* FNV-1a over (pattern masked to its length, length) of every symbol ... */
+    if (coder->decode) {
+        /* ... and over what the decode callback makes of 128 windows spread over the 32-bit range (a coder may have only
+         * this callback, and two coders may share an encode table and differ here) */
+        for (uint32_t k = 0; k < 128; ++k) {
+            uint8_t sym = 0;
+            const uint32_t window = k * 0x02040811u + (k << 25);
+            const uint8_t n = coder->decode(window, &sym, coder->userdata);
+            h = (h ^ (uint64_t)(n ? sym : 0)) * 0x100000001B3ull;
+            h = (h ^ n) * 0x100000001B3ull;
+        }
+    }
     if (!coder->encode) {
         return h;
     }
@@ -264,6 +275,18 @@ int aws_huffman_encode(
 
 /* ------------------------------------------------------------------ decode */
 
+static int decode_piece(struct aws_huffman_decoder *decoder, struct aws_byte_cursor *to_decode, struct aws_byte_buf *output);
+
+/* A device item holds less than 4 GiB of encoded bytes (32-bit chunk arithmetic); the reference's length is a size_t
+ * (source/huffman.c:228).  A longer input is taken in pieces, each a call of its own with the decoder's window carried
+ * from one to the next -- exactly what a caller who streams the input in pieces gets from the reference, ending at
+ * the first piece that does not run to its end (error, or no room left). */
+static size_t s_decode_piece_bytes = (size_t)1 << 31;
+
+void aws_huffman_amd_testing_set_decode_piece_bytes(size_t bytes) {
+    s_decode_piece_bytes = bytes ? bytes : (size_t)1 << 31;
+}
+
 int aws_huffman_decode(
     struct aws_huffman_decoder *decoder,
     struct aws_byte_cursor *to_decode,
@@ -273,7 +296,29 @@ int aws_huffman_decode(
     AWS_ASSERT(decoder->coder);
     AWS_ASSERT(to_decode);
     AWS_ASSERT(output);
+    while (to_decode->len > s_decode_piece_bytes) {
+        struct aws_byte_cursor piece = {s_decode_piece_bytes, to_decode->ptr};
+        const int rc = decode_piece(decoder, &piece, output);
+        const size_t taken = s_decode_piece_bytes - piece.len;
+        to_decode->ptr += taken;
+        to_decode->len -= taken;
+        if (rc != AWS_OP_SUCCESS || piece.len != 0) {
+            /* stopped inside the piece: the reference would have topped its window up from ALL the input left before
+             * the symbol it stopped at (source/huffman.c:196-211), not only from what the piece still held */
+            const int error = rc ? aws_last_error() : 0;
+            while (decoder->num_bits < 32 && to_decode->len > 0) {
+                decoder->working_bits |= (uint64_t)*to_decode->ptr << (56 - decoder->num_bits);
+                decoder->num_bits = (uint8_t)(decoder->num_bits + 8);
+                ++to_decode->ptr;
+                --to_decode->len;
+            }
+            return rc ? aws_raise_error(error) : rc;
+        }
+    }
+    return decode_piece(decoder, to_decode, output);
+}
 
+static int decode_piece(struct aws_huffman_decoder *decoder, struct aws_byte_cursor *to_decode, struct aws_byte_buf *output) {
     const uint32_t held = decoder->num_bits;                 /* read-ahead bits from earlier calls */
     const uint64_t stream_bits = held + (uint64_t)to_decode->len * 8; /* huffman.c:228 */
 
@@ -318,6 +363,7 @@ int aws_huffman_decode(
 
     /* storage for the symbols */
     uint64_t to_store = res.produced;
+    int reserve_error = 0; /* != 0: growing failed; the call ends as the reference's would at that symbol */
     if (grow && to_store > room) {
         /* double until it fits, exactly as the per-symbol loop would have (huffman.c:260-264) */
         while (output->capacity - output->len < to_store) {
@@ -332,8 +378,18 @@ int aws_huffman_decode(
             const int rc = aws_byte_buf_reserve_relative(output, before);
             output->len = keep_len;
             if (rc) {
-                engine_release(eng);
-                return AWS_OP_ERR;
+                /* The reference meets the failed reserve with the buffer full (len == capacity, huffman.c:257-264): the
+                 * symbols before it are stored, the decoder has moved past them, the call returns the reserve's error.
+                 * The same here: the stream once more, with room for exactly what fits -- where that symbol count ends
+                 * is what the state below is made from.  (A failure path: the second decode is not a cost anyone times.) */
+                reserve_error = aws_last_error();
+                if (aws_huffman_amd_engine_decode_host(
+                        eng, carry, carry_bytes, first_bit, to_decode->ptr, to_decode->len, before - keep_len, &res)) {
+                    engine_release(eng);
+                    return AWS_OP_ERR;
+                }
+                to_store = res.produced;
+                break;
             }
         }
     }
@@ -389,5 +445,8 @@ int aws_huffman_decode(
     to_decode->ptr += pulled;
     to_decode->len -= pulled;
 
+    if (reserve_error) {
+        return aws_raise_error(reserve_error);
+    }
     return res.rc == AWS_OP_SUCCESS ? AWS_OP_SUCCESS : aws_raise_error(res.error);
 }

@@ -230,6 +230,14 @@ int aws_huffman_amd_decode_plan_road(
     uint32_t *detail /* NULL, or two words of diagnostics: [0] (ONE_PASS_GAVE_UP) tile << 8 | reason code of one of the tiles
                       * that gave up, [1] sub-chunks whose entry state was guessed wrong and that were walked a second time */);
 
+/*
+ * aws_huffman_decode takes an input of any length (the reference's is a size_t, source/huffman.c:228); a device item holds
+ * less than 4 GiB of encoded bytes, so a longer input is taken in pieces of 2 GiB inside the call, the decoder's window
+ * carried from piece to piece -- what a caller who streams the input gets.  Tests make the pieces small:
+ */
+AWS_COMPRESSION_API
+void aws_huffman_amd_testing_set_decode_piece_bytes(size_t bytes /* 0: back to 2 GiB */);
+
 /* ---- several GPUs: independent items sharded over the devices of one node ---- */
 
 /*

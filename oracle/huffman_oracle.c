@@ -591,3 +591,42 @@ uint64_t oracle_batch_round_trips(
     free(t);
     return bad ? 0 : total;
 }
+
+/* ------------------------------------------------------------------ test helper: a coder made of two
+ *
+ * encode answers from one coder, decode from another (reference huffman.h:53-57 allows any pair of callbacks): what
+ * tests/parity_cases.py::one_sided_coders uses for "a decoder that knows more codes than the encoder". */
+struct oracle_split_coder {
+    struct aws_huffman_symbol_coder vtable;
+    struct aws_huffman_symbol_coder *enc, *dec;
+};
+
+static struct aws_huffman_code split_encode(uint8_t symbol, void *userdata) {
+    struct oracle_split_coder *sc = userdata;
+    return sc->enc->encode(symbol, sc->enc->userdata);
+}
+
+static uint8_t split_decode(uint32_t bits, uint8_t *symbol, void *userdata) {
+    struct oracle_split_coder *sc = userdata;
+    return sc->dec->decode(bits, symbol, sc->dec->userdata);
+}
+
+struct aws_huffman_symbol_coder *oracle_split_coder_new(
+    struct aws_huffman_symbol_coder *encode_from,
+    struct aws_huffman_symbol_coder *decode_from) {
+    struct oracle_split_coder *sc = calloc(1, sizeof(*sc));
+    if (!sc) {
+        return NULL;
+    }
+    sc->enc = encode_from;
+    sc->dec = decode_from;
+    sc->vtable.encode = encode_from ? split_encode : NULL;
+    sc->vtable.decode = decode_from ? split_decode : NULL;
+    sc->vtable.userdata = sc;
+    return &sc->vtable;
+}
+
+void oracle_split_coder_destroy(struct aws_huffman_symbol_coder *coder) {
+    free(coder); /* (the vtable is the object's first member) */
+}
+

@@ -72,6 +72,13 @@ int oracle_huffman_decode(
 struct aws_huffman_symbol_coder *oracle_table_coder_new(const uint32_t patterns[256], const uint8_t num_bits[256]);
 void oracle_table_coder_destroy(struct aws_huffman_symbol_coder *coder);
 
+/* a coder whose encode answers come from one coder and whose decode answers from another (either may be NULL: a coder
+ * with one callback); the two must outlive it */
+struct aws_huffman_symbol_coder *oracle_split_coder_new(
+    struct aws_huffman_symbol_coder *encode_from,
+    struct aws_huffman_symbol_coder *decode_from);
+void oracle_split_coder_destroy(struct aws_huffman_symbol_coder *coder);
+
 /* restates reference source/huffman_testing.c:15-73 and :75-173 (0 = pass) */
 int oracle_huffman_test_transitive(
     struct aws_huffman_symbol_coder *coder,

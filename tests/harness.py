@@ -176,6 +176,7 @@ EXPORTED_SYMBOLS = [
     "aws_huffman_amd_encode_plan_results", "aws_huffman_amd_decode_plan_new", "aws_huffman_amd_decode_plan_destroy",
     "aws_huffman_amd_decode_plan_launch", "aws_huffman_amd_decode_plan_launch_staged",
     "aws_huffman_amd_decode_plan_results", "aws_huffman_amd_decode_plan_road", "aws_huffman_amd_encode_plan_road",
+    "aws_huffman_amd_testing_set_decode_piece_bytes",
     "aws_huffman_amd_device_count", "aws_huffman_amd_device_alloc", "aws_huffman_amd_device_free",
     "aws_huffman_amd_copy_to_device", "aws_huffman_amd_copy_to_host", "aws_huffman_amd_device_fill",
     "aws_huffman_amd_device_fill_splitmix64", "aws_huffman_amd_engine_stream", "aws_huffman_amd_stream_synchronize",
@@ -233,6 +234,7 @@ def load_product(path=None):
     _bind(lib, "aws_huffman_amd_decode_plan_results", C.c_int, [V, P(AmdDecodeResult), V])
     _bind(lib, "aws_huffman_amd_decode_plan_road", C.c_int, [V, V, P(C.c_uint32), P(C.c_uint32)])
     _bind(lib, "aws_huffman_amd_encode_plan_road", C.c_int, [V, P(C.c_uint32)])
+    _bind(lib, "aws_huffman_amd_testing_set_decode_piece_bytes", None, [C.c_size_t])
     _bind(lib, "aws_huffman_amd_device_count", C.c_int, [])
     _bind(lib, "aws_huffman_amd_device_alloc", V, [V, C.c_size_t])
     _bind(lib, "aws_huffman_amd_device_free", None, [V, V])

@@ -1127,3 +1127,111 @@ def encode_roads(w, sizes=(200_000, 16384, 40_000, 3_000_000), seed=57):
         eng.free(d_out)
         eng.close()
         w.product.lib.aws_huffman_amd_table_coder_destroy(coder)
+
+
+# ----------------------------------------------------------------------------- scenario: a coder with one callback, or whose two disagree in range
+def one_sided_coders(w, n=50_000, seed=63):
+    """The reference's decoder only ever calls `decode` (source/huffman.c:235-238), its encoder only `encode` (:60):
+    a coder object may lack the other callback, and the decoder may know more codes than the encoder uses.
+      * decode-only: the test coder's decode callback alone (encode = NULL) decodes the oracle's streams, in one call
+        and in pieces, and stops like the oracle on damaged ones;
+      * encode-only: the encode callback alone encodes the oracle's stream;
+      * a decoder that knows more: encode from the test coder WITH HOLES (symbols 7 and 200 have no code), decode
+        from the full test coder -- streams that contain 7 and 200 still decode (the decode tables, the shortest code
+        and the number of entry states come from the decode callback, not from the encode table)."""
+    rng = np.random.default_rng(seed)
+    data = inputs(rng, n, "uniform")
+    want = oracle_encode(w, data)
+    split = w.oracle.lib.oracle_split_coder_new
+    split.restype, split.argtypes = C.POINTER(harness.SymbolCoder), [C.POINTER(harness.SymbolCoder)] * 2
+    dec_only, enc_only = split(None, w.ocoder), split(w.ocoder, None)
+    mixed = split(w.ocoder_holes, w.ocoder)
+    assert dec_only and enc_only and mixed and not dec_only.contents.encode and not enc_only.contents.decode
+    # decode-only
+    r, back = w.product.decode_all(dec_only, want, n)
+    assert r.rc == 0 and r.produced == n and np.array_equal(back, data)
+    ddo, ddp = w.oracle.new_decoder(w.ocoder), w.product.new_decoder(dec_only)
+    oo, op = np.full(n + 8, SENTINEL, np.uint8), np.full(n + 8, SENTINEL, np.uint8)
+    pos_o = pos_p = 0
+    for lo in range(0, want.size, 7001):  # in pieces: carried window bits
+        hi = min(lo + 7001, want.size)
+        ro = w.oracle.decode_call(ddo, want, lo, hi, oo, pos_o, n)
+        rp = w.product.decode_call(ddp, want, lo, hi, op, pos_p, n)
+        assert rp.key() == ro.key(), (lo, rp, ro)
+        pos_o += ro.produced
+        pos_p += rp.produced
+    assert np.array_equal(oo, op)
+    bad = want.copy()
+    bad[bad.size // 3: bad.size // 3 + 5] = 0xFF
+    ro, _ = w.oracle.decode_all(w.ocoder, bad, n)
+    rp, _ = w.product.decode_all(dec_only, bad, n)
+    assert rp.key()[:4] == ro.key()[:4], (rp, ro)
+    enc = w.product.new_encoder(dec_only)
+    dst = np.zeros(64, np.uint8)
+    r = w.product.encode_call(enc, data[:10].copy(), 0, dst, 0, 64)
+    assert r.rc != 0  # nothing to encode with
+    # encode-only
+    got = w.product.encode_all(enc_only, data)
+    assert np.array_equal(got, want)
+    # the decoder knows more than the encoder
+    few = data.copy()
+    few[(few == 7) | (few == 200)] = 9
+    assert np.array_equal(w.product.encode_all(mixed, few), oracle_encode(w, few))
+    r, back = w.product.decode_all(mixed, want, n)  # (a stream with 7s and 200s in it)
+    assert r.rc == 0 and np.array_equal(back, data)
+    for c in (dec_only, enc_only, mixed):
+        w.oracle.lib.oracle_split_coder_destroy(c)
+
+
+# ----------------------------------------------------------------------------- scenario: growth that fails
+def failed_growth(w, seed=67):
+    """allow_growth with a buffer that cannot grow (no allocator: aws_byte_buf_reserve_relative fails): the reference
+    meets the failed reserve with the buffer full -- the symbols before it are stored, the decoder has moved past
+    them, the call returns the reserve's error (source/huffman.c:257-264,275).  Same observable state, then a second
+    call into a fresh buffer finishes the stream."""
+    rng = np.random.default_rng(seed)
+    for n, cap in ((100, 16), (5000, 64), (40000, 1000), (40000, 0)):
+        data = inputs(rng, n, "uniform")
+        enc = oracle_encode(w, data)
+        outs = []
+        for codec, coder in ((w.oracle, w.ocoder), (w.product, w.pcoder)):
+            d = codec.new_decoder(coder)
+            codec.decoder_allow_growth(d, True)
+            dst = np.full(n + 8, SENTINEL, np.uint8)
+            buf = harness.ByteBuf(0, dst.ctypes.data, cap, None)  # capacity `cap`, nothing to grow with
+            cur = harness.ByteCursor(enc.size, enc.ctypes.data)
+            codec.reset_error()
+            rc = codec._decode(C.byref(d), C.byref(cur), C.byref(buf))
+            err = codec.last_error() if rc else 0
+            first = (rc, err, enc.size - cur.len, buf.len, buf.capacity, d.num_bits, d.working_bits, bytes(dst))
+            # the rest of the stream into a buffer that is large enough
+            rest = np.full(n + 8, SENTINEL, np.uint8)
+            codec.decoder_allow_growth(d, False)
+            r = codec.decode_call(d, enc, enc.size - cur.len, enc.size, rest, 0, n)
+            outs.append((first, r.key(), bytes(rest)))
+        assert outs[0] == outs[1], (n, cap, outs[0][0][:7], outs[1][0][:7], outs[0][1], outs[1][1])
+        if cap:
+            assert outs[0][0][0] != 0 and outs[0][0][3] == cap  # (the oracle itself: an error, the buffer full)
+            assert outs[0][0][7][:cap] + outs[0][2][:n - cap] == bytes(data)
+
+
+# ----------------------------------------------------------------------------- scenario: inputs longer than a device item
+def long_inputs_in_pieces(w, n=60_000, seed=71):
+    """aws_huffman_decode of an input longer than a device item takes (4 GiB) splits it inside the call (2 GiB
+    pieces, the window carried over).  With the pieces made small the same call must still match the oracle's ONE
+    call: whole streams, a damaged stream (the error and where it is raised), a short output, arbitrary bytes."""
+    rng = np.random.default_rng(seed)
+    data = inputs(rng, n, "uniform")
+    good = oracle_encode(w, data)
+    bad = good.copy()
+    bad[good.size // 2: good.size // 2 + 6] = 0xFF
+    noise = rng.integers(0, 256, 20_000).astype(np.uint8)
+    try:
+        for piece in (4099, 1000, 131, 9):
+            w.product.lib.aws_huffman_amd_testing_set_decode_piece_bytes(piece)
+            for stream, cap in ((good, n), (good, n // 2), (bad, n), (noise, n), (good[:good.size - 3], n)):
+                oo, op = np.full(n + 8, SENTINEL, np.uint8), np.full(n + 8, SENTINEL, np.uint8)
+                ddo, ddp = w.oracle.new_decoder(w.ocoder), w.product.new_decoder(w.pcoder)
+                paired_decode(w, ddo, ddp, stream, 0, stream.size, oo, op, 0, cap)
+    finally:
+        w.product.lib.aws_huffman_amd_testing_set_decode_piece_bytes(0)

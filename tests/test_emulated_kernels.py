@@ -115,6 +115,18 @@ def test_encode_roads(world):
     pc.encode_roads(world, sizes=(70_000, 16384, 40_000, 300_000))
 
 
+def test_one_sided_coders(world):
+    pc.one_sided_coders(world, n=50_000)
+
+
+def test_failed_growth(world):
+    pc.failed_growth(world)
+
+
+def test_long_inputs_in_pieces(world):
+    pc.long_inputs_in_pieces(world)
+
+
 def test_decode_roads(world):
     """dec_onepass for the chunks inside streams, the two-pass kernels when told so or when it gives up."""
     pc.decode_roads(world, sizes=(40_000, 90_000, 160_000))

@@ -92,6 +92,18 @@ def test_foreign_coder_callbacks(world):
     pc.foreign_coder_callbacks(world)
 
 
+def test_one_sided_coders(world):
+    pc.one_sided_coders(world, n=400_000)
+
+
+def test_failed_growth(world):
+    pc.failed_growth(world)
+
+
+def test_long_inputs_in_pieces(world):
+    pc.long_inputs_in_pieces(world)
+
+
 def test_recreated_coders(world):
     pc.recreated_coders(world, rounds=8, n=40000)
 
