@@ -6472,7 +6472,8 @@ __global__ __launch_bounds__(kTailThreads) void dec_emit_tail_kernel(
     const u32 *chunk_fn,
     const u32 *chunk_entry,
     const u64 *chunk_base,
-    hufd_dec_result *results) {
+    hufd_dec_result *results,
+    u32 stage_limit /* symbols the stage of dec_emit_fast<TAIL>'s launch holds: what that kernel takes, this one finishes */) {
 
     tail_lds &sh = *reinterpret_cast<tail_lds *>(dyn_lds);
     u16 *lut = reinterpret_cast<u16 *>(dyn_lds + sizeof(tail_lds));
@@ -6533,9 +6534,8 @@ __global__ __launch_bounds__(kTailThreads) void dec_emit_tail_kernel(
     const u32 f0 = chunk_fn[(u64)c * ns + s0];
     const u32 chunk_symbols = wide_count(f0);
     /* exactly the chunks dec_emit_fast<TAIL> emitted in one pass (the two-pass and the long way do their own ends) */
-    if (((cpt[merged_row] >> s0) & 1u) == 0 || cbase + chunk_symbols > it.out_cap ||
-        chunk_symbols + 16 > HUFD_DEC_STAGE_BYTES) {
-        return;
+    if (((cpt[merged_row] >> s0) & 1u) == 0 || cbase + chunk_symbols > it.out_cap || chunk_symbols + 16 > stage_limit) {
+        return; /* (the same test, with the same stage, as dec_emit_fast<TAIL>'s `fast`: the two kernels run side by side) */
     }
     const u32 n_full = (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES);
     const u32 first = n_full, second = n_full + 1;
@@ -7607,7 +7607,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
                 dec_emit_tail_kernel, dim3((a->n_tail + kTailThreads - 1) / kTailThreads), dim3(kTailThreads), lds, ends_st,
                 a->tables, a->items, a->chunk_item, a->tail_chunks, a->n_tail, (const u8 *)a->d_in, (u8 *)a->d_out,
                 (const u16 *)a->cp_tab, (const u16 *)a->lane_count, (const u8 *)a->chunk_regular,
-                (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results);
+                (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results, tail_stage);
         }
         if (have_side) {
             (void)hipEventRecord((hipEvent_t)a->join_event, (hipStream_t)a->side_stream);

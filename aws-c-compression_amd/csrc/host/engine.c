@@ -12,6 +12,34 @@
 
 /* ------------------------------------------------------------------ small helpers */
 
+/*
+ * The calling thread's current HIP device is the caller's business: every entry point that works on an engine's device
+ * switches to it for its own duration and leaves the thread where it found it (a library call that moves a thread to
+ * another GPU makes the caller's next kernel launch, or the next engine picked by the current device, land there).
+ */
+struct device_scope {
+    int previous; /* < 0: nothing to go back to */
+};
+static struct device_scope device_scope_enter(int device) {
+    struct device_scope sc = {-1};
+    int now = -1;
+    if (hufs_get_device(&now) == 0 && now != device) {
+        sc.previous = now;
+    }
+    hufs_set_device(device);
+    return sc;
+}
+static void device_scope_leave(struct device_scope *sc) {
+    if (sc->previous >= 0) {
+        hufs_set_device(sc->previous);
+    }
+}
+#define HUFS_PASTE2(a, b) a##b
+#define HUFS_PASTE(a, b) HUFS_PASTE2(a, b)
+#define ON_DEVICE(device)                                                                                              \
+    struct device_scope HUFS_PASTE(device_scope_, __LINE__) __attribute__((cleanup(device_scope_leave), unused)) =     \
+        device_scope_enter(device)
+
 static int raise_hip(int hip_error) {
     (void)hip_error;
     return aws_raise_error(AWS_ERROR_UNKNOWN);
@@ -144,9 +172,10 @@ int aws_huffman_amd_engine_new(
             return aws_raise_error(AWS_ERROR_UNKNOWN);
         }
     }
-    if (hufs_set_device(device)) {
+    if (device >= hufs_device_count()) {
         return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
     }
+    ON_DEVICE(device);
     {
         const int e = hufk_init(); /* per device, once; safe from several threads */
         if (e) {
@@ -324,7 +353,7 @@ void aws_huffman_amd_engine_destroy(struct aws_huffman_amd_engine *eng) {
     if (!eng) {
         return;
     }
-    hufs_set_device(eng->device);
+    ON_DEVICE(eng->device);
     if (eng->one_enc) {
         aws_huffman_amd_encode_plan_destroy(eng->one_enc);
     }
@@ -348,6 +377,15 @@ void aws_huffman_amd_engine_destroy(struct aws_huffman_amd_engine *eng) {
     free(eng->deep_lut_host);
     pthread_mutex_destroy(&eng->one_lock);
     free(eng);
+}
+
+int aws_huffman_amd_engine_device(const struct aws_huffman_amd_engine *eng) {
+    return eng->device;
+}
+
+int aws_huffman_amd_current_device(void) {
+    int device = -1;
+    return hufs_get_device(&device) ? -1 : device;
 }
 
 uint32_t aws_huffman_amd_engine_max_code_bits(const struct aws_huffman_amd_engine *eng) {
@@ -502,7 +540,7 @@ static int enc_plan_fill(
     }
 
     int err = 0;
-    hufs_set_device(eng->device);
+    ON_DEVICE(eng->device);
     if (n_items > p->cap_items || n_segs > p->cap_segs || n_large > p->cap_large || n_tiny > p->cap_tiny) {
         enc_plan_release_device(p);
         const size_t ci = n_items ? n_items : 1, cs = n_segs ? n_segs : 1, cl = n_large ? n_large : 1, ct = n_tiny ? n_tiny : 1;
@@ -582,9 +620,17 @@ int aws_huffman_amd_encode_plan_new(
     return AWS_OP_SUCCESS;
 }
 
+int aws_huffman_amd_encode_plan_reset(
+    struct aws_huffman_amd_encode_plan *p,
+    const struct aws_huffman_amd_encode_item *items,
+    size_t item_count) {
+    p->look_back_timed_out = false;
+    return enc_plan_fill(p, items, item_count); /* (device arrays are kept where they are large enough) */
+}
+
 void aws_huffman_amd_encode_plan_destroy(struct aws_huffman_amd_encode_plan *p) {
     if (p) {
-        hufs_set_device(p->engine->device);
+        ON_DEVICE(p->engine->device);
         enc_plan_release_device(p);
         free(p);
     }
@@ -638,7 +684,7 @@ int aws_huffman_amd_encode_plan_launch_staged(
     a.states = p->d_states;
     a.results = p->d_results;
     a.stage_events = stage_events;
-    hufs_set_device(p->engine->device);
+    ON_DEVICE(p->engine->device);
     const int err = hufk_encode_launch(&a, stream ? stream : p->engine->stream);
     return err ? raise_hip(err) : AWS_OP_SUCCESS;
 }
@@ -648,7 +694,7 @@ int aws_huffman_amd_encode_plan_raw_results(
     struct hufd_enc_result *raw,
     void *stream) {
     void *st = stream ? stream : p->engine->stream;
-    hufs_set_device(p->engine->device);
+    ON_DEVICE(p->engine->device);
     int err = 0;
     /* The one-pass kernel's waves wait for each other's totals; every wait is bounded, and one that ran out raises a
      * flag.  The kernels of the three-kernel road (no waits between workgroups) are queued behind it on the same
@@ -968,7 +1014,7 @@ static int dec_plan_fill(
 
     int err = 0;
     const uint32_t ns = eng->tables.n_states;
-    hufs_set_device(eng->device);
+    ON_DEVICE(eng->device);
     if (n_items > p->cap_items || n_chunks > p->cap_chunks || n_large > p->cap_large || n_runs > p->cap_runs) {
         dec_plan_release_device(p);
         const size_t ci = n_items ? n_items : 1, cc = n_chunks ? n_chunks : 1, cl = n_large ? n_large : 1;
@@ -1101,9 +1147,16 @@ int aws_huffman_amd_decode_plan_new(
     return AWS_OP_SUCCESS;
 }
 
+int aws_huffman_amd_decode_plan_reset(
+    struct aws_huffman_amd_decode_plan *p,
+    const struct aws_huffman_amd_decode_item *items,
+    size_t item_count) {
+    return dec_plan_fill(p, items, item_count);
+}
+
 void aws_huffman_amd_decode_plan_destroy(struct aws_huffman_amd_decode_plan *p) {
     if (p) {
-        hufs_set_device(p->engine->device);
+        ON_DEVICE(p->engine->device);
         dec_plan_release_device(p);
         free(p->h_items);
         free(p);
@@ -1182,7 +1235,7 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.fuse_block = p->d_fuse_block;
     p->one_pass_tried = a.fuse_mode != 1 && !a.old_sync && p->n_tiles && hufk_decode_one_pass_applies(&a.tables);
     a.stage_events = stage_events;
-    hufs_set_device(p->engine->device);
+    ON_DEVICE(p->engine->device);
     const int err = hufk_decode_launch(&a, stream ? stream : p->engine->stream);
     return err ? raise_hip(err) : AWS_OP_SUCCESS;
 }
@@ -1230,7 +1283,7 @@ int aws_huffman_amd_decode_plan_road(struct aws_huffman_amd_decode_plan *p, void
     }
     void *st = stream ? stream : p->engine->stream;
     uint32_t ctl[4] = {0, 0, 0, 0};
-    hufs_set_device(p->engine->device);
+    ON_DEVICE(p->engine->device);
     int err = hufs_copy_d2h(ctl, p->d_fuse_block, sizeof(ctl), st);
     if (!err) {
         err = hufs_stream_sync(st);
@@ -1256,7 +1309,7 @@ int aws_huffman_amd_decode_plan_results(
     if (!raw) {
         return aws_raise_error(AWS_ERROR_OOM);
     }
-    hufs_set_device(p->engine->device);
+    ON_DEVICE(p->engine->device);
     int err = hufs_copy_d2h(raw, p->d_results, (size_t)p->n_items * sizeof(*raw), st);
     if (!err) {
         err = hufs_stream_sync(st);
@@ -1275,7 +1328,7 @@ int aws_huffman_amd_decode_plan_results(
 /* ------------------------------------------------------------------ one-item helpers for the host-pointer API */
 
 static int one_shot_reserve(struct aws_huffman_amd_engine *eng, size_t in_bytes, size_t out_bytes) {
-    hufs_set_device(eng->device);
+    ON_DEVICE(eng->device);
     if (in_bytes > eng->one_in_cap) {
         hufs_free(eng->one_in);
         eng->one_in_cap = in_bytes + in_bytes / 4 + 4096;
@@ -1319,7 +1372,7 @@ static bool mini_ready(struct aws_huffman_amd_engine *eng) {
     if (eng->mini_host && eng->mini_dev) {
         return true;
     }
-    hufs_set_device(eng->device);
+    ON_DEVICE(eng->device);
     if (!eng->mini_host) {
         eng->mini_host = hufs_host_alloc(MINI_BLOCK);
     }
@@ -1356,7 +1409,7 @@ static int mini_encode(
     rec.n_segs = 0;
     memcpy(eng->mini_host, &rec, sizeof(rec));
     memcpy(eng->mini_host + MINI_IN_AT, host_in, item->in_len);
-    hufs_set_device(eng->device);
+    ON_DEVICE(eng->device);
     int err = hufs_copy_h2d(eng->mini_dev, eng->mini_host, MINI_IN_AT + item->in_len, eng->stream);
     if (!err && item->in_len <= MINI_MAX_IN) {
         err = hufk_encode_one_tiny(
@@ -1501,7 +1554,7 @@ int aws_huffman_amd_engine_decode_host(
         memcpy(eng->mini_host, &rec, sizeof(rec));
         memcpy(eng->mini_host + MINI_IN_AT + 16 - carry_bytes, carry, carry_bytes);
         memcpy(eng->mini_host + MINI_IN_AT + 16, host_in, in_len);
-        hufs_set_device(eng->device);
+        ON_DEVICE(eng->device);
         int e = hufs_copy_h2d(eng->mini_dev, eng->mini_host, MINI_IN_AT + 16 + in_len, eng->stream);
         if (!e) {
             /* a lone thread up to MINI_MAX_IN bytes, a wave (a workgroup with long codes) above */
@@ -1605,7 +1658,7 @@ int aws_huffman_amd_device_count(void) {
 }
 
 void *aws_huffman_amd_device_alloc(struct aws_huffman_amd_engine *eng, size_t size) {
-    hufs_set_device(eng->device);
+    ON_DEVICE(eng->device);
     void *p = hufs_malloc(size);
     if (!p) {
         aws_raise_error(AWS_ERROR_OOM);
@@ -1614,12 +1667,12 @@ void *aws_huffman_amd_device_alloc(struct aws_huffman_amd_engine *eng, size_t si
 }
 
 void aws_huffman_amd_device_free(struct aws_huffman_amd_engine *eng, void *ptr) {
-    hufs_set_device(eng->device);
+    ON_DEVICE(eng->device);
     hufs_free(ptr);
 }
 
 int aws_huffman_amd_copy_to_device(struct aws_huffman_amd_engine *eng, void *dst, const void *src, size_t size) {
-    hufs_set_device(eng->device);
+    ON_DEVICE(eng->device);
     int err = hufs_copy_h2d(dst, src, size, eng->stream);
     if (!err) {
         err = hufs_stream_sync(eng->stream);
@@ -1628,7 +1681,7 @@ int aws_huffman_amd_copy_to_device(struct aws_huffman_amd_engine *eng, void *dst
 }
 
 int aws_huffman_amd_copy_to_host(struct aws_huffman_amd_engine *eng, void *dst, const void *src, size_t size) {
-    hufs_set_device(eng->device);
+    ON_DEVICE(eng->device);
     int err = hufs_copy_d2h(dst, src, size, eng->stream);
     if (!err) {
         err = hufs_stream_sync(eng->stream);
@@ -1637,7 +1690,7 @@ int aws_huffman_amd_copy_to_host(struct aws_huffman_amd_engine *eng, void *dst, 
 }
 
 int aws_huffman_amd_device_fill(struct aws_huffman_amd_engine *eng, void *dst, int byte, size_t size) {
-    hufs_set_device(eng->device);
+    ON_DEVICE(eng->device);
     int err = hufs_memset(dst, byte, size, eng->stream);
     if (!err) {
         err = hufs_stream_sync(eng->stream);
@@ -1646,7 +1699,7 @@ int aws_huffman_amd_device_fill(struct aws_huffman_amd_engine *eng, void *dst, i
 }
 
 int aws_huffman_amd_device_fill_splitmix64(struct aws_huffman_amd_engine *eng, void *dst, size_t size, uint64_t seed) {
-    hufs_set_device(eng->device);
+    ON_DEVICE(eng->device);
     int err = hufk_fill_splitmix64(dst, size, seed, eng->stream);
     if (!err) {
         err = hufs_stream_sync(eng->stream);
@@ -1655,29 +1708,29 @@ int aws_huffman_amd_device_fill_splitmix64(struct aws_huffman_amd_engine *eng, v
 }
 
 int aws_huffman_amd_stream_synchronize(struct aws_huffman_amd_engine *eng, void *stream) {
-    hufs_set_device(eng->device);
+    ON_DEVICE(eng->device);
     const int err = hufs_stream_sync(stream ? stream : eng->stream);
     return err ? raise_hip(err) : AWS_OP_SUCCESS;
 }
 
 void *aws_huffman_amd_event_new(struct aws_huffman_amd_engine *eng) {
-    hufs_set_device(eng->device);
+    ON_DEVICE(eng->device);
     return hufs_event_create();
 }
 
 void aws_huffman_amd_event_destroy(struct aws_huffman_amd_engine *eng, void *event) {
-    hufs_set_device(eng->device);
+    ON_DEVICE(eng->device);
     hufs_event_destroy(event);
 }
 
 int aws_huffman_amd_event_record(struct aws_huffman_amd_engine *eng, void *event, void *stream) {
-    hufs_set_device(eng->device);
+    ON_DEVICE(eng->device);
     const int err = hufs_event_record(event, stream ? stream : eng->stream);
     return err ? raise_hip(err) : AWS_OP_SUCCESS;
 }
 
 int aws_huffman_amd_event_elapsed_ms(struct aws_huffman_amd_engine *eng, void *start, void *stop, float *ms) {
-    hufs_set_device(eng->device);
+    ON_DEVICE(eng->device);
     const int err = hufs_event_elapsed_ms(start, stop, ms);
     return err ? raise_hip(err) : AWS_OP_SUCCESS;
 }

@@ -155,7 +155,18 @@ static struct aws_huffman_amd_engine *engine_acquire(struct aws_huffman_symbol_c
 static void engine_release(struct aws_huffman_amd_engine *eng) {
     pthread_mutex_unlock(&eng->one_lock);
     pthread_mutex_lock(&s_engine_lock);
-    --eng->users;
+    if (--eng->users == 0 && eng->coder == NULL) {
+        /* retired while somebody was inside (its coder destroyed or forgotten, the library cleaned up): the last one out
+         * frees its tables, buffers and streams -- nobody can be handed this engine again */
+        for (int i = 0; i < ENGINE_SLOTS; ++i) {
+            if (s_engines[i] == eng) {
+                s_engines[i] = NULL;
+            }
+        }
+        pthread_mutex_unlock(&s_engine_lock);
+        aws_huffman_amd_engine_destroy(eng);
+        return;
+    }
     pthread_mutex_unlock(&s_engine_lock);
 }
 

@@ -113,6 +113,13 @@ int aws_huffman_amd_encode_plan_new(
     const struct aws_huffman_amd_encode_item *items,
     size_t item_count);
 
+/* the plan for other items (its device arrays are kept where they are large enough: no allocation in the steady state) */
+AWS_COMPRESSION_API
+int aws_huffman_amd_encode_plan_reset(
+    struct aws_huffman_amd_encode_plan *plan,
+    const struct aws_huffman_amd_encode_item *items,
+    size_t item_count);
+
 AWS_COMPRESSION_API
 void aws_huffman_amd_encode_plan_destroy(struct aws_huffman_amd_encode_plan *plan);
 
@@ -171,6 +178,12 @@ AWS_COMPRESSION_API
 int aws_huffman_amd_decode_plan_new(
     struct aws_huffman_amd_decode_plan **plan,
     struct aws_huffman_amd_engine *engine,
+    const struct aws_huffman_amd_decode_item *items,
+    size_t item_count);
+
+AWS_COMPRESSION_API
+int aws_huffman_amd_decode_plan_reset(
+    struct aws_huffman_amd_decode_plan *plan,
     const struct aws_huffman_amd_decode_item *items,
     size_t item_count);
 
@@ -295,6 +308,12 @@ int aws_huffman_amd_shards_decode(
 
 AWS_COMPRESSION_API
 int aws_huffman_amd_device_count(void);
+/* the device an engine works on, and the calling thread's current device (which no call of this library changes: every
+ * entry point switches to its engine's device for its own duration and back) */
+AWS_COMPRESSION_API
+int aws_huffman_amd_engine_device(const struct aws_huffman_amd_engine *engine);
+AWS_COMPRESSION_API
+int aws_huffman_amd_current_device(void);
 AWS_COMPRESSION_API
 void *aws_huffman_amd_device_alloc(struct aws_huffman_amd_engine *engine, size_t size);
 AWS_COMPRESSION_API

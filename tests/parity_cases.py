@@ -480,7 +480,10 @@ def sharded_items(w, devices=(0, 0, 0), n_items=23, seed=71, item_len=16384):
     same way.  (The same device may be listed several times: that is how one GPU, or the emulator, runs this.)"""
     rng = np.random.default_rng(seed)
     G = len(devices)
+    here = w.product.lib.aws_huffman_amd_current_device()  # (no call below may leave this thread on another device)
     sh = harness.Shards(w.product.lib, w.pcoder, list(devices))
+    assert [w.product.lib.aws_huffman_amd_engine_device(sh.engines[g].h) for g in range(G)] == list(devices)
+    assert w.product.lib.aws_huffman_amd_current_device() == here
     lens = [item_len, item_len, 0, 1, item_len + 17, 3 * item_len + 5, 15][:n_items]
     lens += [int(rng.integers(1, 2 * item_len)) for _ in range(n_items - len(lens))]
     blobs = [inputs(rng, n, KINDS[i % 3]) for i, n in enumerate(lens)]
@@ -506,6 +509,8 @@ def sharded_items(w, devices=(0, 0, 0), n_items=23, seed=71, item_len=16384):
         bases.append((d_in, d_out))
     items = [dict(in_offset=in_off[i], in_len=blobs[i].size, out_offset=out_off[i], out_capacity=caps[i]) for i in range(n_items)]
     res = sh.encode(items, bases)
+    assert sh.encode(items, bases) == res  # (the same items again: the shards' plans are kept, nothing is built or uploaded)
+    assert w.product.lib.aws_huffman_amd_current_device() == here
     outs = [sh.engines[g].download(bases[g][1], out_pos[g] + 64) for g in range(G)]
     for i in range(n_items):
         eo = w.oracle.new_encoder(w.ocoder)
@@ -534,6 +539,15 @@ def sharded_items(w, devices=(0, 0, 0), n_items=23, seed=71, item_len=16384):
         dn[g] = pos_out
     d_items.sort(key=lambda t: t[0])
     dres = sh.decode([it for _, it in d_items], dbases)
+    assert sh.decode([it for _, it in d_items], dbases) == dres
+    # other items through the kept plans: the first half of every stream only (a code may be cut: what matters is the oracle's record)
+    halves = [dict(it, in_len=it["in_len"] // 2) for _, it in d_items]
+    hres = sh.decode(halves, dbases)
+    for (i, it), r in zip(d_items, hres):
+        ro, _ = w.oracle.decode_all(w.ocoder, full[i][:it["in_len"] // 2], blobs[i].size)
+        assert r[:3] == (ro.rc, ro.err, ro.produced), (i, r, ro)
+    dres = sh.decode([it for _, it in d_items], dbases)
+    assert w.product.lib.aws_huffman_amd_current_device() == here
     backs = [sh.engines[g].download(dbases[g][1], dn[g] + 64) for g in range(G)]
     for i, it in d_items:
         assert dres[i][0] == 0 and dres[i][2] == blobs[i].size, (i, dres[i])

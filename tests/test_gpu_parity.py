@@ -113,6 +113,9 @@ def test_sharded_items(world):
     threads, the configs[3] split i mod G (on an 8-GPU node: devices=range(8))."""
     ndev = world.product.lib.aws_huffman_amd_device_count()
     pc.sharded_items(world, devices=tuple(g % ndev for g in range(3)), n_items=60)
+    # every GPU of the node once (one on this box, eight on the node the scaling runs use): each engine on its own device,
+    # the caller's thread left where it was
+    pc.sharded_items(world, devices=tuple(range(min(8, ndev))), n_items=64, seed=72)
 
 
 def test_batched_device_api(world, engine):
