@@ -5900,6 +5900,7 @@ __device__ __forceinline__ void dec_emit_chunk(
         if (t == 0) {
             u32 state = entry & 0xFFu, total = 0;
             bool stopped = false;
+#pragma unroll 1
             for (u32 g = 0; g < kGroups; ++g) {
                 g_entry[g] = entry_pack(state, !stopped);
                 g_base[g] = total;
@@ -5916,6 +5917,7 @@ __device__ __forceinline__ void dec_emit_chunk(
         if (t < kGroups) {
             u32 state = g_entry[t] & 0xFFu, total = g_base[t];
             bool stopped = !(g_entry[t] & 0x100u);
+#pragma unroll 1
             for (u32 i = 0; i < kGroupLanes; ++i) {
                 const u32 l = t * kGroupLanes + i;
                 u32 ent = entry_pack(state, !stopped), cnt = 0;
@@ -6039,7 +6041,7 @@ __device__ __forceinline__ void dec_emit_chunk(
 }
 
 /* the chunks list[0 .. *list_count), a few workgroups taking turns (list == NULL: every chunk) */
-__global__ __launch_bounds__(kEmitThreads, 8) void dec_emit_kernel(
+__global__ __launch_bounds__(kEmitThreads, 4) void dec_emit_kernel(
     hufd_tables tb,
     const hufd_dec_item *items,
     const u32 *chunk_item,
@@ -6112,7 +6114,7 @@ __device__ __forceinline__ void dec_emit_fast_chunk(
     hufd_dec_result *results,
     u32 *slow_list, /* chunks left to dec_emit_kernel */
     u32 *slow_count,
-    u32 *dense_list, /* chunks with more symbols than the stage holds: left to dec_emit_dense_kernel */
+    u32 *dense_list, /* chunks with more symbols than the stage holds: left to dec_emit_big_kernel (or, the launch says, to the long way) */
     u32 *dense_count,
     u32 stage_limit /* symbols the stage of this launch holds (HUFD_DEC_STAGE_BYTES, or less: emit_lds_bytes) */) {
 
@@ -6163,7 +6165,7 @@ __device__ __forceinline__ void dec_emit_fast_chunk(
     if (!fast) {
         if (t == 0) {
             if (fits && chunk_symbols + 32 <= 2 * HUFD_DEC_STAGE_BYTES) {
-                dense_list[atomicAdd(dense_count, 1u)] = c; /* short codes: two passes over the stage */
+                dense_list[atomicAdd(dense_count, 1u)] = c; /* short codes: a stage twice as long */
             } else {
                 slow_list[atomicAdd(slow_count, 1u)] = c;
             }
@@ -6443,7 +6445,7 @@ __global__ __launch_bounds__(kEmitFastThreads, 4) void dec_emit_big_kernel(
     const u32 n = *big_count;
     for (u32 k = blockIdx.x; k < n; k += gridDim.x) {
         if (chunk_rec[big_list[k]].valid < HUFD_DEC_CHUNK_BYTES + 8u) {
-            continue; /* holds the end of its stream: dec_emit_dense's, which walks the stream's last symbols too */
+            continue; /* (holds the end of its stream: never listed for this kernel, the long way takes those) */
         }
         /* (a chunk that does not go through here after all is left to the long way, not listed for this kernel again) */
         dec_emit_fast_chunk<LB, false, SURE>(
@@ -6555,335 +6557,6 @@ __global__ __launch_bounds__(kTailThreads) void dec_emit_tail_kernel(
     if (stop_why != HUFD_STOP_NONE) {
         results[item_index].stop_kind = stop_why;
         results[item_index].stop_bit = (chunk_off + (u64)n_full * HUFD_DEC_SUB_BYTES) * 8 + stop_pos;
-    }
-}
-
-/*
- * The same for a chunk of short codes that holds more symbols than the stage (but no more than two stages):
- * emitted in two passes, sub-chunks 0 .. 127 and 128 .. 255 (each thread's first and second chain), each with
- * the whole stage to itself.  dec_emit_fast lists such chunks; a few workgroups take turns over the list.
- */
-template <u32 LB>
-__device__ __forceinline__ void dec_emit_dense_chunk(
-    const hufd_tables &tb,
-    const hufd_dec_item *items,
-    const u32 *chunk_item,
-    const u8 *d_in,
-    u8 *d_out,
-    const u16 *cp_tab,
-    const u16 *lane_count,
-    const u8 *chunk_regular,
-    const u32 *chunk_fn,
-    const u32 *chunk_entry,
-    const u64 *chunk_base,
-    hufd_dec_result *results,
-    u32 *slow_list, /* chunks left to dec_emit_kernel */
-    u32 *slow_count,
-    u32 c) {
-    constexpr bool TAIL = true; /* written for both kinds of chunk */
-
-    emit_shared<LB> &sh = *reinterpret_cast<emit_shared<LB> *>(dyn_lds);
-    const u32 ns = tb.n_states;
-    const u32 t = threadIdx.x;
-    const u32 q = t / kEmitHalf;                 /* my quarter of ... */
-    const u32 lanes[kEmitChains] = {t % kEmitHalf, t % kEmitHalf + kEmitHalf}; /* ... these two sub-chunks */
-    /* the table entries this thread will put into LDS: asked for first, they depend on nothing */
-    constexpr u32 kLutPerThread = ((1u << LB) + kEmitFastThreads - 1) / kEmitFastThreads;
-    u32 lut_raw[kLutPerThread];
-#pragma unroll
-    for (u32 j = 0; j < kLutPerThread; ++j) {
-        const u32 i = t + j * kEmitFastThreads;
-        lut_raw[j] = i < (1u << LB) ? tb.dec_lut[i >> (LB - tb.lut_bits)] : 0u;
-    }
-    const u32 centry = chunk_entry[c];
-    if (!(centry & 0x100u)) {
-        return; /* the stream ended before this chunk */
-    }
-    const u32 s0 = centry & 0xFFu;
-    const u32 item_index = chunk_item[c];
-    const hufd_dec_item it = items[item_index];
-    const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
-    const u64 valid = it.in_len > chunk_off ? it.in_len - chunk_off : 0;
-    /* lanes whose sub-chunk and the 8 bytes after it lie inside the stream (dec_sync_fast: the others are idle or "careful") */
-    const u32 n_full = valid >= (u64)HUFD_DEC_CHUNK_BYTES + 8u ? HUFD_DEC_LANES : (valid >= 8u ? (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES) : 0u);
-    const u64 cbase = chunk_base[c];
-    const u16 *cpt = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES;
-    const u32 merged_row = (kQuarters - 1) * HUFD_DEC_LANES;
-    const u32 f0 = chunk_fn[(u64)c * ns + s0];
-    const u32 chunk_symbols = wide_count(f0);
-    /* all the same for the whole workgroup */
-    const u32 regular = chunk_regular[c]; /* 1: all lanes whole; 2: the chunk that holds the end of the stream */
-    const bool fast = regular != 0 && (regular == 2 || !wide_stop(f0)) && ((cpt[merged_row] >> s0) & 1u) != 0 &&
-                      cbase + chunk_symbols <= it.out_cap && chunk_symbols + 32 <= 2 * HUFD_DEC_STAGE_BYTES;
-    if (!fast) {
-        if (t == 0) {
-#if defined(HUFD_EMU_TRACE)
-            fprintf(stderr, "emit: chunk %u slow: regular %u stop %d alive %d fits %d symbols %u\n", c, regular, (int)wide_stop(f0),
-                    (int)((cpt[merged_row] >> s0) & 1u), (int)(cbase + chunk_symbols <= it.out_cap), chunk_symbols);
-#endif
-            slow_list[atomicAdd(slow_count, 1u)] = c;
-        }
-        return;
-    }
-
-    HUFD_STAMP(1, 0);
-    /* my quarters: rows 8q .. 8q+7 and the word after them */
-    constexpr u32 kRows = kSubWords / kQuarters;
-    const u8 *sub[kEmitChains];
-    u32 w[kEmitChains][kRows + 1];
-    u32 my_cp[kEmitChains], next_cp[kEmitChains], entry_state[kEmitChains], cnt[kEmitChains], own_row[kEmitChains];
-    bool whole[kEmitChains];
-#pragma unroll
-    for (u32 ch = 0; ch < kEmitChains; ++ch) {
-        sub[ch] = d_in + it.in_off + chunk_off + (u64)lanes[ch] * HUFD_DEC_SUB_BYTES;
-        whole[ch] = !TAIL || lanes[ch] < n_full;
-#pragma unroll
-        for (u32 j = 0; j <= kRows; ++j) {
-            w[ch][j] = 0;
-        }
-        if (whole[ch]) {
-            const unaligned_uint4 *p = reinterpret_cast<const unaligned_uint4 *>(sub[ch] + q * kRows * 4);
-#pragma unroll
-            for (u32 j = 0; j < kRows / 4; ++j) {
-                const unaligned_uint4 v = p[j];
-                w[ch][4 * j + 0] = __builtin_bswap32(v.x);
-                w[ch][4 * j + 1] = __builtin_bswap32(v.y);
-                w[ch][4 * j + 2] = __builtin_bswap32(v.z);
-                w[ch][4 * j + 3] = __builtin_bswap32(v.w);
-            }
-            w[ch][kRows] = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(sub[ch] + (q + 1) * kRows * 4)->x);
-        }
-        own_row[ch] = cpt[merged_row + lanes[ch]];
-        my_cp[ch] = q ? cpt[(q - 1) * HUFD_DEC_LANES + lanes[ch]] : 0u;
-        next_cp[ch] = q + 1 < kQuarters ? cpt[q * HUFD_DEC_LANES + lanes[ch]] : 0u;
-        entry_state[ch] = lanes[ch] ? (u32)(cpt[merged_row + lanes[ch] - 1] >> 12) : s0;
-        cnt[ch] = lane_count[(u64)c * HUFD_DEC_LANES + lanes[ch]];
-    }
-#pragma unroll
-    for (u32 j = 0; j < kLutPerThread; ++j) {
-        const u32 i = t + j * kEmitFastThreads;
-        const u32 e = lut_raw[j];
-        const u32 len = e & 0xFFu;
-        if (i < (1u << LB)) {
-            sh.wlut[i] = ((e >> 8) << 16) | ((0x10000u - (len ? len : kWalkDeadLen)) & 0xFFFFu);
-        }
-    }
-    /* where every sub-chunk's symbols go: lane 0's count follows from the chunk's total */
-    u32 incl[kEmitChains] = {0, 0};
-    const u32 wl = t & (kWave - 1), half_wave = (t / kWave) & (kEmitHalf / kWave - 1);
-    if (q == 0) {
-#pragma unroll
-        for (u32 ch = 0; ch < kEmitChains; ++ch) {
-            incl[ch] = wave_inclusive_sum(lanes[ch] ? cnt[ch] : 0u, wl);
-            if (wl == kWave - 1) {
-                sh.wave_tot[ch * (kEmitHalf / kWave) + half_wave] = incl[ch]; /* = lanes[ch] / 64 */
-            }
-        }
-    }
-    __syncthreads();
-    u32 rest = 0;
-#pragma unroll
-    for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
-        rest += sh.wave_tot[wv];
-    }
-    const u32 first_count = chunk_symbols - rest; /* sub-chunk 0, entered in state s0 */
-    if (q == 0) {
-#pragma unroll
-        for (u32 ch = 0; ch < kEmitChains; ++ch) {
-            u32 before = 0;
-#pragma unroll
-            for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
-                before += wv < lanes[ch] / kWave ? sh.wave_tot[wv] : 0u;
-            }
-            sh.lane_base[lanes[ch]] = lanes[ch] ? first_count + before + incl[ch] - cnt[ch] : 0u;
-        }
-    }
-    __syncthreads();
-    HUFD_STAMP(1, 1);
-
-    /*
-     * A chunk of short codes holds more symbols than the stage: it is emitted in two passes, sub-chunks
-     * 0 .. 127 and 128 .. 255 (each thread's first and second chain), each with the whole stage to itself.
-     */
-    const u32 half_first = sh.lane_base[kEmitHalf]; /* symbols of sub-chunks 0 .. 127 */
-    const bool two_pass = chunk_symbols + 16 > HUFD_DEC_STAGE_BYTES;
-    if (two_pass && (half_first + 16 > HUFD_DEC_STAGE_BYTES || chunk_symbols - half_first + 16 > HUFD_DEC_STAGE_BYTES)) {
-        if (t == 0) {
-#if defined(HUFD_EMU_TRACE)
-            fprintf(stderr, "emit: chunk %u slow: halves %u + %u\n", c, half_first, chunk_symbols - half_first);
-#endif
-            slow_list[atomicAdd(slow_count, 1u)] = c;
-        }
-        return;
-    }
-    const row_walk rw(LB, tb.max_bits);
-    const u8 *lut = reinterpret_cast<const u8 *>(sh.wlut);
-    HUFD_STAMP(1, 2);
-    for (u32 pass = 0; pass < (two_pass ? 2u : 1u); ++pass) {
-        const u32 base_sym = two_pass && pass ? half_first : 0u;
-        const u32 n_sym = two_pass ? (pass ? chunk_symbols - half_first : half_first) : chunk_symbols;
-        u8 *out_ptr = d_out + it.out_off + cbase + base_sym;
-        const u32 mis = (u32)((uintptr_t)out_ptr & 15u);
-        u32 st[kEmitChains];
-        /* (byte offsets into the workgroup's LDS record, as in dec_emit_fast: LDS stores, 32-bit arithmetic) */
-        u8 *const lds_bytes = reinterpret_cast<u8 *>(&sh);
-        const u32 stage_at = (u32)(reinterpret_cast<u8 *>(sh.stage) - lds_bytes), dump_at = (u32)(sh.dump - lds_bytes);
-        u32 dst[kEmitChains];
-        bool idle[kEmitChains]; /* a chain with nothing to emit still walks (the two go in step), into the dump */
-        bool in_pass[kEmitChains];
-        bool extend = false;
-#pragma unroll
-        for (u32 ch = 0; ch < kEmitChains; ++ch) {
-            in_pass[ch] = !two_pass || ch == pass;
-            const u32 lane_n = lanes[ch] ? cnt[ch] : first_count;
-            /* my share: from my checkpoint (q = 0: the entry state) to the next usable one; the lanes behind the
-             * whole ones are not walked here */
-            const bool mine = in_pass[ch] && whole[ch] && (q == 0 || (my_cp[ch] & 0x8000u) != 0);
-            const u32 first = q ? lane_n - (my_cp[ch] & 0x7FFu) : 0u;
-            st[ch] = rw.state_at(q ? (my_cp[ch] >> 11) & 15u : entry_state[ch], 0);
-            dst[ch] = mine ? stage_at + mis + (sh.lane_base[lanes[ch]] - base_sym) + first : dump_at;
-            idle[ch] = !mine;
-            /* only sub-chunk 0's first checkpoint can be missing (its head is not known when dec_sync_fast runs) */
-            if (ch == 0) {
-                extend = mine && q == 0 && lanes[0] == 0 && !(next_cp[ch] & 0x8000u);
-            }
-        }
-#pragma unroll
-        for (u32 r = 0; r < kRows; ++r) {
-            u64 pair[kEmitChains];
-#pragma unroll
-            for (u32 ch = 0; ch < kEmitChains; ++ch) {
-                pair[ch] = ((u64)w[ch][r] << 32) | w[ch][r + 1];
-            }
-            for (u32 i = 0; i < rw.sure; ++i) { /* the codes that are certain to start in this row, the two chains in turn */
-                u32 e[kEmitChains];
-#pragma unroll
-                for (u32 ch = 0; ch < kEmitChains; ++ch) {
-                    e[ch] = *reinterpret_cast<const u32 *>(lut + ((u32)(pair[ch] >> (st[ch] & 63u)) & rw.mask));
-                }
-#pragma unroll
-                for (u32 ch = 0; ch < kEmitChains; ++ch) {
-                    lds_bytes[dst[ch]++] = (u8)(e[ch] >> 16);
-                    st[ch] += e[ch];
-                }
-            }
-#pragma unroll
-            for (u32 ch = 0; ch < kEmitChains; ++ch) {
-                while ((st[ch] & 0xFFFFu) > rw.thr) {
-                    const u32 e = *reinterpret_cast<const u32 *>(lut + ((u32)(pair[ch] >> (st[ch] & 63u)) & rw.mask));
-                    lds_bytes[dst[ch]++] = (u8)(e >> 16);
-                    st[ch] += e;
-                }
-                st[ch] += 32u;
-                /* an idle chain starts every row afresh: whatever it decodes, its state and its writes stay in bounds */
-                st[ch] = idle[ch] ? rw.state_at(0, 0) : st[ch];
-                dst[ch] = idle[ch] ? dump_at : dst[ch];
-            }
-        }
-        if (extend) {
-            /* rare: sub-chunk 0 on through the second quarter, words straight from memory */
-            u32 hi = w[0][kRows];
-            for (u32 r = kRows; r < 2 * kRows; ++r) {
-                const u32 lo = __builtin_bswap32(*reinterpret_cast<const u32 *>(sub[0] + (r + 1) * 4));
-                const u64 pair = ((u64)hi << 32) | lo;
-                while ((st[0] & 0xFFFFu) > rw.thr) {
-                    const u32 e = *reinterpret_cast<const u32 *>(lut + ((u32)(pair >> (st[0] & 63u)) & rw.mask));
-                    lds_bytes[dst[0]++] = (u8)(e >> 16);
-                    st[0] += e;
-                }
-                st[0] += 32u;
-                hi = lo;
-            }
-        }
-        if (TAIL && q == 0 && regular == 2) {
-            /* the end of the stream: the one or two sub-chunks behind the whole lanes, a thread each, symbol by symbol */
-#pragma unroll
-            for (u32 ch = 0; ch < kEmitChains; ++ch) {
-                if (in_pass[ch] && !whole[ch] && (own_row[ch] & 0xFFFu) != 0) { /* the true path gets here */
-                    const u32 lane = lanes[ch];
-                    const u64 bytes = valid - (u64)lane * HUFD_DEC_SUB_BYTES;
-                    u8 *d = sh.stage + mis + (sh.lane_base[lane] - base_sym);
-                    u32 pos = entry_state[ch];
-                    u32 *words = sh.tail_words[lane - n_full < 2 ? lane - n_full : 0];
-                    tail_words_load(words, sub[ch], bytes);
-                    auto window_at = [&](u32 at) -> u32 { return tail_window(words, at); };
-                    tail_reader tr;
-                    tr.start(words, pos);
-                    for (u32 k = 0; k < cnt[ch]; ++k) { /* dec_sync_fast counted them: every one is a whole, valid code */
-                        const u32 e = sh.wlut[tr.peek() >> (32u - LB)]; /* symbol << 16 | -length */
-                        const u32 len = (0x10000u - (e & 0xFFFFu)) & 0xFFFFu;
-                        *d++ = (u8)(e >> 16);
-                        pos += len;
-                        tr.skip(len);
-                    }
-                    if ((own_row[ch] >> 12) == kExitStop) {
-                        /* the true path ends here: where, and why (source/huffman.c:240-255) */
-                        u32 sym = 0, why = HUFD_STOP_NONE;
-                        (void)code_at_walk<LB>(window_at(pos), sh.wlut, pos, clamp_remaining(valid, lane), &sym, &why);
-                        results[item_index].stop_kind = why;
-                        results[item_index].stop_bit = (chunk_off + (u64)lane * HUFD_DEC_SUB_BYTES) * 8 + pos;
-                    }
-                }
-            }
-        }
-        HUFD_STAMP(1, 3);
-        __syncthreads();
-        HUFD_STAMP(1, 4);
-        {
-            /* stage byte b belongs at (out_ptr - mis) + b: whole 16-byte rows go out aligned */
-            u8 *gbase = out_ptr - mis;
-            const u32 lo = mis, hi = mis + n_sym;
-            const u32 row_lo = (lo + 15) >> 4, row_hi = hi >> 4;
-            if (row_lo <= row_hi) {
-                for (u32 b = lo + t; b < row_lo * 16; b += kEmitFastThreads) {
-                    gbase[b] = sh.stage[b];
-                }
-                for (u32 r = row_lo + t; r < row_hi; r += kEmitFastThreads) {
-                    *reinterpret_cast<uint4 *>(gbase + (u64)r * 16) = *reinterpret_cast<const uint4 *>(sh.stage + r * 16);
-                }
-                for (u32 b = row_hi * 16 + t; b < hi; b += kEmitFastThreads) {
-                    gbase[b] = sh.stage[b];
-                }
-            } else {
-                for (u32 b = lo + t; b < hi; b += kEmitFastThreads) {
-                    gbase[b] = sh.stage[b];
-                }
-            }
-        }
-        if (two_pass) {
-            __syncthreads(); /* the stage is reused by the second pass */
-        }
-    }
-    HUFD_STAMP(1, 5);
-}
-
-template <u32 LB>
-__global__ __launch_bounds__(kEmitFastThreads, 2) void dec_emit_dense_kernel(
-    hufd_tables tb,
-    const hufd_dec_item *items,
-    const u32 *chunk_item,
-    const u8 *d_in,
-    u8 *d_out,
-    const u16 *cp_tab,
-    const u16 *lane_count,
-    const u8 *chunk_regular,
-    const u32 *chunk_fn,
-    const u32 *chunk_entry,
-    const u64 *chunk_base,
-    hufd_dec_result *results,
-    const u32 *list,
-    const u32 *list_count,
-    u32 *slow_list,
-    u32 *slow_count,
-    const hufd_chunk_rec *only_ends /* not NULL: only the chunks that hold the end of a stream (dec_emit_big took the others) */) {
-    for (u32 i = blockIdx.x; i < *list_count; i += gridDim.x) {
-        if (only_ends && only_ends[list[i]].valid >= HUFD_DEC_CHUNK_BYTES + 8u) {
-            continue;
-        }
-        dec_emit_dense_chunk<LB>(
-            tb, items, chunk_item, d_in, d_out, cp_tab, lane_count, chunk_regular, chunk_fn, chunk_entry, chunk_base, results,
-            slow_list, slow_count, list[i]);
-        __syncthreads(); /* stage and tables are reused by the next chunk */
     }
 }
 
@@ -7543,7 +7216,8 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         emit_lds_bytes<LBV>(TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES), STREAMV, a->tables, a->chunk_rec,              \
         a->tail_chunks, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab, (const u16 *)a->lane_count,       \
         (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry,                           \
-        (const u64 *)a->chunk_base, a->results, a->emit_list, a->emit_count, a->dense_list, a->dense_count,            \
+        (const u64 *)a->chunk_base, a->results, a->emit_list, a->emit_count,                                            \
+        !TAILV && has_big ? a->dense_list : a->emit_list, !TAILV && has_big ? a->dense_count : a->emit_count,          \
         TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES, TAILV ? (const u32 *)nullptr : gate)
         const bool some_inside = a->n_tail < a->n_chunks;
         /* (the few chunks streams end in beside the many inside streams: see the sync kernels above.  And in any case
@@ -7565,6 +7239,9 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
                                         : HUFD_DEC_STAGE_BYTES;
         /* (chunks inside a stream: with the coder's number of certain steps a row compiled in, where there is such a build) */
         const uint32_t emit_sure = a->old_sync ? 0u : row_walk(a->tables.lut_bits <= 10 ? 10u : 12u, a->tables.max_bits).sure;
+        /* chunks of short codes that hold more symbols than dec_emit_fast's stage: dec_emit_big where there is a build of
+         * it for the coder and the chunk lies inside its stream; the others take the long way (dec_emit) */
+        const bool has_big = a->tables.lut_bits <= 10 ? emit_sure >= 2 && emit_sure <= 5 : emit_sure >= 2 && emit_sure <= 3;
         if (a->tables.lut_bits <= 10) {
             if (a->n_tail) {
                 switch (emit_sure) {
@@ -7644,26 +7321,6 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             }
         }
 #undef HUFK_LAUNCH_EMIT_BIG
-        /* the two-pass kernel: the listed chunks that hold the end of a stream -- or all of them, where there is no
-         * build of the other for this coder's number of certain steps */
-        const hufd_chunk_rec *only_ends = big ? a->chunk_rec : nullptr;
-        if (a->tables.lut_bits <= 10) {
-            const uint32_t lds = (uint32_t)sizeof(emit_shared<10>);
-            hipLaunchKernelGGL(
-                dec_emit_dense_kernel<10>, dim3(persistent_grid(dec_emit_dense_kernel<10>, kEmitFastThreads, lds, a->n_chunks)),
-                dim3(kEmitFastThreads), lds, st, a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, (u8 *)a->d_out,
-                (const u16 *)a->cp_tab, (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn,
-                (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results, (const u32 *)a->dense_list,
-                (const u32 *)a->dense_count, a->emit_list, a->emit_count, only_ends);
-        } else {
-            const uint32_t lds = (uint32_t)sizeof(emit_shared<12>);
-            hipLaunchKernelGGL(
-                dec_emit_dense_kernel<12>, dim3(persistent_grid(dec_emit_dense_kernel<12>, kEmitFastThreads, lds, a->n_chunks)),
-                dim3(kEmitFastThreads), lds, st, a->tables, a->items, a->chunk_item, (const u8 *)a->d_in, (u8 *)a->d_out,
-                (const u16 *)a->cp_tab, (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn,
-                (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results, (const u32 *)a->dense_list,
-                (const u32 *)a->dense_count, a->emit_list, a->emit_count, only_ends);
-        }
         hipLaunchKernelGGL(
             dec_emit_kernel,
             dim3(persistent_grid(dec_emit_kernel, kEmitThreads, dec_emit_lds_bytes(&a->tables), a->n_chunks)),
