@@ -13,7 +13,8 @@ HBM bytes follow MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in KiB
 coalesced streaming read, so the read side is doubled (all our big reads are 16 B per lane
 global loads or LDS-DMA); WRITE_SIZE is exact for 16 B per lane streaming stores.
 
-  usage: summarise_profile.py <tag> <name>     e.g.  r01d r01_d_lookback
+  usage: summarise_profile.py <tag> <name> [traffic-file]     e.g.  r01d r01_d_lookback
+  (traffic-file: where the HBM bytes go instead of profiles/pmc_traffic.json, for a profile of a road that is not the default)
 """
 import collections
 import csv
@@ -32,10 +33,11 @@ GROUPS = [  # bench kernel name <- substrings of the device kernel names it cove
     ("enc_count", ["enc_count_kernel"]),
     ("enc_scan", ["enc_scan_small_kernel", "enc_scan_large_kernel"]),
     ("enc_pack", ["enc_pack_wave_kernel", "enc_pack_stream_kernel", "enc_pack_kernel"]),
-    ("dec_sync", ["dec_sync_lean_kernel", "dec_sync_fast_kernel", "dec_sync_tail_kernel", "dec_sync_kernel"]),
+    ("dec_sync", ["dec_onepass_kernel", "dec_sync_lean_kernel", "dec_sync_fast_kernel", "dec_sync_guess_kernel", "dec_sync_tail_kernel",
+                  "dec_sync_kernel"]),
     ("dec_scan", ["dec_scan_small_kernel", "dec_scan_runs_kernel", "dec_scan_top_kernel", "dec_scan_apply_kernel",
                   "dec_tiny_kernel", "dec_deep_kernel"]),
-    ("dec_emit", ["dec_emit_fast_kernel", "dec_emit_tail_kernel", "dec_emit_dense_kernel", "dec_emit_kernel"]),
+    ("dec_emit", ["dec_emit_fast_kernel", "dec_emit_tail_kernel", "dec_emit_big_kernel", "dec_emit_kernel"]),
 ]
 
 
@@ -107,7 +109,7 @@ def main():
               open(os.path.join(dst, name + "_counters.json"), "w"), indent=1, sort_keys=True)
     if traffic:
         traffic["_source"] = name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, FETCH doubled per the gfx950 correction)"
-        json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+        json.dump(traffic, open(os.path.join(dst, sys.argv[3] if len(sys.argv) > 3 else "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(traffic, indent=1))
 
 
