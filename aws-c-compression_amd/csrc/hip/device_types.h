@@ -44,6 +44,7 @@
 #define HUFD_DEEP_LINK 0x80000000u /* entry is a link: [15:0] first entry of the next table, [23:16] its index width */
 #define HUFD_DEC_TINY_BYTES 512u /* decode items up to this long are one thread's work (dec_tiny): no chunks */
 #define HUFD_DEC_COOP_BYTES 768u /* ... and up to this long one wave's (dec_deep<false>): no chunks either */
+#define HUFD_DEC_BLOCK_BYTES 8192u /* one host-pointer call of up to this many encoded bytes (short codes) is one workgroup's work (dec_block): one launch */
 #define HUFD_DEC_STAGE_BYTES 34304u /* LDS bytes for a chunk's decoded symbols (dec_emit_fast: four workgroups per CU) */
 
 #define HUFD_SCAN_SMALL_MAX 64u /* items with at most this many segments/chunks are scanned by one thread */
@@ -76,6 +77,7 @@
 #define HUFD_STOP_END 1u        /* all stream bits consumed */
 #define HUFD_STOP_INCOMPLETE 2u /* a code runs past the end of the stream */
 #define HUFD_STOP_INVALID 3u    /* no code matches */
+#define HUFD_STOP_GAVE_UP 4u    /* (dec_block only) the lanes did not settle in its rounds: nothing decoded, the chunk kernels take the call */
 
 struct hufd_tables {
     const uint64_t *enc_table; /* [256] low 32 bits: code masked to its length, high 32 bits: length (0 = no code) */

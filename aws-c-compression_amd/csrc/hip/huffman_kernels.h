@@ -118,7 +118,12 @@ int hufk_decode_one_tiny(
 /* the same for an item of up to HUFD_DEC_COOP_BYTES encoded bytes (any size with long codes): dec_deep, one launch */
 int hufk_decode_one_coop(
     const struct hufd_tables *tables, const struct hufd_dec_item *item, const uint32_t *zero, const void *d_in, void *d_out,
-    struct hufd_dec_item_state *state, struct hufd_dec_result *result, uint32_t wide /* a workgroup, not one wave */, void *stream);
+    struct hufd_dec_item_state *state, struct hufd_dec_result *result, void *stream);
+/* the same for an item of up to HUFD_DEC_BLOCK_BYTES encoded bytes of a coder without long codes: one workgroup, one
+ * launch (dec_block_kernel); item = the record, in HOST memory (it travels with the launch) */
+int hufk_decode_one_block(
+    const struct hufd_tables *tables, const struct hufd_dec_item *item, const void *d_in, void *d_out,
+    struct hufd_dec_item_state *state, struct hufd_dec_result *result, void *stream);
 /* one item of up to HUFD_ENC_BLOCK_BYTES symbols, one workgroup, one launch (enc_block_kernel) */
 int hufk_encode_one_block(
     const struct hufd_tables *tables, const struct hufd_enc_item *item, const void *d_in, void *d_out,

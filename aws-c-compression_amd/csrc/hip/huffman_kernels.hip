@@ -4925,6 +4925,286 @@ __global__ __launch_bounds__(kDeepThreads) void dec_deep_kernel(
     }
 }
 
+/*
+ * One host-pointer call of more than one thread's bytes and up to HUFD_DEC_BLOCK_BYTES of them (short codes): ONE
+ * workgroup and one launch, as enc_block is for the encoder -- a chunk's tables, lists and five more launches cost
+ * such a call several times its symbols.  A lane takes 64 bits of the stream and keeps them, with the 32 behind them,
+ * in registers (big-endian words, zeros behind the stream's end).  As in dec_deep the lanes settle on their
+ * entries by walking again from where the lane in front really leaves until nothing changes -- exact whatever the
+ * stream does, lane 0's entry being the true one; after kBlockDecRounds rounds it gives the call back instead.  What keeps that to a handful of cheap rounds: a lane remembers the
+ * code starts of its last walk (a bit each), and a walk from another entry ends where it meets one of them -- walks
+ * from different entries fall into step within a few codes -- so after the first round a lane's walk is two or three
+ * codes, and one that leaves its lane as before stops the news from travelling on.  Then the scan of the counts and
+ * the walk that writes the symbols; every walk is source/huffman.c:232-268 a code at a time, stops included.
+ */
+constexpr u32 kBlockDecThreads = 1024;
+constexpr u32 kBlockDecLaneBits = 64;
+constexpr u32 kBlockDecWaves = kBlockDecThreads / 64;
+constexpr u32 kBlockDecRounds = 24; /* (the test coder's streams settle in 3 to 7) */
+static_assert(HUFD_DEC_BLOCK_BYTES * 8 == kBlockDecThreads * kBlockDecLaneBits, "a lane for every 64 bits of the longest call");
+
+struct block_dec_shared {
+    u8 exit_of[kBlockDecThreads];
+    u32 wave_total[kBlockDecWaves];
+    u32 changed[2]; /* a lane walks again: rounds take turns with the two */
+    u32 last_lane;  /* the first lane whose walk from its true entry stops */
+    u32 stop_kind;
+    u64 stop_bit;
+    u64 cap_bit;
+};
+
+/* a lane's 64 bits and the 32 behind them */
+struct block_dec_bits {
+    u32 w0, w1, w2;
+    /* the 32 bits from bit `rel` (< 64) of the lane on */
+    __device__ __forceinline__ u32 window(u32 rel) const {
+        const u32 hi = rel & 32u ? w1 : w0, lo = rel & 32u ? w2 : w1;
+        return (u32)((((u64)hi << 32) | lo) >> (32 - (rel & 31u)));
+    }
+};
+
+/* what a lane knows of its last walk: the code starts in its bits (`seen`: they form one chain, each leads to the
+ * next), how many there are, and how the chain leaves the lane (kDeepStop: it stops inside) */
+struct block_dec_chain {
+    u64 seen;
+    u32 count, exit;
+};
+
+/* Walks from bit `rel` of the lane until it meets the chain of the walk before or leaves the lane, and makes that the
+ * chain.  GUESS: a walk from anywhere, only to find a chain to meet: it steps over a window without a code a bit at a
+ * time and forgets what it saw in front of it (a walk that gets there from a real entry stops there). */
+template <bool GUESS>
+__device__ __forceinline__ void block_dec_count(
+    const u16 *lut, u32 lut_bits, const block_dec_bits &bits, u32 lane_from, u32 rem, u32 rel, block_dec_chain &c) {
+    u64 fresh = 0;
+    u32 count = 0, why = HUFD_STOP_NONE;
+    bool met = false;
+    while (rel < kBlockDecLaneBits) {
+        if ((c.seen >> rel) & 1u) {
+            met = true;
+            count += (u32)__popcll(c.seen >> rel);
+            fresh |= c.seen >> rel << rel;
+            break;
+        }
+        if (lane_from + rel >= rem) {
+            why = HUFD_STOP_END;
+            break;
+        }
+        const u32 len = lut[bits.window(rel) >> (32 - lut_bits)] & 0xFFu;
+        if (len == 0) {
+            if (GUESS) {
+                ++rel;
+                fresh = 0;
+                count = 0;
+                continue;
+            }
+            why = HUFD_STOP_INVALID;
+            break;
+        }
+        if (lane_from + rel + len > rem) {
+            why = HUFD_STOP_INCOMPLETE;
+            break;
+        }
+        fresh |= 1ull << rel;
+        ++count;
+        rel += len;
+    }
+    c.seen = fresh;
+    c.count = count;
+    if (!met) {
+        c.exit = why == HUFD_STOP_NONE ? rel - kBlockDecLaneBits : kDeepStop;
+    }
+}
+
+__global__ __launch_bounds__(kBlockDecThreads) void dec_block_kernel(
+    hufd_tables tb,
+    hufd_dec_item it, /* (by value: a record in memory is one more round trip before the stream's first byte) */
+    const u8 *d_in,
+    u8 *d_out,
+    hufd_dec_item_state *states,
+    hufd_dec_result *results) {
+
+    block_dec_shared &sh = *reinterpret_cast<block_dec_shared *>(dyn_lds);
+    u16 *lut = reinterpret_cast<u16 *>(dyn_lds + sizeof(block_dec_shared));
+    const u32 l = threadIdx.x, lane = l & 63u, wave = l >> 6;
+    const u32 in_len = (u32)it.in_len; /* <= HUFD_DEC_BLOCK_BYTES: the launch's side of the bargain */
+    /* Everything from memory in one go -- the table two entries a lane-load, the lane's own bits and the 32 behind them
+     * out of four aligned words (the stream's first byte sits anywhere) --: a trip to memory is most of such a call. */
+    const u32 rem = in_len * 8;
+    const u32 n_lanes = (rem + kBlockDecLaneBits - 1) / kBlockDecLaneBits;
+    const bool active = l < n_lanes;
+    const u32 lane_from = l * kBlockDecLaneBits;
+    block_dec_bits bits, front;
+    {
+        const u32 *lut_words = reinterpret_cast<const u32 *>(tb.dec_lut);
+        u32 *lut_lds = reinterpret_cast<u32 *>(lut);
+        const u32 lut_pairs = (1u << tb.lut_bits) / 2;
+        static_assert((1u << HUFD_DEC_MAX_LUT_BITS) / 2 <= 2 * kBlockDecThreads, "two loads a lane hold the longest table");
+        const u32 t0 = l < lut_pairs ? lut_words[l] : 0u;
+        const u32 t1 = l + kBlockDecThreads < lut_pairs ? lut_words[l + kBlockDecThreads] : 0u;
+        const u8 *first = d_in + it.in_off;
+        const u32 lead = (u32)(reinterpret_cast<uintptr_t>(first) & 3u);
+        const u32 *words = reinterpret_cast<const u32 *>(first - lead);
+        const u32 mem_words = (lead + in_len + 3) / 4; /* the aligned words that hold bytes of the stream */
+        u32 m[6]; /* from the word two in front of the lane's own on: the lane in front's bits, for the guess */
+#pragma unroll
+        for (u32 k = 0; k < 6; ++k) {
+            m[k] = active && 2 * l + k >= 2 && 2 * l + k - 2 < mem_words ? words[2 * l + k - 2] : 0u;
+        }
+        u32 w[5];
+#pragma unroll
+        for (u32 k = 0; k < 5; ++k) {
+            const u32 i = 2 * l + k - 2; /* stream word i: bytes 4 i .. 4 i + 3, those behind the stream's end read as zero */
+            const u32 raw = (u32)((((u64)m[k + 1] << 32) | m[k]) >> (8 * lead));
+            const u32 have = 2 * l + k >= 2 && 4 * i < in_len ? (in_len - 4 * i < 4 ? in_len - 4 * i : 4u) : 0u;
+            const u32 big = __builtin_bswap32(raw);
+            w[k] = have == 4 ? big : (have ? big & (~0u << (8 * (4 - have))) : 0u);
+        }
+        front.w0 = w[0];
+        front.w1 = w[1];
+        front.w2 = w[2];
+        bits.w0 = w[2];
+        bits.w1 = w[3];
+        bits.w2 = w[4];
+        if (l < lut_pairs) {
+            lut_lds[l] = t0;
+        }
+        if (l + kBlockDecThreads < lut_pairs) {
+            lut_lds[l + kBlockDecThreads] = t1;
+        }
+    }
+    if (l == 0) {
+        sh.stop_kind = HUFD_STOP_NONE;
+        sh.stop_bit = kNoBit;
+        sh.cap_bit = kNoBit;
+        sh.last_lane = kBlockDecThreads;
+    }
+    __syncthreads();
+    block_dec_chain chain = {0, 0, kDeepStop};
+    u32 start = l == 0 ? it.first_bit : 0u;
+    if (active) {
+        if (l == 0) {
+            block_dec_count<false>(lut, tb.lut_bits, bits, lane_from, rem, start, chain);
+        } else {
+            /* the first guess: how a walk from anywhere leaves the lane in front (lane 1's: the true walk) */
+            block_dec_chain guess = {0, 0, kDeepStop};
+            if (l == 1) {
+                block_dec_count<false>(lut, tb.lut_bits, front, 0u, rem, it.first_bit, guess);
+            } else {
+                block_dec_count<true>(lut, tb.lut_bits, front, lane_from - kBlockDecLaneBits, rem, 0u, guess);
+            }
+            if (guess.exit != kDeepStop) {
+                start = guess.exit;
+                block_dec_count<false>(lut, tb.lut_bits, bits, lane_from, rem, start, chain);
+            } else {
+                block_dec_count<true>(lut, tb.lut_bits, bits, lane_from, rem, 0u, chain);
+                start = kDeepStop; /* (no entry yet: whatever the lane in front says first is news) */
+            }
+        }
+    }
+    /* Settling: a lane whose entry is not how the lane in front leaves walks again from there.  A walk that stops says
+     * nothing to the lane behind it (from a wrong entry a window without a code is nothing special): that one keeps
+     * what it has.  When nothing changes any more, lane 0 has the true entry, so has every lane up to the first whose
+     * walk stops -- there the stream stops (source/huffman.c:232-255) -- and the lanes behind that one are not part of
+     * it.  (A lane that never heard from the one in front is behind such a lane.) */
+    for (u32 round = 0;; ++round) {
+        sh.exit_of[l] = (u8)(active ? chain.exit : kDeepStop);
+        if (l == 0) {
+            sh.changed[round & 1u] = 0; /* (the flag of the round before last: everyone has read it) */
+        }
+        __syncthreads();
+        if (active && l > 0) {
+            const u32 prev = sh.exit_of[l - 1];
+            if (prev != kDeepStop && prev != start) {
+                start = prev;
+                block_dec_count<false>(lut, tb.lut_bits, bits, lane_from, rem, start, chain);
+                sh.changed[round & 1u] = 1;
+            }
+        }
+        __syncthreads();
+        if (!sh.changed[round & 1u]) {
+            break;
+        }
+        if (round == kBlockDecRounds) {
+            /* a stream whose walks do not fall into step (codes of one length, say): the news travels a lane a round,
+             * and the chunk kernels' transfer functions are the better tool */
+            if (l == 0) {
+                hufd_dec_result rs = {};
+                rs.stop_kind = HUFD_STOP_GAVE_UP;
+                results[0] = rs;
+            }
+            return;
+        }
+    }
+    if (active && chain.exit == kDeepStop) {
+        atomicMin(&sh.last_lane, l);
+    }
+    __syncthreads();
+    const bool reached = active && l <= sh.last_lane;
+    /* where each lane's symbols go: an exclusive scan of the counts of the lanes on the true path */
+    const u32 mine = reached ? chain.count : 0u;
+    const u32 upto = wave_inclusive_sum(mine, lane);
+    if (lane == 63) {
+        sh.wave_total[wave] = upto;
+    }
+    __syncthreads();
+    u32 before = upto - mine, symbols = 0;
+    for (u32 w = 0; w < kBlockDecWaves; ++w) {
+        const u32 t = sh.wave_total[w];
+        before += w < wave ? t : 0u;
+        symbols += t;
+    }
+    if (reached) {
+        /* the symbols of the lane's chain, and what stopped it if something did */
+        u8 *out = d_out + it.out_off;
+        u32 rel = start, k = before, why = HUFD_STOP_NONE;
+        while (rel < kBlockDecLaneBits) {
+            if (lane_from + rel >= rem) {
+                why = HUFD_STOP_END;
+                break;
+            }
+            const u32 entry = lut[bits.window(rel) >> (32 - tb.lut_bits)];
+            const u32 len = entry & 0xFFu;
+            if (len == 0) {
+                why = HUFD_STOP_INVALID;
+                break;
+            }
+            if (lane_from + rel + len > rem) {
+                why = HUFD_STOP_INCOMPLETE;
+                break;
+            }
+            if (k < it.out_cap) {
+                out[k] = (u8)(entry >> 8);
+            } else if (k == it.out_cap) {
+                sh.cap_bit = lane_from + rel; /* source/huffman.c:257-268: this symbol is not consumed */
+            }
+            ++k;
+            rel += len;
+        }
+        if (why != HUFD_STOP_NONE) {
+            sh.stop_kind = why;
+            sh.stop_bit = lane_from + rel;
+        }
+    }
+    __syncthreads();
+    if (l == 0) {
+        hufd_dec_result rs;
+        rs.total_symbols = symbols;
+        rs.cap_bit = sh.cap_bit;
+        rs.reserved = 0;
+        if (sh.stop_kind != HUFD_STOP_NONE) {
+            rs.stop_kind = sh.stop_kind;
+            rs.stop_bit = sh.stop_bit;
+        } else {
+            /* the last code ended on the last bit of the stream */
+            rs.stop_kind = HUFD_STOP_END;
+            rs.stop_bit = rem;
+        }
+        results[0] = rs;
+        states[0].total_symbols = symbols;
+    }
+}
+
 /* ------------------------------------------------------------------ decode: scan */
 
 /* chunk entry record: [7:0] entry state, [8] reached */
@@ -6955,17 +7235,29 @@ int hufk_decode_one_tiny(
     return (int)hipGetLastError();
 }
 
+int hufk_decode_one_block(
+    const struct hufd_tables *tables, const struct hufd_dec_item *item, const void *d_in, void *d_out,
+    struct hufd_dec_item_state *state, struct hufd_dec_result *result, void *stream) {
+    if (tables->deep_entries) {
+        return (int)hipErrorInvalidValue; /* (long codes: hufk_decode_one_coop) */
+    }
+    hipLaunchKernelGGL(
+        dec_block_kernel, dim3(1), dim3(kBlockDecThreads), (uint32_t)sizeof(block_dec_shared) + (1u << tables->lut_bits) * sizeof(u16),
+        (hipStream_t)stream, *tables, *item, (const u8 *)d_in, (u8 *)d_out, state, result);
+    return (int)hipGetLastError();
+}
+
 int hufk_decode_one_coop(
     const struct hufd_tables *tables, const struct hufd_dec_item *item, const uint32_t *zero, const void *d_in, void *d_out,
-    struct hufd_dec_item_state *state, struct hufd_dec_result *result, uint32_t wide, void *stream) {
+    struct hufd_dec_item_state *state, struct hufd_dec_result *result, void *stream) {
     if (tables->deep_entries) {
         hipLaunchKernelGGL(
             dec_deep_kernel<true>, dim3(1), dim3(kDeepThreads), sizeof(deep_shared) + tables->deep_entries * sizeof(u32),
             (hipStream_t)stream, *tables, item, zero, kDeepLaneBytes, (const u8 *)d_in, (u8 *)d_out, state, result);
     } else {
-        /* (one wave up to HUFD_DEC_COOP_BYTES; beyond, the workgroup the kernel allows: the lanes share the item evenly) */
+        /* (one wave: the lanes share the item evenly) */
         hipLaunchKernelGGL(
-            dec_deep_kernel<false>, dim3(1), dim3(wide ? kDeepThreads : kCoopThreads),
+            dec_deep_kernel<false>, dim3(1), dim3(kCoopThreads),
             sizeof(deep_shared) + (1u << tables->lut_bits) * sizeof(u16), (hipStream_t)stream, *tables, item, zero, 0u,
             (const u8 *)d_in, (u8 *)d_out, state, result);
     }

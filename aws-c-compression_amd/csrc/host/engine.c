@@ -1353,18 +1353,18 @@ static int one_shot_reserve(struct aws_huffman_amd_engine *eng, size_t in_bytes,
 /*
  * Inputs of up to a few KiB (what the reference's HPACK consumer passes is tens of bytes, one call per header field):
  * the item record and the input go up in ONE copy from a page-locked block, ONE launch does the work -- one thread
- * (enc_tiny / dec_tiny) up to MINI_MAX_IN bytes, beyond that one wave (dec_deep) or one workgroup (enc_block,
- * dec_deep) --, the result record and the output come back in ONE copy.  The general road costs a plan upload, four
+ * (enc_tiny / dec_tiny) up to MINI_MAX_IN bytes, beyond that one workgroup (enc_block, dec_block; with long codes one
+ * wave of dec_deep) --, the result record and the output come back in ONE copy.  The general road costs a plan upload, four
  * small pageable copies, four or five launches and two synchronisations for the same call.
  */
 enum {
     MINI_MAX_IN = 128,     /* symbols to encode / encoded bytes (carried ones included) that are ONE THREAD's work */
     MINI_IN_AT = 64,       /* block layout: [0] item record, [64] input (decode: 16 bytes for the carried ones first), */
-    MINI_ZERO_AT = 6208,   /* [6208] zero word, [6272] scratch, */
-    MINI_SCRATCH_AT = 6272,
-    MINI_RESULT_AT = 6336, /* [6336] result record, [6400] output */
-    MINI_OUT_AT = 6400,
-    MINI_BLOCK = 16384,
+    MINI_ZERO_AT = 8320,   /* [8320] zero word, [8384] scratch, */
+    MINI_SCRATCH_AT = 8384,
+    MINI_RESULT_AT = 8448, /* [8448] result record, [8512] output */
+    MINI_OUT_AT = 8512,
+    MINI_BLOCK = 32768,
     MINI_MAX_OUT = MINI_BLOCK - MINI_OUT_AT
 };
 
@@ -1540,9 +1540,10 @@ int aws_huffman_amd_engine_decode_host(
     const uint64_t most_symbols = stream_bits / eng->tables.min_bits;
     const uint64_t dev_out = out_capacity < most_symbols ? out_capacity : most_symbols;
     eng->mini_output = false;
-    /* (decode: one thread, or one wave up to HUFD_DEC_COOP_BYTES; a workgroup of dec_deep's lanes was tried for a few
-     * KiB -- 1.5 ms for 4 KiB: lanes of 24 bytes rarely settle in one round -- the chunk kernels take those) */
-    if (carry_bytes + in_len <= HUFD_DEC_COOP_BYTES && carry_bytes + in_len > 0 && dev_out <= MINI_MAX_OUT && mini_ready(eng)) {
+    /* (decode: one thread, or one workgroup up to HUFD_DEC_BLOCK_BYTES -- with long codes one wave up to
+     * HUFD_DEC_COOP_BYTES; the chunk kernels take what is longer) */
+    const uint64_t mini_in = eng->tables.deep_entries ? HUFD_DEC_COOP_BYTES : HUFD_DEC_BLOCK_BYTES;
+    if (carry_bytes + in_len <= mini_in && carry_bytes + in_len > 0 && dev_out <= MINI_MAX_OUT && mini_ready(eng)) {
         struct hufd_dec_item rec;
         memset(&rec, 0, sizeof(rec));
         rec.in_off = MINI_IN_AT + 16 - carry_bytes;
@@ -1557,18 +1558,22 @@ int aws_huffman_amd_engine_decode_host(
         ON_DEVICE(eng->device);
         int e = hufs_copy_h2d(eng->mini_dev, eng->mini_host, MINI_IN_AT + 16 + in_len, eng->stream);
         if (!e) {
-            /* a lone thread up to MINI_MAX_IN bytes, a wave (a workgroup with long codes) above */
+            /* a lone thread up to MINI_MAX_IN bytes, a workgroup (a wave with long codes) above */
             if (carry_bytes + in_len <= MINI_MAX_IN) {
                 e = hufk_decode_one_tiny(
                     &eng->tables, (const struct hufd_dec_item *)eng->mini_dev, (const uint32_t *)(eng->mini_dev + MINI_ZERO_AT),
                     eng->mini_dev, eng->mini_dev, (struct hufd_dec_item_state *)(eng->mini_dev + MINI_SCRATCH_AT),
                     (struct hufd_dec_result *)(eng->mini_dev + MINI_RESULT_AT), eng->stream);
-            } else {
+            } else if (eng->tables.deep_entries) {
                 e = hufk_decode_one_coop(
                     &eng->tables, (const struct hufd_dec_item *)eng->mini_dev, (const uint32_t *)(eng->mini_dev + MINI_ZERO_AT),
                     eng->mini_dev, eng->mini_dev, (struct hufd_dec_item_state *)(eng->mini_dev + MINI_SCRATCH_AT),
-                    (struct hufd_dec_result *)(eng->mini_dev + MINI_RESULT_AT), carry_bytes + in_len > HUFD_DEC_COOP_BYTES,
-                    eng->stream);
+                    (struct hufd_dec_result *)(eng->mini_dev + MINI_RESULT_AT), eng->stream);
+            } else {
+                e = hufk_decode_one_block(
+                    &eng->tables, &rec, eng->mini_dev, eng->mini_dev,
+                    (struct hufd_dec_item_state *)(eng->mini_dev + MINI_SCRATCH_AT),
+                    (struct hufd_dec_result *)(eng->mini_dev + MINI_RESULT_AT), eng->stream);
             }
         }
         if (!e) {
@@ -1584,6 +1589,9 @@ int aws_huffman_amd_engine_decode_host(
         }
         struct hufd_dec_result raw;
         memcpy(&raw, eng->mini_host + MINI_RESULT_AT, sizeof(raw));
+        if (raw.stop_kind == HUFD_STOP_GAVE_UP) {
+            goto chunked; /* a stream dec_block's lanes do not settle on: nothing is decoded yet */
+        }
         struct aws_huffman_amd_decode_item as_item;
         memset(&as_item, 0, sizeof(as_item));
         as_item.in_len = carry_bytes + in_len;
@@ -1596,6 +1604,7 @@ int aws_huffman_amd_engine_decode_host(
         }
         return AWS_OP_SUCCESS;
     }
+chunked:
     if (one_shot_reserve(eng, 16 + in_len + 16, dev_out + 16)) {
         return AWS_OP_ERR;
     }

@@ -359,6 +359,54 @@ def garbage_decode(w, seed=15, rounds=120, big=70000):
         assert dst[: r.produced].tobytes().hex() == rec["symbols"]
 
 
+# ----------------------------------------------------------------------------- scenario: host-pointer decode calls of one workgroup's size (dec_block: up to 8 KiB encoded)
+def block_decode_calls(w, seed=73):
+    rng = np.random.default_rng(seed)
+
+    def both(coders, stream, caps, first=None):
+        for cap in caps:
+            oo, op = np.full(cap + 8, SENTINEL, np.uint8), np.full(cap + 8, SENTINEL, np.uint8)
+            ddo, ddp = w.oracle.new_decoder(coders[0]), w.product.new_decoder(coders[1])
+            if first:  # a first call that leaves bits in the decoder's window: the next one starts inside a byte
+                r = paired_decode(w, ddo, ddp, stream, 0, first, oo, op, 0, min(cap, 2))
+                paired_decode(w, ddo, ddp, stream, r.consumed, stream.size, oo, op, r.produced, cap)
+            else:
+                paired_decode(w, ddo, ddp, stream, 0, stream.size, oo, op, 0, cap)
+
+    plain = (w.ocoder, w.pcoder)
+    # whole valid streams around the road's limits: 129 and 8192 encoded bytes, a lane's 8 bytes, a wave's 512
+    for kind in KINDS:
+        for want in (129, 130, 136, 137, 511, 512, 513, 520, 1000, 4096, 8184, 8191, 8192, 8193):
+            n = want  # symbols; trimmed until the stream has the wanted length
+            data = inputs(rng, 2 * want, kind)
+            lo, hi = 0, data.size
+            while lo < hi:  # the most symbols whose stream is at most `want` bytes
+                mid = (lo + hi + 1) // 2
+                if (w.oracle.encoded_length(w.oracle.new_encoder(w.ocoder), data[:mid]) + 7) // 8 <= want:
+                    lo = mid
+                else:
+                    hi = mid - 1
+            n = lo
+            stream = oracle_encode(w, data[:n])
+            both(plain, stream, (n, n - 1, n // 2, n + 9, 0))
+            both(plain, stream, (n,), first=3)
+            both(plain, stream[: stream.size - 1], (n,))  # the last code cut off (or the padding missing)
+    # any bytes at all; bytes that never fall into step (one value); no code at all for 30 bits of ones in the middle
+    for size in (200, 777, 2048, 5000, 8192):
+        both(plain, rng.integers(0, 256, size, dtype=np.uint8), (2 * size, 17))
+        for v in (0x00, 0xFF, 0x55, 0x9C):
+            both(plain, np.full(size, v, np.uint8), (2 * size, size // 3))
+    good = oracle_encode(w, inputs(rng, 3000, "uniform"))
+    for at in (0, 8, 63, 64, 1000, good.size - 9, good.size - 5, good.size - 4):
+        bad = good.copy()
+        bad[at : at + 4] = 0xFF
+        both(plain, bad, (3000, 40))
+    # a coder with holes: windows without a code stop the walk where the reference's does
+    holes = (w.ocoder_holes, w.pcoder_holes)
+    for size in (300, 3000, 8000):
+        both(holes, rng.integers(0, 256, size, dtype=np.uint8), (2 * size, 5))
+
+
 # ----------------------------------------------------------------------------- scenario: long streams with damage / short output (several scan runs)
 def damaged_long_streams(w, seed=19, big=10_000_000):
     """Streams of several hundred chunks (more than one scan run of 256 chunks): damage inside a

@@ -49,6 +49,10 @@ def test_garbage_decode(world):
     pc.garbage_decode(world)
 
 
+def test_block_decode_calls(world):
+    pc.block_decode_calls(world)
+
+
 def test_eos_padding_values(world):
     pc.eos_padding_values(world)
 

@@ -56,6 +56,10 @@ def test_garbage_decode(world):
     pc.garbage_decode(world)
 
 
+def test_block_decode_calls(world):
+    pc.block_decode_calls(world)
+
+
 def test_damaged_long_streams(world):
     pc.damaged_long_streams(world)
 
