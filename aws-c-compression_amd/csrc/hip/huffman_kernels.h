@@ -44,6 +44,12 @@ struct hufk_encode_args {
     void **stage_events; /* NULL, or 4 hipEvent_t: before count, after count, after scan, after pack */
 };
 
+struct hufk_wide_item {
+    uint32_t slot;         /* of the item's index in deep_items */
+    uint32_t n_blocks;     /* 32 KiB blocks (HUFD_WIDE_BLOCK_BYTES) */
+    uint64_t block_offset; /* of its scratch in wide_block */
+};
+
 struct hufk_decode_args {
     struct hufd_tables tables;
     const struct hufd_dec_item *items;
@@ -56,6 +62,12 @@ struct hufk_decode_args {
     uint32_t n_tiny;
     const uint32_t *deep_items;  /* [n_deep] longer items of a coder with codes of more than HUFD_DEC_MAX_LUT_BITS bits: no chunks, one workgroup each */
     uint32_t n_deep;
+    /* the deep items of at least wide_from bytes: every 32 KiB block of one is a workgroup's (dec_wide_*) */
+    const struct hufk_wide_item *wide; /* [n_wide], HOST memory */
+    uint32_t n_wide;
+    uint64_t wide_from;
+    void *wide_block; /* scratch: hufk_decode_wide_bytes(blocks) each, at the offsets in `wide` */
+    uint32_t wide_fails; /* 1: they give up (tests of the way back) */
     const uint32_t *large_items; /* per item with more than HUFD_SCAN_SMALL_MAX chunks: item index, its first run */
     uint32_t n_large;
     const uint32_t *runs;        /* per run of HUFD_SCAN_RUN_CHUNKS chunks of a large item: item index, run number */
@@ -115,6 +127,8 @@ int hufk_encode_one_tiny(
 int hufk_decode_one_tiny(
     const struct hufd_tables *tables, const struct hufd_dec_item *item, const uint32_t *zero, const void *d_in, void *d_out,
     struct hufd_dec_item_state *state, struct hufd_dec_result *result, void *stream);
+/* scratch bytes of one wide item of n_blocks blocks */
+uint64_t hufk_decode_wide_bytes(uint64_t n_blocks);
 /* the same for an item of up to HUFD_DEC_COOP_BYTES encoded bytes (any size with long codes): dec_deep, one launch */
 int hufk_decode_one_coop(
     const struct hufd_tables *tables, const struct hufd_dec_item *item, const uint32_t *zero, const void *d_in, void *d_out,

@@ -4596,37 +4596,43 @@ struct stream_reader {
     }
 };
 
-/* decoded symbols on their way to memory: single bytes up to a 4-byte boundary, whole words from there
- * (a one-lane-one-stream walk pays per store, not per byte) */
+/* decoded symbols on their way to memory, sixteen at a time (a one-lane-one-stream walk pays per store, not per
+ * byte, and a 16-byte store needs no alignment) */
 struct symbol_sink {
     u8 *at; /* where the next flushed symbol goes */
-    u32 acc, have;
+    u64 lo, hi;
+    u32 have;
 
     __device__ __forceinline__ void begin(u8 *first) {
         at = first;
-        acc = 0;
+        lo = hi = 0;
         have = 0;
     }
     __device__ __forceinline__ void put(u32 symbol) {
-        if (have == 0 && (reinterpret_cast<uintptr_t>(at) & 3u) != 0) {
-            *at++ = (u8)symbol;
-            return;
+        if (have < 8) {
+            lo |= (u64)symbol << (8 * have);
+        } else {
+            hi |= (u64)symbol << (8 * (have - 8));
         }
-        acc |= symbol << (8 * have);
-        if (++have == 4) {
-            *reinterpret_cast<u32 *>(at) = acc;
-            at += 4;
-            acc = 0;
+        if (++have == 16) {
+            unaligned_uint4 v;
+            v.x = (u32)lo;
+            v.y = (u32)(lo >> 32);
+            v.z = (u32)hi;
+            v.w = (u32)(hi >> 32);
+            *reinterpret_cast<unaligned_uint4 *>(at) = v;
+            at += 16;
+            lo = hi = 0;
             have = 0;
         }
     }
     __device__ __forceinline__ void flush() {
         for (u32 k = 0; k < have; ++k) {
-            at[k] = (u8)(acc >> (8 * k));
+            at[k] = (u8)((k < 8 ? lo >> (8 * k) : hi >> (8 * (k - 8))));
         }
         at += have;
         have = 0;
-        acc = 0;
+        lo = hi = 0;
     }
 };
 
@@ -4750,7 +4756,7 @@ struct deep_walked {
 
 /* follows the codes from stream bit `from` to the first code start at or behind `to`; writes symbol number
  * index + k to out[index + k] while that is below out_cap (out == NULL: count only) */
-template <bool DEEP>
+template <bool DEEP, bool GUESS = false> /* GUESS: a window without a code is stepped over a bit at a time (a walk that only looks for where the codes fall into step) */
 __device__ __forceinline__ deep_walked deep_walk(
     const u32 *deep, const u16 *lut, u32 lut_bits, const u8 *in, u64 in_len, u64 from, u64 to, u8 *out, u64 index, u64 out_cap, u64 *cap_bit) {
     const u64 rem = in_len * 8;
@@ -4772,6 +4778,11 @@ __device__ __forceinline__ deep_walked deep_walk(
         const u32 entry = DEEP ? deep_entry(deep, sr.peek()) : lut[sr.peek() >> (32 - lut_bits)];
         const u32 len = entry & 0xFFu;
         if (len == 0) {
+            if (GUESS) {
+                sr.skip(1);
+                r.pos += 1;
+                continue;
+            }
             r.why = HUFD_STOP_INVALID;
             break;
         }
@@ -4795,6 +4806,45 @@ __device__ __forceinline__ deep_walked deep_walk(
     return r;
 }
 
+/* What a lane's walks from its last few entries came to.  A stream whose walks never fall into step (code lengths
+ * that share a divisor) sends the news of an entry a lane a round down the block; the lanes see the same few entries
+ * over and over, and with these a round costs a look instead of a walk. */
+struct lane_memo {
+    u32 key[4], exit[4], count[4];
+    u32 n;
+    __device__ __forceinline__ void clear() {
+        n = 0;
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) {
+            key[k] = ~0u;
+        }
+    }
+    __device__ __forceinline__ bool find(u32 start, u32 &ex, u32 &cnt) const {
+        bool hit = false;
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) {
+            if (key[k] == start) {
+                ex = exit[k];
+                cnt = count[k];
+                hit = true;
+            }
+        }
+        return hit;
+    }
+    __device__ __forceinline__ void put(u32 start, u32 ex, u32 cnt) {
+        const u32 slot = n & 3u;
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) {
+            if (k == slot) {
+                key[k] = start;
+                exit[k] = ex;
+                count[k] = cnt;
+            }
+        }
+        ++n;
+    }
+};
+
 template <bool DEEP>
 __global__ __launch_bounds__(kDeepThreads) void dec_deep_kernel(
     hufd_tables tb,
@@ -4804,8 +4854,13 @@ __global__ __launch_bounds__(kDeepThreads) void dec_deep_kernel(
     const u8 *d_in,
     u8 *d_out,
     hufd_dec_item_state *states,
-    hufd_dec_result *results) {
+    hufd_dec_result *results,
+    u64 wide_from,   /* gate == NULL: items of at least this many bytes are not this launch's (dec_wide_* take them) */
+    const u32 *gate) /* != NULL: one such item after all, if dec_wide_* gave it up (the word is their ctl[0]) */ {
 
+    if (gate ? gate[0] == 0 : items[deep_items[blockIdx.x]].in_len >= wide_from) {
+        return;
+    }
     deep_shared &sh = *reinterpret_cast<deep_shared *>(dyn_lds);
     u32 *deep = reinterpret_cast<u32 *>(dyn_lds + sizeof(deep_shared));
     u16 *lut = reinterpret_cast<u16 *>(dyn_lds + sizeof(deep_shared));
@@ -4846,11 +4901,14 @@ __global__ __launch_bounds__(kDeepThreads) void dec_deep_kernel(
         const u64 lane_from = (b * round_bytes + (u64)l * lane_bytes) * 8, lane_to = lane_from + lane_bits;
         u32 start = l == 0 ? entry : 0u, my_exit = kDeepStop, my_count = 0;
         bool reached = true, walk = active;
+        lane_memo memo;
+        memo.clear();
         for (;;) {
-            if (walk) {
+            if (walk && !memo.find(start, my_exit, my_count)) {
                 const deep_walked r = deep_walk<DEEP>(deep, lut, tb.lut_bits, in, it.in_len, lane_from + start, lane_to, nullptr, 0, 0, nullptr);
                 my_exit = r.why == HUFD_STOP_NONE ? (u32)(r.pos - lane_to) : kDeepStop;
                 my_count = r.count;
+                memo.put(start, my_exit, my_count);
             }
             sh.exit_of[l] = active && reached ? my_exit : kDeepStop;
             if (l == 0) {
@@ -4922,6 +4980,289 @@ __global__ __launch_bounds__(kDeepThreads) void dec_deep_kernel(
         }
         results[item] = rs;
         states[item].total_symbols = symbols;
+    }
+}
+
+/*
+ * ONE LONG item of a coder with long codes, across the chip.  dec_deep gives such an item one workgroup that takes it
+ * 32 KiB at a time: 0.12 GB/s whatever its length, and HPACK's own code is such a coder.  Here every 32 KiB block is a
+ * workgroup's, in four launches:
+ *   dec_wide_settle<1>  the block's lanes settle on their entries as dec_deep's do, from a GUESS for lane 0 (block 0:
+ *                       the item's true first bit); how the block is left goes to exit1[block];
+ *   dec_wide_settle<2>  lane 0 takes exit1[block - 1] for its entry and the lanes settle again (a handful of them walk:
+ *                       walks from different entries fall into step within a few codes); exit2, the block's symbols;
+ *   dec_wide_scan       where each block's symbols go, the item's total, its result record;
+ *   dec_wide_emit       the walk that writes the symbols.
+ * exit1[b - 1] is block b's true entry if block b - 1 is left the same way from its guess and from its true entry --
+ * by induction from block 0: if exit2 == exit1 for every block, every block had its true entry in the second launch.
+ * One block that is left differently (a stream whose walks never fall into step) raises ctl[0]: the last three kernels
+ * do nothing then and dec_deep, queued behind them with that word as its gate, decodes the item its way.  A walk that
+ * stops (source/huffman.c:232-255) says nothing to the lane or block behind it while entries are guesses; of the
+ * settled lanes the first that stops ends the stream, and what lies behind it is not part of it.
+ */
+constexpr u32 kWideStop = 0xFFu;
+constexpr u32 kWideGuessBytes = 32;
+static_assert(HUFD_WIDE_BLOCK_BYTES == kDeepThreads * kDeepLaneBytes, "a block is one round of dec_deep's lanes");
+
+struct dec_wide_layout {
+    u64 ctl;        /* u32[4]: [0] gave up, [1] the first block whose true walk stops */
+    u64 exit1;      /* u32[n_blocks] */
+    u64 exit2;      /* u32[n_blocks] */
+    u64 count2;     /* u32[n_blocks] symbols of the block's lanes up to the first that stops */
+    u64 base;       /* u64[n_blocks] symbols in front of the block */
+    u64 lane_start; /* u8[n_blocks][kDeepThreads] entry bit of the lane, kWideStop: not part of the stream */
+    u64 lane_exit;  /* u8[n_blocks][kDeepThreads] */
+    u64 lane_count; /* u16[n_blocks][kDeepThreads] */
+    u64 bytes;
+};
+
+__host__ __device__ inline dec_wide_layout dec_wide_layout_of(u64 n_blocks) {
+    dec_wide_layout l;
+    u64 at = 0;
+    l.ctl = at;
+    at += 64;
+    l.exit1 = at;
+    at += (n_blocks * 4 + 63) & ~63ull;
+    l.exit2 = at;
+    at += (n_blocks * 4 + 63) & ~63ull;
+    l.count2 = at;
+    at += (n_blocks * 4 + 63) & ~63ull;
+    l.base = at;
+    at += (n_blocks * 8 + 63) & ~63ull;
+    l.lane_start = at;
+    at += n_blocks * kDeepThreads;
+    l.lane_exit = at;
+    at += n_blocks * kDeepThreads;
+    l.lane_count = at;
+    at += n_blocks * kDeepThreads * 2;
+    l.bytes = at;
+    return l;
+}
+
+struct wide_shared {
+    u32 exit_of[kDeepThreads];
+    u32 scan[kDeepThreads];
+    u32 changed[2];
+    u32 last_lane;
+    u32 pad;
+};
+
+template <u32 PASS>
+__global__ __launch_bounds__(kDeepThreads) void dec_wide_settle_kernel(
+    hufd_tables tb, const hufd_dec_item *items, const u32 *the_item, const u8 *d_in, u8 *block, u32 fails) {
+
+    const hufd_dec_item it = items[the_item[0]];
+    const u64 n_blocks = (it.in_len + (u64)kDeepThreads * kDeepLaneBytes - 1) / ((u64)kDeepThreads * kDeepLaneBytes);
+    const dec_wide_layout lay = dec_wide_layout_of(n_blocks);
+    u32 *ctl = reinterpret_cast<u32 *>(block + lay.ctl);
+    u32 *exit1 = reinterpret_cast<u32 *>(block + lay.exit1), *exit2 = reinterpret_cast<u32 *>(block + lay.exit2);
+    const u64 b = blockIdx.x;
+    const u32 l = threadIdx.x;
+    u8 *lane_start = block + lay.lane_start + b * kDeepThreads, *lane_exit = block + lay.lane_exit + b * kDeepThreads;
+    u16 *lane_count = reinterpret_cast<u16 *>(block + lay.lane_count) + b * kDeepThreads;
+
+    wide_shared &sh = *reinterpret_cast<wide_shared *>(dyn_lds);
+    u32 *deep = reinterpret_cast<u32 *>(dyn_lds + sizeof(wide_shared));
+    for (u32 i = l; i < tb.deep_entries; i += kDeepThreads) {
+        deep[i] = tb.deep_lut[i];
+    }
+    if (l == 0) {
+        sh.last_lane = kDeepThreads;
+    }
+    __syncthreads();
+    const u8 *in = d_in + it.in_off;
+    const u64 block_from = b * kDeepThreads * kDeepLaneBytes;
+    const u64 block_bytes = it.in_len - block_from < (u64)kDeepThreads * kDeepLaneBytes ? it.in_len - block_from : (u64)kDeepThreads * kDeepLaneBytes;
+    const u32 n_lanes = (u32)((block_bytes + kDeepLaneBytes - 1) / kDeepLaneBytes);
+    const bool active = l < n_lanes;
+    const u64 lane_from = (block_from + (u64)l * kDeepLaneBytes) * 8, lane_to = lane_from + kDeepLaneBytes * 8;
+    u32 start, my_exit = kWideStop, my_count = 0;
+    bool walk;
+    lane_memo memo;
+    memo.clear();
+    if (PASS == 1) {
+        start = b == 0 && l == 0 ? it.first_bit : 0u;
+        walk = active;
+        if (active && (b | l) != 0) {
+            /* the first guess: where a walk from anywhere over the 32 bytes in front of the lane crosses into it (on the
+             * HPACK code lengths: right for every lane tried; over 16 bytes, for 29 in 30 -- and one wrong lane is a
+             * second walk for its whole wave) */
+            const deep_walked g = deep_walk<true, true>(
+                deep, nullptr, 0, in, it.in_len, lane_from - kWideGuessBytes * 8, lane_from, nullptr, 0, 0, nullptr);
+            start = g.why == HUFD_STOP_NONE ? (u32)(g.pos - lane_from) : 0u;
+        }
+    } else {
+        start = lane_start[l];
+        my_exit = lane_exit[l];
+        my_count = lane_count[l];
+        memo.put(start, my_exit, my_count);
+        walk = false;
+        if (l == 0 && b > 0) {
+            const u32 entry = exit1[b - 1];
+            if (entry == kWideStop) {
+                /* the block in front stops from its guess: if it does from its true entry too, this block is not part
+                 * of the stream and whatever is written for it is not looked at; if not, that block raises ctl[0] */
+            } else if (entry != start) {
+                start = entry;
+                walk = true;
+            }
+        }
+    }
+    for (u32 round = 0;; ++round) {
+        if (walk && !memo.find(start, my_exit, my_count)) {
+            const deep_walked r = deep_walk<true>(deep, nullptr, 0, in, it.in_len, lane_from + start, lane_to, nullptr, 0, 0, nullptr);
+            my_exit = r.why == HUFD_STOP_NONE ? (u32)(r.pos - lane_to) : kWideStop;
+            my_count = r.count;
+            memo.put(start, my_exit, my_count);
+        }
+        sh.exit_of[l] = active ? my_exit : kWideStop;
+        if (l == 0) {
+            sh.changed[round & 1u] = 0; /* (the flag of the round before last: everyone has read it) */
+        }
+        __syncthreads();
+        walk = false;
+        if (active && l > 0) {
+            const u32 prev = sh.exit_of[l - 1];
+            if (prev != kWideStop && prev != start) {
+                start = prev;
+                walk = true;
+                sh.changed[round & 1u] = 1;
+            }
+        }
+        __syncthreads();
+        if (!sh.changed[round & 1u]) {
+            break;
+        }
+    }
+    if (active && my_exit == kWideStop) {
+        atomicMin(&sh.last_lane, l);
+    }
+    __syncthreads();
+    const u32 last_lane = sh.last_lane;
+    const bool reached = active && l <= last_lane;
+    const u32 block_exit = last_lane < n_lanes ? kWideStop : sh.exit_of[n_lanes - 1];
+    if (PASS == 1) {
+        lane_start[l] = (u8)start;
+        lane_exit[l] = (u8)my_exit;
+        lane_count[l] = (u16)my_count;
+        if (l == 0) {
+            exit1[b] = block_exit;
+        }
+        return;
+    }
+    lane_start[l] = (u8)(reached ? start : kWideStop);
+    lane_count[l] = (u16)(reached ? my_count : 0u);
+    sh.scan[l] = reached ? my_count : 0u;
+    __syncthreads();
+    for (u32 d = kDeepThreads / 2; d > 0; d /= 2) {
+        if (l < d) {
+            sh.scan[l] += sh.scan[l + d];
+        }
+        __syncthreads();
+    }
+    if (l == 0) {
+        exit2[b] = block_exit;
+        reinterpret_cast<u32 *>(block + lay.count2)[b] = sh.scan[0];
+        if ((block_exit != exit1[b] && b + 1 < n_blocks) || fails) {
+            atomicOr(&ctl[0], 1u); /* the block behind this one had a wrong entry */
+        }
+        if (block_exit == kWideStop) {
+            atomicMin(&ctl[1], (u32)b);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dec_wide_scan_kernel(
+    const hufd_dec_item *items, const u32 *the_item, u8 *block, hufd_dec_item_state *states, hufd_dec_result *results) {
+
+    const u32 item = the_item[0];
+    const hufd_dec_item it = items[item];
+    const u64 n_blocks = (it.in_len + (u64)kDeepThreads * kDeepLaneBytes - 1) / ((u64)kDeepThreads * kDeepLaneBytes);
+    const dec_wide_layout lay = dec_wide_layout_of(n_blocks);
+    const u32 *ctl = reinterpret_cast<const u32 *>(block + lay.ctl);
+    if (ctl[0]) {
+        return;
+    }
+    const u32 *count2 = reinterpret_cast<const u32 *>(block + lay.count2);
+    u64 *base = reinterpret_cast<u64 *>(block + lay.base);
+    u64 *part = reinterpret_cast<u64 *>(dyn_lds); /* [256] */
+    const u32 l = threadIdx.x;
+    const u64 stop_block = ctl[1]; /* blocks behind it are not part of the stream */
+    const u64 counted = stop_block < n_blocks ? stop_block + 1 : n_blocks;
+    const u64 per = (counted + 255) / 256, lo = l * per < counted ? l * per : counted, hi = lo + per < counted ? lo + per : counted;
+    u64 sum = 0;
+    for (u64 k = lo; k < hi; ++k) {
+        sum += count2[k];
+    }
+    part[l] = sum;
+    __syncthreads();
+    for (u32 d = 1; d < 256; d *= 2) {
+        const u64 add = l >= d ? part[l - d] : 0;
+        __syncthreads();
+        part[l] += add;
+        __syncthreads();
+    }
+    u64 run = part[l] - sum;
+    for (u64 k = lo; k < hi; ++k) {
+        base[k] = run;
+        run += count2[k];
+    }
+    if (l == 255) {
+        const u64 total = part[255];
+        hufd_dec_result rs;
+        rs.total_symbols = total;
+        rs.cap_bit = kNoBit;
+        rs.reserved = 0;
+        /* the lane that stops fills these in; none does: the last code ended on the last bit of the stream */
+        rs.stop_kind = stop_block < n_blocks ? HUFD_STOP_NONE : HUFD_STOP_END;
+        rs.stop_bit = stop_block < n_blocks ? kNoBit : it.in_len * 8;
+        results[item] = rs;
+        states[item].total_symbols = total;
+    }
+}
+
+__global__ __launch_bounds__(kDeepThreads) void dec_wide_emit_kernel(
+    hufd_tables tb, const hufd_dec_item *items, const u32 *the_item, const u8 *d_in, u8 *d_out, u8 *block, hufd_dec_result *results) {
+
+    const u32 item = the_item[0];
+    const hufd_dec_item it = items[item];
+    const u64 n_blocks = (it.in_len + (u64)kDeepThreads * kDeepLaneBytes - 1) / ((u64)kDeepThreads * kDeepLaneBytes);
+    const dec_wide_layout lay = dec_wide_layout_of(n_blocks);
+    const u32 *ctl = reinterpret_cast<const u32 *>(block + lay.ctl);
+    const u64 b = blockIdx.x;
+    if (ctl[0] || b > ctl[1]) {
+        return;
+    }
+    const u32 l = threadIdx.x;
+    wide_shared &sh = *reinterpret_cast<wide_shared *>(dyn_lds);
+    u32 *deep = reinterpret_cast<u32 *>(dyn_lds + sizeof(wide_shared));
+    for (u32 i = l; i < tb.deep_entries; i += kDeepThreads) {
+        deep[i] = tb.deep_lut[i];
+    }
+    const u32 start = (block + lay.lane_start + b * kDeepThreads)[l];
+    const u32 mine = (reinterpret_cast<const u16 *>(block + lay.lane_count) + b * kDeepThreads)[l];
+    sh.scan[l] = mine;
+    __syncthreads();
+    for (u32 d = 1; d < kDeepThreads; d *= 2) {
+        const u32 add = l >= d ? sh.scan[l - d] : 0u;
+        __syncthreads();
+        sh.scan[l] += add;
+        __syncthreads();
+    }
+    if (start == kWideStop) {
+        return;
+    }
+    const u64 first = reinterpret_cast<const u64 *>(block + lay.base)[b] + (sh.scan[l] - mine);
+    const u64 lane_from = (b * kDeepThreads + l) * (u64)kDeepLaneBytes * 8, lane_to = lane_from + kDeepLaneBytes * 8;
+    u64 cap_bit = kNoBit;
+    const deep_walked r = deep_walk<true>(
+        deep, nullptr, 0, d_in + it.in_off, it.in_len, lane_from + start, lane_to, d_out + it.out_off, first, it.out_cap, &cap_bit);
+    if (cap_bit != kNoBit) {
+        results[item].cap_bit = cap_bit;
+    }
+    if (r.why != HUFD_STOP_NONE) {
+        results[item].stop_kind = r.why;
+        results[item].stop_bit = r.pos;
     }
 }
 
@@ -7235,6 +7576,10 @@ int hufk_decode_one_tiny(
     return (int)hipGetLastError();
 }
 
+uint64_t hufk_decode_wide_bytes(uint64_t n_blocks) {
+    return (dec_wide_layout_of(n_blocks).bytes + 255) & ~255ull;
+}
+
 int hufk_decode_one_block(
     const struct hufd_tables *tables, const struct hufd_dec_item *item, const void *d_in, void *d_out,
     struct hufd_dec_item_state *state, struct hufd_dec_result *result, void *stream) {
@@ -7253,13 +7598,14 @@ int hufk_decode_one_coop(
     if (tables->deep_entries) {
         hipLaunchKernelGGL(
             dec_deep_kernel<true>, dim3(1), dim3(kDeepThreads), sizeof(deep_shared) + tables->deep_entries * sizeof(u32),
-            (hipStream_t)stream, *tables, item, zero, kDeepLaneBytes, (const u8 *)d_in, (u8 *)d_out, state, result);
+            (hipStream_t)stream, *tables, item, zero, kDeepLaneBytes, (const u8 *)d_in, (u8 *)d_out, state, result, ~0ull,
+            (const u32 *)nullptr);
     } else {
         /* (one wave: the lanes share the item evenly) */
         hipLaunchKernelGGL(
             dec_deep_kernel<false>, dim3(1), dim3(kCoopThreads),
             sizeof(deep_shared) + (1u << tables->lut_bits) * sizeof(u16), (hipStream_t)stream, *tables, item, zero, 0u,
-            (const u8 *)d_in, (u8 *)d_out, state, result);
+            (const u8 *)d_in, (u8 *)d_out, state, result, ~0ull, (const u32 *)nullptr);
     }
     return (int)hipGetLastError();
 }
@@ -7478,13 +7824,39 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             (u8 *)a->d_out, a->states, a->results);
     }
     if (a->n_deep && a->tables.deep_entries) {
+        const uint32_t deep_lds = (uint32_t)(sizeof(deep_shared) + a->tables.deep_entries * sizeof(u32));
+        const uint32_t wide_lds = (uint32_t)(sizeof(wide_shared) + a->tables.deep_entries * sizeof(u32));
+        const uint64_t wide_from = a->n_wide ? a->wide_from : ~0ull;
         hipLaunchKernelGGL(
-            dec_deep_kernel<true>, dim3(a->n_deep), dim3(kDeepThreads), sizeof(deep_shared) + a->tables.deep_entries * sizeof(u32),
-            st, a->tables, a->items, a->deep_items, kDeepLaneBytes, (const u8 *)a->d_in, (u8 *)a->d_out, a->states, a->results);
+            dec_deep_kernel<true>, dim3(a->n_deep), dim3(kDeepThreads), deep_lds, st, a->tables, a->items, a->deep_items,
+            kDeepLaneBytes, (const u8 *)a->d_in, (u8 *)a->d_out, a->states, a->results, wide_from, (const u32 *)nullptr);
+        /* the long ones across the chip (dec_wide_*), each with dec_deep behind it in case they give it up */
+        for (uint32_t k = 0; k < a->n_wide; ++k) {
+            const u32 *the_item = a->deep_items + a->wide[k].slot;
+            u8 *blk = (u8 *)a->wide_block + a->wide[k].block_offset;
+            const uint32_t n_blocks = a->wide[k].n_blocks;
+            const dec_wide_layout lay = dec_wide_layout_of(n_blocks);
+            (void)hipMemsetAsync(blk + lay.ctl, 0, 4, st);
+            (void)hipMemsetAsync(blk + lay.ctl + 4, 0xFF, 4, st);
+            hipLaunchKernelGGL(
+                dec_wide_settle_kernel<1>, dim3(n_blocks), dim3(kDeepThreads), wide_lds, st, a->tables, a->items, the_item,
+                (const u8 *)a->d_in, blk, 0u);
+            hipLaunchKernelGGL(
+                dec_wide_settle_kernel<2>, dim3(n_blocks), dim3(kDeepThreads), wide_lds, st, a->tables, a->items, the_item,
+                (const u8 *)a->d_in, blk, a->wide_fails);
+            hipLaunchKernelGGL(dec_wide_scan_kernel, dim3(1), dim3(256), 256 * sizeof(u64), st, a->items, the_item, blk, a->states, a->results);
+            hipLaunchKernelGGL(
+                dec_wide_emit_kernel, dim3(n_blocks), dim3(kDeepThreads), wide_lds, st, a->tables, a->items, the_item,
+                (const u8 *)a->d_in, (u8 *)a->d_out, blk, a->results);
+            hipLaunchKernelGGL(
+                dec_deep_kernel<true>, dim3(1), dim3(kDeepThreads), deep_lds, st, a->tables, a->items, the_item, kDeepLaneBytes,
+                (const u8 *)a->d_in, (u8 *)a->d_out, a->states, a->results, 0ull, (const u32 *)(blk + lay.ctl));
+        }
     } else if (a->n_deep) {
         hipLaunchKernelGGL(
             dec_deep_kernel<false>, dim3(a->n_deep), dim3(kCoopThreads), sizeof(deep_shared) + (1u << a->tables.lut_bits) * sizeof(u16),
-            st, a->tables, a->items, a->deep_items, 0u, (const u8 *)a->d_in, (u8 *)a->d_out, a->states, a->results);
+            st, a->tables, a->items, a->deep_items, 0u, (const u8 *)a->d_in, (u8 *)a->d_out, a->states, a->results, ~0ull,
+            (const u32 *)nullptr);
     }
     if (a->n_large) {
         const uint32_t lds = scan_run_lds_bytes(ns);

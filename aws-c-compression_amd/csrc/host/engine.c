@@ -870,6 +870,13 @@ static uint64_t dec_tiny_limit(const struct aws_huffman_amd_decode_item *items, 
     return HUFD_TINY_FEW_BYTES;
 }
 
+/* deep items of at least this many encoded bytes go across the chip (tests lower it) */
+static uint64_t s_wide_min_bytes = HUFD_WIDE_MIN_BYTES;
+
+void aws_huffman_amd_testing_set_wide_min_bytes(uint64_t bytes) {
+    s_wide_min_bytes = bytes ? bytes : HUFD_WIDE_MIN_BYTES;
+}
+
 static bool dec_item_is_deep(
     const struct aws_huffman_amd_engine *eng, const struct aws_huffman_amd_decode_item *it, uint64_t tiny_limit) {
     /* (the same kernel, as one wave, takes every coder's items that are too short to be worth a chunk's workgroup) */
@@ -941,6 +948,10 @@ static int dec_plan_fill(
         return aws_raise_error(AWS_ERROR_OOM);
     }
     uint32_t chunk = 0, large = 0, run = 0, tail = 0, tiny = 0, deep = 0, tile = 0;
+    struct hufk_wide_item *h_wide = NULL;
+    uint32_t n_wide = 0;
+    uint64_t wide_bytes = 0;
+    bool wide_oom = false;
     uint64_t tail_stage = 0; /* the most symbols a chunk that holds the end of a stream can decode to */
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_decode_item *src = &items[i];
@@ -960,6 +971,19 @@ static int dec_plan_fill(
         } else if (dec_item_is_deep(eng, src, tiny_limit)) {
             dst->tiny = 1;
             h_tiny[n_items - ++deep] = (uint32_t)i;
+            if (eng->tables.deep_entries && src->in_len >= s_wide_min_bytes) {
+                struct hufk_wide_item *more = realloc(h_wide, (n_wide + 1) * sizeof(*more));
+                if (!more) {
+                    wide_oom = true;
+                } else {
+                    h_wide = more;
+                    h_wide[n_wide].slot = deep; /* from the back of the list, for now */
+                    h_wide[n_wide].n_blocks = (uint32_t)((src->in_len + HUFD_WIDE_BLOCK_BYTES - 1) / HUFD_WIDE_BLOCK_BYTES);
+                    h_wide[n_wide].block_offset = wide_bytes;
+                    wide_bytes += hufk_decode_wide_bytes(h_wide[n_wide].n_blocks);
+                    ++n_wide;
+                }
+            }
         }
         {
             const uint64_t subs = dec_item_inside_subs(chunks, src->in_len);
@@ -1012,9 +1036,18 @@ static int dec_plan_fill(
         }
     }
 
-    int err = 0;
+    int err = wide_oom ? 2 : 0;
     const uint32_t ns = eng->tables.n_states;
     ON_DEVICE(eng->device);
+    for (uint32_t k = 0; k < n_wide; ++k) {
+        h_wide[k].slot = deep - h_wide[k].slot; /* the deep items are the last `deep` of d_tiny, filled from the back */
+    }
+    if (!err && wide_bytes > p->cap_wide_block) {
+        hufs_free(p->d_wide_block);
+        p->d_wide_block = hufs_malloc(wide_bytes);
+        p->cap_wide_block = p->d_wide_block ? wide_bytes : 0;
+        err = p->d_wide_block ? 0 : 2;
+    }
     if (n_items > p->cap_items || n_chunks > p->cap_chunks || n_large > p->cap_large || n_runs > p->cap_runs) {
         dec_plan_release_device(p);
         const size_t ci = n_items ? n_items : 1, cc = n_chunks ? n_chunks : 1, cl = n_large ? n_large : 1;
@@ -1113,8 +1146,12 @@ static int dec_plan_fill(
     free(h_tiny);
     free(h_tiles);
     if (err) {
+        free(h_wide);
         return raise_hip(err);
     }
+    free(p->h_wide);
+    p->h_wide = h_wide;
+    p->n_wide = n_wide;
     p->n_items = (uint32_t)n_items;
     p->n_chunks = (uint32_t)n_chunks;
     p->n_large = (uint32_t)n_large;
@@ -1158,6 +1195,8 @@ void aws_huffman_amd_decode_plan_destroy(struct aws_huffman_amd_decode_plan *p) 
     if (p) {
         ON_DEVICE(p->engine->device);
         dec_plan_release_device(p);
+        hufs_free(p->d_wide_block);
+        free(p->h_wide);
         free(p->h_items);
         free(p);
     }
@@ -1190,6 +1229,10 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.tail_stage_bytes = p->tail_stage_bytes;
     a.deep_items = p->d_tiny + (p->n_items - p->n_deep);
     a.n_deep = p->n_deep;
+    a.wide = p->h_wide;
+    a.n_wide = p->n_wide;
+    a.wide_from = s_wide_min_bytes;
+    a.wide_block = p->d_wide_block;
     a.tiny_items = p->d_tiny;
     a.n_tiny = p->n_tiny;
     a.large_items = p->d_large;
@@ -1229,6 +1272,8 @@ int aws_huffman_amd_decode_plan_launch_staged(
          * passes, DESIGN.md 4 "One pass": not the default); "one-pass-fails" does the same with one tile made to give
          * up, so that the way back to the two-pass kernels can be tested */
         a.fuse_mode = mode && strcmp(mode, "one-pass") == 0 ? 0u : (mode && strcmp(mode, "one-pass-fails") == 0 ? 2u : 1u);
+        /* "wide-fails": dec_wide_* give every long item of a coder with long codes back to dec_deep (the way back, for tests) */
+        a.wide_fails = mode && strcmp(mode, "wide-fails") == 0;
     }
     a.tiles = p->d_tiles;
     a.n_tiles = p->n_tiles;

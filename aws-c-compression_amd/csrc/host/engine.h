@@ -115,6 +115,11 @@ struct aws_huffman_amd_decode_plan {
     size_t cap_tiles, cap_fuse_block;
     struct hufd_dec_item_state *d_states;
     struct hufd_dec_result *d_results;
+    /* the long items of a coder with long codes: a workgroup per 32 KiB block (dec_wide_*) */
+    struct hufk_wide_item *h_wide; /* [n_wide] */
+    uint32_t n_wide;
+    void *d_wide_block;
+    size_t cap_wide_block;
 };
 
 /* the engine cache of huffman.c: what an engine is recognised by besides the coder's address, and the two ways out of it */

@@ -177,6 +177,7 @@ EXPORTED_SYMBOLS = [
     "aws_huffman_amd_decode_plan_launch", "aws_huffman_amd_decode_plan_launch_staged",
     "aws_huffman_amd_decode_plan_results", "aws_huffman_amd_decode_plan_road", "aws_huffman_amd_encode_plan_road",
     "aws_huffman_amd_testing_set_decode_piece_bytes",
+    "aws_huffman_amd_testing_set_wide_min_bytes",
     "aws_huffman_amd_engine_device", "aws_huffman_amd_current_device", "aws_huffman_amd_encode_plan_reset",
     "aws_huffman_amd_decode_plan_reset",
     "aws_huffman_amd_device_count", "aws_huffman_amd_device_alloc", "aws_huffman_amd_device_free",
@@ -237,6 +238,7 @@ def load_product(path=None):
     _bind(lib, "aws_huffman_amd_decode_plan_road", C.c_int, [V, V, P(C.c_uint32), P(C.c_uint32)])
     _bind(lib, "aws_huffman_amd_encode_plan_road", C.c_int, [V, P(C.c_uint32)])
     _bind(lib, "aws_huffman_amd_testing_set_decode_piece_bytes", None, [C.c_size_t])
+    _bind(lib, "aws_huffman_amd_testing_set_wide_min_bytes", None, [C.c_uint64])
     _bind(lib, "aws_huffman_amd_device_count", C.c_int, [])
     _bind(lib, "aws_huffman_amd_engine_device", C.c_int, [V])
     _bind(lib, "aws_huffman_amd_current_device", C.c_int, [])

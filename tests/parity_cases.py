@@ -1034,6 +1034,89 @@ def tiny_decode_items(w, n_items=1500, seed=41, engine=None, profile=None, max_l
         eng.close()
 
 
+def wide_long_code_items(w, n=150_000, seed=79, modes=(None, "wide-fails")):
+    """Long items of coders with codes of more than 12 bits (decode through linked tables): a workgroup per 32 KiB
+    block (dec_wide_*) from 64 KiB on here; with "wide-fails" those kernels give every item back to dec_deep."""
+    rng = np.random.default_rng(seed)
+    w.product.lib.aws_huffman_amd_testing_set_wide_min_bytes(2 * 32768)
+    try:
+        for name in ("hpack_lengths", "len4to15"):
+            ocoder, pcoder, lengths = profile_coders(w, name)
+            prob = np.array([2.0 ** -min(l, 16) for l in lengths])
+            prob /= prob.sum()
+            eng = harness.Engine(w.product.lib, pcoder)
+            data = rng.choice(256, size=n, p=prob).astype(np.uint8)
+            good = w.oracle.encode_all(ocoder, data, slack=64 + 4 * n)
+            assert good.size >= 3 * 32768, good.size
+            damaged = good.copy()
+            damaged[good.size // 3: good.size // 3 + 5] = 0xFF  # (hpack: 30 ones have no code)
+            damaged2 = good.copy()
+            damaged2[40000] ^= 0x10  # other symbols from here on, for a while: block 1's guess meets another walk
+            streams = [
+                (good, 0, n), (good, 0, n + 5), (good, 0, n // 2), (good, 0, 0), (damaged, 0, n), (damaged2, 0, 2 * n),
+                (good[: good.size - 3], 0, n), (good[: 2 * 32768 + 1], 0, n), (good[: 2 * 32768], 0, n),
+                (good[: 3 * 32768 - 1], 0, n), (good[:5000], 0, n), (good, 3, 2 * n), (good[100:], 5, 2 * n),
+                (rng.integers(0, 256, 70000, dtype=np.uint8), 0, 70000),
+            ]
+            if name == "len4to15":
+                # code lengths 9, 12 and 15 only: walks from different entries never fall into step, every block is left
+                # differently from its guess and dec_wide_* give the item up by themselves
+                apart = rng.integers(28, 256, 60000).astype(np.uint8)
+                streams.append((w.oracle.encode_all(ocoder, apart, slack=64 + 4 * apart.size), 0, apart.size))
+            offs, pos = [], 3
+            for e, _, _ in streams:
+                offs.append(pos)
+                pos += e.size + int(rng.integers(0, 9))
+            host_enc = np.zeros(pos + 64, np.uint8)
+            for (e, _, _), o in zip(streams, offs):
+                host_enc[o:o + e.size] = e
+            items, expect, pos = [], [], 7
+            for (e, fb, cap), o in zip(streams, offs):
+                d = w.oracle.new_decoder(ocoder)
+                start = 0
+                if fb:  # the rest of the first byte is what a previous call left in the decoder
+                    d.working_bits = (int(e[0]) & (0xFF >> fb)) << (56 + fb)
+                    d.num_bits = 8 - fb
+                    start = 1
+                dst = np.full(cap + 1, SENTINEL, np.uint8)
+                r = w.oracle.decode_call(d, e, start, e.size, dst, 0, cap)
+                bits = (8 - fb if fb else 0) + r.consumed * 8 - r.state[0]
+                expect.append(((r.rc, r.err, r.produced, bits), dst[:cap].copy()))
+                items.append(dict(in_offset=o, in_len=e.size, first_bit=fb, out_offset=pos, out_capacity=cap))
+                pos += cap + int(rng.integers(1, 9))
+            sym_total = pos + 64
+            d_enc, d_sym = eng.alloc(host_enc.size), eng.alloc(sym_total)
+            eng.upload(d_enc, host_enc)
+            want = np.full(sym_total, SENTINEL, np.uint8)
+            for it, (key, sym) in zip(items, expect):
+                want[it["out_offset"]:it["out_offset"] + it["out_capacity"]] = sym
+            assert len({key[:2] for key, _ in expect}) >= 3
+            plan = eng.decode_plan(items)
+            for mode in modes:
+                if mode:
+                    os.environ["AWS_HUFFMAN_AMD_DECODE"] = mode
+                try:
+                    for _ in range(2):  # (a second launch of the plan finds the scratch words of the first)
+                        eng.fill(d_sym, SENTINEL, sym_total)
+                        eng.decode_launch(plan, d_enc, d_sym)
+                        res = eng.decode_results(plan, len(items))
+                        for i, (it, (key, _)) in enumerate(zip(items, expect)):
+                            assert res[i] == key, (name, mode, i, it, res[i], key)
+                        assert np.array_equal(eng.download(d_sym, sym_total), want), (name, mode)
+                finally:
+                    os.environ.pop("AWS_HUFFMAN_AMD_DECODE", None)
+            eng.lib.aws_huffman_amd_decode_plan_destroy(plan)
+            eng.free(d_enc)
+            eng.free(d_sym)
+            # the reference's entry point on a host buffer of that length
+            ddo, ddp = w.oracle.new_decoder(ocoder), w.product.new_decoder(pcoder)
+            oo, op = np.full(n + 8, SENTINEL, np.uint8), np.full(n + 8, SENTINEL, np.uint8)
+            paired_decode(w, ddo, ddp, good, 0, good.size, oo, op, 0, n)
+            eng.close()
+    finally:
+        w.product.lib.aws_huffman_amd_testing_set_wide_min_bytes(0)
+
+
 def first_bit_offsets(w, engine=None):
     """Decode items that start inside their first byte (what a carried decoder state turns into)."""
     rng = np.random.default_rng(19)

@@ -53,6 +53,10 @@ def test_block_decode_calls(world):
     pc.block_decode_calls(world)
 
 
+def test_wide_long_code_items(world):
+    pc.wide_long_code_items(world)
+
+
 def test_eos_padding_values(world):
     pc.eos_padding_values(world)
 

@@ -60,6 +60,10 @@ def test_block_decode_calls(world):
     pc.block_decode_calls(world)
 
 
+def test_wide_long_code_items(world):
+    pc.wide_long_code_items(world)
+
+
 def test_damaged_long_streams(world):
     pc.damaged_long_streams(world)
 
