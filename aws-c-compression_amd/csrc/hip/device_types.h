@@ -46,7 +46,9 @@
 #define HUFD_DEC_COOP_BYTES 768u /* ... and up to this long one wave's (dec_deep<false>): no chunks either */
 #define HUFD_DEC_BLOCK_BYTES 8192u /* one host-pointer call of up to this many encoded bytes (short codes) is one workgroup's work (dec_block): one launch */
 #define HUFD_WIDE_BLOCK_BYTES 32768u /* a long item of a coder with long codes is decoded this many bytes a workgroup (dec_wide_*) */
-#define HUFD_WIDE_MIN_BYTES (16u * HUFD_WIDE_BLOCK_BYTES) /* ... when it is at least this long */
+#define HUFD_WIDE_MIN_BYTES (4u * HUFD_WIDE_BLOCK_BYTES) /* ... when it is at least this long and the batch has fewer than HUFD_WIDE_FEW_ITEMS such items, */
+#define HUFD_WIDE_FEW_ITEMS 128u
+#define HUFD_WIDE_MANY_MIN_BYTES (64u * HUFD_WIDE_BLOCK_BYTES) /* or this long whatever the batch */
 #define HUFD_DEC_STAGE_BYTES 34304u /* LDS bytes for a chunk's decoded symbols (dec_emit_fast: four workgroups per CU) */
 
 #define HUFD_SCAN_SMALL_MAX 64u /* items with at most this many segments/chunks are scanned by one thread */

@@ -870,11 +870,20 @@ static uint64_t dec_tiny_limit(const struct aws_huffman_amd_decode_item *items, 
     return HUFD_TINY_FEW_BYTES;
 }
 
-/* deep items of at least this many encoded bytes go across the chip (tests lower it) */
-static uint64_t s_wide_min_bytes = HUFD_WIDE_MIN_BYTES;
+/* Items of a coder with long codes of at least this many encoded bytes go across the chip, seven launches each
+ * (dec_wide_*): from HUFD_WIDE_MIN_BYTES on when the batch's items do not fill the chip a workgroup each, from
+ * HUFD_WIDE_MANY_MIN_BYTES on when they do.  Tests set one limit for both. */
+static uint64_t s_wide_min_bytes = 0;
 
 void aws_huffman_amd_testing_set_wide_min_bytes(uint64_t bytes) {
-    s_wide_min_bytes = bytes ? bytes : HUFD_WIDE_MIN_BYTES;
+    s_wide_min_bytes = bytes;
+}
+
+static uint64_t wide_min_bytes(size_t deep_items) {
+    if (s_wide_min_bytes) {
+        return s_wide_min_bytes;
+    }
+    return deep_items < HUFD_WIDE_FEW_ITEMS ? HUFD_WIDE_MIN_BYTES : HUFD_WIDE_MANY_MIN_BYTES;
 }
 
 static bool dec_item_is_deep(
@@ -948,6 +957,11 @@ static int dec_plan_fill(
         return aws_raise_error(AWS_ERROR_OOM);
     }
     uint32_t chunk = 0, large = 0, run = 0, tail = 0, tiny = 0, deep = 0, tile = 0;
+    size_t deep_items = 0;
+    for (size_t i = 0; i < n_items && eng->tables.deep_entries; ++i) {
+        deep_items += !dec_item_is_tiny(&items[i], tiny_limit) && dec_item_is_deep(eng, &items[i], tiny_limit);
+    }
+    const uint64_t wide_from = wide_min_bytes(deep_items);
     struct hufk_wide_item *h_wide = NULL;
     uint32_t n_wide = 0;
     uint64_t wide_bytes = 0;
@@ -971,7 +985,7 @@ static int dec_plan_fill(
         } else if (dec_item_is_deep(eng, src, tiny_limit)) {
             dst->tiny = 1;
             h_tiny[n_items - ++deep] = (uint32_t)i;
-            if (eng->tables.deep_entries && src->in_len >= s_wide_min_bytes) {
+            if (eng->tables.deep_entries && src->in_len >= wide_from) {
                 struct hufk_wide_item *more = realloc(h_wide, (n_wide + 1) * sizeof(*more));
                 if (!more) {
                     wide_oom = true;
@@ -1152,6 +1166,7 @@ static int dec_plan_fill(
     free(p->h_wide);
     p->h_wide = h_wide;
     p->n_wide = n_wide;
+    p->wide_from = wide_from;
     p->n_items = (uint32_t)n_items;
     p->n_chunks = (uint32_t)n_chunks;
     p->n_large = (uint32_t)n_large;
@@ -1231,7 +1246,7 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.n_deep = p->n_deep;
     a.wide = p->h_wide;
     a.n_wide = p->n_wide;
-    a.wide_from = s_wide_min_bytes;
+    a.wide_from = p->wide_from;
     a.wide_block = p->d_wide_block;
     a.tiny_items = p->d_tiny;
     a.n_tiny = p->n_tiny;

@@ -118,6 +118,7 @@ struct aws_huffman_amd_decode_plan {
     /* the long items of a coder with long codes: a workgroup per 32 KiB block (dec_wide_*) */
     struct hufk_wide_item *h_wide; /* [n_wide] */
     uint32_t n_wide;
+    uint64_t wide_from; /* encoded bytes from which an item was taken for one */
     void *d_wide_block;
     size_t cap_wide_block;
 };

@@ -253,7 +253,7 @@ void aws_huffman_amd_testing_set_decode_piece_bytes(size_t bytes /* 0: back to 2
 /* testing: from how many encoded bytes on an item of a coder with codes of more than 12 bits is decoded a workgroup
  * per 32 KiB block (dec_wide_*) instead of by one workgroup (dec_deep) */
 AWS_COMPRESSION_API
-void aws_huffman_amd_testing_set_wide_min_bytes(uint64_t bytes /* 0: back to 512 KiB */);
+void aws_huffman_amd_testing_set_wide_min_bytes(uint64_t bytes /* 0: back to 128 KiB (2 MiB in a batch of 128 such items or more) */);
 
 /* ---- several GPUs: independent items sharded over the devices of one node ---- */
 

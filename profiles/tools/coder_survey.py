@@ -15,6 +15,21 @@ import parity_cases as pc  # noqa: E402
 
 lib = harness.load_product()
 n = 128 << 20
+eng = None
+
+
+def timed(launch, reps):
+    """median seconds of one launch + wait, each launch timed by itself, and the slowest one's ratio to the median"""
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        launch()
+        eng.sync()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    return times[len(times) // 2], times[-1] / times[len(times) // 2]
+
+
 rng = np.random.default_rng(3)
 for name, rows in pc.CODER_PROFILES.items():
     lengths = [l for count, l in rows for _ in range(count)]
@@ -34,27 +49,22 @@ for name, rows in pc.CODER_PROFILES.items():
         (rc, err, consumed, e_len, _, _), = eng.encode_results(ep, 1)
         assert rc == 0 and e_len == (bits + 7) // 8, (name, rc, err, e_len, bits)
         eng.sync()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            eng.encode_launch(ep, d_in, d_enc)
-        eng.sync()
-        t_enc = (time.perf_counter() - t0) / 3
+        t_enc, enc_worst = timed(lambda: eng.encode_launch(ep, d_in, d_enc), 7)
         one_pass = bool(lib.aws_huffman_amd_engine_encodes_in_one_pass(eng.h))
         line = "%-14s %-8s %5.2f bits/symbol: encode %7.1f GiB/s (%s)" % (
             name, kind, bits / n, n / 2**30 / t_enc, "one pass" if one_pass else "three kernels")
-        if max(lengths) <= 12 or kind == "matched":
+        if True:
             dp = eng.decode_plan([dict(in_offset=0, in_len=e_len, out_offset=0, out_capacity=n)])
             eng.decode_launch(dp, d_enc, d_back)
             (rc, err, symbols, _), = eng.decode_results(dp, 1)
             assert rc == 0 and symbols == n, (name, rc, err, symbols)
             assert np.array_equal(eng.download(d_back, n), data)
-            t0 = time.perf_counter()
-            reps = 3 if max(lengths) <= 12 else 1
-            for _ in range(reps):
-                eng.decode_launch(dp, d_enc, d_back)
-            eng.sync()
-            t_dec = (time.perf_counter() - t0) / reps
+            t_dec, dec_worst = timed(lambda: eng.decode_launch(dp, d_enc, d_back), 7)
             line += ", decode %7.1f GiB/s of symbols" % (n / 2**30 / t_dec)
+            if max(enc_worst, dec_worst) > 1.5:
+                # (round 2's table had one such line, taken for a stall of the kernels: it is the host's clock around
+                # three launches that was timed then)
+                line += " [slowest of 7 launches / median: encode %.2f, decode %.2f]" % (enc_worst, dec_worst)
             eng.lib.aws_huffman_amd_decode_plan_destroy(dp)
         print(line, flush=True)
         eng.lib.aws_huffman_amd_encode_plan_destroy(ep)
