@@ -4986,31 +4986,41 @@ __global__ __launch_bounds__(kDeepThreads) void dec_deep_kernel(
 /*
  * ONE LONG item of a coder with long codes, across the chip.  dec_deep gives such an item one workgroup that takes it
  * 32 KiB at a time: 0.12 GB/s whatever its length, and HPACK's own code is such a coder.  Here every 32 KiB block is a
- * workgroup's, in four launches:
- *   dec_wide_settle<1>  the block's lanes settle on their entries as dec_deep's do, from a GUESS for lane 0 (block 0:
- *                       the item's true first bit); how the block is left goes to exit1[block];
- *   dec_wide_settle<2>  lane 0 takes exit1[block - 1] for its entry and the lanes settle again (a handful of them walk:
- *                       walks from different entries fall into step within a few codes); exit2, the block's symbols;
+ * workgroup's:
+ *   dec_wide_settle<0>  the block's lanes settle on their entries as dec_deep's do, from a GUESS for lane 0 (block 0:
+ *                       the item's true first bit); how the block is left goes to exits[0][block];
+ *   dec_wide_settle<j>  (j = 1 .. kWideFixes) lane 0 takes exits[j - 1][block - 1] for its entry and the lanes settle
+ *                       again (a handful of them walk: walks from different entries fall into step within a few
+ *                       codes); exits[j][block], the block's symbols, and whether the block is left differently now;
  *   dec_wide_scan       where each block's symbols go, the item's total, its result record;
  *   dec_wide_emit       the walk that writes the symbols.
- * exit1[b - 1] is block b's true entry if block b - 1 is left the same way from its guess and from its true entry --
- * by induction from block 0: if exit2 == exit1 for every block, every block had its true entry in the second launch.
- * One block that is left differently (a stream whose walks never fall into step) raises ctl[0]: the last three kernels
- * do nothing then and dec_deep, queued behind them with that word as its gate, decodes the item its way.  A walk that
- * stops (source/huffman.c:232-255) says nothing to the lane or block behind it while entries are guesses; of the
- * settled lanes the first that stops ends the stream, and what lies behind it is not part of it.
+ * If no block is left differently in launch j than in launch j - 1, every block had its true entry in launch j: by
+ * induction from block 0, whose entry is the item's first bit.  Launch j + 1 runs only if one was (it finds the flag
+ * of launch j): on the HPACK code lengths one launch does; a coder whose walks take hundreds of bits to fall into step
+ * (15-, 12- and 9-bit codes with a few others in between) needs two or three.  What is still moving after kWideFixes
+ * launches -- a stream whose walks never fall into step -- raises ctl[0]: dec_wide_emit does nothing then, and dec_deep,
+ * queued behind it with that word as its gate, decodes the item its way.  A walk that stops
+ * (source/huffman.c:232-255) says nothing to the lane or block behind it while entries are guesses; of the settled
+ * lanes the first that stops ends the stream, and what lies behind it is not part of it.
  */
 constexpr u32 kWideStop = 0xFFu;
 constexpr u32 kWideGuessBytes = 32;
+constexpr u32 kWideFixes = 4;
 static_assert(HUFD_WIDE_BLOCK_BYTES == kDeepThreads * kDeepLaneBytes, "a block is one round of dec_deep's lanes");
 
+/* ctl words */
+constexpr u32 kWideGaveUp = 0;   /* set by dec_wide_scan */
+constexpr u32 kWideStopBlock = 1; /* the first block whose true walk stops (dec_wide_scan) */
+constexpr u32 kWideMoved = 2;    /* [+ j], j = 1 .. kWideFixes: a block was left differently in launch j */
+constexpr u32 kWideStops = 8;    /* [+ j]: the first block whose walk stops, as of launch j */
+
 struct dec_wide_layout {
-    u64 ctl;        /* u32[4]: [0] gave up, [1] the first block whose true walk stops */
-    u64 exit1;      /* u32[n_blocks] */
-    u64 exit2;      /* u32[n_blocks] */
-    u64 count2;     /* u32[n_blocks] symbols of the block's lanes up to the first that stops */
+    u64 ctl;        /* u32[16] */
+    u64 exits;      /* u32[kWideFixes + 1][n_blocks] */
+    u64 count;      /* u32[n_blocks] symbols of the block's lanes up to the first that stops */
+    u64 last;       /* u32[n_blocks] that lane (kDeepThreads: none stops) */
     u64 base;       /* u64[n_blocks] symbols in front of the block */
-    u64 lane_start; /* u8[n_blocks][kDeepThreads] entry bit of the lane, kWideStop: not part of the stream */
+    u64 lane_start; /* u8[n_blocks][kDeepThreads] entry bit of the lane */
     u64 lane_exit;  /* u8[n_blocks][kDeepThreads] */
     u64 lane_count; /* u16[n_blocks][kDeepThreads] */
     u64 bytes;
@@ -5018,17 +5028,18 @@ struct dec_wide_layout {
 
 __host__ __device__ inline dec_wide_layout dec_wide_layout_of(u64 n_blocks) {
     dec_wide_layout l;
+    const u64 row = (n_blocks * 4 + 63) & ~63ull;
     u64 at = 0;
     l.ctl = at;
     at += 64;
-    l.exit1 = at;
-    at += (n_blocks * 4 + 63) & ~63ull;
-    l.exit2 = at;
-    at += (n_blocks * 4 + 63) & ~63ull;
-    l.count2 = at;
-    at += (n_blocks * 4 + 63) & ~63ull;
+    l.exits = at;
+    at += (kWideFixes + 1) * row;
+    l.count = at;
+    at += row;
+    l.last = at;
+    at += row;
     l.base = at;
-    at += (n_blocks * 8 + 63) & ~63ull;
+    at += 2 * row;
     l.lane_start = at;
     at += n_blocks * kDeepThreads;
     l.lane_exit = at;
@@ -5047,15 +5058,20 @@ struct wide_shared {
     u32 pad;
 };
 
-template <u32 PASS>
+template <bool FIRST>
 __global__ __launch_bounds__(kDeepThreads) void dec_wide_settle_kernel(
-    hufd_tables tb, const hufd_dec_item *items, const u32 *the_item, const u8 *d_in, u8 *block, u32 fails) {
+    hufd_tables tb, const hufd_dec_item *items, const u32 *the_item, const u8 *d_in, u8 *block, u32 pass, u32 fails) {
 
     const hufd_dec_item it = items[the_item[0]];
     const u64 n_blocks = (it.in_len + (u64)kDeepThreads * kDeepLaneBytes - 1) / ((u64)kDeepThreads * kDeepLaneBytes);
     const dec_wide_layout lay = dec_wide_layout_of(n_blocks);
     u32 *ctl = reinterpret_cast<u32 *>(block + lay.ctl);
-    u32 *exit1 = reinterpret_cast<u32 *>(block + lay.exit1), *exit2 = reinterpret_cast<u32 *>(block + lay.exit2);
+    if (!FIRST && pass > 1 && ctl[kWideMoved + pass - 1] == 0) {
+        return; /* the launch before this one left every block as the one before it did: done */
+    }
+    const u64 row = ((n_blocks * 4 + 63) & ~63ull) / 4;
+    u32 *exits_now = reinterpret_cast<u32 *>(block + lay.exits) + (FIRST ? 0 : pass) * row;
+    const u32 *exits_before = reinterpret_cast<const u32 *>(block + lay.exits) + (FIRST ? 0 : pass - 1) * row;
     const u64 b = blockIdx.x;
     const u32 l = threadIdx.x;
     u8 *lane_start = block + lay.lane_start + b * kDeepThreads, *lane_exit = block + lay.lane_exit + b * kDeepThreads;
@@ -5080,7 +5096,7 @@ __global__ __launch_bounds__(kDeepThreads) void dec_wide_settle_kernel(
     bool walk;
     lane_memo memo;
     memo.clear();
-    if (PASS == 1) {
+    if (FIRST) {
         start = b == 0 && l == 0 ? it.first_bit : 0u;
         walk = active;
         if (active && (b | l) != 0) {
@@ -5098,10 +5114,10 @@ __global__ __launch_bounds__(kDeepThreads) void dec_wide_settle_kernel(
         memo.put(start, my_exit, my_count);
         walk = false;
         if (l == 0 && b > 0) {
-            const u32 entry = exit1[b - 1];
+            const u32 entry = exits_before[b - 1];
             if (entry == kWideStop) {
-                /* the block in front stops from its guess: if it does from its true entry too, this block is not part
-                 * of the stream and whatever is written for it is not looked at; if not, that block raises ctl[0] */
+                /* the block in front stops: if it still does when nothing moves any more, this block is not part of
+                 * the stream and whatever is written for it is not looked at */
             } else if (entry != start) {
                 start = entry;
                 walk = true;
@@ -5141,17 +5157,15 @@ __global__ __launch_bounds__(kDeepThreads) void dec_wide_settle_kernel(
     const u32 last_lane = sh.last_lane;
     const bool reached = active && l <= last_lane;
     const u32 block_exit = last_lane < n_lanes ? kWideStop : sh.exit_of[n_lanes - 1];
-    if (PASS == 1) {
-        lane_start[l] = (u8)start;
-        lane_exit[l] = (u8)my_exit;
-        lane_count[l] = (u16)my_count;
+    lane_start[l] = (u8)start;
+    lane_exit[l] = (u8)my_exit;
+    lane_count[l] = (u16)my_count;
+    if (FIRST) {
         if (l == 0) {
-            exit1[b] = block_exit;
+            exits_now[b] = block_exit;
         }
         return;
     }
-    lane_start[l] = (u8)(reached ? start : kWideStop);
-    lane_count[l] = (u16)(reached ? my_count : 0u);
     sh.scan[l] = reached ? my_count : 0u;
     __syncthreads();
     for (u32 d = kDeepThreads / 2; d > 0; d /= 2) {
@@ -5161,13 +5175,14 @@ __global__ __launch_bounds__(kDeepThreads) void dec_wide_settle_kernel(
         __syncthreads();
     }
     if (l == 0) {
-        exit2[b] = block_exit;
-        reinterpret_cast<u32 *>(block + lay.count2)[b] = sh.scan[0];
-        if ((block_exit != exit1[b] && b + 1 < n_blocks) || fails) {
-            atomicOr(&ctl[0], 1u); /* the block behind this one had a wrong entry */
+        exits_now[b] = block_exit;
+        reinterpret_cast<u32 *>(block + lay.count)[b] = sh.scan[0];
+        reinterpret_cast<u32 *>(block + lay.last)[b] = last_lane < n_lanes ? last_lane : kDeepThreads;
+        if ((block_exit != exits_before[b] && b + 1 < n_blocks) || fails) {
+            atomicOr(&ctl[kWideMoved + pass], 1u); /* the block behind this one had a wrong entry */
         }
         if (block_exit == kWideStop) {
-            atomicMin(&ctl[1], (u32)b);
+            atomicMin(&ctl[kWideStops + pass], (u32)b);
         }
     }
 }
@@ -5179,20 +5194,30 @@ __global__ __launch_bounds__(256) void dec_wide_scan_kernel(
     const hufd_dec_item it = items[item];
     const u64 n_blocks = (it.in_len + (u64)kDeepThreads * kDeepLaneBytes - 1) / ((u64)kDeepThreads * kDeepLaneBytes);
     const dec_wide_layout lay = dec_wide_layout_of(n_blocks);
-    const u32 *ctl = reinterpret_cast<const u32 *>(block + lay.ctl);
-    if (ctl[0]) {
+    u32 *ctl = reinterpret_cast<u32 *>(block + lay.ctl);
+    const u32 l = threadIdx.x;
+    /* the launch after which nothing moved (launch j ran if launches 1 .. j - 1 all saw something move) */
+    u32 settled = 0;
+    for (u32 j = 1; j <= kWideFixes && !settled; ++j) {
+        if (ctl[kWideMoved + j] == 0) {
+            settled = j;
+        }
+    }
+    if (!settled) {
+        if (l == 0) {
+            ctl[kWideGaveUp] = 1;
+        }
         return;
     }
-    const u32 *count2 = reinterpret_cast<const u32 *>(block + lay.count2);
+    const u32 *count = reinterpret_cast<const u32 *>(block + lay.count);
     u64 *base = reinterpret_cast<u64 *>(block + lay.base);
     u64 *part = reinterpret_cast<u64 *>(dyn_lds); /* [256] */
-    const u32 l = threadIdx.x;
-    const u64 stop_block = ctl[1]; /* blocks behind it are not part of the stream */
+    const u64 stop_block = ctl[kWideStops + settled]; /* blocks behind it are not part of the stream */
     const u64 counted = stop_block < n_blocks ? stop_block + 1 : n_blocks;
     const u64 per = (counted + 255) / 256, lo = l * per < counted ? l * per : counted, hi = lo + per < counted ? lo + per : counted;
     u64 sum = 0;
     for (u64 k = lo; k < hi; ++k) {
-        sum += count2[k];
+        sum += count[k];
     }
     part[l] = sum;
     __syncthreads();
@@ -5205,7 +5230,7 @@ __global__ __launch_bounds__(256) void dec_wide_scan_kernel(
     u64 run = part[l] - sum;
     for (u64 k = lo; k < hi; ++k) {
         base[k] = run;
-        run += count2[k];
+        run += count[k];
     }
     if (l == 255) {
         const u64 total = part[255];
@@ -5218,6 +5243,7 @@ __global__ __launch_bounds__(256) void dec_wide_scan_kernel(
         rs.stop_bit = stop_block < n_blocks ? kNoBit : it.in_len * 8;
         results[item] = rs;
         states[item].total_symbols = total;
+        ctl[kWideStopBlock] = (u32)(stop_block < n_blocks ? stop_block : 0xFFFFFFFFu);
     }
 }
 
@@ -5230,7 +5256,7 @@ __global__ __launch_bounds__(kDeepThreads) void dec_wide_emit_kernel(
     const dec_wide_layout lay = dec_wide_layout_of(n_blocks);
     const u32 *ctl = reinterpret_cast<const u32 *>(block + lay.ctl);
     const u64 b = blockIdx.x;
-    if (ctl[0] || b > ctl[1]) {
+    if (ctl[kWideGaveUp] || b > ctl[kWideStopBlock]) {
         return;
     }
     const u32 l = threadIdx.x;
@@ -5239,8 +5265,10 @@ __global__ __launch_bounds__(kDeepThreads) void dec_wide_emit_kernel(
     for (u32 i = l; i < tb.deep_entries; i += kDeepThreads) {
         deep[i] = tb.deep_lut[i];
     }
+    const bool reached = l <= reinterpret_cast<const u32 *>(block + lay.last)[b] &&
+                         (b * kDeepThreads + l) * (u64)kDeepLaneBytes < it.in_len;
     const u32 start = (block + lay.lane_start + b * kDeepThreads)[l];
-    const u32 mine = (reinterpret_cast<const u16 *>(block + lay.lane_count) + b * kDeepThreads)[l];
+    const u32 mine = reached ? (reinterpret_cast<const u16 *>(block + lay.lane_count) + b * kDeepThreads)[l] : 0u;
     sh.scan[l] = mine;
     __syncthreads();
     for (u32 d = 1; d < kDeepThreads; d *= 2) {
@@ -5249,7 +5277,7 @@ __global__ __launch_bounds__(kDeepThreads) void dec_wide_emit_kernel(
         sh.scan[l] += add;
         __syncthreads();
     }
-    if (start == kWideStop) {
+    if (!reached) {
         return;
     }
     const u64 first = reinterpret_cast<const u64 *>(block + lay.base)[b] + (sh.scan[l] - mine);
@@ -7836,14 +7864,16 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             u8 *blk = (u8 *)a->wide_block + a->wide[k].block_offset;
             const uint32_t n_blocks = a->wide[k].n_blocks;
             const dec_wide_layout lay = dec_wide_layout_of(n_blocks);
-            (void)hipMemsetAsync(blk + lay.ctl, 0, 4, st);
-            (void)hipMemsetAsync(blk + lay.ctl + 4, 0xFF, 4, st);
+            (void)hipMemsetAsync(blk + lay.ctl, 0, 64, st);
+            (void)hipMemsetAsync(blk + lay.ctl + 4 * (kWideStops + 1), 0xFF, 4 * kWideFixes, st);
             hipLaunchKernelGGL(
-                dec_wide_settle_kernel<1>, dim3(n_blocks), dim3(kDeepThreads), wide_lds, st, a->tables, a->items, the_item,
-                (const u8 *)a->d_in, blk, 0u);
-            hipLaunchKernelGGL(
-                dec_wide_settle_kernel<2>, dim3(n_blocks), dim3(kDeepThreads), wide_lds, st, a->tables, a->items, the_item,
-                (const u8 *)a->d_in, blk, a->wide_fails);
+                dec_wide_settle_kernel<true>, dim3(n_blocks), dim3(kDeepThreads), wide_lds, st, a->tables, a->items, the_item,
+                (const u8 *)a->d_in, blk, 0u, 0u);
+            for (u32 pass = 1; pass <= kWideFixes; ++pass) {
+                hipLaunchKernelGGL(
+                    dec_wide_settle_kernel<false>, dim3(n_blocks), dim3(kDeepThreads), wide_lds, st, a->tables, a->items,
+                    the_item, (const u8 *)a->d_in, blk, pass, a->wide_fails);
+            }
             hipLaunchKernelGGL(dec_wide_scan_kernel, dim3(1), dim3(256), 256 * sizeof(u64), st, a->items, the_item, blk, a->states, a->results);
             hipLaunchKernelGGL(
                 dec_wide_emit_kernel, dim3(n_blocks), dim3(kDeepThreads), wide_lds, st, a->tables, a->items, the_item,

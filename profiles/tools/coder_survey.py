@@ -16,6 +16,7 @@ import parity_cases as pc  # noqa: E402
 lib = harness.load_product()
 n = 128 << 20
 eng = None
+slowest_at = 0
 
 
 def timed(launch, reps):
@@ -26,6 +27,8 @@ def timed(launch, reps):
         launch()
         eng.sync()
         times.append(time.perf_counter() - t0)
+    global slowest_at
+    slowest_at = times.index(max(times))
     times.sort()
     return times[len(times) // 2], times[-1] / times[len(times) // 2]
 
@@ -50,6 +53,7 @@ for name, rows in pc.CODER_PROFILES.items():
         assert rc == 0 and e_len == (bits + 7) // 8, (name, rc, err, e_len, bits)
         eng.sync()
         t_enc, enc_worst = timed(lambda: eng.encode_launch(ep, d_in, d_enc), 7)
+        enc_at = slowest_at
         one_pass = bool(lib.aws_huffman_amd_engine_encodes_in_one_pass(eng.h))
         line = "%-14s %-8s %5.2f bits/symbol: encode %7.1f GiB/s (%s)" % (
             name, kind, bits / n, n / 2**30 / t_enc, "one pass" if one_pass else "three kernels")
@@ -64,7 +68,8 @@ for name, rows in pc.CODER_PROFILES.items():
             if max(enc_worst, dec_worst) > 1.5:
                 # (round 2's table had one such line, taken for a stall of the kernels: it is the host's clock around
                 # three launches that was timed then)
-                line += " [slowest of 7 launches / median: encode %.2f, decode %.2f]" % (enc_worst, dec_worst)
+                line += " [slowest of 7 launches / median: encode %.2f (launch %d), decode %.2f (launch %d)]" % (
+                    enc_worst, enc_at, dec_worst, slowest_at)
             eng.lib.aws_huffman_amd_decode_plan_destroy(dp)
         print(line, flush=True)
         eng.lib.aws_huffman_amd_encode_plan_destroy(ep)

@@ -1058,6 +1058,10 @@ def wide_long_code_items(w, n=150_000, seed=79, modes=(None, "wide-fails")):
                 (good[: 3 * 32768 - 1], 0, n), (good[:5000], 0, n), (good, 3, 2 * n), (good[100:], 5, 2 * n),
                 (rng.integers(0, 256, 70000, dtype=np.uint8), 0, 70000),
             ]
+            # symbols at random: mostly the long codes (len4to15: 15, 12 and 9 bits, walks fall into step only at one of the
+            # few others: blocks that are left differently from their guess, a second and third fixing launch)
+            flat = rng.integers(0, 256, 100_000).astype(np.uint8)
+            streams.append((w.oracle.encode_all(ocoder, flat, slack=64 + 4 * flat.size), 0, flat.size))
             if name == "len4to15":
                 # code lengths 9, 12 and 15 only: walks from different entries never fall into step, every block is left
                 # differently from its guess and dec_wide_* give the item up by themselves
