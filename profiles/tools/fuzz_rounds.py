@@ -36,6 +36,8 @@ rounds = [
     ("one_shot_roundtrips", lambda s: pc.one_shot_roundtrips(w, [1, 513, 16385, 100001], seed=s)),
     ("cut_streams", lambda s: pc.cut_streams(w, seed=s, chunks=(1, 3), step=13, span=70, n=120_000)),
     ("other_coders", lambda s: pc.other_coders(w, n=30000, seed=s)),
+    ("block_decode_calls", lambda s: pc.block_decode_calls(w, seed=s) if s % 2 == 0 else None),
+    ("wide_long_code_items", lambda s: pc.wide_long_code_items(w, seed=s) if s % 3 == 0 else None),
     ("damaged_long_streams", lambda s: pc.damaged_long_streams(w, seed=s) if s % 8 == 0 else None),  # 10 M symbols: now and then
 ]
 t0 = time.time()
