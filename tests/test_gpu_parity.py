@@ -354,3 +354,16 @@ def test_decode_with_the_first_sync_kernel(world, engine):
         pc.garbage_decode(world)
     finally:
         del os.environ["AWS_HUFFMAN_AMD_DECODE"]
+
+
+def test_plan_launches_in_a_hip_graph():
+    """an encode launch and the decode launch of its output, captured into one HIP graph on a stream of
+    the caller's and replayed over scrambled outputs (profiles/tools/graph_capture.py: a batch of 16 KiB items and one
+    64 MiB stream -- memsets, kernels, and the second stream's fork and join are all nodes of the graph)."""
+    import subprocess
+    import sys
+
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tools", "graph_capture.py")
+    out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("decoded back bit-exact") == 2, out.stdout
