@@ -44,7 +44,8 @@
 #define HUFD_DEEP_LINK 0x80000000u /* entry is a link: [15:0] first entry of the next table, [23:16] its index width */
 #define HUFD_DEC_TINY_BYTES 512u /* decode items up to this long are one thread's work (dec_tiny): no chunks */
 #define HUFD_DEC_COOP_BYTES 768u /* ... and up to this long one wave's (dec_deep<false>): no chunks either */
-#define HUFD_DEC_BLOCK_BYTES 8192u /* one host-pointer call of up to this many encoded bytes (short codes) is one workgroup's work (dec_block): one launch */
+#define HUFD_DEC_BLOCK_BYTES 8192u /* what dec_block's workgroup takes in one turn: a lane per 64 bits */
+#define HUFD_DEC_BLOCK_MAX_BYTES (4u * HUFD_DEC_BLOCK_BYTES) /* one host-pointer call of up to this many encoded bytes (short codes) is that one workgroup's work: one launch */
 #define HUFD_WIDE_BLOCK_BYTES 32768u /* a long item of a coder with long codes is decoded this many bytes a workgroup (dec_wide_*) */
 #define HUFD_WIDE_MIN_BYTES (4u * HUFD_WIDE_BLOCK_BYTES) /* ... when it is at least this long and the batch has fewer than HUFD_WIDE_FEW_ITEMS such items, */
 #define HUFD_WIDE_FEW_ITEMS 128u

@@ -133,7 +133,7 @@ uint64_t hufk_decode_wide_bytes(uint64_t n_blocks);
 int hufk_decode_one_coop(
     const struct hufd_tables *tables, const struct hufd_dec_item *item, const uint32_t *zero, const void *d_in, void *d_out,
     struct hufd_dec_item_state *state, struct hufd_dec_result *result, void *stream);
-/* the same for an item of up to HUFD_DEC_BLOCK_BYTES encoded bytes of a coder without long codes: one workgroup, one
+/* the same for an item of up to HUFD_DEC_BLOCK_MAX_BYTES encoded bytes of a coder without long codes: one workgroup, one
  * launch (dec_block_kernel); item = the record, in HOST memory (it travels with the launch) */
 int hufk_decode_one_block(
     const struct hufd_tables *tables, const struct hufd_dec_item *item, const void *d_in, void *d_out,

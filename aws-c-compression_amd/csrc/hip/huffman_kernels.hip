@@ -5295,8 +5295,8 @@ __global__ __launch_bounds__(kDeepThreads) void dec_wide_emit_kernel(
 }
 
 /*
- * One host-pointer call of more than one thread's bytes and up to HUFD_DEC_BLOCK_BYTES of them (short codes): ONE
- * workgroup and one launch, as enc_block is for the encoder -- a chunk's tables, lists and five more launches cost
+ * One host-pointer call of more than one thread's bytes and up to HUFD_DEC_BLOCK_MAX_BYTES of them (short codes),
+ * HUFD_DEC_BLOCK_BYTES a turn: ONE workgroup and one launch, as enc_block is for the encoder -- a chunk's tables, lists and five more launches cost
  * such a call several times its symbols.  A lane takes 64 bits of the stream and keeps them, with the 32 behind them,
  * in registers (big-endian words, zeros behind the stream's end).  As in dec_deep the lanes settle on their
  * entries by walking again from where the lane in front really leaves until nothing changes -- exact whatever the
@@ -5310,7 +5310,7 @@ constexpr u32 kBlockDecThreads = 1024;
 constexpr u32 kBlockDecLaneBits = 64;
 constexpr u32 kBlockDecWaves = kBlockDecThreads / 64;
 constexpr u32 kBlockDecRounds = 24; /* (the test coder's streams settle in 3 to 7) */
-static_assert(HUFD_DEC_BLOCK_BYTES * 8 == kBlockDecThreads * kBlockDecLaneBits, "a lane for every 64 bits of the longest call");
+static_assert(HUFD_DEC_BLOCK_BYTES * 8 == kBlockDecThreads * kBlockDecLaneBits, "a lane for every 64 bits of a turn");
 
 struct block_dec_shared {
     u8 exit_of[kBlockDecThreads];
@@ -5396,164 +5396,181 @@ __global__ __launch_bounds__(kBlockDecThreads) void dec_block_kernel(
     block_dec_shared &sh = *reinterpret_cast<block_dec_shared *>(dyn_lds);
     u16 *lut = reinterpret_cast<u16 *>(dyn_lds + sizeof(block_dec_shared));
     const u32 l = threadIdx.x, lane = l & 63u, wave = l >> 6;
-    const u32 in_len = (u32)it.in_len; /* <= HUFD_DEC_BLOCK_BYTES: the launch's side of the bargain */
-    /* Everything from memory in one go -- the table two entries a lane-load, the lane's own bits and the 32 behind them
-     * out of four aligned words (the stream's first byte sits anywhere) --: a trip to memory is most of such a call. */
+    const u32 in_len = (u32)it.in_len; /* <= HUFD_DEC_BLOCK_MAX_BYTES: the launch's side of the bargain */
     const u32 rem = in_len * 8;
-    const u32 n_lanes = (rem + kBlockDecLaneBits - 1) / kBlockDecLaneBits;
-    const bool active = l < n_lanes;
-    const u32 lane_from = l * kBlockDecLaneBits;
-    block_dec_bits bits, front;
+    const u8 *first = d_in + it.in_off;
+    const u32 lead = (u32)(reinterpret_cast<uintptr_t>(first) & 3u);
+    const u32 *words = reinterpret_cast<const u32 *>(first - lead);
+    const u32 mem_words = (lead + in_len + 3) / 4; /* the aligned words that hold bytes of the stream */
     {
+        /* the table, two entries a lane-load (the first turn's bits are asked for before these are waited for) */
         const u32 *lut_words = reinterpret_cast<const u32 *>(tb.dec_lut);
         u32 *lut_lds = reinterpret_cast<u32 *>(lut);
         const u32 lut_pairs = (1u << tb.lut_bits) / 2;
         static_assert((1u << HUFD_DEC_MAX_LUT_BITS) / 2 <= 2 * kBlockDecThreads, "two loads a lane hold the longest table");
-        const u32 t0 = l < lut_pairs ? lut_words[l] : 0u;
-        const u32 t1 = l + kBlockDecThreads < lut_pairs ? lut_words[l + kBlockDecThreads] : 0u;
-        const u8 *first = d_in + it.in_off;
-        const u32 lead = (u32)(reinterpret_cast<uintptr_t>(first) & 3u);
-        const u32 *words = reinterpret_cast<const u32 *>(first - lead);
-        const u32 mem_words = (lead + in_len + 3) / 4; /* the aligned words that hold bytes of the stream */
-        u32 m[6]; /* from the word two in front of the lane's own on: the lane in front's bits, for the guess */
-#pragma unroll
-        for (u32 k = 0; k < 6; ++k) {
-            m[k] = active && 2 * l + k >= 2 && 2 * l + k - 2 < mem_words ? words[2 * l + k - 2] : 0u;
-        }
-        u32 w[5];
-#pragma unroll
-        for (u32 k = 0; k < 5; ++k) {
-            const u32 i = 2 * l + k - 2; /* stream word i: bytes 4 i .. 4 i + 3, those behind the stream's end read as zero */
-            const u32 raw = (u32)((((u64)m[k + 1] << 32) | m[k]) >> (8 * lead));
-            const u32 have = 2 * l + k >= 2 && 4 * i < in_len ? (in_len - 4 * i < 4 ? in_len - 4 * i : 4u) : 0u;
-            const u32 big = __builtin_bswap32(raw);
-            w[k] = have == 4 ? big : (have ? big & (~0u << (8 * (4 - have))) : 0u);
-        }
-        front.w0 = w[0];
-        front.w1 = w[1];
-        front.w2 = w[2];
-        bits.w0 = w[2];
-        bits.w1 = w[3];
-        bits.w2 = w[4];
         if (l < lut_pairs) {
-            lut_lds[l] = t0;
+            lut_lds[l] = lut_words[l];
         }
         if (l + kBlockDecThreads < lut_pairs) {
-            lut_lds[l + kBlockDecThreads] = t1;
+            lut_lds[l + kBlockDecThreads] = lut_words[l + kBlockDecThreads];
         }
     }
     if (l == 0) {
         sh.stop_kind = HUFD_STOP_NONE;
         sh.stop_bit = kNoBit;
         sh.cap_bit = kNoBit;
-        sh.last_lane = kBlockDecThreads;
     }
-    __syncthreads();
-    block_dec_chain chain = {0, 0, kDeepStop};
-    u32 start = l == 0 ? it.first_bit : 0u;
-    if (active) {
+    /* HUFD_DEC_BLOCK_BYTES a turn; a turn's lane 0 is entered the way the turn before is left */
+    u32 symbols = 0, carry = it.first_bit;
+    const u32 turns = (in_len + HUFD_DEC_BLOCK_BYTES - 1) / HUFD_DEC_BLOCK_BYTES;
+    for (u32 turn = 0; turn < turns; ++turn) {
+        const u32 turn_from = turn * HUFD_DEC_BLOCK_BYTES * 8;
+        const u32 n_lanes = rem - turn_from < kBlockDecThreads * kBlockDecLaneBits
+                                ? (rem - turn_from + kBlockDecLaneBits - 1) / kBlockDecLaneBits : kBlockDecThreads;
+        const bool active = l < n_lanes;
+        const u32 lane_from = turn_from + l * kBlockDecLaneBits;
+        /* the lane's own bits and the 32 behind them, and the lane in front's for the guess, out of six aligned words
+         * (the stream's first byte sits anywhere): one trip to memory */
+        block_dec_bits bits, front;
+        {
+            const u32 w_first = lane_from / 32; /* the lane's first stream word */
+            u32 m[6];
+#pragma unroll
+            for (u32 k = 0; k < 6; ++k) {
+                m[k] = active && w_first + k >= 2 && w_first + k - 2 < mem_words ? words[w_first + k - 2] : 0u;
+            }
+            u32 w[5];
+#pragma unroll
+            for (u32 k = 0; k < 5; ++k) {
+                const u32 i = w_first + k - 2; /* stream word i: bytes 4 i .. 4 i + 3, those behind the stream's end read as zero */
+                const u32 raw = (u32)((((u64)m[k + 1] << 32) | m[k]) >> (8 * lead));
+                const u32 have = w_first + k >= 2 && 4 * i < in_len ? (in_len - 4 * i < 4 ? in_len - 4 * i : 4u) : 0u;
+                const u32 big = __builtin_bswap32(raw);
+                w[k] = have == 4 ? big : (have ? big & (~0u << (8 * (4 - have))) : 0u);
+            }
+            front.w0 = w[0];
+            front.w1 = w[1];
+            front.w2 = w[2];
+            bits.w0 = w[2];
+            bits.w1 = w[3];
+            bits.w2 = w[4];
+        }
         if (l == 0) {
-            block_dec_count<false>(lut, tb.lut_bits, bits, lane_from, rem, start, chain);
-        } else {
-            /* the first guess: how a walk from anywhere leaves the lane in front (lane 1's: the true walk) */
-            block_dec_chain guess = {0, 0, kDeepStop};
-            if (l == 1) {
-                block_dec_count<false>(lut, tb.lut_bits, front, 0u, rem, it.first_bit, guess);
-            } else {
-                block_dec_count<true>(lut, tb.lut_bits, front, lane_from - kBlockDecLaneBits, rem, 0u, guess);
-            }
-            if (guess.exit != kDeepStop) {
-                start = guess.exit;
-                block_dec_count<false>(lut, tb.lut_bits, bits, lane_from, rem, start, chain);
-            } else {
-                block_dec_count<true>(lut, tb.lut_bits, bits, lane_from, rem, 0u, chain);
-                start = kDeepStop; /* (no entry yet: whatever the lane in front says first is news) */
-            }
+            sh.last_lane = kBlockDecThreads;
         }
-    }
-    /* Settling: a lane whose entry is not how the lane in front leaves walks again from there.  A walk that stops says
-     * nothing to the lane behind it (from a wrong entry a window without a code is nothing special): that one keeps
-     * what it has.  When nothing changes any more, lane 0 has the true entry, so has every lane up to the first whose
-     * walk stops -- there the stream stops (source/huffman.c:232-255) -- and the lanes behind that one are not part of
-     * it.  (A lane that never heard from the one in front is behind such a lane.) */
-    for (u32 round = 0;; ++round) {
-        sh.exit_of[l] = (u8)(active ? chain.exit : kDeepStop);
-        if (l == 0) {
-            sh.changed[round & 1u] = 0; /* (the flag of the round before last: everyone has read it) */
-        }
-        __syncthreads();
-        if (active && l > 0) {
-            const u32 prev = sh.exit_of[l - 1];
-            if (prev != kDeepStop && prev != start) {
-                start = prev;
-                block_dec_count<false>(lut, tb.lut_bits, bits, lane_from, rem, start, chain);
-                sh.changed[round & 1u] = 1;
-            }
-        }
-        __syncthreads();
-        if (!sh.changed[round & 1u]) {
-            break;
-        }
-        if (round == kBlockDecRounds) {
-            /* a stream whose walks do not fall into step (codes of one length, say): the news travels a lane a round,
-             * and the chunk kernels' transfer functions are the better tool */
+        __syncthreads(); /* (first turn: the table is in LDS) */
+        block_dec_chain chain = {0, 0, kDeepStop};
+        u32 start = l == 0 ? carry : 0u;
+        if (active) {
             if (l == 0) {
-                hufd_dec_result rs = {};
-                rs.stop_kind = HUFD_STOP_GAVE_UP;
-                results[0] = rs;
+                block_dec_count<false>(lut, tb.lut_bits, bits, lane_from, rem, start, chain);
+            } else {
+                /* the first guess: how a walk from anywhere leaves the lane in front (lane 1's: the true walk) */
+                block_dec_chain guess = {0, 0, kDeepStop};
+                if (l == 1) {
+                    block_dec_count<false>(lut, tb.lut_bits, front, lane_from - kBlockDecLaneBits, rem, carry, guess);
+                } else {
+                    block_dec_count<true>(lut, tb.lut_bits, front, lane_from - kBlockDecLaneBits, rem, 0u, guess);
+                }
+                if (guess.exit != kDeepStop) {
+                    start = guess.exit;
+                    block_dec_count<false>(lut, tb.lut_bits, bits, lane_from, rem, start, chain);
+                } else {
+                    block_dec_count<true>(lut, tb.lut_bits, bits, lane_from, rem, 0u, chain);
+                    start = kDeepStop; /* (no entry yet: whatever the lane in front says first is news) */
+                }
             }
-            return;
         }
-    }
-    if (active && chain.exit == kDeepStop) {
-        atomicMin(&sh.last_lane, l);
-    }
-    __syncthreads();
-    const bool reached = active && l <= sh.last_lane;
-    /* where each lane's symbols go: an exclusive scan of the counts of the lanes on the true path */
-    const u32 mine = reached ? chain.count : 0u;
-    const u32 upto = wave_inclusive_sum(mine, lane);
-    if (lane == 63) {
-        sh.wave_total[wave] = upto;
-    }
-    __syncthreads();
-    u32 before = upto - mine, symbols = 0;
-    for (u32 w = 0; w < kBlockDecWaves; ++w) {
-        const u32 t = sh.wave_total[w];
-        before += w < wave ? t : 0u;
-        symbols += t;
-    }
-    if (reached) {
-        /* the symbols of the lane's chain, and what stopped it if something did */
-        u8 *out = d_out + it.out_off;
-        u32 rel = start, k = before, why = HUFD_STOP_NONE;
-        while (rel < kBlockDecLaneBits) {
-            if (lane_from + rel >= rem) {
-                why = HUFD_STOP_END;
+        /* Settling: a lane whose entry is not how the lane in front leaves walks again from there.  A walk that stops
+         * says nothing to the lane behind it (from a wrong entry a window without a code is nothing special): that one
+         * keeps what it has.  When nothing changes any more, lane 0 has the true entry, so has every lane up to the first
+         * whose walk stops -- there the stream stops (source/huffman.c:232-255) -- and the lanes behind that one are not
+         * part of it.  (A lane that never heard from the one in front is behind such a lane.) */
+        for (u32 round = 0;; ++round) {
+            sh.exit_of[l] = (u8)(active ? chain.exit : kDeepStop);
+            if (l == 0) {
+                sh.changed[round & 1u] = 0; /* (the flag of the round before last: everyone has read it) */
+            }
+            __syncthreads();
+            if (active && l > 0) {
+                const u32 prev = sh.exit_of[l - 1];
+                if (prev != kDeepStop && prev != start) {
+                    start = prev;
+                    block_dec_count<false>(lut, tb.lut_bits, bits, lane_from, rem, start, chain);
+                    sh.changed[round & 1u] = 1;
+                }
+            }
+            __syncthreads();
+            if (!sh.changed[round & 1u]) {
                 break;
             }
-            const u32 entry = lut[bits.window(rel) >> (32 - tb.lut_bits)];
-            const u32 len = entry & 0xFFu;
-            if (len == 0) {
-                why = HUFD_STOP_INVALID;
-                break;
+            if (round == kBlockDecRounds) {
+                /* a stream whose walks do not fall into step (codes of one length, say): the news travels a lane a
+                 * round, and the chunk kernels' transfer functions are the better tool */
+                if (l == 0) {
+                    hufd_dec_result rs = {};
+                    rs.stop_kind = HUFD_STOP_GAVE_UP;
+                    results[0] = rs;
+                }
+                return;
             }
-            if (lane_from + rel + len > rem) {
-                why = HUFD_STOP_INCOMPLETE;
-                break;
-            }
-            if (k < it.out_cap) {
-                out[k] = (u8)(entry >> 8);
-            } else if (k == it.out_cap) {
-                sh.cap_bit = lane_from + rel; /* source/huffman.c:257-268: this symbol is not consumed */
-            }
-            ++k;
-            rel += len;
         }
-        if (why != HUFD_STOP_NONE) {
-            sh.stop_kind = why;
-            sh.stop_bit = lane_from + rel;
+        if (active && chain.exit == kDeepStop) {
+            atomicMin(&sh.last_lane, l);
         }
+        __syncthreads();
+        const u32 last_lane = sh.last_lane;
+        const bool reached = active && l <= last_lane;
+        /* where each lane's symbols go: an exclusive scan of the counts of the lanes on the true path */
+        const u32 mine = reached ? chain.count : 0u;
+        const u32 upto = wave_inclusive_sum(mine, lane);
+        if (lane == 63) {
+            sh.wave_total[wave] = upto;
+        }
+        __syncthreads();
+        u32 before = symbols + upto - mine;
+        for (u32 w = 0; w < kBlockDecWaves; ++w) {
+            const u32 t = sh.wave_total[w];
+            before += w < wave ? t : 0u;
+            symbols += t;
+        }
+        if (reached) {
+            /* the symbols of the lane's chain, and what stopped it if something did */
+            u8 *out = d_out + it.out_off;
+            u32 rel = start, k = before, why = HUFD_STOP_NONE;
+            while (rel < kBlockDecLaneBits) {
+                if (lane_from + rel >= rem) {
+                    why = HUFD_STOP_END;
+                    break;
+                }
+                const u32 entry = lut[bits.window(rel) >> (32 - tb.lut_bits)];
+                const u32 len = entry & 0xFFu;
+                if (len == 0) {
+                    why = HUFD_STOP_INVALID;
+                    break;
+                }
+                if (lane_from + rel + len > rem) {
+                    why = HUFD_STOP_INCOMPLETE;
+                    break;
+                }
+                if (k < it.out_cap) {
+                    out[k] = (u8)(entry >> 8);
+                } else if (k == it.out_cap) {
+                    sh.cap_bit = lane_from + rel; /* source/huffman.c:257-268: this symbol is not consumed */
+                }
+                ++k;
+                rel += len;
+            }
+            if (why != HUFD_STOP_NONE) {
+                sh.stop_kind = why;
+                sh.stop_bit = lane_from + rel;
+            }
+        }
+        if (last_lane < n_lanes) {
+            break; /* the stream stops in this turn */
+        }
+        carry = sh.exit_of[n_lanes - 1];
+        __syncthreads(); /* the next turn writes what this one's lanes have just read */
     }
     __syncthreads();
     if (l == 0) {

@@ -1420,11 +1420,11 @@ static int one_shot_reserve(struct aws_huffman_amd_engine *eng, size_t in_bytes,
 enum {
     MINI_MAX_IN = 128,     /* symbols to encode / encoded bytes (carried ones included) that are ONE THREAD's work */
     MINI_IN_AT = 64,       /* block layout: [0] item record, [64] input (decode: 16 bytes for the carried ones first), */
-    MINI_ZERO_AT = 8320,   /* [8320] zero word, [8384] scratch, */
-    MINI_SCRATCH_AT = 8384,
-    MINI_RESULT_AT = 8448, /* [8448] result record, [8512] output */
-    MINI_OUT_AT = 8512,
-    MINI_BLOCK = 32768,
+    MINI_ZERO_AT = 32896,  /* [32896] zero word, [32960] scratch, */
+    MINI_SCRATCH_AT = 32960,
+    MINI_RESULT_AT = 33024, /* [33024] result record, [33088] output */
+    MINI_OUT_AT = 33088,
+    MINI_BLOCK = 131072,
     MINI_MAX_OUT = MINI_BLOCK - MINI_OUT_AT
 };
 
@@ -1602,7 +1602,7 @@ int aws_huffman_amd_engine_decode_host(
     eng->mini_output = false;
     /* (decode: one thread, or one workgroup up to HUFD_DEC_BLOCK_BYTES -- with long codes one wave up to
      * HUFD_DEC_COOP_BYTES; the chunk kernels take what is longer) */
-    const uint64_t mini_in = eng->tables.deep_entries ? HUFD_DEC_COOP_BYTES : HUFD_DEC_BLOCK_BYTES;
+    const uint64_t mini_in = eng->tables.deep_entries ? HUFD_DEC_COOP_BYTES : HUFD_DEC_BLOCK_MAX_BYTES;
     if (carry_bytes + in_len <= mini_in && carry_bytes + in_len > 0 && dev_out <= MINI_MAX_OUT && mini_ready(eng)) {
         struct hufd_dec_item rec;
         memset(&rec, 0, sizeof(rec));

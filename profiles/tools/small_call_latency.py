@@ -15,7 +15,7 @@ lib = harness.load_product()
 codec = harness.Codec(lib, "aws_")
 patterns, lens = harness.load_table()
 coder = lib.aws_huffman_amd_table_coder_new(patterns, lens)
-for n in (15, 300, 1024, 4096, 8192, 65536):
+for n in (15, 300, 1024, 4096, 8192, 16384, 24576, 65536):
     data = (32 + harness.splitmix64_bytes(3, n) % 95).astype(np.uint8)
     enc = np.zeros(2 * n + 16, np.uint8)
     back = np.zeros(n, np.uint8)

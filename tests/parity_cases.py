@@ -359,7 +359,7 @@ def garbage_decode(w, seed=15, rounds=120, big=70000):
         assert dst[: r.produced].tobytes().hex() == rec["symbols"]
 
 
-# ----------------------------------------------------------------------------- scenario: host-pointer decode calls of one workgroup's size (dec_block: up to 8 KiB encoded)
+# ----------------------------------------------------------------------------- scenario: host-pointer decode calls of one workgroup's size (dec_block: up to 32 KiB encoded, 8 KiB a turn)
 def block_decode_calls(w, seed=73):
     rng = np.random.default_rng(seed)
 
@@ -376,7 +376,8 @@ def block_decode_calls(w, seed=73):
     plain = (w.ocoder, w.pcoder)
     # whole valid streams around the road's limits: 129 and 8192 encoded bytes, a lane's 8 bytes, a wave's 512
     for kind in KINDS:
-        for want in (129, 130, 136, 137, 511, 512, 513, 520, 1000, 4096, 8184, 8191, 8192, 8193):
+        for want in (129, 130, 136, 137, 511, 512, 513, 520, 1000, 4096, 8184, 8191, 8192, 8193, 8200, 12000, 16384, 16385,
+                     32760, 32768, 32769):
             n = want  # symbols; trimmed until the stream has the wanted length
             data = inputs(rng, 2 * want, kind)
             lo, hi = 0, data.size
@@ -392,7 +393,7 @@ def block_decode_calls(w, seed=73):
             both(plain, stream, (n,), first=3)
             both(plain, stream[: stream.size - 1], (n,))  # the last code cut off (or the padding missing)
     # any bytes at all; bytes that never fall into step (one value); no code at all for 30 bits of ones in the middle
-    for size in (200, 777, 2048, 5000, 8192):
+    for size in (200, 777, 2048, 5000, 8192, 8200, 20000, 32768):
         both(plain, rng.integers(0, 256, size, dtype=np.uint8), (2 * size, 17))
         for v in (0x00, 0xFF, 0x55, 0x9C):
             both(plain, np.full(size, v, np.uint8), (2 * size, size // 3))
@@ -401,6 +402,12 @@ def block_decode_calls(w, seed=73):
         bad = good.copy()
         bad[at : at + 4] = 0xFF
         both(plain, bad, (3000, 40))
+    good = oracle_encode(w, inputs(rng, 20000, "uniform"))  # three turns of the workgroup
+    for at in (8188, 8192, 8196, 16380, 16384, good.size - 6):
+        bad = good.copy()
+        bad[at : at + 4] = 0xFF
+        both(plain, bad, (20000, 7000))
+    both(plain, good, (20000, 6913, 6914, 13000), first=5)
     # a coder with holes: windows without a code stop the walk where the reference's does
     holes = (w.ocoder_holes, w.pcoder_holes)
     for size in (300, 3000, 8000):
