@@ -20,6 +20,7 @@
 #define HUFD_ENC_SEG_BYTES 16384u
 #define HUFD_ENC_THREADS 256u
 #define HUFD_ENC_BLOCK_BYTES 4096u /* one host-pointer call of up to this many symbols is one workgroup's work (enc_block): one launch */
+#define HUFD_ENC_BLOCK_MAX_BYTES 16384u /* ... and up to this many a workgroup of four times the lanes', if the bit image fits 64 KiB of LDS */
 #define HUFD_ENC_TINY_BYTES 512u /* encode items up to this long are one thread's work (enc_tiny): no segments */
 
 #define HUFD_DEC_SUB_BYTES 128u

@@ -138,9 +138,11 @@ int hufk_decode_one_coop(
 int hufk_decode_one_block(
     const struct hufd_tables *tables, const struct hufd_dec_item *item, const void *d_in, void *d_out,
     struct hufd_dec_item_state *state, struct hufd_dec_result *result, void *stream);
-/* one item of up to HUFD_ENC_BLOCK_BYTES symbols, one workgroup, one launch (enc_block_kernel) */
+/* one item of up to HUFD_ENC_BLOCK_MAX_BYTES symbols, one workgroup, one launch (enc_block_kernel); `symbols` = the
+ * item's in_len (the record itself is in device memory); _fits: whether such an item of this coder is taken */
+int hufk_encode_one_block_fits(const struct hufd_tables *tables, uint64_t symbols);
 int hufk_encode_one_block(
-    const struct hufd_tables *tables, const struct hufd_enc_item *item, const void *d_in, void *d_out,
+    const struct hufd_tables *tables, const struct hufd_enc_item *item, uint32_t symbols, const void *d_in, void *d_out,
     struct hufd_enc_result *result, uint32_t length_only, void *stream);
 int hufk_fill_splitmix64(void *dst, uint64_t len, uint64_t seed, void *stream);
 

@@ -760,7 +760,7 @@ __global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
 }
 
 /*
- * One item of at most HUFD_ENC_BLOCK_BYTES symbols, one workgroup, ONE launch: count, offsets, outcome and bits in
+ * One item of at most HUFD_ENC_BLOCK_MAX_BYTES symbols, one workgroup (of 256 lanes up to HUFD_ENC_BLOCK_BYTES), ONE launch: count, offsets, outcome and bits in
  * one go (the host-pointer calls' road for inputs beyond a header field: with segments the same call is a plan
  * upload and four or five launches).  A thread takes 16 symbols; the outcome is the reference's, in closed form as
  * in enc_finish_item: with `o` carried bits, T bits in all, room for A bytes, first symbol without a code `u` at bit
@@ -768,14 +768,17 @@ __global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
  * in flight is lost), else SUCCESS iff no such symbol and T <= 8A (padded, :178-184), else SHORT_BUFFER with the
  * symbol whose last bit reaches bit 8A consumed and what of its code lies behind that bit carried (:88-100).
  */
-constexpr u32 kBlockEncThreads = 256;
+constexpr u32 kBlockEncThreads = 256;      /* up to HUFD_ENC_BLOCK_BYTES symbols */
+constexpr u32 kBlockEncWideThreads = 1024; /* up to HUFD_ENC_BLOCK_MAX_BYTES (round 3): the same code, four times the lanes */
+static_assert(kBlockEncThreads * 16 == HUFD_ENC_BLOCK_BYTES && kBlockEncWideThreads * 16 == HUFD_ENC_BLOCK_MAX_BYTES, "16 symbols a lane");
 
 struct enc_block_shared {
     u64 unk_key;   /* lowest (index << 32 | bits in front) of a symbol without a code */
     u32 short_consumed, short_ovf_bits, short_ovf_pattern, pad;
-    u32 slots[8];
+    u32 slots[kBlockEncWideThreads / 64];
 };
 
+template <u32 kBlockEncThreads>
 __global__ __launch_bounds__(kBlockEncThreads) void enc_block_kernel(
     hufd_tables tb,
     const hufd_enc_item *item_ptr,
@@ -789,7 +792,9 @@ __global__ __launch_bounds__(kBlockEncThreads) void enc_block_kernel(
     u64 *tab = reinterpret_cast<u64 *>(dyn_lds + round16(img_words * 4));
     enc_block_shared *sh = reinterpret_cast<enc_block_shared *>(tab + 256);
     const u32 tid = threadIdx.x;
-    tab[tid] = tb.enc_table[tid];
+    if (tid < 256) {
+        tab[tid] = tb.enc_table[tid];
+    }
     const hufd_enc_item it = *item_ptr;
     const u32 n = (u32)it.in_len;
     const u8 *src = d_in + it.in_off;
@@ -7593,16 +7598,36 @@ int hufk_encode_one_tiny(
     return (int)hipGetLastError();
 }
 
+int hufk_encode_one_block_fits(const struct hufd_tables *tables, uint64_t symbols) {
+    if (symbols <= HUFD_ENC_BLOCK_BYTES) {
+        return 1;
+    }
+    const uint32_t bits = HUFD_ENC_BLOCK_MAX_BYTES * tables->max_bits + 32 + 128 + 64;
+    const uint32_t img_words = ((bits + 31) / 32 + 3) & ~3u;
+    return symbols <= HUFD_ENC_BLOCK_MAX_BYTES &&
+           ((img_words * 4 + 15) & ~15u) + 256 * 8 + (uint32_t)sizeof(enc_block_shared) <= 65536u;
+}
+
 int hufk_encode_one_block(
-    const struct hufd_tables *tables, const struct hufd_enc_item *item, const void *d_in, void *d_out,
+    const struct hufd_tables *tables, const struct hufd_enc_item *item, uint32_t symbols, const void *d_in, void *d_out,
     struct hufd_enc_result *result, uint32_t length_only, void *stream) {
-    /* (the image: HUFD_ENC_BLOCK_BYTES symbols of the longest code, carried bits, alignment, padding) */
-    const uint32_t bits = HUFD_ENC_BLOCK_BYTES * tables->max_bits + 32 + 128 + 64;
+    /* (the image: the symbols of the longest code, carried bits, alignment, padding) */
+    const bool wide = symbols > HUFD_ENC_BLOCK_BYTES;
+    const uint32_t bits = (wide ? HUFD_ENC_BLOCK_MAX_BYTES : HUFD_ENC_BLOCK_BYTES) * tables->max_bits + 32 + 128 + 64;
     const uint32_t img_words = ((bits + 31) / 32 + 3) & ~3u;
     const uint32_t lds = ((img_words * 4 + 15) & ~15u) + 256 * 8 + (uint32_t)sizeof(enc_block_shared);
-    hipLaunchKernelGGL(
-        enc_block_kernel, dim3(1), dim3(kBlockEncThreads), lds, (hipStream_t)stream, *tables, item, (const u8 *)d_in,
-        (u8 *)d_out, result, img_words, length_only);
+    if (symbols > HUFD_ENC_BLOCK_MAX_BYTES || lds > 65536u) {
+        return (int)hipErrorInvalidValue; /* (hufk_encode_one_block_fits) */
+    }
+    if (wide) {
+        hipLaunchKernelGGL(
+            enc_block_kernel<kBlockEncWideThreads>, dim3(1), dim3(kBlockEncWideThreads), lds, (hipStream_t)stream, *tables, item,
+            (const u8 *)d_in, (u8 *)d_out, result, img_words, length_only);
+    } else {
+        hipLaunchKernelGGL(
+            enc_block_kernel<kBlockEncThreads>, dim3(1), dim3(kBlockEncThreads), lds, (hipStream_t)stream, *tables, item,
+            (const u8 *)d_in, (u8 *)d_out, result, img_words, length_only);
+    }
     return (int)hipGetLastError();
 }
 

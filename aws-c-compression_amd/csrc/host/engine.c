@@ -1478,7 +1478,7 @@ static int mini_encode(
             eng->stream);
     } else if (!err) {
         err = hufk_encode_one_block(
-            &eng->tables, (const struct hufd_enc_item *)eng->mini_dev, eng->mini_dev, eng->mini_dev,
+            &eng->tables, (const struct hufd_enc_item *)eng->mini_dev, (uint32_t)item->in_len, eng->mini_dev, eng->mini_dev,
             (struct hufd_enc_result *)(eng->mini_dev + MINI_RESULT_AT), length_only, eng->stream);
     }
     if (!err) {
@@ -1529,7 +1529,7 @@ int aws_huffman_amd_engine_encode_host(
     const uint64_t dev_out = item.out_capacity < worst ? item.out_capacity : worst;
     item.in_offset = 0;
     item.out_offset = 0;
-    if (item.in_len <= HUFD_ENC_BLOCK_BYTES && (item.in_len || item.overflow_in.num_bits) && item.overflow_in.num_bits <= 32 &&
+    if (hufk_encode_one_block_fits(&eng->tables, item.in_len) && (item.in_len || item.overflow_in.num_bits) && item.overflow_in.num_bits <= 32 &&
         (length_only || dev_out <= MINI_MAX_OUT) && mini_ready(eng)) {
         return mini_encode(eng, &item, dev_out, host_in, host_out, length_only, raw);
     }
