@@ -11,5 +11,8 @@ mkdir -p "$OUT"
 cd "$ROOT"
 for tool in other_distributions tiny_items mid_items host_path_rate small_call_latency long_code_stream coder_survey; do
     timeout 900 python3 profiles/tools/$tool.py > "$OUT/$tool.txt" 2> "$OUT/$tool.err"
+    if [ "$tool" = long_code_stream ]; then  # and a stream long enough to fill the chip a workgroup per 32 KiB block
+        timeout 900 python3 profiles/tools/$tool.py hpack_lengths 134217728 >> "$OUT/$tool.txt" 2>> "$OUT/$tool.err"
+    fi
     echo "== $tool"; tail -4 "$OUT/$tool.txt"
 done
