@@ -47,6 +47,7 @@
 #define HUFD_DEC_COOP_BYTES 768u /* ... and up to this long one wave's (dec_deep<false>): no chunks either */
 #define HUFD_DEC_BLOCK_BYTES 8192u /* what dec_block's workgroup takes in one turn: a lane per 64 bits */
 #define HUFD_DEC_BLOCK_MAX_BYTES (4u * HUFD_DEC_BLOCK_BYTES) /* one host-pointer call of up to this many encoded bytes (short codes) is that one workgroup's work: one launch */
+#define HUFD_FIXED_BLOCK_BYTES 16384u /* a coder whose codes all have one length: its longer items are decoded this many bytes a workgroup (dec_fixed_*) */
 #define HUFD_WIDE_BLOCK_BYTES 32768u /* a long item of a coder with long codes is decoded this many bytes a workgroup (dec_wide_*) */
 #define HUFD_WIDE_MIN_BYTES (4u * HUFD_WIDE_BLOCK_BYTES) /* ... when it is at least this long and the batch has fewer than HUFD_WIDE_FEW_ITEMS such items, */
 #define HUFD_WIDE_FEW_ITEMS 128u
@@ -96,6 +97,9 @@ struct hufd_tables {
     uint32_t deep_entries; /* != 0: codes longer than HUFD_DEC_MAX_LUT_BITS, decode walks deep_lut instead of dec_lut */
     const uint32_t *deep_lut; /* [deep_entries] root table of 1 << HUFD_DEEP_ROOT_BITS entries, then the linked ones;
                                * an entry is symbol << 8 | length, 0 = no code, or a link */
+    uint32_t fixed_bits; /* != 0: every code the decode table knows has this length: symbol k starts at bit k * fixed_bits,
+                          * no walk has to find it (dec_fixed_*) */
+    uint32_t reserved;
 };
 
 struct hufd_enc_item {

@@ -68,6 +68,9 @@ struct hufk_decode_args {
     uint64_t wide_from;
     void *wide_block; /* scratch: hufk_decode_wide_bytes(blocks) each, at the offsets in `wide` */
     uint32_t wide_fails; /* 1: they give up (tests of the way back) */
+    /* a coder with codes of one length (tables.fixed_bits): its items beyond a thread's work, 16 KiB blocks of them */
+    const uint32_t *fixed_blocks; /* [n_fixed_blocks][2]: item, block of HUFD_FIXED_BLOCK_BYTES inside it */
+    uint32_t n_fixed_blocks;
     const uint32_t *large_items; /* per item with more than HUFD_SCAN_SMALL_MAX chunks: item index, its first run */
     uint32_t n_large;
     const uint32_t *runs;        /* per run of HUFD_SCAN_RUN_CHUNKS chunks of a large item: item index, run number */

@@ -5300,6 +5300,119 @@ __global__ __launch_bounds__(kDeepThreads) void dec_wide_emit_kernel(
 }
 
 /*
+ * A coder whose codes all have ONE length L (tables.fixed_bits): symbol k of an item starts at bit first_bit + k L.
+ * Nothing has to be found -- and the walks of the chunked decoder never fall into step on such a stream (L phases,
+ * every one of them valid for ever), which sends every chunk the long way at a twentieth of the speed.  Items beyond a
+ * thread's work are taken 16 KiB a workgroup, 64 bytes a lane, in three launches:
+ *   dec_fixed_check   the first symbol without a code, if there is one (source/huffman.c:240-247): a minimum per item;
+ *   dec_fixed_finish  a thread per item: how many symbols, where and why the stream stops (:232-255), the start bit of
+ *                     symbol number out_cap (:257-268);
+ *   dec_fixed_emit    the symbols in front of all that.
+ */
+constexpr u32 kFixedThreads = 256;
+constexpr u32 kFixedLaneBytes = HUFD_FIXED_BLOCK_BYTES / kFixedThreads;
+
+/* the symbols whose codes START in the lane's bytes and lie wholly inside the stream: [k0, k1) */
+struct fixed_span {
+    u64 k0, k1;
+};
+__device__ __forceinline__ fixed_span fixed_span_of(const hufd_dec_item &it, u32 L, u64 from_byte, u64 to_byte) {
+    const u64 rem = it.in_len * 8, n_full = rem > it.first_bit ? (rem - it.first_bit) / L : 0;
+    const u64 from = from_byte * 8, to = to_byte * 8;
+    fixed_span s;
+    s.k0 = from <= it.first_bit ? 0 : (from - it.first_bit + L - 1) / L;
+    s.k1 = to <= it.first_bit ? 0 : (to - it.first_bit + L - 1) / L;
+    s.k0 = s.k0 < n_full ? s.k0 : n_full;
+    s.k1 = s.k1 < n_full ? s.k1 : n_full;
+    return s;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(kFixedThreads) void dec_fixed_kernel(
+    hufd_tables tb, const hufd_dec_item *items, const u32 *blocks, const u8 *d_in, u8 *d_out, hufd_dec_item_state *states) {
+
+    u16 *lut = reinterpret_cast<u16 *>(dyn_lds);
+    for (u32 i = threadIdx.x; i < (1u << tb.lut_bits); i += kFixedThreads) {
+        lut[i] = tb.dec_lut[i];
+    }
+    __syncthreads();
+    const u32 item = blocks[2 * blockIdx.x];
+    const hufd_dec_item it = items[item];
+    const u32 L = tb.fixed_bits;
+    const u64 from = (u64)blocks[2 * blockIdx.x + 1] * HUFD_FIXED_BLOCK_BYTES + (u64)threadIdx.x * kFixedLaneBytes;
+    if (from >= it.in_len) {
+        return;
+    }
+    const u64 to = from + kFixedLaneBytes < it.in_len ? from + kFixedLaneBytes : it.in_len;
+    fixed_span sp = fixed_span_of(it, L, from, to);
+    if (EMIT) {
+        /* what dec_fixed_finish left: the symbols the stream holds; those with room are written */
+        const u64 total = states[item].total_symbols, limit = total < it.out_cap ? total : it.out_cap;
+        sp.k1 = sp.k1 < limit ? sp.k1 : limit;
+    }
+    if (sp.k0 >= sp.k1) {
+        return;
+    }
+    const u64 pos = it.first_bit + sp.k0 * L;
+    stream_reader sr;
+    sr.start(d_in + it.in_off + (pos >> 3), it.in_len - (pos >> 3), (u32)(pos & 7));
+    symbol_sink sink;
+    sink.begin(EMIT ? d_out + it.out_off + sp.k0 : nullptr);
+    for (u64 k = sp.k0; k < sp.k1; ++k) {
+        const u32 entry = lut[sr.peek() >> (32 - tb.lut_bits)];
+        if (EMIT) {
+            sink.put(entry >> 8);
+        } else if ((entry & 0xFFu) == 0) {
+            atomicMin(reinterpret_cast<unsigned long long *>(&states[item].total_symbols), (unsigned long long)k);
+            break;
+        }
+        sr.skip(L);
+    }
+    if (EMIT) {
+        sink.flush();
+    }
+}
+
+__global__ __launch_bounds__(256) void dec_fixed_finish_kernel(
+    hufd_tables tb, const hufd_dec_item *items, u32 n_items, const u8 *d_in, hufd_dec_item_state *states, hufd_dec_result *results) {
+
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) {
+        return;
+    }
+    const hufd_dec_item it = items[i];
+    if (it.tiny != 2) {
+        return;
+    }
+    const u32 L = tb.fixed_bits;
+    const u64 rem = it.in_len * 8, n_full = rem > it.first_bit ? (rem - it.first_bit) / L : 0;
+    const u64 first_bad = states[i].total_symbols; /* dec_fixed_check's minimum, all ones if every code is one */
+    hufd_dec_result rs;
+    rs.reserved = 0;
+    if (first_bad < n_full) {
+        rs.total_symbols = first_bad;
+        rs.stop_kind = HUFD_STOP_INVALID;
+        rs.stop_bit = it.first_bit + first_bad * L;
+    } else {
+        rs.total_symbols = n_full;
+        const u64 pos = it.first_bit + n_full * L;
+        rs.stop_bit = pos;
+        if (pos >= rem) {
+            rs.stop_kind = HUFD_STOP_END;
+        } else {
+            /* fewer than L bits left: a window without a code, or a code cut off (source/huffman.c:232-255, in that order) */
+            stream_reader sr;
+            sr.start(d_in + it.in_off + (pos >> 3), it.in_len - (pos >> 3), (u32)(pos & 7));
+            const u32 entry = tb.dec_lut[sr.peek() >> (32 - tb.lut_bits)];
+            rs.stop_kind = (entry & 0xFFu) == 0 ? HUFD_STOP_INVALID : HUFD_STOP_INCOMPLETE;
+        }
+    }
+    rs.cap_bit = rs.total_symbols > it.out_cap ? it.first_bit + it.out_cap * L : kNoBit;
+    results[i] = rs;
+    states[i].total_symbols = rs.total_symbols;
+}
+
+/*
  * One host-pointer call of more than one thread's bytes and up to HUFD_DEC_BLOCK_MAX_BYTES of them (short codes),
  * HUFD_DEC_BLOCK_BYTES a turn: ONE workgroup and one launch, as enc_block is for the encoder -- a chunk's tables, lists and five more launches cost
  * such a call several times its symbols.  A lane takes 64 bits of the stream and keeps them, with the 32 behind them,
@@ -7689,6 +7802,9 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     }
     const uint32_t ns = a->tables.n_states;
     stage_mark(a->stage_events, 0, st);
+    if (a->n_fixed_blocks && a->tables.fixed_bits) {
+        (void)hipMemsetAsync(a->states, 0xFF, (size_t)a->n_items * sizeof(hufd_dec_item_state), st);
+    }
     /* The chunks inside streams in ONE pass (dec_onepass) where the coder allows: the kernels of the two-pass road for
      * those chunks are queued behind it all the same and look at its ctl word first -- they run only if it gave up. */
     const u32 *gate = nullptr;
@@ -7929,6 +8045,20 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             dec_deep_kernel<false>, dim3(a->n_deep), dim3(kCoopThreads), sizeof(deep_shared) + (1u << a->tables.lut_bits) * sizeof(u16),
             st, a->tables, a->items, a->deep_items, 0u, (const u8 *)a->d_in, (u8 *)a->d_out, a->states, a->results, ~0ull,
             (const u32 *)nullptr);
+    }
+    if (a->n_fixed_blocks && a->tables.fixed_bits) {
+        /* (the items' state words start as "no symbol without a code": dec_fixed_check takes a minimum in them; the other
+         * items' are written by their own kernels, behind this) */
+        const uint32_t lds = (1u << a->tables.lut_bits) * sizeof(u16);
+        hipLaunchKernelGGL(
+            dec_fixed_kernel<false>, dim3(a->n_fixed_blocks), dim3(kFixedThreads), lds, st, a->tables, a->items, a->fixed_blocks,
+            (const u8 *)a->d_in, (u8 *)a->d_out, a->states);
+        hipLaunchKernelGGL(
+            dec_fixed_finish_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->tables, a->items, a->n_items,
+            (const u8 *)a->d_in, a->states, a->results);
+        hipLaunchKernelGGL(
+            dec_fixed_kernel<true>, dim3(a->n_fixed_blocks), dim3(kFixedThreads), lds, st, a->tables, a->items, a->fixed_blocks,
+            (const u8 *)a->d_in, (u8 *)a->d_out, a->states);
     }
     if (a->n_large) {
         const uint32_t lds = scan_run_lds_bytes(ns);

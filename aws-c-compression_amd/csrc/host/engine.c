@@ -302,6 +302,8 @@ int aws_huffman_amd_engine_new(
     eng->tables.max_bits = max_bits;
     eng->tables.min_bits = min_bits; /* (33: no code known yet) */
     eng->tables.n_states = max_bits > 8 ? max_bits : 8;
+    /* every code the DECODE table knows has one length: symbol k starts at bit k * length (dec_fixed_*) */
+    eng->tables.fixed_bits = eng->can_decode && dec_max && dec_min == dec_max && dec_max <= HUFD_DEC_MAX_LUT_BITS ? dec_max : 0;
 
     if (!eng->can_decode && coder->decode) {
         if (deep_table_build(eng, coder)) {
@@ -892,9 +894,15 @@ static bool dec_item_is_deep(
     return it->in_len > tiny_limit && (eng->tables.deep_entries || it->in_len <= HUFD_DEC_COOP_BYTES);
 }
 
+/* (codes of one length: no chunks, no walks to bring into step) */
+static bool dec_item_is_fixed(
+    const struct aws_huffman_amd_engine *eng, const struct aws_huffman_amd_decode_item *it, uint64_t tiny_limit) {
+    return eng->tables.fixed_bits && it->in_len > tiny_limit;
+}
+
 static uint64_t dec_item_chunks(
     const struct aws_huffman_amd_engine *eng, const struct aws_huffman_amd_decode_item *it, uint64_t tiny_limit) {
-    if (dec_item_is_tiny(it, tiny_limit) || dec_item_is_deep(eng, it, tiny_limit)) {
+    if (dec_item_is_tiny(it, tiny_limit) || dec_item_is_fixed(eng, it, tiny_limit) || dec_item_is_deep(eng, it, tiny_limit)) {
         return 0;
     }
     return (it->in_len + HUFD_DEC_CHUNK_BYTES - 1) / HUFD_DEC_CHUNK_BYTES;
@@ -962,6 +970,8 @@ static int dec_plan_fill(
         deep_items += !dec_item_is_tiny(&items[i], tiny_limit) && dec_item_is_deep(eng, &items[i], tiny_limit);
     }
     const uint64_t wide_from = wide_min_bytes(deep_items);
+    uint32_t *h_fixed = NULL;
+    uint64_t n_fixed = 0;
     struct hufk_wide_item *h_wide = NULL;
     uint32_t n_wide = 0;
     uint64_t wide_bytes = 0;
@@ -982,6 +992,20 @@ static int dec_plan_fill(
         if (dec_item_is_tiny(src, tiny_limit)) {
             dst->tiny = 1;
             h_tiny[tiny++] = (uint32_t)i;
+        } else if (dec_item_is_fixed(eng, src, tiny_limit)) {
+            dst->tiny = 2;
+            const uint64_t blocks = (src->in_len + HUFD_FIXED_BLOCK_BYTES - 1) / HUFD_FIXED_BLOCK_BYTES;
+            uint32_t *more = realloc(h_fixed, (n_fixed + blocks) * 2 * sizeof(uint32_t));
+            if (!more) {
+                wide_oom = true;
+            } else {
+                h_fixed = more;
+                for (uint64_t k = 0; k < blocks; ++k) {
+                    h_fixed[2 * (n_fixed + k)] = (uint32_t)i;
+                    h_fixed[2 * (n_fixed + k) + 1] = (uint32_t)k;
+                }
+                n_fixed += blocks;
+            }
         } else if (dec_item_is_deep(eng, src, tiny_limit)) {
             dst->tiny = 1;
             h_tiny[n_items - ++deep] = (uint32_t)i;
@@ -1056,6 +1080,22 @@ static int dec_plan_fill(
     for (uint32_t k = 0; k < n_wide; ++k) {
         h_wide[k].slot = deep - h_wide[k].slot; /* the deep items are the last `deep` of d_tiny, filled from the back */
     }
+    if (!err && n_fixed > 0xFFFFFFFFull) {
+        err = 2;
+    }
+    if (!err && n_fixed > p->cap_fixed) {
+        hufs_free(p->d_fixed);
+        p->d_fixed = hufs_malloc(n_fixed * 2 * sizeof(uint32_t));
+        p->cap_fixed = p->d_fixed ? n_fixed : 0;
+        err = p->d_fixed ? 0 : 2;
+    }
+    if (!err && n_fixed) {
+        err = hufs_copy_h2d(p->d_fixed, h_fixed, n_fixed * 2 * sizeof(uint32_t), eng->stream);
+        if (!err) {
+            err = hufs_stream_sync(eng->stream); /* (h_fixed is freed below) */
+        }
+    }
+    free(h_fixed);
     if (!err && wide_bytes > p->cap_wide_block) {
         hufs_free(p->d_wide_block);
         p->d_wide_block = hufs_malloc(wide_bytes);
@@ -1167,6 +1207,7 @@ static int dec_plan_fill(
     p->h_wide = h_wide;
     p->n_wide = n_wide;
     p->wide_from = wide_from;
+    p->n_fixed = (uint32_t)n_fixed;
     p->n_items = (uint32_t)n_items;
     p->n_chunks = (uint32_t)n_chunks;
     p->n_large = (uint32_t)n_large;
@@ -1211,6 +1252,7 @@ void aws_huffman_amd_decode_plan_destroy(struct aws_huffman_amd_decode_plan *p) 
         ON_DEVICE(p->engine->device);
         dec_plan_release_device(p);
         hufs_free(p->d_wide_block);
+        hufs_free(p->d_fixed);
         free(p->h_wide);
         free(p->h_items);
         free(p);
@@ -1248,6 +1290,8 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.n_wide = p->n_wide;
     a.wide_from = p->wide_from;
     a.wide_block = p->d_wide_block;
+    a.fixed_blocks = p->d_fixed;
+    a.n_fixed_blocks = p->n_fixed;
     a.tiny_items = p->d_tiny;
     a.n_tiny = p->n_tiny;
     a.large_items = p->d_large;
@@ -1602,7 +1646,9 @@ int aws_huffman_amd_engine_decode_host(
     eng->mini_output = false;
     /* (decode: one thread, or one workgroup up to HUFD_DEC_BLOCK_BYTES -- with long codes one wave up to
      * HUFD_DEC_COOP_BYTES; the chunk kernels take what is longer) */
-    const uint64_t mini_in = eng->tables.deep_entries ? HUFD_DEC_COOP_BYTES : HUFD_DEC_BLOCK_MAX_BYTES;
+    /* (codes of one length: dec_block's lanes would never settle -- a thread, or the plan's dec_fixed kernels) */
+    const uint64_t mini_in =
+        eng->tables.deep_entries ? HUFD_DEC_COOP_BYTES : (eng->tables.fixed_bits ? MINI_MAX_IN : HUFD_DEC_BLOCK_MAX_BYTES);
     if (carry_bytes + in_len <= mini_in && carry_bytes + in_len > 0 && dev_out <= MINI_MAX_OUT && mini_ready(eng)) {
         struct hufd_dec_item rec;
         memset(&rec, 0, sizeof(rec));

@@ -121,6 +121,10 @@ struct aws_huffman_amd_decode_plan {
     uint64_t wide_from; /* encoded bytes from which an item was taken for one */
     void *d_wide_block;
     size_t cap_wide_block;
+    /* a coder with codes of one length: (item, 16 KiB block) for every block of its items beyond a thread's work (dec_fixed_*) */
+    uint32_t *d_fixed;
+    uint32_t n_fixed;
+    size_t cap_fixed;
 };
 
 /* the engine cache of huffman.c: what an engine is recognised by besides the coder's address, and the two ways out of it */

@@ -462,7 +462,8 @@ CODER_PROFILES = {
     "len1to16": [(1, 1), (1, 2), (2, 4), (4, 7), (8, 9), (240, 16)],      # codes shorter than 4 bits: the streaming packer
     "len2to12": [(2, 2), (4, 4), (8, 6), (16, 8), (226, 12)],            # short codes and decode: > 255 symbols a sub-chunk
     "len2to30": [(2, 2), (4, 5), (10, 8), (240, 30)],                    # long codes: the per-symbol packer
-    "len8": [(256, 8)],                                                  # fixed length, decode table of 8 bits
+    "len8": [(256, 8)],                                                  # fixed length, decode table of 8 bits: dec_fixed
+    "len9": [(256, 9)],                                                  # fixed length, half the windows without a code
     # the code lengths of RFC 7541 appendix B (HPACK, the reference's one production coder, in aws-c-http) less its
     # 30-bit EOS: an incomplete code, decode through linked tables
     "hpack_lengths": [(10, 5), (26, 6), (32, 7), (6, 8), (5, 10), (3, 11), (2, 12), (6, 13), (2, 14), (3, 15), (3, 19),
@@ -1041,6 +1042,56 @@ def tiny_decode_items(w, n_items=1500, seed=41, engine=None, profile=None, max_l
         eng.close()
 
 
+def decode_items_like_the_oracle(w, eng, ocoder, streams, rng, label, modes=(None,), kinds=3):
+    """streams: (encoded bytes, first bit, output capacity) each; one plan of them all, launched twice per mode, every
+    record and every output byte (and the bytes between the outputs) as the oracle has them."""
+    offs, pos = [], 3
+    for e, _, _ in streams:
+        offs.append(pos)
+        pos += e.size + int(rng.integers(0, 9))
+    host_enc = np.zeros(pos + 64, np.uint8)
+    for (e, _, _), o in zip(streams, offs):
+        host_enc[o:o + e.size] = e
+    items, expect, pos = [], [], 7
+    for (e, fb, cap), o in zip(streams, offs):
+        d = w.oracle.new_decoder(ocoder)
+        start = 0
+        if fb:  # the rest of the first byte is what a previous call left in the decoder
+            d.working_bits = (int(e[0]) & (0xFF >> fb)) << (56 + fb)
+            d.num_bits = 8 - fb
+            start = 1
+        dst = np.full(cap + 1, SENTINEL, np.uint8)
+        r = w.oracle.decode_call(d, e, start, e.size, dst, 0, cap)
+        bits = (8 - fb if fb else 0) + r.consumed * 8 - r.state[0]
+        expect.append(((r.rc, r.err, r.produced, bits), dst[:cap].copy()))
+        items.append(dict(in_offset=o, in_len=e.size, first_bit=fb, out_offset=pos, out_capacity=cap))
+        pos += cap + int(rng.integers(1, 9))
+    sym_total = pos + 64
+    d_enc, d_sym = eng.alloc(host_enc.size), eng.alloc(sym_total)
+    eng.upload(d_enc, host_enc)
+    want = np.full(sym_total, SENTINEL, np.uint8)
+    for it, (key, sym) in zip(items, expect):
+        want[it["out_offset"]:it["out_offset"] + it["out_capacity"]] = sym
+    assert len({key[:2] for key, _ in expect}) >= kinds
+    plan = eng.decode_plan(items)
+    for mode in modes:
+        if mode:
+            os.environ["AWS_HUFFMAN_AMD_DECODE"] = mode
+        try:
+            for _ in range(2):  # (a second launch of the plan finds the scratch words of the first)
+                eng.fill(d_sym, SENTINEL, sym_total)
+                eng.decode_launch(plan, d_enc, d_sym)
+                res = eng.decode_results(plan, len(items))
+                for i, (it, (key, _)) in enumerate(zip(items, expect)):
+                    assert res[i] == key, (label, mode, i, it, res[i], key)
+                assert np.array_equal(eng.download(d_sym, sym_total), want), (label, mode)
+        finally:
+            os.environ.pop("AWS_HUFFMAN_AMD_DECODE", None)
+    eng.lib.aws_huffman_amd_decode_plan_destroy(plan)
+    eng.free(d_enc)
+    eng.free(d_sym)
+
+
 def wide_long_code_items(w, n=150_000, seed=79, modes=(None, "wide-fails")):
     """Long items of coders with codes of more than 12 bits (decode through linked tables): a workgroup per 32 KiB
     block (dec_wide_*) from 64 KiB on here; with "wide-fails" those kernels give every item back to dec_deep."""
@@ -1074,51 +1125,7 @@ def wide_long_code_items(w, n=150_000, seed=79, modes=(None, "wide-fails")):
                 # differently from its guess and dec_wide_* give the item up by themselves
                 apart = rng.integers(28, 256, 60000).astype(np.uint8)
                 streams.append((w.oracle.encode_all(ocoder, apart, slack=64 + 4 * apart.size), 0, apart.size))
-            offs, pos = [], 3
-            for e, _, _ in streams:
-                offs.append(pos)
-                pos += e.size + int(rng.integers(0, 9))
-            host_enc = np.zeros(pos + 64, np.uint8)
-            for (e, _, _), o in zip(streams, offs):
-                host_enc[o:o + e.size] = e
-            items, expect, pos = [], [], 7
-            for (e, fb, cap), o in zip(streams, offs):
-                d = w.oracle.new_decoder(ocoder)
-                start = 0
-                if fb:  # the rest of the first byte is what a previous call left in the decoder
-                    d.working_bits = (int(e[0]) & (0xFF >> fb)) << (56 + fb)
-                    d.num_bits = 8 - fb
-                    start = 1
-                dst = np.full(cap + 1, SENTINEL, np.uint8)
-                r = w.oracle.decode_call(d, e, start, e.size, dst, 0, cap)
-                bits = (8 - fb if fb else 0) + r.consumed * 8 - r.state[0]
-                expect.append(((r.rc, r.err, r.produced, bits), dst[:cap].copy()))
-                items.append(dict(in_offset=o, in_len=e.size, first_bit=fb, out_offset=pos, out_capacity=cap))
-                pos += cap + int(rng.integers(1, 9))
-            sym_total = pos + 64
-            d_enc, d_sym = eng.alloc(host_enc.size), eng.alloc(sym_total)
-            eng.upload(d_enc, host_enc)
-            want = np.full(sym_total, SENTINEL, np.uint8)
-            for it, (key, sym) in zip(items, expect):
-                want[it["out_offset"]:it["out_offset"] + it["out_capacity"]] = sym
-            assert len({key[:2] for key, _ in expect}) >= 3
-            plan = eng.decode_plan(items)
-            for mode in modes:
-                if mode:
-                    os.environ["AWS_HUFFMAN_AMD_DECODE"] = mode
-                try:
-                    for _ in range(2):  # (a second launch of the plan finds the scratch words of the first)
-                        eng.fill(d_sym, SENTINEL, sym_total)
-                        eng.decode_launch(plan, d_enc, d_sym)
-                        res = eng.decode_results(plan, len(items))
-                        for i, (it, (key, _)) in enumerate(zip(items, expect)):
-                            assert res[i] == key, (name, mode, i, it, res[i], key)
-                        assert np.array_equal(eng.download(d_sym, sym_total), want), (name, mode)
-                finally:
-                    os.environ.pop("AWS_HUFFMAN_AMD_DECODE", None)
-            eng.lib.aws_huffman_amd_decode_plan_destroy(plan)
-            eng.free(d_enc)
-            eng.free(d_sym)
+            decode_items_like_the_oracle(w, eng, ocoder, streams, rng, name, modes)
             # the reference's entry point on a host buffer of that length
             ddo, ddp = w.oracle.new_decoder(ocoder), w.product.new_decoder(pcoder)
             oo, op = np.full(n + 8, SENTINEL, np.uint8), np.full(n + 8, SENTINEL, np.uint8)
@@ -1126,6 +1133,32 @@ def wide_long_code_items(w, n=150_000, seed=79, modes=(None, "wide-fails")):
             eng.close()
     finally:
         w.product.lib.aws_huffman_amd_testing_set_wide_min_bytes(0)
+
+
+def fixed_length_coders(w, n=70_000, seed=83):
+    """Coders whose codes all have one length (8 bits: every window a code; 9 bits: half of them): dec_fixed_* for the
+    items beyond a thread's work, whatever their number and size."""
+    rng = np.random.default_rng(seed)
+    for name in ("len8", "len9"):
+        ocoder, pcoder, _ = profile_coders(w, name)
+        eng = harness.Engine(w.product.lib, pcoder)
+        data = rng.integers(0, 256, n).astype(np.uint8)
+        good = w.oracle.encode_all(ocoder, data, slack=64 + 2 * n)
+        damaged = good.copy()
+        damaged[good.size // 2: good.size // 2 + 3] = 0xFF  # (len9: a window that starts with a one has no code)
+        streams = [
+            (good, 0, n), (good, 0, n + 5), (good, 0, n // 2), (good, 0, 0), (damaged, 0, n), (damaged, 0, 100),
+            (good[: good.size - 1], 0, n), (good[: good.size - 3], 0, n), (good[:16384], 0, n), (good[:16385], 0, n),
+            (good[:16383], 0, n), (good[:200], 0, 400), (good[:64], 0, 100), (good, 3, 2 * n), (good[77:], 5, 2 * n),
+            (rng.integers(0, 256, 40000, dtype=np.uint8), 0, 40000), (np.full(20000, 0xFF, np.uint8), 1, 40000),
+        ] + [(good[o: o + int(rng.integers(129, 3000))], int(rng.integers(0, 8)), 3000) for o in range(0, 40000, 2500)]
+        decode_items_like_the_oracle(w, eng, ocoder, streams, rng, name, kinds=2 if name == "len8" else 3)
+        # the reference's entry points on host buffers, in pieces too
+        ddo, ddp = w.oracle.new_decoder(ocoder), w.product.new_decoder(pcoder)
+        oo, op = np.full(n + 8, SENTINEL, np.uint8), np.full(n + 8, SENTINEL, np.uint8)
+        r = paired_decode(w, ddo, ddp, good, 0, good.size // 3, oo, op, 0, n // 5)
+        paired_decode(w, ddo, ddp, good, r.consumed, good.size, oo, op, r.produced, n)
+        eng.close()
 
 
 def first_bit_offsets(w, engine=None):

@@ -57,6 +57,10 @@ def test_wide_long_code_items(world):
     pc.wide_long_code_items(world)
 
 
+def test_fixed_length_coders(world):
+    pc.fixed_length_coders(world)
+
+
 def test_eos_padding_values(world):
     pc.eos_padding_values(world)
 

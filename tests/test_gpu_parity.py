@@ -64,6 +64,10 @@ def test_wide_long_code_items(world):
     pc.wide_long_code_items(world)
 
 
+def test_fixed_length_coders(world):
+    pc.fixed_length_coders(world)
+
+
 def test_damaged_long_streams(world):
     pc.damaged_long_streams(world)
 
