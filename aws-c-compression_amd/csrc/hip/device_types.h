@@ -99,7 +99,7 @@ struct hufd_tables {
                                * an entry is symbol << 8 | length, 0 = no code, or a link */
     uint32_t fixed_bits; /* != 0: every code the decode table knows has this length: symbol k starts at bit k * fixed_bits,
                           * no walk has to find it (dec_fixed_*) */
-    uint32_t reserved;
+    uint32_t fixed_complete; /* ... and every window of the decode table is a code: nothing to check before the symbols are written */
 };
 
 struct hufd_enc_item {

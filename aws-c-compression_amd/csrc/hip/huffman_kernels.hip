@@ -8050,9 +8050,11 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         /* (the items' state words start as "no symbol without a code": dec_fixed_check takes a minimum in them; the other
          * items' are written by their own kernels, behind this) */
         const uint32_t lds = (1u << a->tables.lut_bits) * sizeof(u16);
-        hipLaunchKernelGGL(
-            dec_fixed_kernel<false>, dim3(a->n_fixed_blocks), dim3(kFixedThreads), lds, st, a->tables, a->items, a->fixed_blocks,
-            (const u8 *)a->d_in, (u8 *)a->d_out, a->states);
+        if (!a->tables.fixed_complete) {
+            hipLaunchKernelGGL(
+                dec_fixed_kernel<false>, dim3(a->n_fixed_blocks), dim3(kFixedThreads), lds, st, a->tables, a->items,
+                a->fixed_blocks, (const u8 *)a->d_in, (u8 *)a->d_out, a->states);
+        }
         hipLaunchKernelGGL(
             dec_fixed_finish_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->tables, a->items, a->n_items,
             (const u8 *)a->d_in, a->states, a->results);

@@ -304,6 +304,17 @@ int aws_huffman_amd_engine_new(
     eng->tables.n_states = max_bits > 8 ? max_bits : 8;
     /* every code the DECODE table knows has one length: symbol k starts at bit k * length (dec_fixed_*) */
     eng->tables.fixed_bits = eng->can_decode && dec_max && dec_min == dec_max && dec_max <= HUFD_DEC_MAX_LUT_BITS ? dec_max : 0;
+    eng->tables.fixed_complete = 0;
+    if (eng->tables.fixed_bits && eng->dec_lut_host) {
+        /* ... and every window is one (256 codes of 8 bits): no stream has a symbol without a code to look for */
+        eng->tables.fixed_complete = 1;
+        for (uint32_t i = 0; i < (1u << eng->tables.lut_bits); ++i) {
+            if ((eng->dec_lut_host[i] & 0xFFu) == 0) {
+                eng->tables.fixed_complete = 0;
+                break;
+            }
+        }
+    }
 
     if (!eng->can_decode && coder->decode) {
         if (deep_table_build(eng, coder)) {
