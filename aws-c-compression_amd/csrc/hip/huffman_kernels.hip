@@ -3871,10 +3871,32 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         return;
     }
     u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
+    /* The sub-chunk's words and the table entries this lane will put into LDS are asked for together, at most four
+     * entries at a time -- a workgroup's time is mostly the latency of what it loads in front of its first walk, and a
+     * loop of load, wait, store over the table was a fifth of that. */
+    constexpr u32 kLutPerLane = (1u << LB) / HUFD_DEC_LANES, kLutBatch = 4;
+    const auto table_share = [&](u32 j0) {
+        u32 lut_raw[kLutBatch];
+#pragma unroll
+        for (u32 j = 0; j < kLutBatch; ++j) {
+            lut_raw[j] = tb.dec_lut[(lane + (j0 + j) * HUFD_DEC_LANES) >> (LB - tb.lut_bits)];
+        }
+#pragma unroll
+        for (u32 j = 0; j < kLutBatch; ++j) {
+            const u32 len = lut_raw[j] & 0xFFu;
+            sh.wlut[lane + (j0 + j) * HUFD_DEC_LANES] = 0x10000u - (len ? len : kWalkDeadLen);
+            sh.hops[lane + (j0 + j) * HUFD_DEC_LANES] = (u16)(len ? 1u << len : 0u);
+        }
+    };
     if (TAIL && lane >= kWave && (lane & ~(kWave - 1)) >= n_full) {
         /* a wave wholly behind the stream's whole lanes: never reached, as far as this kernel knows (dec_sync_tail follows
-         * the true path through the one or two sub-chunks the stream ends in and rewrites their records).  It leaves at
-         * once -- the barriers below count the waves that are still there -- and its slots go to another workgroup. */
+         * the true path through the one or two sub-chunks the stream ends in and rewrites their records).  Its share of
+         * the table done, it leaves -- the barriers below count the waves that are still there -- and its slots go to
+         * another workgroup. */
+#pragma unroll
+        for (u32 j0 = 0; j0 < kLutPerLane; j0 += kLutBatch) {
+            table_share(j0);
+        }
 #pragma unroll
         for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
             cp[qq * HUFD_DEC_LANES] = 0;
@@ -3883,7 +3905,6 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(kExitStop << 12);
         return;
     }
-
     u32 w[kFastRows];
     {
         /* (TAIL: a lane behind the stream's whole lanes reads sub-chunk 0 again -- no branch, no second set of
@@ -3893,19 +3914,20 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
 #pragma unroll
         for (u32 q = 0; q < kSubWords / 4; ++q) {
             const unaligned_uint4 v = line[q];
-            w[4 * q + 0] = __builtin_bswap32(v.x);
-            w[4 * q + 1] = __builtin_bswap32(v.y);
-            w[4 * q + 2] = __builtin_bswap32(v.z);
-            w[4 * q + 3] = __builtin_bswap32(v.w);
+            w[4 * q + 0] = v.x;
+            w[4 * q + 1] = v.y;
+            w[4 * q + 2] = v.z;
+            w[4 * q + 3] = v.w;
         }
-        w[kSubWords] = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(src + (u64)(mine + 1) * HUFD_DEC_SUB_BYTES)->x);
+        w[kSubWords] = reinterpret_cast<const unaligned_u32 *>(src + (u64)(mine + 1) * HUFD_DEC_SUB_BYTES)->x;
     }
-    /* (the threads that are still there: wave 0 and the waves with whole lanes) */
-    const u32 live = !TAIL ? HUFD_DEC_LANES : (n_full + kWave - 1) / kWave * kWave;
-    for (u32 i = lane; i < (1u << LB); i += live) {
-        const u32 len = tb.dec_lut[i >> (LB - tb.lut_bits)] & 0xFFu;
-        sh.wlut[i] = 0x10000u - (len ? len : kWalkDeadLen);
-        sh.hops[i] = (u16)(len ? 1u << len : 0u);
+#pragma unroll
+    for (u32 j0 = 0; j0 < kLutPerLane; j0 += kLutBatch) {
+        table_share(j0);
+    }
+#pragma unroll
+    for (u32 r = 0; r < kFastRows; ++r) {
+        w[r] = __builtin_bswap32(w[r]);
     }
     if (lane == 0) {
         sh.bad = 0;
