@@ -38,6 +38,7 @@ rounds = [
     ("other_coders", lambda s: pc.other_coders(w, n=30000, seed=s)),
     ("block_decode_calls", lambda s: pc.block_decode_calls(w, seed=s) if s % 2 == 0 else None),
     ("wide_long_code_items", lambda s: pc.wide_long_code_items(w, seed=s) if s % 3 == 0 else None),
+    ("fixed_length_coders", lambda s: pc.fixed_length_coders(w, seed=s) if s % 3 == 1 else None),
     ("damaged_long_streams", lambda s: pc.damaged_long_streams(w, seed=s) if s % 8 == 0 else None),  # 10 M symbols: now and then
 ]
 t0 = time.time()
