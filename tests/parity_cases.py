@@ -360,7 +360,7 @@ def garbage_decode(w, seed=15, rounds=120, big=70000):
 
 
 # ----------------------------------------------------------------------------- scenario: host-pointer decode calls of one workgroup's size (dec_block: up to 32 KiB encoded, 8 KiB a turn)
-def block_decode_calls(w, seed=73):
+def block_decode_calls(w, seed=73, wants=None, kinds=None):
     rng = np.random.default_rng(seed)
 
     def both(coders, stream, caps, first=None):
@@ -375,9 +375,9 @@ def block_decode_calls(w, seed=73):
 
     plain = (w.ocoder, w.pcoder)
     # whole valid streams around the road's limits: 129 and 8192 encoded bytes, a lane's 8 bytes, a wave's 512
-    for kind in KINDS:
-        for want in (129, 130, 136, 137, 511, 512, 513, 520, 1000, 4096, 8184, 8191, 8192, 8193, 8200, 12000, 16384, 16385,
-                     32760, 32768, 32769):
+    for kind in kinds or KINDS:
+        for want in wants or (129, 130, 136, 137, 511, 512, 513, 520, 1000, 4096, 8184, 8191, 8192, 8193, 8200, 12000, 16384,
+                              16385, 32760, 32768, 32769):
             n = want  # symbols; trimmed until the stream has the wanted length
             data = inputs(rng, 2 * want, kind)
             lo, hi = 0, data.size
