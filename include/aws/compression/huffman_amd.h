@@ -128,6 +128,12 @@ void aws_huffman_amd_encode_plan_destroy(struct aws_huffman_amd_encode_plan *pla
  * returns without waiting.  `length_only` stops after the length scan: nothing
  * is written and each result's `produced` is aws_huffman_get_encoded_length
  * (+ pending overflow bits) for the item.
+ *
+ * What the launch leaves behind it on the stream is the finished output: work queued on the same stream after it (a
+ * decode launch of the plan's output, a copy, a graph node) may read device_output without fetching the results first.
+ * (The one-pass encoder's waits are bounded; a wave that gives up raises a word that the count / scan / pack kernels,
+ * queued behind it in the same launch, look at first: they do the launch over on the device.  The road a launch took is
+ * reported by aws_huffman_amd_encode_plan_road once its results have been fetched.)
  */
 AWS_COMPRESSION_API
 int aws_huffman_amd_encode_plan_launch(
@@ -142,7 +148,7 @@ int aws_huffman_amd_encode_plan_launch(
  * stream the kernels run on.  stage_events: 4 events from aws_huffman_amd_event_new --
  * [0] before the length count, [1] after it, [2] after the offset scan, [3] after the pack;
  * for an engine that encodes in one pass: [0] before the one-pass kernel, [1] after it,
- * [2] after the per-item outcomes, [3] after the segments left to the per-symbol packer.
+ * [2] after the per-item outcomes, [3] after the (gated, normally empty) kernels of the count / scan / pack road.
  */
 AWS_COMPRESSION_API
 int aws_huffman_amd_encode_plan_launch_staged(
