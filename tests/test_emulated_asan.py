@@ -3,11 +3,13 @@ pool): the parity scenarios of the roads added in round 3, every load and store 
 import os
 import subprocess
 import sys
+import tempfile
 
 import harness
 
 EMU_DIR = os.path.join(harness.REPO, "tests", "emu")
-BUILD = os.path.join(EMU_DIR, "build", "asan")
+# (outside the repository: 60 MB of objects that a GPU box, which gets a snapshot of the tree, has no use for)
+BUILD = os.path.join(tempfile.gettempdir(), "aws-c-compression-emu-asan-%d" % os.getuid())
 ASAN_SO = os.path.join(BUILD, "libaws-c-compression-emu-asan.so")
 
 
