@@ -5032,17 +5032,19 @@ __global__ __launch_bounds__(kDeepThreads) void dec_deep_kernel(
  */
 constexpr u32 kWideStop = 0xFFu;
 constexpr u32 kWideGuessBytes = 32;
-constexpr u32 kWideFixes = 4;
+constexpr u32 kWideFixes = 8; /* (an empty launch is 3 us; the road such an item takes otherwise is a thousand times slower) */
 static_assert(HUFD_WIDE_BLOCK_BYTES == kDeepThreads * kDeepLaneBytes, "a block is one round of dec_deep's lanes");
 
 /* ctl words */
 constexpr u32 kWideGaveUp = 0;   /* set by dec_wide_scan */
 constexpr u32 kWideStopBlock = 1; /* the first block whose true walk stops (dec_wide_scan) */
 constexpr u32 kWideMoved = 2;    /* [+ j], j = 1 .. kWideFixes: a block was left differently in launch j */
-constexpr u32 kWideStops = 8;    /* [+ j]: the first block whose walk stops, as of launch j */
+constexpr u32 kWideStops = 16;   /* [+ j]: the first block whose walk stops, as of launch j */
+constexpr u32 kWideCtlWords = 32;
+static_assert(kWideMoved + kWideFixes < kWideStops && kWideStops + kWideFixes < kWideCtlWords, "the ctl words do not overlap");
 
 struct dec_wide_layout {
-    u64 ctl;        /* u32[16] */
+    u64 ctl;        /* u32[kWideCtlWords] */
     u64 exits;      /* u32[kWideFixes + 1][n_blocks] */
     u64 count;      /* u32[n_blocks] symbols of the block's lanes up to the first that stops */
     u64 last;       /* u32[n_blocks] that lane (kDeepThreads: none stops) */
@@ -5058,7 +5060,7 @@ __host__ __device__ inline dec_wide_layout dec_wide_layout_of(u64 n_blocks) {
     const u64 row = (n_blocks * 4 + 63) & ~63ull;
     u64 at = 0;
     l.ctl = at;
-    at += 64;
+    at += 128;
     l.exits = at;
     at += (kWideFixes + 1) * row;
     l.count = at;
@@ -8044,7 +8046,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             u8 *blk = (u8 *)a->wide_block + a->wide[k].block_offset;
             const uint32_t n_blocks = a->wide[k].n_blocks;
             const dec_wide_layout lay = dec_wide_layout_of(n_blocks);
-            (void)hipMemsetAsync(blk + lay.ctl, 0, 64, st);
+            (void)hipMemsetAsync(blk + lay.ctl, 0, 4 * kWideCtlWords, st);
             (void)hipMemsetAsync(blk + lay.ctl + 4 * (kWideStops + 1), 0xFF, 4 * kWideFixes, st);
             hipLaunchKernelGGL(
                 dec_wide_settle_kernel<true>, dim3(n_blocks), dim3(kDeepThreads), wide_lds, st, a->tables, a->items, the_item,
