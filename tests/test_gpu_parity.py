@@ -371,3 +371,15 @@ def test_plan_launches_in_a_hip_graph():
     out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("decoded back bit-exact") == 2, out.stdout
+
+
+def test_two_one_pass_encoders_on_one_device():
+    """The one-pass encoder's tile schedule wants the device to itself; two engines on one device launching at the same
+    time from two threads take that away for real (profiles/tools/contention.py): whatever waits run out, every launch
+    must leave the right bytes on its stream -- read back before the records are fetched."""
+    import subprocess
+    import sys
+
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tools", "contention.py")
+    out = subprocess.run([sys.executable, tool, str(128 << 20), "8"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "wrong outputs [0, 0]" in out.stdout, out.stdout + out.stderr
