@@ -34,12 +34,34 @@ class Worker:
         assert rc == 0 and consumed == n
         self.want = self.digest()
         self.gave_up = self.wrong = 0
+        # and the same for the one-pass DECODER (opt-in: the caller sets AWS_HUFFMAN_AMD_DECODE=one-pass)
+        self.d_back = self.eng.alloc(n + 64)
+        self.dplan = self.eng.decode_plan([dict(in_offset=0, in_len=self.e_len, out_offset=0, out_capacity=n)])
+        self.want_back = self.digest_of(self.d_in, n)
+        self.dec_gave_up = self.dec_wrong = 0
 
     def digest(self):
         h = hashlib.sha256()
         for off in range(0, self.e_len, 64 << 20):
             h.update(self.eng.download(self.d_enc, min(64 << 20, self.e_len - off), offset=off).tobytes())
         return h.hexdigest()
+
+    def digest_of(self, ptr, size):
+        h = hashlib.sha256()
+        for off in range(0, size, 64 << 20):
+            h.update(self.eng.download(ptr, min(64 << 20, size - off), offset=off).tobytes())
+        return h.hexdigest()
+
+    def run_decode(self, barrier):
+        for _ in range(rounds):
+            self.eng.fill(self.d_back, 0x5A, n)
+            self.eng.sync()
+            barrier.wait()
+            self.eng.decode_launch(self.dplan, self.d_enc, self.d_back)
+            got = self.digest_of(self.d_back, n)
+            (rc, _, symbols, _), = self.eng.decode_results(self.dplan, 1)
+            self.dec_wrong += (rc, symbols, got) != (0, n, self.want_back)
+            self.dec_gave_up += self.eng.decode_road(self.dplan) == 2
 
     def run(self, barrier):
         for _ in range(rounds):
@@ -62,4 +84,12 @@ for t in threads:
     t.join()
 print("two engines on one device, %d simultaneous one-pass encodes of %d MiB each: wrong outputs %s, launches that gave up and "
       "were done over on the device %s" % (rounds, n >> 20, [w.wrong for w in workers], [w.gave_up for w in workers]))
-sys.exit(1 if any(w.wrong for w in workers) else 0)
+if os.environ.get("AWS_HUFFMAN_AMD_DECODE") == "one-pass":
+    threads = [threading.Thread(target=w.run_decode, args=(barrier,)) for w in workers]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    print("the same with the one-pass decoder: wrong outputs %s, launches that gave up and were done over by the two-pass "
+          "kernels %s" % ([w.dec_wrong for w in workers], [w.dec_gave_up for w in workers]))
+sys.exit(1 if any(w.wrong or w.dec_wrong for w in workers) else 0)
