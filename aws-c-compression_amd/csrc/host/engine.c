@@ -1523,7 +1523,9 @@ static int mini_encode(
     rec.tiny = 1;
     rec.n_segs = 0;
     memcpy(eng->mini_host, &rec, sizeof(rec));
-    memcpy(eng->mini_host + MINI_IN_AT, host_in, item->in_len);
+    if (item->in_len) { /* an empty cursor may carry a NULL pointer (source/huffman.c:161-167 never touches it) */
+        memcpy(eng->mini_host + MINI_IN_AT, host_in, item->in_len);
+    }
     ON_DEVICE(eng->device);
     int err = hufs_copy_h2d(eng->mini_dev, eng->mini_host, MINI_IN_AT + item->in_len, eng->stream);
     if (!err && item->in_len <= MINI_MAX_IN) {
@@ -1671,7 +1673,9 @@ int aws_huffman_amd_engine_decode_host(
         rec.tiny = 1;
         memcpy(eng->mini_host, &rec, sizeof(rec));
         memcpy(eng->mini_host + MINI_IN_AT + 16 - carry_bytes, carry, carry_bytes);
-        memcpy(eng->mini_host + MINI_IN_AT + 16, host_in, in_len);
+        if (in_len) { /* carried bits and an empty cursor, which may be {0, NULL} (source/huffman.c:196-211) */
+            memcpy(eng->mini_host + MINI_IN_AT + 16, host_in, in_len);
+        }
         ON_DEVICE(eng->device);
         int e = hufs_copy_h2d(eng->mini_dev, eng->mini_host, MINI_IN_AT + 16 + in_len, eng->stream);
         if (!e) {
@@ -1767,7 +1771,9 @@ chunked:
 
 int aws_huffman_amd_engine_fetch_output(struct aws_huffman_amd_engine *eng, uint8_t *host_out, uint64_t size) {
     if (eng->mini_output) {
-        memcpy(host_out, eng->mini_host + MINI_OUT_AT, size); /* came back with the result record */
+        if (size) {
+            memcpy(host_out, eng->mini_host + MINI_OUT_AT, size); /* came back with the result record */
+        }
         return AWS_OP_SUCCESS;
     }
     int err = hufs_copy_d2h(host_out, eng->one_out, size, eng->stream);

@@ -475,14 +475,20 @@ class Codec:
         return d
 
     def encoded_length(self, enc, data):
+        """aws_huffman_get_encoded_length; an empty `data` is handed over as the cursor {0, NULL}."""
         arr = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8)) if not isinstance(data, np.ndarray) else data
         cur = ByteCursor(arr.size, arr.ctypes.data if arr.size else None)
         return self._get_len(C.byref(enc), cur)
 
     # -- one call; `src`/`dst` are numpy uint8 arrays owned by the caller
-    def encode_call(self, enc, src, src_off, dst, dst_len, dst_cap):
-        """aws_huffman_encode on src[src_off:] into dst with len=dst_len, capacity=dst_cap."""
+    def encode_call(self, enc, src, src_off, dst, dst_len, dst_cap, null_when_empty=False):
+        """aws_huffman_encode on src[src_off:] into dst with len=dst_len, capacity=dst_cap.
+        null_when_empty: an empty cursor is handed over as {0, NULL} (valid for the reference, source/huffman.c:161-167)."""
         cur = ByteCursor(src.size - src_off, src.ctypes.data + src_off if src.size else None)
+        if null_when_empty and cur.len == 0:
+            cur = ByteCursor(0, None)
+            src = src[:0]
+            src_off = 0
         buf = ByteBuf(dst_len, dst.ctypes.data, dst_cap, None)
         self.reset_error()
         rc = self._encode(C.byref(enc), C.byref(cur), C.byref(buf))
@@ -495,15 +501,18 @@ class Codec:
         state = (nb, enc.overflow_bits.pattern if nb else 0)
         return CallResult(rc, err, consumed, buf.len - dst_len, state)
 
-    def decode_call(self, dec, src, src_off, src_end, dst, dst_len, dst_cap):
+    def decode_call(self, dec, src, src_off, src_end, dst, dst_len, dst_cap, null_when_empty=False):
         """aws_huffman_decode on src[src_off:src_end] into dst with len=dst_len, capacity=dst_cap."""
         n = src_end - src_off
         cur = ByteCursor(n, src.ctypes.data + src_off if src.size else None)
+        if null_when_empty and n == 0:
+            cur = ByteCursor(0, None)
         buf = ByteBuf(dst_len, dst.ctypes.data, dst_cap, None)
         self.reset_error()
         rc = self._decode(C.byref(dec), C.byref(cur), C.byref(buf))
         err = self.last_error() if rc != 0 else 0
         state = (dec.num_bits, dec.working_bits)
+        assert not (null_when_empty and n == 0) or not cur.ptr, "an empty NULL cursor came back with a pointer"
         return CallResult(rc, err, n - cur.len, buf.len - dst_len, state)
 
     # -- conveniences

@@ -68,17 +68,17 @@ KINDS = ["uniform", "printable", "short", "long", "constant"]
 
 
 # ----------------------------------------------------------------------------- paired calls
-def paired_encode(w, eo, ep, src, off, dst_o, dst_p, length, cap, coder_pair=None):
-    ro = w.oracle.encode_call(eo, src, off, dst_o, length, cap)
-    rp = w.product.encode_call(ep, src, off, dst_p, length, cap)
+def paired_encode(w, eo, ep, src, off, dst_o, dst_p, length, cap, coder_pair=None, null_when_empty=False):
+    ro = w.oracle.encode_call(eo, src, off, dst_o, length, cap, null_when_empty)
+    rp = w.product.encode_call(ep, src, off, dst_p, length, cap, null_when_empty)
     assert rp.key() == ro.key(), "encode call differs: product %r oracle %r (off=%d len=%d cap=%d)" % (rp, ro, off, length, cap)
     assert np.array_equal(dst_p, dst_o), "encode output bytes differ (off=%d len=%d cap=%d)" % (off, length, cap)
     return ro
 
 
-def paired_decode(w, do, dp, src, off, end, dst_o, dst_p, length, cap):
-    ro = w.oracle.decode_call(do, src, off, end, dst_o, length, cap)
-    rp = w.product.decode_call(dp, src, off, end, dst_p, length, cap)
+def paired_decode(w, do, dp, src, off, end, dst_o, dst_p, length, cap, null_when_empty=False):
+    ro = w.oracle.decode_call(do, src, off, end, dst_o, length, cap, null_when_empty)
+    rp = w.product.decode_call(dp, src, off, end, dst_p, length, cap, null_when_empty)
     assert rp.key() == ro.key(), "decode call differs: product %r oracle %r (off=%d end=%d len=%d cap=%d)" % (
         rp, ro, off, end, length, cap)
     assert np.array_equal(dst_p, dst_o), "decode output bytes differ (off=%d end=%d len=%d cap=%d)" % (off, end, length, cap)
@@ -697,6 +697,60 @@ def dense_symbols(w, n=200_000, seed=31):
             oo, op = np.full(n + 8, SENTINEL, np.uint8), np.full(n + 8, SENTINEL, np.uint8)
             ddo, ddp = w.oracle.new_decoder(w.ocoder), w.product.new_decoder(w.pcoder)
             paired_decode(w, ddo, ddp, enc, 0, enc.size, oo, op, 0, out_cap)
+
+
+# ----------------------------------------------------------------------------- scenario: empty cursors with a NULL pointer
+def null_empty_cursors(w, seed=91):
+    """aws_byte_cursor{0, NULL} is a valid cursor: the reference never touches `ptr` when `len` is 0
+    (source/huffman.c:149-167 flush of pending overflow bits, :196-211 refill, :107-129 length query)."""
+    rng = np.random.default_rng(seed)
+    for n in (0, 1, 9, 300, 5000, 40000):
+        data = inputs(rng, n, "uniform")
+        total = 2 * n + 32
+        # encode: run out of room (pending overflow bits), then flush with {0, NULL} calls of growing capacity
+        for first_cap in (0, 1, n // 2 + 1, total):
+            do, dp = np.full(total, SENTINEL, np.uint8), np.full(total, SENTINEL, np.uint8)
+            eo, ep = w.oracle.new_encoder(w.ocoder, eos_padding=0x3C), w.product.new_encoder(w.pcoder, eos_padding=0x3C)
+            off = length = 0
+            cap = min(first_cap, total)
+            for _ in range(10000):
+                r = paired_encode(w, eo, ep, data, off, do, dp, length, cap, null_when_empty=True)
+                off += r.consumed
+                length += r.produced
+                if r.rc == 0:
+                    break
+                assert r.err == SHORT_BUFFER
+                cap = min(cap + int(rng.choice([0, 1, 2, 500, 50000])), total)
+            assert off == n
+            # and once more on the finished encoder: nothing pending, nothing to encode
+            paired_encode(w, eo, ep, data, n, do, dp, length, total, null_when_empty=True)
+        # the length query on {0, NULL}, fresh and with bits pending
+        eo, ep = w.oracle.new_encoder(w.ocoder), w.product.new_encoder(w.pcoder)
+        assert w.product.encoded_length(ep, b"") == w.oracle.encoded_length(eo, b"")
+        if n:
+            do, dp = np.full(total, SENTINEL, np.uint8), np.full(total, SENTINEL, np.uint8)
+            paired_encode(w, eo, ep, data, 0, do, dp, 0, min(1, total))
+            assert w.product.encoded_length(ep, b"") == w.oracle.encoded_length(eo, b"")
+        # decode: feed everything with too little room (bits stay in the decoder), then {0, NULL} calls with more room
+        enc = oracle_encode(w, data)
+        for first_cap in (0, 1, n // 3 + 1):
+            oo, op = np.full(n + 8, SENTINEL, np.uint8), np.full(n + 8, SENTINEL, np.uint8)
+            ddo, ddp = w.oracle.new_decoder(w.ocoder), w.product.new_decoder(w.pcoder)
+            lo = length = 0
+            cap = min(first_cap, n)
+            for _ in range(20000):
+                r = paired_decode(w, ddo, ddp, enc, lo, enc.size, oo, op, length, cap, null_when_empty=True)
+                lo += r.consumed
+                length += r.produced
+                if r.rc == 0 and length == n:
+                    break
+                if r.rc != 0:
+                    assert r.err == SHORT_BUFFER
+                cap = min(cap + int(rng.choice([0, 1, 3, 700, 50000])), n)
+            else:
+                raise AssertionError("decode with empty cursors did not finish")
+            assert np.array_equal(oo[:n], data)
+            paired_decode(w, ddo, ddp, enc, enc.size, enc.size, oo, op, length, n + 8, null_when_empty=True)
 
 
 # ----------------------------------------------------------------------------- scenario: padding byte values

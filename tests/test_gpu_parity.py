@@ -88,6 +88,10 @@ def test_eos_padding_values(world):
     pc.eos_padding_values(world)
 
 
+def test_null_empty_cursors(world):
+    pc.null_empty_cursors(world)
+
+
 def test_survey_records(world):
     pc.survey_records_on_product(world, names=("G4K", "G16K", "G16KP", "G1M"))
 
