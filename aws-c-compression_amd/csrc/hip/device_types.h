@@ -89,10 +89,13 @@
 struct hufd_tables {
     const uint64_t *enc_table; /* [256] low 32 bits: code masked to its length, high 32 bits: length (0 = no code) */
     const uint16_t *dec_lut;   /* [1 << lut_bits] symbol << 8 | length, length 0 = no code; NULL when decode is unavailable */
-    uint32_t max_bits;
+    uint32_t max_bits; /* longest / shortest code the DECODE kernels can meet (the decode table's own bounds when there is
+                        * one: an encoder with longer codes than its decoder knows must not widen the walk's tables) */
     uint32_t min_bits;
     uint32_t lut_bits;
     uint32_t n_states; /* max(max_bits, 8) */
+    uint32_t enc_max_bits; /* longest / shortest code of the ENCODE table (images, stages, which packer): 0 / 1 without one */
+    uint32_t enc_min_bits;
     uint32_t all_coded; /* every one of the 256 symbols has a code */
     uint32_t deep_entries; /* != 0: codes longer than HUFD_DEC_MAX_LUT_BITS, decode walks deep_lut instead of dec_lut */
     const uint32_t *deep_lut; /* [deep_entries] root table of 1 << HUFD_DEEP_ROOT_BITS entries, then the linked ones;

@@ -1143,7 +1143,7 @@ __device__ __forceinline__ pack_geometry pack_geometry_of(
      * at most 16 bits: four of them always fit a 64-bit register).
      */
     const bool edge_here = g.want_short && g.cap_bits > p0 && g.cap_bits <= g.pend;
-    g.careful = tb.max_bits > 16 || edge_here || g.is_unk_seg;
+    g.careful = tb.enc_max_bits > 16 || edge_here || g.is_unk_seg;
     /* past the item's first symbol without a code the reference never gets */
     g.skip = st.unk_seg != HUFD_NONE32 && s > st.unk_seg;
     return g;
@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(HUFD_ENC_THREADS) void enc_pack_kernel(
         const hufd_enc_item_state st = states[seg.item];
         const pack_geometry g = pack_geometry_of(tb, seg, s, it, st, seg_bitoff[s], seg_bits[s], d_out);
         /* with a list the stream kernel has done every segment that is not on it */
-        const bool mine = !g.skip && (list || g.careful || tb.max_bits > 16);
+        const bool mine = !g.skip && (list || g.careful || tb.enc_max_bits > 16);
 
         __syncthreads(); /* the previous segment's copy-out is done with the image */
         {
@@ -1753,7 +1753,7 @@ __global__ __launch_bounds__(kPackThreads) void enc_pack_wave_kernel(
     }
     __syncthreads();
     const u8 *mine = reinterpret_cast<const u8 *>(tab) + (lane & 31u) * 4u;
-    const bool coder_ok = tb.max_bits <= (NW == 4 ? 12u : 15u) && tb.min_bits >= 4;
+    const bool coder_ok = tb.enc_max_bits <= (NW == 4 ? 12u : 15u) && tb.enc_min_bits >= 4;
 
     const u32 n_tiles = n_segs * kTilesPerSeg;
     uint4 v[kGroupsPerLane], vn[kGroupsPerLane]; /* this tile's symbols and the next one's, asked for a tile ahead */
@@ -3086,10 +3086,11 @@ struct row_walk {
     u32 floor;  /* (u16)state after a row is at least this unless the walk died */
     u32 sure;   /* codes that are certain to start in a row: taken without asking (no compare, no branch, no lane mask) */
 
-    __device__ __host__ __forceinline__ row_walk(u32 lut_bits, u32 max_bits) {
+    /* pos: the bit of the shifted pair the window's lowest bit lands on (2: the window is the byte offset of a dword entry) */
+    __device__ __host__ __forceinline__ row_walk(u32 lut_bits, u32 max_bits, u32 pos = 2) {
         /* 512 = a multiple of 64 that keeps the low half positive through `sure` steps of a dead walk (48 bits each) */
-        thr = 512 + (32 - lut_bits) - 2;
-        mask = ((1u << lut_bits) - 1u) << 2;
+        thr = 512 + (32 - lut_bits) - pos;
+        mask = ((1u << lut_bits) - 1u) << pos;
         floor = thr - max_bits + 1;
         /* a row's first code starts at most max(max_bits - 1, 7) bits in (entry states go up to 7), the others max_bits apart */
         const u32 late = max_bits - 1 > 7 ? max_bits - 1 : 7;
@@ -3783,6 +3784,14 @@ __device__ __forceinline__ u32 lds_word_at(u32 byte_offset) {
 #endif
 }
 
+__device__ __forceinline__ u32 lds_byte_at(u32 byte_offset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const __attribute__((address_space(3))) u8 *)(uintptr_t)byte_offset;
+#else
+    return dyn_lds[byte_offset];
+#endif
+}
+
 template <u32 LB>
 struct lean_shared {
     u32 wlut[1u << LB]; /* 0x10000 - length, length 48 = no code; at a multiple of its own size */
@@ -4098,6 +4107,353 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         fn_out[(u64)lane * HUFD_DEC_LANES] =
             cand_reached ? fn_pack(false, first_exit, cand_count & 0x7FFu) : fn_pack(true, 0, cand_dead);
         /* (TAIL: symbols of the whole lanes only, and no exit yet: dec_sync_tail adds the stream's last symbols and how it ends) */
+        chunk_fn[(u64)c * ns + lane] =
+            cand_reached ? wide_pack(false, TAIL ? 0u : last_exit, cand_count + rest) : wide_pack(true, 0, cand_dead);
+    }
+}
+
+/* ------------------------------------------------------------------ decode: sync, regular chunks, a length table per LDS bank */
+
+/*
+ * What bounds dec_sync_lean is the LDS, not instruction issue (profiles/tools/micro/probe_r04.hip): a
+ * wave's look-up in ONE 4 KiB table lands on the 32 banks at random, about 3.4 lanes on the fullest bank, so a
+ * `ds_read_b32` holds the CU's LDS for ~7 cycles instead of 2, and the four SIMDs of a CU get one step per ~24 cycles
+ * each whatever the number of waves (23.5 measured at 8 waves a SIMD, 26.8 at 4; two chains a lane change nothing).
+ * With the table ONCE PER BANK a look-up never collides: lane l reads bank l % 32.  A copy per bank of dword entries
+ * would be 128 KiB for 1024 windows; of BYTES (all a count-only walk needs: the code's length) it is 32 KiB:
+ *
+ *     byte address of window w for bank b = (w >> 2) << 7 | b << 2 | (w & 3)        (bank = address / 4 % 32)
+ *
+ * which costs the address two instructions more (the window's low two bits go under the bank, its high eight above),
+ * and is shared by a workgroup of 1024 threads = FOUR chunks, two workgroups a CU, 8 waves a SIMD as before.  Measured
+ * on the bare step: 16.4 cycles / 10.9 ns a step and SIMD against 23.5 / 13.6.  Same phases, same tables out as
+ * dec_sync_lean; coders whose decode table has more than 10 bits keep that kernel (4096 windows x 32 banks do not fit).
+ */
+constexpr u32 kBankChunks = 4;
+constexpr u32 kBankThreads = kBankChunks * HUFD_DEC_LANES;
+constexpr u32 kBankLB = 10;
+constexpr u32 kBankTableBytes = (1u << kBankLB) * 32u;
+constexpr u32 kBankWinPos = 5; /* the window's lowest bit in the shifted pair: its high eight bits are address bits 7..14 as they stand */
+
+struct bank_slot { /* a chunk's own part of the workgroup's LDS */
+    u32 exit_state[HUFD_DEC_LANES];
+    u32 sub0[kFastMaxMeet + 4]; /* the first rows of sub-chunk 0, for the threads that try its entry states */
+    u32 wave_sum[HUFD_DEC_LANES / 64];
+    u32 bad;
+    u32 one0; /* sub-chunk 0's own walks have met */
+    u32 pad[2];
+};
+
+struct bank_shared {
+    u8 len[kBankTableBytes]; /* 256 - length, length 48 = no code: state += byte + 0xFF00 is the dword table's 0x10000 - length; at a multiple of its size */
+    u16 hops[1u << kBankLB]; /* 1 << code length of a window (the head it sends on), 0 = no code: phase U's */
+    bank_slot slot[kBankChunks];
+};
+
+__device__ __forceinline__ u32 bank_step(u32 state, u64 pair, u32 bank4) {
+    const u32 t = (u32)(pair >> (state & 63u));
+    const u32 at = (t & (0xFFu << 7)) | bank4;          /* the window's high eight bits, the lane's bank */
+    const u32 low = (t >> kBankWinPos) & 3u;            /* its low two */
+    return state + lds_byte_at(at | low) + 0xFF00u;
+}
+
+template <u32 SURE, bool STEP_BY_STEP = false>
+__device__ __forceinline__ u32 bank_row(u32 state, u32 hi, u32 lo, u32 bank4, const row_walk &rw) {
+    const u64 pair = ((u64)hi << 32) | lo;
+    if (!STEP_BY_STEP) {
+#pragma unroll
+        for (u32 i = 0; i < SURE; ++i) {
+            state = bank_step(state, pair, bank4);
+        }
+    }
+    while ((state & 0xFFFFu) > rw.thr) {
+        state = bank_step(state, pair, bank4);
+    }
+    return state;
+}
+
+template <u32 SURE, bool TAIL> /* TAIL: the chunks listed in tail_chunks (a stream ends in them): see dec_sync_fast */
+__global__ __launch_bounds__(kBankThreads, 8) void dec_sync_bank_kernel(
+    hufd_tables tb,
+    const hufd_chunk_rec *chunk_rec,
+    const u32 *tail_chunks,
+    u32 n_list, /* chunks of the launch (TAIL: entries of tail_chunks) */
+    const u8 *d_in,
+    u16 *fn_tab,
+    u16 *cp_tab,
+    u32 *chunk_fn,
+    u16 *lane_count,
+    u8 *chunk_regular,
+    u32 *tail_entry,
+    u32 *slow_list,
+    u32 *slow_count,
+    u32 *long_list,
+    u32 *long_count,
+    const u32 *gate) {
+
+    if (!TAIL && gate && gate[0] == 0) {
+        return;
+    }
+    bank_shared &sh = *reinterpret_cast<bank_shared *>(dyn_lds);
+    const u32 ns = tb.n_states;
+    const u32 t = threadIdx.x;
+    const u32 slot_no = t / HUFD_DEC_LANES, lane = t % HUFD_DEC_LANES;
+    bank_slot &sl = sh.slot[slot_no];
+    const u32 li = blockIdx.x * kBankChunks + slot_no;
+    const bool have = li < n_list;
+    const u32 c = have ? (TAIL ? tail_chunks[li] : li) : 0u;
+    const hufd_chunk_rec rec = chunk_rec[c];
+    const u64 valid = rec.valid;
+    const u8 *src = d_in + rec.src_off;
+    const row_walk rw(kBankLB, tb.max_bits, kBankWinPos);
+    const u32 table = lds_offset_of(sh.len);
+    const bool coder_ok = tb.lut_bits <= kBankLB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS && rw.sure == SURE &&
+                          (table & (kBankTableBytes - 1u)) == 0;
+    if (!coder_ok) { /* (the same for every thread of the launch: the host does not launch this for such a coder) */
+        if (lane == 0 && have && (TAIL || valid >= (u64)HUFD_DEC_CHUNK_BYTES + 8u)) {
+            chunk_regular[c] = 0;
+            long_list[atomicAdd(long_count, 1u)] = c;
+        }
+        return;
+    }
+    /* the workgroup's tables: every thread a row of four windows in each of eight steps (its bank's copy of them), and one
+     * entry of phase U's table -- whatever becomes of its chunk */
+    const u32 bank4 = table | ((lane & 31u) << 2);
+    {
+        constexpr u32 kRowsPerStep = kBankThreads / 32, kSteps = (1u << kBankLB) / 4 / kRowsPerStep;
+        u16 raw[kSteps][4];
+        const u32 down = kBankLB - tb.lut_bits;
+#pragma unroll
+        for (u32 j = 0; j < kSteps; ++j) {
+            const u32 row = t / 32 + j * kRowsPerStep;
+#pragma unroll
+            for (u32 i = 0; i < 4; ++i) {
+                raw[j][i] = tb.dec_lut[(4 * row + i) >> down];
+            }
+        }
+        const u32 own = tb.dec_lut[t >> down] & 0xFFu;
+#pragma unroll
+        for (u32 j = 0; j < kSteps; ++j) {
+            const u32 row = t / 32 + j * kRowsPerStep;
+            u32 packed = 0;
+#pragma unroll
+            for (u32 i = 0; i < 4; ++i) {
+                const u32 len = raw[j][i] & 0xFFu;
+                packed |= (256u - (len ? len : kWalkDeadLen)) << (8 * i);
+            }
+            reinterpret_cast<u32 *>(sh.len)[row * 32 + (t & 31u)] = packed;
+        }
+        sh.hops[t] = (u16)(own ? 1u << own : 0u);
+    }
+    /* the chunks this instantiation does not take; a slot without a chunk */
+    if (!have || (!TAIL && valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u)) {
+        __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): its share of the tables is in LDS */
+        return; /* (the barriers below count the waves that are still there) */
+    }
+    /* the lanes whose sub-chunk and the 8 bytes behind it lie inside the stream (dec_sync_fast) */
+    const u32 n_full = !TAIL ? HUFD_DEC_LANES : (valid >= 8u ? (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES) : 0u);
+    const bool active = !TAIL || lane < n_full;
+    if (TAIL && n_full == 0) {
+        /* fewer than 136 bytes: no lane is whole, and the whole chunk is one thread's work in dec_sync_tail / dec_emit_tail */
+        if (lane == 0) {
+            chunk_regular[c] = 3;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        return;
+    }
+    u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
+    if (TAIL && lane >= kWave && (lane & ~(kWave - 1)) >= n_full) {
+        /* a wave wholly behind the stream's whole lanes (dec_sync_lean) */
+#pragma unroll
+        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+            cp[qq * HUFD_DEC_LANES] = 0;
+        }
+        lane_count[(u64)c * HUFD_DEC_LANES + lane] = 0;
+        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(kExitStop << 12);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        return;
+    }
+    u32 w[kFastRows];
+    {
+        const u32 mine = active ? lane : 0u;
+        const unaligned_uint4 *line = reinterpret_cast<const unaligned_uint4 *>(src + (u64)mine * HUFD_DEC_SUB_BYTES);
+#pragma unroll
+        for (u32 q = 0; q < kSubWords / 4; ++q) {
+            const unaligned_uint4 v = line[q];
+            w[4 * q + 0] = v.x;
+            w[4 * q + 1] = v.y;
+            w[4 * q + 2] = v.z;
+            w[4 * q + 3] = v.w;
+        }
+        w[kSubWords] = reinterpret_cast<const unaligned_u32 *>(src + (u64)(mine + 1) * HUFD_DEC_SUB_BYTES)->x;
+    }
+#pragma unroll
+    for (u32 r = 0; r < kFastRows; ++r) {
+        w[r] = __builtin_bswap32(w[r]);
+    }
+    if (lane == 0) {
+        sl.bad = 0;
+#pragma unroll
+        for (u32 r = 0; r <= kFastMaxMeet; ++r) {
+            sl.sub0[r] = w[r];
+        }
+#pragma unroll
+        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
+            sl.wave_sum[wv] = 0; /* (TAIL: of the waves that have left) */
+        }
+    }
+    __syncthreads();
+
+    /* U: all entry states as one mask of heads per row, until every lane of the wave is down to one */
+    u64 heads = active ? (1ull << ns) - 1ull : 0ull;
+    u32 meet_row = 0; /* the same for the whole wave */
+    bool one = false, settled = false;
+#pragma unroll
+    for (u32 r = 0; r < kFastMaxMeet; ++r) {
+        if (!settled) {
+            heads = r == 0 ? union_first_row<kBankLB>(ns, active, w[0], w[1], sh.hops) : union_row_fast<kBankLB>(heads, w[r], w[r + 1], sh.hops);
+            one = heads != 0 && (heads & (heads - 1)) == 0;
+            meet_row = r + 1;
+            settled = __all(one || heads == 0);
+        }
+    }
+    const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
+    bool ok = !active || (one && settled);
+    if (lane == 0) {
+        sl.one0 = one;
+    }
+
+    /* R: the one walk from the meeting bit to the end of the sub-chunk */
+    u32 state = rw.state_at(meet_bit, 0);
+    u32 cp_state[kQuarters - 1] = {0, 0, 0};
+    bool dead = false;
+#pragma unroll
+    for (u32 r = 1; r < kSubWords; ++r) {
+        if (r >= meet_row) {
+            if (r % (kSubWords / kQuarters) == 0) {
+                cp_state[r / (kSubWords / kQuarters) - 1] = state;
+            }
+            state = bank_row<SURE>(state, w[r], w[r + 1], bank4, rw);
+            dead = dead || rw.died(state);
+            state = TAIL ? rw.next_row(state, dead) : state + 32u;
+        }
+    }
+    const u32 ref_count = state >> 16; /* symbols from the meeting bit to the end of the sub-chunk */
+    const u32 ref_exit = rw.offset_of(state);
+    ok = ok && (!active || (!dead && ref_exit < ns));
+    sl.exit_state[lane] = ref_exit;
+    __syncthreads();
+
+    /* H: my own sub-chunk from my true entry state, to the meeting bit */
+    const u32 entry = lane ? sl.exit_state[lane - 1] : 0u;
+    u32 count;
+    u32 head_cp = 0; /* the head walk where it enters the second quarter, when the meeting row lies behind that */
+    const bool late = meet_row > kSubWords / kQuarters;
+    {
+        u32 st = rw.state_at(entry < ns ? entry : 0u, 0);
+        bool dd = false;
+#pragma unroll
+        for (u32 r = 0; r < kFastMaxMeet; ++r) {
+            if (r < meet_row) {
+                if (r == kSubWords / kQuarters) {
+                    head_cp = st;
+                }
+                st = bank_row<SURE>(st, w[r], w[r + 1], bank4, rw);
+                dd = dd || rw.died(st);
+                st = TAIL ? rw.next_row(st, dd) : st + 32u;
+            }
+        }
+        const bool reached = !dd && rw.offset_of(st) == meet_bit;
+        ok = ok && (lane == 0 || !active || reached);
+        count = active ? (st >> 16) + ref_count : 0u; /* symbols of the true path that start in my sub-chunk (lanes >= 1) */
+    }
+
+    /* H: sub-chunk 0 from every entry state the chunk may be entered in (threads 0 .. ns-1 of the chunk), step by step:
+     * the count of a walk that dies has to be right */
+    u32 cand_count = 0, cand_dead = 0;
+    bool cand_reached = false;
+    u64 cand_alive = 0;
+    if (lane < kWave) {
+        const u32 target = __shfl(meet_bit, 0), tail0 = __shfl(ref_count, 0); /* sub-chunk 0 is lane 0's */
+        u32 st = rw.state_at(lane < ns ? lane : 0u, 0);
+        bool dd = false;
+        u32 hi = sl.sub0[0];
+        for (u32 r = 0; r < meet_row; ++r) {
+            const u32 lo = sl.sub0[r + 1];
+            st = bank_row<SURE, true>(st, hi, lo, bank4, rw);
+            const bool now = rw.died(st) && !dd;
+            cand_dead = now ? (st >> 16) - 1u : cand_dead; /* the step that found no code is not a symbol */
+            dd = dd || now;
+            st = rw.next_row(st, dd);
+            hi = lo;
+        }
+        cand_reached = !dd && lane < ns && rw.offset_of(st) == target;
+        cand_alive = __ballot(cand_reached);
+        cand_count = (st >> 16) + tail0;
+    }
+
+    const u32 wsum = wave_sum(lane ? count : 0u);
+    if ((lane & (kWave - 1)) == 0) {
+        sl.wave_sum[lane / kWave] = wsum;
+    }
+    if (!ok) {
+        sl.bad = 1;
+    }
+    __syncthreads();
+    if (sl.bad) {
+        if (lane == 0) {
+            chunk_regular[c] = 0;
+            if (TAIL || !sl.one0) {
+                long_list[atomicAdd(long_count, 1u)] = c;
+            } else {
+                slow_list[atomicAdd(slow_count, 1u)] = c;
+            }
+        }
+        return;
+    }
+
+    /* the tables dec_scan and dec_emit read (dec_sync_fast's) */
+    u16 *fn_out = fn_tab + (u64)c * ns * HUFD_DEC_LANES;
+    if (active) {
+#pragma unroll
+        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+            const bool usable = (qq + 1) * (kSubWords / kQuarters) >= meet_row;
+            u32 tail = ref_count - (cp_state[qq] >> 16), bits = rw.offset_of(cp_state[qq]);
+            bool have_cp = usable;
+            if (qq == 0 && late && lane != 0) {
+                tail = count - (head_cp >> 16);
+                bits = rw.offset_of(head_cp);
+                have_cp = true;
+            }
+            cp[qq * HUFD_DEC_LANES] = (u16)(have_cp ? 0x8000u | (bits << 11) | tail : 0u);
+        }
+        lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)(lane ? count : ref_count);
+        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((lane ? 1u << entry : (u32)cand_alive) | (ref_exit << 12));
+    } else {
+        /* (TAIL) behind the whole lanes, in a wave that has some: as for the waves that left */
+#pragma unroll
+        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+            cp[qq * HUFD_DEC_LANES] = 0;
+        }
+        lane_count[(u64)c * HUFD_DEC_LANES + lane] = 0;
+        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(kExitStop << 12);
+    }
+    if (TAIL && lane + 1 == n_full) {
+        tail_entry[c] = ref_exit;
+    }
+    if (lane == 0) {
+        chunk_regular[c] = TAIL ? 2 : 1;
+    }
+    if (lane < ns) {
+        u32 rest = 0;
+#pragma unroll
+        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
+            rest += sl.wave_sum[wv];
+        }
+        const u32 first_exit = sl.exit_state[0];
+        const u32 last_exit = sl.exit_state[HUFD_DEC_LANES - 1];
+        fn_out[(u64)lane * HUFD_DEC_LANES] =
+            cand_reached ? fn_pack(false, first_exit, cand_count & 0x7FFu) : fn_pack(true, 0, cand_dead);
         chunk_fn[(u64)c * ns + lane] =
             cand_reached ? wide_pack(false, TAIL ? 0u : last_exit, cand_count + rest) : wide_pack(true, 0, cand_dead);
     }
@@ -7537,7 +7893,7 @@ int hufk_init(void) {
 
 int hufk_encode_one_pass_applies(const struct hufd_tables *tb) {
     /* every symbol has a code (no stop inside a stream to look for), octs of 4 .. 15-bit codes */
-    return tb->all_coded && tb->max_bits <= 15 && tb->min_bits >= 4;
+    return tb->all_coded && tb->enc_max_bits <= 15 && tb->enc_min_bits >= 4;
 }
 
 int hufk_decode_one_pass_applies(const struct hufd_tables *tb) {
@@ -7605,7 +7961,7 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
         uint8_t *z = (uint8_t *)a->zero_block;
         stage_mark(a->stage_events, 0, st); /* (the clearing of the look-back words is part of what is timed) */
         (void)hipMemsetAsync(a->zero_block, 0, l.bytes, st);
-        const uint32_t region = pack_region_bytes(a->tables.max_bits);
+        const uint32_t region = pack_region_bytes(a->tables.enc_max_bits);
         const uint32_t lds = kPackTabBytes + kPackWaves * region;
         const uint32_t work = (a->n_segs * kTilesPerSeg + kPackWaves - 1) / kPackWaves;
 #define HUFK_LAUNCH_ONEPASS(NWV)                                                                                      \
@@ -7615,7 +7971,7 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
         a->n_segs, (u32 *)(z + l.ctl), (u32 *)(z + l.tile_agg), (u64 *)(z + l.group_acc),                              \
         (u64 *)(z + l.round_base), (u64 *)(z + l.item_base), a->item_total, a->results, (const u8 *)(z + l.null_tile),  \
         a->fail_tile ? a->n_segs * kTilesPerSeg / 2 : HUFD_NONE32)
-        if (a->tables.max_bits <= 12) {
+        if (a->tables.enc_max_bits <= 12) {
             HUFK_LAUNCH_ONEPASS(4);
         } else {
             HUFK_LAUNCH_ONEPASS(5);
@@ -7679,12 +8035,12 @@ static void encode_three_kernels(const struct hufk_encode_args *a, hipStream_t s
     }
     stage_mark(events, 2, st);
     if (a->n_segs && !a->length_only) {
-        const uint32_t img_words = hufk_enc_image_words(a->tables.max_bits);
-        if (a->tables.max_bits <= 15 && a->tables.min_bits >= 4) {
+        const uint32_t img_words = hufk_enc_image_words(a->tables.enc_max_bits);
+        if (a->tables.enc_max_bits <= 15 && a->tables.enc_min_bits >= 4) {
             /* one wave per quarter segment for whole, aligned segments; it lists the others for the per-symbol packer */
-            const uint32_t region = pack_region_bytes(a->tables.max_bits);
+            const uint32_t region = pack_region_bytes(a->tables.enc_max_bits);
             const uint32_t lds = kPackTabBytes + kPackWaves * region;
-            if (a->tables.max_bits <= 12) {
+            if (a->tables.enc_max_bits <= 12) {
                 const uint32_t grid = persistent_grid(enc_pack_wave_kernel<4>, kPackThreads, lds, (a->n_segs * kTilesPerSeg + kPackWaves - 1) / kPackWaves);
                 hipLaunchKernelGGL(
                     enc_pack_wave_kernel<4>, dim3(grid), dim3(kPackThreads), lds, st, a->tables, a->items, a->states,
@@ -7702,7 +8058,7 @@ static void encode_three_kernels(const struct hufk_encode_args *a, hipStream_t s
                 enc_pack_kernel, dim3(most), dim3(HUFD_ENC_THREADS), enc_pack_lds_bytes(img_words), st, a->tables,
                 a->items, a->states, a->segs, a->seg_bits, a->seg_bitoff, (const u8 *)a->d_in, (u8 *)a->d_out,
                 a->results, img_words, a->n_segs, (const u32 *)a->careful_list, (const u32 *)a->careful_count, gate);
-        } else if (a->tables.max_bits <= 16) {
+        } else if (a->tables.enc_max_bits <= 16) {
             /* streaming packer for everything but the listed segments, then those */
             const uint32_t lds = enc_stream_lds_bytes(img_words);
             const uint32_t grid = persistent_grid(enc_pack_stream_kernel, HUFD_ENC_THREADS, lds, a->n_segs);
@@ -7739,7 +8095,7 @@ int hufk_encode_one_block_fits(const struct hufd_tables *tables, uint64_t symbol
     if (symbols <= HUFD_ENC_BLOCK_BYTES) {
         return 1;
     }
-    const uint32_t bits = HUFD_ENC_BLOCK_MAX_BYTES * tables->max_bits + 32 + 128 + 64;
+    const uint32_t bits = HUFD_ENC_BLOCK_MAX_BYTES * tables->enc_max_bits + 32 + 128 + 64;
     const uint32_t img_words = ((bits + 31) / 32 + 3) & ~3u;
     return symbols <= HUFD_ENC_BLOCK_MAX_BYTES &&
            ((img_words * 4 + 15) & ~15u) + 256 * 8 + (uint32_t)sizeof(enc_block_shared) <= 65536u;
@@ -7750,7 +8106,7 @@ int hufk_encode_one_block(
     struct hufd_enc_result *result, uint32_t length_only, void *stream) {
     /* (the image: the symbols of the longest code, carried bits, alignment, padding) */
     const bool wide = symbols > HUFD_ENC_BLOCK_BYTES;
-    const uint32_t bits = (wide ? HUFD_ENC_BLOCK_MAX_BYTES : HUFD_ENC_BLOCK_BYTES) * tables->max_bits + 32 + 128 + 64;
+    const uint32_t bits = (wide ? HUFD_ENC_BLOCK_MAX_BYTES : HUFD_ENC_BLOCK_BYTES) * tables->enc_max_bits + 32 + 128 + 64;
     const uint32_t img_words = ((bits + 31) / 32 + 3) & ~3u;
     const uint32_t lds = ((img_words * 4 + 15) & ~15u) + 256 * 8 + (uint32_t)sizeof(enc_block_shared);
     if (symbols > HUFD_ENC_BLOCK_MAX_BYTES || lds > 65536u) {
@@ -7832,7 +8188,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     /* The chunks inside streams in ONE pass (dec_onepass) where the coder allows: the kernels of the two-pass road for
      * those chunks are queued behind it all the same and look at its ctl word first -- they run only if it gave up. */
     const u32 *gate = nullptr;
-    if (a->n_chunks && a->n_tiles && a->tiles && a->fuse_block && a->fuse_mode != 1 && !a->old_sync &&
+    if (a->n_chunks && a->n_tiles && a->tiles && a->fuse_block && a->fuse_mode != 1 && a->old_sync != 1 &&
         hufk_decode_one_pass_applies(&a->tables)) {
         const uint32_t lb = a->tables.lut_bits <= 10 ? 10u : 12u;
         const uint32_t sure = row_walk(lb, a->tables.max_bits).sure;
@@ -7886,7 +8242,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
          * (inside a stream, first sub-chunk's walks meet) and the ones for the long way.  The second is the emit stage's
          * list, free until then; one list where there is no dec_sync_guess for the launch. */
         const uint32_t sure_of_launch = row_walk(a->tables.lut_bits <= 10 ? 10u : 12u, a->tables.max_bits).sure;
-        const bool guessing = some_inside && a->old_sync == 0 && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS &&
+        const bool guessing = some_inside && a->old_sync != 1 && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS &&
                               (a->tables.lut_bits <= 10 ? sure_of_launch >= 2 && sure_of_launch <= 5
                                                         : sure_of_launch >= 2 && sure_of_launch <= 3);
         u32 *lean_long_list = guessing ? a->emit_list : a->slow_list;
@@ -7923,7 +8279,36 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
             a->slow_list, a->slow_count, lean_long_list, lean_long_count, gate);                                       \
     }
-        if (!a->old_sync && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS) {
+        /* ... and of those, for a decode table of up to 10 bits, the one with a length table per LDS bank, four chunks a
+         * workgroup (AWS_HUFFMAN_AMD_DECODE=lean-sync: the kernel it replaced as the default) */
+#define HUFK_LAUNCH_SYNC_BANK(SUREV)                                                                                    \
+    if (a->n_tail) {                                                                                                   \
+        hipLaunchKernelGGL(                                                                                            \
+            (dec_sync_bank_kernel<SUREV, true>), dim3((a->n_tail + kBankChunks - 1) / kBankChunks), dim3(kBankThreads), \
+            (uint32_t)sizeof(bank_shared), tst, a->tables, a->chunk_rec, a->tail_chunks, a->n_tail,                     \
+            (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
+            a->slow_list, a->slow_count, lean_long_list, lean_long_count, (const u32 *)nullptr);                        \
+    }                                                                                                                  \
+    if (some_inside) {                                                                                                 \
+        hipLaunchKernelGGL(                                                                                            \
+            (dec_sync_bank_kernel<SUREV, false>), dim3((a->n_chunks + kBankChunks - 1) / kBankChunks), dim3(kBankThreads), \
+            (uint32_t)sizeof(bank_shared), st, a->tables, a->chunk_rec, a->tail_chunks, a->n_chunks,                    \
+            (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
+            a->slow_list, a->slow_count, lean_long_list, lean_long_count, gate);                                       \
+    }
+        if (a->old_sync == 0 && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS && a->tables.lut_bits <= kBankLB &&
+            row_walk(kBankLB, a->tables.max_bits, kBankWinPos).sure == sure) {
+            lean = true;
+            switch (sure) {
+                case 2: HUFK_LAUNCH_SYNC_BANK(2); break;
+                case 3: HUFK_LAUNCH_SYNC_BANK(3); break;
+                case 4: HUFK_LAUNCH_SYNC_BANK(4); break;
+                case 5: HUFK_LAUNCH_SYNC_BANK(5); break;
+                default: lean = false; break;
+            }
+        }
+#undef HUFK_LAUNCH_SYNC_BANK
+        if (!lean && a->old_sync != 1 && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS) {
             lean = true;
             if (a->tables.lut_bits <= 10) {
                 switch (sure) {
@@ -8130,7 +8515,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
                                         ? (a->tail_stage_bytes + 255u) & ~255u
                                         : HUFD_DEC_STAGE_BYTES;
         /* (chunks inside a stream: with the coder's number of certain steps a row compiled in, where there is such a build) */
-        const uint32_t emit_sure = a->old_sync ? 0u : row_walk(a->tables.lut_bits <= 10 ? 10u : 12u, a->tables.max_bits).sure;
+        const uint32_t emit_sure = a->old_sync == 1 ? 0u : row_walk(a->tables.lut_bits <= 10 ? 10u : 12u, a->tables.max_bits).sure;
         /* chunks of short codes that hold more symbols than dec_emit_fast's stage: dec_emit_big where there is a build of
          * it for the coder and the chunk lies inside its stream; the others take the long way (dec_emit) */
         const bool has_big = a->tables.lut_bits <= 10 ? emit_sure >= 2 && emit_sure <= 5 : emit_sure >= 2 && emit_sure <= 3;

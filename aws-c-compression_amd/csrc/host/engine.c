@@ -293,11 +293,15 @@ int aws_huffman_amd_engine_new(
         }
         free(probe);
     }
-    /* one set of code-length bounds for both halves: what sizes images, stages and entry states must hold for the longest
-     * and the shortest code either callback knows */
+    /* two sets of code-length bounds: the encode table's own size images and stages and pick the packer; the decode
+     * kernels' entry states, walk tables and certain steps follow what the DECODE table knows -- an encoder with codes of
+     * 13..32 bits beside a decoder whose table has 12 or fewer must not give the chunk kernels more entry states than
+     * they have registers for (they hold HUFD_DEC_MAX_LUT_BITS, or 16 on the long way) */
+    eng->tables.enc_max_bits = max_bits;
+    eng->tables.enc_min_bits = min_bits > 32 ? 1 : min_bits;
     if (eng->can_decode && dec_max) {
-        max_bits = dec_max > max_bits ? dec_max : max_bits;
-        min_bits = dec_min < min_bits ? dec_min : min_bits;
+        max_bits = dec_max;
+        min_bits = dec_min;
     }
     eng->tables.max_bits = max_bits;
     eng->tables.min_bits = min_bits; /* (33: no code known yet) */
@@ -402,7 +406,7 @@ int aws_huffman_amd_current_device(void) {
 }
 
 uint32_t aws_huffman_amd_engine_max_code_bits(const struct aws_huffman_amd_engine *eng) {
-    return eng->tables.max_bits;
+    return eng->tables.max_bits > eng->tables.enc_max_bits ? eng->tables.max_bits : eng->tables.enc_max_bits;
 }
 
 bool aws_huffman_amd_engine_can_decode(const struct aws_huffman_amd_engine *eng) {
@@ -1336,7 +1340,8 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.results = p->d_results;
     {
         const char *mode = getenv("AWS_HUFFMAN_AMD_DECODE");
-        a.old_sync = mode && strcmp(mode, "old-sync") == 0; /* the kernel dec_sync_lean replaced, for comparison and tests */
+        /* "old-sync": the kernel dec_sync_lean replaced; "lean-sync": the one dec_sync_bank replaced (comparison and tests) */
+        a.old_sync = mode && strcmp(mode, "old-sync") == 0 ? 1u : (mode && strcmp(mode, "lean-sync") == 0 ? 2u : 0u);
         /* the chunks inside streams: sync + scan + emit (two passes over the stream) unless told otherwise.  "one-pass"
          * puts dec_onepass in front of them (every encoded byte read once; on an MI355X it takes as long as the two
          * passes, DESIGN.md 4 "One pass": not the default); "one-pass-fails" does the same with one tile made to give
@@ -1348,7 +1353,7 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.tiles = p->d_tiles;
     a.n_tiles = p->n_tiles;
     a.fuse_block = p->d_fuse_block;
-    p->one_pass_tried = a.fuse_mode != 1 && !a.old_sync && p->n_tiles && hufk_decode_one_pass_applies(&a.tables);
+    p->one_pass_tried = a.fuse_mode != 1 && a.old_sync != 1 && p->n_tiles && hufk_decode_one_pass_applies(&a.tables);
     a.stage_events = stage_events;
     ON_DEVICE(p->engine->device);
     const int err = hufk_decode_launch(&a, stream ? stream : p->engine->stream);
@@ -1573,16 +1578,16 @@ int aws_huffman_amd_engine_encode_host(
      * (huffman_test_transitive_chunked, HPACK's SHORT_BUFFER resumption) otherwise pays for the whole rest of its
      * input in every call: O(n^2 / chunk) bytes over the bus and through the count.
      */
-    if (!length_only && eng->tables.min_bits && item.out_capacity < (UINT64_MAX >> 4)) {
+    if (!length_only && eng->tables.enc_min_bits && item.out_capacity < (UINT64_MAX >> 4)) {
         const uint64_t room_bits = item.out_capacity * 8;
         const uint64_t carried = item.overflow_in.num_bits;
-        const uint64_t fit = room_bits > carried ? (room_bits - carried + eng->tables.min_bits - 1) / eng->tables.min_bits : 0;
+        const uint64_t fit = room_bits > carried ? (room_bits - carried + eng->tables.enc_min_bits - 1) / eng->tables.enc_min_bits : 0;
         if (fit + 1 < item.in_len) {
             item.in_len = fit + 1;
         }
     }
     /* the device output never needs more than the worst-case encoding */
-    const uint64_t worst = (item.in_len * eng->tables.max_bits + item.overflow_in.num_bits + 7) / 8;
+    const uint64_t worst = (item.in_len * eng->tables.enc_max_bits + item.overflow_in.num_bits + 7) / 8;
     const uint64_t dev_out = item.out_capacity < worst ? item.out_capacity : worst;
     item.in_offset = 0;
     item.out_offset = 0;

@@ -26,7 +26,8 @@ Contract (one JSON line on stdout from rank 0):
 
 For N > 1 the driver launches one process per GPU through torch.distributed.run; ranks share nothing but a barrier
 and a max-reduction of the step time (no collective on the data path: the items are independent, DESIGN.md
-"Multi-GPU").
+"Multi-GPU").  Started as a plain process (`python bench.py --gpus N`, WORLD_SIZE unset) it starts the N ranks
+itself (spawn_ranks) and passes rank 0's line through.
 """
 import argparse
 import ctypes as C
@@ -127,6 +128,32 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cores():
+    """Cores this process may actually run on: the scheduler affinity mask, cut down by a cgroup CPU quota when there
+    is one (os.cpu_count() is the machine's: on a leased box it said 256 where 12.8 cores' worth of work got done)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            fields = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if fields[0] != "max":
+                    quota = int(fields[0]) / int(fields[1])
+            else:
+                q = int(fields[0])
+                if q > 0:
+                    quota = q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError, ZeroDivisionError):
+            continue
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def cpu_baseline(sample_bytes, seed, batch_seconds=8.0, buffer_bytes=16384):
     """The oracle on the host: the stream on one core (bounded prefix), the configs[3] batch on all cores."""
     import numpy as np
@@ -154,7 +181,7 @@ def cpu_baseline(sample_bytes, seed, batch_seconds=8.0, buffer_bytes=16384):
     # configs[3] on all host cores: one thread per core, each encoding + decoding 16 KiB buffers of its own for a
     # bounded time -- pthreads inside the oracle library (Python threads spent the time on the interpreter lock:
     # 0.24 GiB/s on 256 cores where this gives the cores' real rate)
-    cores = os.cpu_count() or 1
+    cores, quota = usable_cores()  # one thread per core this process can USE (affinity mask and cgroup quota)
     oracle.lib.oracle_batch_round_trips.restype = C.c_uint64
     oracle.lib.oracle_batch_round_trips.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_uint32, C.POINTER(C.c_double)]
     took = C.c_double()
@@ -178,12 +205,15 @@ def cpu_baseline(sample_bytes, seed, batch_seconds=8.0, buffer_bytes=16384):
         "decode_GiBps": round(sample_bytes / GIB / t_dec, 5),
         "cpu_model": cpu_model(),
         "host_cores": cores,
+        "host_cores_how": "len(os.sched_getaffinity(0)) = %d, cgroup cpu quota = %s, os.cpu_count() = %s" % (
+            len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else -1,
+            "none" if quota is None else "%.1f" % quota, os.cpu_count()),
         "all_cores_cfg4": {
             "value": round(sum(done) * buffer_bytes / GIB / tb, 5),
             "unit": "GiB/s",
             "cores": cores,
             "sample": "%d x %d B buffers (BASELINE configs[3] shape) encoded + decoded in %.1f s by %d threads, one per "
-                      "host core" % (sum(done), buffer_bytes, tb, cores),
+                      "usable host core" % (sum(done), buffer_bytes, tb, cores),
         },
     }
 
@@ -498,8 +528,42 @@ def run_host_abi(args, ranks, lib, eng, coder):
     return out, n, e_len, wall, kernel_ms, t_enc_ms, t_dec_ms, per_rank, seed
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: this process becomes the launcher.  N fresh children, one
+    per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would -- started before this
+    process has loaded the HIP library or touched a device (a process that has initialised the GPU must not exec or
+    fork workers on this pool), each its own stream and device, nothing shared but the gloo barrier and the
+    max-reduction of the step time.  Rank 0's stdout is this process's: its one JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    children = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                         stdout=None if rank == 0 else subprocess.DEVNULL))
+    codes = []
+    try:
+        for child in children:
+            codes.append(child.wait())
+    finally:
+        for child in children:
+            if child.poll() is None:
+                child.kill()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit("bench.py: rank(s) failed: %r" % bad)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
     import harness  # the HIP library is loaded before anything else (torch, in Ranks) can pull in another HIP runtime
 
     lib = harness.load_product(args.library)

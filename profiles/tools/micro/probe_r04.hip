@@ -292,8 +292,8 @@ static void run_walk(const char *name, u32 table_bytes) {
     struct shape { int threads, bpc; };
     for (shape s : {shape{256, 4}, shape{256, 8}, shape{1024, 1}, shape{1024, 2}}) {
         const int wps = s.threads / 256 * s.bpc;
+        if (table_bytes * s.bpc > 160u * 1024u) continue; /* (32 KiB x 8 does not fit) */
         const u32 lds = lds_for(s.bpc, table_bytes);
-        if ((MODE == 2 || MODE == 3 || MODE == 5) && s.threads == 256 && s.bpc == 8) continue; /* 32 KiB x 8 does not fit */
         const int grid = g_cus * s.bpc, n_waves = grid * s.threads / 64;
         CK(hipFuncSetAttribute((const void *)walk_kernel<MODE, CHAINS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         auto r = timed([&] { hipLaunchKernelGGL((walk_kernel<MODE, CHAINS>), dim3(grid), dim3(s.threads), lds, 0, d_words, d_out, iters, table_bytes, d_clocks); }, n_waves);

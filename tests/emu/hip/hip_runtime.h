@@ -252,8 +252,17 @@ inline unsigned long long wave_ballot(bool predicate) {
 
 #define HIP_DYNAMIC_SHARED(type, var) static type *const var = reinterpret_cast<type *>(hip_emu::lds());
 
+/* HIP_EMU_TRACE=1: the name of every kernel launched, on stderr (tests that must know which road a call took) */
+namespace hip_emu {
+inline void trace_launch(const char *name) {
+    static const bool on = std::getenv("HIP_EMU_TRACE") != nullptr;
+    if (on) {
+        std::fprintf(stderr, "hip_emu launch %s\n", name);
+    }
+}
+} // namespace hip_emu
 #define hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, ...)                                                \
-    hip_emu::launch((grid), (block), (lds_bytes), [&]() { (kernel)(__VA_ARGS__); })
+    (hip_emu::trace_launch(#kernel), hip_emu::launch((grid), (block), (lds_bytes), [&]() { (kernel)(__VA_ARGS__); }))
 
 inline void __syncthreads() {
     hip_emu::yield(hip_emu::Wait::kBlock);

@@ -364,6 +364,19 @@ def test_decode_with_the_first_sync_kernel(world, engine):
         del os.environ["AWS_HUFFMAN_AMD_DECODE"]
 
 
+def test_decode_with_the_second_sync_kernel(world, engine):
+    """AWS_HUFFMAN_AMD_DECODE=lean-sync: dec_sync_lean (one table of dword entries a chunk) for the chunks that
+    dec_sync_bank (a length table per LDS bank, four chunks a workgroup) takes by default since round 4."""
+    os.environ["AWS_HUFFMAN_AMD_DECODE"] = "lean-sync"
+    try:
+        pc.one_shot_roundtrips(world, sizes=[40000, 200001, 3 * 1024 * 1024 + 5])
+        pc.cut_streams(world, chunks=(1, 2), step=31)
+        pc.garbage_decode(world)
+        pc.batched_device_api(world, engine=engine)
+    finally:
+        del os.environ["AWS_HUFFMAN_AMD_DECODE"]
+
+
 def test_plan_launches_in_a_hip_graph():
     """an encode launch and the decode launch of its output, captured into one HIP graph on a stream of
     the caller's and replayed over scrambled outputs (profiles/tools/graph_capture.py: a batch of 16 KiB items and one

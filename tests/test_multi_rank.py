@@ -36,13 +36,15 @@ def emulator():
     return EMU_SO
 
 
-def run_bench(emulator, nproc, extra=()):
+def run_bench(emulator, nproc, extra=(), launcher=True):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    for name in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(name, None)
     bench = os.path.join(harness.REPO, "bench.py")
     args = ["--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--bytes", str(STREAM_BYTES),
             "--no-cpu-baseline", "--library", emulator, *extra]
-    if nproc == 1:
-        cmd = [sys.executable, bench, *args]
+    if nproc == 1 or not launcher:
+        cmd = [sys.executable, bench, *args]  # (N > 1 without a launcher: bench.py starts its ranks itself)
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                "--master-addr", "127.0.0.1", "--master-port", str(free_port()), bench, *args]
@@ -89,6 +91,17 @@ def test_two_ranks_independent_streams(emulator, oracle):
         assert (r["encoded_bytes"], r["sha256_encoded"]) == (e_len, digest), "rank %d stream differs from the oracle" % r["rank"]
     assert out["ranks"][0]["sha256_encoded"] != out["ranks"][1]["sha256_encoded"]
     assert out["cpu_baseline"] is None  # reported at N = 1 only
+
+
+def test_two_ranks_without_a_launcher(emulator, oracle):
+    """`python bench.py --gpus 2` as a plain process, the way the driver runs `--gpus 1`: two ranks all the same."""
+    out = run_bench(emulator, 2, launcher=False)
+    check_line(out, 2)
+    assert [r["rank"] for r in out["ranks"]] == [0, 1] and [r["seed"] for r in out["ranks"]] == [5, 6]
+    assert [r["device"] for r in out["ranks"]] == [0, 0]  # (the emulator has one device; on a node: 0 and 1)
+    for r in out["ranks"]:
+        e_len, digest = expected_stream(oracle, r["rank"])
+        assert (r["encoded_bytes"], r["sha256_encoded"]) == (e_len, digest), "rank %d stream differs from the oracle" % r["rank"]
 
 
 def expected_batch(oracle, rank, world, buffers, size):
