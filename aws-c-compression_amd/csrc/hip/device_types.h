@@ -100,6 +100,8 @@ struct hufd_tables {
     uint32_t deep_entries; /* != 0: codes longer than HUFD_DEC_MAX_LUT_BITS, decode walks deep_lut instead of dec_lut */
     const uint32_t *deep_lut; /* [deep_entries] root table of 1 << HUFD_DEEP_ROOT_BITS entries, then the linked ones;
                                * an entry is symbol << 8 | length, 0 = no code, or a link */
+    const uint32_t *bank_rows; /* NULL, or [256] for a decode table of up to 10 bits: dword r = the length bytes dec_sync_bank's
+                                * table holds for the 10-bit windows 4r .. 4r+3 (256 - length, no code: 256 - 48), lowest first */
     uint32_t fixed_bits; /* != 0: every code the decode table knows has this length: symbol k starts at bit k * fixed_bits,
                           * no walk has to find it (dec_fixed_*) */
     uint32_t fixed_complete; /* ... and every window of the decode table is a code: nothing to check before the symbols are written */

@@ -101,8 +101,9 @@ struct hufk_decode_args {
     struct hufd_dec_item_state *states; /* [n_items] scratch */
     struct hufd_dec_result *results;    /* [n_items] */
     uint32_t tail_stage_bytes; /* the most symbols a chunk that holds the end of a stream can decode to, +32 (0: unknown) */
-    uint32_t old_sync; /* 0: dec_sync_bank for the chunks of a decode table of up to 10 bits, dec_sync_lean for the others; 1: dec_sync_fast
-                        * for every chunk (AWS_HUFFMAN_AMD_DECODE=old-sync); 2: dec_sync_lean for every chunk it takes (=lean-sync) */
+    uint32_t old_sync; /* 0: dec_sync_lean for the chunks it takes (the default); 1: dec_sync_fast for every chunk
+                        * (AWS_HUFFMAN_AMD_DECODE=old-sync); 2: as 0 (=lean-sync); 3: dec_sync_bank where the decode table has up
+                        * to 10 bits (=bank-sync: a length table per LDS bank, measured slower) */
     void **stage_events; /* NULL, or 4 hipEvent_t: before sync, after sync, after scan, after emit */
     const struct hufd_tile_rec *tiles; /* [n_tiles] dec_onepass (the chunks inside streams in one pass): built with the plan */
     uint32_t n_tiles;

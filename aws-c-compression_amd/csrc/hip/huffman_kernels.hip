@@ -21,9 +21,11 @@
  */
 #include <hip/hip_runtime.h>
 #include <numeric>
+#include <type_traits>
 
 #include <pthread.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "device_types.h"
@@ -4129,8 +4131,6 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
  * on the bare step: 16.4 cycles / 10.9 ns a step and SIMD against 23.5 / 13.6.  Same phases, same tables out as
  * dec_sync_lean; coders whose decode table has more than 10 bits keep that kernel (4096 windows x 32 banks do not fit).
  */
-constexpr u32 kBankChunks = 4;
-constexpr u32 kBankThreads = kBankChunks * HUFD_DEC_LANES;
 constexpr u32 kBankLB = 10;
 constexpr u32 kBankTableBytes = (1u << kBankLB) * 32u;
 constexpr u32 kBankWinPos = 5; /* the window's lowest bit in the shifted pair: its high eight bits are address bits 7..14 as they stand */
@@ -4144,10 +4144,11 @@ struct bank_slot { /* a chunk's own part of the workgroup's LDS */
     u32 pad[2];
 };
 
+template <u32 CHUNKS> /* chunks a workgroup takes: CHUNKS x 256 threads share the tables */
 struct bank_shared {
     u8 len[kBankTableBytes]; /* 256 - length, length 48 = no code: state += byte + 0xFF00 is the dword table's 0x10000 - length; at a multiple of its size */
     u16 hops[1u << kBankLB]; /* 1 << code length of a window (the head it sends on), 0 = no code: phase U's */
-    bank_slot slot[kBankChunks];
+    bank_slot slot[CHUNKS];
 };
 
 __device__ __forceinline__ u32 bank_step(u32 state, u64 pair, u32 bank4) {
@@ -4172,8 +4173,8 @@ __device__ __forceinline__ u32 bank_row(u32 state, u32 hi, u32 lo, u32 bank4, co
     return state;
 }
 
-template <u32 SURE, bool TAIL> /* TAIL: the chunks listed in tail_chunks (a stream ends in them): see dec_sync_fast */
-__global__ __launch_bounds__(kBankThreads, 8) void dec_sync_bank_kernel(
+template <u32 SURE, bool TAIL, u32 CHUNKS> /* TAIL: the chunks listed in tail_chunks (a stream ends in them): see dec_sync_fast */
+__global__ __launch_bounds__(CHUNKS * HUFD_DEC_LANES, 8) void dec_sync_bank_kernel(
     hufd_tables tb,
     const hufd_chunk_rec *chunk_rec,
     const u32 *tail_chunks,
@@ -4194,12 +4195,13 @@ __global__ __launch_bounds__(kBankThreads, 8) void dec_sync_bank_kernel(
     if (!TAIL && gate && gate[0] == 0) {
         return;
     }
-    bank_shared &sh = *reinterpret_cast<bank_shared *>(dyn_lds);
+    constexpr u32 kBankThreads = CHUNKS * HUFD_DEC_LANES;
+    bank_shared<CHUNKS> &sh = *reinterpret_cast<bank_shared<CHUNKS> *>(dyn_lds);
     const u32 ns = tb.n_states;
     const u32 t = threadIdx.x;
     const u32 slot_no = t / HUFD_DEC_LANES, lane = t % HUFD_DEC_LANES;
     bank_slot &sl = sh.slot[slot_no];
-    const u32 li = blockIdx.x * kBankChunks + slot_no;
+    const u32 li = blockIdx.x * CHUNKS + slot_no;
     const bool have = li < n_list;
     const u32 c = have ? (TAIL ? tail_chunks[li] : li) : 0u;
     const hufd_chunk_rec rec = chunk_rec[c];
@@ -4207,7 +4209,7 @@ __global__ __launch_bounds__(kBankThreads, 8) void dec_sync_bank_kernel(
     const u8 *src = d_in + rec.src_off;
     const row_walk rw(kBankLB, tb.max_bits, kBankWinPos);
     const u32 table = lds_offset_of(sh.len);
-    const bool coder_ok = tb.lut_bits <= kBankLB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS && rw.sure == SURE &&
+    const bool coder_ok = tb.lut_bits <= kBankLB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS && rw.sure == SURE && tb.bank_rows &&
                           (table & (kBankTableBytes - 1u)) == 0;
     if (!coder_ok) { /* (the same for every thread of the launch: the host does not launch this for such a coder) */
         if (lane == 0 && have && (TAIL || valid >= (u64)HUFD_DEC_CHUNK_BYTES + 8u)) {
@@ -4216,34 +4218,32 @@ __global__ __launch_bounds__(kBankThreads, 8) void dec_sync_bank_kernel(
         }
         return;
     }
-    /* the workgroup's tables: every thread a row of four windows in each of eight steps (its bank's copy of them), and one
-     * entry of phase U's table -- whatever becomes of its chunk */
+    /* the workgroup's tables: the length bytes come four windows a dword from the engine (hufd_tables.bank_rows); a thread
+     * puts its bank's copy of kPerThread consecutive rows into LDS, and one entry of phase U's table -- whatever becomes
+     * of its chunk */
     const u32 bank4 = table | ((lane & 31u) << 2);
     {
-        constexpr u32 kRowsPerStep = kBankThreads / 32, kSteps = (1u << kBankLB) / 4 / kRowsPerStep;
-        u16 raw[kSteps][4];
-        const u32 down = kBankLB - tb.lut_bits;
+        constexpr u32 kPerThread = 256 * 32 / kBankThreads; /* 8 with four chunks, 16 with two */
+        const u32 row0 = t / 32 * kPerThread;
+        uint4 raw[kPerThread / 4];
 #pragma unroll
-        for (u32 j = 0; j < kSteps; ++j) {
-            const u32 row = t / 32 + j * kRowsPerStep;
-#pragma unroll
-            for (u32 i = 0; i < 4; ++i) {
-                raw[j][i] = tb.dec_lut[(4 * row + i) >> down];
-            }
+        for (u32 j = 0; j < kPerThread / 4; ++j) {
+            raw[j] = reinterpret_cast<const uint4 *>(tb.bank_rows + row0)[j];
         }
-        const u32 own = tb.dec_lut[t >> down] & 0xFFu;
+        const u32 own = tb.dec_lut[t % (1u << kBankLB) >> (kBankLB - tb.lut_bits)] & 0xFFu;
+        u32 *rows = reinterpret_cast<u32 *>(sh.len) + row0 * 32 + (t & 31u);
 #pragma unroll
-        for (u32 j = 0; j < kSteps; ++j) {
-            const u32 row = t / 32 + j * kRowsPerStep;
-            u32 packed = 0;
-#pragma unroll
-            for (u32 i = 0; i < 4; ++i) {
-                const u32 len = raw[j][i] & 0xFFu;
-                packed |= (256u - (len ? len : kWalkDeadLen)) << (8 * i);
-            }
-            reinterpret_cast<u32 *>(sh.len)[row * 32 + (t & 31u)] = packed;
+        for (u32 j = 0; j < kPerThread / 4; ++j) {
+            rows[(4 * j + 0) * 32] = raw[j].x;
+            rows[(4 * j + 1) * 32] = raw[j].y;
+            rows[(4 * j + 2) * 32] = raw[j].z;
+            rows[(4 * j + 3) * 32] = raw[j].w;
         }
-        sh.hops[t] = (u16)(own ? 1u << own : 0u);
+#pragma unroll
+        for (u32 i = t; i < (1u << kBankLB); i += kBankThreads) { /* (one trip with four chunks, two with two) */
+            const u32 len = i == t ? own : tb.dec_lut[i >> (kBankLB - tb.lut_bits)] & 0xFFu;
+            sh.hops[i] = (u16)(len ? 1u << len : 0u);
+        }
     }
     /* the chunks this instantiation does not take; a slot without a chunk */
     if (!have || (!TAIL && valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u)) {
@@ -8279,24 +8279,31 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
             a->slow_list, a->slow_count, lean_long_list, lean_long_count, gate);                                       \
     }
-        /* ... and of those, for a decode table of up to 10 bits, the one with a length table per LDS bank, four chunks a
-         * workgroup (AWS_HUFFMAN_AMD_DECODE=lean-sync: the kernel it replaced as the default) */
-#define HUFK_LAUNCH_SYNC_BANK(SUREV)                                                                                    \
+        /* ... or, asked for (AWS_HUFFMAN_AMD_DECODE=bank-sync), for a decode table of up to 10 bits the one with a length table
+         * per LDS bank, four (or two) chunks a workgroup: measured slower than dec_sync_lean, see there */
+#define HUFK_LAUNCH_SYNC_BANK_N(SUREV, CH)                                                                              \
     if (a->n_tail) {                                                                                                   \
         hipLaunchKernelGGL(                                                                                            \
-            (dec_sync_bank_kernel<SUREV, true>), dim3((a->n_tail + kBankChunks - 1) / kBankChunks), dim3(kBankThreads), \
-            (uint32_t)sizeof(bank_shared), tst, a->tables, a->chunk_rec, a->tail_chunks, a->n_tail,                     \
+            (dec_sync_bank_kernel<SUREV, true, CH>), dim3((a->n_tail + CH - 1) / CH), dim3(CH * HUFD_DEC_LANES),        \
+            (uint32_t)sizeof(bank_shared<CH>), tst, a->tables, a->chunk_rec, a->tail_chunks, a->n_tail,                 \
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
             a->slow_list, a->slow_count, lean_long_list, lean_long_count, (const u32 *)nullptr);                        \
     }                                                                                                                  \
     if (some_inside) {                                                                                                 \
         hipLaunchKernelGGL(                                                                                            \
-            (dec_sync_bank_kernel<SUREV, false>), dim3((a->n_chunks + kBankChunks - 1) / kBankChunks), dim3(kBankThreads), \
-            (uint32_t)sizeof(bank_shared), st, a->tables, a->chunk_rec, a->tail_chunks, a->n_chunks,                    \
+            (dec_sync_bank_kernel<SUREV, false, CH>), dim3((a->n_chunks + CH - 1) / CH), dim3(CH * HUFD_DEC_LANES),     \
+            (uint32_t)sizeof(bank_shared<CH>), st, a->tables, a->chunk_rec, a->tail_chunks, a->n_chunks,                \
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
             a->slow_list, a->slow_count, lean_long_list, lean_long_count, gate);                                       \
     }
-        if (a->old_sync == 0 && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS && a->tables.lut_bits <= kBankLB &&
+#define HUFK_LAUNCH_SYNC_BANK(SUREV)                                                                                    \
+    if (bank_chunks == 2) {                                                                                            \
+        HUFK_LAUNCH_SYNC_BANK_N(SUREV, 2)                                                                              \
+    } else {                                                                                                           \
+        HUFK_LAUNCH_SYNC_BANK_N(SUREV, 4)                                                                              \
+    }
+        static const uint32_t bank_chunks = getenv("AWS_HUFFMAN_AMD_BANK_CHUNKS") ? (uint32_t)atoi(getenv("AWS_HUFFMAN_AMD_BANK_CHUNKS")) : 4u; /* (experiments) */
+        if (a->old_sync == 3 && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS && a->tables.lut_bits <= kBankLB && a->tables.bank_rows &&
             row_walk(kBankLB, a->tables.max_bits, kBankWinPos).sure == sure) {
             lean = true;
             switch (sure) {
@@ -8308,7 +8315,8 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             }
         }
 #undef HUFK_LAUNCH_SYNC_BANK
-        if (!lean && a->old_sync != 1 && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS) {
+#undef HUFK_LAUNCH_SYNC_BANK_N
+        if (!lean && a->old_sync != 1 && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS) { /* (0, 2: dec_sync_lean) */
             lean = true;
             if (a->tables.lut_bits <= 10) {
                 switch (sure) {

@@ -355,10 +355,24 @@ int aws_huffman_amd_engine_new(
         eng->d_dec_lut =
             device_upload(eng->dec_lut_host, (size_t)sizeof(uint16_t) << eng->tables.lut_bits, eng->stream, &err);
     }
+    if (!err && eng->dec_lut_host && eng->tables.lut_bits <= 10) {
+        /* dec_sync_bank's length bytes, four windows of 10 bits a dword (hufd_tables.bank_rows) */
+        uint32_t rows[256];
+        const uint32_t down = 10 - eng->tables.lut_bits;
+        for (uint32_t r = 0; r < 256; ++r) {
+            rows[r] = 0;
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t len = eng->dec_lut_host[(4 * r + i) >> down] & 0xFFu;
+                rows[r] |= (256u - (len ? len : 48u)) << (8 * i);
+            }
+        }
+        eng->d_bank_rows = device_upload(rows, sizeof(rows), eng->stream, &err);
+    }
     if (err) {
         aws_huffman_amd_engine_destroy(eng);
         return raise_hip(err);
     }
+    eng->tables.bank_rows = eng->d_bank_rows;
     eng->tables.enc_table = eng->d_enc_table;
     eng->tables.dec_lut = eng->d_dec_lut;
     eng->tables.deep_lut = eng->d_deep_lut;
@@ -383,6 +397,7 @@ void aws_huffman_amd_engine_destroy(struct aws_huffman_amd_engine *eng) {
     hufs_host_free(eng->mini_host);
     hufs_free(eng->d_enc_table);
     hufs_free(eng->d_dec_lut);
+    hufs_free(eng->d_bank_rows);
     hufs_free(eng->d_deep_lut);
     hufs_event_destroy(eng->fork_event);
     hufs_event_destroy(eng->join_event);
@@ -1340,8 +1355,10 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.results = p->d_results;
     {
         const char *mode = getenv("AWS_HUFFMAN_AMD_DECODE");
-        /* "old-sync": the kernel dec_sync_lean replaced; "lean-sync": the one dec_sync_bank replaced (comparison and tests) */
-        a.old_sync = mode && strcmp(mode, "old-sync") == 0 ? 1u : (mode && strcmp(mode, "lean-sync") == 0 ? 2u : 0u);
+        /* "old-sync": the kernel dec_sync_lean replaced; "bank-sync": dec_sync_bank, the round-4 kernel with a length table
+         * per LDS bank that did not beat it (comparison and tests); "lean-sync": the default by name */
+        a.old_sync = mode && strcmp(mode, "old-sync") == 0 ? 1u
+                     : (mode && strcmp(mode, "lean-sync") == 0 ? 2u : (mode && strcmp(mode, "bank-sync") == 0 ? 3u : 0u));
         /* the chunks inside streams: sync + scan + emit (two passes over the stream) unless told otherwise.  "one-pass"
          * puts dec_onepass in front of them (every encoded byte read once; on an MI355X it takes as long as the two
          * passes, DESIGN.md 4 "One pass": not the default); "one-pass-fails" does the same with one tile made to give

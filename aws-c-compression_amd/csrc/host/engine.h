@@ -33,6 +33,7 @@ struct aws_huffman_amd_engine {
 
     void *d_enc_table;
     void *d_dec_lut;
+    void *d_bank_rows; /* tables.bank_rows */
     struct hufd_tables tables;
     bool single_pass; /* enc_onepass where the coder allows it (not with AWS_HUFFMAN_AMD_ENCODE=three-kernel) */
     bool encode_fails; /* AWS_HUFFMAN_AMD_ENCODE=one-pass-fails: a wave of enc_onepass is made to give up (tests of the way back) */

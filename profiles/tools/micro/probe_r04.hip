@@ -87,8 +87,21 @@ __global__ __launch_bounds__(1024, 8) void valu_kernel(u32 *out, int iters, u64 
 constexpr int kRows = 8;
 constexpr int kSure = 3;
 
+__device__ const u32 *g_table_ptr;
 template <int MODE>
-__device__ __forceinline__ u32 walk_step(u32 state, u32 hi, u32 lo, u32 table, u32 bank4) {
+__device__ __forceinline__ u32 walk_step(u32 state, u32 hi, u32 lo, u32 table, u32 bank4, const u32 *gtab = nullptr) {
+    if (MODE == 8) { /* a 1 KiB table of bytes in global memory: 8 cache lines instead of 32 */
+        const u64 pair = ((u64)hi << 32) | lo;
+        return state + 0xFF00u + *(reinterpret_cast<const u8 *>(gtab) + ((u32)(pair >> (state & 63u)) & 0x3FFu));
+    }
+    if (MODE == 9) { /* a 2 KiB table of 16-bit entries in global memory */
+        const u64 pair = ((u64)hi << 32) | lo;
+        return state + 0xFF00u + *reinterpret_cast<const unsigned short *>(reinterpret_cast<const u8 *>(gtab) + ((u32)(pair >> (state & 63u)) & 0x7FEu));
+    }
+    if (MODE == 6) { /* the 4 KiB table in global memory (L1-resident): the vector memory pipe instead of the LDS */
+        const u64 pair = ((u64)hi << 32) | lo;
+        return state + *reinterpret_cast<const u32 *>(reinterpret_cast<const u8 *>(gtab) + ((u32)(pair >> (state & 63u)) & 0xFFCu));
+    }
     if (MODE == 0) {
         const u64 pair = ((u64)hi << 32) | lo;
         return state + lds_u32(((u32)(pair >> (state & 63u)) & 0xFFCu) | table);
@@ -113,7 +126,7 @@ __device__ __forceinline__ u32 walk_step(u32 state, u32 hi, u32 lo, u32 table, u
 }
 
 template <int MODE, int CHAINS>
-__global__ __launch_bounds__(1024, 8) void walk_kernel(const u32 *words, u32 *out, int iters, u32 lds_bytes, u64 *clocks) {
+__global__ __launch_bounds__(1024, 8) void walk_kernel(const u32 *words, u32 *out, int iters, u32 lds_bytes, u64 *clocks, const u32 *gtab = nullptr, int global_every = 0) {
     const u32 lane = threadIdx.x;
     const u32 base = lds_base();
     /* fill the whole dynamic LDS with entries: a "length" of 5..10 per byte / nibble / dword, whatever the mode reads */
@@ -146,18 +159,37 @@ __global__ __launch_bounds__(1024, 8) void walk_kernel(const u32 *words, u32 *ou
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c) st[c] = 37u + lane + c;
     const u64 t0 = __builtin_amdgcn_s_memtime();
-    for (int it = 0; it < iters; ++it) {
+    /* MODE 7: every `global_every`-th wave of the workgroup looks up through global memory, the others through the LDS */
+    const bool by_memory = MODE == 6 || MODE >= 8 || (MODE == 7 && global_every && (threadIdx.x / 64) % global_every == 0);
+    if (MODE >= 6 && by_memory) {
+        for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int r = 0; r < kRows; ++r) {
+            for (int r = 0; r < kRows; ++r) {
 #pragma unroll
-            for (int s = 0; s < kSure; ++s) {
+                for (int s = 0; s < kSure; ++s) {
 #pragma unroll
-                for (int c = 0; c < CHAINS; ++c) {
-                    st[c] = walk_step<MODE>(st[c], w[c][r], w[c][r + 1], base, bank4);
+                    for (int c = 0; c < CHAINS; ++c) {
+                        st[c] = walk_step<(MODE >= 8 ? MODE : 6)>(st[c], w[c][r], w[c][r + 1], base, bank4, gtab);
+                    }
                 }
-            }
 #pragma unroll
-            for (int c = 0; c < CHAINS; ++c) st[c] += 32u;
+                for (int c = 0; c < CHAINS; ++c) st[c] += 32u;
+            }
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) {
+#pragma unroll
+                for (int s = 0; s < kSure; ++s) {
+#pragma unroll
+                    for (int c = 0; c < CHAINS; ++c) {
+                        st[c] = walk_step<(MODE >= 6 ? 0 : MODE)>(st[c], w[c][r], w[c][r + 1], base, bank4);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < CHAINS; ++c) st[c] += 32u;
+            }
         }
     }
     const u64 t1 = __builtin_amdgcn_s_memtime();
@@ -286,8 +318,9 @@ static void run_valu(const char *name) {
     }
 }
 
+static u32 *d_gtab;
 template <int MODE, int CHAINS>
-static void run_walk(const char *name, u32 table_bytes) {
+static void run_walk(const char *name, u32 table_bytes, int global_every = 0) {
     const int iters = 400;
     struct shape { int threads, bpc; };
     for (shape s : {shape{256, 4}, shape{256, 8}, shape{1024, 1}, shape{1024, 2}}) {
@@ -296,7 +329,7 @@ static void run_walk(const char *name, u32 table_bytes) {
         const u32 lds = lds_for(s.bpc, table_bytes);
         const int grid = g_cus * s.bpc, n_waves = grid * s.threads / 64;
         CK(hipFuncSetAttribute((const void *)walk_kernel<MODE, CHAINS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        auto r = timed([&] { hipLaunchKernelGGL((walk_kernel<MODE, CHAINS>), dim3(grid), dim3(s.threads), lds, 0, d_words, d_out, iters, table_bytes, d_clocks); }, n_waves);
+        auto r = timed([&] { hipLaunchKernelGGL((walk_kernel<MODE, CHAINS>), dim3(grid), dim3(s.threads), lds, 0, d_words, d_out, iters, table_bytes, d_clocks, d_gtab, global_every); }, n_waves);
         const double steps = (double)iters * kRows * kSure * CHAINS; /* per wave */
         printf("{\"probe\":\"walk\",\"table\":\"%s\",\"chains\":%d,\"block\":%d,\"blocks_per_cu\":%d,\"waves_per_simd\":%d,\"ms\":%.4f,"
                "\"cycles_per_step_per_simd\":%.2f,\"wave_cycles_per_step\":%.1f,\"ns_per_step_per_simd\":%.3f}\n",
@@ -369,6 +402,25 @@ int main(int argc, char **argv) {
         run_valu<4, 8>("v_bfe_u32");
         run_valu<5, 8>("v_perm_b32");
         run_valu<6, 8>("v_lshl_or_b32");
+    }
+    {
+        std::vector<u32> gt(1024);
+        for (u32 i = 0; i < 1024; ++i) {
+            u32 h = i * 2654435761u;
+            h ^= h >> 15;
+            gt[i] = 0x10000u - (5u + h % 6u);
+        }
+        CK(hipMalloc(&d_gtab, 4096));
+        CK(hipMemcpy(d_gtab, gt.data(), 4096, hipMemcpyHostToDevice));
+    }
+    if (what == "all" || what == "mixed") {
+        run_walk<0, 1>("shared dword 4K in LDS", 4096);
+        run_walk<6, 1>("dword 4K in global memory (L1)", 4096);
+        run_walk<8, 1>("byte 1K in global memory (L1)", 4096);
+        run_walk<9, 1>("u16 2K in global memory (L1)", 4096);
+        run_walk<7, 1>("LDS, every 4th wave through global memory", 4096, 4);
+        run_walk<7, 1>("LDS, every 2nd wave through global memory", 4096, 2);
+        run_walk<7, 1>("LDS, every 8th wave through global memory", 4096, 8);
     }
     if (what == "all" || what == "walk") {
         run_walk<0, 1>("shared dword 4K, lshr_b64", 4096);

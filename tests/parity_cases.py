@@ -1422,6 +1422,24 @@ def one_sided_coders(w, n=50_000, seed=63):
     assert np.array_equal(w.product.encode_all(mixed, few), oracle_encode(w, few))
     r, back = w.product.decode_all(mixed, want, n)  # (a stream with 7s and 200s in it)
     assert r.rc == 0 and np.array_equal(back, data)
+    # an encoder with codes of up to 30 bits beside a decoder whose table has 10: the decode kernels' entry states, walk
+    # tables and certain steps follow the DECODE table (the chunk kernels hold 12 entry states, 16 on the long way; with
+    # the encoder's 30 they would overrun), the packer and its images the encode table
+    for name in ("len2to30", "hpack_lengths", "len1to16"):
+        long_oc, _, lengths = profile_coders(w, name)
+        odd = split(long_oc, w.ocoder)
+        assert odd
+        plain = rng.integers(0, 256, 20_000).astype(np.uint8)
+        got = w.product.encode_all(odd, plain, slack=64 + 4 * plain.size)
+        assert np.array_equal(got, w.oracle.encode_all(long_oc, plain, slack=64 + 4 * plain.size)), name
+        for stream, size in ((want, n), (oracle_encode(w, inputs(rng, 70_000, "constant")), 70_000)):
+            ro, back_o = w.oracle.decode_all(w.ocoder, stream, size)  # (regular chunks; a stream whose phases never meet: the long way)
+            rp, back_p = w.product.decode_all(odd, stream, size)
+            assert rp.key() == ro.key() and np.array_equal(back_p, back_o), (name, rp, ro)
+        ro, _ = w.oracle.decode_all(w.ocoder, bad, n)
+        rp, _ = w.product.decode_all(odd, bad, n)
+        assert rp.key()[:4] == ro.key()[:4], (name, rp, ro)
+        w.oracle.lib.oracle_split_coder_destroy(odd)
     for c in (dec_only, enc_only, mixed):
         w.oracle.lib.oracle_split_coder_destroy(c)
 

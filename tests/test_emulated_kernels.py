@@ -170,9 +170,11 @@ def test_three_kernel_encoder(oracle):
         del os.environ["AWS_HUFFMAN_AMD_ENCODE"]
 
 
-def test_default_sync_kernel_is_the_one_with_a_table_per_bank(world):
-    """Which kernels a plain 100 KB decode call launches in the emulator build (HIP_EMU_TRACE): the chunks inside the
-    stream and the one it ends in both take dec_sync_bank, not the kernels it replaced."""
+def test_sync_kernel_with_a_table_per_bank(world):
+    """AWS_HUFFMAN_AMD_DECODE=bank-sync: dec_sync_bank (a length table per LDS bank, four chunks a workgroup; round 4,
+    measured slower than dec_sync_lean on the MI355X and kept behind the switch).  Which kernels a plain 100 KB decode
+    call launches in the emulator build (HIP_EMU_TRACE): by default dec_sync_lean, with the switch dec_sync_bank for the
+    chunks inside the stream and the one it ends in; and the scenarios with it."""
     code = (
         "import sys; sys.path.insert(0, %r)\n"
         "import numpy as np, harness\n"
@@ -182,18 +184,35 @@ def test_default_sync_kernel_is_the_one_with_a_table_per_bank(world):
         "enc = o.encode_all(o.lib.oracle_table_coder_new(*t), data)\n"
         "r, back = p.decode_all(p.lib.aws_huffman_amd_table_coder_new(*t), enc, data.size)\n"
         "assert r.rc == 0 and np.array_equal(back, data)\n" % (os.path.join(harness.REPO, "tests"), EMU_SO))
-    done = subprocess.run([os.sys.executable, "-c", code], env=dict(os.environ, HIP_EMU_TRACE="1"), capture_output=True, text=True)
-    assert done.returncode == 0, done.stderr[-3000:]
-    launched = [ln.split("launch ", 1)[1] for ln in done.stderr.splitlines() if ln.startswith("hip_emu launch ")]
-    assert any("dec_sync_bank_kernel<" in k and "true>" in k for k in launched), launched
-    assert any("dec_sync_bank_kernel<" in k and "false>" in k for k in launched), launched
-    assert not any("dec_sync_lean_kernel" in k or "dec_sync_fast_kernel" in k for k in launched), launched
+
+    def launched_with(mode):
+        env = dict(os.environ, HIP_EMU_TRACE="1")
+        env.pop("AWS_HUFFMAN_AMD_DECODE", None)
+        if mode:
+            env["AWS_HUFFMAN_AMD_DECODE"] = mode
+        done = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        assert done.returncode == 0, done.stderr[-3000:]
+        return [ln.split("launch ", 1)[1] for ln in done.stderr.splitlines() if ln.startswith("hip_emu launch ")]
+
+    plain = launched_with(None)
+    assert any("dec_sync_lean_kernel" in k for k in plain) and not any("dec_sync_bank_kernel" in k for k in plain), plain
+    bank = launched_with("bank-sync")
+    assert any("dec_sync_bank_kernel<" in k and "true" in k for k in bank), bank
+    assert any("dec_sync_bank_kernel<" in k and "false" in k for k in bank), bank
+    assert not any("dec_sync_lean_kernel" in k or "dec_sync_fast_kernel" in k for k in bank), bank
+    os.environ["AWS_HUFFMAN_AMD_DECODE"] = "bank-sync"
+    try:
+        pc.one_shot_roundtrips(world, sizes=[40000, 200001])
+        pc.cut_streams(world, chunks=(1, 2), step=31, n=120_000)
+        pc.garbage_decode(world, rounds=30)
+        pc.batched_device_api(world)
+    finally:
+        del os.environ["AWS_HUFFMAN_AMD_DECODE"]
 
 
-def test_decode_with_the_sync_kernels_of_earlier_rounds(world):
-    """AWS_HUFFMAN_AMD_DECODE=lean-sync / old-sync: dec_sync_lean, dec_sync_fast for the chunks dec_sync_bank takes by
-    default (the switch is read per launch)."""
-    for mode in ("lean-sync", "old-sync"):
+def test_decode_with_the_first_sync_kernel(world):
+    """AWS_HUFFMAN_AMD_DECODE=old-sync: dec_sync_fast for every chunk (the switch is read per launch)."""
+    for mode in ("old-sync",):
         os.environ["AWS_HUFFMAN_AMD_DECODE"] = mode
         try:
             pc.one_shot_roundtrips(world, sizes=[40000, 200001])
