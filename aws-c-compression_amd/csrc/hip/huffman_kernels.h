@@ -125,6 +125,10 @@ int hufk_decode_launch(const struct hufk_decode_args *args, void *stream);
 /* whether the chunks inside streams of this coder are decoded in one pass (dec_onepass), given fuse_mode != 1 */
 int hufk_decode_one_pass_applies(const struct hufd_tables *tables);
 uint64_t hufk_decode_zero_bytes(uint32_t n_tiles, uint32_t n_items);
+/* fills chunk_item[n_chunks] and chunk_rec[n_chunks] of a decode plan from its item records, on the device */
+int hufk_decode_plan_chunks(
+    const struct hufd_dec_item *items, uint32_t n_items, uint32_t n_chunks, uint32_t *chunk_item, struct hufd_chunk_rec *chunk_rec,
+    void *stream);
 /* one short item whose record already sits in device memory (the host-pointer calls' small-input road): one launch */
 int hufk_encode_one_tiny(
     const struct hufd_tables *tables, const struct hufd_enc_item *item, const uint32_t *zero, const void *d_in, void *d_out,

@@ -7724,6 +7724,41 @@ __global__ __launch_bounds__(kTailThreads) void dec_emit_tail_kernel(
     }
 }
 
+/* ------------------------------------------------------------------ decode plans: the per-chunk records */
+
+/*
+ * What a decode plan holds per CHUNK (which item it belongs to, hufd_chunk_rec) follows from the item records: built here,
+ * a thread a chunk, instead of by a loop on the host -- for BASELINE configs[3] that loop and the copies of its arrays
+ * were most of the time it took to make a plan, more than the launch the plan is for.  The item of chunk c is the last
+ * one whose first chunk is not behind c (items without chunks share their first chunk with the item behind them).
+ */
+__global__ __launch_bounds__(256) void dec_plan_chunks_kernel(
+    const hufd_dec_item *items, u32 n_items, u32 n_chunks, u32 *chunk_item, hufd_chunk_rec *chunk_rec) {
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) {
+        return;
+    }
+    u32 lo = 0, hi = n_items; /* items[lo].first_chunk <= c < items[hi].first_chunk (hi == n_items: no such item) */
+    while (hi - lo > 1) {
+        const u32 mid = lo + (hi - lo) / 2;
+        if (items[mid].first_chunk <= c) {
+            lo = mid;
+        } else {
+            hi = mid;
+        }
+    }
+    const hufd_dec_item it = items[lo];
+    const u64 off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES, left = it.in_len - off;
+    hufd_chunk_rec rec;
+    rec.src_off = it.in_off + off;
+    rec.out_off = it.out_off;
+    rec.out_cap = it.out_cap;
+    rec.valid = left < 0xFFFFFFFFull ? (u32)left : 0xFFFFFFFFu;
+    rec.item = lo;
+    chunk_item[c] = lo;
+    chunk_rec[c] = rec;
+}
+
 /* ------------------------------------------------------------------ synthetic input */
 
 __global__ __launch_bounds__(256) void splitmix64_fill_kernel(u8 *dst, u64 len, u64 seed) {
@@ -7905,6 +7940,18 @@ int hufk_decode_one_pass_applies(const struct hufd_tables *tb) {
     const uint32_t lb = tb->lut_bits <= 10 ? 10u : 12u;
     const uint32_t sure = row_walk(lb, tb->max_bits).sure;
     return lb == 10 ? sure >= 2 && sure <= 5 : sure >= 2 && sure <= 3;
+}
+
+int hufk_decode_plan_chunks(
+    const struct hufd_dec_item *items, uint32_t n_items, uint32_t n_chunks, uint32_t *chunk_item, struct hufd_chunk_rec *chunk_rec,
+    void *stream) {
+    if (n_chunks == 0 || n_items == 0) {
+        return 0;
+    }
+    hipLaunchKernelGGL(
+        dec_plan_chunks_kernel, dim3((n_chunks + 255) / 256), dim3(256), 0, (hipStream_t)stream, items, n_items, n_chunks, chunk_item,
+        chunk_rec);
+    return (int)hipGetLastError();
 }
 
 uint64_t hufk_decode_zero_bytes(uint32_t n_tiles, uint32_t n_items) {

@@ -476,15 +476,18 @@ static uint64_t enc_tiny_limit(const struct aws_huffman_amd_engine *eng, const s
     /* (the one-pass kernel packs ragged tiles at full speed: measured, a wave beats a thread from about 1 KiB an item) */
     const uint64_t classes[2] = {
         aws_huffman_amd_engine_encodes_in_one_pass(eng) ? HUFD_ENC_TINY_WAVE_BYTES : HUFD_TINY_MANY_BYTES, HUFD_ENC_TINY_BYTES};
-    for (int c = 0; c < 2; ++c) {
-        uint64_t count = 0, longest = 0;
-        for (size_t i = 0; i < n_items; ++i) {
-            if (items[i].in_len <= classes[c]) {
-                ++count;
-                longest = items[i].in_len > longest ? items[i].in_len : longest;
+    uint64_t count[2] = {0, 0}, longest[2] = {0, 0}; /* (one pass over the items for both classes) */
+    for (size_t i = 0; i < n_items; ++i) {
+        const uint64_t len = items[i].in_len;
+        for (int c = 0; c < 2; ++c) {
+            if (len <= classes[c]) {
+                ++count[c];
+                longest[c] = len > longest[c] ? len : longest[c];
             }
         }
-        if (longest > HUFD_TINY_FEW_BYTES && count >= HUFD_ENC_TINY_PER_BYTE * longest) {
+    }
+    for (int c = 0; c < 2; ++c) {
+        if (longest[c] > HUFD_TINY_FEW_BYTES && count[c] >= HUFD_ENC_TINY_PER_BYTE * longest[c]) {
             return classes[c];
         }
     }
@@ -887,15 +890,19 @@ static bool dec_item_is_tiny(const struct aws_huffman_amd_decode_item *it, uint6
 /* the longest item a lone thread takes in this plan: see HUFD_DEC_TINY_PER_BYTE */
 static uint64_t dec_tiny_limit(const struct aws_huffman_amd_decode_item *items, size_t n_items) {
     static const uint64_t classes[2] = {HUFD_TINY_MANY_BYTES * 3 / 2, HUFD_DEC_TINY_BYTES};
-    for (int c = 0; c < 2; ++c) {
-        uint64_t count = 0, longest = 0;
-        for (size_t i = 0; i < n_items; ++i) {
-            if (items[i].in_len <= classes[c]) {
-                ++count;
-                longest = items[i].in_len > longest ? items[i].in_len : longest;
+    /* (one pass over the items for both classes: a plan of a million header-sized items is read from memory once here) */
+    uint64_t count[2] = {0, 0}, longest[2] = {0, 0};
+    for (size_t i = 0; i < n_items; ++i) {
+        const uint64_t len = items[i].in_len;
+        for (int c = 0; c < 2; ++c) {
+            if (len <= classes[c]) {
+                ++count[c];
+                longest[c] = len > longest[c] ? len : longest[c];
             }
         }
-        if (longest > HUFD_TINY_FEW_BYTES && count >= HUFD_DEC_TINY_PER_BYTE * longest) {
+    }
+    for (int c = 0; c < 2; ++c) {
+        if (longest[c] > HUFD_TINY_FEW_BYTES && count[c] >= HUFD_DEC_TINY_PER_BYTE * longest[c]) {
             return classes[c];
         }
     }
@@ -959,6 +966,18 @@ static int dec_plan_fill(
         return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION);
     }
     const uint64_t tiny_limit = dec_tiny_limit(items, n_items);
+    /* dec_onepass's tile records only where that kernel is asked for (AWS_HUFFMAN_AMD_DECODE=one-pass, one-pass-fails) and
+     * applies to the coder: three records per 16 KiB item that the default road never reads were the largest part of
+     * what a plan cost to make */
+    bool want_tiles = false;
+    {
+        const char *mode = getenv("AWS_HUFFMAN_AMD_DECODE");
+        want_tiles = mode && (strcmp(mode, "one-pass") == 0 || strcmp(mode, "one-pass-fails") == 0) &&
+                     hufk_decode_one_pass_applies(&eng->tables);
+    }
+    /* a failed refill must not leave counts of the fill before behind (the device arrays may be gone or too small) */
+    p->n_items = p->n_chunks = p->n_large = p->n_runs = p->n_tail = p->n_tiles = p->n_fixed = p->n_wide = 0;
+    p->n_tiny = p->n_deep = 0;
     uint64_t n_chunks = 0, n_large = 0, n_runs = 0, n_tiles = 0;
     for (size_t i = 0; i < n_items; ++i) {
         /* symbol counts in the scan's function entries are 26-bit; 4 GiB of encoded bytes per item is the limit */
@@ -969,28 +988,24 @@ static int dec_plan_fill(
         n_chunks += chunks;
         n_large += chunks > HUFD_SCAN_SMALL_MAX;
         n_runs += chunks > HUFD_SCAN_SMALL_MAX ? (chunks + HUFD_SCAN_RUN_CHUNKS - 1) / HUFD_SCAN_RUN_CHUNKS : 0;
-        n_tiles += dec_item_tiles(chunks, items[i].in_len);
+        n_tiles += want_tiles ? dec_item_tiles(chunks, items[i].in_len) : 0;
     }
     if (n_chunks >= 0xFFFFFFFFull || n_items >= 0xFFFFFFFFull || n_tiles >= 0x00FFFFFFull) {
         return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
     }
 
     struct hufd_dec_item *h_items = malloc((n_items ? n_items : 1) * sizeof(*h_items));
-    uint32_t *h_chunk_item = malloc((n_chunks ? n_chunks : 1) * sizeof(uint32_t));
-    struct hufd_chunk_rec *h_chunk_rec = malloc((n_chunks ? n_chunks : 1) * sizeof(*h_chunk_rec));
     uint32_t *h_large = malloc((n_large ? n_large : 1) * 2 * sizeof(uint32_t));
     uint32_t *h_runs = malloc((n_runs ? n_runs : 1) * 2 * sizeof(uint32_t));
     uint32_t *h_tail = malloc((n_items ? n_items : 1) * 2 * sizeof(uint32_t));
     uint32_t *h_tiny = malloc((n_items ? n_items : 1) * sizeof(uint32_t));
     struct hufd_tile_rec *h_tiles = malloc((n_tiles ? n_tiles : 1) * sizeof(*h_tiles));
-    if (!h_tiles || !h_items || !h_chunk_item || !h_chunk_rec || !h_large || !h_runs || !h_tail || !h_tiny) {
-        free(h_chunk_rec);
+    if (!h_tiles || !h_items || !h_large || !h_runs || !h_tail || !h_tiny) {
         free(h_tail);
         free(h_tiny);
         free(h_tiles);
         free(h_runs);
         free(h_items);
-        free(h_chunk_item);
         free(h_large);
         return aws_raise_error(AWS_ERROR_OOM);
     }
@@ -1055,7 +1070,7 @@ static int dec_plan_fill(
         }
         {
             const uint64_t subs = dec_item_inside_subs(chunks, src->in_len);
-            const uint64_t tiles_here = dec_item_tiles(chunks, src->in_len);
+            const uint64_t tiles_here = want_tiles ? dec_item_tiles(chunks, src->in_len) : 0;
             for (uint64_t k = 0; k < tiles_here; ++k) {
                 /* tile 0: sub-chunks 0 .. 63; tile k: sub-chunk 63 k (again) and 63 k + 1 .. 63 k + 63 */
                 const uint64_t first_sub = k * (HUFD_TILE_LANES - 1);
@@ -1071,27 +1086,20 @@ static int dec_plan_fill(
                 tr->reserved = 0;
             }
         }
-        for (uint32_t k = 0; k < chunks; ++k) {
-            /* fewer than a chunk + 8 bytes left: the end of the stream is in (or just behind) this chunk */
+        /* the chunks that hold the end of the stream, or lie just behind it: fewer than a chunk + 8 bytes left from their
+         * first byte on -- the item's last chunk, and the one in front of it when the last one holds less than 8 bytes.
+         * (chunk -> item and the records per chunk are made on the device: hufk_decode_plan_chunks) */
+        for (uint32_t k = chunks > 2 ? chunks - 2 : 0; k < chunks; ++k) {
             if (src->in_len - (uint64_t)k * HUFD_DEC_CHUNK_BYTES < (uint64_t)HUFD_DEC_CHUNK_BYTES + 8u) {
-                h_tail[tail++] = chunk;
+                h_tail[tail++] = chunk + k;
                 const uint64_t left = src->in_len - (uint64_t)k * HUFD_DEC_CHUNK_BYTES;
                 const uint32_t shortest = eng->tables.min_bits ? eng->tables.min_bits : 1;
                 uint64_t holds = left * 8 / shortest + 1;
                 holds = holds < src->out_capacity ? holds : src->out_capacity;
                 tail_stage = holds > tail_stage ? holds : tail_stage;
             }
-            {
-                const uint64_t off = (uint64_t)k * HUFD_DEC_CHUNK_BYTES, left = src->in_len - off;
-                struct hufd_chunk_rec *cr = &h_chunk_rec[chunk];
-                cr->src_off = src->in_offset + off;
-                cr->out_off = src->out_offset;
-                cr->out_cap = src->out_capacity;
-                cr->valid = left < 0xFFFFFFFFull ? (uint32_t)left : 0xFFFFFFFFu;
-                cr->item = (uint32_t)i;
-            }
-            h_chunk_item[chunk++] = (uint32_t)i;
         }
+        chunk += chunks;
         if (chunks > HUFD_SCAN_SMALL_MAX) {
             h_large[2 * large] = (uint32_t)i;
             h_large[2 * large + 1] = run;
@@ -1200,10 +1208,7 @@ static int dec_plan_fill(
         err = hufs_copy_h2d(p->d_tiny, h_tiny, (tiny || deep ? n_items : 0) * sizeof(uint32_t), eng->stream);
     }
     if (!err) {
-        err = hufs_copy_h2d(p->d_chunk_item, h_chunk_item, n_chunks * sizeof(uint32_t), eng->stream);
-        if (!err) {
-            err = hufs_copy_h2d(p->d_chunk_rec, h_chunk_rec, n_chunks * sizeof(*h_chunk_rec), eng->stream);
-        }
+        err = hufk_decode_plan_chunks(p->d_items, (uint32_t)n_items, (uint32_t)n_chunks, p->d_chunk_item, p->d_chunk_rec, eng->stream);
     }
     if (!err) {
         err = hufs_copy_h2d(p->d_large, h_large, n_large * 2 * sizeof(uint32_t), eng->stream);
@@ -1222,8 +1227,6 @@ static int dec_plan_fill(
         }
     }
     free(h_items);
-    free(h_chunk_item);
-    free(h_chunk_rec);
     free(h_large);
     free(h_runs);
     free(h_tail);

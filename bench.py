@@ -293,13 +293,14 @@ def digest_of(eng, ptr, size):
     return h.hexdigest()
 
 
-def rooflines(out, names_e, names_d, kernel_ms, t_enc_ms, t_dec_ms, n, e_len, algo_per_kernel):
-    traffic = load_traffic(out["config"].get("decode_road", "two-pass"))
+def rooflines(out, names_e, names_d, kernel_ms, t_enc_ms, t_dec_ms, n, e_len, algo_per_kernel, traffic_measured=True):
+    # (the committed counter passes are of the 1 GiB stream: another workload's `traffic` is null, not the stream's figure)
+    traffic = load_traffic(out["config"].get("decode_road", "two-pass")) if traffic_measured else None
     enc = roofline_of("encode", names_e, n + e_len, t_enc_ms, traffic)
     dec = roofline_of("decode", names_d, n + e_len, t_dec_ms, traffic)
     out["roofline_encode"], out["roofline_decode"] = enc, dec
     out["roofline"] = dec if t_dec_ms >= t_enc_ms else enc
-    out["traffic_source"] = (traffic or {}).get("_source", "profiles/pmc_traffic.json: HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, "
+    out["traffic_source"] = "none: HBM traffic was not measured for this workload" if not traffic_measured else (traffic or {}).get("_source", "profiles/pmc_traffic.json: HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, "
                                                 "separate rocprofv3 --pmc passes of this command, committed profile), not this run")
     dominant = max(kernel_ms, key=lambda k: kernel_ms[k])
     out["roofline_kernel"] = roofline_of(dominant, [dominant], algo_per_kernel[dominant], kernel_ms[dominant], traffic)
@@ -399,6 +400,7 @@ def run_cfg4(args, ranks, lib, eng):
     items = [dict(in_offset=k * size, in_len=size, out_offset=k * stride, out_capacity=size if i % 4 == 0 else stride)
              for k, i in enumerate(mine)]
     plan = eng.encode_plan(items)
+    plan_ms = {"encode": round(eng.last_plan_ms, 3)}
     eng.encode_launch(plan, d_in, d_out)
     res = eng.encode_results(plan, count)
     short = [k for k, i in enumerate(mine) if i % 4 == 0]
@@ -411,6 +413,7 @@ def run_cfg4(args, ranks, lib, eng):
     resume = [dict(in_offset=k * size + res[k][2], in_len=size - res[k][2], out_offset=k * stride + size,
                    out_capacity=size, overflow_in=(res[k][5], res[k][4])) for k in short]
     plan2 = eng.encode_plan(resume) if resume else None
+    plan_ms["encode_resume"] = round(eng.last_plan_ms, 3) if resume else 0.0
     lengths = [r[3] for r in res]
     if plan2:
         eng.encode_launch(plan2, d_in, d_out)
@@ -420,6 +423,7 @@ def run_cfg4(args, ranks, lib, eng):
             lengths[k] += r[3]
     dplan = eng.decode_plan([dict(in_offset=k * stride, in_len=lengths[k], out_offset=k * size, out_capacity=size)
                              for k in range(count)])
+    plan_ms["decode"] = round(eng.last_plan_ms, 3)
     eng.decode_launch(dplan, d_out, d_back)
     dres = eng.decode_results(dplan, count)
     assert all(r[0] == 0 and r[2] == size for r in dres)
@@ -461,12 +465,16 @@ def run_cfg4(args, ranks, lib, eng):
                         "every fourth one capacity-limited (SHORT_BUFFER record, then a resume call), all decoded back, "
                         "HBM-resident" % (count_all, size),
             "buffers": count_all, "buffer_bytes": size, "bit_exact": bit_exact,
+            # what MAKING the three plans of a step cost on this host (aws_huffman_amd_*_plan_new, device allocations
+            # included; a decode plan depends on the encoded lengths, so a fresh batch pays it): not in ms_per_step,
+            # which times launches of plans that exist
+            "plan_ms": plan_ms,
         },
         "scaling": "strong",
     }
     algo = {names_e[0]: n + e_len if names_e[0] == "enc_onepass" else n, names_e[1]: 0, names_e[2]: 0 if names_e[0] == "enc_onepass" else n + e_len,
             "dec_sync": e_len, "dec_scan": 0, "dec_emit": e_len + n}
-    rooflines(out, names_e, names_d, kernel_ms, t_enc_ms, t_dec_ms, n, e_len, algo)
+    rooflines(out, names_e, names_d, kernel_ms, t_enc_ms, t_dec_ms, n, e_len, algo, traffic_measured=False)
     per_rank = {"rank": ranks.rank, "buffers": count, "encoded_bytes": e_len, "sha256_encoded_streams": enc_digest,
                 "encode_ms": round(t_enc_ms, 4), "decode_ms": round(t_dec_ms, 4)}
     return out, n, e_len, wall, kernel_ms, t_enc_ms, t_dec_ms, per_rank, 2
@@ -618,6 +626,7 @@ def main():
         def leg(fn, *more):
             o, ln, le, w, kms, te, td, _, _ = fn(*more)
             return {"workload": o["config"]["workload"], "bit_exact": o["config"]["bit_exact"], "steps": more[0].steps,
+                    **({"plan_ms": o["config"]["plan_ms"]} if "plan_ms" in o["config"] else {}),
                     "value_GiBps": round(ln / GIB / max((te + td) * 1e-3, 1e-12), 2),
                     "encode_ms": round(te, 4), "decode_ms": round(td, 4),
                     "encode_path_frac_of_hbm_peak": round((ln + le) / max(te * 1e-3, 1e-12) / HBM_PEAK_BYTES_PER_S, 4),

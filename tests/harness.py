@@ -11,6 +11,7 @@ Two libraries speak the same C ABI (include/aws/compression/huffman.h):
 "run the same scenario on both and compare everything observable".
 """
 import ctypes as C
+import time
 import json
 import os
 
@@ -309,7 +310,10 @@ class Engine:
             arr[i].overflow_in.pattern, arr[i].overflow_in.num_bits = ov
             arr[i].eos_padding = it.get("eos_padding", 0xFF)
         plan = C.c_void_p()
-        if self.lib.aws_huffman_amd_encode_plan_new(C.byref(plan), self.h, arr, len(items)) != 0:
+        t0 = time.perf_counter()
+        rc = self.lib.aws_huffman_amd_encode_plan_new(C.byref(plan), self.h, arr, len(items))
+        self.last_plan_ms = (time.perf_counter() - t0) * 1e3  # what making the plan cost (the C call alone)
+        if rc != 0:
             raise RuntimeError("encode_plan_new failed, error %d" % self.lib.aws_last_error())
         return plan
 
@@ -355,7 +359,10 @@ class Engine:
             arr[i].first_bit = it.get("first_bit", 0)
             arr[i].out_offset, arr[i].out_capacity = it["out_offset"], it["out_capacity"]
         plan = C.c_void_p()
-        if self.lib.aws_huffman_amd_decode_plan_new(C.byref(plan), self.h, arr, len(items)) != 0:
+        t0 = time.perf_counter()
+        rc = self.lib.aws_huffman_amd_decode_plan_new(C.byref(plan), self.h, arr, len(items))
+        self.last_plan_ms = (time.perf_counter() - t0) * 1e3
+        if rc != 0:
             raise RuntimeError("decode_plan_new failed, error %d" % self.lib.aws_last_error())
         return plan
 

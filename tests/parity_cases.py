@@ -1282,10 +1282,10 @@ def decode_roads(w, engine=None, sizes=(40_000, 300_000, 1_100_000), seed=53):
         eng.fill(d_out, SENTINEL, int(out_offs[-1]) + 64)
         items = [dict(in_offset=int(in_offs[i]), in_len=int(encs[i].size), out_offset=int(out_offs[i]),
                       out_capacity=int(caps[i])) for i in range(len(encs))]
-        plan = eng.decode_plan(items)
         if mode:
-            os.environ["AWS_HUFFMAN_AMD_DECODE"] = mode
+            os.environ["AWS_HUFFMAN_AMD_DECODE"] = mode  # (read when the plan is made -- dec_onepass's tile records -- and at the launch)
         try:
+            plan = eng.decode_plan(items)
             eng.decode_launch(plan, d_in, d_out)
         finally:
             if mode:

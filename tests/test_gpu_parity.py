@@ -213,6 +213,9 @@ def test_config2_config3_one_gib_stream(world, engine):
         engine.fill(d_back, 0x5A, n + 64)
         os.environ["AWS_HUFFMAN_AMD_DECODE"] = mode
         try:
+            # (the switch is read when a plan is made -- only then does it get dec_onepass's tile records -- and at the launch)
+            engine.lib.aws_huffman_amd_decode_plan_destroy(dplan)
+            dplan = engine.decode_plan([dict(in_offset=0, in_len=e, out_offset=0, out_capacity=n)])
             engine.decode_launch(dplan, d_enc, d_back)
         finally:
             del os.environ["AWS_HUFFMAN_AMD_DECODE"]

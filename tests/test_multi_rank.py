@@ -140,3 +140,5 @@ def test_single_rank_line(emulator, oracle):
     for leg in ("cfg4", "host_abi"):
         assert out[leg]["bit_exact"] is True and "value_GiBps" in out[leg] and "encode_ms" in out[leg], leg  # (the emulator has no clock for events)
     assert "configs[3]" in out["cfg4"]["workload"] and "HOST memory" in out["host_abi"]["workload"]
+    # what making the batch's plans cost rides along, and a traffic figure only where it was measured for the workload
+    assert set(out["cfg4"]["plan_ms"]) == {"encode", "encode_resume", "decode"} and out["cfg4"]["roofline"]["traffic"] is None
