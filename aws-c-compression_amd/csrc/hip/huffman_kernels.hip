@@ -7798,15 +7798,30 @@ static int current_compute_units() {
 
 /* workgroups of a persistent kernel that one launch keeps resident: CUs x blocks per CU */
 template <typename Kernel>
-static uint32_t persistent_grid(Kernel kernel, uint32_t threads, uint32_t lds_bytes, uint32_t work_items) {
+static uint32_t persistent_grid(Kernel kernel, uint32_t threads, uint32_t lds_bytes, uint32_t work_items, uint32_t sgprs = 0) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)threads, lds_bytes) != hipSuccess ||
         per_cu < 1) {
         per_cu = 1;
     }
+    /* The occupancy query knows nothing of the scalar registers: a SIMD has 800 of them and a wave is given its count
+     * rounded up to 16, plus 16, so the hardware admits floor(800 / that) waves a SIMD -- one block a CU fewer than the
+     * query says in two bands of the count (MI355X_MICROARCH.md, "Residency and cooperative launch").  A grid whose
+     * workgroups WAIT for each other must not be larger than what is resident: those kernels say how many they use
+     * (kOnepassSgprs: read off the build, profiles/tools/spill_census.py prints it), and the smaller number counts. */
+    if (sgprs) {
+        const uint32_t waves_per_simd = 800u / ((sgprs + 15u) / 16u * 16u + 16u);
+        const uint32_t waves_per_block_and_simd = (threads + 255u) / 256u;
+        const uint32_t by_sgprs = waves_per_simd / waves_per_block_and_simd;
+        per_cu = by_sgprs >= 1 && (int)by_sgprs < per_cu ? (int)by_sgprs : per_cu;
+    }
     const uint64_t resident = (uint64_t)current_compute_units() * (uint32_t)per_cu;
     return (uint32_t)(work_items < resident ? work_items : resident);
 }
+
+/* scalar registers of enc_onepass and dec_onepass (every instantiation: the compiler uses all 102 + VCC + the rest);
+ * tests/test_library_boundary.py::test_onepass_kernels_scalar_registers holds the build to it */
+constexpr uint32_t kOnepassSgprs = 106;
 
 /* layout of the block the one-pass encoder wants zeroed before every launch (all offsets multiples of 8) */
 struct onepass_layout {
@@ -8013,7 +8028,7 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
         const uint32_t work = (a->n_segs * kTilesPerSeg + kPackWaves - 1) / kPackWaves;
 #define HUFK_LAUNCH_ONEPASS(NWV)                                                                                      \
     hipLaunchKernelGGL(                                                                                                \
-        enc_onepass_kernel<NWV>, dim3(persistent_grid(enc_onepass_kernel<NWV>, kPackThreads, lds, work)),              \
+        enc_onepass_kernel<NWV>, dim3(persistent_grid(enc_onepass_kernel<NWV>, kPackThreads, lds, work, kOnepassSgprs)), \
         dim3(kPackThreads), lds, st, a->tables, a->items, a->segs, (const u8 *)a->d_in, (u8 *)a->d_out, region,        \
         a->n_segs, (u32 *)(z + l.ctl), (u32 *)(z + l.tile_agg), (u64 *)(z + l.group_acc),                              \
         (u64 *)(z + l.round_base), (u64 *)(z + l.item_base), a->item_total, a->results, (const u8 *)(z + l.null_tile),  \
@@ -8245,7 +8260,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         bool launched = true;
 #define HUFK_LAUNCH_ONEPASS_DEC(LBV, SUREV)                                                                            \
     /* a turn of the grid = a round of the look-back: whole groups of tiles, at most 128 of them */                  \
-    const uint32_t resident = persistent_grid(dec_onepass_kernel<LBV, SUREV>, kFuseThreads, (uint32_t)sizeof(fuse_shared<LBV>), 1u << 20); \
+    const uint32_t resident = persistent_grid(dec_onepass_kernel<LBV, SUREV>, kFuseThreads, (uint32_t)sizeof(fuse_shared<LBV>), 1u << 20, kOnepassSgprs); \
     const uint32_t want = (a->n_tiles + kFuseWaves - 1) / kFuseWaves;                                                  \
     const uint32_t unit = kOpGroupTiles / std::gcd(kOpGroupTiles, kFuseWaves); /* workgroups that make whole groups */ \
     uint32_t grid = want < resident ? (want + unit - 1) / unit * unit : resident / unit * unit;                        \

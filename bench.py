@@ -246,7 +246,18 @@ class Stages:
             t_enc.append(e_sum)
             t_dec.append(d_sum)
         kernel_ms = {k: statistics.median(v) for k, v in per_step.items()}
+        self.per_step = per_step
         return kernel_ms, statistics.median(t_enc), statistics.median(t_dec)
+
+    def gave_up_steps(self):
+        """Timed steps in which the one-pass encoder gave up and the three-kernel road behind it did the launch over (a
+        silent demotion otherwise: the output is right either way).  Told from the stage that holds the gated launches:
+        empty, they take ~0.02 ms; doing a launch over, tens of times that."""
+        if self.names_e[0] != "enc_onepass":
+            return 0
+        gated = self.per_step[self.names_e[2]]
+        floor = statistics.median(gated)
+        return sum(1 for ms in gated if ms > 0.1 and ms > 8 * floor)
 
 
 def roofline_of(label, kernels, algo_bytes, ms, traffic_table):
@@ -370,6 +381,9 @@ def run_stream(args, ranks, lib, eng):
             "bit_exact_checked": "records and sha256 of the encoded stream and of the decoded bytes after the last timed step",
             "encode_road": roads[eng.encode_road(enc_plan)].replace("two-pass", "three-kernel"),
             "decode_road": roads[eng.decode_road(dec_plan)],
+            # timed steps in which the one-pass encoder gave up (a wait ran out: something else held CUs) and the
+            # three-kernel road did the launch over on the device -- right output, slower step
+            "gave_up": stages.gave_up_steps(),
         },
         "scaling": "weak",
     }
@@ -469,6 +483,7 @@ def run_cfg4(args, ranks, lib, eng):
             # included; a decode plan depends on the encoded lengths, so a fresh batch pays it): not in ms_per_step,
             # which times launches of plans that exist
             "plan_ms": plan_ms,
+            "gave_up": stages.gave_up_steps(),
         },
         "scaling": "strong",
     }

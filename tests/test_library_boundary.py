@@ -168,3 +168,29 @@ def test_fails_loudly_without_a_gpu(product_lib):
     dst = np.zeros(8, np.uint8)
     r = codec.encode_call(codec.new_encoder(coder), src, 0, dst, 0, 8)
     assert r.rc == -1 and r.err == 6 and r.consumed == 0 and r.produced == 0  # no silent CPU encode
+
+
+def test_onepass_kernels_scalar_registers(tmp_path):
+    """The grids of enc_onepass and dec_onepass are sized to be resident as a whole: by the occupancy query AND by the
+    scalar-register rule the query does not know (persistent_grid, kOnepassSgprs in csrc/hip/huffman_kernels.hip).  The
+    constant must cover what the build really uses: compiled to assembly here, `.sgpr_count` of every instantiation."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(harness.REPO, "aws-c-compression_amd", "csrc", "hip", "huffman_kernels.hip")
+    declared = int(re.search(r"constexpr uint32_t kOnepassSgprs = (\d+);", open(src).read()).group(1))
+    asm = tmp_path / "kernels.s"
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+                           "-I" + os.path.join(harness.REPO, "include"), "-I" + os.path.join(harness.REPO, "include", "compat"),
+                           src, "-o", str(asm)], stderr=subprocess.DEVNULL)
+    counts = {}
+    name = None
+    for line in open(asm):
+        m = re.match(r"\s+\.name:\s+(\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.match(r"\s+\.sgpr_count:\s+(\d+)", line)
+        if m and name and ("enc_onepass_kernel" in name or "dec_onepass_kernel" in name):
+            counts[name] = int(m.group(1))
+    assert len(counts) >= 6, counts
+    assert max(counts.values()) <= declared, (declared, counts)
