@@ -651,6 +651,12 @@ def main():
         short.steps, short.warmup = 5, 2
         try:
             line["cfg4"] = leg(run_cfg4, short, ranks, lib, eng)
+            # the same batch shape with 2 KiB items (128 MiB in 65 536 of them): between header size and a whole
+            # segment / chunk, where a workgroup per item is mostly idle lanes ("mid-size items")
+            mid = argparse.Namespace(**vars(short))
+            mid.buffer_bytes = 2048
+            line["mid_items"] = leg(run_cfg4, mid, ranks, lib, eng)
+            line["mid_items"]["workload"] = line["mid_items"]["workload"].replace("BASELINE configs[3]", "configs[3]'s shape with 2 KiB items")
             short.steps, short.warmup = 3, 1  # (one 256 MiB buffer, or the stream's size when that was given and is smaller)
             line["host_abi"] = leg(run_host_abi, short, ranks, lib, eng, coder)
             line["host_abi"].pop("encode_path_frac_of_hbm_peak"), line["host_abi"].pop("decode_path_frac_of_hbm_peak")

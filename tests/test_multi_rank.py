@@ -137,7 +137,7 @@ def test_single_rank_line(emulator, oracle):
     assert (out["config"]["encoded_bytes"], out["config"]["sha256_encoded"]) == (e_len, digest)
     assert out["config"]["bit_exact"] is True and "after the last timed step" in out["config"]["bit_exact_checked"]
     assert out["config"]["encode_road"] in ("one-pass", "three-kernel") and out["config"]["decode_road"] == "two-pass"
-    for leg in ("cfg4", "host_abi"):
+    for leg in ("cfg4", "mid_items", "host_abi"):
         assert out[leg]["bit_exact"] is True and "value_GiBps" in out[leg] and "encode_ms" in out[leg], leg  # (the emulator has no clock for events)
     assert "configs[3]" in out["cfg4"]["workload"] and "HOST memory" in out["host_abi"]["workload"]
     # what making the batch's plans cost rides along, and a traffic figure only where it was measured for the workload
