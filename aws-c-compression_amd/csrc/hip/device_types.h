@@ -161,6 +161,29 @@ struct hufd_dec_item {
     uint32_t tiny; /* 1: the item has no chunks, dec_tiny decodes it */
 };
 
+/* The caller's item records as the public header lays them out (include/aws/compression/huffman_amd.h: struct
+ * aws_huffman_amd_decode_item / _encode_item; csrc/host/engine.c holds the two pairs to the same sizes and offsets): a
+ * plan whose items are all one thread's work is made from them ON THE DEVICE (hufk_*_plan_tiny_items). */
+struct hufd_raw_dec_item {
+    uint64_t in_offset;
+    uint64_t in_len;
+    uint32_t first_bit;
+    uint32_t pad;
+    uint64_t out_offset;
+    uint64_t out_capacity;
+};
+struct hufd_raw_enc_item {
+    uint64_t in_offset;
+    uint64_t in_len;
+    uint64_t out_offset;
+    uint64_t out_capacity;
+    uint32_t ovf_pattern;
+    uint8_t ovf_bits;
+    uint8_t pad0[3];
+    uint8_t eos_padding;
+    uint8_t pad1[7];
+};
+
 /* written by the scan kernel */
 struct hufd_dec_item_state {
     uint64_t total_symbols; /* symbols on the true path before it stops */

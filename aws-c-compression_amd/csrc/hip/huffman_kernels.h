@@ -125,6 +125,10 @@ int hufk_decode_launch(const struct hufk_decode_args *args, void *stream);
 /* whether the chunks inside streams of this coder are decoded in one pass (dec_onepass), given fuse_mode != 1 */
 int hufk_decode_one_pass_applies(const struct hufd_tables *tables);
 uint64_t hufk_decode_zero_bytes(uint32_t n_tiles, uint32_t n_items);
+/* a plan of items that are all one thread's work: the kernels' item records and the list of such items (= all of them) from
+ * the caller's records, copied to the device as they are (struct hufd_raw_dec_item / hufd_raw_enc_item) */
+int hufk_decode_plan_tiny_items(const void *raw_items, uint32_t n_items, struct hufd_dec_item *items, uint32_t *tiny_list, void *stream);
+int hufk_encode_plan_tiny_items(const void *raw_items, uint32_t n_items, struct hufd_enc_item *items, uint32_t *tiny_list, void *stream);
 /* fills chunk_item[n_chunks] and chunk_rec[n_chunks] of a decode plan from its item records, on the device */
 int hufk_decode_plan_chunks(
     const struct hufd_dec_item *items, uint32_t n_items, uint32_t n_chunks, uint32_t *chunk_item, struct hufd_chunk_rec *chunk_rec,

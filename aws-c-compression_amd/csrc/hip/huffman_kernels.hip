@@ -7759,6 +7759,52 @@ __global__ __launch_bounds__(256) void dec_plan_chunks_kernel(
     chunk_rec[c] = rec;
 }
 
+/*
+ * A plan whose items are ALL one thread's work (header-sized strings, the reference's production use): nothing of it
+ * needs the host's attention per item -- the caller's records are copied up as they are and turned into the kernels'
+ * records here; the list of thread-per-item items is every item.  (A million such items cost the host loop 27 ms.)
+ */
+__global__ __launch_bounds__(256) void dec_plan_tiny_items_kernel(const hufd_raw_dec_item *raw, u32 n_items, hufd_dec_item *items, u32 *tiny_list) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) {
+        return;
+    }
+    const hufd_raw_dec_item r = raw[i];
+    hufd_dec_item it;
+    it.in_off = r.in_offset;
+    it.in_len = r.in_len;
+    it.out_off = r.out_offset;
+    it.out_cap = r.out_capacity;
+    it.first_bit = r.first_bit;
+    it.first_chunk = 0;
+    it.n_chunks = 0;
+    it.tiny = 1;
+    items[i] = it;
+    tiny_list[i] = i;
+}
+
+__global__ __launch_bounds__(256) void enc_plan_tiny_items_kernel(const hufd_raw_enc_item *raw, u32 n_items, hufd_enc_item *items, u32 *tiny_list) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) {
+        return;
+    }
+    const hufd_raw_enc_item r = raw[i];
+    const u32 ob = r.ovf_bits;
+    hufd_enc_item it;
+    it.in_off = r.in_offset;
+    it.in_len = r.in_len;
+    it.out_off = r.out_offset;
+    it.out_cap = r.out_capacity;
+    it.ovf_bits = ob;
+    it.ovf_pattern = ob == 0 ? 0u : (ob >= 32 ? r.ovf_pattern : r.ovf_pattern & ((1u << ob) - 1u));
+    it.eos_padding = r.eos_padding;
+    it.first_seg = 0;
+    it.n_segs = 0;
+    it.tiny = 1;
+    items[i] = it;
+    tiny_list[i] = i;
+}
+
 /* ------------------------------------------------------------------ synthetic input */
 
 __global__ __launch_bounds__(256) void splitmix64_fill_kernel(u8 *dst, u64 len, u64 seed) {
@@ -7966,6 +8012,26 @@ int hufk_decode_plan_chunks(
     hipLaunchKernelGGL(
         dec_plan_chunks_kernel, dim3((n_chunks + 255) / 256), dim3(256), 0, (hipStream_t)stream, items, n_items, n_chunks, chunk_item,
         chunk_rec);
+    return (int)hipGetLastError();
+}
+
+int hufk_decode_plan_tiny_items(const void *raw_items, uint32_t n_items, struct hufd_dec_item *items, uint32_t *tiny_list, void *stream) {
+    if (n_items == 0) {
+        return 0;
+    }
+    hipLaunchKernelGGL(
+        dec_plan_tiny_items_kernel, dim3((n_items + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+        (const hufd_raw_dec_item *)raw_items, n_items, items, tiny_list);
+    return (int)hipGetLastError();
+}
+
+int hufk_encode_plan_tiny_items(const void *raw_items, uint32_t n_items, struct hufd_enc_item *items, uint32_t *tiny_list, void *stream) {
+    if (n_items == 0) {
+        return 0;
+    }
+    hipLaunchKernelGGL(
+        enc_plan_tiny_items_kernel, dim3((n_items + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+        (const hufd_raw_enc_item *)raw_items, n_items, items, tiny_list);
     return (int)hipGetLastError();
 }
 

@@ -467,18 +467,46 @@ static void enc_plan_release_device(struct aws_huffman_amd_encode_plan *p) {
 }
 
 /* short items with anything to write (symbols or carried bits) are one thread's work, without segments */
+/* fewer items than this: the host's loop over them costs less than an allocation and a launch */
+#define PLAN_ON_DEVICE_MIN_ITEMS 4096u
+
+struct item_stats { /* of a plan's items, from the pass that finds the thread-per-item limit */
+    uint64_t shortest, longest;
+    uint32_t worst_bits; /* largest first_bit (decode) / overflow_in.num_bits (encode) */
+};
+
+/* the caller's records go to the device as they are when every item of a plan is one thread's work: the kernels that
+ * read them there (hufk_*_plan_tiny_items) see these layouts */
+_Static_assert(sizeof(struct aws_huffman_amd_decode_item) == sizeof(struct hufd_raw_dec_item), "decode item layout");
+_Static_assert(offsetof(struct aws_huffman_amd_decode_item, first_bit) == offsetof(struct hufd_raw_dec_item, first_bit), "decode item layout");
+_Static_assert(offsetof(struct aws_huffman_amd_decode_item, out_offset) == offsetof(struct hufd_raw_dec_item, out_offset), "decode item layout");
+_Static_assert(offsetof(struct aws_huffman_amd_decode_item, out_capacity) == offsetof(struct hufd_raw_dec_item, out_capacity), "decode item layout");
+_Static_assert(sizeof(struct aws_huffman_amd_encode_item) == sizeof(struct hufd_raw_enc_item), "encode item layout");
+_Static_assert(offsetof(struct aws_huffman_amd_encode_item, out_capacity) == offsetof(struct hufd_raw_enc_item, out_capacity), "encode item layout");
+_Static_assert(offsetof(struct aws_huffman_amd_encode_item, overflow_in) == offsetof(struct hufd_raw_enc_item, ovf_pattern), "encode item layout");
+_Static_assert(offsetof(struct aws_huffman_amd_encode_item, overflow_in) + offsetof(struct aws_huffman_code, num_bits) ==
+                   offsetof(struct hufd_raw_enc_item, ovf_bits), "encode item layout");
+_Static_assert(offsetof(struct aws_huffman_amd_encode_item, eos_padding) == offsetof(struct hufd_raw_enc_item, eos_padding), "encode item layout");
+
 static bool enc_item_is_tiny(const struct aws_huffman_amd_encode_item *it, uint64_t limit) {
     return it->in_len <= limit && (it->in_len > 0 || it->overflow_in.num_bits);
 }
 
 /* the longest item a lone thread takes in this plan: see HUFD_ENC_TINY_PER_BYTE */
-static uint64_t enc_tiny_limit(const struct aws_huffman_amd_engine *eng, const struct aws_huffman_amd_encode_item *items, size_t n_items) {
+static uint64_t enc_tiny_limit(
+    const struct aws_huffman_amd_engine *eng, const struct aws_huffman_amd_encode_item *items, size_t n_items, struct item_stats *st) {
     /* (the one-pass kernel packs ragged tiles at full speed: measured, a wave beats a thread from about 1 KiB an item) */
     const uint64_t classes[2] = {
         aws_huffman_amd_engine_encodes_in_one_pass(eng) ? HUFD_ENC_TINY_WAVE_BYTES : HUFD_TINY_MANY_BYTES, HUFD_ENC_TINY_BYTES};
     uint64_t count[2] = {0, 0}, longest[2] = {0, 0}; /* (one pass over the items for both classes) */
+    st->shortest = UINT64_MAX;
+    st->longest = 0;
+    st->worst_bits = 0;
     for (size_t i = 0; i < n_items; ++i) {
         const uint64_t len = items[i].in_len;
+        st->shortest = len < st->shortest ? len : st->shortest;
+        st->longest = len > st->longest ? len : st->longest;
+        st->worst_bits = items[i].overflow_in.num_bits > st->worst_bits ? items[i].overflow_in.num_bits : st->worst_bits;
         for (int c = 0; c < 2; ++c) {
             if (len <= classes[c]) {
                 ++count[c];
@@ -502,6 +530,37 @@ static uint64_t enc_item_segments(const struct aws_huffman_amd_encode_item *it, 
 }
 
 /* (Re)fills a plan from host items, growing its device arrays when needed. */
+/* the plan's device arrays for this many items, segments, large and thread-per-item items (grown, never shrunk); 0 or a HIP error */
+static int enc_plan_reserve(struct aws_huffman_amd_encode_plan *p, size_t n_items, size_t n_segs, size_t n_large, size_t n_tiny) {
+    if (n_items > p->cap_items || n_segs > p->cap_segs || n_large > p->cap_large || n_tiny > p->cap_tiny) {
+        enc_plan_release_device(p);
+        const size_t ci = n_items ? n_items : 1, cs = n_segs ? n_segs : 1, cl = n_large ? n_large : 1, ct = n_tiny ? n_tiny : 1;
+        p->d_items = hufs_malloc(ci * sizeof(struct hufd_enc_item));
+        p->d_segs = hufs_malloc(cs * sizeof(struct hufd_enc_seg));
+        p->d_large = hufs_malloc(cl * sizeof(uint32_t));
+        p->d_tiny = hufs_malloc(ct * sizeof(uint32_t));
+        p->d_seg_bits = hufs_malloc(cs * sizeof(uint32_t));
+        p->d_wave_bits = hufs_malloc(cs * 4 * sizeof(uint32_t));
+        p->d_seg_unk = hufs_malloc(cs * sizeof(uint32_t));
+        p->d_seg_bitoff = hufs_malloc(cs * sizeof(uint64_t));
+        p->d_careful = hufs_malloc((2 * ci + cs + 4) * sizeof(uint32_t)); /* the scan lists up to two segments an item, the wave packer any segment it leaves */
+        p->d_zero = hufs_malloc(hufk_encode_zero_bytes((uint32_t)cs, (uint32_t)ci));
+        p->d_unk_seen = hufs_malloc(cs);
+        p->d_item_total = hufs_malloc(ci * sizeof(uint64_t));
+        p->d_states = hufs_malloc(ci * sizeof(struct hufd_enc_item_state));
+        p->d_results = hufs_malloc(ci * sizeof(struct hufd_enc_result));
+        if (!p->d_items || !p->d_segs || !p->d_large || !p->d_tiny || !p->d_seg_bits || !p->d_wave_bits || !p->d_seg_unk || !p->d_seg_bitoff ||
+            !p->d_careful || !p->d_zero || !p->d_unk_seen || !p->d_item_total || !p->d_states || !p->d_results) {
+            return 2;
+        }
+        p->cap_items = ci;
+        p->cap_segs = cs;
+        p->cap_large = cl;
+        p->cap_tiny = ct;
+    }
+    return 0;
+}
+
 static int enc_plan_fill(
     struct aws_huffman_amd_encode_plan *p,
     const struct aws_huffman_amd_encode_item *items,
@@ -511,7 +570,36 @@ static int enc_plan_fill(
     if (!eng->can_encode) {
         return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION); /* a coder without an encode callback: good for decoding only */
     }
-    const uint64_t tiny_limit = enc_tiny_limit(eng, items, n_items);
+    struct item_stats stats;
+    const uint64_t tiny_limit = enc_tiny_limit(eng, items, n_items, &stats);
+    if (n_items >= PLAN_ON_DEVICE_MIN_ITEMS && n_items < 0xFFFFFFFFull && stats.shortest >= 1 && stats.longest <= tiny_limit &&
+        stats.worst_bits <= 32) {
+        /* every item is one thread's work (enc_item_is_tiny): no segments, no lists to make -- the caller's records go to the
+         * device as they are and become the kernels' there (hufk_encode_plan_tiny_items) */
+        ON_DEVICE(eng->device);
+        int e = enc_plan_reserve(p, n_items, 0, 0, n_items);
+        void *d_raw = e ? NULL : hufs_malloc(n_items * sizeof(*items));
+        if (!e && !d_raw) {
+            e = 2;
+        }
+        if (!e) {
+            e = hufs_copy_h2d(d_raw, items, n_items * sizeof(*items), eng->stream);
+        }
+        if (!e) {
+            e = hufk_encode_plan_tiny_items(d_raw, (uint32_t)n_items, p->d_items, p->d_tiny, eng->stream);
+        }
+        if (!e) {
+            e = hufs_stream_sync(eng->stream);
+        }
+        hufs_free(d_raw);
+        p->n_items = p->n_segs = p->n_large = p->n_tiny = 0;
+        if (e) {
+            return raise_hip(e);
+        }
+        p->n_items = (uint32_t)n_items;
+        p->n_tiny = (uint32_t)n_items;
+        return AWS_OP_SUCCESS;
+    }
     uint64_t n_segs = 0, n_large = 0, n_tiny = 0;
     for (size_t i = 0; i < n_items; ++i) {
         if (items[i].overflow_in.num_bits > 32) {
@@ -576,32 +664,7 @@ static int enc_plan_fill(
 
     int err = 0;
     ON_DEVICE(eng->device);
-    if (n_items > p->cap_items || n_segs > p->cap_segs || n_large > p->cap_large || n_tiny > p->cap_tiny) {
-        enc_plan_release_device(p);
-        const size_t ci = n_items ? n_items : 1, cs = n_segs ? n_segs : 1, cl = n_large ? n_large : 1, ct = n_tiny ? n_tiny : 1;
-        p->d_items = hufs_malloc(ci * sizeof(struct hufd_enc_item));
-        p->d_segs = hufs_malloc(cs * sizeof(struct hufd_enc_seg));
-        p->d_large = hufs_malloc(cl * sizeof(uint32_t));
-        p->d_tiny = hufs_malloc(ct * sizeof(uint32_t));
-        p->d_seg_bits = hufs_malloc(cs * sizeof(uint32_t));
-        p->d_wave_bits = hufs_malloc(cs * 4 * sizeof(uint32_t));
-        p->d_seg_unk = hufs_malloc(cs * sizeof(uint32_t));
-        p->d_seg_bitoff = hufs_malloc(cs * sizeof(uint64_t));
-        p->d_careful = hufs_malloc((2 * ci + cs + 4) * sizeof(uint32_t)); /* the scan lists up to two segments an item, the wave packer any segment it leaves */
-        p->d_zero = hufs_malloc(hufk_encode_zero_bytes((uint32_t)cs, (uint32_t)ci));
-        p->d_unk_seen = hufs_malloc(cs);
-        p->d_item_total = hufs_malloc(ci * sizeof(uint64_t));
-        p->d_states = hufs_malloc(ci * sizeof(struct hufd_enc_item_state));
-        p->d_results = hufs_malloc(ci * sizeof(struct hufd_enc_result));
-        if (!p->d_items || !p->d_segs || !p->d_large || !p->d_tiny || !p->d_seg_bits || !p->d_wave_bits || !p->d_seg_unk || !p->d_seg_bitoff ||
-            !p->d_careful || !p->d_zero || !p->d_unk_seen || !p->d_item_total || !p->d_states || !p->d_results) {
-            err = 2;
-        }
-        p->cap_items = ci;
-        p->cap_segs = cs;
-        p->cap_large = cl;
-        p->cap_tiny = ct;
-    }
+    err = enc_plan_reserve(p, n_items, n_segs, n_large, n_tiny);
     if (!err) {
         err = hufs_copy_h2d(p->d_items, h_items, n_items * sizeof(*h_items), eng->stream);
     }
@@ -888,12 +951,18 @@ static bool dec_item_is_tiny(const struct aws_huffman_amd_decode_item *it, uint6
 }
 
 /* the longest item a lone thread takes in this plan: see HUFD_DEC_TINY_PER_BYTE */
-static uint64_t dec_tiny_limit(const struct aws_huffman_amd_decode_item *items, size_t n_items) {
+static uint64_t dec_tiny_limit(const struct aws_huffman_amd_decode_item *items, size_t n_items, struct item_stats *st) {
     static const uint64_t classes[2] = {HUFD_TINY_MANY_BYTES * 3 / 2, HUFD_DEC_TINY_BYTES};
     /* (one pass over the items for both classes: a plan of a million header-sized items is read from memory once here) */
     uint64_t count[2] = {0, 0}, longest[2] = {0, 0};
+    st->shortest = UINT64_MAX;
+    st->longest = 0;
+    st->worst_bits = 0;
     for (size_t i = 0; i < n_items; ++i) {
         const uint64_t len = items[i].in_len;
+        st->shortest = len < st->shortest ? len : st->shortest;
+        st->longest = len > st->longest ? len : st->longest;
+        st->worst_bits = items[i].first_bit > st->worst_bits ? items[i].first_bit : st->worst_bits;
         for (int c = 0; c < 2; ++c) {
             if (len <= classes[c]) {
                 ++count[c];
@@ -956,6 +1025,49 @@ static uint64_t dec_item_tiles(uint64_t chunks, uint64_t in_len) {
     return subs == 0 ? 0 : (subs <= HUFD_TILE_LANES ? 1 : 1 + (subs - HUFD_TILE_LANES + HUFD_TILE_LANES - 2) / (HUFD_TILE_LANES - 1));
 }
 
+/* the plan's device arrays for this many items, chunks, large items and runs (grown, never shrunk); 0 or a HIP error */
+static int dec_plan_reserve(struct aws_huffman_amd_decode_plan *p, size_t n_items, size_t n_chunks, size_t n_large, size_t n_runs) {
+    const uint32_t ns = p->engine->tables.n_states;
+    if (n_items > p->cap_items || n_chunks > p->cap_chunks || n_large > p->cap_large || n_runs > p->cap_runs) {
+        dec_plan_release_device(p);
+        const size_t ci = n_items ? n_items : 1, cc = n_chunks ? n_chunks : 1, cl = n_large ? n_large : 1;
+        const size_t cr = n_runs ? n_runs : 1;
+        p->d_items = hufs_malloc(ci * sizeof(struct hufd_dec_item));
+        p->d_chunk_item = hufs_malloc(cc * sizeof(uint32_t));
+        p->d_tail = hufs_malloc(ci * 2 * sizeof(uint32_t));
+        p->d_tiny = hufs_malloc(ci * sizeof(uint32_t));
+        p->d_large = hufs_malloc(cl * 2 * sizeof(uint32_t));
+        p->d_runs = hufs_malloc(cr * 2 * sizeof(uint32_t));
+        p->d_run_fn = hufs_malloc(cr * ns * sizeof(uint32_t));
+        p->d_run_entry = hufs_malloc(cr * sizeof(uint32_t));
+        p->d_run_base = hufs_malloc(cr * sizeof(uint64_t));
+        p->d_fn_tab = hufs_malloc(cc * ns * HUFD_DEC_LANES * sizeof(uint16_t));
+        p->d_cp_tab = hufs_malloc(cc * HUFD_DEC_CP_ROWS * HUFD_DEC_LANES * sizeof(uint16_t));
+        p->d_chunk_fn = hufs_malloc(cc * ns * sizeof(uint32_t));
+        p->d_slow_list = hufs_malloc((cc + 1) * sizeof(uint32_t)); /* [0] count, [1..] chunks */
+        p->d_emit_list = hufs_malloc((cc + 1) * sizeof(uint32_t));
+        p->d_dense_list = hufs_malloc((cc + 1) * sizeof(uint32_t));
+        p->d_lane_count = hufs_malloc(cc * HUFD_DEC_LANES * sizeof(uint16_t));
+        p->d_chunk_regular = hufs_malloc(cc);
+        p->d_tail_entry = hufs_malloc(cc * sizeof(uint32_t));
+        p->d_chunk_entry = hufs_malloc(cc * sizeof(uint32_t));
+        p->d_chunk_base = hufs_malloc(cc * sizeof(uint64_t));
+        p->d_chunk_rec = hufs_malloc(cc * sizeof(struct hufd_chunk_rec));
+        p->d_states = hufs_malloc(ci * sizeof(struct hufd_dec_item_state));
+        p->d_results = hufs_malloc(ci * sizeof(struct hufd_dec_result));
+        if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_cp_tab || !p->d_chunk_fn || !p->d_slow_list || !p->d_chunk_entry ||
+            !p->d_tail || !p->d_tiny || !p->d_dense_list || !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_tail_entry || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
+            !p->d_chunk_base || !p->d_chunk_rec || !p->d_states || !p->d_results) {
+            return 2;
+        }
+        p->cap_items = ci;
+        p->cap_chunks = cc;
+        p->cap_large = cl;
+        p->cap_runs = cr;
+    }
+    return 0;
+}
+
 static int dec_plan_fill(
     struct aws_huffman_amd_decode_plan *p,
     const struct aws_huffman_amd_decode_item *items,
@@ -965,7 +1077,46 @@ static int dec_plan_fill(
     if (!eng->can_decode) {
         return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION);
     }
-    const uint64_t tiny_limit = dec_tiny_limit(items, n_items);
+    struct item_stats stats;
+    const uint64_t tiny_limit = dec_tiny_limit(items, n_items, &stats);
+    /* a failed refill must not leave counts of the fill before behind (the device arrays may be gone or too small) */
+    p->n_items = p->n_chunks = p->n_large = p->n_runs = p->n_tail = p->n_tiles = p->n_fixed = p->n_wide = 0;
+    p->n_tiny = p->n_deep = 0;
+    if (n_items >= PLAN_ON_DEVICE_MIN_ITEMS && n_items < 0xFFFFFFFFull && stats.shortest >= 1 && stats.longest <= tiny_limit &&
+        stats.worst_bits <= 7) {
+        /* every item is one thread's work (dec_item_is_tiny): no chunks, no lists to make -- the caller's records go to the
+         * device as they are and become the kernels' there (hufk_decode_plan_tiny_items) */
+        ON_DEVICE(eng->device);
+        int e = dec_plan_reserve(p, n_items, 0, 0, 0);
+        void *d_raw = e ? NULL : hufs_malloc(n_items * sizeof(*items));
+        if (!e && !d_raw) {
+            e = 2;
+        }
+        if (!e) {
+            e = hufs_copy_h2d(d_raw, items, n_items * sizeof(*items), eng->stream);
+        }
+        if (!e) {
+            e = hufk_decode_plan_tiny_items(d_raw, (uint32_t)n_items, p->d_items, p->d_tiny, eng->stream);
+        }
+        struct aws_huffman_amd_decode_item *keep = e ? NULL : realloc(p->h_items, n_items * sizeof(*keep));
+        if (!e && !keep) {
+            e = 2;
+        }
+        if (!e) {
+            memcpy(keep, items, n_items * sizeof(*keep)); /* (while the copy and the kernel run) */
+            p->h_items = keep;
+            e = hufs_stream_sync(eng->stream);
+        }
+        hufs_free(d_raw);
+        if (e) {
+            return raise_hip(e);
+        }
+        p->wide_from = wide_min_bytes(0);
+        p->tail_stage_bytes = 0;
+        p->n_items = (uint32_t)n_items;
+        p->n_tiny = (uint32_t)n_items;
+        return AWS_OP_SUCCESS;
+    }
     /* dec_onepass's tile records only where that kernel is asked for (AWS_HUFFMAN_AMD_DECODE=one-pass, one-pass-fails) and
      * applies to the coder: three records per 16 KiB item that the default road never reads were the largest part of
      * what a plan cost to make */
@@ -975,9 +1126,6 @@ static int dec_plan_fill(
         want_tiles = mode && (strcmp(mode, "one-pass") == 0 || strcmp(mode, "one-pass-fails") == 0) &&
                      hufk_decode_one_pass_applies(&eng->tables);
     }
-    /* a failed refill must not leave counts of the fill before behind (the device arrays may be gone or too small) */
-    p->n_items = p->n_chunks = p->n_large = p->n_runs = p->n_tail = p->n_tiles = p->n_fixed = p->n_wide = 0;
-    p->n_tiny = p->n_deep = 0;
     uint64_t n_chunks = 0, n_large = 0, n_runs = 0, n_tiles = 0;
     for (size_t i = 0; i < n_items; ++i) {
         /* symbol counts in the scan's function entries are 26-bit; 4 GiB of encoded bytes per item is the limit */
@@ -1113,7 +1261,6 @@ static int dec_plan_fill(
     }
 
     int err = wide_oom ? 2 : 0;
-    const uint32_t ns = eng->tables.n_states;
     ON_DEVICE(eng->device);
     for (uint32_t k = 0; k < n_wide; ++k) {
         h_wide[k].slot = deep - h_wide[k].slot; /* the deep items are the last `deep` of d_tiny, filled from the back */
@@ -1140,42 +1287,8 @@ static int dec_plan_fill(
         p->cap_wide_block = p->d_wide_block ? wide_bytes : 0;
         err = p->d_wide_block ? 0 : 2;
     }
-    if (n_items > p->cap_items || n_chunks > p->cap_chunks || n_large > p->cap_large || n_runs > p->cap_runs) {
-        dec_plan_release_device(p);
-        const size_t ci = n_items ? n_items : 1, cc = n_chunks ? n_chunks : 1, cl = n_large ? n_large : 1;
-        const size_t cr = n_runs ? n_runs : 1;
-        p->d_items = hufs_malloc(ci * sizeof(struct hufd_dec_item));
-        p->d_chunk_item = hufs_malloc(cc * sizeof(uint32_t));
-        p->d_tail = hufs_malloc(ci * 2 * sizeof(uint32_t));
-        p->d_tiny = hufs_malloc(ci * sizeof(uint32_t));
-        p->d_large = hufs_malloc(cl * 2 * sizeof(uint32_t));
-        p->d_runs = hufs_malloc(cr * 2 * sizeof(uint32_t));
-        p->d_run_fn = hufs_malloc(cr * ns * sizeof(uint32_t));
-        p->d_run_entry = hufs_malloc(cr * sizeof(uint32_t));
-        p->d_run_base = hufs_malloc(cr * sizeof(uint64_t));
-        p->d_fn_tab = hufs_malloc(cc * ns * HUFD_DEC_LANES * sizeof(uint16_t));
-        p->d_cp_tab = hufs_malloc(cc * HUFD_DEC_CP_ROWS * HUFD_DEC_LANES * sizeof(uint16_t));
-        p->d_chunk_fn = hufs_malloc(cc * ns * sizeof(uint32_t));
-        p->d_slow_list = hufs_malloc((cc + 1) * sizeof(uint32_t)); /* [0] count, [1..] chunks */
-        p->d_emit_list = hufs_malloc((cc + 1) * sizeof(uint32_t));
-        p->d_dense_list = hufs_malloc((cc + 1) * sizeof(uint32_t));
-        p->d_lane_count = hufs_malloc(cc * HUFD_DEC_LANES * sizeof(uint16_t));
-        p->d_chunk_regular = hufs_malloc(cc);
-        p->d_tail_entry = hufs_malloc(cc * sizeof(uint32_t));
-        p->d_chunk_entry = hufs_malloc(cc * sizeof(uint32_t));
-        p->d_chunk_base = hufs_malloc(cc * sizeof(uint64_t));
-        p->d_chunk_rec = hufs_malloc(cc * sizeof(struct hufd_chunk_rec));
-        p->d_states = hufs_malloc(ci * sizeof(struct hufd_dec_item_state));
-        p->d_results = hufs_malloc(ci * sizeof(struct hufd_dec_result));
-        if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_cp_tab || !p->d_chunk_fn || !p->d_slow_list || !p->d_chunk_entry ||
-            !p->d_tail || !p->d_tiny || !p->d_dense_list || !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_tail_entry || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
-            !p->d_chunk_base || !p->d_chunk_rec || !p->d_states || !p->d_results) {
-            err = 2;
-        }
-        p->cap_items = ci;
-        p->cap_chunks = cc;
-        p->cap_large = cl;
-        p->cap_runs = cr;
+    if (!err) {
+        err = dec_plan_reserve(p, n_items, n_chunks, n_large, n_runs);
     }
     {
         const size_t zero_bytes = (size_t)hufk_decode_zero_bytes((uint32_t)n_tiles, (uint32_t)n_items);

@@ -753,6 +753,71 @@ def null_empty_cursors(w, seed=91):
             paired_decode(w, ddo, ddp, enc, enc.size, enc.size, oo, op, length, n + 8, null_when_empty=True)
 
 
+# ----------------------------------------------------------------------------- scenario: plans made on the device
+def many_header_sized_items(w, n_items=6000, seed=97, engine=None):
+    """A batch in which EVERY item is one thread's work (header-sized strings, 1..90 symbols, none empty) and that has
+    at least PLAN_ON_DEVICE_MIN_ITEMS (4096) of them: the plan is then made on the device from the caller's records as
+    they are (csrc/host/engine.c, hufk_*_plan_tiny_items).  Encode -- some items with carried overflow bits, some with
+    too little room -- and decode of the results, every record and every byte against the oracle's call for that item."""
+    rng = np.random.default_rng(seed)
+    eng = engine or harness.Engine(w.product.lib, w.pcoder)
+    lens = rng.integers(1, 91, n_items)
+    plains = [inputs(rng, int(n), KINDS[i % 3]) for i, n in enumerate(lens)]
+    in_offs = np.concatenate([[3], 3 + np.cumsum(lens[:-1] + rng.integers(0, 3, n_items - 1))]).astype(np.int64)
+    blob = np.full(int(in_offs[-1] + lens[-1]) + 64, 0xC3, np.uint8)
+    for pl, o in zip(plains, in_offs):
+        blob[o:o + pl.size] = pl
+    caps = [int(2 * n + 8) if i % 7 else int(rng.integers(0, n + 1)) for i, n in enumerate(lens)]  # every seventh: short
+    out_offs = np.concatenate([[1], 1 + np.cumsum(np.array(caps[:-1]) + 5)]).astype(np.int64)
+    out_total = int(out_offs[-1] + caps[-1]) + 64
+    carried = []  # (pattern, bits) as an encoder that ran out of room leaves them: nothing above the bits
+    for i in range(n_items):
+        bits = int(rng.integers(1, 10)) if i % 5 == 0 else 0
+        carried.append((int(rng.integers(0, 1 << bits)) if bits else 0, bits))
+    d_in, d_out = eng.alloc(blob.size), eng.alloc(out_total)
+    eng.upload(d_in, blob)
+    eng.fill(d_out, SENTINEL, out_total)
+    plan = eng.encode_plan([dict(in_offset=int(in_offs[i]), in_len=int(lens[i]), out_offset=int(out_offs[i]), out_capacity=caps[i],
+                                 overflow_in=carried[i], eos_padding=0x5F) for i in range(n_items)])
+    eng.encode_launch(plan, d_in, d_out)
+    got = eng.encode_results(plan, n_items)
+    back = eng.download(d_out, out_total)
+    enc_streams = []
+    for i in range(n_items):
+        eo = w.oracle.new_encoder(w.ocoder, eos_padding=0x5F)
+        eo.overflow_bits.pattern, eo.overflow_bits.num_bits = carried[i]
+        dst = np.full(caps[i] + 4, SENTINEL, np.uint8)
+        r = w.oracle.encode_call(eo, plains[i], 0, dst, 0, caps[i])
+        assert got[i][:4] == (r.rc, r.err, r.consumed, r.produced) and (got[i][4], got[i][5] if got[i][4] else 0) == r.state, (i, got[i], r)
+        assert np.array_equal(back[out_offs[i]:out_offs[i] + caps[i] + 4], dst), i
+        enc_streams.append(dst[:r.produced].copy())
+    eng.lib.aws_huffman_amd_encode_plan_destroy(plan)
+    # decode what was produced (whole streams, cut ones where the room ran out, empty ones left out: every item non-empty)
+    keep = [i for i in range(n_items) if enc_streams[i].size]
+    assert len(keep) >= 4096
+    sym_caps = [int(lens[i]) if i % 3 else int(rng.integers(0, lens[i] + 1)) for i in keep]
+    sym_offs = np.concatenate([[2], 2 + np.cumsum(np.array(sym_caps[:-1]) + 3)]).astype(np.int64)
+    sym_total = int(sym_offs[-1] + sym_caps[-1]) + 64
+    d_back = eng.alloc(sym_total)
+    eng.fill(d_back, SENTINEL, sym_total)
+    dplan = eng.decode_plan([dict(in_offset=int(out_offs[i]), in_len=int(enc_streams[i].size), out_offset=int(sym_offs[k]),
+                                  out_capacity=sym_caps[k]) for k, i in enumerate(keep)])
+    eng.decode_launch(dplan, d_out, d_back)
+    dres = eng.decode_results(dplan, len(keep))
+    dback = eng.download(d_back, sym_total)
+    for k, i in enumerate(keep):
+        dd = w.oracle.new_decoder(w.ocoder)
+        want = np.full(sym_caps[k] + 3, SENTINEL, np.uint8)
+        r = w.oracle.decode_call(dd, enc_streams[i], 0, enc_streams[i].size, want, 0, sym_caps[k])
+        assert dres[k][:3] == (r.rc, r.err, r.produced), (k, i, dres[k], r)
+        assert np.array_equal(dback[sym_offs[k]:sym_offs[k] + sym_caps[k] + 3], want), (k, i)
+    eng.lib.aws_huffman_amd_decode_plan_destroy(dplan)
+    for ptr in (d_in, d_out, d_back):
+        eng.free(ptr)
+    if engine is None:
+        eng.close()
+
+
 # ----------------------------------------------------------------------------- scenario: padding byte values
 def eos_padding_values(w):
     rng = np.random.default_rng(16)

@@ -92,6 +92,10 @@ def test_null_empty_cursors(world):
     pc.null_empty_cursors(world)
 
 
+def test_many_header_sized_items(world):
+    pc.many_header_sized_items(world)
+
+
 def test_survey_records(world):
     pc.survey_records_on_product(world, names=("G4K", "G16K", "G16KP", "G1M"))
 
