@@ -91,6 +91,9 @@ struct hufk_decode_args {
     uint32_t *dense_count; /* [1] */
     uint16_t *lane_count;  /* [n_chunks][HUFD_DEC_LANES] scratch */
     uint8_t *chunk_regular; /* [n_chunks] scratch */
+    uint8_t *chunk_flags;   /* [2 * n_chunks] scratch of dec_sync_resident: chunk_bad, then chunk_one0 (zeroed by the launch) */
+    const uint32_t *item_first_tile; /* [n_items + 1] dec_sync_resident's tiles of the items in front (built with the plan) */
+    uint32_t n_res_tiles;            /* = item_first_tile[n_items] */
     uint32_t *tail_entry;   /* [n_chunks] scratch: state in which the last whole lane of an end-of-stream chunk leaves */
     uint32_t *chunk_entry; /* [n_chunks] scratch */
     uint64_t *chunk_base;  /* [n_chunks] scratch */
@@ -103,7 +106,8 @@ struct hufk_decode_args {
     uint32_t tail_stage_bytes; /* the most symbols a chunk that holds the end of a stream can decode to, +32 (0: unknown) */
     uint32_t old_sync; /* 0: dec_sync_lean for the chunks it takes (the default); 1: dec_sync_fast for every chunk
                         * (AWS_HUFFMAN_AMD_DECODE=old-sync); 2: as 0 (=lean-sync); 3: dec_sync_bank where the decode table has up
-                        * to 10 bits (=bank-sync: a length table per LDS bank, measured slower) */
+                        * to 10 bits (=bank-sync: a length table per LDS bank, measured slower); 4: dec_sync_resident for the chunks inside
+                        * streams of such a coder (=resident-sync: resident waves, the table once per bank; measured slower too) */
     void **stage_events; /* NULL, or 4 hipEvent_t: before sync, after sync, after scan, after emit */
     const struct hufd_tile_rec *tiles; /* [n_tiles] dec_onepass (the chunks inside streams in one pass): built with the plan */
     uint32_t n_tiles;

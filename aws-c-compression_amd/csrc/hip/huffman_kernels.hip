@@ -6922,6 +6922,311 @@ __global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
     FUSE_STAMP_FLUSH;
 }
 
+/* ------------------------------------------------------------------ decode: sync, chunks inside streams, resident waves and a walk table per LDS bank */
+
+/*
+ * What bounds dec_sync_lean is the LDS: 32 lanes' look-ups in ONE table land on the 32 banks at random, ~3.4 on the
+ * fullest, and the CU's four SIMDs get a step per ~24 cycles each however many waves there are
+ * (profiles/r04_micro/probe_walk.jsonl).  A table copy per bank never collides -- but with dword entries on a 10-bit
+ * window it is 128 KiB, ONE workgroup a CU; and workgroups of 1024 threads that take chunks the way dec_sync_lean does
+ * (three barriers a chunk, table filled per workgroup) lose more than the look-ups win (dec_sync_bank, above).  So here:
+ *
+ *   - one RESIDENT workgroup of 16 waves per CU fills the 128 KiB table once (entry of window w for bank b at byte
+ *     w << 7 | b << 2: the address is (window bits as they stand) | bank, one instruction as in dec_sync_lean);
+ *   - its waves are on their own from then on: a wave takes TILES of 64 neighbouring sub-chunks of one item in turn
+ *     (tile k = sub-chunks 63 k .. 63 k + 63: lane 0 of every tile but an item's first walks the last sub-chunk of the
+ *     tile in front again, only to learn how it is left -- dec_onepass's tiles), so that a lane's entry state comes from
+ *     its neighbour lane by a wave shift and nothing ever waits for another wave: no barrier after the table;
+ *   - what is per CHUNK (its function for dec_scan, whether it is regular) is put together by dec_sync_resident_finish
+ *     from what the lanes left per sub-chunk.
+ *
+ * Same phases U, R, H per lane and the same records per sub-chunk as dec_sync_lean; the chunks streams END in keep
+ * dec_sync_lean<TAIL>.  Coders whose decode table has more than 10 bits keep dec_sync_lean (4096 rows do not fit).
+ */
+constexpr u32 kResLB = 10;
+constexpr u32 kResWinPos = 7; /* the window's lowest bit in the shifted pair: the window IS address bits 7..16, the row of its entry */
+constexpr u32 kResThreads = 1024;
+constexpr u32 kResWaves = kResThreads / kWave;
+constexpr u32 kResTableBytes = (1u << kResLB) * 128u;
+constexpr u32 kResMinTiles = 2048; /* fewer tiles (16 MiB of stream) do not fill the chip's resident waves: the chunk kernels take the launch */
+
+struct resident_shared {
+    u32 wlut[(1u << kResLB) * 32]; /* word w * 32 + b: 0x10000 - length of window w (48: no code), read by the lanes with lane % 32 == b */
+    u16 hops[1u << kResLB];        /* 1 << code length of a window, 0 = no code: phase U's (one copy: phase U is a fifth of the look-ups) */
+};
+
+template <u32 SURE>
+__global__ __launch_bounds__(kResThreads, 4) void dec_sync_resident_kernel(
+    hufd_tables tb,
+    const hufd_dec_item *items,
+    u32 n_items,
+    const u32 *item_first_tile, /* [n_items + 1] tiles of the items in front; [n_items] = all tiles */
+    const u8 *d_in,
+    u16 *fn_tab,
+    u16 *cp_tab,
+    u16 *lane_count,
+    u8 *chunk_bad,  /* [chunk] zeroed: set where a sub-chunk of the chunk is not regular by this kernel's rules */
+    u8 *chunk_one0 /* [chunk] zeroed: set where sub-chunk 0's own walks have met (what dec_sync_guess needs of a chunk) */) {
+
+    resident_shared &sh = *reinterpret_cast<resident_shared *>(dyn_lds);
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const u32 ns = tb.n_states;
+    const row_walk rw(kResLB, tb.max_bits, kResWinPos);
+    const u32 table_at = lds_offset_of(sh.wlut);
+    const bool coder_ok = tb.lut_bits <= kResLB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS && rw.sure == SURE && tb.bank_rows &&
+                          (table_at & (kResTableBytes - 1u)) == 0;
+    const u32 n_tiles = item_first_tile[n_items];
+    if (!coder_ok) { /* (the same for the whole launch, which the host does not make for such a coder: every chunk the long way) */
+        for (u32 i = blockIdx.x * kResThreads + tid; i < n_items; i += gridDim.x * kResThreads) {
+            const hufd_dec_item it = items[i];
+            const u32 inside = it.n_chunks && it.in_len >= 8 ? (u32)((it.in_len - 8) / HUFD_DEC_CHUNK_BYTES) : 0u;
+            for (u32 c = 0; c < (inside < it.n_chunks ? inside : it.n_chunks); ++c) {
+                chunk_bad[it.first_chunk + c] = 1;
+            }
+        }
+        return;
+    }
+    /* the table: a thread writes its bank's copy of 32 rows (bank_rows holds the length bytes, four windows a dword) */
+    {
+        const u32 bank = tid & 31u, first = tid / 32 * 32; /* rows first .. first + 31 */
+#pragma unroll 4
+        for (u32 j = 0; j < 8; ++j) {
+            const u32 four = tb.bank_rows[first / 4 + j];
+#pragma unroll
+            for (u32 i = 0; i < 4; ++i) {
+                const u32 len = 256u - ((four >> (8 * i)) & 0xFFu); /* (bank_rows: 256 - length) */
+                sh.wlut[(first + 4 * j + i) * 32 + bank] = 0x10000u - len;
+            }
+        }
+        const u32 own = tb.dec_lut[tid >> (kResLB - tb.lut_bits)] & 0xFFu;
+        sh.hops[tid] = (u16)(own ? 1u << own : 0u);
+    }
+    __syncthreads();
+    const u32 table = table_at | ((lane & 31u) << 2);
+
+    const u32 stride = gridDim.x * kResWaves;
+    u32 item_lo = 0; /* (tiles come in rising order for a wave: the search for a tile's item starts at the last one's) */
+    for (u32 T = blockIdx.x * kResWaves + wave; T < n_tiles; T += stride) {
+        /* the tile's item: the last one whose first tile is not behind T */
+        u32 lo = item_lo, hi = n_items;
+        while (hi - lo > 1) {
+            const u32 mid = lo + (hi - lo) / 2;
+            if (item_first_tile[mid] <= T) {
+                lo = mid;
+            } else {
+                hi = mid;
+            }
+        }
+        item_lo = lo;
+        const hufd_dec_item it = items[lo];
+        const u32 k = T - item_first_tile[lo];
+        const u32 inside_chunks = (u32)((it.in_len - 8) / HUFD_DEC_CHUNK_BYTES) < it.n_chunks ? (u32)((it.in_len - 8) / HUFD_DEC_CHUNK_BYTES) : it.n_chunks;
+        const u32 subs = inside_chunks * HUFD_DEC_LANES;
+        const u32 first_sub = k * (kWave - 1);
+        const u32 n_lanes = subs - first_sub < kWave ? subs - first_sub : kWave;
+        const bool active = lane < n_lanes;
+        const bool payload = active && (k == 0 || lane != 0); /* lane 0 of a later tile: walked again for its exit only */
+        const u32 g = first_sub + (active ? lane : 0u);      /* my sub-chunk of the item */
+        const u32 c = it.first_chunk + g / HUFD_DEC_LANES, cl = g % HUFD_DEC_LANES; /* its chunk, its lane there */
+        const u8 *src = d_in + it.in_off + (u64)g * HUFD_DEC_SUB_BYTES;
+        u32 w[kFastRows];
+        {
+            const unaligned_uint4 *line = reinterpret_cast<const unaligned_uint4 *>(src);
+#pragma unroll
+            for (u32 q = 0; q < kSubWords / 4; ++q) {
+                const unaligned_uint4 v = line[q];
+                w[4 * q + 0] = v.x;
+                w[4 * q + 1] = v.y;
+                w[4 * q + 2] = v.z;
+                w[4 * q + 3] = v.w;
+            }
+            w[kSubWords] = reinterpret_cast<const unaligned_u32 *>(src + HUFD_DEC_SUB_BYTES)->x;
+        }
+#pragma unroll
+        for (u32 r = 0; r < kFastRows; ++r) {
+            w[r] = __builtin_bswap32(w[r]);
+        }
+
+        /* U: all entry states as one mask of heads per row, until every lane of the wave is down to one */
+        u64 heads = active ? (1ull << ns) - 1ull : 0ull;
+        u32 meet_row = 0; /* the same for the whole wave */
+        bool one = false, settled = false;
+#pragma unroll
+        for (u32 r = 0; r < kFastMaxMeet; ++r) {
+            if (!settled) {
+                heads = r == 0 ? union_first_row<kResLB>(ns, active, w[0], w[1], sh.hops) : union_row_fast<kResLB>(heads, w[r], w[r + 1], sh.hops);
+                one = heads != 0 && (heads & (heads - 1)) == 0;
+                meet_row = r + 1;
+                settled = __all(one || heads == 0);
+            }
+        }
+        const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
+        bool ok = !active || (one && settled);
+
+        /* R: the one walk from the meeting bit to the end of the sub-chunk */
+        u32 state = rw.state_at(meet_bit, 0);
+        u32 cp_state[kQuarters - 1] = {0, 0, 0};
+        bool dead = false;
+#pragma unroll
+        for (u32 r = 1; r < kSubWords; ++r) {
+            if (r >= meet_row) {
+                if (r % (kSubWords / kQuarters) == 0) {
+                    cp_state[r / (kSubWords / kQuarters) - 1] = state;
+                }
+                state = lean_row<SURE>(state, w[r], w[r + 1], table, rw);
+                dead = dead || rw.died(state);
+                state += 32u; /* (a walk that has died drifts: the chunk is not regular then and nothing of this is kept) */
+            }
+        }
+        const u32 ref_count = state >> 16; /* symbols from the meeting bit to the end of the sub-chunk */
+        const u32 ref_exit = rw.offset_of(state);
+        ok = ok && (!active || (!dead && ref_exit < ns));
+
+        /* H: my own sub-chunk from my true entry state -- how the lane in front leaves -- to the meeting bit */
+        const u32 front_exit = wave_from_front(ref_exit);
+        const bool front_ok = wave_from_front((u32)ok) != 0;
+        const u32 entry = lane ? front_exit : 0u;
+        u32 count;
+        u32 head_cp = 0; /* the head walk where it enters the second quarter, when the meeting row lies behind that */
+        const bool late = meet_row > kSubWords / kQuarters;
+        {
+            u32 st = rw.state_at(entry < ns ? entry : 0u, 0);
+            bool dd = false;
+#pragma unroll
+            for (u32 r = 0; r < kFastMaxMeet; ++r) {
+                if (r < meet_row) {
+                    if (r == kSubWords / kQuarters) {
+                        head_cp = st;
+                    }
+                    st = lean_row<SURE>(st, w[r], w[r + 1], table, rw);
+                    dd = dd || rw.died(st);
+                    st += 32u;
+                }
+            }
+            const bool reached = !dd && rw.offset_of(st) == meet_bit;
+            /* (a chunk's sub-chunk 0 is entered the way dec_scan finds out: its candidates below, not its neighbour) */
+            ok = ok && (!payload || cl == 0 || (reached && front_ok && entry < ns));
+            count = active ? (st >> 16) + ref_count : 0u; /* symbols of the true path that start in my sub-chunk (lanes of a chunk >= 1) */
+        }
+
+        /* H: a chunk's sub-chunk 0 from every entry state the chunk may be entered in (lanes 0 .. ns-1 of the wave, on the
+         * owner lane's words), step by step: the count of a walk that dies has to be right.  At most one chunk starts in a tile. */
+        const u64 owners = __ballot(payload && cl == 0);
+        if (owners) {
+            const u32 owner = (u32)__builtin_ctzll(owners);
+            const u32 target = wave_read(meet_bit, owner), tail0 = wave_read(ref_count, owner), first_exit = wave_read(ref_exit, owner);
+            const u32 oc = wave_read(c, owner);
+            const bool owner_one = wave_read((u32)one, owner) != 0;
+            u32 st = rw.state_at(lane < ns ? lane : 0u, 0);
+            bool dd = false;
+            u32 cand_dead = 0;
+            u32 hi = wave_read(w[0], owner);
+#pragma unroll
+            for (u32 r = 0; r < kFastMaxMeet; ++r) {
+                if (r < meet_row) {
+                    const u32 lo_w = wave_read(w[r + 1], owner);
+                    st = lean_row<SURE, true>(st, hi, lo_w, table, rw);
+                    const bool now = rw.died(st) && !dd;
+                    cand_dead = now ? (st >> 16) - 1u : cand_dead; /* the step that found no code is not a symbol */
+                    dd = dd || now;
+                    st = rw.next_row(st, dd);
+                    hi = lo_w;
+                }
+            }
+            const bool cand_reached = !dd && lane < ns && rw.offset_of(st) == target;
+            const u64 cand_alive = __ballot(cand_reached);
+            const u32 cand_count = (st >> 16) + tail0;
+            if (lane < ns) {
+                fn_tab[((u64)oc * ns + lane) * HUFD_DEC_LANES] =
+                    cand_reached ? fn_pack(false, first_exit, cand_count & 0x7FFu) : fn_pack(true, 0, cand_dead);
+            }
+            if (lane == owner) {
+                chunk_one0[oc] = owner_one ? 1 : 0;
+                /* (the owner's own row of merged states: which entry states of the chunk reach the meeting bit) */
+                cp_tab[(u64)oc * kCpRows * HUFD_DEC_LANES + (kQuarters - 1) * HUFD_DEC_LANES] = (u16)((u32)cand_alive | (ref_exit << 12));
+            }
+        }
+
+        if (payload) {
+            if (!ok) {
+                chunk_bad[c] = 1;
+            }
+            u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + cl;
+#pragma unroll
+            for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+                const bool usable = (qq + 1) * (kSubWords / kQuarters) >= meet_row;
+                u32 tail = ref_count - (cp_state[qq] >> 16), bits = rw.offset_of(cp_state[qq]);
+                bool have_cp = usable;
+                if (qq == 0 && late && cl != 0) {
+                    tail = count - (head_cp >> 16);
+                    bits = rw.offset_of(head_cp);
+                    have_cp = true;
+                }
+                cp[qq * HUFD_DEC_LANES] = (u16)(have_cp ? 0x8000u | (bits << 11) | tail : 0u);
+            }
+            lane_count[(u64)c * HUFD_DEC_LANES + cl] = (u16)(cl ? count : ref_count);
+            if (cl) {
+                /* (a lane behind one whose walks did not meet has no entry state: its chunk is marked, nothing of this is read) */
+                cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((1u << (entry < ns ? entry : 0u)) | (ref_exit << 12));
+            }
+        }
+    }
+}
+
+/* what dec_sync_resident leaves per sub-chunk, put together per chunk: the chunk's function for dec_scan (a workgroup a
+ * chunk: the symbols of its lanes 1 .. 255 summed), whether it is regular, and the lists of the chunks that are not */
+__global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_resident_finish_kernel(
+    hufd_tables tb,
+    const hufd_chunk_rec *chunk_rec,
+    const u16 *fn_tab,
+    const u16 *cp_tab,
+    const u16 *lane_count,
+    const u8 *chunk_bad,
+    const u8 *chunk_one0,
+    u32 *chunk_fn,
+    u8 *chunk_regular,
+    u32 *slow_list,
+    u32 *slow_count,
+    u32 *long_list,
+    u32 *long_count) {
+    u32 *wave_tot = reinterpret_cast<u32 *>(dyn_lds); /* [HUFD_DEC_LANES / kWave] */
+    const u32 c = blockIdx.x, lane = threadIdx.x, ns = tb.n_states;
+    if (chunk_rec[c].valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
+        return; /* holds the end of its stream: dec_sync_lean<TAIL>'s */
+    }
+    if (chunk_bad[c]) {
+        if (lane == 0) {
+            chunk_regular[c] = 0;
+            if (chunk_one0[c]) {
+                slow_list[atomicAdd(slow_count, 1u)] = c;
+            } else {
+                long_list[atomicAdd(long_count, 1u)] = c;
+            }
+        }
+        return;
+    }
+    const u32 mine = lane ? lane_count[(u64)c * HUFD_DEC_LANES + lane] : 0u;
+    const u32 wsum = wave_sum(mine);
+    if ((lane & (kWave - 1)) == 0) {
+        wave_tot[lane / kWave] = wsum;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        chunk_regular[c] = 1;
+    }
+    if (lane < ns) {
+        u32 rest = 0;
+#pragma unroll
+        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
+            rest += wave_tot[wv];
+        }
+        const u32 last_exit = (u32)cp_tab[(u64)c * kCpRows * HUFD_DEC_LANES + (kQuarters - 1) * HUFD_DEC_LANES + HUFD_DEC_LANES - 1] >> 12;
+        const u32 f = fn_tab[((u64)c * ns + lane) * HUFD_DEC_LANES];
+        chunk_fn[(u64)c * ns + lane] =
+            (f & 0x8000u) ? wide_pack(true, 0, f & 0x7FFu) : wide_pack(false, last_exit, (f & 0x7FFu) + rest);
+    }
+}
+
 /* ------------------------------------------------------------------ decode: emit */
 
 /*
@@ -7937,6 +8242,17 @@ int hufk_init(void) {
     HUFK_ALLOW_BIG_LDS(12, 2)
     HUFK_ALLOW_BIG_LDS(12, 3)
 #undef HUFK_ALLOW_BIG_LDS
+#define HUFK_ALLOW_BIG_LDS(SUREV)                                                                                       \
+    if (e == hipSuccess) {                                                                                             \
+        e = hipFuncSetAttribute(                                                                                       \
+            reinterpret_cast<const void *>(&dec_sync_resident_kernel<SUREV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+            lds_max);                                                                                                  \
+    }
+    HUFK_ALLOW_BIG_LDS(2)
+    HUFK_ALLOW_BIG_LDS(3)
+    HUFK_ALLOW_BIG_LDS(4)
+    HUFK_ALLOW_BIG_LDS(5)
+#undef HUFK_ALLOW_BIG_LDS
     if (e == hipSuccess) {
         e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&dec_onepass_kernel<12, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -8400,13 +8716,48 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
             a->slow_list, a->slow_count, lean_long_list, lean_long_count, (const u32 *)nullptr);                        \
     }                                                                                                                  \
-    if (some_inside) {                                                                                                 \
+    if (inside_by_chunks) {                                                                                            \
         hipLaunchKernelGGL(                                                                                            \
             (dec_sync_lean_kernel<LBV, SUREV, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES),                         \
             (uint32_t)sizeof(lean_shared<LBV>), st, a->tables, a->chunk_rec, a->tail_chunks,                            \
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
             a->slow_list, a->slow_count, lean_long_list, lean_long_count, gate);                                       \
     }
+        /* Asked for (AWS_HUFFMAN_AMD_DECODE=resident-sync): the chunks inside streams, where there are enough of them to fill
+         * the chip and the decode table has up to 10 bits, by resident waves with the walk table once per LDS bank
+         * (dec_sync_resident), what is per chunk put together behind them; the chunks streams end in keep
+         * dec_sync_lean<TAIL>.  Measured at half dec_sync_lean's speed (one workgroup a CU = 4 waves a SIMD): see there. */
+        bool resident = false;
+        /* (tests and experiments: AWS_HUFFMAN_AMD_RESIDENT_MIN_TILES = the fewest tiles a launch takes this way) */
+        const char *min_text = getenv("AWS_HUFFMAN_AMD_RESIDENT_MIN_TILES");
+        const uint32_t min_tiles = min_text ? (uint32_t)strtoul(min_text, nullptr, 10) : kResMinTiles;
+        if (a->old_sync == 4 && !gate && some_inside && a->n_res_tiles >= min_tiles && a->item_first_tile && a->chunk_flags &&
+            a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS && a->tables.lut_bits <= kResLB && a->tables.bank_rows &&
+            row_walk(kResLB, a->tables.max_bits, kResWinPos).sure == sure && sure >= 2 && sure <= 5) {
+            resident = true;
+            (void)hipMemsetAsync(a->chunk_flags, 0, (size_t)2 * a->n_chunks, st);
+            const uint32_t cus = current_compute_units();
+            const uint32_t want = (a->n_res_tiles + kResWaves - 1) / kResWaves;
+            const uint32_t grid = want < cus ? want : cus;
+#define HUFK_LAUNCH_SYNC_RESIDENT(SUREV)                                                                                \
+    hipLaunchKernelGGL(                                                                                                \
+        (dec_sync_resident_kernel<SUREV>), dim3(grid), dim3(kResThreads), (uint32_t)sizeof(resident_shared), st,        \
+        a->tables, a->items, a->n_items, a->item_first_tile, (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->lane_count,  \
+        a->chunk_flags, a->chunk_flags + a->n_chunks)
+            switch (sure) {
+                case 2: HUFK_LAUNCH_SYNC_RESIDENT(2); break;
+                case 3: HUFK_LAUNCH_SYNC_RESIDENT(3); break;
+                case 4: HUFK_LAUNCH_SYNC_RESIDENT(4); break;
+                default: HUFK_LAUNCH_SYNC_RESIDENT(5); break;
+            }
+#undef HUFK_LAUNCH_SYNC_RESIDENT
+            hipLaunchKernelGGL(
+                dec_sync_resident_finish_kernel, dim3(a->n_chunks), dim3(HUFD_DEC_LANES), 64, st, a->tables, a->chunk_rec,
+                (const u16 *)a->fn_tab, (const u16 *)a->cp_tab, (const u16 *)a->lane_count, (const u8 *)a->chunk_flags,
+                (const u8 *)(a->chunk_flags + a->n_chunks), a->chunk_fn, a->chunk_regular, a->slow_list, a->slow_count,
+                lean_long_list, lean_long_count);
+        }
+        const bool inside_by_chunks = some_inside && !resident; /* the kernels below take the chunks inside streams a workgroup each */
         /* ... or, asked for (AWS_HUFFMAN_AMD_DECODE=bank-sync), for a decode table of up to 10 bits the one with a length table
          * per LDS bank, four (or two) chunks a workgroup: measured slower than dec_sync_lean, see there */
 #define HUFK_LAUNCH_SYNC_BANK_N(SUREV, CH)                                                                              \
@@ -8417,7 +8768,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
             a->slow_list, a->slow_count, lean_long_list, lean_long_count, (const u32 *)nullptr);                        \
     }                                                                                                                  \
-    if (some_inside) {                                                                                                 \
+    if (inside_by_chunks) {                                                                                            \
         hipLaunchKernelGGL(                                                                                            \
             (dec_sync_bank_kernel<SUREV, false, CH>), dim3((a->n_chunks + CH - 1) / CH), dim3(CH * HUFD_DEC_LANES),     \
             (uint32_t)sizeof(bank_shared<CH>), st, a->tables, a->chunk_rec, a->tail_chunks, a->n_chunks,                \
@@ -8444,7 +8795,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         }
 #undef HUFK_LAUNCH_SYNC_BANK
 #undef HUFK_LAUNCH_SYNC_BANK_N
-        if (!lean && a->old_sync != 1 && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS) { /* (0, 2: dec_sync_lean) */
+        if (!lean && a->old_sync != 1 && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS) { /* (0, 2: dec_sync_lean; 4: for the chunks streams end in) */
             lean = true;
             if (a->tables.lut_bits <= 10) {
                 switch (sure) {

@@ -906,6 +906,8 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     hufs_free(p->d_dense_list);
     hufs_free(p->d_lane_count);
     hufs_free(p->d_chunk_regular);
+    hufs_free(p->d_chunk_flags);
+    hufs_free(p->d_first_tile);
     hufs_free(p->d_tail_entry);
     hufs_free(p->d_chunk_entry);
     hufs_free(p->d_chunk_base);
@@ -931,6 +933,8 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     p->d_dense_list = NULL;
     p->d_lane_count = NULL;
     p->d_chunk_regular = NULL;
+    p->d_chunk_flags = NULL;
+    p->d_first_tile = NULL;
     p->d_tail_entry = NULL;
     p->d_chunk_entry = NULL;
     p->d_chunk_base = NULL;
@@ -1049,6 +1053,8 @@ static int dec_plan_reserve(struct aws_huffman_amd_decode_plan *p, size_t n_item
         p->d_dense_list = hufs_malloc((cc + 1) * sizeof(uint32_t));
         p->d_lane_count = hufs_malloc(cc * HUFD_DEC_LANES * sizeof(uint16_t));
         p->d_chunk_regular = hufs_malloc(cc);
+        p->d_chunk_flags = hufs_malloc(2 * cc);
+        p->d_first_tile = hufs_malloc((ci + 1) * sizeof(uint32_t));
         p->d_tail_entry = hufs_malloc(cc * sizeof(uint32_t));
         p->d_chunk_entry = hufs_malloc(cc * sizeof(uint32_t));
         p->d_chunk_base = hufs_malloc(cc * sizeof(uint64_t));
@@ -1056,7 +1062,7 @@ static int dec_plan_reserve(struct aws_huffman_amd_decode_plan *p, size_t n_item
         p->d_states = hufs_malloc(ci * sizeof(struct hufd_dec_item_state));
         p->d_results = hufs_malloc(ci * sizeof(struct hufd_dec_result));
         if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_cp_tab || !p->d_chunk_fn || !p->d_slow_list || !p->d_chunk_entry ||
-            !p->d_tail || !p->d_tiny || !p->d_dense_list || !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_tail_entry || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
+            !p->d_tail || !p->d_tiny || !p->d_dense_list || !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_chunk_flags || !p->d_first_tile || !p->d_tail_entry || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
             !p->d_chunk_base || !p->d_chunk_rec || !p->d_states || !p->d_results) {
             return 2;
         }
@@ -1082,6 +1088,7 @@ static int dec_plan_fill(
     /* a failed refill must not leave counts of the fill before behind (the device arrays may be gone or too small) */
     p->n_items = p->n_chunks = p->n_large = p->n_runs = p->n_tail = p->n_tiles = p->n_fixed = p->n_wide = 0;
     p->n_tiny = p->n_deep = 0;
+    p->n_res_tiles = 0;
     if (n_items >= PLAN_ON_DEVICE_MIN_ITEMS && n_items < 0xFFFFFFFFull && stats.shortest >= 1 && stats.longest <= tiny_limit &&
         stats.worst_bits <= 7) {
         /* every item is one thread's work (dec_item_is_tiny): no chunks, no lists to make -- the caller's records go to the
@@ -1143,12 +1150,14 @@ static int dec_plan_fill(
     }
 
     struct hufd_dec_item *h_items = malloc((n_items ? n_items : 1) * sizeof(*h_items));
+    uint32_t *h_first_tile = malloc((n_items + 1) * sizeof(uint32_t)); /* dec_sync_resident's tiles of the items in front */
     uint32_t *h_large = malloc((n_large ? n_large : 1) * 2 * sizeof(uint32_t));
     uint32_t *h_runs = malloc((n_runs ? n_runs : 1) * 2 * sizeof(uint32_t));
     uint32_t *h_tail = malloc((n_items ? n_items : 1) * 2 * sizeof(uint32_t));
     uint32_t *h_tiny = malloc((n_items ? n_items : 1) * sizeof(uint32_t));
     struct hufd_tile_rec *h_tiles = malloc((n_tiles ? n_tiles : 1) * sizeof(*h_tiles));
-    if (!h_tiles || !h_items || !h_large || !h_runs || !h_tail || !h_tiny) {
+    if (!h_tiles || !h_items || !h_first_tile || !h_large || !h_runs || !h_tail || !h_tiny) {
+        free(h_first_tile);
         free(h_tail);
         free(h_tiny);
         free(h_tiles);
@@ -1170,6 +1179,7 @@ static int dec_plan_fill(
     uint64_t wide_bytes = 0;
     bool wide_oom = false;
     uint64_t tail_stage = 0; /* the most symbols a chunk that holds the end of a stream can decode to */
+    uint64_t res_tiles = 0;
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_decode_item *src = &items[i];
         struct hufd_dec_item *dst = &h_items[i];
@@ -1182,6 +1192,8 @@ static int dec_plan_fill(
         dst->first_chunk = chunk;
         dst->n_chunks = chunks;
         dst->tiny = 0;
+        h_first_tile[i] = (uint32_t)res_tiles;
+        res_tiles += dec_item_tiles(chunks, src->in_len);
         if (dec_item_is_tiny(src, tiny_limit)) {
             dst->tiny = 1;
             h_tiny[tiny++] = (uint32_t)i;
@@ -1308,8 +1320,12 @@ static int dec_plan_fill(
             err = hufs_copy_h2d(p->d_tiles, h_tiles, n_tiles * sizeof(*h_tiles), eng->stream);
         }
     }
+    h_first_tile[n_items] = res_tiles < 0xFFFFFFFFull ? (uint32_t)res_tiles : 0u; /* (too many: the launch keeps to the kernels without tiles) */
     if (!err) {
         err = hufs_copy_h2d(p->d_items, h_items, n_items * sizeof(*h_items), eng->stream);
+    }
+    if (!err && res_tiles && res_tiles < 0xFFFFFFFFull) {
+        err = hufs_copy_h2d(p->d_first_tile, h_first_tile, (n_items + 1) * sizeof(uint32_t), eng->stream);
     }
     if (!err) {
         err = hufs_copy_h2d(p->d_runs, h_runs, n_runs * 2 * sizeof(uint32_t), eng->stream);
@@ -1339,6 +1355,8 @@ static int dec_plan_fill(
             p->h_items = keep;
         }
     }
+    const uint32_t res_tiles_kept = h_first_tile[n_items];
+    free(h_first_tile);
     free(h_items);
     free(h_large);
     free(h_runs);
@@ -1360,6 +1378,7 @@ static int dec_plan_fill(
     p->n_runs = (uint32_t)n_runs;
     p->n_tail = tail;
     p->n_tiles = (uint32_t)n_tiles;
+    p->n_res_tiles = res_tiles_kept;
     p->tail_stage_bytes = tail_stage + 32 < 0xFFFFFFFFu ? (uint32_t)tail_stage + 32u : 0u;
     p->n_tiny = tiny;
     p->n_deep = deep;
@@ -1460,6 +1479,9 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.dense_list = p->d_dense_list + 1;
     a.lane_count = p->d_lane_count;
     a.chunk_regular = p->d_chunk_regular;
+    a.chunk_flags = p->d_chunk_flags;
+    a.item_first_tile = p->d_first_tile;
+    a.n_res_tiles = p->n_res_tiles;
     a.tail_entry = p->d_tail_entry;
     a.chunk_entry = p->d_chunk_entry;
     a.chunk_base = p->d_chunk_base;
@@ -1472,9 +1494,11 @@ int aws_huffman_amd_decode_plan_launch_staged(
     {
         const char *mode = getenv("AWS_HUFFMAN_AMD_DECODE");
         /* "old-sync": the kernel dec_sync_lean replaced; "bank-sync": dec_sync_bank, the round-4 kernel with a length table
-         * per LDS bank that did not beat it (comparison and tests); "lean-sync": the default by name */
+         * per LDS bank that did not beat it, "resident-sync": dec_sync_resident, resident waves with the table once per bank,
+         * which did not either (comparison and tests); "lean-sync": the default by name */
         a.old_sync = mode && strcmp(mode, "old-sync") == 0 ? 1u
-                     : (mode && strcmp(mode, "lean-sync") == 0 ? 2u : (mode && strcmp(mode, "bank-sync") == 0 ? 3u : 0u));
+                     : (mode && strcmp(mode, "lean-sync") == 0 ? 2u
+                        : (mode && strcmp(mode, "bank-sync") == 0 ? 3u : (mode && strcmp(mode, "resident-sync") == 0 ? 4u : 0u)));
         /* the chunks inside streams: sync + scan + emit (two passes over the stream) unless told otherwise.  "one-pass"
          * puts dec_onepass in front of them (every encoded byte read once; on an MI355X it takes as long as the two
          * passes, DESIGN.md 4 "One pass": not the default); "one-pass-fails" does the same with one tile made to give

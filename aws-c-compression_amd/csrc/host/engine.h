@@ -105,6 +105,9 @@ struct aws_huffman_amd_decode_plan {
     uint32_t *d_dense_list; /* [0] how many, [1..] chunks with more symbols than one emit stage */
     uint16_t *d_lane_count;
     uint8_t *d_chunk_regular;
+    uint8_t *d_chunk_flags;     /* [2 * cap_chunks] dec_sync_resident's chunk_bad and chunk_one0 */
+    uint32_t *d_first_tile;     /* [cap_items + 1] dec_sync_resident's tiles of the items in front */
+    uint32_t n_res_tiles;
     uint32_t *d_tail_entry;
     uint32_t *d_chunk_entry;
     uint64_t *d_chunk_base;

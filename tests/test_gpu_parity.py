@@ -96,6 +96,23 @@ def test_many_header_sized_items(world):
     pc.many_header_sized_items(world)
 
 
+def test_resident_sync_kernel_on_small_streams(world):
+    """AWS_HUFFMAN_AMD_DECODE=resident-sync: dec_sync_resident (resident waves, the walk table once per LDS bank, tiles
+    of 64 sub-chunks; round 4, measured at half dec_sync_lean's speed and kept behind the switch), made to take every
+    launch that has a chunk inside a stream (by default: launches of at least 2048 tiles = 16 MiB of stream)."""
+    os.environ["AWS_HUFFMAN_AMD_RESIDENT_MIN_TILES"] = "1"
+    os.environ["AWS_HUFFMAN_AMD_DECODE"] = "resident-sync"
+    try:
+        pc.one_shot_roundtrips(world, sizes=[40000, 200001, 16384 * 66 + 3], seed=23)
+        pc.cut_streams(world, chunks=(1, 2, 5), step=31, n=250_000)
+        pc.garbage_decode(world, rounds=40)
+        pc.unknown_symbols(world)
+        pc.batched_device_api(world)
+    finally:
+        del os.environ["AWS_HUFFMAN_AMD_RESIDENT_MIN_TILES"]
+        del os.environ["AWS_HUFFMAN_AMD_DECODE"]
+
+
 def test_survey_records(world):
     pc.survey_records_on_product(world, names=("G4K", "G16K", "G16KP", "G1M"))
 
