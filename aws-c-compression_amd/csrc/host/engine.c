@@ -572,6 +572,8 @@ static int enc_plan_fill(
     }
     struct item_stats stats;
     const uint64_t tiny_limit = enc_tiny_limit(eng, items, n_items, &stats);
+    /* a failed refill must not leave counts of the fill before behind (the device arrays may be gone or too small) */
+    p->n_items = p->n_segs = p->n_large = p->n_tiny = 0;
     if (n_items >= PLAN_ON_DEVICE_MIN_ITEMS && n_items < 0xFFFFFFFFull && stats.shortest >= 1 && stats.longest <= tiny_limit &&
         stats.worst_bits <= 32) {
         /* every item is one thread's work (enc_item_is_tiny): no segments, no lists to make -- the caller's records go to the
@@ -592,7 +594,6 @@ static int enc_plan_fill(
             e = hufs_stream_sync(eng->stream);
         }
         hufs_free(d_raw);
-        p->n_items = p->n_segs = p->n_large = p->n_tiny = 0;
         if (e) {
             return raise_hip(e);
         }

@@ -309,14 +309,23 @@ int aws_huffman_decode(
     AWS_ASSERT(output);
     while (to_decode->len > s_decode_piece_bytes) {
         struct aws_byte_cursor piece = {s_decode_piece_bytes, to_decode->ptr};
+        const uint64_t bits_before = decoder->working_bits;
+        const uint8_t held_before = decoder->num_bits;
+        const size_t len_before = output->len;
         const int rc = decode_piece(decoder, &piece, output);
+        const int error = rc ? aws_last_error() : 0; /* (read at once: nothing below may replace it) */
         const size_t taken = s_decode_piece_bytes - piece.len;
         to_decode->ptr += taken;
         to_decode->len -= taken;
+        if (rc != AWS_OP_SUCCESS && error != AWS_ERROR_SHORT_BUFFER && error != AWS_ERROR_COMPRESSION_UNKNOWN_SYMBOL && taken == 0 &&
+            decoder->working_bits == bits_before && decoder->num_bits == held_before && output->len == len_before) {
+            /* not an outcome of the stream -- no engine, no device, no memory for the staging buffers -- and nothing was
+             * decoded: the reference consumes no input on such an error, the cursor and the decoder stay as they were */
+            return aws_raise_error(error);
+        }
         if (rc != AWS_OP_SUCCESS || piece.len != 0) {
             /* stopped inside the piece: the reference would have topped its window up from ALL the input left before
              * the symbol it stopped at (source/huffman.c:196-211), not only from what the piece still held */
-            const int error = rc ? aws_last_error() : 0;
             while (decoder->num_bits < 32 && to_decode->len > 0) {
                 decoder->working_bits |= (uint64_t)*to_decode->ptr << (56 - decoder->num_bits);
                 decoder->num_bits = (uint8_t)(decoder->num_bits + 8);
