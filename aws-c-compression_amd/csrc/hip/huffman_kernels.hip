@@ -4459,6 +4459,284 @@ __global__ __launch_bounds__(CHUNKS * HUFD_DEC_LANES, 8) void dec_sync_bank_kern
     }
 }
 
+/* ------------------------------------------------------------------ decode: sync, several short end-of-stream chunks a workgroup */
+
+/*
+ * A batch of items of a few KiB each is all chunks that streams END in, one per item, with a handful of whole lanes: 19
+ * of 256 for a 2 KiB item.  dec_sync_lean<TAIL> gives such a chunk a workgroup of its own -- one wave of 19 lanes, a table
+ * of 4 KiB filled, three barriers -- and the batch decodes at a seventh of a stream's rate (bench.py, the mid_items leg).
+ * Here a workgroup takes SEVERAL such chunks: its 256 threads are `slots` of `width` lanes (the most whole lanes any
+ * end-of-stream chunk of the launch has, at least 16), a chunk a slot, so that the waves are full and the table and the
+ * barriers are shared.  Same phases per lane, same records out as dec_sync_lean<TAIL>; what is per chunk there (the
+ * candidates' walks of sub-chunk 0, the sum of the lanes' symbols, the verdict) is per slot here, through LDS words
+ * instead of wave votes, because a slot need not start on a wave.
+ */
+constexpr u32 kPackMaxSlots = 16;
+constexpr u32 kPackMinChunks = 64; /* fewer end-of-stream chunks in a launch: a workgroup each (dec_sync_lean<TAIL>) */
+
+template <u32 LB>
+struct pack_shared {
+    u32 wlut[1u << LB]; /* 0x10000 - length, length 48 = no code; at a multiple of its own size */
+    u32 exit_state[HUFD_DEC_LANES];
+    u32 sub0[kPackMaxSlots][kFastMaxMeet + 4]; /* a slot's first rows of sub-chunk 0, for the threads that try its entry states */
+    u32 sum[kPackMaxSlots];      /* symbols of the slot's lanes >= 1 */
+    u32 bad[kPackMaxSlots];
+    u32 alive[kPackMaxSlots];    /* entry states of the slot's chunk that reach the meeting bit */
+    u32 meet0[kPackMaxSlots];    /* of the slot's sub-chunk 0: meeting row << 8 | meeting bit | its walks have met << 31 */
+    u32 tail0[kPackMaxSlots];    /* ... its symbols from the meeting bit on */
+    u16 hops[1u << LB]; /* 1 << code length of a window (the head it sends on), 0 = no code */
+};
+
+template <u32 LB, u32 SURE>
+__global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_pack_kernel(
+    hufd_tables tb,
+    const hufd_chunk_rec *chunk_rec,
+    const u32 *tail_chunks,
+    u32 n_tail,
+    u32 width, /* lanes a slot: >= 16, >= the whole lanes of every chunk of the launch, <= 128 */
+    const u8 *d_in,
+    u16 *fn_tab,
+    u16 *cp_tab,
+    u32 *chunk_fn,
+    u16 *lane_count,
+    u8 *chunk_regular,
+    u32 *tail_entry,
+    u32 *long_list,
+    u32 *long_count) {
+
+    pack_shared<LB> &sh = *reinterpret_cast<pack_shared<LB> *>(dyn_lds);
+    const u32 ns = tb.n_states;
+    const u32 t = threadIdx.x;
+    const u32 slots = HUFD_DEC_LANES / width;
+    const u32 slot = t / width, lane = t % width;
+    const row_walk rw(LB, tb.max_bits);
+    const u32 table = lds_offset_of(sh.wlut);
+    /* the table: every thread its share, whatever becomes of its slot */
+    {
+        constexpr u32 kLutPerLane = (1u << LB) / HUFD_DEC_LANES;
+        u32 lut_raw[kLutPerLane];
+#pragma unroll
+        for (u32 j = 0; j < kLutPerLane; ++j) {
+            lut_raw[j] = tb.dec_lut[(t + j * HUFD_DEC_LANES) >> (LB - tb.lut_bits)];
+        }
+#pragma unroll
+        for (u32 j = 0; j < kLutPerLane; ++j) {
+            const u32 len = lut_raw[j] & 0xFFu;
+            sh.wlut[t + j * HUFD_DEC_LANES] = 0x10000u - (len ? len : kWalkDeadLen);
+            sh.hops[t + j * HUFD_DEC_LANES] = (u16)(len ? 1u << len : 0u);
+        }
+    }
+    const u32 li = blockIdx.x * slots + slot;
+    const bool have = slot < slots && li < n_tail;
+    const u32 c = have ? tail_chunks[li] : 0u;
+    const hufd_chunk_rec rec = chunk_rec[c];
+    const u64 valid = rec.valid;
+    const u8 *src = d_in + rec.src_off;
+    const u32 n_full = valid >= 8u ? (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES) : 0u;
+    const bool eligible = tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS && rw.sure == SURE && (table & ((4u << LB) - 1u)) == 0 &&
+                          n_full <= width;
+    /* (threads that leave here still count for the barriers below as long as their wave lives: `mine` keeps them out of
+     * everything but the barriers) */
+    bool mine = have;
+    if (mine && n_full == 0 && tb.lut_bits <= HUFD_DEC_MAX_LUT_BITS) {
+        if (lane == 0) {
+            chunk_regular[c] = 3; /* fewer than 136 bytes: the whole chunk is one thread's work in dec_sync_tail / dec_emit_tail */
+        }
+        mine = false;
+    }
+    if (mine && !eligible) {
+        if (lane == 0) {
+            chunk_regular[c] = 0;
+            long_list[atomicAdd(long_count, 1u)] = c;
+        }
+        mine = false;
+    }
+    const bool active = mine && lane < n_full;
+    u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES;
+    u32 w[kFastRows];
+    {
+        const u32 from = active ? lane : 0u;
+        const u8 *at = mine ? src + (u64)from * HUFD_DEC_SUB_BYTES : d_in; /* (a thread without a chunk reads the input's first bytes: never looked at) */
+        const unaligned_uint4 *line = reinterpret_cast<const unaligned_uint4 *>(at);
+#pragma unroll
+        for (u32 q = 0; q < kSubWords / 4; ++q) {
+            const unaligned_uint4 v = mine ? line[q] : unaligned_uint4{0, 0, 0, 0};
+            w[4 * q + 0] = v.x;
+            w[4 * q + 1] = v.y;
+            w[4 * q + 2] = v.z;
+            w[4 * q + 3] = v.w;
+        }
+        w[kSubWords] = mine ? reinterpret_cast<const unaligned_u32 *>(at + HUFD_DEC_SUB_BYTES)->x : 0u;
+    }
+#pragma unroll
+    for (u32 r = 0; r < kFastRows; ++r) {
+        w[r] = __builtin_bswap32(w[r]);
+    }
+    if (slot < kPackMaxSlots && lane == 0) {
+        sh.bad[slot] = 0;
+        sh.sum[slot] = 0;
+        sh.alive[slot] = 0;
+#pragma unroll
+        for (u32 r = 0; r <= kFastMaxMeet; ++r) {
+            sh.sub0[slot][r] = w[r];
+        }
+    }
+    __syncthreads();
+
+    /* U: all entry states as one mask of heads per row, until every lane of the wave is down to one */
+    u64 heads = active ? (1ull << ns) - 1ull : 0ull;
+    u32 meet_row = 0; /* the same for the whole wave */
+    bool one = false, settled = false;
+#pragma unroll
+    for (u32 r = 0; r < kFastMaxMeet; ++r) {
+        if (!settled) {
+            heads = r == 0 ? union_first_row<LB>(ns, active, w[0], w[1], sh.hops) : union_row_fast<LB>(heads, w[r], w[r + 1], sh.hops);
+            one = heads != 0 && (heads & (heads - 1)) == 0;
+            meet_row = r + 1;
+            settled = __all(one || heads == 0);
+        }
+    }
+    const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
+    bool ok = !active || (one && settled);
+
+    /* R: the one walk from the meeting bit to the end of the sub-chunk */
+    u32 state = rw.state_at(meet_bit, 0);
+    u32 cp_state[kQuarters - 1] = {0, 0, 0};
+    bool dead = false;
+#pragma unroll
+    for (u32 r = 1; r < kSubWords; ++r) {
+        if (r >= meet_row) {
+            if (r % (kSubWords / kQuarters) == 0) {
+                cp_state[r / (kSubWords / kQuarters) - 1] = state;
+            }
+            state = lean_row<SURE>(state, w[r], w[r + 1], table, rw);
+            dead = dead || rw.died(state);
+            state = rw.next_row(state, dead); /* (lanes without data walk zeros: put back on a row start, their state stays in range) */
+        }
+    }
+    const u32 ref_count = state >> 16; /* symbols from the meeting bit to the end of the sub-chunk */
+    const u32 ref_exit = rw.offset_of(state);
+    ok = ok && (!active || (!dead && ref_exit < ns));
+    sh.exit_state[t] = ref_exit;
+    if (mine && lane == 0) {
+        sh.meet0[slot] = (meet_row << 8) | meet_bit | (one ? 0x80000000u : 0u);
+        sh.tail0[slot] = ref_count;
+    }
+    __syncthreads();
+
+    /* H: my own sub-chunk from my true entry state, to the meeting bit */
+    const u32 entry = lane ? sh.exit_state[t - 1] : 0u;
+    u32 count;
+    u32 head_cp = 0; /* the head walk where it enters the second quarter, when the meeting row lies behind that */
+    const bool late = meet_row > kSubWords / kQuarters;
+    {
+        u32 st = rw.state_at(entry < ns ? entry : 0u, 0);
+        bool dd = false;
+#pragma unroll
+        for (u32 r = 0; r < kFastMaxMeet; ++r) {
+            if (r < meet_row) {
+                if (r == kSubWords / kQuarters) {
+                    head_cp = st;
+                }
+                st = lean_row<SURE>(st, w[r], w[r + 1], table, rw);
+                dd = dd || rw.died(st);
+                st = rw.next_row(st, dd);
+            }
+        }
+        const bool reached = !dd && rw.offset_of(st) == meet_bit;
+        ok = ok && (lane == 0 || !active || reached);
+        count = active ? (st >> 16) + ref_count : 0u; /* symbols of the true path that start in my sub-chunk (lanes >= 1) */
+    }
+
+    /* H: sub-chunk 0 of my slot's chunk from every entry state the chunk may be entered in (lanes 0 .. ns-1 of the slot),
+     * step by step: the count of a walk that dies has to be right */
+    u32 cand_count = 0, cand_dead = 0;
+    bool cand_reached = false;
+    if (mine && lane < ns) {
+        const u32 m0 = sh.meet0[slot], rows0 = (m0 >> 8) & 0xFFu, target = m0 & 0xFFu;
+        u32 st = rw.state_at(lane, 0);
+        bool dd = false;
+        u32 hi = sh.sub0[slot][0];
+        for (u32 r = 0; r < rows0; ++r) {
+            const u32 lo = sh.sub0[slot][r + 1];
+            st = lean_row<SURE, true>(st, hi, lo, table, rw);
+            const bool now = rw.died(st) && !dd;
+            cand_dead = now ? (st >> 16) - 1u : cand_dead; /* the step that found no code is not a symbol */
+            dd = dd || now;
+            st = rw.next_row(st, dd);
+            hi = lo;
+        }
+        cand_reached = !dd && rw.offset_of(st) == target;
+        cand_count = (st >> 16) + sh.tail0[slot];
+        if (cand_reached) {
+            atomicOr(&sh.alive[slot], 1u << lane);
+        }
+    }
+    if (active && lane) {
+        atomicAdd(&sh.sum[slot], count);
+    }
+    if (mine && !ok) {
+        sh.bad[slot] = 1;
+    }
+    __syncthreads();
+    if (!mine) {
+        return;
+    }
+    if (sh.bad[slot]) {
+        if (lane == 0) {
+            chunk_regular[c] = 0;
+            long_list[atomicAdd(long_count, 1u)] = c;
+        }
+        return;
+    }
+
+    /* the tables dec_scan and dec_emit read (dec_sync_fast's) */
+    if (active) {
+        u16 *mcp = cp + lane;
+#pragma unroll
+        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+            const bool usable = (qq + 1) * (kSubWords / kQuarters) >= meet_row;
+            u32 tail = ref_count - (cp_state[qq] >> 16), bits = rw.offset_of(cp_state[qq]);
+            bool have_cp = usable;
+            if (qq == 0 && late && lane != 0) {
+                tail = count - (head_cp >> 16);
+                bits = rw.offset_of(head_cp);
+                have_cp = true;
+            }
+            mcp[qq * HUFD_DEC_LANES] = (u16)(have_cp ? 0x8000u | (bits << 11) | tail : 0u);
+        }
+        lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)(lane ? count : ref_count);
+        mcp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((lane ? 1u << entry : sh.alive[slot]) | (ref_exit << 12));
+    }
+    /* the chunk's lanes behind the whole ones: never reached, as far as this kernel knows (dec_sync_tail follows the true
+     * path through the one or two sub-chunks the stream ends in and rewrites their records) */
+    if (lane < 2 && n_full + lane < HUFD_DEC_LANES) {
+        /* (the two sub-chunks the stream can end in; dec_emit_fast<TAIL> takes the lanes behind them as empty without
+         * looking: writing a record for each of the chunk's 256 lanes cost this kernel more than its walks) */
+        const u32 l = n_full + lane;
+#pragma unroll
+        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+            cp[qq * HUFD_DEC_LANES + l] = 0;
+        }
+        lane_count[(u64)c * HUFD_DEC_LANES + l] = 0;
+        cp[(kQuarters - 1) * HUFD_DEC_LANES + l] = (u16)(kExitStop << 12);
+    }
+    if (lane + 1 == n_full) {
+        tail_entry[c] = ref_exit;
+    }
+    if (lane == 0) {
+        chunk_regular[c] = 2;
+    }
+    if (lane < ns) {
+        const u32 rest = sh.sum[slot];
+        const u32 first_exit = sh.exit_state[slot * width];
+        fn_tab[((u64)c * ns + lane) * HUFD_DEC_LANES] =
+            cand_reached ? fn_pack(false, first_exit, cand_count & 0x7FFu) : fn_pack(true, 0, cand_dead);
+        /* (symbols of the whole lanes only, and no exit yet: dec_sync_tail adds the stream's last symbols and how it ends) */
+        chunk_fn[(u64)c * ns + lane] = cand_reached ? wide_pack(false, 0u, cand_count + rest) : wide_pack(true, 0, cand_dead);
+    }
+}
+
 /* ------------------------------------------------------------------ decode: sync, second chance for chunks inside a stream */
 
 /*
@@ -7701,7 +7979,8 @@ __device__ __forceinline__ void dec_emit_fast_chunk(
     u32 own_cnt = 0; /* TAIL: thread t < 256 does this for sub-chunk t, whoever walks it */
     if (TAIL) {
         if (t < HUFD_DEC_LANES) {
-            own_cnt = lane_count[(u64)c * HUFD_DEC_LANES + t];
+            /* (the lanes behind the stream's last two sub-chunks hold nothing; dec_sync_pack does not even write their records) */
+            own_cnt = t < n_full + 2 ? lane_count[(u64)c * HUFD_DEC_LANES + t] : 0u;
             incl[0] = wave_inclusive_sum(t ? own_cnt : 0u, wl);
             if (wl == kWave - 1) {
                 sh.wave_tot[t / kWave] = incl[0];
@@ -8708,8 +8987,18 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         /* chunks inside a stream: the lean kernel where it is compiled for this coder's number of certain steps a row */
         const uint32_t sure = row_walk(a->tables.lut_bits <= 10 ? 10u : 12u, a->tables.max_bits).sure;
         bool lean = false;
+        /* the chunks streams end in: several to a workgroup where they are short and many (dec_sync_pack) */
+        const uint32_t pack_width = a->tail_lanes < 16u ? 16u : a->tail_lanes;
+        const bool pack = a->old_sync == 0 && a->n_tail >= kPackMinChunks && pack_width <= HUFD_DEC_LANES / 2;
+        const uint32_t pack_slots = HUFD_DEC_LANES / pack_width;
 #define HUFK_LAUNCH_SYNC_LEAN(LBV, SUREV)                                                                               \
-    if (a->n_tail) {                                                                                                   \
+    if (a->n_tail && pack) {                                                                                           \
+        hipLaunchKernelGGL(                                                                                            \
+            (dec_sync_pack_kernel<LBV, SUREV>), dim3((a->n_tail + pack_slots - 1) / pack_slots), dim3(HUFD_DEC_LANES),  \
+            (uint32_t)sizeof(pack_shared<LBV>), tst, a->tables, a->chunk_rec, a->tail_chunks, a->n_tail, pack_width,    \
+            (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
+            lean_long_list, lean_long_count);                                                                          \
+    } else if (a->n_tail) {                                                                                            \
         hipLaunchKernelGGL(                                                                                            \
             (dec_sync_lean_kernel<LBV, SUREV, true>), dim3(a->n_tail), dim3(HUFD_DEC_LANES),                            \
             (uint32_t)sizeof(lean_shared<LBV>), tst, a->tables, a->chunk_rec, a->tail_chunks,                           \

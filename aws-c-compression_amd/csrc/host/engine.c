@@ -1121,6 +1121,7 @@ static int dec_plan_fill(
         }
         p->wide_from = wide_min_bytes(0);
         p->tail_stage_bytes = 0;
+        p->tail_lanes = 0;
         p->n_items = (uint32_t)n_items;
         p->n_tiny = (uint32_t)n_items;
         return AWS_OP_SUCCESS;
@@ -1180,6 +1181,7 @@ static int dec_plan_fill(
     uint64_t wide_bytes = 0;
     bool wide_oom = false;
     uint64_t tail_stage = 0; /* the most symbols a chunk that holds the end of a stream can decode to */
+    uint64_t tail_lanes = 0; /* ... and the most whole lanes it has */
     uint64_t res_tiles = 0;
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_decode_item *src = &items[i];
@@ -1258,6 +1260,8 @@ static int dec_plan_fill(
                 uint64_t holds = left * 8 / shortest + 1;
                 holds = holds < src->out_capacity ? holds : src->out_capacity;
                 tail_stage = holds > tail_stage ? holds : tail_stage;
+                const uint64_t whole = left >= 8 ? (left - 8) / HUFD_DEC_SUB_BYTES : 0;
+                tail_lanes = whole > tail_lanes ? whole : tail_lanes;
             }
         }
         chunk += chunks;
@@ -1381,6 +1385,7 @@ static int dec_plan_fill(
     p->n_tiles = (uint32_t)n_tiles;
     p->n_res_tiles = res_tiles_kept;
     p->tail_stage_bytes = tail_stage + 32 < 0xFFFFFFFFu ? (uint32_t)tail_stage + 32u : 0u;
+    p->tail_lanes = tail_lanes < HUFD_DEC_LANES ? (uint32_t)tail_lanes : HUFD_DEC_LANES;
     p->n_tiny = tiny;
     p->n_deep = deep;
     return AWS_OP_SUCCESS;
@@ -1450,6 +1455,7 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.tail_chunks = p->d_tail;
     a.n_tail = p->n_tail;
     a.tail_stage_bytes = p->tail_stage_bytes;
+    a.tail_lanes = p->tail_lanes;
     a.deep_items = p->d_tiny + (p->n_items - p->n_deep);
     a.n_deep = p->n_deep;
     a.wide = p->h_wide;

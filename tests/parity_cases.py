@@ -1211,6 +1211,37 @@ def decode_items_like_the_oracle(w, eng, ocoder, streams, rng, label, modes=(Non
     eng.free(d_sym)
 
 
+def mid_sized_items(w, n_items=150, seed=101, engine=None, modes=(None, "lean-sync"), longest=9000):
+    """A batch of items between header size and a whole chunk (0.8 .. ~10 KiB of encoded bytes each): every one is a
+    chunk its stream ENDS in, with a handful of whole lanes -- several of them share a workgroup (dec_sync_pack,
+    dec_emit_pack), one slot each.  Whole streams, cut ones, damaged ones, arbitrary bytes, streams that start inside a
+    byte, room for all, some or none of the symbols; a plan with a few longer items among them (the slot width follows
+    the longest end-of-stream chunk) and, "lean-sync", the same through a workgroup per chunk."""
+    rng = np.random.default_rng(seed)
+    eng = engine or harness.Engine(w.product.lib, w.pcoder)
+    for label, lens in (("2-3 KiB", rng.integers(1700, 2600, n_items)), ("0.7-9 KiB", rng.integers(700, longest, n_items)),
+                        ("1 KiB and one long", np.concatenate([rng.integers(900, 1200, n_items - 1), [70_000]]))):
+        streams = []
+        for i, n in enumerate(lens):
+            kind = i % 7
+            if kind == 6:
+                enc = rng.integers(0, 256, int(n), dtype=np.uint8)  # arbitrary bytes
+            else:
+                enc = oracle_encode(w, inputs(rng, int(n), KINDS[i % 3]), eos=[None, 0x00, 0x5A][i % 3])
+                if kind == 3:
+                    enc = enc[:int(rng.integers(600, enc.size + 1))]  # cut
+                if kind == 4:
+                    enc = enc.copy()
+                    at = int(rng.integers(0, enc.size - 4))
+                    enc[at:at + 4] = 0xFF  # ten one bits: no code
+            fb = int(rng.integers(0, 8)) if kind == 5 else 0
+            cap = [int(n) + 8, int(n), int(rng.integers(0, n)), int(n) + 8][i % 4]
+            streams.append((enc, fb, cap))
+        decode_items_like_the_oracle(w, eng, w.ocoder, streams, rng, label, modes=modes, kinds=3)
+    if engine is None:
+        eng.close()
+
+
 def wide_long_code_items(w, n=150_000, seed=79, modes=(None, "wide-fails")):
     """Long items of coders with codes of more than 12 bits (decode through linked tables): a workgroup per 32 KiB
     block (dec_wide_*) from 64 KiB on here; with "wide-fails" those kernels give every item back to dec_deep."""
