@@ -8203,6 +8203,263 @@ __global__ __launch_bounds__(kEmitFastThreads, 4) void dec_emit_big_kernel(
     }
 }
 
+/* ------------------------------------------------------------------ decode: emit, several short end-of-stream chunks a workgroup */
+
+/*
+ * dec_emit_fast<TAIL> for the chunks dec_sync_pack took several to a workgroup, the same way: the workgroup's 512 threads
+ * are slots of 4 x ceil(width / 2) threads (a thread a quarter of two neighbouring sub-chunks), a chunk a slot, each
+ * with a stage of its own for the launch's largest chunk; the table and the barriers are shared, the symbol offsets of
+ * all slots' lanes come from one scan over the lanes back to back.  The same test decides which chunks go this way as in
+ * dec_emit_fast<TAIL> (dec_emit_tail, beside this kernel, applies it too); the others go on the list for the long way.
+ */
+template <u32 LB>
+struct emit_pack_shared {
+    u32 wlut[1u << LB];
+    u32 lane_excl[HUFD_DEC_LANES + 4]; /* symbols of the lanes in front, all slots' lanes back to back (a slot's lane 0 counts nothing) */
+    u32 wave_tot[HUFD_DEC_LANES / 64];
+    u32 slot_chunk[kPackMaxSlots];     /* the slot's chunk, or HUFD_NONE32: nothing to do for the slot here */
+    u32 slot_full[kPackMaxSlots];      /* ... its whole lanes */
+    u8 dump[512];                      /* where a chain that has nothing to emit writes */
+    __attribute__((aligned(16))) u8 stage[16]; /* slots x emit_pack_stage_bytes(stage_limit) */
+};
+__host__ __device__ constexpr u32 emit_pack_stage_bytes(u32 stage_limit) {
+    return (stage_limit + 32u + 15u) & ~15u;
+}
+
+template <u32 LB, u32 SURE>
+__global__ __launch_bounds__(kEmitFastThreads, 6) void dec_emit_pack_kernel(
+    hufd_tables tb,
+    const hufd_chunk_rec *chunk_rec,
+    const u32 *tail_chunks,
+    u32 n_tail,
+    u32 width,  /* lanes a slot (dec_sync_pack's) */
+    u32 slots,  /* slots a workgroup: what its threads and its LDS hold */
+    const u8 *d_in,
+    u8 *d_out,
+    const u16 *cp_tab,
+    const u16 *lane_count,
+    const u8 *chunk_regular,
+    const u32 *chunk_fn,
+    const u32 *chunk_entry,
+    const u64 *chunk_base,
+    u32 *slow_list, /* chunks left to dec_emit_kernel */
+    u32 *slow_count,
+    u32 stage_limit /* symbols a slot's stage holds */) {
+
+    emit_pack_shared<LB> &sh = *reinterpret_cast<emit_pack_shared<LB> *>(dyn_lds);
+    const u32 ns = tb.n_states;
+    const u32 t = threadIdx.x;
+    const u32 half = (width + 1) / 2, slot_threads = kQuarters * half, slot_lanes = 2 * half;
+    const u32 slot = t / slot_threads, tt = t % slot_threads;
+    const u32 q = tt % kQuarters;
+    const u32 lanes[kEmitChains] = {2 * (tt / kQuarters), 2 * (tt / kQuarters) + 1};
+    constexpr u32 kLutPerThread = ((1u << LB) + kEmitFastThreads - 1) / kEmitFastThreads;
+    u32 lut_raw[kLutPerThread];
+#pragma unroll
+    for (u32 j = 0; j < kLutPerThread; ++j) {
+        const u32 i = t + j * kEmitFastThreads;
+        lut_raw[j] = i < (1u << LB) ? tb.dec_lut[i >> (LB - tb.lut_bits)] : 0u;
+    }
+    const u32 li = blockIdx.x * slots + slot;
+    const bool have = slot < slots && li < n_tail;
+    const u32 c = have ? tail_chunks[li] : 0u;
+    const u32 centry = have ? chunk_entry[c] : 0u;
+    const u32 s0 = centry & 0xFFu;
+    const hufd_chunk_rec rec = chunk_rec[c];
+    const u64 valid = rec.valid;
+    const u32 n_full = valid >= 8u ? (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES) : 0u;
+    const u64 cbase = have ? chunk_base[c] : 0;
+    const u16 *cpt = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES;
+    const u32 merged_row = (kQuarters - 1) * HUFD_DEC_LANES;
+    const u32 f0 = have ? chunk_fn[(u64)c * ns + s0] : 0u;
+    const u32 chunk_symbols = wide_count(f0);
+    const u32 regular = have ? chunk_regular[c] : 0u;
+    /* (the stream ended before this chunk; fewer than 136 bytes: dec_emit_tail does the whole chunk) */
+    const bool wanted = have && (centry & 0x100u) != 0 && regular != 3;
+    const bool fits = wanted && regular == 2 && ((cpt[merged_row] >> s0) & 1u) != 0 && cbase + chunk_symbols <= rec.out_cap;
+    const bool fast = fits && chunk_symbols + 16 <= stage_limit && n_full + 2 <= slot_lanes &&
+                      (lds_offset_of(sh.wlut) & ((4u << LB) - 1u)) == 0 && SURE == row_walk(LB, tb.max_bits).sure;
+    if (tt == 0 && slot < kPackMaxSlots) {
+        sh.slot_chunk[slot] = fast ? c : HUFD_NONE32;
+        sh.slot_full[slot] = n_full;
+        if (wanted && !fast) {
+            slow_list[atomicAdd(slow_count, 1u)] = c;
+        }
+    }
+
+    /* my quarters: rows 8q .. 8q+7 and the word after them */
+    constexpr u32 kRows = kSubWords / kQuarters;
+    u32 w[kEmitChains][kRows + 1];
+    u32 my_cp[kEmitChains], next_cp[kEmitChains], entry_state[kEmitChains], cnt[kEmitChains];
+    bool whole[kEmitChains];
+#pragma unroll
+    for (u32 ch = 0; ch < kEmitChains; ++ch) {
+        whole[ch] = fast && lanes[ch] < n_full;
+#pragma unroll
+        for (u32 j = 0; j <= kRows; ++j) {
+            w[ch][j] = 0;
+        }
+        my_cp[ch] = next_cp[ch] = entry_state[ch] = cnt[ch] = 0;
+        if (whole[ch]) {
+            const u8 *sub = d_in + rec.src_off + (u64)lanes[ch] * HUFD_DEC_SUB_BYTES;
+            const unaligned_uint4 *p = reinterpret_cast<const unaligned_uint4 *>(sub + q * kRows * 4);
+#pragma unroll
+            for (u32 j = 0; j < kRows / 4; ++j) {
+                const unaligned_uint4 v = p[j];
+                w[ch][4 * j + 0] = __builtin_bswap32(v.x);
+                w[ch][4 * j + 1] = __builtin_bswap32(v.y);
+                w[ch][4 * j + 2] = __builtin_bswap32(v.z);
+                w[ch][4 * j + 3] = __builtin_bswap32(v.w);
+            }
+            w[ch][kRows] = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(sub + (q + 1) * kRows * 4)->x);
+            my_cp[ch] = q ? cpt[(q - 1) * HUFD_DEC_LANES + lanes[ch]] : 0u;
+            next_cp[ch] = q + 1 < kQuarters ? cpt[q * HUFD_DEC_LANES + lanes[ch]] : 0u;
+            entry_state[ch] = lanes[ch] ? (u32)(cpt[merged_row + lanes[ch] - 1] >> 12) : s0;
+            cnt[ch] = lane_count[(u64)c * HUFD_DEC_LANES + lanes[ch]];
+        }
+    }
+#pragma unroll
+    for (u32 j = 0; j < kLutPerThread; ++j) {
+        const u32 i = t + j * kEmitFastThreads;
+        const u32 e = lut_raw[j];
+        const u32 len = e & 0xFFu;
+        if (i < (1u << LB)) {
+            sh.wlut[i] = ((e >> 8) << 16) | ((0x10000u - (len ? len : kWalkDeadLen)) & 0xFFFFu);
+        }
+    }
+    __syncthreads();
+
+    /* where every sub-chunk's symbols go: one scan over all slots' lanes, back to back (thread g < 256 = lane g % slot_lanes
+     * of slot g / slot_lanes); the two sub-chunks a stream can end in count (dec_sync_tail wrote their symbols), a slot's
+     * lane 0 does not (its count follows from the chunk's total) */
+    u32 incl = 0, own = 0;
+    if (t < HUFD_DEC_LANES) {
+        const u32 sa = t / slot_lanes, la = t % slot_lanes;
+        const u32 ca = sa < slots && sa < kPackMaxSlots ? sh.slot_chunk[sa] : HUFD_NONE32;
+        own = ca != HUFD_NONE32 && la != 0 && la < sh.slot_full[sa] + 2 && la < HUFD_DEC_LANES ? lane_count[(u64)ca * HUFD_DEC_LANES + la] : 0u;
+        incl = wave_inclusive_sum(own, t & (kWave - 1));
+        if ((t & (kWave - 1)) == kWave - 1) {
+            sh.wave_tot[t / kWave] = incl;
+        }
+    }
+    __syncthreads();
+    if (t < HUFD_DEC_LANES) {
+        u32 before = 0;
+#pragma unroll
+        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
+            before += wv < t / kWave ? sh.wave_tot[wv] : 0u;
+        }
+        sh.lane_excl[t] = before + incl - own;
+        if (t == HUFD_DEC_LANES - 1) {
+            sh.lane_excl[HUFD_DEC_LANES] = before + incl;
+        }
+    }
+    __syncthreads();
+    if (!fast) {
+        return; /* (the barrier behind the walk counts the waves that are still there) */
+    }
+
+    const u32 base_g = slot * slot_lanes; /* my slot's lane 0 among all slots' lanes */
+    const u32 slot_first = sh.lane_excl[base_g], slot_end = sh.lane_excl[base_g + slot_lanes];
+    const u32 first_count = chunk_symbols - (slot_end - slot_first); /* sub-chunk 0, entered in state s0 */
+    const auto base_of = [&](u32 l) { return l ? first_count + sh.lane_excl[base_g + l] - slot_first : 0u; };
+    u8 *out_ptr = d_out + rec.out_off + cbase;
+    const u32 mis = (u32)((uintptr_t)out_ptr & 15u);
+    const row_walk rw(LB, tb.max_bits);
+    u8 *const lds_bytes = reinterpret_cast<u8 *>(&sh);
+    const u32 stage_at = (u32)(sh.stage - lds_bytes) + slot * emit_pack_stage_bytes(stage_limit), dump_at = (u32)(sh.dump - lds_bytes);
+    u32 st[kEmitChains], dst[kEmitChains];
+    bool idle[kEmitChains]; /* a chain with nothing to emit still walks (the two go in step): over zeros, into the dump */
+    bool extend = false;
+#pragma unroll
+    for (u32 ch = 0; ch < kEmitChains; ++ch) {
+        const u32 lane_n = lanes[ch] ? cnt[ch] : first_count;
+        const bool mine = whole[ch] && (q == 0 || (my_cp[ch] & 0x8000u) != 0);
+        const u32 first = q ? lane_n - (my_cp[ch] & 0x7FFu) : 0u;
+        st[ch] = rw.state_at(q ? (my_cp[ch] >> 11) & 15u : entry_state[ch], 0);
+        dst[ch] = mine ? stage_at + mis + base_of(lanes[ch]) + first : dump_at;
+        idle[ch] = !mine;
+        if (ch == 0) {
+            extend = whole[0] && q == 0 && lanes[0] == 0 && !(next_cp[ch] & 0x8000u);
+        }
+    }
+    const u32 table = lds_offset_of(sh.wlut);
+    if (!__all(idle[0] && idle[1])) {
+#pragma unroll
+        for (u32 r = 0; r < kRows; ++r) {
+            u64 pair[kEmitChains];
+#pragma unroll
+            for (u32 ch = 0; ch < kEmitChains; ++ch) {
+                pair[ch] = ((u64)w[ch][r] << 32) | w[ch][r + 1];
+            }
+#pragma unroll
+            for (u32 i = 0; i < SURE; ++i) { /* the codes that are certain to start in this row, the two chains in turn */
+                u32 e[kEmitChains];
+#pragma unroll
+                for (u32 ch = 0; ch < kEmitChains; ++ch) {
+                    e[ch] = lds_word_at(((u32)(pair[ch] >> (st[ch] & 63u)) & rw.mask) | table);
+                }
+#pragma unroll
+                for (u32 ch = 0; ch < kEmitChains; ++ch) {
+                    lds_bytes[dst[ch]++] = (u8)(e[ch] >> 16);
+                    st[ch] += e[ch];
+                }
+            }
+#pragma unroll
+            for (u32 ch = 0; ch < kEmitChains; ++ch) {
+                while ((st[ch] & 0xFFFFu) > rw.thr) {
+                    const u32 e = lds_word_at(((u32)(pair[ch] >> (st[ch] & 63u)) & rw.mask) | table);
+                    lds_bytes[dst[ch]++] = (u8)(e >> 16);
+                    st[ch] += e;
+                }
+                st[ch] += 32u;
+                /* an idle chain starts every row afresh: whatever it decodes, its state and its writes stay in bounds */
+                st[ch] = idle[ch] ? rw.state_at(0, 0) : st[ch];
+                dst[ch] = idle[ch] ? dump_at : dst[ch];
+            }
+        }
+    }
+    if (extend) {
+        /* rare: sub-chunk 0 on through the second quarter, words straight from memory */
+        u32 hi = w[0][kRows];
+        for (u32 r = kRows; r < 2 * kRows; ++r) {
+            const u32 lo = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(d_in + rec.src_off + (r + 1) * 4)->x);
+            const u64 pair = ((u64)hi << 32) | lo;
+            while ((st[0] & 0xFFFFu) > rw.thr) {
+                const u32 e = lds_word_at(((u32)(pair >> (st[0] & 63u)) & rw.mask) | table);
+                lds_bytes[dst[0]++] = (u8)(e >> 16);
+                st[0] += e;
+            }
+            st[0] += 32u;
+            hi = lo;
+        }
+    }
+    /* (the symbols of the one or two sub-chunks behind the whole lanes are dec_emit_tail's, straight to memory) */
+    __syncthreads();
+
+    {
+        /* my slot's stage byte b belongs at (out_ptr - mis) + b: whole 16-byte rows go out aligned */
+        u8 *gbase = out_ptr - mis;
+        const u8 *stage = lds_bytes + stage_at;
+        const u32 lo = mis, hi = mis + base_of(n_full); /* (the whole lanes' symbols: n_full + 2 <= slot_lanes) */
+        const u32 row_lo = (lo + 15) >> 4, row_hi = hi >> 4;
+        if (row_lo <= row_hi) {
+            /* (fewer than 16 bytes in front of the first whole row and behind the last: one byte a thread at most) */
+            if (lo + tt < row_lo * 16) {
+                gbase[lo + tt] = stage[lo + tt];
+            }
+            for (u32 r = row_lo + tt; r < row_hi; r += slot_threads) {
+                *reinterpret_cast<uint4 *>(gbase + (u64)r * 16) = *reinterpret_cast<const uint4 *>(stage + r * 16);
+            }
+            if (row_hi * 16 + tt < hi) {
+                gbase[row_hi * 16 + tt] = stage[row_hi * 16 + tt];
+            }
+        } else if (lo + tt < hi) {
+            gbase[lo + tt] = stage[lo + tt]; /* no whole row: fewer than 31 bytes */
+        }
+    }
+}
+
 /*
  * The symbols of the one or two sub-chunks a stream ends in, for the chunks dec_emit_fast<TAIL> took: one THREAD
  * per chunk, straight to memory (dec_sync_tail's walk again, this time keeping the symbols), and the record of
@@ -8988,7 +9245,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         const uint32_t sure = row_walk(a->tables.lut_bits <= 10 ? 10u : 12u, a->tables.max_bits).sure;
         bool lean = false;
         /* the chunks streams end in: several to a workgroup where they are short and many (dec_sync_pack) */
-        const uint32_t pack_width = a->tail_lanes < 16u ? 16u : a->tail_lanes;
+        const uint32_t pack_width = a->tail_lanes + 2u < 16u ? 16u : a->tail_lanes + 2u; /* (+ the two sub-chunks a stream can end in: dec_emit_pack's scan) */
         const bool pack = a->old_sync == 0 && a->n_tail >= kPackMinChunks && pack_width <= HUFD_DEC_LANES / 2;
         const uint32_t pack_slots = HUFD_DEC_LANES / pack_width;
 #define HUFK_LAUNCH_SYNC_LEAN(LBV, SUREV)                                                                               \
@@ -9286,17 +9543,51 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             (void)hipEventRecord((hipEvent_t)a->fork_event, st);
             (void)hipStreamWaitEvent((hipStream_t)a->side_stream, (hipEvent_t)a->fork_event, 0);
         }
-        /* the stage of the launch for the chunks streams end in: what the plan says such a chunk can hold at most */
-        const uint32_t tail_stage = a->tail_stage_bytes >= 4096 && a->tail_stage_bytes < HUFD_DEC_STAGE_BYTES
-                                        ? (a->tail_stage_bytes + 255u) & ~255u
-                                        : HUFD_DEC_STAGE_BYTES;
         /* (chunks inside a stream: with the coder's number of certain steps a row compiled in, where there is such a build) */
         const uint32_t emit_sure = a->old_sync == 1 ? 0u : row_walk(a->tables.lut_bits <= 10 ? 10u : 12u, a->tables.max_bits).sure;
+        /* the chunks streams end in, where they are short and many: several to a workgroup (dec_emit_pack, as dec_sync_pack) */
+        const uint32_t epack_width = a->tail_lanes + 2u < 16u ? 16u : a->tail_lanes + 2u;
+        const uint32_t epack_threads = kQuarters * ((epack_width + 1) / 2);
+        const uint32_t epack_stage = emit_pack_stage_bytes((a->tail_stage_bytes + 255u) & ~255u);
+        const uint32_t epack_fixed = (uint32_t)(a->tables.lut_bits <= 10 ? sizeof(emit_pack_shared<10>) : sizeof(emit_pack_shared<12>));
+        uint32_t epack_slots = kEmitFastThreads / epack_threads;
+        epack_slots = epack_slots > kPackMaxSlots ? kPackMaxSlots : epack_slots;
+        epack_slots = epack_slots * epack_stage + epack_fixed > 60u * 1024u ? (60u * 1024u - epack_fixed) / epack_stage : epack_slots;
+        const bool epack = a->old_sync == 0 && a->n_tail >= kPackMinChunks && epack_width <= HUFD_DEC_LANES / 2 && a->tail_stage_bytes &&
+                           epack_slots >= 2 && emit_sure >= 2 && emit_sure <= (a->tables.lut_bits <= 10 ? 5u : 3u);
+        /* the stage of the launch for the chunks streams end in: what the plan says such a chunk can hold at most */
+        const uint32_t tail_stage = epack ? (a->tail_stage_bytes + 255u) & ~255u
+                                    : a->tail_stage_bytes >= 4096 && a->tail_stage_bytes < HUFD_DEC_STAGE_BYTES
+                                        ? (a->tail_stage_bytes + 255u) & ~255u
+                                        : HUFD_DEC_STAGE_BYTES;
+#define HUFK_LAUNCH_EMIT_PACK(LBV, SUREV)                                                                               \
+    hipLaunchKernelGGL(                                                                                                \
+        (dec_emit_pack_kernel<LBV, SUREV>), dim3((a->n_tail + epack_slots - 1) / epack_slots), dim3(kEmitFastThreads),   \
+        (uint32_t)sizeof(emit_pack_shared<LBV>) + epack_slots * epack_stage, tst, a->tables, a->chunk_rec, a->tail_chunks, \
+        a->n_tail, epack_width, epack_slots, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab,              \
+        (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry, \
+        (const u64 *)a->chunk_base, a->emit_list, a->emit_count, tail_stage)
         /* chunks of short codes that hold more symbols than dec_emit_fast's stage: dec_emit_big where there is a build of
          * it for the coder and the chunk lies inside its stream; the others take the long way (dec_emit) */
         const bool has_big = a->tables.lut_bits <= 10 ? emit_sure >= 2 && emit_sure <= 5 : emit_sure >= 2 && emit_sure <= 3;
+        if (a->n_tail && epack) {
+            if (a->tables.lut_bits <= 10) {
+                switch (emit_sure) {
+                    case 2: HUFK_LAUNCH_EMIT_PACK(10, 2); break;
+                    case 3: HUFK_LAUNCH_EMIT_PACK(10, 3); break;
+                    case 4: HUFK_LAUNCH_EMIT_PACK(10, 4); break;
+                    default: HUFK_LAUNCH_EMIT_PACK(10, 5); break;
+                }
+            } else {
+                switch (emit_sure) {
+                    case 2: HUFK_LAUNCH_EMIT_PACK(12, 2); break;
+                    default: HUFK_LAUNCH_EMIT_PACK(12, 3); break;
+                }
+            }
+        }
+#undef HUFK_LAUNCH_EMIT_PACK
         if (a->tables.lut_bits <= 10) {
-            if (a->n_tail) {
+            if (a->n_tail && !epack) {
                 switch (emit_sure) {
                     case 2: HUFK_LAUNCH_EMIT_FAST(10, true, 2, a->n_tail, tst); break;
                     case 3: HUFK_LAUNCH_EMIT_FAST(10, true, 3, a->n_tail, tst); break;
@@ -9315,7 +9606,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
                 }
             }
         } else {
-            if (a->n_tail) {
+            if (a->n_tail && !epack) {
                 switch (emit_sure) {
                     case 2: HUFK_LAUNCH_EMIT_FAST(12, true, 2, a->n_tail, tst); break;
                     case 3: HUFK_LAUNCH_EMIT_FAST(12, true, 3, a->n_tail, tst); break;

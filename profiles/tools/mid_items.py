@@ -17,7 +17,7 @@ coder = lib.aws_huffman_amd_table_coder_new(patterns, lens)
 oracle = harness.oracle_codec()
 ocoder = oracle.lib.oracle_table_coder_new(patterns, lens)
 eng = harness.Engine(lib, coder)
-total = 128 << 20
+total = int(os.environ.get("MID_ITEMS_TOTAL_MIB", "128")) << 20  # (a smaller batch has fewer items: a class may then leave the thread-per-item road)
 data = harness.splitmix64_bytes(6, total)
 d_in, d_back = eng.alloc(total), eng.alloc(total + 64)
 eng.upload(d_in, data)
