@@ -3,7 +3,7 @@
 every result is compared with the CPU oracle, bit for bit.  Not part of the timed or graded runs: a soak for the
 paths the seeded tests visit once.
 
-  usage: fuzz_rounds.py [seconds=240] [first_seed=1000]
+  usage: fuzz_rounds.py [seconds=240] [first_seed=1000] [only-rounds-named-like]
 """
 import os
 import sys
@@ -17,6 +17,7 @@ import parity_cases as pc  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+only = sys.argv[3] if len(sys.argv) > 3 else ""  # a substring: only the rounds whose names hold it
 lib = harness.load_product()
 assert lib.aws_huffman_amd_device_count() >= 1
 w = pc.World(harness.oracle_codec(), harness.Codec(lib, "aws_"))
@@ -40,7 +41,13 @@ rounds = [
     ("wide_long_code_items", lambda s: pc.wide_long_code_items(w, seed=s) if s % 3 == 0 else None),
     ("fixed_length_coders", lambda s: pc.fixed_length_coders(w, seed=s) if s % 3 == 1 else None),
     ("damaged_long_streams", lambda s: pc.damaged_long_streams(w, seed=s) if s % 8 == 0 else None),  # 10 M symbols: now and then
+    # round 4: several short end-of-stream chunks a workgroup (dec_sync_pack, dec_emit_pack), plans made on the device
+    ("mid_sized_items", lambda s: pc.mid_sized_items(w, n_items=120, seed=s, engine=eng, modes=(None,))),
+    ("mid_sized_items narrow", lambda s: pc.mid_sized_items(w, n_items=90, seed=s, engine=eng, modes=(None,), longest=1900)),
+    ("many_header_sized_items", lambda s: pc.many_header_sized_items(w, n_items=4200, seed=s, engine=eng) if s % 2 == 0 else None),
+    ("null_empty_cursors", lambda s: pc.null_empty_cursors(w, seed=s) if s % 4 == 0 else None),
 ]
+rounds = [r for r in rounds if only in r[0]]
 t0 = time.time()
 done = failed = 0
 while time.time() - t0 < budget:

@@ -200,6 +200,8 @@ __global__ __launch_bounds__(1024, 8) void walk_kernel(const u32 *words, u32 *ou
     if ((lane & 63) == 0) clocks[(blockIdx.x * blockDim.x + lane) >> 6] = t1 - t0;
 }
 
+struct __attribute__((packed, aligned(1))) u32u { u32 v; };
+struct __attribute__((packed, aligned(1))) u16u { unsigned short v; };
 // ------------------------------------------------------------------ (iv) LDS stage stores
 // MODE 0: a byte per step at slot + count (lanes' slots 108 bytes apart: random banks), as dec_emit_fast
 // MODE 1: a dword every fourth step at an aligned slot (stride 33 dwords: a bank of its own per lane)
@@ -208,7 +210,7 @@ template <int MODE>
 __global__ __launch_bounds__(1024, 8) void stage_kernel(u32 *out, int iters, u64 *clocks) {
     const u32 lane = threadIdx.x;
     const u32 base = lds_base();
-    const u32 slot = base + (MODE == 0 ? lane * 27u : lane * 33u * 4u % (27u * 1024u));
+    const u32 slot = base + (MODE == 0 || MODE >= 3 ? lane * 27u : lane * 33u * 4u % (27u * 1024u));
     u32 acc = lane;
     const u64 t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
@@ -219,6 +221,13 @@ __global__ __launch_bounds__(1024, 8) void stage_kernel(u32 *out, int iters, u64
                 *(__attribute__((address_space(3))) u8 *)(uintptr_t)(slot + k) = (u8)acc;
             } else if (MODE == 1) {
                 if ((k & 3) == 3) *(__attribute__((address_space(3))) u32 *)(uintptr_t)(slot + (k & ~3u)) = acc;
+            } else if (MODE == 3) {
+                /* a row's three certain symbols as ONE unaligned dword store (the fourth byte is overwritten by what follows) */
+                if (k % 3 == 2) ((__attribute__((address_space(3))) u32u *)(uintptr_t)(slot + k - 2))->v = acc;
+            } else if (MODE == 4) {
+                /* two symbols as one unaligned 16-bit store, the third as a byte */
+                if (k % 3 == 1) ((__attribute__((address_space(3))) u16u *)(uintptr_t)(slot + k - 1))->v = (unsigned short)acc;
+                if (k % 3 == 2) *(__attribute__((address_space(3))) u8 *)(uintptr_t)(slot + k) = (u8)acc;
             } else {
                 *(__attribute__((address_space(3))) u32 *)(uintptr_t)(slot + (k & ~3u)) = acc;
             }
@@ -233,7 +242,6 @@ __global__ __launch_bounds__(1024, 8) void stage_kernel(u32 *out, int iters, u64
 // ------------------------------------------------------------------ (v) scattered global stores
 // every lane owns `run` bytes of the output (lanes back to back); MODE 0: unaligned dword stores, MODE 1: byte stores,
 // MODE 2: unaligned 8-byte stores 4 bytes apart (overlapping: a row's symbols with slack), MODE 3: 16-byte unaligned
-struct __attribute__((packed, aligned(1))) u32u { u32 v; };
 struct __attribute__((packed, aligned(1))) u64u { u64 v; };
 struct __attribute__((packed, aligned(1))) u128u { u32 x, y, z, w; };
 template <int MODE>
@@ -438,6 +446,8 @@ int main(int argc, char **argv) {
         run_stage<0>("byte per step");
         run_stage<1>("dword per 4 steps");
         run_stage<2>("dword per step");
+        run_stage<3>("unaligned dword per 3 steps");
+        run_stage<4>("unaligned 16 bits + a byte per 3 steps");
     }
     if (what == "all" || what == "scatter") {
         const u64 total = 1ull << 30;

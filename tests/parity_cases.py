@@ -1229,10 +1229,10 @@ def mid_sized_items(w, n_items=150, seed=101, engine=None, modes=(None, "lean-sy
             else:
                 enc = oracle_encode(w, inputs(rng, int(n), KINDS[i % 3]), eos=[None, 0x00, 0x5A][i % 3])
                 if kind == 3:
-                    enc = enc[:int(rng.integers(600, enc.size + 1))]  # cut
+                    enc = enc[:int(rng.integers(min(600, enc.size), enc.size + 1))]  # cut
                 if kind == 4:
                     enc = enc.copy()
-                    at = int(rng.integers(0, enc.size - 4))
+                    at = int(rng.integers(0, max(enc.size - 4, 1)))
                     enc[at:at + 4] = 0xFF  # ten one bits: no code
             fb = int(rng.integers(0, 8)) if kind == 5 else 0
             cap = [int(n) + 8, int(n), int(rng.integers(0, n)), int(n) + 8][i % 4]
