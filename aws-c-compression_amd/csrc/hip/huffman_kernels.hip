@@ -4487,8 +4487,10 @@ struct pack_shared {
     u16 hops[1u << LB]; /* 1 << code length of a window (the head it sends on), 0 = no code */
 };
 
+/* (six waves a SIMD: at the 64 registers that eight allow the kernel spills 22 -- and a spill inside these divergent walks
+ * is what once came back wrong, DESIGN.md 5 "Tried"; 80 registers, none) */
 template <u32 LB, u32 SURE>
-__global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_pack_kernel(
+__global__ __launch_bounds__(HUFD_DEC_LANES, 6) void dec_sync_pack_kernel(
     hufd_tables tb,
     const hufd_chunk_rec *chunk_rec,
     const u32 *tail_chunks,

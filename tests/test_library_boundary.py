@@ -170,22 +170,29 @@ def test_fails_loudly_without_a_gpu(product_lib):
     assert r.rc == -1 and r.err == 6 and r.consumed == 0 and r.produced == 0  # no silent CPU encode
 
 
-def test_onepass_kernels_scalar_registers(tmp_path):
-    """The grids of enc_onepass and dec_onepass are sized to be resident as a whole: by the occupancy query AND by the
-    scalar-register rule the query does not know (persistent_grid, kOnepassSgprs in csrc/hip/huffman_kernels.hip).  The
-    constant must cover what the build really uses: compiled to assembly here, `.sgpr_count` of every instantiation."""
+@pytest.fixture(scope="module")
+def kernel_listing(tmp_path_factory):
+    """The kernels compiled to assembly for gfx950 (the code-object metadata is what the two tests below read)."""
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
     src = os.path.join(harness.REPO, "aws-c-compression_amd", "csrc", "hip", "huffman_kernels.hip")
-    declared = int(re.search(r"constexpr uint32_t kOnepassSgprs = (\d+);", open(src).read()).group(1))
-    asm = tmp_path / "kernels.s"
+    asm = tmp_path_factory.mktemp("asm") / "kernels.s"
     subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
                            "-I" + os.path.join(harness.REPO, "include"), "-I" + os.path.join(harness.REPO, "include", "compat"),
                            src, "-o", str(asm)], stderr=subprocess.DEVNULL)
+    return src, open(asm).read()
+
+
+def test_onepass_kernels_scalar_registers(kernel_listing):
+    """The grids of enc_onepass and dec_onepass are sized to be resident as a whole: by the occupancy query AND by the
+    scalar-register rule the query does not know (persistent_grid, kOnepassSgprs in csrc/hip/huffman_kernels.hip).  The
+    constant must cover what the build really uses: `.sgpr_count` of every instantiation."""
+    src, listing = kernel_listing
+    declared = int(re.search(r"constexpr uint32_t kOnepassSgprs = (\d+);", open(src).read()).group(1))
     counts = {}
     name = None
-    for line in open(asm):
+    for line in listing.splitlines():
         m = re.match(r"\s+\.name:\s+(\S+)", line)
         if m:
             name = m.group(1)
@@ -194,3 +201,14 @@ def test_onepass_kernels_scalar_registers(tmp_path):
             counts[name] = int(m.group(1))
     assert len(counts) >= 6, counts
     assert max(counts.values()) <= declared, (declared, counts)
+
+
+def test_no_kernel_spills_vector_registers(kernel_listing):
+    """No kernel of the library has scratch memory or a spilled vector register (profiles/tools/spill_census.py prints
+    the same table): a value spilled inside these kernels' divergent walks once came back wrong, and a spill in a
+    look-back kernel waits for every poll in flight.  Scalar registers parked in vector lanes are not memory."""
+    _, listing = kernel_listing
+    rows = re.findall(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", listing, re.S)
+    assert len(rows) >= 100
+    bad = [(n, int(scratch), int(spills)) for n, scratch, spills in rows if int(scratch) or int(spills)]
+    assert not bad, bad
