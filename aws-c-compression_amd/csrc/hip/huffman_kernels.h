@@ -104,7 +104,8 @@ struct hufk_decode_args {
     struct hufd_dec_item_state *states; /* [n_items] scratch */
     struct hufd_dec_result *results;    /* [n_items] */
     uint32_t tail_stage_bytes; /* the most symbols a chunk that holds the end of a stream can decode to, +32 (0: unknown) */
-    uint32_t tail_lanes;       /* the most whole lanes (sub-chunks with 8 more bytes behind them) such a chunk has; 256: unknown */
+    uint32_t tail_lanes;       /* the most whole lanes (sub-chunks with 8 more bytes behind them) a NARROW such chunk has */
+    uint32_t n_tail_narrow;    /* the first so many of tail_chunks have at most HUFD_DEC_PACK_LANES whole lanes: they may share workgroups */
     uint32_t old_sync; /* 0: dec_sync_lean for the chunks it takes (the default); 1: dec_sync_fast for every chunk
                         * (AWS_HUFFMAN_AMD_DECODE=old-sync); 2: as 0 (=lean-sync); 3: dec_sync_bank where the decode table has up
                         * to 10 bits (=bank-sync: a length table per LDS bank, measured slower); 4: dec_sync_resident for the chunks inside

@@ -9248,19 +9248,23 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         bool lean = false;
         /* the chunks streams end in: several to a workgroup where they are short and many (dec_sync_pack) */
         const uint32_t pack_width = a->tail_lanes + 2u < 16u ? 16u : a->tail_lanes + 2u; /* (+ the two sub-chunks a stream can end in: dec_emit_pack's scan) */
-        const bool pack = a->old_sync == 0 && a->n_tail >= kPackMinChunks && pack_width <= HUFD_DEC_LANES / 2;
+        const bool pack = a->old_sync == 0 && a->n_tail_narrow >= kPackMinChunks && pack_width <= HUFD_DEC_LANES / 2;
         const uint32_t pack_slots = HUFD_DEC_LANES / pack_width;
+        /* (the plan lists the chunks with few whole lanes first: those go several to a workgroup, the others one each) */
+        const uint32_t n_packed = pack ? a->n_tail_narrow : 0u, n_single = a->n_tail - n_packed;
+        const u32 *single_chunks = a->tail_chunks + n_packed;
 #define HUFK_LAUNCH_SYNC_LEAN(LBV, SUREV)                                                                               \
-    if (a->n_tail && pack) {                                                                                           \
+    if (n_packed) {                                                                                                    \
         hipLaunchKernelGGL(                                                                                            \
-            (dec_sync_pack_kernel<LBV, SUREV>), dim3((a->n_tail + pack_slots - 1) / pack_slots), dim3(HUFD_DEC_LANES),  \
-            (uint32_t)sizeof(pack_shared<LBV>), tst, a->tables, a->chunk_rec, a->tail_chunks, a->n_tail, pack_width,    \
+            (dec_sync_pack_kernel<LBV, SUREV>), dim3((n_packed + pack_slots - 1) / pack_slots), dim3(HUFD_DEC_LANES),   \
+            (uint32_t)sizeof(pack_shared<LBV>), tst, a->tables, a->chunk_rec, a->tail_chunks, n_packed, pack_width,     \
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
             lean_long_list, lean_long_count);                                                                          \
-    } else if (a->n_tail) {                                                                                            \
+    }                                                                                                                  \
+    if (n_single) {                                                                                                    \
         hipLaunchKernelGGL(                                                                                            \
-            (dec_sync_lean_kernel<LBV, SUREV, true>), dim3(a->n_tail), dim3(HUFD_DEC_LANES),                            \
-            (uint32_t)sizeof(lean_shared<LBV>), tst, a->tables, a->chunk_rec, a->tail_chunks,                           \
+            (dec_sync_lean_kernel<LBV, SUREV, true>), dim3(n_single), dim3(HUFD_DEC_LANES),                             \
+            (uint32_t)sizeof(lean_shared<LBV>), tst, a->tables, a->chunk_rec, single_chunks,                            \
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
             a->slow_list, a->slow_count, lean_long_list, lean_long_count, (const u32 *)nullptr);                        \
     }                                                                                                                  \
@@ -9526,7 +9530,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     hipLaunchKernelGGL(                                                                                                \
         (dec_emit_fast_kernel<LBV, TAILV, SUREV>), dim3(GRID), dim3(kEmitFastThreads),                                  \
         emit_lds_bytes<LBV>(TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES), STREAMV, a->tables, a->chunk_rec,              \
-        a->tail_chunks, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab, (const u16 *)a->lane_count,       \
+        emit_single_chunks, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab, (const u16 *)a->lane_count,   \
         (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry,                           \
         (const u64 *)a->chunk_base, a->results, a->emit_list, a->emit_count,                                            \
         !TAILV && has_big ? a->dense_list : a->emit_list, !TAILV && has_big ? a->dense_count : a->emit_count,          \
@@ -9555,24 +9559,26 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         uint32_t epack_slots = kEmitFastThreads / epack_threads;
         epack_slots = epack_slots > kPackMaxSlots ? kPackMaxSlots : epack_slots;
         epack_slots = epack_slots * epack_stage + epack_fixed > 60u * 1024u ? (60u * 1024u - epack_fixed) / epack_stage : epack_slots;
-        const bool epack = a->old_sync == 0 && a->n_tail >= kPackMinChunks && epack_width <= HUFD_DEC_LANES / 2 && a->tail_stage_bytes &&
+        const bool epack = a->old_sync == 0 && a->n_tail_narrow >= kPackMinChunks && epack_width <= HUFD_DEC_LANES / 2 && a->tail_stage_bytes &&
                            epack_slots >= 2 && emit_sure >= 2 && emit_sure <= (a->tables.lut_bits <= 10 ? 5u : 3u);
         /* the stage of the launch for the chunks streams end in: what the plan says such a chunk can hold at most */
         const uint32_t tail_stage = epack ? (a->tail_stage_bytes + 255u) & ~255u
                                     : a->tail_stage_bytes >= 4096 && a->tail_stage_bytes < HUFD_DEC_STAGE_BYTES
                                         ? (a->tail_stage_bytes + 255u) & ~255u
                                         : HUFD_DEC_STAGE_BYTES;
+        const uint32_t e_packed = epack ? a->n_tail_narrow : 0u, e_single = a->n_tail - e_packed;
+        const u32 *emit_single_chunks = a->tail_chunks + e_packed; /* (the chunks streams end in that get a workgroup each) */
 #define HUFK_LAUNCH_EMIT_PACK(LBV, SUREV)                                                                               \
     hipLaunchKernelGGL(                                                                                                \
-        (dec_emit_pack_kernel<LBV, SUREV>), dim3((a->n_tail + epack_slots - 1) / epack_slots), dim3(kEmitFastThreads),   \
+        (dec_emit_pack_kernel<LBV, SUREV>), dim3((e_packed + epack_slots - 1) / epack_slots), dim3(kEmitFastThreads),    \
         (uint32_t)sizeof(emit_pack_shared<LBV>) + epack_slots * epack_stage, tst, a->tables, a->chunk_rec, a->tail_chunks, \
-        a->n_tail, epack_width, epack_slots, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab,              \
+        e_packed, epack_width, epack_slots, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab,               \
         (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry, \
         (const u64 *)a->chunk_base, a->emit_list, a->emit_count, tail_stage)
         /* chunks of short codes that hold more symbols than dec_emit_fast's stage: dec_emit_big where there is a build of
          * it for the coder and the chunk lies inside its stream; the others take the long way (dec_emit) */
         const bool has_big = a->tables.lut_bits <= 10 ? emit_sure >= 2 && emit_sure <= 5 : emit_sure >= 2 && emit_sure <= 3;
-        if (a->n_tail && epack) {
+        if (e_packed) {
             if (a->tables.lut_bits <= 10) {
                 switch (emit_sure) {
                     case 2: HUFK_LAUNCH_EMIT_PACK(10, 2); break;
@@ -9589,13 +9595,13 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         }
 #undef HUFK_LAUNCH_EMIT_PACK
         if (a->tables.lut_bits <= 10) {
-            if (a->n_tail && !epack) {
+            if (e_single) {
                 switch (emit_sure) {
-                    case 2: HUFK_LAUNCH_EMIT_FAST(10, true, 2, a->n_tail, tst); break;
-                    case 3: HUFK_LAUNCH_EMIT_FAST(10, true, 3, a->n_tail, tst); break;
-                    case 4: HUFK_LAUNCH_EMIT_FAST(10, true, 4, a->n_tail, tst); break;
-                    case 5: HUFK_LAUNCH_EMIT_FAST(10, true, 5, a->n_tail, tst); break;
-                    default: HUFK_LAUNCH_EMIT_FAST(10, true, 0, a->n_tail, tst); break;
+                    case 2: HUFK_LAUNCH_EMIT_FAST(10, true, 2, e_single, tst); break;
+                    case 3: HUFK_LAUNCH_EMIT_FAST(10, true, 3, e_single, tst); break;
+                    case 4: HUFK_LAUNCH_EMIT_FAST(10, true, 4, e_single, tst); break;
+                    case 5: HUFK_LAUNCH_EMIT_FAST(10, true, 5, e_single, tst); break;
+                    default: HUFK_LAUNCH_EMIT_FAST(10, true, 0, e_single, tst); break;
                 }
             }
             if (some_inside) {
@@ -9608,11 +9614,11 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
                 }
             }
         } else {
-            if (a->n_tail && !epack) {
+            if (e_single) {
                 switch (emit_sure) {
-                    case 2: HUFK_LAUNCH_EMIT_FAST(12, true, 2, a->n_tail, tst); break;
-                    case 3: HUFK_LAUNCH_EMIT_FAST(12, true, 3, a->n_tail, tst); break;
-                    default: HUFK_LAUNCH_EMIT_FAST(12, true, 0, a->n_tail, tst); break;
+                    case 2: HUFK_LAUNCH_EMIT_FAST(12, true, 2, e_single, tst); break;
+                    case 3: HUFK_LAUNCH_EMIT_FAST(12, true, 3, e_single, tst); break;
+                    default: HUFK_LAUNCH_EMIT_FAST(12, true, 0, e_single, tst); break;
                 }
             }
             if (some_inside) {

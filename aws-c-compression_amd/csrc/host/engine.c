@@ -470,6 +470,18 @@ static void enc_plan_release_device(struct aws_huffman_amd_encode_plan *p) {
 /* fewer items than this: the host's loop over them costs less than an allocation and a launch */
 #define PLAN_ON_DEVICE_MIN_ITEMS 4096u
 
+/* items per byte of the longest item from which a length class goes to a thread per item (HUFD_*_TINY_PER_BYTE;
+ * AWS_HUFFMAN_AMD_ENC_TINY_PER_BYTE / _DEC_: experiments) */
+static uint64_t tiny_per_byte(bool decode) {
+    static uint64_t cached[2] = {0, 0};
+    if (!cached[decode]) {
+        const char *text = getenv(decode ? "AWS_HUFFMAN_AMD_DEC_TINY_PER_BYTE" : "AWS_HUFFMAN_AMD_ENC_TINY_PER_BYTE");
+        const uint64_t v = text ? strtoull(text, NULL, 10) : 0;
+        cached[decode] = v ? v : (decode ? HUFD_DEC_TINY_PER_BYTE : HUFD_ENC_TINY_PER_BYTE);
+    }
+    return cached[decode];
+}
+
 struct item_stats { /* of a plan's items, from the pass that finds the thread-per-item limit */
     uint64_t shortest, longest;
     uint32_t worst_bits; /* largest first_bit (decode) / overflow_in.num_bits (encode) */
@@ -515,7 +527,7 @@ static uint64_t enc_tiny_limit(
         }
     }
     for (int c = 0; c < 2; ++c) {
-        if (longest[c] > HUFD_TINY_FEW_BYTES && count[c] >= HUFD_ENC_TINY_PER_BYTE * longest[c]) {
+        if (longest[c] > HUFD_TINY_FEW_BYTES && count[c] >= tiny_per_byte(false) * longest[c]) {
             return classes[c];
         }
     }
@@ -957,7 +969,10 @@ static bool dec_item_is_tiny(const struct aws_huffman_amd_decode_item *it, uint6
 
 /* the longest item a lone thread takes in this plan: see HUFD_DEC_TINY_PER_BYTE */
 static uint64_t dec_tiny_limit(const struct aws_huffman_amd_decode_item *items, size_t n_items, struct item_stats *st) {
-    static const uint64_t classes[2] = {HUFD_TINY_MANY_BYTES * 3 / 2, HUFD_DEC_TINY_BYTES};
+    /* (round 4: the upper class ended at 3 KiB of encoded bytes; since several short chunks share a workgroup -- dec_sync_pack,
+     * dec_emit_pack -- items above what one wave takes decode 1.8 .. 2.8 times faster through the chunk kernels than a thread each:
+     * 1 KiB items 0.82 -> 0.45 ms, 1.5 KiB 1.13 -> 0.41 ms per 128 MiB) */
+    static const uint64_t classes[2] = {HUFD_DEC_COOP_BYTES, HUFD_DEC_TINY_BYTES};
     /* (one pass over the items for both classes: a plan of a million header-sized items is read from memory once here) */
     uint64_t count[2] = {0, 0}, longest[2] = {0, 0};
     st->shortest = UINT64_MAX;
@@ -976,7 +991,7 @@ static uint64_t dec_tiny_limit(const struct aws_huffman_amd_decode_item *items, 
         }
     }
     for (int c = 0; c < 2; ++c) {
-        if (longest[c] > HUFD_TINY_FEW_BYTES && count[c] >= HUFD_DEC_TINY_PER_BYTE * longest[c]) {
+        if (longest[c] > HUFD_TINY_FEW_BYTES && count[c] >= tiny_per_byte(true) * longest[c]) {
             return classes[c];
         }
     }
@@ -1031,6 +1046,12 @@ static uint64_t dec_item_tiles(uint64_t chunks, uint64_t in_len) {
 }
 
 /* the plan's device arrays for this many items, chunks, large items and runs (grown, never shrunk); 0 or a HIP error */
+/* whole lanes of a chunk with `left` bytes of its item from its first byte on: sub-chunks with 8 more bytes behind them */
+static uint64_t whole_lanes_of(uint64_t left) {
+    const uint64_t in_chunk = left < HUFD_DEC_CHUNK_BYTES + 8u ? left : HUFD_DEC_CHUNK_BYTES + 8u;
+    return in_chunk >= 8 ? (in_chunk - 8) / HUFD_DEC_SUB_BYTES : 0;
+}
+
 static int dec_plan_reserve(struct aws_huffman_amd_decode_plan *p, size_t n_items, size_t n_chunks, size_t n_large, size_t n_runs) {
     const uint32_t ns = p->engine->tables.n_states;
     if (n_items > p->cap_items || n_chunks > p->cap_chunks || n_large > p->cap_large || n_runs > p->cap_runs) {
@@ -1122,6 +1143,7 @@ static int dec_plan_fill(
         p->wide_from = wide_min_bytes(0);
         p->tail_stage_bytes = 0;
         p->tail_lanes = 0;
+        p->n_tail_narrow = 0;
         p->n_items = (uint32_t)n_items;
         p->n_tiny = (uint32_t)n_items;
         return AWS_OP_SUCCESS;
@@ -1168,7 +1190,7 @@ static int dec_plan_fill(
         free(h_large);
         return aws_raise_error(AWS_ERROR_OOM);
     }
-    uint32_t chunk = 0, large = 0, run = 0, tail = 0, tiny = 0, deep = 0, tile = 0;
+    uint32_t chunk = 0, large = 0, run = 0, tail = 0, narrow = 0, wide = 0, tiny = 0, deep = 0, tile = 0;
     size_t deep_items = 0;
     for (size_t i = 0; i < n_items && eng->tables.deep_entries; ++i) {
         deep_items += !dec_item_is_tiny(&items[i], tiny_limit) && dec_item_is_deep(eng, &items[i], tiny_limit);
@@ -1254,14 +1276,22 @@ static int dec_plan_fill(
          * (chunk -> item and the records per chunk are made on the device: hufk_decode_plan_chunks) */
         for (uint32_t k = chunks > 2 ? chunks - 2 : 0; k < chunks; ++k) {
             if (src->in_len - (uint64_t)k * HUFD_DEC_CHUNK_BYTES < (uint64_t)HUFD_DEC_CHUNK_BYTES + 8u) {
-                h_tail[tail++] = chunk + k;
                 const uint64_t left = src->in_len - (uint64_t)k * HUFD_DEC_CHUNK_BYTES;
+                /* (the chunks with few whole lanes first: several of those share a workgroup, dec_sync_pack) */
+                if (whole_lanes_of(left) <= HUFD_DEC_PACK_LANES) {
+                    h_tail[narrow++] = chunk + k;
+                } else {
+                    h_tail[2 * (n_items ? n_items : 1) - ++wide] = chunk + k;
+                }
+                ++tail;
                 const uint32_t shortest = eng->tables.min_bits ? eng->tables.min_bits : 1;
                 uint64_t holds = left * 8 / shortest + 1;
                 holds = holds < src->out_capacity ? holds : src->out_capacity;
                 tail_stage = holds > tail_stage ? holds : tail_stage;
-                const uint64_t whole = left >= 8 ? (left - 8) / HUFD_DEC_SUB_BYTES : 0;
-                tail_lanes = whole > tail_lanes ? whole : tail_lanes;
+                const uint64_t whole = whole_lanes_of(left);
+                if (whole <= HUFD_DEC_PACK_LANES) {
+                    tail_lanes = whole > tail_lanes ? whole : tail_lanes;
+                }
             }
         }
         chunk += chunks;
@@ -1335,6 +1365,10 @@ static int dec_plan_fill(
     if (!err) {
         err = hufs_copy_h2d(p->d_runs, h_runs, n_runs * 2 * sizeof(uint32_t), eng->stream);
     }
+    /* (the wide chunks were listed from the back, last one first: behind the narrow ones, in their order) */
+    for (uint32_t k = 0; k < wide; ++k) {
+        h_tail[narrow + k] = h_tail[2 * (n_items ? n_items : 1) - 1 - k];
+    }
     if (!err) {
         err = hufs_copy_h2d(p->d_tail, h_tail, tail * sizeof(uint32_t), eng->stream);
     }
@@ -1386,6 +1420,7 @@ static int dec_plan_fill(
     p->n_res_tiles = res_tiles_kept;
     p->tail_stage_bytes = tail_stage + 32 < 0xFFFFFFFFu ? (uint32_t)tail_stage + 32u : 0u;
     p->tail_lanes = tail_lanes < HUFD_DEC_LANES ? (uint32_t)tail_lanes : HUFD_DEC_LANES;
+    p->n_tail_narrow = narrow;
     p->n_tiny = tiny;
     p->n_deep = deep;
     return AWS_OP_SUCCESS;
@@ -1456,6 +1491,7 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.n_tail = p->n_tail;
     a.tail_stage_bytes = p->tail_stage_bytes;
     a.tail_lanes = p->tail_lanes;
+    a.n_tail_narrow = p->n_tail_narrow;
     a.deep_items = p->d_tiny + (p->n_items - p->n_deep);
     a.n_deep = p->n_deep;
     a.wide = p->h_wide;
