@@ -482,6 +482,23 @@ static uint64_t tiny_per_byte(bool decode) {
     return cached[decode];
 }
 
+/* ... and for an encoder that packs ragged tiles in one pass (a wave a tile: ~1.6 ns an item whatever its length, where a lone
+ * thread needs ~0.7 us a symbol of the LONGEST item): the thread road pays from ~430 items per byte on -- measured,
+ * profiles/tools/mid_items.py: 447 K items of 300 B 1.02 ms by threads against 2.82 by tiles, but BASELINE configs[3]'s
+ * 16 384 resume items of ~320 symbols 251 us by threads where tiles take a tenth */
+static uint64_t enc_tiny_per_byte(const struct aws_huffman_amd_engine *eng) {
+    static uint64_t one_pass = 0;
+    if (!aws_huffman_amd_engine_encodes_in_one_pass(eng)) {
+        return tiny_per_byte(false);
+    }
+    if (!one_pass) {
+        const char *text = getenv("AWS_HUFFMAN_AMD_ENC_TINY_PER_BYTE");
+        const uint64_t v = text ? strtoull(text, NULL, 10) : 0;
+        one_pass = v ? v : HUFD_ENC_TINY_PER_BYTE_ONE_PASS;
+    }
+    return one_pass;
+}
+
 struct item_stats { /* of a plan's items, from the pass that finds the thread-per-item limit */
     uint64_t shortest, longest;
     uint32_t worst_bits; /* largest first_bit (decode) / overflow_in.num_bits (encode) */
@@ -527,7 +544,7 @@ static uint64_t enc_tiny_limit(
         }
     }
     for (int c = 0; c < 2; ++c) {
-        if (longest[c] > HUFD_TINY_FEW_BYTES && count[c] >= tiny_per_byte(false) * longest[c]) {
+        if (longest[c] > HUFD_TINY_FEW_BYTES && count[c] >= enc_tiny_per_byte(eng) * longest[c]) {
             return classes[c];
         }
     }
