@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG/tools
 mkdir -p "$OUT"
 cd "$ROOT"
-for tool in other_distributions tiny_items mid_items host_path_rate small_call_latency long_code_stream coder_survey graph_capture contention; do
+for tool in other_distributions tiny_items mid_items plan_time host_path_rate small_call_latency long_code_stream coder_survey graph_capture contention; do
     timeout 900 python3 profiles/tools/$tool.py > "$OUT/$tool.txt" 2> "$OUT/$tool.err"
     if [ "$tool" = long_code_stream ]; then  # and a stream long enough to fill the chip a workgroup per 32 KiB block
         timeout 900 python3 profiles/tools/$tool.py hpack_lengths 134217728 >> "$OUT/$tool.txt" 2>> "$OUT/$tool.err"
