@@ -27,6 +27,7 @@ int hufs_memset(void *dst, int byte, size_t size, void *stream);
 
 int hufs_stream_create(void **stream);
 int hufs_stream_destroy(void *stream);
+int hufs_device_sync(void); /* every stream of the current device */
 int hufs_stream_sync(void *stream);
 
 void *hufs_event_create(void);

@@ -82,6 +82,10 @@ int hufs_stream_destroy(void *stream) {
     return stream ? (int)hipStreamDestroy((hipStream_t)stream) : 0;
 }
 
+int hufs_device_sync(void) {
+    return (int)hipDeviceSynchronize();
+}
+
 int hufs_stream_sync(void *stream) {
     return (int)hipStreamSynchronize((hipStream_t)stream);
 }

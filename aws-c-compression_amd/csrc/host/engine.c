@@ -188,6 +188,7 @@ int aws_huffman_amd_engine_new(
         return aws_raise_error(AWS_ERROR_OOM);
     }
     pthread_mutex_init(&eng->one_lock, NULL);
+    pthread_mutex_init(&eng->spare_lock, NULL);
     eng->device = device;
     eng->coder = coder;
     eng->key_encode = (void *)coder->encode;
@@ -391,6 +392,20 @@ void aws_huffman_amd_engine_destroy(struct aws_huffman_amd_engine *eng) {
     if (eng->one_dec) {
         aws_huffman_amd_decode_plan_destroy(eng->one_dec);
     }
+    /* (the plans destroyed last, kept for the next *_plan_new: gone for good now) */
+    {
+        struct aws_huffman_amd_encode_plan *se = eng->spare_enc;
+        struct aws_huffman_amd_decode_plan *sd = eng->spare_dec;
+        eng->spare_enc = NULL;
+        eng->spare_dec = NULL;
+        eng->retiring = true;
+        if (se) {
+            aws_huffman_amd_encode_plan_destroy(se);
+        }
+        if (sd) {
+            aws_huffman_amd_decode_plan_destroy(sd);
+        }
+    }
     hufs_free(eng->one_in);
     hufs_free(eng->one_out);
     hufs_free(eng->mini_dev);
@@ -408,6 +423,7 @@ void aws_huffman_amd_engine_destroy(struct aws_huffman_amd_engine *eng) {
     free(eng->dec_lut_host);
     free(eng->deep_lut_host);
     pthread_mutex_destroy(&eng->one_lock);
+    pthread_mutex_destroy(&eng->spare_lock);
     free(eng);
 }
 
@@ -735,11 +751,30 @@ int aws_huffman_amd_encode_plan_new(
     size_t item_count) {
 
     *out_plan = NULL;
-    struct aws_huffman_amd_encode_plan *p = calloc(1, sizeof(*p));
-    if (!p) {
-        return aws_raise_error(AWS_ERROR_OOM);
+    /* the plan destroyed last, if the engine kept it: its device arrays serve again where they are large enough */
+    pthread_mutex_lock(&eng->spare_lock);
+    struct aws_huffman_amd_encode_plan *p = eng->spare_enc;
+    eng->spare_enc = NULL;
+    pthread_mutex_unlock(&eng->spare_lock);
+    if (p) {
+        /* its last launch may still run on the caller's stream (freeing the arrays used to wait for it) */
+        ON_DEVICE(eng->device);
+        if (hufs_device_sync()) {
+            aws_huffman_amd_encode_plan_destroy(p);
+            return aws_raise_error(AWS_ERROR_UNKNOWN);
+        }
+        p->last_input = NULL;
+        p->last_output = NULL;
+        p->last_single_pass = false;
+        p->last_timed_out = false;
+        p->look_back_timed_out = false;
+    } else {
+        p = calloc(1, sizeof(*p));
+        if (!p) {
+            return aws_raise_error(AWS_ERROR_OOM);
+        }
+        p->engine = eng;
     }
-    p->engine = eng;
     if (enc_plan_fill(p, items, item_count)) {
         aws_huffman_amd_encode_plan_destroy(p);
         return AWS_OP_ERR;
@@ -758,7 +793,18 @@ int aws_huffman_amd_encode_plan_reset(
 
 void aws_huffman_amd_encode_plan_destroy(struct aws_huffman_amd_encode_plan *p) {
     if (p) {
-        ON_DEVICE(p->engine->device);
+        struct aws_huffman_amd_engine *eng = p->engine;
+        /* the engine keeps ONE destroyed plan with its device arrays for the next aws_huffman_amd_encode_plan_new */
+        pthread_mutex_lock(&eng->spare_lock);
+        const bool keep = !eng->retiring && !eng->spare_enc && p->cap_items && p != eng->one_enc;
+        if (keep) {
+            eng->spare_enc = p;
+        }
+        pthread_mutex_unlock(&eng->spare_lock);
+        if (keep) {
+            return;
+        }
+        ON_DEVICE(eng->device);
         enc_plan_release_device(p);
         free(p);
     }
@@ -1450,11 +1496,24 @@ int aws_huffman_amd_decode_plan_new(
     size_t item_count) {
 
     *out_plan = NULL;
-    struct aws_huffman_amd_decode_plan *p = calloc(1, sizeof(*p));
-    if (!p) {
-        return aws_raise_error(AWS_ERROR_OOM);
+    pthread_mutex_lock(&eng->spare_lock);
+    struct aws_huffman_amd_decode_plan *p = eng->spare_dec;
+    eng->spare_dec = NULL;
+    pthread_mutex_unlock(&eng->spare_lock);
+    if (p) {
+        ON_DEVICE(eng->device);
+        if (hufs_device_sync()) {
+            aws_huffman_amd_decode_plan_destroy(p);
+            return aws_raise_error(AWS_ERROR_UNKNOWN);
+        }
+        p->one_pass_tried = 0;
+    } else {
+        p = calloc(1, sizeof(*p));
+        if (!p) {
+            return aws_raise_error(AWS_ERROR_OOM);
+        }
+        p->engine = eng;
     }
-    p->engine = eng;
     if (dec_plan_fill(p, items, item_count)) {
         aws_huffman_amd_decode_plan_destroy(p);
         return AWS_OP_ERR;
@@ -1472,6 +1531,16 @@ int aws_huffman_amd_decode_plan_reset(
 
 void aws_huffman_amd_decode_plan_destroy(struct aws_huffman_amd_decode_plan *p) {
     if (p) {
+        struct aws_huffman_amd_engine *eng = p->engine;
+        pthread_mutex_lock(&eng->spare_lock);
+        const bool keep = !eng->retiring && !eng->spare_dec && p->cap_items && p != eng->one_dec;
+        if (keep) {
+            eng->spare_dec = p;
+        }
+        pthread_mutex_unlock(&eng->spare_lock);
+        if (keep) {
+            return;
+        }
         ON_DEVICE(p->engine->device);
         dec_plan_release_device(p);
         hufs_free(p->d_wide_block);

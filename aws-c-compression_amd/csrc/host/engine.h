@@ -52,6 +52,13 @@ struct aws_huffman_amd_engine {
     uint8_t *mini_host; /* page-locked */
     uint8_t *mini_dev;
     bool mini_output; /* the last decode left its symbols in mini_host */
+    /* one destroyed plan of each kind, kept with its device arrays for the next *_plan_new of this engine to take over
+     * (a fresh plan otherwise pays some twenty-five device allocations: 1 .. 15 ms for BASELINE configs[3], where filling
+     * it takes 0.5 ms); freed with the engine */
+    pthread_mutex_t spare_lock;
+    struct aws_huffman_amd_encode_plan *spare_enc;
+    struct aws_huffman_amd_decode_plan *spare_dec;
+    bool retiring; /* the engine is being destroyed: plans are freed, not kept */
 };
 
 struct aws_huffman_amd_encode_plan {

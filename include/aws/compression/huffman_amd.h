@@ -126,6 +126,10 @@ int aws_huffman_amd_encode_plan_reset(
     const struct aws_huffman_amd_encode_item *items,
     size_t item_count);
 
+/* The engine keeps the device arrays of ONE destroyed plan of each kind (encode, decode) for its next
+ * aws_huffman_amd_*_plan_new, which waits for the device before it rewrites them (as freeing them did): in the steady
+ * state of make / launch / destroy a new plan costs what a reset costs and allocates nothing.  The arrays go back to the
+ * device with the engine; `plan` must not be used after this call either way. */
 AWS_COMPRESSION_API
 void aws_huffman_amd_encode_plan_destroy(struct aws_huffman_amd_encode_plan *plan);
 

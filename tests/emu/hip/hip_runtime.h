@@ -419,6 +419,9 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
 inline hipError_t hipStreamDestroy(hipStream_t) {
     return hipSuccess;
 }
+inline hipError_t hipDeviceSynchronize() {
+    return hipSuccess;
+}
 inline hipError_t hipStreamSynchronize(hipStream_t) {
     return hipSuccess;
 }

@@ -1242,6 +1242,41 @@ def mid_sized_items(w, n_items=150, seed=101, engine=None, modes=(None, "lean-sy
         eng.close()
 
 
+def plans_one_after_another(w, seed=107):
+    """An engine keeps the device arrays of ONE destroyed plan of each kind for the next aws_huffman_amd_*_plan_new: plans
+    of different shapes made, launched and destroyed after one another on one engine (larger after smaller and the other
+    way round, header-sized after chunked), and two plans alive at once of which only one can be an adopted one."""
+    eng = harness.Engine(w.product.lib, w.pcoder)
+    batched_device_api(w, n_items=5, item_len=40_000, engine=eng)
+    tiny_encode_items(w, n_items=300, seed=seed, engine=eng)
+    tiny_decode_items(w, n_items=300, seed=seed + 1, engine=eng)
+    mid_sized_items(w, n_items=30, seed=seed + 2, engine=eng, modes=(None,))
+    batched_device_api(w, n_items=12, item_len=3000, engine=eng)
+    rng = np.random.default_rng(seed)
+    data = inputs(rng, 50_000, "uniform")
+    enc = oracle_encode(w, data)
+    d_enc, d_a, d_b = eng.alloc(enc.size + 64), eng.alloc(data.size + 64), eng.alloc(data.size + 64)
+    eng.upload(d_enc, enc)
+    whole = [dict(in_offset=0, in_len=enc.size, out_offset=0, out_capacity=data.size)]
+    cut = [dict(in_offset=0, in_len=enc.size // 2, out_offset=3, out_capacity=data.size)]
+    a, b = eng.decode_plan(whole), eng.decode_plan(cut)
+    eng.decode_launch(a, d_enc, d_a)
+    eng.decode_launch(b, d_enc, d_b)
+    ra, rb = eng.decode_results(a, 1)[0], eng.decode_results(b, 1)[0]
+    assert ra[:3] == (0, 0, data.size) and np.array_equal(eng.download(d_a, data.size), data)
+    assert rb[0] == 0 and 0 < rb[2] < data.size and np.array_equal(eng.download(d_b, rb[2] + 3)[3:], data[:rb[2]])
+    eng.lib.aws_huffman_amd_decode_plan_destroy(a)
+    eng.lib.aws_huffman_amd_decode_plan_destroy(b)
+    a = eng.decode_plan(cut)  # (adopts what a was)
+    eng.fill(d_b, SENTINEL, data.size + 64)
+    eng.decode_launch(a, d_enc, d_b)
+    assert eng.decode_results(a, 1)[0] == rb and np.array_equal(eng.download(d_b, rb[2] + 3)[3:], data[:rb[2]])
+    eng.lib.aws_huffman_amd_decode_plan_destroy(a)
+    for d in (d_enc, d_a, d_b):
+        eng.free(d)
+    eng.close()
+
+
 def wide_long_code_items(w, n=150_000, seed=79, modes=(None, "wide-fails")):
     """Long items of coders with codes of more than 12 bits (decode through linked tables): a workgroup per 32 KiB
     block (dec_wide_*) from 64 KiB on here; with "wide-fails" those kernels give every item back to dec_deep."""
