@@ -5676,8 +5676,11 @@ constexpr u32 kWideGaveUp = 0;   /* set by dec_wide_scan */
 constexpr u32 kWideStopBlock = 1; /* the first block whose true walk stops (dec_wide_scan) */
 constexpr u32 kWideMoved = 2;    /* [+ j], j = 1 .. kWideFixes: a block was left differently in launch j */
 constexpr u32 kWideStops = 16;   /* [+ j]: the first block whose walk stops, as of launch j */
+constexpr u32 kWideFnRoad = 26;  /* set by dec_wide_fn_scan: the item went by transfer functions, dec_wide_fn_emit writes its symbols */
 constexpr u32 kWideCtlWords = 32;
-static_assert(kWideMoved + kWideFixes < kWideStops && kWideStops + kWideFixes < kWideCtlWords, "the ctl words do not overlap");
+static_assert(kWideMoved + kWideFixes < kWideStops && kWideStops + kWideFixes < kWideFnRoad && kWideFnRoad < kWideCtlWords,
+              "the ctl words do not overlap");
+constexpr u32 kWideEntries = 32; /* entry bits of a lane: a code has at most 32 bits, so the first code start in a lane is bit 0 .. 31 */
 
 struct dec_wide_layout {
     u64 ctl;        /* u32[kWideCtlWords] */
@@ -5688,6 +5691,10 @@ struct dec_wide_layout {
     u64 lane_start; /* u8[n_blocks][kDeepThreads] entry bit of the lane */
     u64 lane_exit;  /* u8[n_blocks][kDeepThreads] */
     u64 lane_count; /* u16[n_blocks][kDeepThreads] */
+    /* the road by transfer functions (dec_wide_fn_*), for an item whose walks never fall into step */
+    u64 fn_exit;    /* u8[n_blocks][kWideEntries][kDeepThreads] how a lane entered at bit e is left (kWideStop: its walk stops) */
+    u64 fn_block;   /* u64[n_blocks][kWideEntries] the same for a block: exit in the low byte, symbols above it */
+    u64 fn_entry;   /* u32[n_blocks] the bit the block is truly entered at */
     u64 bytes;
 };
 
@@ -5711,6 +5718,13 @@ __host__ __device__ inline dec_wide_layout dec_wide_layout_of(u64 n_blocks) {
     at += n_blocks * kDeepThreads;
     l.lane_count = at;
     at += n_blocks * kDeepThreads * 2;
+    at = (at + 63) & ~63ull;
+    l.fn_exit = at;
+    at += n_blocks * kWideEntries * kDeepThreads;
+    l.fn_block = at;
+    at += n_blocks * kWideEntries * 8;
+    l.fn_entry = at;
+    at += row;
     l.bytes = at;
     return l;
 }
@@ -5950,6 +5964,275 @@ __global__ __launch_bounds__(kDeepThreads) void dec_wide_emit_kernel(
     u64 cap_bit = kNoBit;
     const deep_walked r = deep_walk<true>(
         deep, nullptr, 0, d_in + it.in_off, it.in_len, lane_from + start, lane_to, d_out + it.out_off, first, it.out_cap, &cap_bit);
+    if (cap_bit != kNoBit) {
+        results[item].cap_bit = cap_bit;
+    }
+    if (r.why != HUFD_STOP_NONE) {
+        results[item].stop_kind = r.why;
+        results[item].stop_bit = r.pos;
+    }
+}
+
+/*
+ * The road for an item dec_wide_scan gave up: a stream whose walks never fall into step (code lengths that share a
+ * divisor: 9, 12 and 15 bits -- three phases, each of them valid for ever; an adversary builds one from HPACK's
+ * even-length codes alone).  There a block's exit is a FUNCTION of its entry, and settling sends the truth one block a
+ * launch.  So the functions are computed and composed (the generator's decision tree makes every code length equally
+ * cheap, source/huffman_generator/generator.c:154-214; this is what keeps every input on the whole chip here):
+ *   dec_wide_fn        a lane's function: from each of the entry bits 0 .. max_bits - 1 a short walk over the lane's
+ *                      first 64 bits (walks that will ever meet have mostly met by then), and from each DISTINCT bit
+ *                      these land on one walk to the end of the lane -- as many long walks as the stream has phases
+ *                      (three, in the example), not 32.  Exits to memory (a byte an entry and lane: a quarter of the
+ *                      block's own size), counts stay in LDS for the fold over the block's lanes: the block's function.
+ *   dec_wide_fn_scan   one workgroup: the blocks' functions composed in two levels (a thread a run of blocks, then the
+ *                      256 runs in turn, then every run again from its true entry): each block's true entry bit, the
+ *                      symbols in front of it, the first block whose walk stops, the item's result record.
+ *   dec_wide_fn_emit   a block's lanes get their entries from the block's (one thread follows the stored exits), count
+ *                      their own symbols with one walk and write them with a second.
+ * All three look at ctl first and do nothing for an item dec_wide_settle settled.
+ */
+struct wide_fn_shared {
+    u8 exit_of[kWideEntries][kDeepThreads];
+    u16 count_of[kWideEntries][kDeepThreads];
+    u32 scan[kDeepThreads];
+    u32 last_lane;
+    u32 pad[3];
+};
+
+__global__ __launch_bounds__(kDeepThreads) void dec_wide_fn_kernel(
+    hufd_tables tb, const hufd_dec_item *items, const u32 *the_item, const u8 *d_in, u8 *block) {
+
+    const hufd_dec_item it = items[the_item[0]];
+    const u64 n_blocks = (it.in_len + (u64)kDeepThreads * kDeepLaneBytes - 1) / ((u64)kDeepThreads * kDeepLaneBytes);
+    const dec_wide_layout lay = dec_wide_layout_of(n_blocks);
+    const u32 *ctl = reinterpret_cast<const u32 *>(block + lay.ctl);
+    if (!ctl[kWideGaveUp]) {
+        return;
+    }
+    wide_fn_shared &sh = *reinterpret_cast<wide_fn_shared *>(dyn_lds);
+    u32 *deep = reinterpret_cast<u32 *>(dyn_lds + sizeof(wide_fn_shared));
+    const u64 b = blockIdx.x;
+    const u32 l = threadIdx.x;
+    for (u32 i = l; i < tb.deep_entries; i += kDeepThreads) {
+        deep[i] = tb.deep_lut[i];
+    }
+    __syncthreads();
+    const u8 *in = d_in + it.in_off;
+    const u64 block_from = b * kDeepThreads * kDeepLaneBytes;
+    const u64 block_bytes = it.in_len - block_from < (u64)kDeepThreads * kDeepLaneBytes ? it.in_len - block_from : (u64)kDeepThreads * kDeepLaneBytes;
+    const u32 n_lanes = (u32)((block_bytes + kDeepLaneBytes - 1) / kDeepLaneBytes);
+    const u32 n_entries = tb.max_bits < kWideEntries ? tb.max_bits : kWideEntries;
+    const u64 lane_from = (block_from + (u64)l * kDeepLaneBytes) * 8, lane_to = lane_from + kDeepLaneBytes * 8;
+    constexpr u32 kShortBits = 64;
+    if (l < n_lanes) {
+        /* short walks: where the walk entered at bit e stands once it is past the lane's first 64 bits */
+        u32 landed = 0; /* bit o: some walk stands o bits past them */
+        for (u32 e = 0; e < n_entries; ++e) {
+            const deep_walked r = deep_walk<true>(deep, nullptr, 0, in, it.in_len, lane_from + e, lane_from + kShortBits, nullptr, 0, 0, nullptr);
+            const bool on = r.why == HUFD_STOP_NONE;
+            const u32 o = on ? (u32)(r.pos - (lane_from + kShortBits)) : 0u;
+            sh.exit_of[e][l] = (u8)(on ? o : kWideStop);
+            sh.count_of[e][l] = (u16)r.count;
+            landed |= on ? 1u << o : 0u;
+        }
+        /* one long walk from every bit a walk landed on; the entries that landed there take its exit and add its count.
+         * (An entry's record holds its landing bit until its long walk is done: the bits are taken in rising order and a
+         * record that is through is marked in `done`, so an exit is never taken for a landing bit.) */
+        u32 done = 0;
+        for (u32 e = 0; e < n_entries; ++e) {
+            done |= sh.exit_of[e][l] == kWideStop ? 1u << e : 0u;
+        }
+        while (landed) {
+            const u32 o = (u32)__builtin_ctz(landed);
+            landed &= landed - 1;
+            const deep_walked r = deep_walk<true>(deep, nullptr, 0, in, it.in_len, lane_from + kShortBits + o, lane_to, nullptr, 0, 0, nullptr);
+            const u32 ex = r.why == HUFD_STOP_NONE ? (u32)(r.pos - lane_to) : kWideStop;
+            for (u32 e = 0; e < n_entries; ++e) {
+                if (!((done >> e) & 1u) && sh.exit_of[e][l] == o) {
+                    sh.exit_of[e][l] = (u8)ex;
+                    sh.count_of[e][l] = (u16)(sh.count_of[e][l] + r.count);
+                    done |= 1u << e;
+                }
+            }
+        }
+    }
+    for (u32 e = (l < n_lanes ? n_entries : 0u); e < kWideEntries; ++e) {
+        sh.exit_of[e][l] = (u8)kWideStop; /* (no code start there, no lane there: never looked at as an entry that goes on) */
+        sh.count_of[e][l] = 0;
+    }
+    __syncthreads();
+    u8 *fn_exit = block + lay.fn_exit + b * (u64)kWideEntries * kDeepThreads;
+    for (u32 e = 0; e < kWideEntries; ++e) {
+        fn_exit[e * kDeepThreads + l] = sh.exit_of[e][l];
+    }
+    /* the block's function: thread e follows entry e through the lanes */
+    if (l < kWideEntries) {
+        u32 at = l < n_entries ? l : kWideStop;
+        u64 symbols = 0;
+        for (u32 k = 0; k < n_lanes && at != kWideStop; ++k) {
+            symbols += sh.count_of[at][k];
+            at = sh.exit_of[at][k];
+        }
+        reinterpret_cast<u64 *>(block + lay.fn_block)[b * kWideEntries + l] = (symbols << 8) | at;
+    }
+}
+
+constexpr u32 kWideFnScanThreads = 256;
+struct wide_fn_scan_shared {
+    u64 count_of[kWideFnScanThreads][kWideEntries + 1]; /* (+ 1: the threads' rows start in different banks) */
+    u8 exit_of[kWideFnScanThreads][kWideEntries];
+    u32 seg_entry[kWideFnScanThreads];
+    u64 seg_base[kWideFnScanThreads];
+    u64 stop_block;
+    u64 total;
+};
+
+__global__ __launch_bounds__(kWideFnScanThreads) void dec_wide_fn_scan_kernel(
+    const hufd_dec_item *items, const u32 *the_item, u8 *block, hufd_dec_item_state *states, hufd_dec_result *results, u32 fails) {
+
+    const u32 item = the_item[0];
+    const hufd_dec_item it = items[item];
+    const u64 n_blocks = (it.in_len + (u64)kDeepThreads * kDeepLaneBytes - 1) / ((u64)kDeepThreads * kDeepLaneBytes);
+    const dec_wide_layout lay = dec_wide_layout_of(n_blocks);
+    u32 *ctl = reinterpret_cast<u32 *>(block + lay.ctl);
+    if (!ctl[kWideGaveUp] || fails >= 2) {
+        return; /* (fails >= 2: this road gives the item up as well, for the test of dec_deep behind it) */
+    }
+    wide_fn_scan_shared &sh = *reinterpret_cast<wide_fn_scan_shared *>(dyn_lds);
+    const u32 t = threadIdx.x;
+    const u64 *fn_block = reinterpret_cast<const u64 *>(block + lay.fn_block);
+    u32 *fn_entry = reinterpret_cast<u32 *>(block + lay.fn_entry);
+    u64 *base = reinterpret_cast<u64 *>(block + lay.base);
+    const u64 per = (n_blocks + kWideFnScanThreads - 1) / kWideFnScanThreads;
+    const u64 lo = t * per < n_blocks ? t * per : n_blocks, hi = lo + per < n_blocks ? lo + per : n_blocks;
+    /* my run of blocks as a function of the bit it is entered at */
+    for (u32 e = 0; e < kWideEntries; ++e) {
+        u32 at = e;
+        u64 symbols = 0;
+        for (u64 k = lo; k < hi && at != kWideStop; ++k) {
+            const u64 f = fn_block[k * kWideEntries + at];
+            symbols += f >> 8;
+            at = (u32)(f & 0xFFu);
+        }
+        sh.exit_of[t][e] = (u8)at;
+        sh.count_of[t][e] = symbols;
+    }
+    if (t == 0) {
+        sh.stop_block = n_blocks;
+    }
+    __syncthreads();
+    if (t == 0) {
+        u32 at = it.first_bit;
+        u64 symbols = 0;
+        for (u32 k = 0; k < kWideFnScanThreads; ++k) {
+            sh.seg_entry[k] = at;
+            sh.seg_base[k] = symbols;
+            if (at != kWideStop) {
+                symbols += sh.count_of[k][at];
+                at = sh.exit_of[k][at];
+            }
+        }
+        sh.total = symbols;
+    }
+    __syncthreads();
+    {
+        u32 at = sh.seg_entry[t];
+        u64 symbols = sh.seg_base[t];
+        for (u64 k = lo; k < hi; ++k) {
+            fn_entry[k] = at;
+            base[k] = symbols;
+            if (at != kWideStop) {
+                const u64 f = fn_block[k * kWideEntries + at];
+                symbols += f >> 8;
+                at = (u32)(f & 0xFFu);
+                if (at == kWideStop) {
+                    sh.stop_block = k; /* (one thread at most: behind the stop every entry is "not part of the stream") */
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        const u64 stop_block = sh.stop_block;
+        hufd_dec_result rs;
+        rs.total_symbols = sh.total;
+        rs.cap_bit = kNoBit;
+        rs.reserved = 0;
+        /* the lane that stops fills these in; none does: the last code ended on the last bit of the stream */
+        rs.stop_kind = stop_block < n_blocks ? HUFD_STOP_NONE : HUFD_STOP_END;
+        rs.stop_bit = stop_block < n_blocks ? kNoBit : it.in_len * 8;
+        results[item] = rs;
+        states[item].total_symbols = sh.total;
+        ctl[kWideStopBlock] = (u32)(stop_block < n_blocks ? stop_block : 0xFFFFFFFFu);
+        ctl[kWideFnRoad] = 1;
+        ctl[kWideGaveUp] = 0; /* dec_deep, queued behind this road with that word as its gate, stays out of it */
+    }
+}
+
+__global__ __launch_bounds__(kDeepThreads) void dec_wide_fn_emit_kernel(
+    hufd_tables tb, const hufd_dec_item *items, const u32 *the_item, const u8 *d_in, u8 *d_out, u8 *block, hufd_dec_result *results) {
+
+    const u32 item = the_item[0];
+    const hufd_dec_item it = items[item];
+    const u64 n_blocks = (it.in_len + (u64)kDeepThreads * kDeepLaneBytes - 1) / ((u64)kDeepThreads * kDeepLaneBytes);
+    const dec_wide_layout lay = dec_wide_layout_of(n_blocks);
+    const u32 *ctl = reinterpret_cast<const u32 *>(block + lay.ctl);
+    const u64 b = blockIdx.x;
+    if (!ctl[kWideFnRoad] || b > ctl[kWideStopBlock]) {
+        return;
+    }
+    wide_fn_shared &sh = *reinterpret_cast<wide_fn_shared *>(dyn_lds);
+    u32 *deep = reinterpret_cast<u32 *>(dyn_lds + sizeof(wide_fn_shared));
+    const u32 l = threadIdx.x;
+    for (u32 i = l; i < tb.deep_entries; i += kDeepThreads) {
+        deep[i] = tb.deep_lut[i];
+    }
+    const u8 *fn_exit = block + lay.fn_exit + b * (u64)kWideEntries * kDeepThreads;
+    for (u32 e = 0; e < kWideEntries; ++e) {
+        sh.exit_of[e][l] = fn_exit[e * kDeepThreads + l];
+    }
+    const u64 block_from = b * kDeepThreads * kDeepLaneBytes;
+    const u64 block_bytes = it.in_len - block_from < (u64)kDeepThreads * kDeepLaneBytes ? it.in_len - block_from : (u64)kDeepThreads * kDeepLaneBytes;
+    const u32 n_lanes = (u32)((block_bytes + kDeepLaneBytes - 1) / kDeepLaneBytes);
+    __syncthreads();
+    /* the lanes' entries, from the block's: one thread follows the exits (sh.scan holds them for a moment) */
+    if (l == 0) {
+        u32 at = reinterpret_cast<const u32 *>(block + lay.fn_entry)[b];
+        u32 last = kDeepThreads;
+        for (u32 k = 0; k < n_lanes; ++k) {
+            sh.scan[k] = at;
+            at = sh.exit_of[at][k];
+            if (at == kWideStop) {
+                last = k; /* its walk stops: the lanes behind it are not part of the stream */
+                break;
+            }
+        }
+        sh.last_lane = last;
+    }
+    __syncthreads();
+    const bool reached = l < n_lanes && l <= sh.last_lane;
+    const u32 start = reached ? sh.scan[l] : 0u;
+    __syncthreads();
+    const u8 *in = d_in + it.in_off;
+    const u64 lane_from = (block_from + (u64)l * kDeepLaneBytes) * 8, lane_to = lane_from + kDeepLaneBytes * 8;
+    u32 mine = 0;
+    if (reached) {
+        mine = deep_walk<true>(deep, nullptr, 0, in, it.in_len, lane_from + start, lane_to, nullptr, 0, 0, nullptr).count;
+    }
+    sh.scan[l] = mine;
+    __syncthreads();
+    for (u32 d = 1; d < kDeepThreads; d *= 2) {
+        const u32 add = l >= d ? sh.scan[l - d] : 0u;
+        __syncthreads();
+        sh.scan[l] += add;
+        __syncthreads();
+    }
+    if (!reached) {
+        return;
+    }
+    const u64 first = reinterpret_cast<const u64 *>(block + lay.base)[b] + (sh.scan[l] - mine);
+    u64 cap_bit = kNoBit;
+    const deep_walked r = deep_walk<true>(deep, nullptr, 0, in, it.in_len, lane_from + start, lane_to, d_out + it.out_off, first, it.out_cap, &cap_bit);
     if (cap_bit != kNoBit) {
         results[item].cap_bit = cap_bit;
     }
@@ -8836,6 +9119,18 @@ int hufk_init(void) {
         e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&enc_onepass_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     }
+    if (e == hipSuccess) {
+        e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&dec_wide_fn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    }
+    if (e == hipSuccess) {
+        e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&dec_wide_fn_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    }
+    if (e == hipSuccess) {
+        e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&dec_wide_fn_emit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    }
     s_device_ready[device] = e == hipSuccess;
     pthread_mutex_unlock(&s_init_lock);
     return (int)e;
@@ -9483,6 +9778,17 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             hipLaunchKernelGGL(dec_wide_scan_kernel, dim3(1), dim3(256), 256 * sizeof(u64), st, a->items, the_item, blk, a->states, a->results);
             hipLaunchKernelGGL(
                 dec_wide_emit_kernel, dim3(n_blocks), dim3(kDeepThreads), wide_lds, st, a->tables, a->items, the_item,
+                (const u8 *)a->d_in, (u8 *)a->d_out, blk, a->results);
+            /* an item they gave up (its walks never fall into step) by transfer functions; all three return at once otherwise */
+            const uint32_t fn_lds = (uint32_t)(sizeof(wide_fn_shared) + a->tables.deep_entries * sizeof(u32));
+            hipLaunchKernelGGL(
+                dec_wide_fn_kernel, dim3(n_blocks), dim3(kDeepThreads), fn_lds, st, a->tables, a->items, the_item,
+                (const u8 *)a->d_in, blk);
+            hipLaunchKernelGGL(
+                dec_wide_fn_scan_kernel, dim3(1), dim3(kWideFnScanThreads), sizeof(wide_fn_scan_shared), st, a->items, the_item, blk,
+                a->states, a->results, a->wide_fails);
+            hipLaunchKernelGGL(
+                dec_wide_fn_emit_kernel, dim3(n_blocks), dim3(kDeepThreads), fn_lds, st, a->tables, a->items, the_item,
                 (const u8 *)a->d_in, (u8 *)a->d_out, blk, a->results);
             hipLaunchKernelGGL(
                 dec_deep_kernel<true>, dim3(1), dim3(kDeepThreads), deep_lds, st, a->tables, a->items, the_item, kDeepLaneBytes,

@@ -1634,7 +1634,9 @@ int aws_huffman_amd_decode_plan_launch_staged(
          * up, so that the way back to the two-pass kernels can be tested */
         a.fuse_mode = mode && strcmp(mode, "one-pass") == 0 ? 0u : (mode && strcmp(mode, "one-pass-fails") == 0 ? 2u : 1u);
         /* "wide-fails": dec_wide_* give every long item of a coder with long codes back to dec_deep (the way back, for tests) */
-        a.wide_fails = mode && strcmp(mode, "wide-fails") == 0;
+        a.wide_fails = mode && strcmp(mode, "wide-fails") == 0 ? 1u : 0u;
+        /* "wide-fn-fails": and dec_wide_fn_*, the road for such an item by transfer functions, gives it back as well */
+        a.wide_fails = mode && strcmp(mode, "wide-fn-fails") == 0 ? 2u : a.wide_fails;
     }
     a.tiles = p->d_tiles;
     a.n_tiles = p->n_tiles;

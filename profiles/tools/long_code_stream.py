@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""One long stream of a coder with codes of more than 12 bits (tests/parity_cases.py CODER_PROFILES,
-default hpack_lengths): encode through the segment kernels, decode by one thread (dec_tiny<DEEP>).  For DESIGN.md."""
+"""One long stream of a coder with codes of more than 12 bits (tests/parity_cases.py CODER_PROFILES, default
+hpack_lengths): encode through the segment kernels, decode a workgroup per 32 KiB block (dec_wide_*).  `len4to15` gives
+the printable symbols codes of 9, 12 and 15 bits only: a stream whose walks never fall into step, which dec_wide_settle
+gives up and dec_wide_fn_* decode by transfer functions (round 3: one workgroup, 0.048 GB/s).  For DESIGN.md."""
 import ctypes as C
 import os
 import sys

@@ -13,6 +13,8 @@ for tool in other_distributions tiny_items mid_items plan_time host_path_rate sm
     timeout 900 python3 profiles/tools/$tool.py > "$OUT/$tool.txt" 2> "$OUT/$tool.err"
     if [ "$tool" = long_code_stream ]; then  # and a stream long enough to fill the chip a workgroup per 32 KiB block
         timeout 900 python3 profiles/tools/$tool.py hpack_lengths 134217728 >> "$OUT/$tool.txt" 2>> "$OUT/$tool.err"
+        # ... and one whose walks never fall into step (printable symbols of len4to15: codes of 9, 12 and 15 bits only)
+        timeout 900 python3 profiles/tools/$tool.py len4to15 134217728 >> "$OUT/$tool.txt" 2>> "$OUT/$tool.err"
     fi
     echo "== $tool"; tail -4 "$OUT/$tool.txt"
 done

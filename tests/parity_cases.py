@@ -1277,9 +1277,11 @@ def plans_one_after_another(w, seed=107):
     eng.close()
 
 
-def wide_long_code_items(w, n=150_000, seed=79, modes=(None, "wide-fails")):
+def wide_long_code_items(w, n=150_000, seed=79, modes=(None, "wide-fails", "wide-fn-fails")):
     """Long items of coders with codes of more than 12 bits (decode through linked tables): a workgroup per 32 KiB
-    block (dec_wide_*) from 64 KiB on here; with "wide-fails" those kernels give every item back to dec_deep."""
+    block (dec_wide_*) from 64 KiB on here; with "wide-fails" those kernels give every item up as they do a stream whose
+    walks never fall into step, and it goes by transfer functions (dec_wide_fn_*: every road a second time, that way);
+    with "wide-fn-fails" those give it up as well and dec_deep, the last way back, takes it."""
     rng = np.random.default_rng(seed)
     w.product.lib.aws_huffman_amd_testing_set_wide_min_bytes(2 * 32768)
     try:
@@ -1318,6 +1320,24 @@ def wide_long_code_items(w, n=150_000, seed=79, modes=(None, "wide-fails")):
             eng.close()
     finally:
         w.product.lib.aws_huffman_amd_testing_set_wide_min_bytes(0)
+
+
+def never_in_step_stream(w, n=40_000_000, seed=113):
+    """ONE long stream whose walks never fall into step (code lengths 9, 12 and 15 only: three phases, each valid for
+    ever): dec_wide_settle gives it up and it goes by transfer functions (dec_wide_fn_*), every block a workgroup --
+    whole, cut inside a block, damaged two thirds in, entered three bits into its first byte, short of room."""
+    rng = np.random.default_rng(seed)
+    ocoder, pcoder, _ = profile_coders(w, "len4to15")
+    eng = harness.Engine(w.product.lib, pcoder)
+    apart = rng.integers(28, 256, n).astype(np.uint8)
+    good = w.oracle.encode_all(ocoder, apart, slack=64 + 2 * n)
+    assert good.size > 300 * 32768 or n < 1_000_000  # (more blocks than dec_wide_fn_scan has threads: runs of several)
+    damaged = good.copy()
+    at = 2 * (good.size // 3)
+    damaged[at:at + 4] = 0xFF  # (no code starts with 16 ones)
+    streams = [(good, 0, n), (good[: good.size // 2 + 11], 0, n), (damaged, 0, n), (good[7:], 3, n), (good, 0, n // 3)]
+    decode_items_like_the_oracle(w, eng, ocoder, streams, rng, "never in step", modes=(None,), kinds=2)
+    eng.close()
 
 
 def fixed_length_coders(w, n=70_000, seed=83):

@@ -57,6 +57,10 @@ def test_wide_long_code_items(world):
     pc.wide_long_code_items(world)
 
 
+def test_never_in_step_stream(world):
+    pc.never_in_step_stream(world, n=400_000)
+
+
 def test_fixed_length_coders(world):
     pc.fixed_length_coders(world)
 

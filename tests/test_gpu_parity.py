@@ -64,6 +64,10 @@ def test_wide_long_code_items(world):
     pc.wide_long_code_items(world)
 
 
+def test_never_in_step_stream(world):
+    pc.never_in_step_stream(world)
+
+
 def test_fixed_length_coders(world):
     pc.fixed_length_coders(world)
 
