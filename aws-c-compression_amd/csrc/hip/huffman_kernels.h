@@ -67,7 +67,8 @@ struct hufk_decode_args {
     uint32_t n_wide;
     uint64_t wide_from;
     void *wide_block; /* scratch: hufk_decode_wide_bytes(blocks) each, at the offsets in `wide` */
-    uint32_t wide_fails; /* 1: they give up (tests of the way back) */
+    uint32_t wide_fails; /* 1: they give up (tests of the way back); 2: and dec_wide_fn_* behind them as well */
+    uint32_t few_walks;  /* 1: the chunks inside streams whose walks do not fall into step go to dec_sync_few / dec_sync_true; 0: the long way */
     /* a coder with codes of one length (tables.fixed_bits): its items beyond a thread's work, 16 KiB blocks of them */
     const uint32_t *fixed_blocks; /* [n_fixed_blocks][2]: item, block of HUFD_FIXED_BLOCK_BYTES inside it */
     uint32_t n_fixed_blocks;

@@ -2819,6 +2819,7 @@ constexpr u32 kQuarterBits = HUFD_DEC_SUB_BITS / kQuarters;
 constexpr u32 kCpRows = HUFD_DEC_CP_ROWS;                    /* kQuarters - 1 checkpoints + the merged-state mask */
 constexpr u32 kEmitThreads = HUFD_DEC_LANES * kQuarters;
 constexpr u32 kExitStop = 15, kExitNoRef = 14;        /* top nibble of the merged-state row (states are < 13) */
+constexpr u8 kRegularFew = 4; /* chunk_regular between dec_sync_few and dec_sync_true (0: the long way, 1: regular, 2: regular up to the end of its stream, 3: a thread's work) */
 
 /* narrow transfer-function entry (per sub-chunk): [15] stop, [14:11] exit state, [10:0] symbols */
 __device__ __forceinline__ u16 fn_pack(bool stop, u32 exit_state, u32 count) {
@@ -3344,7 +3345,11 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     const u32 *list_count) {
     const u32 n = list ? *list_count : n_chunks;
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
-        dec_sync_chunk<NS>(tb, items, chunk_item, d_in, fn_tab, cp_tab, chunk_fn, chunk_regular, list ? list[i] : i);
+        const u32 c = list ? list[i] : i;
+        if (list && chunk_regular[c] == kRegularFew) {
+            continue; /* dec_sync_few, in front of this kernel on the same list, took it */
+        }
+        dec_sync_chunk<NS>(tb, items, chunk_item, d_in, fn_tab, cp_tab, chunk_fn, chunk_regular, c);
         __syncthreads(); /* the image is loaded anew for the next chunk */
     }
 }
@@ -3454,6 +3459,7 @@ __device__ __forceinline__ u32 code_at_walk(u32 window, const u32 *wlut, u32 pos
 
 constexpr u32 kFastRows = kSubWords + 1;  /* a window of the last row reaches into the next sub-chunk's first word */
 constexpr u32 kFastMaxMeet = 16;          /* no single head after this many rows: not regular */
+constexpr u32 kFastHopelessRows = 6;      /* most lanes of a wave with several heads after this many: not regular either (dec_sync_lean) */
 
 template <u32 LB>
 struct fast_shared {
@@ -3957,15 +3963,23 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     u64 heads = active ? (1ull << ns) - 1ull : 0ull;
     u32 meet_row = 0; /* the same for the whole wave */
     bool one = false, settled = false;
+    /* a wave most of whose lanes still follow several walks after kFastHopelessRows rows is looking at a stream whose
+     * walks do not fall into step (one symbol over and over: as many walks as its code has bits, for ever) -- ten more
+     * rows of all of them, and then the one walk, were 0.8 ms of a 1.8 ms decode of 256 MiB of such symbols */
+    bool hopeless = false;
 #pragma unroll
     for (u32 r = 0; r < kFastMaxMeet; ++r) {
-        if (!settled) {
+        if (!settled && !hopeless) {
             heads = r == 0 ? union_first_row<LB>(ns, active, w[0], w[1], sh.hops) : union_row_fast<LB>(heads, w[r], w[r + 1], sh.hops);
             one = heads != 0 && (heads & (heads - 1)) == 0;
             meet_row = r + 1;
             settled = __all(one || heads == 0);
+            if (r + 1 == kFastHopelessRows) {
+                hopeless = !settled && __popcll(__ballot(!one && heads != 0)) > kWave / 2;
+            }
         }
     }
+
     const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
     bool ok = !active || (one && settled);
     if (lane == 0) {
@@ -3978,7 +3992,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     bool dead = false;
 #pragma unroll
     for (u32 r = 1; r < kSubWords; ++r) {
-        if (r >= meet_row) {
+        if (r >= meet_row && !hopeless) { /* (hopeless: no row of this walk, none of the head walks below -- the chunk is not regular) */
             if (r % (kSubWords / kQuarters) == 0) {
                 cp_state[r / (kSubWords / kQuarters) - 1] = state;
             }
@@ -4006,7 +4020,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         bool dd = false;
 #pragma unroll
         for (u32 r = 0; r < kFastMaxMeet; ++r) {
-            if (r < meet_row) {
+            if (r < meet_row && !hopeless) {
                 if (r == kSubWords / kQuarters) {
                     head_cp = st;
                 }
@@ -4025,7 +4039,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     u32 cand_count = 0, cand_dead = 0;
     bool cand_reached = false;
     u64 cand_alive = 0;
-    if (lane < kWave) {
+    if (lane < kWave && !hopeless) {
         const u32 target = __shfl(meet_bit, 0), tail0 = __shfl(ref_count, 0); /* sub-chunk 0 is lane 0's */
         u32 st = rw.state_at(lane < ns ? lane : 0u, 0);
         bool dd = false;
@@ -5051,6 +5065,293 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 4) void dec_sync_guess_kernel(
         }
         dec_sync_guess_chunk<LB, SURE>(c, tb, chunk_rec, d_in, fn_tab, cp_tab, chunk_fn, lane_count, chunk_regular, slow_list, slow_count);
         __syncthreads(); /* the tables in LDS are written again */
+    }
+}
+
+/* ------------------------------------------------------------------ decode: sync, chunks whose walks do not fall into step */
+
+/*
+ * The chunks inside a stream that dec_sync_lean and dec_sync_guess gave up: in some sub-chunk the walks from the
+ * possible entry bits do not become one -- one symbol over and over (as many walks as its code has bits, each valid
+ * for ever), two symbols of one length taking turns, any stream whose code lengths share a divisor.  An adversary picks
+ * those; the long way (dec_sync) follows every entry's walk a bit of the stream at a time out of an LDS image, 1 ms for
+ * 160 MB, and the emit kernel behind it has no checkpoints to start threads at.  Here, as for the long-code coders
+ * (dec_wide_fn):
+ *   dec_sync_few    a lane's sub-chunk in registers as in dec_sync_lean; from every entry bit a walk over the first two
+ *                   rows, and from every DISTINCT bit these land on ONE walk to the end of the sub-chunk (as many as the
+ *                   stream has phases, at most kFewMaxWalks -- more, or the end of a stream in the chunk: the long way
+ *                   after all).  Each entry's (exit, symbols, or where its walk stops) goes into the tables in the long
+ *                   way's format, folded to the chunk's function for dec_scan as there.
+ *   dec_sync_true   behind dec_scan, which says where each such chunk is truly entered: one thread follows the lanes'
+ *                   functions to every lane's true entry, every lane walks its sub-chunk ONCE more from there and leaves
+ *                   the records of a regular chunk (count, exit, a checkpoint a quarter, all on the true walk) -- so the
+ *                   fast emit kernels take the chunk, a thread a quarter.  A true walk that stops in the chunk leaves it
+ *                   to the long way's emit kernel with dec_sync_few's tables.
+ * Between the two a chunk is marked kRegularFew in chunk_regular (nobody else looks at it then).
+ */
+constexpr u32 kFewMaxWalks = 8;
+constexpr u32 kFewHeadRows = 2;
+
+template <u32 LB>
+struct few_shared {
+    u32 wlut[1u << LB]; /* 0x10000 - length, length 48 = no code; at a multiple of its own size */
+    u16 ftab[HUFD_DEC_MAX_STATES * HUFD_DEC_LANES];
+    u32 gtab[kGroups * HUFD_DEC_MAX_STATES];
+    u32 entry_of[HUFD_DEC_LANES];
+    u32 bad;
+    u32 pad[3];
+};
+
+/* one row of a walk whose count has to be right when it dies (dec_sync_lean's walks of sub-chunk 0's entries) */
+template <u32 LB>
+__device__ __forceinline__ u32 few_row(u32 st, u32 hi, u32 lo, u32 table, const row_walk &rw, bool &dd, u32 &dead_count) {
+    st = lean_row<0, true>(st, hi, lo, table, rw);
+    const bool now = rw.died(st) && !dd;
+    dead_count = now ? (st >> 16) - 1u : dead_count; /* the step that found no code is not a symbol */
+    dd = dd || now;
+    return rw.next_row(st, dd);
+}
+
+template <u32 LB>
+__device__ __forceinline__ void few_load_words(u32 (&w)[kFastRows], const u8 *sub) {
+    const unaligned_uint4 *line = reinterpret_cast<const unaligned_uint4 *>(sub);
+#pragma unroll
+    for (u32 q = 0; q < kSubWords / 4; ++q) {
+        const unaligned_uint4 v = line[q];
+        w[4 * q + 0] = __builtin_bswap32(v.x);
+        w[4 * q + 1] = __builtin_bswap32(v.y);
+        w[4 * q + 2] = __builtin_bswap32(v.z);
+        w[4 * q + 3] = __builtin_bswap32(v.w);
+    }
+    w[kSubWords] = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(sub + HUFD_DEC_SUB_BYTES)->x);
+}
+
+template <u32 LB>
+__device__ __forceinline__ void few_table(few_shared<LB> &sh, const hufd_tables &tb, u32 lane) {
+    for (u32 i = lane; i < (1u << LB); i += HUFD_DEC_LANES) {
+        const u32 len = tb.dec_lut[i >> (LB - tb.lut_bits)] & 0xFFu;
+        sh.wlut[i] = 0x10000u - (len ? len : kWalkDeadLen);
+    }
+}
+
+template <u32 LB>
+__global__ __launch_bounds__(HUFD_DEC_LANES, 4) void dec_sync_few_kernel(
+    hufd_tables tb,
+    const hufd_chunk_rec *chunk_rec,
+    const u8 *d_in,
+    u16 *fn_tab,
+    u16 *cp_tab,
+    u32 *chunk_fn,
+    u8 *chunk_regular,
+    const u32 *list, /* what the kernels in front gave up; dec_sync, behind this one, goes through it again and skips the chunks marked here */
+    const u32 *list_count,
+    u32 *done_list, /* the chunks taken here, for dec_sync_true */
+    u32 *done_count) {
+
+    few_shared<LB> &sh = *reinterpret_cast<few_shared<LB> *>(dyn_lds);
+    const u32 ns = tb.n_states;
+    const u32 lane = threadIdx.x;
+    const u32 table = lds_offset_of(sh.wlut);
+    const row_walk rw(LB, tb.max_bits);
+    if (tb.lut_bits > LB || tb.max_bits > HUFD_DEC_MAX_LUT_BITS || ns > HUFD_DEC_MAX_STATES || (table & ((4u << LB) - 1u)) != 0) {
+        return;
+    }
+    few_table<LB>(sh, tb, lane);
+    if (lane == 0) {
+        sh.bad = 0;
+    }
+    __syncthreads();
+    const u32 n = *list_count;
+    for (u32 k = blockIdx.x; k < n; k += gridDim.x) {
+        const u32 c = list[k];
+        const hufd_chunk_rec rec = chunk_rec[c];
+        if (rec.valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
+            continue; /* holds the end of its stream: the long way's */
+        }
+        u32 w[kFastRows];
+        few_load_words<LB>(w, d_in + rec.src_off + (u64)lane * HUFD_DEC_SUB_BYTES);
+
+        /* every entry bit over the first rows: where it lands and what it counted (kept in the entry's place in the LDS
+         * table, the landing bit where the exit will be: registers are for the sub-chunk), or where it died */
+        u32 landed = 0, pending = 0;
+#pragma unroll
+        for (u32 s = 0; s < HUFD_DEC_MAX_STATES; ++s) {
+            if (s < ns) {
+                u32 st = rw.state_at(s, 0), dead_count = 0;
+                bool dd = false;
+#pragma unroll
+                for (u32 r = 0; r < kFewHeadRows; ++r) {
+                    st = few_row<LB>(st, w[r], w[r + 1], table, rw, dd, dead_count);
+                }
+                const u32 o = rw.offset_of(st);
+                const bool on = !dd && o < 16u;
+                sh.ftab[s * HUFD_DEC_LANES + lane] = on ? fn_pack(false, o, (st >> 16) & 0x7FFu) : fn_pack(true, 0, dead_count & 0x7FFu);
+                pending |= on ? 1u << s : 0u;
+                landed |= on ? 1u << o : 0u;
+            }
+        }
+        bool ok = __builtin_popcount(landed) <= (int)kFewMaxWalks;
+        /* one walk from every bit a walk landed on, to the end of the sub-chunk */
+        u32 todo = ok ? landed : 0u;
+        while (todo) {
+            const u32 o = (u32)__builtin_ctz(todo);
+            todo &= todo - 1;
+            u32 st = rw.state_at(o, 0), dead_count = 0;
+            bool dd = false;
+#pragma unroll
+            for (u32 r = kFewHeadRows; r < kSubWords; ++r) {
+                st = few_row<LB>(st, w[r], w[r + 1], table, rw, dd, dead_count);
+            }
+            const u32 ex = rw.offset_of(st);
+            ok = ok && (dd || ex < ns);
+            const u32 more = dd ? dead_count : st >> 16;
+            for (u32 s = 0; s < ns; ++s) {
+                const u32 f = sh.ftab[s * HUFD_DEC_LANES + lane];
+                if (((pending >> s) & 1u) && ((f >> 11) & 15u) == o) {
+                    sh.ftab[s * HUFD_DEC_LANES + lane] = fn_pack(dd, dd ? 0u : ex & 15u, ((f & 0x7FFu) + more) & 0x7FFu);
+                    pending &= ~(1u << s);
+                }
+            }
+        }
+        if (!ok) {
+            sh.bad = 1;
+        }
+        __syncthreads();
+        const bool bad = sh.bad != 0;
+        __syncthreads();
+        if (bad) {
+            if (lane == 0) {
+                sh.bad = 0;
+            }
+            __syncthreads();
+            continue; /* (too many walks in some lane: the long way) */
+        }
+        /* the tables, as dec_sync leaves them for a chunk without a walk all entries run into: no checkpoints */
+        for (u32 s = 0; s < ns; ++s) {
+            fn_tab[((u64)c * ns + s) * HUFD_DEC_LANES + lane] = sh.ftab[s * HUFD_DEC_LANES + lane];
+        }
+        {
+            u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
+#pragma unroll
+            for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+                cp[qq * HUFD_DEC_LANES] = 0;
+            }
+            cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(kExitNoRef << 12);
+        }
+        __syncthreads();
+        if (lane < kGroups * ns) {
+            const u32 g = lane / ns, start = lane % ns;
+            sh.gtab[g * ns + start] = wide_pack(chain_fold(kGroupLanes, start, [&](u32 i, u32 stt) {
+                return widen(sh.ftab[stt * HUFD_DEC_LANES + g * kGroupLanes + i]);
+            }));
+        }
+        __syncthreads();
+        if (lane < ns) {
+            chunk_fn[(u64)c * ns + lane] =
+                wide_pack(chain_fold(kGroups, lane, [&](u32 g, u32 stt) { return sh.gtab[g * ns + stt]; }));
+        }
+        if (lane == 0) {
+            chunk_regular[c] = kRegularFew;
+            done_list[atomicAdd(done_count, 1u)] = c;
+        }
+        __syncthreads(); /* the tables in LDS are written again */
+    }
+}
+
+template <u32 LB>
+__global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_true_kernel(
+    hufd_tables tb,
+    const hufd_chunk_rec *chunk_rec,
+    const u8 *d_in,
+    const u16 *fn_tab,
+    u16 *cp_tab,
+    u16 *lane_count,
+    u8 *chunk_regular,
+    const u32 *chunk_entry,
+    const u32 *list, /* dec_sync_few's chunks */
+    const u32 *list_count) {
+
+    few_shared<LB> &sh = *reinterpret_cast<few_shared<LB> *>(dyn_lds);
+    const u32 ns = tb.n_states;
+    const u32 lane = threadIdx.x;
+    const u32 table = lds_offset_of(sh.wlut);
+    const row_walk rw(LB, tb.max_bits);
+    const u32 n = *list_count;
+    if (n == 0) {
+        return;
+    }
+    few_table<LB>(sh, tb, lane);
+    if (lane == 0) {
+        sh.bad = 0;
+    }
+    __syncthreads();
+    for (u32 k = blockIdx.x; k < n; k += gridDim.x) {
+        const u32 c = list[k];
+        const u32 centry = chunk_entry[c];
+        if (!(centry & 0x100u)) {
+            /* the stream ended before this chunk: nobody emits it, and it must not look regular to anybody */
+            if (lane == 0) {
+                chunk_regular[c] = 0;
+            }
+            continue;
+        }
+        const hufd_chunk_rec rec = chunk_rec[c];
+        u32 w[kFastRows];
+        few_load_words<LB>(w, d_in + rec.src_off + (u64)lane * HUFD_DEC_SUB_BYTES);
+        for (u32 s = 0; s < ns; ++s) {
+            sh.ftab[s * HUFD_DEC_LANES + lane] = fn_tab[((u64)c * ns + s) * HUFD_DEC_LANES + lane];
+        }
+        __syncthreads();
+        if (lane == 0) {
+            u32 at = centry & 0xFFu;
+            bool stops = at >= ns;
+            for (u32 l = 0; l < HUFD_DEC_LANES && !stops; ++l) {
+                sh.entry_of[l] = at;
+                const u32 f = sh.ftab[at * HUFD_DEC_LANES + l];
+                stops = (f & 0x8000u) != 0;
+                at = (f >> 11) & 15u;
+            }
+            sh.bad = stops ? 1u : 0u;
+        }
+        __syncthreads();
+        bool ok = sh.bad == 0;
+        const u32 entry = ok ? sh.entry_of[lane] : 0u;
+        const u32 next_entry = ok && lane + 1 < HUFD_DEC_LANES ? sh.entry_of[lane + 1] : HUFD_NONE32;
+        __syncthreads();
+        /* the true walk: count, exit, where it enters the quarters */
+        u32 st = rw.state_at(entry, 0), dead_count = 0;
+        u32 cp_state[kQuarters - 1] = {0, 0, 0};
+        bool dd = false;
+#pragma unroll
+        for (u32 r = 0; r < kSubWords; ++r) {
+            if (r && r % (kSubWords / kQuarters) == 0) {
+                cp_state[r / (kSubWords / kQuarters) - 1] = st;
+            }
+            st = few_row<LB>(st, w[r], w[r + 1], table, rw, dd, dead_count);
+        }
+        const u32 count = st >> 16, ex = rw.offset_of(st);
+        /* (what dec_sync_few said of this walk holds: anything else is a chunk for the long way) */
+        if (ok && (dd || ex >= ns || (next_entry != HUFD_NONE32 && ex != next_entry))) {
+            sh.bad = 1;
+        }
+        __syncthreads();
+        const bool good = sh.bad == 0;
+        __syncthreads();
+        if (good) {
+            u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
+#pragma unroll
+            for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+                const u32 tail = count - (cp_state[qq] >> 16), bits = rw.offset_of(cp_state[qq]);
+                cp[qq * HUFD_DEC_LANES] = (u16)(bits < 16u ? 0x8000u | (bits << 11) | tail : 0u);
+            }
+            lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)count;
+            cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((1u << entry) | (ex << 12));
+        }
+        if (lane == 0) {
+            chunk_regular[c] = good ? 1 : 0;
+            sh.bad = 0;
+        }
+        __syncthreads();
     }
 }
 
@@ -9458,6 +9759,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         return 0;
     }
     const uint32_t ns = a->tables.n_states;
+    bool few = false; /* dec_sync_few ran: dec_sync_true follows behind the scan */
     stage_mark(a->stage_events, 0, st);
     if (a->n_fixed_blocks && a->tables.fixed_bits) {
         (void)hipMemsetAsync(a->states, 0xFF, (size_t)a->n_items * sizeof(hufd_dec_item_state), st);
@@ -9730,6 +10032,25 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             if (guessed) {
                 long_list = a->emit_list;
                 long_count = a->emit_count;
+                /* of those, the chunks inside streams whose walks do not fall into step: a few walks a lane, not the long
+                 * way's every bit (dec_sync_few; its list -- dec_sync_lean's, used up by now -- is for dec_sync_true below) */
+                if (some_inside && a->few_walks) {
+                    few = true;
+                    (void)hipMemsetAsync(a->slow_count, 0, sizeof(uint32_t), st);
+                    if (a->tables.lut_bits <= 10) {
+                        hipLaunchKernelGGL(
+                            (dec_sync_few_kernel<10>),
+                            dim3(persistent_grid(dec_sync_few_kernel<10>, HUFD_DEC_LANES, (uint32_t)sizeof(few_shared<10>), a->n_chunks)),
+                            dim3(HUFD_DEC_LANES), (uint32_t)sizeof(few_shared<10>), st, a->tables, a->chunk_rec, (const u8 *)a->d_in,
+                            a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, long_list, long_count, a->slow_list, a->slow_count);
+                    } else {
+                        hipLaunchKernelGGL(
+                            (dec_sync_few_kernel<12>),
+                            dim3(persistent_grid(dec_sync_few_kernel<12>, HUFD_DEC_LANES, (uint32_t)sizeof(few_shared<12>), a->n_chunks)),
+                            dim3(HUFD_DEC_LANES), (uint32_t)sizeof(few_shared<12>), st, a->tables, a->chunk_rec, (const u8 *)a->d_in,
+                            a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, long_list, long_count, a->slow_list, a->slow_count);
+                    }
+                }
             }
         }
         hipLaunchKernelGGL(
@@ -9826,6 +10147,24 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         hipLaunchKernelGGL(
             dec_scan_apply_kernel, dim3(a->n_runs), dim3(256), lds, st, a->items, a->runs, ns, a->chunk_fn,
             (const u32 *)a->run_entry, (const u64 *)a->run_base, a->chunk_entry, a->chunk_base, gate);
+    }
+    if (few) {
+        /* dec_sync_few's chunks, now that dec_scan has said where each is entered: the true walk's records (dec_sync_true) */
+        if (a->tables.lut_bits <= 10) {
+            hipLaunchKernelGGL(
+                (dec_sync_true_kernel<10>),
+                dim3(persistent_grid(dec_sync_true_kernel<10>, HUFD_DEC_LANES, (uint32_t)sizeof(few_shared<10>), a->n_chunks)),
+                dim3(HUFD_DEC_LANES), (uint32_t)sizeof(few_shared<10>), st, a->tables, a->chunk_rec, (const u8 *)a->d_in,
+                (const u16 *)a->fn_tab, a->cp_tab, a->lane_count, a->chunk_regular, (const u32 *)a->chunk_entry,
+                (const u32 *)a->slow_list, (const u32 *)a->slow_count);
+        } else {
+            hipLaunchKernelGGL(
+                (dec_sync_true_kernel<12>),
+                dim3(persistent_grid(dec_sync_true_kernel<12>, HUFD_DEC_LANES, (uint32_t)sizeof(few_shared<12>), a->n_chunks)),
+                dim3(HUFD_DEC_LANES), (uint32_t)sizeof(few_shared<12>), st, a->tables, a->chunk_rec, (const u8 *)a->d_in,
+                (const u16 *)a->fn_tab, a->cp_tab, a->lane_count, a->chunk_regular, (const u32 *)a->chunk_entry,
+                (const u32 *)a->slow_list, (const u32 *)a->slow_count);
+        }
     }
     stage_mark(a->stage_events, 2, st);
     if (a->n_chunks) {

@@ -1637,6 +1637,8 @@ int aws_huffman_amd_decode_plan_launch_staged(
         a.wide_fails = mode && strcmp(mode, "wide-fails") == 0 ? 1u : 0u;
         /* "wide-fn-fails": and dec_wide_fn_*, the road for such an item by transfer functions, gives it back as well */
         a.wide_fails = mode && strcmp(mode, "wide-fn-fails") == 0 ? 2u : a.wide_fails;
+        /* "long-way": the chunks whose walks do not fall into step through dec_sync and dec_emit (not dec_sync_few / _true) */
+        a.few_walks = mode && strcmp(mode, "long-way") == 0 ? 0u : 1u;
     }
     a.tiles = p->d_tiles;
     a.n_tiles = p->n_tiles;

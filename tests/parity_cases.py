@@ -699,6 +699,40 @@ def dense_symbols(w, n=200_000, seed=31):
             paired_decode(w, ddo, ddp, enc, 0, enc.size, oo, op, 0, out_cap)
 
 
+def streams_out_of_step(w, n=260_000, seed=109, modes=(None, "long-way")):
+    """Streams whose walks from different entry bits never become one: one symbol over and over, two symbols of one
+    length taking turns, a short pattern repeated -- every chunk of them is one dec_sync_lean gives up after a few rows;
+    dec_sync_few / dec_sync_true take those inside the stream (a few walks a lane, then the true walk's records for the
+    fast emit kernels), "long-way" sends them through dec_sync / dec_emit as before round 4.  Whole, cut, damaged in
+    the middle (a true walk that stops inside a chunk), entered inside a byte, short of room, and behind a stretch of
+    ordinary symbols (chunks of both kinds in one item)."""
+    rng = np.random.default_rng(seed)
+    lens = np.array([w.table[1][i] for i in range(256)])
+    short = np.flatnonzero(lens == lens[lens > 0].min())
+    mid = np.flatnonzero(lens == np.sort(np.unique(lens[lens > 0]))[2])
+    longest = np.flatnonzero(lens == lens.max())
+    pattern = np.array([short[0], short[1], short[0], short[2]], np.uint8)
+    bases = [
+        np.full(n, short[0], np.uint8),
+        np.tile(np.array([short[1], short[2]], np.uint8), n // 2),
+        np.tile(pattern, n // 4),
+        np.full(n // 2, longest[0], np.uint8),
+        np.tile(np.array([mid[0], mid[1 % mid.size]], np.uint8), n // 2),
+        np.concatenate([inputs(rng, n // 3, "uniform"), np.full(n // 2, short[3 % short.size], np.uint8), inputs(rng, n // 4, "printable")]),
+    ]
+    eng = harness.Engine(w.product.lib, w.pcoder)
+    for b, data in enumerate(bases):
+        enc = oracle_encode(w, data)
+        assert enc.size > 3 * 32768, enc.size
+        damaged = enc.copy()
+        at = enc.size // 2 + 1000
+        damaged[at:at + 4] = 0xFF
+        streams = [(enc, 0, data.size), (enc[: 2 * 32768 + 4000], 0, data.size), (damaged, 0, data.size),
+                   (enc[5:], 3, data.size), (enc, 0, data.size // 3), (enc[: 3 * 32768], 0, data.size + 9)]
+        decode_items_like_the_oracle(w, eng, w.ocoder, streams, rng, "out of step %d" % b, modes=modes, kinds=1)
+    eng.close()
+
+
 # ----------------------------------------------------------------------------- scenario: empty cursors with a NULL pointer
 def null_empty_cursors(w, seed=91):
     """aws_byte_cursor{0, NULL} is a valid cursor: the reference never touches `ptr` when `len` is 0

@@ -57,6 +57,10 @@ def test_wide_long_code_items(world):
     pc.wide_long_code_items(world)
 
 
+def test_streams_out_of_step(world):
+    pc.streams_out_of_step(world)
+
+
 def test_never_in_step_stream(world):
     pc.never_in_step_stream(world, n=400_000)
 
