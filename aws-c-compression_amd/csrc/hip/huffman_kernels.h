@@ -135,6 +135,10 @@ uint64_t hufk_decode_zero_bytes(uint32_t n_tiles, uint32_t n_items);
 /* a plan of items that are all one thread's work: the kernels' item records and the list of such items (= all of them) from
  * the caller's records, copied to the device as they are (struct hufd_raw_dec_item / hufd_raw_enc_item) */
 int hufk_decode_plan_tiny_items(const void *raw_items, uint32_t n_items, struct hufd_dec_item *items, uint32_t *tiny_list, void *stream);
+/* items[i] = the encoded output of encode item i as its result record on the device describes it, decoded back to where its symbols came from */
+int hufk_decode_plan_from_encode(
+    const struct hufd_enc_item *enc_items, const struct hufd_enc_result *enc_results, uint32_t n_items, struct hufd_dec_item *items,
+    uint32_t *tiny_list, void *stream);
 int hufk_encode_plan_tiny_items(const void *raw_items, uint32_t n_items, struct hufd_enc_item *items, uint32_t *tiny_list, void *stream);
 /* fills chunk_item[n_chunks] and chunk_rec[n_chunks] of a decode plan from its item records, on the device */
 int hufk_decode_plan_chunks(

@@ -9210,6 +9210,29 @@ __global__ __launch_bounds__(256) void dec_plan_tiny_items_kernel(const hufd_raw
     tiny_list[i] = i;
 }
 
+/* The decode plan of what an encode launch left (aws_huffman_amd_decode_plan_from_encode): item i is encode item i's
+ * output -- where it was written, as many bytes as its record says were -- decoded to where the symbols came from.  The
+ * lengths never leave the device. */
+__global__ __launch_bounds__(256) void dec_plan_from_encode_kernel(
+    const hufd_enc_item *enc_items, const hufd_enc_result *enc_results, u32 n_items, hufd_dec_item *items, u32 *tiny_list) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) {
+        return;
+    }
+    const hufd_enc_item e = enc_items[i];
+    hufd_dec_item it;
+    it.in_off = e.out_off;
+    it.in_len = enc_results[i].produced;
+    it.out_off = e.in_off;
+    it.out_cap = e.in_len;
+    it.first_bit = 0;
+    it.first_chunk = 0;
+    it.n_chunks = 0;
+    it.tiny = 1;
+    items[i] = it;
+    tiny_list[i] = i;
+}
+
 __global__ __launch_bounds__(256) void enc_plan_tiny_items_kernel(const hufd_raw_enc_item *raw, u32 n_items, hufd_enc_item *items, u32 *tiny_list) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) {
@@ -9472,6 +9495,18 @@ int hufk_decode_plan_tiny_items(const void *raw_items, uint32_t n_items, struct 
     hipLaunchKernelGGL(
         dec_plan_tiny_items_kernel, dim3((n_items + 255) / 256), dim3(256), 0, (hipStream_t)stream,
         (const hufd_raw_dec_item *)raw_items, n_items, items, tiny_list);
+    return (int)hipGetLastError();
+}
+
+int hufk_decode_plan_from_encode(
+    const struct hufd_enc_item *enc_items, const struct hufd_enc_result *enc_results, uint32_t n_items, struct hufd_dec_item *items,
+    uint32_t *tiny_list, void *stream) {
+    if (n_items == 0) {
+        return 0;
+    }
+    hipLaunchKernelGGL(
+        dec_plan_from_encode_kernel, dim3((n_items + 255) / 256), dim3(256), 0, (hipStream_t)stream, enc_items, enc_results, n_items,
+        items, tiny_list);
     return (int)hipGetLastError();
 }
 

@@ -518,6 +518,7 @@ static uint64_t enc_tiny_per_byte(const struct aws_huffman_amd_engine *eng) {
 struct item_stats { /* of a plan's items, from the pass that finds the thread-per-item limit */
     uint64_t shortest, longest;
     uint32_t worst_bits; /* largest first_bit (decode) / overflow_in.num_bits (encode) */
+    uint64_t largest_out_cap; /* (encode) */
 };
 
 /* the caller's records go to the device as they are when every item of a plan is one thread's work: the kernels that
@@ -547,11 +548,13 @@ static uint64_t enc_tiny_limit(
     st->shortest = UINT64_MAX;
     st->longest = 0;
     st->worst_bits = 0;
+    st->largest_out_cap = 0;
     for (size_t i = 0; i < n_items; ++i) {
         const uint64_t len = items[i].in_len;
         st->shortest = len < st->shortest ? len : st->shortest;
         st->longest = len > st->longest ? len : st->longest;
         st->worst_bits = items[i].overflow_in.num_bits > st->worst_bits ? items[i].overflow_in.num_bits : st->worst_bits;
+        st->largest_out_cap = items[i].out_capacity > st->largest_out_cap ? items[i].out_capacity : st->largest_out_cap;
         for (int c = 0; c < 2; ++c) {
             if (len <= classes[c]) {
                 ++count[c];
@@ -619,6 +622,8 @@ static int enc_plan_fill(
     const uint64_t tiny_limit = enc_tiny_limit(eng, items, n_items, &stats);
     /* a failed refill must not leave counts of the fill before behind (the device arrays may be gone or too small) */
     p->n_items = p->n_segs = p->n_large = p->n_tiny = 0;
+    p->largest_out_cap = stats.largest_out_cap;
+    p->most_overflow_bits = stats.worst_bits;
     if (n_items >= PLAN_ON_DEVICE_MIN_ITEMS && n_items < 0xFFFFFFFFull && stats.shortest >= 1 && stats.longest <= tiny_limit &&
         stats.worst_bits <= 32) {
         /* every item is one thread's work (enc_item_is_tiny): no segments, no lists to make -- the caller's records go to the
@@ -1174,6 +1179,7 @@ static int dec_plan_fill(
     p->n_items = p->n_chunks = p->n_large = p->n_runs = p->n_tail = p->n_tiles = p->n_fixed = p->n_wide = 0;
     p->n_tiny = p->n_deep = 0;
     p->n_res_tiles = 0;
+    p->chained = false;
     if (n_items >= PLAN_ON_DEVICE_MIN_ITEMS && n_items < 0xFFFFFFFFull && stats.shortest >= 1 && stats.longest <= tiny_limit &&
         stats.worst_bits <= 7) {
         /* every item is one thread's work (dec_item_is_tiny): no chunks, no lists to make -- the caller's records go to the
@@ -1728,10 +1734,80 @@ int aws_huffman_amd_decode_plan_results(
         free(raw);
         return raise_hip(err);
     }
+    if (p->chained) {
+        /* the items' lengths were never on the host: the device's records say what each result is a result of */
+        struct hufd_dec_item *dev_items = malloc((p->n_items ? p->n_items : 1) * sizeof(*dev_items));
+        err = dev_items ? hufs_copy_d2h(dev_items, p->d_items, (size_t)p->n_items * sizeof(*dev_items), st) : 2;
+        if (!err) {
+            err = hufs_stream_sync(st);
+        }
+        for (uint32_t i = 0; i < p->n_items && !err; ++i) {
+            struct aws_huffman_amd_decode_item it;
+            memset(&it, 0, sizeof(it));
+            it.in_offset = dev_items[i].in_off;
+            it.in_len = dev_items[i].in_len;
+            it.first_bit = (uint8_t)dev_items[i].first_bit;
+            it.out_offset = dev_items[i].out_off;
+            it.out_capacity = dev_items[i].out_cap;
+            aws_huffman_amd_decode_result_from_raw(&raw[i], &it, &results[i]);
+        }
+        free(dev_items);
+        free(raw);
+        return err ? raise_hip(err) : AWS_OP_SUCCESS;
+    }
     for (uint32_t i = 0; i < p->n_items; ++i) {
         aws_huffman_amd_decode_result_from_raw(&raw[i], &p->h_items[i], &results[i]);
     }
     free(raw);
+    return AWS_OP_SUCCESS;
+}
+
+int aws_huffman_amd_decode_plan_from_encode(
+    struct aws_huffman_amd_decode_plan *p,
+    const struct aws_huffman_amd_encode_plan *encoded,
+    void *stream) {
+
+    struct aws_huffman_amd_engine *eng = p->engine;
+    if (!eng->can_decode) {
+        return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION);
+    }
+    if (!encoded || encoded->engine->device != eng->device) {
+        return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
+    }
+    /* Whatever the launch produced, every item must be ONE THREAD's work for the decoder (then the plan has no chunk
+     * geometry, which only the host can lay out): the most bytes an item can have left is its output capacity.  The same
+     * rule as for a plan from host records (dec_tiny_limit), with the capacities for the lengths. */
+    const uint64_t n_items = encoded->n_items, longest = encoded->largest_out_cap;
+    bool thread_each = n_items >= 1 && n_items < 0xFFFFFFFFull && longest <= HUFD_TINY_FEW_BYTES;
+    {
+        static const uint64_t classes[2] = {HUFD_DEC_COOP_BYTES, HUFD_DEC_TINY_BYTES};
+        for (int c = 0; c < 2 && !thread_each && n_items >= 1 && n_items < 0xFFFFFFFFull; ++c) {
+            thread_each = longest <= classes[c] && n_items >= tiny_per_byte(true) * longest;
+        }
+    }
+    if (!thread_each) {
+        return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION); /* (the caller fetches the lengths and makes the plan from records) */
+    }
+    p->n_items = p->n_chunks = p->n_large = p->n_runs = p->n_tail = p->n_tiles = p->n_fixed = p->n_wide = 0;
+    p->n_tiny = p->n_deep = 0;
+    p->n_res_tiles = 0;
+    p->chained = false;
+    ON_DEVICE(eng->device);
+    int e = dec_plan_reserve(p, n_items, 0, 0, 0);
+    if (!e) {
+        e = hufk_decode_plan_from_encode(
+            encoded->d_items, encoded->d_results, (uint32_t)n_items, p->d_items, p->d_tiny, stream ? stream : eng->stream);
+    }
+    if (e) {
+        return raise_hip(e);
+    }
+    p->wide_from = wide_min_bytes(0);
+    p->tail_stage_bytes = 0;
+    p->tail_lanes = 0;
+    p->n_tail_narrow = 0;
+    p->n_items = (uint32_t)n_items;
+    p->n_tiny = (uint32_t)n_items;
+    p->chained = true;
     return AWS_OP_SUCCESS;
 }
 

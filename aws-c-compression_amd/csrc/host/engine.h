@@ -87,6 +87,9 @@ struct aws_huffman_amd_encode_plan {
     bool last_single_pass;
     bool last_timed_out; /* the last launch whose results were fetched was done over by the three-kernel road */
     bool look_back_timed_out;
+    /* of the items as they were given: what aws_huffman_amd_decode_plan_from_encode asks before it chains a decode plan */
+    uint64_t largest_out_cap; /* the most encoded bytes an item can leave */
+    uint32_t most_overflow_bits;
 };
 
 struct aws_huffman_amd_decode_plan {
@@ -122,6 +125,7 @@ struct aws_huffman_amd_decode_plan {
     uint64_t *d_chunk_base;
     struct hufd_chunk_rec *d_chunk_rec;
     uint32_t one_pass_tried; /* the last launch queued dec_onepass for the chunks inside streams */
+    bool chained; /* made by aws_huffman_amd_decode_plan_from_encode: the items' lengths are known on the device only (h_items is not filled) */
     struct hufd_tile_rec *d_tiles; /* [n_tiles] dec_onepass: the chunks inside streams as tiles of 64 sub-chunks, one wave each */
     void *d_fuse_block;            /* its look-back words, zeroed by every launch; first: its ctl words */
     uint32_t n_tiles;

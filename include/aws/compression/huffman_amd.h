@@ -206,6 +206,24 @@ int aws_huffman_amd_decode_plan_reset(
     const struct aws_huffman_amd_decode_item *items,
     size_t item_count);
 
+/*
+ * `plan` reset to decode what `encoded`'s LAST LAUNCH produced, made on the device from that launch's records: the
+ * encoded lengths never come to the host (encode -> decode of a batch without a round trip).  Decode item i is encode
+ * item i's output -- at its out_offset in the buffer that launch wrote, which is the decode launch's input; as many
+ * bytes as its record says were produced, whatever the record's verdict; from bit 0 -- decoded to where its symbols came
+ * from: out_offset = the encode item's in_offset, out_capacity = its in_len.  The records are written on `stream`
+ * (NULL: the engine's): behind the encode launch if that is the launch's stream, and in front of a decode launch on it.
+ * Only for batches of short items: when every item, whatever it produced, is one thread's work for the decoder (the
+ * most an item can have left is its out_capacity: up to 128 bytes each, or up to 512 / 768 when the batch has
+ * thousands of them -- header fields); otherwise AWS_ERROR_UNSUPPORTED_OPERATION, nothing changed, and the caller
+ * fetches the lengths (aws_huffman_amd_encode_plan_results) and resets the plan from records.  Both plans on one device.
+ */
+AWS_COMPRESSION_API
+int aws_huffman_amd_decode_plan_from_encode(
+    struct aws_huffman_amd_decode_plan *plan,
+    const struct aws_huffman_amd_encode_plan *encoded,
+    void *stream);
+
 AWS_COMPRESSION_API
 void aws_huffman_amd_decode_plan_destroy(struct aws_huffman_amd_decode_plan *plan);
 

@@ -25,6 +25,7 @@ PRODUCT_SO = os.path.join(REPO, "aws-c-compression_amd", "libaws-c-compression-a
 AWS_OP_SUCCESS = 0
 AWS_OP_ERR = -1
 AWS_ERROR_SHORT_BUFFER = 4
+AWS_ERROR_UNSUPPORTED_OPERATION = 6
 AWS_ERROR_COMPRESSION_UNKNOWN_SYMBOL = 0x0C00
 
 
@@ -180,7 +181,7 @@ EXPORTED_SYMBOLS = [
     "aws_huffman_amd_testing_set_decode_piece_bytes",
     "aws_huffman_amd_testing_set_wide_min_bytes",
     "aws_huffman_amd_engine_device", "aws_huffman_amd_current_device", "aws_huffman_amd_encode_plan_reset",
-    "aws_huffman_amd_decode_plan_reset",
+    "aws_huffman_amd_decode_plan_reset", "aws_huffman_amd_decode_plan_from_encode",
     "aws_huffman_amd_device_count", "aws_huffman_amd_device_alloc", "aws_huffman_amd_device_free",
     "aws_huffman_amd_copy_to_device", "aws_huffman_amd_copy_to_host", "aws_huffman_amd_device_fill",
     "aws_huffman_amd_device_fill_splitmix64", "aws_huffman_amd_engine_stream", "aws_huffman_amd_stream_synchronize",
@@ -365,6 +366,16 @@ class Engine:
         if rc != 0:
             raise RuntimeError("decode_plan_new failed, error %d" % self.lib.aws_last_error())
         return plan
+
+    def decode_plan_from_encode(self, plan, encode_plan):
+        """plan reset to decode what encode_plan's last launch produced; the lengths stay on the device.  False: the batch is
+        not one of short items (AWS_ERROR_UNSUPPORTED_OPERATION, the plan is as it was)."""
+        self.lib.aws_huffman_amd_decode_plan_from_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        rc = self.lib.aws_huffman_amd_decode_plan_from_encode(plan, encode_plan, None)
+        if rc != 0:
+            assert self.lib.aws_last_error() == AWS_ERROR_UNSUPPORTED_OPERATION, self.lib.aws_last_error()
+            return False
+        return True
 
     def decode_launch(self, plan, d_in, d_out, events=None):
         assert self.lib.aws_huffman_amd_decode_plan_launch_staged(plan, d_in, d_out, None, events) == 0

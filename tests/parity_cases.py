@@ -852,6 +852,69 @@ def many_header_sized_items(w, n_items=6000, seed=97, engine=None):
         eng.close()
 
 
+def encode_then_decode_on_the_device(w, seed=119, engine=None, batches=((40, 50), (9000, 90), (30000, 300))):
+    """aws_huffman_amd_decode_plan_from_encode: a batch of header-sized strings encoded, then decoded back by a plan made
+    on the device from the encode launch's records -- the encoded lengths never come to the host.  Some items run out of
+    room (they decode to the symbols that fit), some are empty, some symbols have no code (holes coder: checked apart);
+    every decode record and every byte as the oracle's call on that item's encoded bytes gives them.  A few items and
+    thousands of them (the classes of the thread-per-item rule); a batch with a long item is refused."""
+    rng = np.random.default_rng(seed)
+    eng = engine or harness.Engine(w.product.lib, w.pcoder)
+    for n_items, longest in batches:  # (40 items a byte of the largest capacity from 128 bytes on: HUFD_DEC_TINY_PER_BYTE)
+        lens = rng.integers(0, longest + 1, n_items)
+        lens[rng.integers(0, n_items, 3)] = 0
+        plains = [inputs(rng, int(n), KINDS[i % 3]) for i, n in enumerate(lens)]
+        in_offs = np.concatenate([[5], 5 + np.cumsum(lens[:-1] + rng.integers(0, 4, n_items - 1))]).astype(np.int64)
+        in_total = int(in_offs[-1] + lens[-1]) + 64
+        blob = np.full(in_total, 0xC3, np.uint8)
+        for pl, o in zip(plains, in_offs):
+            blob[o:o + pl.size] = pl
+        caps = [min(int(2 * n + 4), 2 * longest) if i % 9 else int(rng.integers(0, n + 1)) for i, n in enumerate(lens)]  # every ninth: short
+        out_offs = np.concatenate([[1], 1 + np.cumsum(np.array(caps[:-1]) + 2)]).astype(np.int64)
+        out_total = int(out_offs[-1] + caps[-1]) + 64
+        d_in, d_enc, d_back = eng.alloc(in_total), eng.alloc(out_total), eng.alloc(in_total)
+        eng.upload(d_in, blob)
+        eng.fill(d_enc, SENTINEL, out_total)
+        eng.fill(d_back, SENTINEL, in_total)
+        eplan = eng.encode_plan([dict(in_offset=int(in_offs[i]), in_len=int(lens[i]), out_offset=int(out_offs[i]), out_capacity=caps[i])
+                                 for i in range(n_items)])
+        dplan = eng.decode_plan([])
+        eng.encode_launch(eplan, d_in, d_enc)
+        assert eng.decode_plan_from_encode(dplan, eplan)  # (behind the launch on the engine's stream: no results fetched)
+        eng.decode_launch(dplan, d_enc, d_back)
+        dres = eng.decode_results(dplan, n_items)
+        eres = eng.encode_results(eplan, n_items)
+        enc_bytes, back = eng.download(d_enc, out_total), eng.download(d_back, in_total)
+        want = np.full(in_total, SENTINEL, np.uint8)
+        for i in range(n_items):
+            stream = enc_bytes[out_offs[i]:out_offs[i] + eres[i][3]]
+            dd = w.oracle.new_decoder(w.ocoder)
+            sym = np.full(int(lens[i]) + 1, SENTINEL, np.uint8)
+            r = w.oracle.decode_call(dd, stream, 0, stream.size, sym, 0, int(lens[i]))
+            assert dres[i][:3] == (r.rc, r.err, r.produced), (n_items, i, dres[i], r, eres[i])
+            want[in_offs[i]:in_offs[i] + lens[i]] = sym[:lens[i]]
+            if eres[i][0] == 0:
+                assert r.produced == lens[i] and np.array_equal(sym[:lens[i]], plains[i]), i  # the round trip itself
+        assert np.array_equal(back, want)
+        # the plan is an ordinary one again after a reset from records
+        eng.lib.aws_huffman_amd_decode_plan_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        eng.lib.aws_huffman_amd_encode_plan_destroy(eplan)
+        eng.lib.aws_huffman_amd_decode_plan_destroy(dplan)
+        for ptr in (d_in, d_enc, d_back):
+            eng.free(ptr)
+    # a batch that is not one of short items: refused, the decode plan as it was
+    d_in = eng.alloc(70000)
+    eplan = eng.encode_plan([dict(in_offset=0, in_len=10, out_offset=0, out_capacity=40),
+                             dict(in_offset=100, in_len=30000, out_offset=100, out_capacity=60000)])
+    dplan = eng.decode_plan([dict(in_offset=0, in_len=0, out_offset=0, out_capacity=0)])
+    assert not eng.decode_plan_from_encode(dplan, eplan)
+    eng.lib.aws_huffman_amd_encode_plan_destroy(eplan)
+    eng.lib.aws_huffman_amd_decode_plan_destroy(dplan)
+    eng.free(d_in)
+    if engine is None:
+        eng.close()
+
+
 # ----------------------------------------------------------------------------- scenario: padding byte values
 def eos_padding_values(w):
     rng = np.random.default_rng(16)

@@ -104,6 +104,10 @@ def test_many_header_sized_items(world):
     pc.many_header_sized_items(world)
 
 
+def test_encode_then_decode_on_the_device(world):
+    pc.encode_then_decode_on_the_device(world)
+
+
 def test_mid_sized_items(world):
     pc.mid_sized_items(world)
 
