@@ -46,6 +46,12 @@ rounds = [
     ("mid_sized_items narrow", lambda s: pc.mid_sized_items(w, n_items=90, seed=s, engine=eng, modes=(None,), longest=1900)),
     ("many_header_sized_items", lambda s: pc.many_header_sized_items(w, n_items=4200, seed=s, engine=eng) if s % 2 == 0 else None),
     ("null_empty_cursors", lambda s: pc.null_empty_cursors(w, seed=s) if s % 4 == 0 else None),
+    # later in round 4: streams whose walks never become one (dec_sync_few / _true, dec_wide_fn_*), plans chained on the device
+    ("streams_out_of_step", lambda s: pc.streams_out_of_step(w, n=260_000 + 996 * (s % 50), seed=s, modes=(None,))),
+    ("never_in_step_stream", lambda s: pc.never_in_step_stream(w, n=300_000 + 1009 * (s % 40), seed=s) if s % 3 == 2 else None),
+    ("encode_then_decode_on_the_device", lambda s: pc.encode_then_decode_on_the_device(w, seed=s, engine=eng, batches=((60, 60), (7300, 90)))
+     if s % 2 == 1 else None),
+    ("plans_one_after_another", lambda s: pc.plans_one_after_another(w, seed=s) if s % 4 == 2 else None),
 ]
 rounds = [r for r in rounds if only in r[0]]
 t0 = time.time()
