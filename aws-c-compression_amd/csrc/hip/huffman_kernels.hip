@@ -3975,7 +3975,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
             meet_row = r + 1;
             settled = __all(one || heads == 0);
             if (r + 1 == kFastHopelessRows) {
-                hopeless = !settled && __popcll(__ballot(!one && heads != 0)) > kWave / 2;
+                hopeless = !settled && __popcll(__ballot(!one && heads != 0)) > kWave - kWave / 8;
             }
         }
     }
