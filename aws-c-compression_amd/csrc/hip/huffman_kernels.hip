@@ -5153,15 +5153,15 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 4) void dec_sync_few_kernel(
     const u32 lane = threadIdx.x;
     const u32 table = lds_offset_of(sh.wlut);
     const row_walk rw(LB, tb.max_bits);
-    if (tb.lut_bits > LB || tb.max_bits > HUFD_DEC_MAX_LUT_BITS || ns > HUFD_DEC_MAX_STATES || (table & ((4u << LB) - 1u)) != 0) {
-        return;
+    const u32 n = *list_count;
+    if (n == 0 || tb.lut_bits > LB || tb.max_bits > HUFD_DEC_MAX_LUT_BITS || ns > HUFD_DEC_MAX_STATES || (table & ((4u << LB) - 1u)) != 0) {
+        return; /* (nearly always: nothing was given up) */
     }
     few_table<LB>(sh, tb, lane);
     if (lane == 0) {
         sh.bad = 0;
     }
     __syncthreads();
-    const u32 n = *list_count;
     for (u32 k = blockIdx.x; k < n; k += gridDim.x) {
         const u32 c = list[k];
         const hufd_chunk_rec rec = chunk_rec[c];
