@@ -1,7 +1,8 @@
 """TEST INFRASTRUCTURE.  Parity scenarios against the emulator build of the library made with AddressSanitizer on top
 of UBSan (tests/test_emulated_asan.py builds it and runs this with libasan preloaded): the roads that index by what a
-stream says -- one-launch calls, long-code items across blocks, fixed-length coders, the ways back -- with every
-access of the kernels' code checked."""
+stream says -- one-launch calls, long-code items across blocks (settled and by transfer functions), fixed-length coders,
+the ways back, the chunks whose walks never become one, the packed end-of-stream chunks, plans chained on the device --
+with every access of the kernels' code checked."""
 import os
 import sys
 
@@ -13,8 +14,12 @@ import parity_cases as pc  # noqa: E402
 w = pc.World(harness.oracle_codec(), harness.Codec(harness.load_product(sys.argv[1]), "aws_"))
 import time
 
-for run in (lambda: pc.block_decode_calls(w, wants=(130, 513, 8192, 8193, 16385, 32768), kinds=("uniform", "long")), lambda: pc.fixed_length_coders(w), lambda: pc.wide_long_code_items(w, modes=(None,)),
-            lambda: pc.one_shot_roundtrips(w, sizes=[255, 4097, 16384])):
+for run in (lambda: pc.block_decode_calls(w, wants=(130, 513, 8192, 8193, 16385, 32768), kinds=("uniform", "long")), lambda: pc.fixed_length_coders(w),
+            lambda: pc.wide_long_code_items(w, modes=(None, "wide-fails")),  # (round 4: and every stream by transfer functions, dec_wide_fn_*)
+            lambda: pc.one_shot_roundtrips(w, sizes=[255, 4097, 16384]),
+            # round 4: streams whose walks never become one (dec_sync_few / _true), several short chunks a workgroup, plans chained on the device
+            lambda: pc.streams_out_of_step(w, n=170_000, modes=(None,)), lambda: pc.never_in_step_stream(w, n=200_000),
+            lambda: pc.mid_sized_items(w, n_items=40, modes=(None,)), lambda: pc.encode_then_decode_on_the_device(w, batches=((40, 50),))):
     t0 = time.time()
     run()
     print("%.0f s" % (time.time() - t0), flush=True)
