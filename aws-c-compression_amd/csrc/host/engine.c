@@ -1459,7 +1459,9 @@ static int dec_plan_fill(
         if (!keep) {
             err = 2;
         } else {
-            memcpy(keep, items, n_items * sizeof(*keep));
+            if (n_items) { /* (a plan of no items may be given no array: memcpy wants a pointer even for nothing) */
+                memcpy(keep, items, n_items * sizeof(*keep));
+            }
             p->h_items = keep;
         }
     }

@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--buffers", type=int, default=65536, help="cfg4: buffers in the batch")
     ap.add_argument("--buffer-bytes", type=int, default=16384, help="cfg4: bytes per buffer")
     ap.add_argument("--cpu-sample-mib", type=int, default=96, help="prefix of the stream timed on the CPU oracle")
+    ap.add_argument("--header-items", type=int, default=1 << 20, help="items of the header_items leg (16..80 bytes each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="stream, one GPU: leave out the short cfg4 and host-abi legs that ride along as extra keys")
@@ -397,6 +398,62 @@ def run_stream(args, ranks, lib, eng):
     return out, n, e_len, wall, kernel_ms, t_enc_ms, t_dec_ms, per_rank, seed
 
 
+def run_header_items(lib, eng, n_items=1 << 20, steps=5, warmup=2):
+    """A million header-field-sized strings (16..80 printable bytes each, 48 MiB: what the reference's one consumer, HPACK,
+    hands over one call at a time), as ONE batch: encode launch -> the decode plan made on the device from that launch's
+    records (aws_huffman_amd_decode_plan_from_encode: the encoded lengths never come to the host) -> decode launch ->
+    synchronise.  Wall clock per such round trip; the decoded bytes are compared with the input."""
+    import numpy as np
+
+    import harness
+
+    rng = np.random.default_rng(11)
+    lens = rng.integers(16, 81, n_items)
+    in_offs = np.concatenate([[0], np.cumsum(lens[:-1])]).astype(np.int64)
+    total_in, cap = int(lens.sum()), 128
+    arr = (harness.AmdEncodeItem * n_items)()
+    for i in range(n_items):
+        arr[i].in_offset, arr[i].in_len, arr[i].out_offset, arr[i].out_capacity = int(in_offs[i]), int(lens[i]), i * cap, cap
+        arr[i].eos_padding = 0xFF
+    d_in, d_enc, d_back = eng.alloc(total_in + 64), eng.alloc(n_items * cap + 64), eng.alloc(total_in + 64)
+    data = (32 + harness.splitmix64_bytes(17, total_in) % 95).astype(np.uint8)
+    eng.upload(d_in, data)
+    eplan, dplan = C.c_void_p(), C.c_void_p()
+    t0 = time.perf_counter()
+    assert lib.aws_huffman_amd_encode_plan_new(C.byref(eplan), eng.h, arr, n_items) == 0
+    plan_ms = (time.perf_counter() - t0) * 1e3
+    assert lib.aws_huffman_amd_decode_plan_new(C.byref(dplan), eng.h, None, 0) == 0
+    lib.aws_huffman_amd_decode_plan_from_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def round_trip():
+        eng.encode_launch(eplan, d_in, d_enc)
+        assert lib.aws_huffman_amd_decode_plan_from_encode(dplan, eplan, None) == 0
+        eng.decode_launch(dplan, d_enc, d_back)
+        eng.sync()
+
+    times = []
+    for k in range(warmup + steps):
+        if k == warmup:
+            eng.fill(d_back, 0xEE, total_in)  # (the timed steps decode into scrambled memory)
+        t0 = time.perf_counter()
+        round_trip()
+        times.append((time.perf_counter() - t0) * 1e3)
+    ms = statistics.median(times[warmup:])
+    eres, dres = eng.encode_results(eplan, n_items), eng.decode_results(dplan, n_items)
+    bit_exact = (all(r[0] == 0 for r in eres) and all(r[0] == 0 and r[2] == int(lens[i]) for i, r in enumerate(dres)) and
+                 np.array_equal(eng.download(d_back, total_in), data))
+    assert bit_exact, "the batch of header-sized items did not round-trip"
+    lib.aws_huffman_amd_encode_plan_destroy(eplan)
+    lib.aws_huffman_amd_decode_plan_destroy(dplan)
+    for ptr in (d_in, d_enc, d_back):
+        eng.free(ptr)
+    return {"workload": "%d items of 16..80 printable bytes (%.1f MiB), one batch: encode launch, decode plan chained to it on the "
+                        "device (no lengths on the host), decode launch, synchronise" % (n_items, total_in / (1 << 20)),
+            "bit_exact": bit_exact, "steps": steps, "round_trip_ms": round(ms, 4), "items_per_s": round(n_items / (ms * 1e-3)),
+            "value_GiBps": round(total_in / GIB / (ms * 1e-3), 2), "plan_ms": {"encode": round(plan_ms, 3), "decode_chained_call": "queued with the launches"},
+            "timing": "host wall clock around the three calls and the synchronise, median of %d" % steps}
+
+
 def run_cfg4(args, ranks, lib, eng):
     import numpy as np
 
@@ -657,6 +714,7 @@ def main():
             mid.buffer_bytes = 2048
             line["mid_items"] = leg(run_cfg4, mid, ranks, lib, eng)
             line["mid_items"]["workload"] = line["mid_items"]["workload"].replace("BASELINE configs[3]", "configs[3]'s shape with 2 KiB items")
+            line["header_items"] = run_header_items(lib, eng, n_items=args.header_items)
             short.steps, short.warmup = 3, 1  # (one 256 MiB buffer, or the stream's size when that was given and is smaller)
             line["host_abi"] = leg(run_host_abi, short, ranks, lib, eng, coder)
             line["host_abi"].pop("encode_path_frac_of_hbm_peak"), line["host_abi"].pop("decode_path_frac_of_hbm_peak")

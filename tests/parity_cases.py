@@ -906,7 +906,11 @@ def encode_then_decode_on_the_device(w, seed=119, engine=None, batches=((40, 50)
     d_in = eng.alloc(70000)
     eplan = eng.encode_plan([dict(in_offset=0, in_len=10, out_offset=0, out_capacity=40),
                              dict(in_offset=100, in_len=30000, out_offset=100, out_capacity=60000)])
-    dplan = eng.decode_plan([dict(in_offset=0, in_len=0, out_offset=0, out_capacity=0)])
+    dplan = C.c_void_p()  # (a plan of no items, from no array at all)
+    assert eng.lib.aws_huffman_amd_decode_plan_new(C.byref(dplan), eng.h, None, 0) == 0
+    spare = C.c_void_p()
+    assert eng.lib.aws_huffman_amd_encode_plan_new(C.byref(spare), eng.h, None, 0) == 0
+    eng.lib.aws_huffman_amd_encode_plan_destroy(spare)
     assert not eng.decode_plan_from_encode(dplan, eplan)
     eng.lib.aws_huffman_amd_encode_plan_destroy(eplan)
     eng.lib.aws_huffman_amd_decode_plan_destroy(dplan)

@@ -131,7 +131,7 @@ def test_two_ranks_split_the_batch(emulator, oracle):
 def test_single_rank_line(emulator, oracle):
     """The default line of one GPU: the stream, verified after the timed steps, with BASELINE configs[3] and the
     reference's entry points on host memory riding along as extra keys (here with a small batch)."""
-    out = run_bench(emulator, 1, extra=("--buffers", "12", "--buffer-bytes", "16384"))
+    out = run_bench(emulator, 1, extra=("--buffers", "12", "--buffer-bytes", "16384", "--header-items", "3000"))
     check_line(out, 1)
     e_len, digest = expected_stream(oracle, 0)
     assert (out["config"]["encoded_bytes"], out["config"]["sha256_encoded"]) == (e_len, digest)
@@ -140,5 +140,7 @@ def test_single_rank_line(emulator, oracle):
     for leg in ("cfg4", "mid_items", "host_abi"):
         assert out[leg]["bit_exact"] is True and "value_GiBps" in out[leg] and "encode_ms" in out[leg], leg  # (the emulator has no clock for events)
     assert "configs[3]" in out["cfg4"]["workload"] and "HOST memory" in out["host_abi"]["workload"]
+    # a batch of header-sized items encoded, its decode plan chained to it on the device, decoded back
+    assert out["header_items"]["bit_exact"] is True and out["header_items"]["items_per_s"] > 0 and "3000 items" in out["header_items"]["workload"]
     # what making the batch's plans cost rides along, and a traffic figure only where it was measured for the workload
     assert set(out["cfg4"]["plan_ms"]) == {"encode", "encode_resume", "decode"} and out["cfg4"]["roofline"]["traffic"] is None
