@@ -596,9 +596,40 @@ constexpr u32 kTinyThreads = 256;
 struct tiny_sink {
     u8 *out;
     u64 cap;
-    u64 produced;
+    u64 produced; /* bytes that have their place in the output (the last few of them may still wait in `held`) */
     u64 acc;  /* low nacc bits: code bits not yet stored, oldest highest */
     u32 nacc;
+    /* whole words on their way to ONE 16-byte store (round 4: what these one-lane-one-item kernels pay for is memory
+     * requests -- a line a lane and store -- and a 57-byte item was 14 word stores): words are held from a 16-byte
+     * aligned place on while 16 bytes still fit, and go out together when the fourth is in */
+    uint4 held;
+    u32 n_held;
+
+    __device__ void hold(u32 word) {
+        held.x = n_held == 0 ? word : held.x;
+        held.y = n_held == 1 ? word : held.y;
+        held.z = n_held == 2 ? word : held.z;
+        held.w = n_held == 3 ? word : held.w;
+        ++n_held;
+        if (n_held == 4) {
+            *reinterpret_cast<uint4 *>(out + produced - 16) = held;
+            n_held = 0;
+        }
+    }
+    /* the words still held, one store each (the item ends, or stops, with fewer than four) */
+    __device__ void release() {
+        u8 *at = out + produced - 4 * n_held;
+        if (n_held > 0) {
+            *reinterpret_cast<u32 *>(at) = held.x;
+        }
+        if (n_held > 1) {
+            *reinterpret_cast<u32 *>(at + 4) = held.y;
+        }
+        if (n_held > 2) {
+            *reinterpret_cast<u32 *>(at + 8) = held.z;
+        }
+        n_held = 0;
+    }
 
     /* stores what has gathered -- whole words once the output address is word aligned and four bytes still fit
      * (fewer than 32 gathered bits then wait: a one-lane walk pays per store), single bytes otherwise; true when
@@ -610,9 +641,15 @@ struct tiny_sink {
                 if (nacc < 32) {
                     return false;
                 }
-                *reinterpret_cast<u32 *>(out + produced) = __builtin_bswap32((u32)(acc >> (nacc - 32)));
+                const u32 word = __builtin_bswap32((u32)(acc >> (nacc - 32)));
+                const bool fresh16 = ((reinterpret_cast<uintptr_t>(out) + produced) & 15) == 0 && cap - produced >= 16;
                 produced += 4;
                 nacc -= 32;
+                if (n_held || fresh16) {
+                    hold(word);
+                } else {
+                    *reinterpret_cast<u32 *>(out + produced - 4) = word;
+                }
             } else {
                 if (nacc < 8) {
                     return false;
@@ -628,6 +665,7 @@ struct tiny_sink {
     }
     /* the whole bytes still waiting (there is room for them: they only wait while four bytes fit) */
     __device__ void finish() {
+        release();
         while (nacc >= 8) {
             out[produced++] = (u8)(acc >> (nacc - 8));
             nacc -= 8;
@@ -693,12 +731,79 @@ __global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
         return;
     }
 
+    if (it.ovf_bits == 0 && it.out_cap >= ((u64)n * tb.enc_max_bits + 7) / 8 + 4) {
+        /* Room for whatever the symbols turn into (what a caller sizing by the worst case gives every item) and nothing
+         * carried in: no byte of the output has to be asked for.  The reference's loop (source/huffman.c:161-184) is then
+         * code after code into the accumulator, a word out whenever 32 bits have gathered -- four of them as ONE 16-byte
+         * store, at whatever address (the memory system takes any alignment; what these one-lane-one-item kernels pay
+         * for is requests) --, the whole bytes left at the end, and the padding.  The general loop below asks three
+         * questions a symbol that have one answer here. */
+        u8 *out = d_out + it.out_off;
+        u64 acc = 0;
+        u32 nacc = 0, produced = 0, n_held = 0, bits = 0;
+        uint4 held = uint4{0, 0, 0, 0};
+        bool unknown = false;
+        u32 k = 0;
+        for (; k < n; ++k) {
+            const u64 ent = tab[symbol(k)];
+            const u32 len = (u32)(ent >> 32);
+            if (len == 0) { /* source/huffman.c:62-64: the symbol is consumed, the byte under construction is not written */
+                unknown = true;
+                break;
+            }
+            bits += len;
+            acc = (acc << len) | (u32)ent;
+            nacc += len;
+            if (nacc >= 32) {
+                const u32 word = __builtin_bswap32((u32)(acc >> (nacc - 32)));
+                nacc -= 32;
+                held.x = n_held == 0 ? word : held.x;
+                held.y = n_held == 1 ? word : held.y;
+                held.z = n_held == 2 ? word : held.z;
+                held.w = n_held == 3 ? word : held.w;
+                if (++n_held == 4) {
+                    unaligned_uint4 v = {held.x, held.y, held.z, held.w};
+                    *reinterpret_cast<unaligned_uint4 *>(out + produced) = v;
+                    produced += 16;
+                    n_held = 0;
+                }
+            }
+        }
+        if (n_held > 0) {
+            reinterpret_cast<unaligned_u32 *>(out + produced)->x = held.x;
+        }
+        if (n_held > 1) {
+            reinterpret_cast<unaligned_u32 *>(out + produced + 4)->x = held.y;
+        }
+        if (n_held > 2) {
+            reinterpret_cast<unaligned_u32 *>(out + produced + 8)->x = held.z;
+        }
+        produced += 4 * n_held;
+        while (nacc >= 8) {
+            out[produced++] = (u8)(acc >> (nacc - 8));
+            nacc -= 8;
+        }
+        if (unknown) {
+            rs.status = HUFD_ENC_UNKNOWN;
+            rs.consumed = k + 1;
+        } else if (nacc) { /* source/huffman.c:178-184 */
+            const u32 room = 8 - nacc;
+            out[produced++] = (u8)((acc << room) | (it.eos_padding & ((1u << room) - 1)));
+        }
+        rs.produced = produced;
+        rs.total_bits = bits;
+        results[item] = rs;
+        return;
+    }
+
     tiny_sink sink;
     sink.out = d_out + it.out_off;
     sink.cap = it.out_cap;
     sink.produced = 0;
     sink.acc = 0;
     sink.nacc = 0;
+    sink.held = uint4{0, 0, 0, 0};
+    sink.n_held = 0;
     bool stopped = false;
     if (it.ovf_bits) {
         if (sink.cap == 0) {
@@ -750,6 +855,8 @@ __global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
     }
     if (rs.status != HUFD_ENC_SHORT) {
         sink.finish(); /* (before a symbol without a code too: the reference had written those bytes) */
+    } else {
+        sink.release();
     }
     if (!stopped && sink.nacc) { /* source/huffman.c:178-184 */
         const u32 room = 8 - sink.nacc;
