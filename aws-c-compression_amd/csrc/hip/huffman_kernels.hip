@@ -709,11 +709,17 @@ __global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
     /* aligned 16-byte reads of the symbols, handed out one at a time (what counts is the number of requests) */
     const u32 lead = (u32)(reinterpret_cast<uintptr_t>(in) & 15u);
     const uint4 *blocks = reinterpret_cast<const uint4 *>(in - lead);
-    uint4 block = uint4{0, 0, 0, 0};
+    uint4 block = uint4{0, 0, 0, 0}, block_ahead = uint4{0, 0, 0, 0};
+    const u32 last_block = n ? (lead + n - 1) >> 4 : 0u;
     auto symbol = [&](u32 k) -> u32 {
         const u32 a = lead + k;
         if (k == 0 || (a & 15u) == 0) {
-            block = blocks[a >> 4];
+            /* (the block behind this one is asked for now and looked at sixteen symbols on: its trip to memory is not waited for) */
+            const u32 b = a >> 4;
+            block = k == 0 ? blocks[b] : block_ahead;
+            if (b < last_block) {
+                block_ahead = blocks[b + 1];
+            }
         }
         const u32 w = (a >> 2) & 3u;
         const u32 word = w == 0 ? block.x : (w == 1 ? block.y : (w == 2 ? block.z : block.w));
@@ -731,69 +737,79 @@ __global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
         return;
     }
 
-    if (it.ovf_bits == 0 && it.out_cap >= ((u64)n * tb.enc_max_bits + 7) / 8 + 4) {
+    if (it.ovf_bits == 0 && n != 0 && it.out_cap >= ((u64)n * tb.enc_max_bits + 7) / 8 + 4) {
         /* Room for whatever the symbols turn into (what a caller sizing by the worst case gives every item) and nothing
          * carried in: no byte of the output has to be asked for.  The reference's loop (source/huffman.c:161-184) is then
          * code after code into the accumulator, a word out whenever 32 bits have gathered -- four of them as ONE 16-byte
          * store, at whatever address (the memory system takes any alignment; what these one-lane-one-item kernels pay
-         * for is requests) --, the whole bytes left at the end, and the padding.  The general loop below asks three
-         * questions a symbol that have one answer here. */
+         * for is requests) --, the whole bytes left at the end, and the padding.  The kernel is bound by the instructions
+         * a symbol costs (a wave runs as long as its longest item): the symbols are taken a 16-byte block at a time, each
+         * at a place in the block the compiler knows, those in front of the item and behind it as codes of no bits; the
+         * general loop below asks three questions a symbol that have one answer here.  A symbol without a code (rare)
+         * sends the item through the general loop after all. */
         u8 *out = d_out + it.out_off;
         u64 acc = 0;
-        u32 nacc = 0, produced = 0, n_held = 0, bits = 0;
+        u32 nacc = 0, produced = 0, n_held = 0;
         uint4 held = uint4{0, 0, 0, 0};
         bool unknown = false;
-        u32 k = 0;
-        for (; k < n; ++k) {
-            const u64 ent = tab[symbol(k)];
-            const u32 len = (u32)(ent >> 32);
-            if (len == 0) { /* source/huffman.c:62-64: the symbol is consumed, the byte under construction is not written */
-                unknown = true;
-                break;
+        const u32 end = lead + n;
+        uint4 ahead = blocks[0];
+        for (u32 b = 0; b * 16 < end && !unknown; ++b) {
+            const uint4 blk = ahead;
+            if (b < last_block) {
+                ahead = blocks[b + 1]; /* (looked at sixteen symbols on: its trip to memory is not waited for) */
             }
-            bits += len;
-            acc = (acc << len) | (u32)ent;
-            nacc += len;
-            if (nacc >= 32) {
-                const u32 word = __builtin_bswap32((u32)(acc >> (nacc - 32)));
-                nacc -= 32;
-                held.x = n_held == 0 ? word : held.x;
-                held.y = n_held == 1 ? word : held.y;
-                held.z = n_held == 2 ? word : held.z;
-                held.w = n_held == 3 ? word : held.w;
-                if (++n_held == 4) {
-                    unaligned_uint4 v = {held.x, held.y, held.z, held.w};
-                    *reinterpret_cast<unaligned_uint4 *>(out + produced) = v;
-                    produced += 16;
-                    n_held = 0;
+            const u32 wds[4] = {blk.x, blk.y, blk.z, blk.w};
+#pragma unroll
+            for (u32 j = 0; j < 16; ++j) {
+                const u32 idx = b * 16 + j;
+                const bool mine = idx - lead < n && !unknown; /* (unsigned: also false in front of the item; nothing behind a symbol without a code) */
+                const u64 ent = tab[(wds[j >> 2] >> (8 * (j & 3))) & 0xFFu];
+                const u32 len = mine ? (u32)(ent >> 32) : 0u;
+                unknown = unknown || (mine && len == 0);
+                acc = (acc << len) | (mine ? (u32)ent : 0u);
+                nacc += len;
+                if (nacc >= 32) {
+                    const u32 word = __builtin_bswap32((u32)(acc >> (nacc - 32)));
+                    nacc -= 32;
+                    held.x = n_held == 0 ? word : held.x;
+                    held.y = n_held == 1 ? word : held.y;
+                    held.z = n_held == 2 ? word : held.z;
+                    held.w = n_held == 3 ? word : held.w;
+                    if (++n_held == 4) {
+                        unaligned_uint4 v = {held.x, held.y, held.z, held.w};
+                        *reinterpret_cast<unaligned_uint4 *>(out + produced) = v;
+                        produced += 16;
+                        n_held = 0;
+                    }
                 }
             }
         }
-        if (n_held > 0) {
-            reinterpret_cast<unaligned_u32 *>(out + produced)->x = held.x;
+        if (!unknown) {
+            if (n_held > 0) {
+                reinterpret_cast<unaligned_u32 *>(out + produced)->x = held.x;
+            }
+            if (n_held > 1) {
+                reinterpret_cast<unaligned_u32 *>(out + produced + 4)->x = held.y;
+            }
+            if (n_held > 2) {
+                reinterpret_cast<unaligned_u32 *>(out + produced + 8)->x = held.z;
+            }
+            produced += 4 * n_held;
+            const u32 bits = 8 * produced + nacc; /* every code bit of the item */
+            while (nacc >= 8) {
+                out[produced++] = (u8)(acc >> (nacc - 8));
+                nacc -= 8;
+            }
+            if (nacc) { /* source/huffman.c:178-184 */
+                const u32 room = 8 - nacc;
+                out[produced++] = (u8)((acc << room) | (it.eos_padding & ((1u << room) - 1)));
+            }
+            rs.produced = produced;
+            rs.total_bits = bits;
+            results[item] = rs;
+            return;
         }
-        if (n_held > 1) {
-            reinterpret_cast<unaligned_u32 *>(out + produced + 4)->x = held.y;
-        }
-        if (n_held > 2) {
-            reinterpret_cast<unaligned_u32 *>(out + produced + 8)->x = held.z;
-        }
-        produced += 4 * n_held;
-        while (nacc >= 8) {
-            out[produced++] = (u8)(acc >> (nacc - 8));
-            nacc -= 8;
-        }
-        if (unknown) {
-            rs.status = HUFD_ENC_UNKNOWN;
-            rs.consumed = k + 1;
-        } else if (nacc) { /* source/huffman.c:178-184 */
-            const u32 room = 8 - nacc;
-            out[produced++] = (u8)((acc << room) | (it.eos_padding & ((1u << room) - 1)));
-        }
-        rs.produced = produced;
-        rs.total_bits = bits;
-        results[item] = rs;
-        return;
     }
 
     tiny_sink sink;
@@ -5751,10 +5767,13 @@ __global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
     sr.start(d_in + it.in_off, it.in_len, it.first_bit);
     symbol_sink sink;
     sink.begin(d_out + it.out_off);
-    const u64 rem = it.in_len * 8;
-    u64 pos = it.first_bit;
+    /* (a thread's item is a few hundred bytes at most: positions and counts fit 32 bits, which is half the instructions
+     * of the loop's arithmetic) */
+    const u32 rem = (u32)(it.in_len * 8);
+    const u32 cap = it.out_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (u32)it.out_cap;
+    u32 pos = it.first_bit;
     u32 why = HUFD_STOP_NONE;
-    u64 n = 0, cap_bit = kNoBit;
+    u32 n = 0, cap_pos = 0xFFFFFFFFu;
     for (;;) {
         /* one symbol of source/huffman.c:232-255 */
         if (pos >= rem) {
@@ -5772,10 +5791,10 @@ __global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
             why = HUFD_STOP_INCOMPLETE;
             break;
         }
-        if (n < it.out_cap) {
+        if (n < cap) {
             sink.put(entry >> 8);
-        } else if (n == it.out_cap) {
-            cap_bit = pos; /* source/huffman.c:257-268: this symbol is not consumed */
+        } else if (n == cap) {
+            cap_pos = pos; /* source/huffman.c:257-268: this symbol is not consumed */
         }
         ++n;
         sr.skip(len);
@@ -5785,7 +5804,7 @@ __global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
     hufd_dec_result rs;
     rs.total_symbols = n;
     rs.stop_bit = pos;
-    rs.cap_bit = cap_bit;
+    rs.cap_bit = cap_pos == 0xFFFFFFFFu ? kNoBit : (u64)cap_pos;
     rs.stop_kind = why;
     rs.reserved = 0;
     results[item] = rs;

@@ -1140,7 +1140,8 @@ def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False, max_le
             nb = int(rng.integers(1, 33))
             ov = (int(rng.integers(0, 1 << nb)), nb)
         full = (ov[1] + 10 * b.size + 7) // 8 + 2
-        cap = [full, int(rng.integers(0, full + 1)), max(b.size * 5 // 8, 0), 0, int(rng.integers(0, 6))][int(rng.integers(0, 5))]
+        # (4 * size + 8: room for the worst case of any coder here -- the road enc_tiny takes without asking for bytes)
+        cap = [full, int(rng.integers(0, full + 1)), max(b.size * 5 // 8, 0), 0, int(rng.integers(0, 6)), 4 * b.size + 8][int(rng.integers(0, 6))]
         if i % 7 == 3:  # the exact size, and one less
             e = w.oracle.new_encoder(oc)
             e.overflow_bits.pattern, e.overflow_bits.num_bits = ov
