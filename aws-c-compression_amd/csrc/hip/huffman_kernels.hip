@@ -5763,10 +5763,6 @@ __global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
     }
     const u32 item = tiny_items[t];
     const hufd_dec_item it = items[item];
-    stream_reader sr;
-    sr.start(d_in + it.in_off, it.in_len, it.first_bit);
-    symbol_sink sink;
-    sink.begin(d_out + it.out_off);
     /* (a thread's item is a few hundred bytes at most: positions and counts fit 32 bits, which is half the instructions
      * of the loop's arithmetic) */
     const u32 rem = (u32)(it.in_len * 8);
@@ -5774,6 +5770,94 @@ __global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
     u32 pos = it.first_bit;
     u32 why = HUFD_STOP_NONE;
     u32 n = 0, cap_pos = 0xFFFFFFFFu;
+    if (!DEEP) {
+        /* The stretch of the stream where no question but "is this a code" and "is there room" has to be asked: every
+         * window lies wholly inside the stream.  The kernel is bound by the instructions a symbol costs (150 in the
+         * general loop below, with its end-of-stream tests, 64-bit positions and a reader that masks what lies behind
+         * the stream); here: window, table, symbol into a word of four, shift, a refill every 32 bits out of the
+         * 16-byte block in registers (the block behind it already asked for).  The general loop takes over where
+         * this one stops -- near the end of the stream, at a window without a code, or when the room runs out -- and
+         * reports what there is to report. */
+        const u32 need = tb.lut_bits > tb.max_bits ? tb.lut_bits : tb.max_bits;
+        const u8 *first = d_in + it.in_off;
+        const u32 lead = (u32)(reinterpret_cast<uintptr_t>(first) & 15u);
+        const uint4 *blocks = reinterpret_cast<const uint4 *>(first - lead);
+        const u32 end_bytes = lead + (u32)it.in_len;
+        if (rem >= pos + need + 64) {
+            uint4 blk = blocks[0], ahead = end_bytes > 16 ? blocks[1] : uint4{0, 0, 0, 0};
+            u32 wi = (lead * 8 + pos) >> 5; /* the word (of the aligned blocks) the walk starts in: in block 0 */
+            const auto next_word = [&]() -> u32 {
+                if ((wi & 3u) == 0 && wi != 0) {
+                    blk = ahead;
+                    if (((wi >> 2) + 1) * 16 < end_bytes) {
+                        ahead = blocks[(wi >> 2) + 1];
+                    }
+                }
+                const u32 k = wi & 3u;
+                const u32 raw = k == 0 ? blk.x : (k == 1 ? blk.y : (k == 2 ? blk.z : blk.w));
+                ++wi;
+                return __builtin_bswap32(raw);
+            };
+            const u32 w0 = next_word(), w1 = next_word();
+            const u32 off = (lead * 8 + pos) & 31u;
+            u64 win = (((u64)w0 << 32) | w1) << off;
+            u32 nb = 64 - off;
+            u8 *outp = d_out + it.out_off;
+            u32 word = 0, sh = 0, n_held = 0;
+            uint4 held = uint4{0, 0, 0, 0};
+            const u32 lbits = tb.lut_bits;
+            while (pos + need <= rem && n < cap) {
+                const u32 e = lut[(u32)(win >> (64 - lbits))];
+                const u32 len = e & 0xFFu;
+                if (len == 0) {
+                    break;
+                }
+                word |= (e >> 8) << sh;
+                sh += 8;
+                if (sh == 32) {
+                    held.x = n_held == 0 ? word : held.x;
+                    held.y = n_held == 1 ? word : held.y;
+                    held.z = n_held == 2 ? word : held.z;
+                    held.w = n_held == 3 ? word : held.w;
+                    word = 0;
+                    sh = 0;
+                    if (++n_held == 4) {
+                        unaligned_uint4 v = {held.x, held.y, held.z, held.w};
+                        *reinterpret_cast<unaligned_uint4 *>(outp) = v;
+                        outp += 16;
+                        n_held = 0;
+                    }
+                }
+                ++n;
+                pos += len;
+                win <<= len;
+                nb -= len;
+                if (nb <= 32) {
+                    win |= (u64)next_word() << (32 - nb);
+                    nb += 32;
+                }
+            }
+            if (n_held > 0) {
+                reinterpret_cast<unaligned_u32 *>(outp)->x = held.x;
+            }
+            if (n_held > 1) {
+                reinterpret_cast<unaligned_u32 *>(outp + 4)->x = held.y;
+            }
+            if (n_held > 2) {
+                reinterpret_cast<unaligned_u32 *>(outp + 8)->x = held.z;
+            }
+            outp += 4 * n_held;
+            for (u32 k = 0; k < sh; k += 8) {
+                *outp++ = (u8)(word >> k);
+            }
+        }
+    }
+    stream_reader sr = {};
+    if (pos < rem) {
+        sr.start(d_in + it.in_off + (pos >> 3), it.in_len - (pos >> 3), pos & 7u);
+    }
+    symbol_sink sink;
+    sink.begin(d_out + it.out_off + n);
     for (;;) {
         /* one symbol of source/huffman.c:232-255 */
         if (pos >= rem) {
