@@ -9841,9 +9841,11 @@ static void encode_three_kernels(const struct hufk_encode_args *a, hipStream_t s
         (void)hipMemsetAsync(a->careful_count, 0, sizeof(uint32_t), st);
     }
     stage_mark(events, 1, st);
-    hipLaunchKernelGGL(
-        enc_scan_small_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, a->seg_bits,
-        a->seg_unk, a->seg_bitoff, a->careful_list, a->careful_count, a->states, a->results, gate);
+    if (a->n_tiny != a->n_items) { /* (a plan of thread-per-item items only has nothing to scan: a thread an item that finds that out is 10 us; an EMPTY item is not such an item -- its record is written here) */
+        hipLaunchKernelGGL(
+            enc_scan_small_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, a->seg_bits,
+            a->seg_unk, a->seg_bitoff, a->careful_list, a->careful_count, a->states, a->results, gate);
+    }
     if (a->n_large) {
         hipLaunchKernelGGL(
             enc_scan_large_kernel, dim3(a->n_large), dim3(HUFD_SCAN_LARGE_THREADS), 256, st, a->items, a->large_items,
@@ -10304,9 +10306,11 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, long_list, long_count);
     }
     stage_mark(a->stage_events, 1, st);
-    hipLaunchKernelGGL(
-        dec_scan_small_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, ns, a->chunk_fn,
-        a->chunk_entry, a->chunk_base, a->states, a->results, gate);
+    if (a->n_tiny != a->n_items) { /* (as in the encoder: nothing to scan, and no empty item's record to write, in a plan of thread-per-item items only) */
+        hipLaunchKernelGGL(
+            dec_scan_small_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, ns, a->chunk_fn,
+            a->chunk_entry, a->chunk_base, a->states, a->results, gate);
+    }
     if (a->n_tiny && a->tables.deep_entries) {
         hipLaunchKernelGGL(
             dec_tiny_kernel<true>, dim3((a->n_tiny + kTinyDecThreads - 1) / kTinyDecThreads), dim3(kTinyDecThreads),
