@@ -33,7 +33,7 @@
 #define HUFD_TINY_MANY_BYTES 2048u /* symbols (encode); encoded bytes x 2 / 3 (decode) */
 #define HUFD_ENC_TINY_WAVE_BYTES 1024u /* the same class for encode where the one-pass kernel is used */
 #define HUFD_ENC_TINY_PER_BYTE 18u
-#define HUFD_ENC_TINY_PER_BYTE_ONE_PASS 300u /* the same where the one-pass encoder packs ragged tiles (csrc/host/engine.c: enc_tiny_per_byte) */
+#define HUFD_ENC_TINY_PER_BYTE_ONE_PASS 100u /* the same where the one-pass encoder packs ragged tiles (csrc/host/engine.c: enc_tiny_per_byte) */
 #define HUFD_DEC_TINY_PER_BYTE 40u /* (round 2: a chunk of a short stream costs ~14 ns now, was ~74) */
 #define HUFD_TINY_FEW_BYTES 128u   /* the class that always goes to a thread */
 #define HUFD_DEC_MAX_STATES 16u

@@ -709,17 +709,14 @@ __global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
     /* aligned 16-byte reads of the symbols, handed out one at a time (what counts is the number of requests) */
     const u32 lead = (u32)(reinterpret_cast<uintptr_t>(in) & 15u);
     const uint4 *blocks = reinterpret_cast<const uint4 *>(in - lead);
-    uint4 block = uint4{0, 0, 0, 0}, block_ahead = uint4{0, 0, 0, 0};
+    uint4 block = uint4{0, 0, 0, 0};
+    u32 block_at = 0xFFFFFFFFu; /* which block `block` holds (the general loop may start anywhere in the item) */
     const u32 last_block = n ? (lead + n - 1) >> 4 : 0u;
     auto symbol = [&](u32 k) -> u32 {
         const u32 a = lead + k;
-        if (k == 0 || (a & 15u) == 0) {
-            /* (the block behind this one is asked for now and looked at sixteen symbols on: its trip to memory is not waited for) */
-            const u32 b = a >> 4;
-            block = k == 0 ? blocks[b] : block_ahead;
-            if (b < last_block) {
-                block_ahead = blocks[b + 1];
-            }
+        if ((a >> 4) != block_at) {
+            block_at = a >> 4;
+            block = blocks[block_at];
         }
         const u32 w = (a >> 2) & 3u;
         const u32 word = w == 0 ? block.x : (w == 1 ? block.y : (w == 2 ? block.z : block.w));
@@ -737,24 +734,26 @@ __global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
         return;
     }
 
-    if (it.ovf_bits == 0 && n != 0 && it.out_cap >= ((u64)n * tb.enc_max_bits + 7) / 8 + 4) {
-        /* Room for whatever the symbols turn into (what a caller sizing by the worst case gives every item) and nothing
-         * carried in: no byte of the output has to be asked for.  The reference's loop (source/huffman.c:161-184) is then
-         * code after code into the accumulator, a word out whenever 32 bits have gathered -- four of them as ONE 16-byte
-         * store, at whatever address (the memory system takes any alignment; what these one-lane-one-item kernels pay
-         * for is requests) --, the whole bytes left at the end, and the padding.  The kernel is bound by the instructions
-         * a symbol costs (a wave runs as long as its longest item): the symbols are taken a 16-byte block at a time, each
-         * at a place in the block the compiler knows, those in front of the item and behind it as codes of no bits; the
-         * general loop below asks three questions a symbol that have one answer here.  A symbol without a code (rare)
-         * sends the item through the general loop after all. */
+    /* The stretch of the item where the output has room to spare: the reference's loop (source/huffman.c:161-184) is
+     * there code after code into the accumulator, a word out whenever 32 bits have gathered -- four of them as ONE
+     * 16-byte store, at whatever address (the memory system takes any alignment; these one-lane-one-item kernels pay for
+     * requests) -- and none of its questions about the next free byte.  The kernel is bound by the instructions a symbol
+     * costs (a wave runs as long as its longest item): the symbols are taken a 16-byte block at a time, each at a place
+     * in the block the compiler knows, those in front of the item, behind it or behind the stretch as codes of no bits.
+     * The stretch ends at a symbol without a code, or 64 bits short of the output's end: the general loop below takes
+     * over there with what has gathered, and everything the reference says about running out of room is its to say. */
+    u32 fast_done = 0, fast_bits = 0, fast_produced = 0, fast_nacc = 0;
+    u64 fast_acc = 0;
+    if (it.ovf_bits == 0 && n != 0 && it.out_cap >= 8) {
         u8 *out = d_out + it.out_off;
+        const u32 cap_bits = it.out_cap > 0x0FFFFFFFull ? 0x7FFFFFF8u : (u32)it.out_cap * 8u;
         u64 acc = 0;
-        u32 nacc = 0, produced = 0, n_held = 0;
+        u32 nacc = 0, produced = 0, n_held = 0, bits = 0, done = 0;
         uint4 held = uint4{0, 0, 0, 0};
-        bool unknown = false;
+        bool stop = false;
         const u32 end = lead + n;
         uint4 ahead = blocks[0];
-        for (u32 b = 0; b * 16 < end && !unknown; ++b) {
+        for (u32 b = 0; b * 16 < end && !stop; ++b) {
             const uint4 blk = ahead;
             if (b < last_block) {
                 ahead = blocks[b + 1]; /* (looked at sixteen symbols on: its trip to memory is not waited for) */
@@ -763,11 +762,15 @@ __global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
 #pragma unroll
             for (u32 j = 0; j < 16; ++j) {
                 const u32 idx = b * 16 + j;
-                const bool mine = idx - lead < n && !unknown; /* (unsigned: also false in front of the item; nothing behind a symbol without a code) */
+                const bool mine = idx - lead < n && !stop; /* (unsigned: also false in front of the item) */
                 const u64 ent = tab[(wds[j >> 2] >> (8 * (j & 3))) & 0xFFu];
-                const u32 len = mine ? (u32)(ent >> 32) : 0u;
-                unknown = unknown || (mine && len == 0);
-                acc = (acc << len) | (mine ? (u32)ent : 0u);
+                const u32 code_len = (u32)(ent >> 32);
+                const bool take = mine && code_len != 0 && bits + code_len + 64u <= cap_bits;
+                stop = stop || (mine && !take);
+                const u32 len = take ? code_len : 0u;
+                done += take ? 1u : 0u;
+                bits += len;
+                acc = (acc << len) | (take ? (u32)ent : 0u);
                 nacc += len;
                 if (nacc >= 32) {
                     const u32 word = __builtin_bswap32((u32)(acc >> (nacc - 32)));
@@ -785,39 +788,28 @@ __global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
                 }
             }
         }
-        if (!unknown) {
-            if (n_held > 0) {
-                reinterpret_cast<unaligned_u32 *>(out + produced)->x = held.x;
-            }
-            if (n_held > 1) {
-                reinterpret_cast<unaligned_u32 *>(out + produced + 4)->x = held.y;
-            }
-            if (n_held > 2) {
-                reinterpret_cast<unaligned_u32 *>(out + produced + 8)->x = held.z;
-            }
-            produced += 4 * n_held;
-            const u32 bits = 8 * produced + nacc; /* every code bit of the item */
-            while (nacc >= 8) {
-                out[produced++] = (u8)(acc >> (nacc - 8));
-                nacc -= 8;
-            }
-            if (nacc) { /* source/huffman.c:178-184 */
-                const u32 room = 8 - nacc;
-                out[produced++] = (u8)((acc << room) | (it.eos_padding & ((1u << room) - 1)));
-            }
-            rs.produced = produced;
-            rs.total_bits = bits;
-            results[item] = rs;
-            return;
+        if (n_held > 0) {
+            reinterpret_cast<unaligned_u32 *>(out + produced)->x = held.x;
         }
+        if (n_held > 1) {
+            reinterpret_cast<unaligned_u32 *>(out + produced + 4)->x = held.y;
+        }
+        if (n_held > 2) {
+            reinterpret_cast<unaligned_u32 *>(out + produced + 8)->x = held.z;
+        }
+        fast_produced = produced + 4 * n_held;
+        fast_done = done;
+        fast_bits = bits;
+        fast_nacc = nacc;
+        fast_acc = nacc ? acc & ((1ull << nacc) - 1) : 0;
     }
 
     tiny_sink sink;
     sink.out = d_out + it.out_off;
     sink.cap = it.out_cap;
-    sink.produced = 0;
-    sink.acc = 0;
-    sink.nacc = 0;
+    sink.produced = fast_produced;
+    sink.acc = fast_acc;
+    sink.nacc = fast_nacc;
     sink.held = uint4{0, 0, 0, 0};
     sink.n_held = 0;
     bool stopped = false;
@@ -841,8 +833,8 @@ __global__ __launch_bounds__(kTinyThreads) void enc_tiny_kernel(
             }
         }
     }
-    u64 bits = it.ovf_bits;
-    for (u32 k = 0; k < n && !stopped; ++k) {
+    u64 bits = it.ovf_bits + fast_bits;
+    for (u32 k = fast_done; k < n && !stopped; ++k) {
         if (sink.produced == sink.cap) { /* source/huffman.c:162-164 */
             rs.status = HUFD_ENC_SHORT;
             rs.consumed = k;
