@@ -5621,6 +5621,7 @@ __global__ __launch_bounds__(kTailThreads) void dec_sync_tail_kernel(
  * such items they cost far more than the symbols.
  */
 constexpr u32 kTinyDecThreads = 128;
+constexpr u32 kTinyDecDeepThreads = 512; /* a batch of items of a coder with long codes: the linked tables (tens of KiB) are filled per workgroup, and what a CU's LDS holds of them bounds its waves */
 
 struct stream_reader {
     /* the stream 16 aligned bytes at a time: what limits these one-lane-one-stream walks is the number of
@@ -5727,7 +5728,7 @@ __device__ __forceinline__ u32 deep_entry(const u32 *deep, u32 window) {
 }
 
 template <bool DEEP> /* codes of more than HUFD_DEC_MAX_LUT_BITS bits: linked tables, and items of any size */
-__global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
+__global__ __launch_bounds__(DEEP ? kTinyDecDeepThreads : kTinyDecThreads) void dec_tiny_kernel(
     hufd_tables tb,
     const hufd_dec_item *items,
     const u32 *tiny_items,
@@ -5740,16 +5741,16 @@ __global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
     u16 *lut = reinterpret_cast<u16 *>(dyn_lds);
     u32 *deep = reinterpret_cast<u32 *>(dyn_lds);
     if (DEEP) {
-        for (u32 i = threadIdx.x; i < tb.deep_entries; i += kTinyDecThreads) {
+        for (u32 i = threadIdx.x; i < tb.deep_entries; i += blockDim.x) {
             deep[i] = tb.deep_lut[i];
         }
     } else {
-        for (u32 i = threadIdx.x; i < (1u << tb.lut_bits); i += kTinyDecThreads) {
+        for (u32 i = threadIdx.x; i < (1u << tb.lut_bits); i += blockDim.x) {
             lut[i] = tb.dec_lut[i];
         }
     }
     __syncthreads();
-    const u32 t = blockIdx.x * kTinyDecThreads + threadIdx.x;
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiny) {
         return;
     }
@@ -5762,7 +5763,7 @@ __global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
     u32 pos = it.first_bit;
     u32 why = HUFD_STOP_NONE;
     u32 n = 0, cap_pos = 0xFFFFFFFFu;
-    if (!DEEP) {
+    {
         /* The stretch of the stream where no question but "is this a code" and "is there room" has to be asked: every
          * window lies wholly inside the stream.  The kernel is bound by the instructions a symbol costs (150 in the
          * general loop below, with its end-of-stream tests, 64-bit positions and a reader that masks what lies behind
@@ -5770,7 +5771,7 @@ __global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
          * 16-byte block in registers (the block behind it already asked for).  The general loop takes over where
          * this one stops -- near the end of the stream, at a window without a code, or when the room runs out -- and
          * reports what there is to report. */
-        const u32 need = tb.lut_bits > tb.max_bits ? tb.lut_bits : tb.max_bits;
+        const u32 need = DEEP ? 32u : (tb.lut_bits > tb.max_bits ? tb.lut_bits : tb.max_bits); /* (DEEP: the linked tables look at up to 32 bits) */
         const u8 *first = d_in + it.in_off;
         const u32 lead = (u32)(reinterpret_cast<uintptr_t>(first) & 15u);
         const uint4 *blocks = reinterpret_cast<const uint4 *>(first - lead);
@@ -5799,12 +5800,12 @@ __global__ __launch_bounds__(kTinyDecThreads) void dec_tiny_kernel(
             uint4 held = uint4{0, 0, 0, 0};
             const u32 lbits = tb.lut_bits;
             while (pos + need <= rem && n < cap) {
-                const u32 e = lut[(u32)(win >> (64 - lbits))];
+                const u32 e = DEEP ? deep_entry(deep, (u32)(win >> 32)) : lut[(u32)(win >> (64 - lbits))];
                 const u32 len = e & 0xFFu;
                 if (len == 0) {
                     break;
                 }
-                word |= (e >> 8) << sh;
+                word |= ((e >> 8) & 0xFFu) << sh;
                 sh += 8;
                 if (sh == 32) {
                     held.x = n_held == 0 ? word : held.x;
@@ -10305,7 +10306,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     }
     if (a->n_tiny && a->tables.deep_entries) {
         hipLaunchKernelGGL(
-            dec_tiny_kernel<true>, dim3((a->n_tiny + kTinyDecThreads - 1) / kTinyDecThreads), dim3(kTinyDecThreads),
+            dec_tiny_kernel<true>, dim3((a->n_tiny + kTinyDecDeepThreads - 1) / kTinyDecDeepThreads), dim3(kTinyDecDeepThreads),
             a->tables.deep_entries * sizeof(u32), st, a->tables, a->items, a->tiny_items, a->n_tiny, (const u8 *)a->d_in,
             (u8 *)a->d_out, a->states, a->results);
     } else if (a->n_tiny) {
