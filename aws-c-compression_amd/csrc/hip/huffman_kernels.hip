@@ -220,6 +220,22 @@ __device__ __forceinline__ u32 load_be32(const u8 *base, u64 index, u64 valid_by
     return v;
 }
 
+/* the first `n_words` big-endian words of `bytes` bytes at `src` (zeros behind them) into `dst`: 16 bytes a load where
+ * 16 lie inside (a thread that reads a stream's end on its own pays per request: 9 instead of 34 for 135 bytes) */
+__device__ __forceinline__ void load_be32_run(u32 *dst, const u8 *src, u64 bytes, u32 n_words) {
+    u32 k = 0;
+    for (; k + 4 <= n_words && (u64)k * 4 + 16 <= bytes; k += 4) {
+        const unaligned_uint4 v = *reinterpret_cast<const unaligned_uint4 *>(src + k * 4);
+        dst[k + 0] = __builtin_bswap32(v.x);
+        dst[k + 1] = __builtin_bswap32(v.y);
+        dst[k + 2] = __builtin_bswap32(v.z);
+        dst[k + 3] = __builtin_bswap32(v.w);
+    }
+    for (; k < n_words; ++k) {
+        dst[k] = (u64)k * 4 < bytes ? load_be32(src, k, bytes, true) : 0u;
+    }
+}
+
 /* ------------------------------------------------------------------ LDS bit image */
 
 /* OR the low `nbits` (1..32) bits of `pattern` into the MSB-first bit image at bit `q`. */
@@ -5563,9 +5579,7 @@ __global__ __launch_bounds__(kTailThreads) void dec_sync_tail_kernel(
     if (kind == 3) {
         /* a chunk of fewer than 136 bytes (a short item, or the last bytes of a long one): its whole transfer function */
         u32 *tiny = sh.words[threadIdx.x];
-        for (u32 k = 0; k < kTailWords; ++k) {
-            tiny[k] = load_be32(d_in + it.in_off + chunk_off, k, valid, false);
-        }
+        load_be32_run(tiny, d_in + it.in_off + chunk_off, valid, kTailWords);
         /* (an item's first chunk is only ever entered at the item's first bit) */
         const bool only = c == it.first_chunk;
         for (u32 st = only ? it.first_bit : 0u; st < (only ? it.first_bit + 1u : ns); ++st) {
@@ -5579,9 +5593,7 @@ __global__ __launch_bounds__(kTailThreads) void dec_sync_tail_kernel(
     const u8 *tsrc = d_in + it.in_off + chunk_off + (u64)n_full * HUFD_DEC_SUB_BYTES;
     const u64 tail_bytes = valid - (u64)n_full * HUFD_DEC_SUB_BYTES; /* 8 .. 135 */
     u32 *words = sh.words[threadIdx.x];
-    for (u32 k = 0; k < kTailWords; ++k) {
-        words[k] = load_be32(tsrc, k, tail_bytes, true);
-    }
+    load_be32_run(words, tsrc, tail_bytes, kTailWords);
     const u32 entry = tail_entry[c];
     const u32 limit = (n_full + 1 < HUFD_DEC_LANES ? 2u : 1u) * HUFD_DEC_SUB_BITS; /* the last lane's walk ends with the chunk */
     u32 stop_pos = 0, stop_why = 0;
@@ -9297,9 +9309,7 @@ __global__ __launch_bounds__(kTailThreads) void dec_emit_tail_kernel(
         /* the whole chunk: symbols while there is room, the start bit of the one that finds none
          * (source/huffman.c:257-268), else where and why the stream stops (:240-255) */
         u32 *tiny = sh.words[threadIdx.x];
-        for (u32 k = 0; k < kTailWords; ++k) {
-            tiny[k] = load_be32(d_in + it.in_off + chunk_off, k, valid, false);
-        }
+        load_be32_run(tiny, d_in + it.in_off + chunk_off, valid, kTailWords);
         const u64 room = it.out_cap > cbase ? it.out_cap - cbase : 0;
         u8 *out = d_out + it.out_off + cbase;
         const u32 rem = (u32)(valid * 8);
@@ -9341,9 +9351,7 @@ __global__ __launch_bounds__(kTailThreads) void dec_emit_tail_kernel(
     const u8 *tsrc = d_in + it.in_off + chunk_off + (u64)n_full * HUFD_DEC_SUB_BYTES;
     const u64 tail_bytes = valid - (u64)n_full * HUFD_DEC_SUB_BYTES;
     u32 *words = sh.words[threadIdx.x];
-    for (u32 k = 0; k < kTailWords; ++k) {
-        words[k] = load_be32(tsrc, k, tail_bytes, true);
-    }
+    load_be32_run(words, tsrc, tail_bytes, kTailWords);
     const u32 limit = (second < HUFD_DEC_LANES ? 2u : 1u) * HUFD_DEC_SUB_BITS;
     u8 *out = d_out + it.out_off + cbase + (chunk_symbols - n_first - n_second);
     u32 stop_pos = 0, stop_why = HUFD_STOP_NONE;
