@@ -9433,7 +9433,9 @@ __global__ __launch_bounds__(256) void dec_plan_from_encode_kernel(
     const hufd_enc_item e = enc_items[i];
     hufd_dec_item it;
     it.in_off = e.out_off;
-    it.in_len = enc_results[i].produced;
+    /* (never more than the item's room: the record of a plan that was not launched yet is whatever the memory held) */
+    const u64 produced = enc_results[i].produced;
+    it.in_len = produced < e.out_cap ? produced : e.out_cap;
     it.out_off = e.in_off;
     it.out_cap = e.in_len;
     it.first_bit = 0;
