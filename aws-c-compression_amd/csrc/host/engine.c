@@ -1435,8 +1435,16 @@ static int dec_plan_fill(
         err = hufs_copy_h2d(p->d_runs, h_runs, n_runs * 2 * sizeof(uint32_t), eng->stream);
     }
     /* (the wide chunks were listed from the back, last one first: behind the narrow ones, in their order) */
-    for (uint32_t k = 0; k < wide; ++k) {
-        h_tail[narrow + k] = h_tail[2 * (n_items ? n_items : 1) - 1 - k];
+    if (wide) {
+        /* (the two blocks may overlap when nearly every slot of the list is taken: turn the back block round where it
+         * lies, then move it down as a whole -- a copy entry by entry overwrote wide chunks it had not read yet) */
+        uint32_t *back = h_tail + (2 * (n_items ? n_items : 1) - wide);
+        for (uint32_t lo = 0, hi = wide - 1; lo < hi; ++lo, --hi) {
+            const uint32_t t = back[lo];
+            back[lo] = back[hi];
+            back[hi] = t;
+        }
+        memmove(h_tail + narrow, back, (size_t)wide * sizeof(uint32_t));
     }
     if (!err) {
         err = hufs_copy_h2d(p->d_tail, h_tail, tail * sizeof(uint32_t), eng->stream);

@@ -1344,6 +1344,36 @@ def mid_sized_items(w, n_items=150, seed=101, engine=None, modes=(None, "lean-sy
         eng.close()
 
 
+def streams_with_two_last_chunks(w, seed=127, engine=None, modes=(None, "lean-sync")):
+    """Items of k * 32 KiB + 1..7 encoded bytes: the item's last chunk holds fewer than 8 bytes, so the chunk in front of
+    it is listed as one a stream ends in as well -- two entries of the plan's end-of-stream list an item, one wide and
+    one narrow.  Plans in which such items outnumber the others (the list is then full to its last slot: wide chunks are
+    collected from its back and moved in behind the narrow ones), alone and mixed with short items."""
+    rng = np.random.default_rng(seed)
+    eng = engine or harness.Engine(w.product.lib, w.pcoder)
+    long_enc = oracle_encode(w, inputs(rng, 70_000, "uniform"))
+    assert long_enc.size > 2 * 32768 + 7
+
+    def cut_to(n, damaged=False):
+        e = long_enc[:n].copy()
+        if damaged:
+            e[n - 3:n] = 0xFF
+        return (e, 0, n)  # (room for every symbol: at least 5 bits each)
+
+    short = lambda n: (oracle_encode(w, inputs(rng, n, "uniform")), 0, n + 8)
+    for label, streams in (
+            ("two of 32772", [cut_to(32772), cut_to(32772)]),
+            ("three of 32772", [cut_to(32772)] * 3),
+            ("32773 + 65543 + 32769", [cut_to(32773), cut_to(65543), cut_to(32769, damaged=True)]),
+            ("one of 32772", [cut_to(32772)]),
+            ("three of 32780", [cut_to(32780)] * 3),
+            ("mixed with short ones", [cut_to(32775), short(900), cut_to(65537), cut_to(32770), short(1500), cut_to(32771)]),
+            ("more short ones than long", [short(700), cut_to(32772), short(800), short(2000), cut_to(65540), short(40)])):
+        decode_items_like_the_oracle(w, eng, w.ocoder, streams, rng, label, modes=modes, kinds=1)
+    if engine is None:
+        eng.close()
+
+
 def plans_one_after_another(w, seed=107):
     """An engine keeps the device arrays of ONE destroyed plan of each kind for the next aws_huffman_amd_*_plan_new: plans
     of different shapes made, launched and destroyed after one another on one engine (larger after smaller and the other

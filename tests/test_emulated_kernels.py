@@ -93,6 +93,10 @@ def test_plans_one_after_another(world):
     pc.plans_one_after_another(world)
 
 
+def test_streams_with_two_last_chunks(world):
+    pc.streams_with_two_last_chunks(world)
+
+
 def test_resident_sync_kernel_on_small_streams(world):
     """AWS_HUFFMAN_AMD_DECODE=resident-sync: dec_sync_resident (resident waves, the walk table once per LDS bank, tiles
     of 64 sub-chunks; round 4, measured at half dec_sync_lean's speed and kept behind the switch), made to take every
