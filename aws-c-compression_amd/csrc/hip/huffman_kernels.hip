@@ -3986,6 +3986,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     if (!TAIL && gate && gate[0] == 0) {
         return;
     }
+    HUFD_STAMP(0, 0);
     lean_shared<LB> &sh = *reinterpret_cast<lean_shared<LB> *>(dyn_lds);
     const u32 ns = tb.n_states;
     const u32 lane = threadIdx.x;
@@ -4089,6 +4090,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         }
     }
     __syncthreads();
+    HUFD_STAMP(0, 1);
 
     /* U: all entry states as one mask of heads per row, until every lane of the wave is down to one */
     u64 heads = active ? (1ull << ns) - 1ull : 0ull;
@@ -4111,6 +4113,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         }
     }
 
+    HUFD_STAMP(0, 2);
     const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
     bool ok = !active || (one && settled);
     if (lane == 0) {
@@ -4139,7 +4142,9 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     const u32 ref_exit = rw.offset_of(state);
     ok = ok && (!active || (!dead && ref_exit < ns));
     sh.exit_state[lane] = ref_exit;
+    HUFD_STAMP(0, 3);
     __syncthreads();
+    HUFD_STAMP(0, 4);
 
     /* H: my own sub-chunk from my true entry state, to the meeting bit */
     const u32 entry = lane ? sh.exit_state[lane - 1] : 0u;
@@ -4189,6 +4194,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         cand_count = (st >> 16) + tail0;
     }
 
+    HUFD_STAMP(0, 5);
     const u32 wsum = wave_sum(lane ? count : 0u);
     if ((lane & (kWave - 1)) == 0) {
         sh.wave_sum[lane / kWave] = wsum;
@@ -4257,6 +4263,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         chunk_fn[(u64)c * ns + lane] =
             cand_reached ? wide_pack(false, TAIL ? 0u : last_exit, cand_count + rest) : wide_pack(true, 0, cand_dead);
     }
+    HUFD_STAMP(0, 6);
 }
 
 /* ------------------------------------------------------------------ decode: sync, regular chunks, a length table per LDS bank */

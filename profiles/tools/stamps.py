@@ -66,6 +66,7 @@ for _ in range(2):
     eng.decode_launch(dp, d_enc, d_back)
     eng.decode_results(dp, 1)
 chunks = (e_len + 32767) // 32768
-report("dec_sync", rows(0, min(chunks, MAX_WG), 6),
-       ["load", "phase U (all entry states to one head)", "phase R (walk to the end)", "wait barrier", "publish + fold"])
+report("dec_sync_lean", rows(0, min(chunks, MAX_WG), 7)[1:],  # (row 0 is also the end-of-stream instantiation's)
+       ["loads, table, barrier", "phase U (all entry states to one head)", "phase R (the one walk to the end)", "wait barrier",
+        "phase H (own entry to the meeting bit) + sub-chunk 0's candidates", "sums, barrier, records out"])
 report("dec_emit", rows(1, min(chunks, MAX_WG), 6), ["load", "entry chains", "walk", "wait barrier", "copy out"])
