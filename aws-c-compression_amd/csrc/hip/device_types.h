@@ -45,6 +45,7 @@
 #define HUFD_DEEP_MAX_ENTRIES 16384u
 #define HUFD_DEEP_LINK 0x80000000u /* entry is a link: [15:0] first entry of the next table, [23:16] its index width */
 #define HUFD_DEC_TINY_BYTES 512u /* decode items up to this long are one thread's work (dec_tiny): no chunks */
+#define HUFD_DEC_PACK_MIN_CHUNKS 64u /* fewer such chunks in a launch: a workgroup each (dec_sync_lean<TAIL>) */
 #define HUFD_DEC_PACK_LANES 83u /* end-of-stream chunks with at most this many whole lanes share workgroups (dec_sync_pack: three slots of 85 lanes or more of fewer; two chunks a workgroup measured no faster than one) */
 #define HUFD_DEC_COOP_BYTES 768u /* ... and up to this long one wave's (dec_deep<false>): no chunks either */
 #define HUFD_DEC_BLOCK_BYTES 8192u /* what dec_block's workgroup takes in one turn: a lane per 64 bits */
@@ -102,8 +103,6 @@ struct hufd_tables {
     uint32_t deep_entries; /* != 0: codes longer than HUFD_DEC_MAX_LUT_BITS, decode walks deep_lut instead of dec_lut */
     const uint32_t *deep_lut; /* [deep_entries] root table of 1 << HUFD_DEEP_ROOT_BITS entries, then the linked ones;
                                * an entry is symbol << 8 | length, 0 = no code, or a link */
-    const uint32_t *bank_rows; /* NULL, or [256] for a decode table of up to 10 bits: dword r = the length bytes dec_sync_bank's
-                                * table holds for the 10-bit windows 4r .. 4r+3 (256 - length, no code: 256 - 48), lowest first */
     uint32_t fixed_bits; /* != 0: every code the decode table knows has this length: symbol k starts at bit k * fixed_bits,
                           * no walk has to find it (dec_fixed_*) */
     uint32_t fixed_complete; /* ... and every window of the decode table is a code: nothing to check before the symbols are written */
@@ -209,21 +208,5 @@ struct hufd_chunk_rec {
     uint32_t valid;   /* bytes of the item from the chunk's first on (saturated) */
     uint32_t item;
 };
-
-/* one per tile of dec_onepass, built with the plan.  A tile = up to 64 neighbouring sub-chunks (of HUFD_FUSE_SUB_BYTES) of one item that lie inside
- * its stream (with at least 8 more bytes behind them), one wave's work; but for an item's first tile, lane 0 is the last
- * sub-chunk of the tile in front (walked again only to learn how it is left): tiles advance by 63 sub-chunks. */
-struct hufd_tile_rec {
-    uint64_t src_off;    /* bytes from the input base pointer to the sub-chunk of lane 0 */
-    uint64_t out_off;    /* bytes from the output base pointer to the item's first symbol */
-    uint64_t out_cap;    /* the item's output capacity */
-    uint32_t item;
-    uint16_t n_lanes;    /* sub-chunks of the tile, lane 0 included */
-    uint16_t flags;      /* bit 0: the item's first tile, bit 1: its last, bits 8..10: the item's first bit */
-    uint32_t tail_chunk; /* (last tile) the item's first chunk that is not wholly inside the stream */
-    uint32_t reserved;
-};
-#define HUFD_TILE_LANES 64u
-#define HUFD_FUSE_SUB_BYTES 128u /* a lane's sub-chunk in dec_onepass */
 
 #endif /* HUFFMAN_AMD_DEVICE_TYPES_H */

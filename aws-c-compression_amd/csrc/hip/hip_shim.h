@@ -33,6 +33,8 @@ int hufs_stream_sync(void *stream);
 void *hufs_event_create(void);
 void hufs_event_destroy(void *event);
 int hufs_event_record(void *event, void *stream);
+void *hufs_event_create_untimed(void); /* an event that is only waited for */
+int hufs_event_sync(void *event);
 int hufs_event_elapsed_ms(void *start, void *stop, float *ms);
 
 #ifdef __cplusplus

@@ -108,6 +108,15 @@ int hufs_event_record(void *event, void *stream) {
     return (int)hipEventRecord((hipEvent_t)event, (hipStream_t)stream);
 }
 
+void *hufs_event_create_untimed(void) {
+    hipEvent_t e = nullptr;
+    return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? (void *)e : nullptr;
+}
+
+int hufs_event_sync(void *event) {
+    return (int)hipEventSynchronize((hipEvent_t)event);
+}
+
 int hufs_event_elapsed_ms(void *start, void *stop, float *ms) {
     hipError_t e = hipEventSynchronize((hipEvent_t)stop);
     if (e != hipSuccess) {

@@ -38,7 +38,7 @@ struct hufk_encode_args {
     uint8_t *seg_unk_seen;   /* [n_segs] scratch */
     uint64_t *item_total;    /* [n_items] scratch */
     uint32_t single_pass;    /* 1: one kernel reads the symbols once (enc_onepass) instead of count / scan / pack */
-    uint32_t fail_tile;      /* 1: a wave of enc_onepass is made to give up (AWS_HUFFMAN_AMD_ENCODE=one-pass-fails: the way back, for tests) */
+    uint32_t fail_tile;      /* 1: a wave of enc_onepass is made to give up (the way back, for tests: aws_huffman_amd_testing_set_encode_road) */
     struct hufd_enc_item_state *states; /* [n_items] scratch */
     struct hufd_enc_result *results;    /* [n_items] */
     void **stage_events; /* NULL, or 4 hipEvent_t: before count, after count, after scan, after pack */
@@ -92,9 +92,6 @@ struct hufk_decode_args {
     uint32_t *dense_count; /* [1] */
     uint16_t *lane_count;  /* [n_chunks][HUFD_DEC_LANES] scratch */
     uint8_t *chunk_regular; /* [n_chunks] scratch */
-    uint8_t *chunk_flags;   /* [2 * n_chunks] scratch of dec_sync_resident: chunk_bad, then chunk_one0 (zeroed by the launch) */
-    const uint32_t *item_first_tile; /* [n_items + 1] dec_sync_resident's tiles of the items in front (built with the plan) */
-    uint32_t n_res_tiles;            /* = item_first_tile[n_items] */
     uint32_t *tail_entry;   /* [n_chunks] scratch: state in which the last whole lane of an end-of-stream chunk leaves */
     uint32_t *chunk_entry; /* [n_chunks] scratch */
     uint64_t *chunk_base;  /* [n_chunks] scratch */
@@ -107,17 +104,9 @@ struct hufk_decode_args {
     uint32_t tail_stage_bytes; /* the most symbols a chunk that holds the end of a stream can decode to, +32 (0: unknown) */
     uint32_t tail_lanes;       /* the most whole lanes (sub-chunks with 8 more bytes behind them) a NARROW such chunk has */
     uint32_t n_tail_narrow;    /* the first so many of tail_chunks have at most HUFD_DEC_PACK_LANES whole lanes: they may share workgroups */
-    uint32_t old_sync; /* 0: dec_sync_lean for the chunks it takes (the default); 1: dec_sync_fast for every chunk
-                        * (AWS_HUFFMAN_AMD_DECODE=old-sync); 2: as 0 (=lean-sync); 3: dec_sync_bank where the decode table has up
-                        * to 10 bits (=bank-sync: a length table per LDS bank, measured slower); 4: dec_sync_resident for the chunks inside
-                        * streams of such a coder (=resident-sync: resident waves, the table once per bank; measured slower too) */
+    uint32_t one_chunk_a_workgroup; /* 1: the chunks streams end in get a workgroup each, however short and many (tests: the road a plan of
+                                     * few such chunks takes, for a plan of many) */
     void **stage_events; /* NULL, or 4 hipEvent_t: before sync, after sync, after scan, after emit */
-    const struct hufd_tile_rec *tiles; /* [n_tiles] dec_onepass (the chunks inside streams in one pass): built with the plan */
-    uint32_t n_tiles;
-    void *fuse_block;      /* hufk_decode_zero_bytes(n_tiles, n_items) bytes of scratch for dec_onepass, zeroed by the launch;
-                            * its first word: dec_onepass gave up, the two-pass kernels behind it take every chunk */
-    uint32_t fuse_mode;    /* 1: the two-pass kernels only (the default); 0: dec_onepass in front of them where the coder allows
-                            * (AWS_HUFFMAN_AMD_DECODE=one-pass); 2: the same with one tile made to give up (=one-pass-fails) */
 };
 
 /* one-time per-process kernel attribute setup (dynamic LDS above 64 KiB) */
@@ -129,9 +118,6 @@ int hufk_encode_one_pass_applies(const struct hufd_tables *tables);
 uint64_t hufk_encode_zero_bytes(uint32_t n_segs, uint32_t n_items);
 int hufk_encode_launch(const struct hufk_encode_args *args, void *stream);
 int hufk_decode_launch(const struct hufk_decode_args *args, void *stream);
-/* whether the chunks inside streams of this coder are decoded in one pass (dec_onepass), given fuse_mode != 1 */
-int hufk_decode_one_pass_applies(const struct hufd_tables *tables);
-uint64_t hufk_decode_zero_bytes(uint32_t n_tiles, uint32_t n_items);
 /* a plan of items that are all one thread's work: the kernels' item records and the list of such items (= all of them) from
  * the caller's records, copied to the device as they are (struct hufd_raw_dec_item / hufd_raw_enc_item) */
 int hufk_decode_plan_tiny_items(const void *raw_items, uint32_t n_items, struct hufd_dec_item *items, uint32_t *tiny_list, void *stream);

@@ -3646,261 +3646,6 @@ __device__ __forceinline__ u64 union_first_row(u32 ns, bool active, u32 hi, u32 
     return union_row_fast<LB>(heads, hi, lo, hops);
 }
 
-/*
- * (The TAIL instantiation must not spill vector registers: with a cap of 80 -- four spills to scratch -- about
- * one chunk in a thousand of BASELINE config 4 got a wrong symbol count, a different one every run: a value
- * that is live across the one-lane "careful" region came back from scratch with other lanes' slots never
- * written.  At four waves per SIMD it needs 85 registers and spills nothing.)
- */
-template <u32 LB, bool TAIL> /* TAIL: the chunks that hold the end of a stream (listed in tail_chunks); else all the others */
-__global__ __launch_bounds__(HUFD_DEC_LANES, TAIL ? (LB <= 10 ? 6 : 4) : 8) void dec_sync_fast_kernel(
-    hufd_tables tb,
-    const hufd_dec_item *items,
-    const u32 *chunk_item,
-    const u32 *tail_chunks,
-    const u8 *d_in,
-    u16 *fn_tab,
-    u16 *cp_tab,
-    u32 *chunk_fn,
-    u16 *lane_count,  /* [chunk][lane]: symbols of the true path that start in the sub-chunk (lane 0: from the meeting bit on) */
-    u8 *chunk_regular, /* [chunk]: 1 = these tables come from here and dec_emit_fast may use them */
-    u32 *tail_entry,  /* [chunk] TAIL: the state in which the last whole lane leaves (dec_sync_tail picks it up) */
-    u32 *slow_list,   /* chunks left to dec_sync_kernel */
-    u32 *slow_count) {
-
-    fast_shared<LB> &sh = *reinterpret_cast<fast_shared<LB> *>(dyn_lds);
-
-    const u32 ns = tb.n_states;
-    const u32 lane = threadIdx.x;
-    const u32 c = TAIL ? tail_chunks[blockIdx.x] : blockIdx.x;
-    const hufd_dec_item it = items[chunk_item[c]];
-    const u64 chunk_off = (u64)(c - it.first_chunk) * HUFD_DEC_CHUNK_BYTES;
-    const u64 valid = it.in_len > chunk_off ? it.in_len - chunk_off : 0;
-    const u8 *src = d_in + it.in_off + chunk_off;
-    if (!TAIL && valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
-        return; /* the other instantiation's */
-    }
-    /*
-     * Lanes whose sub-chunk and the 8 bytes after it lie inside the stream walk as described (every code that
-     * starts in them is whole).  In the chunk that holds the end of the stream the lanes behind them are idle,
-     * except for the first one: it follows the true path from where the last such lane leaves it to where the
-     * stream stops, symbol by symbol with the end-of-stream tests of source/huffman.c:232-255 -- through its own
-     * sub-chunk and, if a few more bytes follow, the next one.
-     */
-    const u32 n_full = !TAIL ? HUFD_DEC_LANES : (valid >= 8u ? (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES) : 0u);
-    const bool tail_chunk = TAIL;
-    const bool eligible = n_full >= 1 && ((uintptr_t)src & 15u) == 0 && tb.lut_bits <= LB &&
-                          tb.max_bits <= HUFD_DEC_MAX_LUT_BITS;
-    const bool active = !TAIL || lane < n_full;
-    if (TAIL && n_full == 0 && tb.lut_bits <= HUFD_DEC_MAX_LUT_BITS) {
-        /* fewer than 136 bytes: no lane is whole, and the whole chunk is one thread's work in dec_sync_tail / dec_emit_tail */
-        if (lane == 0) {
-            chunk_regular[c] = 3;
-        }
-        return;
-    }
-    if (!eligible) {
-        if (lane == 0) {
-            chunk_regular[c] = 0;
-            slow_list[atomicAdd(slow_count, 1u)] = c;
-        }
-        return;
-    }
-
-    HUFD_STAMP(0, 0);
-    u32 w[kFastRows];
-#pragma unroll
-    for (u32 r = 0; r < kFastRows; ++r) {
-        w[r] = 0;
-    }
-    if (active) {
-        const uint4 *line = reinterpret_cast<const uint4 *>(src + (u64)lane * HUFD_DEC_SUB_BYTES);
-#pragma unroll
-        for (u32 q = 0; q < kSubWords / 4; ++q) {
-            const uint4 v = line[q];
-            w[4 * q + 0] = __builtin_bswap32(v.x);
-            w[4 * q + 1] = __builtin_bswap32(v.y);
-            w[4 * q + 2] = __builtin_bswap32(v.z);
-            w[4 * q + 3] = __builtin_bswap32(v.w);
-        }
-        w[kSubWords] = __builtin_bswap32(*reinterpret_cast<const u32 *>(src + (u64)(lane + 1) * HUFD_DEC_SUB_BYTES));
-    }
-    for (u32 i = lane; i < (1u << LB); i += HUFD_DEC_LANES) {
-        const u32 len = tb.dec_lut[i >> (LB - tb.lut_bits)] & 0xFFu;
-        sh.wlut[i] = 0x10000u - (len ? len : kWalkDeadLen);
-        sh.hops[i] = (u16)(len ? 1u << len : 0u);
-    }
-    if (lane == 0) {
-        sh.bad = 0;
-#pragma unroll
-        for (u32 r = 0; r <= kFastMaxMeet; ++r) {
-            sh.sub0[r] = w[r];
-        }
-    }
-    __syncthreads();
-    HUFD_STAMP(0, 1);
-
-    const row_walk rw(LB, tb.max_bits);
-
-    /* U */
-    u64 heads = active ? (1ull << ns) - 1ull : 0ull;
-    u32 meet_row = 0; /* the same for the whole wave */
-    bool one = false, settled = false;
-#pragma unroll
-    for (u32 r = 0; r < kFastMaxMeet; ++r) {
-        if (!settled) {
-            heads = union_row_fast<LB>(heads, w[r], w[r + 1], sh.hops);
-            one = heads != 0 && (heads & (heads - 1)) == 0;
-            meet_row = r + 1;
-            settled = __all(one || heads == 0);
-        }
-    }
-    const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
-    bool ok = !active || (one && settled);
-    HUFD_STAMP(0, 2);
-
-    /* R (not for a wave behind the stream's whole lanes: it would walk zeros for as long as the others walk codes) */
-    u32 state = rw.state_at(meet_bit, 0);
-    u32 cp_state[kQuarters - 1] = {0, 0, 0};
-    bool dead = false;
-    const bool wave_on = !TAIL || (lane & ~(kWave - 1)) < n_full;
-#pragma unroll
-    for (u32 r = 1; r < kSubWords; ++r) {
-        if (r >= meet_row && wave_on) {
-            if (r % (kSubWords / kQuarters) == 0) {
-                cp_state[r / (kSubWords / kQuarters) - 1] = state;
-            }
-            state = rw.row(state, w[r], w[r + 1], sh.wlut);
-            dead = dead || rw.died(state);
-            state = rw.next_row(state, dead);
-        }
-    }
-    const u32 ref_count = state >> 16; /* symbols from the meeting bit to the end of the sub-chunk */
-    const u32 ref_exit = rw.offset_of(state);
-    ok = ok && (!active || (!dead && ref_exit < ns));
-    sh.exit_state[lane] = ref_exit;
-    __syncthreads();
-    HUFD_STAMP(0, 3);
-
-    /* H: my own sub-chunk from my true entry state */
-    const u32 entry = lane ? sh.exit_state[lane - 1] : 0u;
-    u32 count;
-    u32 head_cp = 0;         /* the head walk where it enters the second quarter, when the meeting row lies behind that */
-    const bool late = meet_row > kSubWords / kQuarters;
-    {
-        u32 st = rw.state_at(entry, 0);
-        bool dd = false;
-#pragma unroll
-        for (u32 r = 0; r < kFastMaxMeet; ++r) {
-            if (r < meet_row) {
-                if (r == kSubWords / kQuarters) {
-                    head_cp = st;
-                }
-                st = rw.row(st, w[r], w[r + 1], sh.wlut);
-                dd = dd || rw.died(st);
-                st = rw.next_row(st, dd);
-            }
-        }
-        const bool reached = !dd && rw.offset_of(st) == meet_bit;
-        ok = ok && (lane == 0 || !active || reached);
-        count = active ? (st >> 16) + ref_count : 0u; /* symbols of the true path that start in my sub-chunk (lanes >= 1) */
-    }
-
-    /* H: sub-chunk 0 from every entry state the chunk may be entered in (threads 0 .. ns-1) */
-    u32 cand_count = 0, cand_dead = 0;
-    bool cand_reached = false;
-    u64 cand_alive = 0;
-    if (lane < kWave) {
-        const u32 target = __shfl(meet_bit, 0), tail0 = __shfl(ref_count, 0); /* sub-chunk 0 is lane 0's */
-        u32 st = rw.state_at(lane < ns ? lane : 0u, 0);
-        bool dd = false;
-        u32 hi = sh.sub0[0];
-        for (u32 r = 0; r < meet_row; ++r) {
-            const u32 lo = sh.sub0[r + 1];
-            st = rw.row<true>(st, hi, lo, sh.wlut);
-            const bool now = rw.died(st) && !dd;
-            cand_dead = now ? (st >> 16) - 1u : cand_dead; /* the step that found no code is not a symbol */
-            dd = dd || now;
-            st = rw.next_row(st, dd);
-            hi = lo;
-        }
-        cand_reached = !dd && lane < ns && rw.offset_of(st) == target;
-        cand_alive = __ballot(cand_reached);
-        cand_count = (st >> 16) + tail0;
-    }
-
-    const u32 wsum = wave_sum(lane ? count : 0u);
-    if ((lane & (kWave - 1)) == 0) {
-        sh.wave_sum[lane / kWave] = wsum;
-    }
-    if (!ok) {
-        sh.bad = 1;
-    }
-    __syncthreads();
-    HUFD_STAMP(0, 4);
-    if (sh.bad) {
-        if (lane == 0) {
-            chunk_regular[c] = 0;
-            slow_list[atomicAdd(slow_count, 1u)] = c;
-        }
-        return;
-    }
-
-    /* the tables dec_scan and dec_emit read, in the format of the long way; only the rows they will look at */
-    u16 *fn_out = fn_tab + (u64)c * ns * HUFD_DEC_LANES;
-    u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
-    if (active) {
-        /* (lanes >= 1 have no row in fn_tab: their one count that matters is in lane_count) */
-#pragma unroll
-        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-            /* a checkpoint in front of the meeting row is not on the one walk: the first one is then taken from
-             * the head walk (not for lane 0, whose head is only known to dec_scan) */
-            const bool usable = (qq + 1) * (kSubWords / kQuarters) >= meet_row;
-            u32 tail = ref_count - (cp_state[qq] >> 16), bits = rw.offset_of(cp_state[qq]);
-            bool have = usable;
-            if (qq == 0 && late && lane != 0) {
-                tail = count - (head_cp >> 16);
-                bits = rw.offset_of(head_cp);
-                have = true;
-            }
-            cp[qq * HUFD_DEC_LANES] = (u16)(have ? 0x8000u | (bits << 11) | tail : 0u);
-        }
-        lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)(lane ? count : ref_count);
-        const u32 merged = lane ? 1u << entry : (u32)cand_alive;
-        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(merged | (ref_exit << 12));
-    } else if (TAIL) {
-        /* behind the whole lanes: never reached, as far as this kernel knows -- dec_sync_tail follows the true path
-         * through the one or two sub-chunks the stream ends in and rewrites their records */
-#pragma unroll
-        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-            cp[qq * HUFD_DEC_LANES] = 0;
-        }
-        lane_count[(u64)c * HUFD_DEC_LANES + lane] = 0;
-        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(kExitStop << 12);
-    }
-    if (TAIL && lane + 1 == n_full) {
-        tail_entry[c] = ref_exit;
-    }
-    if (lane == 0) {
-        chunk_regular[c] = tail_chunk ? 2 : 1;
-    }
-    if (lane < ns) {
-        u32 rest = 0;
-#pragma unroll
-        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
-            rest += sh.wave_sum[wv];
-        }
-        const u32 first_exit = sh.exit_state[0];
-        const u32 last_exit = sh.exit_state[HUFD_DEC_LANES - 1];
-        fn_out[(u64)lane * HUFD_DEC_LANES] =
-            cand_reached ? fn_pack(false, first_exit, cand_count & 0x7FFu) : fn_pack(true, 0, cand_dead);
-        /* (TAIL: symbols of the whole lanes only, and no exit yet: dec_sync_tail adds the stream's last symbols and how it ends) */
-        chunk_fn[(u64)c * ns + lane] =
-            cand_reached ? wide_pack(false, TAIL ? 0u : last_exit, cand_count + rest) : wide_pack(true, 0, cand_dead);
-    }
-    HUFD_STAMP(0, 5);
-}
-
 /* ------------------------------------------------------------------ decode: sync, regular chunks, fewer instructions */
 
 /*
@@ -3959,12 +3704,12 @@ __device__ __forceinline__ u32 lean_row(u32 state, u32 hi, u32 lo, u32 table, co
 }
 
 /*
- * dec_sync_fast for the chunks inside a stream with fewer instructions (it was bound by them: 297 M vector
+ * The sync kernel for regular chunks (round 1's dec_sync_fast, retired in round 5, with fewer instructions: it was bound by them, 297 M vector
  * instructions per GiB, 17.7 per symbol, at one per 4 cycles and SIMD).  Same phases, same tables out; what is
  * different is what a step of a walk costs: the number of certain steps a row is known to the compiler (no loop
  * around them), a table entry's address is one instruction (lean_row), the words are byte-swapped once.
  */
-template <u32 LB, u32 SURE, bool TAIL = false> /* TAIL: the chunks listed in tail_chunks (a stream ends in them): see dec_sync_fast */
+template <u32 LB, u32 SURE, bool TAIL = false> /* TAIL: the chunks listed in tail_chunks (a stream ends in them) */
 __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     hufd_tables tb,
     const hufd_chunk_rec *chunk_rec,
@@ -3980,12 +3725,8 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
                      * do meet: dec_sync_guess tries them its way */
     u32 *slow_count,
     u32 *long_list, /* the others that are not regular: dec_sync's (may be the same list as slow_list) */
-    u32 *long_count,
-    const u32 *gate /* NULL, or dec_onepass's ctl: the chunks inside streams are this kernel's only if that one gave up */) {
+    u32 *long_count) {
 
-    if (!TAIL && gate && gate[0] == 0) {
-        return;
-    }
     HUFD_STAMP(0, 0);
     lean_shared<LB> &sh = *reinterpret_cast<lean_shared<LB> *>(dyn_lds);
     const u32 ns = tb.n_states;
@@ -3997,7 +3738,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     if (!TAIL && valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
         return; /* holds the end of its stream: the other instantiation's */
     }
-    /* the lanes whose sub-chunk and the 8 bytes behind it lie inside the stream (dec_sync_fast) */
+    /* the lanes whose sub-chunk and the 8 bytes behind it lie inside the stream */
     const u32 n_full = !TAIL ? HUFD_DEC_LANES : (valid >= 8u ? (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES) : 0u);
     const bool active = !TAIL || lane < n_full;
     if (TAIL && n_full == 0 && tb.lut_bits <= HUFD_DEC_MAX_LUT_BITS) {
@@ -4011,7 +3752,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     const u32 table = lds_offset_of(sh.wlut);
     /* (a chunk may lie at any address: the loads need no alignment) */
     const bool eligible = n_full >= 1 && tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS &&
-                          rw.sure == SURE && (table & ((4u << LB) - 1u)) == 0;
+                          rw.sure >= SURE && (table & ((4u << LB) - 1u)) == 0;
     if (!eligible) {
         if (lane == 0) {
             chunk_regular[c] = 0;
@@ -4215,7 +3956,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         return;
     }
 
-    /* the tables dec_scan and dec_emit read (dec_sync_fast's) */
+    /* the tables dec_scan and dec_emit read (the regular chunks' format) */
     u16 *fn_out = fn_tab + (u64)c * ns * HUFD_DEC_LANES;
     if (active) {
 #pragma unroll
@@ -4266,351 +4007,6 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     HUFD_STAMP(0, 6);
 }
 
-/* ------------------------------------------------------------------ decode: sync, regular chunks, a length table per LDS bank */
-
-/*
- * What bounds dec_sync_lean is the LDS, not instruction issue (profiles/tools/micro/probe_r04.hip): a
- * wave's look-up in ONE 4 KiB table lands on the 32 banks at random, about 3.4 lanes on the fullest bank, so a
- * `ds_read_b32` holds the CU's LDS for ~7 cycles instead of 2, and the four SIMDs of a CU get one step per ~24 cycles
- * each whatever the number of waves (23.5 measured at 8 waves a SIMD, 26.8 at 4; two chains a lane change nothing).
- * With the table ONCE PER BANK a look-up never collides: lane l reads bank l % 32.  A copy per bank of dword entries
- * would be 128 KiB for 1024 windows; of BYTES (all a count-only walk needs: the code's length) it is 32 KiB:
- *
- *     byte address of window w for bank b = (w >> 2) << 7 | b << 2 | (w & 3)        (bank = address / 4 % 32)
- *
- * which costs the address two instructions more (the window's low two bits go under the bank, its high eight above),
- * and is shared by a workgroup of 1024 threads = FOUR chunks, two workgroups a CU, 8 waves a SIMD as before.  Measured
- * on the bare step: 16.4 cycles / 10.9 ns a step and SIMD against 23.5 / 13.6.  Same phases, same tables out as
- * dec_sync_lean; coders whose decode table has more than 10 bits keep that kernel (4096 windows x 32 banks do not fit).
- */
-constexpr u32 kBankLB = 10;
-constexpr u32 kBankTableBytes = (1u << kBankLB) * 32u;
-constexpr u32 kBankWinPos = 5; /* the window's lowest bit in the shifted pair: its high eight bits are address bits 7..14 as they stand */
-
-struct bank_slot { /* a chunk's own part of the workgroup's LDS */
-    u32 exit_state[HUFD_DEC_LANES];
-    u32 sub0[kFastMaxMeet + 4]; /* the first rows of sub-chunk 0, for the threads that try its entry states */
-    u32 wave_sum[HUFD_DEC_LANES / 64];
-    u32 bad;
-    u32 one0; /* sub-chunk 0's own walks have met */
-    u32 pad[2];
-};
-
-template <u32 CHUNKS> /* chunks a workgroup takes: CHUNKS x 256 threads share the tables */
-struct bank_shared {
-    u8 len[kBankTableBytes]; /* 256 - length, length 48 = no code: state += byte + 0xFF00 is the dword table's 0x10000 - length; at a multiple of its size */
-    u16 hops[1u << kBankLB]; /* 1 << code length of a window (the head it sends on), 0 = no code: phase U's */
-    bank_slot slot[CHUNKS];
-};
-
-__device__ __forceinline__ u32 bank_step(u32 state, u64 pair, u32 bank4) {
-    const u32 t = (u32)(pair >> (state & 63u));
-    const u32 at = (t & (0xFFu << 7)) | bank4;          /* the window's high eight bits, the lane's bank */
-    const u32 low = (t >> kBankWinPos) & 3u;            /* its low two */
-    return state + lds_byte_at(at | low) + 0xFF00u;
-}
-
-template <u32 SURE, bool STEP_BY_STEP = false>
-__device__ __forceinline__ u32 bank_row(u32 state, u32 hi, u32 lo, u32 bank4, const row_walk &rw) {
-    const u64 pair = ((u64)hi << 32) | lo;
-    if (!STEP_BY_STEP) {
-#pragma unroll
-        for (u32 i = 0; i < SURE; ++i) {
-            state = bank_step(state, pair, bank4);
-        }
-    }
-    while ((state & 0xFFFFu) > rw.thr) {
-        state = bank_step(state, pair, bank4);
-    }
-    return state;
-}
-
-template <u32 SURE, bool TAIL, u32 CHUNKS> /* TAIL: the chunks listed in tail_chunks (a stream ends in them): see dec_sync_fast */
-__global__ __launch_bounds__(CHUNKS * HUFD_DEC_LANES, 8) void dec_sync_bank_kernel(
-    hufd_tables tb,
-    const hufd_chunk_rec *chunk_rec,
-    const u32 *tail_chunks,
-    u32 n_list, /* chunks of the launch (TAIL: entries of tail_chunks) */
-    const u8 *d_in,
-    u16 *fn_tab,
-    u16 *cp_tab,
-    u32 *chunk_fn,
-    u16 *lane_count,
-    u8 *chunk_regular,
-    u32 *tail_entry,
-    u32 *slow_list,
-    u32 *slow_count,
-    u32 *long_list,
-    u32 *long_count,
-    const u32 *gate) {
-
-    if (!TAIL && gate && gate[0] == 0) {
-        return;
-    }
-    constexpr u32 kBankThreads = CHUNKS * HUFD_DEC_LANES;
-    bank_shared<CHUNKS> &sh = *reinterpret_cast<bank_shared<CHUNKS> *>(dyn_lds);
-    const u32 ns = tb.n_states;
-    const u32 t = threadIdx.x;
-    const u32 slot_no = t / HUFD_DEC_LANES, lane = t % HUFD_DEC_LANES;
-    bank_slot &sl = sh.slot[slot_no];
-    const u32 li = blockIdx.x * CHUNKS + slot_no;
-    const bool have = li < n_list;
-    const u32 c = have ? (TAIL ? tail_chunks[li] : li) : 0u;
-    const hufd_chunk_rec rec = chunk_rec[c];
-    const u64 valid = rec.valid;
-    const u8 *src = d_in + rec.src_off;
-    const row_walk rw(kBankLB, tb.max_bits, kBankWinPos);
-    const u32 table = lds_offset_of(sh.len);
-    const bool coder_ok = tb.lut_bits <= kBankLB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS && rw.sure == SURE && tb.bank_rows &&
-                          (table & (kBankTableBytes - 1u)) == 0;
-    if (!coder_ok) { /* (the same for every thread of the launch: the host does not launch this for such a coder) */
-        if (lane == 0 && have && (TAIL || valid >= (u64)HUFD_DEC_CHUNK_BYTES + 8u)) {
-            chunk_regular[c] = 0;
-            long_list[atomicAdd(long_count, 1u)] = c;
-        }
-        return;
-    }
-    /* the workgroup's tables: the length bytes come four windows a dword from the engine (hufd_tables.bank_rows); a thread
-     * puts its bank's copy of kPerThread consecutive rows into LDS, and one entry of phase U's table -- whatever becomes
-     * of its chunk */
-    const u32 bank4 = table | ((lane & 31u) << 2);
-    {
-        constexpr u32 kPerThread = 256 * 32 / kBankThreads; /* 8 with four chunks, 16 with two */
-        const u32 row0 = t / 32 * kPerThread;
-        uint4 raw[kPerThread / 4];
-#pragma unroll
-        for (u32 j = 0; j < kPerThread / 4; ++j) {
-            raw[j] = reinterpret_cast<const uint4 *>(tb.bank_rows + row0)[j];
-        }
-        const u32 own = tb.dec_lut[t % (1u << kBankLB) >> (kBankLB - tb.lut_bits)] & 0xFFu;
-        u32 *rows = reinterpret_cast<u32 *>(sh.len) + row0 * 32 + (t & 31u);
-#pragma unroll
-        for (u32 j = 0; j < kPerThread / 4; ++j) {
-            rows[(4 * j + 0) * 32] = raw[j].x;
-            rows[(4 * j + 1) * 32] = raw[j].y;
-            rows[(4 * j + 2) * 32] = raw[j].z;
-            rows[(4 * j + 3) * 32] = raw[j].w;
-        }
-#pragma unroll
-        for (u32 i = t; i < (1u << kBankLB); i += kBankThreads) { /* (one trip with four chunks, two with two) */
-            const u32 len = i == t ? own : tb.dec_lut[i >> (kBankLB - tb.lut_bits)] & 0xFFu;
-            sh.hops[i] = (u16)(len ? 1u << len : 0u);
-        }
-    }
-    /* the chunks this instantiation does not take; a slot without a chunk */
-    if (!have || (!TAIL && valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u)) {
-        __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): its share of the tables is in LDS */
-        return; /* (the barriers below count the waves that are still there) */
-    }
-    /* the lanes whose sub-chunk and the 8 bytes behind it lie inside the stream (dec_sync_fast) */
-    const u32 n_full = !TAIL ? HUFD_DEC_LANES : (valid >= 8u ? (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES) : 0u);
-    const bool active = !TAIL || lane < n_full;
-    if (TAIL && n_full == 0) {
-        /* fewer than 136 bytes: no lane is whole, and the whole chunk is one thread's work in dec_sync_tail / dec_emit_tail */
-        if (lane == 0) {
-            chunk_regular[c] = 3;
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        return;
-    }
-    u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
-    if (TAIL && lane >= kWave && (lane & ~(kWave - 1)) >= n_full) {
-        /* a wave wholly behind the stream's whole lanes (dec_sync_lean) */
-#pragma unroll
-        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-            cp[qq * HUFD_DEC_LANES] = 0;
-        }
-        lane_count[(u64)c * HUFD_DEC_LANES + lane] = 0;
-        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(kExitStop << 12);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        return;
-    }
-    u32 w[kFastRows];
-    {
-        const u32 mine = active ? lane : 0u;
-        const unaligned_uint4 *line = reinterpret_cast<const unaligned_uint4 *>(src + (u64)mine * HUFD_DEC_SUB_BYTES);
-#pragma unroll
-        for (u32 q = 0; q < kSubWords / 4; ++q) {
-            const unaligned_uint4 v = line[q];
-            w[4 * q + 0] = v.x;
-            w[4 * q + 1] = v.y;
-            w[4 * q + 2] = v.z;
-            w[4 * q + 3] = v.w;
-        }
-        w[kSubWords] = reinterpret_cast<const unaligned_u32 *>(src + (u64)(mine + 1) * HUFD_DEC_SUB_BYTES)->x;
-    }
-#pragma unroll
-    for (u32 r = 0; r < kFastRows; ++r) {
-        w[r] = __builtin_bswap32(w[r]);
-    }
-    if (lane == 0) {
-        sl.bad = 0;
-#pragma unroll
-        for (u32 r = 0; r <= kFastMaxMeet; ++r) {
-            sl.sub0[r] = w[r];
-        }
-#pragma unroll
-        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
-            sl.wave_sum[wv] = 0; /* (TAIL: of the waves that have left) */
-        }
-    }
-    __syncthreads();
-
-    /* U: all entry states as one mask of heads per row, until every lane of the wave is down to one */
-    u64 heads = active ? (1ull << ns) - 1ull : 0ull;
-    u32 meet_row = 0; /* the same for the whole wave */
-    bool one = false, settled = false;
-#pragma unroll
-    for (u32 r = 0; r < kFastMaxMeet; ++r) {
-        if (!settled) {
-            heads = r == 0 ? union_first_row<kBankLB>(ns, active, w[0], w[1], sh.hops) : union_row_fast<kBankLB>(heads, w[r], w[r + 1], sh.hops);
-            one = heads != 0 && (heads & (heads - 1)) == 0;
-            meet_row = r + 1;
-            settled = __all(one || heads == 0);
-        }
-    }
-    const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
-    bool ok = !active || (one && settled);
-    if (lane == 0) {
-        sl.one0 = one;
-    }
-
-    /* R: the one walk from the meeting bit to the end of the sub-chunk */
-    u32 state = rw.state_at(meet_bit, 0);
-    u32 cp_state[kQuarters - 1] = {0, 0, 0};
-    bool dead = false;
-#pragma unroll
-    for (u32 r = 1; r < kSubWords; ++r) {
-        if (r >= meet_row) {
-            if (r % (kSubWords / kQuarters) == 0) {
-                cp_state[r / (kSubWords / kQuarters) - 1] = state;
-            }
-            state = bank_row<SURE>(state, w[r], w[r + 1], bank4, rw);
-            dead = dead || rw.died(state);
-            state = TAIL ? rw.next_row(state, dead) : state + 32u;
-        }
-    }
-    const u32 ref_count = state >> 16; /* symbols from the meeting bit to the end of the sub-chunk */
-    const u32 ref_exit = rw.offset_of(state);
-    ok = ok && (!active || (!dead && ref_exit < ns));
-    sl.exit_state[lane] = ref_exit;
-    __syncthreads();
-
-    /* H: my own sub-chunk from my true entry state, to the meeting bit */
-    const u32 entry = lane ? sl.exit_state[lane - 1] : 0u;
-    u32 count;
-    u32 head_cp = 0; /* the head walk where it enters the second quarter, when the meeting row lies behind that */
-    const bool late = meet_row > kSubWords / kQuarters;
-    {
-        u32 st = rw.state_at(entry < ns ? entry : 0u, 0);
-        bool dd = false;
-#pragma unroll
-        for (u32 r = 0; r < kFastMaxMeet; ++r) {
-            if (r < meet_row) {
-                if (r == kSubWords / kQuarters) {
-                    head_cp = st;
-                }
-                st = bank_row<SURE>(st, w[r], w[r + 1], bank4, rw);
-                dd = dd || rw.died(st);
-                st = TAIL ? rw.next_row(st, dd) : st + 32u;
-            }
-        }
-        const bool reached = !dd && rw.offset_of(st) == meet_bit;
-        ok = ok && (lane == 0 || !active || reached);
-        count = active ? (st >> 16) + ref_count : 0u; /* symbols of the true path that start in my sub-chunk (lanes >= 1) */
-    }
-
-    /* H: sub-chunk 0 from every entry state the chunk may be entered in (threads 0 .. ns-1 of the chunk), step by step:
-     * the count of a walk that dies has to be right */
-    u32 cand_count = 0, cand_dead = 0;
-    bool cand_reached = false;
-    u64 cand_alive = 0;
-    if (lane < kWave) {
-        const u32 target = __shfl(meet_bit, 0), tail0 = __shfl(ref_count, 0); /* sub-chunk 0 is lane 0's */
-        u32 st = rw.state_at(lane < ns ? lane : 0u, 0);
-        bool dd = false;
-        u32 hi = sl.sub0[0];
-        for (u32 r = 0; r < meet_row; ++r) {
-            const u32 lo = sl.sub0[r + 1];
-            st = bank_row<SURE, true>(st, hi, lo, bank4, rw);
-            const bool now = rw.died(st) && !dd;
-            cand_dead = now ? (st >> 16) - 1u : cand_dead; /* the step that found no code is not a symbol */
-            dd = dd || now;
-            st = rw.next_row(st, dd);
-            hi = lo;
-        }
-        cand_reached = !dd && lane < ns && rw.offset_of(st) == target;
-        cand_alive = __ballot(cand_reached);
-        cand_count = (st >> 16) + tail0;
-    }
-
-    const u32 wsum = wave_sum(lane ? count : 0u);
-    if ((lane & (kWave - 1)) == 0) {
-        sl.wave_sum[lane / kWave] = wsum;
-    }
-    if (!ok) {
-        sl.bad = 1;
-    }
-    __syncthreads();
-    if (sl.bad) {
-        if (lane == 0) {
-            chunk_regular[c] = 0;
-            if (TAIL || !sl.one0) {
-                long_list[atomicAdd(long_count, 1u)] = c;
-            } else {
-                slow_list[atomicAdd(slow_count, 1u)] = c;
-            }
-        }
-        return;
-    }
-
-    /* the tables dec_scan and dec_emit read (dec_sync_fast's) */
-    u16 *fn_out = fn_tab + (u64)c * ns * HUFD_DEC_LANES;
-    if (active) {
-#pragma unroll
-        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-            const bool usable = (qq + 1) * (kSubWords / kQuarters) >= meet_row;
-            u32 tail = ref_count - (cp_state[qq] >> 16), bits = rw.offset_of(cp_state[qq]);
-            bool have_cp = usable;
-            if (qq == 0 && late && lane != 0) {
-                tail = count - (head_cp >> 16);
-                bits = rw.offset_of(head_cp);
-                have_cp = true;
-            }
-            cp[qq * HUFD_DEC_LANES] = (u16)(have_cp ? 0x8000u | (bits << 11) | tail : 0u);
-        }
-        lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)(lane ? count : ref_count);
-        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((lane ? 1u << entry : (u32)cand_alive) | (ref_exit << 12));
-    } else {
-        /* (TAIL) behind the whole lanes, in a wave that has some: as for the waves that left */
-#pragma unroll
-        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-            cp[qq * HUFD_DEC_LANES] = 0;
-        }
-        lane_count[(u64)c * HUFD_DEC_LANES + lane] = 0;
-        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(kExitStop << 12);
-    }
-    if (TAIL && lane + 1 == n_full) {
-        tail_entry[c] = ref_exit;
-    }
-    if (lane == 0) {
-        chunk_regular[c] = TAIL ? 2 : 1;
-    }
-    if (lane < ns) {
-        u32 rest = 0;
-#pragma unroll
-        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
-            rest += sl.wave_sum[wv];
-        }
-        const u32 first_exit = sl.exit_state[0];
-        const u32 last_exit = sl.exit_state[HUFD_DEC_LANES - 1];
-        fn_out[(u64)lane * HUFD_DEC_LANES] =
-            cand_reached ? fn_pack(false, first_exit, cand_count & 0x7FFu) : fn_pack(true, 0, cand_dead);
-        chunk_fn[(u64)c * ns + lane] =
-            cand_reached ? wide_pack(false, TAIL ? 0u : last_exit, cand_count + rest) : wide_pack(true, 0, cand_dead);
-    }
-}
-
 /* ------------------------------------------------------------------ decode: sync, several short end-of-stream chunks a workgroup */
 
 /*
@@ -4624,7 +4020,7 @@ __global__ __launch_bounds__(CHUNKS * HUFD_DEC_LANES, 8) void dec_sync_bank_kern
  * instead of wave votes, because a slot need not start on a wave.
  */
 constexpr u32 kPackMaxSlots = 16;
-constexpr u32 kPackMinChunks = 64; /* fewer end-of-stream chunks in a launch: a workgroup each (dec_sync_lean<TAIL>) */
+constexpr u32 kPackMinChunks = HUFD_DEC_PACK_MIN_CHUNKS;
 
 template <u32 LB>
 struct pack_shared {
@@ -4687,7 +4083,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 6) void dec_sync_pack_kernel(
     const u64 valid = rec.valid;
     const u8 *src = d_in + rec.src_off;
     const u32 n_full = valid >= 8u ? (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES) : 0u;
-    const bool eligible = tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS && rw.sure == SURE && (table & ((4u << LB) - 1u)) == 0 &&
+    const bool eligible = tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS && rw.sure >= SURE && (table & ((4u << LB) - 1u)) == 0 &&
                           n_full <= width;
     /* (threads that leave here still count for the barriers below as long as their wave lives: `mine` keeps them out of
      * everything but the barriers) */
@@ -4844,7 +4240,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 6) void dec_sync_pack_kernel(
         return;
     }
 
-    /* the tables dec_scan and dec_emit read (dec_sync_fast's) */
+    /* the tables dec_scan and dec_emit read (the regular chunks' format) */
     if (active) {
         u16 *mcp = cp + lane;
 #pragma unroll
@@ -4935,7 +4331,7 @@ __device__ __forceinline__ void dec_sync_guess_chunk(
     const u8 *src = d_in + rec.src_off;
     const row_walk rw(LB, tb.max_bits);
     const u32 table = lds_offset_of(sh.wlut);
-    const bool eligible = tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS && tb.min_bits >= 3 && rw.sure == SURE &&
+    const bool eligible = tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS && tb.min_bits >= 3 && rw.sure >= SURE &&
                           (table & ((4u << LB) - 1u)) == 0;
     if (!eligible) {
         if (lane == 0) {
@@ -5142,7 +4538,7 @@ __device__ __forceinline__ void dec_sync_guess_chunk(
         return;
     }
 
-    /* the tables dec_scan and dec_emit read (dec_sync_fast's).  (The lane number as a value the compiler cannot trace:
+    /* the tables dec_scan and dec_emit read (the regular chunks' format).  (The lane number as a value the compiler cannot trace:
      * where the records go is worked out here, not in front of the walks where the registers are needed.) */
     u32 lane_o = lane;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -5496,12 +4892,12 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_true_kernel(
 /* ------------------------------------------------------------------ decode: the end of a stream */
 
 /*
- * One THREAD per chunk that holds the end of a stream (after dec_sync_fast<TAIL>, which took its whole lanes):
+ * One THREAD per chunk that holds the end of a stream (after dec_sync_lean<TAIL> / dec_sync_pack, which took its whole lanes):
  * follows the true path from where the last whole lane leaves it to where the stream stops, symbol by symbol
  * with the end-of-stream tests of source/huffman.c:232-255, through the first sub-chunk behind the whole lanes
  * and the few bytes of the next one.  Then completes the chunk's tables: records of those one or two lanes,
  * and symbols + stop (or exit state) in the chunk function.  A walk of ~100 dependent steps is slow for one
- * thread and nothing for 65 536 of them side by side; inside dec_sync_fast it held a workgroup up and cost
+ * thread and nothing for 65 536 of them side by side; inside the chunk's workgroup it held a workgroup up and cost
  * the kernel its occupancy.
  */
 constexpr u32 kTailThreads = 128;
@@ -5577,7 +4973,7 @@ __global__ __launch_bounds__(kTailThreads) void dec_sync_tail_kernel(
     const u32 c = tail_chunks[i];
     const u32 kind = chunk_regular[c];
     if (kind != 2 && kind != 3) {
-        return; /* not taken by dec_sync_fast: the long way does all of it */
+        return; /* not taken by the regular chunks' kernel: the long way does all of it */
     }
     const u32 ns = tb.n_states;
     const hufd_dec_item it = items[chunk_item[c]];
@@ -7210,8 +6606,7 @@ __global__ __launch_bounds__(256) void dec_scan_small_kernel(
     u32 *chunk_entry,
     u64 *chunk_base,
     hufd_dec_item_state *states,
-    hufd_dec_result *results,
-    const u32 *fuse_ctl /* NULL, or dec_onepass's ctl: [0] == 0 says that kernel has decoded every chunk inside a stream */) {
+    hufd_dec_result *results) {
 
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) {
@@ -7221,20 +6616,13 @@ __global__ __launch_bounds__(256) void dec_scan_small_kernel(
     if (it.tiny) {
         return;
     }
-    /* the chunks in front of the one(s) the stream ends in: with dec_onepass done, the scan starts behind them, from what
-     * the last of them left (and then takes an item of any length: there are at most two chunks to go) */
-    const u32 inside = fuse_ctl && fuse_ctl[0] == 0 && it.in_len >= 8 ? (u32)((it.in_len - 8) / HUFD_DEC_CHUNK_BYTES) : 0u;
-    if (it.n_chunks > HUFD_SCAN_SMALL_MAX && inside == 0) {
+    if (it.n_chunks > HUFD_SCAN_SMALL_MAX) {
         return;
     }
     u32 state = it.first_bit;
     u64 total = 0;
     bool stopped = false;
-    if (inside) {
-        state = chunk_entry[it.first_chunk + inside] & 0xFFu;
-        total = chunk_base[it.first_chunk + inside];
-    }
-    for (u32 k = inside; k < it.n_chunks; ++k) {
+    for (u32 k = 0; k < it.n_chunks; ++k) {
         const u32 c = it.first_chunk + k;
         chunk_entry[c] = entry_pack(state, !stopped);
         chunk_base[c] = total;
@@ -7286,10 +6674,7 @@ static uint32_t scan_run_lds_bytes(uint32_t ns) {
 }
 
 __global__ __launch_bounds__(256) void dec_scan_runs_kernel(
-    const hufd_dec_item *items, const u32 *runs, u32 ns, const u32 *chunk_fn, u32 *run_fn, const u32 *gate) {
-    if (gate && gate[0] == 0) {
-        return; /* dec_onepass has done the chunks inside the streams: dec_scan_small goes on from there */
-    }
+    const hufd_dec_item *items, const u32 *runs, u32 ns, const u32 *chunk_fn, u32 *run_fn) {
     u32 *fn = reinterpret_cast<u32 *>(dyn_lds);
     u32 *sub = fn + kRunChunks * ns;
     const u32 run = blockIdx.x;
@@ -7311,11 +6696,7 @@ __global__ __launch_bounds__(256) void dec_scan_top_kernel(
     u32 *run_entry,
     u64 *run_base,
     hufd_dec_item_state *states,
-    hufd_dec_result *results,
-    const u32 *gate) {
-    if (gate && gate[0] == 0) {
-        return;
-    }
+    hufd_dec_result *results) {
     u32 *fn = reinterpret_cast<u32 *>(dyn_lds); /* [kTopTile][ns] */
     const u32 i = large_items[2 * blockIdx.x], run0 = large_items[2 * blockIdx.x + 1];
     const hufd_dec_item it = items[i];
@@ -7356,11 +6737,7 @@ __global__ __launch_bounds__(256) void dec_scan_apply_kernel(
     const u32 *run_entry,
     const u64 *run_base,
     u32 *chunk_entry,
-    u64 *chunk_base,
-    const u32 *gate) {
-    if (gate && gate[0] == 0) {
-        return;
-    }
+    u64 *chunk_base) {
     u32 *fn = reinterpret_cast<u32 *>(dyn_lds);
     u32 *sub = fn + kRunChunks * ns;
     u32 *sub_entry = sub + kSubRuns * ns;                           /* [kSubRuns] */
@@ -7406,913 +6783,6 @@ __global__ __launch_bounds__(256) void dec_scan_apply_kernel(
     }
 }
 
-/* ------------------------------------------------------------------ decode: one pass for the chunks inside a stream */
-
-/*
- * dec_sync_lean + dec_scan + dec_emit_fast read every encoded byte twice and walk every code twice (count, then emit):
- * 1.65 x the algorithmic HBM traffic and ~33 vector instructions a symbol.  This kernel reads the stream once and
- * walks it once.  Two things make that possible:
- *
- *  - a walk's symbols do not have to wait for their place in the output: they go to the lane's SLOT in LDS as they
- *    are found.  All lanes of a wave stand in the same row (32-bit word) of their sub-chunks, a row holds at most
- *    eight codes, and the steps of a row are unrolled (the codes that are certain to start in it, then nested
- *    conditions): the k-th code of a row is stored at (slot + symbols before the row) + k, k in the instruction.  The
- *    table entry is symbol << 16 | 4096 - length: one add moves the shift amount (low 12 bits) and a symbol count
- *    modulo 16 (the next four), which is what the row's end needs to move the slot address on; one byte store keeps
- *    the symbol.  (An 8-byte store per row of a register pair filled by v_perm_b32 was measured first: LDS stores
- *    that are not aligned cost several times their aligned price, 2.3 ms against this.)  When the counts of a tile
- *    are known the slots leave for HBM, eight lanes a slot, 16 bytes each (the memory system takes any alignment);
- *  - nothing waits for an entry state.  A TILE is one wave's work: 64 neighbouring sub-chunks of 128 bytes, and the
- *    three phases of dec_sync_lean per lane: U, all entry states of the sub-chunk as one mask of heads per row until
- *    one head is left (meeting row m, the same for the wave; meeting bit per lane) -- from there on the sub-chunk is
- *    walked the same way however it was entered; R, the one walk from the meeting bit to the end of the sub-chunk,
- *    symbols to the lane's slot; H, rows 0 .. m-1 again from the true entry state -- the exit state of the lane in
- *    front, one shuffle away -- symbols BEHIND that lane's R symbols in ITS slot: slot j then holds, in stream
- *    order and without a gap, the symbols from sub-chunk j's meeting bit to sub-chunk j+1's.  Lane 0 of a tile is
- *    the LAST sub-chunk of the tile in front, walked again only to tell lane 1 how it is left (its symbols are the
- *    other tile's): everything a tile computes is a function of its own bytes alone, and every tile costs the same
- *    (a first version that GUESSED entry states from a walk through the rows in front and walked again where the
- *    guess was wrong had 4 % of the tiles take twice the time -- and every tile behind them wait for their counts:
- *    2.3 ms).  The item's first tile is entered at the item's first bit.
- *
- * A tile's place in the output is the sum of the counts in front of it: the look-back of enc_onepass (a flagged word
- * per tile, a memory-side sum + arrival count per group of 64 tiles, the bits in front of every round of 64 groups
- * from one wave that does nothing else).
- *
- * Exactness: as dec_sync_lean -- the heads of every sub-chunk must fall into one within 16 rows, every H walk must land on
- * its own meeting bit, no walk may meet a window without a code, a slot's symbols must fit it (128), the output must
- * fit the item's capacity.  Whatever is not so (a damaged or cut stream, one that does not synchronise,
- * symbol-dense data, a short output buffer) raises ctl[0]; tiles behind
- * give up when they see it, nothing wrong has been written (a tile writes only once every tile in front of it has
- * published a count), and the kernels of the two-pass road, queued behind this one, look at ctl[0] first and then do
- * the whole launch.  Every wait is bounded the same way.  (source/huffman.c:213-286 is what is reproduced; this is
- * the road of BASELINE configs[2].)
- */
-constexpr u32 kFuseWaves = 8;
-constexpr u32 kFuseSubBytes = HUFD_FUSE_SUB_BYTES; /* a lane's sub-chunk: 128 bytes as in the two-pass kernels.  (64 bytes -- half the LDS a lane holds, so
-                                                     * 6 waves a SIMD instead of 4 -- was measured: a tile's front is then too short to cover the time its
-                                                     * neighbours' counts need to arrive, every wave polls, and the polls slow everything down: 4 ms and more.) */
-constexpr u32 kFuseSubWords = kFuseSubBytes / 4;
-constexpr u32 kFuseThreads = kFuseWaves * kWave;
-constexpr u32 kFuseRowSyms = 8;      /* codes that can start in a row (at least 4 bits each) */
-constexpr u32 kFuseSlotBytes = 136;  /* 34 words: neighbouring lanes' slots two banks apart */
-constexpr u32 kFuseSlotFill = 128;   /* a slot that fills up to here is not trusted (a row's eight bytes may lie behind) */
-constexpr u32 kFuseHeadBytes = 144;  /* an item's first symbols: its first sub-chunk in front of its meeting bit (16 rows of eight) */
-constexpr u32 kFuseField = 12;       /* bits of a walk state that hold the shift amount; the symbol count modulo 16 is the 4 above */
-constexpr u32 kFuseFieldMask = (1u << kFuseField) - 1u;
-constexpr u32 kFuseSpinLimit = 1u << 14;
-constexpr u32 kFuseReady = 1u << 31; /* tile_agg: [31] published, [23:0] symbols */
-
-struct fuse_walk {
-    u32 thr, mask, floor;
-    __device__ __host__ __forceinline__ fuse_walk(u32 lut_bits, u32 max_bits) {
-        thr = 512 + (32 - lut_bits) - 2; /* (row_walk's: 512 keeps the field positive through the certain steps of a dead walk) */
-        mask = ((1u << lut_bits) - 1u) << 2;
-        floor = thr - max_bits + 1;
-    }
-    __device__ __forceinline__ u32 state_at(u32 k) const { /* next code starts k bits into the current row, no symbols yet */
-        return thr + 32 - k;
-    }
-    __device__ __forceinline__ u32 offset_of(u32 state) const {
-        return thr + 32 - (state & kFuseFieldMask);
-    }
-    __device__ __forceinline__ bool open(u32 state) const { /* a code starts in the current row */
-        return (state & kFuseFieldMask) > thr;
-    }
-    __device__ __forceinline__ bool died(u32 state) const {
-        return (state & kFuseFieldMask) < floor;
-    }
-    __device__ __forceinline__ u32 count16_of(u32 state) const { /* symbols so far, modulo 16 */
-        return (state >> kFuseField) & 15u;
-    }
-};
-
-template <u32 LB>
-struct fuse_shared {
-    u32 wlut[1u << LB]; /* symbol << 16 | 4096 - length, length 48 = no code; at a multiple of its own size */
-    u16 hops[1u << LB]; /* 1 << code length of a window (the head it sends on), 0 = no code */
-    /* per wave: the lanes' slots, then room for an item's first symbols (what any other tile's lane 0 writes there is never read) */
-    __attribute__((aligned(16))) u8 slots[kFuseWaves][kWave * kFuseSlotBytes + kFuseHeadBytes];
-    u32 meta[kFuseWaves][kWave]; /* per slot: where its symbols go in the tile [15:0], how many [31:16] */
-};
-
-template <u32 POS>
-__device__ __forceinline__ void fuse_step(u32 &state, u64 pair, u32 table, const fuse_walk &fw, u8 *lds_bytes, u32 at) {
-    const u32 e = lds_word_at(((u32)(pair >> (state & 63u)) & fw.mask) | table);
-    lds_bytes[at + POS] = (u8)(e >> 16);
-    state += e;
-}
-/* the codes of a row behind the certain ones: nested, so that a lane's k-th code has a compile-time place */
-template <u32 POS>
-__device__ __forceinline__ void fuse_more(u32 &state, u64 pair, u32 table, const fuse_walk &fw, u8 *lds_bytes, u32 at) {
-    if constexpr (POS < kFuseRowSyms) {
-        if (fw.open(state)) {
-            fuse_step<POS>(state, pair, table, fw, lds_bytes, at);
-            fuse_more<POS + 1>(state, pair, table, fw, lds_bytes, at);
-        }
-    }
-}
-template <u32 POS, u32 SURE>
-__device__ __forceinline__ void fuse_sure(u32 &state, u64 pair, u32 table, const fuse_walk &fw, u8 *lds_bytes, u32 at) {
-    if constexpr (POS < SURE) {
-        fuse_step<POS>(state, pair, table, fw, lds_bytes, at);
-        fuse_sure<POS + 1, SURE>(state, pair, table, fw, lds_bytes, at);
-    }
-}
-
-/* what a tile waits for, asked for together and waited for once (a poll costs a trip to memory: five of them one after
- * the other made a missed first look cost five trips) */
-__device__ __forceinline__ void fuse_ask_all(
-    const u32 *pa, const u64 *pb, const u64 *pb2, const u64 *prb, const u64 *pib, const u32 *pctl, u32 &a, u64 &b, u64 &b2, u64 &rb,
-    u64 &ib, u32 &gave_up) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("global_load_dword %0, %6, off sc1\n\t"
-                 "global_load_dwordx2 %1, %7, off sc1\n\t"
-                 "global_load_dwordx2 %2, %8, off sc1\n\t"
-                 "global_load_dwordx2 %3, %9, off sc1\n\t"
-                 "global_load_dwordx2 %4, %10, off sc1\n\t"
-                 "global_load_dword %5, %11, off sc1\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(a), "=&v"(b), "=&v"(b2), "=&v"(rb), "=&v"(ib), "=&v"(gave_up)
-                 : "v"(pa), "v"(pb), "v"(pb2), "v"(prb), "v"(pib), "v"(pctl)
-                 : "memory");
-#else
-    a = *pa;
-    b = *pb;
-    b2 = *pb2;
-    rb = *prb;
-    ib = *pib;
-    gave_up = *pctl;
-#endif
-}
-/* the value of the lane in front / behind (lane 0 / lane 63: its own), and of a lane every lane names alike: data-parallel
- * moves and a scalar read, no LDS permute and no index register kept for it */
-__device__ __forceinline__ u32 wave_from_front(u32 v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false); /* wave_shr:1 */
-#else
-    return __shfl_up(v, 1);
-#endif
-}
-__device__ __forceinline__ u32 wave_from_behind(u32 v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xF, 0xF, false); /* wave_shl:1 */
-#else
-    return __shfl_down(v, 1);
-#endif
-}
-__device__ __forceinline__ u32 wave_read(u32 v, u32 lane_same_everywhere) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (u32)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)lane_same_everywhere));
-#else
-    return __shfl(v, lane_same_everywhere);
-#endif
-}
-
-/* layout of the block the kernel wants zeroed before every launch (all offsets multiples of 8) */
-struct dec_onepass_layout {
-    uint64_t ctl, tile_agg, group_acc, round_base, item_base, bytes;
-};
-static dec_onepass_layout dec_onepass_layout_of(uint64_t n_tiles, uint64_t n_items) {
-    const uint64_t groups = (n_tiles + kOpGroupTiles - 1) / kOpGroupTiles;
-    const uint64_t rounds = groups; /* (a round is what the grid does in one turn, at least a group: no more rounds than groups) */
-    dec_onepass_layout l;
-    l.ctl = 0;
-    l.tile_agg = 32;
-    l.group_acc = l.tile_agg + ((n_tiles * 4 + 7) & ~7ull);
-    l.round_base = l.group_acc + (groups ? groups : 1) * 8 * kOpGroupStride;
-    l.item_base = l.round_base + (rounds + 1) * 8;
-    l.bytes = l.item_base + (n_items ? n_items : 1) * 8;
-    return l;
-}
-
-/* (diagnostic build: this kernel keeps its stamp sums in registers -- static LDS in front of the tables would move them
- * off the multiple of their size that the walk's addressing wants) */
-#ifdef HUFD_STAMPS
-#define FUSE_STAMP_DECL unsigned long long fuse_stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define FUSE_STAMP_ADD(phase)                                                                                          \
-    do {                                                                                                               \
-        if (threadIdx.x == 0) {                                                                                        \
-            fuse_stamp_acc[phase] += (unsigned long long)clock64();                                                    \
-        }                                                                                                              \
-    } while (0)
-#define FUSE_STAMP_COUNT(phase, n)                                                                                     \
-    do {                                                                                                               \
-        if (threadIdx.x == 0) {                                                                                        \
-            fuse_stamp_acc[phase] += (unsigned long long)(n);                                                          \
-        }                                                                                                              \
-    } while (0)
-#define FUSE_STAMP_FLUSH                                                                                               \
-    do {                                                                                                               \
-        if (threadIdx.x == 0 && blockIdx.x < HUFD_STAMP_MAX_WG) {                                                      \
-            for (u32 i = 0; i < 8; ++i) {                                                                              \
-                hufd_stamp_rows[(u64)blockIdx.x * 8 + i] = fuse_stamp_acc[i];                                          \
-            }                                                                                                          \
-        }                                                                                                              \
-    } while (0)
-#else
-#define FUSE_STAMP_DECL
-#define FUSE_STAMP_ADD(phase)
-#define FUSE_STAMP_COUNT(phase, n)
-#define FUSE_STAMP_FLUSH
-#endif
-
-template <u32 LB, u32 SURE>
-__global__ __launch_bounds__(kFuseThreads, 4) void dec_onepass_kernel(
-    hufd_tables tb,
-    const hufd_tile_rec *__restrict__ tiles,
-    u32 n_tiles,
-    const u8 *__restrict__ d_in,
-    u8 *__restrict__ d_out,
-    u32 *ctl,        /* [0] raised by the first tile that cannot go this way, [1] which and why; zeroed */
-    u32 *tile_agg,   /* [n_tiles] zeroed */
-    u64 *group_acc,  /* zeroed */
-    u64 *round_base, /* [rounds + 1] zeroed */
-    u64 *item_base,  /* [n_items] zeroed */
-    u32 *chunk_entry, /* of the chunk behind an item's last chunk inside the stream: what dec_scan_small goes on from */
-    u64 *chunk_base,
-    u32 fail_tile /* a tile that is to give up (tests of the way back); HUFD_NONE32: none */,
-    u32 round_groups /* groups of kOpGroupTiles tiles that the grid takes in one turn = a round of the look-back (at most 128) */) {
-
-    FUSE_STAMP_DECL
-    fuse_shared<LB> &sh = *reinterpret_cast<fuse_shared<LB> *>(dyn_lds);
-    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = uniform32(tid / kWave);
-    for (u32 i = tid; i < (1u << LB); i += kFuseThreads) {
-        const u32 e = tb.dec_lut[i >> (LB - tb.lut_bits)];
-        const u32 len = e & 0xFFu;
-        sh.wlut[i] = ((e >> 8) << 16) | ((1u << kFuseField) - (len ? len : kWalkDeadLen));
-        sh.hops[i] = (u16)(len ? 1u << len : 0u);
-    }
-    __syncthreads();
-    const fuse_walk fw(LB, tb.max_bits);
-    const u32 ns = tb.n_states;
-    const u32 wlut_at = lds_offset_of(sh.wlut);
-
-    if ((wlut_at & ((4u << LB) - 1u)) != 0) {
-        if (lane == 0) {
-            ctl[1] = 1u;
-            word_store(&ctl[0], 1u);
-        }
-        return;
-    }
-
-    /* tiles in turn over the waves of the grid: the tiles a tile waits for belong to this turn or an earlier one, so to
-     * running waves as long as the whole grid is resident (the launch sizes it so; every wait is bounded anyway) */
-    const u32 stride = gridDim.x * kFuseWaves;
-    u8 *const lds_bytes = reinterpret_cast<u8 *>(&sh);
-    const u32 slot_at = (u32)(sh.slots[wave] - lds_bytes) + lane * kFuseSlotBytes; /* my slot, as an LDS byte offset */
-    const u32 head_at = (u32)(sh.slots[wave] - lds_bytes) + kWave * kFuseSlotBytes;
-    /* The FRONT of a tile -- its rows into registers and phase U -- needs no slot: it is done for the NEXT tile between
-     * the publishing of this tile's count and the look at the counts in front of it, which have that long to arrive
-     * (asked for at once, every wave of the chip polled for half a tile's time, and the polls slowed everything down:
-     * 1.67 ms). */
-    hufd_tile_rec rec;
-    u32 w[kFuseSubWords + 1];
-    u32 meet_row = 0, meet_bit = 0, why = 0;
-    /* what the tile whose count has just been published will want to know: asked for in the middle of the next tile's
-     * phase U (not at once: the counts of the tiles beside it are on their way at the same moment), looked at after it */
-    u32 ask_g = 0, ask_p = 0, ask_rr = 0, ask_gi = 0, ask_item = 0; /* (the same in every lane: the addresses are worked out when they are used) */
-    auto ask_a = [&]() { return &tile_agg[ask_g * kOpGroupTiles + (lane < ask_p ? lane : 0u)]; };
-    auto ask_b = [&]() { return &group_acc[(u64)(ask_rr * round_groups + (lane < ask_gi ? lane : 0u)) * kOpGroupStride]; };
-    auto ask_b2 = [&]() { return &group_acc[(u64)(ask_rr * round_groups + (lane + kWave < ask_gi ? lane + kWave : 0u)) * kOpGroupStride]; };
-    auto ask_rb = [&]() { return &round_base[ask_rr]; };
-    auto ask_ib = [&]() { return &item_base[ask_item]; };
-    u32 a = 0;
-    u64 b = 0, b2 = 0, rb = 0, ib = 0;
-    auto front = [&](u32 t, bool ask) {
-        rec = tiles[t];
-        const bool active = lane < rec.n_lanes;
-        const u8 *src = d_in + rec.src_off + (u64)(active ? lane : 0u) * kFuseSubBytes;
-        {
-            const unaligned_uint4 *line = reinterpret_cast<const unaligned_uint4 *>(src);
-#pragma unroll
-            for (u32 q = 0; q < kFuseSubWords / 4; ++q) {
-                const unaligned_uint4 v = line[q];
-                w[4 * q + 0] = __builtin_bswap32(v.x);
-                w[4 * q + 1] = __builtin_bswap32(v.y);
-                w[4 * q + 2] = __builtin_bswap32(v.z);
-                w[4 * q + 3] = __builtin_bswap32(v.w);
-            }
-            w[kFuseSubWords] = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(src + kFuseSubBytes)->x);
-        }
-
-        /* U: all entry states as one mask of heads per row, until every lane of the wave is down to one */
-        u64 heads = active ? (1ull << ns) - 1ull : 0ull;
-        bool one = false, settled = false;
-        meet_row = 0; /* the same for the whole wave */
-#pragma unroll
-        for (u32 r = 0; r < kFastMaxMeet; ++r) {
-            if (r == 2 && ask) {
-                a = word_load(ask_a());
-                b = granule_load(ask_b());
-                b2 = granule_load(ask_b2());
-                rb = granule_load(ask_rb());
-                ib = granule_load(ask_ib());
-            }
-            if (!settled) {
-                heads = r == 0 ? union_first_row<LB>(ns, active, w[0], w[1], sh.hops) : union_row_fast<LB>(heads, w[r], w[r + 1], sh.hops);
-                one = heads != 0 && (heads & (heads - 1)) == 0;
-                meet_row = r + 1;
-                settled = __all(one || heads == 0);
-            }
-        }
-        meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
-        why = __any(active && !(one && settled)) ? 2u : 0u; /* (diagnostics: the first reason the tile has for giving up) */
-    };
-
-    u32 t = blockIdx.x * kFuseWaves + wave;
-    if (lane == 0 && t == 0) {
-        granule_store(&round_base[0], kOpReady);
-    }
-    if (t >= n_tiles || uniform32(word_load(&ctl[0])) != 0) {
-        return;
-    }
-    front(t, false);
-    for (;;) {
-        FUSE_STAMP_ADD(0);
-        const u32 n_lanes = rec.n_lanes;
-        const bool first_tile = (rec.flags & 1u) != 0; /* of its item: lane 0 is entered at the item's first bit and its symbols are the tile's */
-        const bool active = lane < n_lanes;
-        const bool payload = active && (first_tile || lane != 0);
-        /* (what the end of the tile needs of its record: the record itself is the next tile's by then) */
-        const u64 my_out_off = rec.out_off, my_out_cap = rec.out_cap;
-        const u32 my_item = rec.item, my_flags = rec.flags, my_tail_chunk = rec.tail_chunk;
-
-        /* R: the one walk from the meeting bit to the end of the sub-chunk, the k-th code of a row to my slot at the count
-         * before the row + k.  A walk that meets a window without a code is put on the next row's first bit and goes on,
-         * so that its state and its stores stay in bounds; `dead` says so. */
-        const u32 full = slot_at + kFuseSlotFill;
-        u32 exit_state, in_slot;
-        bool dead = false;
-        {
-            u32 state = fw.state_at(meet_bit);
-            u32 at = slot_at, c16 = 0;
-#pragma unroll
-            for (u32 r = 1; r < kFuseSubWords; ++r) {
-                if (r >= meet_row) {
-                    const u64 pair = ((u64)w[r] << 32) | w[r + 1];
-                    fuse_sure<0, SURE>(state, pair, wlut_at, fw, lds_bytes, at);
-                    fuse_more<SURE>(state, pair, wlut_at, fw, lds_bytes, at);
-                    const bool now = fw.died(state) || fw.open(state);
-                    dead = dead || now;
-                    const u32 now16 = fw.count16_of(state);
-                    at += (now16 - c16) & 15u; /* (a row holds at most eight codes) */
-                    at = at < full ? at : full; /* (a slot that is full stays full: the tile gives up below) */
-                    c16 = now16;
-                    state = now ? (state & ~kFuseFieldMask) | fw.state_at(0) : state + 32u;
-                }
-            }
-            exit_state = fw.offset_of(state);
-            in_slot = at - slot_at;
-        }
-        FUSE_STAMP_ADD(1);
-
-        /* H: my own sub-chunk from my true entry state (how the lane in front leaves; the item's first bit) to the meeting
-         * bit, symbols behind that lane's in its slot (lane 0: to the room behind the slots) */
-        u32 head_n; /* symbols of my sub-chunk in front of its meeting bit */
-        {
-            const u32 front_exit = wave_from_front(exit_state), front_fill = wave_from_front(in_slot);
-            const u32 entry = lane ? front_exit : (u32)(my_flags >> 8) & 7u;
-            const u32 at0 = lane ? slot_at - kFuseSlotBytes + front_fill : head_at;
-            const u32 lim = lane ? slot_at - kFuseSlotBytes + kFuseSlotFill : head_at + kFuseHeadBytes - 16u;
-            u32 state = fw.state_at(entry < ns ? entry : 0u);
-            u32 at = at0, c16 = 0;
-            bool dd = false;
-#pragma unroll
-            for (u32 r = 0; r < kFastMaxMeet; ++r) {
-                if (r < meet_row) {
-                    const u64 pair = ((u64)w[r] << 32) | w[r + 1];
-                    fuse_sure<0, SURE>(state, pair, wlut_at, fw, lds_bytes, at);
-                    fuse_more<SURE>(state, pair, wlut_at, fw, lds_bytes, at);
-                    const bool now = fw.died(state) || fw.open(state);
-                    dd = dd || now;
-                    const u32 now16 = fw.count16_of(state);
-                    at += (now16 - c16) & 15u;
-                    at = at < lim ? at : lim;
-                    c16 = now16;
-                    state = now ? (state & ~kFuseFieldMask) | fw.state_at(0) : state + 32u;
-                }
-            }
-            head_n = at - at0;
-            /* (lane 0 of a tile that is not its item's first has no entry state to start from, and nothing of this is its own) */
-            const bool mine = payload;
-            const bool landed = !dd && fw.offset_of(state) == meet_bit && at < lim && entry < ns;
-            why = !why && __any(mine && !landed) ? 3u : why;
-        }
-        FUSE_STAMP_ADD(2);
-        FUSE_STAMP_COUNT(7, 1);
-        why = !why && __any(active && (dead || exit_state >= ns)) ? 4u : why;
-        why = t == fail_tile ? 11u : why;
-
-        /* what every slot holds: its lane's R symbols (not lane 0's, unless the item starts here) and the next lane's H
-         * symbols (not behind the tile's last lane: those are the next tile's); in front of slot 0 an item's first symbols */
-        const u32 next_head = wave_from_behind(head_n);
-        const u32 skip = payload ? 0u : in_slot; /* (lane 0 of a tile that is not its item's first: only what lane 1 put behind its symbols) */
-        const u32 n = active ? (payload ? in_slot : 0u) + (lane + 1 < n_lanes ? next_head : 0u) : 0u;
-        why = !why && __any(active && skip + n >= kFuseSlotFill) ? 7u : why; /* symbol-dense data: more than a slot holds */
-        const u32 first_n = first_tile ? wave_read(head_n, 0) : 0u;
-        const u32 incl = wave_inclusive_sum_dpp(n, lane);
-        const u32 pos = first_n + incl - n;
-        const u32 total = first_n + wave_read(incl, kWave - 1);
-        const u32 leaves = wave_read(exit_state, n_lanes - 1) & 15u;
-        const u32 g = t / kOpGroupTiles, p = t % kOpGroupTiles, rr = g / round_groups, gi = g % round_groups;
-        /* (every lane asks for something, the words it does not need among them) */
-        ask_g = g;
-        ask_p = p;
-        ask_rr = rr;
-        ask_gi = gi;
-        ask_item = my_item;
-        if (!why) {
-            if (lane == 0) {
-                u32 arrive_hi = (u32)(kOpArrive >> 32); /* (made here, not kept in a register pair -- or spilled -- across the turn) */
-#if defined(__HIP_DEVICE_COMPILE__)
-                asm volatile("" : "+v"(arrive_hi));
-#endif
-                arrival_quiet(&tile_agg[t], kFuseReady | total, &group_acc[(u64)g * kOpGroupStride], ((u64)arrive_hi << 32) | total);
-            }
-            /* The wave with a round's last tile watches the round's groups arrive and says how many symbols lie in front of
-             * the next round.  (The grid is 4096 waves on an MI355X, a round 4096 tiles: a round is what the grid does in
-             * one turn, so that nobody but this wave waits for more of the turn than the tiles in front of its own -- with
-             * one wave of the grid set aside for this, as in enc_onepass, a turn was 4095 tiles, every round's first
-             * tiles lay in the next turn and every tile of that turn waited for them by way of the round's base.) */
-            if ((t + 1) % (round_groups * kOpGroupTiles) == 0) {
-                const u32 r = t / (round_groups * kOpGroupTiles);
-                u64 rb0 = 0, gb = 0, gb2 = 0;
-                for (u32 spins = 0;; ++spins) {
-                    gb = lane < round_groups ? granule_load_now(&group_acc[(u64)(r * round_groups + lane) * kOpGroupStride])
-                                             : kOpGroupTiles * kOpArrive;
-                    gb2 = lane + kWave < round_groups ? granule_load_now(&group_acc[(u64)(r * round_groups + lane + kWave) * kOpGroupStride])
-                                                      : kOpGroupTiles * kOpArrive;
-                    rb0 = granule_load_now(&round_base[r]);
-                    if (__all((gb >> 40) == kOpGroupTiles && (gb2 >> 40) == kOpGroupTiles && (rb0 & kOpReady) != 0)) {
-                        break;
-                    }
-                    if (spins > kFuseSpinLimit || uniform32(word_load_now(&ctl[0])) != 0) {
-                        why = spins > kFuseSpinLimit ? 9u : 14u;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(8);
-                }
-                if (!why) {
-                    const u64 mine_g = (lane < round_groups ? (gb & kOpSum) : 0) + (lane + kWave < round_groups ? (gb2 & kOpSum) : 0);
-                    const u64 sum = (u64)wave_read(wave_inclusive_sum_dpp((u32)(mine_g & 0xFFFFFu), lane), kWave - 1) +
-                                    ((u64)wave_read(wave_inclusive_sum_dpp((u32)(mine_g >> 20), lane), kWave - 1) << 20);
-                    if (lane == 0) {
-                        granule_store(&round_base[r + 1], kOpReady | ((rb0 & ~kOpReady) + sum));
-                    }
-                }
-            }
-        }
-        FUSE_STAMP_ADD(3);
-
-        /* ---- the next tile's front, while this tile's count travels */
-        const u32 t_mine = t;
-        u32 why_mine = why;
-        t += stride;
-        const bool more = t < n_tiles && uniform32(word_load(&ctl[0])) == 0;
-        if (more) {
-            front(t, true);
-        } else {
-            a = word_load(ask_a());
-            b = granule_load(ask_b());
-            b2 = granule_load(ask_b2());
-            rb = granule_load(ask_rb());
-            ib = granule_load(ask_ib());
-        }
-        const u32 why_next = why;
-        why = why_mine;
-        FUSE_STAMP_ADD(4);
-
-        u64 item_off = 0;
-        if (!why) {
-            /* ---- the symbols in front of the tile: asked for above; what is not there yet is asked for again, all of
-             * it together and waited for once */
-            for (u32 spins = 0;; ++spins) {
-                a = lane < p ? a : kFuseReady;
-                b = lane < gi ? b : kOpGroupTiles * kOpArrive;
-                b2 = lane + kWave < gi ? b2 : kOpGroupTiles * kOpArrive;
-                ib = first_tile ? kOpReady : ib;
-                const bool there = (a & kFuseReady) != 0 && (b >> 40) == kOpGroupTiles && (b2 >> 40) == kOpGroupTiles &&
-                                   (rb & kOpReady) != 0 && (ib & kOpReady) != 0;
-                if (__all(there)) {
-                    break;
-                }
-                u32 gave_up = 0;
-                __builtin_amdgcn_s_sleep(4);
-                fuse_ask_all(ask_a(), ask_b(), ask_b2(), ask_rb(), ask_ib(), &ctl[0], a, b, b2, rb, ib, gave_up);
-                if (spins > kFuseSpinLimit || uniform32(gave_up) != 0) {
-                    why = spins > kFuseSpinLimit ? 8u : 14u;
-                    break;
-                }
-            }
-        }
-        if (!why) {
-            /* (sums of 40-bit numbers as two sums of 20-bit halves: data-parallel moves, no LDS permutes, no index registers) */
-            const u64 mine_b = (lane < gi ? (b & kOpSum) : 0ull) + (lane + kWave < gi ? (b2 & kOpSum) : 0ull);
-            const u32 part_lo = (lane < p ? a & 0xFFFFFFu : 0u) + (u32)(mine_b & 0xFFFFFu);
-            const u32 part_hi = (u32)(mine_b >> 20);
-            u64 front = (u64)wave_read(wave_inclusive_sum_dpp(part_lo, lane), kWave - 1) +
-                        ((u64)wave_read(wave_inclusive_sum_dpp(part_hi, lane), kWave - 1) << 20);
-            front += rb & ~kOpReady;
-            if (first_tile) {
-                if (lane == 0) {
-                    granule_store(&item_base[my_item], kOpReady | front);
-                }
-            } else {
-                item_off = front - (ib & ~kOpReady);
-            }
-            why = !why && item_off + total > my_out_cap ? 10u : why; /* the output is too short: the other road finds the edge */
-        }
-        FUSE_STAMP_ADD(5);
-        if (!why) {
-            /* ---- the slots to HBM: eight lanes a slot, 16 bytes each, the last 16 of a slot as they lie (they overlap
-             * the row in front with the same bytes) */
-            u8 *dst = d_out + my_out_off + item_off;
-            /* (the lane number as a value the compiler cannot trace: what is derived from it in this block is then worked
-             * out here, not kept in registers across the whole turn -- or spilled: this kernel must not spill, a reload
-             * waits for every load and atomic in flight) */
-            u32 lane_o = lane;
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("" : "+v"(lane_o));
-#endif
-            const u32 slot_o = (u32)(sh.slots[wave] - lds_bytes) + lane_o * kFuseSlotBytes;
-            if (lane_o < first_n) {
-                dst[lane_o] = lds_bytes[head_at + lane_o]; /* an item's first symbols (at most 128: 16 rows of eight) */
-            }
-            if (lane_o + kWave < first_n) {
-                dst[lane_o + kWave] = lds_bytes[head_at + lane_o + kWave];
-            }
-            /* (slot 0 of a tile that is not its item's first holds only what lane 1 put behind lane 0's symbols, often
-             * fewer than 16: a byte a lane; the other slots in 16-byte rows, and the rare one with fewer than 16 symbols --
-             * a late meeting row leaves the tile's last lane few -- by its own lane, byte by byte) */
-            if (!first_tile) {
-                const u32 n0 = wave_read(n, 0), k0 = wave_read(skip, 0);
-                if (lane_o < n0) {
-                    dst[lane_o] = sh.slots[wave][k0 + lane_o];
-                }
-                if (lane_o + kWave < n0) {
-                    dst[lane_o + kWave] = sh.slots[wave][k0 + lane_o + kWave];
-                }
-            }
-            constexpr u32 kSlotRows = kFuseSlotFill / 16, kTrips = kSlotRows; /* 16-byte rows a slot can hold: that many lanes a slot */
-            const u32 row = lane_o % kSlotRows;
-            sh.meta[wave][lane_o] = pos | ((!first_tile && lane_o == 0 ? 0u : n) << 16);
-            wave_step();
-            /* all the reads, then all the stores: a store behind every read had the wave wait for LDS every time */
-            unaligned_uint4 v[kTrips];
-            u32 to[kTrips];
-#pragma unroll
-            for (u32 it = 0; it < kTrips; ++it) {
-                const u32 s = it * (kWave / kSlotRows) + lane_o / kSlotRows;
-                const u32 m = sh.meta[wave][s];
-                const u32 ns_ = m >> 16, ps = m & 0xFFFFu;
-                const u32 from = 16 * row + 16 <= ns_ ? 16 * row : (ns_ >= 16 ? ns_ - 16 : 0u);
-                v[it] = *reinterpret_cast<const unaligned_uint4 *>(sh.slots[wave] + s * kFuseSlotBytes + from);
-                to[it] = 16 * row < ns_ && ns_ >= 16 ? ps + from : HUFD_NONE32;
-            }
-#pragma unroll
-            for (u32 it = 0; it < kTrips; ++it) {
-                if (to[it] != HUFD_NONE32) {
-                    *reinterpret_cast<unaligned_uint4 *>(dst + to[it]) = v[it];
-                }
-            }
-            if (__any(n != 0 && n < 16u && (first_tile || lane_o != 0))) {
-                if (n < 16u && (first_tile || lane_o != 0)) {
-                    for (u32 i = 0; i < n; ++i) {
-                        dst[pos + i] = lds_bytes[slot_o + skip + i];
-                    }
-                }
-            }
-            wave_step(); /* the slots are free for the next tile */
-        }
-        FUSE_STAMP_ADD(6);
-        if (why) {
-            if (lane == 0) {
-                if (word_load_now(&ctl[0]) == 0) {
-                    ctl[1] = (t_mine << 8) | why; /* (diagnostics; who is first is not decided exactly) */
-                }
-                word_store(&ctl[0], 1u);
-            }
-            return;
-        }
-        if ((my_flags & 2u) != 0 && lane == 0) {
-            /* the item's last tile inside the stream: the chunk(s) the stream ends in start here */
-            chunk_entry[my_tail_chunk] = entry_pack(leaves, true);
-            chunk_base[my_tail_chunk] = item_off + total;
-        }
-        if (!more) {
-            break;
-        }
-        why = why_next;
-    }
-    FUSE_STAMP_FLUSH;
-}
-
-/* ------------------------------------------------------------------ decode: sync, chunks inside streams, resident waves and a walk table per LDS bank */
-
-/*
- * What bounds dec_sync_lean is the LDS: 32 lanes' look-ups in ONE table land on the 32 banks at random, ~3.4 on the
- * fullest, and the CU's four SIMDs get a step per ~24 cycles each however many waves there are
- * (profiles/r04_micro/probe_walk.jsonl).  A table copy per bank never collides -- but with dword entries on a 10-bit
- * window it is 128 KiB, ONE workgroup a CU; and workgroups of 1024 threads that take chunks the way dec_sync_lean does
- * (three barriers a chunk, table filled per workgroup) lose more than the look-ups win (dec_sync_bank, above).  So here:
- *
- *   - one RESIDENT workgroup of 16 waves per CU fills the 128 KiB table once (entry of window w for bank b at byte
- *     w << 7 | b << 2: the address is (window bits as they stand) | bank, one instruction as in dec_sync_lean);
- *   - its waves are on their own from then on: a wave takes TILES of 64 neighbouring sub-chunks of one item in turn
- *     (tile k = sub-chunks 63 k .. 63 k + 63: lane 0 of every tile but an item's first walks the last sub-chunk of the
- *     tile in front again, only to learn how it is left -- dec_onepass's tiles), so that a lane's entry state comes from
- *     its neighbour lane by a wave shift and nothing ever waits for another wave: no barrier after the table;
- *   - what is per CHUNK (its function for dec_scan, whether it is regular) is put together by dec_sync_resident_finish
- *     from what the lanes left per sub-chunk.
- *
- * Same phases U, R, H per lane and the same records per sub-chunk as dec_sync_lean; the chunks streams END in keep
- * dec_sync_lean<TAIL>.  Coders whose decode table has more than 10 bits keep dec_sync_lean (4096 rows do not fit).
- */
-constexpr u32 kResLB = 10;
-constexpr u32 kResWinPos = 7; /* the window's lowest bit in the shifted pair: the window IS address bits 7..16, the row of its entry */
-constexpr u32 kResThreads = 1024;
-constexpr u32 kResWaves = kResThreads / kWave;
-constexpr u32 kResTableBytes = (1u << kResLB) * 128u;
-constexpr u32 kResMinTiles = 2048; /* fewer tiles (16 MiB of stream) do not fill the chip's resident waves: the chunk kernels take the launch */
-
-struct resident_shared {
-    u32 wlut[(1u << kResLB) * 32]; /* word w * 32 + b: 0x10000 - length of window w (48: no code), read by the lanes with lane % 32 == b */
-    u16 hops[1u << kResLB];        /* 1 << code length of a window, 0 = no code: phase U's (one copy: phase U is a fifth of the look-ups) */
-};
-
-template <u32 SURE>
-__global__ __launch_bounds__(kResThreads, 4) void dec_sync_resident_kernel(
-    hufd_tables tb,
-    const hufd_dec_item *items,
-    u32 n_items,
-    const u32 *item_first_tile, /* [n_items + 1] tiles of the items in front; [n_items] = all tiles */
-    const u8 *d_in,
-    u16 *fn_tab,
-    u16 *cp_tab,
-    u16 *lane_count,
-    u8 *chunk_bad,  /* [chunk] zeroed: set where a sub-chunk of the chunk is not regular by this kernel's rules */
-    u8 *chunk_one0 /* [chunk] zeroed: set where sub-chunk 0's own walks have met (what dec_sync_guess needs of a chunk) */) {
-
-    resident_shared &sh = *reinterpret_cast<resident_shared *>(dyn_lds);
-    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    const u32 ns = tb.n_states;
-    const row_walk rw(kResLB, tb.max_bits, kResWinPos);
-    const u32 table_at = lds_offset_of(sh.wlut);
-    const bool coder_ok = tb.lut_bits <= kResLB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS && rw.sure == SURE && tb.bank_rows &&
-                          (table_at & (kResTableBytes - 1u)) == 0;
-    const u32 n_tiles = item_first_tile[n_items];
-    if (!coder_ok) { /* (the same for the whole launch, which the host does not make for such a coder: every chunk the long way) */
-        for (u32 i = blockIdx.x * kResThreads + tid; i < n_items; i += gridDim.x * kResThreads) {
-            const hufd_dec_item it = items[i];
-            const u32 inside = it.n_chunks && it.in_len >= 8 ? (u32)((it.in_len - 8) / HUFD_DEC_CHUNK_BYTES) : 0u;
-            for (u32 c = 0; c < (inside < it.n_chunks ? inside : it.n_chunks); ++c) {
-                chunk_bad[it.first_chunk + c] = 1;
-            }
-        }
-        return;
-    }
-    /* the table: a thread writes its bank's copy of 32 rows (bank_rows holds the length bytes, four windows a dword) */
-    {
-        const u32 bank = tid & 31u, first = tid / 32 * 32; /* rows first .. first + 31 */
-#pragma unroll 4
-        for (u32 j = 0; j < 8; ++j) {
-            const u32 four = tb.bank_rows[first / 4 + j];
-#pragma unroll
-            for (u32 i = 0; i < 4; ++i) {
-                const u32 len = 256u - ((four >> (8 * i)) & 0xFFu); /* (bank_rows: 256 - length) */
-                sh.wlut[(first + 4 * j + i) * 32 + bank] = 0x10000u - len;
-            }
-        }
-        const u32 own = tb.dec_lut[tid >> (kResLB - tb.lut_bits)] & 0xFFu;
-        sh.hops[tid] = (u16)(own ? 1u << own : 0u);
-    }
-    __syncthreads();
-    const u32 table = table_at | ((lane & 31u) << 2);
-
-    const u32 stride = gridDim.x * kResWaves;
-    u32 item_lo = 0; /* (tiles come in rising order for a wave: the search for a tile's item starts at the last one's) */
-    for (u32 T = blockIdx.x * kResWaves + wave; T < n_tiles; T += stride) {
-        /* the tile's item: the last one whose first tile is not behind T */
-        u32 lo = item_lo, hi = n_items;
-        while (hi - lo > 1) {
-            const u32 mid = lo + (hi - lo) / 2;
-            if (item_first_tile[mid] <= T) {
-                lo = mid;
-            } else {
-                hi = mid;
-            }
-        }
-        item_lo = lo;
-        const hufd_dec_item it = items[lo];
-        const u32 k = T - item_first_tile[lo];
-        const u32 inside_chunks = (u32)((it.in_len - 8) / HUFD_DEC_CHUNK_BYTES) < it.n_chunks ? (u32)((it.in_len - 8) / HUFD_DEC_CHUNK_BYTES) : it.n_chunks;
-        const u32 subs = inside_chunks * HUFD_DEC_LANES;
-        const u32 first_sub = k * (kWave - 1);
-        const u32 n_lanes = subs - first_sub < kWave ? subs - first_sub : kWave;
-        const bool active = lane < n_lanes;
-        const bool payload = active && (k == 0 || lane != 0); /* lane 0 of a later tile: walked again for its exit only */
-        const u32 g = first_sub + (active ? lane : 0u);      /* my sub-chunk of the item */
-        const u32 c = it.first_chunk + g / HUFD_DEC_LANES, cl = g % HUFD_DEC_LANES; /* its chunk, its lane there */
-        const u8 *src = d_in + it.in_off + (u64)g * HUFD_DEC_SUB_BYTES;
-        u32 w[kFastRows];
-        {
-            const unaligned_uint4 *line = reinterpret_cast<const unaligned_uint4 *>(src);
-#pragma unroll
-            for (u32 q = 0; q < kSubWords / 4; ++q) {
-                const unaligned_uint4 v = line[q];
-                w[4 * q + 0] = v.x;
-                w[4 * q + 1] = v.y;
-                w[4 * q + 2] = v.z;
-                w[4 * q + 3] = v.w;
-            }
-            w[kSubWords] = reinterpret_cast<const unaligned_u32 *>(src + HUFD_DEC_SUB_BYTES)->x;
-        }
-#pragma unroll
-        for (u32 r = 0; r < kFastRows; ++r) {
-            w[r] = __builtin_bswap32(w[r]);
-        }
-
-        /* U: all entry states as one mask of heads per row, until every lane of the wave is down to one */
-        u64 heads = active ? (1ull << ns) - 1ull : 0ull;
-        u32 meet_row = 0; /* the same for the whole wave */
-        bool one = false, settled = false;
-#pragma unroll
-        for (u32 r = 0; r < kFastMaxMeet; ++r) {
-            if (!settled) {
-                heads = r == 0 ? union_first_row<kResLB>(ns, active, w[0], w[1], sh.hops) : union_row_fast<kResLB>(heads, w[r], w[r + 1], sh.hops);
-                one = heads != 0 && (heads & (heads - 1)) == 0;
-                meet_row = r + 1;
-                settled = __all(one || heads == 0);
-            }
-        }
-        const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
-        bool ok = !active || (one && settled);
-
-        /* R: the one walk from the meeting bit to the end of the sub-chunk */
-        u32 state = rw.state_at(meet_bit, 0);
-        u32 cp_state[kQuarters - 1] = {0, 0, 0};
-        bool dead = false;
-#pragma unroll
-        for (u32 r = 1; r < kSubWords; ++r) {
-            if (r >= meet_row) {
-                if (r % (kSubWords / kQuarters) == 0) {
-                    cp_state[r / (kSubWords / kQuarters) - 1] = state;
-                }
-                state = lean_row<SURE>(state, w[r], w[r + 1], table, rw);
-                dead = dead || rw.died(state);
-                state += 32u; /* (a walk that has died drifts: the chunk is not regular then and nothing of this is kept) */
-            }
-        }
-        const u32 ref_count = state >> 16; /* symbols from the meeting bit to the end of the sub-chunk */
-        const u32 ref_exit = rw.offset_of(state);
-        ok = ok && (!active || (!dead && ref_exit < ns));
-
-        /* H: my own sub-chunk from my true entry state -- how the lane in front leaves -- to the meeting bit */
-        const u32 front_exit = wave_from_front(ref_exit);
-        const bool front_ok = wave_from_front((u32)ok) != 0;
-        const u32 entry = lane ? front_exit : 0u;
-        u32 count;
-        u32 head_cp = 0; /* the head walk where it enters the second quarter, when the meeting row lies behind that */
-        const bool late = meet_row > kSubWords / kQuarters;
-        {
-            u32 st = rw.state_at(entry < ns ? entry : 0u, 0);
-            bool dd = false;
-#pragma unroll
-            for (u32 r = 0; r < kFastMaxMeet; ++r) {
-                if (r < meet_row) {
-                    if (r == kSubWords / kQuarters) {
-                        head_cp = st;
-                    }
-                    st = lean_row<SURE>(st, w[r], w[r + 1], table, rw);
-                    dd = dd || rw.died(st);
-                    st += 32u;
-                }
-            }
-            const bool reached = !dd && rw.offset_of(st) == meet_bit;
-            /* (a chunk's sub-chunk 0 is entered the way dec_scan finds out: its candidates below, not its neighbour) */
-            ok = ok && (!payload || cl == 0 || (reached && front_ok && entry < ns));
-            count = active ? (st >> 16) + ref_count : 0u; /* symbols of the true path that start in my sub-chunk (lanes of a chunk >= 1) */
-        }
-
-        /* H: a chunk's sub-chunk 0 from every entry state the chunk may be entered in (lanes 0 .. ns-1 of the wave, on the
-         * owner lane's words), step by step: the count of a walk that dies has to be right.  At most one chunk starts in a tile. */
-        const u64 owners = __ballot(payload && cl == 0);
-        if (owners) {
-            const u32 owner = (u32)__builtin_ctzll(owners);
-            const u32 target = wave_read(meet_bit, owner), tail0 = wave_read(ref_count, owner), first_exit = wave_read(ref_exit, owner);
-            const u32 oc = wave_read(c, owner);
-            const bool owner_one = wave_read((u32)one, owner) != 0;
-            u32 st = rw.state_at(lane < ns ? lane : 0u, 0);
-            bool dd = false;
-            u32 cand_dead = 0;
-            u32 hi = wave_read(w[0], owner);
-#pragma unroll
-            for (u32 r = 0; r < kFastMaxMeet; ++r) {
-                if (r < meet_row) {
-                    const u32 lo_w = wave_read(w[r + 1], owner);
-                    st = lean_row<SURE, true>(st, hi, lo_w, table, rw);
-                    const bool now = rw.died(st) && !dd;
-                    cand_dead = now ? (st >> 16) - 1u : cand_dead; /* the step that found no code is not a symbol */
-                    dd = dd || now;
-                    st = rw.next_row(st, dd);
-                    hi = lo_w;
-                }
-            }
-            const bool cand_reached = !dd && lane < ns && rw.offset_of(st) == target;
-            const u64 cand_alive = __ballot(cand_reached);
-            const u32 cand_count = (st >> 16) + tail0;
-            if (lane < ns) {
-                fn_tab[((u64)oc * ns + lane) * HUFD_DEC_LANES] =
-                    cand_reached ? fn_pack(false, first_exit, cand_count & 0x7FFu) : fn_pack(true, 0, cand_dead);
-            }
-            if (lane == owner) {
-                chunk_one0[oc] = owner_one ? 1 : 0;
-                /* (the owner's own row of merged states: which entry states of the chunk reach the meeting bit) */
-                cp_tab[(u64)oc * kCpRows * HUFD_DEC_LANES + (kQuarters - 1) * HUFD_DEC_LANES] = (u16)((u32)cand_alive | (ref_exit << 12));
-            }
-        }
-
-        if (payload) {
-            if (!ok) {
-                chunk_bad[c] = 1;
-            }
-            u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + cl;
-#pragma unroll
-            for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-                const bool usable = (qq + 1) * (kSubWords / kQuarters) >= meet_row;
-                u32 tail = ref_count - (cp_state[qq] >> 16), bits = rw.offset_of(cp_state[qq]);
-                bool have_cp = usable;
-                if (qq == 0 && late && cl != 0) {
-                    tail = count - (head_cp >> 16);
-                    bits = rw.offset_of(head_cp);
-                    have_cp = true;
-                }
-                cp[qq * HUFD_DEC_LANES] = (u16)(have_cp ? 0x8000u | (bits << 11) | tail : 0u);
-            }
-            lane_count[(u64)c * HUFD_DEC_LANES + cl] = (u16)(cl ? count : ref_count);
-            if (cl) {
-                /* (a lane behind one whose walks did not meet has no entry state: its chunk is marked, nothing of this is read) */
-                cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((1u << (entry < ns ? entry : 0u)) | (ref_exit << 12));
-            }
-        }
-    }
-}
-
-/* what dec_sync_resident leaves per sub-chunk, put together per chunk: the chunk's function for dec_scan (a workgroup a
- * chunk: the symbols of its lanes 1 .. 255 summed), whether it is regular, and the lists of the chunks that are not */
-__global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_resident_finish_kernel(
-    hufd_tables tb,
-    const hufd_chunk_rec *chunk_rec,
-    const u16 *fn_tab,
-    const u16 *cp_tab,
-    const u16 *lane_count,
-    const u8 *chunk_bad,
-    const u8 *chunk_one0,
-    u32 *chunk_fn,
-    u8 *chunk_regular,
-    u32 *slow_list,
-    u32 *slow_count,
-    u32 *long_list,
-    u32 *long_count) {
-    u32 *wave_tot = reinterpret_cast<u32 *>(dyn_lds); /* [HUFD_DEC_LANES / kWave] */
-    const u32 c = blockIdx.x, lane = threadIdx.x, ns = tb.n_states;
-    if (chunk_rec[c].valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
-        return; /* holds the end of its stream: dec_sync_lean<TAIL>'s */
-    }
-    if (chunk_bad[c]) {
-        if (lane == 0) {
-            chunk_regular[c] = 0;
-            if (chunk_one0[c]) {
-                slow_list[atomicAdd(slow_count, 1u)] = c;
-            } else {
-                long_list[atomicAdd(long_count, 1u)] = c;
-            }
-        }
-        return;
-    }
-    const u32 mine = lane ? lane_count[(u64)c * HUFD_DEC_LANES + lane] : 0u;
-    const u32 wsum = wave_sum(mine);
-    if ((lane & (kWave - 1)) == 0) {
-        wave_tot[lane / kWave] = wsum;
-    }
-    __syncthreads();
-    if (lane == 0) {
-        chunk_regular[c] = 1;
-    }
-    if (lane < ns) {
-        u32 rest = 0;
-#pragma unroll
-        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
-            rest += wave_tot[wv];
-        }
-        const u32 last_exit = (u32)cp_tab[(u64)c * kCpRows * HUFD_DEC_LANES + (kQuarters - 1) * HUFD_DEC_LANES + HUFD_DEC_LANES - 1] >> 12;
-        const u32 f = fn_tab[((u64)c * ns + lane) * HUFD_DEC_LANES];
-        chunk_fn[(u64)c * ns + lane] =
-            (f & 0x8000u) ? wide_pack(true, 0, f & 0x7FFu) : wide_pack(false, last_exit, (f & 0x7FFu) + rest);
-    }
-}
-
 /* ------------------------------------------------------------------ decode: emit */
 
 /*
@@ -8328,7 +6798,7 @@ __device__ __forceinline__ void dec_emit_chunk(
     u8 *d_out,
     const u16 *fn_tab,
     const u16 *cp_tab,
-    const u16 *lane_count_tab, /* chunks from dec_sync_fast: the symbol counts of lanes >= 1 are here, not in fn_tab */
+    const u16 *lane_count_tab, /* regular chunks: the symbol counts of lanes >= 1 are here, not in fn_tab */
     const u8 *chunk_regular,
     const u32 *chunk_entry,
     const u64 *chunk_base,
@@ -8622,11 +7092,11 @@ __global__ __launch_bounds__(kEmitThreads, 4) void dec_emit_kernel(
 /* ------------------------------------------------------------------ decode: emit, regular chunks */
 
 /*
- * dec_emit for the chunks dec_sync_fast found regular, when the whole chunk fits the output and
+ * dec_emit for the chunks the sync kernels found regular, when the whole chunk fits the output and
  * the LDS stage; every other chunk is put on a list for dec_emit_kernel.  Four threads per
  * sub-chunk as there (thread (lane, q) starts at checkpoint q), but each holds its quarter of the
  * sub-chunk in registers (nine words of the lane's own 128-byte line) and walks it row by row like
- * dec_sync_fast: shift, mask, table, byte store, two adds a symbol.  The table entry is
+ * dec_sync_lean: shift, mask, table, byte store, two adds a symbol.  The table entry is
  * symbol << 16 | (0x10000 - length) & 0xFFFF; only the low half of the walk state is ever looked
  * at, so the symbol may ride along in the add.
  */
@@ -8698,7 +7168,7 @@ __device__ __forceinline__ void dec_emit_fast_chunk(
     const u32 s0 = centry & 0xFFu;
     const hufd_chunk_rec rec = chunk_rec[c]; /* (asked for with the chunk's entry: not chunk -> item -> its record) */
     const u64 valid = rec.valid;
-    /* lanes whose sub-chunk and the 8 bytes after it lie inside the stream (dec_sync_fast: the others are idle or "careful") */
+    /* lanes whose sub-chunk and the 8 bytes after it lie inside the stream (dec_sync_lean: the others are idle or "careful") */
     if (!TAIL && valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
         return; /* the other instantiation's */
     }
@@ -8716,7 +7186,7 @@ __device__ __forceinline__ void dec_emit_fast_chunk(
     const bool fits = regular != 0 && (regular == 2 || !wide_stop(f0)) && ((cpt[merged_row] >> s0) & 1u) != 0 &&
                       cbase + chunk_symbols <= rec.out_cap;
     const bool fast = fits && chunk_symbols + 16 <= stage_limit &&
-                      (lds_offset_of(sh.wlut) & ((4u << LB) - 1u)) == 0 && (SURE == 0 || SURE == row_walk(LB, tb.max_bits).sure);
+                      (lds_offset_of(sh.wlut) & ((4u << LB) - 1u)) == 0 && SURE <= row_walk(LB, tb.max_bits).sure;
     if (!fast) {
         if (t == 0) {
             if (fits && chunk_symbols + 32 <= 2 * HUFD_DEC_STAGE_BYTES) {
@@ -8854,7 +7324,7 @@ __device__ __forceinline__ void dec_emit_fast_chunk(
         st[ch] = rw.state_at(q ? (my_cp[ch] >> 11) & 15u : entry_state[ch], 0);
         dst[ch] = mine ? stage_at + mis + sh.lane_base[lanes[ch]] + first : dump_at;
         idle[ch] = !mine;
-        /* only sub-chunk 0's first checkpoint can be missing (its head is not known when dec_sync_fast runs) */
+        /* only sub-chunk 0's first checkpoint can be missing (its head is not known when the sync kernel runs) */
         if (ch == 0) {
             extend = q == 0 && lanes[0] == 0 && !(next_cp[ch] & 0x8000u);
         }
@@ -8963,11 +7433,7 @@ __global__ __launch_bounds__(kEmitFastThreads, TAIL ? 6 : 8) void dec_emit_fast_
     u32 *slow_count,
     u32 *dense_list, /* chunks with more symbols than the stage holds: left to dec_emit_big_kernel */
     u32 *dense_count,
-    u32 stage_limit /* symbols the stage of this launch holds (HUFD_DEC_STAGE_BYTES, or less: emit_lds_bytes) */,
-    const u32 *gate /* NULL, or dec_onepass's ctl: the chunks inside streams are this kernel's only if that one gave up */) {
-    if (!TAIL && gate && gate[0] == 0) {
-        return;
-    }
+    u32 stage_limit /* symbols the stage of this launch holds (HUFD_DEC_STAGE_BYTES, or less: emit_lds_bytes) */) {
     dec_emit_fast_chunk<LB, TAIL, SURE>(
         TAIL ? tail_chunks[blockIdx.x] : blockIdx.x, tb, chunk_rec, d_in, d_out, cp_tab, lane_count, chunk_regular, chunk_fn,
         chunk_entry, chunk_base, results, slow_list, slow_count, dense_list, dense_count, stage_limit);
@@ -9086,7 +7552,7 @@ __global__ __launch_bounds__(kEmitFastThreads, 6) void dec_emit_pack_kernel(
     const bool wanted = have && (centry & 0x100u) != 0 && regular != 3;
     const bool fits = wanted && regular == 2 && ((cpt[merged_row] >> s0) & 1u) != 0 && cbase + chunk_symbols <= rec.out_cap;
     const bool fast = fits && chunk_symbols + 16 <= stage_limit && n_full + 2 <= slot_lanes &&
-                      (lds_offset_of(sh.wlut) & ((4u << LB) - 1u)) == 0 && SURE == row_walk(LB, tb.max_bits).sure;
+                      (lds_offset_of(sh.wlut) & ((4u << LB) - 1u)) == 0 && SURE <= row_walk(LB, tb.max_bits).sure;
     if (tt == 0 && slot < kPackMaxSlots) {
         sh.slot_chunk[slot] = fast ? c : HUFD_NONE32;
         sh.slot_full[slot] = n_full;
@@ -9535,7 +8001,7 @@ static uint32_t persistent_grid(Kernel kernel, uint32_t threads, uint32_t lds_by
     return (uint32_t)(work_items < resident ? work_items : resident);
 }
 
-/* scalar registers of enc_onepass and dec_onepass (every instantiation: the compiler uses all 102 + VCC + the rest);
+/* scalar registers of enc_onepass (every instantiation: the compiler uses all 102 + VCC + the rest);
  * tests/test_library_boundary.py::test_onepass_kernels_scalar_registers holds the build to it */
 constexpr uint32_t kOnepassSgprs = 106;
 
@@ -9600,32 +8066,11 @@ int hufk_init(void) {
             reinterpret_cast<const void *>(&dec_emit_big_kernel<LBV, SUREV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
             lds_max);                                                                                                  \
     }
-    HUFK_ALLOW_BIG_LDS(10, 2)
     HUFK_ALLOW_BIG_LDS(10, 3)
     HUFK_ALLOW_BIG_LDS(10, 4)
     HUFK_ALLOW_BIG_LDS(10, 5)
     HUFK_ALLOW_BIG_LDS(12, 2)
-    HUFK_ALLOW_BIG_LDS(12, 3)
 #undef HUFK_ALLOW_BIG_LDS
-#define HUFK_ALLOW_BIG_LDS(SUREV)                                                                                       \
-    if (e == hipSuccess) {                                                                                             \
-        e = hipFuncSetAttribute(                                                                                       \
-            reinterpret_cast<const void *>(&dec_sync_resident_kernel<SUREV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-            lds_max);                                                                                                  \
-    }
-    HUFK_ALLOW_BIG_LDS(2)
-    HUFK_ALLOW_BIG_LDS(3)
-    HUFK_ALLOW_BIG_LDS(4)
-    HUFK_ALLOW_BIG_LDS(5)
-#undef HUFK_ALLOW_BIG_LDS
-    if (e == hipSuccess) {
-        e = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&dec_onepass_kernel<12, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    }
-    if (e == hipSuccess) {
-        e = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&dec_onepass_kernel<12, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    }
     if (e == hipSuccess) {
         e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&dec_sync_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -9685,17 +8130,6 @@ int hufk_encode_one_pass_applies(const struct hufd_tables *tb) {
     return tb->all_coded && tb->enc_max_bits <= 15 && tb->enc_min_bits >= 4;
 }
 
-int hufk_decode_one_pass_applies(const struct hufd_tables *tb) {
-    /* the chunked decoder's tables, slots sized for codes of at least 4 bits, and a build for the coder's number of
-     * certain steps a row (the instantiations hufk_decode_launch picks from) */
-    if (!tb->dec_lut || tb->deep_entries || tb->max_bits > HUFD_DEC_MAX_LUT_BITS || tb->min_bits < 4) {
-        return 0;
-    }
-    const uint32_t lb = tb->lut_bits <= 10 ? 10u : 12u;
-    const uint32_t sure = row_walk(lb, tb->max_bits).sure;
-    return lb == 10 ? sure >= 2 && sure <= 5 : sure >= 2 && sure <= 3;
-}
-
 int hufk_decode_plan_chunks(
     const struct hufd_dec_item *items, uint32_t n_items, uint32_t n_chunks, uint32_t *chunk_item, struct hufd_chunk_rec *chunk_rec,
     void *stream) {
@@ -9738,10 +8172,6 @@ int hufk_encode_plan_tiny_items(const void *raw_items, uint32_t n_items, struct 
         enc_plan_tiny_items_kernel, dim3((n_items + 255) / 256), dim3(256), 0, (hipStream_t)stream,
         (const hufd_raw_enc_item *)raw_items, n_items, items, tiny_list);
     return (int)hipGetLastError();
-}
-
-uint64_t hufk_decode_zero_bytes(uint32_t n_tiles, uint32_t n_items) {
-    return dec_onepass_layout_of(n_tiles, n_items).bytes;
 }
 
 uint64_t hufk_encode_zero_bytes(uint32_t n_segs, uint32_t n_items) {
@@ -10021,53 +8451,14 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     if (a->n_fixed_blocks && a->tables.fixed_bits) {
         (void)hipMemsetAsync(a->states, 0xFF, (size_t)a->n_items * sizeof(hufd_dec_item_state), st);
     }
-    /* The chunks inside streams in ONE pass (dec_onepass) where the coder allows: the kernels of the two-pass road for
-     * those chunks are queued behind it all the same and look at its ctl word first -- they run only if it gave up. */
-    const u32 *gate = nullptr;
-    if (a->n_chunks && a->n_tiles && a->tiles && a->fuse_block && a->fuse_mode != 1 && a->old_sync != 1 &&
-        hufk_decode_one_pass_applies(&a->tables)) {
-        const uint32_t lb = a->tables.lut_bits <= 10 ? 10u : 12u;
-        const uint32_t sure = row_walk(lb, a->tables.max_bits).sure;
-        const u32 fail_tile = a->fuse_mode == 2 ? a->n_tiles / 2 : HUFD_NONE32;
-        const dec_onepass_layout l = dec_onepass_layout_of(a->n_tiles, a->n_items);
-        u8 *blk = (u8 *)a->fuse_block;
-        bool launched = true;
-#define HUFK_LAUNCH_ONEPASS_DEC(LBV, SUREV)                                                                            \
-    /* a turn of the grid = a round of the look-back: whole groups of tiles, at most 128 of them */                  \
-    const uint32_t resident = persistent_grid(dec_onepass_kernel<LBV, SUREV>, kFuseThreads, (uint32_t)sizeof(fuse_shared<LBV>), 1u << 20, kOnepassSgprs); \
-    const uint32_t want = (a->n_tiles + kFuseWaves - 1) / kFuseWaves;                                                  \
-    const uint32_t unit = kOpGroupTiles / std::gcd(kOpGroupTiles, kFuseWaves); /* workgroups that make whole groups */ \
-    uint32_t grid = want < resident ? (want + unit - 1) / unit * unit : resident / unit * unit;                        \
-    grid = grid > 128u * kOpGroupTiles / kFuseWaves ? 128u * kOpGroupTiles / kFuseWaves / unit * unit : grid;           \
-    grid = grid ? grid : unit;                                                                                         \
-    if (getenv("AWS_HUFFMAN_AMD_ONEPASS_GRID")) { /* (experiments) */                                                 \
-        grid = (uint32_t)atoi(getenv("AWS_HUFFMAN_AMD_ONEPASS_GRID")) / unit * unit;                                   \
-        grid = grid ? grid : unit;                                                                                     \
-    }                                                                                                                  \
-    hipLaunchKernelGGL(                                                                                                \
-        (dec_onepass_kernel<LBV, SUREV>), dim3(grid),                                                                  \
-        dim3(kFuseThreads), (uint32_t)sizeof(fuse_shared<LBV>), st, a->tables, a->tiles, a->n_tiles,                   \
-        (const u8 *)a->d_in, (u8 *)a->d_out, (u32 *)(blk + l.ctl), (u32 *)(blk + l.tile_agg), (u64 *)(blk + l.group_acc), \
-        (u64 *)(blk + l.round_base), (u64 *)(blk + l.item_base), a->chunk_entry, a->chunk_base, fail_tile,           \
-        grid * kFuseWaves / kOpGroupTiles)
-        (void)hipMemsetAsync(blk, 0, l.bytes, st);
-        if (lb == 10) {
-            switch (sure) {
-                case 2: { HUFK_LAUNCH_ONEPASS_DEC(10, 2); } break;
-                case 3: { HUFK_LAUNCH_ONEPASS_DEC(10, 3); } break;
-                case 4: { HUFK_LAUNCH_ONEPASS_DEC(10, 4); } break;
-                case 5: { HUFK_LAUNCH_ONEPASS_DEC(10, 5); } break;
-                default: launched = false; break;
-            }
-        } else {
-            switch (sure) {
-                case 2: { HUFK_LAUNCH_ONEPASS_DEC(12, 2); } break;
-                case 3: { HUFK_LAUNCH_ONEPASS_DEC(12, 3); } break;
-                default: launched = false; break;
-            }
-        }
-#undef HUFK_LAUNCH_ONEPASS_DEC
-        gate = launched ? (const u32 *)(blk + l.ctl) : nullptr;
+    /* the builds of the row-synchronous kernels: a decode table of up to 10 bits with 3, 4 or 5 certain steps a row (codes
+     * of up to 10, 8, 6 bits; a coder of shorter codes still has more certain steps than that: the rest are asked for),
+     * of 11 or 12 bits with 2 */
+    const uint32_t lb_of_launch = a->tables.lut_bits <= 10 ? 10u : 12u;
+    const uint32_t sure_of_coder = row_walk(lb_of_launch, a->tables.max_bits).sure;
+    const uint32_t sure = lb_of_launch == 10 ? (sure_of_coder > 5 ? 5u : sure_of_coder) : (sure_of_coder > 2 ? 2u : sure_of_coder);
+    if (a->n_chunks && (a->tables.max_bits > HUFD_DEC_MAX_LUT_BITS || (lb_of_launch == 10 ? sure < 3 : sure != 2))) {
+        return (int)hipErrorInvalidValue; /* (a plan has chunks only for a decode table of up to 12 bits; see row_walk for the steps) */
     }
     if (a->n_chunks) {
         /* chunks inside the stream the short way; the rest, and those that turn out irregular, through the list */
@@ -10077,10 +8468,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         /* two lists of chunks that are not regular by dec_sync_lean's rules: the ones dec_sync_guess may still take
          * (inside a stream, first sub-chunk's walks meet) and the ones for the long way.  The second is the emit stage's
          * list, free until then; one list where there is no dec_sync_guess for the launch. */
-        const uint32_t sure_of_launch = row_walk(a->tables.lut_bits <= 10 ? 10u : 12u, a->tables.max_bits).sure;
-        const bool guessing = some_inside && a->old_sync != 1 && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS &&
-                              (a->tables.lut_bits <= 10 ? sure_of_launch >= 2 && sure_of_launch <= 5
-                                                        : sure_of_launch >= 2 && sure_of_launch <= 3);
+        const bool guessing = some_inside;
         u32 *lean_long_list = guessing ? a->emit_list : a->slow_list;
         u32 *lean_long_count = guessing ? a->emit_count : a->slow_count;
         if (guessing) {
@@ -10097,12 +8485,9 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             (void)hipEventRecord((hipEvent_t)a->fork_event, st);
             (void)hipStreamWaitEvent(tst, (hipEvent_t)a->fork_event, 0);
         }
-        /* chunks inside a stream: the lean kernel where it is compiled for this coder's number of certain steps a row */
-        const uint32_t sure = row_walk(a->tables.lut_bits <= 10 ? 10u : 12u, a->tables.max_bits).sure;
-        bool lean = false;
         /* the chunks streams end in: several to a workgroup where they are short and many (dec_sync_pack) */
         const uint32_t pack_width = a->tail_lanes + 2u < 16u ? 16u : a->tail_lanes + 2u; /* (+ the two sub-chunks a stream can end in: dec_emit_pack's scan) */
-        const bool pack = a->old_sync == 0 && a->n_tail_narrow >= kPackMinChunks && pack_width <= HUFD_DEC_LANES / 2;
+        const bool pack = a->one_chunk_a_workgroup == 0 && a->n_tail_narrow >= kPackMinChunks && pack_width <= HUFD_DEC_LANES / 2;
         const uint32_t pack_slots = HUFD_DEC_LANES / pack_width;
         /* (the plan lists the chunks with few whole lanes first: those go several to a workgroup, the others one each) */
         const uint32_t n_packed = pack ? a->n_tail_narrow : 0u, n_single = a->n_tail - n_packed;
@@ -10120,131 +8505,25 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             (dec_sync_lean_kernel<LBV, SUREV, true>), dim3(n_single), dim3(HUFD_DEC_LANES),                             \
             (uint32_t)sizeof(lean_shared<LBV>), tst, a->tables, a->chunk_rec, single_chunks,                            \
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
-            a->slow_list, a->slow_count, lean_long_list, lean_long_count, (const u32 *)nullptr);                        \
+            a->slow_list, a->slow_count, lean_long_list, lean_long_count);                                             \
     }                                                                                                                  \
-    if (inside_by_chunks) {                                                                                            \
+    if (some_inside) {                                                                                                 \
         hipLaunchKernelGGL(                                                                                            \
             (dec_sync_lean_kernel<LBV, SUREV, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES),                         \
             (uint32_t)sizeof(lean_shared<LBV>), st, a->tables, a->chunk_rec, a->tail_chunks,                            \
             (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
-            a->slow_list, a->slow_count, lean_long_list, lean_long_count, gate);                                       \
+            a->slow_list, a->slow_count, lean_long_list, lean_long_count);                                             \
     }
-        /* Asked for (AWS_HUFFMAN_AMD_DECODE=resident-sync): the chunks inside streams, where there are enough of them to fill
-         * the chip and the decode table has up to 10 bits, by resident waves with the walk table once per LDS bank
-         * (dec_sync_resident), what is per chunk put together behind them; the chunks streams end in keep
-         * dec_sync_lean<TAIL>.  Measured at half dec_sync_lean's speed (one workgroup a CU = 4 waves a SIMD): see there. */
-        bool resident = false;
-        /* (tests and experiments: AWS_HUFFMAN_AMD_RESIDENT_MIN_TILES = the fewest tiles a launch takes this way) */
-        const char *min_text = getenv("AWS_HUFFMAN_AMD_RESIDENT_MIN_TILES");
-        const uint32_t min_tiles = min_text ? (uint32_t)strtoul(min_text, nullptr, 10) : kResMinTiles;
-        if (a->old_sync == 4 && !gate && some_inside && a->n_res_tiles >= min_tiles && a->item_first_tile && a->chunk_flags &&
-            a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS && a->tables.lut_bits <= kResLB && a->tables.bank_rows &&
-            row_walk(kResLB, a->tables.max_bits, kResWinPos).sure == sure && sure >= 2 && sure <= 5) {
-            resident = true;
-            (void)hipMemsetAsync(a->chunk_flags, 0, (size_t)2 * a->n_chunks, st);
-            const uint32_t cus = current_compute_units();
-            const uint32_t want = (a->n_res_tiles + kResWaves - 1) / kResWaves;
-            const uint32_t grid = want < cus ? want : cus;
-#define HUFK_LAUNCH_SYNC_RESIDENT(SUREV)                                                                                \
-    hipLaunchKernelGGL(                                                                                                \
-        (dec_sync_resident_kernel<SUREV>), dim3(grid), dim3(kResThreads), (uint32_t)sizeof(resident_shared), st,        \
-        a->tables, a->items, a->n_items, a->item_first_tile, (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->lane_count,  \
-        a->chunk_flags, a->chunk_flags + a->n_chunks)
+        if (lb_of_launch == 10) {
             switch (sure) {
-                case 2: HUFK_LAUNCH_SYNC_RESIDENT(2); break;
-                case 3: HUFK_LAUNCH_SYNC_RESIDENT(3); break;
-                case 4: HUFK_LAUNCH_SYNC_RESIDENT(4); break;
-                default: HUFK_LAUNCH_SYNC_RESIDENT(5); break;
-            }
-#undef HUFK_LAUNCH_SYNC_RESIDENT
-            hipLaunchKernelGGL(
-                dec_sync_resident_finish_kernel, dim3(a->n_chunks), dim3(HUFD_DEC_LANES), 64, st, a->tables, a->chunk_rec,
-                (const u16 *)a->fn_tab, (const u16 *)a->cp_tab, (const u16 *)a->lane_count, (const u8 *)a->chunk_flags,
-                (const u8 *)(a->chunk_flags + a->n_chunks), a->chunk_fn, a->chunk_regular, a->slow_list, a->slow_count,
-                lean_long_list, lean_long_count);
-        }
-        const bool inside_by_chunks = some_inside && !resident; /* the kernels below take the chunks inside streams a workgroup each */
-        /* ... or, asked for (AWS_HUFFMAN_AMD_DECODE=bank-sync), for a decode table of up to 10 bits the one with a length table
-         * per LDS bank, four (or two) chunks a workgroup: measured slower than dec_sync_lean, see there */
-#define HUFK_LAUNCH_SYNC_BANK_N(SUREV, CH)                                                                              \
-    if (a->n_tail) {                                                                                                   \
-        hipLaunchKernelGGL(                                                                                            \
-            (dec_sync_bank_kernel<SUREV, true, CH>), dim3((a->n_tail + CH - 1) / CH), dim3(CH * HUFD_DEC_LANES),        \
-            (uint32_t)sizeof(bank_shared<CH>), tst, a->tables, a->chunk_rec, a->tail_chunks, a->n_tail,                 \
-            (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
-            a->slow_list, a->slow_count, lean_long_list, lean_long_count, (const u32 *)nullptr);                        \
-    }                                                                                                                  \
-    if (inside_by_chunks) {                                                                                            \
-        hipLaunchKernelGGL(                                                                                            \
-            (dec_sync_bank_kernel<SUREV, false, CH>), dim3((a->n_chunks + CH - 1) / CH), dim3(CH * HUFD_DEC_LANES),     \
-            (uint32_t)sizeof(bank_shared<CH>), st, a->tables, a->chunk_rec, a->tail_chunks, a->n_chunks,                \
-            (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
-            a->slow_list, a->slow_count, lean_long_list, lean_long_count, gate);                                       \
-    }
-#define HUFK_LAUNCH_SYNC_BANK(SUREV)                                                                                    \
-    if (bank_chunks == 2) {                                                                                            \
-        HUFK_LAUNCH_SYNC_BANK_N(SUREV, 2)                                                                              \
-    } else {                                                                                                           \
-        HUFK_LAUNCH_SYNC_BANK_N(SUREV, 4)                                                                              \
-    }
-        static const uint32_t bank_chunks = getenv("AWS_HUFFMAN_AMD_BANK_CHUNKS") ? (uint32_t)atoi(getenv("AWS_HUFFMAN_AMD_BANK_CHUNKS")) : 4u; /* (experiments) */
-        if (a->old_sync == 3 && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS && a->tables.lut_bits <= kBankLB && a->tables.bank_rows &&
-            row_walk(kBankLB, a->tables.max_bits, kBankWinPos).sure == sure) {
-            lean = true;
-            switch (sure) {
-                case 2: HUFK_LAUNCH_SYNC_BANK(2); break;
-                case 3: HUFK_LAUNCH_SYNC_BANK(3); break;
-                case 4: HUFK_LAUNCH_SYNC_BANK(4); break;
-                case 5: HUFK_LAUNCH_SYNC_BANK(5); break;
-                default: lean = false; break;
-            }
-        }
-#undef HUFK_LAUNCH_SYNC_BANK
-#undef HUFK_LAUNCH_SYNC_BANK_N
-        if (!lean && a->old_sync != 1 && a->tables.max_bits <= HUFD_DEC_MAX_LUT_BITS) { /* (0, 2: dec_sync_lean; 4: for the chunks streams end in) */
-            lean = true;
-            if (a->tables.lut_bits <= 10) {
-                switch (sure) {
-                    case 2: HUFK_LAUNCH_SYNC_LEAN(10, 2); break;
-                    case 3: HUFK_LAUNCH_SYNC_LEAN(10, 3); break;
-                    case 4: HUFK_LAUNCH_SYNC_LEAN(10, 4); break;
-                    case 5: HUFK_LAUNCH_SYNC_LEAN(10, 5); break;
-                    default: lean = false; break;
-                }
-            } else {
-                switch (sure) {
-                    case 2: HUFK_LAUNCH_SYNC_LEAN(12, 2); break;
-                    case 3: HUFK_LAUNCH_SYNC_LEAN(12, 3); break;
-                    default: lean = false; break;
-                }
-            }
-        }
-#undef HUFK_LAUNCH_SYNC_LEAN
-        if (a->tables.lut_bits <= 10) {
-            if (some_inside && !lean)
-            hipLaunchKernelGGL(
-                (dec_sync_fast_kernel<10, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<10>),
-                st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
-                a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry, a->slow_list, a->slow_count);
-            if (a->n_tail && !lean) {
-                hipLaunchKernelGGL(
-                    (dec_sync_fast_kernel<10, true>), dim3(a->n_tail), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<10>),
-                    tst, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
-                    a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry, a->slow_list, a->slow_count);
+                case 3: HUFK_LAUNCH_SYNC_LEAN(10, 3); break;
+                case 4: HUFK_LAUNCH_SYNC_LEAN(10, 4); break;
+                default: HUFK_LAUNCH_SYNC_LEAN(10, 5); break;
             }
         } else {
-            if (some_inside && !lean)
-            hipLaunchKernelGGL(
-                (dec_sync_fast_kernel<12, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<12>),
-                st, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
-                a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry, a->slow_list, a->slow_count);
-            if (a->n_tail && !lean) {
-                hipLaunchKernelGGL(
-                    (dec_sync_fast_kernel<12, true>), dim3(a->n_tail), dim3(HUFD_DEC_LANES), (uint32_t)sizeof(fast_shared<12>),
-                    tst, a->tables, a->items, a->chunk_item, a->tail_chunks, (const u8 *)a->d_in, a->fn_tab, a->cp_tab,
-                    a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry, a->slow_list, a->slow_count);
-            }
+            HUFK_LAUNCH_SYNC_LEAN(12, 2);
         }
+#undef HUFK_LAUNCH_SYNC_LEAN
         if (a->n_tail) {
             /* the last symbols of every stream, a thread each; then the chunk functions are complete */
             const uint32_t lds = (uint32_t)sizeof(tail_lds) + (2u << a->tables.lut_bits);
@@ -10260,8 +8539,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         /* the chunks inside streams that dec_sync_lean gave up on: a second chance that asks less of the coder
          * (dec_sync_guess); what that gives up on goes on a second list (the emit stage's, free until then) */
         const u32 *long_list = a->slow_list, *long_count = a->slow_count;
-        if (lean && guessing) {
-            bool guessed = true;
+        if (guessing) {
 #define HUFK_LAUNCH_SYNC_GUESS(LBV, SUREV)                                                                              \
     hipLaunchKernelGGL(                                                                                                \
         (dec_sync_guess_kernel<LBV, SUREV>),                                                                           \
@@ -10270,43 +8548,35 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         dim3(HUFD_DEC_LANES), (uint32_t)sizeof(lean_shared<LBV>), st, a->tables, a->chunk_rec, (const u8 *)a->d_in,     \
         a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, (const u32 *)a->slow_list,                 \
         (const u32 *)a->slow_count, a->emit_list, a->emit_count)
-            if (a->tables.lut_bits <= 10) {
+            if (lb_of_launch == 10) {
                 switch (sure) {
-                    case 2: HUFK_LAUNCH_SYNC_GUESS(10, 2); break;
                     case 3: HUFK_LAUNCH_SYNC_GUESS(10, 3); break;
                     case 4: HUFK_LAUNCH_SYNC_GUESS(10, 4); break;
-                    case 5: HUFK_LAUNCH_SYNC_GUESS(10, 5); break;
-                    default: guessed = false; break;
+                    default: HUFK_LAUNCH_SYNC_GUESS(10, 5); break;
                 }
             } else {
-                switch (sure) {
-                    case 2: HUFK_LAUNCH_SYNC_GUESS(12, 2); break;
-                    case 3: HUFK_LAUNCH_SYNC_GUESS(12, 3); break;
-                    default: guessed = false; break;
-                }
+                HUFK_LAUNCH_SYNC_GUESS(12, 2);
             }
 #undef HUFK_LAUNCH_SYNC_GUESS
-            if (guessed) {
-                long_list = a->emit_list;
-                long_count = a->emit_count;
-                /* of those, the chunks inside streams whose walks do not fall into step: a few walks a lane, not the long
-                 * way's every bit (dec_sync_few; its list -- dec_sync_lean's, used up by now -- is for dec_sync_true below) */
-                if (some_inside && a->few_walks) {
-                    few = true;
-                    (void)hipMemsetAsync(a->slow_count, 0, sizeof(uint32_t), st);
-                    if (a->tables.lut_bits <= 10) {
-                        hipLaunchKernelGGL(
-                            (dec_sync_few_kernel<10>),
-                            dim3(persistent_grid(dec_sync_few_kernel<10>, HUFD_DEC_LANES, (uint32_t)sizeof(few_shared<10>), a->n_chunks)),
-                            dim3(HUFD_DEC_LANES), (uint32_t)sizeof(few_shared<10>), st, a->tables, a->chunk_rec, (const u8 *)a->d_in,
-                            a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, long_list, long_count, a->slow_list, a->slow_count);
-                    } else {
-                        hipLaunchKernelGGL(
-                            (dec_sync_few_kernel<12>),
-                            dim3(persistent_grid(dec_sync_few_kernel<12>, HUFD_DEC_LANES, (uint32_t)sizeof(few_shared<12>), a->n_chunks)),
-                            dim3(HUFD_DEC_LANES), (uint32_t)sizeof(few_shared<12>), st, a->tables, a->chunk_rec, (const u8 *)a->d_in,
-                            a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, long_list, long_count, a->slow_list, a->slow_count);
-                    }
+            long_list = a->emit_list;
+            long_count = a->emit_count;
+            /* of those, the chunks inside streams whose walks do not fall into step: a few walks a lane, not the long
+             * way's every bit (dec_sync_few; its list -- dec_sync_lean's, used up by now -- is for dec_sync_true below) */
+            if (a->few_walks) {
+                few = true;
+                (void)hipMemsetAsync(a->slow_count, 0, sizeof(uint32_t), st);
+                if (a->tables.lut_bits <= 10) {
+                    hipLaunchKernelGGL(
+                        (dec_sync_few_kernel<10>),
+                        dim3(persistent_grid(dec_sync_few_kernel<10>, HUFD_DEC_LANES, (uint32_t)sizeof(few_shared<10>), a->n_chunks)),
+                        dim3(HUFD_DEC_LANES), (uint32_t)sizeof(few_shared<10>), st, a->tables, a->chunk_rec, (const u8 *)a->d_in,
+                        a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, long_list, long_count, a->slow_list, a->slow_count);
+                } else {
+                    hipLaunchKernelGGL(
+                        (dec_sync_few_kernel<12>),
+                        dim3(persistent_grid(dec_sync_few_kernel<12>, HUFD_DEC_LANES, (uint32_t)sizeof(few_shared<12>), a->n_chunks)),
+                        dim3(HUFD_DEC_LANES), (uint32_t)sizeof(few_shared<12>), st, a->tables, a->chunk_rec, (const u8 *)a->d_in,
+                        a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, long_list, long_count, a->slow_list, a->slow_count);
                 }
             }
         }
@@ -10319,7 +8589,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     if (a->n_tiny != a->n_items) { /* (as in the encoder: nothing to scan, and no empty item's record to write, in a plan of thread-per-item items only) */
         hipLaunchKernelGGL(
             dec_scan_small_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, ns, a->chunk_fn,
-            a->chunk_entry, a->chunk_base, a->states, a->results, gate);
+            a->chunk_entry, a->chunk_base, a->states, a->results);
     }
     if (a->n_tiny && a->tables.deep_entries) {
         hipLaunchKernelGGL(
@@ -10399,13 +8669,13 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     if (a->n_large) {
         const uint32_t lds = scan_run_lds_bytes(ns);
         hipLaunchKernelGGL(
-            dec_scan_runs_kernel, dim3(a->n_runs), dim3(256), lds, st, a->items, a->runs, ns, a->chunk_fn, a->run_fn, gate);
+            dec_scan_runs_kernel, dim3(a->n_runs), dim3(256), lds, st, a->items, a->runs, ns, a->chunk_fn, a->run_fn);
         hipLaunchKernelGGL(
             dec_scan_top_kernel, dim3(a->n_large), dim3(256), kTopTile * ns * 4, st, a->items, a->large_items, ns,
-            (const u32 *)a->run_fn, a->run_entry, a->run_base, a->states, a->results, gate);
+            (const u32 *)a->run_fn, a->run_entry, a->run_base, a->states, a->results);
         hipLaunchKernelGGL(
             dec_scan_apply_kernel, dim3(a->n_runs), dim3(256), lds, st, a->items, a->runs, ns, a->chunk_fn,
-            (const u32 *)a->run_entry, (const u64 *)a->run_base, a->chunk_entry, a->chunk_base, gate);
+            (const u32 *)a->run_entry, (const u64 *)a->run_base, a->chunk_entry, a->chunk_base);
     }
     if (few) {
         /* dec_sync_few's chunks, now that dec_scan has said where each is entered: the true walk's records (dec_sync_true) */
@@ -10437,8 +8707,8 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         emit_single_chunks, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab, (const u16 *)a->lane_count,   \
         (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry,                           \
         (const u64 *)a->chunk_base, a->results, a->emit_list, a->emit_count,                                            \
-        !TAILV && has_big ? a->dense_list : a->emit_list, !TAILV && has_big ? a->dense_count : a->emit_count,          \
-        TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES, TAILV ? (const u32 *)nullptr : gate)
+        !TAILV ? a->dense_list : a->emit_list, !TAILV ? a->dense_count : a->emit_count,                                \
+        TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES)
         const bool some_inside = a->n_tail < a->n_chunks;
         /* (the few chunks streams end in beside the many inside streams: see the sync kernels above.  And in any case
          * dec_emit_tail beside dec_emit_fast<TAIL>: it works out for itself which chunks that kernel takes, reads
@@ -10454,7 +8724,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             (void)hipStreamWaitEvent((hipStream_t)a->side_stream, (hipEvent_t)a->fork_event, 0);
         }
         /* (chunks inside a stream: with the coder's number of certain steps a row compiled in, where there is such a build) */
-        const uint32_t emit_sure = a->old_sync == 1 ? 0u : row_walk(a->tables.lut_bits <= 10 ? 10u : 12u, a->tables.max_bits).sure;
+        const uint32_t emit_sure = sure; /* (the build for the coder: see above) */
         /* the chunks streams end in, where they are short and many: several to a workgroup (dec_emit_pack, as dec_sync_pack) */
         const uint32_t epack_width = a->tail_lanes + 2u < 16u ? 16u : a->tail_lanes + 2u;
         const uint32_t epack_threads = kQuarters * ((epack_width + 1) / 2);
@@ -10463,8 +8733,8 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         uint32_t epack_slots = kEmitFastThreads / epack_threads;
         epack_slots = epack_slots > kPackMaxSlots ? kPackMaxSlots : epack_slots;
         epack_slots = epack_slots * epack_stage + epack_fixed > 60u * 1024u ? (60u * 1024u - epack_fixed) / epack_stage : epack_slots;
-        const bool epack = a->old_sync == 0 && a->n_tail_narrow >= kPackMinChunks && epack_width <= HUFD_DEC_LANES / 2 && a->tail_stage_bytes &&
-                           epack_slots >= 2 && emit_sure >= 2 && emit_sure <= (a->tables.lut_bits <= 10 ? 5u : 3u);
+        const bool epack = a->one_chunk_a_workgroup == 0 && a->n_tail_narrow >= kPackMinChunks && epack_width <= HUFD_DEC_LANES / 2 &&
+                           a->tail_stage_bytes && epack_slots >= 2;
         /* the stage of the launch for the chunks streams end in: what the plan says such a chunk can hold at most */
         const uint32_t tail_stage = epack ? (a->tail_stage_bytes + 255u) & ~255u
                                     : a->tail_stage_bytes >= 4096 && a->tail_stage_bytes < HUFD_DEC_STAGE_BYTES
@@ -10479,58 +8749,41 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         e_packed, epack_width, epack_slots, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab,               \
         (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry, \
         (const u64 *)a->chunk_base, a->emit_list, a->emit_count, tail_stage)
-        /* chunks of short codes that hold more symbols than dec_emit_fast's stage: dec_emit_big where there is a build of
-         * it for the coder and the chunk lies inside its stream; the others take the long way (dec_emit) */
-        const bool has_big = a->tables.lut_bits <= 10 ? emit_sure >= 2 && emit_sure <= 5 : emit_sure >= 2 && emit_sure <= 3;
+        /* chunks of short codes that hold more symbols than dec_emit_fast's stage: dec_emit_big where the chunk lies
+         * inside its stream; the others take the long way (dec_emit) */
         if (e_packed) {
-            if (a->tables.lut_bits <= 10) {
+            if (lb_of_launch == 10) {
                 switch (emit_sure) {
-                    case 2: HUFK_LAUNCH_EMIT_PACK(10, 2); break;
                     case 3: HUFK_LAUNCH_EMIT_PACK(10, 3); break;
                     case 4: HUFK_LAUNCH_EMIT_PACK(10, 4); break;
                     default: HUFK_LAUNCH_EMIT_PACK(10, 5); break;
                 }
             } else {
-                switch (emit_sure) {
-                    case 2: HUFK_LAUNCH_EMIT_PACK(12, 2); break;
-                    default: HUFK_LAUNCH_EMIT_PACK(12, 3); break;
-                }
+                HUFK_LAUNCH_EMIT_PACK(12, 2);
             }
         }
 #undef HUFK_LAUNCH_EMIT_PACK
-        if (a->tables.lut_bits <= 10) {
+        if (lb_of_launch == 10) {
             if (e_single) {
                 switch (emit_sure) {
-                    case 2: HUFK_LAUNCH_EMIT_FAST(10, true, 2, e_single, tst); break;
                     case 3: HUFK_LAUNCH_EMIT_FAST(10, true, 3, e_single, tst); break;
                     case 4: HUFK_LAUNCH_EMIT_FAST(10, true, 4, e_single, tst); break;
-                    case 5: HUFK_LAUNCH_EMIT_FAST(10, true, 5, e_single, tst); break;
-                    default: HUFK_LAUNCH_EMIT_FAST(10, true, 0, e_single, tst); break;
+                    default: HUFK_LAUNCH_EMIT_FAST(10, true, 5, e_single, tst); break;
                 }
             }
             if (some_inside) {
                 switch (emit_sure) {
-                    case 2: HUFK_LAUNCH_EMIT_FAST(10, false, 2, a->n_chunks, st); break;
                     case 3: HUFK_LAUNCH_EMIT_FAST(10, false, 3, a->n_chunks, st); break;
                     case 4: HUFK_LAUNCH_EMIT_FAST(10, false, 4, a->n_chunks, st); break;
-                    case 5: HUFK_LAUNCH_EMIT_FAST(10, false, 5, a->n_chunks, st); break;
-                    default: HUFK_LAUNCH_EMIT_FAST(10, false, 0, a->n_chunks, st); break;
+                    default: HUFK_LAUNCH_EMIT_FAST(10, false, 5, a->n_chunks, st); break;
                 }
             }
         } else {
             if (e_single) {
-                switch (emit_sure) {
-                    case 2: HUFK_LAUNCH_EMIT_FAST(12, true, 2, e_single, tst); break;
-                    case 3: HUFK_LAUNCH_EMIT_FAST(12, true, 3, e_single, tst); break;
-                    default: HUFK_LAUNCH_EMIT_FAST(12, true, 0, e_single, tst); break;
-                }
+                HUFK_LAUNCH_EMIT_FAST(12, true, 2, e_single, tst);
             }
             if (some_inside) {
-                switch (emit_sure) {
-                    case 2: HUFK_LAUNCH_EMIT_FAST(12, false, 2, a->n_chunks, st); break;
-                    case 3: HUFK_LAUNCH_EMIT_FAST(12, false, 3, a->n_chunks, st); break;
-                    default: HUFK_LAUNCH_EMIT_FAST(12, false, 0, a->n_chunks, st); break;
-                }
+                HUFK_LAUNCH_EMIT_FAST(12, false, 2, a->n_chunks, st);
             }
         }
 #undef HUFK_LAUNCH_EMIT_FAST
@@ -10548,7 +8801,6 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         }
         /* chunks of short codes (more symbols than one stage): resident workgroups with a stage twice as long take turns
          * over their list */
-        bool big = false;
 #define HUFK_LAUNCH_EMIT_BIG(LBV, SUREV)                                                                                \
     do {                                                                                                               \
         const uint32_t lds = emit_lds_bytes<LBV>(kEmitBigStage);                                                       \
@@ -10559,22 +8811,15 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
             (const u16 *)a->cp_tab, (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn, \
             (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results, a->emit_list, a->emit_count,          \
             (const u32 *)a->dense_list, (const u32 *)a->dense_count);                                                  \
-        big = true;                                                                                                    \
     } while (0)
-        if (a->tables.lut_bits <= 10) {
+        if (lb_of_launch == 10) {
             switch (emit_sure) {
-                case 2: HUFK_LAUNCH_EMIT_BIG(10, 2); break;
                 case 3: HUFK_LAUNCH_EMIT_BIG(10, 3); break;
                 case 4: HUFK_LAUNCH_EMIT_BIG(10, 4); break;
-                case 5: HUFK_LAUNCH_EMIT_BIG(10, 5); break;
-                default: break;
+                default: HUFK_LAUNCH_EMIT_BIG(10, 5); break;
             }
         } else {
-            switch (emit_sure) {
-                case 2: HUFK_LAUNCH_EMIT_BIG(12, 2); break;
-                case 3: HUFK_LAUNCH_EMIT_BIG(12, 3); break;
-                default: break;
-            }
+            HUFK_LAUNCH_EMIT_BIG(12, 2);
         }
 #undef HUFK_LAUNCH_EMIT_BIG
         hipLaunchKernelGGL(

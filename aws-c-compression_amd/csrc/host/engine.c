@@ -10,7 +10,40 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* the tests' switches (huffman_amd.h "testing hooks"): process-wide words, read with the plans and launches that follow */
+static uint32_t s_testing_encode_road = 0, s_testing_decode_road = 0;
+static uint64_t s_testing_per_byte[2] = {0, 0}; /* [0] encode, [1] decode */
+
+void aws_huffman_amd_testing_set_encode_road(uint32_t flags) {
+    __atomic_store_n(&s_testing_encode_road, flags, __ATOMIC_RELAXED);
+}
+void aws_huffman_amd_testing_set_decode_road(uint32_t flags) {
+    __atomic_store_n(&s_testing_decode_road, flags, __ATOMIC_RELAXED);
+}
+void aws_huffman_amd_testing_set_items_per_byte(uint64_t encode, uint64_t decode) {
+    __atomic_store_n(&s_testing_per_byte[0], encode, __ATOMIC_RELAXED);
+    __atomic_store_n(&s_testing_per_byte[1], decode, __ATOMIC_RELAXED);
+}
+static uint32_t testing_encode_road(void) {
+    return __atomic_load_n(&s_testing_encode_road, __ATOMIC_RELAXED);
+}
+static uint32_t testing_decode_road(void) {
+    return __atomic_load_n(&s_testing_decode_road, __ATOMIC_RELAXED);
+}
+
+
 /* ------------------------------------------------------------------ small helpers */
+
+/* behind a plan's launch, on the launch's stream: the event a later owner of the plan's device arrays waits for */
+static int plan_mark_done(void **event, void *stream) {
+    if (!*event) {
+        *event = hufs_event_create_untimed();
+        if (!*event) {
+            return 2;
+        }
+    }
+    return hufs_event_record(*event, stream);
+}
 
 /*
  * The calling thread's current HIP device is the caller's business: every entry point that works on an engine's device
@@ -220,13 +253,13 @@ int aws_huffman_amd_engine_new(
         }
     }
     {
-        const char *mode = getenv("AWS_HUFFMAN_AMD_ENCODE");
-        /* one pass over the input where the coder allows it (hufk_encode_one_pass_applies); "three-kernel"
-         * forces count / scan / pack, the road every other coder takes */
-        eng->single_pass = !(mode && strcmp(mode, "three-kernel") == 0);
-        /* "one-pass-fails": a wave of the one-pass kernel is made to give up, as if a look-back wait had run out: the
-         * three-kernel road queued behind it on the stream does the launch over (tests) */
-        eng->encode_fails = mode && strcmp(mode, "one-pass-fails") == 0;
+        const uint32_t road = testing_encode_road();
+        /* one pass over the input where the coder allows it (hufk_encode_one_pass_applies); the tests can ask for count /
+         * scan / pack, the road every other coder takes */
+        eng->single_pass = !(road & AWS_HUFFMAN_AMD_TEST_ENCODE_THREE_KERNEL);
+        /* ... or for a wave of the one-pass kernel that gives up, as if a look-back wait had run out: the three-kernel
+         * road queued behind it on the stream does the launch over */
+        eng->encode_fails = (road & AWS_HUFFMAN_AMD_TEST_ENCODE_ONE_PASS_FAILS) != 0;
     }
     /* decode tables from the DECODE callback alone (the reference's decoder knows nothing else: source/huffman.c:235-238;
      * reference huffman.h:48).  Every window of HUFD_DEC_MAX_LUT_BITS bits is asked twice, the bits behind it all zero
@@ -356,24 +389,10 @@ int aws_huffman_amd_engine_new(
         eng->d_dec_lut =
             device_upload(eng->dec_lut_host, (size_t)sizeof(uint16_t) << eng->tables.lut_bits, eng->stream, &err);
     }
-    if (!err && eng->dec_lut_host && eng->tables.lut_bits <= 10) {
-        /* dec_sync_bank's length bytes, four windows of 10 bits a dword (hufd_tables.bank_rows) */
-        uint32_t rows[256];
-        const uint32_t down = 10 - eng->tables.lut_bits;
-        for (uint32_t r = 0; r < 256; ++r) {
-            rows[r] = 0;
-            for (uint32_t i = 0; i < 4; ++i) {
-                const uint32_t len = eng->dec_lut_host[(4 * r + i) >> down] & 0xFFu;
-                rows[r] |= (256u - (len ? len : 48u)) << (8 * i);
-            }
-        }
-        eng->d_bank_rows = device_upload(rows, sizeof(rows), eng->stream, &err);
-    }
     if (err) {
         aws_huffman_amd_engine_destroy(eng);
         return raise_hip(err);
     }
-    eng->tables.bank_rows = eng->d_bank_rows;
     eng->tables.enc_table = eng->d_enc_table;
     eng->tables.dec_lut = eng->d_dec_lut;
     eng->tables.deep_lut = eng->d_deep_lut;
@@ -412,7 +431,6 @@ void aws_huffman_amd_engine_destroy(struct aws_huffman_amd_engine *eng) {
     hufs_host_free(eng->mini_host);
     hufs_free(eng->d_enc_table);
     hufs_free(eng->d_dec_lut);
-    hufs_free(eng->d_bank_rows);
     hufs_free(eng->d_deep_lut);
     hufs_event_destroy(eng->fork_event);
     hufs_event_destroy(eng->join_event);
@@ -486,16 +504,11 @@ static void enc_plan_release_device(struct aws_huffman_amd_encode_plan *p) {
 /* fewer items than this: the host's loop over them costs less than an allocation and a launch */
 #define PLAN_ON_DEVICE_MIN_ITEMS 4096u
 
-/* items per byte of the longest item from which a length class goes to a thread per item (HUFD_*_TINY_PER_BYTE;
- * AWS_HUFFMAN_AMD_ENC_TINY_PER_BYTE / _DEC_: experiments) */
+/* items per byte of the longest item from which a length class goes to a thread per item (HUFD_*_TINY_PER_BYTE; the tests
+ * set other numbers: aws_huffman_amd_testing_set_items_per_byte) */
 static uint64_t tiny_per_byte(bool decode) {
-    static uint64_t cached[2] = {0, 0};
-    if (!cached[decode]) {
-        const char *text = getenv(decode ? "AWS_HUFFMAN_AMD_DEC_TINY_PER_BYTE" : "AWS_HUFFMAN_AMD_ENC_TINY_PER_BYTE");
-        const uint64_t v = text ? strtoull(text, NULL, 10) : 0;
-        cached[decode] = v ? v : (decode ? HUFD_DEC_TINY_PER_BYTE : HUFD_ENC_TINY_PER_BYTE);
-    }
-    return cached[decode];
+    const uint64_t asked = __atomic_load_n(&s_testing_per_byte[decode], __ATOMIC_RELAXED);
+    return asked ? asked : (decode ? HUFD_DEC_TINY_PER_BYTE : HUFD_ENC_TINY_PER_BYTE);
 }
 
 /* ... and for an encoder that packs ragged tiles in one pass (a wave a tile: ~1.6 ns an item whatever its length, where a lone
@@ -503,16 +516,11 @@ static uint64_t tiny_per_byte(bool decode) {
  * profiles/tools/mid_items.py: 447 K items of 300 B 1.02 ms by threads against 2.82 by tiles, but BASELINE configs[3]'s
  * 16 384 resume items of ~320 symbols 251 us by threads where tiles take a tenth */
 static uint64_t enc_tiny_per_byte(const struct aws_huffman_amd_engine *eng) {
-    static uint64_t one_pass = 0;
-    if (!aws_huffman_amd_engine_encodes_in_one_pass(eng)) {
+    const uint64_t asked = __atomic_load_n(&s_testing_per_byte[0], __ATOMIC_RELAXED);
+    if (asked || !aws_huffman_amd_engine_encodes_in_one_pass(eng)) {
         return tiny_per_byte(false);
     }
-    if (!one_pass) {
-        const char *text = getenv("AWS_HUFFMAN_AMD_ENC_TINY_PER_BYTE");
-        const uint64_t v = text ? strtoull(text, NULL, 10) : 0;
-        one_pass = v ? v : HUFD_ENC_TINY_PER_BYTE_ONE_PASS;
-    }
-    return one_pass;
+    return HUFD_ENC_TINY_PER_BYTE_ONE_PASS;
 }
 
 struct item_stats { /* of a plan's items, from the pass that finds the thread-per-item limit */
@@ -622,6 +630,8 @@ static int enc_plan_fill(
     const uint64_t tiny_limit = enc_tiny_limit(eng, items, n_items, &stats);
     /* a failed refill must not leave counts of the fill before behind (the device arrays may be gone or too small) */
     p->n_items = p->n_segs = p->n_large = p->n_tiny = 0;
+    p->launched = false; /* (the records of a launch of other items say nothing about these) */
+    memset(&p->stats, 0, sizeof(p->stats));
     p->largest_out_cap = stats.largest_out_cap;
     p->most_overflow_bits = stats.worst_bits;
     if (n_items >= PLAN_ON_DEVICE_MIN_ITEMS && n_items < 0xFFFFFFFFull && stats.shortest >= 1 && stats.longest <= tiny_limit &&
@@ -649,9 +659,11 @@ static int enc_plan_fill(
         }
         p->n_items = (uint32_t)n_items;
         p->n_tiny = (uint32_t)n_items;
+        p->stats.items = p->stats.by_thread = n_items;
+        p->stats.thread_limit = tiny_limit;
         return AWS_OP_SUCCESS;
     }
-    uint64_t n_segs = 0, n_large = 0, n_tiny = 0;
+    uint64_t n_segs = 0, n_large = 0, n_tiny = 0, n_cut = 0;
     for (size_t i = 0; i < n_items; ++i) {
         if (items[i].overflow_in.num_bits > 32) {
             return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
@@ -660,6 +672,7 @@ static int enc_plan_fill(
         n_segs += segs;
         n_large += segs > HUFD_SCAN_SMALL_MAX;
         n_tiny += enc_item_is_tiny(&items[i], tiny_limit);
+        n_cut += segs != 0;
     }
     if (n_segs >= 0xFFFFFFFFull || n_items >= 0xFFFFFFFFull) {
         return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
@@ -742,6 +755,22 @@ static int enc_plan_fill(
     p->n_segs = (uint32_t)n_segs;
     p->n_large = (uint32_t)n_large;
     p->n_tiny = (uint32_t)n_tiny;
+    p->stats.items = n_items;
+    p->stats.thread_limit = tiny_limit;
+    p->stats.by_thread = n_tiny;
+    p->stats.by_pieces = n_cut;
+    p->stats.pieces = n_segs;
+    p->stats.empty = n_items - n_tiny - n_cut;
+    return AWS_OP_SUCCESS;
+}
+
+int aws_huffman_amd_encode_plan_stats(const struct aws_huffman_amd_encode_plan *plan, struct aws_huffman_amd_plan_stats *stats) {
+    *stats = plan->stats;
+    return AWS_OP_SUCCESS;
+}
+
+int aws_huffman_amd_decode_plan_stats(const struct aws_huffman_amd_decode_plan *plan, struct aws_huffman_amd_plan_stats *stats) {
+    *stats = plan->stats;
     return AWS_OP_SUCCESS;
 }
 
@@ -762,14 +791,17 @@ int aws_huffman_amd_encode_plan_new(
     eng->spare_enc = NULL;
     pthread_mutex_unlock(&eng->spare_lock);
     if (p) {
-        /* its last launch may still run on the caller's stream (freeing the arrays used to wait for it) */
+        /* its last launch may still run on the caller's stream (freeing the arrays used to wait for it): waited for by the
+         * event that launch left behind -- not for every stream of the device, on which other threads' batches may run */
         ON_DEVICE(eng->device);
-        if (hufs_device_sync()) {
+        if (p->done_event && hufs_event_sync(p->done_event)) {
+            p->unkeepable = true; /* (freed, not parked again for the next caller to fail on) */
             aws_huffman_amd_encode_plan_destroy(p);
             return aws_raise_error(AWS_ERROR_UNKNOWN);
         }
         p->last_input = NULL;
         p->last_output = NULL;
+        p->launched = false;
         p->last_single_pass = false;
         p->last_timed_out = false;
         p->look_back_timed_out = false;
@@ -801,7 +833,7 @@ void aws_huffman_amd_encode_plan_destroy(struct aws_huffman_amd_encode_plan *p) 
         struct aws_huffman_amd_engine *eng = p->engine;
         /* the engine keeps ONE destroyed plan with its device arrays for the next aws_huffman_amd_encode_plan_new */
         pthread_mutex_lock(&eng->spare_lock);
-        const bool keep = !eng->retiring && !eng->spare_enc && p->cap_items && p != eng->one_enc;
+        const bool keep = !eng->retiring && !eng->spare_enc && p->cap_items && p != eng->one_enc && !p->unkeepable;
         if (keep) {
             eng->spare_enc = p;
         }
@@ -811,6 +843,7 @@ void aws_huffman_amd_encode_plan_destroy(struct aws_huffman_amd_encode_plan *p) 
         }
         ON_DEVICE(eng->device);
         enc_plan_release_device(p);
+        hufs_event_destroy(p->done_event);
         free(p);
     }
 }
@@ -859,12 +892,16 @@ int aws_huffman_amd_encode_plan_launch_staged(
     a.fail_tile = p->engine->encode_fails;
     p->last_input = device_input;
     p->last_output = device_output;
+    p->launched = true;
     p->last_single_pass = a.single_pass && p->n_segs && !length_only && hufk_encode_one_pass_applies(&p->engine->tables);
     a.states = p->d_states;
     a.results = p->d_results;
     a.stage_events = stage_events;
     ON_DEVICE(p->engine->device);
-    const int err = hufk_encode_launch(&a, stream ? stream : p->engine->stream);
+    int err = hufk_encode_launch(&a, stream ? stream : p->engine->stream);
+    if (!err) {
+        err = plan_mark_done(&p->done_event, stream ? stream : p->engine->stream);
+    }
     return err ? raise_hip(err) : AWS_OP_SUCCESS;
 }
 
@@ -987,14 +1024,10 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     hufs_free(p->d_dense_list);
     hufs_free(p->d_lane_count);
     hufs_free(p->d_chunk_regular);
-    hufs_free(p->d_chunk_flags);
-    hufs_free(p->d_first_tile);
     hufs_free(p->d_tail_entry);
     hufs_free(p->d_chunk_entry);
     hufs_free(p->d_chunk_base);
     hufs_free(p->d_chunk_rec);
-    hufs_free(p->d_tiles);
-    hufs_free(p->d_fuse_block);
     hufs_free(p->d_states);
     hufs_free(p->d_results);
     p->d_items = NULL;
@@ -1014,15 +1047,10 @@ static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
     p->d_dense_list = NULL;
     p->d_lane_count = NULL;
     p->d_chunk_regular = NULL;
-    p->d_chunk_flags = NULL;
-    p->d_first_tile = NULL;
     p->d_tail_entry = NULL;
     p->d_chunk_entry = NULL;
     p->d_chunk_base = NULL;
     p->d_chunk_rec = NULL;
-    p->d_tiles = NULL;
-    p->d_fuse_block = NULL;
-    p->cap_tiles = p->cap_fuse_block = 0;
     p->d_states = NULL;
     p->d_results = NULL;
     p->cap_items = p->cap_chunks = p->cap_large = p->cap_runs = 0;
@@ -1102,17 +1130,6 @@ static uint64_t dec_item_chunks(
     return (it->in_len + HUFD_DEC_CHUNK_BYTES - 1) / HUFD_DEC_CHUNK_BYTES;
 }
 
-/* sub-chunks of an item that dec_onepass takes: those of its chunks that lie inside the stream with 8 more bytes behind */
-static uint64_t dec_item_inside_subs(uint64_t chunks, uint64_t in_len) {
-    const uint64_t inside = chunks && in_len >= 8 ? (in_len - 8) / HUFD_DEC_CHUNK_BYTES : 0;
-    return (inside < chunks ? inside : chunks) * (HUFD_DEC_CHUNK_BYTES / HUFD_FUSE_SUB_BYTES);
-}
-/* ... as tiles: the first of 64 sub-chunks, the others of 63 and the last one of the tile in front */
-static uint64_t dec_item_tiles(uint64_t chunks, uint64_t in_len) {
-    const uint64_t subs = dec_item_inside_subs(chunks, in_len);
-    return subs == 0 ? 0 : (subs <= HUFD_TILE_LANES ? 1 : 1 + (subs - HUFD_TILE_LANES + HUFD_TILE_LANES - 2) / (HUFD_TILE_LANES - 1));
-}
-
 /* the plan's device arrays for this many items, chunks, large items and runs (grown, never shrunk); 0 or a HIP error */
 /* whole lanes of a chunk with `left` bytes of its item from its first byte on: sub-chunks with 8 more bytes behind them */
 static uint64_t whole_lanes_of(uint64_t left) {
@@ -1143,8 +1160,6 @@ static int dec_plan_reserve(struct aws_huffman_amd_decode_plan *p, size_t n_item
         p->d_dense_list = hufs_malloc((cc + 1) * sizeof(uint32_t));
         p->d_lane_count = hufs_malloc(cc * HUFD_DEC_LANES * sizeof(uint16_t));
         p->d_chunk_regular = hufs_malloc(cc);
-        p->d_chunk_flags = hufs_malloc(2 * cc);
-        p->d_first_tile = hufs_malloc((ci + 1) * sizeof(uint32_t));
         p->d_tail_entry = hufs_malloc(cc * sizeof(uint32_t));
         p->d_chunk_entry = hufs_malloc(cc * sizeof(uint32_t));
         p->d_chunk_base = hufs_malloc(cc * sizeof(uint64_t));
@@ -1152,7 +1167,7 @@ static int dec_plan_reserve(struct aws_huffman_amd_decode_plan *p, size_t n_item
         p->d_states = hufs_malloc(ci * sizeof(struct hufd_dec_item_state));
         p->d_results = hufs_malloc(ci * sizeof(struct hufd_dec_result));
         if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_cp_tab || !p->d_chunk_fn || !p->d_slow_list || !p->d_chunk_entry ||
-            !p->d_tail || !p->d_tiny || !p->d_dense_list || !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_chunk_flags || !p->d_first_tile || !p->d_tail_entry || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
+            !p->d_tail || !p->d_tiny || !p->d_dense_list || !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_tail_entry || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
             !p->d_chunk_base || !p->d_chunk_rec || !p->d_states || !p->d_results) {
             return 2;
         }
@@ -1176,9 +1191,9 @@ static int dec_plan_fill(
     struct item_stats stats;
     const uint64_t tiny_limit = dec_tiny_limit(items, n_items, &stats);
     /* a failed refill must not leave counts of the fill before behind (the device arrays may be gone or too small) */
-    p->n_items = p->n_chunks = p->n_large = p->n_runs = p->n_tail = p->n_tiles = p->n_fixed = p->n_wide = 0;
+    p->n_items = p->n_chunks = p->n_large = p->n_runs = p->n_tail = p->n_fixed = p->n_wide = 0;
     p->n_tiny = p->n_deep = 0;
-    p->n_res_tiles = 0;
+    memset(&p->stats, 0, sizeof(p->stats));
     p->chained = false;
     if (n_items >= PLAN_ON_DEVICE_MIN_ITEMS && n_items < 0xFFFFFFFFull && stats.shortest >= 1 && stats.longest <= tiny_limit &&
         stats.worst_bits <= 7) {
@@ -1215,18 +1230,11 @@ static int dec_plan_fill(
         p->n_tail_narrow = 0;
         p->n_items = (uint32_t)n_items;
         p->n_tiny = (uint32_t)n_items;
+        p->stats.items = p->stats.by_thread = n_items;
+        p->stats.thread_limit = tiny_limit;
         return AWS_OP_SUCCESS;
     }
-    /* dec_onepass's tile records only where that kernel is asked for (AWS_HUFFMAN_AMD_DECODE=one-pass, one-pass-fails) and
-     * applies to the coder: three records per 16 KiB item that the default road never reads were the largest part of
-     * what a plan cost to make */
-    bool want_tiles = false;
-    {
-        const char *mode = getenv("AWS_HUFFMAN_AMD_DECODE");
-        want_tiles = mode && (strcmp(mode, "one-pass") == 0 || strcmp(mode, "one-pass-fails") == 0) &&
-                     hufk_decode_one_pass_applies(&eng->tables);
-    }
-    uint64_t n_chunks = 0, n_large = 0, n_runs = 0, n_tiles = 0;
+    uint64_t n_chunks = 0, n_large = 0, n_runs = 0, n_cut = 0;
     for (size_t i = 0; i < n_items; ++i) {
         /* symbol counts in the scan's function entries are 26-bit; 4 GiB of encoded bytes per item is the limit */
         if (items[i].first_bit > 7 || items[i].in_len > 0xFFFFFFFFull) {
@@ -1234,46 +1242,41 @@ static int dec_plan_fill(
         }
         const uint64_t chunks = dec_item_chunks(eng, &items[i], tiny_limit);
         n_chunks += chunks;
+        n_cut += chunks != 0;
         n_large += chunks > HUFD_SCAN_SMALL_MAX;
         n_runs += chunks > HUFD_SCAN_SMALL_MAX ? (chunks + HUFD_SCAN_RUN_CHUNKS - 1) / HUFD_SCAN_RUN_CHUNKS : 0;
-        n_tiles += want_tiles ? dec_item_tiles(chunks, items[i].in_len) : 0;
     }
-    if (n_chunks >= 0xFFFFFFFFull || n_items >= 0xFFFFFFFFull || n_tiles >= 0x00FFFFFFull) {
+    if (n_chunks >= 0xFFFFFFFFull || n_items >= 0xFFFFFFFFull) {
         return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
     }
 
     struct hufd_dec_item *h_items = malloc((n_items ? n_items : 1) * sizeof(*h_items));
-    uint32_t *h_first_tile = malloc((n_items + 1) * sizeof(uint32_t)); /* dec_sync_resident's tiles of the items in front */
     uint32_t *h_large = malloc((n_large ? n_large : 1) * 2 * sizeof(uint32_t));
     uint32_t *h_runs = malloc((n_runs ? n_runs : 1) * 2 * sizeof(uint32_t));
     uint32_t *h_tail = malloc((n_items ? n_items : 1) * 2 * sizeof(uint32_t));
     uint32_t *h_tiny = malloc((n_items ? n_items : 1) * sizeof(uint32_t));
-    struct hufd_tile_rec *h_tiles = malloc((n_tiles ? n_tiles : 1) * sizeof(*h_tiles));
-    if (!h_tiles || !h_items || !h_first_tile || !h_large || !h_runs || !h_tail || !h_tiny) {
-        free(h_first_tile);
+    if (!h_items || !h_large || !h_runs || !h_tail || !h_tiny) {
         free(h_tail);
         free(h_tiny);
-        free(h_tiles);
         free(h_runs);
         free(h_items);
         free(h_large);
         return aws_raise_error(AWS_ERROR_OOM);
     }
-    uint32_t chunk = 0, large = 0, run = 0, tail = 0, narrow = 0, wide = 0, tiny = 0, deep = 0, tile = 0;
+    uint32_t chunk = 0, large = 0, run = 0, tail = 0, narrow = 0, wide = 0, tiny = 0, deep = 0;
     size_t deep_items = 0;
     for (size_t i = 0; i < n_items && eng->tables.deep_entries; ++i) {
         deep_items += !dec_item_is_tiny(&items[i], tiny_limit) && dec_item_is_deep(eng, &items[i], tiny_limit);
     }
     const uint64_t wide_from = wide_min_bytes(deep_items);
     uint32_t *h_fixed = NULL;
-    uint64_t n_fixed = 0;
+    uint64_t n_fixed = 0, fixed_items = 0;
     struct hufk_wide_item *h_wide = NULL;
     uint32_t n_wide = 0;
     uint64_t wide_bytes = 0;
     bool wide_oom = false;
     uint64_t tail_stage = 0; /* the most symbols a chunk that holds the end of a stream can decode to */
     uint64_t tail_lanes = 0; /* ... and the most whole lanes it has */
-    uint64_t res_tiles = 0;
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_decode_item *src = &items[i];
         struct hufd_dec_item *dst = &h_items[i];
@@ -1286,13 +1289,12 @@ static int dec_plan_fill(
         dst->first_chunk = chunk;
         dst->n_chunks = chunks;
         dst->tiny = 0;
-        h_first_tile[i] = (uint32_t)res_tiles;
-        res_tiles += dec_item_tiles(chunks, src->in_len);
         if (dec_item_is_tiny(src, tiny_limit)) {
             dst->tiny = 1;
             h_tiny[tiny++] = (uint32_t)i;
         } else if (dec_item_is_fixed(eng, src, tiny_limit)) {
             dst->tiny = 2;
+            ++fixed_items;
             const uint64_t blocks = (src->in_len + HUFD_FIXED_BLOCK_BYTES - 1) / HUFD_FIXED_BLOCK_BYTES;
             uint32_t *more = realloc(h_fixed, (n_fixed + blocks) * 2 * sizeof(uint32_t));
             if (!more) {
@@ -1320,24 +1322,6 @@ static int dec_plan_fill(
                     wide_bytes += hufk_decode_wide_bytes(h_wide[n_wide].n_blocks);
                     ++n_wide;
                 }
-            }
-        }
-        {
-            const uint64_t subs = dec_item_inside_subs(chunks, src->in_len);
-            const uint64_t tiles_here = want_tiles ? dec_item_tiles(chunks, src->in_len) : 0;
-            for (uint64_t k = 0; k < tiles_here; ++k) {
-                /* tile 0: sub-chunks 0 .. 63; tile k: sub-chunk 63 k (again) and 63 k + 1 .. 63 k + 63 */
-                const uint64_t first_sub = k * (HUFD_TILE_LANES - 1);
-                const uint64_t left = subs - first_sub;
-                struct hufd_tile_rec *tr = &h_tiles[tile++];
-                tr->src_off = src->in_offset + first_sub * HUFD_FUSE_SUB_BYTES;
-                tr->out_off = src->out_offset;
-                tr->out_cap = src->out_capacity;
-                tr->item = (uint32_t)i;
-                tr->n_lanes = (uint16_t)(left < HUFD_TILE_LANES ? left : HUFD_TILE_LANES);
-                tr->flags = (uint16_t)((k == 0 ? 1u : 0u) | (k + 1 == tiles_here ? 2u : 0u) | ((uint32_t)src->first_bit << 8));
-                tr->tail_chunk = chunk + (uint32_t)(subs / (HUFD_DEC_CHUNK_BYTES / HUFD_FUSE_SUB_BYTES));
-                tr->reserved = 0;
             }
         }
         /* the chunks that hold the end of the stream, or lie just behind it: fewer than a chunk + 8 bytes left from their
@@ -1406,30 +1390,8 @@ static int dec_plan_fill(
     if (!err) {
         err = dec_plan_reserve(p, n_items, n_chunks, n_large, n_runs);
     }
-    {
-        const size_t zero_bytes = (size_t)hufk_decode_zero_bytes((uint32_t)n_tiles, (uint32_t)n_items);
-        if (!err && n_tiles > p->cap_tiles) {
-            hufs_free(p->d_tiles);
-            p->d_tiles = hufs_malloc(n_tiles * sizeof(struct hufd_tile_rec));
-            p->cap_tiles = p->d_tiles ? n_tiles : 0;
-            err = p->d_tiles ? 0 : 2;
-        }
-        if (!err && zero_bytes > p->cap_fuse_block) {
-            hufs_free(p->d_fuse_block);
-            p->d_fuse_block = hufs_malloc(zero_bytes);
-            p->cap_fuse_block = p->d_fuse_block ? zero_bytes : 0;
-            err = p->d_fuse_block ? 0 : 2;
-        }
-        if (!err && n_tiles) {
-            err = hufs_copy_h2d(p->d_tiles, h_tiles, n_tiles * sizeof(*h_tiles), eng->stream);
-        }
-    }
-    h_first_tile[n_items] = res_tiles < 0xFFFFFFFFull ? (uint32_t)res_tiles : 0u; /* (too many: the launch keeps to the kernels without tiles) */
     if (!err) {
         err = hufs_copy_h2d(p->d_items, h_items, n_items * sizeof(*h_items), eng->stream);
-    }
-    if (!err && res_tiles && res_tiles < 0xFFFFFFFFull) {
-        err = hufs_copy_h2d(p->d_first_tile, h_first_tile, (n_items + 1) * sizeof(uint32_t), eng->stream);
     }
     if (!err) {
         err = hufs_copy_h2d(p->d_runs, h_runs, n_runs * 2 * sizeof(uint32_t), eng->stream);
@@ -1473,14 +1435,11 @@ static int dec_plan_fill(
             p->h_items = keep;
         }
     }
-    const uint32_t res_tiles_kept = h_first_tile[n_items];
-    free(h_first_tile);
     free(h_items);
     free(h_large);
     free(h_runs);
     free(h_tail);
     free(h_tiny);
-    free(h_tiles);
     if (err) {
         free(h_wide);
         return raise_hip(err);
@@ -1495,13 +1454,25 @@ static int dec_plan_fill(
     p->n_large = (uint32_t)n_large;
     p->n_runs = (uint32_t)n_runs;
     p->n_tail = tail;
-    p->n_tiles = (uint32_t)n_tiles;
-    p->n_res_tiles = res_tiles_kept;
     p->tail_stage_bytes = tail_stage + 32 < 0xFFFFFFFFu ? (uint32_t)tail_stage + 32u : 0u;
     p->tail_lanes = tail_lanes < HUFD_DEC_LANES ? (uint32_t)tail_lanes : HUFD_DEC_LANES;
     p->n_tail_narrow = narrow;
     p->n_tiny = tiny;
     p->n_deep = deep;
+    {
+        const bool packs = narrow >= HUFD_DEC_PACK_MIN_CHUNKS && p->tail_lanes + 2u <= HUFD_DEC_LANES / 2;
+        p->stats.items = n_items;
+        p->stats.thread_limit = tiny_limit;
+        p->stats.by_thread = tiny;
+        p->stats.by_blocks = n_wide + fixed_items;
+        p->stats.by_wave = eng->tables.deep_entries ? 0 : deep;
+        p->stats.by_workgroup = eng->tables.deep_entries ? deep - n_wide : 0;
+        p->stats.by_pieces = n_cut;
+        p->stats.pieces = n_chunks;
+        p->stats.end_pieces_packed = packs ? narrow : 0;
+        p->stats.end_pieces_single = tail - p->stats.end_pieces_packed;
+        p->stats.empty = n_items - tiny - deep - fixed_items - n_cut;
+    }
     return AWS_OP_SUCCESS;
 }
 
@@ -1517,12 +1488,13 @@ int aws_huffman_amd_decode_plan_new(
     eng->spare_dec = NULL;
     pthread_mutex_unlock(&eng->spare_lock);
     if (p) {
+        /* (as for an encode plan: the spare's last launch is waited for by its own event) */
         ON_DEVICE(eng->device);
-        if (hufs_device_sync()) {
+        if (p->done_event && hufs_event_sync(p->done_event)) {
+            p->unkeepable = true;
             aws_huffman_amd_decode_plan_destroy(p);
             return aws_raise_error(AWS_ERROR_UNKNOWN);
         }
-        p->one_pass_tried = 0;
     } else {
         p = calloc(1, sizeof(*p));
         if (!p) {
@@ -1549,7 +1521,7 @@ void aws_huffman_amd_decode_plan_destroy(struct aws_huffman_amd_decode_plan *p) 
     if (p) {
         struct aws_huffman_amd_engine *eng = p->engine;
         pthread_mutex_lock(&eng->spare_lock);
-        const bool keep = !eng->retiring && !eng->spare_dec && p->cap_items && p != eng->one_dec;
+        const bool keep = !eng->retiring && !eng->spare_dec && p->cap_items && p != eng->one_dec && !p->unkeepable;
         if (keep) {
             eng->spare_dec = p;
         }
@@ -1559,6 +1531,7 @@ void aws_huffman_amd_decode_plan_destroy(struct aws_huffman_amd_decode_plan *p) 
         }
         ON_DEVICE(p->engine->device);
         dec_plan_release_device(p);
+        hufs_event_destroy(p->done_event);
         hufs_free(p->d_wide_block);
         hufs_free(p->d_fixed);
         free(p->h_wide);
@@ -1624,9 +1597,6 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.dense_list = p->d_dense_list + 1;
     a.lane_count = p->d_lane_count;
     a.chunk_regular = p->d_chunk_regular;
-    a.chunk_flags = p->d_chunk_flags;
-    a.item_first_tile = p->d_first_tile;
-    a.n_res_tiles = p->n_res_tiles;
     a.tail_entry = p->d_tail_entry;
     a.chunk_entry = p->d_chunk_entry;
     a.chunk_base = p->d_chunk_base;
@@ -1637,32 +1607,20 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.states = p->d_states;
     a.results = p->d_results;
     {
-        const char *mode = getenv("AWS_HUFFMAN_AMD_DECODE");
-        /* "old-sync": the kernel dec_sync_lean replaced; "bank-sync": dec_sync_bank, the round-4 kernel with a length table
-         * per LDS bank that did not beat it, "resident-sync": dec_sync_resident, resident waves with the table once per bank,
-         * which did not either (comparison and tests); "lean-sync": the default by name */
-        a.old_sync = mode && strcmp(mode, "old-sync") == 0 ? 1u
-                     : (mode && strcmp(mode, "lean-sync") == 0 ? 2u
-                        : (mode && strcmp(mode, "bank-sync") == 0 ? 3u : (mode && strcmp(mode, "resident-sync") == 0 ? 4u : 0u)));
-        /* the chunks inside streams: sync + scan + emit (two passes over the stream) unless told otherwise.  "one-pass"
-         * puts dec_onepass in front of them (every encoded byte read once; on an MI355X it takes as long as the two
-         * passes, DESIGN.md 4 "One pass": not the default); "one-pass-fails" does the same with one tile made to give
-         * up, so that the way back to the two-pass kernels can be tested */
-        a.fuse_mode = mode && strcmp(mode, "one-pass") == 0 ? 0u : (mode && strcmp(mode, "one-pass-fails") == 0 ? 2u : 1u);
-        /* "wide-fails": dec_wide_* give every long item of a coder with long codes back to dec_deep (the way back, for tests) */
-        a.wide_fails = mode && strcmp(mode, "wide-fails") == 0 ? 1u : 0u;
-        /* "wide-fn-fails": and dec_wide_fn_*, the road for such an item by transfer functions, gives it back as well */
-        a.wide_fails = mode && strcmp(mode, "wide-fn-fails") == 0 ? 2u : a.wide_fails;
-        /* "long-way": the chunks whose walks do not fall into step through dec_sync and dec_emit (not dec_sync_few / _true) */
-        a.few_walks = mode && strcmp(mode, "long-way") == 0 ? 0u : 1u;
+        const uint32_t road = testing_decode_road();
+        a.one_chunk_a_workgroup = (road & AWS_HUFFMAN_AMD_TEST_DECODE_ONE_CHUNK_A_WORKGROUP) != 0;
+        /* dec_wide_* give every long item of a coder with long codes up: dec_wide_fn_*, the road for such an item by
+         * transfer functions, takes it -- or gives it up as well, and dec_deep takes it (the ways back) */
+        a.wide_fails = road & AWS_HUFFMAN_AMD_TEST_DECODE_WIDE_FN_FAILS ? 2u : (road & AWS_HUFFMAN_AMD_TEST_DECODE_WIDE_FAILS ? 1u : 0u);
+        /* the chunks whose walks do not fall into step through dec_sync and dec_emit (not dec_sync_few / _true) */
+        a.few_walks = road & AWS_HUFFMAN_AMD_TEST_DECODE_LONG_WAY ? 0u : 1u;
     }
-    a.tiles = p->d_tiles;
-    a.n_tiles = p->n_tiles;
-    a.fuse_block = p->d_fuse_block;
-    p->one_pass_tried = a.fuse_mode != 1 && a.old_sync != 1 && p->n_tiles && hufk_decode_one_pass_applies(&a.tables);
     a.stage_events = stage_events;
     ON_DEVICE(p->engine->device);
-    const int err = hufk_decode_launch(&a, stream ? stream : p->engine->stream);
+    int err = hufk_decode_launch(&a, stream ? stream : p->engine->stream);
+    if (!err) {
+        err = plan_mark_done(&p->done_event, stream ? stream : p->engine->stream);
+    }
     return err ? raise_hip(err) : AWS_OP_SUCCESS;
 }
 
@@ -1704,24 +1662,8 @@ int aws_huffman_amd_decode_plan_road(struct aws_huffman_amd_decode_plan *p, void
     if (detail) {
         detail[0] = detail[1] = 0;
     }
-    if (!p->one_pass_tried) {
-        return AWS_OP_SUCCESS;
-    }
-    void *st = stream ? stream : p->engine->stream;
-    uint32_t ctl[4] = {0, 0, 0, 0};
-    ON_DEVICE(p->engine->device);
-    int err = hufs_copy_d2h(ctl, p->d_fuse_block, sizeof(ctl), st);
-    if (!err) {
-        err = hufs_stream_sync(st);
-    }
-    if (err) {
-        return raise_hip(err);
-    }
-    *road = ctl[0] ? AWS_HUFFMAN_AMD_ROAD_ONE_PASS_GAVE_UP : AWS_HUFFMAN_AMD_ROAD_ONE_PASS;
-    if (detail) {
-        detail[0] = ctl[0] ? ctl[1] : 0;
-        detail[1] = ctl[2];
-    }
+    (void)p;
+    (void)stream;
     return AWS_OP_SUCCESS;
 }
 
@@ -1781,8 +1723,8 @@ int aws_huffman_amd_decode_plan_from_encode(
     if (!eng->can_decode) {
         return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION);
     }
-    if (!encoded || encoded->engine->device != eng->device) {
-        return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
+    if (!encoded || encoded->engine->device != eng->device || !encoded->launched) {
+        return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT); /* (a plan that was never launched has no records to read lengths from) */
     }
     /* Whatever the launch produced, every item must be ONE THREAD's work for the decoder (then the plan has no chunk
      * geometry, which only the host can lay out): the most bytes an item can have left is its output capacity.  The same
@@ -1798,9 +1740,9 @@ int aws_huffman_amd_decode_plan_from_encode(
     if (!thread_each) {
         return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION); /* (the caller fetches the lengths and makes the plan from records) */
     }
-    p->n_items = p->n_chunks = p->n_large = p->n_runs = p->n_tail = p->n_tiles = p->n_fixed = p->n_wide = 0;
+    p->n_items = p->n_chunks = p->n_large = p->n_runs = p->n_tail = p->n_fixed = p->n_wide = 0;
     p->n_tiny = p->n_deep = 0;
-    p->n_res_tiles = 0;
+    memset(&p->stats, 0, sizeof(p->stats));
     p->chained = false;
     ON_DEVICE(eng->device);
     int e = dec_plan_reserve(p, n_items, 0, 0, 0);
@@ -1818,6 +1760,8 @@ int aws_huffman_amd_decode_plan_from_encode(
     p->n_items = (uint32_t)n_items;
     p->n_tiny = (uint32_t)n_items;
     p->chained = true;
+    p->stats.items = p->stats.by_thread = n_items;
+    p->stats.thread_limit = longest;
     return AWS_OP_SUCCESS;
 }
 

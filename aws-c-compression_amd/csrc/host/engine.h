@@ -33,10 +33,9 @@ struct aws_huffman_amd_engine {
 
     void *d_enc_table;
     void *d_dec_lut;
-    void *d_bank_rows; /* tables.bank_rows */
     struct hufd_tables tables;
-    bool single_pass; /* enc_onepass where the coder allows it (not with AWS_HUFFMAN_AMD_ENCODE=three-kernel) */
-    bool encode_fails; /* AWS_HUFFMAN_AMD_ENCODE=one-pass-fails: a wave of enc_onepass is made to give up (tests of the way back) */
+    bool single_pass; /* enc_onepass where the coder allows it (the tests can make an engine that keeps to count / scan / pack) */
+    bool encode_fails; /* a wave of enc_onepass is made to give up (tests of the way back: aws_huffman_amd_testing_set_encode_road) */
 
     /* scratch of the host-pointer API: one item at a time, one caller at a time (`one_lock`); `users` keeps the
      * engine cache of huffman.c from retiring an engine somebody is inside of */
@@ -84,9 +83,13 @@ struct aws_huffman_amd_encode_plan {
     /* single-pass bookkeeping: what the last launch was given, and whether look-back ever timed out */
     const void *last_input;
     void *last_output;
+    void *done_event; /* recorded behind every launch on the launch's stream: what a new plan on this one's arrays waits for */
+    bool unkeepable;  /* not to be kept as the engine's spare (waiting for its last launch failed) */
+    bool launched; /* the plan's items have been launched at least once: their records exist (aws_huffman_amd_decode_plan_from_encode asks) */
     bool last_single_pass;
     bool last_timed_out; /* the last launch whose results were fetched was done over by the three-kernel road */
     bool look_back_timed_out;
+    struct aws_huffman_amd_plan_stats stats; /* how the items are taken (aws_huffman_amd_encode_plan_stats) */
     /* of the items as they were given: what aws_huffman_amd_decode_plan_from_encode asks before it chains a decode plan */
     uint64_t largest_out_cap; /* the most encoded bytes an item can leave */
     uint32_t most_overflow_bits;
@@ -112,24 +115,19 @@ struct aws_huffman_amd_decode_plan {
     uint16_t *d_fn_tab;
     uint16_t *d_cp_tab;
     uint32_t *d_chunk_fn;
-    uint32_t *d_slow_list; /* [0] how many, [1..] the chunks dec_sync_fast left to dec_sync */
+    uint32_t *d_slow_list; /* [0] how many, [1..] the chunks the regular chunks' kernels left to dec_sync */
     uint32_t *d_emit_list; /* the same for dec_emit_fast / dec_emit */
     uint32_t *d_dense_list; /* [0] how many, [1..] chunks with more symbols than one emit stage */
     uint16_t *d_lane_count;
     uint8_t *d_chunk_regular;
-    uint8_t *d_chunk_flags;     /* [2 * cap_chunks] dec_sync_resident's chunk_bad and chunk_one0 */
-    uint32_t *d_first_tile;     /* [cap_items + 1] dec_sync_resident's tiles of the items in front */
-    uint32_t n_res_tiles;
     uint32_t *d_tail_entry;
     uint32_t *d_chunk_entry;
     uint64_t *d_chunk_base;
     struct hufd_chunk_rec *d_chunk_rec;
-    uint32_t one_pass_tried; /* the last launch queued dec_onepass for the chunks inside streams */
+    struct aws_huffman_amd_plan_stats stats; /* how the items are taken (aws_huffman_amd_decode_plan_stats) */
+    void *done_event; /* recorded behind every launch on the launch's stream: what a new plan on this one's arrays waits for */
+    bool unkeepable;  /* not to be kept as the engine's spare (waiting for its last launch failed) */
     bool chained; /* made by aws_huffman_amd_decode_plan_from_encode: the items' lengths are known on the device only (h_items is not filled) */
-    struct hufd_tile_rec *d_tiles; /* [n_tiles] dec_onepass: the chunks inside streams as tiles of 64 sub-chunks, one wave each */
-    void *d_fuse_block;            /* its look-back words, zeroed by every launch; first: its ctl words */
-    uint32_t n_tiles;
-    size_t cap_tiles, cap_fuse_block;
     struct hufd_dec_item_state *d_states;
     struct hufd_dec_result *d_results;
     /* the long items of a coder with long codes: a workgroup per 32 KiB block (dec_wide_*) */

@@ -285,9 +285,7 @@ def roofline_of(label, kernels, algo_bytes, ms, traffic_table):
     }
 
 
-def load_traffic(decode_road="two-pass"):
-    # the one-pass decoder has its own committed counter passes (profiles/tools/profile_one_pass.sh)
-    name = "pmc_traffic_one_pass.json" if decode_road == "one-pass" else "pmc_traffic.json"
+def load_traffic(name="pmc_traffic.json"):
     path = os.path.join(REPO, "profiles", name)
     return json.load(open(path)) if os.path.exists(path) else None
 
@@ -307,7 +305,7 @@ def digest_of(eng, ptr, size):
 
 def rooflines(out, names_e, names_d, kernel_ms, t_enc_ms, t_dec_ms, n, e_len, algo_per_kernel, traffic_measured=True):
     # (the committed counter passes are of the 1 GiB stream: another workload's `traffic` is null, not the stream's figure)
-    traffic = load_traffic(out["config"].get("decode_road", "two-pass")) if traffic_measured else None
+    traffic = load_traffic() if traffic_measured else None
     enc = roofline_of("encode", names_e, n + e_len, t_enc_ms, traffic)
     dec = roofline_of("decode", names_d, n + e_len, t_dec_ms, traffic)
     out["roofline_encode"], out["roofline_decode"] = enc, dec
@@ -390,8 +388,6 @@ def run_stream(args, ranks, lib, eng):
     }
     algo = {names_e[0]: n + e_len if names_e[0] == "enc_onepass" else n, names_e[1]: 0, names_e[2]: 0 if names_e[0] == "enc_onepass" else n + e_len,
             "dec_sync": e_len, "dec_scan": 0, "dec_emit": e_len + n}
-    if out["config"]["decode_road"] == "one-pass":      # dec_onepass is timed in the dec_sync stage and does the whole decode
-        algo.update({"dec_sync": e_len + n, "dec_emit": 0})
     rooflines(out, names_e, names_d, kernel_ms, t_enc_ms, t_dec_ms, n, e_len, algo)
     per_rank = {"rank": ranks.rank, "seed": seed, "encoded_bytes": e_len, "sha256_encoded": enc_digest,
                 "encode_ms": round(t_enc_ms, 4), "decode_ms": round(t_dec_ms, 4)}

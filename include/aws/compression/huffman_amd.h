@@ -98,7 +98,7 @@ AWS_COMPRESSION_API
 bool aws_huffman_amd_engine_can_decode(const struct aws_huffman_amd_engine *engine);
 
 /* Whether encode plans of this engine run as one kernel that reads the symbols once (coders whose 256 symbols all have
- * codes of 4 .. 15 bits, unless AWS_HUFFMAN_AMD_ENCODE=three-kernel) or as count / scan / pack: which kernels the
+ * codes of 4 .. 15 bits) or as count / scan / pack: which kernels the
  * stage events of aws_huffman_amd_encode_plan_launch_staged bracket depends on it. */
 AWS_COMPRESSION_API
 bool aws_huffman_amd_engine_encodes_in_one_pass(const struct aws_huffman_amd_engine *engine);
@@ -198,8 +198,7 @@ int aws_huffman_amd_decode_plan_new(
     size_t item_count);
 
 /* (as aws_huffman_amd_encode_plan_reset: the plan's previous launch must have finished; a failed call leaves a plan
- * without items.  AWS_HUFFMAN_AMD_DECODE=one-pass is read when a plan is MADE, new or reset -- only then does it get the
- * tile records dec_onepass wants -- and again at the launch.) */
+ * without items) */
 AWS_COMPRESSION_API
 int aws_huffman_amd_decode_plan_reset(
     struct aws_huffman_amd_decode_plan *plan,
@@ -216,7 +215,9 @@ int aws_huffman_amd_decode_plan_reset(
  * Only for batches of short items: when every item, whatever it produced, is one thread's work for the decoder (the
  * most an item can have left is its out_capacity: up to 128 bytes each, or up to 512 / 768 when the batch has
  * thousands of them -- header fields); otherwise AWS_ERROR_UNSUPPORTED_OPERATION, nothing changed, and the caller
- * fetches the lengths (aws_huffman_amd_encode_plan_results) and resets the plan from records.  Both plans on one device.
+ * fetches the lengths (aws_huffman_amd_encode_plan_results) and resets the plan from records.  Both plans on one device;
+ * `encoded` must have been launched since it was last filled (AWS_ERROR_INVALID_ARGUMENT otherwise, nothing changed).  A HIP
+ * failure inside the call leaves `plan` without items, as a failed reset does.
  */
 AWS_COMPRESSION_API
 int aws_huffman_amd_decode_plan_from_encode(
@@ -252,18 +253,9 @@ int aws_huffman_amd_decode_plan_results(
 #define AWS_HUFFMAN_AMD_ROAD_TWO_PASS 0u
 #define AWS_HUFFMAN_AMD_ROAD_ONE_PASS 1u
 #define AWS_HUFFMAN_AMD_ROAD_ONE_PASS_GAVE_UP 2u
-/*
- * Which kernels decoded the chunks inside the streams of the plan's last launch (a chunk = 32 KiB of one item's
- * encoded bytes; the chunks streams END in always take the kernels written for them).  Diagnostics and tests: the
- * results are the same either way.  Waits for the stream.
- *   TWO_PASS           sync + scan + emit (every coder; the default)
- *   ONE_PASS           dec_onepass: every encoded byte read once, every code walked once (coders with codes of 4..12 bits;
- *                      selected by AWS_HUFFMAN_AMD_DECODE=one-pass -- on an MI355X it takes as long as the two passes)
- *   ONE_PASS_GAVE_UP   dec_onepass met a chunk it does not take (damaged, cut or non-synchronising stream, symbol-dense
- *                      data, short output) and the two-pass kernels queued behind it on the same stream did the launch
- */
-/* The same question for the encoder, of the plan's last launch whose results were fetched (no wait of its own):
- *   TWO_PASS           here: count + scan + pack, the three-kernel road (every coder; AWS_HUFFMAN_AMD_ENCODE=three-kernel)
+/* Which kernels encoded the plan's last launch whose results were fetched (diagnostics and tests: the results are the same
+ * either way; no wait of its own):
+ *   TWO_PASS           count + scan + pack, the three-kernel road (every coder)
  *   ONE_PASS           enc_onepass: every symbol read once (coders with codes of 4..15 bits for all 256 symbols; the default)
  *   ONE_PASS_GAVE_UP   a look-back wait of enc_onepass ran out (the grid was not resident as a whole) and the three-kernel
  *                      kernels queued behind it on the same stream did the launch over; the plan stays on that road
@@ -272,13 +264,56 @@ int aws_huffman_amd_decode_plan_results(
 AWS_COMPRESSION_API
 int aws_huffman_amd_encode_plan_road(const struct aws_huffman_amd_encode_plan *plan, uint32_t *road);
 
+/* The decoder has one road for the chunks inside streams since round 5 (sync + scan + emit: TWO_PASS; the one-pass decoder
+ * of rounds 3-4 measured no faster and is retired, DESIGN.md "Tried"); kept so that callers of the query still link. */
 AWS_COMPRESSION_API
 int aws_huffman_amd_decode_plan_road(
     struct aws_huffman_amd_decode_plan *plan,
     void *stream,
     uint32_t *road,
-    uint32_t *detail /* NULL, or two words of diagnostics: [0] (ONE_PASS_GAVE_UP) tile << 8 | reason code of one of the tiles
-                      * that gave up, [1] sub-chunks whose entry state was guessed wrong and that were walked a second time */);
+    uint32_t *detail /* NULL, or two words: zero */);
+
+/*
+ * How a plan's items are taken, for diagnostics and tests that have to know WHICH kernels an item went through (the
+ * results do not depend on it).  Counted when the plan is made or reset; nothing is launched, nothing waited for.
+ */
+struct aws_huffman_amd_plan_stats {
+    uint64_t items;
+    uint64_t thread_limit;    /* the longest item (symbols to encode / encoded bytes to decode) a lone thread takes in this plan */
+    uint64_t by_thread;       /* items one THREAD takes (enc_tiny / dec_tiny) */
+    uint64_t by_wave;         /* decode: items one WAVE takes (dec_deep, short codes) */
+    uint64_t by_workgroup;    /* decode: items one WORKGROUP takes (dec_deep, codes of more than 12 bits) */
+    uint64_t by_blocks;       /* decode: items taken a workgroup per block (long codes across the chip, codes of one length) */
+    uint64_t by_pieces;       /* items cut into segments of 16 Ki symbols (encode) / chunks of 32 KiB (decode) ... */
+    uint64_t pieces;          /* ... and how many of those there are */
+    uint64_t end_pieces_packed; /* decode: chunks a stream ends in that share a workgroup with others (dec_sync_pack) ... */
+    uint64_t end_pieces_single; /* ... and that have one of their own */
+    uint64_t empty;           /* items with nothing to do */
+};
+AWS_COMPRESSION_API
+int aws_huffman_amd_encode_plan_stats(const struct aws_huffman_amd_encode_plan *plan, struct aws_huffman_amd_plan_stats *stats);
+AWS_COMPRESSION_API
+int aws_huffman_amd_decode_plan_stats(const struct aws_huffman_amd_decode_plan *plan, struct aws_huffman_amd_plan_stats *stats);
+
+/* ---- testing hooks: process-wide, for the library's own tests (none selects a road that is faster or slower by
+ *      design -- they force the ways BACK the launches carry, so that those can be compared with the oracle too) ---- */
+
+/* read when an ENGINE is made */
+#define AWS_HUFFMAN_AMD_TEST_ENCODE_THREE_KERNEL 1u   /* count + scan + pack for every coder */
+#define AWS_HUFFMAN_AMD_TEST_ENCODE_ONE_PASS_FAILS 2u /* a wave of enc_onepass gives up half-way: the kernels behind it do the launch over */
+AWS_COMPRESSION_API
+void aws_huffman_amd_testing_set_encode_road(uint32_t flags /* 0: back to the default */);
+/* read at every decode LAUNCH */
+#define AWS_HUFFMAN_AMD_TEST_DECODE_LONG_WAY 1u              /* chunks whose walks never fall into step: dec_sync + dec_emit, not dec_sync_few / _true */
+#define AWS_HUFFMAN_AMD_TEST_DECODE_WIDE_FAILS 2u            /* dec_wide_* give every long item of a long-code coder up (dec_wide_fn_* take it) */
+#define AWS_HUFFMAN_AMD_TEST_DECODE_WIDE_FN_FAILS 4u         /* ... and dec_wide_fn_* as well (dec_deep takes it) */
+#define AWS_HUFFMAN_AMD_TEST_DECODE_ONE_CHUNK_A_WORKGROUP 8u /* short end-of-stream chunks do not share workgroups */
+AWS_COMPRESSION_API
+void aws_huffman_amd_testing_set_decode_road(uint32_t flags /* 0: back to the default */);
+/* read when a PLAN is made or reset: from how many items per byte of its longest item on a class of short items goes to a
+ * thread per item (0: the built-in rule, HUFD_*_TINY_PER_BYTE) */
+AWS_COMPRESSION_API
+void aws_huffman_amd_testing_set_items_per_byte(uint64_t encode, uint64_t decode);
 
 /*
  * aws_huffman_decode takes an input of any length (the reference's is a size_t, source/huffman.c:228); a device item holds

@@ -429,6 +429,10 @@ inline hipError_t hipEventCreate(hipEvent_t *e) {
     *e = reinterpret_cast<hipEvent_t>(std::malloc(8));
     return hipSuccess;
 }
+constexpr unsigned hipEventDisableTiming = 2;
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) {
+    return hipEventCreate(e);
+}
 inline hipError_t hipEventDestroy(hipEvent_t e) {
     std::free(e);
     return hipSuccess;

@@ -26,6 +26,7 @@ AWS_OP_SUCCESS = 0
 AWS_OP_ERR = -1
 AWS_ERROR_SHORT_BUFFER = 4
 AWS_ERROR_UNSUPPORTED_OPERATION = 6
+AWS_ERROR_INVALID_ARGUMENT = 34
 AWS_ERROR_COMPRESSION_UNKNOWN_SYMBOL = 0x0C00
 
 
@@ -161,6 +162,62 @@ class AmdDecodeResult(C.Structure):
     _fields_ = [("rc", C.c_int32), ("error", C.c_int32), ("produced", C.c_uint64), ("bits_consumed", C.c_uint64)]
 
 
+class PlanStats(C.Structure):
+    """struct aws_huffman_amd_plan_stats: how a plan's items are taken (which kernels an item goes through)."""
+    _fields_ = [(name, C.c_uint64) for name in (
+        "items", "thread_limit", "by_thread", "by_wave", "by_workgroup", "by_blocks", "by_pieces", "pieces",
+        "end_pieces_packed", "end_pieces_single", "empty")]
+
+    def as_dict(self):
+        return {name: int(getattr(self, name)) for name, _ in self._fields_}
+
+
+# the library's testing hooks (huffman_amd.h): the ways BACK a launch carries, by the names the scenarios use
+ENCODE_ROADS = {None: 0, "three-kernel": 1, "one-pass-fails": 2}
+DECODE_ROADS = {None: 0, "long-way": 1, "wide-fails": 2, "wide-fn-fails": 4, "lean-sync": 8}
+
+
+class encode_road:
+    """with harness.encode_road(lib, "three-kernel"): engines MADE inside keep to count / scan / pack."""
+
+    def __init__(self, lib, name):
+        self.lib, self.flags = lib, ENCODE_ROADS[name]
+
+    def __enter__(self):
+        self.lib.aws_huffman_amd_testing_set_encode_road(self.flags)
+
+    def __exit__(self, *exc):
+        self.lib.aws_huffman_amd_testing_set_encode_road(0)
+
+
+class decode_road:
+    """with harness.decode_road(lib, "long-way"): decode LAUNCHES inside take that way back ("lean-sync": short
+    end-of-stream chunks a workgroup each)."""
+
+    def __init__(self, lib, name):
+        self.lib, self.flags = lib, DECODE_ROADS[name]
+
+    def __enter__(self):
+        self.lib.aws_huffman_amd_testing_set_decode_road(self.flags)
+
+    def __exit__(self, *exc):
+        self.lib.aws_huffman_amd_testing_set_decode_road(0)
+
+
+class items_per_byte:
+    """with harness.items_per_byte(lib, encode=1): plans MADE inside give a thread to every item of a short-item class that
+    holds at least that many items per byte of its longest item (0: the built-in rule)."""
+
+    def __init__(self, lib, encode=0, decode=0):
+        self.lib, self.encode, self.decode = lib, encode, decode
+
+    def __enter__(self):
+        self.lib.aws_huffman_amd_testing_set_items_per_byte(self.encode, self.decode)
+
+    def __exit__(self, *exc):
+        self.lib.aws_huffman_amd_testing_set_items_per_byte(0, 0)
+
+
 class ShardIo(C.Structure):
     _fields_ = [("device_input", C.c_void_p), ("device_output", C.c_void_p)]
 
@@ -180,6 +237,8 @@ EXPORTED_SYMBOLS = [
     "aws_huffman_amd_decode_plan_results", "aws_huffman_amd_decode_plan_road", "aws_huffman_amd_encode_plan_road",
     "aws_huffman_amd_testing_set_decode_piece_bytes",
     "aws_huffman_amd_testing_set_wide_min_bytes",
+    "aws_huffman_amd_testing_set_encode_road", "aws_huffman_amd_testing_set_decode_road",
+    "aws_huffman_amd_testing_set_items_per_byte", "aws_huffman_amd_encode_plan_stats", "aws_huffman_amd_decode_plan_stats",
     "aws_huffman_amd_engine_device", "aws_huffman_amd_current_device", "aws_huffman_amd_encode_plan_reset",
     "aws_huffman_amd_decode_plan_reset", "aws_huffman_amd_decode_plan_from_encode",
     "aws_huffman_amd_device_count", "aws_huffman_amd_device_alloc", "aws_huffman_amd_device_free",
@@ -241,6 +300,11 @@ def load_product(path=None):
     _bind(lib, "aws_huffman_amd_encode_plan_road", C.c_int, [V, P(C.c_uint32)])
     _bind(lib, "aws_huffman_amd_testing_set_decode_piece_bytes", None, [C.c_size_t])
     _bind(lib, "aws_huffman_amd_testing_set_wide_min_bytes", None, [C.c_uint64])
+    _bind(lib, "aws_huffman_amd_testing_set_encode_road", None, [C.c_uint32])
+    _bind(lib, "aws_huffman_amd_testing_set_decode_road", None, [C.c_uint32])
+    _bind(lib, "aws_huffman_amd_testing_set_items_per_byte", None, [C.c_uint64, C.c_uint64])
+    _bind(lib, "aws_huffman_amd_encode_plan_stats", C.c_int, [V, P(PlanStats)])
+    _bind(lib, "aws_huffman_amd_decode_plan_stats", C.c_int, [V, P(PlanStats)])
     _bind(lib, "aws_huffman_amd_device_count", C.c_int, [])
     _bind(lib, "aws_huffman_amd_engine_device", C.c_int, [V])
     _bind(lib, "aws_huffman_amd_current_device", C.c_int, [])
@@ -381,12 +445,20 @@ class Engine:
         assert self.lib.aws_huffman_amd_decode_plan_launch_staged(plan, d_in, d_out, None, events) == 0
 
     def decode_road(self, plan):
-        """0: two-pass kernels only, 1: one pass (dec_onepass), 2: dec_onepass gave up and the two-pass kernels took over."""
+        """0: sync + scan + emit, the one road since round 5 (the query is kept for callers that link it)."""
         road, detail = C.c_uint32(99), (C.c_uint32 * 2)()
         assert self.lib.aws_huffman_amd_decode_plan_road(plan, None, C.byref(road), detail) == 0
-        # (tile, reason) of a tile that gave up; sub-chunks walked twice (wrong guess of the entry state)
-        self.last_road_detail = (detail[0] >> 8, detail[0] & 0xFF, detail[1])
         return road.value
+
+    def encode_stats(self, plan):
+        st = PlanStats()
+        assert self.lib.aws_huffman_amd_encode_plan_stats(plan, C.byref(st)) == 0
+        return st.as_dict()
+
+    def decode_stats(self, plan):
+        st = PlanStats()
+        assert self.lib.aws_huffman_amd_decode_plan_stats(plan, C.byref(st)) == 0
+        return st.as_dict()
 
     def decode_results(self, plan, n):
         res = (AmdDecodeResult * max(n, 1))()

@@ -97,22 +97,6 @@ def test_streams_with_two_last_chunks(world):
     pc.streams_with_two_last_chunks(world)
 
 
-def test_resident_sync_kernel_on_small_streams(world):
-    """AWS_HUFFMAN_AMD_DECODE=resident-sync: dec_sync_resident (resident waves, the walk table once per LDS bank, tiles
-    of 64 sub-chunks; round 4, measured at half dec_sync_lean's speed and kept behind the switch), made to take every
-    launch that has a chunk inside a stream (by default: launches of at least 2048 tiles = 16 MiB of stream)."""
-    os.environ["AWS_HUFFMAN_AMD_RESIDENT_MIN_TILES"] = "1"
-    os.environ["AWS_HUFFMAN_AMD_DECODE"] = "resident-sync"
-    try:
-        pc.one_shot_roundtrips(world, sizes=[40000, 200001], seed=23)  # (the GPU suite: also more chunks than one scan run holds)
-        pc.cut_streams(world, chunks=(1, 2), step=31, n=120_000)
-        pc.garbage_decode(world, rounds=30)
-        pc.unknown_symbols(world)
-        pc.batched_device_api(world)
-    finally:
-        del os.environ["AWS_HUFFMAN_AMD_RESIDENT_MIN_TILES"]
-        del os.environ["AWS_HUFFMAN_AMD_DECODE"]
-
 
 def test_survey_records(world):
     pc.survey_records_on_product(world)
@@ -189,7 +173,7 @@ def test_long_inputs_in_pieces(world):
 
 
 def test_decode_roads(world):
-    """dec_onepass for the chunks inside streams, the two-pass kernels when told so or when it gives up."""
+    """Plans of several streams, one damaged or short of room."""
     pc.decode_roads(world, sizes=(40_000, 90_000, 160_000))
 
 
@@ -200,71 +184,18 @@ def test_large_items_take_the_workgroup_scan(world):
 
 def test_three_kernel_encoder(oracle):
     """Coders the one-pass encoder takes (every symbol coded, codes of 4..15 bits -- the test coder) also have the
-    count / scan / pack road (AWS_HUFFMAN_AMD_ENCODE=three-kernel): it is what the library falls back to when a
+    count / scan / pack road (aws_huffman_amd_testing_set_encode_road): it is what the library falls back to when a
     look-back wait runs out, and what every other coder takes.  Same scenarios."""
-    os.environ["AWS_HUFFMAN_AMD_ENCODE"] = "three-kernel"
-    try:
-        product = harness.Codec(harness.load_product(EMU_SO), "aws_")
+    product = harness.Codec(harness.load_product(EMU_SO), "aws_")
+    with harness.encode_road(product.lib, "three-kernel"):
         w = pc.World(oracle, product)  # fresh coder objects: fresh engines that read the switch
         pc.reference_unit_tests(w.product, w.pcoder)
         pc.one_shot_roundtrips(w, sizes=[1, 17, 4096, 16384, 16385, 40000])
         pc.streaming_encode(w, sizes=[40, 33000])
         pc.unknown_symbols(w)
         pc.batched_device_api(w)
-    finally:
-        del os.environ["AWS_HUFFMAN_AMD_ENCODE"]
 
 
-def test_sync_kernel_with_a_table_per_bank(world):
-    """AWS_HUFFMAN_AMD_DECODE=bank-sync: dec_sync_bank (a length table per LDS bank, four chunks a workgroup; round 4,
-    measured slower than dec_sync_lean on the MI355X and kept behind the switch).  Which kernels a plain 100 KB decode
-    call launches in the emulator build (HIP_EMU_TRACE): by default dec_sync_lean, with the switch dec_sync_bank for the
-    chunks inside the stream and the one it ends in; and the scenarios with it."""
-    code = (
-        "import sys; sys.path.insert(0, %r)\n"
-        "import numpy as np, harness\n"
-        "o = harness.oracle_codec(); p = harness.Codec(harness.load_product(%r), 'aws_')\n"
-        "t = harness.load_table()\n"
-        "data = np.random.default_rng(3).integers(0, 256, 100000, dtype=np.uint8)\n"
-        "enc = o.encode_all(o.lib.oracle_table_coder_new(*t), data)\n"
-        "r, back = p.decode_all(p.lib.aws_huffman_amd_table_coder_new(*t), enc, data.size)\n"
-        "assert r.rc == 0 and np.array_equal(back, data)\n" % (os.path.join(harness.REPO, "tests"), EMU_SO))
-
-    def launched_with(mode):
-        env = dict(os.environ, HIP_EMU_TRACE="1")
-        env.pop("AWS_HUFFMAN_AMD_DECODE", None)
-        if mode:
-            env["AWS_HUFFMAN_AMD_DECODE"] = mode
-        done = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True)
-        assert done.returncode == 0, done.stderr[-3000:]
-        return [ln.split("launch ", 1)[1] for ln in done.stderr.splitlines() if ln.startswith("hip_emu launch ")]
-
-    plain = launched_with(None)
-    assert any("dec_sync_lean_kernel" in k for k in plain) and not any("dec_sync_bank_kernel" in k for k in plain), plain
-    bank = launched_with("bank-sync")
-    assert any("dec_sync_bank_kernel<" in k and "true" in k for k in bank), bank
-    assert any("dec_sync_bank_kernel<" in k and "false" in k for k in bank), bank
-    assert not any("dec_sync_lean_kernel" in k or "dec_sync_fast_kernel" in k for k in bank), bank
-    os.environ["AWS_HUFFMAN_AMD_DECODE"] = "bank-sync"
-    try:
-        pc.one_shot_roundtrips(world, sizes=[40000, 200001])
-        pc.cut_streams(world, chunks=(1, 2), step=31, n=120_000)
-        pc.garbage_decode(world, rounds=30)
-        pc.batched_device_api(world)
-    finally:
-        del os.environ["AWS_HUFFMAN_AMD_DECODE"]
-
-
-def test_decode_with_the_first_sync_kernel(world):
-    """AWS_HUFFMAN_AMD_DECODE=old-sync: dec_sync_fast for every chunk (the switch is read per launch)."""
-    for mode in ("old-sync",):
-        os.environ["AWS_HUFFMAN_AMD_DECODE"] = mode
-        try:
-            pc.one_shot_roundtrips(world, sizes=[40000, 200001])
-            pc.cut_streams(world, chunks=(1, 2), step=31, n=120_000)
-            pc.garbage_decode(world, rounds=30)
-        finally:
-            del os.environ["AWS_HUFFMAN_AMD_DECODE"]
 
 
 def test_one_pass_encoder_across_rounds(world):

@@ -120,22 +120,6 @@ def test_streams_with_two_last_chunks(world):
     pc.streams_with_two_last_chunks(world)
 
 
-def test_resident_sync_kernel_on_small_streams(world):
-    """AWS_HUFFMAN_AMD_DECODE=resident-sync: dec_sync_resident (resident waves, the walk table once per LDS bank, tiles
-    of 64 sub-chunks; round 4, measured at half dec_sync_lean's speed and kept behind the switch), made to take every
-    launch that has a chunk inside a stream (by default: launches of at least 2048 tiles = 16 MiB of stream)."""
-    os.environ["AWS_HUFFMAN_AMD_RESIDENT_MIN_TILES"] = "1"
-    os.environ["AWS_HUFFMAN_AMD_DECODE"] = "resident-sync"
-    try:
-        pc.one_shot_roundtrips(world, sizes=[40000, 200001, 16384 * 66 + 3], seed=23)
-        pc.cut_streams(world, chunks=(1, 2, 5), step=31, n=250_000)
-        pc.garbage_decode(world, rounds=40)
-        pc.unknown_symbols(world)
-        pc.batched_device_api(world)
-    finally:
-        del os.environ["AWS_HUFFMAN_AMD_RESIDENT_MIN_TILES"]
-        del os.environ["AWS_HUFFMAN_AMD_DECODE"]
-
 
 def test_survey_records(world):
     pc.survey_records_on_product(world, names=("G4K", "G16K", "G16KP", "G1M"))
@@ -253,21 +237,6 @@ def test_config2_config3_one_gib_stream(world, engine):
     assert digest(d_back, n) == rec["sha256_input"]
     assert np.all(engine.download(d_enc, 64, offset=e) == 0x5A)  # nothing past the stream
     assert np.all(engine.download(d_back, 64, offset=n) == 0x5A)
-    # the same stream in one pass (dec_onepass), and through the two-pass kernels after dec_onepass gave up half-way
-    for mode, road in (("one-pass", pc.ROAD_ONE_PASS), ("one-pass-fails", pc.ROAD_GAVE_UP)):
-        engine.fill(d_back, 0x5A, n + 64)
-        os.environ["AWS_HUFFMAN_AMD_DECODE"] = mode
-        try:
-            # (the switch is read when a plan is made -- only then does it get dec_onepass's tile records -- and at the launch)
-            engine.lib.aws_huffman_amd_decode_plan_destroy(dplan)
-            dplan = engine.decode_plan([dict(in_offset=0, in_len=e, out_offset=0, out_capacity=n)])
-            engine.decode_launch(dplan, d_enc, d_back)
-        finally:
-            del os.environ["AWS_HUFFMAN_AMD_DECODE"]
-        (rc, err, symbols, bits), = engine.decode_results(dplan, 1)
-        assert (rc, err, symbols) == (0, 0, n) and engine.decode_road(dplan) == road, mode
-        assert digest(d_back, n) == rec["sha256_input"], mode
-        assert np.all(engine.download(d_back, 64, offset=n) == 0x5A)
     engine.lib.aws_huffman_amd_encode_plan_destroy(plan)
     engine.lib.aws_huffman_amd_decode_plan_destroy(dplan)
     for p in (d_in, d_enc, d_back):
@@ -336,12 +305,12 @@ def test_config4_batch_of_16k_buffers(world, engine):
 
 
 def test_three_kernel_encoder(oracle):
-    """The count / scan / pack road (AWS_HUFFMAN_AMD_ENCODE=three-kernel) on the GPU: what every coder outside the
+    """The count / scan / pack road (aws_huffman_amd_testing_set_encode_road) on the GPU: what every coder outside the
     one-pass kernel's range takes, and what is queued behind every one-pass launch in case a look-back wait runs out.
     Same scenarios as the default road, and the 1 GiB stream's digest."""
-    os.environ["AWS_HUFFMAN_AMD_ENCODE"] = "three-kernel"
-    try:
-        w = pc.World(oracle, harness.Codec(harness.load_product(), "aws_"))
+    lib = harness.load_product()
+    with harness.encode_road(lib, "three-kernel"):
+        w = pc.World(oracle, harness.Codec(lib, "aws_"))
         pc.one_shot_roundtrips(w, sizes=[1, 17, 16384, 16385, 40000, 3 * 1024 * 1024 + 5])
         pc.streaming_encode(w, sizes=[40, 33000])
         pc.unknown_symbols(w)
@@ -362,8 +331,6 @@ def test_three_kernel_encoder(oracle):
             h.update(eng.download(d_enc, min(256 << 20, e - off), offset=off).tobytes())
         assert h.hexdigest() == rec["sha256_encoded"]
         eng.close()
-    finally:
-        del os.environ["AWS_HUFFMAN_AMD_ENCODE"]
 
 
 def test_encode_roads(world):
@@ -377,12 +344,10 @@ def test_encode_roads(world):
 def test_one_gib_stream_when_the_one_pass_encoder_gives_up(oracle):
     """The 1 GiB stream with a wave of enc_onepass made to give up half-way: the three-kernel road behind it on the
     stream must leave the pinned stream."""
-    os.environ["AWS_HUFFMAN_AMD_ENCODE"] = "one-pass-fails"
-    try:
-        w = pc.World(oracle, harness.Codec(harness.load_product(), "aws_"))
+    lib = harness.load_product()
+    with harness.encode_road(lib, "one-pass-fails"):
+        w = pc.World(oracle, harness.Codec(lib, "aws_"))
         eng = harness.Engine(w.product.lib, w.pcoder)
-    finally:
-        del os.environ["AWS_HUFFMAN_AMD_ENCODE"]
     rec = PROBE["streams"]["G1G"]
     n, e = rec["len"], rec["encoded_len"]
     d_in, d_enc = eng.alloc(n), eng.alloc(e + 64)
@@ -400,29 +365,6 @@ def test_one_gib_stream_when_the_one_pass_encoder_gives_up(oracle):
     eng.close()
 
 
-def test_decode_with_the_first_sync_kernel(world, engine):
-    """AWS_HUFFMAN_AMD_DECODE=old-sync: dec_sync_fast for every chunk instead of dec_sync_lean (kept for coders and
-    comparisons; the end-of-stream chunks of other launches take it where dec_sync_lean has no build)."""
-    os.environ["AWS_HUFFMAN_AMD_DECODE"] = "old-sync"
-    try:
-        pc.one_shot_roundtrips(world, sizes=[40000, 200001, 3 * 1024 * 1024 + 5])
-        pc.cut_streams(world, chunks=(1, 2), step=31)
-        pc.garbage_decode(world)
-    finally:
-        del os.environ["AWS_HUFFMAN_AMD_DECODE"]
-
-
-def test_decode_with_the_sync_kernel_with_a_table_per_bank(world, engine):
-    """AWS_HUFFMAN_AMD_DECODE=bank-sync: dec_sync_bank (a length table per LDS bank, four chunks a workgroup; round 4,
-    measured slower than dec_sync_lean and kept behind the switch)."""
-    os.environ["AWS_HUFFMAN_AMD_DECODE"] = "bank-sync"
-    try:
-        pc.one_shot_roundtrips(world, sizes=[40000, 200001, 3 * 1024 * 1024 + 5])
-        pc.cut_streams(world, chunks=(1, 2), step=31)
-        pc.garbage_decode(world)
-        pc.batched_device_api(world, engine=engine)
-    finally:
-        del os.environ["AWS_HUFFMAN_AMD_DECODE"]
 
 
 def test_plan_launches_in_a_hip_graph():
@@ -446,7 +388,5 @@ def test_two_one_pass_encoders_on_one_device():
     import sys
 
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tools", "contention.py")
-    # (with the one-pass decoder switched on the tool does the same with decode launches afterwards)
-    env = dict(os.environ, AWS_HUFFMAN_AMD_DECODE="one-pass")
-    out = subprocess.run([sys.executable, tool, str(128 << 20), "8"], capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([sys.executable, tool, str(128 << 20), "8"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.count("wrong outputs [0, 0]") == 2, out.stdout + out.stderr

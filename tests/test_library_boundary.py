@@ -172,24 +172,39 @@ def test_fails_loudly_without_a_gpu(product_lib):
 
 @pytest.fixture(scope="module")
 def kernel_listing(tmp_path_factory):
-    """The kernels compiled to assembly for gfx950 (the code-object metadata is what the two tests below read)."""
+    """The kernels compiled to assembly for gfx950 (the code-object metadata is what the tests below read): every
+    translation unit of csrc/hip, listings and sources concatenated."""
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
-    src = os.path.join(harness.REPO, "aws-c-compression_amd", "csrc", "hip", "huffman_kernels.hip")
-    asm = tmp_path_factory.mktemp("asm") / "kernels.s"
-    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
-                           "-I" + os.path.join(harness.REPO, "include"), "-I" + os.path.join(harness.REPO, "include", "compat"),
-                           src, "-o", str(asm)], stderr=subprocess.DEVNULL)
-    return src, open(asm).read()
+    hip_dir = os.path.join(harness.REPO, "aws-c-compression_amd", "csrc", "hip")
+    out_dir = tmp_path_factory.mktemp("asm")
+    sources, jobs = [], []
+    for name in sorted(os.listdir(hip_dir)):
+        if name.endswith(".hip") and name != "hip_shim.hip":
+            src = os.path.join(hip_dir, name)
+            asm = out_dir / (name + ".s")
+            jobs.append((asm, subprocess.Popen(
+                [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+                 "-I" + os.path.join(harness.REPO, "include"), "-I" + os.path.join(harness.REPO, "include", "compat"),
+                 src, "-o", str(asm)], stderr=subprocess.DEVNULL)))
+            sources.append(open(src).read())
+    for name in sorted(os.listdir(hip_dir)):
+        if name.endswith(".hpp"):
+            sources.append(open(os.path.join(hip_dir, name)).read())
+    listing = ""
+    for asm, job in jobs:
+        assert job.wait() == 0, asm
+        listing += open(asm).read()
+    return "\n".join(sources), listing
 
 
 def test_onepass_kernels_scalar_registers(kernel_listing):
-    """The grids of enc_onepass and dec_onepass are sized to be resident as a whole: by the occupancy query AND by the
-    scalar-register rule the query does not know (persistent_grid, kOnepassSgprs in csrc/hip/huffman_kernels.hip).  The
-    constant must cover what the build really uses: `.sgpr_count` of every instantiation."""
+    """The grid of enc_onepass is sized to be resident as a whole: by the occupancy query AND by the scalar-register rule
+    the query does not know (persistent_grid, kOnepassSgprs in csrc/hip).  The constant must cover what the build really
+    uses: `.sgpr_count` of every instantiation."""
     src, listing = kernel_listing
-    declared = int(re.search(r"constexpr uint32_t kOnepassSgprs = (\d+);", open(src).read()).group(1))
+    declared = int(re.search(r"constexpr uint32_t kOnepassSgprs = (\d+);", src).group(1))
     counts = {}
     name = None
     for line in listing.splitlines():
@@ -197,10 +212,20 @@ def test_onepass_kernels_scalar_registers(kernel_listing):
         if m:
             name = m.group(1)
         m = re.match(r"\s+\.sgpr_count:\s+(\d+)", line)
-        if m and name and ("enc_onepass_kernel" in name or "dec_onepass_kernel" in name):
+        if m and name and "enc_onepass_kernel" in name:
             counts[name] = int(m.group(1))
-    assert len(counts) >= 6, counts
+    assert len(counts) >= 2, counts
     assert max(counts.values()) <= declared, (declared, counts)
+
+
+def test_kernel_census(kernel_listing):
+    """What a maintainer links: at most 90 kernels (round 4 shipped 130, 51 of them instantiations of experiments that had
+    measured slower and of builds no coder selects)."""
+    _, listing = kernel_listing
+    names = set(re.findall(r"\.name:\s+(\S+)", listing))
+    names = {n for n in names if not n.endswith(".kd")}
+    assert 40 <= len(names) <= 90, len(names)
+    assert not [n for n in names if "dec_onepass" in n or "dec_sync_bank" in n or "dec_sync_resident" in n or "dec_sync_fast" in n]
 
 
 def test_no_kernel_spills_vector_registers(kernel_listing):
@@ -209,6 +234,6 @@ def test_no_kernel_spills_vector_registers(kernel_listing):
     look-back kernel waits for every poll in flight.  Scalar registers parked in vector lanes are not memory."""
     _, listing = kernel_listing
     rows = re.findall(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", listing, re.S)
-    assert len(rows) >= 100
+    assert len(rows) >= 60
     bad = [(n, int(scratch), int(spills)) for n, scratch, spills in rows if int(scratch) or int(spills)]
     assert not bad, bad
