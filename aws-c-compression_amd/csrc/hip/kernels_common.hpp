@@ -1,0 +1,310 @@
+/*
+ * HIP kernels of the Huffman hot path for gfx950 (MI355X, CDNA4, wave64): what every translation unit of csrc/hip
+ * starts from -- types, the diagnostic stamps, wave and block primitives, input helpers, the LDS bit image.
+ *
+ * The kernels by path: encode_kernels.hip (count / scan / pack, one pass, short items, one-block calls),
+ * decode_sync_kernels.hip (transfer functions of sub-chunks: the long way, regular chunks, packed end-of-stream chunks,
+ * second chances, the end of a stream), decode_items_kernels.hip (items without chunks: a thread, a wave, a workgroup,
+ * blocks across the chip, long codes, codes of one length, one-block calls), decode_emit_kernels.hip (symbols out),
+ * decode_launch.hip (entry scan, plans on the device, the launch sequence).
+ *
+ * Encode  (replaces the per-symbol loop of reference source/huffman.c:161-173 and
+ *          the bit packer :59-105):
+ *   enc_count   per segment: sum of code lengths, first symbol without a code
+ *   enc_scan_*  per item: exclusive bit offset of every segment, outcome of the call
+ *               (closed form of the reference's stop conditions, DESIGN.md "Encode")
+ *   enc_pack    per segment: codes -> bitstream image in LDS -> aligned 16-byte stores
+ *
+ * Decode  (replaces the window/walk loop of reference source/huffman.c:230-281 and
+ *          the refill :196-211):
+ *   dec_sync    per sub-chunk: transfer function entry state -> (exit state, symbols),
+ *               folded per chunk
+ *   dec_scan_*  per item: true entry state and output offset of every chunk
+ *   dec_emit    per chunk: true entry state of every lane, table walk, symbols staged
+ *               in LDS, aligned 16-byte stores
+ *
+ * No MFMA anywhere: this is byte/bit work bound by HBM and LDS, not a contraction.
+ * All LDS lives in the dynamic region with 16-byte carves (guide: Guideline 17).
+ */
+#ifndef HUFFMAN_AMD_KERNELS_COMMON_HPP
+#define HUFFMAN_AMD_KERNELS_COMMON_HPP
+#include <hip/hip_runtime.h>
+#include <numeric>
+#include <type_traits>
+
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "device_types.h"
+#include "huffman_kernels.h"
+
+namespace {
+
+
+typedef unsigned int u32;
+typedef uint64_t u64;
+typedef unsigned short u16;
+typedef unsigned char u8;
+
+constexpr u32 kWave = 64;
+constexpr u64 kNoBit = ~0ull;
+
+HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, dyn_lds)
+
+/*
+ * Diagnostic build only (-DHUFD_STAMPS, profiles/tools/stamps.py): wave 0 of every
+ * workgroup adds the shader clock at phase boundaries into a table of its own; differences
+ * of the sums / workgroups = average phase length.  Never compiled into the product.
+ */
+#ifdef HUFD_STAMPS
+/* one private row of 8 clocks per workgroup and kernel: plain stores, no contention */
+__device__ unsigned long long *hufd_stamp_rows; /* [3][HUFD_STAMP_MAX_WG][8], set by hufk_stamps_attach */
+#define HUFD_STAMP_MAX_WG 131072u
+#define HUFD_STAMP(kernel, phase)                                                                                      \
+    do {                                                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x < HUFD_STAMP_MAX_WG) {                                                      \
+            hufd_stamp_rows[((u64)(kernel)*HUFD_STAMP_MAX_WG + blockIdx.x) * 8 + (phase)] =                            \
+                (unsigned long long)clock64();                                                                         \
+        }                                                                                                              \
+    } while (0)
+/* the same, summed over the turns of a persistent workgroup: kept in LDS (a stamp must not add a memory round trip to
+ * the phase it measures), written out once by HUFD_STAMP_FLUSH */
+#define HUFD_STAMP_DECL __shared__ unsigned long long hufd_stamp_acc[8];
+#define HUFD_STAMP_ZERO                                                                                                \
+    do {                                                                                                               \
+        if (threadIdx.x < 8) {                                                                                         \
+            hufd_stamp_acc[threadIdx.x] = 0;                                                                           \
+        }                                                                                                              \
+    } while (0)
+#ifdef HUFD_STAMPS_WHY /* slots 3 .. 5 count events instead of clocks */
+#define HUFD_STAMP_TIMED(phase) ((phase) < 3 || (phase) > 5)
+#else
+#define HUFD_STAMP_TIMED(phase) true
+#endif
+#define HUFD_STAMP_ADD(kernel, phase)                                                                                  \
+    do {                                                                                                               \
+        if (threadIdx.x == 0 && HUFD_STAMP_TIMED(phase)) {                                                             \
+            hufd_stamp_acc[phase] += (unsigned long long)clock64();                                                    \
+        }                                                                                                              \
+    } while (0)
+#define HUFD_STAMP_COUNT(phase, n)                                                                                     \
+    do {                                                                                                               \
+        if (threadIdx.x == 0) {                                                                                        \
+            hufd_stamp_acc[phase] += (unsigned long long)(n);                                                          \
+        }                                                                                                              \
+    } while (0)
+#define HUFD_STAMP_FLUSH(kernel)                                                                                       \
+    do {                                                                                                               \
+        if (threadIdx.x < 8 && blockIdx.x < HUFD_STAMP_MAX_WG) {                                                       \
+            hufd_stamp_rows[((u64)(kernel)*HUFD_STAMP_MAX_WG + blockIdx.x) * 8 + threadIdx.x] =                        \
+                hufd_stamp_acc[threadIdx.x];                                                                           \
+        }                                                                                                              \
+    } while (0)
+#else
+#define HUFD_STAMP(kernel, phase)
+#define HUFD_STAMP_ADD(kernel, phase)
+#define HUFD_STAMP_DECL
+#define HUFD_STAMP_ZERO
+#define HUFD_STAMP_COUNT(phase, n)
+#define HUFD_STAMP_FLUSH(kernel)
+#endif
+
+/* 16 / 4 bytes at any address (one load: the memory system takes any alignment) */
+struct __attribute__((packed, aligned(1))) unaligned_uint4 {
+    u32 x, y, z, w;
+};
+struct __attribute__((packed, aligned(1))) unaligned_u32 {
+    u32 x;
+};
+
+__device__ __forceinline__ u32 round16(u32 x) {
+    return (x + 15u) & ~15u;
+}
+
+/* ------------------------------------------------------------------ wave / block primitives */
+
+__device__ __forceinline__ u32 wave_inclusive_sum(u32 v, u32 lane) {
+#pragma unroll
+    for (u32 d = 1; d < kWave; d <<= 1) {
+        const u32 up = __shfl_up(v, d);
+        if (lane >= d) {
+            v += up;
+        }
+    }
+    return v;
+}
+
+/* the same sum with data-parallel-primitive moves instead of LDS permutes: six adds, no LDS traffic */
+__device__ __forceinline__ u32 wave_inclusive_sum_dpp(u32 v, u32 lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)lane;
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); /* row_shr:1 */
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false); /* row_shr:2 */
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false); /* row_shr:4 */
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false); /* row_shr:8 */
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); /* row_bcast:15 into rows 1 and 3 */
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); /* row_bcast:31 into rows 2 and 3 */
+    return v;
+#else
+    return wave_inclusive_sum(v, lane);
+#endif
+}
+
+__device__ __forceinline__ u32 wave_min(u32 v) {
+#pragma unroll
+    for (u32 d = kWave / 2; d > 0; d >>= 1) {
+        const u32 o = __shfl_xor(v, d);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ u32 wave_sum(u32 v) {
+#pragma unroll
+    for (u32 d = kWave / 2; d > 0; d >>= 1) {
+        v += __shfl_xor(v, d);
+    }
+    return v;
+}
+
+/* Exclusive sum over the workgroup; `slots` is LDS scratch of THREADS/64 words. */
+template <u32 THREADS>
+__device__ __forceinline__ u32 block_exclusive_sum(u32 v, u32 *slots, u32 &total) {
+    constexpr u32 kWaves = THREADS / kWave;
+    const u32 lane = threadIdx.x & (kWave - 1);
+    const u32 wave = threadIdx.x / kWave;
+    const u32 incl = wave_inclusive_sum(v, lane);
+    if (lane == kWave - 1) {
+        slots[wave] = incl;
+    }
+    __syncthreads();
+    u32 before = 0, all = 0;
+#pragma unroll
+    for (u32 w = 0; w < kWaves; ++w) {
+        const u32 t = slots[w];
+        before += w < wave ? t : 0;
+        all += t;
+    }
+    __syncthreads();
+    total = all;
+    return before + incl - v;
+}
+
+/* ------------------------------------------------------------------ input helpers */
+
+/* 16 input symbols of one lane: an aligned 16-byte load when possible. */
+__device__ __forceinline__ void load_group(const u8 *src, u32 valid, bool aligned, u32 (&w)[4]) {
+    if (valid == 16 && aligned) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(src);
+        w[0] = v.x;
+        w[1] = v.y;
+        w[2] = v.z;
+        w[3] = v.w;
+        return;
+    }
+    w[0] = w[1] = w[2] = w[3] = 0;
+    for (u32 j = 0; j < valid; ++j) {
+        w[j >> 2] |= (u32)src[j] << (8 * (j & 3));
+    }
+}
+
+__device__ __forceinline__ u32 group_byte(const u32 (&w)[4], u32 j) {
+    return (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+}
+
+/* big-endian 32-bit word `index` of a byte range, zero past `valid_bytes` */
+__device__ __forceinline__ u32 load_be32(const u8 *base, u64 index, u64 valid_bytes, bool aligned) {
+    const u64 at = index * 4;
+    if (aligned && at + 4 <= valid_bytes) {
+        return __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(base + at)->x); /* (whole words: one load, at any address) */
+    }
+    u32 v = 0;
+#pragma unroll
+    for (u32 b = 0; b < 4; ++b) {
+        if (at + b < valid_bytes) {
+            v |= (u32)base[at + b] << (24 - 8 * b);
+        }
+    }
+    return v;
+}
+
+/* the first `n_words` big-endian words of `bytes` bytes at `src` (zeros behind them) into `dst`: 16 bytes a load where
+ * 16 lie inside (a thread that reads a stream's end on its own pays per request: 9 instead of 34 for 135 bytes) */
+__device__ __forceinline__ void load_be32_run(u32 *dst, const u8 *src, u64 bytes, u32 n_words) {
+    u32 k = 0;
+    for (; k + 4 <= n_words && (u64)k * 4 + 16 <= bytes; k += 4) {
+        const unaligned_uint4 v = *reinterpret_cast<const unaligned_uint4 *>(src + k * 4);
+        dst[k + 0] = __builtin_bswap32(v.x);
+        dst[k + 1] = __builtin_bswap32(v.y);
+        dst[k + 2] = __builtin_bswap32(v.z);
+        dst[k + 3] = __builtin_bswap32(v.w);
+    }
+    for (; k < n_words; ++k) {
+        dst[k] = (u64)k * 4 < bytes ? load_be32(src, k, bytes, true) : 0u;
+    }
+}
+
+/* ------------------------------------------------------------------ LDS bit image */
+
+/* OR the low `nbits` (1..32) bits of `pattern` into the MSB-first bit image at bit `q`. */
+__device__ __forceinline__ void image_or_bits(u32 *img, u32 q, u32 pattern, u32 nbits) {
+    const u64 left = ((u64)pattern << (64 - nbits)) >> (q & 31);
+    const u32 hi = (u32)(left >> 32), lo = (u32)left;
+    atomicOr(&img[q >> 5], hi);
+    if (lo) {
+        atomicOr(&img[(q >> 5) + 1], lo);
+    }
+}
+
+/*
+ * Copies image bytes [lo, hi) to global memory.  Image byte b lives in bits
+ * 31-8*(b&3).. of word b>>2 and belongs at gbase + b, where gbase is 16-byte
+ * aligned, so whole 16-byte rows go out as aligned dwordx4 stores.
+ */
+template <u32 THREADS>
+__device__ __forceinline__ void image_store(const u32 *img, u8 *gbase, u32 lo, u32 hi) {
+    if (hi <= lo) {
+        return;
+    }
+    const u32 row_lo = (lo + 15) >> 4, row_hi = hi >> 4;
+    if (row_lo <= row_hi) {
+        for (u32 b = lo + threadIdx.x; b < row_lo * 16; b += THREADS) {
+            gbase[b] = (u8)(img[b >> 2] >> (24 - 8 * (b & 3)));
+        }
+        /* four rows per thread in flight: the LDS reads are issued together, then the stores */
+        for (u32 r = row_lo + threadIdx.x; r < row_hi; r += 4 * THREADS) {
+            uint4 v[4];
+#pragma unroll
+            for (u32 u = 0; u < 4; ++u) {
+                const u32 ru = r + u * THREADS;
+                v[u] = *reinterpret_cast<const uint4 *>(&img[(ru < row_hi ? ru : r) * 4]);
+            }
+#pragma unroll
+            for (u32 u = 0; u < 4; ++u) {
+                const u32 ru = r + u * THREADS;
+                if (ru < row_hi) {
+                    uint4 o;
+                    o.x = __builtin_bswap32(v[u].x);
+                    o.y = __builtin_bswap32(v[u].y);
+                    o.z = __builtin_bswap32(v[u].z);
+                    o.w = __builtin_bswap32(v[u].w);
+                    *reinterpret_cast<uint4 *>(gbase + (u64)ru * 16) = o;
+                }
+            }
+        }
+        for (u32 b = row_hi * 16 + threadIdx.x; b < hi; b += THREADS) {
+            gbase[b] = (u8)(img[b >> 2] >> (24 - 8 * (b & 3)));
+        }
+    } else {
+        for (u32 b = lo + threadIdx.x; b < hi; b += THREADS) {
+            gbase[b] = (u8)(img[b >> 2] >> (24 - 8 * (b & 3)));
+        }
+    }
+}
+
+
+} /* namespace */
+
+#endif /* HUFFMAN_AMD_KERNELS_COMMON_HPP */

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Static instruction census of one kernel in a hipcc -S listing (gfx950).
 
-  hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -S -Iinclude -Iinclude/compat \
-        aws-c-compression_amd/csrc/hip/huffman_kernels.hip -o /tmp/k.s
+  for f in aws-c-compression_amd/csrc/hip/*_kernels.hip aws-c-compression_amd/csrc/hip/decode_launch.hip; do
+    hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -S -Iinclude -Iinclude/compat $f -o /tmp/$(basename $f).s
+  done; cat /tmp/*.hip.s > /tmp/k.s
   python profiles/tools/isa_count.py /tmp/k.s enc_pack_wave_kernelILj4 [--blocks]
 
 Prints the number of vector-ALU, scalar, LDS and vector-memory instructions of the kernel

@@ -1113,10 +1113,11 @@ def batched_device_api(w, n_items=9, seed=18, item_len=16384, engine=None):
         eng.close()
 
 
-def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False, max_len=560, edge_lens=True):
+def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False, max_len=560, edge_lens=True, thread_limit=None):
     """Items either side of HUFD_ENC_TINY_BYTES (512 symbols; one thread each below it), with every kind
     of stop: roomy, exact, one byte short, cut anywhere, no room at all, carried overflow bits that fit,
-    fill the output exactly or do not fit, symbols without a code."""
+    fill the output exactly or do not fit, symbols without a code.  thread_limit: the longest item the plan must give a
+    thread of its own (aws_huffman_amd_encode_plan_stats) -- the road is asserted, not assumed."""
     rng = np.random.default_rng(seed)
     own = engine is None or holes
     eng = harness.Engine(w.product.lib, w.pcoder_holes if holes else w.pcoder) if own else engine
@@ -1164,6 +1165,12 @@ def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False, max_le
     eng.upload(d_in, host_in)
     eng.fill(d_out, SENTINEL, out_total)
     plan = eng.encode_plan(items)
+    stats = eng.encode_stats(plan)
+    assert stats["items"] == len(items) and stats["by_thread"] + stats["by_pieces"] + stats["empty"] == len(items), stats
+    if thread_limit is not None:
+        by_thread = sum(1 for it in items if it["in_len"] <= thread_limit and (it["in_len"] or it["overflow_in"][1]))
+        assert stats["thread_limit"] == thread_limit and stats["by_thread"] == by_thread, (stats, by_thread)
+        assert max(it["in_len"] for it in items if it["in_len"] <= thread_limit) > thread_limit * 3 // 4  # (such items exist)
     eng.encode_launch(plan, d_in, d_out)
     res = eng.encode_results(plan, len(items))
     got = eng.download(d_out, out_total)
@@ -1195,9 +1202,10 @@ def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False, max_le
         eng.close()
 
 
-def tiny_decode_items(w, n_items=1500, seed=41, engine=None, profile=None, max_len=460):
+def tiny_decode_items(w, n_items=1500, seed=41, engine=None, profile=None, max_len=460, thread_limit=None):
     """Streams either side of HUFD_DEC_TINY_BYTES (512 bytes; one thread each below it): whole encodings, cut
-    ones, arbitrary bytes, starting inside their first byte, with room for all, some or none of their symbols."""
+    ones, arbitrary bytes, starting inside their first byte, with room for all, some or none of their symbols.
+    thread_limit: the longest item the plan must give a thread of its own (aws_huffman_amd_decode_plan_stats)."""
     rng = np.random.default_rng(seed)
     ocoder, pcoder = w.ocoder, w.pcoder
     if profile:
@@ -1252,6 +1260,13 @@ def tiny_decode_items(w, n_items=1500, seed=41, engine=None, profile=None, max_l
     eng.upload(d_enc, host_enc)
     eng.fill(d_sym, SENTINEL, sym_total)
     plan = eng.decode_plan(items)
+    stats = eng.decode_stats(plan)
+    assert stats["items"] == len(items), stats
+    assert stats["by_thread"] + stats["by_wave"] + stats["by_workgroup"] + stats["by_blocks"] + stats["by_pieces"] + stats["empty"] == len(items), stats
+    if thread_limit is not None:
+        by_thread = sum(1 for it in items if 0 < it["in_len"] <= thread_limit)
+        assert stats["thread_limit"] == thread_limit and stats["by_thread"] == by_thread, (stats, by_thread)
+        assert max(it["in_len"] for it in items if it["in_len"] <= thread_limit) > thread_limit * 3 // 4
     eng.decode_launch(plan, d_enc, d_sym)
     res = eng.decode_results(plan, len(items))
     got = eng.download(d_sym, sym_total)

@@ -131,12 +131,18 @@ def test_tiny_encode_items(world):
     # 18 items per byte of the longest: one thread each (the GPU tests do this with items of up to 512 and 1200 symbols)
     pc.tiny_encode_items(world, n_items=3700, seed=40, max_len=200, edge_lens=False)
     pc.tiny_encode_items(world, n_items=400, seed=38, holes=True)
+    # a thread per item up to 1024 symbols (the rule asks for 100 items per byte of the longest: set aside by the tests' switch)
+    with harness.items_per_byte(world.product.lib, encode=1):
+        pc.tiny_encode_items(world, n_items=1200, seed=46, max_len=1100, thread_limit=1024)
+        pc.tiny_encode_items(world, n_items=2300, seed=47, holes=True, max_len=2100, thread_limit=2048)  # (a coder with holes keeps to count / scan / pack: its class ends at 2048)
 
 
 def test_tiny_decode_items(world):
     pc.tiny_decode_items(world, n_items=400)  # a handful: one thread up to 128 bytes, one wave up to 768, chunks above
     pc.tiny_decode_items(world, n_items=3300, seed=44)  # 6 items per byte of the longest: one thread up to 512
     pc.tiny_decode_items(world, n_items=400, seed=42, profile="hpack_lengths")
+    with harness.items_per_byte(world.product.lib, decode=1):
+        pc.tiny_decode_items(world, n_items=900, seed=48, max_len=900, thread_limit=768)
 
 
 def test_first_bit_offsets(world):

@@ -175,9 +175,19 @@ def test_tiny_encode_items(world, engine):
 
 
 def test_many_short_items_take_one_thread_each(world, engine):
-    """Enough items of at most HUFD_TINY_MANY_BYTES (HUFD_*_TINY_PER_BYTE per byte of the longest): a thread each."""
-    pc.tiny_encode_items(world, n_items=66000, seed=39, engine=engine, max_len=1200)
-    pc.tiny_decode_items(world, n_items=66000, seed=43, engine=engine, max_len=1000)
+    """A thread per item for a whole class of short items, by the library's own rule (HUFD_*_TINY_PER_BYTE items per byte of
+    the class's longest item): the one-pass coder's enc_tiny on items of up to 1024 symbols, dec_tiny on items of up to 768
+    encoded bytes -- every kind of stop of the scenarios among them, and the plans say that this is the road they took."""
+    pc.tiny_encode_items(world, n_items=125000, seed=39, engine=engine, max_len=1200, thread_limit=1024)
+    pc.tiny_decode_items(world, n_items=66000, seed=43, engine=engine, max_len=1000, thread_limit=768)
+    # fewer items than the rule asks for, and the rule set aside by the tests' switch: the same road for them
+    with harness.items_per_byte(world.product.lib, encode=1, decode=1):
+        pc.tiny_encode_items(world, n_items=9000, seed=139, engine=engine, max_len=1100, thread_limit=1024)
+        pc.tiny_encode_items(world, n_items=9000, seed=140, holes=True, max_len=2100, thread_limit=2048)  # (a coder with holes keeps to count / scan / pack: its class ends at 2048)
+        pc.tiny_decode_items(world, n_items=9000, seed=143, engine=engine, max_len=900, thread_limit=768)
+    # and by default such a handful goes by tiles / chunks above 128 symbols / bytes
+    pc.tiny_encode_items(world, n_items=3000, seed=141, engine=engine, max_len=1100, thread_limit=128)
+    pc.tiny_decode_items(world, n_items=300, seed=144, engine=engine, max_len=900, thread_limit=128)
 
 
 def test_tiny_decode_items(world, engine):
