@@ -209,4 +209,22 @@ struct hufd_chunk_rec {
     uint32_t item;
 };
 
+/* Where the items of a plan that is made on the device come from (plan_kernels.hip): the caller's records in DEVICE memory,
+ * a stride, or what an encode launch left */
+#define HUFD_ITEMS_DEVICE_ARRAY 0u
+#define HUFD_ITEMS_STRIDED 1u
+#define HUFD_ITEMS_FROM_ENCODE 2u
+struct hufd_item_source {
+    uint32_t kind;
+    uint32_t first_bit;   /* strided, decode */
+    uint32_t eos_padding; /* strided, encode */
+    uint32_t pad;
+    const void *raw; /* device array: struct hufd_raw_dec_item[] / hufd_raw_enc_item[] */
+    /* strided: item i lies at in_offset + i * in_stride (in_len bytes) and goes to out_offset + i * out_stride (room: out_capacity) */
+    uint64_t in_offset, in_stride, in_len, out_offset, out_stride, out_capacity;
+    /* from an encode plan's last launch: its item records and result records */
+    const struct hufd_enc_item *enc_items;
+    const struct hufd_enc_result *enc_results;
+};
+
 #endif /* HUFFMAN_AMD_DEVICE_TYPES_H */

@@ -130,6 +130,29 @@ int hufk_encode_plan_tiny_items(const void *raw_items, uint32_t n_items, struct 
 int hufk_decode_plan_chunks(
     const struct hufd_dec_item *items, uint32_t n_items, uint32_t n_chunks, uint32_t *chunk_item, struct hufd_chunk_rec *chunk_rec,
     void *stream);
+/* Plans made on the device from items the host never looks at (plan_kernels.hip).  _count: what the items come to -- statistics,
+ * the thread-per-item rule, counts per item scanned into positions; copies the totals back and WAITS for the stream (the sizes
+ * of the plan's arrays and of the launch's grids are the host's to know).  _fill: the records and lists, from the same scratch. */
+struct hufk_plan_totals {
+    uint64_t totals[8]; /* decode: chunks, thread items, wave items, large items, runs, narrow / wide end-of-stream chunks, items
+                         * with chunks; encode: segments, thread items, -, large items, -, -, -, items with segments */
+    uint64_t tiny_limit;
+    uint64_t shortest, longest, largest_out_cap, tail_stage, tail_lanes;
+    uint32_t worst_bits, invalid;
+};
+uint64_t hufk_plan_scratch_bytes(uint64_t n_items);
+int hufk_decode_plan_count(
+    const struct hufd_item_source *src, uint32_t n_items, uint64_t per_byte, uint32_t shortest_code_bits, void *scratch,
+    struct hufk_plan_totals *totals, void *stream);
+int hufk_decode_plan_fill(
+    const struct hufd_item_source *src, uint32_t n_items, uint32_t shortest_code_bits, const void *scratch, struct hufd_dec_item *items,
+    uint32_t *tiny_list, uint32_t *tail_list, uint32_t *large_list, uint32_t *run_list, void *stream);
+int hufk_encode_plan_count(
+    const struct hufd_item_source *src, uint32_t n_items, uint64_t class0, uint64_t class1, uint64_t per_byte, void *scratch,
+    struct hufk_plan_totals *totals, void *stream);
+int hufk_encode_plan_fill(
+    const struct hufd_item_source *src, uint32_t n_items, uint32_t n_segs, const void *scratch, struct hufd_enc_item *items,
+    struct hufd_enc_seg *segs, uint32_t *tiny_list, uint32_t *large_list, void *stream);
 /* one short item whose record already sits in device memory (the host-pointer calls' small-input road): one launch */
 int hufk_encode_one_tiny(
     const struct hufd_tables *tables, const struct hufd_enc_item *item, const uint32_t *zero, const void *d_in, void *d_out,

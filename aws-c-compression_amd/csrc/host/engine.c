@@ -468,35 +468,37 @@ void *aws_huffman_amd_engine_stream(struct aws_huffman_amd_engine *eng) {
 
 /* ------------------------------------------------------------------ encode plans */
 
+/* A plan's device arrays are cuts of ONE allocation (a new plan paid some twenty-five hipMallocs: 1 .. 15 ms for
+ * BASELINE configs[3], where filling it takes 0.5 ms): every array starts at a multiple of 256 bytes. */
+static size_t arena_cut(size_t *total, size_t bytes) {
+    const size_t at = (*total + 255u) & ~(size_t)255u;
+    *total = at + bytes;
+    return at;
+}
+
+#define ENC_PLAN_ARRAYS(X, ci, cs, cl, ct)                                                                                 \
+    X(d_items, (ci) * sizeof(struct hufd_enc_item))                                                                    \
+    X(d_segs, (cs) * sizeof(struct hufd_enc_seg))                                                                      \
+    X(d_large, (cl) * sizeof(uint32_t))                                                                                \
+    X(d_tiny, (ct) * sizeof(uint32_t))                                                                                 \
+    X(d_seg_bits, (cs) * sizeof(uint32_t))                                                                             \
+    X(d_wave_bits, (cs) * 4 * sizeof(uint32_t))                                                                        \
+    X(d_seg_unk, (cs) * sizeof(uint32_t))                                                                              \
+    X(d_seg_bitoff, (cs) * sizeof(uint64_t))                                                                           \
+    /* the scan lists up to two segments an item, the wave packer any segment it leaves */                              \
+    X(d_careful, (2 * (ci) + (cs) + 4) * sizeof(uint32_t))                                                             \
+    X(d_zero, hufk_encode_zero_bytes((uint32_t)(cs), (uint32_t)(ci)))                                                  \
+    X(d_unk_seen, (cs))                                                                                                \
+    X(d_item_total, (ci) * sizeof(uint64_t))                                                                           \
+    X(d_states, (ci) * sizeof(struct hufd_enc_item_state))                                                             \
+    X(d_results, (ci) * sizeof(struct hufd_enc_result))
+
 static void enc_plan_release_device(struct aws_huffman_amd_encode_plan *p) {
-    hufs_free(p->d_items);
-    hufs_free(p->d_segs);
-    hufs_free(p->d_large);
-    hufs_free(p->d_tiny);
-    hufs_free(p->d_seg_bits);
-    hufs_free(p->d_wave_bits);
-    hufs_free(p->d_seg_unk);
-    hufs_free(p->d_seg_bitoff);
-    hufs_free(p->d_careful);
-    hufs_free(p->d_zero);
-    hufs_free(p->d_unk_seen);
-    hufs_free(p->d_item_total);
-    hufs_free(p->d_states);
-    hufs_free(p->d_results);
-    p->d_items = NULL;
-    p->d_segs = NULL;
-    p->d_large = NULL;
-    p->d_tiny = NULL;
-    p->d_seg_bits = NULL;
-    p->d_wave_bits = NULL;
-    p->d_seg_unk = NULL;
-    p->d_seg_bitoff = NULL;
-    p->d_careful = NULL;
-    p->d_zero = NULL;
-    p->d_unk_seen = NULL;
-    p->d_item_total = NULL;
-    p->d_states = NULL;
-    p->d_results = NULL;
+    hufs_free(p->d_arena);
+    p->d_arena = NULL;
+#define ENC_FORGET(name, bytes) p->name = NULL;
+    ENC_PLAN_ARRAYS(ENC_FORGET, 0, 0, 0, 0)
+#undef ENC_FORGET
     p->cap_items = p->cap_segs = p->cap_large = p->cap_tiny = 0;
 }
 
@@ -591,24 +593,18 @@ static int enc_plan_reserve(struct aws_huffman_amd_encode_plan *p, size_t n_item
     if (n_items > p->cap_items || n_segs > p->cap_segs || n_large > p->cap_large || n_tiny > p->cap_tiny) {
         enc_plan_release_device(p);
         const size_t ci = n_items ? n_items : 1, cs = n_segs ? n_segs : 1, cl = n_large ? n_large : 1, ct = n_tiny ? n_tiny : 1;
-        p->d_items = hufs_malloc(ci * sizeof(struct hufd_enc_item));
-        p->d_segs = hufs_malloc(cs * sizeof(struct hufd_enc_seg));
-        p->d_large = hufs_malloc(cl * sizeof(uint32_t));
-        p->d_tiny = hufs_malloc(ct * sizeof(uint32_t));
-        p->d_seg_bits = hufs_malloc(cs * sizeof(uint32_t));
-        p->d_wave_bits = hufs_malloc(cs * 4 * sizeof(uint32_t));
-        p->d_seg_unk = hufs_malloc(cs * sizeof(uint32_t));
-        p->d_seg_bitoff = hufs_malloc(cs * sizeof(uint64_t));
-        p->d_careful = hufs_malloc((2 * ci + cs + 4) * sizeof(uint32_t)); /* the scan lists up to two segments an item, the wave packer any segment it leaves */
-        p->d_zero = hufs_malloc(hufk_encode_zero_bytes((uint32_t)cs, (uint32_t)ci));
-        p->d_unk_seen = hufs_malloc(cs);
-        p->d_item_total = hufs_malloc(ci * sizeof(uint64_t));
-        p->d_states = hufs_malloc(ci * sizeof(struct hufd_enc_item_state));
-        p->d_results = hufs_malloc(ci * sizeof(struct hufd_enc_result));
-        if (!p->d_items || !p->d_segs || !p->d_large || !p->d_tiny || !p->d_seg_bits || !p->d_wave_bits || !p->d_seg_unk || !p->d_seg_bitoff ||
-            !p->d_careful || !p->d_zero || !p->d_unk_seen || !p->d_item_total || !p->d_states || !p->d_results) {
+        size_t total = 0;
+#define ENC_SIZE(name, bytes) (void)arena_cut(&total, (bytes));
+        ENC_PLAN_ARRAYS(ENC_SIZE, ci, cs, cl, ct)
+#undef ENC_SIZE
+        p->d_arena = hufs_malloc(total);
+        if (!p->d_arena) {
             return 2;
         }
+        total = 0;
+#define ENC_PLACE(name, bytes) p->name = (void *)((uint8_t *)p->d_arena + arena_cut(&total, (bytes)));
+        ENC_PLAN_ARRAYS(ENC_PLACE, ci, cs, cl, ct)
+#undef ENC_PLACE
         p->cap_items = ci;
         p->cap_segs = cs;
         p->cap_large = cl;
@@ -820,6 +816,103 @@ int aws_huffman_amd_encode_plan_new(
     return AWS_OP_SUCCESS;
 }
 
+/* the scratch a planning pass on the device wants, grown as needed */
+static int plan_scratch_reserve(void **scratch, size_t *cap, size_t n_items) {
+    const size_t want = (size_t)hufk_plan_scratch_bytes(n_items);
+    if (want > *cap) {
+        hufs_free(*scratch);
+        *scratch = hufs_malloc(want);
+        *cap = *scratch ? want : 0;
+    }
+    return *scratch ? 0 : 2;
+}
+
+/* A plan from items the host does not look at (plan_kernels.hip): described by a stride, or lying in device memory.  Three
+ * small launches count, one copy brings a few totals back (the wait of the call), then the records are written on `stream`:
+ * the plan is good for launches on that stream, or on another once this one has been waited for. */
+static int enc_plan_fill_on_device(struct aws_huffman_amd_encode_plan *p, const struct hufd_item_source *src, size_t n_items, void *stream) {
+    struct aws_huffman_amd_engine *eng = p->engine;
+    if (!eng->can_encode) {
+        return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION);
+    }
+    p->n_items = p->n_segs = p->n_large = p->n_tiny = 0;
+    p->launched = false;
+    p->look_back_timed_out = false;
+    memset(&p->stats, 0, sizeof(p->stats));
+    p->largest_out_cap = 0;
+    p->most_overflow_bits = 0;
+    if (n_items == 0) {
+        return AWS_OP_SUCCESS;
+    }
+    if (n_items >= 0xFFFFFFFFull) {
+        return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
+    }
+    void *st = stream ? stream : eng->stream;
+    ON_DEVICE(eng->device);
+    struct hufk_plan_totals t;
+    int e = plan_scratch_reserve(&p->d_plan_scratch, &p->cap_plan_scratch, n_items);
+    if (!e) {
+        const uint64_t class0 = aws_huffman_amd_engine_encodes_in_one_pass(eng) ? HUFD_ENC_TINY_WAVE_BYTES : HUFD_TINY_MANY_BYTES;
+        e = hufk_encode_plan_count(src, (uint32_t)n_items, class0, HUFD_ENC_TINY_BYTES, enc_tiny_per_byte(eng), p->d_plan_scratch, &t, st);
+    }
+    if (e) {
+        return raise_hip(e);
+    }
+    if (t.invalid || t.totals[0] >= 0xFFFFFFFFull) {
+        return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
+    }
+    e = enc_plan_reserve(p, n_items, (size_t)t.totals[0], (size_t)t.totals[3], (size_t)t.totals[1]);
+    if (!e) {
+        e = hufk_encode_plan_fill(
+            src, (uint32_t)n_items, (uint32_t)t.totals[0], p->d_plan_scratch, p->d_items, p->d_segs, p->d_tiny, p->d_large, st);
+    }
+    if (e) {
+        return raise_hip(e);
+    }
+    p->n_items = (uint32_t)n_items;
+    p->n_segs = (uint32_t)t.totals[0];
+    p->n_large = (uint32_t)t.totals[3];
+    p->n_tiny = (uint32_t)t.totals[1];
+    p->largest_out_cap = t.largest_out_cap;
+    p->most_overflow_bits = t.worst_bits;
+    p->stats.items = n_items;
+    p->stats.thread_limit = t.tiny_limit;
+    p->stats.by_thread = t.totals[1];
+    p->stats.by_pieces = t.totals[7];
+    p->stats.pieces = t.totals[0];
+    p->stats.empty = n_items - t.totals[1] - t.totals[7];
+    return AWS_OP_SUCCESS;
+}
+
+static void strided_source(struct hufd_item_source *src, const struct aws_huffman_amd_strided_items *items) {
+    memset(src, 0, sizeof(*src));
+    src->kind = HUFD_ITEMS_STRIDED;
+    src->first_bit = items->first_bit;
+    src->eos_padding = items->eos_padding;
+    src->in_offset = items->in_offset;
+    src->in_stride = items->in_stride;
+    src->in_len = items->in_len;
+    src->out_offset = items->out_offset;
+    src->out_stride = items->out_stride;
+    src->out_capacity = items->out_capacity;
+}
+
+int aws_huffman_amd_encode_plan_reset_strided(
+    struct aws_huffman_amd_encode_plan *p, const struct aws_huffman_amd_strided_items *items, void *stream) {
+    struct hufd_item_source src;
+    strided_source(&src, items);
+    return enc_plan_fill_on_device(p, &src, (size_t)items->count, stream);
+}
+
+int aws_huffman_amd_encode_plan_reset_device_items(
+    struct aws_huffman_amd_encode_plan *p, const struct aws_huffman_amd_encode_item *device_items, size_t item_count, void *stream) {
+    struct hufd_item_source src;
+    memset(&src, 0, sizeof(src));
+    src.kind = HUFD_ITEMS_DEVICE_ARRAY;
+    src.raw = device_items;
+    return enc_plan_fill_on_device(p, &src, item_count, stream);
+}
+
 int aws_huffman_amd_encode_plan_reset(
     struct aws_huffman_amd_encode_plan *p,
     const struct aws_huffman_amd_encode_item *items,
@@ -843,6 +936,7 @@ void aws_huffman_amd_encode_plan_destroy(struct aws_huffman_amd_encode_plan *p) 
         }
         ON_DEVICE(eng->device);
         enc_plan_release_device(p);
+        hufs_free(p->d_plan_scratch);
         hufs_event_destroy(p->done_event);
         free(p);
     }
@@ -1006,53 +1100,37 @@ int aws_huffman_amd_encode_plan_results(
 
 /* ------------------------------------------------------------------ decode plans */
 
+#define DEC_PLAN_ARRAYS(X, ci, cc, cl, cr, ns)                                                                            \
+    X(d_items, (ci) * sizeof(struct hufd_dec_item))                                                                    \
+    X(d_chunk_item, (cc) * sizeof(uint32_t))                                                                           \
+    X(d_tail, (ci) * 2 * sizeof(uint32_t))                                                                             \
+    X(d_tiny, (ci) * sizeof(uint32_t))                                                                                 \
+    X(d_large, (cl) * 2 * sizeof(uint32_t))                                                                            \
+    X(d_runs, (cr) * 2 * sizeof(uint32_t))                                                                             \
+    X(d_run_fn, (cr) * (ns) * sizeof(uint32_t))                                                                        \
+    X(d_run_entry, (cr) * sizeof(uint32_t))                                                                            \
+    X(d_run_base, (cr) * sizeof(uint64_t))                                                                             \
+    X(d_fn_tab, (cc) * (ns) * HUFD_DEC_LANES * sizeof(uint16_t))                                                       \
+    X(d_cp_tab, (cc) * HUFD_DEC_CP_ROWS * HUFD_DEC_LANES * sizeof(uint16_t))                                           \
+    X(d_chunk_fn, (cc) * (ns) * sizeof(uint32_t))                                                                      \
+    X(d_slow_list, ((cc) + 1) * sizeof(uint32_t)) /* [0] count, [1..] chunks */                                        \
+    X(d_emit_list, ((cc) + 1) * sizeof(uint32_t))                                                                      \
+    X(d_dense_list, ((cc) + 1) * sizeof(uint32_t))                                                                     \
+    X(d_lane_count, (cc) * HUFD_DEC_LANES * sizeof(uint16_t))                                                          \
+    X(d_chunk_regular, (cc))                                                                                           \
+    X(d_tail_entry, (cc) * sizeof(uint32_t))                                                                           \
+    X(d_chunk_entry, (cc) * sizeof(uint32_t))                                                                          \
+    X(d_chunk_base, (cc) * sizeof(uint64_t))                                                                           \
+    X(d_chunk_rec, (cc) * sizeof(struct hufd_chunk_rec))                                                               \
+    X(d_states, (ci) * sizeof(struct hufd_dec_item_state))                                                             \
+    X(d_results, (ci) * sizeof(struct hufd_dec_result))
+
 static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
-    hufs_free(p->d_items);
-    hufs_free(p->d_chunk_item);
-    hufs_free(p->d_tail);
-    hufs_free(p->d_large);
-    hufs_free(p->d_tiny);
-    hufs_free(p->d_runs);
-    hufs_free(p->d_run_fn);
-    hufs_free(p->d_run_entry);
-    hufs_free(p->d_run_base);
-    hufs_free(p->d_fn_tab);
-    hufs_free(p->d_cp_tab);
-    hufs_free(p->d_chunk_fn);
-    hufs_free(p->d_slow_list);
-    hufs_free(p->d_emit_list);
-    hufs_free(p->d_dense_list);
-    hufs_free(p->d_lane_count);
-    hufs_free(p->d_chunk_regular);
-    hufs_free(p->d_tail_entry);
-    hufs_free(p->d_chunk_entry);
-    hufs_free(p->d_chunk_base);
-    hufs_free(p->d_chunk_rec);
-    hufs_free(p->d_states);
-    hufs_free(p->d_results);
-    p->d_items = NULL;
-    p->d_chunk_item = NULL;
-    p->d_tail = NULL;
-    p->d_large = NULL;
-    p->d_tiny = NULL;
-    p->d_runs = NULL;
-    p->d_run_fn = NULL;
-    p->d_run_entry = NULL;
-    p->d_run_base = NULL;
-    p->d_fn_tab = NULL;
-    p->d_cp_tab = NULL;
-    p->d_chunk_fn = NULL;
-    p->d_slow_list = NULL;
-    p->d_emit_list = NULL;
-    p->d_dense_list = NULL;
-    p->d_lane_count = NULL;
-    p->d_chunk_regular = NULL;
-    p->d_tail_entry = NULL;
-    p->d_chunk_entry = NULL;
-    p->d_chunk_base = NULL;
-    p->d_chunk_rec = NULL;
-    p->d_states = NULL;
-    p->d_results = NULL;
+    hufs_free(p->d_arena);
+    p->d_arena = NULL;
+#define DEC_FORGET(name, bytes) p->name = NULL;
+    DEC_PLAN_ARRAYS(DEC_FORGET, 0, 0, 0, 0, 0)
+#undef DEC_FORGET
     p->cap_items = p->cap_chunks = p->cap_large = p->cap_runs = 0;
 }
 
@@ -1143,34 +1221,18 @@ static int dec_plan_reserve(struct aws_huffman_amd_decode_plan *p, size_t n_item
         dec_plan_release_device(p);
         const size_t ci = n_items ? n_items : 1, cc = n_chunks ? n_chunks : 1, cl = n_large ? n_large : 1;
         const size_t cr = n_runs ? n_runs : 1;
-        p->d_items = hufs_malloc(ci * sizeof(struct hufd_dec_item));
-        p->d_chunk_item = hufs_malloc(cc * sizeof(uint32_t));
-        p->d_tail = hufs_malloc(ci * 2 * sizeof(uint32_t));
-        p->d_tiny = hufs_malloc(ci * sizeof(uint32_t));
-        p->d_large = hufs_malloc(cl * 2 * sizeof(uint32_t));
-        p->d_runs = hufs_malloc(cr * 2 * sizeof(uint32_t));
-        p->d_run_fn = hufs_malloc(cr * ns * sizeof(uint32_t));
-        p->d_run_entry = hufs_malloc(cr * sizeof(uint32_t));
-        p->d_run_base = hufs_malloc(cr * sizeof(uint64_t));
-        p->d_fn_tab = hufs_malloc(cc * ns * HUFD_DEC_LANES * sizeof(uint16_t));
-        p->d_cp_tab = hufs_malloc(cc * HUFD_DEC_CP_ROWS * HUFD_DEC_LANES * sizeof(uint16_t));
-        p->d_chunk_fn = hufs_malloc(cc * ns * sizeof(uint32_t));
-        p->d_slow_list = hufs_malloc((cc + 1) * sizeof(uint32_t)); /* [0] count, [1..] chunks */
-        p->d_emit_list = hufs_malloc((cc + 1) * sizeof(uint32_t));
-        p->d_dense_list = hufs_malloc((cc + 1) * sizeof(uint32_t));
-        p->d_lane_count = hufs_malloc(cc * HUFD_DEC_LANES * sizeof(uint16_t));
-        p->d_chunk_regular = hufs_malloc(cc);
-        p->d_tail_entry = hufs_malloc(cc * sizeof(uint32_t));
-        p->d_chunk_entry = hufs_malloc(cc * sizeof(uint32_t));
-        p->d_chunk_base = hufs_malloc(cc * sizeof(uint64_t));
-        p->d_chunk_rec = hufs_malloc(cc * sizeof(struct hufd_chunk_rec));
-        p->d_states = hufs_malloc(ci * sizeof(struct hufd_dec_item_state));
-        p->d_results = hufs_malloc(ci * sizeof(struct hufd_dec_result));
-        if (!p->d_items || !p->d_chunk_item || !p->d_large || !p->d_fn_tab || !p->d_cp_tab || !p->d_chunk_fn || !p->d_slow_list || !p->d_chunk_entry ||
-            !p->d_tail || !p->d_tiny || !p->d_dense_list || !p->d_emit_list || !p->d_lane_count || !p->d_chunk_regular || !p->d_tail_entry || !p->d_runs || !p->d_run_fn || !p->d_run_entry || !p->d_run_base ||
-            !p->d_chunk_base || !p->d_chunk_rec || !p->d_states || !p->d_results) {
+        size_t total = 0;
+#define DEC_SIZE(name, bytes) (void)arena_cut(&total, (bytes));
+        DEC_PLAN_ARRAYS(DEC_SIZE, ci, cc, cl, cr, ns)
+#undef DEC_SIZE
+        p->d_arena = hufs_malloc(total);
+        if (!p->d_arena) {
             return 2;
         }
+        total = 0;
+#define DEC_PLACE(name, bytes) p->name = (void *)((uint8_t *)p->d_arena + arena_cut(&total, (bytes)));
+        DEC_PLAN_ARRAYS(DEC_PLACE, ci, cc, cl, cr, ns)
+#undef DEC_PLACE
         p->cap_items = ci;
         p->cap_chunks = cc;
         p->cap_large = cl;
@@ -1510,6 +1572,158 @@ int aws_huffman_amd_decode_plan_new(
     return AWS_OP_SUCCESS;
 }
 
+/* the items of a source the device planner does not take (a coder with codes of more than 12 bits or of one length: their plans
+ * hold what only the host lays out), brought to the host: the loop over them makes the plan */
+static int dec_items_to_host(
+    struct aws_huffman_amd_decode_plan *p, const struct hufd_item_source *src, size_t n_items, void *st, struct aws_huffman_amd_decode_item **out) {
+    struct aws_huffman_amd_decode_item *items = calloc(n_items ? n_items : 1, sizeof(*items));
+    if (!items) {
+        return 2;
+    }
+    int e = 0;
+    if (src->kind == HUFD_ITEMS_STRIDED) {
+        for (size_t i = 0; i < n_items; ++i) {
+            items[i].in_offset = src->in_offset + i * src->in_stride;
+            items[i].in_len = src->in_len;
+            items[i].first_bit = (uint8_t)src->first_bit;
+            items[i].out_offset = src->out_offset + i * src->out_stride;
+            items[i].out_capacity = src->out_capacity;
+        }
+    } else if (src->kind == HUFD_ITEMS_DEVICE_ARRAY) {
+        e = hufs_copy_d2h(items, src->raw, n_items * sizeof(*items), st);
+        if (!e) {
+            e = hufs_stream_sync(st);
+        }
+    } else {
+        struct hufd_enc_item *ei = malloc((n_items ? n_items : 1) * sizeof(*ei));
+        struct hufd_enc_result *er = malloc((n_items ? n_items : 1) * sizeof(*er));
+        e = ei && er ? 0 : 2;
+        if (!e) {
+            e = hufs_copy_d2h(ei, src->enc_items, n_items * sizeof(*ei), st);
+        }
+        if (!e) {
+            e = hufs_copy_d2h(er, src->enc_results, n_items * sizeof(*er), st);
+        }
+        if (!e) {
+            e = hufs_stream_sync(st);
+        }
+        for (size_t i = 0; i < n_items && !e; ++i) {
+            items[i].in_offset = ei[i].out_off;
+            items[i].in_len = er[i].produced < ei[i].out_cap ? er[i].produced : ei[i].out_cap;
+            items[i].out_offset = ei[i].in_off;
+            items[i].out_capacity = ei[i].in_len;
+        }
+        free(ei);
+        free(er);
+    }
+    (void)p;
+    if (e) {
+        free(items);
+        return e;
+    }
+    *out = items;
+    return 0;
+}
+
+/* as enc_plan_fill_on_device: chunks, lists and per-chunk records of the items of `src`, made on the device */
+static int dec_plan_fill_on_device(struct aws_huffman_amd_decode_plan *p, const struct hufd_item_source *src, size_t n_items, void *stream) {
+    struct aws_huffman_amd_engine *eng = p->engine;
+    if (!eng->can_decode) {
+        return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION);
+    }
+    void *st = stream ? stream : eng->stream;
+    if (eng->tables.deep_entries || eng->tables.fixed_bits) {
+        struct aws_huffman_amd_decode_item *items = NULL;
+        ON_DEVICE(eng->device);
+        const int e = dec_items_to_host(p, src, n_items, st, &items);
+        if (e) {
+            return raise_hip(e);
+        }
+        const int rc = dec_plan_fill(p, items, n_items);
+        free(items);
+        return rc;
+    }
+    p->n_items = p->n_chunks = p->n_large = p->n_runs = p->n_tail = p->n_fixed = p->n_wide = 0;
+    p->n_tiny = p->n_deep = 0;
+    memset(&p->stats, 0, sizeof(p->stats));
+    p->chained = false;
+    p->wide_from = wide_min_bytes(0);
+    p->tail_stage_bytes = 0;
+    p->tail_lanes = 0;
+    p->n_tail_narrow = 0;
+    if (n_items == 0) {
+        return AWS_OP_SUCCESS;
+    }
+    if (n_items >= 0xFFFFFFFFull) {
+        return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
+    }
+    ON_DEVICE(eng->device);
+    struct hufk_plan_totals t;
+    int e = plan_scratch_reserve(&p->d_plan_scratch, &p->cap_plan_scratch, n_items);
+    if (!e) {
+        e = hufk_decode_plan_count(src, (uint32_t)n_items, tiny_per_byte(true), eng->tables.min_bits, p->d_plan_scratch, &t, st);
+    }
+    if (e) {
+        return raise_hip(e);
+    }
+    if (t.invalid || t.totals[0] >= 0xFFFFFFFFull) {
+        return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
+    }
+    const uint64_t n_chunks = t.totals[0], tiny = t.totals[1], coop = t.totals[2], n_large = t.totals[3], n_runs = t.totals[4];
+    const uint64_t narrow = t.totals[5], wide = t.totals[6];
+    e = dec_plan_reserve(p, n_items, (size_t)n_chunks, (size_t)n_large, (size_t)n_runs);
+    if (!e) {
+        e = hufk_decode_plan_fill(
+            src, (uint32_t)n_items, eng->tables.min_bits, p->d_plan_scratch, p->d_items, p->d_tiny, p->d_tail, p->d_large, p->d_runs, st);
+    }
+    if (!e) {
+        e = hufk_decode_plan_chunks(p->d_items, (uint32_t)n_items, (uint32_t)n_chunks, p->d_chunk_item, p->d_chunk_rec, st);
+    }
+    if (e) {
+        return raise_hip(e);
+    }
+    p->n_items = (uint32_t)n_items;
+    p->n_chunks = (uint32_t)n_chunks;
+    p->n_large = (uint32_t)n_large;
+    p->n_runs = (uint32_t)n_runs;
+    p->n_tail = (uint32_t)(narrow + wide);
+    p->n_tail_narrow = (uint32_t)narrow;
+    p->n_tiny = (uint32_t)tiny;
+    p->n_deep = (uint32_t)coop;
+    p->tail_stage_bytes = t.tail_stage + 32 < 0xFFFFFFFFu ? (uint32_t)t.tail_stage + 32u : 0u;
+    p->tail_lanes = t.tail_lanes < HUFD_DEC_LANES ? (uint32_t)t.tail_lanes : HUFD_DEC_LANES;
+    p->chained = true; /* (the items are known on the device only: the results are translated from its records) */
+    {
+        const bool packs = narrow >= HUFD_DEC_PACK_MIN_CHUNKS && p->tail_lanes + 2u <= HUFD_DEC_LANES / 2;
+        p->stats.items = n_items;
+        p->stats.thread_limit = t.tiny_limit;
+        p->stats.by_thread = tiny;
+        p->stats.by_wave = coop;
+        p->stats.by_pieces = t.totals[7];
+        p->stats.pieces = n_chunks;
+        p->stats.end_pieces_packed = packs ? narrow : 0;
+        p->stats.end_pieces_single = narrow + wide - p->stats.end_pieces_packed;
+        p->stats.empty = n_items - tiny - coop - t.totals[7];
+    }
+    return AWS_OP_SUCCESS;
+}
+
+int aws_huffman_amd_decode_plan_reset_strided(
+    struct aws_huffman_amd_decode_plan *p, const struct aws_huffman_amd_strided_items *items, void *stream) {
+    struct hufd_item_source src;
+    strided_source(&src, items);
+    return dec_plan_fill_on_device(p, &src, (size_t)items->count, stream);
+}
+
+int aws_huffman_amd_decode_plan_reset_device_items(
+    struct aws_huffman_amd_decode_plan *p, const struct aws_huffman_amd_decode_item *device_items, size_t item_count, void *stream) {
+    struct hufd_item_source src;
+    memset(&src, 0, sizeof(src));
+    src.kind = HUFD_ITEMS_DEVICE_ARRAY;
+    src.raw = device_items;
+    return dec_plan_fill_on_device(p, &src, item_count, stream);
+}
+
 int aws_huffman_amd_decode_plan_reset(
     struct aws_huffman_amd_decode_plan *p,
     const struct aws_huffman_amd_decode_item *items,
@@ -1531,6 +1745,7 @@ void aws_huffman_amd_decode_plan_destroy(struct aws_huffman_amd_decode_plan *p) 
         }
         ON_DEVICE(p->engine->device);
         dec_plan_release_device(p);
+        hufs_free(p->d_plan_scratch);
         hufs_event_destroy(p->done_event);
         hufs_free(p->d_wide_block);
         hufs_free(p->d_fixed);
@@ -1738,7 +1953,14 @@ int aws_huffman_amd_decode_plan_from_encode(
         }
     }
     if (!thread_each) {
-        return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION); /* (the caller fetches the lengths and makes the plan from records) */
+        /* items with chunks (or too few short ones for a thread each): the general plan, made on the device from the
+         * launch's records -- the lengths stay there; what comes back are the few totals that size the plan */
+        struct hufd_item_source src;
+        memset(&src, 0, sizeof(src));
+        src.kind = HUFD_ITEMS_FROM_ENCODE;
+        src.enc_items = encoded->d_items;
+        src.enc_results = encoded->d_results;
+        return dec_plan_fill_on_device(p, &src, (size_t)n_items, stream);
     }
     p->n_items = p->n_chunks = p->n_large = p->n_runs = p->n_tail = p->n_fixed = p->n_wide = 0;
     p->n_tiny = p->n_deep = 0;

@@ -64,6 +64,7 @@ struct aws_huffman_amd_encode_plan {
     struct aws_huffman_amd_engine *engine;
     uint32_t n_items, n_segs, n_large;
     size_t cap_items, cap_segs, cap_large;
+    void *d_arena; /* the ONE device allocation the arrays below are cuts of */
     struct hufd_enc_item *d_items;
     struct hufd_enc_seg *d_segs;
     uint32_t *d_large;
@@ -85,6 +86,8 @@ struct aws_huffman_amd_encode_plan {
     void *last_output;
     void *done_event; /* recorded behind every launch on the launch's stream: what a new plan on this one's arrays waits for */
     bool unkeepable;  /* not to be kept as the engine's spare (waiting for its last launch failed) */
+    void *d_plan_scratch; /* of a plan made on the device (hufk_plan_scratch_bytes) */
+    size_t cap_plan_scratch;
     bool launched; /* the plan's items have been launched at least once: their records exist (aws_huffman_amd_decode_plan_from_encode asks) */
     bool last_single_pass;
     bool last_timed_out; /* the last launch whose results were fetched was done over by the three-kernel road */
@@ -103,6 +106,7 @@ struct aws_huffman_amd_decode_plan {
     uint32_t n_tail_narrow; /* the first so many of d_tail have at most HUFD_DEC_PACK_LANES whole lanes */
     size_t cap_items, cap_chunks, cap_large, cap_runs;
     struct aws_huffman_amd_decode_item *h_items; /* host copy for result translation */
+    void *d_arena; /* the ONE device allocation the arrays below are cuts of (but d_wide_block and d_fixed) */
     struct hufd_dec_item *d_items;
     uint32_t *d_chunk_item;
     uint32_t *d_tiny;      /* [n_items]: from the front the items of at most HUFD_DEC_TINY_BYTES encoded bytes, from the back the longer ones of a coder with long codes */
@@ -125,9 +129,11 @@ struct aws_huffman_amd_decode_plan {
     uint64_t *d_chunk_base;
     struct hufd_chunk_rec *d_chunk_rec;
     struct aws_huffman_amd_plan_stats stats; /* how the items are taken (aws_huffman_amd_decode_plan_stats) */
+    void *d_plan_scratch; /* of a plan made on the device (hufk_plan_scratch_bytes) */
+    size_t cap_plan_scratch;
     void *done_event; /* recorded behind every launch on the launch's stream: what a new plan on this one's arrays waits for */
     bool unkeepable;  /* not to be kept as the engine's spare (waiting for its last launch failed) */
-    bool chained; /* made by aws_huffman_amd_decode_plan_from_encode: the items' lengths are known on the device only (h_items is not filled) */
+    bool chained; /* made on the device (from an encode plan's records, a stride, or items in device memory): the items are known there only (h_items is not filled) */
     struct hufd_dec_item_state *d_states;
     struct hufd_dec_result *d_results;
     /* the long items of a coder with long codes: a workgroup per 32 KiB block (dec_wide_*) */

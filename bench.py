@@ -420,6 +420,30 @@ def run_header_items(lib, eng, n_items=1 << 20, steps=5, warmup=2):
     plan_ms = (time.perf_counter() - t0) * 1e3
     assert lib.aws_huffman_amd_decode_plan_new(C.byref(dplan), eng.h, None, 0) == 0
     lib.aws_huffman_amd_decode_plan_from_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    # the same records lying in device memory (a caller that makes them there, or keeps them): the plan without a host loop
+    d_items = eng.alloc(C.sizeof(arr))
+    eng.upload(d_items, np.frombuffer(arr, dtype=np.uint8))
+    fresh_plan = eng.empty_encode_plan()
+    dev_plan_ms = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        assert lib.aws_huffman_amd_encode_plan_reset_device_items(fresh_plan, d_items, n_items, None) == 0
+        dev_plan_ms.append((time.perf_counter() - t0) * 1e3)
+
+    def fresh_round_trip():
+        # nothing kept from a batch before: encode plan from the records, launch, chained decode plan, launch, wait
+        assert lib.aws_huffman_amd_encode_plan_reset_device_items(fresh_plan, d_items, n_items, None) == 0
+        eng.encode_launch(fresh_plan, d_in, d_enc)
+        assert lib.aws_huffman_amd_decode_plan_from_encode(dplan, fresh_plan, None) == 0
+        eng.decode_launch(dplan, d_enc, d_back)
+        eng.sync()
+
+    fresh = []
+    for k in range(warmup + steps):
+        t0 = time.perf_counter()
+        fresh_round_trip()
+        fresh.append((time.perf_counter() - t0) * 1e3)
+    fresh_ms = statistics.median(fresh[warmup:])
 
     def round_trip():
         eng.encode_launch(eplan, d_in, d_enc)
@@ -440,13 +464,19 @@ def run_header_items(lib, eng, n_items=1 << 20, steps=5, warmup=2):
                  np.array_equal(eng.download(d_back, total_in), data))
     assert bit_exact, "the batch of header-sized items did not round-trip"
     lib.aws_huffman_amd_encode_plan_destroy(eplan)
+    lib.aws_huffman_amd_encode_plan_destroy(fresh_plan)
     lib.aws_huffman_amd_decode_plan_destroy(dplan)
-    for ptr in (d_in, d_enc, d_back):
+    for ptr in (d_in, d_enc, d_back, d_items):
         eng.free(ptr)
     return {"workload": "%d items of 16..80 printable bytes (%.1f MiB), one batch: encode launch, decode plan chained to it on the "
                         "device (no lengths on the host), decode launch, synchronise" % (n_items, total_in / (1 << 20)),
             "bit_exact": bit_exact, "steps": steps, "round_trip_ms": round(ms, 4), "items_per_s": round(n_items / (ms * 1e-3)),
-            "value_GiBps": round(total_in / GIB / (ms * 1e-3), 2), "plan_ms": {"encode": round(plan_ms, 3), "decode_chained_call": "queued with the launches"},
+            "value_GiBps": round(total_in / GIB / (ms * 1e-3), 2),
+            # what a batch that is NEW costs: its encode plan made from the records in device memory (three small launches and
+            # a wait for a few totals), launch, chained decode plan, launch, wait -- nothing kept from a batch before
+            "fresh_round_trip_ms": round(fresh_ms, 4), "fresh_items_per_s": round(n_items / (fresh_ms * 1e-3)),
+            "plan_ms": {"encode": round(statistics.median(dev_plan_ms), 3), "encode_from_host_records": round(plan_ms, 3),
+                        "decode_chained_call": "queued with the launches"},
             "timing": "host wall clock around the three calls and the synchronise, median of %d" % steps}
 
 
@@ -526,6 +556,86 @@ def run_cfg4(args, ranks, lib, eng):
     bit_exact = all(r[0] == 0 and r[2] == size for r in dres) and digest_of(eng, d_back, count * size) == digest_of(eng, d_in, count * size)
     assert bit_exact, "the timed steps did not leave the batch's round trip"
     kernel_ms, t_enc_ms, t_dec_ms = stages.medians()
+
+    # ---- a batch that is NEW: every plan made for it, from records in device memory (no loop over the items on the host),
+    # with what the reference's contract makes the host do in between -- look at the records of the first call to learn
+    # which buffers ran out of room and with what carried bits, then call again for those.
+    enc_arr = eng._encode_item_array(items)
+    d_items1 = eng.alloc(C.sizeof(enc_arr))
+    eng.upload(d_items1, np.frombuffer(enc_arr, dtype=np.uint8))
+    res_arr = eng._encode_item_array(resume) if resume else None
+    d_items2 = eng.alloc(C.sizeof(res_arr)) if resume else None
+    dec_arr = eng._decode_item_array([dict(in_offset=k * stride, in_len=lengths[k], out_offset=k * size, out_capacity=size) for k in range(count)])
+    d_items3 = eng.alloc(C.sizeof(dec_arr))
+    f1, f2, f3 = eng.empty_encode_plan(), eng.empty_encode_plan(), eng.empty_decode_plan()
+    fresh_plan_ms = {"encode": [], "encode_resume": [], "decode": []}
+    fresh_ms = []
+    res_buf = (harness.AmdEncodeResult * count)()
+    for rep_k in range(4):
+        t_start = time.perf_counter()
+        t0 = time.perf_counter()
+        assert lib.aws_huffman_amd_encode_plan_reset_device_items(f1, d_items1, count, None) == 0
+        fresh_plan_ms["encode"].append((time.perf_counter() - t0) * 1e3)
+        eng.encode_launch(f1, d_in, d_out)
+        assert lib.aws_huffman_amd_encode_plan_results(f1, res_buf, None) == 0  # (the records: which buffers want a second call)
+        if resume:
+            t0 = time.perf_counter()
+            eng.upload(d_items2, np.frombuffer(res_arr, dtype=np.uint8))
+            assert lib.aws_huffman_amd_encode_plan_reset_device_items(f2, d_items2, len(resume), None) == 0
+            fresh_plan_ms["encode_resume"].append((time.perf_counter() - t0) * 1e3)
+            eng.encode_launch(f2, d_in, d_out)
+            assert lib.aws_huffman_amd_encode_plan_results(f2, res_buf, None) == 0
+        t0 = time.perf_counter()
+        eng.upload(d_items3, np.frombuffer(dec_arr, dtype=np.uint8))  # (the streams' lengths: known on the host from the records)
+        assert lib.aws_huffman_amd_decode_plan_reset_device_items(f3, d_items3, count, None) == 0
+        fresh_plan_ms["decode"].append((time.perf_counter() - t0) * 1e3)
+        eng.decode_launch(f3, d_out, d_back)
+        eng.sync()
+        fresh_ms.append((time.perf_counter() - t_start) * 1e3)
+    fres = eng.decode_results(f3, count)
+    assert all(r[0] == 0 and r[2] == size for r in fres) and digest_of(eng, d_back, count * size) == digest_of(eng, d_in, count * size)
+    # ... and with room for every output: encode plan from a STRIDE, decode plan chained to the launch on the device -- not one
+    # record comes to the host before the end
+    roomy = eng.empty_encode_plan()
+    chained = eng.empty_decode_plan()
+    desc = harness.StridedItems(count=count, in_offset=0, in_stride=size, in_len=size, out_offset=0, out_stride=stride,
+                                out_capacity=stride, eos_padding=0xFF)
+    lib.aws_huffman_amd_decode_plan_from_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    chained_ms, chained_plan_ms = [], {"encode": [], "decode": []}
+    for rep_k in range(4):
+        eng.fill(d_back, 0xEE, count * size)
+        eng.sync()
+        t_start = time.perf_counter()
+        assert lib.aws_huffman_amd_encode_plan_reset_strided(roomy, C.byref(desc), None) == 0
+        chained_plan_ms["encode"].append((time.perf_counter() - t_start) * 1e3)
+        eng.encode_launch(roomy, d_in, d_out)
+        t0 = time.perf_counter()
+        assert lib.aws_huffman_amd_decode_plan_from_encode(chained, roomy, None) == 0
+        chained_plan_ms["decode"].append((time.perf_counter() - t0) * 1e3)  # (includes the wait for the encode launch)
+        eng.decode_launch(chained, d_out, d_back)
+        eng.sync()
+        chained_ms.append((time.perf_counter() - t_start) * 1e3)
+    cres = eng.decode_results(chained, count)
+    assert all(r[0] == 0 and r[2] == size for r in cres) and digest_of(eng, d_back, count * size) == digest_of(eng, d_in, count * size)
+    for pl in (f1, f2, roomy):
+        lib.aws_huffman_amd_encode_plan_destroy(pl)
+    for pl in (f3, chained):
+        lib.aws_huffman_amd_decode_plan_destroy(pl)
+    for ptr in (d_items1, d_items2, d_items3):
+        if ptr:
+            eng.free(ptr)
+    med = statistics.median
+    fresh_keys = {
+        "fresh_batch_ms": round(med(fresh_ms[1:]), 4),
+        "fresh_batch_GiBps": round(count * size / GIB / (med(fresh_ms[1:]) * 1e-3), 2),
+        "fresh_plan_ms": {k: round(med(v[1:]), 3) if v else 0.0 for k, v in fresh_plan_ms.items()},
+        "fresh_chained_ms": round(med(chained_ms[1:]), 4),
+        "fresh_chained_GiBps": round(count * size / GIB / (med(chained_ms[1:]) * 1e-3), 2),
+        "fresh_chained_plan_ms": {k: round(med(v[1:]), 3) for k, v in chained_plan_ms.items()},
+        "fresh": "host wall clock, median of 3: every plan made for the batch from records in device memory (fresh_batch: with "
+                 "the reference's SHORT_BUFFER -> second call in between, records fetched; fresh_chained: room for every "
+                 "output, encode plan from a stride, decode plan chained on the device), launches, waits",
+    }
     out = {
         "config": {
             "workload": "BASELINE configs[3]: %d buffers x %d B (buffer i = splitmix64 seed 2+i, rank r takes i = r mod N), "
@@ -540,6 +650,7 @@ def run_cfg4(args, ranks, lib, eng):
         },
         "scaling": "strong",
     }
+    out["config"].update(fresh_keys)
     algo = {names_e[0]: n + e_len if names_e[0] == "enc_onepass" else n, names_e[1]: 0, names_e[2]: 0 if names_e[0] == "enc_onepass" else n + e_len,
             "dec_sync": e_len, "dec_scan": 0, "dec_emit": e_len + n}
     rooflines(out, names_e, names_d, kernel_ms, t_enc_ms, t_dec_ms, n, e_len, algo, traffic_measured=False)
@@ -695,6 +806,7 @@ def main():
             o, ln, le, w, kms, te, td, _, _ = fn(*more)
             return {"workload": o["config"]["workload"], "bit_exact": o["config"]["bit_exact"], "steps": more[0].steps,
                     **({"plan_ms": o["config"]["plan_ms"]} if "plan_ms" in o["config"] else {}),
+                    **{k: v for k, v in o["config"].items() if k.startswith("fresh")},
                     "value_GiBps": round(ln / GIB / max((te + td) * 1e-3, 1e-12), 2),
                     "encode_ms": round(te, 4), "decode_ms": round(td, 4),
                     "encode_path_frac_of_hbm_peak": round((ln + le) / max(te * 1e-3, 1e-12) / HBM_PEAK_BYTES_PER_S, 4),

@@ -206,18 +206,56 @@ int aws_huffman_amd_decode_plan_reset(
     size_t item_count);
 
 /*
+ * Plans without a loop over the items on the host: the items are DESCRIBED (a stride: a batch of equal buffers), or their
+ * records already LIE in device memory (made there by the caller's own kernels, or uploaded once and used again).  The
+ * plan's records, segments / chunks and lists are made by a few small launches on `stream` (NULL: the engine's); the
+ * call waits once, for a handful of totals that size the plan's arrays and the launch's grids -- O(1) host work whatever
+ * the number of items (BASELINE configs[3]'s 65 536 buffers: a tenth of a millisecond a plan where the host's loop, its
+ * arrays and their copies took 0.4 - 1.9 ms).  The plan is then good for launches on the same stream, or on another once
+ * that stream has been waited for.  Per item nothing changes: what aws_huffman_encode / aws_huffman_decode do for it.
+ * As for the _reset calls: the plan's previous launch must have finished; a failed call leaves a plan without items.
+ * (Coders with codes of more than 12 bits, or of one length: the decode plan needs what only the host lays out -- the
+ * items are brought to the host and its loop makes the plan; same results, not the same speed.)
+ */
+struct aws_huffman_amd_strided_items {
+    uint64_t count;
+    uint64_t in_offset;    /* item i reads in_len bytes at in_offset + i * in_stride of the launch's input ... */
+    uint64_t in_stride;
+    uint64_t in_len;       /* (symbols to encode / encoded bytes to decode) */
+    uint64_t out_offset;   /* ... and writes at out_offset + i * out_stride of its output, */
+    uint64_t out_stride;
+    uint64_t out_capacity; /* at most this many bytes */
+    uint8_t first_bit;     /* decode: as aws_huffman_amd_decode_item.first_bit, the same for every item */
+    uint8_t eos_padding;   /* encode: as aws_huffman_amd_encode_item.eos_padding (no carried overflow bits) */
+};
+AWS_COMPRESSION_API
+int aws_huffman_amd_encode_plan_reset_strided(
+    struct aws_huffman_amd_encode_plan *plan, const struct aws_huffman_amd_strided_items *items, void *stream);
+AWS_COMPRESSION_API
+int aws_huffman_amd_decode_plan_reset_strided(
+    struct aws_huffman_amd_decode_plan *plan, const struct aws_huffman_amd_strided_items *items, void *stream);
+/* device_items: item_count records of the public layout in DEVICE memory, readable on `stream` */
+AWS_COMPRESSION_API
+int aws_huffman_amd_encode_plan_reset_device_items(
+    struct aws_huffman_amd_encode_plan *plan, const struct aws_huffman_amd_encode_item *device_items, size_t item_count, void *stream);
+AWS_COMPRESSION_API
+int aws_huffman_amd_decode_plan_reset_device_items(
+    struct aws_huffman_amd_decode_plan *plan, const struct aws_huffman_amd_decode_item *device_items, size_t item_count, void *stream);
+
+/*
  * `plan` reset to decode what `encoded`'s LAST LAUNCH produced, made on the device from that launch's records: the
  * encoded lengths never come to the host (encode -> decode of a batch without a round trip).  Decode item i is encode
  * item i's output -- at its out_offset in the buffer that launch wrote, which is the decode launch's input; as many
  * bytes as its record says were produced, whatever the record's verdict; from bit 0 -- decoded to where its symbols came
  * from: out_offset = the encode item's in_offset, out_capacity = its in_len.  The records are written on `stream`
  * (NULL: the engine's): behind the encode launch if that is the launch's stream, and in front of a decode launch on it.
- * Only for batches of short items: when every item, whatever it produced, is one thread's work for the decoder (the
- * most an item can have left is its out_capacity: up to 128 bytes each, or up to 512 / 768 when the batch has
- * thousands of them -- header fields); otherwise AWS_ERROR_UNSUPPORTED_OPERATION, nothing changed, and the caller
- * fetches the lengths (aws_huffman_amd_encode_plan_results) and resets the plan from records.  Both plans on one device;
- * `encoded` must have been launched since it was last filled (AWS_ERROR_INVALID_ARGUMENT otherwise, nothing changed).  A HIP
- * failure inside the call leaves `plan` without items, as a failed reset does.
+ * A batch of short items -- every item, whatever it produced, one thread's work for the decoder (the most an item can have
+ * left is its out_capacity: up to 128 bytes each, or up to 512 / 768 when the batch has thousands of them: header
+ * fields) -- costs the host a few microseconds and no wait.  Any other batch (items with chunks: BASELINE configs[3]'s
+ * 16 KiB buffers) is planned on the device as for aws_huffman_amd_decode_plan_reset_device_items, from the launch's
+ * records: the call waits for the encode launch and a handful of totals; the lengths stay on the device.  Both plans on
+ * one device; `encoded` must have been launched since it was last filled (AWS_ERROR_INVALID_ARGUMENT otherwise, nothing
+ * changed).  A HIP failure inside the call leaves `plan` without items, as a failed reset does.
  */
 AWS_COMPRESSION_API
 int aws_huffman_amd_decode_plan_from_encode(

@@ -162,6 +162,13 @@ class AmdDecodeResult(C.Structure):
     _fields_ = [("rc", C.c_int32), ("error", C.c_int32), ("produced", C.c_uint64), ("bits_consumed", C.c_uint64)]
 
 
+class StridedItems(C.Structure):
+    """struct aws_huffman_amd_strided_items: a batch of equal items a stride apart."""
+    _fields_ = [("count", C.c_uint64), ("in_offset", C.c_uint64), ("in_stride", C.c_uint64), ("in_len", C.c_uint64),
+                ("out_offset", C.c_uint64), ("out_stride", C.c_uint64), ("out_capacity", C.c_uint64),
+                ("first_bit", C.c_uint8), ("eos_padding", C.c_uint8)]
+
+
 class PlanStats(C.Structure):
     """struct aws_huffman_amd_plan_stats: how a plan's items are taken (which kernels an item goes through)."""
     _fields_ = [(name, C.c_uint64) for name in (
@@ -239,6 +246,8 @@ EXPORTED_SYMBOLS = [
     "aws_huffman_amd_testing_set_wide_min_bytes",
     "aws_huffman_amd_testing_set_encode_road", "aws_huffman_amd_testing_set_decode_road",
     "aws_huffman_amd_testing_set_items_per_byte", "aws_huffman_amd_encode_plan_stats", "aws_huffman_amd_decode_plan_stats",
+    "aws_huffman_amd_encode_plan_reset_strided", "aws_huffman_amd_decode_plan_reset_strided",
+    "aws_huffman_amd_encode_plan_reset_device_items", "aws_huffman_amd_decode_plan_reset_device_items",
     "aws_huffman_amd_engine_device", "aws_huffman_amd_current_device", "aws_huffman_amd_encode_plan_reset",
     "aws_huffman_amd_decode_plan_reset", "aws_huffman_amd_decode_plan_from_encode",
     "aws_huffman_amd_device_count", "aws_huffman_amd_device_alloc", "aws_huffman_amd_device_free",
@@ -303,6 +312,10 @@ def load_product(path=None):
     _bind(lib, "aws_huffman_amd_testing_set_encode_road", None, [C.c_uint32])
     _bind(lib, "aws_huffman_amd_testing_set_decode_road", None, [C.c_uint32])
     _bind(lib, "aws_huffman_amd_testing_set_items_per_byte", None, [C.c_uint64, C.c_uint64])
+    _bind(lib, "aws_huffman_amd_encode_plan_reset_strided", C.c_int, [V, P(StridedItems), V])
+    _bind(lib, "aws_huffman_amd_decode_plan_reset_strided", C.c_int, [V, P(StridedItems), V])
+    _bind(lib, "aws_huffman_amd_encode_plan_reset_device_items", C.c_int, [V, V, C.c_size_t, V])
+    _bind(lib, "aws_huffman_amd_decode_plan_reset_device_items", C.c_int, [V, V, C.c_size_t, V])
     _bind(lib, "aws_huffman_amd_encode_plan_stats", C.c_int, [V, P(PlanStats)])
     _bind(lib, "aws_huffman_amd_decode_plan_stats", C.c_int, [V, P(PlanStats)])
     _bind(lib, "aws_huffman_amd_device_count", C.c_int, [])
@@ -382,6 +395,64 @@ class Engine:
             raise RuntimeError("encode_plan_new failed, error %d" % self.lib.aws_last_error())
         return plan
 
+    def _encode_item_array(self, items):
+        arr = (AmdEncodeItem * max(len(items), 1))()
+        for i, it in enumerate(items):
+            arr[i].in_offset, arr[i].in_len = it["in_offset"], it["in_len"]
+            arr[i].out_offset, arr[i].out_capacity = it["out_offset"], it["out_capacity"]
+            ov = it.get("overflow_in", (0, 0))
+            arr[i].overflow_in.pattern, arr[i].overflow_in.num_bits = ov
+            arr[i].eos_padding = it.get("eos_padding", 0xFF)
+        return arr
+
+    def empty_encode_plan(self):
+        plan = C.c_void_p()
+        assert self.lib.aws_huffman_amd_encode_plan_new(C.byref(plan), self.h, None, 0) == 0
+        return plan
+
+    def empty_decode_plan(self):
+        plan = C.c_void_p()
+        assert self.lib.aws_huffman_amd_decode_plan_new(C.byref(plan), self.h, None, 0) == 0
+        return plan
+
+    def encode_plan_from_device_items(self, items, plan=None):
+        """The items' records uploaded, the plan made from them ON THE DEVICE (no host loop over the items).  Returns
+        (plan, device array): the array is the caller's to free."""
+        arr = self._encode_item_array(items)
+        d_items = self.alloc(C.sizeof(arr))
+        self.upload(d_items, np.frombuffer(arr, dtype=np.uint8))
+        plan = plan or self.empty_encode_plan()
+        t0 = time.perf_counter()
+        rc = self.lib.aws_huffman_amd_encode_plan_reset_device_items(plan, d_items, len(items), None)
+        self.last_plan_ms = (time.perf_counter() - t0) * 1e3
+        if rc != 0:
+            raise RuntimeError("encode_plan_reset_device_items failed, error %d" % self.lib.aws_last_error())
+        return plan, d_items
+
+    def decode_plan_from_device_items(self, items, plan=None):
+        arr = self._decode_item_array(items)
+        d_items = self.alloc(C.sizeof(arr))
+        self.upload(d_items, np.frombuffer(arr, dtype=np.uint8))
+        plan = plan or self.empty_decode_plan()
+        t0 = time.perf_counter()
+        rc = self.lib.aws_huffman_amd_decode_plan_reset_device_items(plan, d_items, len(items), None)
+        self.last_plan_ms = (time.perf_counter() - t0) * 1e3
+        if rc != 0:
+            raise RuntimeError("decode_plan_reset_device_items failed, error %d" % self.lib.aws_last_error())
+        return plan, d_items
+
+    def plan_strided(self, encode, plan=None, **fields):
+        """A plan of `count` equal items a stride apart, made on the device from the description alone."""
+        desc = StridedItems(**fields)
+        plan = plan or (self.empty_encode_plan() if encode else self.empty_decode_plan())
+        fn = self.lib.aws_huffman_amd_encode_plan_reset_strided if encode else self.lib.aws_huffman_amd_decode_plan_reset_strided
+        t0 = time.perf_counter()
+        rc = fn(plan, C.byref(desc), None)
+        self.last_plan_ms = (time.perf_counter() - t0) * 1e3
+        if rc != 0:
+            raise RuntimeError("plan_reset_strided failed, error %d" % self.lib.aws_last_error())
+        return plan
+
     def encode_launch(self, plan, d_in, d_out, length_only=False, events=None):
         assert self.lib.aws_huffman_amd_encode_plan_launch_staged(plan, d_in, d_out, length_only, None, events) == 0
 
@@ -417,12 +488,16 @@ class Engine:
         assert self.lib.aws_huffman_amd_encode_plan_encoded_lengths(plan, out, None) == 0
         return list(out[:n])
 
-    def decode_plan(self, items):
+    def _decode_item_array(self, items):
         arr = (AmdDecodeItem * max(len(items), 1))()
         for i, it in enumerate(items):
             arr[i].in_offset, arr[i].in_len = it["in_offset"], it["in_len"]
             arr[i].first_bit = it.get("first_bit", 0)
             arr[i].out_offset, arr[i].out_capacity = it["out_offset"], it["out_capacity"]
+        return arr
+
+    def decode_plan(self, items):
+        arr = self._decode_item_array(items)
         plan = C.c_void_p()
         t0 = time.perf_counter()
         rc = self.lib.aws_huffman_amd_decode_plan_new(C.byref(plan), self.h, arr, len(items))

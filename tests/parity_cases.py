@@ -902,8 +902,11 @@ def encode_then_decode_on_the_device(w, seed=119, engine=None, batches=((40, 50)
         eng.lib.aws_huffman_amd_decode_plan_destroy(dplan)
         for ptr in (d_in, d_enc, d_back):
             eng.free(ptr)
-    # a batch that is not one of short items: refused, the decode plan as it was
+    # a batch that is not one of short items: the general plan, made on the device from the launch's records all the same
+    # (plans_made_on_the_device has the whole of it)
     d_in = eng.alloc(70000)
+    both = inputs(rng, 70000, "uniform")
+    eng.upload(d_in, both)
     eplan = eng.encode_plan([dict(in_offset=0, in_len=10, out_offset=0, out_capacity=40),
                              dict(in_offset=100, in_len=30000, out_offset=100, out_capacity=60000)])
     dplan = C.c_void_p()  # (a plan of no items, from no array at all)
@@ -917,11 +920,20 @@ def encode_then_decode_on_the_device(w, seed=119, engine=None, batches=((40, 50)
     assert eng.lib.aws_last_error() == harness.AWS_ERROR_INVALID_ARGUMENT, eng.lib.aws_last_error()
     d_enc = eng.alloc(70000)
     eng.encode_launch(eplan, d_in, d_enc)
-    assert not eng.decode_plan_from_encode(dplan, eplan)
+    assert eng.decode_plan_from_encode(dplan, eplan)
+    assert eng.decode_stats(dplan)["by_pieces"] == 1 and eng.decode_stats(dplan)["by_thread"] == 1
+    d_back = eng.alloc(70000)
+    eng.fill(d_back, SENTINEL, 70000)
+    eng.decode_launch(dplan, d_enc, d_back)
+    assert [r[:3] for r in eng.decode_results(dplan, 2)] == [(0, 0, 10), (0, 0, 30000)]
+    back = eng.download(d_back, 70000)
+    assert np.array_equal(back[:10], both[:10]) and np.array_equal(back[100:30100], both[100:30100])
+    assert np.all(back[10:100] == SENTINEL) and np.all(back[30100:] == SENTINEL)
     eng.lib.aws_huffman_amd_encode_plan_destroy(eplan)
     eng.lib.aws_huffman_amd_decode_plan_destroy(dplan)
     eng.free(d_in)
     eng.free(d_enc)
+    eng.free(d_back)
     if engine is None:
         eng.close()
 
@@ -1388,6 +1400,189 @@ def streams_with_two_last_chunks(w, seed=127, engine=None, modes=(None, "lean-sy
             ("mixed with short ones", [cut_to(32775), short(900), cut_to(65537), cut_to(32770), short(1500), cut_to(32771)]),
             ("more short ones than long", [short(700), cut_to(32772), short(800), short(2000), cut_to(65540), short(40)])):
         decode_items_like_the_oracle(w, eng, w.ocoder, streams, rng, label, modes=modes, kinds=1)
+    if engine is None:
+        eng.close()
+
+
+def plans_made_on_the_device(w, seed=131, engine=None, big=2_200_000, n_small=300):
+    """A plan made on the device -- from the caller's records lying in DEVICE memory, from a stride, or (decode) from what
+    an encode launch left -- is the plan the host's loop makes: the same counts (aws_huffman_amd_*_plan_stats), and for
+    the same buffers the same records, output bytes and guard bytes.  Items of every class in one plan: empty, one
+    thread's work, one wave's, a chunk or a few, two end-of-stream chunks, more than 64 chunks / segments; carried
+    overflow bits, short outputs, first-bit offsets, cut and damaged streams; then batches of equal buffers by stride
+    (BASELINE configs[3]'s shape, some with too little room), and encode -> decode of such a batch without its lengths
+    ever coming to the host."""
+    rng = np.random.default_rng(seed)
+    eng = engine or harness.Engine(w.product.lib, w.pcoder)
+    lib = eng.lib
+
+    # ---- encode: host records against the same records in device memory
+    lens = [0, 0, 1, 100, 128, 129, 600, 1024, 1025, 5000, 16384, 16385, 40_000, big] + [int(x) for x in rng.integers(0, 3000, n_small)]
+    blobs = [inputs(rng, n, KINDS[i % 4]) for i, n in enumerate(lens)]
+    in_offs, pos = [], 5
+    for b in blobs:
+        in_offs.append(pos)
+        pos += b.size + int(rng.integers(0, 4))
+    host_in = np.zeros(pos + 64, np.uint8)
+    for b, o in zip(blobs, in_offs):
+        host_in[o:o + b.size] = b
+    items, pos = [], 3
+    for i, b in enumerate(blobs):
+        ov = (int(rng.integers(0, 1 << 7)), 7) if i % 5 == 1 else (0, 0)
+        full = (ov[1] + 10 * b.size + 7) // 8 + 2
+        cap = [full, full, max(full // 2, 0), full, 0][i % 5] if b.size < 50_000 else full
+        items.append(dict(in_offset=in_offs[i], in_len=b.size, out_offset=pos, out_capacity=cap, overflow_in=ov,
+                          eos_padding=[0xFF, 0x00, 0xA5][i % 3]))
+        pos += cap + int(rng.integers(1, 9))
+    out_total = pos + 64
+    d_in, d_a, d_b = eng.alloc(host_in.size), eng.alloc(out_total), eng.alloc(out_total)
+    eng.upload(d_in, host_in)
+    host_plan = eng.encode_plan(items)
+    dev_plan, d_items = eng.encode_plan_from_device_items(items)
+    assert eng.encode_stats(host_plan) == eng.encode_stats(dev_plan), (eng.encode_stats(host_plan), eng.encode_stats(dev_plan))
+    assert eng.encode_stats(dev_plan)["by_pieces"] >= 4 and eng.encode_stats(dev_plan)["by_thread"] >= 3
+    for d_out, plan in ((d_a, host_plan), (d_b, dev_plan)):
+        eng.fill(d_out, SENTINEL, out_total)
+        eng.encode_launch(plan, d_in, d_out)
+    res_host, res_dev = eng.encode_results(host_plan, len(items)), eng.encode_results(dev_plan, len(items))
+    assert res_host == res_dev, [(i, a, b) for i, (a, b) in enumerate(zip(res_host, res_dev)) if a != b][:3]
+    assert len({r[:2] for r in res_host}) >= 2
+    enc_all = eng.download(d_a, out_total)
+    assert np.array_equal(enc_all, eng.download(d_b, out_total)), "encode: the device-made plan wrote other bytes"
+    # (and the host-made plan is the oracle's: a few items of every class)
+    for i in list(range(14)) + [20, 21]:
+        e = w.oracle.new_encoder(w.ocoder, eos_padding=items[i]["eos_padding"])
+        e.overflow_bits.pattern, e.overflow_bits.num_bits = items[i]["overflow_in"]
+        c = items[i]["out_capacity"]
+        dst = np.full(c + 1, SENTINEL, np.uint8)
+        r = w.oracle.encode_call(e, blobs[i], 0, dst, 0, c)
+        assert res_host[i] == (r.rc, r.err, r.consumed, r.produced, r.state[0], r.state[1]), (i, res_host[i], r)
+        assert np.array_equal(enc_all[items[i]["out_offset"]:items[i]["out_offset"] + c], dst[:c]), i
+
+    # ---- decode what was written (whole streams, cut ones, a damaged one, a first-bit offset, short outputs):
+    # host records, the same in device memory, and -- for the whole ones -- chained to the encode plan
+    ditems = []
+    for i, (it, r) in enumerate(zip(items, res_host)):
+        produced = r[3]
+        in_len = produced if i % 7 else produced // 2  # (every seventh cut in half)
+        cap = [it["in_len"], it["in_len"] + 5, it["in_len"] // 2][i % 3] if it["in_len"] < 50_000 else it["in_len"]
+        ditems.append(dict(in_offset=it["out_offset"], in_len=in_len, first_bit=0, out_offset=it["in_offset"], out_capacity=cap))
+    damaged = int(np.argmax(lens))
+    bad = eng.download(d_a, 8, offset=items[damaged]["out_offset"] + 1_000_000)
+    eng.upload(d_a, np.full(4, 0xFF, np.uint8), offset=items[damaged]["out_offset"] + 1_000_000)
+    sym_total = host_in.size
+    d_sa, d_sb = eng.alloc(sym_total), eng.alloc(sym_total)
+    host_dplan = eng.decode_plan(ditems)
+    dev_dplan, d_ditems = eng.decode_plan_from_device_items(ditems)
+    assert eng.decode_stats(host_dplan) == eng.decode_stats(dev_dplan), (eng.decode_stats(host_dplan), eng.decode_stats(dev_dplan))
+    st = eng.decode_stats(dev_dplan)
+    assert st["by_pieces"] >= 4 and st["by_thread"] >= 3 and st["by_wave"] >= 1 and st["end_pieces_packed"] + st["end_pieces_single"] >= 4, st
+    for d_out, plan in ((d_sa, host_dplan), (d_sb, dev_dplan)):
+        eng.fill(d_out, SENTINEL, sym_total)
+        eng.decode_launch(plan, d_a, d_out)
+    dres_host, dres_dev = eng.decode_results(host_dplan, len(ditems)), eng.decode_results(dev_dplan, len(ditems))
+    assert dres_host == dres_dev, [(i, a, b) for i, (a, b) in enumerate(zip(dres_host, dres_dev)) if a != b][:3]
+    assert len({r[:2] for r in dres_host}) >= 3  # (whole, short of room, a symbol without a code)
+    assert np.array_equal(eng.download(d_sa, sym_total), eng.download(d_sb, sym_total)), "decode: the device-made plan wrote other bytes"
+    eng.upload(d_a, bad[:4], offset=items[damaged]["out_offset"] + 1_000_000)
+    # chained: what the encode launch of dev_plan left in d_b, decoded back to where it came from
+    chained = eng.empty_decode_plan()
+    eng.encode_launch(dev_plan, d_in, d_b)
+    assert eng.decode_plan_from_encode(chained, dev_plan)
+    st = eng.decode_stats(chained)
+    assert st["items"] == len(items) and st["by_pieces"] >= 4, st
+    eng.fill(d_sb, SENTINEL, sym_total)
+    eng.decode_launch(chained, d_b, d_sb)
+    cres = eng.decode_results(chained, len(items))
+    back = eng.download(d_sb, sym_total)
+    want = np.full(sym_total, SENTINEL, np.uint8)
+    for i, (it, r) in enumerate(zip(items, res_host)):
+        # (what was consumed comes back -- but for the symbol whose code was cut by a short output, and for carried bits,
+        #  which are somebody else's symbols: only items encoded whole from nothing are compared byte by byte)
+        # (nor items padded with other bits than ones: those may read as one more symbol, reference huffman.h "eos_padding")
+        if r[0] == 0 and it["overflow_in"][1] == 0 and it["eos_padding"] == 0xFF:
+            assert cres[i][:3] == (0, 0, it["in_len"]), (i, cres[i], it)
+            want[it["in_offset"]:it["in_offset"] + it["in_len"]] = blobs[i]
+        else:
+            want[it["in_offset"]:it["in_offset"] + it["in_len"]] = back[it["in_offset"]:it["in_offset"] + it["in_len"]]
+    assert np.array_equal(back, want), "chained decode: wrong symbols, or bytes outside an item"
+    for plan in (host_plan, dev_plan):
+        lib.aws_huffman_amd_encode_plan_destroy(plan)
+    for plan in (host_dplan, dev_dplan, chained):
+        lib.aws_huffman_amd_decode_plan_destroy(plan)
+    for ptr in (d_in, d_a, d_b, d_sa, d_sb, d_items, d_ditems):
+        eng.free(ptr)
+
+    # ---- batches of equal buffers by stride: 16 KiB and 700 B, with room and with too little
+    for count, size, cap in ((70, 16384, 2 * 16384), (70, 16384, 16384), (5000, 700, 1400), (5000, 100, 90), (3, 2_000_000, 4_000_000)):
+        data = inputs(rng, count * size, "uniform")
+        d_in, d_enc1, d_enc2, d_back = eng.alloc(data.size + 64), eng.alloc(count * cap + 64), eng.alloc(count * cap + 64), eng.alloc(data.size + 64)
+        eng.upload(d_in, data)
+        host_items = [dict(in_offset=k * size, in_len=size, out_offset=k * cap, out_capacity=cap, eos_padding=0xFF) for k in range(count)]
+        host_plan = eng.encode_plan(host_items)
+        strided = eng.plan_strided(True, count=count, in_offset=0, in_stride=size, in_len=size, out_offset=0, out_stride=cap,
+                                   out_capacity=cap, eos_padding=0xFF)
+        assert eng.encode_stats(host_plan) == eng.encode_stats(strided), (count, size, eng.encode_stats(host_plan), eng.encode_stats(strided))
+        for d_out, plan in ((d_enc1, host_plan), (d_enc2, strided)):
+            eng.fill(d_out, SENTINEL, count * cap + 64)
+            eng.encode_launch(plan, d_in, d_out)
+        r1, r2 = eng.encode_results(host_plan, count), eng.encode_results(strided, count)
+        assert r1 == r2, (count, size, cap)
+        assert np.array_equal(eng.download(d_enc1, count * cap + 64), eng.download(d_enc2, count * cap + 64)), (count, size, cap)
+        # decode of the strided launch's output, chained (lengths on the device only) and by stride where every item is whole
+        chained = eng.empty_decode_plan()
+        assert eng.decode_plan_from_encode(chained, strided)
+        eng.fill(d_back, SENTINEL, data.size + 64)
+        eng.decode_launch(chained, d_enc2, d_back)
+        cres = eng.decode_results(chained, count)
+        back = eng.download(d_back, data.size + 64)
+        for k in range(count):
+            if r1[k][0] == 0:
+                assert cres[k][:3] == (0, 0, size), (count, size, cap, k, cres[k])
+                assert np.array_equal(back[k * size:(k + 1) * size], data[k * size:(k + 1) * size]), (count, size, cap, k)
+            else:
+                # the room ran out: the symbols whose codes went out whole come back (the cut one does not)
+                assert r1[k][:2] == (-1, harness.AWS_ERROR_SHORT_BUFFER) and cres[k][2] in (r1[k][2] - 1, r1[k][2]), (k, r1[k], cres[k])
+                assert np.array_equal(back[k * size:k * size + r1[k][2] - 1], data[k * size:k * size + r1[k][2] - 1])
+        assert np.all(back[data.size:] == SENTINEL)
+        if all(r[0] == 0 for r in r1) and len({r[3] for r in r1}) == 1:
+            pass  # (equal encoded lengths happen for no random batch: the decode-by-stride case is made below)
+        lib.aws_huffman_amd_encode_plan_destroy(host_plan)
+        lib.aws_huffman_amd_encode_plan_destroy(strided)
+        lib.aws_huffman_amd_decode_plan_destroy(chained)
+        for ptr in (d_in, d_enc1, d_enc2, d_back):
+            eng.free(ptr)
+    # decode by stride: equal slots of encoded bytes, each holding a stream and then other bytes -- every item is "the slot",
+    # and what lies behind a stream's end is decoded on (or stops it) exactly as for the oracle
+    for count, slot, n_sym in ((40, 20000, 16384), (3000, 300, 200)):
+        streams = [oracle_encode(w, inputs(rng, n_sym, "uniform"), eos=0x00) for _ in range(count)]
+        assert max(e.size for e in streams) <= slot
+        blob = rng.integers(0, 256, count * slot + 64, dtype=np.uint8)
+        for k, e in enumerate(streams):
+            blob[k * slot:k * slot + e.size] = e
+        cap = n_sym + 40
+        d_enc, d_s1, d_s2 = eng.alloc(blob.size), eng.alloc(count * cap + 64), eng.alloc(count * cap + 64)
+        eng.upload(d_enc, blob)
+        host_items = [dict(in_offset=k * slot, in_len=slot, out_offset=k * cap, out_capacity=cap) for k in range(count)]
+        host_plan = eng.decode_plan(host_items)
+        strided = eng.plan_strided(False, count=count, in_offset=0, in_stride=slot, in_len=slot, out_offset=0, out_stride=cap, out_capacity=cap)
+        assert eng.decode_stats(host_plan) == eng.decode_stats(strided)
+        for d_out, plan in ((d_s1, host_plan), (d_s2, strided)):
+            eng.fill(d_out, SENTINEL, count * cap + 64)
+            eng.decode_launch(plan, d_enc, d_out)
+        assert eng.decode_results(host_plan, count) == eng.decode_results(strided, count)
+        got = eng.download(d_s2, count * cap + 64)
+        assert np.array_equal(eng.download(d_s1, count * cap + 64), got)
+        for k in (0, 1, count - 1):
+            d = w.oracle.new_decoder(w.ocoder)
+            dst = np.full(cap + 1, SENTINEL, np.uint8)
+            r = w.oracle.decode_call(d, blob[k * slot:(k + 1) * slot], 0, slot, dst, 0, cap)
+            assert eng.decode_results(strided, count)[k][:3] == (r.rc, r.err, r.produced), (k, r)
+            assert np.array_equal(got[k * cap:(k + 1) * cap], dst[:cap]), k
+        lib.aws_huffman_amd_decode_plan_destroy(host_plan)
+        lib.aws_huffman_amd_decode_plan_destroy(strided)
+        for ptr in (d_enc, d_s1, d_s2):
+            eng.free(ptr)
     if engine is None:
         eng.close()
 

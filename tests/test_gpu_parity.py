@@ -120,6 +120,10 @@ def test_streams_with_two_last_chunks(world):
     pc.streams_with_two_last_chunks(world)
 
 
+def test_plans_made_on_the_device(world):
+    pc.plans_made_on_the_device(world)
+
+
 
 def test_survey_records(world):
     pc.survey_records_on_product(world, names=("G4K", "G16K", "G16KP", "G1M"))
