@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=("stream", "cfg4", "host-abi"), default="stream")
+    ap.add_argument("--no-fresh", action="store_true", help="cfg4: without the fresh-batch measurements (profiling runs: only the timed step's launches)")
     ap.add_argument("--bytes", type=int, default=GIB, help="stream: bytes per GPU (default 1 GiB, the BASELINE config); host-abi: bytes per call (default 256 MiB)")
     ap.add_argument("--buffers", type=int, default=65536, help="cfg4: buffers in the batch")
     ap.add_argument("--buffer-bytes", type=int, default=16384, help="cfg4: bytes per buffer")
@@ -303,9 +304,11 @@ def digest_of(eng, ptr, size):
     return h.hexdigest()
 
 
-def rooflines(out, names_e, names_d, kernel_ms, t_enc_ms, t_dec_ms, n, e_len, algo_per_kernel, traffic_measured=True):
-    # (the committed counter passes are of the 1 GiB stream: another workload's `traffic` is null, not the stream's figure)
-    traffic = load_traffic() if traffic_measured else None
+def rooflines(out, names_e, names_d, kernel_ms, t_enc_ms, t_dec_ms, n, e_len, algo_per_kernel, traffic_measured=True, traffic_file="pmc_traffic.json"):
+    # (the committed counter passes are per workload: the 1 GiB stream's, BASELINE configs[3]'s; any other workload's
+    # `traffic` is null, not another workload's figure)
+    traffic = load_traffic(traffic_file) if traffic_measured else None
+    traffic_measured = traffic is not None
     enc = roofline_of("encode", names_e, n + e_len, t_enc_ms, traffic)
     dec = roofline_of("decode", names_d, n + e_len, t_dec_ms, traffic)
     out["roofline_encode"], out["roofline_decode"] = enc, dec
@@ -340,9 +343,17 @@ def run_stream(args, ranks, lib, eng):
     in_digest = digest_of(eng, d_in, n)
     assert digest_of(eng, d_back, n) == in_digest, "round trip is not bit-exact"
     enc_digest = digest_of(eng, d_enc, e_len)
+    pinned_by = None
     if n == GIB and seed == 5:
         pinned = harness.load_json("survey_probe_records.json")["streams"]["G1G"]
         assert (e_len, enc_digest) == (pinned["encoded_len"], pinned["sha256_encoded"]), "encoded stream differs from the reference's"
+        pinned_by = "the survey's record of the real reference (tests/golden/survey_probe_records.json)"
+    elif n == GIB and str(seed) in harness.load_json("config5_stream_pins.json")["streams"]:
+        # configs[4]: rank g's stream is seed 5 + g; seeds 6 .. 12 are pinned by the oracle (tests/golden/make_config5_pins.py)
+        pinned = harness.load_json("config5_stream_pins.json")["streams"][str(seed)]
+        assert in_digest == pinned["sha256_input"], "rank %d: input stream differs from the pinned one" % ranks.rank
+        assert (e_len, enc_digest) == (pinned["encoded_len"], pinned["sha256_encoded"]), "rank %d: encoded stream differs from the oracle's" % ranks.rank
+        pinned_by = "the pinned oracle's record (tests/golden/config5_stream_pins.json)"
 
     names_e, names_d = stage_names(lib, eng)
     stages = Stages(eng, args.steps, names_e, names_d)
@@ -389,7 +400,7 @@ def run_stream(args, ranks, lib, eng):
     algo = {names_e[0]: n + e_len if names_e[0] == "enc_onepass" else n, names_e[1]: 0, names_e[2]: 0 if names_e[0] == "enc_onepass" else n + e_len,
             "dec_sync": e_len, "dec_scan": 0, "dec_emit": e_len + n}
     rooflines(out, names_e, names_d, kernel_ms, t_enc_ms, t_dec_ms, n, e_len, algo)
-    per_rank = {"rank": ranks.rank, "seed": seed, "encoded_bytes": e_len, "sha256_encoded": enc_digest,
+    per_rank = {"rank": ranks.rank, "seed": seed, "encoded_bytes": e_len, "sha256_encoded": enc_digest, "pinned_by": pinned_by,
                 "encode_ms": round(t_enc_ms, 4), "decode_ms": round(t_dec_ms, 4)}
     return out, n, e_len, wall, kernel_ms, t_enc_ms, t_dec_ms, per_rank, seed
 
@@ -557,85 +568,87 @@ def run_cfg4(args, ranks, lib, eng):
     assert bit_exact, "the timed steps did not leave the batch's round trip"
     kernel_ms, t_enc_ms, t_dec_ms = stages.medians()
 
-    # ---- a batch that is NEW: every plan made for it, from records in device memory (no loop over the items on the host),
-    # with what the reference's contract makes the host do in between -- look at the records of the first call to learn
-    # which buffers ran out of room and with what carried bits, then call again for those.
-    enc_arr = eng._encode_item_array(items)
-    d_items1 = eng.alloc(C.sizeof(enc_arr))
-    eng.upload(d_items1, np.frombuffer(enc_arr, dtype=np.uint8))
-    res_arr = eng._encode_item_array(resume) if resume else None
-    d_items2 = eng.alloc(C.sizeof(res_arr)) if resume else None
-    dec_arr = eng._decode_item_array([dict(in_offset=k * stride, in_len=lengths[k], out_offset=k * size, out_capacity=size) for k in range(count)])
-    d_items3 = eng.alloc(C.sizeof(dec_arr))
-    f1, f2, f3 = eng.empty_encode_plan(), eng.empty_encode_plan(), eng.empty_decode_plan()
-    fresh_plan_ms = {"encode": [], "encode_resume": [], "decode": []}
-    fresh_ms = []
-    res_buf = (harness.AmdEncodeResult * count)()
-    for rep_k in range(4):
-        t_start = time.perf_counter()
-        t0 = time.perf_counter()
-        assert lib.aws_huffman_amd_encode_plan_reset_device_items(f1, d_items1, count, None) == 0
-        fresh_plan_ms["encode"].append((time.perf_counter() - t0) * 1e3)
-        eng.encode_launch(f1, d_in, d_out)
-        assert lib.aws_huffman_amd_encode_plan_results(f1, res_buf, None) == 0  # (the records: which buffers want a second call)
-        if resume:
+    fresh_keys = {}
+    if not getattr(args, "no_fresh", False):
+        # ---- a batch that is NEW: every plan made for it, from records in device memory (no loop over the items on the host),
+        # with what the reference's contract makes the host do in between -- look at the records of the first call to learn
+        # which buffers ran out of room and with what carried bits, then call again for those.
+        enc_arr = eng._encode_item_array(items)
+        d_items1 = eng.alloc(C.sizeof(enc_arr))
+        eng.upload(d_items1, np.frombuffer(enc_arr, dtype=np.uint8))
+        res_arr = eng._encode_item_array(resume) if resume else None
+        d_items2 = eng.alloc(C.sizeof(res_arr)) if resume else None
+        dec_arr = eng._decode_item_array([dict(in_offset=k * stride, in_len=lengths[k], out_offset=k * size, out_capacity=size) for k in range(count)])
+        d_items3 = eng.alloc(C.sizeof(dec_arr))
+        f1, f2, f3 = eng.empty_encode_plan(), eng.empty_encode_plan(), eng.empty_decode_plan()
+        fresh_plan_ms = {"encode": [], "encode_resume": [], "decode": []}
+        fresh_ms = []
+        res_buf = (harness.AmdEncodeResult * count)()
+        for rep_k in range(4):
+            t_start = time.perf_counter()
             t0 = time.perf_counter()
-            eng.upload(d_items2, np.frombuffer(res_arr, dtype=np.uint8))
-            assert lib.aws_huffman_amd_encode_plan_reset_device_items(f2, d_items2, len(resume), None) == 0
-            fresh_plan_ms["encode_resume"].append((time.perf_counter() - t0) * 1e3)
-            eng.encode_launch(f2, d_in, d_out)
-            assert lib.aws_huffman_amd_encode_plan_results(f2, res_buf, None) == 0
-        t0 = time.perf_counter()
-        eng.upload(d_items3, np.frombuffer(dec_arr, dtype=np.uint8))  # (the streams' lengths: known on the host from the records)
-        assert lib.aws_huffman_amd_decode_plan_reset_device_items(f3, d_items3, count, None) == 0
-        fresh_plan_ms["decode"].append((time.perf_counter() - t0) * 1e3)
-        eng.decode_launch(f3, d_out, d_back)
-        eng.sync()
-        fresh_ms.append((time.perf_counter() - t_start) * 1e3)
-    fres = eng.decode_results(f3, count)
-    assert all(r[0] == 0 and r[2] == size for r in fres) and digest_of(eng, d_back, count * size) == digest_of(eng, d_in, count * size)
-    # ... and with room for every output: encode plan from a STRIDE, decode plan chained to the launch on the device -- not one
-    # record comes to the host before the end
-    roomy = eng.empty_encode_plan()
-    chained = eng.empty_decode_plan()
-    desc = harness.StridedItems(count=count, in_offset=0, in_stride=size, in_len=size, out_offset=0, out_stride=stride,
-                                out_capacity=stride, eos_padding=0xFF)
-    lib.aws_huffman_amd_decode_plan_from_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-    chained_ms, chained_plan_ms = [], {"encode": [], "decode": []}
-    for rep_k in range(4):
-        eng.fill(d_back, 0xEE, count * size)
-        eng.sync()
-        t_start = time.perf_counter()
-        assert lib.aws_huffman_amd_encode_plan_reset_strided(roomy, C.byref(desc), None) == 0
-        chained_plan_ms["encode"].append((time.perf_counter() - t_start) * 1e3)
-        eng.encode_launch(roomy, d_in, d_out)
-        t0 = time.perf_counter()
-        assert lib.aws_huffman_amd_decode_plan_from_encode(chained, roomy, None) == 0
-        chained_plan_ms["decode"].append((time.perf_counter() - t0) * 1e3)  # (includes the wait for the encode launch)
-        eng.decode_launch(chained, d_out, d_back)
-        eng.sync()
-        chained_ms.append((time.perf_counter() - t_start) * 1e3)
-    cres = eng.decode_results(chained, count)
-    assert all(r[0] == 0 and r[2] == size for r in cres) and digest_of(eng, d_back, count * size) == digest_of(eng, d_in, count * size)
-    for pl in (f1, f2, roomy):
-        lib.aws_huffman_amd_encode_plan_destroy(pl)
-    for pl in (f3, chained):
-        lib.aws_huffman_amd_decode_plan_destroy(pl)
-    for ptr in (d_items1, d_items2, d_items3):
-        if ptr:
-            eng.free(ptr)
-    med = statistics.median
-    fresh_keys = {
-        "fresh_batch_ms": round(med(fresh_ms[1:]), 4),
-        "fresh_batch_GiBps": round(count * size / GIB / (med(fresh_ms[1:]) * 1e-3), 2),
-        "fresh_plan_ms": {k: round(med(v[1:]), 3) if v else 0.0 for k, v in fresh_plan_ms.items()},
-        "fresh_chained_ms": round(med(chained_ms[1:]), 4),
-        "fresh_chained_GiBps": round(count * size / GIB / (med(chained_ms[1:]) * 1e-3), 2),
-        "fresh_chained_plan_ms": {k: round(med(v[1:]), 3) for k, v in chained_plan_ms.items()},
-        "fresh": "host wall clock, median of 3: every plan made for the batch from records in device memory (fresh_batch: with "
-                 "the reference's SHORT_BUFFER -> second call in between, records fetched; fresh_chained: room for every "
-                 "output, encode plan from a stride, decode plan chained on the device), launches, waits",
-    }
+            assert lib.aws_huffman_amd_encode_plan_reset_device_items(f1, d_items1, count, None) == 0
+            fresh_plan_ms["encode"].append((time.perf_counter() - t0) * 1e3)
+            eng.encode_launch(f1, d_in, d_out)
+            assert lib.aws_huffman_amd_encode_plan_results(f1, res_buf, None) == 0  # (the records: which buffers want a second call)
+            if resume:
+                t0 = time.perf_counter()
+                eng.upload(d_items2, np.frombuffer(res_arr, dtype=np.uint8))
+                assert lib.aws_huffman_amd_encode_plan_reset_device_items(f2, d_items2, len(resume), None) == 0
+                fresh_plan_ms["encode_resume"].append((time.perf_counter() - t0) * 1e3)
+                eng.encode_launch(f2, d_in, d_out)
+                assert lib.aws_huffman_amd_encode_plan_results(f2, res_buf, None) == 0
+            t0 = time.perf_counter()
+            eng.upload(d_items3, np.frombuffer(dec_arr, dtype=np.uint8))  # (the streams' lengths: known on the host from the records)
+            assert lib.aws_huffman_amd_decode_plan_reset_device_items(f3, d_items3, count, None) == 0
+            fresh_plan_ms["decode"].append((time.perf_counter() - t0) * 1e3)
+            eng.decode_launch(f3, d_out, d_back)
+            eng.sync()
+            fresh_ms.append((time.perf_counter() - t_start) * 1e3)
+        fres = eng.decode_results(f3, count)
+        assert all(r[0] == 0 and r[2] == size for r in fres) and digest_of(eng, d_back, count * size) == digest_of(eng, d_in, count * size)
+        # ... and with room for every output: encode plan from a STRIDE, decode plan chained to the launch on the device -- not one
+        # record comes to the host before the end
+        roomy = eng.empty_encode_plan()
+        chained = eng.empty_decode_plan()
+        desc = harness.StridedItems(count=count, in_offset=0, in_stride=size, in_len=size, out_offset=0, out_stride=stride,
+                                    out_capacity=stride, eos_padding=0xFF)
+        lib.aws_huffman_amd_decode_plan_from_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        chained_ms, chained_plan_ms = [], {"encode": [], "decode": []}
+        for rep_k in range(4):
+            eng.fill(d_back, 0xEE, count * size)
+            eng.sync()
+            t_start = time.perf_counter()
+            assert lib.aws_huffman_amd_encode_plan_reset_strided(roomy, C.byref(desc), None) == 0
+            chained_plan_ms["encode"].append((time.perf_counter() - t_start) * 1e3)
+            eng.encode_launch(roomy, d_in, d_out)
+            t0 = time.perf_counter()
+            assert lib.aws_huffman_amd_decode_plan_from_encode(chained, roomy, None) == 0
+            chained_plan_ms["decode"].append((time.perf_counter() - t0) * 1e3)  # (includes the wait for the encode launch)
+            eng.decode_launch(chained, d_out, d_back)
+            eng.sync()
+            chained_ms.append((time.perf_counter() - t_start) * 1e3)
+        cres = eng.decode_results(chained, count)
+        assert all(r[0] == 0 and r[2] == size for r in cres) and digest_of(eng, d_back, count * size) == digest_of(eng, d_in, count * size)
+        for pl in (f1, f2, roomy):
+            lib.aws_huffman_amd_encode_plan_destroy(pl)
+        for pl in (f3, chained):
+            lib.aws_huffman_amd_decode_plan_destroy(pl)
+        for ptr in (d_items1, d_items2, d_items3):
+            if ptr:
+                eng.free(ptr)
+        med = statistics.median
+        fresh_keys = {
+            "fresh_batch_ms": round(med(fresh_ms[1:]), 4),
+            "fresh_batch_GiBps": round(count * size / GIB / (med(fresh_ms[1:]) * 1e-3), 2),
+            "fresh_plan_ms": {k: round(med(v[1:]), 3) if v else 0.0 for k, v in fresh_plan_ms.items()},
+            "fresh_chained_ms": round(med(chained_ms[1:]), 4),
+            "fresh_chained_GiBps": round(count * size / GIB / (med(chained_ms[1:]) * 1e-3), 2),
+            "fresh_chained_plan_ms": {k: round(med(v[1:]), 3) for k, v in chained_plan_ms.items()},
+            "fresh": "host wall clock, median of 3: every plan made for the batch from records in device memory (fresh_batch: with "
+                     "the reference's SHORT_BUFFER -> second call in between, records fetched; fresh_chained: room for every "
+                     "output, encode plan from a stride, decode plan chained on the device), launches, waits",
+        }
     out = {
         "config": {
             "workload": "BASELINE configs[3]: %d buffers x %d B (buffer i = splitmix64 seed 2+i, rank r takes i = r mod N), "
@@ -653,7 +666,9 @@ def run_cfg4(args, ranks, lib, eng):
     out["config"].update(fresh_keys)
     algo = {names_e[0]: n + e_len if names_e[0] == "enc_onepass" else n, names_e[1]: 0, names_e[2]: 0 if names_e[0] == "enc_onepass" else n + e_len,
             "dec_sync": e_len, "dec_scan": 0, "dec_emit": e_len + n}
-    rooflines(out, names_e, names_d, kernel_ms, t_enc_ms, t_dec_ms, n, e_len, algo, traffic_measured=False)
+    # (HBM traffic: counter passes of this workload at 16 KiB a buffer and the full batch, profiles/tools/cfg4_traffic.sh)
+    rooflines(out, names_e, names_d, kernel_ms, t_enc_ms, t_dec_ms, n, e_len, algo,
+              traffic_measured=(size == 16384 and count_all == 65536 and ranks.world == 1), traffic_file="pmc_traffic_cfg4.json")
     per_rank = {"rank": ranks.rank, "buffers": count, "encoded_bytes": e_len, "sha256_encoded_streams": enc_digest,
                 "encode_ms": round(t_enc_ms, 4), "decode_ms": round(t_dec_ms, 4)}
     return out, n, e_len, wall, kernel_ms, t_enc_ms, t_dec_ms, per_rank, 2

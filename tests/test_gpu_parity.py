@@ -318,6 +318,45 @@ def test_config4_batch_of_16k_buffers(world, engine):
         engine.free(p)
 
 
+def test_config5_streams_of_other_ranks(engine):
+    """BASELINE.json configs[4]: rank g of an N-GPU run encodes and decodes splitmix64(seed 5 + g).  The streams of the
+    first and the last other rank (seeds 6 and 12), on this one GPU, against the pinned oracle's records
+    (tests/golden/config5_stream_pins.json, made by make_config5_pins.py -- whose seed 5 reproduces the survey's record of
+    the real reference): length and sha256 of the encoded stream, and the round trip."""
+    pins = harness.load_json("config5_stream_pins.json")
+    n = pins["len"]
+    d_in, d_enc, d_back = engine.alloc(n), engine.alloc(n * 10 // 8 + 64), engine.alloc(n + 64)
+
+    def digest(ptr, size):
+        h = hashlib.sha256()
+        for off in range(0, size, 256 << 20):
+            h.update(engine.download(ptr, min(256 << 20, size - off), offset=off).tobytes())
+        return h.hexdigest()
+
+    for seed in (6, 12):
+        rec = pins["streams"][str(seed)]
+        e = rec["encoded_len"]
+        engine.fill_splitmix64(d_in, n, seed)
+        engine.fill(d_enc, 0x5A, e + 64)
+        engine.fill(d_back, 0x5A, n + 64)
+        plan = engine.encode_plan([dict(in_offset=0, in_len=n, out_offset=0, out_capacity=n * 10 // 8 + 64)])
+        engine.encode_launch(plan, d_in, d_enc)
+        (rc, err, consumed, produced, ob, op), = engine.encode_results(plan, 1)
+        assert (rc, err, consumed, produced, ob) == (0, 0, n, e, 0), seed
+        dplan = engine.decode_plan([dict(in_offset=0, in_len=e, out_offset=0, out_capacity=n)])
+        engine.decode_launch(dplan, d_enc, d_back)
+        (rc, err, symbols, bits), = engine.decode_results(dplan, 1)
+        assert (rc, err, symbols) == (0, 0, n), seed
+        assert digest(d_in, n) == rec["sha256_input"], seed
+        assert digest(d_enc, e) == rec["sha256_encoded"], seed
+        assert digest(d_back, n) == rec["sha256_input"], seed
+        assert np.all(engine.download(d_enc, 64, offset=e) == 0x5A) and np.all(engine.download(d_back, 64, offset=n) == 0x5A)
+        engine.lib.aws_huffman_amd_encode_plan_destroy(plan)
+        engine.lib.aws_huffman_amd_decode_plan_destroy(dplan)
+    for p in (d_in, d_enc, d_back):
+        engine.free(p)
+
+
 def test_three_kernel_encoder(oracle):
     """The count / scan / pack road (aws_huffman_amd_testing_set_encode_road) on the GPU: what every coder outside the
     one-pass kernel's range takes, and what is queued behind every one-pass launch in case a look-back wait runs out.

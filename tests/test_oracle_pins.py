@@ -366,3 +366,19 @@ def test_unknown_symbol_and_empty_input(oracle):
     r = oracle.encode_call(e2, np.zeros(0, dtype=np.uint8), 0, dst, 0, 16)
     assert (r.rc, r.consumed, r.produced) == (0, 0, 0)
     oracle.lib.oracle_table_coder_destroy(coder)
+
+
+def test_config5_pins_are_anchored_to_the_survey():
+    """tests/golden/config5_stream_pins.json (the oracle over the 1 GiB streams of seeds 5 .. 12, make_config5_pins.py):
+    its seed 5 must be the survey's record of the REAL reference, and every other stream is the same generator's with
+    another seed -- same length in, about the same length out."""
+    pins = harness.load_json("config5_stream_pins.json")
+    ref = PROBE["streams"]["G1G"]
+    five = pins["streams"]["5"]
+    assert pins["len"] == ref["len"] == 1 << 30
+    assert (five["encoded_len"], five["sha256_input"], five["sha256_encoded"]) == (ref["encoded_len"], ref["sha256_input"], ref["sha256_encoded"])
+    assert sorted(int(k) for k in pins["streams"]) == list(range(5, 13))
+    for seed, rec in pins["streams"].items():
+        assert rec["seed"] == int(seed) and abs(rec["encoded_len"] - ref["encoded_len"]) < 100_000
+        assert len(rec["sha256_encoded"]) == 64 and len(rec["sha256_input"]) == 64
+    assert len({r["sha256_encoded"] for r in pins["streams"].values()}) == 8
