@@ -437,7 +437,7 @@ __device__ __forceinline__ u32 code_at_walk(u32 window, const u32 *wlut, u32 pos
 
 constexpr u32 kFastRows = kSubWords + 1;  /* a window of the last row reaches into the next sub-chunk's first word */
 constexpr u32 kFastMaxMeet = 16;          /* no single head after this many rows: not regular */
-constexpr u32 kFastHopelessRows = 6;      /* most lanes of a wave with several heads after this many: not regular either (dec_sync_lean) */
+constexpr u32 kFastHopelessRows = 6;      /* most lanes of a wave with several heads after this many: not regular either (dec_sync_one) */
 
 template <u32 LB>
 struct fast_shared {
@@ -526,7 +526,7 @@ __device__ __forceinline__ u32 lds_byte_at(u32 byte_offset) {
 /* ------------------------------------------------------------------ decode: the end of a stream */
 
 /*
- * One THREAD per chunk that holds the end of a stream (after dec_sync_lean<TAIL> / dec_sync_pack, which took its whole lanes):
+ * One THREAD per chunk that holds the end of a stream (after dec_sync_one<TAIL> / dec_sync_pack, which took its whole lanes):
  * follows the true path from where the last whole lane leaves it to where the stream stops, symbol by symbol
  * with the end-of-stream tests of source/huffman.c:232-255, through the first sub-chunk behind the whole lanes
  * and the few bytes of the next one.  Then completes the chunk's tables: records of those one or two lanes,

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(kEmitThreads, 4) void dec_emit_kernel(
  * the LDS stage; every other chunk is put on a list for dec_emit_kernel.  Four threads per
  * sub-chunk as there (thread (lane, q) starts at checkpoint q), but each holds its quarter of the
  * sub-chunk in registers (nine words of the lane's own 128-byte line) and walks it row by row like
- * dec_sync_lean: shift, mask, table, byte store, two adds a symbol.  The table entry is
+ * dec_sync_one: shift, mask, table, byte store, two adds a symbol.  The table entry is
  * symbol << 16 | (0x10000 - length) & 0xFFFF; only the low half of the walk state is ever looked
  * at, so the symbol may ride along in the add.
  */
@@ -396,7 +396,7 @@ __device__ __forceinline__ void dec_emit_fast_chunk(
     const u32 s0 = centry & 0xFFu;
     const hufd_chunk_rec rec = chunk_rec[c]; /* (asked for with the chunk's entry: not chunk -> item -> its record) */
     const u64 valid = rec.valid;
-    /* lanes whose sub-chunk and the 8 bytes after it lie inside the stream (dec_sync_lean: the others are idle or "careful") */
+    /* lanes whose sub-chunk and the 8 bytes after it lie inside the stream (dec_sync_one: the others are idle or "careful") */
     if (!TAIL && valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
         return; /* the other instantiation's */
     }
@@ -599,9 +599,11 @@ __device__ __forceinline__ void dec_emit_fast_chunk(
     }
     }
     if (extend) {
-        /* rare: sub-chunk 0 on through the second quarter, words straight from memory */
+        /* rare: sub-chunk 0 on through the second quarter -- and the third and fourth when their checkpoints are missing too
+         * (dec_sync_one: the walks of sub-chunk 0 met late) --, words straight from memory */
+        const u32 extend_end = (cpt[1 * HUFD_DEC_LANES] & 0x8000u) ? 2 * kRows : ((cpt[2 * HUFD_DEC_LANES] & 0x8000u) ? 3 * kRows : 4 * kRows);
         u32 hi = w[0][kRows];
-        for (u32 r = kRows; r < 2 * kRows; ++r) {
+        for (u32 r = kRows; r < extend_end; ++r) {
             /* (sub-chunk 0: the address is rebuilt from the chunk's, so that no pointer has to stay in registers for this) */
             const u32 lo = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(d_in + rec.src_off + (r + 1) * 4)->x);
             const u64 pair = ((u64)hi << 32) | lo;
@@ -922,9 +924,10 @@ __global__ __launch_bounds__(kEmitFastThreads, 6) void dec_emit_pack_kernel(
         }
     }
     if (extend) {
-        /* rare: sub-chunk 0 on through the second quarter, words straight from memory */
+        /* rare: sub-chunk 0 on through the second quarter (and further while checkpoints are missing), words straight from memory */
+        const u32 extend_end = (cpt[1 * HUFD_DEC_LANES] & 0x8000u) ? 2 * kRows : ((cpt[2 * HUFD_DEC_LANES] & 0x8000u) ? 3 * kRows : 4 * kRows);
         u32 hi = w[0][kRows];
-        for (u32 r = kRows; r < 2 * kRows; ++r) {
+        for (u32 r = kRows; r < extend_end; ++r) {
             const u32 lo = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(d_in + rec.src_off + (r + 1) * 4)->x);
             const u64 pair = ((u64)hi << 32) | lo;
             while ((st[0] & 0xFFFFu) > rw.thr) {

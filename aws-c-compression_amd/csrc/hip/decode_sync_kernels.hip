@@ -2,7 +2,7 @@
  * Decode, first pass: the transfer function of every sub-chunk (entry state -> exit state, symbols) and of every chunk,
  * replacing the window / walk loop of reference source/huffman.c:230-281 for counting.
  *   dec_sync                      the long way: all entry states, nothing assumed (any chunk, on a list)
- *   dec_sync_lean                 regular chunks: the sub-chunk in registers, phases U, R, H
+ *   dec_sync_one                  regular chunks: the sub-chunk in registers, one guessed walk and one from the true entry
  *   dec_sync_pack                 several short end-of-stream chunks a workgroup
  *   dec_sync_guess                second chance for chunks inside a stream
  *   dec_sync_few, dec_sync_true   chunks whose walks never fall into step
@@ -249,7 +249,14 @@ struct lean_shared {
     u16 hops[1u << LB]; /* 1 << code length of a window (the head it sends on), 0 = no code */
 };
 
-/* row_walk::row with the number of certain steps known to the compiler and the table given as an LDS offset */
+/* row_walk::row with the number of certain steps known to the compiler and the table given as an LDS offset.
+ *
+ * The loop over the codes that MAY start in the row is written out for the GPU: what the compiler makes of
+ * `while ((state & 0xFFFF) > thr)` is five vector instructions a trip (shift, address, add, and, compare) and three scalar
+ * ones that fold the compare into the exec mask; here the compare is v_cmpx_lt_u16 -- the low half as it stands, straight
+ * into exec -- so a trip is four vector instructions and a branch.  These kernels' time follows the vector instructions a
+ * step costs (profiles/r05_micro: the walk at eight waves a SIMD is held by issue as much as by the LDS).  v62 / v63 are
+ * the block's own temporaries (a 64-bit shift result whose low word becomes the address, then the entry). */
 template <u32 SURE, bool STEP_BY_STEP = false>
 __device__ __forceinline__ u32 lean_row(u32 state, u32 hi, u32 lo, u32 table, const row_walk &rw) {
     const u64 pair = ((u64)hi << 32) | lo;
@@ -259,20 +266,129 @@ __device__ __forceinline__ u32 lean_row(u32 state, u32 hi, u32 lo, u32 table, co
             state += lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
         }
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 saved_exec;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_u16_e32 vcc, %[thr], %[st]\n\t"
+        "s_cbranch_execz 2f\n"
+        "1:\n\t"
+        "v_lshrrev_b64 v[62:63], %[st], %[pair]\n\t"
+        "v_and_or_b32 v62, v62, %[mask], %[tab]\n\t"
+        "ds_read_b32 v62, v62\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_add_u32_e32 %[st], %[st], v62\n\t"
+        "v_cmpx_lt_u16_e32 vcc, %[thr], %[st]\n\t"
+        "s_cbranch_execnz 1b\n"
+        "2:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [st] "+v"(state), [sv] "=&s"(saved_exec)
+        : [pair] "v"(pair), [mask] "s"(rw.mask), [tab] "v"(table), [thr] "s"(rw.thr)
+        : "vcc", "v62", "v63");
+#else
     while ((state & 0xFFFFu) > rw.thr) {
         state += lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
     }
+#endif
     return state;
 }
 
+/* ------------------------------------------------------------------ decode: sync, regular chunks, one guessed walk */
+
 /*
- * The sync kernel for regular chunks (round 1's dec_sync_fast, retired in round 5, with fewer instructions: it was bound by them, 297 M vector
- * instructions per GiB, 17.7 per symbol, at one per 4 cycles and SIMD).  Same phases, same tables out; what is
- * different is what a step of a walk costs: the number of certain steps a row is known to the compiler (no loop
- * around them), a table entry's address is one instruction (lean_row), the words are byte-swapped once.
+ * Round 2-4's dec_sync_lean (retired: profiles/tools/micro/retired) spent a quarter of a workgroup's life in phase U -- every entry state of every sub-chunk followed as a
+ * mask of heads until one is left, five rows that cost what twenty rows of one walk cost -- only to learn where the walks
+ * meet.  Nobody needs to know that in advance.  Here every lane starts ONE walk at bit 0 of its sub-chunk, a guess, and
+ * walks to the end, counting (phase R over all 32 rows; a window without a code moves the walk one bit on, so that a walk
+ * on a wrong phase keeps looking for the right one: it falls into step with the true walk after two rows on average).
+ * The walk's state is kept at a few row boundaries.  Lane i's true entry is how lane i - 1's walk LEAVES -- right
+ * whenever that walk fell into step before its sub-chunk's end -- and phase H walks from there until it stands where the
+ * guessed walk stood at one of the kept boundaries: from that row on the two are one walk, and the lane's symbols are
+ * H's up to there and R's from there.  Per wave H runs as long as its slowest lane needs (8 rows on average for the test
+ * coder, where U + H took five rows each): 32 + 8 rows of one walk instead of U + 27 + 5.
+ *
+ * Exactness: a sub-chunk's records are kept only if H met R (both walks then ARE the true path from that row), neither
+ * walk stepped over a window without a code on the true path (counted in the walk's state: such a window is where the
+ * reference stops, source/huffman.c:240-247 -- the long way finds the stop), and the exit is a state; the chain of
+ * entries is true by induction from sub-chunk 0, whose candidates (threads 0 .. ns-1, every entry state, step by step)
+ * must each die or meet lane 0's walk within sixteen rows.  Anything else: the chunk is not regular, as for
+ * that kernel, same lists.  Same records out.
  */
+constexpr u32 kOneRecs = 9;
+__device__ __host__ constexpr u32 one_rec_row(u32 j) { /* the row boundaries at which the guessed walk's state is kept; the last: the sub-chunk's end */
+    return j == 0 ? 6u : j == 1 ? 8u : j == 2 ? 10u : j == 3 ? 12u : j == 4 ? 16u : j == 5 ? 20u : j == 6 ? 24u : j == 7 ? 28u : 32u;
+}
+/* (a walk that meets the guessed one only at the sub-chunk's END has walked all of it from the true entry: it needs nothing
+ * of the guessed walk but that it leaves the same way -- one lane in ten thousand meets later than row 16, and a chunk
+ * that is given up for it costs the launches behind this one their latency) */
+constexpr u32 kOneMaxMerge = kSubWords;
+constexpr u32 kOneMaxMerge0 = kSubWords;
+constexpr u32 kOneRecs0 = kOneRecs;
+constexpr u32 kOneGarbageRow = 4, kOneGarbageDead = 48; /* that many windows without a code in a lane's first rows: not a stream of this coder */
+
+/* which kept boundary a row is (kOneRecs: none) */
+__device__ __host__ constexpr u32 one_rec_index(u32 row) {
+    u32 at = kOneRecs;
+    for (u32 j = 0; j < kOneRecs; ++j) {
+        at = one_rec_row(j) == row ? j : at;
+    }
+    return at;
+}
+
+/* state = symbols << 21 | windows without a code << 10 | position (as row_walk's low half: thr + 32 - bits into the row) */
+struct one_walk {
+    u32 thr, mask;
+    __device__ __forceinline__ one_walk(u32 lut_bits) {
+        thr = 512 + (32 - lut_bits) - 2;
+        mask = ((1u << lut_bits) - 1u) << 2;
+    }
+    __device__ __forceinline__ u32 state_at(u32 k) const {
+        return thr + 32 - k;
+    }
+    __device__ __forceinline__ u32 offset_of(u32 state) const {
+        return thr + 32 - (state & 0x3FFu);
+    }
+    static __device__ __forceinline__ u32 count_of(u32 state) {
+        return state >> 21;
+    }
+    static __device__ __forceinline__ u32 dead_of(u32 state) {
+        return (state >> 10) & 0x7FFu;
+    }
+    static __device__ __forceinline__ u32 entry_of(u32 len) { /* a code: a symbol more, `len` bits on; none: a mark more, one bit on */
+        return len ? (1u << 21) - len : (1u << 10) - 1u;
+    }
+    /* every code of the walk that starts in the row whose words are hi:lo (SURE of them without asking) */
+    template <u32 SURE>
+    __device__ __forceinline__ u32 row(u32 state, u32 hi, u32 lo, u32 table) const {
+        const u64 pair = ((u64)hi << 32) | lo;
+#pragma unroll
+        for (u32 i = 0; i < SURE; ++i) {
+            state += lds_word_at(((u32)(pair >> (state & 63u)) & mask) | table);
+        }
+        while ((state & 0x3FFu) > thr) {
+            state += lds_word_at(((u32)(pair >> (state & 63u)) & mask) | table);
+        }
+        return state;
+    }
+};
+
+template <u32 LB>
+struct one_shared {
+    u32 wlut[1u << LB]; /* one_walk::entry_of(length); at a multiple of its own size */
+    u32 exit_state[HUFD_DEC_LANES];
+    u32 sub0[kSubWords + 4]; /* sub-chunk 0's rows, for the threads that try its entry states */
+    /* every lane's guessed walk at the kept boundaries, and at the quarter boundaries behind them: written and read by the lane
+     * itself (and lane 0's by the threads that try sub-chunk 0's entry states) -- in LDS because 33 words of stream are what a
+     * lane's registers hold at eight waves a SIMD: with these twelve beside them the kernel spilled, and took twice as long */
+    u32 kept[kOneRecs + kQuarters - 1][HUFD_DEC_LANES];
+    u32 wave_sum[HUFD_DEC_LANES / 64];
+    u32 bad;
+    u32 decided0; /* every entry state of sub-chunk 0 died or met lane 0's walk: what dec_sync_guess needs of a chunk */
+    u32 pad[2];
+};
+
 template <u32 LB, u32 SURE, bool TAIL = false> /* TAIL: the chunks listed in tail_chunks (a stream ends in them) */
-__global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
+__global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
     hufd_tables tb,
     const hufd_chunk_rec *chunk_rec,
     const u32 *tail_chunks,
@@ -283,18 +399,18 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     u16 *lane_count,
     u8 *chunk_regular,
     u32 *tail_entry, /* [chunk] TAIL: the state in which the last whole lane leaves (dec_sync_tail picks it up) */
-    u32 *slow_list, /* chunks inside a stream that are not regular by this kernel's rules but whose first sub-chunk's walks
-                     * do meet: dec_sync_guess tries them its way */
+    u32 *slow_list,  /* chunks inside a stream that are not regular by this kernel's rules but whose first sub-chunk's
+                      * walks are decided: dec_sync_guess tries them its way */
     u32 *slow_count,
-    u32 *long_list, /* the others that are not regular: dec_sync's (may be the same list as slow_list) */
+    u32 *long_list,  /* the others that are not regular: dec_sync's (may be the same list as slow_list) */
     u32 *long_count) {
 
     HUFD_STAMP(0, 0);
-    lean_shared<LB> &sh = *reinterpret_cast<lean_shared<LB> *>(dyn_lds);
+    one_shared<LB> &sh = *reinterpret_cast<one_shared<LB> *>(dyn_lds);
     const u32 ns = tb.n_states;
     const u32 lane = threadIdx.x;
     const u32 c = TAIL ? tail_chunks[blockIdx.x] : blockIdx.x;
-    const hufd_chunk_rec rec = chunk_rec[c]; /* (one load: not chunk -> item -> its record) */
+    const hufd_chunk_rec rec = chunk_rec[c];
     const u64 valid = rec.valid;
     const u8 *src = d_in + rec.src_off;
     if (!TAIL && valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
@@ -304,17 +420,15 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     const u32 n_full = !TAIL ? HUFD_DEC_LANES : (valid >= 8u ? (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES) : 0u);
     const bool active = !TAIL || lane < n_full;
     if (TAIL && n_full == 0 && tb.lut_bits <= HUFD_DEC_MAX_LUT_BITS) {
-        /* fewer than 136 bytes: no lane is whole, and the whole chunk is one thread's work in dec_sync_tail / dec_emit_tail */
         if (lane == 0) {
-            chunk_regular[c] = 3;
+            chunk_regular[c] = 3; /* fewer than 136 bytes: one thread's work in dec_sync_tail / dec_emit_tail */
         }
         return;
     }
-    const row_walk rw(LB, tb.max_bits);
+    const one_walk ow(LB);
     const u32 table = lds_offset_of(sh.wlut);
-    /* (a chunk may lie at any address: the loads need no alignment) */
     const bool eligible = n_full >= 1 && tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS &&
-                          rw.sure >= SURE && (table & ((4u << LB) - 1u)) == 0;
+                          row_walk(LB, tb.max_bits).sure >= SURE && (table & ((4u << LB) - 1u)) == 0;
     if (!eligible) {
         if (lane == 0) {
             chunk_regular[c] = 0;
@@ -323,9 +437,6 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         return;
     }
     u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
-    /* The sub-chunk's words and the table entries this lane will put into LDS are asked for together, at most four
-     * entries at a time -- a workgroup's time is mostly the latency of what it loads in front of its first walk, and a
-     * loop of load, wait, store over the table was a fifth of that. */
     constexpr u32 kLutPerLane = (1u << LB) / HUFD_DEC_LANES, kLutBatch = 4;
     const auto table_share = [&](u32 j0) {
         u32 lut_raw[kLutBatch];
@@ -335,16 +446,11 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
         }
 #pragma unroll
         for (u32 j = 0; j < kLutBatch; ++j) {
-            const u32 len = lut_raw[j] & 0xFFu;
-            sh.wlut[lane + (j0 + j) * HUFD_DEC_LANES] = 0x10000u - (len ? len : kWalkDeadLen);
-            sh.hops[lane + (j0 + j) * HUFD_DEC_LANES] = (u16)(len ? 1u << len : 0u);
+            sh.wlut[lane + (j0 + j) * HUFD_DEC_LANES] = one_walk::entry_of(lut_raw[j] & 0xFFu);
         }
     };
     if (TAIL && lane >= kWave && (lane & ~(kWave - 1)) >= n_full) {
-        /* a wave wholly behind the stream's whole lanes: never reached, as far as this kernel knows (dec_sync_tail follows
-         * the true path through the one or two sub-chunks the stream ends in and rewrites their records).  Its share of
-         * the table done, it leaves -- the barriers below count the waves that are still there -- and its slots go to
-         * another workgroup. */
+        /* a wave wholly behind the stream's whole lanes: its share of the table done, it leaves: the barriers below count the waves that are still there */
 #pragma unroll
         for (u32 j0 = 0; j0 < kLutPerLane; j0 += kLutBatch) {
             table_share(j0);
@@ -359,8 +465,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     }
     u32 w[kFastRows];
     {
-        /* (TAIL: a lane behind the stream's whole lanes reads sub-chunk 0 again -- no branch, no second set of
-         * registers for "nothing", and words that are codes; what it makes of them is never looked at) */
+        /* (TAIL: a lane behind the stream's whole lanes reads sub-chunk 0 again: words that are codes, never looked at) */
         const u32 mine = active ? lane : 0u;
         const unaligned_uint4 *line = reinterpret_cast<const unaligned_uint4 *>(src + (u64)mine * HUFD_DEC_SUB_BYTES);
 #pragma unroll
@@ -383,8 +488,9 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     }
     if (lane == 0) {
         sh.bad = 0;
+        sh.decided0 = 0;
 #pragma unroll
-        for (u32 r = 0; r <= kFastMaxMeet; ++r) {
+        for (u32 r = 0; r <= kOneMaxMerge0; ++r) {
             sh.sub0[r] = w[r];
         }
 #pragma unroll
@@ -394,107 +500,187 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     }
     __syncthreads();
     HUFD_STAMP(0, 1);
-
-    /* U: all entry states as one mask of heads per row, until every lane of the wave is down to one */
-    u64 heads = active ? (1ull << ns) - 1ull : 0ull;
-    u32 meet_row = 0; /* the same for the whole wave */
-    bool one = false, settled = false;
-    /* a wave most of whose lanes still follow several walks after kFastHopelessRows rows is looking at a stream whose
-     * walks do not fall into step (one symbol over and over: as many walks as its code has bits, for ever) -- ten more
-     * rows of all of them, and then the one walk, were 0.8 ms of a 1.8 ms decode of 256 MiB of such symbols */
-    bool hopeless = false;
-#pragma unroll
-    for (u32 r = 0; r < kFastMaxMeet; ++r) {
-        if (!settled && !hopeless) {
-            heads = r == 0 ? union_first_row<LB>(ns, active, w[0], w[1], sh.hops) : union_row_fast<LB>(heads, w[r], w[r + 1], sh.hops);
-            one = heads != 0 && (heads & (heads - 1)) == 0;
-            meet_row = r + 1;
-            settled = __all(one || heads == 0);
-            if (r + 1 == kFastHopelessRows) {
-                hopeless = !settled && __popcll(__ballot(!one && heads != 0)) > kWave - kWave / 8;
-            }
-        }
-    }
-
     HUFD_STAMP(0, 2);
-    const u32 meet_bit = one ? (u32)__builtin_ctzll(heads) : 0u; /* bits into row meet_row */
-    bool ok = !active || (one && settled);
-    if (lane == 0) {
-        sh.pad[2] = one; /* sub-chunk 0's own walks have met (whatever the wave's other lanes' have): what dec_sync_guess needs of a chunk */
-    }
 
-    /* R: the one walk from the meeting bit to the end of the sub-chunk */
-    u32 state = rw.state_at(meet_bit, 0);
-    u32 cp_state[kQuarters - 1] = {0, 0, 0};
-    bool dead = false;
+    /* R: one walk from bit 0, a guess, over the whole sub-chunk; its state kept at a few row boundaries */
+    u32 state = ow.state_at(0);
+    bool hopeless = false; /* (the same for the wave) */
 #pragma unroll
-    for (u32 r = 1; r < kSubWords; ++r) {
-        if (r >= meet_row && !hopeless) { /* (hopeless: no row of this walk, none of the head walks below -- the chunk is not regular) */
-            if (r % (kSubWords / kQuarters) == 0) {
-                cp_state[r / (kSubWords / kQuarters) - 1] = state;
+    for (u32 r = 0; r < kSubWords; ++r) {
+        if (!hopeless) {
+            if (one_rec_index(r) < kOneRecs) {
+                sh.kept[one_rec_index(r)][lane] = state;
             }
-            state = lean_row<SURE>(state, w[r], w[r + 1], table, rw);
-            dead = dead || rw.died(state);
-            /* (a walk that has died drifts: the chunk is not regular then and nothing of this is kept.  TAIL: the lanes
-             * behind the stream walk zeros, which need not be a code -- drifting, their state would wrap and the row
-             * loop run for thousands of steps: they are put back on a row start) */
-            state = TAIL ? rw.next_row(state, dead) : state + 32u;
+            if (r != 0 && r % (kSubWords / kQuarters) == 0) {
+                sh.kept[kOneRecs + r / (kSubWords / kQuarters) - 1][lane] = state;
+            }
+            state = ow.template row<SURE>(state, w[r], w[r + 1], table) + 32u;
+            if (r + 1 == kOneGarbageRow) {
+                /* dozens of windows without a code in four rows: bytes that are no stream of this coder (a walk over them
+                 * steps a bit at a time) -- the long way says where the first one is */
+                hopeless = __any(active && one_walk::dead_of(state) > kOneGarbageDead);
+            }
         }
     }
-    const u32 ref_count = state >> 16; /* symbols from the meeting bit to the end of the sub-chunk */
-    const u32 ref_exit = rw.offset_of(state);
-    ok = ok && (!active || (!dead && ref_exit < ns));
+    const u32 last = state;
+    sh.kept[kOneRecs - 1][lane] = last; /* (the boundary behind the last row: the sub-chunk's end) */
+    const u32 ref_exit = ow.offset_of(last);
+    bool ok = !hopeless && (!active || ref_exit < ns);
     sh.exit_state[lane] = ref_exit;
     HUFD_STAMP(0, 3);
     __syncthreads();
     HUFD_STAMP(0, 4);
 
-    /* H: my own sub-chunk from my true entry state, to the meeting bit */
+    /* H: my own sub-chunk from my true entry state, until I stand where my guessed walk stood */
     const u32 entry = lane ? sh.exit_state[lane - 1] : 0u;
-    u32 count;
-    u32 head_cp = 0; /* the head walk where it enters the second quarter, when the meeting row lies behind that */
-    const bool late = meet_row > kSubWords / kQuarters;
+    u32 count = 0, meet_row = 0;
+    u32 head_cp[kQuarters - 1] = {0, 0, 0}; /* the walk from the true entry where it enters the second, third and fourth quarter */
     {
-        u32 st = rw.state_at(entry < ns ? entry : 0u, 0);
-        bool dd = false;
+        u32 st = ow.state_at(entry < ns ? entry : 0u);
+        bool met = !active || lane == 0; /* (lane 0's entry is only known to dec_scan: the candidates below) */
+        u32 h_at = 0, r_at = 0;
+        bool done = false; /* (the same for the wave) */
+        constexpr u32 kInRegisters = 24; /* the rows H walks out of the lane's registers: behind them the words come from memory again */
 #pragma unroll
-        for (u32 r = 0; r < kFastMaxMeet; ++r) {
-            if (r < meet_row && !hopeless) {
-                if (r == kSubWords / kQuarters) {
-                    head_cp = st;
+        for (u32 r = 0; r <= kInRegisters; ++r) {
+            if (!done && !hopeless) {
+                if (r != 0 && r % (kSubWords / kQuarters) == 0) {
+                    head_cp[r / (kSubWords / kQuarters) - 1] = st;
                 }
-                st = lean_row<SURE>(st, w[r], w[r + 1], table, rw);
-                dd = dd || rw.died(st);
-                st = TAIL ? rw.next_row(st, dd) : st + 32u;
+                if (one_rec_index(r) < kOneRecs) {
+                    const u32 there = sh.kept[one_rec_index(r)][lane];
+                    if (!met && ((st ^ there) & 0x3FFu) == 0) {
+                        met = true;
+                        h_at = st;
+                        r_at = there;
+                        meet_row = r;
+                    }
+                    done = __all(met);
+                    if (one_rec_index(r) == 0) {
+                        if (!done) {
+                            /* most of the wave's lanes still apart after six rows: a stream whose walks do not fall into step
+                             * (one symbol over and over) -- no regular chunk, and no more rows spent on finding that out */
+                            hopeless = __popcll(__ballot(!met)) > kWave - kWave / 8;
+                        }
+                    }
+                }
+                if (r < kInRegisters) {
+                    if (!done && !hopeless) {
+                        st = ow.template row<SURE>(st, w[r], w[r + 1], table) + 32u;
+                    }
+                }
             }
         }
-        const bool reached = !dd && rw.offset_of(st) == meet_bit;
-        ok = ok && (lane == 0 || !active || reached);
-        count = active ? (st >> 16) + ref_count : 0u; /* symbols of the true path that start in my sub-chunk (lanes >= 1) */
+        if (!done && !hopeless) {
+            /* rare (a wave in a hundred): a lane still apart from its guessed walk after 24 rows.  On to the sub-chunk's end,
+             * the words from memory (kept in registers for this they cost the kernel its eight waves a SIMD); a walk that
+             * has covered the whole sub-chunk from the true entry needs the guessed one only to leave the same way. */
+            const u8 *mine = src + (u64)(active ? lane : 0u) * HUFD_DEC_SUB_BYTES;
+            u32 hi = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(mine + 4 * kInRegisters)->x);
+            for (u32 r = kInRegisters; r < kSubWords && !done; ++r) {
+                const u32 lo = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(mine + 4 * (r + 1))->x);
+                st = ow.template row<0>(st, hi, lo, table) + 32u;
+                hi = lo;
+                if (r + 1 == one_rec_row(kOneRecs - 2) || r + 1 == one_rec_row(kOneRecs - 1)) {
+                    const u32 there = sh.kept[r + 1 == one_rec_row(kOneRecs - 2) ? kOneRecs - 2 : kOneRecs - 1][lane];
+                    if (!met && ((st ^ there) & 0x3FFu) == 0) {
+                        met = true;
+                        h_at = st;
+                        r_at = there;
+                        meet_row = r + 1;
+                    }
+                    done = __all(met);
+                }
+            }
+        }
+        if (active && lane) {
+            /* met, no window without a code on the true path (H's part, R's part), my entry a state */
+            ok = ok && !hopeless && met && entry < ns && one_walk::dead_of(h_at) == 0 && one_walk::dead_of(last) == one_walk::dead_of(r_at);
+            count = one_walk::count_of(h_at) + one_walk::count_of(last) - one_walk::count_of(r_at);
+        }
     }
 
-    /* H: sub-chunk 0 from every entry state the chunk may be entered in (threads 0 .. ns-1), step by step: the count
-     * of a walk that dies has to be right */
-    u32 cand_count = 0, cand_dead = 0;
+    /* H: sub-chunk 0 from every entry state the chunk may be entered in (threads 0 .. ns-1), step by step: each dies at a
+     * window without a code (the count up to there has to be right) or meets lane 0's walk */
+    u32 cand_count = 0, cand_dead = 0, meet_row0 = 0, ref_count0 = 0;
     bool cand_reached = false;
     u64 cand_alive = 0;
-    if (lane < kWave && !hopeless) {
-        const u32 target = __shfl(meet_bit, 0), tail0 = __shfl(ref_count, 0); /* sub-chunk 0 is lane 0's */
-        u32 st = rw.state_at(lane < ns ? lane : 0u, 0);
-        bool dd = false;
+    if (lane < kWave) {
+        const u32 last0 = sh.kept[kOneRecs - 1][0];
+        u32 st = ow.state_at(lane < ns ? lane : 0u);
+        bool dd = lane >= ns, met = false;
+        u32 c_at = 0, r_at = 0, my_row = 0;
         u32 hi = sh.sub0[0];
-        for (u32 r = 0; r < meet_row; ++r) {
+        for (u32 r = 0; r <= kOneMaxMerge0 && !hopeless; ++r) {
+            u32 j = kOneRecs0;
+#pragma unroll
+            for (u32 k = 0; k < kOneRecs0; ++k) {
+                j = r == one_rec_row(k) ? k : j;
+            }
+            if (j < kOneRecs0) {
+                const u32 there = sh.kept[j][0];
+                if (!dd && !met && ((st ^ there) & 0x3FFu) == 0) {
+                    met = true;
+                    c_at = st;
+                    r_at = there;
+                    my_row = r;
+                }
+            }
+            if (__all(dd || met) || r == kOneMaxMerge0) {
+                break;
+            }
             const u32 lo = sh.sub0[r + 1];
-            st = lean_row<SURE, true>(st, hi, lo, table, rw);
-            const bool now = rw.died(st) && !dd;
-            cand_dead = now ? (st >> 16) - 1u : cand_dead; /* the step that found no code is not a symbol */
-            dd = dd || now;
-            st = rw.next_row(st, dd);
+            if (!dd && !met) {
+                /* the row as the other walks take it; a window without a code in it (a walk on a wrong phase: within a
+                 * row or two) and the row is taken again, step by step, for the count up to that window -- these ten lanes'
+                 * walks are the tail of the workgroup's life, the other waves wait for them */
+                const u32 before = st;
+                st = ow.template row<SURE>(st, hi, lo, table);
+                if (one_walk::dead_of(st)) {
+                    const u64 pair = ((u64)hi << 32) | lo;
+                    st = before;
+                    for (;;) {
+                        const u32 e = lds_word_at(((u32)(pair >> (st & 63u)) & ow.mask) | table);
+                        if (e == one_walk::entry_of(0)) {
+                            break;
+                        }
+                        st += e;
+                    }
+                    dd = true;
+                    cand_dead = one_walk::count_of(st); /* (the step that found no code is not a symbol) */
+                }
+            }
+            st += 32u;
             hi = lo;
         }
-        cand_reached = !dd && lane < ns && rw.offset_of(st) == target;
+        const bool decided = !hopeless && __all(dd || met);
+        cand_reached = met && lane < ns;
         cand_alive = __ballot(cand_reached);
-        cand_count = (st >> 16) + tail0;
+        /* where the last of them met it: from that row on lane 0's walk is the true one whatever the chunk's entry */
+        u32 latest = met ? my_row : 0u;
+#pragma unroll
+        for (u32 d = kWave / 2; d > 0; d >>= 1) {
+            const u32 o = __shfl_xor(latest, d);
+            latest = o > latest ? o : latest;
+        }
+        meet_row0 = latest;
+        cand_count = one_walk::count_of(c_at) + one_walk::count_of(last0) - one_walk::count_of(r_at);
+        /* (a window without a code on lane 0's walk behind where a candidate met it: that candidate's path has it too) */
+        const bool clean = !met || one_walk::dead_of(last0) == one_walk::dead_of(r_at);
+        if (lane == 0) {
+            sh.decided0 = decided;
+        }
+        const bool all_clean = __all(clean); /* (every lane of the wave asks: not behind a lane's own `ok`) */
+        ok = ok && decided && all_clean && cand_alive != 0;
+        if (lane == 0) {
+            meet_row = meet_row0;
+            u32 at0 = sh.kept[0][0];
+#pragma unroll
+            for (u32 k = 0; k < kOneRecs0; ++k) {
+                at0 = meet_row0 == one_rec_row(k) ? sh.kept[k][0] : at0;
+            }
+            ref_count0 = one_walk::count_of(last0) - one_walk::count_of(at0);
+        }
     }
 
     HUFD_STAMP(0, 5);
@@ -509,7 +695,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     if (sh.bad) {
         if (lane == 0) {
             chunk_regular[c] = 0;
-            if (TAIL || !sh.pad[2]) {
+            if (TAIL || !sh.decided0) {
                 long_list[atomicAdd(long_count, 1u)] = c;
             } else {
                 slow_list[atomicAdd(slow_count, 1u)] = c;
@@ -521,22 +707,25 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
     /* the tables dec_scan and dec_emit read (the regular chunks' format) */
     u16 *fn_out = fn_tab + (u64)c * ns * HUFD_DEC_LANES;
     if (active) {
+        const u32 total = lane ? count : ref_count0; /* (lane 0: from where its walk is the true one) */
 #pragma unroll
-    for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-        /* a checkpoint in front of the meeting row is not on the one walk: the first one is then taken from the head
-         * walk (not for lane 0, whose head is only known to dec_scan) */
-        const bool usable = (qq + 1) * (kSubWords / kQuarters) >= meet_row;
-        u32 tail = ref_count - (cp_state[qq] >> 16), bits = rw.offset_of(cp_state[qq]);
-        bool have = usable;
-        if (qq == 0 && late && lane != 0) {
-            tail = count - (head_cp >> 16);
-            bits = rw.offset_of(head_cp);
-            have = true;
+        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+            /* a checkpoint in front of the meeting row is not on the guessed walk's true part: it is taken from the walk
+             * from the true entry, which passed it (not for lane 0, whose true entry is only known to dec_scan: its first
+             * checkpoint may be missing, dec_emit_fast walks on through that quarter) */
+            const u32 boundary = (qq + 1) * (kSubWords / kQuarters);
+            bool have = boundary >= meet_row;
+            const u32 at_boundary = sh.kept[kOneRecs + qq][lane];
+            u32 tail = one_walk::count_of(last) - one_walk::count_of(at_boundary), bits = ow.offset_of(at_boundary);
+            if (!have && lane != 0) {
+                tail = count - one_walk::count_of(head_cp[qq]);
+                bits = ow.offset_of(head_cp[qq]);
+                have = true;
+            }
+            cp[qq * HUFD_DEC_LANES] = (u16)(have ? 0x8000u | (bits << 11) | tail : 0u);
         }
-        cp[qq * HUFD_DEC_LANES] = (u16)(have ? 0x8000u | (bits << 11) | tail : 0u);
-    }
-    lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)(lane ? count : ref_count);
-    cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((lane ? 1u << entry : (u32)cand_alive) | (ref_exit << 12));
+        lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)total;
+        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((lane ? 1u << entry : (u32)cand_alive) | (ref_exit << 12));
     } else {
         /* (TAIL) behind the whole lanes, in a wave that has some: as for the waves that left */
 #pragma unroll
@@ -573,11 +762,11 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_lean_kernel(
 
 /*
  * A batch of items of a few KiB each is all chunks that streams END in, one per item, with a handful of whole lanes: 19
- * of 256 for a 2 KiB item.  dec_sync_lean<TAIL> gives such a chunk a workgroup of its own -- one wave of 19 lanes, a table
+ * of 256 for a 2 KiB item.  dec_sync_one<TAIL> gives such a chunk a workgroup of its own -- one wave of 19 lanes, a table
  * of 4 KiB filled, three barriers -- and the batch decodes at a seventh of a stream's rate (bench.py, the mid_items leg).
  * Here a workgroup takes SEVERAL such chunks: its 256 threads are `slots` of `width` lanes (the most whole lanes any
  * end-of-stream chunk of the launch has, at least 16), a chunk a slot, so that the waves are full and the table and the
- * barriers are shared.  Same phases per lane, same records out as dec_sync_lean<TAIL>; what is per chunk there (the
+ * barriers are shared.  Same phases per lane, same records out as dec_sync_one<TAIL>; what is per chunk there (the
  * candidates' walks of sub-chunk 0, the sum of the lanes' symbols, the verdict) is per slot here, through LDS words
  * instead of wave votes, because a slot need not start on a wave.
  */
@@ -850,11 +1039,13 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 6) void dec_sync_pack_kernel(
 /* ------------------------------------------------------------------ decode: sync, second chance for chunks inside a stream */
 
 /*
- * dec_sync_lean wants ALL entry states of EVERY sub-chunk to fall into one walk within 16 rows.  The test coder does
- * that; a coder that synchronises slowly on its own kind of data does not (codes of 4 .. 12 bits on symbols drawn to
- * match them: a quarter of the sub-chunks still have several heads after 16 rows), so none of its chunks is regular
- * and all of them take the long way at a tenth of the speed.  This kernel takes the chunks dec_sync_lean gave up on
- * (its list) and asks less: only sub-chunk 0, whose entry state nobody in the chunk can know, goes through phase U
+ * Rounds 2-4's dec_sync_lean wanted ALL entry states of EVERY sub-chunk to fall into one walk within 16 rows; a coder that
+ * synchronises slowly on its own kind of data (codes of 4 .. 12 bits on symbols drawn to match them: a quarter of the
+ * sub-chunks still have several heads after 16 rows) had no regular chunk, and this kernel was written for those.
+ * dec_sync_one (round 5) takes late meetings itself; what it gives up inside a stream are chunks with a wave most of
+ * whose lanes stay apart after six rows, or with a window without a code on the true path.  This kernel takes them from
+ * its list and asks less: only sub-chunk 0, whose entry state nobody in the chunk can know, goes through phase U (all
+ * entry states as a mask of heads, union_row_fast)
  * and the candidates' walks as there.  Every other lane starts ONE walk kGuessRows rows in front of its sub-chunk
  * (a window without a code moves it one bit on), takes where that walk crosses into the sub-chunk as its entry state
  * -- a guess -- and walks on to the end, counting.  Then lane j's guess is checked against lane j - 1's exit state,
@@ -1093,7 +1284,7 @@ __device__ __forceinline__ void dec_sync_guess_chunk(
     __syncthreads();
     if (sh.bad) {
         if (lane == 0) {
-            slow_list[atomicAdd(slow_count, 1u)] = c; /* (chunk_regular[c] is 0 already: dec_sync_lean's) */
+            slow_list[atomicAdd(slow_count, 1u)] = c; /* (chunk_regular[c] is 0 already: dec_sync_one's) */
         }
         return;
     }
@@ -1143,7 +1334,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 4) void dec_sync_guess_kernel(
     u32 *chunk_fn,
     u16 *lane_count,
     u8 *chunk_regular,
-    const u32 *given_up,       /* dec_sync_lean's list ... */
+    const u32 *given_up,       /* dec_sync_one's list ... */
     const u32 *given_up_count,
     u32 *slow_list,            /* ... and the one dec_sync works through */
     u32 *slow_count) {
@@ -1165,13 +1356,13 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 4) void dec_sync_guess_kernel(
 /* ------------------------------------------------------------------ decode: sync, chunks whose walks do not fall into step */
 
 /*
- * The chunks inside a stream that dec_sync_lean and dec_sync_guess gave up: in some sub-chunk the walks from the
+ * The chunks inside a stream that dec_sync_one and dec_sync_guess gave up: in some sub-chunk the walks from the
  * possible entry bits do not become one -- one symbol over and over (as many walks as its code has bits, each valid
  * for ever), two symbols of one length taking turns, any stream whose code lengths share a divisor.  An adversary picks
  * those; the long way (dec_sync) follows every entry's walk a bit of the stream at a time out of an LDS image, 1 ms for
  * 160 MB, and the emit kernel behind it has no checkpoints to start threads at.  Here, as for the long-code coders
  * (dec_wide_fn):
- *   dec_sync_few    a lane's sub-chunk in registers as in dec_sync_lean; from every entry bit a walk over the first two
+ *   dec_sync_few    a lane's sub-chunk in registers as in dec_sync_one; from every entry bit a walk over the first two
  *                   rows, and from every DISTINCT bit these land on ONE walk to the end of the sub-chunk (as many as the
  *                   stream has phases, at most kFewMaxWalks -- more, or the end of a stream in the chunk: the long way
  *                   after all).  Each entry's (exit, symbols, or where its walk stops) goes into the tables in the long
@@ -1196,7 +1387,7 @@ struct few_shared {
     u32 pad[3];
 };
 
-/* one row of a walk whose count has to be right when it dies (dec_sync_lean's walks of sub-chunk 0's entries) */
+/* one row of a walk whose count has to be right when it dies (dec_sync_one's walks of sub-chunk 0's entries) */
 template <u32 LB>
 __device__ __forceinline__ u32 few_row(u32 st, u32 hi, u32 lo, u32 table, const row_walk &rw, bool &dd, u32 &dead_count) {
     st = lean_row<0, true>(st, hi, lo, table, rw);
@@ -1564,7 +1755,7 @@ void hufk_host::decode_sync_stage(const struct hufk_decode_args *a, hipStream_t 
     const auto sync = ns <= 8 ? dec_sync_kernel<8> : (ns <= 10 ? dec_sync_kernel<10> : dec_sync_kernel<12>);
     (void)hipMemsetAsync(a->slow_count, 0, sizeof(uint32_t), st);
     const bool some_inside = a->n_tail < a->n_chunks; /* chunks with a whole chunk + 8 bytes of stream left */
-    /* two lists of chunks that are not regular by dec_sync_lean's rules: the ones dec_sync_guess may still take
+    /* two lists of chunks that are not regular by dec_sync_one's rules: the ones dec_sync_guess may still take
      * (inside a stream, first sub-chunk's walks meet) and the ones for the long way.  The second is the emit stage's
      * list, free until then; one list where there is no dec_sync_guess for the launch. */
     const bool guessing = some_inside;
@@ -1601,15 +1792,15 @@ if (n_packed) {                                                                 
 }                                                                                                                  \
 if (n_single) {                                                                                                    \
     hipLaunchKernelGGL(                                                                                            \
-        (dec_sync_lean_kernel<LBV, SUREV, true>), dim3(n_single), dim3(HUFD_DEC_LANES),                             \
-        (uint32_t)sizeof(lean_shared<LBV>), tst, a->tables, a->chunk_rec, single_chunks,                            \
+        (dec_sync_one_kernel<LBV, SUREV, true>), dim3(n_single), dim3(HUFD_DEC_LANES),                              \
+        (uint32_t)sizeof(one_shared<LBV>), tst, a->tables, a->chunk_rec, single_chunks,                             \
         (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
         a->slow_list, a->slow_count, lean_long_list, lean_long_count);                                             \
 }                                                                                                                  \
 if (some_inside) {                                                                                                 \
     hipLaunchKernelGGL(                                                                                            \
-        (dec_sync_lean_kernel<LBV, SUREV, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES),                         \
-        (uint32_t)sizeof(lean_shared<LBV>), st, a->tables, a->chunk_rec, a->tail_chunks,                            \
+        (dec_sync_one_kernel<LBV, SUREV, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES),                          \
+        (uint32_t)sizeof(one_shared<LBV>), st, a->tables, a->chunk_rec, a->tail_chunks,                             \
         (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
         a->slow_list, a->slow_count, lean_long_list, lean_long_count);                                             \
 }
@@ -1635,7 +1826,7 @@ if (some_inside) {                                                              
         (void)hipEventRecord((hipEvent_t)a->join_event, tst);
         (void)hipStreamWaitEvent(st, (hipEvent_t)a->join_event, 0);
     }
-    /* the chunks inside streams that dec_sync_lean gave up on: a second chance that asks less of the coder
+    /* the chunks inside streams that dec_sync_one gave up on: a second chance that asks less of the coder
      * (dec_sync_guess); what that gives up on goes on a second list (the emit stage's, free until then) */
     const u32 *long_list = a->slow_list, *long_count = a->slow_count;
     if (guessing) {
@@ -1660,7 +1851,7 @@ hipLaunchKernelGGL(                                                             
         long_list = a->emit_list;
         long_count = a->emit_count;
         /* of those, the chunks inside streams whose walks do not fall into step: a few walks a lane, not the long
-         * way's every bit (dec_sync_few; its list -- dec_sync_lean's, used up by now -- is for dec_sync_true below) */
+         * way's every bit (dec_sync_few; its list -- dec_sync_one's, used up by now -- is for dec_sync_true below) */
         if (a->few_walks) {
             few = true;
             (void)hipMemsetAsync(a->slow_count, 0, sizeof(uint32_t), st);
