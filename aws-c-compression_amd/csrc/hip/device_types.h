@@ -31,6 +31,8 @@
  * shorter than the segments / chunks of all of them (~33 / ~74 ns an item): the plan takes the largest of these
  * length classes that holds at least HUFD_*_TINY_PER_BYTE items per byte of its longest item. */
 #define HUFD_TINY_MANY_BYTES 2048u /* symbols (encode); encoded bytes x 2 / 3 (decode) */
+#define HUFD_ENC_SOLO_BYTES 4096u /* encode items up to one tile of symbols that no thread takes are one wave's work where the
+                                   * one-pass encoder applies (enc_onepass<.., SOLO>): no segments, no look-back */
 #define HUFD_ENC_TINY_WAVE_BYTES 1024u /* the same class for encode where the one-pass kernel is used */
 #define HUFD_ENC_TINY_PER_BYTE 18u
 #define HUFD_ENC_TINY_PER_BYTE_ONE_PASS 100u /* the same where the one-pass encoder packs ragged tiles (csrc/host/engine.c: enc_tiny_per_byte) */
@@ -118,7 +120,7 @@ struct hufd_enc_item {
     uint32_t eos_padding;
     uint32_t first_seg; /* index of the item's first segment in the plan's segment numbering */
     uint32_t n_segs;
-    uint32_t tiny; /* 1: the item has no segments, enc_tiny encodes it */
+    uint32_t tiny; /* 1: the item has no segments, enc_tiny encodes it; 2: no segments either, a wave of enc_onepass<.., SOLO> does */
 };
 
 /* one per segment, built with the plan: where the segment's symbols are, without pointer chasing */

@@ -2012,7 +2012,12 @@ struct op_tile {
     const u8 *tsrc;
 };
 
-template <u32 NW> /* words an oct can touch: 4 for codes of at most 12 bits, 5 up to 15 */
+/* SOLO: the items of one tile at most that the plan lists apart (hufd_enc_item.tiny == 2: up to HUFD_ENC_SOLO_BYTES symbols),
+ * a wave an item in turn.  Such an item's bits start at its own bit 0 (or behind its carried bits): nobody in front of it to
+ * ask, nobody behind it to tell -- the same turn (look-ups, octs, scan, image, last byte, copy-out, the note at a capacity
+ * edge) without the look-back.  As tiles of the stream's kernel a 2 KiB item was FOUR turns (a segment is four tiles,
+ * three of them empty, each waiting for its offsets like any tile): 65 536 of them took as long as 1 GiB of whole tiles. */
+template <u32 NW, bool SOLO = false> /* NW: words an oct can touch: 4 for codes of at most 12 bits, 5 up to 15 */
 __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
     hufd_tables tb,
     const hufd_enc_item *__restrict__ items,
@@ -2029,7 +2034,9 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
     u64 *__restrict__ item_total,
     hufd_enc_result *__restrict__ results, /* the tile with the capacity edge leaves a note for enc_finish_kernel here */
     const u8 *__restrict__ null_tile /* kTileBytes readable bytes: what a wave "prefetches" when no tile follows */,
-    u32 fail_tile /* a tile whose wave is to give up (tests of the way back); HUFD_NONE32: none */) {
+    u32 fail_tile /* a tile whose wave is to give up (tests of the way back); HUFD_NONE32: none */,
+    const u32 *__restrict__ solo_items = nullptr /* SOLO: the items, one tile each */,
+    u32 n_solo = 0) {
 
     HUFD_STAMP_DECL
     HUFD_STAMP_ZERO;
@@ -2053,20 +2060,34 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
     }
     __syncthreads();
     const u8 *mine = reinterpret_cast<const u8 *>(tab) + (lane & 31u) * 4u;
-    const u32 n_tiles = n_segs * kTilesPerSeg;
+    const u32 n_tiles = SOLO ? n_solo : n_segs * kTilesPerSeg;
 
     /* (t is a scalar, the descriptor arrays are read-only: these are scalar loads, no vector registers, no vector-memory wait) */
     auto describe = [&](u32 t) -> op_tile {
         op_tile d;
         const u32 tc = t < n_tiles ? t : n_tiles - 1; /* (a tile past the end is never worked on) */
         d.t = t;
-        d.s = tc / kTilesPerSeg;
-        d.w4 = tc % kTilesPerSeg;
-        d.seg = segs[d.s];
+        if (SOLO) {
+            /* the item is its own one segment, and that segment's one tile */
+            const u32 item = solo_items[tc];
+            d.s = tc;
+            d.w4 = 0;
+            d.seg.in_off = items[item].in_off;
+            d.seg.len = (u32)items[item].in_len;
+            d.seg.item = item;
+            d.seg.index = 0;
+            d.seg.flags = 3;
+            d.seg.next_len = 0;
+            d.seg.reserved = 0;
+        } else {
+            d.s = tc / kTilesPerSeg;
+            d.w4 = tc % kTilesPerSeg;
+            d.seg = segs[d.s];
+        }
         const u8 *src = d_in + d.seg.in_off;
         d.carried = items[d.seg.item].ovf_bits;
         d.carried_pattern = items[d.seg.item].ovf_pattern;
-        d.item_first_tile = items[d.seg.item].first_seg * kTilesPerSeg;
+        d.item_first_tile = SOLO ? t : items[d.seg.item].first_seg * kTilesPerSeg;
         d.tsrc = src + d.w4 * kTileBytes;
         const u32 from = d.w4 * kTileBytes;
         d.n_sym = (t < n_tiles && d.seg.len > from) ? (d.seg.len - from < kTileBytes ? d.seg.len - from : kTileBytes) : 0u;
@@ -2085,7 +2106,7 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
      * then 9 of 10 tiles found their round's base missing at the first look and every wave polled a third of its
      * time, in step with the one wave that held the round's last tile).
      */
-    if (blockIdx.x == 0 && wave == kPackWaves - 1) {
+    if (!SOLO && blockIdx.x == 0 && wave == kPackWaves - 1) {
         const u32 full_rounds = n_tiles / kOpRoundTiles; /* (nobody asks for the base behind a round that is not full) */
         u64 base = 0;
         if (lane == 0) {
@@ -2125,8 +2146,8 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
     }
     /* tiles in turn over the packing waves of the grid: the tiles a tile waits for belong to this turn or an earlier
      * one, so to the running waves as long as the whole grid is resident (the launch sizes it so) */
-    const u32 stride = gridDim.x * kPackWaves - 1;
-    u32 t_new = blockIdx.x * kPackWaves + wave - (blockIdx.x ? 1u : 0u);
+    const u32 stride = gridDim.x * kPackWaves - (SOLO ? 0u : 1u);
+    u32 t_new = blockIdx.x * kPackWaves + wave - (!SOLO && blockIdx.x ? 1u : 0u);
     if (t_new >= n_tiles) {
         return;
     }
@@ -2181,6 +2202,11 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
      * it, the tiles of its group in front of it, its item's base.  Every lane, no branch: the compiler then knows how
      * many younger loads a wait for these may leave in flight. */
     auto ask_offsets = [&](u32 &a_raw, u64 &b_raw, u64 &rb_raw, u64 &ib_raw) {
+        if (SOLO) {
+            a_raw = 0;
+            b_raw = rb_raw = ib_raw = 0;
+            return;
+        }
         const u32 g = old.t / kOpGroupTiles, p = old.t % kOpGroupTiles, r = g / kOpRoundGroups, gi_r = g % kOpRoundGroups;
         a_raw = word_load(&tile_agg[g * kOpGroupTiles + (lane < p ? lane : 0u)]);
         b_raw = granule_load(&group_acc[(u64)(r * kOpRoundGroups + (lane < gi_r ? lane : 0u)) * kOpGroupStride]);
@@ -2202,8 +2228,8 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         const u32 since = old.t - old.item_first_tile; /* tiles of my item in front of me */
         const bool near = since <= p;
         u64 ib = (old.first_tile || near) ? kOpReady : (seg.item == base_item ? base_value : ib_raw);
-        bool gave_up = old.t == fail_tile;
-        for (u32 spins = 0; !gave_up; ++spins) {
+        bool gave_up = !SOLO && old.t == fail_tile;
+        for (u32 spins = 0; !gave_up && !SOLO; ++spins) {
             const bool there = (a & kOpTileReady) != 0 && (b >> 40) == kOpGroupTiles && (rb & kOpReady) != 0 &&
                                (ib & kOpReady) != 0;
             if (spins == 0) {
@@ -2261,7 +2287,9 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         const u32 in_round = (u32)sums, in_item = (u32)(sums >> 32);
         const u64 before = uniform64((rb & ~kOpReady) + in_round); /* bits of every tile of the plan in front of this one */
         u64 bw; /* stream bit (inside the item) of the tile's first code */
-        if (old.first_tile) {
+        if (SOLO) {
+            bw = old.carried;
+        } else if (old.first_tile) {
             bw = old.carried;
             base_value = kOpReady | before;
             base_item = seg.item;
@@ -2280,7 +2308,7 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         const u64 out_cap = uniform64(items[seg.item].out_cap);
         const u64 cap_bits = out_cap > (~0ull >> 3) ? ~0ull : out_cap * 8;
         /* ---- what enc_finish_kernel turns into the call's outcome: the item's bit total ... */
-        if (lane == 0 && old.w4 == kTilesPerSeg - 1 && (seg.flags & 2u)) {
+        if (lane == 0 && (SOLO || old.w4 == kTilesPerSeg - 1) && (seg.flags & 2u)) {
             item_total[seg.item] = bn; /* (tiles behind the item's last symbol hold no bits) */
         }
         /* ... and, when the output is too short, which tile holds the symbol whose last bit reaches the capacity edge (exactly
@@ -2427,7 +2455,7 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         HUFD_STAMP_ADD(2, 1);
 
         /* tell the tiles behind the fresh one (see arrival_quiet) */
-        if (lane == 0) {
+        if (!SOLO && lane == 0) {
             arrival_quiet(&tile_agg[fresh.t], kOpTileReady | fresh.bits, &group_acc[(u64)(fresh.t / kOpGroupTiles) * kOpGroupStride], kOpArrive | fresh.bits);
         }
         if (have_old) {
@@ -2565,9 +2593,12 @@ __global__ __launch_bounds__(256) void enc_finish_kernel(
     hufd_enc_item_state *states,
     hufd_enc_result *results,
     const u32 *gave_up /* the word enc_onepass raises when a look-back wait ran out: totals and notes are not whole then, and
-                        * the three-kernel road behind this kernel does the launch over, records included */) {
+                        * the three-kernel road behind this kernel does the launch over, records included */,
+    u32 which /* bit 0: the items with segments; bit 1: the items of one tile that the plan lists apart (their kernel waits
+               * for nobody: whatever road the others took, theirs are whole) */) {
 
-    if (gave_up[0] != 0) {
+    const bool with_segments = (which & 1u) && !(gave_up && gave_up[0] != 0), solo = (which & 2u) != 0;
+    if (!with_segments && !solo) {
         return;
     }
     u64 *note_first = reinterpret_cast<u64 *>(dyn_lds), *note_bit = note_first + 256; /* kFinishLdsBytes */
@@ -2580,9 +2611,10 @@ __global__ __launch_bounds__(256) void enc_finish_kernel(
     }
     code_len[tid] = (u32)(tb.enc_table[tid] >> 32);
     __syncthreads();
-    if (tid < kFinishItems && i < n_items && !items[i].tiny /* enc_tiny's */) {
+    const u32 road = tid < kFinishItems && i < n_items ? items[i].tiny : 1u; /* (1: enc_tiny's) */
+    if ((road == 0 && with_segments) || (road == 2 && solo)) {
         const hufd_enc_item it = items[i];
-        const u64 total = it.n_segs ? item_total[i] : it.ovf_bits;
+        const u64 total = (it.n_segs || road == 2) ? item_total[i] : it.ovf_bits;
         const u64 cap_bits = it.out_cap > (~0ull >> 3) ? ~0ull : it.out_cap * 8;
         const hufd_enc_result note = results[i];
         hufd_enc_result rs;
@@ -2720,7 +2752,8 @@ hipError_t hufk_host::init_encode(int lds_max) {
     const void *kernels[] = {
         reinterpret_cast<const void *>(&enc_pack_kernel),      reinterpret_cast<const void *>(&enc_pack_stream_kernel),
         reinterpret_cast<const void *>(&enc_pack_wave_kernel<4>), reinterpret_cast<const void *>(&enc_pack_wave_kernel<5>),
-        reinterpret_cast<const void *>(&enc_onepass_kernel<4>),   reinterpret_cast<const void *>(&enc_onepass_kernel<5>)};
+        reinterpret_cast<const void *>(&enc_onepass_kernel<4>),   reinterpret_cast<const void *>(&enc_onepass_kernel<5>),
+        reinterpret_cast<const void *>(&enc_onepass_kernel<4, true>), reinterpret_cast<const void *>(&enc_onepass_kernel<5, true>)};
     for (const void *k : kernels) {
         if (e == hipSuccess) {
             e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -2730,6 +2763,46 @@ hipError_t hufk_host::init_encode(int lds_max) {
 }
 
 static void encode_three_kernels(const struct hufk_encode_args *a, hipStream_t st, const u32 *gate);
+
+/* the items of one tile that the plan lists apart (enc_onepass<.., SOLO>: a wave an item, nobody waits for anybody), and
+ * their outcomes; a launch that only asks for lengths counts them a thread each */
+static void encode_solo_items(const struct hufk_encode_args *a, hipStream_t st, bool finish) {
+    if (!a->n_solo) {
+        return;
+    }
+    if (a->length_only) {
+        hipLaunchKernelGGL(
+            enc_tiny_kernel, dim3((a->n_solo + kTinyThreads - 1) / kTinyThreads), dim3(kTinyThreads), 256 * sizeof(u64), st, a->tables,
+            a->items, a->solo_items, a->n_solo, (const u8 *)a->d_in, (u8 *)a->d_out, a->results, 1u);
+        return;
+    }
+    const onepass_layout l = onepass_layout_of(a->n_segs, a->n_items);
+    const uint8_t *z = (const uint8_t *)a->zero_block;
+    if (finish) { /* (no one-pass launch ahead of this one has cleared the block) */
+        (void)hipMemsetAsync((void *)(z + l.null_tile), 0, l.bytes - l.null_tile, st);
+    }
+    const uint32_t region = pack_region_bytes(a->tables.enc_max_bits);
+    const uint32_t lds = kPackTabBytes + kPackWaves * region;
+    const uint32_t work = (a->n_solo + kPackWaves - 1) / kPackWaves;
+#define HUFK_LAUNCH_SOLO(NWV)                                                                                          \
+    hipLaunchKernelGGL(                                                                                                \
+        (enc_onepass_kernel<NWV, true>), dim3(persistent_grid(enc_onepass_kernel<NWV, true>, kPackThreads, lds, work)), \
+        dim3(kPackThreads), lds, st, a->tables, a->items, (const hufd_enc_seg *)nullptr, (const u8 *)a->d_in,          \
+        (u8 *)a->d_out, region, 0u, (u32 *)nullptr, (u32 *)nullptr, (u64 *)nullptr, (u64 *)nullptr, (u64 *)nullptr,     \
+        a->item_total, a->results, z + l.null_tile, HUFD_NONE32, a->solo_items, a->n_solo)
+    if (a->tables.enc_max_bits <= 12) {
+        HUFK_LAUNCH_SOLO(4);
+    } else {
+        HUFK_LAUNCH_SOLO(5);
+    }
+#undef HUFK_LAUNCH_SOLO
+    if (finish) {
+        hipLaunchKernelGGL(
+            enc_finish_kernel, dim3((a->n_items + kFinishItems - 1) / kFinishItems), dim3(256), kFinishLdsBytes, st, a->tables,
+            a->items, a->n_items, a->item_total, (const u8 *)a->d_in, a->careful_list, a->careful_count, a->states, a->results,
+            (const u32 *)nullptr, 2u);
+    }
+}
 
 extern "C" {
 
@@ -2764,8 +2837,9 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
     if (a->n_segs == 0 && a->n_items == 0) {
         return 0;
     }
-    if (a->n_segs && !a->length_only && a->single_pass && hufk_encode_one_pass_applies(&a->tables) && a->zero_block) {
-        /* one pass: count + offsets + pack in one kernel, then the per-item outcome */
+    if ((a->n_segs || a->n_solo) && !a->length_only && a->single_pass && hufk_encode_one_pass_applies(&a->tables) && a->zero_block) {
+        /* one pass: count + offsets + pack in one kernel (and the items of one tile by a kernel of their own, a wave each),
+         * then the per-item outcome */
         const onepass_layout l = onepass_layout_of(a->n_segs, a->n_items);
         uint8_t *z = (uint8_t *)a->zero_block;
         stage_mark(a->stage_events, 0, st); /* (the clearing of the look-back words is part of what is timed) */
@@ -2780,17 +2854,20 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
         a->n_segs, (u32 *)(z + l.ctl), (u32 *)(z + l.tile_agg), (u64 *)(z + l.group_acc),                              \
         (u64 *)(z + l.round_base), (u64 *)(z + l.item_base), a->item_total, a->results, (const u8 *)(z + l.null_tile),  \
         a->fail_tile ? a->n_segs * kTilesPerSeg / 2 : HUFD_NONE32)
-        if (a->tables.enc_max_bits <= 12) {
+        if (!a->n_segs) {
+            /* (items of one tile only) */
+        } else if (a->tables.enc_max_bits <= 12) {
             HUFK_LAUNCH_ONEPASS(4);
         } else {
             HUFK_LAUNCH_ONEPASS(5);
         }
 #undef HUFK_LAUNCH_ONEPASS
+        encode_solo_items(a, st, false);
         stage_mark(a->stage_events, 1, st);
         hipLaunchKernelGGL(
             enc_finish_kernel, dim3((a->n_items + kFinishItems - 1) / kFinishItems), dim3(256), kFinishLdsBytes, st, a->tables, a->items, a->n_items,
             a->item_total, (const u8 *)a->d_in, a->careful_list, a->careful_count, a->states, a->results,
-            (const u32 *)(z + l.ctl) + 1);
+            (const u32 *)(z + l.ctl) + 1, a->n_solo ? 3u : 1u);
         stage_mark(a->stage_events, 2, st);
         if (a->n_tiny) {
             hipLaunchKernelGGL(
@@ -2802,12 +2879,15 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
         /* The way back, on the same stream: the three-kernel road (no waits between workgroups) queued behind the one
          * pass, every kernel of it looking first at the word a wave raises when a look-back wait runs out -- whoever
          * works on the output behind this launch finds it whole either way, without the host in between. */
-        encode_three_kernels(a, st, (const u32 *)(z + l.ctl) + 1);
+        if (a->n_segs) {
+            encode_three_kernels(a, st, (const u32 *)(z + l.ctl) + 1);
+        }
         stage_mark(a->stage_events, 3, st);
         return (int)hipGetLastError();
     }
     stage_mark(a->stage_events, 0, st);
     encode_three_kernels(a, st, nullptr);
+    encode_solo_items(a, st, true);
     stage_mark(a->stage_events, 3, st);
     return (int)hipGetLastError();
 }

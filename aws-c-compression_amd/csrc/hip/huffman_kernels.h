@@ -23,6 +23,8 @@ struct hufk_encode_args {
     uint32_t n_large;
     const uint32_t *tiny_items;  /* [n_tiny] items of at most HUFD_ENC_TINY_BYTES symbols: no segments, one thread each */
     uint32_t n_tiny;
+    const uint32_t *solo_items;  /* [n_solo] items of one tile at most (hufd_enc_item.tiny == 2): no segments, one wave each */
+    uint32_t n_solo;
     uint32_t length_only; /* stop after the scan */
     const void *d_in;
     void *d_out;
@@ -135,7 +137,7 @@ int hufk_decode_plan_chunks(
  * of the plan's arrays and of the launch's grids are the host's to know).  _fill: the records and lists, from the same scratch. */
 struct hufk_plan_totals {
     uint64_t totals[8]; /* decode: chunks, thread items, wave items, large items, runs, narrow / wide end-of-stream chunks, items
-                         * with chunks; encode: segments, thread items, -, large items, -, -, -, items with segments */
+                         * with chunks; encode: segments, thread items, one-tile items, large items, -, -, -, items with segments */
     uint64_t tiny_limit;
     uint64_t shortest, longest, largest_out_cap, tail_stage, tail_lanes;
     uint32_t worst_bits, invalid;
@@ -148,11 +150,11 @@ int hufk_decode_plan_fill(
     const struct hufd_item_source *src, uint32_t n_items, uint32_t shortest_code_bits, const void *scratch, struct hufd_dec_item *items,
     uint32_t *tiny_list, uint32_t *tail_list, uint32_t *large_list, uint32_t *run_list, void *stream);
 int hufk_encode_plan_count(
-    const struct hufd_item_source *src, uint32_t n_items, uint64_t class0, uint64_t class1, uint64_t per_byte, void *scratch,
-    struct hufk_plan_totals *totals, void *stream);
+    const struct hufd_item_source *src, uint32_t n_items, uint64_t class0, uint64_t class1, uint64_t per_byte, uint64_t solo_limit,
+    void *scratch, struct hufk_plan_totals *totals, void *stream);
 int hufk_encode_plan_fill(
-    const struct hufd_item_source *src, uint32_t n_items, uint32_t n_segs, const void *scratch, struct hufd_enc_item *items,
-    struct hufd_enc_seg *segs, uint32_t *tiny_list, uint32_t *large_list, void *stream);
+    const struct hufd_item_source *src, uint32_t n_items, uint32_t n_segs, uint64_t solo_limit, const void *scratch,
+    struct hufd_enc_item *items, struct hufd_enc_seg *segs, uint32_t *tiny_list, uint32_t *large_list, uint32_t *solo_list, void *stream);
 /* one short item whose record already sits in device memory (the host-pointer calls' small-input road): one launch */
 int hufk_encode_one_tiny(
     const struct hufd_tables *tables, const struct hufd_enc_item *item, const uint32_t *zero, const void *d_in, void *d_out,

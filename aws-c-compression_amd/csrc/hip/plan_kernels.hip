@@ -202,8 +202,9 @@ __device__ __forceinline__ dec_counts count_dec_item(const raw_item &r, u64 tiny
     return c;
 }
 
-/* ... and one encode item: [0] segments, [1] thread-per-item items, [3] large items, [7] items with segments */
-__device__ __forceinline__ void count_enc_item(const raw_item &r, u64 tiny_limit, u32 *v) {
+/* ... and one encode item: [0] segments, [1] thread-per-item items, [2] one-tile items (a wave each), [3] large items,
+ * [7] items with segments */
+__device__ __forceinline__ void count_enc_item(const raw_item &r, u64 tiny_limit, u64 solo_limit, u32 *v) {
     for (u32 k = 0; k < kPlanVec; ++k) {
         v[k] = 0;
     }
@@ -211,6 +212,10 @@ __device__ __forceinline__ void count_enc_item(const raw_item &r, u64 tiny_limit
     v[1] = tiny;
     if (tiny || r.in_len == 0) {
         return; /* (an item with nothing to do and nothing carried has no segments either: (0 + 16383) / 16384) */
+    }
+    if (r.in_len <= solo_limit) {
+        v[2] = 1;
+        return;
     }
     const u32 segs = (u32)((r.in_len + HUFD_ENC_SEG_BYTES - 1) / HUFD_ENC_SEG_BYTES);
     v[0] = segs;
@@ -221,7 +226,7 @@ __device__ __forceinline__ void count_enc_item(const raw_item &r, u64 tiny_limit
 /* the workgroup's sums of every counter, for the scan over workgroups */
 template <bool ENC>
 __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(
-    hufd_item_source src, u32 n_items, const plan_decision *decision, u32 shortest_code, plan_stats *stats, u32 *block_sums) {
+    hufd_item_source src, u32 n_items, const plan_decision *decision, u32 shortest_code, u64 solo_limit, plan_stats *stats, u32 *block_sums) {
     u32 *sums = reinterpret_cast<u32 *>(dyn_lds); /* [kPlanVec] */
     u64 *maxes = reinterpret_cast<u64 *>(dyn_lds + 64); /* tail_stage, tail_lanes */
     if (threadIdx.x < kPlanVec) {
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(
     if (i < n_items) {
         const raw_item r = load_item<ENC>(src, i);
         if (ENC) {
-            count_enc_item(r, decision->tiny_limit, v);
+            count_enc_item(r, decision->tiny_limit, solo_limit, v);
         } else {
             const dec_counts c = count_dec_item(r, decision->tiny_limit, shortest_code);
             for (u32 k = 0; k < kPlanVec; ++k) {
@@ -371,8 +376,8 @@ __global__ __launch_bounds__(kPlanThreads) void plan_dec_fill_kernel(
 }
 
 __global__ __launch_bounds__(kPlanThreads) void plan_enc_fill_kernel(
-    hufd_item_source src, u32 n_items, const plan_decision *decision, const u32 *block_sums, hufd_enc_item *items, u32 *tiny_list,
-    u32 *large_list) {
+    hufd_item_source src, u32 n_items, const plan_decision *decision, u64 solo_limit, const u32 *block_sums, hufd_enc_item *items,
+    u32 *tiny_list, u32 *large_list, u32 *solo_list) {
     u32 *slots = reinterpret_cast<u32 *>(dyn_lds);
     const u32 i = blockIdx.x * kPlanThreads + threadIdx.x;
     raw_item r;
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_enc_fill_kernel(
     }
     if (i < n_items) {
         r = load_item<true>(src, i);
-        count_enc_item(r, decision->tiny_limit, v);
+        count_enc_item(r, decision->tiny_limit, solo_limit, v);
     }
     u32 pos[kPlanVec];
     positions_of(v, block_sums + (u64)blockIdx.x * kPlanVec, slots, pos);
@@ -399,10 +404,13 @@ __global__ __launch_bounds__(kPlanThreads) void plan_enc_fill_kernel(
     it.eos_padding = r.eos;
     it.first_seg = pos[0];
     it.n_segs = v[0];
-    it.tiny = v[1];
+    it.tiny = v[1] ? 1u : (v[2] ? 2u : 0u);
     items[i] = it;
     if (v[1]) {
         tiny_list[pos[1]] = i;
+    }
+    if (v[2]) {
+        solo_list[pos[2]] = i;
     }
     if (v[3]) {
         large_list[pos[3]] = i;
@@ -447,7 +455,7 @@ u32 plan_blocks(u32 n_items) {
 
 template <bool ENC>
 int plan_count(
-    const hufd_item_source *src, u32 n_items, u64 class0, u64 class1, u64 per_byte, u32 shortest_code, void *scratch,
+    const hufd_item_source *src, u32 n_items, u64 class0, u64 class1, u64 per_byte, u32 shortest_code, u64 solo_limit, void *scratch,
     hufk_plan_totals *out, hipStream_t st) {
     plan_stats *stats = reinterpret_cast<plan_stats *>(scratch);
     plan_decision *decision = reinterpret_cast<plan_decision *>(reinterpret_cast<u8 *>(scratch) + sizeof(plan_stats));
@@ -459,7 +467,7 @@ int plan_count(
     }
     hipLaunchKernelGGL((plan_stats_kernel<ENC>), dim3(blocks), dim3(kPlanThreads), sizeof(plan_stats), st, *src, n_items, class0, class1, stats);
     hipLaunchKernelGGL(plan_decide_kernel, dim3(1), dim3(64), 0, st, stats, class0, class1, per_byte, decision);
-    hipLaunchKernelGGL((plan_count_kernel<ENC>), dim3(blocks), dim3(kPlanThreads), 128, st, *src, n_items, decision, shortest_code, stats, block_sums);
+    hipLaunchKernelGGL((plan_count_kernel<ENC>), dim3(blocks), dim3(kPlanThreads), 128, st, *src, n_items, decision, shortest_code, solo_limit, stats, block_sums);
     hipLaunchKernelGGL(plan_scan_blocks_kernel, dim3(1), dim3(kPlanThreads), 128, st, block_sums, blocks, decision);
     struct {
         plan_stats s;
@@ -497,7 +505,7 @@ uint64_t hufk_plan_scratch_bytes(uint64_t n_items) {
 int hufk_decode_plan_count(
     const struct hufd_item_source *src, uint32_t n_items, uint64_t per_byte, uint32_t shortest_code_bits, void *scratch,
     struct hufk_plan_totals *totals, void *stream) {
-    return plan_count<false>(src, n_items, HUFD_DEC_COOP_BYTES, HUFD_DEC_TINY_BYTES, per_byte, shortest_code_bits, scratch, totals, (hipStream_t)stream);
+    return plan_count<false>(src, n_items, HUFD_DEC_COOP_BYTES, HUFD_DEC_TINY_BYTES, per_byte, shortest_code_bits, 0, scratch, totals, (hipStream_t)stream);
 }
 
 int hufk_decode_plan_fill(
@@ -512,19 +520,19 @@ int hufk_decode_plan_fill(
 }
 
 int hufk_encode_plan_count(
-    const struct hufd_item_source *src, uint32_t n_items, uint64_t class0, uint64_t class1, uint64_t per_byte, void *scratch,
-    struct hufk_plan_totals *totals, void *stream) {
-    return plan_count<true>(src, n_items, class0, class1, per_byte, 0, scratch, totals, (hipStream_t)stream);
+    const struct hufd_item_source *src, uint32_t n_items, uint64_t class0, uint64_t class1, uint64_t per_byte, uint64_t solo_limit,
+    void *scratch, struct hufk_plan_totals *totals, void *stream) {
+    return plan_count<true>(src, n_items, class0, class1, per_byte, 0, solo_limit, scratch, totals, (hipStream_t)stream);
 }
 
 int hufk_encode_plan_fill(
-    const struct hufd_item_source *src, uint32_t n_items, uint32_t n_segs, const void *scratch, struct hufd_enc_item *items,
-    struct hufd_enc_seg *segs, uint32_t *tiny_list, uint32_t *large_list, void *stream) {
+    const struct hufd_item_source *src, uint32_t n_items, uint32_t n_segs, uint64_t solo_limit, const void *scratch,
+    struct hufd_enc_item *items, struct hufd_enc_seg *segs, uint32_t *tiny_list, uint32_t *large_list, uint32_t *solo_list, void *stream) {
     const plan_decision *decision = reinterpret_cast<const plan_decision *>(reinterpret_cast<const u8 *>(scratch) + sizeof(plan_stats));
     const u32 *block_sums = reinterpret_cast<const u32 *>(reinterpret_cast<const u8 *>(scratch) + sizeof(plan_stats) + sizeof(plan_decision));
     hipLaunchKernelGGL(
         plan_enc_fill_kernel, dim3(plan_blocks(n_items)), dim3(kPlanThreads), 64, (hipStream_t)stream, *src, n_items, decision,
-        block_sums, items, tiny_list, large_list);
+        solo_limit, block_sums, items, tiny_list, large_list, solo_list);
     if (n_segs) {
         hipLaunchKernelGGL(
             plan_enc_segs_kernel, dim3((n_segs + kPlanThreads - 1) / kPlanThreads), dim3(kPlanThreads), 0, (hipStream_t)stream,

@@ -481,6 +481,7 @@ static size_t arena_cut(size_t *total, size_t bytes) {
     X(d_segs, (cs) * sizeof(struct hufd_enc_seg))                                                                      \
     X(d_large, (cl) * sizeof(uint32_t))                                                                                \
     X(d_tiny, (ct) * sizeof(uint32_t))                                                                                 \
+    X(d_solo, (ci) * sizeof(uint32_t))                                                                                 \
     X(d_seg_bits, (cs) * sizeof(uint32_t))                                                                             \
     X(d_wave_bits, (cs) * 4 * sizeof(uint32_t))                                                                        \
     X(d_seg_unk, (cs) * sizeof(uint32_t))                                                                              \
@@ -580,9 +581,18 @@ static uint64_t enc_tiny_limit(
     return HUFD_TINY_FEW_BYTES;
 }
 
-static uint64_t enc_item_segments(const struct aws_huffman_amd_encode_item *it, uint64_t tiny_limit) {
-    if (enc_item_is_tiny(it, tiny_limit)) {
-        return 0; /* one thread encodes it (enc_tiny) */
+/* the longest item that is one wave's work without segments (enc_onepass<.., SOLO>: the one-pass packer, waiting for nobody) */
+static uint64_t enc_solo_limit(const struct aws_huffman_amd_engine *eng) {
+    return aws_huffman_amd_engine_encodes_in_one_pass(eng) ? HUFD_ENC_SOLO_BYTES : 0;
+}
+
+static bool enc_item_is_solo(const struct aws_huffman_amd_encode_item *it, uint64_t tiny_limit, uint64_t solo_limit) {
+    return !enc_item_is_tiny(it, tiny_limit) && it->in_len > 0 && it->in_len <= solo_limit;
+}
+
+static uint64_t enc_item_segments(const struct aws_huffman_amd_encode_item *it, uint64_t tiny_limit, uint64_t solo_limit) {
+    if (enc_item_is_tiny(it, tiny_limit) || enc_item_is_solo(it, tiny_limit, solo_limit)) {
+        return 0; /* one thread encodes it (enc_tiny), or one wave */
     }
     return (it->in_len + HUFD_ENC_SEG_BYTES - 1) / HUFD_ENC_SEG_BYTES;
 }
@@ -625,7 +635,7 @@ static int enc_plan_fill(
     struct item_stats stats;
     const uint64_t tiny_limit = enc_tiny_limit(eng, items, n_items, &stats);
     /* a failed refill must not leave counts of the fill before behind (the device arrays may be gone or too small) */
-    p->n_items = p->n_segs = p->n_large = p->n_tiny = 0;
+    p->n_items = p->n_segs = p->n_large = p->n_tiny = p->n_solo = 0;
     p->launched = false; /* (the records of a launch of other items say nothing about these) */
     memset(&p->stats, 0, sizeof(p->stats));
     p->largest_out_cap = stats.largest_out_cap;
@@ -659,15 +669,17 @@ static int enc_plan_fill(
         p->stats.thread_limit = tiny_limit;
         return AWS_OP_SUCCESS;
     }
-    uint64_t n_segs = 0, n_large = 0, n_tiny = 0, n_cut = 0;
+    const uint64_t solo_limit = enc_solo_limit(eng);
+    uint64_t n_segs = 0, n_large = 0, n_tiny = 0, n_cut = 0, n_solo = 0;
     for (size_t i = 0; i < n_items; ++i) {
         if (items[i].overflow_in.num_bits > 32) {
             return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
         }
-        const uint64_t segs = enc_item_segments(&items[i], tiny_limit);
+        const uint64_t segs = enc_item_segments(&items[i], tiny_limit, solo_limit);
         n_segs += segs;
         n_large += segs > HUFD_SCAN_SMALL_MAX;
         n_tiny += enc_item_is_tiny(&items[i], tiny_limit);
+        n_solo += enc_item_is_solo(&items[i], tiny_limit, solo_limit);
         n_cut += segs != 0;
     }
     if (n_segs >= 0xFFFFFFFFull || n_items >= 0xFFFFFFFFull) {
@@ -678,18 +690,20 @@ static int enc_plan_fill(
     struct hufd_enc_seg *h_segs = malloc((n_segs ? n_segs : 1) * sizeof(*h_segs));
     uint32_t *h_large = malloc((n_large ? n_large : 1) * sizeof(uint32_t));
     uint32_t *h_tiny = malloc((n_tiny ? n_tiny : 1) * sizeof(uint32_t));
-    if (!h_items || !h_segs || !h_large || !h_tiny) {
+    uint32_t *h_solo = malloc((n_solo ? n_solo : 1) * sizeof(uint32_t));
+    if (!h_items || !h_segs || !h_large || !h_tiny || !h_solo) {
         free(h_items);
         free(h_segs);
         free(h_large);
         free(h_tiny);
+        free(h_solo);
         return aws_raise_error(AWS_ERROR_OOM);
     }
-    uint32_t seg = 0, large = 0, tiny = 0;
+    uint32_t seg = 0, large = 0, tiny = 0, solo = 0;
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_encode_item *src = &items[i];
         struct hufd_enc_item *dst = &h_items[i];
-        const uint32_t segs = (uint32_t)enc_item_segments(src, tiny_limit);
+        const uint32_t segs = (uint32_t)enc_item_segments(src, tiny_limit, solo_limit);
         const uint32_t ob = src->overflow_in.num_bits;
         dst->in_off = src->in_offset;
         dst->in_len = src->in_len;
@@ -700,9 +714,11 @@ static int enc_plan_fill(
         dst->eos_padding = src->eos_padding;
         dst->first_seg = seg;
         dst->n_segs = segs;
-        dst->tiny = enc_item_is_tiny(src, tiny_limit) ? 1u : 0u;
-        if (dst->tiny) {
+        dst->tiny = enc_item_is_tiny(src, tiny_limit) ? 1u : (enc_item_is_solo(src, tiny_limit, solo_limit) ? 2u : 0u);
+        if (dst->tiny == 1) {
             h_tiny[tiny++] = (uint32_t)i;
+        } else if (dst->tiny == 2) {
+            h_solo[solo++] = (uint32_t)i;
         }
         for (uint32_t k = 0; k < segs; ++k) {
             struct hufd_enc_seg *sd = &h_segs[seg++];
@@ -738,12 +754,16 @@ static int enc_plan_fill(
         err = hufs_copy_h2d(p->d_tiny, h_tiny, n_tiny * sizeof(uint32_t), eng->stream);
     }
     if (!err) {
+        err = hufs_copy_h2d(p->d_solo, h_solo, n_solo * sizeof(uint32_t), eng->stream);
+    }
+    if (!err) {
         err = hufs_stream_sync(eng->stream);
     }
     free(h_items);
     free(h_segs);
     free(h_large);
     free(h_tiny);
+    free(h_solo);
     if (err) {
         return raise_hip(err);
     }
@@ -751,12 +771,14 @@ static int enc_plan_fill(
     p->n_segs = (uint32_t)n_segs;
     p->n_large = (uint32_t)n_large;
     p->n_tiny = (uint32_t)n_tiny;
+    p->n_solo = (uint32_t)n_solo;
     p->stats.items = n_items;
     p->stats.thread_limit = tiny_limit;
     p->stats.by_thread = n_tiny;
+    p->stats.by_wave = n_solo;
     p->stats.by_pieces = n_cut;
     p->stats.pieces = n_segs;
-    p->stats.empty = n_items - n_tiny - n_cut;
+    p->stats.empty = n_items - n_tiny - n_solo - n_cut;
     return AWS_OP_SUCCESS;
 }
 
@@ -835,7 +857,7 @@ static int enc_plan_fill_on_device(struct aws_huffman_amd_encode_plan *p, const 
     if (!eng->can_encode) {
         return aws_raise_error(AWS_ERROR_UNSUPPORTED_OPERATION);
     }
-    p->n_items = p->n_segs = p->n_large = p->n_tiny = 0;
+    p->n_items = p->n_segs = p->n_large = p->n_tiny = p->n_solo = 0;
     p->launched = false;
     p->look_back_timed_out = false;
     memset(&p->stats, 0, sizeof(p->stats));
@@ -853,7 +875,8 @@ static int enc_plan_fill_on_device(struct aws_huffman_amd_encode_plan *p, const 
     int e = plan_scratch_reserve(&p->d_plan_scratch, &p->cap_plan_scratch, n_items);
     if (!e) {
         const uint64_t class0 = aws_huffman_amd_engine_encodes_in_one_pass(eng) ? HUFD_ENC_TINY_WAVE_BYTES : HUFD_TINY_MANY_BYTES;
-        e = hufk_encode_plan_count(src, (uint32_t)n_items, class0, HUFD_ENC_TINY_BYTES, enc_tiny_per_byte(eng), p->d_plan_scratch, &t, st);
+        e = hufk_encode_plan_count(
+            src, (uint32_t)n_items, class0, HUFD_ENC_TINY_BYTES, enc_tiny_per_byte(eng), enc_solo_limit(eng), p->d_plan_scratch, &t, st);
     }
     if (e) {
         return raise_hip(e);
@@ -864,7 +887,8 @@ static int enc_plan_fill_on_device(struct aws_huffman_amd_encode_plan *p, const 
     e = enc_plan_reserve(p, n_items, (size_t)t.totals[0], (size_t)t.totals[3], (size_t)t.totals[1]);
     if (!e) {
         e = hufk_encode_plan_fill(
-            src, (uint32_t)n_items, (uint32_t)t.totals[0], p->d_plan_scratch, p->d_items, p->d_segs, p->d_tiny, p->d_large, st);
+            src, (uint32_t)n_items, (uint32_t)t.totals[0], enc_solo_limit(eng), p->d_plan_scratch, p->d_items, p->d_segs, p->d_tiny,
+            p->d_large, p->d_solo, st);
     }
     if (e) {
         return raise_hip(e);
@@ -873,14 +897,16 @@ static int enc_plan_fill_on_device(struct aws_huffman_amd_encode_plan *p, const 
     p->n_segs = (uint32_t)t.totals[0];
     p->n_large = (uint32_t)t.totals[3];
     p->n_tiny = (uint32_t)t.totals[1];
+    p->n_solo = (uint32_t)t.totals[2];
     p->largest_out_cap = t.largest_out_cap;
     p->most_overflow_bits = t.worst_bits;
     p->stats.items = n_items;
     p->stats.thread_limit = t.tiny_limit;
     p->stats.by_thread = t.totals[1];
+    p->stats.by_wave = t.totals[2];
     p->stats.by_pieces = t.totals[7];
     p->stats.pieces = t.totals[0];
-    p->stats.empty = n_items - t.totals[1] - t.totals[7];
+    p->stats.empty = n_items - t.totals[1] - t.totals[2] - t.totals[7];
     return AWS_OP_SUCCESS;
 }
 
@@ -969,6 +995,8 @@ int aws_huffman_amd_encode_plan_launch_staged(
     a.large_items = p->d_large;
     a.tiny_items = p->d_tiny;
     a.n_tiny = p->n_tiny;
+    a.solo_items = p->d_solo;
+    a.n_solo = p->n_solo;
     a.n_large = p->n_large;
     a.length_only = length_only;
     a.d_in = device_input;
@@ -987,7 +1015,8 @@ int aws_huffman_amd_encode_plan_launch_staged(
     p->last_input = device_input;
     p->last_output = device_output;
     p->launched = true;
-    p->last_single_pass = a.single_pass && p->n_segs && !length_only && hufk_encode_one_pass_applies(&p->engine->tables);
+    p->last_single_pass =
+        a.single_pass && (p->n_segs || p->n_solo) && !length_only && hufk_encode_one_pass_applies(&p->engine->tables);
     a.states = p->d_states;
     a.results = p->d_results;
     a.stage_events = stage_events;

@@ -70,6 +70,8 @@ struct aws_huffman_amd_encode_plan {
     uint32_t *d_large;
     uint32_t *d_tiny; /* items of at most HUFD_ENC_TINY_BYTES symbols */
     uint32_t n_tiny;
+    uint32_t *d_solo; /* items of at most HUFD_ENC_SOLO_BYTES symbols that no thread takes: a wave each, no segments */
+    uint32_t n_solo;
     size_t cap_tiny;
     uint32_t *d_seg_bits;
     uint32_t *d_wave_bits; /* [n_segs][4]: bits of each quarter of a segment */

@@ -1125,17 +1125,19 @@ def batched_device_api(w, n_items=9, seed=18, item_len=16384, engine=None):
         eng.close()
 
 
-def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False, max_len=560, edge_lens=True, thread_limit=None):
+def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False, max_len=560, edge_lens=True, thread_limit=None,
+                      wave_limit=None, more_lens=()):
     """Items either side of HUFD_ENC_TINY_BYTES (512 symbols; one thread each below it), with every kind
     of stop: roomy, exact, one byte short, cut anywhere, no room at all, carried overflow bits that fit,
     fill the output exactly or do not fit, symbols without a code.  thread_limit: the longest item the plan must give a
-    thread of its own (aws_huffman_amd_encode_plan_stats) -- the road is asserted, not assumed."""
+    thread of its own (aws_huffman_amd_encode_plan_stats) -- the road is asserted, not assumed; wave_limit: the longest
+    one that is a wave's work without segments (HUFD_ENC_SOLO_BYTES where the coder encodes in one pass, else 0)."""
     rng = np.random.default_rng(seed)
     own = engine is None or holes
     eng = harness.Engine(w.product.lib, w.pcoder_holes if holes else w.pcoder) if own else engine
     oc = w.ocoder_holes if holes else w.ocoder
-    lens = ([0, 0, 1, 2, 3, 511, 512, 513, 600] if edge_lens else [0, 0, 1, 2, 3, 127, 128, 129, max_len - 1]) + [
-        int(rng.integers(0, max_len)) for _ in range(n_items - 9)]
+    lens = ([0, 0, 1, 2, 3, 511, 512, 513, 600] if edge_lens else [0, 0, 1, 2, 3, 127, 128, 129, max_len - 1]) + list(more_lens)
+    lens += [int(rng.integers(0, max_len)) for _ in range(n_items - len(lens))]
     blobs = []
     for i, n in enumerate(lens):
         b = inputs(rng, n, KINDS[i % 4])
@@ -1178,7 +1180,11 @@ def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False, max_le
     eng.fill(d_out, SENTINEL, out_total)
     plan = eng.encode_plan(items)
     stats = eng.encode_stats(plan)
-    assert stats["items"] == len(items) and stats["by_thread"] + stats["by_pieces"] + stats["empty"] == len(items), stats
+    assert stats["items"] == len(items), stats
+    assert stats["by_thread"] + stats["by_wave"] + stats["by_pieces"] + stats["empty"] == len(items), stats
+    if wave_limit is not None:
+        by_wave = sum(1 for it in items if stats["thread_limit"] < it["in_len"] <= wave_limit)
+        assert stats["by_wave"] == by_wave and (by_wave > len(items) // 4 or not wave_limit), (stats, by_wave)
     if thread_limit is not None:
         by_thread = sum(1 for it in items if it["in_len"] <= thread_limit and (it["in_len"] or it["overflow_in"][1]))
         assert stats["thread_limit"] == thread_limit and stats["by_thread"] == by_thread, (stats, by_thread)

@@ -141,6 +141,20 @@ def test_tiny_encode_items(world):
         pc.tiny_encode_items(world, n_items=2300, seed=47, holes=True, max_len=2100, thread_limit=2048)  # (a coder with holes keeps to count / scan / pack: its class ends at 2048)
 
 
+def test_mid_sized_encode_items(world):
+    """Items either side of one tile (HUFD_ENC_SOLO_BYTES = 4096 symbols): a wave each without segments below it where the
+    coder encodes in one pass, segments above; every kind of stop of the short items' scenario, and the same items with
+    the one-pass road's look-back given up and with a coder that takes count / scan / pack."""
+    edges = (4095, 4096, 4097, 8192, 16384, 16385)
+    pc.tiny_encode_items(world, n_items=220, seed=151, max_len=9000, edge_lens=False, wave_limit=4096, more_lens=edges)
+    pc.tiny_encode_items(world, n_items=90, seed=152, max_len=4000, edge_lens=False, wave_limit=4096)  # (no segments at all)
+    pc.tiny_encode_items(world, n_items=120, seed=153, holes=True, max_len=9000, edge_lens=False, wave_limit=0, more_lens=edges)
+    with harness.encode_road(world.product.lib, "one-pass-fails"):
+        pc.tiny_encode_items(world, n_items=120, seed=154, max_len=9000, edge_lens=False, wave_limit=4096, more_lens=edges)
+    with harness.encode_road(world.product.lib, "three-kernel"):
+        pc.tiny_encode_items(world, n_items=120, seed=155, max_len=9000, edge_lens=False, wave_limit=0, more_lens=edges)
+
+
 def test_tiny_decode_items(world):
     pc.tiny_decode_items(world, n_items=400)  # a handful: one thread up to 128 bytes, one wave up to 768, chunks above
     pc.tiny_decode_items(world, n_items=3300, seed=44)  # 6 items per byte of the longest: one thread up to 512

@@ -178,6 +178,20 @@ def test_tiny_encode_items(world, engine):
     pc.tiny_encode_items(world, n_items=11000, seed=35, holes=True)
 
 
+def test_mid_sized_encode_items(world, engine):
+    """Items either side of one tile (HUFD_ENC_SOLO_BYTES = 4096 symbols): a wave each without segments below it where the
+    coder encodes in one pass, segments above (the encode twin of test_mid_sized_items); with every kind of stop of the
+    short items' scenario, a plan of such items only, a coder that takes count / scan / pack, and the two test roads."""
+    edges = (4095, 4096, 4097, 8192, 16384, 16385)
+    pc.tiny_encode_items(world, n_items=2500, seed=151, engine=engine, max_len=9000, edge_lens=False, wave_limit=4096, more_lens=edges)
+    pc.tiny_encode_items(world, n_items=5000, seed=152, engine=engine, max_len=4000, edge_lens=False, wave_limit=4096)
+    pc.tiny_encode_items(world, n_items=1200, seed=153, holes=True, max_len=9000, edge_lens=False, wave_limit=0, more_lens=edges)
+    with harness.encode_road(world.product.lib, "one-pass-fails"):
+        pc.tiny_encode_items(world, n_items=1200, seed=154, max_len=9000, edge_lens=False, wave_limit=4096, more_lens=edges)
+    with harness.encode_road(world.product.lib, "three-kernel"):
+        pc.tiny_encode_items(world, n_items=1200, seed=155, max_len=9000, edge_lens=False, wave_limit=0, more_lens=edges)
+
+
 def test_many_short_items_take_one_thread_each(world, engine):
     """A thread per item for a whole class of short items, by the library's own rule (HUFD_*_TINY_PER_BYTE items per byte of
     the class's longest item): the one-pass coder's enc_tiny on items of up to 1024 symbols, dec_tiny on items of up to 768
