@@ -257,7 +257,7 @@ struct lean_shared {
  * into exec -- so a trip is four vector instructions and a branch.  These kernels' time follows the vector instructions a
  * step costs (profiles/r05_micro: the walk at eight waves a SIMD is held by issue as much as by the LDS).  v62 / v63 are
  * the block's own temporaries (a 64-bit shift result whose low word becomes the address, then the entry). */
-template <u32 SURE, bool STEP_BY_STEP = false>
+template <u32 SURE, bool STEP_BY_STEP = false, bool PLAIN = false> /* PLAIN: the loop as the compiler writes it (a kernel held to 64 registers has none to set aside for the block) */
 __device__ __forceinline__ u32 lean_row(u32 state, u32 hi, u32 lo, u32 table, const row_walk &rw) {
     const u64 pair = ((u64)hi << 32) | lo;
     if (!STEP_BY_STEP) {
@@ -267,6 +267,12 @@ __device__ __forceinline__ u32 lean_row(u32 state, u32 hi, u32 lo, u32 table, co
         }
     }
 #if defined(__HIP_DEVICE_COMPILE__)
+    if (PLAIN) {
+        while ((state & 0xFFFFu) > rw.thr) {
+            state += lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
+        }
+        return state;
+    }
     u64 saved_exec;
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
@@ -384,7 +390,8 @@ struct one_shared {
     u32 wave_sum[HUFD_DEC_LANES / 64];
     u32 bad;
     u32 decided0; /* every entry state of sub-chunk 0 died or met lane 0's walk: what dec_sync_guess needs of a chunk */
-    u32 pad[2];
+    u32 moved;    /* a lane leaves its sub-chunk in another state than the lane behind it took for its entry */
+    u32 bad_mine; /* a lane's walk from its entry went wrong (which may be the entry's fault: see `moved`) */
 };
 
 template <u32 LB, u32 SURE, bool TAIL = false> /* TAIL: the chunks listed in tail_chunks (a stream ends in them) */
@@ -489,6 +496,8 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
     if (lane == 0) {
         sh.bad = 0;
         sh.decided0 = 0;
+        sh.moved = 0;
+        sh.bad_mine = 0;
 #pragma unroll
         for (u32 r = 0; r <= kOneMaxMerge0; ++r) {
             sh.sub0[r] = w[r];
@@ -524,15 +533,16 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
     }
     const u32 last = state;
     sh.kept[kOneRecs - 1][lane] = last; /* (the boundary behind the last row: the sub-chunk's end) */
-    const u32 ref_exit = ow.offset_of(last);
-    bool ok = !hopeless && (!active || ref_exit < ns);
+    u32 ref_exit = ow.offset_of(last); /* (how the lane leaves: the guessed walk's way, unless the true walk never met it) */
+    bool ok = !hopeless; /* what speaks against the chunk whatever its lanes' entries are ... */
+    bool ok_mine = !active || ref_exit < ns; /* ... and what may change for a lane when the lane in front of it leaves another way */
     sh.exit_state[lane] = ref_exit;
     HUFD_STAMP(0, 3);
     __syncthreads();
     HUFD_STAMP(0, 4);
 
     /* H: my own sub-chunk from my true entry state, until I stand where my guessed walk stood */
-    const u32 entry = lane ? sh.exit_state[lane - 1] : 0u;
+    u32 entry = lane ? sh.exit_state[lane - 1] : 0u;
     u32 count = 0, meet_row = 0;
     u32 head_cp[kQuarters - 1] = {0, 0, 0}; /* the walk from the true entry where it enters the second, third and fourth quarter */
     {
@@ -593,9 +603,23 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
                 }
             }
         }
+        if (active && lane && !hopeless && !met && entry < ns) {
+            /* Never met (a lane in some hundred thousand; the loop above has then run to the sub-chunk's end): the walk from
+             * the true entry has covered the whole sub-chunk -- the records are all its own, and it leaves as IT does, which
+             * is not how the lane behind this one thought: that one walks again below (a chunk given up for this cost the
+             * launches behind this kernel 30 us of dec_sync_guess, for two dozen chunks of the 1 GiB stream). */
+            met = true;
+            h_at = st;
+            r_at = last;
+            meet_row = kSubWords;
+            ref_exit = ow.offset_of(st);
+            sh.exit_state[lane] = ref_exit; /* (read again behind the next barrier only) */
+            sh.moved = 1;
+        }
         if (active && lane) {
-            /* met, no window without a code on the true path (H's part, R's part), my entry a state */
-            ok = ok && !hopeless && met && entry < ns && one_walk::dead_of(h_at) == 0 && one_walk::dead_of(last) == one_walk::dead_of(r_at);
+            /* met, no window without a code on the true path (H's part, R's part), my entry a state, my exit too */
+            ok_mine = !hopeless && met && entry < ns && ref_exit < ns && one_walk::dead_of(h_at) == 0 &&
+                      one_walk::dead_of(last) == one_walk::dead_of(r_at);
             count = one_walk::count_of(h_at) + one_walk::count_of(last) - one_walk::count_of(r_at);
         }
     }
@@ -618,8 +642,12 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
                 j = r == one_rec_row(k) ? k : j;
             }
             if (j < kOneRecs0) {
+                /* (lane 0's walk started on a guess: while it is on a wrong phase it may step over a window without a
+                 * code.  A candidate that stands where that walk stood IN FRONT of such a window does not join it: it
+                 * walks on by itself, the same way, and dies at that window with the count that is right -- two dozen
+                 * chunks of the 1 GiB stream were given up for this, 30 us of dec_sync_guess behind every decode) */
                 const u32 there = sh.kept[j][0];
-                if (!dd && !met && ((st ^ there) & 0x3FFu) == 0) {
+                if (!dd && !met && ((st ^ there) & 0x3FFu) == 0 && one_walk::dead_of(last0) == one_walk::dead_of(there)) {
                     met = true;
                     c_at = st;
                     r_at = there;
@@ -691,7 +719,83 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
     if (!ok) {
         sh.bad = 1;
     }
+    if (!ok_mine) {
+        sh.bad_mine = 1;
+    }
     __syncthreads();
+    if (!sh.moved && sh.bad_mine) {
+        sh.bad = 1; /* (every thread that gets here writes the same) */
+    }
+    if (sh.moved && !sh.bad) {
+        /* Rare.  A lane's exit moved: the lane behind it walks its sub-chunk again from the entry that is now known, the
+         * words from memory, until it stands where its guessed walk stood -- or to the end, and then ITS exit may move.
+         * A few rounds of that, one lane at work in each; a chunk that is not settled by then is not regular. */
+        constexpr u32 kRounds = 4;
+        u32 round = 0;
+        for (; round < kRounds; ++round) {
+            __syncthreads(); /* (everybody has read `moved`) */
+            if (lane == 0) {
+                sh.moved = 0;
+            }
+            __syncthreads();
+            const u32 entry_now = lane ? sh.exit_state[lane - 1] : 0u;
+            if (active && lane && entry_now != entry) {
+                entry = entry_now;
+                bool fine = entry < ns;
+                if (fine) {
+                    const u8 *mine = src + (u64)lane * HUFD_DEC_SUB_BYTES;
+                    u32 st = ow.state_at(entry), h_at = 0, r_at = 0;
+                    bool met = false;
+                    u32 hi = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(mine)->x);
+                    for (u32 r = 0;; ++r) {
+#pragma unroll
+                        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+                            head_cp[qq] = r == (qq + 1) * (kSubWords / kQuarters) ? st : head_cp[qq];
+                        }
+                        const u32 j = one_rec_index(r);
+                        if (j < kOneRecs && ((st ^ sh.kept[j][lane]) & 0x3FFu) == 0) {
+                            met = true;
+                            h_at = st;
+                            r_at = sh.kept[j][lane];
+                            meet_row = r;
+                        }
+                        if (met || r == kSubWords) {
+                            break;
+                        }
+                        const u32 lo = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(mine + 4 * (r + 1))->x);
+                        st = ow.template row<0>(st, hi, lo, table) + 32u;
+                        hi = lo;
+                    }
+                    if (!met) {
+                        h_at = st;
+                        r_at = last;
+                        meet_row = kSubWords;
+                    }
+                    const u32 exit_now = met ? ow.offset_of(last) : ow.offset_of(st);
+                    if (exit_now != ref_exit) {
+                        ref_exit = exit_now;
+                        sh.exit_state[lane] = exit_now;
+                        sh.moved = 1;
+                    }
+                    fine = ref_exit < ns && one_walk::dead_of(h_at) == 0 && one_walk::dead_of(last) == one_walk::dead_of(r_at);
+                    count = one_walk::count_of(h_at) + one_walk::count_of(last) - one_walk::count_of(r_at);
+                }
+                ok_mine = fine;
+            }
+            __syncthreads();
+            if (!sh.moved) {
+                break;
+            }
+        }
+        if (round == kRounds || !ok_mine) {
+            sh.bad = 1; /* (a lane whose first walk went wrong on a wrong entry and was never asked to walk again: its entry stood) */
+        }
+        const u32 wsum_now = wave_sum(lane ? count : 0u);
+        if ((lane & (kWave - 1)) == 0) {
+            sh.wave_sum[lane / kWave] = wsum_now;
+        }
+        __syncthreads();
+    }
     if (sh.bad) {
         if (lane == 0) {
             chunk_regular[c] = 0;
@@ -1390,7 +1494,7 @@ struct few_shared {
 /* one row of a walk whose count has to be right when it dies (dec_sync_one's walks of sub-chunk 0's entries) */
 template <u32 LB>
 __device__ __forceinline__ u32 few_row(u32 st, u32 hi, u32 lo, u32 table, const row_walk &rw, bool &dd, u32 &dead_count) {
-    st = lean_row<0, true>(st, hi, lo, table, rw);
+    st = lean_row<0, true, true>(st, hi, lo, table, rw);
     const bool now = rw.died(st) && !dd;
     dead_count = now ? (st >> 16) - 1u : dead_count; /* the step that found no code is not a symbol */
     dd = dd || now;

@@ -161,6 +161,7 @@ __device__ __forceinline__ u64 whole_lanes_of(u64 left) {
 
 __device__ __forceinline__ dec_counts count_dec_item(const raw_item &r, u64 tiny_limit, u32 shortest_code) {
     dec_counts c;
+#pragma unroll
     for (u32 k = 0; k < kPlanVec; ++k) {
         c.v[k] = 0;
     }
@@ -182,15 +183,27 @@ __device__ __forceinline__ dec_counts count_dec_item(const raw_item &r, u64 tiny
         c.v[4] = (chunks + HUFD_SCAN_RUN_CHUNKS - 1) / HUFD_SCAN_RUN_CHUNKS;
     }
     u32 n = 0;
-    for (u32 k = chunks > 2 ? chunks - 2 : 0; k < chunks; ++k) {
+    /* (registers, not an array in memory: no index that is not a constant) */
+#pragma unroll
+    for (u32 t = 0; t < 2; ++t) {
+        const u32 k = chunks - 2 + t; /* the last two chunks; an item of one chunk has no chunk "-1" */
+        if (chunks < 2 && t == 0) {
+            continue;
+        }
         const u64 left = r.in_len - (u64)k * HUFD_DEC_CHUNK_BYTES;
         if (left < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
             const u64 whole = whole_lanes_of(left);
             const bool narrow = whole <= HUFD_DEC_PACK_LANES;
-            c.tail_chunk[n] = k;
-            c.tail_narrow[n] = narrow;
+            if (n == 0) {
+                c.tail_chunk[0] = k;
+                c.tail_narrow[0] = narrow;
+            } else {
+                c.tail_chunk[1] = k;
+                c.tail_narrow[1] = narrow;
+            }
             ++n;
-            c.v[narrow ? 5 : 6] += 1;
+            c.v[5] += narrow ? 1u : 0u;
+            c.v[6] += narrow ? 0u : 1u;
             u64 holds = left * 8 / (shortest_code ? shortest_code : 1) + 1;
             holds = holds < r.out_cap ? holds : r.out_cap;
             c.tail_stage = holds > c.tail_stage ? holds : c.tail_stage;
@@ -205,6 +218,7 @@ __device__ __forceinline__ dec_counts count_dec_item(const raw_item &r, u64 tiny
 /* ... and one encode item: [0] segments, [1] thread-per-item items, [2] one-tile items (a wave each), [3] large items,
  * [7] items with segments */
 __device__ __forceinline__ void count_enc_item(const raw_item &r, u64 tiny_limit, u64 solo_limit, u32 *v) {
+#pragma unroll
     for (u32 k = 0; k < kPlanVec; ++k) {
         v[k] = 0;
     }
@@ -238,6 +252,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(
     __syncthreads();
     const u32 i = blockIdx.x * kPlanThreads + threadIdx.x;
     u32 v[kPlanVec];
+#pragma unroll
     for (u32 k = 0; k < kPlanVec; ++k) {
         v[k] = 0;
     }
@@ -247,6 +262,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(
             count_enc_item(r, decision->tiny_limit, solo_limit, v);
         } else {
             const dec_counts c = count_dec_item(r, decision->tiny_limit, shortest_code);
+#pragma unroll
             for (u32 k = 0; k < kPlanVec; ++k) {
                 v[k] = c.v[k];
             }
@@ -258,6 +274,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(
             }
         }
     }
+#pragma unroll
     for (u32 k = 0; k < kPlanVec; ++k) {
         const u32 w = wave_sum(v[k]);
         if ((threadIdx.x & (kWave - 1)) == 0 && w) {
@@ -288,6 +305,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_scan_blocks_kernel(u32 *blo
     __syncthreads();
     for (u32 base = 0; base < n_blocks; base += kPlanThreads) {
         const u32 b = base + threadIdx.x;
+#pragma unroll
         for (u32 k = 0; k < kPlanVec; ++k) {
             const u32 mine = b < n_blocks ? block_sums[(u64)b * kPlanVec + k] : 0u;
             u32 total = 0;
@@ -311,6 +329,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_scan_blocks_kernel(u32 *blo
 
 /* every counter's position of this thread's item: the workgroup's base + the sums of the threads in front */
 __device__ __forceinline__ void positions_of(const u32 *v, const u32 *block_base, u32 *slots, u32 *pos) {
+#pragma unroll
     for (u32 k = 0; k < kPlanVec; ++k) {
         u32 total = 0;
         pos[k] = block_base[k] + block_exclusive_sum<kPlanThreads>(v[k], slots, total);
@@ -325,6 +344,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_dec_fill_kernel(
     const u32 i = blockIdx.x * kPlanThreads + threadIdx.x;
     raw_item r;
     dec_counts c;
+#pragma unroll
     for (u32 k = 0; k < kPlanVec; ++k) {
         c.v[k] = 0;
     }
@@ -364,6 +384,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_dec_fill_kernel(
     /* (the chunks with few whole lanes first: several of those share a workgroup; the wide ones behind them) */
     const u32 narrow_total = (u32)decision->totals[5];
     u32 narrow_at = pos[5], wide_at = narrow_total + pos[6];
+#pragma unroll
     for (u32 t = 0; t < 2; ++t) {
         if (c.tail_chunk[t] != ~0u) {
             if (c.tail_narrow[t]) {
@@ -382,6 +403,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_enc_fill_kernel(
     const u32 i = blockIdx.x * kPlanThreads + threadIdx.x;
     raw_item r;
     u32 v[kPlanVec];
+#pragma unroll
     for (u32 k = 0; k < kPlanVec; ++k) {
         v[k] = 0;
     }
@@ -480,6 +502,7 @@ int plan_count(
     if (e != hipSuccess) {
         return (int)e;
     }
+#pragma unroll
     for (u32 k = 0; k < kPlanVec; ++k) {
         out->totals[k] = host.d.totals[k];
     }

@@ -733,6 +733,47 @@ def streams_out_of_step(w, n=260_000, seed=109, modes=(None, "long-way")):
     eng.close()
 
 
+def walks_that_never_meet(w, seed=137, engine=None, runs=(130, 260, 420, 900), modes=(None,)):
+    """Ordinary streams with a stretch of ONE long-code symbol in them whose code, rotated, is a code of the same length
+    again (the test coder's symbols 255, 254, 252 ...: seven of nine rotations): a lane whose sub-chunk lies inside the
+    stretch starts its guessed walk on a wrong phase and stays on it to the sub-chunk's end -- the walk from its true entry
+    never stands where the guessed one stood.  A handful of such lanes in a chunk (fewer than the wave that gives a chunk
+    up as out of step): dec_sync_one keeps the true walk's own records for them, lets them leave as the true walk does
+    and has the lane behind walk again.  Inside long streams and in the chunk a stream ends in; whole, cut inside the
+    stretch, damaged, entered inside a byte, short of room."""
+    rng = np.random.default_rng(seed)
+    patterns, lens = w.table
+    longest = max(int(x) for x in lens)
+
+    def rotations_that_are_codes(sym):
+        code = int(patterns[sym])
+        n = 0
+        for r in range(1, longest):
+            rot = ((code << r) | (code >> (longest - r))) & ((1 << longest) - 1)
+            n += any(int(lens[s]) == longest and int(patterns[s]) == rot for s in range(256))
+        return n
+
+    stuck = sorted((s for s in range(256) if int(lens[s]) == longest), key=rotations_that_are_codes, reverse=True)[:4]
+    assert rotations_that_are_codes(stuck[0]) >= 3, "no symbol of this coder keeps a walk on a wrong phase"
+    eng = engine or harness.Engine(w.product.lib, w.pcoder)
+    for b, run in enumerate(runs):
+        sym = stuck[b % len(stuck)]
+        for total in (90_000, 21_000, 9_000):  # chunks inside a stream; a wide end-of-stream chunk; a narrow one
+            front = int(rng.integers(300, total // 2))
+            data = np.concatenate([inputs(rng, front, "uniform"), np.full(run, sym, np.uint8),
+                                   inputs(rng, 700, "uniform"), np.full(run // 2 + 60, stuck[(b + 1) % len(stuck)], np.uint8),
+                                   inputs(rng, max(total - front - run - 700, 100), "uniform")])
+            enc = oracle_encode(w, data)
+            inside = (front + run // 2) * enc.size // data.size  # (about the middle of the first stretch)
+            damaged = enc.copy()
+            damaged[inside:inside + 3] ^= 0x5A
+            streams = [(enc, 0, data.size), (enc[:inside], 0, data.size), (damaged, 0, data.size), (enc[3:], 5, data.size),
+                       (enc, 0, front + run // 3), (enc, 0, data.size + 7)]
+            decode_items_like_the_oracle(w, eng, w.ocoder, streams, rng, "never meet %d/%d" % (run, total), modes=modes, kinds=1)
+    if engine is None:
+        eng.close()
+
+
 # ----------------------------------------------------------------------------- scenario: empty cursors with a NULL pointer
 def null_empty_cursors(w, seed=91):
     """aws_byte_cursor{0, NULL} is a valid cursor: the reference never touches `ptr` when `len` is 0

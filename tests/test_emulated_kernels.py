@@ -155,6 +155,10 @@ def test_mid_sized_encode_items(world):
         pc.tiny_encode_items(world, n_items=120, seed=155, max_len=9000, edge_lens=False, wave_limit=0, more_lens=edges)
 
 
+def test_walks_that_never_meet(world):
+    pc.walks_that_never_meet(world, runs=(130, 420))
+
+
 def test_tiny_decode_items(world):
     pc.tiny_decode_items(world, n_items=400)  # a handful: one thread up to 128 bytes, one wave up to 768, chunks above
     pc.tiny_decode_items(world, n_items=3300, seed=44)  # 6 items per byte of the longest: one thread up to 512

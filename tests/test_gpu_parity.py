@@ -192,6 +192,11 @@ def test_mid_sized_encode_items(world, engine):
         pc.tiny_encode_items(world, n_items=1200, seed=155, max_len=9000, edge_lens=False, wave_limit=0, more_lens=edges)
 
 
+def test_walks_that_never_meet(world, engine):
+    pc.walks_that_never_meet(world, engine=engine)
+    pc.walks_that_never_meet(world, engine=engine, seed=138, runs=(200, 333, 1500), modes=(None, "long-way"))
+
+
 def test_many_short_items_take_one_thread_each(world, engine):
     """A thread per item for a whole class of short items, by the library's own rule (HUFD_*_TINY_PER_BYTE items per byte of
     the class's longest item): the one-pass coder's enc_tiny on items of up to 1024 symbols, dec_tiny on items of up to 768
