@@ -1100,16 +1100,15 @@ hipError_t hufk_host::init_decode_emit(int lds_max) {
 void hufk_host::decode_emit_stage(const struct hufk_decode_args *a, hipStream_t st, const decode_launch_state &s) {
     const uint32_t lb_of_launch = s.lb, sure = s.sure;
     /* regular chunks that fit their output the short way; the rest through the list */
-    (void)hipMemsetAsync(a->emit_count, 0, sizeof(uint32_t), st);
-    (void)hipMemsetAsync(a->dense_count, 0, sizeof(uint32_t), st);
+    u32 *const emit_count = a->counters + HUFK_DEC_COUNT_EMIT, *const dense_count = a->counters + HUFK_DEC_COUNT_DENSE;
 #define HUFK_LAUNCH_EMIT_FAST(LBV, TAILV, SUREV, GRID, STREAMV)                                                          \
 hipLaunchKernelGGL(                                                                                                \
     (dec_emit_fast_kernel<LBV, TAILV, SUREV>), dim3(GRID), dim3(kEmitFastThreads),                                  \
     emit_lds_bytes<LBV>(TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES), STREAMV, a->tables, a->chunk_rec,              \
     emit_single_chunks, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab, (const u16 *)a->lane_count,   \
     (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry,                           \
-    (const u64 *)a->chunk_base, a->results, a->emit_list, a->emit_count,                                            \
-    !TAILV ? a->dense_list : a->emit_list, !TAILV ? a->dense_count : a->emit_count,                                \
+    (const u64 *)a->chunk_base, a->results, a->emit_list, emit_count,                                            \
+    !TAILV ? a->dense_list : a->emit_list, !TAILV ? dense_count : emit_count,                                \
     TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES)
     const bool some_inside = a->n_tail < a->n_chunks;
     /* (the few chunks streams end in beside the many inside streams: see the sync kernels above.  And in any case
@@ -1150,7 +1149,7 @@ hipLaunchKernelGGL(                                                             
     (uint32_t)sizeof(emit_pack_shared<LBV>) + epack_slots * epack_stage, tst, a->tables, a->chunk_rec, a->tail_chunks, \
     e_packed, epack_width, epack_slots, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab,               \
     (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry, \
-    (const u64 *)a->chunk_base, a->emit_list, a->emit_count, tail_stage)
+    (const u64 *)a->chunk_base, a->emit_list, emit_count, tail_stage)
     /* chunks of short codes that hold more symbols than dec_emit_fast's stage: dec_emit_big where the chunk lies
      * inside its stream; the others take the long way (dec_emit) */
     if (e_packed) {
@@ -1211,8 +1210,8 @@ do {                                                                            
         dim3(persistent_grid(dec_emit_big_kernel<LBV, SUREV>, kEmitFastThreads, lds, a->n_chunks)),                 \
         dim3(kEmitFastThreads), lds, st, a->tables, a->chunk_rec, (const u8 *)a->d_in, (u8 *)a->d_out,             \
         (const u16 *)a->cp_tab, (const u16 *)a->lane_count, (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn, \
-        (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results, a->emit_list, a->emit_count,          \
-        (const u32 *)a->dense_list, (const u32 *)a->dense_count);                                                  \
+        (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results, a->emit_list, emit_count,          \
+        (const u32 *)a->dense_list, (const u32 *)dense_count);                                                  \
 } while (0)
     if (lb_of_launch == 10) {
         switch (emit_sure) {
@@ -1230,5 +1229,5 @@ do {                                                                            
         dim3(kEmitThreads), dec_emit_lds_bytes(&a->tables), st, a->tables, a->items, a->chunk_item, a->n_chunks,
         (const u8 *)a->d_in, (u8 *)a->d_out, a->fn_tab, a->cp_tab, (const u16 *)a->lane_count,
         (const u8 *)a->chunk_regular, a->chunk_entry, a->chunk_base, a->results, (const u32 *)a->emit_list,
-        (const u32 *)a->emit_count);
+        (const u32 *)emit_count);
 }

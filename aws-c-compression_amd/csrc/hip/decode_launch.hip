@@ -117,7 +117,19 @@ __global__ __launch_bounds__(256) void dec_scan_runs_kernel(
     }
 }
 
-constexpr u32 kTopTile = 1024; /* run functions of an item held in LDS at a time */
+#ifndef HUFD_SCAN_TOP_TILE /* (tests/emu: a few runs a tile, two a group) */
+#define HUFD_SCAN_TOP_TILE 512u
+#define HUFD_SCAN_TOP_GROUP 16u
+#endif
+constexpr u32 kTopTile = HUFD_SCAN_TOP_TILE; /* run functions of an item held in LDS at a time (with the groups' tables: 37 KiB for 16 states) */
+constexpr u32 kTopGroup = HUFD_SCAN_TOP_GROUP;  /* ... and walked in groups of this many: the true path is a chain of dependent look-ups, ~0.1 us
+                                * each -- 152 runs of the 1 GiB stream one after the other were 18 us between the sync and the
+                                * emit kernels; 16 (every group from every state, side by side) + 10 (the groups) + 16 (inside
+                                * the groups, side by side) are 5 */
+constexpr u32 kTopGroups = kTopTile / kTopGroup;
+static uint32_t scan_top_lds_bytes(uint32_t ns) {
+    return kTopTile * ns * 4 + kTopGroups * ns * 8 + kTopGroups * 4 + kTopGroups * 8 + 16;
+}
 
 __global__ __launch_bounds__(256) void dec_scan_top_kernel(
     const hufd_dec_item *items,
@@ -129,6 +141,10 @@ __global__ __launch_bounds__(256) void dec_scan_top_kernel(
     hufd_dec_item_state *states,
     hufd_dec_result *results) {
     u32 *fn = reinterpret_cast<u32 *>(dyn_lds); /* [kTopTile][ns] */
+    u32 *group_to = fn + kTopTile * ns;         /* [kTopGroups][ns] where a group leaves: stop << 31 | state */
+    u32 *group_count = group_to + kTopGroups * ns; /* [kTopGroups][ns] ... and its symbols on the way (16 runs: < 2^30) */
+    u32 *group_entry = group_count + kTopGroups * ns; /* [kTopGroups] the true path at the group's first run (entry_pack) */
+    u64 *group_base = reinterpret_cast<u64 *>(group_entry + kTopGroups + (kTopGroups & 1u)); /* [kTopGroups] */
     const u32 i = large_items[2 * blockIdx.x], run0 = large_items[2 * blockIdx.x + 1];
     const hufd_dec_item it = items[i];
     const u32 n_runs = (it.n_chunks + kRunChunks - 1) / kRunChunks;
@@ -142,15 +158,45 @@ __global__ __launch_bounds__(256) void dec_scan_top_kernel(
             fn[k] = run_fn[(u64)(run0 + base) * ns + k];
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            for (u32 k = 0; k < n; ++k) {
-                run_entry[run0 + base + k] = entry_pack(state, !stopped);
-                run_base[run0 + base + k] = total;
-                if (!stopped) {
-                    const u32 f = fn[k * ns + state];
-                    total += wide_count(f);
-                    stopped = wide_stop(f);
-                    state = wide_state(f);
+        const u32 groups = (n + kTopGroup - 1) / kTopGroup;
+        /* every group from every state */
+        for (u32 idx = threadIdx.x; idx < groups * ns; idx += blockDim.x) {
+            const u32 g = idx / ns, first = g * kTopGroup;
+            const u32 cnt = n - first < kTopGroup ? n - first : kTopGroup;
+            const fold_result r = chain_fold(cnt, idx % ns, [&](u32 q, u32 stt) { return fn[(first + q) * ns + stt]; });
+            group_to[idx] = (r.stop ? 0x80000000u : 0u) | r.state;
+            group_count[idx] = (u32)r.count;
+        }
+        __syncthreads();
+        /* the true path over the groups (every thread walks it: the item's outcome is thread 0's) */
+        for (u32 g = 0; g < groups; ++g) {
+            if (threadIdx.x == 0) {
+                group_entry[g] = entry_pack(state, !stopped);
+                group_base[g] = total;
+            }
+            if (!stopped) {
+                const u32 to = group_to[g * ns + state];
+                total += group_count[g * ns + state];
+                stopped = (to >> 31) != 0;
+                state = to & 0x7FFFFFFFu;
+            }
+        }
+        __syncthreads();
+        /* ... and inside the groups, a thread each */
+        for (u32 g = threadIdx.x; g < groups; g += blockDim.x) {
+            u32 st = group_entry[g] & 0xFFu;
+            bool stop = !(group_entry[g] & 0x100u);
+            u64 sum = group_base[g];
+            const u32 first = g * kTopGroup;
+            const u32 cnt = n - first < kTopGroup ? n - first : kTopGroup;
+            for (u32 q = 0; q < cnt; ++q) {
+                run_entry[run0 + base + first + q] = entry_pack(st, !stop);
+                run_base[run0 + base + first + q] = sum;
+                if (!stop) {
+                    const u32 f = fn[(first + q) * ns + st];
+                    sum += wide_count(f);
+                    stop = wide_stop(f);
+                    st = wide_state(f);
                 }
             }
         }
@@ -435,10 +481,11 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     }
     decode_launch_state state = {lb_of_launch, sure, false};
     if (a->n_chunks) {
+        (void)hipMemsetAsync(a->counters, 0, HUFK_DEC_COUNTERS * sizeof(uint32_t), st);
         hufk_host::decode_sync_stage(a, st, state);
     }
     stage_mark(a->stage_events, 1, st);
-    if (a->n_tiny != a->n_items) { /* (as in the encoder: nothing to scan, and no empty item's record to write, in a plan of thread-per-item items only) */
+    if (a->n_tiny != a->n_items && a->n_large != a->n_items) { /* (as in the encoder: nothing to scan, and no empty item's record to write, in a plan of thread-per-item items only; nor in one of long items only -- one stream --, which are dec_scan_runs / _top / _apply's) */
         hipLaunchKernelGGL(
             dec_scan_small_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, ns, a->chunk_fn,
             a->chunk_entry, a->chunk_base, a->states, a->results);
@@ -449,7 +496,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         hipLaunchKernelGGL(
             dec_scan_runs_kernel, dim3(a->n_runs), dim3(256), lds, st, a->items, a->runs, ns, a->chunk_fn, a->run_fn);
         hipLaunchKernelGGL(
-            dec_scan_top_kernel, dim3(a->n_large), dim3(256), kTopTile * ns * 4, st, a->items, a->large_items, ns,
+            dec_scan_top_kernel, dim3(a->n_large), dim3(256), scan_top_lds_bytes(ns), st, a->items, a->large_items, ns,
             (const u32 *)a->run_fn, a->run_entry, a->run_base, a->states, a->results);
         hipLaunchKernelGGL(
             dec_scan_apply_kernel, dim3(a->n_runs), dim3(256), lds, st, a->items, a->runs, ns, a->chunk_fn,

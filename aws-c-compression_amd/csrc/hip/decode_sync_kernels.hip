@@ -1857,17 +1857,14 @@ void hufk_host::decode_sync_stage(const struct hufk_decode_args *a, hipStream_t 
     bool few = false;
     /* chunks inside the stream the short way; the rest, and those that turn out irregular, through the list */
     const auto sync = ns <= 8 ? dec_sync_kernel<8> : (ns <= 10 ? dec_sync_kernel<10> : dec_sync_kernel<12>);
-    (void)hipMemsetAsync(a->slow_count, 0, sizeof(uint32_t), st);
+    u32 *const slow_count = a->counters + HUFK_DEC_COUNT_SLOW, *const few_count = a->counters + HUFK_DEC_COUNT_FEW;
     const bool some_inside = a->n_tail < a->n_chunks; /* chunks with a whole chunk + 8 bytes of stream left */
     /* two lists of chunks that are not regular by dec_sync_one's rules: the ones dec_sync_guess may still take
      * (inside a stream, first sub-chunk's walks meet) and the ones for the long way.  The second is the emit stage's
      * list, free until then; one list where there is no dec_sync_guess for the launch. */
     const bool guessing = some_inside;
     u32 *lean_long_list = guessing ? a->emit_list : a->slow_list;
-    u32 *lean_long_count = guessing ? a->emit_count : a->slow_count;
-    if (guessing) {
-        (void)hipMemsetAsync(a->emit_count, 0, sizeof(uint32_t), st);
-    }
+    u32 *lean_long_count = guessing ? a->counters + HUFK_DEC_COUNT_LONG : slow_count;
     /* A few chunks that streams end in beside many inside streams (one long stream: ONE): their kernels are tiny
      * and, one after the other behind the big ones, cost a tenth of the decode time in launch and drain.  They run on
      * a second stream of the engine's, beside the big kernels, forked off and joined with events. */
@@ -1899,14 +1896,14 @@ if (n_single) {                                                                 
         (dec_sync_one_kernel<LBV, SUREV, true>), dim3(n_single), dim3(HUFD_DEC_LANES),                              \
         (uint32_t)sizeof(one_shared<LBV>), tst, a->tables, a->chunk_rec, single_chunks,                             \
         (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
-        a->slow_list, a->slow_count, lean_long_list, lean_long_count);                                             \
+        a->slow_list, slow_count, lean_long_list, lean_long_count);                                                \
 }                                                                                                                  \
 if (some_inside) {                                                                                                 \
     hipLaunchKernelGGL(                                                                                            \
         (dec_sync_one_kernel<LBV, SUREV, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES),                          \
         (uint32_t)sizeof(one_shared<LBV>), st, a->tables, a->chunk_rec, a->tail_chunks,                             \
         (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
-        a->slow_list, a->slow_count, lean_long_list, lean_long_count);                                             \
+        a->slow_list, slow_count, lean_long_list, lean_long_count);                                                \
 }
     if (lb_of_launch == 10) {
         switch (sure) {
@@ -1932,7 +1929,7 @@ if (some_inside) {                                                              
     }
     /* the chunks inside streams that dec_sync_one gave up on: a second chance that asks less of the coder
      * (dec_sync_guess); what that gives up on goes on a second list (the emit stage's, free until then) */
-    const u32 *long_list = a->slow_list, *long_count = a->slow_count;
+    const u32 *long_list = a->slow_list, *long_count = slow_count;
     if (guessing) {
 #define HUFK_LAUNCH_SYNC_GUESS(LBV, SUREV)                                                                              \
 hipLaunchKernelGGL(                                                                                                \
@@ -1941,7 +1938,7 @@ hipLaunchKernelGGL(                                                             
                          a->n_chunks)),                                                                            \
     dim3(HUFD_DEC_LANES), (uint32_t)sizeof(lean_shared<LBV>), st, a->tables, a->chunk_rec, (const u8 *)a->d_in,     \
     a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, (const u32 *)a->slow_list,                 \
-    (const u32 *)a->slow_count, a->emit_list, a->emit_count)
+    (const u32 *)slow_count, a->emit_list, a->counters + HUFK_DEC_COUNT_LONG)
         if (lb_of_launch == 10) {
             switch (sure) {
                 case 3: HUFK_LAUNCH_SYNC_GUESS(10, 3); break;
@@ -1953,24 +1950,23 @@ hipLaunchKernelGGL(                                                             
         }
 #undef HUFK_LAUNCH_SYNC_GUESS
         long_list = a->emit_list;
-        long_count = a->emit_count;
+        long_count = a->counters + HUFK_DEC_COUNT_LONG;
         /* of those, the chunks inside streams whose walks do not fall into step: a few walks a lane, not the long
          * way's every bit (dec_sync_few; its list -- dec_sync_one's, used up by now -- is for dec_sync_true below) */
         if (a->few_walks) {
-            few = true;
-            (void)hipMemsetAsync(a->slow_count, 0, sizeof(uint32_t), st);
+            few = true; /* (its list: dec_sync_one's array, used up by now, with a counter of its own) */
             if (a->tables.lut_bits <= 10) {
                 hipLaunchKernelGGL(
                     (dec_sync_few_kernel<10>),
                     dim3(persistent_grid(dec_sync_few_kernel<10>, HUFD_DEC_LANES, (uint32_t)sizeof(few_shared<10>), a->n_chunks)),
                     dim3(HUFD_DEC_LANES), (uint32_t)sizeof(few_shared<10>), st, a->tables, a->chunk_rec, (const u8 *)a->d_in,
-                    a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, long_list, long_count, a->slow_list, a->slow_count);
+                    a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, long_list, long_count, a->slow_list, few_count);
             } else {
                 hipLaunchKernelGGL(
                     (dec_sync_few_kernel<12>),
                     dim3(persistent_grid(dec_sync_few_kernel<12>, HUFD_DEC_LANES, (uint32_t)sizeof(few_shared<12>), a->n_chunks)),
                     dim3(HUFD_DEC_LANES), (uint32_t)sizeof(few_shared<12>), st, a->tables, a->chunk_rec, (const u8 *)a->d_in,
-                    a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, long_list, long_count, a->slow_list, a->slow_count);
+                    a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, long_list, long_count, a->slow_list, few_count);
             }
         }
     }
@@ -1992,13 +1988,13 @@ void hufk_host::decode_sync_true_stage(const struct hufk_decode_args *a, hipStre
             dim3(persistent_grid(dec_sync_true_kernel<10>, HUFD_DEC_LANES, (uint32_t)sizeof(few_shared<10>), a->n_chunks)),
             dim3(HUFD_DEC_LANES), (uint32_t)sizeof(few_shared<10>), st, a->tables, a->chunk_rec, (const u8 *)a->d_in,
             (const u16 *)a->fn_tab, a->cp_tab, a->lane_count, a->chunk_regular, (const u32 *)a->chunk_entry,
-            (const u32 *)a->slow_list, (const u32 *)a->slow_count);
+            (const u32 *)a->slow_list, (const u32 *)(a->counters + HUFK_DEC_COUNT_FEW));
     } else {
         hipLaunchKernelGGL(
             (dec_sync_true_kernel<12>),
             dim3(persistent_grid(dec_sync_true_kernel<12>, HUFD_DEC_LANES, (uint32_t)sizeof(few_shared<12>), a->n_chunks)),
             dim3(HUFD_DEC_LANES), (uint32_t)sizeof(few_shared<12>), st, a->tables, a->chunk_rec, (const u8 *)a->d_in,
             (const u16 *)a->fn_tab, a->cp_tab, a->lane_count, a->chunk_regular, (const u32 *)a->chunk_entry,
-            (const u32 *)a->slow_list, (const u32 *)a->slow_count);
+            (const u32 *)a->slow_list, (const u32 *)(a->counters + HUFK_DEC_COUNT_FEW));
     }
 }

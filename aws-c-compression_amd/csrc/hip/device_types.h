@@ -61,7 +61,9 @@
 
 #define HUFD_SCAN_SMALL_MAX 64u /* items with at most this many segments/chunks are scanned by one thread */
 #define HUFD_SCAN_LARGE_THREADS 1024u
+#ifndef HUFD_SCAN_RUN_CHUNKS /* (tests/emu builds with short runs, so that its streams of a few MB have several) */
 #define HUFD_SCAN_RUN_CHUNKS 256u /* a large decode item is scanned in runs of this many chunks, one workgroup per run */
+#endif
 #define HUFD_SCAN_SUB_CHUNKS 16u  /* ... each folded in sub-runs of this many */
 
 /* look-back of the one-pass encoder: tiles per group, groups per round (the emulator build of tests/emu

@@ -52,6 +52,14 @@ struct hufk_wide_item {
     uint64_t block_offset; /* of its scratch in wide_block */
 };
 
+/* hufk_decode_args.counters: */
+#define HUFK_DEC_COUNT_SLOW 0u      /* slow_list: the chunks dec_sync_one / dec_sync_pack leave to dec_sync_guess (or, without one, to dec_sync) */
+#define HUFK_DEC_COUNT_LONG 1u      /* emit_list: the chunks for the long way (dec_sync_few's and dec_sync's list) */
+#define HUFK_DEC_COUNT_FEW 2u       /* slow_list again: dec_sync_few's chunks, for dec_sync_true */
+#define HUFK_DEC_COUNT_EMIT 3u      /* emit_list again: the chunks dec_emit_fast leaves to dec_emit */
+#define HUFK_DEC_COUNT_DENSE 4u     /* dense_list */
+#define HUFK_DEC_COUNTERS 8u
+
 struct hufk_decode_args {
     struct hufd_tables tables;
     const struct hufd_dec_item *items;
@@ -87,11 +95,11 @@ struct hufk_decode_args {
     uint16_t *cp_tab;      /* [n_chunks][HUFD_DEC_CP_ROWS][HUFD_DEC_LANES] scratch: walk checkpoints */
     uint32_t *chunk_fn;    /* [n_chunks][n_states] scratch */
     uint32_t *slow_list;   /* [n_chunks] scratch: chunks that take the long way through dec_sync */
-    uint32_t *slow_count;  /* [1] */
     uint32_t *emit_list;   /* [n_chunks] scratch: chunks left to dec_emit by dec_emit_fast */
-    uint32_t *emit_count;  /* [1] */
     uint32_t *dense_list;  /* [n_chunks] scratch: chunks dec_emit_fast leaves to dec_emit_dense */
-    uint32_t *dense_count; /* [1] */
+    uint32_t *counters;    /* [HUFK_DEC_COUNTERS] scratch: how many entries the lists hold, one word for every use a launch
+                            * makes of a list (the arrays take turns, the words do not: ONE clearing a launch, in front
+                            * of its first kernel -- three more between the sync and the emit kernels cost ~3 us each) */
     uint16_t *lane_count;  /* [n_chunks][HUFD_DEC_LANES] scratch */
     uint8_t *chunk_regular; /* [n_chunks] scratch */
     uint32_t *tail_entry;   /* [n_chunks] scratch: state in which the last whole lane of an end-of-stream chunk leaves */

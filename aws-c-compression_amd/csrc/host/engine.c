@@ -1145,6 +1145,7 @@ int aws_huffman_amd_encode_plan_results(
     X(d_slow_list, ((cc) + 1) * sizeof(uint32_t)) /* [0] count, [1..] chunks */                                        \
     X(d_emit_list, ((cc) + 1) * sizeof(uint32_t))                                                                      \
     X(d_dense_list, ((cc) + 1) * sizeof(uint32_t))                                                                     \
+    X(d_counters, HUFK_DEC_COUNTERS * sizeof(uint32_t))                                                                \
     X(d_lane_count, (cc) * HUFD_DEC_LANES * sizeof(uint16_t))                                                          \
     X(d_chunk_regular, (cc))                                                                                           \
     X(d_tail_entry, (cc) * sizeof(uint32_t))                                                                           \
@@ -1833,12 +1834,10 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.fn_tab = p->d_fn_tab;
     a.cp_tab = p->d_cp_tab;
     a.chunk_fn = p->d_chunk_fn;
-    a.slow_count = p->d_slow_list;
     a.slow_list = p->d_slow_list + 1;
-    a.emit_count = p->d_emit_list;
     a.emit_list = p->d_emit_list + 1;
-    a.dense_count = p->d_dense_list;
     a.dense_list = p->d_dense_list + 1;
+    a.counters = p->d_counters;
     a.lane_count = p->d_lane_count;
     a.chunk_regular = p->d_chunk_regular;
     a.tail_entry = p->d_tail_entry;

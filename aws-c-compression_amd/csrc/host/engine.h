@@ -124,6 +124,7 @@ struct aws_huffman_amd_decode_plan {
     uint32_t *d_slow_list; /* [0] how many, [1..] the chunks the regular chunks' kernels left to dec_sync */
     uint32_t *d_emit_list; /* the same for dec_emit_fast / dec_emit */
     uint32_t *d_dense_list; /* [0] how many, [1..] chunks with more symbols than one emit stage */
+    uint32_t *d_counters;   /* [HUFK_DEC_COUNTERS] the lists' lengths (hufk_decode_args.counters) */
     uint16_t *d_lane_count;
     uint8_t *d_chunk_regular;
     uint32_t *d_tail_entry;
