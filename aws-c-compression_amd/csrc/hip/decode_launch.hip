@@ -69,14 +69,14 @@ __global__ __launch_bounds__(256) void dec_scan_small_kernel(
 
 /*
  * Items with many chunks are scanned in RUNS of HUFD_SCAN_RUN_CHUNKS chunks, one workgroup per
- * run, in three short launches (the walk along an item is a chain of dependent table look-ups:
+ * run, in two short launches (the walk along an item is a chain of dependent table look-ups:
  * what matters is that every look-up is an LDS read and every chain is short):
  *   dec_scan_runs   the run's chunk functions into LDS, folded 16 at a time and then once more:
  *                   the run's own transfer function
- *   dec_scan_top    per item: the true path through its run functions (in LDS) -> entry state and
- *                   symbol offset of every run, outcome of the item
- *   dec_scan_apply  per run: the same fold again, then the true path through the 16 sub-runs and
- *                   through the chunks of each -> entry state and symbol offset of every chunk
+ *   dec_scan_apply  per run: the true path through the run functions of the item's runs in front of it (in LDS, in
+ *                   groups) -> the run's entry; the same fold of its chunks again, then the true path through the 16
+ *                   sub-runs and through the chunks of each -> entry state and symbol offset of every chunk; the
+ *                   item's last run writes the item's outcome
  */
 constexpr u32 kRunChunks = HUFD_SCAN_RUN_CHUNKS, kSubRun = HUFD_SCAN_SUB_CHUNKS, kSubRuns = kRunChunks / kSubRun;
 
@@ -100,8 +100,11 @@ __device__ __forceinline__ u32 scan_run_load(const hufd_dec_item &it, u32 k, u32
     return n;
 }
 
-static uint32_t scan_run_lds_bytes(uint32_t ns) {
+__device__ __host__ constexpr u32 scan_run_lds_bytes_device(u32 ns) {
     return kRunChunks * ns * 4 + kSubRuns * ns * 4 + kSubRuns * 4 + kSubRuns * 8 + 16;
+}
+static uint32_t scan_run_lds_bytes(uint32_t ns) {
+    return scan_run_lds_bytes_device(ns);
 }
 
 __global__ __launch_bounds__(256) void dec_scan_runs_kernel(
@@ -121,41 +124,33 @@ __global__ __launch_bounds__(256) void dec_scan_runs_kernel(
 #define HUFD_SCAN_TOP_TILE 512u
 #define HUFD_SCAN_TOP_GROUP 16u
 #endif
-constexpr u32 kTopTile = HUFD_SCAN_TOP_TILE; /* run functions of an item held in LDS at a time (with the groups' tables: 37 KiB for 16 states) */
+constexpr u32 kTopTile = HUFD_SCAN_TOP_TILE; /* run functions of an item held in LDS at a time (an item has at most 512 runs: 4 GiB) */
 constexpr u32 kTopGroup = HUFD_SCAN_TOP_GROUP;  /* ... and walked in groups of this many: the true path is a chain of dependent look-ups, ~0.1 us
                                 * each -- 152 runs of the 1 GiB stream one after the other were 18 us between the sync and the
-                                * emit kernels; 16 (every group from every state, side by side) + 10 (the groups) + 16 (inside
-                                * the groups, side by side) are 5 */
+                                * emit kernels; 16 (every group from every state, side by side) + 10 (the groups) are 3 */
 constexpr u32 kTopGroups = kTopTile / kTopGroup;
-static uint32_t scan_top_lds_bytes(uint32_t ns) {
-    return kTopTile * ns * 4 + kTopGroups * ns * 8 + kTopGroups * 4 + kTopGroups * 8 + 16;
-}
 
-__global__ __launch_bounds__(256) void dec_scan_top_kernel(
-    const hufd_dec_item *items,
-    const u32 *large_items,
-    u32 ns,
-    const u32 *run_fn,
-    u32 *run_entry,
-    u64 *run_base,
-    hufd_dec_item_state *states,
-    hufd_dec_result *results) {
-    u32 *fn = reinterpret_cast<u32 *>(dyn_lds); /* [kTopTile][ns] */
-    u32 *group_to = fn + kTopTile * ns;         /* [kTopGroups][ns] where a group leaves: stop << 31 | state */
-    u32 *group_count = group_to + kTopGroups * ns; /* [kTopGroups][ns] ... and its symbols on the way (16 runs: < 2^30) */
-    u32 *group_entry = group_count + kTopGroups * ns; /* [kTopGroups] the true path at the group's first run (entry_pack) */
-    u64 *group_base = reinterpret_cast<u64 *>(group_entry + kTopGroups + (kTopGroups & 1u)); /* [kTopGroups] */
-    const u32 i = large_items[2 * blockIdx.x], run0 = large_items[2 * blockIdx.x + 1];
-    const hufd_dec_item it = items[i];
-    const u32 n_runs = (it.n_chunks + kRunChunks - 1) / kRunChunks;
-    u32 state = it.first_bit;
-    u64 total = 0;
-    bool stopped = false;
-    for (u32 base = 0; base < n_runs; base += kTopTile) {
-        const u32 n = n_runs - base < kTopTile ? n_runs - base : kTopTile;
+struct scan_point { /* the true path at a run's first chunk */
+    u32 state;
+    bool stopped;
+    u64 total;
+};
+
+/*
+ * The true path of item `it` up to its run `k` (0: the item's first bit), through the run functions of the runs in front:
+ * the whole workgroup, every thread gets the answer.  `fn`: kTopTile * ns words of LDS, `group`: 2 * kTopGroups * ns.
+ * (Round 4 had a kernel of its own for this, a workgroup an item, between dec_scan_runs and dec_scan_apply: a launch more
+ * on every decode's critical path.  Every run's workgroup now walks the runs in front of its own -- at most 511 -- itself.)
+ */
+__device__ __forceinline__ scan_point scan_path_to_run(const hufd_dec_item &it, const u32 *run_fn_of_item, u32 k, u32 ns, u32 *fn, u32 *group) {
+    u32 *group_to = group;                       /* [kTopGroups][ns] where a group leaves: stop << 31 | state */
+    u32 *group_count = group + kTopGroups * ns;  /* [kTopGroups][ns] ... and its symbols on the way (16 runs: < 2^30) */
+    scan_point p = {it.first_bit, false, 0};
+    for (u32 base = 0; base < k; base += kTopTile) {
+        const u32 n = k - base < kTopTile ? k - base : kTopTile;
         __syncthreads();
-        for (u32 k = threadIdx.x; k < n * ns; k += blockDim.x) {
-            fn[k] = run_fn[(u64)(run0 + base) * ns + k];
+        for (u32 q = threadIdx.x; q < n * ns; q += blockDim.x) {
+            fn[q] = run_fn_of_item[(u64)base * ns + q];
         }
         __syncthreads();
         const u32 groups = (n + kTopGroup - 1) / kTopGroup;
@@ -168,42 +163,20 @@ __global__ __launch_bounds__(256) void dec_scan_top_kernel(
             group_count[idx] = (u32)r.count;
         }
         __syncthreads();
-        /* the true path over the groups (every thread walks it: the item's outcome is thread 0's) */
-        for (u32 g = 0; g < groups; ++g) {
-            if (threadIdx.x == 0) {
-                group_entry[g] = entry_pack(state, !stopped);
-                group_base[g] = total;
-            }
-            if (!stopped) {
-                const u32 to = group_to[g * ns + state];
-                total += group_count[g * ns + state];
-                stopped = (to >> 31) != 0;
-                state = to & 0x7FFFFFFFu;
-            }
-        }
-        __syncthreads();
-        /* ... and inside the groups, a thread each */
-        for (u32 g = threadIdx.x; g < groups; g += blockDim.x) {
-            u32 st = group_entry[g] & 0xFFu;
-            bool stop = !(group_entry[g] & 0x100u);
-            u64 sum = group_base[g];
-            const u32 first = g * kTopGroup;
-            const u32 cnt = n - first < kTopGroup ? n - first : kTopGroup;
-            for (u32 q = 0; q < cnt; ++q) {
-                run_entry[run0 + base + first + q] = entry_pack(st, !stop);
-                run_base[run0 + base + first + q] = sum;
-                if (!stop) {
-                    const u32 f = fn[(first + q) * ns + st];
-                    sum += wide_count(f);
-                    stop = wide_stop(f);
-                    st = wide_state(f);
-                }
-            }
+        /* the true path over the groups */
+        for (u32 g = 0; g < groups && !p.stopped; ++g) {
+            const u32 to = group_to[g * ns + p.state];
+            p.total += group_count[g * ns + p.state];
+            p.stopped = (to >> 31) != 0;
+            p.state = to & 0x7FFFFFFFu;
         }
     }
-    if (threadIdx.x == 0) {
-        dec_finish_item(it, total, stopped, &states[i], &results[i]);
-    }
+    __syncthreads();
+    return p;
+}
+
+static uint32_t scan_apply_lds_bytes(uint32_t ns) {
+    return scan_run_lds_bytes(ns) + kTopTile * ns * 4 + 2 * kTopGroups * ns * 4;
 }
 
 __global__ __launch_bounds__(256) void dec_scan_apply_kernel(
@@ -211,22 +184,27 @@ __global__ __launch_bounds__(256) void dec_scan_apply_kernel(
     const u32 *runs,
     u32 ns,
     const u32 *chunk_fn,
-    const u32 *run_entry,
-    const u64 *run_base,
+    const u32 *run_fn,
     u32 *chunk_entry,
-    u64 *chunk_base) {
+    u64 *chunk_base,
+    hufd_dec_item_state *states,
+    hufd_dec_result *results) {
     u32 *fn = reinterpret_cast<u32 *>(dyn_lds);
     u32 *sub = fn + kRunChunks * ns;
     u32 *sub_entry = sub + kSubRuns * ns;                           /* [kSubRuns] */
     u64 *sub_base = reinterpret_cast<u64 *>(sub_entry + kSubRuns);  /* [kSubRuns] */
+    u32 *path_fn = reinterpret_cast<u32 *>(dyn_lds + scan_run_lds_bytes_device(ns));
+    u32 *path_group = path_fn + kTopTile * ns;
     const u32 run = blockIdx.x;
-    const hufd_dec_item it = items[runs[2 * run]];
-    const u32 k = runs[2 * run + 1];
+    const u32 item = runs[2 * run], k = runs[2 * run + 1];
+    const hufd_dec_item it = items[item];
+    /* (an item's runs are listed one after the other: its first is k in front of this one) */
+    const scan_point at = scan_path_to_run(it, run_fn + (u64)(run - k) * ns, k, ns, path_fn, path_group);
     const u32 n = scan_run_load(it, k, ns, chunk_fn, fn, sub);
     if (threadIdx.x == 0) {
-        u32 state = run_entry[run] & 0xFFu;
-        bool stopped = !(run_entry[run] & 0x100u);
-        u64 total = run_base[run];
+        u32 state = at.state;
+        bool stopped = at.stopped;
+        u64 total = at.total;
         for (u32 j = 0; j < kSubRuns; ++j) {
             sub_entry[j] = entry_pack(state, !stopped);
             sub_base[j] = total;
@@ -236,6 +214,9 @@ __global__ __launch_bounds__(256) void dec_scan_apply_kernel(
                 stopped = wide_stop(f);
                 state = wide_state(f);
             }
+        }
+        if ((k + 1) * kRunChunks >= it.n_chunks) {
+            dec_finish_item(it, total, stopped, &states[item], &results[item]); /* the item's last run: its outcome */
         }
     }
     __syncthreads();
@@ -496,11 +477,8 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
         hipLaunchKernelGGL(
             dec_scan_runs_kernel, dim3(a->n_runs), dim3(256), lds, st, a->items, a->runs, ns, a->chunk_fn, a->run_fn);
         hipLaunchKernelGGL(
-            dec_scan_top_kernel, dim3(a->n_large), dim3(256), scan_top_lds_bytes(ns), st, a->items, a->large_items, ns,
-            (const u32 *)a->run_fn, a->run_entry, a->run_base, a->states, a->results);
-        hipLaunchKernelGGL(
-            dec_scan_apply_kernel, dim3(a->n_runs), dim3(256), lds, st, a->items, a->runs, ns, a->chunk_fn,
-            (const u32 *)a->run_entry, (const u64 *)a->run_base, a->chunk_entry, a->chunk_base);
+            dec_scan_apply_kernel, dim3(a->n_runs), dim3(256), scan_apply_lds_bytes(ns), st, a->items, a->runs, ns, a->chunk_fn,
+            (const u32 *)a->run_fn, a->chunk_entry, a->chunk_base, a->states, a->results);
     }
     hufk_host::decode_sync_true_stage(a, st, state);
     stage_mark(a->stage_events, 2, st);

@@ -2949,7 +2949,7 @@ static void encode_three_kernels(const struct hufk_encode_args *a, hipStream_t s
         (void)hipMemsetAsync(a->careful_count, 0, sizeof(uint32_t), st);
     }
     stage_mark(events, 1, st);
-    if (a->n_tiny != a->n_items) { /* (a plan of thread-per-item items only has nothing to scan: a thread an item that finds that out is 10 us; an EMPTY item is not such an item -- its record is written here) */
+    if (a->n_tiny != a->n_items && a->n_large != a->n_items) { /* (a plan of thread-per-item items only has nothing to scan: a thread an item that finds that out is 10 us; an EMPTY item is not such an item -- its record is written here; a plan of long items only -- one stream -- is enc_scan_large's) */
         hipLaunchKernelGGL(
             enc_scan_small_kernel, dim3((a->n_items + 255) / 256), dim3(256), 0, st, a->items, a->n_items, a->seg_bits,
             a->seg_unk, a->seg_bitoff, a->careful_list, a->careful_count, a->states, a->results, gate);

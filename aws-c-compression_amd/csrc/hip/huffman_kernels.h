@@ -87,8 +87,6 @@ struct hufk_decode_args {
     const uint32_t *runs;        /* per run of HUFD_SCAN_RUN_CHUNKS chunks of a large item: item index, run number */
     uint32_t n_runs;
     uint32_t *run_fn;            /* [n_runs][n_states] scratch */
-    uint32_t *run_entry;         /* [n_runs] scratch */
-    uint64_t *run_base;          /* [n_runs] scratch */
     const void *d_in;
     void *d_out;
     uint16_t *fn_tab;      /* [n_chunks][n_states][HUFD_DEC_LANES] scratch */

@@ -1137,8 +1137,6 @@ int aws_huffman_amd_encode_plan_results(
     X(d_large, (cl) * 2 * sizeof(uint32_t))                                                                            \
     X(d_runs, (cr) * 2 * sizeof(uint32_t))                                                                             \
     X(d_run_fn, (cr) * (ns) * sizeof(uint32_t))                                                                        \
-    X(d_run_entry, (cr) * sizeof(uint32_t))                                                                            \
-    X(d_run_base, (cr) * sizeof(uint64_t))                                                                             \
     X(d_fn_tab, (cc) * (ns) * HUFD_DEC_LANES * sizeof(uint16_t))                                                       \
     X(d_cp_tab, (cc) * HUFD_DEC_CP_ROWS * HUFD_DEC_LANES * sizeof(uint16_t))                                           \
     X(d_chunk_fn, (cc) * (ns) * sizeof(uint32_t))                                                                      \
@@ -1827,8 +1825,6 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.runs = p->d_runs;
     a.n_runs = p->n_runs;
     a.run_fn = p->d_run_fn;
-    a.run_entry = p->d_run_entry;
-    a.run_base = p->d_run_base;
     a.d_in = device_input;
     a.d_out = device_output;
     a.fn_tab = p->d_fn_tab;

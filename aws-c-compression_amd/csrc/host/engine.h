@@ -116,8 +116,6 @@ struct aws_huffman_amd_decode_plan {
     uint32_t *d_large;     /* per large item: item index, its first run */
     uint32_t *d_runs;      /* per run: item index, run number inside the item */
     uint32_t *d_run_fn;    /* [n_runs][n_states] */
-    uint32_t *d_run_entry; /* [n_runs] */
-    uint64_t *d_run_base;  /* [n_runs] */
     uint16_t *d_fn_tab;
     uint16_t *d_cp_tab;
     uint32_t *d_chunk_fn;
