@@ -624,44 +624,48 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
         }
     }
 
-    /* H: sub-chunk 0 from every entry state the chunk may be entered in (threads 0 .. ns-1), step by step: each dies at a
-     * window without a code (the count up to there has to be right) or meets lane 0's walk */
+    HUFD_STAMP(0, 7);
+    /* H: sub-chunk 0 from every entry state the chunk may be entered in (threads 0 .. ns-1): each dies at a window without a
+     * code (the count up to there has to be right) or meets lane 0's guessed walk -- which the wave's last thread walks
+     * AGAIN beside them, a row at a time, so that they can meet it at any row boundary (two rows on average; met at the
+     * kept boundaries only, every candidate walked six rows at least, and these walks are the tail of the workgroup's
+     * life: the other waves wait for them) */
     u32 cand_count = 0, cand_dead = 0, meet_row0 = 0, ref_count0 = 0;
     bool cand_reached = false;
     u64 cand_alive = 0;
     if (lane < kWave) {
+        constexpr u32 kTwin = kWave - 1;
+        const bool twin = lane == kTwin;
         const u32 last0 = sh.kept[kOneRecs - 1][0];
         u32 st = ow.state_at(lane < ns ? lane : 0u);
         bool dd = lane >= ns, met = false;
-        u32 c_at = 0, r_at = 0, my_row = 0;
+        u32 c_at = 0, r_at = 0;
+        u32 at0 = st, latest = 0; /* lane 0's walk where the last candidate met it, and the row (the same in every thread) */
         u32 hi = sh.sub0[0];
-        for (u32 r = 0; r <= kOneMaxMerge0 && !hopeless; ++r) {
-            u32 j = kOneRecs0;
-#pragma unroll
-            for (u32 k = 0; k < kOneRecs0; ++k) {
-                j = r == one_rec_row(k) ? k : j;
+        for (u32 r = 0; !hopeless; ++r) {
+            /* (lane 0's walk started on a guess: while it is on a wrong phase it may step over a window without a code.  A
+             * candidate that stands where that walk stands IN FRONT of such a window does not join it: it walks on by
+             * itself, the same way, and dies at that window with the count that is right) */
+            const u32 there = __shfl(st, kTwin);
+            const bool now = !twin && !dd && !met && ((st ^ there) & 0x3FFu) == 0 && one_walk::dead_of(last0) == one_walk::dead_of(there);
+            if (now) {
+                met = true;
+                c_at = st;
+                r_at = there;
             }
-            if (j < kOneRecs0) {
-                /* (lane 0's walk started on a guess: while it is on a wrong phase it may step over a window without a
-                 * code.  A candidate that stands where that walk stood IN FRONT of such a window does not join it: it
-                 * walks on by itself, the same way, and dies at that window with the count that is right -- two dozen
-                 * chunks of the 1 GiB stream were given up for this, 30 us of dec_sync_guess behind every decode) */
-                const u32 there = sh.kept[j][0];
-                if (!dd && !met && ((st ^ there) & 0x3FFu) == 0 && one_walk::dead_of(last0) == one_walk::dead_of(there)) {
-                    met = true;
-                    c_at = st;
-                    r_at = there;
-                    my_row = r;
-                }
+            if (__any(now)) {
+                at0 = there;
+                latest = r;
             }
-            if (__all(dd || met) || r == kOneMaxMerge0) {
+            if (__all(dd || met || twin) || r == kSubWords) {
                 break;
             }
             const u32 lo = sh.sub0[r + 1];
-            if (!dd && !met) {
+            if (twin) {
+                st = ow.template row<SURE>(st, hi, lo, table); /* (as phase R took the row: the marks are part of the state) */
+            } else if (!dd && !met) {
                 /* the row as the other walks take it; a window without a code in it (a walk on a wrong phase: within a
-                 * row or two) and the row is taken again, step by step, for the count up to that window -- these ten lanes'
-                 * walks are the tail of the workgroup's life, the other waves wait for them */
+                 * row or two) and the row is taken again, step by step, for the count up to that window */
                 const u32 before = st;
                 st = ow.template row<SURE>(st, hi, lo, table);
                 if (one_walk::dead_of(st)) {
@@ -681,32 +685,18 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
             st += 32u;
             hi = lo;
         }
-        const bool decided = !hopeless && __all(dd || met);
+        const bool decided = !hopeless && __all(dd || met || twin);
         cand_reached = met && lane < ns;
         cand_alive = __ballot(cand_reached);
         /* where the last of them met it: from that row on lane 0's walk is the true one whatever the chunk's entry */
-        u32 latest = met ? my_row : 0u;
-#pragma unroll
-        for (u32 d = kWave / 2; d > 0; d >>= 1) {
-            const u32 o = __shfl_xor(latest, d);
-            latest = o > latest ? o : latest;
-        }
         meet_row0 = latest;
         cand_count = one_walk::count_of(c_at) + one_walk::count_of(last0) - one_walk::count_of(r_at);
-        /* (a window without a code on lane 0's walk behind where a candidate met it: that candidate's path has it too) */
-        const bool clean = !met || one_walk::dead_of(last0) == one_walk::dead_of(r_at);
         if (lane == 0) {
             sh.decided0 = decided;
         }
-        const bool all_clean = __all(clean); /* (every lane of the wave asks: not behind a lane's own `ok`) */
-        ok = ok && decided && all_clean && cand_alive != 0;
+        ok = ok && decided && cand_alive != 0;
         if (lane == 0) {
             meet_row = meet_row0;
-            u32 at0 = sh.kept[0][0];
-#pragma unroll
-            for (u32 k = 0; k < kOneRecs0; ++k) {
-                at0 = meet_row0 == one_rec_row(k) ? sh.kept[k][0] : at0;
-            }
             ref_count0 = one_walk::count_of(last0) - one_walk::count_of(at0);
         }
     }

@@ -366,8 +366,8 @@ int aws_huffman_amd_engine_new(
 
     int err = hufs_stream_create(&eng->stream);
     if (!err && hufs_stream_create(&eng->side_stream) == 0) {
-        eng->fork_event = hufs_event_create();
-        eng->join_event = hufs_event_create();
+        eng->fork_event = hufs_event_create_untimed();
+        eng->join_event = hufs_event_create_untimed();
         if (!eng->fork_event || !eng->join_event) {
             /* (no overlap then: the kernels run one after the other on the one stream) */
             hufs_event_destroy(eng->fork_event);

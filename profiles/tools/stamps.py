@@ -66,7 +66,10 @@ for _ in range(2):
     eng.decode_launch(dp, d_enc, d_back)
     eng.decode_results(dp, 1)
 chunks = (e_len + 32767) // 32768
-report("dec_sync_lean", rows(0, min(chunks, MAX_WG), 7)[1:],  # (row 0 is also the end-of-stream instantiation's)
-       ["loads, table, barrier", "phase U (all entry states to one head)", "phase R (the one walk to the end)", "wait barrier",
-        "phase H (own entry to the meeting bit) + sub-chunk 0's candidates", "sums, barrier, records out"])
+r = rows(0, min(chunks, MAX_WG), 8)[1:]  # (row 0 is also the end-of-stream instantiation's)
+r = np.stack([r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4], r[:, 7], r[:, 5], r[:, 6]], axis=1)
+r = r[(np.diff(r, axis=1) >= 0).all(axis=1) & (r[:, 0] > 0)]  # (the chunk the stream ends in is the other instantiation's: no stamps)
+report("dec_sync_one", r,
+       ["loads, table, barrier", "-", "phase R (one guessed walk over the sub-chunk)", "wait barrier",
+        "phase H (own entry to where it meets the guessed walk)", "sub-chunk 0's candidates (wave 0)", "sums, barrier, records out"])
 report("dec_emit", rows(1, min(chunks, MAX_WG), 6), ["load", "entry chains", "walk", "wait barrier", "copy out"])
