@@ -272,6 +272,8 @@ __global__ __launch_bounds__(256) void dec_plan_chunks_kernel(
     rec.out_cap = it.out_cap;
     rec.valid = left < 0xFFFFFFFFull ? (u32)left : 0xFFFFFFFFu;
     rec.item = lo;
+    rec.entry_bit = c == it.first_chunk ? it.first_bit : HUFD_NONE32;
+    rec.reserved = 0;
     chunk_item[c] = lo;
     chunk_rec[c] = rec;
 }

@@ -638,7 +638,9 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
         const bool twin = lane == kTwin;
         const u32 last0 = sh.kept[kOneRecs - 1][0];
         u32 st = ow.state_at(lane < ns ? lane : 0u);
-        bool dd = lane >= ns, met = false;
+        /* (an item's first chunk is only ever entered at the item's first bit: one candidate, not ns -- every chunk of
+         * BASELINE configs[3]; the other states' entries of the chunk function are never asked for) */
+        bool dd = rec.entry_bit == HUFD_NONE32 ? lane >= ns : lane != rec.entry_bit, met = false;
         u32 c_at = 0, r_at = 0;
         u32 at0 = st, latest = 0; /* lane 0's walk where the last candidate met it, and the row (the same in every thread) */
         u32 hi = sh.sub0[0];

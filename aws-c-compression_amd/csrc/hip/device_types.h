@@ -211,6 +211,9 @@ struct hufd_chunk_rec {
     uint64_t out_cap; /* the item's output capacity */
     uint32_t valid;   /* bytes of the item from the chunk's first on (saturated) */
     uint32_t item;
+    uint32_t entry_bit; /* the item's first chunk: the bit the item starts at -- the one state the chunk is ever entered in;
+                         * HUFD_NONE32: a chunk inside its item, entered as the chunk in front of it is left */
+    uint32_t reserved;
 };
 
 /* Where the items of a plan that is made on the device come from (plan_kernels.hip): the caller's records in DEVICE memory,
