@@ -392,6 +392,7 @@ struct one_shared {
     u32 decided0; /* every entry state of sub-chunk 0 died or met lane 0's walk: what dec_sync_guess needs of a chunk */
     u32 moved;    /* a lane leaves its sub-chunk in another state than the lane behind it took for its entry */
     u32 bad_mine; /* a lane's walk from its entry went wrong (which may be the entry's fault: see `moved`) */
+
 };
 
 template <u32 LB, u32 SURE, bool TAIL = false> /* TAIL: the chunks listed in tail_chunks (a stream ends in them) */
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
     one_shared<LB> &sh = *reinterpret_cast<one_shared<LB> *>(dyn_lds);
     const u32 ns = tb.n_states;
     const u32 lane = threadIdx.x;
-    const u32 c = TAIL ? tail_chunks[blockIdx.x] : blockIdx.x;
+    const u32 c = TAIL ? wave_uniform(tail_chunks[blockIdx.x]) : blockIdx.x;
     const hufd_chunk_rec rec = chunk_rec[c];
     const u64 valid = rec.valid;
     const u8 *src = d_in + rec.src_off;
@@ -489,15 +490,13 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
     for (u32 j0 = 0; j0 < kLutPerLane; j0 += kLutBatch) {
         table_share(j0);
     }
-#pragma unroll
-    for (u32 r = 0; r < kFastRows; ++r) {
-        w[r] = __builtin_bswap32(w[r]);
-    }
     if (lane == 0) {
         sh.bad = 0;
         sh.decided0 = 0;
         sh.moved = 0;
         sh.bad_mine = 0;
+        /* (as loaded: the candidates' walks swap the bytes of the words they read -- swapped first, the copy's temporaries
+         * were four registers the TAIL instantiation does not have) */
 #pragma unroll
         for (u32 r = 0; r <= kOneMaxMerge0; ++r) {
             sh.sub0[r] = w[r];
@@ -506,6 +505,10 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
         for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
             sh.wave_sum[wv] = 0; /* (TAIL: of the waves that have left) */
         }
+    }
+#pragma unroll
+    for (u32 r = 0; r < kFastRows; ++r) {
+        w[r] = __builtin_bswap32(w[r]);
     }
     __syncthreads();
     HUFD_STAMP(0, 1);
@@ -640,10 +643,11 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
         u32 st = ow.state_at(lane < ns ? lane : 0u);
         /* (an item's first chunk is only ever entered at the item's first bit: one candidate, not ns -- every chunk of
          * BASELINE configs[3]; the other states' entries of the chunk function are never asked for) */
-        bool dd = rec.entry_bit == HUFD_NONE32 ? lane >= ns : lane != rec.entry_bit, met = false;
+        const u32 only = rec.entry_bit; /* (a scalar: the record is the same for the workgroup) */
+        bool dd = only == HUFD_NONE32 ? lane >= ns : lane != only, met = false;
         u32 c_at = 0, r_at = 0;
         u32 at0 = st, latest = 0; /* lane 0's walk where the last candidate met it, and the row (the same in every thread) */
-        u32 hi = sh.sub0[0];
+        u32 hi = __builtin_bswap32(sh.sub0[0]);
         for (u32 r = 0; !hopeless; ++r) {
             /* (lane 0's walk started on a guess: while it is on a wrong phase it may step over a window without a code.  A
              * candidate that stands where that walk stands IN FRONT of such a window does not join it: it walks on by
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
             if (__all(dd || met || twin) || r == kSubWords) {
                 break;
             }
-            const u32 lo = sh.sub0[r + 1];
+            const u32 lo = __builtin_bswap32(sh.sub0[r + 1]);
             if (twin) {
                 st = ow.template row<SURE>(st, hi, lo, table); /* (as phase R took the row: the marks are part of the state) */
             } else if (!dd && !met) {

@@ -49,6 +49,16 @@ typedef unsigned short u16;
 typedef unsigned char u8;
 
 constexpr u32 kWave = 64;
+
+/* a value that is the same in every lane of the wave, as a scalar (what is derived from it -- a record's address, its
+ * fields -- then lives in scalar registers and is loaded by the scalar unit) */
+__device__ __forceinline__ u32 wave_uniform(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readfirstlane(x);
+#else
+    return x;
+#endif
+}
 constexpr u64 kNoBit = ~0ull;
 
 HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, dyn_lds)
