@@ -33,9 +33,9 @@ GROUPS = [  # bench kernel name <- substrings of the device kernel names it cove
     ("enc_count", ["enc_count_kernel"]),
     ("enc_scan", ["enc_scan_small_kernel", "enc_scan_large_kernel"]),
     ("enc_pack", ["enc_pack_wave_kernel", "enc_pack_stream_kernel", "enc_pack_kernel"]),
-    ("dec_sync", ["dec_sync_lean_kernel", "dec_sync_pack_kernel", "dec_sync_guess_kernel", "dec_sync_few_kernel", "dec_sync_tail_kernel",
+    ("dec_sync", ["dec_sync_one_kernel", "dec_sync_pack_kernel", "dec_sync_guess_kernel", "dec_sync_few_kernel", "dec_sync_tail_kernel",
                   "dec_sync_kernel"]),
-    ("dec_scan", ["dec_scan_small_kernel", "dec_scan_runs_kernel", "dec_scan_top_kernel", "dec_scan_apply_kernel",
+    ("dec_scan", ["dec_scan_small_kernel", "dec_scan_runs_kernel", "dec_scan_apply_kernel",
                   "dec_sync_true_kernel", "dec_tiny_kernel", "dec_deep_kernel"]),
     ("dec_emit", ["dec_emit_fast_kernel", "dec_emit_pack_kernel", "dec_emit_tail_kernel", "dec_emit_big_kernel", "dec_emit_kernel"]),
 ]
@@ -84,7 +84,8 @@ def main():
     steps = None
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         sums, calls = counter_sums(os.path.join(src, sub))
-        n_steps = max([v for k, v in calls.items() if "dec_scan_small_kernel" in k] or [0])  # one per decode launch
+        # one per decode launch (the 1 GiB stream: dec_scan_runs; a plan without long items: dec_scan_small)
+        n_steps = max([v for k, v in calls.items() if "dec_scan_runs_kernel" in k or "dec_scan_small_kernel" in k] or [0])
         if not n_steps:
             continue
         steps = n_steps
