@@ -33,6 +33,10 @@
 #define HUFD_TINY_MANY_BYTES 2048u /* symbols (encode); encoded bytes x 2 / 3 (decode) */
 #define HUFD_ENC_SOLO_BYTES 4096u /* encode items up to one tile of symbols that no thread takes are one wave's work where the
                                    * one-pass encoder applies (enc_onepass<.., SOLO>): no segments, no look-back */
+#define HUFD_ENC_SOLO_MANY_BYTES HUFD_ENC_SEG_BYTES /* ... and items of up to a segment (four tiles, one after the other by the
+                                   * same wave) when the plan holds at least HUFD_ENC_SOLO_MANY_ITEMS items: the chip is full
+                                   * of waves either way, and none of them waits (BASELINE configs[3]: 65 536 items of 16 KiB) */
+#define HUFD_ENC_SOLO_MANY_ITEMS 256u
 #define HUFD_ENC_TINY_WAVE_BYTES 1024u /* the same class for encode where the one-pass kernel is used */
 #define HUFD_ENC_TINY_PER_BYTE 18u
 #define HUFD_ENC_TINY_PER_BYTE_ONE_PASS 100u /* the same where the one-pass encoder packs ragged tiles (csrc/host/engine.c: enc_tiny_per_byte) */

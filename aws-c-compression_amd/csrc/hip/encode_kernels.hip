@@ -2060,7 +2060,9 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
     }
     __syncthreads();
     const u8 *mine = reinterpret_cast<const u8 *>(tab) + (lane & 31u) * 4u;
-    const u32 n_tiles = SOLO ? n_solo : n_segs * kTilesPerSeg;
+    /* (SOLO: tile t = tile t % 4 of listed item t / 4 -- an item of up to a segment; the tiles behind its last symbol are
+     * never taken, see next_tile) */
+    const u32 n_tiles = SOLO ? n_solo * kTilesPerSeg : n_segs * kTilesPerSeg;
 
     /* (t is a scalar, the descriptor arrays are read-only: these are scalar loads, no vector registers, no vector-memory wait) */
     auto describe = [&](u32 t) -> op_tile {
@@ -2068,10 +2070,10 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         const u32 tc = t < n_tiles ? t : n_tiles - 1; /* (a tile past the end is never worked on) */
         d.t = t;
         if (SOLO) {
-            /* the item is its own one segment, and that segment's one tile */
-            const u32 item = solo_items[tc];
-            d.s = tc;
-            d.w4 = 0;
+            /* the item is its own one segment */
+            const u32 item = solo_items[tc / kTilesPerSeg];
+            d.s = tc / kTilesPerSeg;
+            d.w4 = tc % kTilesPerSeg;
             d.seg.in_off = items[item].in_off;
             d.seg.len = (u32)items[item].in_len;
             d.seg.item = item;
@@ -2087,7 +2089,7 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         const u8 *src = d_in + d.seg.in_off;
         d.carried = items[d.seg.item].ovf_bits;
         d.carried_pattern = items[d.seg.item].ovf_pattern;
-        d.item_first_tile = SOLO ? t : items[d.seg.item].first_seg * kTilesPerSeg;
+        d.item_first_tile = SOLO ? t - d.w4 : items[d.seg.item].first_seg * kTilesPerSeg;
         d.tsrc = src + d.w4 * kTileBytes;
         const u32 from = d.w4 * kTileBytes;
         d.n_sym = (t < n_tiles && d.seg.len > from) ? (d.seg.len - from < kTileBytes ? d.seg.len - from : kTileBytes) : 0u;
@@ -2147,10 +2149,21 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
     /* tiles in turn over the packing waves of the grid: the tiles a tile waits for belong to this turn or an earlier
      * one, so to the running waves as long as the whole grid is resident (the launch sizes it so) */
     const u32 stride = gridDim.x * kPackWaves - (SOLO ? 0u : 1u);
-    u32 t_new = blockIdx.x * kPackWaves + wave - (!SOLO && blockIdx.x ? 1u : 0u);
+    u32 t_new = SOLO ? (blockIdx.x * kPackWaves + wave) * kTilesPerSeg : blockIdx.x * kPackWaves + wave - (blockIdx.x ? 1u : 0u);
     if (t_new >= n_tiles) {
         return;
     }
+    /* the tile this wave takes behind tile `d`.  SOLO: the item's next tile while it has symbols left, then the first tile
+     * of the wave's next item -- the wave packs its item's tiles one after the other and knows the bits in front of each
+     * (solo_bits), which is all the look-back would tell it */
+    auto next_tile = [&](const op_tile &d) -> u32 {
+        if (!SOLO) {
+            return d.t + stride;
+        }
+        const u32 from_next = (d.w4 + 1) * kTileBytes;
+        return d.w4 + 1 < kTilesPerSeg && d.seg.len > from_next ? d.t + 1 : d.t - d.w4 + stride * kTilesPerSeg;
+    };
+    u64 solo_bits = 0; /* SOLO: the item's bits in front of the tile that is finished next */
     op_tile fresh = describe(t_new); /* the tile whose symbols are looked up in this turn ... */
     op_tile old = fresh;             /* ... and the one before it, whose image is copied out in this turn */
     bool have_old = false;
@@ -2288,7 +2301,7 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         const u64 before = uniform64((rb & ~kOpReady) + in_round); /* bits of every tile of the plan in front of this one */
         u64 bw; /* stream bit (inside the item) of the tile's first code */
         if (SOLO) {
-            bw = old.carried;
+            bw = old.first_tile ? (u64)old.carried : solo_bits;
         } else if (old.first_tile) {
             bw = old.carried;
             base_value = kOpReady | before;
@@ -2304,11 +2317,14 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
             bw = before - (base_value & ~kOpReady) + old.carried;
         }
         const u64 bn = bw + old.bits;
+        if (SOLO) {
+            solo_bits = bn;
+        }
 
         const u64 out_cap = uniform64(items[seg.item].out_cap);
         const u64 cap_bits = out_cap > (~0ull >> 3) ? ~0ull : out_cap * 8;
         /* ---- what enc_finish_kernel turns into the call's outcome: the item's bit total ... */
-        if (lane == 0 && (SOLO || old.w4 == kTilesPerSeg - 1) && (seg.flags & 2u)) {
+        if (lane == 0 && (SOLO ? old.ends_item : old.w4 == kTilesPerSeg - 1) && (seg.flags & 2u)) {
             item_total[seg.item] = bn; /* (tiles behind the item's last symbol hold no bits) */
         }
         /* ... and, when the output is too short, which tile holds the symbol whose last bit reaches the capacity edge (exactly
@@ -2382,7 +2398,8 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         halo0 = *(fresh.halo_n > 0 ? fresh.tsrc + fresh.n_sym : seg_first);
         halo1 = *(fresh.halo_n > 1 ? fresh.tsrc + fresh.n_sym + 1 : seg_first);
         /* the tile after it: its symbols are on their way while this one is packed */
-        nxt = describe(t_new + stride);
+        const u32 t_next = next_tile(fresh);
+        nxt = describe(t_next);
         tile_loads(nxt, vn);
 
         /* ---- the fresh tile's bits: codes -> pairs -> quads -> octs, one wave scan per two groups.  A ragged tile takes
@@ -2548,7 +2565,7 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         old_halo1 = halo1;
         have_old = true;
         fresh = nxt;
-        t_new += stride;
+        t_new = t_next;
 #pragma unroll
         for (u32 gi = 0; gi < kGroupsPerLane; ++gi) {
             v[gi] = vn[gi];

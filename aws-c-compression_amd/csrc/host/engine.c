@@ -582,8 +582,11 @@ static uint64_t enc_tiny_limit(
 }
 
 /* the longest item that is one wave's work without segments (enc_onepass<.., SOLO>: the one-pass packer, waiting for nobody) */
-static uint64_t enc_solo_limit(const struct aws_huffman_amd_engine *eng) {
-    return aws_huffman_amd_engine_encodes_in_one_pass(eng) ? HUFD_ENC_SOLO_BYTES : 0;
+static uint64_t enc_solo_limit(const struct aws_huffman_amd_engine *eng, size_t n_items) {
+    if (!aws_huffman_amd_engine_encodes_in_one_pass(eng)) {
+        return 0;
+    }
+    return n_items >= HUFD_ENC_SOLO_MANY_ITEMS ? HUFD_ENC_SOLO_MANY_BYTES : HUFD_ENC_SOLO_BYTES;
 }
 
 static bool enc_item_is_solo(const struct aws_huffman_amd_encode_item *it, uint64_t tiny_limit, uint64_t solo_limit) {
@@ -669,7 +672,7 @@ static int enc_plan_fill(
         p->stats.thread_limit = tiny_limit;
         return AWS_OP_SUCCESS;
     }
-    const uint64_t solo_limit = enc_solo_limit(eng);
+    const uint64_t solo_limit = enc_solo_limit(eng, n_items);
     uint64_t n_segs = 0, n_large = 0, n_tiny = 0, n_cut = 0, n_solo = 0;
     for (size_t i = 0; i < n_items; ++i) {
         if (items[i].overflow_in.num_bits > 32) {
@@ -876,7 +879,7 @@ static int enc_plan_fill_on_device(struct aws_huffman_amd_encode_plan *p, const 
     if (!e) {
         const uint64_t class0 = aws_huffman_amd_engine_encodes_in_one_pass(eng) ? HUFD_ENC_TINY_WAVE_BYTES : HUFD_TINY_MANY_BYTES;
         e = hufk_encode_plan_count(
-            src, (uint32_t)n_items, class0, HUFD_ENC_TINY_BYTES, enc_tiny_per_byte(eng), enc_solo_limit(eng), p->d_plan_scratch, &t, st);
+            src, (uint32_t)n_items, class0, HUFD_ENC_TINY_BYTES, enc_tiny_per_byte(eng), enc_solo_limit(eng, n_items), p->d_plan_scratch, &t, st);
     }
     if (e) {
         return raise_hip(e);
@@ -887,7 +890,7 @@ static int enc_plan_fill_on_device(struct aws_huffman_amd_encode_plan *p, const 
     e = enc_plan_reserve(p, n_items, (size_t)t.totals[0], (size_t)t.totals[3], (size_t)t.totals[1]);
     if (!e) {
         e = hufk_encode_plan_fill(
-            src, (uint32_t)n_items, (uint32_t)t.totals[0], enc_solo_limit(eng), p->d_plan_scratch, p->d_items, p->d_segs, p->d_tiny,
+            src, (uint32_t)n_items, (uint32_t)t.totals[0], enc_solo_limit(eng, n_items), p->d_plan_scratch, p->d_items, p->d_segs, p->d_tiny,
             p->d_large, p->d_solo, st);
     }
     if (e) {

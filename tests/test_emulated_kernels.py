@@ -145,12 +145,15 @@ def test_mid_sized_encode_items(world):
     """Items either side of one tile (HUFD_ENC_SOLO_BYTES = 4096 symbols): a wave each without segments below it where the
     coder encodes in one pass, segments above; every kind of stop of the short items' scenario, and the same items with
     the one-pass road's look-back given up and with a coder that takes count / scan / pack."""
-    edges = (4095, 4096, 4097, 8192, 16384, 16385)
+    edges = (4095, 4096, 4097, 8191, 8192, 8193, 12288, 16383, 16384, 16385)
+    # (256 items or more: up to a segment, four tiles one after the other by the same wave)
+    pc.tiny_encode_items(world, n_items=300, seed=157, max_len=20000, edge_lens=False, wave_limit=16384, more_lens=edges)
     pc.tiny_encode_items(world, n_items=220, seed=151, max_len=9000, edge_lens=False, wave_limit=4096, more_lens=edges)
     pc.tiny_encode_items(world, n_items=90, seed=152, max_len=4000, edge_lens=False, wave_limit=4096)  # (no segments at all)
     pc.tiny_encode_items(world, n_items=120, seed=153, holes=True, max_len=9000, edge_lens=False, wave_limit=0, more_lens=edges)
     with harness.encode_road(world.product.lib, "one-pass-fails"):
         pc.tiny_encode_items(world, n_items=120, seed=154, max_len=9000, edge_lens=False, wave_limit=4096, more_lens=edges)
+        pc.tiny_encode_items(world, n_items=260, seed=158, max_len=20000, edge_lens=False, wave_limit=16384, more_lens=edges)
     with harness.encode_road(world.product.lib, "three-kernel"):
         pc.tiny_encode_items(world, n_items=120, seed=155, max_len=9000, edge_lens=False, wave_limit=0, more_lens=edges)
 

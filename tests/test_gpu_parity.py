@@ -179,15 +179,18 @@ def test_tiny_encode_items(world, engine):
 
 
 def test_mid_sized_encode_items(world, engine):
-    """Items either side of one tile (HUFD_ENC_SOLO_BYTES = 4096 symbols): a wave each without segments below it where the
-    coder encodes in one pass, segments above (the encode twin of test_mid_sized_items); with every kind of stop of the
-    short items' scenario, a plan of such items only, a coder that takes count / scan / pack, and the two test roads."""
-    edges = (4095, 4096, 4097, 8192, 16384, 16385)
-    pc.tiny_encode_items(world, n_items=2500, seed=151, engine=engine, max_len=9000, edge_lens=False, wave_limit=4096, more_lens=edges)
-    pc.tiny_encode_items(world, n_items=5000, seed=152, engine=engine, max_len=4000, edge_lens=False, wave_limit=4096)
+    """Items either side of one tile and of one segment (4096 / 16384 symbols): a wave each without segments where the coder
+    encodes in one pass -- up to a tile in a small plan (HUFD_ENC_SOLO_BYTES), up to a segment, four tiles one after the
+    other, in a plan of 256 items or more (HUFD_ENC_SOLO_MANY_*) --, segments above (the encode twin of
+    test_mid_sized_items); with every kind of stop of the short items' scenario, a plan of such items only, a coder that
+    takes count / scan / pack, and the two test roads."""
+    edges = (4095, 4096, 4097, 8191, 8192, 8193, 12288, 16383, 16384, 16385, 20000)
+    pc.tiny_encode_items(world, n_items=2500, seed=151, engine=engine, max_len=20000, edge_lens=False, wave_limit=16384, more_lens=edges)
+    pc.tiny_encode_items(world, n_items=5000, seed=152, engine=engine, max_len=4000, edge_lens=False, wave_limit=16384)
+    pc.tiny_encode_items(world, n_items=200, seed=156, engine=engine, max_len=9000, edge_lens=False, wave_limit=4096, more_lens=edges)
     pc.tiny_encode_items(world, n_items=1200, seed=153, holes=True, max_len=9000, edge_lens=False, wave_limit=0, more_lens=edges)
     with harness.encode_road(world.product.lib, "one-pass-fails"):
-        pc.tiny_encode_items(world, n_items=1200, seed=154, max_len=9000, edge_lens=False, wave_limit=4096, more_lens=edges)
+        pc.tiny_encode_items(world, n_items=1200, seed=154, max_len=20000, edge_lens=False, wave_limit=16384, more_lens=edges)
     with harness.encode_road(world.product.lib, "three-kernel"):
         pc.tiny_encode_items(world, n_items=1200, seed=155, max_len=9000, edge_lens=False, wave_limit=0, more_lens=edges)
 
