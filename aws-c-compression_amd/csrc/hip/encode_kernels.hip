@@ -2597,7 +2597,8 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
  * `consumed` counts up to and with it, the overflow is what of its code did not fit
  * (source/huffman.c:88-98).
  */
-constexpr u32 kFinishItems = 64; /* per workgroup of 256: a wave of it per 16 items that may each need a tile read again */
+constexpr u32 kFinishItems = 16; /* per workgroup of 256: a wave of it per four items that may each need a tile read again
+                                  * (64 an item: BASELINE configs[3], a quarter of whose items need it, 0.079 -> 0.073 ms) */
 constexpr u32 kFinishLdsBytes = 256 * (8 + 8 + 4 + 4 + 4) + 16;
 __global__ __launch_bounds__(256) void enc_finish_kernel(
     hufd_tables tb,
@@ -2795,9 +2796,7 @@ static void encode_solo_items(const struct hufk_encode_args *a, hipStream_t st, 
     }
     const onepass_layout l = onepass_layout_of(a->n_segs, a->n_items);
     const uint8_t *z = (const uint8_t *)a->zero_block;
-    if (finish) { /* (no one-pass launch ahead of this one has cleared the block) */
-        (void)hipMemsetAsync((void *)(z + l.null_tile), 0, l.bytes - l.null_tile, st);
-    }
+    /* (the readable nothing at z + l.null_tile may hold anything: what a wave loads from there is never looked at) */
     const uint32_t region = pack_region_bytes(a->tables.enc_max_bits);
     const uint32_t lds = kPackTabBytes + kPackWaves * region;
     const uint32_t work = (a->n_solo + kPackWaves - 1) / kPackWaves;
@@ -2860,7 +2859,9 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
         const onepass_layout l = onepass_layout_of(a->n_segs, a->n_items);
         uint8_t *z = (uint8_t *)a->zero_block;
         stage_mark(a->stage_events, 0, st); /* (the clearing of the look-back words is part of what is timed) */
-        (void)hipMemsetAsync(a->zero_block, 0, l.bytes, st);
+        /* (a plan without segments -- every item a wave's or a thread's -- has no look-back words: the control words only;
+         * BASELINE configs[3]'s 65 536 item bases were half a megabyte cleared for nobody) */
+        (void)hipMemsetAsync(a->zero_block, 0, a->n_segs ? l.bytes : l.tile_agg, st);
         const uint32_t region = pack_region_bytes(a->tables.enc_max_bits);
         const uint32_t lds = kPackTabBytes + kPackWaves * region;
         const uint32_t work = (a->n_segs * kTilesPerSeg + kPackWaves - 1) / kPackWaves;
