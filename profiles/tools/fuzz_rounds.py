@@ -52,6 +52,16 @@ rounds = [
     ("encode_then_decode_on_the_device", lambda s: pc.encode_then_decode_on_the_device(w, seed=s, engine=eng, batches=((60, 60), (7300, 90)))
      if s % 2 == 1 else None),
     ("plans_one_after_another", lambda s: pc.plans_one_after_another(w, seed=s) if s % 4 == 2 else None),
+    # round 5: dec_sync_one's rare lanes, plans made on the device, items a wave encodes without segments (one tile; up
+    # to a segment in a plan of 256 items or more), streams with two last chunks
+    ("walks_that_never_meet", lambda s: pc.walks_that_never_meet(w, seed=s, engine=eng, runs=(130 + s % 97, 260 + s % 211, 700 + s % 409))),
+    ("mid_sized_encode_items", lambda s: pc.tiny_encode_items(w, n_items=300 + s % 40, seed=s, engine=eng, max_len=20000, edge_lens=False,
+                                                              more_lens=(4095, 4096, 4097, 8192, 12288, 16383, 16384, 16385))),
+    ("mid_sized_encode_items few", lambda s: pc.tiny_encode_items(w, n_items=120, seed=s, engine=eng, max_len=9000, edge_lens=False,
+                                                                  more_lens=(4095, 4096, 4097, 8192))),
+    ("plans_made_on_the_device", lambda s: pc.plans_made_on_the_device(w, seed=s, engine=eng, big=600_000 + 1013 * (s % 60), n_small=200 + s % 120)
+     if s % 3 == 0 else None),
+    ("streams_with_two_last_chunks", lambda s: pc.streams_with_two_last_chunks(w, seed=s, engine=eng, modes=(None,)) if s % 3 == 1 else None),
 ]
 rounds = [r for r in rounds if only in r[0]]
 t0 = time.time()
