@@ -514,6 +514,23 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
     HUFD_STAMP(0, 1);
     HUFD_STAMP(0, 2);
 
+    /* the guessed walk's states at the kept boundaries: in registers where the kernel has them to spare (inside a stream:
+     * 48 + 12 of 64), in LDS for the chunks streams end in (54) */
+    constexpr bool kKeptInRegisters = !TAIL;
+    u32 kept_r[kOneRecs + kQuarters - 1];
+#pragma unroll
+    for (u32 q = 0; q < kOneRecs + kQuarters - 1; ++q) {
+        kept_r[q] = 0;
+    }
+    auto kept_set = [&](u32 q, u32 v) {
+        if (kKeptInRegisters) {
+            kept_r[q] = v;
+        } else {
+            sh.kept[q][lane] = v;
+        }
+    };
+    auto kept_get = [&](u32 q) -> u32 { return kKeptInRegisters ? kept_r[q] : sh.kept[q][lane]; };
+
     /* R: one walk from bit 0, a guess, over the whole sub-chunk; its state kept at a few row boundaries */
     u32 state = ow.state_at(0);
     bool hopeless = false; /* (the same for the wave) */
@@ -521,10 +538,10 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
     for (u32 r = 0; r < kSubWords; ++r) {
         if (!hopeless) {
             if (one_rec_index(r) < kOneRecs) {
-                sh.kept[one_rec_index(r)][lane] = state;
+                kept_set(one_rec_index(r), state);
             }
             if (r != 0 && r % (kSubWords / kQuarters) == 0) {
-                sh.kept[kOneRecs + r / (kSubWords / kQuarters) - 1][lane] = state;
+                kept_set(kOneRecs + r / (kSubWords / kQuarters) - 1, state);
             }
             state = ow.template row<SURE>(state, w[r], w[r + 1], table) + 32u;
             if (r + 1 == kOneGarbageRow) {
@@ -535,7 +552,10 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
         }
     }
     const u32 last = state;
-    sh.kept[kOneRecs - 1][lane] = last; /* (the boundary behind the last row: the sub-chunk's end) */
+    kept_set(kOneRecs - 1, last); /* (the boundary behind the last row: the sub-chunk's end) */
+    if (kKeptInRegisters && lane == 0) {
+        sh.kept[kOneRecs - 1][0] = last; /* (what the candidates of sub-chunk 0 ask of lane 0's walk) */
+    }
     u32 ref_exit = ow.offset_of(last); /* (how the lane leaves: the guessed walk's way, unless the true walk never met it) */
     bool ok = !hopeless; /* what speaks against the chunk whatever its lanes' entries are ... */
     bool ok_mine = !active || ref_exit < ns; /* ... and what may change for a lane when the lane in front of it leaves another way */
@@ -561,7 +581,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
                     head_cp[r / (kSubWords / kQuarters) - 1] = st;
                 }
                 if (one_rec_index(r) < kOneRecs) {
-                    const u32 there = sh.kept[one_rec_index(r)][lane];
+                    const u32 there = kept_get(one_rec_index(r));
                     if (!met && ((st ^ there) & 0x3FFu) == 0) {
                         met = true;
                         h_at = st;
@@ -595,7 +615,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
                 st = ow.template row<0>(st, hi, lo, table) + 32u;
                 hi = lo;
                 if (r + 1 == one_rec_row(kOneRecs - 2) || r + 1 == one_rec_row(kOneRecs - 1)) {
-                    const u32 there = sh.kept[r + 1 == one_rec_row(kOneRecs - 2) ? kOneRecs - 2 : kOneRecs - 1][lane];
+                    const u32 there = r + 1 == one_rec_row(kOneRecs - 2) ? kept_get(kOneRecs - 2) : kept_get(kOneRecs - 1);
                     if (!met && ((st ^ there) & 0x3FFu) == 0) {
                         met = true;
                         h_at = st;
@@ -749,10 +769,15 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
                             head_cp[qq] = r == (qq + 1) * (kSubWords / kQuarters) ? st : head_cp[qq];
                         }
                         const u32 j = one_rec_index(r);
-                        if (j < kOneRecs && ((st ^ sh.kept[j][lane]) & 0x3FFu) == 0) {
+                        u32 there = 0;
+#pragma unroll
+                        for (u32 q = 0; q < kOneRecs; ++q) {
+                            there = j == q ? kept_get(q) : there;
+                        }
+                        if (j < kOneRecs && ((st ^ there) & 0x3FFu) == 0) {
                             met = true;
                             h_at = st;
-                            r_at = sh.kept[j][lane];
+                            r_at = there;
                             meet_row = r;
                         }
                         if (met || r == kSubWords) {
@@ -815,7 +840,7 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
              * checkpoint may be missing, dec_emit_fast walks on through that quarter) */
             const u32 boundary = (qq + 1) * (kSubWords / kQuarters);
             bool have = boundary >= meet_row;
-            const u32 at_boundary = sh.kept[kOneRecs + qq][lane];
+            const u32 at_boundary = kept_get(kOneRecs + qq);
             u32 tail = one_walk::count_of(last) - one_walk::count_of(at_boundary), bits = ow.offset_of(at_boundary);
             if (!have && lane != 0) {
                 tail = count - one_walk::count_of(head_cp[qq]);

@@ -1516,8 +1516,9 @@ def plans_made_on_the_device(w, seed=131, engine=None, big=2_200_000, n_small=30
         cap = [it["in_len"], it["in_len"] + 5, it["in_len"] // 2][i % 3] if it["in_len"] < 50_000 else it["in_len"]
         ditems.append(dict(in_offset=it["out_offset"], in_len=in_len, first_bit=0, out_offset=it["in_offset"], out_capacity=cap))
     damaged = int(np.argmax(lens))
-    bad = eng.download(d_a, 8, offset=items[damaged]["out_offset"] + 1_000_000)
-    eng.upload(d_a, np.full(4, 0xFF, np.uint8), offset=items[damaged]["out_offset"] + 1_000_000)
+    damage_at = items[damaged]["out_offset"] + min(1_000_000, res_host[damaged][3] // 2)  # (inside the longest item's output)
+    bad = eng.download(d_a, 8, offset=damage_at)
+    eng.upload(d_a, np.full(4, 0xFF, np.uint8), offset=damage_at)
     sym_total = host_in.size
     d_sa, d_sb = eng.alloc(sym_total), eng.alloc(sym_total)
     host_dplan = eng.decode_plan(ditems)
@@ -1532,7 +1533,7 @@ def plans_made_on_the_device(w, seed=131, engine=None, big=2_200_000, n_small=30
     assert dres_host == dres_dev, [(i, a, b) for i, (a, b) in enumerate(zip(dres_host, dres_dev)) if a != b][:3]
     assert len({r[:2] for r in dres_host}) >= 3  # (whole, short of room, a symbol without a code)
     assert np.array_equal(eng.download(d_sa, sym_total), eng.download(d_sb, sym_total)), "decode: the device-made plan wrote other bytes"
-    eng.upload(d_a, bad[:4], offset=items[damaged]["out_offset"] + 1_000_000)
+    eng.upload(d_a, bad[:4], offset=damage_at)
     # chained: what the encode launch of dev_plan left in d_b, decoded back to where it came from
     chained = eng.empty_decode_plan()
     eng.encode_launch(dev_plan, d_in, d_b)
