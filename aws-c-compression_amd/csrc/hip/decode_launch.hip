@@ -356,6 +356,39 @@ static pthread_mutex_t s_init_lock = PTHREAD_MUTEX_INITIALIZER;
 
 } /* namespace */
 
+namespace {
+struct occupancy_note {
+    const void *kernel;
+    uint32_t threads, lds_bytes;
+    int per_cu;
+};
+constexpr int kOccupancyNotes = 256;
+occupancy_note s_occupancy[kOccupancyNotes];
+int s_occupancy_count = 0;
+pthread_mutex_t s_occupancy_lock = PTHREAD_MUTEX_INITIALIZER;
+} /* namespace */
+
+int hufk_host::blocks_per_cu_remembered(const void *kernel, uint32_t threads, uint32_t lds_bytes) {
+    int found = -1;
+    pthread_mutex_lock(&s_occupancy_lock);
+    for (int i = 0; i < s_occupancy_count; ++i) {
+        if (s_occupancy[i].kernel == kernel && s_occupancy[i].threads == threads && s_occupancy[i].lds_bytes == lds_bytes) {
+            found = s_occupancy[i].per_cu;
+            break;
+        }
+    }
+    pthread_mutex_unlock(&s_occupancy_lock);
+    return found;
+}
+
+void hufk_host::blocks_per_cu_remember(const void *kernel, uint32_t threads, uint32_t lds_bytes, int per_cu) {
+    pthread_mutex_lock(&s_occupancy_lock);
+    if (s_occupancy_count < kOccupancyNotes) { /* (a full table: the query is asked again, as before) */
+        s_occupancy[s_occupancy_count++] = occupancy_note{kernel, threads, lds_bytes, per_cu};
+    }
+    pthread_mutex_unlock(&s_occupancy_lock);
+}
+
 int hufk_host::current_compute_units() {
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMaxDevices || s_compute_units[device] <= 0) {

@@ -15,13 +15,22 @@ namespace hufk_host {
 /* compute units of the calling thread's current device (hufk_init has counted them; 256 before that) */
 int current_compute_units();
 
+/* what the occupancy query said of a kernel at a block size and an LDS size, remembered: a launch sizes the grids of some
+ * ten resident kernels, and the query is a few microseconds of the host's time each (the first one of a kernel a good deal
+ * more) -- a third of what a small call costs.  (One table a process: every device of a process is the same chip.) */
+int blocks_per_cu_remembered(const void *kernel, uint32_t threads, uint32_t lds_bytes); /* -1: not asked yet */
+void blocks_per_cu_remember(const void *kernel, uint32_t threads, uint32_t lds_bytes, int per_cu);
+
 /* workgroups of a persistent kernel that one launch keeps resident: CUs x blocks per CU */
 template <typename Kernel>
 inline uint32_t persistent_grid(Kernel kernel, uint32_t threads, uint32_t lds_bytes, uint32_t work_items, uint32_t sgprs = 0) {
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)threads, lds_bytes) != hipSuccess ||
-        per_cu < 1) {
-        per_cu = 1;
+    int per_cu = blocks_per_cu_remembered(reinterpret_cast<const void *>(kernel), threads, lds_bytes);
+    if (per_cu < 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)threads, lds_bytes) != hipSuccess ||
+            per_cu < 1) {
+            per_cu = 1;
+        }
+        blocks_per_cu_remember(reinterpret_cast<const void *>(kernel), threads, lds_bytes, per_cu);
     }
     /* The occupancy query knows nothing of the scalar registers: a SIMD has 800 of them and a wave is given its count
      * rounded up to 16, plus 16, so the hardware admits floor(800 / that) waves a SIMD -- one block a CU fewer than the
