@@ -2327,15 +2327,6 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         if (lane == 0 && (SOLO ? old.ends_item : old.w4 == kTilesPerSeg - 1) && (seg.flags & 2u)) {
             item_total[seg.item] = bn; /* (tiles behind the item's last symbol hold no bits) */
         }
-        /* ... and, when the output is too short, which tile holds the symbol whose last bit reaches the capacity edge (exactly
-         * one does) and where that tile's bits start: enc_finish_kernel looks the symbol up */
-        if (lane == 0 && bw < cap_bits && cap_bits <= bn) {
-            hufd_enc_result *r = &results[seg.item];
-            r->consumed = (u64)seg.index * HUFD_ENC_SEG_BYTES + old.w4 * kTileBytes; /* the item's symbols in front of the tile */
-            r->total_bits = bw;
-            r->ovf_bits = old.n_sym;
-        }
-
         {
             u8 *out_ptr = d_out + uniform64(items[seg.item].out_off);
             /* the last byte: the next tile's head, or the padding when the item ends here (huffman.c:178-184) */
@@ -2370,6 +2361,69 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
             region_store_shifted(img, out_ptr, bw, jlo, jhi, lane);
         }
         wave_step(); /* the image is free for the fresh tile */
+        /* When the output is too short: the symbol whose last bit reaches the capacity edge (exactly one tile holds it).  The
+         * wave takes its tile's symbols once more -- out of the L2, into the image's LDS, which is free now --, every lane
+         * counts the bits of 64 of them, and the 64 symbols around the edge are then a symbol a lane: `consumed` (up to and
+         * with that symbol) and the bits of its code that did not fit (source/huffman.c:88-98) go into the item's record,
+         * where enc_finish_kernel picks them up.  (Rounds 2-4 left a note here and enc_finish read the tile again, a wave
+         * an item: 143 registers, three waves a SIMD -- 61-67 us for BASELINE configs[3], a quarter of whose outputs are
+         * short.) */
+        if (bw < cap_bits && cap_bits <= bn) {
+            const u32 target = (u32)(cap_bits - bw); /* the edge, in bits from the tile's first code: 1 .. the tile's bits */
+            u8 *stage = reinterpret_cast<u8 *>(img);
+            const bool staged = region_bytes >= kTileBytes + 16u; /* (codes of 8 bits or more; shorter: straight from memory) */
+            if (staged) {
+                for (u32 at = lane * 16; at < old.n_sym; at += kWave * 16) {
+                    if (at + 16 <= old.n_sym) {
+                        const unaligned_uint4 q = *reinterpret_cast<const unaligned_uint4 *>(old.tsrc + at);
+                        *reinterpret_cast<uint4 *>(stage + at) = uint4{q.x, q.y, q.z, q.w};
+                    } else { /* the tile's last symbols: one by one (nothing behind the item is read) */
+                        for (u32 j = at; j < old.n_sym; ++j) {
+                            stage[j] = old.tsrc[j];
+                        }
+                    }
+                }
+                wave_step();
+            }
+            const u8 *syms = staged ? stage : old.tsrc;
+            /* lane l counts symbols 64 l .. 64 l + 63 */
+            const u32 from = lane * 64 < old.n_sym ? lane * 64 : old.n_sym, to = from + 64 < old.n_sym ? from + 64 : old.n_sym;
+            u32 sum = 0;
+            if (staged) {
+                /* (a word of four symbols a read: their look-ups do not wait for each other) */
+                for (u32 j = from; j < to; j += 4) {
+                    const u32 four = *reinterpret_cast<const u32 *>(stage + j);
+#pragma unroll
+                    for (u32 b = 0; b < 4; ++b) {
+                        const u32 e4 = *reinterpret_cast<const u32 *>(mine + ((four >> (8 * b)) & 0xFFu) * 128u);
+                        sum += j + b < to ? e4 & 0xFFFFu : 0u;
+                    }
+                }
+            } else {
+                for (u32 j = from; j < to; ++j) {
+                    sum += *reinterpret_cast<const u32 *>(mine + (u32)syms[j] * 128u) & 0xFFFFu;
+                }
+            }
+            const u32 incl = wave_inclusive_sum_dpp(sum, lane);
+            /* the lane whose symbols hold the edge, and the bits in front of them */
+            const u64 holds = __ballot(incl - sum < target && target <= incl);
+            const u32 edge_lane = (u32)__builtin_ctzll(holds | (1ull << 63));
+            const u32 edge_rel = __shfl(incl - sum, edge_lane);
+            /* ... its 64 symbols, one a lane */
+            const u32 j = edge_lane * 64 + lane;
+            const u32 e = j < old.n_sym ? *reinterpret_cast<const u32 *>(mine + (u32)syms[j] * 128u) : 0u;
+            const u32 len = e & 0xFFFFu;
+            const u32 incl2 = wave_inclusive_sum_dpp(len, lane);
+            const u32 rel = edge_rel + incl2 - len;
+            if (len && rel < target && target <= rel + len) {
+                const u32 left = rel + len - target;
+                hufd_enc_result *r = &results[seg.item];
+                r->consumed = (u64)seg.index * HUFD_ENC_SEG_BYTES + old.w4 * kTileBytes + j + 1;
+                r->ovf_bits = left;
+                r->ovf_pattern = left ? ((e >> 16) >> (16u - len)) & ((1u << left) - 1u) : 0u;
+            }
+            wave_step(); /* (the image is the fresh tile's from here) */
+        }
         return true;
     };
 
@@ -2590,16 +2644,12 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
 
 /*
  * After the one pass: one thread per item turns the item's bit total into the outcome of the call
- * (enc_finish_item; every symbol has a code here).  For a call that ran out of room the tile holding
- * the capacity edge has left a note in the item's result record -- the item's symbols in front of
- * the tile (consumed), the stream bit its codes start at (total_bits), its symbols (ovf_bits) -- and
- * a wave of this workgroup reads that tile again to find the symbol whose last bit reaches the edge:
- * `consumed` counts up to and with it, the overflow is what of its code did not fit
- * (source/huffman.c:88-98).
+ * (enc_finish_item; every symbol has a code here).  For a call that ran out of room the wave that packed the
+ * tile holding the capacity edge has left the answer in the item's result record: `consumed` up to and with
+ * the symbol whose last bit reaches the edge, and what of its code did not fit (source/huffman.c:88-98).
  */
-constexpr u32 kFinishItems = 16; /* per workgroup of 256: a wave of it per four items that may each need a tile read again
-                                  * (64 an item: BASELINE configs[3], a quarter of whose items need it, 0.079 -> 0.073 ms) */
-constexpr u32 kFinishLdsBytes = 256 * (8 + 8 + 4 + 4 + 4) + 16;
+constexpr u32 kFinishItems = 256; /* a thread an item */
+constexpr u32 kFinishLdsBytes = 0;
 __global__ __launch_bounds__(256) void enc_finish_kernel(
     hufd_tables tb,
     const hufd_enc_item *items,
@@ -2619,17 +2669,8 @@ __global__ __launch_bounds__(256) void enc_finish_kernel(
     if (!with_segments && !solo) {
         return;
     }
-    u64 *note_first = reinterpret_cast<u64 *>(dyn_lds), *note_bit = note_first + 256; /* kFinishLdsBytes */
-    u32 *code_len = reinterpret_cast<u32 *>(note_bit + 256), *noted = code_len + 256, *note_syms = noted + 256;
-    u32 &n_noted = note_syms[256];
-    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    const u32 i = blockIdx.x * kFinishItems + tid;
-    if (tid == 0) {
-        n_noted = 0;
-    }
-    code_len[tid] = (u32)(tb.enc_table[tid] >> 32);
-    __syncthreads();
-    const u32 road = tid < kFinishItems && i < n_items ? items[i].tiny : 1u; /* (1: enc_tiny's) */
+    const u32 i = blockIdx.x * kFinishItems + threadIdx.x;
+    const u32 road = i < n_items ? items[i].tiny : 1u; /* (1: enc_tiny's) */
     if ((road == 0 && with_segments) || (road == 2 && solo)) {
         const hufd_enc_item it = items[i];
         const u64 total = (it.n_segs || road == 2) ? item_total[i] : it.ovf_bits;
@@ -2638,69 +2679,13 @@ __global__ __launch_bounds__(256) void enc_finish_kernel(
         hufd_enc_result rs;
         /* (no segment is named as the edge's: nothing is listed for enc_pack_kernel) */
         enc_finish_item(it, total, HUFD_NONE32, 0, 0, 0, HUFD_NONE32, careful_list, careful_count, &states[i], &rs);
-        results[i] = rs;
         if (rs.status == HUFD_ENC_SHORT && it.ovf_bits < cap_bits) {
-            const u32 k = atomicAdd(&n_noted, 1u);
-            noted[k] = i;
-            note_first[k] = note.consumed;
-            note_bit[k] = note.total_bits;
-            note_syms[k] = note.ovf_bits;
+            /* (the wave of enc_onepass that packed the tile holding the capacity edge has left these) */
+            rs.consumed = note.consumed;
+            rs.ovf_bits = note.ovf_bits;
+            rs.ovf_pattern = note.ovf_pattern;
         }
-    }
-    __syncthreads();
-    for (u32 k = wave; k < n_noted; k += blockDim.x / kWave) {
-        const hufd_enc_item it = items[noted[k]];
-        const u8 *src = d_in + it.in_off + note_first[k];
-        const u32 n_sym = note_syms[k];
-        const u32 target = (u32)(it.out_cap * 8 - note_bit[k]); /* the edge, in bits from the tile's first code: 1 .. the tile's bits */
-        /* lane l counts symbols 64 l .. 64 l + 63 (four loads, all on their way before the first look-up), the lane that
-         * holds the edge walks them once more */
-        const u32 from = lane * 64 < n_sym ? lane * 64 : n_sym, to = from + 64 < n_sym ? from + 64 : n_sym;
-        u32 wd[16];
-        if (to - from == 64) {
-#pragma unroll
-            for (u32 g = 0; g < 4; ++g) {
-                const unaligned_uint4 q = *reinterpret_cast<const unaligned_uint4 *>(src + from + 16 * g);
-                wd[4 * g] = q.x, wd[4 * g + 1] = q.y, wd[4 * g + 2] = q.z, wd[4 * g + 3] = q.w;
-            }
-        } else {
-            /* the tile's last symbols: one by one (nothing behind the item is read) */
-#pragma unroll
-            for (u32 g = 0; g < 16; ++g) {
-                wd[g] = 0;
-            }
-            for (u32 j = from; j < to; ++j) {
-                const u32 at = j - from;
-                const u32 v = (u32)src[j] << (8 * (at & 3u));
-#pragma unroll
-                for (u32 g = 0; g < 16; ++g) {
-                    wd[g] |= g == (at >> 2) ? v : 0u;
-                }
-            }
-        }
-        const u32 mine_n = to - from;
-        u32 sum = 0;
-#pragma unroll
-        for (u32 b = 0; b < 64; ++b) {
-            sum += b < mine_n ? code_len[(wd[b >> 2] >> (8 * (b & 3u))) & 0xFFu] : 0u;
-        }
-        const u32 incl = wave_inclusive_sum_dpp(sum, lane);
-        u32 rel = incl - sum;
-        if (rel < target && target <= incl) {
-#pragma unroll
-            for (u32 b = 0; b < 64; ++b) {
-                const u32 sym = (wd[b >> 2] >> (8 * (b & 3u))) & 0xFFu;
-                const u32 len = b < mine_n ? code_len[sym] : 0u;
-                if (rel < target && target <= rel + len) {
-                    const u32 left = rel + len - target;
-                    hufd_enc_result *r = &results[noted[k]];
-                    r->consumed = note_first[k] + from + b + 1;
-                    r->ovf_bits = left;
-                    r->ovf_pattern = left ? ((u32)tb.enc_table[sym] & ((1u << left) - 1u)) : 0u;
-                }
-                rel += len;
-            }
-        }
+        results[i] = rs;
     }
 }
 
