@@ -1509,17 +1509,21 @@ def plans_made_on_the_device(w, seed=131, engine=None, big=2_200_000, n_small=30
 
     # ---- decode what was written (whole streams, cut ones, a damaged one, a first-bit offset, short outputs):
     # host records, the same in device memory, and -- for the whole ones -- chained to the encode plan
-    ditems = []
+    # (every output a window of its own: a stream with carried bits in front, or padded with other bits than ones, may hold
+    #  more symbols than went in -- back where the symbols came from, with room for five more, two items wrote the same
+    #  byte, and which of them did last is nobody's to say: found by the round-5 soak, 3 runs in 270)
+    ditems, dpos = [], 3
     for i, (it, r) in enumerate(zip(items, res_host)):
         produced = r[3]
         in_len = produced if i % 7 else produced // 2  # (every seventh cut in half)
         cap = [it["in_len"], it["in_len"] + 5, it["in_len"] // 2][i % 3] if it["in_len"] < 50_000 else it["in_len"]
-        ditems.append(dict(in_offset=it["out_offset"], in_len=in_len, first_bit=0, out_offset=it["in_offset"], out_capacity=cap))
+        ditems.append(dict(in_offset=it["out_offset"], in_len=in_len, first_bit=0, out_offset=dpos, out_capacity=cap))
+        dpos += cap + int(rng.integers(1, 9))
     damaged = int(np.argmax(lens))
     damage_at = items[damaged]["out_offset"] + min(1_000_000, res_host[damaged][3] // 2)  # (inside the longest item's output)
     bad = eng.download(d_a, 8, offset=damage_at)
     eng.upload(d_a, np.full(4, 0xFF, np.uint8), offset=damage_at)
-    sym_total = host_in.size
+    sym_total = max(host_in.size, dpos + 64)
     d_sa, d_sb = eng.alloc(sym_total), eng.alloc(sym_total)
     host_dplan = eng.decode_plan(ditems)
     dev_dplan, d_ditems = eng.decode_plan_from_device_items(ditems)
@@ -1532,7 +1536,22 @@ def plans_made_on_the_device(w, seed=131, engine=None, big=2_200_000, n_small=30
     dres_host, dres_dev = eng.decode_results(host_dplan, len(ditems)), eng.decode_results(dev_dplan, len(ditems))
     assert dres_host == dres_dev, [(i, a, b) for i, (a, b) in enumerate(zip(dres_host, dres_dev)) if a != b][:3]
     assert len({r[:2] for r in dres_host}) >= 3  # (whole, short of room, a symbol without a code)
-    assert np.array_equal(eng.download(d_sa, sym_total), eng.download(d_sb, sym_total)), "decode: the device-made plan wrote other bytes"
+    out_a, out_b = eng.download(d_sa, sym_total), eng.download(d_sb, sym_total)
+    if not np.array_equal(out_a, out_b):  # (say which item, and which of the two plans the oracle agrees with)
+        at = int(np.flatnonzero(out_a != out_b)[0])
+        who = [i for i, d in enumerate(ditems) if d["out_offset"] <= at < d["out_offset"] + max(d["out_capacity"], 1)]
+        detail = {"first_difference_at": at, "bytes_that_differ": int((out_a != out_b).sum()), "items": who}
+        enc_now = eng.download(d_a, out_total)
+        for i in who[:1]:
+            d = ditems[i]
+            dec = w.oracle.new_decoder(w.ocoder)
+            dst = np.full(d["out_capacity"] + 1, SENTINEL, np.uint8)
+            r = w.oracle.decode_call(dec, enc_now[d["in_offset"]:d["in_offset"] + d["in_len"]].copy(), 0, d["in_len"], dst, 0, d["out_capacity"])
+            lo, hi = d["out_offset"], d["out_offset"] + d["out_capacity"]
+            detail.update(item=d, oracle=(r.rc, r.err, r.produced), record=dres_host[i], offset_in_item=at - lo,
+                          host_plan_is_the_oracles=bool(np.array_equal(out_a[lo:hi], dst[:d["out_capacity"]])),
+                          device_plan_is_the_oracles=bool(np.array_equal(out_b[lo:hi], dst[:d["out_capacity"]])))
+        raise AssertionError("decode: the device-made plan wrote other bytes: %r" % (detail,))
     eng.upload(d_a, bad[:4], offset=damage_at)
     # chained: what the encode launch of dev_plan left in d_b, decoded back to where it came from
     chained = eng.empty_decode_plan()
