@@ -1451,7 +1451,8 @@ def streams_with_two_last_chunks(w, seed=127, engine=None, modes=(None, "lean-sy
         eng.close()
 
 
-def plans_made_on_the_device(w, seed=131, engine=None, big=2_200_000, n_small=300):
+def plans_made_on_the_device(w, seed=131, engine=None, big=2_200_000, n_small=300,
+                             strided_batches=((70, 16384, 2 * 16384), (70, 16384, 16384), (5000, 700, 1400), (5000, 100, 90), (3, 2_000_000, 4_000_000))):
     """A plan made on the device -- from the caller's records lying in DEVICE memory, from a stride, or (decode) from what
     an encode launch left -- is the plan the host's loop makes: the same counts (aws_huffman_amd_*_plan_stats), and for
     the same buffers the same records, output bytes and guard bytes.  Items of every class in one plan: empty, one
@@ -1582,7 +1583,7 @@ def plans_made_on_the_device(w, seed=131, engine=None, big=2_200_000, n_small=30
         eng.free(ptr)
 
     # ---- batches of equal buffers by stride: 16 KiB and 700 B, with room and with too little
-    for count, size, cap in ((70, 16384, 2 * 16384), (70, 16384, 16384), (5000, 700, 1400), (5000, 100, 90), (3, 2_000_000, 4_000_000)):
+    for count, size, cap in strided_batches:
         data = inputs(rng, count * size, "uniform")
         d_in, d_enc1, d_enc2, d_back = eng.alloc(data.size + 64), eng.alloc(count * cap + 64), eng.alloc(count * cap + 64), eng.alloc(data.size + 64)
         eng.upload(d_in, data)
