@@ -51,7 +51,7 @@
 #define HUFD_DEEP_MAX_ENTRIES 16384u
 #define HUFD_DEEP_LINK 0x80000000u /* entry is a link: [15:0] first entry of the next table, [23:16] its index width */
 #define HUFD_DEC_TINY_BYTES 512u /* decode items up to this long are one thread's work (dec_tiny): no chunks */
-#define HUFD_DEC_PACK_MIN_CHUNKS 64u /* fewer such chunks in a launch: a workgroup each (dec_sync_lean<TAIL>) */
+#define HUFD_DEC_PACK_MIN_CHUNKS 64u /* fewer such chunks in a launch: a workgroup each (dec_sync_one<TAIL>) */
 #define HUFD_DEC_PACK_LANES 83u /* end-of-stream chunks with at most this many whole lanes share workgroups (dec_sync_pack: three slots of 85 lanes or more of fewer; two chunks a workgroup measured no faster than one) */
 #define HUFD_DEC_COOP_BYTES 768u /* ... and up to this long one wave's (dec_deep<false>): no chunks either */
 #define HUFD_DEC_BLOCK_BYTES 8192u /* what dec_block's workgroup takes in one turn: a lane per 64 bits */

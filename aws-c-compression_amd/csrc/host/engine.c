@@ -1,7 +1,7 @@
 /*
  * Host layer (C99) of libaws-c-compression-amd: engines, plans and the
  * translation between the reference's call semantics and the device records.
- * All symbol work happens in the HIP kernels (csrc/hip/huffman_kernels.hip);
+ * All symbol work happens in the HIP kernels (csrc/hip/*_kernels.hip);
  * this file tabulates coders, lays out items, launches, and reads results back.
  * There is no CPU implementation of encode or decode here.
  */

@@ -227,8 +227,9 @@ def test_first_bit_offsets(world, engine):
 
 
 def test_decode_roads(world, engine):
-    """dec_onepass for the chunks inside streams; the two-pass kernels when told so and when it gives up (forced,
-    damaged stream, short output): same records, same bytes, nothing written that should not be."""
+    """One stream's chunks by the default road and by the tests' roads (the long way for chunks whose walks never become
+    one, a workgroup per end-of-stream chunk), whole, damaged and short of room: same records, same bytes, nothing written
+    that should not be."""
     pc.decode_roads(world, engine=engine)
     pc.decode_roads(world, engine=engine, sizes=(5_000_000, 33_000, 12_000_000, 70_000), seed=54)
 
