@@ -1,7 +1,7 @@
 /*
  * Host layer (C99) of libaws-c-compression-amd: engines, plans and the
  * translation between the reference's call semantics and the device records.
- * All symbol work happens in the HIP kernels (csrc/hip/*_kernels.hip);
+ * All symbol work happens in the HIP kernels (the *_kernels.hip files of csrc/hip);
  * this file tabulates coders, lays out items, launches, and reads results back.
  * There is no CPU implementation of encode or decode here.
  */
@@ -34,8 +34,14 @@ static uint32_t testing_decode_road(void) {
 
 /* ------------------------------------------------------------------ small helpers */
 
-/* behind a plan's launch, on the launch's stream: the event a later owner of the plan's device arrays waits for */
-static int plan_mark_done(void **event, void *stream) {
+/* behind a plan's launch: what a later owner of the plan's device arrays waits for.  On a caller's stream an event (the
+ * stream may be gone by then); on the engine's own stream nothing -- that stream lives as long as the engine and is
+ * waited for itself (an event record is a packet of its own on the queue: ~4 us behind every launch) */
+static int plan_mark_done(void **event, bool *on_engine_stream, const struct aws_huffman_amd_engine *eng, void *stream) {
+    if (!stream || stream == eng->stream) {
+        *on_engine_stream = true;
+        return 0;
+    }
     if (!*event) {
         *event = hufs_event_create_untimed();
         if (!*event) {
@@ -43,6 +49,14 @@ static int plan_mark_done(void **event, void *stream) {
         }
     }
     return hufs_event_record(*event, stream);
+}
+
+static int plan_wait_done(void *event, bool on_engine_stream, const struct aws_huffman_amd_engine *eng) {
+    int err = on_engine_stream ? hufs_stream_sync(eng->stream) : 0;
+    if (!err && event) {
+        err = hufs_event_sync(event);
+    }
+    return err;
 }
 
 /*
@@ -815,11 +829,12 @@ int aws_huffman_amd_encode_plan_new(
         /* its last launch may still run on the caller's stream (freeing the arrays used to wait for it): waited for by the
          * event that launch left behind -- not for every stream of the device, on which other threads' batches may run */
         ON_DEVICE(eng->device);
-        if (p->done_event && hufs_event_sync(p->done_event)) {
+        if (plan_wait_done(p->done_event, p->done_on_engine_stream, eng)) {
             p->unkeepable = true; /* (freed, not parked again for the next caller to fail on) */
             aws_huffman_amd_encode_plan_destroy(p);
             return aws_raise_error(AWS_ERROR_UNKNOWN);
         }
+        p->done_on_engine_stream = false;
         p->last_input = NULL;
         p->last_output = NULL;
         p->launched = false;
@@ -1026,7 +1041,7 @@ int aws_huffman_amd_encode_plan_launch_staged(
     ON_DEVICE(p->engine->device);
     int err = hufk_encode_launch(&a, stream ? stream : p->engine->stream);
     if (!err) {
-        err = plan_mark_done(&p->done_event, stream ? stream : p->engine->stream);
+        err = plan_mark_done(&p->done_event, &p->done_on_engine_stream, p->engine, stream);
     }
     return err ? raise_hip(err) : AWS_OP_SUCCESS;
 }
@@ -1583,11 +1598,12 @@ int aws_huffman_amd_decode_plan_new(
     if (p) {
         /* (as for an encode plan: the spare's last launch is waited for by its own event) */
         ON_DEVICE(eng->device);
-        if (p->done_event && hufs_event_sync(p->done_event)) {
+        if (plan_wait_done(p->done_event, p->done_on_engine_stream, eng)) {
             p->unkeepable = true;
             aws_huffman_amd_decode_plan_destroy(p);
             return aws_raise_error(AWS_ERROR_UNKNOWN);
         }
+        p->done_on_engine_stream = false;
     } else {
         p = calloc(1, sizeof(*p));
         if (!p) {
@@ -1861,7 +1877,7 @@ int aws_huffman_amd_decode_plan_launch_staged(
     ON_DEVICE(p->engine->device);
     int err = hufk_decode_launch(&a, stream ? stream : p->engine->stream);
     if (!err) {
-        err = plan_mark_done(&p->done_event, stream ? stream : p->engine->stream);
+        err = plan_mark_done(&p->done_event, &p->done_on_engine_stream, p->engine, stream);
     }
     return err ? raise_hip(err) : AWS_OP_SUCCESS;
 }

@@ -86,7 +86,8 @@ struct aws_huffman_amd_encode_plan {
     /* single-pass bookkeeping: what the last launch was given, and whether look-back ever timed out */
     const void *last_input;
     void *last_output;
-    void *done_event; /* recorded behind every launch on the launch's stream: what a new plan on this one's arrays waits for */
+    void *done_event; /* recorded behind every launch on a caller's stream: what a new plan on this one's arrays waits for */
+    bool done_on_engine_stream; /* ... a launch on the engine's own stream: that stream is waited for */
     bool unkeepable;  /* not to be kept as the engine's spare (waiting for its last launch failed) */
     void *d_plan_scratch; /* of a plan made on the device (hufk_plan_scratch_bytes) */
     size_t cap_plan_scratch;
@@ -132,7 +133,8 @@ struct aws_huffman_amd_decode_plan {
     struct aws_huffman_amd_plan_stats stats; /* how the items are taken (aws_huffman_amd_decode_plan_stats) */
     void *d_plan_scratch; /* of a plan made on the device (hufk_plan_scratch_bytes) */
     size_t cap_plan_scratch;
-    void *done_event; /* recorded behind every launch on the launch's stream: what a new plan on this one's arrays waits for */
+    void *done_event; /* recorded behind every launch on a caller's stream: what a new plan on this one's arrays waits for */
+    bool done_on_engine_stream; /* ... a launch on the engine's own stream: that stream is waited for */
     bool unkeepable;  /* not to be kept as the engine's spare (waiting for its last launch failed) */
     bool chained; /* made on the device (from an encode plan's records, a stride, or items in device memory): the items are known there only (h_items is not filled) */
     struct hufd_dec_item_state *d_states;
