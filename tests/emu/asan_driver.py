@@ -1,8 +1,8 @@
 """TEST INFRASTRUCTURE.  Parity scenarios against the emulator build of the library made with AddressSanitizer on top
 of UBSan (tests/test_emulated_asan.py builds it and runs this with libasan preloaded): the roads that index by what a
 stream says -- one-launch calls, long-code items across blocks (settled and by transfer functions), fixed-length coders,
-the ways back, the chunks whose walks never become one, the packed end-of-stream chunks, plans chained on or made by the
-device, the encoder's wave-per-item road --
+the ways back, the chunks whose walks never become one, the packed end-of-stream chunks, plans chained on the device, the
+encoder's wave-per-item road --
 with every access of the kernels' code checked."""
 import os
 import sys
@@ -23,11 +23,10 @@ for run in (lambda: pc.block_decode_calls(w, wants=(130, 513, 8192, 8193, 16385,
             lambda: pc.mid_sized_items(w, n_items=40, modes=(None,)), lambda: pc.encode_then_decode_on_the_device(w, batches=((40, 50),)),
             # round 5: dec_sync_one's rare lanes (walks that never meet: the lane behind walks again from memory), encode items a
             # wave takes without segments (one tile; up to a segment in a plan of 256 items: the capacity edge found by the packing
-            # wave, staged through the image's LDS), plans made by kernels
+            # wave, staged through the image's LDS)
             lambda: pc.walks_that_never_meet(w, runs=(130, 420)),
             lambda: pc.tiny_encode_items(w, n_items=270, seed=161, max_len=20000, edge_lens=False, more_lens=(4095, 4096, 4097, 16383, 16384, 16385)),
-            lambda: pc.tiny_encode_items(w, n_items=90, seed=162, max_len=9000, edge_lens=False, more_lens=(4095, 4096, 4097)),
-            lambda: pc.plans_made_on_the_device(w, big=300_000, n_small=120, strided_batches=((9, 16384, 2 * 16384), (4200, 100, 90), (2, 70_000, 140_000)))):
+            lambda: pc.tiny_encode_items(w, n_items=90, seed=162, max_len=9000, edge_lens=False, more_lens=(4095, 4096, 4097))):
     t0 = time.time()
     run()
     print("%.0f s" % (time.time() - t0), flush=True)
