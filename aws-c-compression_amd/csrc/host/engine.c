@@ -699,7 +699,7 @@ static int enc_plan_fill(
         n_solo += enc_item_is_solo(&items[i], tiny_limit, solo_limit);
         n_cut += segs != 0;
     }
-    if (n_segs >= 0xFFFFFFFFull || n_items >= 0xFFFFFFFFull) {
+    if (n_segs >= 0xFFFFFFFFull || n_items >= 0xFFFFFFFFull || n_solo >= (1ull << 30)) { /* (tile numbers are 32 bits: four tiles a wave's item) */
         return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
     }
 
@@ -899,7 +899,7 @@ static int enc_plan_fill_on_device(struct aws_huffman_amd_encode_plan *p, const 
     if (e) {
         return raise_hip(e);
     }
-    if (t.invalid || t.totals[0] >= 0xFFFFFFFFull) {
+    if (t.invalid || t.totals[0] >= 0xFFFFFFFFull || t.totals[2] >= (1ull << 30)) {
         return aws_raise_error(AWS_ERROR_INVALID_ARGUMENT);
     }
     e = enc_plan_reserve(p, n_items, (size_t)t.totals[0], (size_t)t.totals[3], (size_t)t.totals[1]);
