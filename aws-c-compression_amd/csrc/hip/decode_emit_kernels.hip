@@ -382,11 +382,14 @@ __device__ __forceinline__ void dec_emit_fast_chunk(
     const u32 lanes[kEmitChains] = {TAIL ? 2 * (t / kQuarters) : t % kEmitHalf,
                                     TAIL ? 2 * (t / kQuarters) + 1 : t % kEmitHalf + kEmitHalf};
     /* the table entries this thread will put into LDS: asked for first, they depend on nothing */
-    constexpr u32 kLutPerThread = ((1u << LB) + kEmitFastThreads - 1) / kEmitFastThreads;
+    /* (TAIL with a 10-bit table: the workgroup may be launched with fewer threads than 512 -- 256 at least --, see the launch) */
+    constexpr bool kNarrowBlock = TAIL && LB == 10;
+    constexpr u32 kLutPerThread = kNarrowBlock ? (1u << LB) / HUFD_DEC_LANES : ((1u << LB) + kEmitFastThreads - 1) / kEmitFastThreads;
+    const u32 lut_stride = kNarrowBlock ? blockDim.x : kEmitFastThreads;
     u32 lut_raw[kLutPerThread];
 #pragma unroll
     for (u32 j = 0; j < kLutPerThread; ++j) {
-        const u32 i = t + j * kEmitFastThreads;
+        const u32 i = t + j * lut_stride;
         lut_raw[j] = i < (1u << LB) ? tb.dec_lut[i >> (LB - tb.lut_bits)] : 0u;
     }
     const u32 centry = chunk_entry[c];
@@ -460,7 +463,7 @@ __device__ __forceinline__ void dec_emit_fast_chunk(
     }
 #pragma unroll
     for (u32 j = 0; j < kLutPerThread; ++j) {
-        const u32 i = t + j * kEmitFastThreads;
+        const u32 i = t + j * lut_stride;
         const u32 e = lut_raw[j];
         const u32 len = e & 0xFFu;
         if (i < (1u << LB)) {
@@ -1103,13 +1106,18 @@ void hufk_host::decode_emit_stage(const struct hufk_decode_args *a, hipStream_t 
     u32 *const emit_count = a->counters + HUFK_DEC_COUNT_EMIT, *const dense_count = a->counters + HUFK_DEC_COUNT_DENSE;
 #define HUFK_LAUNCH_EMIT_FAST(LBV, TAILV, SUREV, GRID, STREAMV)                                                          \
 hipLaunchKernelGGL(                                                                                                \
-    (dec_emit_fast_kernel<LBV, TAILV, SUREV>), dim3(GRID), dim3(kEmitFastThreads),                                  \
+    (dec_emit_fast_kernel<LBV, TAILV, SUREV>), dim3(GRID), dim3((TAILV) && (LBV) == 10 ? tail_block : kEmitFastThreads), \
     emit_lds_bytes<LBV>(TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES), STREAMV, a->tables, a->chunk_rec,              \
     emit_single_chunks, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab, (const u16 *)a->lane_count,   \
     (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry,                           \
     (const u64 *)a->chunk_base, a->results, a->emit_list, emit_count,                                            \
     !TAILV ? a->dense_list : a->emit_list, !TAILV ? dense_count : emit_count,                                \
     TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES)
+    /* dec_emit_fast<TAIL>'s workgroup: four quarters to two sub-chunks a thread over the most whole lanes a wide chunk of the
+     * launch has (+ the wave that rounds it up), never fewer than the 256 threads of its scan: BASELINE configs[3]'s chunks
+     * have 152 whole lanes -- 320 threads, six workgroups a CU's wave slots hold instead of four (0.83 -> 0.78 ms) */
+    const uint32_t tail_live = a->tail_wide_lanes ? (kQuarters * ((a->tail_wide_lanes + 1) / 2) + kWave - 1) / kWave * kWave : kEmitFastThreads;
+    const uint32_t tail_block = tail_live < HUFD_DEC_LANES ? HUFD_DEC_LANES : (tail_live < kEmitFastThreads ? tail_live : kEmitFastThreads);
     const bool some_inside = a->n_tail < a->n_chunks;
     /* (the few chunks streams end in beside the many inside streams: see the sync kernels above.  And in any case
      * dec_emit_tail beside dec_emit_fast<TAIL>: it works out for itself which chunks that kernel takes, reads

@@ -111,6 +111,7 @@ struct hufk_decode_args {
     struct hufd_dec_result *results;    /* [n_items] */
     uint32_t tail_stage_bytes; /* the most symbols a chunk that holds the end of a stream can decode to, +32 (0: unknown) */
     uint32_t tail_lanes;       /* the most whole lanes (sub-chunks with 8 more bytes behind them) a NARROW such chunk has */
+    uint32_t tail_wide_lanes;  /* ... and a wide one (0: not known -- as many as a chunk has) */
     uint32_t n_tail_narrow;    /* the first so many of tail_chunks have at most HUFD_DEC_PACK_LANES whole lanes: they may share workgroups */
     uint32_t one_chunk_a_workgroup; /* 1: the chunks streams end in get a workgroup each, however short and many (tests: the road a plan of
                                      * few such chunks takes, for a plan of many) */
@@ -145,7 +146,7 @@ struct hufk_plan_totals {
     uint64_t totals[8]; /* decode: chunks, thread items, wave items, large items, runs, narrow / wide end-of-stream chunks, items
                          * with chunks; encode: segments, thread items, one-tile items, large items, -, -, -, items with segments */
     uint64_t tiny_limit;
-    uint64_t shortest, longest, largest_out_cap, tail_stage, tail_lanes;
+    uint64_t shortest, longest, largest_out_cap, tail_stage, tail_lanes, wide_lanes;
     uint32_t worst_bits, invalid;
 };
 uint64_t hufk_plan_scratch_bytes(uint64_t n_items);

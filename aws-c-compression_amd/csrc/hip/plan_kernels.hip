@@ -22,7 +22,8 @@ struct plan_stats {
     u64 count[2], longest_in_class[2]; /* items of at most classes[c] bytes, and the longest of them */
     u64 not_shortest, longest, largest_out_cap, worst_bits, invalid; /* not_shortest: the largest ~in_len (all zero = no item yet) */
     u64 tail_stage, tail_lanes; /* decode: of the chunks streams end in */
-    u64 pad[5];
+    u64 wide_lanes;             /* ... the most whole lanes of those that are not narrow */
+    u64 pad[4];
 };
 struct plan_decision {
     u64 tiny_limit;
@@ -151,7 +152,7 @@ struct dec_counts {
     u32 v[kPlanVec];
     u32 tail_chunk[2]; /* the item's chunks (numbered inside it) streams end in: up to two */
     u32 tail_narrow[2];
-    u64 tail_stage, tail_lanes;
+    u64 tail_stage, tail_lanes, wide_lanes;
 };
 
 __device__ __forceinline__ u64 whole_lanes_of(u64 left) {
@@ -167,7 +168,7 @@ __device__ __forceinline__ dec_counts count_dec_item(const raw_item &r, u64 tiny
     }
     c.tail_chunk[0] = c.tail_chunk[1] = ~0u;
     c.tail_narrow[0] = c.tail_narrow[1] = 0;
-    c.tail_stage = c.tail_lanes = 0;
+    c.tail_stage = c.tail_lanes = c.wide_lanes = 0;
     const bool tiny = r.in_len > 0 && r.in_len <= tiny_limit;
     const bool coop = !tiny && r.in_len > tiny_limit && r.in_len <= HUFD_DEC_COOP_BYTES;
     c.v[1] = tiny;
@@ -209,6 +210,8 @@ __device__ __forceinline__ dec_counts count_dec_item(const raw_item &r, u64 tiny
             c.tail_stage = holds > c.tail_stage ? holds : c.tail_stage;
             if (narrow) {
                 c.tail_lanes = whole > c.tail_lanes ? whole : c.tail_lanes;
+            } else {
+                c.wide_lanes = whole > c.wide_lanes ? whole : c.wide_lanes;
             }
         }
     }
@@ -242,11 +245,11 @@ template <bool ENC>
 __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(
     hufd_item_source src, u32 n_items, const plan_decision *decision, u32 shortest_code, u64 solo_limit, plan_stats *stats, u32 *block_sums) {
     u32 *sums = reinterpret_cast<u32 *>(dyn_lds); /* [kPlanVec] */
-    u64 *maxes = reinterpret_cast<u64 *>(dyn_lds + 64); /* tail_stage, tail_lanes */
+    u64 *maxes = reinterpret_cast<u64 *>(dyn_lds + 64); /* tail_stage, tail_lanes, wide_lanes */
     if (threadIdx.x < kPlanVec) {
         sums[threadIdx.x] = 0;
     }
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < 3) {
         maxes[threadIdx.x] = 0;
     }
     __syncthreads();
@@ -272,6 +275,9 @@ __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(
             if (c.tail_lanes) {
                 atomicMax(&maxes[1], c.tail_lanes);
             }
+            if (c.wide_lanes) {
+                atomicMax(&maxes[2], c.wide_lanes);
+            }
         }
     }
 #pragma unroll
@@ -291,6 +297,9 @@ __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(
         }
         if (maxes[1]) {
             atomicMax(&stats->tail_lanes, maxes[1]);
+        }
+        if (maxes[2]) {
+            atomicMax(&stats->wide_lanes, maxes[2]);
         }
     }
 }
@@ -514,6 +523,7 @@ int plan_count(
     out->invalid = (uint32_t)host.s.invalid;
     out->tail_stage = host.s.tail_stage;
     out->tail_lanes = host.s.tail_lanes;
+    out->wide_lanes = host.s.wide_lanes;
     return (int)hipGetLastError();
 }
 

@@ -1335,6 +1335,8 @@ static int dec_plan_fill(
         p->wide_from = wide_min_bytes(0);
         p->tail_stage_bytes = 0;
         p->tail_lanes = 0;
+    p->tail_wide_lanes = 0;
+        p->tail_wide_lanes = 0;
         p->n_tail_narrow = 0;
         p->n_items = (uint32_t)n_items;
         p->n_tiny = (uint32_t)n_items;
@@ -1385,6 +1387,7 @@ static int dec_plan_fill(
     bool wide_oom = false;
     uint64_t tail_stage = 0; /* the most symbols a chunk that holds the end of a stream can decode to */
     uint64_t tail_lanes = 0; /* ... and the most whole lanes it has */
+    uint64_t wide_lanes = 0; /* ... and a wide one has (dec_emit_fast<TAIL>'s workgroup size) */
     for (size_t i = 0; i < n_items; ++i) {
         const struct aws_huffman_amd_decode_item *src = &items[i];
         struct hufd_dec_item *dst = &h_items[i];
@@ -1452,6 +1455,8 @@ static int dec_plan_fill(
                 const uint64_t whole = whole_lanes_of(left);
                 if (whole <= HUFD_DEC_PACK_LANES) {
                     tail_lanes = whole > tail_lanes ? whole : tail_lanes;
+                } else {
+                    wide_lanes = whole > wide_lanes ? whole : wide_lanes;
                 }
             }
         }
@@ -1564,6 +1569,7 @@ static int dec_plan_fill(
     p->n_tail = tail;
     p->tail_stage_bytes = tail_stage + 32 < 0xFFFFFFFFu ? (uint32_t)tail_stage + 32u : 0u;
     p->tail_lanes = tail_lanes < HUFD_DEC_LANES ? (uint32_t)tail_lanes : HUFD_DEC_LANES;
+    p->tail_wide_lanes = wide_lanes < HUFD_DEC_LANES ? (uint32_t)wide_lanes : HUFD_DEC_LANES;
     p->n_tail_narrow = narrow;
     p->n_tiny = tiny;
     p->n_deep = deep;
@@ -1697,6 +1703,7 @@ static int dec_plan_fill_on_device(struct aws_huffman_amd_decode_plan *p, const 
     p->wide_from = wide_min_bytes(0);
     p->tail_stage_bytes = 0;
     p->tail_lanes = 0;
+    p->tail_wide_lanes = 0;
     p->n_tail_narrow = 0;
     if (n_items == 0) {
         return AWS_OP_SUCCESS;
@@ -1739,6 +1746,7 @@ static int dec_plan_fill_on_device(struct aws_huffman_amd_decode_plan *p, const 
     p->n_deep = (uint32_t)coop;
     p->tail_stage_bytes = t.tail_stage + 32 < 0xFFFFFFFFu ? (uint32_t)t.tail_stage + 32u : 0u;
     p->tail_lanes = t.tail_lanes < HUFD_DEC_LANES ? (uint32_t)t.tail_lanes : HUFD_DEC_LANES;
+    p->tail_wide_lanes = t.wide_lanes < HUFD_DEC_LANES ? (uint32_t)t.wide_lanes : HUFD_DEC_LANES;
     p->chained = true; /* (the items are known on the device only: the results are translated from its records) */
     {
         const bool packs = narrow >= HUFD_DEC_PACK_MIN_CHUNKS && p->tail_lanes + 2u <= HUFD_DEC_LANES / 2;
@@ -1828,6 +1836,7 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.n_tail = p->n_tail;
     a.tail_stage_bytes = p->tail_stage_bytes;
     a.tail_lanes = p->tail_lanes;
+    a.tail_wide_lanes = p->tail_wide_lanes;
     a.n_tail_narrow = p->n_tail_narrow;
     a.deep_items = p->d_tiny + (p->n_items - p->n_deep);
     a.n_deep = p->n_deep;
@@ -2021,6 +2030,7 @@ int aws_huffman_amd_decode_plan_from_encode(
     p->wide_from = wide_min_bytes(0);
     p->tail_stage_bytes = 0;
     p->tail_lanes = 0;
+    p->tail_wide_lanes = 0;
     p->n_tail_narrow = 0;
     p->n_items = (uint32_t)n_items;
     p->n_tiny = (uint32_t)n_items;

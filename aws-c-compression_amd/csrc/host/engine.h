@@ -106,6 +106,7 @@ struct aws_huffman_amd_decode_plan {
     uint32_t n_items, n_chunks, n_large, n_runs, n_tail, n_tiny, n_deep;
     uint32_t tail_stage_bytes; /* symbols (+32) a chunk that holds the end of a stream can decode to: sizes dec_emit_fast<TAIL>'s LDS stage */
     uint32_t tail_lanes; /* the most whole lanes a chunk that holds the end of a stream has (dec_sync_pack's slot width) */
+    uint32_t tail_wide_lanes; /* ... and one that is not narrow (dec_emit_fast<TAIL>'s workgroup size) */
     uint32_t n_tail_narrow; /* the first so many of d_tail have at most HUFD_DEC_PACK_LANES whole lanes */
     size_t cap_items, cap_chunks, cap_large, cap_runs;
     struct aws_huffman_amd_decode_item *h_items; /* host copy for result translation */
