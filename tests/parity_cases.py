@@ -527,6 +527,24 @@ def other_coders(w, n=60000, seed=23):
                     paired_decode(w, ddo, ddp, want, 0, cut, oo, op, 0, n)
 
 
+def long_streams_of_other_coders(w, names=("len4to12", "len2to12"), n=22_000_000, seed=29):
+    """One long stream of a coder whose decode table has 12 bits (the 12-bit builds of dec_sync_one / dec_emit_fast, twelve
+    entry states in dec_scan's tables), long enough for several scan runs: whole, damaged in its middle, cut, short of
+    room -- every record and byte as the oracle has them."""
+    rng = np.random.default_rng(seed)
+    for name in names:
+        oc, pcoder, lengths = profile_coders(w, name)
+        prob = np.array([2.0 ** -l for l in lengths])
+        data = rng.choice(256, size=n, p=prob / prob.sum()).astype(np.uint8)
+        enc = w.oracle.encode_all(oc, data, slack=64 + n)
+        damaged = enc.copy()
+        damaged[enc.size // 2 + 777:enc.size // 2 + 781] ^= 0xA5
+        eng = harness.Engine(w.product.lib, pcoder)
+        streams = [(enc, 0, n), (damaged, 0, n), (enc[: enc.size // 3 + 5], 0, n), (enc, 0, n // 2 + 3)]
+        decode_items_like_the_oracle(w, eng, oc, streams, rng, "long stream of %s" % name, kinds=2)
+        eng.close()
+
+
 # ----------------------------------------------------------------------------- scenario: items sharded over several engines (one per GPU)
 def sharded_items(w, devices=(0, 0, 0), n_items=23, seed=71, item_len=16384):
     """huffman_amd.h "several GPUs": item i runs on shard i mod G (the split of BASELINE configs[3]),

@@ -158,6 +158,10 @@ def test_mid_sized_encode_items(world):
         pc.tiny_encode_items(world, n_items=120, seed=155, max_len=9000, edge_lens=False, wave_limit=0, more_lens=edges)
 
 
+def test_long_streams_of_other_coders(world):
+    pc.long_streams_of_other_coders(world, names=("len4to12",), n=2_600_000)  # (runs of 32 chunks in this build: three of them)
+
+
 def test_walks_that_never_meet(world):
     pc.walks_that_never_meet(world, runs=(130, 420))
 

@@ -195,6 +195,10 @@ def test_mid_sized_encode_items(world, engine):
         pc.tiny_encode_items(world, n_items=1200, seed=155, max_len=9000, edge_lens=False, wave_limit=0, more_lens=edges)
 
 
+def test_long_streams_of_other_coders(world):
+    pc.long_streams_of_other_coders(world)
+
+
 def test_walks_that_never_meet(world, engine):
     pc.walks_that_never_meet(world, engine=engine)
     pc.walks_that_never_meet(world, engine=engine, seed=138, runs=(200, 333, 1500), modes=(None, "long-way"))
