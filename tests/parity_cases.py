@@ -1185,16 +1185,23 @@ def batched_device_api(w, n_items=9, seed=18, item_len=16384, engine=None):
 
 
 def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False, max_len=560, edge_lens=True, thread_limit=None,
-                      wave_limit=None, more_lens=()):
+                      wave_limit=None, more_lens=(), profile=None):
     """Items either side of HUFD_ENC_TINY_BYTES (512 symbols; one thread each below it), with every kind
     of stop: roomy, exact, one byte short, cut anywhere, no room at all, carried overflow bits that fit,
     fill the output exactly or do not fit, symbols without a code.  thread_limit: the longest item the plan must give a
     thread of its own (aws_huffman_amd_encode_plan_stats) -- the road is asserted, not assumed; wave_limit: the longest
-    one that is a wave's work without segments (HUFD_ENC_SOLO_BYTES where the coder encodes in one pass, else 0)."""
+    one that is a wave's work without segments (HUFD_ENC_SOLO_BYTES where the coder encodes in one pass, else 0);
+    profile: one of CODER_PROFILES instead of the test coder (len4to15: the packing kernel's build for codes of 13-15 bits)."""
     rng = np.random.default_rng(seed)
-    own = engine is None or holes
-    eng = harness.Engine(w.product.lib, w.pcoder_holes if holes else w.pcoder) if own else engine
-    oc = w.ocoder_holes if holes else w.ocoder
+    own = engine is None or holes or profile is not None
+    code_lens = [int(w.table[1][b]) for b in range(256)]
+    if profile is not None:
+        oc, profile_pcoder, code_lens = profile_coders(w, profile)
+        eng = harness.Engine(w.product.lib, profile_pcoder)
+    else:
+        eng = harness.Engine(w.product.lib, w.pcoder_holes if holes else w.pcoder) if own else engine
+        oc = w.ocoder_holes if holes else w.ocoder
+    longest_code = max(code_lens)
     lens = ([0, 0, 1, 2, 3, 511, 512, 513, 600] if edge_lens else [0, 0, 1, 2, 3, 127, 128, 129, max_len - 1]) + list(more_lens)
     lens += [int(rng.integers(0, max_len)) for _ in range(n_items - len(lens))]
     blobs = []
@@ -1220,7 +1227,7 @@ def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False, max_le
         if i % 4 == 1:
             nb = int(rng.integers(1, 33))
             ov = (int(rng.integers(0, 1 << nb)), nb)
-        full = (ov[1] + 10 * b.size + 7) // 8 + 2
+        full = (ov[1] + longest_code * b.size + 7) // 8 + 2
         # (4 * size + 8: room for the worst case of any coder here -- the road enc_tiny takes without asking for bytes)
         cap = [full, int(rng.integers(0, full + 1)), max(b.size * 5 // 8, 0), 0, int(rng.integers(0, 6)), 4 * b.size + 8][int(rng.integers(0, 6))]
         if i % 7 == 3:  # the exact size, and one less
@@ -1265,7 +1272,7 @@ def tiny_encode_items(w, n_items=1500, seed=37, engine=None, holes=False, max_le
     assert np.array_equal(got, want), "tiny items: wrong bytes, or bytes outside an item"
     assert len(kinds) >= (3 if holes else 2)
     eng.encode_launch(plan, d_in, d_out, length_only=True)
-    lens_of = [int(w.table[1][b]) for b in range(256)]
+    lens_of = list(code_lens)
     if holes:
         lens_of[7] = lens_of[200] = 0
     lens_arr = np.asarray(lens_of, dtype=np.int64)

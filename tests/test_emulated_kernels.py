@@ -149,6 +149,8 @@ def test_mid_sized_encode_items(world):
     # (256 items or more: up to a segment, four tiles one after the other by the same wave)
     pc.tiny_encode_items(world, n_items=300, seed=157, max_len=20000, edge_lens=False, wave_limit=16384, more_lens=edges)
     pc.tiny_encode_items(world, n_items=220, seed=151, max_len=9000, edge_lens=False, wave_limit=4096, more_lens=edges)
+    # (codes of up to 15 bits: the packing kernel's other build)
+    pc.tiny_encode_items(world, n_items=270, seed=171, max_len=20000, edge_lens=False, wave_limit=16384, more_lens=edges, profile="len4to15")
     pc.tiny_encode_items(world, n_items=90, seed=152, max_len=4000, edge_lens=False, wave_limit=4096)  # (no segments at all)
     pc.tiny_encode_items(world, n_items=120, seed=153, holes=True, max_len=9000, edge_lens=False, wave_limit=0, more_lens=edges)
     with harness.encode_road(world.product.lib, "one-pass-fails"):

@@ -188,6 +188,9 @@ def test_mid_sized_encode_items(world, engine):
     pc.tiny_encode_items(world, n_items=2500, seed=151, engine=engine, max_len=20000, edge_lens=False, wave_limit=16384, more_lens=edges)
     pc.tiny_encode_items(world, n_items=5000, seed=152, engine=engine, max_len=4000, edge_lens=False, wave_limit=16384)
     pc.tiny_encode_items(world, n_items=200, seed=156, engine=engine, max_len=9000, edge_lens=False, wave_limit=4096, more_lens=edges)
+    # (codes of up to 15 bits: the packing kernel's other build)
+    pc.tiny_encode_items(world, n_items=1500, seed=171, max_len=20000, edge_lens=False, wave_limit=16384, more_lens=edges, profile="len4to15")
+    pc.tiny_encode_items(world, n_items=150, seed=172, max_len=9000, edge_lens=False, wave_limit=4096, more_lens=edges, profile="len4to15")
     pc.tiny_encode_items(world, n_items=1200, seed=153, holes=True, max_len=9000, edge_lens=False, wave_limit=0, more_lens=edges)
     with harness.encode_road(world.product.lib, "one-pass-fails"):
         pc.tiny_encode_items(world, n_items=1200, seed=154, max_len=20000, edge_lens=False, wave_limit=16384, more_lens=edges)
