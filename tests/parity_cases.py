@@ -1681,6 +1681,51 @@ def plans_made_on_the_device(w, seed=131, engine=None, big=2_200_000, n_small=30
         eng.close()
 
 
+def device_plans_of_other_coders(w, names=("hpack_lengths", "len8", "len2to30", "len1to16"), seed=149,
+                                  batches=((60, 16384), (700, 600), (5000, 60))):
+    """Plans from a stride and chained on the device, for the coders the chunk kernels do not take (codes of more than 12
+    bits: items a thread / a wave / a workgroup each; one code length: no walk at all) and for encoders outside the one-pass
+    kernel's codes: the same records and bytes as the plan made from host records, the oracle's bytes, and the symbols back."""
+    rng = np.random.default_rng(seed)
+    for name in names:
+        oc, pcoder, lengths = profile_coders(w, name)
+        eng = harness.Engine(w.product.lib, pcoder)
+        lib = eng.lib
+        longest = max(lengths)
+        for count, size in batches:
+            data = (32 + rng.integers(0, 95, count * size)).astype(np.uint8)
+            cap = (longest * size + 7) // 8 + 8
+            d_in, d_e1, d_e2, d_back = eng.alloc(data.size + 64), eng.alloc(count * cap + 64), eng.alloc(count * cap + 64), eng.alloc(data.size + 64)
+            eng.upload(d_in, data)
+            host_plan = eng.encode_plan([dict(in_offset=k * size, in_len=size, out_offset=k * cap, out_capacity=cap, eos_padding=0xFF) for k in range(count)])
+            strided = eng.plan_strided(True, count=count, in_offset=0, in_stride=size, in_len=size, out_offset=0, out_stride=cap, out_capacity=cap, eos_padding=0xFF)
+            assert eng.encode_stats(host_plan) == eng.encode_stats(strided), (name, count, size)
+            for d_out, plan in ((d_e1, host_plan), (d_e2, strided)):
+                eng.fill(d_out, SENTINEL, count * cap + 64)
+                eng.encode_launch(plan, d_in, d_out)
+            r1, r2 = eng.encode_results(host_plan, count), eng.encode_results(strided, count)
+            assert r1 == r2 and all(r[0] == 0 and r[2] == size for r in r1), (name, count, size)
+            enc = eng.download(d_e2, count * cap + 64)
+            assert np.array_equal(eng.download(d_e1, count * cap + 64), enc), (name, count, size)
+            for k in (0, count // 2, count - 1):
+                want = w.oracle.encode_all(oc, data[k * size:(k + 1) * size], slack=64)
+                assert r1[k][3] == want.size and np.array_equal(enc[k * cap:k * cap + want.size], want), (name, k)
+            chained = eng.empty_decode_plan()
+            assert eng.decode_plan_from_encode(chained, strided)
+            eng.fill(d_back, SENTINEL, data.size + 64)
+            eng.decode_launch(chained, d_e2, d_back)
+            cres = eng.decode_results(chained, count)
+            assert all(r[:3] == (0, 0, size) for r in cres), (name, count, size, [r for r in cres if r[:3] != (0, 0, size)][:2])
+            back = eng.download(d_back, data.size + 64)
+            assert np.array_equal(back[:data.size], data) and np.all(back[data.size:] == SENTINEL), (name, count, size)
+            lib.aws_huffman_amd_encode_plan_destroy(host_plan)
+            lib.aws_huffman_amd_encode_plan_destroy(strided)
+            lib.aws_huffman_amd_decode_plan_destroy(chained)
+            for ptr in (d_in, d_e1, d_e2, d_back):
+                eng.free(ptr)
+        eng.close()
+
+
 def plans_one_after_another(w, seed=107):
     """An engine keeps the device arrays of ONE destroyed plan of each kind for the next aws_huffman_amd_*_plan_new: plans
     of different shapes made, launched and destroyed after one another on one engine (larger after smaller and the other

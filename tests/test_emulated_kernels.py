@@ -164,6 +164,10 @@ def test_long_streams_of_other_coders(world):
     pc.long_streams_of_other_coders(world, names=("len4to12",), n=2_600_000)  # (runs of 32 chunks in this build: three of them)
 
 
+def test_device_plans_of_other_coders(world):
+    pc.device_plans_of_other_coders(world, batches=((9, 16384), (120, 600), (4200, 60)))
+
+
 def test_walks_that_never_meet(world):
     pc.walks_that_never_meet(world, runs=(130, 420))
 

@@ -202,6 +202,10 @@ def test_long_streams_of_other_coders(world):
     pc.long_streams_of_other_coders(world)
 
 
+def test_device_plans_of_other_coders(world):
+    pc.device_plans_of_other_coders(world)
+
+
 def test_walks_that_never_meet(world, engine):
     pc.walks_that_never_meet(world, engine=engine)
     pc.walks_that_never_meet(world, engine=engine, seed=138, runs=(200, 333, 1500), modes=(None, "long-way"))
