@@ -165,7 +165,7 @@ def test_long_streams_of_other_coders(world):
 
 
 def test_device_plans_of_other_coders(world):
-    pc.device_plans_of_other_coders(world, batches=((9, 16384), (120, 600), (4200, 60)))
+    pc.device_plans_of_other_coders(world, names=("hpack_lengths", "len8", "len1to16"), batches=((9, 16384), (4200, 60)))
 
 
 def test_walks_that_never_meet(world):
