@@ -316,9 +316,12 @@ __device__ __forceinline__ u32 lean_row(u32 state, u32 hi, u32 lo, u32 table, co
  * Exactness: a sub-chunk's records are kept only if H met R (both walks then ARE the true path from that row), neither
  * walk stepped over a window without a code on the true path (counted in the walk's state: such a window is where the
  * reference stops, source/huffman.c:240-247 -- the long way finds the stop), and the exit is a state; the chain of
- * entries is true by induction from sub-chunk 0, whose candidates (threads 0 .. ns-1, every entry state, step by step)
- * must each die or meet lane 0's walk within sixteen rows.  Anything else: the chunk is not regular, as for
- * that kernel, same lists.  Same records out.
+ * entries is true by induction from sub-chunk 0, whose candidates (threads 0 .. ns-1: every entry state the chunk may be
+ * entered in -- one, the item's first bit, for an item's first chunk) must each die or meet lane 0's walk inside the
+ * sub-chunk: at any row boundary, the wave's last thread walking lane 0's guessed walk again beside them.  A lane whose two
+ * walks never meet (the true one has then covered the whole sub-chunk) keeps the true walk's records and leaves as it
+ * does; the lane behind it walks again from that entry, a few rounds at most.  Anything else: the chunk is not regular,
+ * as for that kernel, same lists.  Same records out.
  */
 constexpr u32 kOneRecs = 9;
 __device__ __host__ constexpr u32 one_rec_row(u32 j) { /* the row boundaries at which the guessed walk's state is kept; the last: the sub-chunk's end */
