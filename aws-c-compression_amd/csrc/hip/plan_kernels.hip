@@ -16,6 +16,9 @@ namespace {
 
 constexpr u32 kPlanThreads = 256;
 constexpr u32 kPlanVec = 8; /* counters per item that are scanned into positions */
+/* the longest encode item a plan made here takes: its segments fit 32 bits with room to spare (the host's loop refuses
+ * a plan of 0xFFFFFFFF segments or more, csrc/host/engine.c enc_plan_fill) */
+constexpr u64 kEncItemMaxBytes = (u64)(0xFFFFFFFEull - 1) * HUFD_ENC_SEG_BYTES;
 
 /* device scratch of a planning pass: [0] statistics, [1] the decision, then a vector of sums per workgroup */
 struct plan_stats {
@@ -23,7 +26,8 @@ struct plan_stats {
     u64 not_shortest, longest, largest_out_cap, worst_bits, invalid; /* not_shortest: the largest ~in_len (all zero = no item yet) */
     u64 tail_stage, tail_lanes; /* decode: of the chunks streams end in */
     u64 wide_lanes;             /* ... the most whole lanes of those that are not narrow */
-    u64 pad[4];
+    u64 pieces;                 /* all items' segments / chunks, summed in 64 bits (the scanned positions are 32 bits wide) */
+    u64 pad[3];
 };
 struct plan_decision {
     u64 tiny_limit;
@@ -106,7 +110,9 @@ __global__ __launch_bounds__(kPlanThreads) void plan_stats_kernel(hufd_item_sour
         atomicMax(&local->longest, r.in_len);
         atomicMax(&local->largest_out_cap, r.out_cap);
         atomicMax(&local->worst_bits, (u64)r.bits);
-        if (ENC ? r.bits > 32 : (r.bits > 7 || r.in_len > 0xFFFFFFFFull)) {
+        /* (an item is refused where the host's loop refuses it: a decode item holds less than 4 GiB; an encode item's
+         *  segments must be a number the 32-bit counts below can hold -- more of them than that is no plan either way) */
+        if (ENC ? (r.bits > 32 || r.in_len > kEncItemMaxBytes) : (r.bits > 7 || r.in_len > 0xFFFFFFFFull)) {
             atomicMax(&local->invalid, (u64)1);
         }
     }
@@ -245,11 +251,11 @@ template <bool ENC>
 __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(
     hufd_item_source src, u32 n_items, const plan_decision *decision, u32 shortest_code, u64 solo_limit, plan_stats *stats, u32 *block_sums) {
     u32 *sums = reinterpret_cast<u32 *>(dyn_lds); /* [kPlanVec] */
-    u64 *maxes = reinterpret_cast<u64 *>(dyn_lds + 64); /* tail_stage, tail_lanes, wide_lanes */
+    u64 *maxes = reinterpret_cast<u64 *>(dyn_lds + 64); /* tail_stage, tail_lanes, wide_lanes, then the pieces in 64 bits */
     if (threadIdx.x < kPlanVec) {
         sums[threadIdx.x] = 0;
     }
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < 4) {
         maxes[threadIdx.x] = 0;
     }
     __syncthreads();
@@ -287,9 +293,16 @@ __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(
             atomicAdd(&sums[k], w);
         }
     }
+    /* the 32-bit sums above wrap for a batch of 2^32 pieces or more; this one does not, and the host refuses by it */
+    if (v[0]) {
+        atomicAdd(&maxes[3], (u64)v[0]);
+    }
     __syncthreads();
     if (threadIdx.x < kPlanVec) {
         block_sums[(u64)blockIdx.x * kPlanVec + threadIdx.x] = sums[threadIdx.x];
+    }
+    if (threadIdx.x == 0 && maxes[3]) {
+        atomicAdd(&stats->pieces, maxes[3]);
     }
     if (!ENC && threadIdx.x == 0) {
         if (maxes[0]) {
@@ -521,6 +534,7 @@ int plan_count(
     out->largest_out_cap = host.s.largest_out_cap;
     out->worst_bits = (uint32_t)host.s.worst_bits;
     out->invalid = (uint32_t)host.s.invalid;
+    out->totals[0] = host.s.pieces; /* (the 64-bit sum: what the scan's 32 bits say only while it is below 2^32) */
     out->tail_stage = host.s.tail_stage;
     out->tail_lanes = host.s.tail_lanes;
     out->wide_lanes = host.s.wide_lanes;

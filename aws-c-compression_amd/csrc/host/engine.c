@@ -925,7 +925,10 @@ static int enc_plan_fill_on_device(struct aws_huffman_amd_encode_plan *p, const 
     p->stats.by_pieces = t.totals[7];
     p->stats.pieces = t.totals[0];
     p->stats.empty = n_items - t.totals[1] - t.totals[2] - t.totals[7];
-    return AWS_OP_SUCCESS;
+    /* the record-writing kernels run on `st` behind the one wait above: whoever gets this plan's arrays next (a plan
+     * destroyed before any launch is the engine's spare) waits for them as for a launch */
+    e = plan_mark_done(&p->done_event, &p->done_on_engine_stream, eng, stream);
+    return e ? raise_hip(e) : AWS_OP_SUCCESS;
 }
 
 static void strided_source(struct hufd_item_source *src, const struct aws_huffman_amd_strided_items *items) {
@@ -1032,7 +1035,7 @@ int aws_huffman_amd_encode_plan_launch_staged(
     a.fail_tile = p->engine->encode_fails;
     p->last_input = device_input;
     p->last_output = device_output;
-    p->launched = true;
+    p->launched = !length_only; /* (a length query leaves lengths in the records and no output: nothing to chain a decode to) */
     p->last_single_pass =
         a.single_pass && (p->n_segs || p->n_solo) && !length_only && hufk_encode_one_pass_applies(&p->engine->tables);
     a.states = p->d_states;
@@ -1760,7 +1763,8 @@ static int dec_plan_fill_on_device(struct aws_huffman_amd_decode_plan *p, const 
         p->stats.end_pieces_single = narrow + wide - p->stats.end_pieces_packed;
         p->stats.empty = n_items - tiny - coop - t.totals[7];
     }
-    return AWS_OP_SUCCESS;
+    e = plan_mark_done(&p->done_event, &p->done_on_engine_stream, eng, stream); /* (as enc_plan_fill_on_device) */
+    return e ? raise_hip(e) : AWS_OP_SUCCESS;
 }
 
 int aws_huffman_amd_decode_plan_reset_strided(
@@ -2037,7 +2041,8 @@ int aws_huffman_amd_decode_plan_from_encode(
     p->chained = true;
     p->stats.items = p->stats.by_thread = n_items;
     p->stats.thread_limit = longest;
-    return AWS_OP_SUCCESS;
+    e = plan_mark_done(&p->done_event, &p->done_on_engine_stream, eng, stream); /* (hufk_decode_plan_from_encode is in flight) */
+    return e ? raise_hip(e) : AWS_OP_SUCCESS;
 }
 
 /* ------------------------------------------------------------------ one-item helpers for the host-pointer API */

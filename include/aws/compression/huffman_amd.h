@@ -254,8 +254,8 @@ int aws_huffman_amd_decode_plan_reset_device_items(
  * fields) -- costs the host a few microseconds and no wait.  Any other batch (items with chunks: BASELINE configs[3]'s
  * 16 KiB buffers) is planned on the device as for aws_huffman_amd_decode_plan_reset_device_items, from the launch's
  * records: the call waits for the encode launch and a handful of totals; the lengths stay on the device.  Both plans on
- * one device; `encoded` must have been launched since it was last filled (AWS_ERROR_INVALID_ARGUMENT otherwise, nothing
- * changed).  A HIP failure inside the call leaves `plan` without items, as a failed reset does.
+ * one device; `encoded`'s last launch since it was filled must have written output -- never launched, or a length
+ * query last (its records hold lengths of bytes nobody wrote): AWS_ERROR_INVALID_ARGUMENT, nothing changed.  A HIP failure inside the call leaves `plan` without items, as a failed reset does.
  */
 AWS_COMPRESSION_API
 int aws_huffman_amd_decode_plan_from_encode(

@@ -14,8 +14,8 @@ for tag in ("pmc", "pmc_stream"):
     for f in glob.glob(sys.argv[1] + "/" + tag + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "dec_sync_lean" in k or "dec_emit_fast" in k:
-                name = ("lean" if "lean" in k else "emit") + ("<TAIL>" if ("ELb1E" in k or ", true" in k) else "")
+            if "dec_sync_one" in k or "dec_sync_pack" in k or "dec_emit_fast" in k:
+                name = ("sync_pack" if "sync_pack" in k else "sync_one" if "sync_one" in k else "emit") + ("<TAIL>" if ("ELb1E" in k or ", true" in k) else "")
                 acc[name][r["Counter_Name"]] += float(r["Counter_Value"]); 
                 if r["Counter_Name"] == "SQ_WAVES": calls[name] += 1
     for name in sorted(acc):

@@ -719,7 +719,7 @@ def dense_symbols(w, n=200_000, seed=31):
 
 def streams_out_of_step(w, n=260_000, seed=109, modes=(None, "long-way")):
     """Streams whose walks from different entry bits never become one: one symbol over and over, two symbols of one
-    length taking turns, a short pattern repeated -- every chunk of them is one dec_sync_lean gives up after a few rows;
+    length taking turns, a short pattern repeated -- every chunk of them is one dec_sync_one gives up after a few rows;
     dec_sync_few / dec_sync_true take those inside the stream (a few walks a lane, then the true walk's records for the
     fast emit kernels), "long-way" sends them through dec_sync / dec_emit as before round 4.  Whole, cut, damaged in
     the middle (a true walk that stops inside a chunk), entered inside a byte, short of room, and behind a stretch of
@@ -1677,6 +1677,45 @@ def plans_made_on_the_device(w, seed=131, engine=None, big=2_200_000, n_small=30
         lib.aws_huffman_amd_decode_plan_destroy(strided)
         for ptr in (d_enc, d_s1, d_s2):
             eng.free(ptr)
+    # ---- what the host's loop refuses, the device's passes refuse: an item whose segments do not fit 32 bits (2^45 symbols
+    # an item used to wrap to no pieces at all and the plan was accepted), a batch whose pieces together do not, and a decode
+    # chained to a launch that only measured
+    refused, refused_d = eng.empty_encode_plan(), eng.empty_decode_plan()
+    for count, in_len in ((2, 1 << 45), (1, 1 << 46), (300, 1 << 46), (3, (0xFFFFFFFE - 1) * 16384 + 1), (70_000, 1 << 30), (1, (1 << 64) - 1)):
+        desc = harness.StridedItems(count=count, in_offset=0, in_stride=0, in_len=in_len, out_offset=0, out_stride=0, out_capacity=16, eos_padding=0xFF)
+        assert lib.aws_huffman_amd_encode_plan_reset_strided(refused, C.byref(desc), None) != 0, (count, in_len)
+        assert lib.aws_last_error() == harness.AWS_ERROR_INVALID_ARGUMENT and eng.encode_stats(refused)["items"] == 0, (count, in_len)
+    for count, in_len in ((2, 1 << 32), (70_000, (1 << 32) - 1)):
+        desc = harness.StridedItems(count=count, in_offset=0, in_stride=0, in_len=in_len, out_offset=0, out_stride=0, out_capacity=16)
+        assert lib.aws_huffman_amd_decode_plan_reset_strided(refused_d, C.byref(desc), None) != 0, (count, in_len)
+        assert lib.aws_last_error() == harness.AWS_ERROR_INVALID_ARGUMENT and eng.decode_stats(refused_d)["items"] == 0, (count, in_len)
+    data = inputs(rng, 40 * 3000, "uniform")
+    d_in, d_enc = eng.alloc(data.size + 64), eng.alloc(40 * 6000 + 64)
+    eng.upload(d_in, data)
+    measured = eng.plan_strided(True, plan=refused, count=40, in_offset=0, in_stride=3000, in_len=3000, out_offset=0, out_stride=6000,
+                                out_capacity=6000, eos_padding=0xFF)
+    lib.aws_huffman_amd_decode_plan_from_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    assert lib.aws_huffman_amd_decode_plan_from_encode(refused_d, measured, None) != 0  # (never launched)
+    assert lib.aws_last_error() == harness.AWS_ERROR_INVALID_ARGUMENT
+    eng.encode_launch(measured, d_in, d_enc)
+    eng.encode_launch(measured, d_in, d_enc, length_only=True)
+    want_lens = [oracle_encode(w, data[k * 3000:(k + 1) * 3000]).size for k in range(40)]
+    assert eng.encoded_lengths(measured, 40) == want_lens
+    assert lib.aws_huffman_amd_decode_plan_from_encode(refused_d, measured, None) != 0  # (launched, but a length query last)
+    assert lib.aws_last_error() == harness.AWS_ERROR_INVALID_ARGUMENT
+    eng.encode_launch(measured, d_in, d_enc)
+    assert eng.decode_plan_from_encode(refused_d, measured)
+    # (a plan destroyed with its record-writing kernels still queued is the engine's spare: the next plan_new waits for them)
+    lib.aws_huffman_amd_decode_plan_destroy(refused_d)
+    again = eng.decode_plan([dict(in_offset=0, in_len=want_lens[0], out_offset=0, out_capacity=3000)])
+    d_back = eng.alloc(3000 + 64)
+    eng.decode_launch(again, d_enc, d_back)
+    assert eng.decode_results(again, 1)[0][:3] == (0, 0, 3000)
+    assert np.array_equal(eng.download(d_back, 3000), data[:3000])
+    lib.aws_huffman_amd_decode_plan_destroy(again)
+    lib.aws_huffman_amd_encode_plan_destroy(measured)
+    for ptr in (d_in, d_enc, d_back):
+        eng.free(ptr)
     if engine is None:
         eng.close()
 
