@@ -309,7 +309,12 @@ __global__ __launch_bounds__(kEmitThreads, 4) void dec_emit_kernel(
     const u64 *chunk_base,
     hufd_dec_result *results,
     const u32 *list,
-    const u32 *list_count) {
+    const u32 *list_count,
+    const u32 *counters = nullptr /* the launch's list counters ... */,
+    u32 *summary = nullptr /* ... and where this kernel, the launch's last, leaves them for the host (NULL: nowhere) */) {
+    if (summary && blockIdx.x == 0 && threadIdx.x < HUFK_DEC_COUNTERS) {
+        summary[threadIdx.x] = counters[threadIdx.x];
+    }
     const u32 n = list ? *list_count : n_chunks;
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
         dec_emit_chunk(tb, items, chunk_item, d_in, d_out, fn_tab, cp_tab, lane_count_tab, chunk_regular, chunk_entry, chunk_base, results, list ? list[i] : i);
@@ -1111,7 +1116,7 @@ hipLaunchKernelGGL(                                                             
     emit_single_chunks, (const u8 *)a->d_in, (u8 *)a->d_out, (const u16 *)a->cp_tab, (const u16 *)a->lane_count,   \
     (const u8 *)a->chunk_regular, (const u32 *)a->chunk_fn, (const u32 *)a->chunk_entry,                           \
     (const u64 *)a->chunk_base, a->results, a->emit_list, emit_count,                                            \
-    !TAILV ? a->dense_list : a->emit_list, !TAILV ? dense_count : emit_count,                                \
+    !TAILV && big ? a->dense_list : a->emit_list, !TAILV && big ? dense_count : emit_count,                  \
     TAILV ? tail_stage : HUFD_DEC_STAGE_BYTES)
     /* dec_emit_fast<TAIL>'s workgroup: four quarters to two sub-chunks a thread over the most whole lanes a wide chunk of the
      * launch has (+ the wave that rounds it up), never fewer than the 256 threads of its scan: BASELINE configs[3]'s chunks
@@ -1119,6 +1124,7 @@ hipLaunchKernelGGL(                                                             
     const uint32_t tail_live = a->tail_wide_lanes ? (kQuarters * ((a->tail_wide_lanes + 1) / 2) + kWave - 1) / kWave * kWave : kEmitFastThreads;
     const uint32_t tail_block = tail_live < HUFD_DEC_LANES ? HUFD_DEC_LANES : (tail_live < kEmitFastThreads ? tail_live : kEmitFastThreads);
     const bool some_inside = a->n_tail < a->n_chunks;
+    const bool big = !a->quiet; /* (quiet: chunks of more symbols than the stage holds take the long way with the others) */
     /* (the few chunks streams end in beside the many inside streams: see the sync kernels above.  And in any case
      * dec_emit_tail beside dec_emit_fast<TAIL>: it works out for itself which chunks that kernel takes, reads
      * nothing it writes and writes other bytes) */
@@ -1221,7 +1227,9 @@ do {                                                                            
         (const u32 *)a->chunk_entry, (const u64 *)a->chunk_base, a->results, a->emit_list, emit_count,          \
         (const u32 *)a->dense_list, (const u32 *)dense_count);                                                  \
 } while (0)
-    if (lb_of_launch == 10) {
+    if (!big) {
+        /* (nothing was listed for it) */
+    } else if (lb_of_launch == 10) {
         switch (emit_sure) {
             case 3: HUFK_LAUNCH_EMIT_BIG(10, 3); break;
             case 4: HUFK_LAUNCH_EMIT_BIG(10, 4); break;
@@ -1237,5 +1245,5 @@ do {                                                                            
         dim3(kEmitThreads), dec_emit_lds_bytes(&a->tables), st, a->tables, a->items, a->chunk_item, a->n_chunks,
         (const u8 *)a->d_in, (u8 *)a->d_out, a->fn_tab, a->cp_tab, (const u16 *)a->lane_count,
         (const u8 *)a->chunk_regular, a->chunk_entry, a->chunk_base, a->results, (const u32 *)a->emit_list,
-        (const u32 *)emit_count);
+        (const u32 *)emit_count, (const u32 *)a->counters, a->summary);
 }

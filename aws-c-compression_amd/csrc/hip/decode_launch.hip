@@ -497,7 +497,9 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     }
     decode_launch_state state = {lb_of_launch, sure, false};
     if (a->n_chunks) {
-        (void)hipMemsetAsync(a->counters, 0, HUFK_DEC_COUNTERS * sizeof(uint32_t), st);
+        if (!a->counters_next) {
+            (void)hipMemsetAsync(a->counters, 0, HUFK_DEC_COUNTERS * sizeof(uint32_t), st);
+        }
         hufk_host::decode_sync_stage(a, st, state);
     }
     stage_mark(a->stage_events, 1, st);

@@ -226,7 +226,12 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     u32 *chunk_fn,
     u8 *chunk_regular,
     const u32 *list,
-    const u32 *list_count) {
+    const u32 *list_count,
+    u32 *clear_next /* NULL, or the plan's other set of list counters: cleared here for the launch behind this one (every launch
+                     * with chunks runs this kernel, and nothing of THIS launch reads that set) */) {
+    if (clear_next && blockIdx.x == 0 && threadIdx.x < HUFK_DEC_COUNTERS) {
+        clear_next[threadIdx.x] = 0;
+    }
     const u32 n = list ? *list_count : n_chunks;
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
         const u32 c = list ? list[i] : i;
@@ -651,6 +656,66 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
     }
 
     HUFD_STAMP(0, 7);
+    /* What every wave has to say is said here, IN FRONT of the walks of sub-chunk 0's candidates, which are wave 0's alone
+     * and the tail of a workgroup's life (a seventh of it): the other waves used to stand at the barrier behind those walks.
+     * Now they leave their records and go -- their wave slots are the next workgroup's that much earlier.  (Records of a
+     * chunk that wave 0 then finds irregular are never looked at: chunk_regular says so, and the kernels that take the
+     * chunk write them again.  When a lane's exit moved -- rare -- everybody stays for the rounds below.) */
+    {
+        const u32 wsum0 = wave_sum(lane ? count : 0u);
+        if ((lane & (kWave - 1)) == 0) {
+            sh.wave_sum[lane / kWave] = wsum0;
+        }
+        if (!ok) {
+            sh.bad = 1;
+        }
+        if (!ok_mine) {
+            sh.bad_mine = 1;
+        }
+    }
+    __syncthreads();
+    const bool stay = sh.moved != 0; /* (the same for the workgroup) */
+    auto lane_records = [&]() {
+        if (active) {
+#pragma unroll
+            for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+                /* a checkpoint in front of the meeting row is not on the guessed walk's true part: it is taken from the walk
+                 * from the true entry, which passed it (not for lane 0, whose true entry is only known to dec_scan: its first
+                 * checkpoint may be missing, dec_emit_fast walks on through that quarter) */
+                const u32 boundary = (qq + 1) * (kSubWords / kQuarters);
+                bool have = boundary >= meet_row;
+                const u32 at_boundary = kept_get(kOneRecs + qq);
+                u32 tail = one_walk::count_of(last) - one_walk::count_of(at_boundary), bits = ow.offset_of(at_boundary);
+                if (!have && lane != 0) {
+                    tail = count - one_walk::count_of(head_cp[qq]);
+                    bits = ow.offset_of(head_cp[qq]);
+                    have = true;
+                }
+                cp[qq * HUFD_DEC_LANES] = (u16)(have ? 0x8000u | (bits << 11) | tail : 0u);
+            }
+        } else {
+            /* (TAIL) behind the whole lanes, in a wave that has some: as for the waves that left */
+#pragma unroll
+            for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
+                cp[qq * HUFD_DEC_LANES] = 0;
+            }
+            lane_count[(u64)c * HUFD_DEC_LANES + lane] = 0;
+            cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(kExitStop << 12);
+        }
+        if (TAIL && lane + 1 == n_full) {
+            tail_entry[c] = ref_exit;
+        }
+    };
+    if (!stay && lane >= kWave) {
+        if (!sh.bad && !sh.bad_mine) {
+            lane_records();
+            if (active) {
+                lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)count;
+                cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((1u << entry) | (ref_exit << 12));
+            }
+        }
+        return;
+    }
     /* H: sub-chunk 0 from every entry state the chunk may be entered in (threads 0 .. ns-1): each dies at a window without a
      * code (the count up to there has to be right) or meets lane 0's guessed walk -- which the wave's last thread walks
      * AGAIN beside them, a row at a time, so that they can meet it at any row boundary (two rows on average; met at the
@@ -731,21 +796,16 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
     }
 
     HUFD_STAMP(0, 5);
-    const u32 wsum = wave_sum(lane ? count : 0u);
-    if ((lane & (kWave - 1)) == 0) {
-        sh.wave_sum[lane / kWave] = wsum;
-    }
     if (!ok) {
-        sh.bad = 1;
+        sh.bad = 1; /* (wave 0: what the candidates' walks said) */
     }
-    if (!ok_mine) {
-        sh.bad_mine = 1;
+    if (stay) {
+        __syncthreads(); /* (everybody is still here) */
     }
-    __syncthreads();
-    if (!sh.moved && sh.bad_mine) {
+    if (!stay && sh.bad_mine) {
         sh.bad = 1; /* (every thread that gets here writes the same) */
     }
-    if (sh.moved && !sh.bad) {
+    if (stay && !sh.bad) {
         /* Rare.  A lane's exit moved: the lane behind it walks its sub-chunk again from the entry that is now known, the
          * words from memory, until it stands where its guessed walk stood -- or to the end, and then ITS exit may move.
          * A few rounds of that, one lane at work in each; a chunk that is not settled by then is not regular. */
@@ -834,37 +894,11 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
 
     /* the tables dec_scan and dec_emit read (the regular chunks' format) */
     u16 *fn_out = fn_tab + (u64)c * ns * HUFD_DEC_LANES;
+    lane_records();
     if (active) {
         const u32 total = lane ? count : ref_count0; /* (lane 0: from where its walk is the true one) */
-#pragma unroll
-        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-            /* a checkpoint in front of the meeting row is not on the guessed walk's true part: it is taken from the walk
-             * from the true entry, which passed it (not for lane 0, whose true entry is only known to dec_scan: its first
-             * checkpoint may be missing, dec_emit_fast walks on through that quarter) */
-            const u32 boundary = (qq + 1) * (kSubWords / kQuarters);
-            bool have = boundary >= meet_row;
-            const u32 at_boundary = kept_get(kOneRecs + qq);
-            u32 tail = one_walk::count_of(last) - one_walk::count_of(at_boundary), bits = ow.offset_of(at_boundary);
-            if (!have && lane != 0) {
-                tail = count - one_walk::count_of(head_cp[qq]);
-                bits = ow.offset_of(head_cp[qq]);
-                have = true;
-            }
-            cp[qq * HUFD_DEC_LANES] = (u16)(have ? 0x8000u | (bits << 11) | tail : 0u);
-        }
         lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)total;
         cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((lane ? 1u << entry : (u32)cand_alive) | (ref_exit << 12));
-    } else {
-        /* (TAIL) behind the whole lanes, in a wave that has some: as for the waves that left */
-#pragma unroll
-        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-            cp[qq * HUFD_DEC_LANES] = 0;
-        }
-        lane_count[(u64)c * HUFD_DEC_LANES + lane] = 0;
-        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(kExitStop << 12);
-    }
-    if (TAIL && lane + 1 == n_full) {
-        tail_entry[c] = ref_exit;
     }
     if (lane == 0) {
         chunk_regular[c] = TAIL ? 2 : 1;
@@ -1886,7 +1920,7 @@ void hufk_host::decode_sync_stage(const struct hufk_decode_args *a, hipStream_t 
     /* two lists of chunks that are not regular by dec_sync_one's rules: the ones dec_sync_guess may still take
      * (inside a stream, first sub-chunk's walks meet) and the ones for the long way.  The second is the emit stage's
      * list, free until then; one list where there is no dec_sync_guess for the launch. */
-    const bool guessing = some_inside;
+    const bool guessing = some_inside && !a->quiet; /* (quiet: dec_sync_one's two lists are one, the long way's) */
     u32 *lean_long_list = guessing ? a->emit_list : a->slow_list;
     u32 *lean_long_count = guessing ? a->counters + HUFK_DEC_COUNT_LONG : slow_count;
     /* A few chunks that streams end in beside many inside streams (one long stream: ONE): their kernels are tiny
@@ -1997,7 +2031,7 @@ hipLaunchKernelGGL(                                                             
     hipLaunchKernelGGL(
         sync, dim3(persistent_grid(sync, HUFD_DEC_LANES, dec_sync_lds_bytes(&a->tables), a->n_chunks)),
         dim3(HUFD_DEC_LANES), dec_sync_lds_bytes(&a->tables), st, a->tables, a->items, a->chunk_item, a->n_chunks,
-        (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, long_list, long_count);
+        (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, long_list, long_count, a->counters_next);
     s.few = few;
 }
 

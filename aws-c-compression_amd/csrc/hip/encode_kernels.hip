@@ -2671,8 +2671,17 @@ __global__ __launch_bounds__(256) void enc_finish_kernel(
                         * the three-kernel road behind this kernel does the launch over, records included */,
     u32 which /* bit 0: the items with segments; bit 1: the items of one tile that the plan lists apart (their kernel waits
                * for nobody: whatever road the others took, theirs are whole); bit 2: the packing waves have left, for every
-               * item short of room, what of it was consumed (not in a length query: nothing was packed) */) {
+               * item short of room, what of it was consumed (not in a length query: nothing was packed) */,
+    uint4 *clear_from = nullptr /* the look-back words of the launch (the packing kernel is through with them), ... */,
+    u64 clear_vec16 = 0         /* ... so many 16-byte pieces: cleared here for the plan's next launch, whatever road this one took */,
+    u32 *ctl_next = nullptr     /* the other set of control words: the next launch's */) {
 
+    for (u64 k = (u64)blockIdx.x * kFinishItems + threadIdx.x; k < clear_vec16; k += (u64)gridDim.x * kFinishItems) {
+        clear_from[k] = uint4{0, 0, 0, 0};
+    }
+    if (ctl_next && blockIdx.x == 0 && threadIdx.x < 8) {
+        ctl_next[threadIdx.x] = 0;
+    }
     const bool with_segments = (which & 1u) && !(gave_up && gave_up[0] != 0), solo = (which & 2u) != 0;
     if (!with_segments && !solo) {
         return;
@@ -2724,7 +2733,11 @@ __global__ __launch_bounds__(256) void enc_plan_tiny_items_kernel(const hufd_raw
  * tests/test_library_boundary.py::test_onepass_kernels_scalar_registers holds the build to it */
 constexpr uint32_t kOnepassSgprs = 106;
 
-/* layout of the block the one-pass encoder wants zeroed before every launch (all offsets multiples of 8) */
+/* layout of the block the one-pass encoder wants clear when a launch starts (all offsets multiples of 8).  It is cleared when
+ * the plan gets it and then by every launch behind itself: enc_finish, which runs when the packing kernel is through with the
+ * look-back words, clears them and the OTHER set of control words (this launch's set holds the word the kernels of the way
+ * back, queued behind enc_finish, look at) -- a clearing command in front of every launch was a packet of ~4 us on the queue
+ * and a gap behind it. */
 struct onepass_layout {
     uint64_t ctl, tile_agg, group_acc, round_base, item_base, null_tile, bytes;
 };
@@ -2734,8 +2747,8 @@ static onepass_layout onepass_layout_of(uint64_t n_segs, uint64_t n_items) {
     const uint64_t groups = (tiles + kOpGroupTiles - 1) / kOpGroupTiles;
     const uint64_t rounds = (groups + kOpRoundGroups - 1) / kOpRoundGroups;
     onepass_layout l;
-    l.ctl = 0;
-    l.tile_agg = 32;
+    l.ctl = 0; /* two sets of eight control words, which take turns: [0, 32) and [32, 64) */
+    l.tile_agg = 64;
     l.group_acc = l.tile_agg + ((tiles * 4 + 7) & ~7ull);
     l.round_base = l.group_acc + groups * 8 * kOpGroupStride;
     l.item_base = l.round_base + (rounds + 1) * 8;
@@ -2844,12 +2857,20 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
     if ((a->n_segs || a->n_solo) && !a->length_only && a->single_pass && hufk_encode_one_pass_applies(&a->tables) && a->zero_block) {
         /* one pass: count + offsets + pack in one kernel (and the items of one tile by a kernel of their own, a wave each),
          * then the per-item outcome */
-        const onepass_layout l = onepass_layout_of(a->n_segs, a->n_items);
+        onepass_layout l = onepass_layout_of(a->n_segs, a->n_items);
         uint8_t *z = (uint8_t *)a->zero_block;
-        stage_mark(a->stage_events, 0, st); /* (the clearing of the look-back words is part of what is timed) */
-        /* (a plan without segments -- every item a wave's or a thread's -- has no look-back words: the control words only;
-         * BASELINE configs[3]'s 65 536 item bases were half a megabyte cleared for nobody) */
-        (void)hipMemsetAsync(a->zero_block, 0, a->n_segs ? l.bytes : l.tile_agg, st);
+        stage_mark(a->stage_events, 0, st);
+        /* the block is clear: the plan's last launch left it so (enc_finish below), or the plan cleared it when it got it.
+         * (Not known to be: cleared here, all of it the plan may ever have used.) */
+        if (!a->zero_is_clear) {
+            (void)hipMemsetAsync(a->zero_block, 0, a->zero_bytes ? a->zero_bytes : l.bytes, st);
+        }
+        const uint64_t ctl_next = (a->zero_set & 1u) ? 0u : 32u;
+        l.ctl = (a->zero_set & 1u) ? 32u : 0u; /* this launch's set of control words */
+        /* (the words the three-kernel road counts its listed segments in belong to the set: a copy of the arguments says so) */
+        struct hufk_encode_args with_set = *a;
+        with_set.careful_count = (uint32_t *)(z + l.ctl) + 2;
+        a = &with_set;
         const uint32_t region = pack_region_bytes(a->tables.enc_max_bits);
         const uint32_t lds = kPackTabBytes + kPackWaves * region;
         const uint32_t work = (a->n_segs * kTilesPerSeg + kPackWaves - 1) / kPackWaves;
@@ -2870,10 +2891,19 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
 #undef HUFK_LAUNCH_ONEPASS
         encode_solo_items(a, st, false);
         stage_mark(a->stage_events, 1, st);
-        hipLaunchKernelGGL(
-            enc_finish_kernel, dim3((a->n_items + kFinishItems - 1) / kFinishItems), dim3(256), kFinishLdsBytes, st, a->tables, a->items, a->n_items,
-            a->item_total, (const u8 *)a->d_in, a->careful_list, a->careful_count, a->states, a->results,
-            (const u32 *)(z + l.ctl) + 1, a->n_solo ? 7u : 5u);
+        {
+            /* (a plan without segments -- every item a wave's or a thread's -- has no look-back words: BASELINE configs[3]'s
+             * 65 536 item bases were half a megabyte cleared for nobody) */
+            const uint64_t clear_vec16 = a->n_segs ? (l.null_tile - l.tile_agg) / 16 : 0;
+            const uint64_t item_blocks = (a->n_items + kFinishItems - 1) / kFinishItems;
+            uint64_t clear_blocks = (clear_vec16 + kFinishItems * 4 - 1) / (kFinishItems * 4); /* four pieces a thread */
+            clear_blocks = clear_blocks > 1024 ? 1024 : clear_blocks;
+            hipLaunchKernelGGL(
+                enc_finish_kernel, dim3((uint32_t)(item_blocks > clear_blocks ? item_blocks : clear_blocks)), dim3(256), kFinishLdsBytes, st,
+                a->tables, a->items, a->n_items, a->item_total, (const u8 *)a->d_in, a->careful_list, a->careful_count, a->states,
+                a->results, (const u32 *)(z + l.ctl) + 1, a->n_solo ? 7u : 5u, (uint4 *)(z + l.tile_agg), clear_vec16,
+                (u32 *)(z + ctl_next));
+        }
         stage_mark(a->stage_events, 2, st);
         if (a->n_tiny) {
             hipLaunchKernelGGL(

@@ -35,8 +35,12 @@ struct hufk_encode_args {
     uint32_t *careful_list;  /* [2 * n_items] scratch: segments for the per-symbol packer */
     uint32_t *careful_count; /* [1] scratch */
     /* one-pass path (every symbol coded, codes of 4 .. 15 bits): */
-    void *zero_block;        /* hufk_encode_zero_bytes(n_segs, n_items) bytes, zeroed by the launch: word 0 ticket,
-                              * word 1 "a wait ran out", word 2 careful_count, then the look-back tables */
+    void *zero_block;        /* hufk_encode_zero_bytes(n_segs, n_items) bytes, clear when the launch starts and when it is
+                              * through: two sets of control words that take turns (word 0 ticket, word 1 "a wait ran
+                              * out", word 2 careful_count), then the look-back tables */
+    uint32_t zero_set;       /* which set of control words this launch takes (0 / 1) */
+    uint32_t zero_is_clear;  /* 1: the block is known to be clear (the plan's last launch left it so); 0: the launch clears it first */
+    uint64_t zero_bytes;     /* all of the block (what a clearing takes when the layout of the launch that dirtied it is not known) */
     uint8_t *seg_unk_seen;   /* [n_segs] scratch */
     uint64_t *item_total;    /* [n_items] scratch */
     uint32_t single_pass;    /* 1: one kernel reads the symbols once (enc_onepass) instead of count / scan / pack */
@@ -96,8 +100,17 @@ struct hufk_decode_args {
     uint32_t *emit_list;   /* [n_chunks] scratch: chunks left to dec_emit by dec_emit_fast */
     uint32_t *dense_list;  /* [n_chunks] scratch: chunks dec_emit_fast leaves to dec_emit_dense */
     uint32_t *counters;    /* [HUFK_DEC_COUNTERS] scratch: how many entries the lists hold, one word for every use a launch
-                            * makes of a list (the arrays take turns, the words do not: ONE clearing a launch, in front
-                            * of its first kernel -- three more between the sync and the emit kernels cost ~3 us each) */
+                            * makes of a list (the arrays take turns, the words do not).  All zero when the launch starts:
+                            * a plan has TWO sets that take turns, and a launch clears the other one for the launch
+                            * behind it (`counters_next`, by the long way's sync kernel, which every launch with chunks
+                            * has) -- a clearing command in front of every launch was ~4 us of its own */
+    uint32_t *counters_next; /* [HUFK_DEC_COUNTERS] the set this launch clears; NULL: `counters` is cleared by a command in front of the launch */
+    uint32_t *summary;       /* NULL, or [HUFK_DEC_COUNTERS]: the launch's last kernel leaves its counters here (in front of the
+                              * result records: one copy fetches both) -- what the host reads `quiet` from */
+    uint32_t quiet;          /* 1: the plan's last fetched launch listed no chunk for any kernel but the regular ones: this
+                              * launch goes without the kernels that only make listed chunks FASTER (dec_sync_guess, _few,
+                              * _true, dec_emit_big -- an empty launch is ~4 us each); whatever is listed takes the long way
+                              * (dec_sync, dec_emit: exact for every chunk), and the counters say so at the next fetch */
     uint16_t *lane_count;  /* [n_chunks][HUFD_DEC_LANES] scratch */
     uint8_t *chunk_regular; /* [n_chunks] scratch */
     uint32_t *tail_entry;   /* [n_chunks] scratch: state in which the last whole lane of an end-of-stream chunk leaves */

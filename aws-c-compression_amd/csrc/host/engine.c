@@ -636,6 +636,16 @@ static int enc_plan_reserve(struct aws_huffman_amd_encode_plan *p, size_t n_item
         p->cap_segs = cs;
         p->cap_large = cl;
         p->cap_tiny = ct;
+        /* the one-pass encoder's look-back block starts out clear; from then on every launch clears it behind itself */
+        int e = hufs_memset(p->d_zero, 0, (size_t)hufk_encode_zero_bytes((uint32_t)cs, (uint32_t)ci), p->engine->stream);
+        if (!e) {
+            e = hufs_stream_sync(p->engine->stream);
+        }
+        if (e) {
+            return e;
+        }
+        p->zero_is_clear = true;
+        p->one_pass_launches = 0;
     }
     return 0;
 }
@@ -1028,7 +1038,10 @@ int aws_huffman_amd_encode_plan_launch_staged(
     a.seg_bitoff = p->d_seg_bitoff;
     a.careful_list = p->d_careful;
     a.zero_block = p->d_zero;
-    a.careful_count = (uint32_t *)p->d_zero + 2;
+    a.zero_set = p->one_pass_launches & 1u;
+    a.zero_is_clear = p->zero_is_clear;
+    a.zero_bytes = hufk_encode_zero_bytes((uint32_t)p->cap_segs, (uint32_t)p->cap_items);
+    a.careful_count = (uint32_t *)p->d_zero + 2; /* (a launch of the one-pass road takes the word of its own set) */
     a.seg_unk_seen = p->d_unk_seen;
     a.item_total = p->d_item_total;
     a.single_pass = p->engine->single_pass && !p->look_back_timed_out;
@@ -1043,6 +1056,13 @@ int aws_huffman_amd_encode_plan_launch_staged(
     a.stage_events = stage_events;
     ON_DEVICE(p->engine->device);
     int err = hufk_encode_launch(&a, stream ? stream : p->engine->stream);
+    if (p->last_single_pass) {
+        /* the launch took a set of control words (the results' fetch reads its "a wait ran out" word) and leaves the block
+         * clear behind itself -- unless it could not be queued whole */
+        p->last_ctl_set = a.zero_set;
+        ++p->one_pass_launches;
+        p->zero_is_clear = !err;
+    }
     if (!err) {
         err = plan_mark_done(&p->done_event, &p->done_on_engine_stream, p->engine, stream);
     }
@@ -1064,7 +1084,7 @@ int aws_huffman_amd_encode_plan_raw_results(
      * is likely to run out again, and costs milliseconds). */
     uint32_t timed_out = 0;
     if (p->last_single_pass) {
-        err = hufs_copy_d2h(&timed_out, p->d_zero + sizeof(uint32_t), sizeof(timed_out), st);
+        err = hufs_copy_d2h(&timed_out, p->d_zero + 32u * p->last_ctl_set + sizeof(uint32_t), sizeof(timed_out), st);
     }
     if (!err) {
         err = hufs_copy_d2h(raw, p->d_results, (size_t)p->n_items * sizeof(*raw), st);
@@ -1150,6 +1170,7 @@ int aws_huffman_amd_encode_plan_results(
 
 /* ------------------------------------------------------------------ decode plans */
 
+#define DEC_SUMMARY_BYTES 256u
 #define DEC_PLAN_ARRAYS(X, ci, cc, cl, cr, ns)                                                                            \
     X(d_items, (ci) * sizeof(struct hufd_dec_item))                                                                    \
     X(d_chunk_item, (cc) * sizeof(uint32_t))                                                                           \
@@ -1164,7 +1185,7 @@ int aws_huffman_amd_encode_plan_results(
     X(d_slow_list, ((cc) + 1) * sizeof(uint32_t)) /* [0] count, [1..] chunks */                                        \
     X(d_emit_list, ((cc) + 1) * sizeof(uint32_t))                                                                      \
     X(d_dense_list, ((cc) + 1) * sizeof(uint32_t))                                                                     \
-    X(d_counters, HUFK_DEC_COUNTERS * sizeof(uint32_t))                                                                \
+    X(d_counters, 2 * HUFK_DEC_COUNTERS * sizeof(uint32_t)) /* two sets: a launch uses one and clears the other */      \
     X(d_lane_count, (cc) * HUFD_DEC_LANES * sizeof(uint16_t))                                                          \
     X(d_chunk_regular, (cc))                                                                                           \
     X(d_tail_entry, (cc) * sizeof(uint32_t))                                                                           \
@@ -1172,6 +1193,9 @@ int aws_huffman_amd_encode_plan_results(
     X(d_chunk_base, (cc) * sizeof(uint64_t))                                                                           \
     X(d_chunk_rec, (cc) * sizeof(struct hufd_chunk_rec))                                                               \
     X(d_states, (ci) * sizeof(struct hufd_dec_item_state))                                                             \
+    /* the list counters as the launch's last kernel found them, one arena cut (256 bytes) in front of the records:    \
+     * ONE copy brings both to the host */                                                                             \
+    X(d_summary, DEC_SUMMARY_BYTES)                                                                                    \
     X(d_results, (ci) * sizeof(struct hufd_dec_result))
 
 static void dec_plan_release_device(struct aws_huffman_amd_decode_plan *p) {
@@ -1286,6 +1310,18 @@ static int dec_plan_reserve(struct aws_huffman_amd_decode_plan *p, size_t n_item
         p->cap_chunks = cc;
         p->cap_large = cl;
         p->cap_runs = cr;
+        /* the list counters start out clear; from then on every launch leaves the set it did not use clear for the next one */
+        int e = hufs_memset(p->d_counters, 0, 2 * HUFK_DEC_COUNTERS * sizeof(uint32_t), p->engine->stream);
+        if (!e) {
+            e = hufs_stream_sync(p->engine->stream);
+        }
+        if (e) {
+            return e;
+        }
+        p->launches_with_chunks = 0;
+        if ((uint8_t *)p->d_results != (uint8_t *)p->d_summary + DEC_SUMMARY_BYTES) {
+            return 1; /* (the one copy of aws_huffman_amd_decode_plan_results counts on it: cuts are 256 bytes apart) */
+        }
     }
     return 0;
 }
@@ -1303,6 +1339,7 @@ static int dec_plan_fill(
     const uint64_t tiny_limit = dec_tiny_limit(items, n_items, &stats);
     /* a failed refill must not leave counts of the fill before behind (the device arrays may be gone or too small) */
     p->n_items = p->n_chunks = p->n_large = p->n_runs = p->n_tail = p->n_fixed = p->n_wide = 0;
+    p->quiet = false; /* (other items: nothing is known of what their launches list) */
     p->n_tiny = p->n_deep = 0;
     memset(&p->stats, 0, sizeof(p->stats));
     p->chained = false;
@@ -1700,6 +1737,7 @@ static int dec_plan_fill_on_device(struct aws_huffman_amd_decode_plan *p, const 
         return rc;
     }
     p->n_items = p->n_chunks = p->n_large = p->n_runs = p->n_tail = p->n_fixed = p->n_wide = 0;
+    p->quiet = false; /* (other items: nothing is known of what their launches list) */
     p->n_tiny = p->n_deep = 0;
     memset(&p->stats, 0, sizeof(p->stats));
     p->chained = false;
@@ -1865,7 +1903,15 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.slow_list = p->d_slow_list + 1;
     a.emit_list = p->d_emit_list + 1;
     a.dense_list = p->d_dense_list + 1;
-    a.counters = p->d_counters;
+    /* (the two sets of list counters take turns: this launch's is clear -- the launch before cleared it, or the reserve did --
+     * and this launch clears the other) */
+    a.counters = p->d_counters + (p->launches_with_chunks & 1u) * HUFK_DEC_COUNTERS;
+    a.counters_next = p->d_counters + ((p->launches_with_chunks + 1u) & 1u) * HUFK_DEC_COUNTERS;
+    if (p->n_chunks) {
+        ++p->launches_with_chunks;
+    }
+    a.summary = p->d_summary;
+    a.quiet = p->quiet && !(testing_decode_road() & AWS_HUFFMAN_AMD_TEST_DECODE_ALL_KERNELS);
     a.lane_count = p->d_lane_count;
     a.chunk_regular = p->d_chunk_regular;
     a.tail_entry = p->d_tail_entry;
@@ -1928,6 +1974,10 @@ void aws_huffman_amd_decode_result_from_raw(
     }
 }
 
+bool aws_huffman_amd_decode_plan_is_quiet(const struct aws_huffman_amd_decode_plan *p) {
+    return p->quiet;
+}
+
 int aws_huffman_amd_decode_plan_road(struct aws_huffman_amd_decode_plan *p, void *stream, uint32_t *road, uint32_t *detail) {
     *road = AWS_HUFFMAN_AMD_ROAD_TWO_PASS;
     if (detail) {
@@ -1944,18 +1994,29 @@ int aws_huffman_amd_decode_plan_results(
     void *stream) {
 
     void *st = stream ? stream : p->engine->stream;
-    struct hufd_dec_result *raw = malloc((p->n_items ? p->n_items : 1) * sizeof(*raw));
-    if (!raw) {
+    uint8_t *fetched = malloc(DEC_SUMMARY_BYTES + (p->n_items ? p->n_items : 1) * sizeof(struct hufd_dec_result));
+    if (!fetched) {
         return aws_raise_error(AWS_ERROR_OOM);
     }
+    struct hufd_dec_result *raw = (struct hufd_dec_result *)(fetched + DEC_SUMMARY_BYTES);
     ON_DEVICE(p->engine->device);
-    int err = hufs_copy_d2h(raw, p->d_results, (size_t)p->n_items * sizeof(*raw), st);
+    /* (the records and, in front of them, what the last launch's lists held: one copy) */
+    int err = hufs_copy_d2h(fetched, p->d_summary, DEC_SUMMARY_BYTES + (size_t)p->n_items * sizeof(*raw), st);
     if (!err) {
         err = hufs_stream_sync(st);
     }
     if (err) {
-        free(raw);
+        free(fetched);
         return raise_hip(err);
+    }
+    if (p->n_chunks && p->launches_with_chunks) {
+        /* A launch that listed no chunk for any kernel but the regular ones (an ordinary stream of a coder whose walks fall
+         * into step): the plan's next launches go without the kernels that only make listed chunks faster -- four empty
+         * launches of ~4 us each.  A launch of a quiet plan that does list chunks sends them the long way (exact for every
+         * chunk, a fifth of the speed), says so here, and the kernels are back from the next launch on. */
+        const uint32_t *listed = (const uint32_t *)fetched;
+        p->quiet = !(listed[HUFK_DEC_COUNT_SLOW] | listed[HUFK_DEC_COUNT_LONG] | listed[HUFK_DEC_COUNT_FEW] |
+                     listed[HUFK_DEC_COUNT_EMIT] | listed[HUFK_DEC_COUNT_DENSE]);
     }
     if (p->chained) {
         /* the items' lengths were never on the host: the device's records say what each result is a result of */
@@ -1975,13 +2036,13 @@ int aws_huffman_amd_decode_plan_results(
             aws_huffman_amd_decode_result_from_raw(&raw[i], &it, &results[i]);
         }
         free(dev_items);
-        free(raw);
+        free(fetched);
         return err ? raise_hip(err) : AWS_OP_SUCCESS;
     }
     for (uint32_t i = 0; i < p->n_items; ++i) {
         aws_huffman_amd_decode_result_from_raw(&raw[i], &p->h_items[i], &results[i]);
     }
-    free(raw);
+    free(fetched);
     return AWS_OP_SUCCESS;
 }
 
@@ -2019,6 +2080,7 @@ int aws_huffman_amd_decode_plan_from_encode(
         return dec_plan_fill_on_device(p, &src, (size_t)n_items, stream);
     }
     p->n_items = p->n_chunks = p->n_large = p->n_runs = p->n_tail = p->n_fixed = p->n_wide = 0;
+    p->quiet = false; /* (other items: nothing is known of what their launches list) */
     p->n_tiny = p->n_deep = 0;
     memset(&p->stats, 0, sizeof(p->stats));
     p->chained = false;

@@ -78,7 +78,10 @@ struct aws_huffman_amd_encode_plan {
     uint32_t *d_seg_unk;
     uint64_t *d_seg_bitoff;
     uint32_t *d_careful; /* [2 * cap_items + 4]: segments for the per-symbol packer */
-    uint8_t *d_zero;     /* look-back granules [cap_segs] u64 | ticket, error flag | careful count: zeroed per launch */
+    uint8_t *d_zero;     /* two sets of control words (ticket, "a wait ran out", careful count) | look-back words: clear between launches */
+    uint32_t one_pass_launches; /* its parity: the set of control words the next launch of the one-pass road takes */
+    uint32_t last_ctl_set;      /* ... and the one the last such launch took */
+    bool zero_is_clear;         /* d_zero is clear (the last launch left it so, or the reserve did) */
     uint8_t *d_unk_seen; /* [cap_segs] */
     uint64_t *d_item_total; /* [cap_items] */
     struct hufd_enc_item_state *d_states;
@@ -124,7 +127,8 @@ struct aws_huffman_amd_decode_plan {
     uint32_t *d_slow_list; /* [0] how many, [1..] the chunks the regular chunks' kernels left to dec_sync */
     uint32_t *d_emit_list; /* the same for dec_emit_fast / dec_emit */
     uint32_t *d_dense_list; /* [0] how many, [1..] chunks with more symbols than one emit stage */
-    uint32_t *d_counters;   /* [HUFK_DEC_COUNTERS] the lists' lengths (hufk_decode_args.counters) */
+    uint32_t *d_counters;   /* [2][HUFK_DEC_COUNTERS] the lists' lengths (hufk_decode_args.counters), two sets that take turns */
+    uint32_t launches_with_chunks; /* its parity: the set the next launch uses (that launch clears the other one) */
     uint16_t *d_lane_count;
     uint8_t *d_chunk_regular;
     uint32_t *d_tail_entry;
@@ -139,7 +143,9 @@ struct aws_huffman_amd_decode_plan {
     bool unkeepable;  /* not to be kept as the engine's spare (waiting for its last launch failed) */
     bool chained; /* made on the device (from an encode plan's records, a stride, or items in device memory): the items are known there only (h_items is not filled) */
     struct hufd_dec_item_state *d_states;
+    uint32_t *d_summary; /* [HUFK_DEC_COUNTERS] of the last launch, as its last kernel left them: 256 bytes in front of d_results */
     struct hufd_dec_result *d_results;
+    bool quiet; /* the last fetched launch listed no chunk for any kernel but the regular ones (see aws_huffman_amd_decode_plan_results) */
     /* the long items of a coder with long codes: a workgroup per 32 KiB block (dec_wide_*) */
     struct hufk_wide_item *h_wide; /* [n_wide] */
     uint32_t n_wide;

@@ -288,6 +288,17 @@ int aws_huffman_amd_decode_plan_results(
     struct aws_huffman_amd_decode_result *results,
     void *stream);
 
+/* A launch lists the chunks its regular kernels do not take (a chunk whose walks do not fall into step, that is damaged,
+ * that holds more symbols than the emit stage) for the long way -- dec_sync / dec_emit, exact for any chunk -- and for a
+ * handful of kernels in front of it that take most listed chunks several times faster (dec_sync_guess, _few, _true,
+ * dec_emit_big).  An ordinary stream lists nothing, and those four are then empty launches of ~4 us each.  The fetch of
+ * a launch's results also brings back how many chunks it listed: none, and the plan is QUIET -- its next launches go
+ * without the four, whatever they list goes the long way (the same results, a fifth of the speed for those chunks),
+ * the next fetch says so and the four are back.  A plan is not quiet until a fetch has said so, and not after a reset.
+ * (Diagnostics and tests; AWS_HUFFMAN_AMD_TEST_DECODE_ALL_KERNELS makes every launch queue all of them.) */
+AWS_COMPRESSION_API
+bool aws_huffman_amd_decode_plan_is_quiet(const struct aws_huffman_amd_decode_plan *plan);
+
 #define AWS_HUFFMAN_AMD_ROAD_TWO_PASS 0u
 #define AWS_HUFFMAN_AMD_ROAD_ONE_PASS 1u
 #define AWS_HUFFMAN_AMD_ROAD_ONE_PASS_GAVE_UP 2u
@@ -346,6 +357,7 @@ void aws_huffman_amd_testing_set_encode_road(uint32_t flags /* 0: back to the de
 #define AWS_HUFFMAN_AMD_TEST_DECODE_WIDE_FAILS 2u            /* dec_wide_* give every long item of a long-code coder up (dec_wide_fn_* take it) */
 #define AWS_HUFFMAN_AMD_TEST_DECODE_WIDE_FN_FAILS 4u         /* ... and dec_wide_fn_* as well (dec_deep takes it) */
 #define AWS_HUFFMAN_AMD_TEST_DECODE_ONE_CHUNK_A_WORKGROUP 8u /* short end-of-stream chunks do not share workgroups */
+#define AWS_HUFFMAN_AMD_TEST_DECODE_ALL_KERNELS 16u          /* every launch queues the kernels for listed chunks, whatever the plan's last fetched launch listed */
 AWS_COMPRESSION_API
 void aws_huffman_amd_testing_set_decode_road(uint32_t flags /* 0: back to the default */);
 /* read when a PLAN is made or reset: from how many items per byte of its longest item on a class of short items goes to a

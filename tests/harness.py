@@ -181,7 +181,7 @@ class PlanStats(C.Structure):
 
 # the library's testing hooks (huffman_amd.h): the ways BACK a launch carries, by the names the scenarios use
 ENCODE_ROADS = {None: 0, "three-kernel": 1, "one-pass-fails": 2}
-DECODE_ROADS = {None: 0, "long-way": 1, "wide-fails": 2, "wide-fn-fails": 4, "lean-sync": 8}
+DECODE_ROADS = {None: 0, "long-way": 1, "wide-fails": 2, "wide-fn-fails": 4, "lean-sync": 8, "all-kernels": 16}
 
 
 class encode_road:
@@ -242,6 +242,7 @@ EXPORTED_SYMBOLS = [
     "aws_huffman_amd_encode_plan_results", "aws_huffman_amd_decode_plan_new", "aws_huffman_amd_decode_plan_destroy",
     "aws_huffman_amd_decode_plan_launch", "aws_huffman_amd_decode_plan_launch_staged",
     "aws_huffman_amd_decode_plan_results", "aws_huffman_amd_decode_plan_road", "aws_huffman_amd_encode_plan_road",
+    "aws_huffman_amd_decode_plan_is_quiet",
     "aws_huffman_amd_testing_set_decode_piece_bytes",
     "aws_huffman_amd_testing_set_wide_min_bytes",
     "aws_huffman_amd_testing_set_encode_road", "aws_huffman_amd_testing_set_decode_road",
@@ -307,6 +308,8 @@ def load_product(path=None):
     _bind(lib, "aws_huffman_amd_decode_plan_results", C.c_int, [V, P(AmdDecodeResult), V])
     _bind(lib, "aws_huffman_amd_decode_plan_road", C.c_int, [V, V, P(C.c_uint32), P(C.c_uint32)])
     _bind(lib, "aws_huffman_amd_encode_plan_road", C.c_int, [V, P(C.c_uint32)])
+    if hasattr(lib, "aws_huffman_amd_decode_plan_is_quiet"):  # (profiles/tools/ab.sh loads older builds beside this one)
+        _bind(lib, "aws_huffman_amd_decode_plan_is_quiet", C.c_bool, [V])
     _bind(lib, "aws_huffman_amd_testing_set_decode_piece_bytes", None, [C.c_size_t])
     _bind(lib, "aws_huffman_amd_testing_set_wide_min_bytes", None, [C.c_uint64])
     _bind(lib, "aws_huffman_amd_testing_set_encode_road", None, [C.c_uint32])
@@ -524,6 +527,10 @@ class Engine:
         road, detail = C.c_uint32(99), (C.c_uint32 * 2)()
         assert self.lib.aws_huffman_amd_decode_plan_road(plan, None, C.byref(road), detail) == 0
         return road.value
+
+    def decode_plan_is_quiet(self, plan):
+        """The plan's last fetched launch listed no chunk: its next launch goes without the kernels for listed chunks."""
+        return bool(self.lib.aws_huffman_amd_decode_plan_is_quiet(plan))
 
     def encode_stats(self, plan):
         st = PlanStats()

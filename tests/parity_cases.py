@@ -751,6 +751,98 @@ def streams_out_of_step(w, n=260_000, seed=109, modes=(None, "long-way")):
     eng.close()
 
 
+def quiet_plans(w, n=300_000, seed=151, engine=None):
+    """A plan whose last fetched launch listed no chunk for any kernel but the regular ones is QUIET: its launches go without
+    dec_sync_guess / _few / _true / dec_emit_big.  The same plan over OTHER bytes of the same lengths -- a stream whose walks
+    never fall into step, chunks of more symbols than the emit stage holds, damage, arbitrary bytes -- sends what it lists the
+    long way: the oracle's records and bytes all the same, the fetch says that chunks were listed, and the next launch has
+    the kernels back (and "all-kernels" has them in every launch)."""
+    rng = np.random.default_rng(seed)
+    eng = engine or harness.Engine(w.product.lib, w.pcoder)
+    lens = np.array([w.table[1][i] for i in range(256)])
+    short = np.flatnonzero(lens == lens[lens > 0].min())
+    plain = [oracle_encode(w, inputs(rng, m, "uniform")) for m in (n, n // 3, 40_000)]
+    sizes = [e.size for e in plain]
+    caps = [e.size * 8 // int(lens[lens > 0].min()) + 9 for e in plain]  # (room for the densest stream of that many bytes)
+
+    def of_length(data, size):
+        enc = oracle_encode(w, data)
+        assert enc.size >= size
+        return enc[:size].copy()
+
+    def variant(kind):
+        out = [e.copy() for e in plain]
+        if kind == "one symbol":  # (every chunk of item 0 listed: its walks never fall into step)
+            out[0] = of_length(np.full(sizes[0] * 8 // 5 + 8, short[0], np.uint8), sizes[0])
+        elif kind == "short codes":  # (more symbols in a chunk than the emit stage holds)
+            out[1] = of_length(short[rng.integers(0, short.size, sizes[1] * 8 // 5 + 8)].astype(np.uint8), sizes[1])
+        elif kind == "damage":
+            out[0][sizes[0] // 2:sizes[0] // 2 + 4] = 0xFF
+        elif kind == "bytes":
+            out[2] = rng.integers(0, 256, sizes[2], dtype=np.uint8)
+        return out
+
+    offs, pos = [], 5
+    for e in plain:
+        offs.append(pos)
+        pos += e.size + int(rng.integers(0, 9))
+    enc_total = pos + 64
+    items, pos = [], 3
+    for o, e, cap in zip(offs, plain, caps):
+        items.append(dict(in_offset=o, in_len=e.size, first_bit=0, out_offset=pos, out_capacity=cap))
+        pos += cap + int(rng.integers(1, 9))
+    sym_total = pos + 64
+    d_enc, d_sym = eng.alloc(enc_total), eng.alloc(sym_total)
+    plan = eng.decode_plan(items)
+    assert eng.decode_stats(plan)["by_pieces"] == len(items)
+
+    def launch_and_check(streams, label):
+        host = np.zeros(enc_total, np.uint8)
+        want = np.full(sym_total, SENTINEL, np.uint8)
+        keys = []
+        for it, e in zip(items, streams):
+            host[it["in_offset"]:it["in_offset"] + e.size] = e
+            d = w.oracle.new_decoder(w.ocoder)
+            dst = np.full(it["out_capacity"] + 1, SENTINEL, np.uint8)
+            r = w.oracle.decode_call(d, e, 0, e.size, dst, 0, it["out_capacity"])
+            keys.append((r.rc, r.err, r.produced, r.consumed * 8 - r.state[0]))
+            want[it["out_offset"]:it["out_offset"] + it["out_capacity"]] = dst[:it["out_capacity"]]
+        eng.upload(d_enc, host)
+        eng.fill(d_sym, SENTINEL, sym_total)
+        eng.decode_launch(plan, d_enc, d_sym)
+        res = eng.decode_results(plan, len(items))
+        assert res == keys, (label, res, keys)
+        assert np.array_equal(eng.download(d_sym, sym_total), want), label
+
+    assert not eng.decode_plan_is_quiet(plan)  # (nothing fetched yet)
+    launch_and_check(plain, "plain, first launch")
+    assert eng.decode_plan_is_quiet(plan)
+    launch_and_check(plain, "plain, quiet")
+    for kind in ("one symbol", "short codes", "damage", "bytes"):
+        assert eng.decode_plan_is_quiet(plan), kind
+        streams = variant(kind)
+        launch_and_check(streams, kind + ", by a quiet plan")  # (what is listed goes the long way)
+        assert not eng.decode_plan_is_quiet(plan), kind  # (chunks were listed)
+        launch_and_check(streams, kind + ", with the kernels back")
+        assert not eng.decode_plan_is_quiet(plan), kind
+        launch_and_check(plain, "plain after " + kind)
+        assert eng.decode_plan_is_quiet(plan), kind
+        with harness.decode_road(eng.lib, "all-kernels"):
+            launch_and_check(streams, kind + ", quiet plan, every kernel queued")
+        launch_and_check(plain, "plain again after " + kind)
+    # a reset makes the plan forget
+    assert eng.decode_plan_is_quiet(plan)
+    arr = eng._decode_item_array(items[:2])
+    eng.lib.aws_huffman_amd_decode_plan_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    assert eng.lib.aws_huffman_amd_decode_plan_reset(plan, arr, 2) == 0
+    assert not eng.decode_plan_is_quiet(plan)
+    eng.lib.aws_huffman_amd_decode_plan_destroy(plan)
+    eng.free(d_enc)
+    eng.free(d_sym)
+    if engine is None:
+        eng.close()
+
+
 def walks_that_never_meet(w, seed=137, engine=None, runs=(130, 260, 420, 900), modes=(None,)):
     """Ordinary streams with a stretch of ONE long-code symbol in them whose code, rotated, is a code of the same length
     again (the test coder's symbols 255, 254, 252 ...: seven of nine rotations): a lane whose sub-chunk lies inside the

@@ -120,6 +120,10 @@ def test_streams_with_two_last_chunks(world):
     pc.streams_with_two_last_chunks(world)
 
 
+def test_quiet_plans(world):
+    pc.quiet_plans(world)
+
+
 def test_plans_made_on_the_device(world):
     pc.plans_made_on_the_device(world)
 
