@@ -1099,7 +1099,6 @@ hipError_t hufk_host::init_decode_emit(int lds_max) {
     }
     HUFK_ALLOW_BIG_LDS(10, 3)
     HUFK_ALLOW_BIG_LDS(10, 4)
-    HUFK_ALLOW_BIG_LDS(10, 5)
     HUFK_ALLOW_BIG_LDS(12, 2)
 #undef HUFK_ALLOW_BIG_LDS
     return e;
@@ -1170,8 +1169,7 @@ hipLaunchKernelGGL(                                                             
         if (lb_of_launch == 10) {
             switch (emit_sure) {
                 case 3: HUFK_LAUNCH_EMIT_PACK(10, 3); break;
-                case 4: HUFK_LAUNCH_EMIT_PACK(10, 4); break;
-                default: HUFK_LAUNCH_EMIT_PACK(10, 5); break;
+                default: HUFK_LAUNCH_EMIT_PACK(10, 4); break;
             }
         } else {
             HUFK_LAUNCH_EMIT_PACK(12, 2);
@@ -1182,15 +1180,13 @@ hipLaunchKernelGGL(                                                             
         if (e_single) {
             switch (emit_sure) {
                 case 3: HUFK_LAUNCH_EMIT_FAST(10, true, 3, e_single, tst); break;
-                case 4: HUFK_LAUNCH_EMIT_FAST(10, true, 4, e_single, tst); break;
-                default: HUFK_LAUNCH_EMIT_FAST(10, true, 5, e_single, tst); break;
+                default: HUFK_LAUNCH_EMIT_FAST(10, true, 4, e_single, tst); break;
             }
         }
         if (some_inside) {
             switch (emit_sure) {
                 case 3: HUFK_LAUNCH_EMIT_FAST(10, false, 3, a->n_chunks, st); break;
-                case 4: HUFK_LAUNCH_EMIT_FAST(10, false, 4, a->n_chunks, st); break;
-                default: HUFK_LAUNCH_EMIT_FAST(10, false, 5, a->n_chunks, st); break;
+                default: HUFK_LAUNCH_EMIT_FAST(10, false, 4, a->n_chunks, st); break;
             }
         }
     } else {
@@ -1232,8 +1228,7 @@ do {                                                                            
     } else if (lb_of_launch == 10) {
         switch (emit_sure) {
             case 3: HUFK_LAUNCH_EMIT_BIG(10, 3); break;
-            case 4: HUFK_LAUNCH_EMIT_BIG(10, 4); break;
-            default: HUFK_LAUNCH_EMIT_BIG(10, 5); break;
+            default: HUFK_LAUNCH_EMIT_BIG(10, 4); break;
         }
     } else {
         HUFK_LAUNCH_EMIT_BIG(12, 2);

@@ -486,12 +486,13 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     if (a->n_fixed_blocks && a->tables.fixed_bits) {
         (void)hipMemsetAsync(a->states, 0xFF, (size_t)a->n_items * sizeof(hufd_dec_item_state), st);
     }
-    /* the builds of the row-synchronous kernels: a decode table of up to 10 bits with 3, 4 or 5 certain steps a row (codes
-     * of up to 10, 8, 6 bits; a coder of shorter codes still has more certain steps than that: the rest are asked for),
+    /* the builds of the row-synchronous kernels: a decode table of up to 10 bits with 3 or 4 certain steps a row (codes
+     * of up to 10, 8 bits; a coder of shorter codes has more certain steps than that: the rest are asked for -- round 6
+     * took the builds with 5 out, for codes of at most 6 bits, when the kernels for a few stream ends among many chunks came in),
      * of 11 or 12 bits with 2 */
     const uint32_t lb_of_launch = a->tables.lut_bits <= 10 ? 10u : 12u;
     const uint32_t sure_of_coder = row_walk(lb_of_launch, a->tables.max_bits).sure;
-    const uint32_t sure = lb_of_launch == 10 ? (sure_of_coder > 5 ? 5u : sure_of_coder) : (sure_of_coder > 2 ? 2u : sure_of_coder);
+    const uint32_t sure = lb_of_launch == 10 ? (sure_of_coder > 4 ? 4u : sure_of_coder) : (sure_of_coder > 2 ? 2u : sure_of_coder);
     if (a->n_chunks && (a->tables.max_bits > HUFD_DEC_MAX_LUT_BITS || (lb_of_launch == 10 ? sure < 3 : sure != 2))) {
         return (int)hipErrorInvalidValue; /* (a plan has chunks only for a decode table of up to 12 bits; see row_walk for the steps) */
     }

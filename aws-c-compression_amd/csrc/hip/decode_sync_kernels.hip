@@ -420,505 +420,46 @@ __global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_kernel(
     u32 *slow_count,
     u32 *long_list,  /* the others that are not regular: dec_sync's (may be the same list as slow_list) */
     u32 *long_count) {
-
-    HUFD_STAMP(0, 0);
-    one_shared<LB> &sh = *reinterpret_cast<one_shared<LB> *>(dyn_lds);
-    const u32 ns = tb.n_states;
-    const u32 lane = threadIdx.x;
+    constexpr bool FOLLOW = false;
     const u32 c = TAIL ? wave_uniform(tail_chunks[blockIdx.x]) : blockIdx.x;
-    const hufd_chunk_rec rec = chunk_rec[c];
-    const u64 valid = rec.valid;
-    const u8 *src = d_in + rec.src_off;
-    if (!TAIL && valid < (u64)HUFD_DEC_CHUNK_BYTES + 8u) {
-        return; /* holds the end of its stream: the other instantiation's */
-    }
-    /* the lanes whose sub-chunk and the 8 bytes behind it lie inside the stream */
-    const u32 n_full = !TAIL ? HUFD_DEC_LANES : (valid >= 8u ? (u32)((valid - 8u) / HUFD_DEC_SUB_BYTES) : 0u);
-    const bool active = !TAIL || lane < n_full;
-    if (TAIL && n_full == 0 && tb.lut_bits <= HUFD_DEC_MAX_LUT_BITS) {
-        if (lane == 0) {
-            chunk_regular[c] = 3; /* fewer than 136 bytes: one thread's work in dec_sync_tail / dec_emit_tail */
-        }
-        return;
-    }
-    const one_walk ow(LB);
-    const u32 table = lds_offset_of(sh.wlut);
-    const bool eligible = n_full >= 1 && tb.lut_bits <= LB && tb.max_bits <= HUFD_DEC_MAX_LUT_BITS &&
-                          row_walk(LB, tb.max_bits).sure >= SURE && (table & ((4u << LB) - 1u)) == 0;
-    if (!eligible) {
-        if (lane == 0) {
-            chunk_regular[c] = 0;
-            long_list[atomicAdd(long_count, 1u)] = c;
-        }
-        return;
-    }
-    u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane;
-    constexpr u32 kLutPerLane = (1u << LB) / HUFD_DEC_LANES, kLutBatch = 4;
-    const auto table_share = [&](u32 j0) {
-        u32 lut_raw[kLutBatch];
-#pragma unroll
-        for (u32 j = 0; j < kLutBatch; ++j) {
-            lut_raw[j] = tb.dec_lut[(lane + (j0 + j) * HUFD_DEC_LANES) >> (LB - tb.lut_bits)];
-        }
-#pragma unroll
-        for (u32 j = 0; j < kLutBatch; ++j) {
-            sh.wlut[lane + (j0 + j) * HUFD_DEC_LANES] = one_walk::entry_of(lut_raw[j] & 0xFFu);
-        }
-    };
-    if (TAIL && lane >= kWave && (lane & ~(kWave - 1)) >= n_full) {
-        /* a wave wholly behind the stream's whole lanes: its share of the table done, it leaves: the barriers below count the waves that are still there */
-#pragma unroll
-        for (u32 j0 = 0; j0 < kLutPerLane; j0 += kLutBatch) {
-            table_share(j0);
-        }
-#pragma unroll
-        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-            cp[qq * HUFD_DEC_LANES] = 0;
-        }
-        lane_count[(u64)c * HUFD_DEC_LANES + lane] = 0;
-        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(kExitStop << 12);
-        return;
-    }
-    u32 w[kFastRows];
-    {
-        /* (TAIL: a lane behind the stream's whole lanes reads sub-chunk 0 again: words that are codes, never looked at) */
-        const u32 mine = active ? lane : 0u;
-        const unaligned_uint4 *line = reinterpret_cast<const unaligned_uint4 *>(src + (u64)mine * HUFD_DEC_SUB_BYTES);
-#pragma unroll
-        for (u32 q = 0; q < kSubWords / 4; ++q) {
-            const unaligned_uint4 v = line[q];
-            w[4 * q + 0] = v.x;
-            w[4 * q + 1] = v.y;
-            w[4 * q + 2] = v.z;
-            w[4 * q + 3] = v.w;
-        }
-        w[kSubWords] = reinterpret_cast<const unaligned_u32 *>(src + (u64)(mine + 1) * HUFD_DEC_SUB_BYTES)->x;
-    }
-#pragma unroll
-    for (u32 j0 = 0; j0 < kLutPerLane; j0 += kLutBatch) {
-        table_share(j0);
-    }
-    if (lane == 0) {
-        sh.bad = 0;
-        sh.decided0 = 0;
-        sh.moved = 0;
-        sh.bad_mine = 0;
-        /* (as loaded: the candidates' walks swap the bytes of the words they read -- swapped first, the copy's temporaries
-         * were four registers the TAIL instantiation does not have) */
-#pragma unroll
-        for (u32 r = 0; r <= kOneMaxMerge0; ++r) {
-            sh.sub0[r] = w[r];
-        }
-#pragma unroll
-        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
-            sh.wave_sum[wv] = 0; /* (TAIL: of the waves that have left) */
-        }
-    }
-#pragma unroll
-    for (u32 r = 0; r < kFastRows; ++r) {
-        w[r] = __builtin_bswap32(w[r]);
-    }
-    __syncthreads();
-    HUFD_STAMP(0, 1);
-    HUFD_STAMP(0, 2);
-
-    /* the guessed walk's states at the kept boundaries: in registers where the kernel has them to spare (inside a stream:
-     * 48 + 12 of 64), in LDS for the chunks streams end in (54) */
-    constexpr bool kKeptInRegisters = !TAIL;
-    u32 kept_r[kOneRecs + kQuarters - 1];
-#pragma unroll
-    for (u32 q = 0; q < kOneRecs + kQuarters - 1; ++q) {
-        kept_r[q] = 0;
-    }
-    auto kept_set = [&](u32 q, u32 v) {
-        if (kKeptInRegisters) {
-            kept_r[q] = v;
-        } else {
-            sh.kept[q][lane] = v;
-        }
-    };
-    auto kept_get = [&](u32 q) -> u32 { return kKeptInRegisters ? kept_r[q] : sh.kept[q][lane]; };
-
-    /* R: one walk from bit 0, a guess, over the whole sub-chunk; its state kept at a few row boundaries */
-    u32 state = ow.state_at(0);
-    bool hopeless = false; /* (the same for the wave) */
-#pragma unroll
-    for (u32 r = 0; r < kSubWords; ++r) {
-        if (!hopeless) {
-            if (one_rec_index(r) < kOneRecs) {
-                kept_set(one_rec_index(r), state);
-            }
-            if (r != 0 && r % (kSubWords / kQuarters) == 0) {
-                kept_set(kOneRecs + r / (kSubWords / kQuarters) - 1, state);
-            }
-            state = ow.template row<SURE>(state, w[r], w[r + 1], table) + 32u;
-            if (r + 1 == kOneGarbageRow) {
-                /* dozens of windows without a code in four rows: bytes that are no stream of this coder (a walk over them
-                 * steps a bit at a time) -- the long way says where the first one is */
-                hopeless = __any(active && one_walk::dead_of(state) > kOneGarbageDead);
-            }
-        }
-    }
-    const u32 last = state;
-    kept_set(kOneRecs - 1, last); /* (the boundary behind the last row: the sub-chunk's end) */
-    if (kKeptInRegisters && lane == 0) {
-        sh.kept[kOneRecs - 1][0] = last; /* (what the candidates of sub-chunk 0 ask of lane 0's walk) */
-    }
-    u32 ref_exit = ow.offset_of(last); /* (how the lane leaves: the guessed walk's way, unless the true walk never met it) */
-    bool ok = !hopeless; /* what speaks against the chunk whatever its lanes' entries are ... */
-    bool ok_mine = !active || ref_exit < ns; /* ... and what may change for a lane when the lane in front of it leaves another way */
-    sh.exit_state[lane] = ref_exit;
-    HUFD_STAMP(0, 3);
-    __syncthreads();
-    HUFD_STAMP(0, 4);
-
-    /* H: my own sub-chunk from my true entry state, until I stand where my guessed walk stood */
-    u32 entry = lane ? sh.exit_state[lane - 1] : 0u;
-    u32 count = 0, meet_row = 0;
-    u32 head_cp[kQuarters - 1] = {0, 0, 0}; /* the walk from the true entry where it enters the second, third and fourth quarter */
-    {
-        u32 st = ow.state_at(entry < ns ? entry : 0u);
-        bool met = !active || lane == 0; /* (lane 0's entry is only known to dec_scan: the candidates below) */
-        u32 h_at = 0, r_at = 0;
-        bool done = false; /* (the same for the wave) */
-        constexpr u32 kInRegisters = 24; /* the rows H walks out of the lane's registers: behind them the words come from memory again */
-#pragma unroll
-        for (u32 r = 0; r <= kInRegisters; ++r) {
-            if (!done && !hopeless) {
-                if (r != 0 && r % (kSubWords / kQuarters) == 0) {
-                    head_cp[r / (kSubWords / kQuarters) - 1] = st;
-                }
-                if (one_rec_index(r) < kOneRecs) {
-                    const u32 there = kept_get(one_rec_index(r));
-                    if (!met && ((st ^ there) & 0x3FFu) == 0) {
-                        met = true;
-                        h_at = st;
-                        r_at = there;
-                        meet_row = r;
-                    }
-                    done = __all(met);
-                    if (one_rec_index(r) == 0) {
-                        if (!done) {
-                            /* most of the wave's lanes still apart after six rows: a stream whose walks do not fall into step
-                             * (one symbol over and over) -- no regular chunk, and no more rows spent on finding that out */
-                            hopeless = __popcll(__ballot(!met)) > kWave - kWave / 8;
-                        }
-                    }
-                }
-                if (r < kInRegisters) {
-                    if (!done && !hopeless) {
-                        st = ow.template row<SURE>(st, w[r], w[r + 1], table) + 32u;
-                    }
-                }
-            }
-        }
-        if (!done && !hopeless) {
-            /* rare (a wave in a hundred): a lane still apart from its guessed walk after 24 rows.  On to the sub-chunk's end,
-             * the words from memory (kept in registers for this they cost the kernel its eight waves a SIMD); a walk that
-             * has covered the whole sub-chunk from the true entry needs the guessed one only to leave the same way. */
-            const u8 *mine = src + (u64)(active ? lane : 0u) * HUFD_DEC_SUB_BYTES;
-            u32 hi = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(mine + 4 * kInRegisters)->x);
-            for (u32 r = kInRegisters; r < kSubWords && !done; ++r) {
-                const u32 lo = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(mine + 4 * (r + 1))->x);
-                st = ow.template row<0>(st, hi, lo, table) + 32u;
-                hi = lo;
-                if (r + 1 == one_rec_row(kOneRecs - 2) || r + 1 == one_rec_row(kOneRecs - 1)) {
-                    const u32 there = r + 1 == one_rec_row(kOneRecs - 2) ? kept_get(kOneRecs - 2) : kept_get(kOneRecs - 1);
-                    if (!met && ((st ^ there) & 0x3FFu) == 0) {
-                        met = true;
-                        h_at = st;
-                        r_at = there;
-                        meet_row = r + 1;
-                    }
-                    done = __all(met);
-                }
-            }
-        }
-        if (active && lane && !hopeless && !met && entry < ns) {
-            /* Never met (a lane in some hundred thousand; the loop above has then run to the sub-chunk's end): the walk from
-             * the true entry has covered the whole sub-chunk -- the records are all its own, and it leaves as IT does, which
-             * is not how the lane behind this one thought: that one walks again below (a chunk given up for this cost the
-             * launches behind this kernel 30 us of dec_sync_guess, for two dozen chunks of the 1 GiB stream). */
-            met = true;
-            h_at = st;
-            r_at = last;
-            meet_row = kSubWords;
-            ref_exit = ow.offset_of(st);
-            sh.exit_state[lane] = ref_exit; /* (read again behind the next barrier only) */
-            sh.moved = 1;
-        }
-        if (active && lane) {
-            /* met, no window without a code on the true path (H's part, R's part), my entry a state, my exit too */
-            ok_mine = !hopeless && met && entry < ns && ref_exit < ns && one_walk::dead_of(h_at) == 0 &&
-                      one_walk::dead_of(last) == one_walk::dead_of(r_at);
-            count = one_walk::count_of(h_at) + one_walk::count_of(last) - one_walk::count_of(r_at);
-        }
-    }
-
-    HUFD_STAMP(0, 7);
-    /* What every wave has to say is said here, IN FRONT of the walks of sub-chunk 0's candidates, which are wave 0's alone
-     * and the tail of a workgroup's life (a seventh of it): the other waves used to stand at the barrier behind those walks.
-     * Now they leave their records and go -- their wave slots are the next workgroup's that much earlier.  (Records of a
-     * chunk that wave 0 then finds irregular are never looked at: chunk_regular says so, and the kernels that take the
-     * chunk write them again.  When a lane's exit moved -- rare -- everybody stays for the rounds below.) */
-    {
-        const u32 wsum0 = wave_sum(lane ? count : 0u);
-        if ((lane & (kWave - 1)) == 0) {
-            sh.wave_sum[lane / kWave] = wsum0;
-        }
-        if (!ok) {
-            sh.bad = 1;
-        }
-        if (!ok_mine) {
-            sh.bad_mine = 1;
-        }
-    }
-    __syncthreads();
-    const bool stay = sh.moved != 0; /* (the same for the workgroup) */
-    auto lane_records = [&]() {
-        if (active) {
-#pragma unroll
-            for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-                /* a checkpoint in front of the meeting row is not on the guessed walk's true part: it is taken from the walk
-                 * from the true entry, which passed it (not for lane 0, whose true entry is only known to dec_scan: its first
-                 * checkpoint may be missing, dec_emit_fast walks on through that quarter) */
-                const u32 boundary = (qq + 1) * (kSubWords / kQuarters);
-                bool have = boundary >= meet_row;
-                const u32 at_boundary = kept_get(kOneRecs + qq);
-                u32 tail = one_walk::count_of(last) - one_walk::count_of(at_boundary), bits = ow.offset_of(at_boundary);
-                if (!have && lane != 0) {
-                    tail = count - one_walk::count_of(head_cp[qq]);
-                    bits = ow.offset_of(head_cp[qq]);
-                    have = true;
-                }
-                cp[qq * HUFD_DEC_LANES] = (u16)(have ? 0x8000u | (bits << 11) | tail : 0u);
-            }
-        } else {
-            /* (TAIL) behind the whole lanes, in a wave that has some: as for the waves that left */
-#pragma unroll
-            for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-                cp[qq * HUFD_DEC_LANES] = 0;
-            }
-            lane_count[(u64)c * HUFD_DEC_LANES + lane] = 0;
-            cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)(kExitStop << 12);
-        }
-        if (TAIL && lane + 1 == n_full) {
-            tail_entry[c] = ref_exit;
-        }
-    };
-    if (!stay && lane >= kWave) {
-        if (!sh.bad && !sh.bad_mine) {
-            lane_records();
-            if (active) {
-                lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)count;
-                cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((1u << entry) | (ref_exit << 12));
-            }
-        }
-        return;
-    }
-    /* H: sub-chunk 0 from every entry state the chunk may be entered in (threads 0 .. ns-1): each dies at a window without a
-     * code (the count up to there has to be right) or meets lane 0's guessed walk -- which the wave's last thread walks
-     * AGAIN beside them, a row at a time, so that they can meet it at any row boundary (two rows on average; met at the
-     * kept boundaries only, every candidate walked six rows at least, and these walks are the tail of the workgroup's
-     * life: the other waves wait for them) */
-    u32 cand_count = 0, cand_dead = 0, meet_row0 = 0, ref_count0 = 0;
-    bool cand_reached = false;
-    u64 cand_alive = 0;
-    if (lane < kWave) {
-        constexpr u32 kTwin = kWave - 1;
-        const bool twin = lane == kTwin;
-        const u32 last0 = sh.kept[kOneRecs - 1][0];
-        u32 st = ow.state_at(lane < ns ? lane : 0u);
-        /* (an item's first chunk is only ever entered at the item's first bit: one candidate, not ns -- every chunk of
-         * BASELINE configs[3]; the other states' entries of the chunk function are never asked for) */
-        const u32 only = rec.entry_bit; /* (a scalar: the record is the same for the workgroup) */
-        bool dd = only == HUFD_NONE32 ? lane >= ns : lane != only, met = false;
-        u32 c_at = 0, r_at = 0;
-        u32 at0 = st, latest = 0; /* lane 0's walk where the last candidate met it, and the row (the same in every thread) */
-        u32 hi = __builtin_bswap32(sh.sub0[0]);
-        for (u32 r = 0; !hopeless; ++r) {
-            /* (lane 0's walk started on a guess: while it is on a wrong phase it may step over a window without a code.  A
-             * candidate that stands where that walk stands IN FRONT of such a window does not join it: it walks on by
-             * itself, the same way, and dies at that window with the count that is right) */
-            const u32 there = __shfl(st, kTwin);
-            const bool now = !twin && !dd && !met && ((st ^ there) & 0x3FFu) == 0 && one_walk::dead_of(last0) == one_walk::dead_of(there);
-            if (now) {
-                met = true;
-                c_at = st;
-                r_at = there;
-            }
-            if (__any(now)) {
-                at0 = there;
-                latest = r;
-            }
-            if (__all(dd || met || twin) || r == kSubWords) {
-                break;
-            }
-            const u32 lo = __builtin_bswap32(sh.sub0[r + 1]);
-            if (twin) {
-                st = ow.template row<SURE>(st, hi, lo, table); /* (as phase R took the row: the marks are part of the state) */
-            } else if (!dd && !met) {
-                /* the row as the other walks take it; a window without a code in it (a walk on a wrong phase: within a
-                 * row or two) and the row is taken again, step by step, for the count up to that window */
-                const u32 before = st;
-                st = ow.template row<SURE>(st, hi, lo, table);
-                if (one_walk::dead_of(st)) {
-                    const u64 pair = ((u64)hi << 32) | lo;
-                    st = before;
-                    for (;;) {
-                        const u32 e = lds_word_at(((u32)(pair >> (st & 63u)) & ow.mask) | table);
-                        if (e == one_walk::entry_of(0)) {
-                            break;
-                        }
-                        st += e;
-                    }
-                    dd = true;
-                    cand_dead = one_walk::count_of(st); /* (the step that found no code is not a symbol) */
-                }
-            }
-            st += 32u;
-            hi = lo;
-        }
-        const bool decided = !hopeless && __all(dd || met || twin);
-        cand_reached = met && lane < ns;
-        cand_alive = __ballot(cand_reached);
-        /* where the last of them met it: from that row on lane 0's walk is the true one whatever the chunk's entry */
-        meet_row0 = latest;
-        cand_count = one_walk::count_of(c_at) + one_walk::count_of(last0) - one_walk::count_of(r_at);
-        if (lane == 0) {
-            sh.decided0 = decided;
-        }
-        ok = ok && decided && cand_alive != 0;
-        if (lane == 0) {
-            meet_row = meet_row0;
-            ref_count0 = one_walk::count_of(last0) - one_walk::count_of(at0);
-        }
-    }
-
-    HUFD_STAMP(0, 5);
-    if (!ok) {
-        sh.bad = 1; /* (wave 0: what the candidates' walks said) */
-    }
-    if (stay) {
-        __syncthreads(); /* (everybody is still here) */
-    }
-    if (!stay && sh.bad_mine) {
-        sh.bad = 1; /* (every thread that gets here writes the same) */
-    }
-    if (stay && !sh.bad) {
-        /* Rare.  A lane's exit moved: the lane behind it walks its sub-chunk again from the entry that is now known, the
-         * words from memory, until it stands where its guessed walk stood -- or to the end, and then ITS exit may move.
-         * A few rounds of that, one lane at work in each; a chunk that is not settled by then is not regular. */
-        constexpr u32 kRounds = 4;
-        u32 round = 0;
-        for (; round < kRounds; ++round) {
-            __syncthreads(); /* (everybody has read `moved`) */
-            if (lane == 0) {
-                sh.moved = 0;
-            }
-            __syncthreads();
-            const u32 entry_now = lane ? sh.exit_state[lane - 1] : 0u;
-            if (active && lane && entry_now != entry) {
-                entry = entry_now;
-                bool fine = entry < ns;
-                if (fine) {
-                    const u8 *mine = src + (u64)lane * HUFD_DEC_SUB_BYTES;
-                    u32 st = ow.state_at(entry), h_at = 0, r_at = 0;
-                    bool met = false;
-                    u32 hi = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(mine)->x);
-                    for (u32 r = 0;; ++r) {
-#pragma unroll
-                        for (u32 qq = 0; qq + 1 < kQuarters; ++qq) {
-                            head_cp[qq] = r == (qq + 1) * (kSubWords / kQuarters) ? st : head_cp[qq];
-                        }
-                        const u32 j = one_rec_index(r);
-                        u32 there = 0;
-#pragma unroll
-                        for (u32 q = 0; q < kOneRecs; ++q) {
-                            there = j == q ? kept_get(q) : there;
-                        }
-                        if (j < kOneRecs && ((st ^ there) & 0x3FFu) == 0) {
-                            met = true;
-                            h_at = st;
-                            r_at = there;
-                            meet_row = r;
-                        }
-                        if (met || r == kSubWords) {
-                            break;
-                        }
-                        const u32 lo = __builtin_bswap32(reinterpret_cast<const unaligned_u32 *>(mine + 4 * (r + 1))->x);
-                        st = ow.template row<0>(st, hi, lo, table) + 32u;
-                        hi = lo;
-                    }
-                    if (!met) {
-                        h_at = st;
-                        r_at = last;
-                        meet_row = kSubWords;
-                    }
-                    const u32 exit_now = met ? ow.offset_of(last) : ow.offset_of(st);
-                    if (exit_now != ref_exit) {
-                        ref_exit = exit_now;
-                        sh.exit_state[lane] = exit_now;
-                        sh.moved = 1;
-                    }
-                    fine = ref_exit < ns && one_walk::dead_of(h_at) == 0 && one_walk::dead_of(last) == one_walk::dead_of(r_at);
-                    count = one_walk::count_of(h_at) + one_walk::count_of(last) - one_walk::count_of(r_at);
-                }
-                ok_mine = fine;
-            }
-            __syncthreads();
-            if (!sh.moved) {
-                break;
-            }
-        }
-        if (round == kRounds || !ok_mine) {
-            sh.bad = 1; /* (a lane whose first walk went wrong on a wrong entry and was never asked to walk again: its entry stood) */
-        }
-        const u32 wsum_now = wave_sum(lane ? count : 0u);
-        if ((lane & (kWave - 1)) == 0) {
-            sh.wave_sum[lane / kWave] = wsum_now;
-        }
-        __syncthreads();
-    }
-    if (sh.bad) {
-        if (lane == 0) {
-            chunk_regular[c] = 0;
-            if (TAIL || !sh.decided0) {
-                long_list[atomicAdd(long_count, 1u)] = c;
-            } else {
-                slow_list[atomicAdd(slow_count, 1u)] = c;
-            }
-        }
-        return;
-    }
-
-    /* the tables dec_scan and dec_emit read (the regular chunks' format) */
-    u16 *fn_out = fn_tab + (u64)c * ns * HUFD_DEC_LANES;
-    lane_records();
-    if (active) {
-        const u32 total = lane ? count : ref_count0; /* (lane 0: from where its walk is the true one) */
-        lane_count[(u64)c * HUFD_DEC_LANES + lane] = (u16)total;
-        cp[(kQuarters - 1) * HUFD_DEC_LANES] = (u16)((lane ? 1u << entry : (u32)cand_alive) | (ref_exit << 12));
-    }
-    if (lane == 0) {
-        chunk_regular[c] = TAIL ? 2 : 1;
-    }
-    if (lane < ns) {
-        u32 rest = 0;
-#pragma unroll
-        for (u32 wv = 0; wv < HUFD_DEC_LANES / kWave; ++wv) {
-            rest += sh.wave_sum[wv];
-        }
-        const u32 first_exit = sh.exit_state[0];
-        const u32 last_exit = sh.exit_state[HUFD_DEC_LANES - 1];
-        fn_out[(u64)lane * HUFD_DEC_LANES] =
-            cand_reached ? fn_pack(false, first_exit, cand_count & 0x7FFu) : fn_pack(true, 0, cand_dead);
-        /* (TAIL: symbols of the whole lanes only, and no exit yet: dec_sync_tail adds the stream's last symbols and how it ends) */
-        chunk_fn[(u64)c * ns + lane] =
-            cand_reached ? wide_pack(false, TAIL ? 0u : last_exit, cand_count + rest) : wide_pack(true, 0, cand_dead);
-    }
-    HUFD_STAMP(0, 6);
+#include "decode_sync_one_body.inc"
 }
+
+/*
+ * A launch with a FEW chunks that streams end in among many inside streams (one long stream: one): the grid's first
+ * `n_tail` workgroups take those -- each with the careful walk over its stream's last symbols at its end (FOLLOW) --, the
+ * others the chunks inside streams.  Kernels of their own for the few (dec_sync_one<TAIL> and, behind it, dec_sync_tail) are
+ * one workgroup's work each, one after the other a fifth of the big kernel's time: they ran beside it on a second stream,
+ * forked off the launch's and joined again -- four commands on the launch's stream, ~4 us each, in every decode.
+ */
+template <u32 LB, u32 SURE>
+__global__ __launch_bounds__(HUFD_DEC_LANES, 8) void dec_sync_one_mixed_kernel(
+    hufd_tables tb,
+    const hufd_chunk_rec *chunk_rec,
+    const u32 *tail_chunks,
+    u32 n_tail,
+    const u8 *d_in,
+    u16 *fn_tab,
+    u16 *cp_tab,
+    u32 *chunk_fn,
+    u16 *lane_count,
+    u8 *chunk_regular,
+    u32 *tail_entry,
+    u32 *slow_list,
+    u32 *slow_count,
+    u32 *long_list,
+    u32 *long_count) {
+    if (blockIdx.x < n_tail) {
+        constexpr bool TAIL = true, FOLLOW = true;
+        const u32 c = wave_uniform(tail_chunks[blockIdx.x]);
+#include "decode_sync_one_body.inc"
+    } else {
+        constexpr bool TAIL = false, FOLLOW = false;
+        const u32 c = blockIdx.x - n_tail;
+#include "decode_sync_one_body.inc"
+    }
+}
+
 
 /* ------------------------------------------------------------------ decode: sync, several short end-of-stream chunks a workgroup */
 
@@ -1927,7 +1468,11 @@ void hufk_host::decode_sync_stage(const struct hufk_decode_args *a, hipStream_t 
      * and, one after the other behind the big ones, cost a tenth of the decode time in launch and drain.  They run on
      * a second stream of the engine's, beside the big kernels, forked off and joined with events. */
     /* (not for a launch of a few chunks: the fork and the join are four commands, ~30 us of a small call) */
-    const bool beside = some_inside && a->n_tail && a->side_stream && a->fork_event && a->join_event &&
+    /* Since round 6 the few go INTO the big kernel's grid, as its first workgroups, each with its stream's last symbols
+     * behind it (dec_sync_one_mixed_kernel): no second stream, no fork, no join -- four commands of ~4 us less on the
+     * launch's stream.  (`tails_apart`, the tests': the kernels of their own, as for a launch of many such chunks.) */
+    const bool folded = hufk_host::tails_are_folded(a);
+    const bool beside = !folded && some_inside && a->n_tail && a->side_stream && a->fork_event && a->join_event &&
                         (uint64_t)a->n_tail * 8 <= a->n_chunks && a->n_chunks >= kBesideMinChunks;
     hipStream_t tst = beside ? (hipStream_t)a->side_stream : st;
     if (beside) {
@@ -1942,21 +1487,27 @@ void hufk_host::decode_sync_stage(const struct hufk_decode_args *a, hipStream_t 
     const uint32_t n_packed = pack ? a->n_tail_narrow : 0u, n_single = a->n_tail - n_packed;
     const u32 *single_chunks = a->tail_chunks + n_packed;
 #define HUFK_LAUNCH_SYNC_LEAN(LBV, SUREV)                                                                               \
-if (n_packed) {                                                                                                    \
+if (folded) {                                                                                                      \
+    hipLaunchKernelGGL(                                                                                            \
+        (dec_sync_one_mixed_kernel<LBV, SUREV>), dim3(a->n_chunks + a->n_tail), dim3(HUFD_DEC_LANES),              \
+        (uint32_t)sizeof(one_shared<LBV>), st, a->tables, a->chunk_rec, a->tail_chunks, a->n_tail,                  \
+        (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
+        a->slow_list, slow_count, lean_long_list, lean_long_count);                                                \
+} else if (n_packed) {                                                                                                    \
     hipLaunchKernelGGL(                                                                                            \
         (dec_sync_pack_kernel<LBV, SUREV>), dim3((n_packed + pack_slots - 1) / pack_slots), dim3(HUFD_DEC_LANES),   \
         (uint32_t)sizeof(pack_shared<LBV>), tst, a->tables, a->chunk_rec, a->tail_chunks, n_packed, pack_width,     \
         (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
         lean_long_list, lean_long_count);                                                                          \
 }                                                                                                                  \
-if (n_single) {                                                                                                    \
+if (!folded && n_single) {                                                                                         \
     hipLaunchKernelGGL(                                                                                            \
         (dec_sync_one_kernel<LBV, SUREV, true>), dim3(n_single), dim3(HUFD_DEC_LANES),                              \
         (uint32_t)sizeof(one_shared<LBV>), tst, a->tables, a->chunk_rec, single_chunks,                             \
         (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->lane_count, a->chunk_regular, a->tail_entry,     \
         a->slow_list, slow_count, lean_long_list, lean_long_count);                                                \
 }                                                                                                                  \
-if (some_inside) {                                                                                                 \
+if (!folded && some_inside) {                                                                                      \
     hipLaunchKernelGGL(                                                                                            \
         (dec_sync_one_kernel<LBV, SUREV, false>), dim3(a->n_chunks), dim3(HUFD_DEC_LANES),                          \
         (uint32_t)sizeof(one_shared<LBV>), st, a->tables, a->chunk_rec, a->tail_chunks,                             \
@@ -1966,14 +1517,13 @@ if (some_inside) {                                                              
     if (lb_of_launch == 10) {
         switch (sure) {
             case 3: HUFK_LAUNCH_SYNC_LEAN(10, 3); break;
-            case 4: HUFK_LAUNCH_SYNC_LEAN(10, 4); break;
-            default: HUFK_LAUNCH_SYNC_LEAN(10, 5); break;
+            default: HUFK_LAUNCH_SYNC_LEAN(10, 4); break;
         }
     } else {
         HUFK_LAUNCH_SYNC_LEAN(12, 2);
     }
 #undef HUFK_LAUNCH_SYNC_LEAN
-    if (a->n_tail) {
+    if (a->n_tail && !folded) {
         /* the last symbols of every stream, a thread each; then the chunk functions are complete */
         const uint32_t lds = (uint32_t)sizeof(tail_lds) + (2u << a->tables.lut_bits);
         hipLaunchKernelGGL(
@@ -2000,8 +1550,7 @@ hipLaunchKernelGGL(                                                             
         if (lb_of_launch == 10) {
             switch (sure) {
                 case 3: HUFK_LAUNCH_SYNC_GUESS(10, 3); break;
-                case 4: HUFK_LAUNCH_SYNC_GUESS(10, 4); break;
-                default: HUFK_LAUNCH_SYNC_GUESS(10, 5); break;
+                default: HUFK_LAUNCH_SYNC_GUESS(10, 4); break;
             }
         } else {
             HUFK_LAUNCH_SYNC_GUESS(12, 2);

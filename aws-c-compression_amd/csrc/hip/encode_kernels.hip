@@ -1505,15 +1505,6 @@ constexpr u32 kPackWaves = 8; /* waves (= independent tiles in flight) per workg
 constexpr u32 kPackThreads = kPackWaves * kWave;
 constexpr u32 kPackTabBytes = 256 * 32 * 4;
 
-/* lanes of a wave take turns in program order: nothing on the GPU, a rendezvous of the wave's fibers under tests/emu */
-__device__ __forceinline__ void wave_step() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_wave_barrier();
-#else
-    (void)__ballot(1);
-#endif
-}
-
 __device__ __forceinline__ u32 funnel(u32 hi, u32 lo, u32 shift /* 0..31 */) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_alignbit(hi, lo, shift);

@@ -128,6 +128,8 @@ struct hufk_decode_args {
     uint32_t n_tail_narrow;    /* the first so many of tail_chunks have at most HUFD_DEC_PACK_LANES whole lanes: they may share workgroups */
     uint32_t one_chunk_a_workgroup; /* 1: the chunks streams end in get a workgroup each, however short and many (tests: the road a plan of
                                      * few such chunks takes, for a plan of many) */
+    uint32_t tails_apart;           /* 1: ... and kernels of their own even where they are few among many chunks inside streams (tests:
+                                     * such a launch folds them into the big kernels' grids) */
     void **stage_events; /* NULL, or 4 hipEvent_t: before sync, after sync, after scan, after emit */
 };
 

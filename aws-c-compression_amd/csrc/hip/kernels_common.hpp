@@ -135,6 +135,16 @@ __device__ __forceinline__ u32 round16(u32 x) {
 
 /* ------------------------------------------------------------------ wave / block primitives */
 
+/* lanes of a wave take turns in program order (what one lane wrote to LDS, another reads behind this): nothing on the GPU
+ * but a line the compiler does not move LDS accesses across, a rendezvous of the wave's fibers under tests/emu */
+__device__ __forceinline__ void wave_step() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_wave_barrier();
+#else
+    (void)__ballot(1);
+#endif
+}
+
 __device__ __forceinline__ u32 wave_inclusive_sum(u32 v, u32 lane) {
 #pragma unroll
     for (u32 d = 1; d < kWave; d <<= 1) {

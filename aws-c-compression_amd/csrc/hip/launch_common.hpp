@@ -55,10 +55,16 @@ inline void stage_mark(void **events, int index, hipStream_t st) {
 
 constexpr uint32_t kBesideMinChunks = 1024; /* launches of fewer chunks keep to one stream */
 
+/* a FEW chunks that streams end in among many inside streams (one long stream: one): they are workgroups of the big
+ * kernels' own grids (dec_sync_one_mixed_kernel, dec_emit_fast_mixed_kernel), not launches of their own */
+inline bool tails_are_folded(const struct hufk_decode_args *a) {
+    return a->n_tail && a->n_tail < a->n_chunks && (uint64_t)a->n_tail * 8 <= a->n_chunks && !a->tails_apart;
+}
+
 /* which builds of the row-synchronous kernels a launch takes, and what its sync stage tells the stages behind it */
 struct decode_launch_state {
     uint32_t lb;   /* 10 or 12: the decode table's bits as compiled */
-    uint32_t sure; /* certain steps a row as compiled: 3, 4, 5 (10-bit tables) or 2 (12-bit) */
+    uint32_t sure; /* certain steps a row as compiled: 3, 4 (10-bit tables) or 2 (12-bit) */
     bool few;      /* dec_sync_few ran: dec_sync_true follows behind the scan */
 };
 

@@ -1623,8 +1623,11 @@ static int dec_plan_fill(
         p->stats.by_workgroup = eng->tables.deep_entries ? deep - n_wide : 0;
         p->stats.by_pieces = n_cut;
         p->stats.pieces = n_chunks;
-        p->stats.end_pieces_packed = packs ? narrow : 0;
-        p->stats.end_pieces_single = tail - p->stats.end_pieces_packed;
+        /* (a few among many chunks inside streams: workgroups of the big kernels' own grids -- hufk_host::tails_are_folded) */
+        const bool folded = tail && tail < n_chunks && (uint64_t)tail * 8 <= n_chunks;
+        p->stats.end_pieces_folded = folded ? tail : 0;
+        p->stats.end_pieces_packed = packs && !folded ? narrow : 0;
+        p->stats.end_pieces_single = tail - p->stats.end_pieces_packed - p->stats.end_pieces_folded;
         p->stats.empty = n_items - tiny - deep - fixed_items - n_cut;
     }
     return AWS_OP_SUCCESS;
@@ -1797,8 +1800,10 @@ static int dec_plan_fill_on_device(struct aws_huffman_amd_decode_plan *p, const 
         p->stats.by_wave = coop;
         p->stats.by_pieces = t.totals[7];
         p->stats.pieces = n_chunks;
-        p->stats.end_pieces_packed = packs ? narrow : 0;
-        p->stats.end_pieces_single = narrow + wide - p->stats.end_pieces_packed;
+        const bool folded = narrow + wide && narrow + wide < n_chunks && (narrow + wide) * 8 <= n_chunks;
+        p->stats.end_pieces_folded = folded ? narrow + wide : 0;
+        p->stats.end_pieces_packed = packs && !folded ? narrow : 0;
+        p->stats.end_pieces_single = narrow + wide - p->stats.end_pieces_packed - p->stats.end_pieces_folded;
         p->stats.empty = n_items - tiny - coop - t.totals[7];
     }
     e = plan_mark_done(&p->done_event, &p->done_on_engine_stream, eng, stream); /* (as enc_plan_fill_on_device) */
@@ -1926,6 +1931,7 @@ int aws_huffman_amd_decode_plan_launch_staged(
     {
         const uint32_t road = testing_decode_road();
         a.one_chunk_a_workgroup = (road & AWS_HUFFMAN_AMD_TEST_DECODE_ONE_CHUNK_A_WORKGROUP) != 0;
+        a.tails_apart = (road & AWS_HUFFMAN_AMD_TEST_DECODE_TAILS_APART) != 0;
         /* dec_wide_* give every long item of a coder with long codes up: dec_wide_fn_*, the road for such an item by
          * transfer functions, takes it -- or gives it up as well, and dec_deep takes it (the ways back) */
         a.wide_fails = road & AWS_HUFFMAN_AMD_TEST_DECODE_WIDE_FN_FAILS ? 2u : (road & AWS_HUFFMAN_AMD_TEST_DECODE_WIDE_FAILS ? 1u : 0u);

@@ -338,6 +338,8 @@ struct aws_huffman_amd_plan_stats {
     uint64_t end_pieces_packed; /* decode: chunks a stream ends in that share a workgroup with others (dec_sync_pack) ... */
     uint64_t end_pieces_single; /* ... and that have one of their own */
     uint64_t empty;           /* items with nothing to do */
+    uint64_t end_pieces_folded; /* decode: chunks a stream ends in that are workgroups of the big kernels' own grids (a few among
+                                 * many chunks inside streams: one long stream's one) */
 };
 AWS_COMPRESSION_API
 int aws_huffman_amd_encode_plan_stats(const struct aws_huffman_amd_encode_plan *plan, struct aws_huffman_amd_plan_stats *stats);
@@ -357,6 +359,7 @@ void aws_huffman_amd_testing_set_encode_road(uint32_t flags /* 0: back to the de
 #define AWS_HUFFMAN_AMD_TEST_DECODE_WIDE_FAILS 2u            /* dec_wide_* give every long item of a long-code coder up (dec_wide_fn_* take it) */
 #define AWS_HUFFMAN_AMD_TEST_DECODE_WIDE_FN_FAILS 4u         /* ... and dec_wide_fn_* as well (dec_deep takes it) */
 #define AWS_HUFFMAN_AMD_TEST_DECODE_ONE_CHUNK_A_WORKGROUP 8u /* short end-of-stream chunks do not share workgroups */
+#define AWS_HUFFMAN_AMD_TEST_DECODE_TAILS_APART 32u          /* a few end-of-stream chunks among many chunks inside streams: kernels of their own, not workgroups of the big kernels */
 #define AWS_HUFFMAN_AMD_TEST_DECODE_ALL_KERNELS 16u          /* every launch queues the kernels for listed chunks, whatever the plan's last fetched launch listed */
 AWS_COMPRESSION_API
 void aws_huffman_amd_testing_set_decode_road(uint32_t flags /* 0: back to the default */);

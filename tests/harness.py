@@ -173,7 +173,7 @@ class PlanStats(C.Structure):
     """struct aws_huffman_amd_plan_stats: how a plan's items are taken (which kernels an item goes through)."""
     _fields_ = [(name, C.c_uint64) for name in (
         "items", "thread_limit", "by_thread", "by_wave", "by_workgroup", "by_blocks", "by_pieces", "pieces",
-        "end_pieces_packed", "end_pieces_single", "empty")]
+        "end_pieces_packed", "end_pieces_single", "empty", "end_pieces_folded")]
 
     def as_dict(self):
         return {name: int(getattr(self, name)) for name, _ in self._fields_}
@@ -181,7 +181,7 @@ class PlanStats(C.Structure):
 
 # the library's testing hooks (huffman_amd.h): the ways BACK a launch carries, by the names the scenarios use
 ENCODE_ROADS = {None: 0, "three-kernel": 1, "one-pass-fails": 2}
-DECODE_ROADS = {None: 0, "long-way": 1, "wide-fails": 2, "wide-fn-fails": 4, "lean-sync": 8, "all-kernels": 16}
+DECODE_ROADS = {None: 0, "long-way": 1, "wide-fails": 2, "wide-fn-fails": 4, "lean-sync": 8, "all-kernels": 16, "tails-apart": 32}
 
 
 class encode_road:

@@ -751,6 +751,56 @@ def streams_out_of_step(w, n=260_000, seed=109, modes=(None, "long-way")):
     eng.close()
 
 
+def few_ends_among_many_chunks(w, n=330_000, seed=157, engine=None, modes=(None, "tails-apart")):
+    """Long items (nine chunks and more each): the FEW chunks such a plan's streams end in are workgroups of the big kernels'
+    own grids, the stream's last symbols followed by the workgroup itself (dec_sync_one_mixed_kernel) -- "tails-apart": kernels
+    of their own, as for a plan of many such chunks.  Ends of every kind: fewer than 8 bytes in the last chunk, 8 .. 135 (one
+    thread's work), a lane or two more, nearly a whole chunk, exactly a whole chunk; cut inside a code, damaged in the last
+    bytes, damaged in front of them, arbitrary bytes at the end, short of room, entered inside a byte."""
+    rng = np.random.default_rng(seed)
+    eng = engine or harness.Engine(w.product.lib, w.pcoder)
+    data = inputs(rng, n, "uniform")
+    enc = oracle_encode(w, data)
+    chunk = 32768
+    k = 9
+    assert enc.size > (k + 1) * chunk + 6000, enc.size
+    batches = []
+    ends = [0, 1, 7, 8, 9, 100, 135, 136, 137, 263, 264, 300, 5000, chunk - 129, chunk - 1]
+    streams = [(enc[:k * chunk + e].copy(), 0, n) for e in ends]
+    streams.append((enc.copy(), 0, n))  # (whole: ends with its padding)
+    batches.append(("cuts", streams, 1))
+    streams = []
+    for e in (50, 135, 200, 700, 9000):
+        cut = enc[:k * chunk + e].copy()
+        for back in (3, 40, 140, 400):  # (damage in the stream's last bytes, in the lane in front of them, further in front)
+            if back < cut.size:
+                bad = cut.copy()
+                bad[-back:-back + 2 if back > 2 else None] = 0xFF
+                streams.append((bad, 0, n))
+        noise = cut.copy()
+        noise[-min(e, 120):] = rng.integers(0, 256, min(e, 120), dtype=np.uint8)
+        streams.append((noise, 0, n))
+    batches.append(("damage", streams, 2))
+    whole_syms = n
+    streams = [(enc[:k * chunk + 200].copy(), 0, cap) for cap in (n // 2, 280_000, 290_000, 5)]
+    streams += [(enc[5:k * chunk + 5 + e].copy(), 3, n) for e in (60, 135, 2000)]
+    streams += [(enc.copy(), 0, whole_syms - 1), (enc.copy(), 0, whole_syms)]
+    batches.append(("room and first bits", streams, 2))
+    # (such a plan says so: three streams of ten chunks -- three ends among thirty chunks; one of two chunks: not a few among many)
+    probe = eng.decode_plan([dict(in_offset=i * 11 * chunk, in_len=k * chunk + 200, out_offset=i * n, out_capacity=n) for i in range(3)])
+    st = eng.decode_stats(probe)
+    assert st["end_pieces_folded"] == 3 and st["end_pieces_single"] == 0 and st["end_pieces_packed"] == 0, st
+    eng.lib.aws_huffman_amd_decode_plan_destroy(probe)
+    probe = eng.decode_plan([dict(in_offset=0, in_len=chunk + 200, out_offset=0, out_capacity=n)])
+    st = eng.decode_stats(probe)
+    assert st["end_pieces_folded"] == 0 and st["end_pieces_single"] == 1, st
+    eng.lib.aws_huffman_amd_decode_plan_destroy(probe)
+    for label, streams, kinds in batches:
+        decode_items_like_the_oracle(w, eng, w.ocoder, streams, rng, label, modes=modes, kinds=kinds)
+    if engine is None:
+        eng.close()
+
+
 def quiet_plans(w, n=300_000, seed=151, engine=None):
     """A plan whose last fetched launch listed no chunk for any kernel but the regular ones is QUIET: its launches go without
     dec_sync_guess / _few / _true / dec_emit_big.  The same plan over OTHER bytes of the same lengths -- a stream whose walks

@@ -97,6 +97,10 @@ def test_streams_with_two_last_chunks(world):
     pc.streams_with_two_last_chunks(world)
 
 
+def test_few_ends_among_many_chunks(world):
+    pc.few_ends_among_many_chunks(world)
+
+
 def test_quiet_plans(world):
     pc.quiet_plans(world, n=150_000)
 
