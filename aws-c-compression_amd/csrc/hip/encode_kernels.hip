@@ -2008,7 +2008,14 @@ struct op_tile {
  * ask, nobody behind it to tell -- the same turn (look-ups, octs, scan, image, last byte, copy-out, the note at a capacity
  * edge) without the look-back.  As tiles of the stream's kernel a 2 KiB item was FOUR turns (a segment is four tiles,
  * three of them empty, each waiting for its offsets like any tile): 65 536 of them took as long as 1 GiB of whole tiles. */
-template <u32 NW, bool SOLO = false> /* NW: words an oct can touch: 4 for codes of at most 12 bits, 5 up to 15 */
+/* ORDERED: the way back.  Tiles by TICKET (one counter, a draw a tile) instead of by rule: a tile then only ever waits for
+ * tiles that were drawn before it, by waves that run -- no wait can last for ever whatever share of the grid is resident, so
+ * none is bounded and nobody gives up.  A word handing out tickets is slow (~90 a microsecond: a 1 GiB stream's 262 144
+ * tiles take 3 ms, five times the kernel by rule), which is why this is not the first kernel of a launch but the one
+ * queued behind it, looking at the word a wave of the first raises when a wait of its ran out (`gate`: an empty launch
+ * otherwise) and doing the launch over with look-back words of its own.  (Rounds 3-5 had the three-kernel road there:
+ * four empty launches of ~4 us behind every encode.) */
+template <u32 NW, bool SOLO = false, bool ORDERED = false> /* NW: words an oct can touch: 4 for codes of at most 12 bits, 5 up to 15 */
 __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
     hufd_tables tb,
     const hufd_enc_item *__restrict__ items,
@@ -2026,9 +2033,16 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
     hufd_enc_result *__restrict__ results, /* the tile with the capacity edge leaves a note for enc_finish_kernel here */
     const u8 *__restrict__ null_tile /* kTileBytes readable bytes: what a wave "prefetches" when no tile follows */,
     u32 fail_tile /* a tile whose wave is to give up (tests of the way back); HUFD_NONE32: none */,
-    const u32 *__restrict__ solo_items = nullptr /* SOLO: the items, one tile each */,
+    const u32 *__restrict__ solo_items = nullptr /* SOLO: the items, one tile each.  ORDERED: the word that says whether the
+                                                  * launch's first one-pass kernel gave up (else this one has nothing to do) --
+                                                  * in this place because a parameter more costs the kernel by rule a vector
+                                                  * register and eighteen scalar ones parked in vector lanes (measured: 8 us) */,
     u32 n_solo = 0) {
 
+    static_assert(!(SOLO && ORDERED), "items a wave takes whole wait for nobody");
+    if (ORDERED && solo_items[0] == 0) {
+        return;
+    }
     HUFD_STAMP_DECL
     HUFD_STAMP_ZERO;
     u32 *tab = reinterpret_cast<u32 *>(dyn_lds); /* [256][32] */
@@ -2116,7 +2130,7 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
                 if (__all((b >> 40) == kOpGroupTiles)) {
                     break;
                 }
-                if (++spins > kOpSpinLimit || uniform32(word_load_now(&ctl[1])) != 0) {
+                if (!ORDERED && (++spins > kOpSpinLimit || uniform32(word_load_now(&ctl[1])) != 0)) {
                     if (lane == 0) {
                         ctl[1] = 1; /* (the waves that wait for this base give up in their turn) */
                     }
@@ -2142,7 +2156,16 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
     /* tiles in turn over the packing waves of the grid: the tiles a tile waits for belong to this turn or an earlier
      * one, so to the running waves as long as the whole grid is resident (the launch sizes it so) */
     const u32 stride = gridDim.x * kPackWaves - (SOLO ? 0u : 1u);
-    u32 t_new = SOLO ? (blockIdx.x * kPackWaves + wave) * kTilesPerSeg : blockIdx.x * kPackWaves + wave - (blockIdx.x ? 1u : 0u);
+    /* ORDERED: the next ticket of the launch's counter (ctl[0]), the same in every lane */
+    auto draw = [&]() -> u32 {
+        u32 ticket = 0;
+        if (lane == 0) {
+            ticket = atomicAdd(&ctl[0], 1u);
+        }
+        return uniform32(ticket);
+    };
+    u32 t_new = ORDERED ? draw()
+                        : (SOLO ? (blockIdx.x * kPackWaves + wave) * kTilesPerSeg : blockIdx.x * kPackWaves + wave - (blockIdx.x ? 1u : 0u));
     if (t_new >= n_tiles) {
         return;
     }
@@ -2150,6 +2173,9 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
      * of the wave's next item -- the wave packs its item's tiles one after the other and knows the bits in front of each
      * (solo_bits), which is all the look-back would tell it */
     auto next_tile = [&](const op_tile &d) -> u32 {
+        if (ORDERED) {
+            return draw();
+        }
         if (!SOLO) {
             return d.t + stride;
         }
@@ -2234,7 +2260,7 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         const u32 since = old.t - old.item_first_tile; /* tiles of my item in front of me */
         const bool near = since <= p;
         u64 ib = (old.first_tile || near) ? kOpReady : (seg.item == base_item ? base_value : ib_raw);
-        bool gave_up = !SOLO && old.t == fail_tile;
+        bool gave_up = !SOLO && !ORDERED && old.t == fail_tile;
         for (u32 spins = 0; !gave_up && !SOLO; ++spins) {
             const bool there = (a & kOpTileReady) != 0 && (b >> 40) == kOpGroupTiles && (rb & kOpReady) != 0 &&
                                (ib & kOpReady) != 0;
@@ -2255,7 +2281,7 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
                 HUFD_STAMP_COUNT(6, spins);
                 break;
             }
-            if (spins > kOpSpinLimit || uniform32(word_load_now(&ctl[1])) != 0) {
+            if (!ORDERED && (spins > kOpSpinLimit || uniform32(word_load_now(&ctl[1])) != 0)) {
                 gave_up = true; /* (or somebody else has: the launch is redone anyway) */
                 break;
             }
@@ -2275,7 +2301,7 @@ __global__ __launch_bounds__(kPackThreads, 4) void enc_onepass_kernel(
         }
         if (gave_up) {
             if (lane == 0) {
-                ctl[1] = 1; /* the kernels of the three-kernel road, queued behind this one, see it and do the launch over */
+                ctl[1] = 1; /* the ORDERED kernel, queued behind this one, sees it and does the launch over */
             }
             return false;
         }
@@ -2665,10 +2691,16 @@ __global__ __launch_bounds__(256) void enc_finish_kernel(
                * item short of room, what of it was consumed (not in a length query: nothing was packed) */,
     uint4 *clear_from = nullptr /* the look-back words of the launch (the packing kernel is through with them), ... */,
     u64 clear_vec16 = 0         /* ... so many 16-byte pieces: cleared here for the plan's next launch, whatever road this one took */,
-    u32 *ctl_next = nullptr     /* the other set of control words: the next launch's */) {
+    u32 *ctl_next = nullptr     /* the other set of control words: the next launch's */,
+    uint4 *clear_again = nullptr /* the way back's own look-back words, as many: cleared when the way back ran (`ran_again`) */,
+    const u32 *ran_again = nullptr) {
 
+    const bool again = clear_again && ran_again[0] != 0;
     for (u64 k = (u64)blockIdx.x * kFinishItems + threadIdx.x; k < clear_vec16; k += (u64)gridDim.x * kFinishItems) {
         clear_from[k] = uint4{0, 0, 0, 0};
+        if (again) {
+            clear_again[k] = uint4{0, 0, 0, 0};
+        }
     }
     if (ctl_next && blockIdx.x == 0 && threadIdx.x < 8) {
         ctl_next[threadIdx.x] = 0;
@@ -2731,6 +2763,7 @@ constexpr uint32_t kOnepassSgprs = 106;
  * and a gap behind it. */
 struct onepass_layout {
     uint64_t ctl, tile_agg, group_acc, round_base, item_base, null_tile, bytes;
+    uint64_t again; /* from tile_agg to the same word of the way back's own set of look-back words (enc_onepass<.., ORDERED>) */
 };
 
 static onepass_layout onepass_layout_of(uint64_t n_segs, uint64_t n_items) {
@@ -2744,7 +2777,8 @@ static onepass_layout onepass_layout_of(uint64_t n_segs, uint64_t n_items) {
     l.round_base = l.group_acc + groups * 8 * kOpGroupStride;
     l.item_base = l.round_base + (rounds + 1) * 8;
     l.null_tile = (l.item_base + n_items * 8 + 15) & ~15ull;
-    l.bytes = l.null_tile + kTileBytes;
+    l.again = l.null_tile + kTileBytes - l.tile_agg; /* (a multiple of 16) */
+    l.bytes = l.tile_agg + 2 * l.again - kTileBytes;
     return l;
 }
 
@@ -2768,7 +2802,8 @@ hipError_t hufk_host::init_encode(int lds_max) {
         reinterpret_cast<const void *>(&enc_pack_kernel),      reinterpret_cast<const void *>(&enc_pack_stream_kernel),
         reinterpret_cast<const void *>(&enc_pack_wave_kernel<4>), reinterpret_cast<const void *>(&enc_pack_wave_kernel<5>),
         reinterpret_cast<const void *>(&enc_onepass_kernel<4>),   reinterpret_cast<const void *>(&enc_onepass_kernel<5>),
-        reinterpret_cast<const void *>(&enc_onepass_kernel<4, true>), reinterpret_cast<const void *>(&enc_onepass_kernel<5, true>)};
+        reinterpret_cast<const void *>(&enc_onepass_kernel<4, true>), reinterpret_cast<const void *>(&enc_onepass_kernel<5, true>),
+        reinterpret_cast<const void *>(&enc_onepass_kernel<4, false, true>), reinterpret_cast<const void *>(&enc_onepass_kernel<5, false, true>)};
     for (const void *k : kernels) {
         if (e == hipSuccess) {
             e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -2778,6 +2813,11 @@ hipError_t hufk_host::init_encode(int lds_max) {
 }
 
 static void encode_three_kernels(const struct hufk_encode_args *a, hipStream_t st, const u32 *gate);
+
+/* workgroups of the way back (enc_onepass<.., ORDERED>): what it costs every launch is its EMPTY launch -- ~10 us with the
+ * 512 workgroups (74 KiB of LDS each) that fill the chip, ~4 with these --, and what it can do when it runs is bounded by its
+ * ticket counter (~90 tiles a microsecond) before it is by its waves: 64 x 8 waves at ~9 us a tile are 57 */
+constexpr uint32_t kOrderedBlocks = 64;
 
 /* the items of one tile that the plan lists apart (enc_onepass<.., SOLO>: a wave an item, nobody waits for anybody), and
  * their outcomes; a launch that only asks for lengths counts them a thread each */
@@ -2871,7 +2911,16 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
         dim3(kPackThreads), lds, st, a->tables, a->items, a->segs, (const u8 *)a->d_in, (u8 *)a->d_out, region,        \
         a->n_segs, (u32 *)(z + l.ctl), (u32 *)(z + l.tile_agg), (u64 *)(z + l.group_acc),                              \
         (u64 *)(z + l.round_base), (u64 *)(z + l.item_base), a->item_total, a->results, (const u8 *)(z + l.null_tile),  \
-        a->fail_tile ? a->n_segs * kTilesPerSeg / 2 : HUFD_NONE32)
+        a->fail_tile ? a->n_segs * kTilesPerSeg / 2 : HUFD_NONE32);                                                    \
+    /* the way back, on the same stream: the same kernel with its tiles by ticket (no wait of its can last for ever) and \
+     * look-back words of its own, looking first at the word a wave of the kernel above raises when a wait of its ran   \
+     * out -- whoever works on the output behind this launch finds it whole either way, without the host in between */ \
+    hipLaunchKernelGGL(                                                                                                \
+        (enc_onepass_kernel<NWV, false, true>), dim3(work < kOrderedBlocks ? work : kOrderedBlocks),                   \
+        dim3(kPackThreads), lds, st, a->tables, a->items, a->segs, (const u8 *)a->d_in, (u8 *)a->d_out, region,        \
+        a->n_segs, (u32 *)(z + l.ctl), (u32 *)(z + l.again + l.tile_agg), (u64 *)(z + l.again + l.group_acc),          \
+        (u64 *)(z + l.again + l.round_base), (u64 *)(z + l.again + l.item_base), a->item_total, a->results,            \
+        (const u8 *)(z + l.null_tile), HUFD_NONE32, (const u32 *)(z + l.ctl) + 1, 0u)
         if (!a->n_segs) {
             /* (items of one tile only) */
         } else if (a->tables.enc_max_bits <= 12) {
@@ -2892,8 +2941,9 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
             hipLaunchKernelGGL(
                 enc_finish_kernel, dim3((uint32_t)(item_blocks > clear_blocks ? item_blocks : clear_blocks)), dim3(256), kFinishLdsBytes, st,
                 a->tables, a->items, a->n_items, a->item_total, (const u8 *)a->d_in, a->careful_list, a->careful_count, a->states,
-                a->results, (const u32 *)(z + l.ctl) + 1, a->n_solo ? 7u : 5u, (uint4 *)(z + l.tile_agg), clear_vec16,
-                (u32 *)(z + ctl_next));
+                a->results, (const u32 *)nullptr /* (totals and notes are whole: the way back has seen to it) */, a->n_solo ? 7u : 5u,
+                (uint4 *)(z + l.tile_agg), clear_vec16, (u32 *)(z + ctl_next), (uint4 *)(z + l.again + l.tile_agg),
+                (const u32 *)(z + l.ctl) + 1);
         }
         stage_mark(a->stage_events, 2, st);
         if (a->n_tiny) {
@@ -2902,13 +2952,8 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
             a->tables, a->items, a->tiny_items, a->n_tiny, (const u8 *)a->d_in, (u8 *)a->d_out, a->results,
             a->length_only);
         }
-        /* (nothing is left for the per-symbol packer: every segment was packed by a wave, the capacity edge found by one) */
-        /* The way back, on the same stream: the three-kernel road (no waits between workgroups) queued behind the one
-         * pass, every kernel of it looking first at the word a wave raises when a look-back wait runs out -- whoever
-         * works on the output behind this launch finds it whole either way, without the host in between. */
-        if (a->n_segs) {
-            encode_three_kernels(a, st, (const u32 *)(z + l.ctl) + 1);
-        }
+        /* (nothing is left for the per-symbol packer: every segment was packed by a wave, the capacity edge found by one;
+         * nor for the three-kernel road, the way back of rounds 3-5: see enc_onepass<.., ORDERED>) */
         stage_mark(a->stage_events, 3, st);
         return (int)hipGetLastError();
     }
