@@ -310,10 +310,21 @@ __global__ __launch_bounds__(kEmitThreads, 4) void dec_emit_kernel(
     hufd_dec_result *results,
     const u32 *list,
     const u32 *list_count,
-    const u32 *counters = nullptr /* the launch's list counters ... */,
-    u32 *summary = nullptr /* ... and where this kernel, the launch's last, leaves them for the host (NULL: nowhere) */) {
-    if (summary && blockIdx.x == 0 && threadIdx.x < HUFK_DEC_COUNTERS) {
-        summary[threadIdx.x] = counters[threadIdx.x];
+    u32 *counters = nullptr /* the launch's list counters ... */,
+    u32 *summary = nullptr /* ... and where this kernel, the launch's last, leaves them for the host (NULL: nowhere) */,
+    u32 self_cleared = 0 /* 1: ... and clears the SYNC stage's words for the launch behind this one (nobody reads them any more;
+                          * the emit stage's, which this kernel's workgroups read, are cleared by that launch's sync stage) */) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (summary) {
+            for (u32 k = 0; k < HUFK_DEC_COUNTERS; ++k) {
+                summary[k] = counters[k];
+            }
+        }
+        if (self_cleared) {
+            counters[HUFK_DEC_COUNT_SLOW] = 0;
+            counters[HUFK_DEC_COUNT_LONG] = 0;
+            counters[HUFK_DEC_COUNT_FEW] = 0;
+        }
     }
     const u32 n = list ? *list_count : n_chunks;
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
@@ -1240,5 +1251,5 @@ do {                                                                            
         dim3(kEmitThreads), dec_emit_lds_bytes(&a->tables), st, a->tables, a->items, a->chunk_item, a->n_chunks,
         (const u8 *)a->d_in, (u8 *)a->d_out, a->fn_tab, a->cp_tab, (const u16 *)a->lane_count,
         (const u8 *)a->chunk_regular, a->chunk_entry, a->chunk_base, a->results, (const u32 *)a->emit_list,
-        (const u32 *)emit_count, (const u32 *)a->counters, a->summary);
+        (const u32 *)emit_count, a->counters, a->summary, a->counters_self_cleared);
 }

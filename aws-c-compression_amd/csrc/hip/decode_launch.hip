@@ -498,7 +498,7 @@ int hufk_decode_launch(const struct hufk_decode_args *a, void *stream) {
     }
     decode_launch_state state = {lb_of_launch, sure, false};
     if (a->n_chunks) {
-        if (!a->counters_next) {
+        if (!a->counters_self_cleared) {
             (void)hipMemsetAsync(a->counters, 0, HUFK_DEC_COUNTERS * sizeof(uint32_t), st);
         }
         hufk_host::decode_sync_stage(a, st, state);

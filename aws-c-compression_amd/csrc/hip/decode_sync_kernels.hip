@@ -227,10 +227,12 @@ __global__ __launch_bounds__(HUFD_DEC_LANES) void dec_sync_kernel(
     u8 *chunk_regular,
     const u32 *list,
     const u32 *list_count,
-    u32 *clear_next /* NULL, or the plan's other set of list counters: cleared here for the launch behind this one (every launch
-                     * with chunks runs this kernel, and nothing of THIS launch reads that set) */) {
-    if (clear_next && blockIdx.x == 0 && threadIdx.x < HUFK_DEC_COUNTERS) {
-        clear_next[threadIdx.x] = 0;
+    u32 *clear /* NULL, or the launch's list counters: the EMIT stage's words are cleared here, by the sync stage's last kernel
+                * (the launch before left them as they were when its last kernel read them; nothing of this launch has
+                * looked at them yet) */) {
+    if (clear && blockIdx.x == 0 && threadIdx.x == 0) {
+        clear[HUFK_DEC_COUNT_EMIT] = 0;
+        clear[HUFK_DEC_COUNT_DENSE] = 0;
     }
     const u32 n = list ? *list_count : n_chunks;
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
@@ -1580,7 +1582,8 @@ hipLaunchKernelGGL(                                                             
     hipLaunchKernelGGL(
         sync, dim3(persistent_grid(sync, HUFD_DEC_LANES, dec_sync_lds_bytes(&a->tables), a->n_chunks)),
         dim3(HUFD_DEC_LANES), dec_sync_lds_bytes(&a->tables), st, a->tables, a->items, a->chunk_item, a->n_chunks,
-        (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, long_list, long_count, a->counters_next);
+        (const u8 *)a->d_in, a->fn_tab, a->cp_tab, a->chunk_fn, a->chunk_regular, long_list, long_count,
+        a->counters_self_cleared ? a->counters : (u32 *)nullptr);
     s.few = few;
 }
 

@@ -2689,21 +2689,18 @@ __global__ __launch_bounds__(256) void enc_finish_kernel(
     u32 which /* bit 0: the items with segments; bit 1: the items of one tile that the plan lists apart (their kernel waits
                * for nobody: whatever road the others took, theirs are whole); bit 2: the packing waves have left, for every
                * item short of room, what of it was consumed (not in a length query: nothing was packed) */,
-    uint4 *clear_from = nullptr /* the look-back words of the launch (the packing kernel is through with them), ... */,
+    uint4 *clear_from = nullptr /* the look-back words of the launch (the packing kernels are through with them), both sets, ... */,
     u64 clear_vec16 = 0         /* ... so many 16-byte pieces: cleared here for the plan's next launch, whatever road this one took */,
-    u32 *ctl_next = nullptr     /* the other set of control words: the next launch's */,
-    uint4 *clear_again = nullptr /* the way back's own look-back words, as many: cleared when the way back ran (`ran_again`) */,
-    const u32 *ran_again = nullptr) {
+    u32 *ctl = nullptr          /* the control words: [1] "a wait ran out" is copied to [4] for the host, then [0] and [1] are cleared
+                                 * (no workgroup of this kernel reads them) */) {
 
-    const bool again = clear_again && ran_again[0] != 0;
     for (u64 k = (u64)blockIdx.x * kFinishItems + threadIdx.x; k < clear_vec16; k += (u64)gridDim.x * kFinishItems) {
         clear_from[k] = uint4{0, 0, 0, 0};
-        if (again) {
-            clear_again[k] = uint4{0, 0, 0, 0};
-        }
     }
-    if (ctl_next && blockIdx.x == 0 && threadIdx.x < 8) {
-        ctl_next[threadIdx.x] = 0;
+    if (ctl && blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl[4] = ctl[1];
+        ctl[0] = 0;
+        ctl[1] = 0;
     }
     const bool with_segments = (which & 1u) && !(gave_up && gave_up[0] != 0), solo = (which & 2u) != 0;
     if (!with_segments && !solo) {
@@ -2757,10 +2754,10 @@ __global__ __launch_bounds__(256) void enc_plan_tiny_items_kernel(const hufd_raw
 constexpr uint32_t kOnepassSgprs = 106;
 
 /* layout of the block the one-pass encoder wants clear when a launch starts (all offsets multiples of 8).  It is cleared when
- * the plan gets it and then by every launch behind itself: enc_finish, which runs when the packing kernel is through with the
- * look-back words, clears them and the OTHER set of control words (this launch's set holds the word the kernels of the way
- * back, queued behind enc_finish, look at) -- a clearing command in front of every launch was a packet of ~4 us on the queue
- * and a gap behind it. */
+ * the plan gets it and then by every launch behind itself (so that a launch captured in a graph can be replayed): enc_finish,
+ * which runs when the packing kernels -- the one by rule and, gated, the way back -- are through with the look-back words,
+ * clears both their sets and the control words (after copying "a wait ran out" to where the host reads it).  A clearing
+ * command in front of every launch was a packet of ~4 us on the queue. */
 struct onepass_layout {
     uint64_t ctl, tile_agg, group_acc, round_base, item_base, null_tile, bytes;
     uint64_t again; /* from tile_agg to the same word of the way back's own set of look-back words (enc_onepass<.., ORDERED>) */
@@ -2771,7 +2768,8 @@ static onepass_layout onepass_layout_of(uint64_t n_segs, uint64_t n_items) {
     const uint64_t groups = (tiles + kOpGroupTiles - 1) / kOpGroupTiles;
     const uint64_t rounds = (groups + kOpRoundGroups - 1) / kOpRoundGroups;
     onepass_layout l;
-    l.ctl = 0; /* two sets of eight control words, which take turns: [0, 32) and [32, 64) */
+    l.ctl = 0; /* sixteen control words: [0] the way back's tickets, [1] "a wait ran out", [2] careful_count, [4] word 1 of the
+                * last launch (for the host: enc_finish clears word 1 itself) */
     l.tile_agg = 64;
     l.group_acc = l.tile_agg + ((tiles * 4 + 7) & ~7ull);
     l.round_base = l.group_acc + groups * 8 * kOpGroupStride;
@@ -2896,12 +2894,6 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
         if (!a->zero_is_clear) {
             (void)hipMemsetAsync(a->zero_block, 0, a->zero_bytes ? a->zero_bytes : l.bytes, st);
         }
-        const uint64_t ctl_next = (a->zero_set & 1u) ? 0u : 32u;
-        l.ctl = (a->zero_set & 1u) ? 32u : 0u; /* this launch's set of control words */
-        /* (the words the three-kernel road counts its listed segments in belong to the set: a copy of the arguments says so) */
-        struct hufk_encode_args with_set = *a;
-        with_set.careful_count = (uint32_t *)(z + l.ctl) + 2;
-        a = &with_set;
         const uint32_t region = pack_region_bytes(a->tables.enc_max_bits);
         const uint32_t lds = kPackTabBytes + kPackWaves * region;
         const uint32_t work = (a->n_segs * kTilesPerSeg + kPackWaves - 1) / kPackWaves;
@@ -2934,7 +2926,8 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
         {
             /* (a plan without segments -- every item a wave's or a thread's -- has no look-back words: BASELINE configs[3]'s
              * 65 536 item bases were half a megabyte cleared for nobody) */
-            const uint64_t clear_vec16 = a->n_segs ? (l.null_tile - l.tile_agg) / 16 : 0;
+            /* (both sets of look-back words, the readable nothing between them along with them: one stretch) */
+            const uint64_t clear_vec16 = a->n_segs ? (l.bytes - l.tile_agg) / 16 : 0;
             const uint64_t item_blocks = (a->n_items + kFinishItems - 1) / kFinishItems;
             uint64_t clear_blocks = (clear_vec16 + kFinishItems * 4 - 1) / (kFinishItems * 4); /* four pieces a thread */
             clear_blocks = clear_blocks > 1024 ? 1024 : clear_blocks;
@@ -2942,8 +2935,7 @@ int hufk_encode_launch(const struct hufk_encode_args *a, void *stream) {
                 enc_finish_kernel, dim3((uint32_t)(item_blocks > clear_blocks ? item_blocks : clear_blocks)), dim3(256), kFinishLdsBytes, st,
                 a->tables, a->items, a->n_items, a->item_total, (const u8 *)a->d_in, a->careful_list, a->careful_count, a->states,
                 a->results, (const u32 *)nullptr /* (totals and notes are whole: the way back has seen to it) */, a->n_solo ? 7u : 5u,
-                (uint4 *)(z + l.tile_agg), clear_vec16, (u32 *)(z + ctl_next), (uint4 *)(z + l.again + l.tile_agg),
-                (const u32 *)(z + l.ctl) + 1);
+                (uint4 *)(z + l.tile_agg), clear_vec16, (u32 *)(z + l.ctl));
         }
         stage_mark(a->stage_events, 2, st);
         if (a->n_tiny) {

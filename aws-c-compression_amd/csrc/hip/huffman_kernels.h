@@ -36,9 +36,8 @@ struct hufk_encode_args {
     uint32_t *careful_count; /* [1] scratch */
     /* one-pass path (every symbol coded, codes of 4 .. 15 bits): */
     void *zero_block;        /* hufk_encode_zero_bytes(n_segs, n_items) bytes, clear when the launch starts and when it is
-                              * through: two sets of control words that take turns (word 0 ticket, word 1 "a wait ran
-                              * out", word 2 careful_count), then the look-back tables */
-    uint32_t zero_set;       /* which set of control words this launch takes (0 / 1) */
+                              * through: the control words (word 0 the way back's tickets, word 1 "a wait ran out", word 2
+                              * careful_count, word 4 word 1 of the last launch), then the look-back tables, twice */
     uint32_t zero_is_clear;  /* 1: the block is known to be clear (the plan's last launch left it so); 0: the launch clears it first */
     uint64_t zero_bytes;     /* all of the block (what a clearing takes when the layout of the launch that dirtied it is not known) */
     uint8_t *seg_unk_seen;   /* [n_segs] scratch */
@@ -100,11 +99,13 @@ struct hufk_decode_args {
     uint32_t *emit_list;   /* [n_chunks] scratch: chunks left to dec_emit by dec_emit_fast */
     uint32_t *dense_list;  /* [n_chunks] scratch: chunks dec_emit_fast leaves to dec_emit_dense */
     uint32_t *counters;    /* [HUFK_DEC_COUNTERS] scratch: how many entries the lists hold, one word for every use a launch
-                            * makes of a list (the arrays take turns, the words do not).  All zero when the launch starts:
-                            * a plan has TWO sets that take turns, and a launch clears the other one for the launch
-                            * behind it (`counters_next`, by the long way's sync kernel, which every launch with chunks
-                            * has) -- a clearing command in front of every launch was ~4 us of its own */
-    uint32_t *counters_next; /* [HUFK_DEC_COUNTERS] the set this launch clears; NULL: `counters` is cleared by a command in front of the launch */
+                            * makes of a list (the arrays take turns, the words do not).  Clear when the plan gets them, and
+                            * every launch leaves them as it needs them itself (so that a launch captured in a graph can be
+                            * replayed): the sync stage's words are cleared by the launch's LAST kernel (dec_emit, the long
+                            * way: nobody reads them behind the sync stage), the emit stage's by the last kernel of the
+                            * sync stage (dec_sync, the long way: nobody has touched them yet) -- both run in every launch
+                            * with chunks.  A clearing command in front of every launch was ~4 us of its own. */
+    uint32_t counters_self_cleared; /* 1: as above; 0: cleared by a command in front of the launch */
     uint32_t *summary;       /* NULL, or [HUFK_DEC_COUNTERS]: the launch's last kernel leaves its counters here (in front of the
                               * result records: one copy fetches both) -- what the host reads `quiet` from */
     uint32_t quiet;          /* 1: the plan's last fetched launch listed no chunk for any kernel but the regular ones: this

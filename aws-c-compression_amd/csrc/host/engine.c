@@ -645,7 +645,6 @@ static int enc_plan_reserve(struct aws_huffman_amd_encode_plan *p, size_t n_item
             return e;
         }
         p->zero_is_clear = true;
-        p->one_pass_launches = 0;
     }
     return 0;
 }
@@ -1038,10 +1037,9 @@ int aws_huffman_amd_encode_plan_launch_staged(
     a.seg_bitoff = p->d_seg_bitoff;
     a.careful_list = p->d_careful;
     a.zero_block = p->d_zero;
-    a.zero_set = p->one_pass_launches & 1u;
     a.zero_is_clear = p->zero_is_clear;
     a.zero_bytes = hufk_encode_zero_bytes((uint32_t)p->cap_segs, (uint32_t)p->cap_items);
-    a.careful_count = (uint32_t *)p->d_zero + 2; /* (a launch of the one-pass road takes the word of its own set) */
+    a.careful_count = (uint32_t *)p->d_zero + 2;
     a.seg_unk_seen = p->d_unk_seen;
     a.item_total = p->d_item_total;
     a.single_pass = p->engine->single_pass && !p->look_back_timed_out;
@@ -1057,11 +1055,7 @@ int aws_huffman_amd_encode_plan_launch_staged(
     ON_DEVICE(p->engine->device);
     int err = hufk_encode_launch(&a, stream ? stream : p->engine->stream);
     if (p->last_single_pass) {
-        /* the launch took a set of control words (the results' fetch reads its "a wait ran out" word) and leaves the block
-         * clear behind itself -- unless it could not be queued whole */
-        p->last_ctl_set = a.zero_set;
-        ++p->one_pass_launches;
-        p->zero_is_clear = !err;
+        p->zero_is_clear = !err; /* (the launch leaves the block clear behind itself -- unless it could not be queued whole) */
     }
     if (!err) {
         err = plan_mark_done(&p->done_event, &p->done_on_engine_stream, p->engine, stream);
@@ -1084,7 +1078,7 @@ int aws_huffman_amd_encode_plan_raw_results(
      * is likely to run out again, and costs milliseconds). */
     uint32_t timed_out = 0;
     if (p->last_single_pass) {
-        err = hufs_copy_d2h(&timed_out, p->d_zero + 32u * p->last_ctl_set + sizeof(uint32_t), sizeof(timed_out), st);
+        err = hufs_copy_d2h(&timed_out, p->d_zero + 4 * sizeof(uint32_t), sizeof(timed_out), st); /* (enc_finish's copy of the word) */
     }
     if (!err) {
         err = hufs_copy_d2h(raw, p->d_results, (size_t)p->n_items * sizeof(*raw), st);
@@ -1185,7 +1179,7 @@ int aws_huffman_amd_encode_plan_results(
     X(d_slow_list, ((cc) + 1) * sizeof(uint32_t)) /* [0] count, [1..] chunks */                                        \
     X(d_emit_list, ((cc) + 1) * sizeof(uint32_t))                                                                      \
     X(d_dense_list, ((cc) + 1) * sizeof(uint32_t))                                                                     \
-    X(d_counters, 2 * HUFK_DEC_COUNTERS * sizeof(uint32_t)) /* two sets: a launch uses one and clears the other */      \
+    X(d_counters, HUFK_DEC_COUNTERS * sizeof(uint32_t))                                                                \
     X(d_lane_count, (cc) * HUFD_DEC_LANES * sizeof(uint16_t))                                                          \
     X(d_chunk_regular, (cc))                                                                                           \
     X(d_tail_entry, (cc) * sizeof(uint32_t))                                                                           \
@@ -1310,8 +1304,8 @@ static int dec_plan_reserve(struct aws_huffman_amd_decode_plan *p, size_t n_item
         p->cap_chunks = cc;
         p->cap_large = cl;
         p->cap_runs = cr;
-        /* the list counters start out clear; from then on every launch leaves the set it did not use clear for the next one */
-        int e = hufs_memset(p->d_counters, 0, 2 * HUFK_DEC_COUNTERS * sizeof(uint32_t), p->engine->stream);
+        /* the list counters start out clear; from then on every launch clears them for itself and for the one behind it (hufk_decode_args.counters) */
+        int e = hufs_memset(p->d_counters, 0, HUFK_DEC_COUNTERS * sizeof(uint32_t), p->engine->stream);
         if (!e) {
             e = hufs_stream_sync(p->engine->stream);
         }
@@ -1908,10 +1902,8 @@ int aws_huffman_amd_decode_plan_launch_staged(
     a.slow_list = p->d_slow_list + 1;
     a.emit_list = p->d_emit_list + 1;
     a.dense_list = p->d_dense_list + 1;
-    /* (the two sets of list counters take turns: this launch's is clear -- the launch before cleared it, or the reserve did --
-     * and this launch clears the other) */
-    a.counters = p->d_counters + (p->launches_with_chunks & 1u) * HUFK_DEC_COUNTERS;
-    a.counters_next = p->d_counters + ((p->launches_with_chunks + 1u) & 1u) * HUFK_DEC_COUNTERS;
+    a.counters = p->d_counters;
+    a.counters_self_cleared = 1;
     if (p->n_chunks) {
         ++p->launches_with_chunks;
     }

@@ -78,9 +78,7 @@ struct aws_huffman_amd_encode_plan {
     uint32_t *d_seg_unk;
     uint64_t *d_seg_bitoff;
     uint32_t *d_careful; /* [2 * cap_items + 4]: segments for the per-symbol packer */
-    uint8_t *d_zero;     /* two sets of control words (ticket, "a wait ran out", careful count) | look-back words: clear between launches */
-    uint32_t one_pass_launches; /* its parity: the set of control words the next launch of the one-pass road takes */
-    uint32_t last_ctl_set;      /* ... and the one the last such launch took */
+    uint8_t *d_zero;     /* control words (tickets, "a wait ran out", careful count, the last launch's "a wait ran out") | look-back words, twice: clear between launches */
     bool zero_is_clear;         /* d_zero is clear (the last launch left it so, or the reserve did) */
     uint8_t *d_unk_seen; /* [cap_segs] */
     uint64_t *d_item_total; /* [cap_items] */
@@ -127,8 +125,8 @@ struct aws_huffman_amd_decode_plan {
     uint32_t *d_slow_list; /* [0] how many, [1..] the chunks the regular chunks' kernels left to dec_sync */
     uint32_t *d_emit_list; /* the same for dec_emit_fast / dec_emit */
     uint32_t *d_dense_list; /* [0] how many, [1..] chunks with more symbols than one emit stage */
-    uint32_t *d_counters;   /* [2][HUFK_DEC_COUNTERS] the lists' lengths (hufk_decode_args.counters), two sets that take turns */
-    uint32_t launches_with_chunks; /* its parity: the set the next launch uses (that launch clears the other one) */
+    uint32_t *d_counters;   /* [HUFK_DEC_COUNTERS] the lists' lengths (hufk_decode_args.counters): clear between launches */
+    uint32_t launches_with_chunks; /* (a fetch of results says what the last of them listed: `quiet`) */
     uint16_t *d_lane_count;
     uint8_t *d_chunk_regular;
     uint32_t *d_tail_entry;

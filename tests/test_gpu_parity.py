@@ -465,14 +465,15 @@ def test_one_gib_stream_when_the_one_pass_encoder_gives_up(oracle):
 def test_plan_launches_in_a_hip_graph():
     """an encode launch and the decode launch of its output, captured into one HIP graph on a stream of
     the caller's and replayed over scrambled outputs (profiles/tools/graph_capture.py: a batch of 16 KiB items and one
-    64 MiB stream -- memsets, kernels, and the second stream's fork and join are all nodes of the graph)."""
+    64 MiB stream -- kernels and the second stream's fork and join are all nodes of the graph; and a stream whose replays
+    take the ways back every time: what those leave in control words and counters must not outlive a replay)."""
     import subprocess
     import sys
 
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tools", "graph_capture.py")
     out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count("decoded back bit-exact") == 2, out.stdout
+    assert out.stdout.count("decoded back bit-exact") == 3 and out.stdout.count("(the ways back)") == 1, out.stdout
 
 
 def test_two_one_pass_encoders_on_one_device():
