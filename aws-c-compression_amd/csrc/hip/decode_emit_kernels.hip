@@ -366,6 +366,45 @@ __host__ __device__ constexpr u32 emit_lds_bytes(u32 stage_bytes) {
     return (u32)sizeof(emit_shared<LB>) - HUFD_DEC_STAGE_BYTES + stage_bytes;
 }
 
+/*
+ * The codes of a row behind the certain ones, one chain: while a code starts in the row, its table entry, its symbol to the
+ * stage, the state on.  Written out for the GPU as lean_row is: what the compiler makes of the loop in C is eight vector
+ * instructions a trip (shift, address, a copy of the store address, that address + 1, + the record's base, the state's add, a
+ * compare through SDWA) and two scalar ones that fold the compare into the exec mask; here five and a branch -- the compare is
+ * v_cmpx_lt_u16 on the state's low half, straight into exec.  2.2 of a row's 5.2 trips are such trips, for either chain.
+ * `at`: where the chain's next symbol goes, as an LDS address.  v62 / v63 are the block's own temporaries.
+ */
+__device__ __forceinline__ void emit_uncertain_codes(u32 &state, u32 &at, u64 pair, u32 table, const row_walk &rw) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 saved_exec;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_u16_e32 vcc, %[thr], %[st]\n\t"
+        "s_cbranch_execz 2f\n"
+        "1:\n\t"
+        "v_lshrrev_b64 v[62:63], %[st], %[pair]\n\t"
+        "v_and_or_b32 v62, v62, %[mask], %[tab]\n\t"
+        "ds_read_b32 v62, v62\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_add_u32_e32 %[st], %[st], v62\n\t"
+        "ds_write_b8_d16_hi %[at], v62\n\t"
+        "v_add_u32_e32 %[at], 1, %[at]\n\t"
+        "v_cmpx_lt_u16_e32 vcc, %[thr], %[st]\n\t"
+        "s_cbranch_execnz 1b\n"
+        "2:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [st] "+v"(state), [at] "+v"(at), [sv] "=&s"(saved_exec)
+        : [pair] "v"(pair), [mask] "s"(rw.mask), [tab] "v"(table), [thr] "s"(rw.thr)
+        : "vcc", "v62", "v63", "memory");
+#else
+    while ((state & 0xFFFFu) > rw.thr) {
+        const u32 e = lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
+        dyn_lds[at++] = (u8)(e >> 16);
+        state += e;
+    }
+#endif
+}
+
 template <u32 LB, bool TAIL, u32 SURE = 0> /* TAIL: a chunk that may hold the end of a stream; else one inside a stream.
                                              * SURE: the codes that are certain to start in a row, when the launch knows (0: asked of the coder at run time) */
 __device__ __forceinline__ void dec_emit_fast_chunk(
@@ -558,6 +597,7 @@ __device__ __forceinline__ void dec_emit_fast_chunk(
      * the stores into flat ones with 64-bit address arithmetic */
     u8 *const lds_bytes = reinterpret_cast<u8 *>(&sh);
     const u32 stage_at = (u32)(reinterpret_cast<u8 *>(sh.stage) - lds_bytes), dump_at = (u32)(sh.dump - lds_bytes);
+    const u32 stage_base = lds_offset_of(lds_bytes); /* (dst[] counts from here) */
     u32 dst[kEmitChains];
     bool idle[kEmitChains]; /* a chain with nothing to emit still walks (the two go in step): over zeros, into the dump */
     bool extend = false;
@@ -605,10 +645,10 @@ __device__ __forceinline__ void dec_emit_fast_chunk(
         }
 #pragma unroll
         for (u32 ch = 0; ch < kEmitChains; ++ch) {
-            while ((st[ch] & 0xFFFFu) > rw.thr) {
-                const u32 e = lds_word_at(((u32)(pair[ch] >> (st[ch] & 63u)) & rw.mask) | table);
-                lds_bytes[dst[ch]++] = (u8)(e >> 16);
-                st[ch] += e;
+            {
+                u32 at = dst[ch] + stage_base; /* (as an LDS address, for the hand-written loop) */
+                emit_uncertain_codes(st[ch], at, pair[ch], table, rw);
+                dst[ch] = at - stage_base;
             }
             st[ch] += 32u;
             /* an idle chain starts every row afresh: whatever it decodes, its state and its writes stay in bounds */
