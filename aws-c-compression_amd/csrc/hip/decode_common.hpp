@@ -523,6 +523,97 @@ __device__ __forceinline__ u32 lds_byte_at(u32 byte_offset) {
 #endif
 }
 
+/* ------------------------------------------------------------------ decode: the rows' loops written out for the GPU */
+
+/* row_walk::row with the number of certain steps known to the compiler and the table given as an LDS offset.
+ *
+ * The loop over the codes that MAY start in the row is written out for the GPU: what the compiler makes of
+ * `while ((state & 0xFFFF) > thr)` is five vector instructions a trip (shift, address, add, and, compare) and three scalar
+ * ones that fold the compare into the exec mask; here the compare is v_cmpx_lt_u16 -- the low half as it stands, straight
+ * into exec -- so a trip is four vector instructions and a branch.  These kernels' time follows the vector instructions a
+ * step costs (profiles/r05_micro: the walk at eight waves a SIMD is held by issue as much as by the LDS).  v62 / v63 are
+ * the block's own temporaries (a 64-bit shift result whose low word becomes the address, then the entry). */
+template <u32 SURE, bool STEP_BY_STEP = false, bool PLAIN = false> /* PLAIN: the loop as the compiler writes it (a kernel held to 64 registers has none to set aside for the block) */
+__device__ __forceinline__ u32 lean_row(u32 state, u32 hi, u32 lo, u32 table, const row_walk &rw) {
+    const u64 pair = ((u64)hi << 32) | lo;
+    if (!STEP_BY_STEP) {
+#pragma unroll
+        for (u32 i = 0; i < SURE; ++i) {
+            state += lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
+        }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (PLAIN) {
+        while ((state & 0xFFFFu) > rw.thr) {
+            state += lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
+        }
+        return state;
+    }
+    u64 saved_exec;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_u16_e32 vcc, %[thr], %[st]\n\t"
+        "s_cbranch_execz 2f\n"
+        "1:\n\t"
+        "v_lshrrev_b64 v[62:63], %[st], %[pair]\n\t"
+        "v_and_or_b32 v62, v62, %[mask], %[tab]\n\t"
+        "ds_read_b32 v62, v62\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_add_u32_e32 %[st], %[st], v62\n\t"
+        "v_cmpx_lt_u16_e32 vcc, %[thr], %[st]\n\t"
+        "s_cbranch_execnz 1b\n"
+        "2:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [st] "+v"(state), [sv] "=&s"(saved_exec)
+        : [pair] "v"(pair), [mask] "s"(rw.mask), [tab] "v"(table), [thr] "s"(rw.thr)
+        : "vcc", "v62", "v63");
+#else
+    while ((state & 0xFFFFu) > rw.thr) {
+        state += lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
+    }
+#endif
+    return state;
+}
+
+/*
+ * The codes of a row behind the certain ones, one chain: while a code starts in the row, its table entry, its symbol to the
+ * stage, the state on.  Written out for the GPU as lean_row is: what the compiler makes of the loop in C is eight vector
+ * instructions a trip (shift, address, a copy of the store address, that address + 1, + the record's base, the state's add, a
+ * compare through SDWA) and two scalar ones that fold the compare into the exec mask; here five and a branch -- the compare is
+ * v_cmpx_lt_u16 on the state's low half, straight into exec.  2.2 of a row's 5.2 trips are such trips, for either chain.
+ * `at`: where the chain's next symbol goes, as an LDS address.  v62 / v63 are the block's own temporaries.
+ */
+__device__ __forceinline__ void emit_uncertain_codes(u32 &state, u32 &at, u64 pair, u32 table, const row_walk &rw) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 saved_exec;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_u16_e32 vcc, %[thr], %[st]\n\t"
+        "s_cbranch_execz 2f\n"
+        "1:\n\t"
+        "v_lshrrev_b64 v[62:63], %[st], %[pair]\n\t"
+        "v_and_or_b32 v62, v62, %[mask], %[tab]\n\t"
+        "ds_read_b32 v62, v62\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_add_u32_e32 %[st], %[st], v62\n\t"
+        "ds_write_b8_d16_hi %[at], v62\n\t"
+        "v_add_u32_e32 %[at], 1, %[at]\n\t"
+        "v_cmpx_lt_u16_e32 vcc, %[thr], %[st]\n\t"
+        "s_cbranch_execnz 1b\n"
+        "2:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [st] "+v"(state), [at] "+v"(at), [sv] "=&s"(saved_exec)
+        : [pair] "v"(pair), [mask] "s"(rw.mask), [tab] "v"(table), [thr] "s"(rw.thr)
+        : "vcc", "v62", "v63", "memory");
+#else
+    while ((state & 0xFFFFu) > rw.thr) {
+        const u32 e = lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
+        dyn_lds[at++] = (u8)(e >> 16);
+        state += e;
+    }
+#endif
+}
+
 /* ------------------------------------------------------------------ decode: the end of a stream */
 
 /*

@@ -366,44 +366,6 @@ __host__ __device__ constexpr u32 emit_lds_bytes(u32 stage_bytes) {
     return (u32)sizeof(emit_shared<LB>) - HUFD_DEC_STAGE_BYTES + stage_bytes;
 }
 
-/*
- * The codes of a row behind the certain ones, one chain: while a code starts in the row, its table entry, its symbol to the
- * stage, the state on.  Written out for the GPU as lean_row is: what the compiler makes of the loop in C is eight vector
- * instructions a trip (shift, address, a copy of the store address, that address + 1, + the record's base, the state's add, a
- * compare through SDWA) and two scalar ones that fold the compare into the exec mask; here five and a branch -- the compare is
- * v_cmpx_lt_u16 on the state's low half, straight into exec.  2.2 of a row's 5.2 trips are such trips, for either chain.
- * `at`: where the chain's next symbol goes, as an LDS address.  v62 / v63 are the block's own temporaries.
- */
-__device__ __forceinline__ void emit_uncertain_codes(u32 &state, u32 &at, u64 pair, u32 table, const row_walk &rw) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    u64 saved_exec;
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "v_cmpx_lt_u16_e32 vcc, %[thr], %[st]\n\t"
-        "s_cbranch_execz 2f\n"
-        "1:\n\t"
-        "v_lshrrev_b64 v[62:63], %[st], %[pair]\n\t"
-        "v_and_or_b32 v62, v62, %[mask], %[tab]\n\t"
-        "ds_read_b32 v62, v62\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_add_u32_e32 %[st], %[st], v62\n\t"
-        "ds_write_b8_d16_hi %[at], v62\n\t"
-        "v_add_u32_e32 %[at], 1, %[at]\n\t"
-        "v_cmpx_lt_u16_e32 vcc, %[thr], %[st]\n\t"
-        "s_cbranch_execnz 1b\n"
-        "2:\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [st] "+v"(state), [at] "+v"(at), [sv] "=&s"(saved_exec)
-        : [pair] "v"(pair), [mask] "s"(rw.mask), [tab] "v"(table), [thr] "s"(rw.thr)
-        : "vcc", "v62", "v63", "memory");
-#else
-    while ((state & 0xFFFFu) > rw.thr) {
-        const u32 e = lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
-        dyn_lds[at++] = (u8)(e >> 16);
-        state += e;
-    }
-#endif
-}
 
 template <u32 LB, bool TAIL, u32 SURE = 0> /* TAIL: a chunk that may hold the end of a stream; else one inside a stream.
                                              * SURE: the codes that are certain to start in a row, when the launch knows (0: asked of the coder at run time) */

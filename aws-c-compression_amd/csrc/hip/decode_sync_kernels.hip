@@ -256,55 +256,6 @@ struct lean_shared {
     u16 hops[1u << LB]; /* 1 << code length of a window (the head it sends on), 0 = no code */
 };
 
-/* row_walk::row with the number of certain steps known to the compiler and the table given as an LDS offset.
- *
- * The loop over the codes that MAY start in the row is written out for the GPU: what the compiler makes of
- * `while ((state & 0xFFFF) > thr)` is five vector instructions a trip (shift, address, add, and, compare) and three scalar
- * ones that fold the compare into the exec mask; here the compare is v_cmpx_lt_u16 -- the low half as it stands, straight
- * into exec -- so a trip is four vector instructions and a branch.  These kernels' time follows the vector instructions a
- * step costs (profiles/r05_micro: the walk at eight waves a SIMD is held by issue as much as by the LDS).  v62 / v63 are
- * the block's own temporaries (a 64-bit shift result whose low word becomes the address, then the entry). */
-template <u32 SURE, bool STEP_BY_STEP = false, bool PLAIN = false> /* PLAIN: the loop as the compiler writes it (a kernel held to 64 registers has none to set aside for the block) */
-__device__ __forceinline__ u32 lean_row(u32 state, u32 hi, u32 lo, u32 table, const row_walk &rw) {
-    const u64 pair = ((u64)hi << 32) | lo;
-    if (!STEP_BY_STEP) {
-#pragma unroll
-        for (u32 i = 0; i < SURE; ++i) {
-            state += lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
-        }
-    }
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (PLAIN) {
-        while ((state & 0xFFFFu) > rw.thr) {
-            state += lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
-        }
-        return state;
-    }
-    u64 saved_exec;
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "v_cmpx_lt_u16_e32 vcc, %[thr], %[st]\n\t"
-        "s_cbranch_execz 2f\n"
-        "1:\n\t"
-        "v_lshrrev_b64 v[62:63], %[st], %[pair]\n\t"
-        "v_and_or_b32 v62, v62, %[mask], %[tab]\n\t"
-        "ds_read_b32 v62, v62\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_add_u32_e32 %[st], %[st], v62\n\t"
-        "v_cmpx_lt_u16_e32 vcc, %[thr], %[st]\n\t"
-        "s_cbranch_execnz 1b\n"
-        "2:\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [st] "+v"(state), [sv] "=&s"(saved_exec)
-        : [pair] "v"(pair), [mask] "s"(rw.mask), [tab] "v"(table), [thr] "s"(rw.thr)
-        : "vcc", "v62", "v63");
-#else
-    while ((state & 0xFFFFu) > rw.thr) {
-        state += lds_word_at(((u32)(pair >> (state & 63u)) & rw.mask) | table);
-    }
-#endif
-    return state;
-}
 
 /* ------------------------------------------------------------------ decode: sync, regular chunks, one guessed walk */
 
@@ -897,15 +848,13 @@ __device__ __forceinline__ void dec_sync_guess_chunk(
     const u32 first_row = lane ? 0u : meet_row; /* (meet_row >= 1) */
     for (u32 round = 0;; ++round) {
         if (__any(walking)) {
-#if defined(__HIP_DEVICE_COMPILE__)
             /* (the words as values the compiler cannot trace through the rounds: it otherwise builds every row's 64-bit
              * window register pair once, in front of the loop -- twice the registers, and a value spilled inside this
              * divergent loop has come back wrong on this toolchain) */
 #pragma unroll
             for (u32 r = 0; r < kFastRows; ++r) {
-                asm volatile("" : "+v"(w[r]));
+                opaque(w[r]);
             }
-#endif
             u32 st = rw.state_at(from_bit, 0);
             bool dd = false;
 #pragma unroll
@@ -997,9 +946,7 @@ __device__ __forceinline__ void dec_sync_guess_chunk(
     /* the tables dec_scan and dec_emit read (the regular chunks' format).  (The lane number as a value the compiler cannot trace:
      * where the records go is worked out here, not in front of the walks where the registers are needed.) */
     u32 lane_o = lane;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(lane_o));
-#endif
+    opaque(lane_o);
     u16 *fn_out = fn_tab + (u64)c * ns * HUFD_DEC_LANES;
     u16 *cp = cp_tab + (u64)c * kCpRows * HUFD_DEC_LANES + lane_o;
 #pragma unroll

@@ -30,21 +30,6 @@ __device__ __forceinline__ void load_segment_groups(
     }
 }
 
-/* A segment descriptor is the same in every lane: say so, and it lives in scalar registers. */
-__device__ __forceinline__ hufd_enc_seg uniform_seg(const hufd_enc_seg *p) {
-    hufd_enc_seg d = *p;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const u32 lo = __builtin_amdgcn_readfirstlane((u32)d.in_off);
-    const u32 hi = __builtin_amdgcn_readfirstlane((u32)(d.in_off >> 32));
-    d.in_off = ((u64)hi << 32) | lo;
-    d.len = __builtin_amdgcn_readfirstlane(d.len);
-    d.item = __builtin_amdgcn_readfirstlane(d.item);
-    d.index = __builtin_amdgcn_readfirstlane(d.index);
-    d.flags = __builtin_amdgcn_readfirstlane(d.flags);
-    d.next_len = __builtin_amdgcn_readfirstlane(d.next_len);
-#endif
-    return d;
-}
 
 /*
  * Bits per segment and its first symbol without a code.  The kernel is a stream of table
@@ -902,31 +887,7 @@ struct enc_pack_shared {
     u32 halo_unknown;
 };
 
-/*
- * Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also
- * drains the vector-memory counter, which would stall on an LDS-DMA prefetch or on the
- * copy-out stores that are meant to stay in flight (guide: "Pipelining across barriers").
- */
-__device__ __forceinline__ void barrier_lds() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#else
-    __syncthreads();
-#endif
-}
 
-/* 16 bytes global -> LDS without a register in between (global_load_lds_dwordx4) */
-__device__ __forceinline__ void lds_dma16(const void *global_src, void *lds_dst) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void *)global_src, (__attribute__((address_space(3))) void *)lds_dst,
-        16, 0, 0);
-#else
-    memcpy(lds_dst, global_src, 16);
-#endif
-}
 
 /* OR `len` (0..64) right-aligned bits of `value` into the image at bit q: at most three words. */
 __device__ __forceinline__ void image_or_quad(u32 *img, u32 q, u64 value, u32 len) {
@@ -1505,13 +1466,6 @@ constexpr u32 kPackWaves = 8; /* waves (= independent tiles in flight) per workg
 constexpr u32 kPackThreads = kPackWaves * kWave;
 constexpr u32 kPackTabBytes = 256 * 32 * 4;
 
-__device__ __forceinline__ u32 funnel(u32 hi, u32 lo, u32 shift /* 0..31 */) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_alignbit(hi, lo, shift);
-#else
-    return (u32)(((((u64)hi) << 32) | lo) >> shift);
-#endif
-}
 
 /* bytes of LDS one tile's bit image needs: the tile's bits, 16 bytes of alignment in front, the words a last unit spills */
 __device__ __host__ inline u32 pack_region_bytes(u32 max_bits) {
@@ -1866,64 +1820,10 @@ __device__ __forceinline__ void word_store(u32 *p, u32 v) {
 __device__ __forceinline__ u32 word_load(const u32 *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-/*
- * The same loads for a poll loop: load and wait in one piece of assembly, so that the compiler sees a value, not a
- * load in flight.  (A load it knows of inside the loop makes every wait behind the loop a wait for everything --
- * among it the next tile's symbols, which are meant to stay in flight.)  Polling with atomics (which are carried out
- * at the memory side and cannot be served from a cache) was tried: 2 000 waves asking for one word that way take
- * turns at ~12 ns each -- 18 ms instead of 0.6.
- */
-__device__ __forceinline__ u32 word_load_now(const u32 *p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    u32 v;
-    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
-    return v;
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ u64 granule_load_now(const u64 *p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    u64 v;
-    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
-    return v;
-#else
-    return *p;
-#endif
-}
-/*
- * A tile's arrival (flagged word + add to its group), issued without the compiler knowing of a store in flight: with
- * loads and a store outstanding together it makes every wait a wait for everything (it has to assume that the two
- * kinds complete in any order), and the wait behind this is for the old tile's offsets only -- the next tile's symbols
- * are meant to stay in flight.  A counted wait that does not count these two still covers the loads it is for: at
- * most two of the operations it lets stand are these, the others are loads, which complete in order.
- */
-__device__ __forceinline__ void arrival_quiet(u32 *flag_word, u32 flagged, u64 *group, u64 add) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("global_store_dword %0, %1, off sc1\n\tglobal_atomic_add_x2 %2, %3, off"
-                 :
-                 : "v"(flag_word), "v"(flagged), "v"(group), "v"(add)
-                 : "memory");
-#else
-    *flag_word = flagged;
-    *group += add;
-#endif
-}
 __device__ __forceinline__ u64 granule_add(u64 *p, u64 v) {
     return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-/* a value that is the same in every lane, as a scalar */
-__device__ __forceinline__ u32 uniform32(u32 x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_readfirstlane(x);
-#else
-    return __shfl(x, 0);
-#endif
-}
-__device__ __forceinline__ u64 uniform64(u64 x) {
-    return ((u64)uniform32((u32)(x >> 32)) << 32) | uniform32((u32)x);
-}
 
 /*
  * Copies stream bytes [jlo, jhi) of an item out of a tile image whose bit 0 is stream bit `bit0`
@@ -1935,11 +1835,9 @@ __device__ __forceinline__ void region_store_shifted(const u32 *img, u8 *out_ptr
     if (jhi <= jlo) {
         return;
     }
-#if defined(__HIP_DEVICE_COMPILE__)
     /* (the lane number as a value the compiler cannot trace: what is derived from it -- the lane's place in the image --
      * is then worked out here, two instructions, instead of being kept in registers, or spilled, across the turn) */
-    asm volatile("" : "+v"(lane));
-#endif
+    opaque(lane);
     /* (an item's carried bits lie in front of image bit 0, in img[-1]: image bit numbers may be negative down to -32) */
     auto byte_at = [&](u64 j) -> u8 {
         const int ib = (int)(u32)(8 * j - bit0);

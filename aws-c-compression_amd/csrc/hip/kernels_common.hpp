@@ -135,6 +135,128 @@ __device__ __forceinline__ u32 round16(u32 x) {
 
 /* ------------------------------------------------------------------ wave / block primitives */
 
+/* ------------------------------------------------------------------ what the GPU build and the CPU test build (tests/emu) spell differently:
+ * every `#if defined(__HIP_DEVICE_COMPILE__)` of the kernels is in this header or in decode_common.hpp, none in a kernel */
+
+/* a value the compiler cannot trace any further back (what it would otherwise work out early and keep in registers, or build
+ * twice, is then worked out where it is used); nothing under tests/emu */
+__device__ __forceinline__ void opaque(u32 &x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#else
+    (void)x;
+#endif
+}
+
+/* A segment descriptor is the same in every lane: say so, and it lives in scalar registers. */
+__device__ __forceinline__ hufd_enc_seg uniform_seg(const hufd_enc_seg *p) {
+    hufd_enc_seg d = *p;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 lo = __builtin_amdgcn_readfirstlane((u32)d.in_off);
+    const u32 hi = __builtin_amdgcn_readfirstlane((u32)(d.in_off >> 32));
+    d.in_off = ((u64)hi << 32) | lo;
+    d.len = __builtin_amdgcn_readfirstlane(d.len);
+    d.item = __builtin_amdgcn_readfirstlane(d.item);
+    d.index = __builtin_amdgcn_readfirstlane(d.index);
+    d.flags = __builtin_amdgcn_readfirstlane(d.flags);
+    d.next_len = __builtin_amdgcn_readfirstlane(d.next_len);
+#endif
+    return d;
+}
+
+/*
+ * Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also
+ * drains the vector-memory counter, which would stall on an LDS-DMA prefetch or on the
+ * copy-out stores that are meant to stay in flight (guide: "Pipelining across barriers").
+ */
+__device__ __forceinline__ void barrier_lds() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
+/* 16 bytes global -> LDS without a register in between (global_load_lds_dwordx4) */
+__device__ __forceinline__ void lds_dma16(const void *global_src, void *lds_dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)global_src, (__attribute__((address_space(3))) void *)lds_dst,
+        16, 0, 0);
+#else
+    memcpy(lds_dst, global_src, 16);
+#endif
+}
+
+__device__ __forceinline__ u32 funnel(u32 hi, u32 lo, u32 shift /* 0..31 */) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, shift);
+#else
+    return (u32)(((((u64)hi) << 32) | lo) >> shift);
+#endif
+}
+
+/*
+ * The same loads for a poll loop: load and wait in one piece of assembly, so that the compiler sees a value, not a
+ * load in flight.  (A load it knows of inside the loop makes every wait behind the loop a wait for everything --
+ * among it the next tile's symbols, which are meant to stay in flight.)  Polling with atomics (which are carried out
+ * at the memory side and cannot be served from a cache) was tried: 2 000 waves asking for one word that way take
+ * turns at ~12 ns each -- 18 ms instead of 0.6.
+ */
+__device__ __forceinline__ u32 word_load_now(const u32 *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+#else
+    return *p;
+#endif
+}
+
+__device__ __forceinline__ u64 granule_load_now(const u64 *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+#else
+    return *p;
+#endif
+}
+
+/*
+ * A tile's arrival (flagged word + add to its group), issued without the compiler knowing of a store in flight: with
+ * loads and a store outstanding together it makes every wait a wait for everything (it has to assume that the two
+ * kinds complete in any order), and the wait behind this is for the old tile's offsets only -- the next tile's symbols
+ * are meant to stay in flight.  A counted wait that does not count these two still covers the loads it is for: at
+ * most two of the operations it lets stand are these, the others are loads, which complete in order.
+ */
+__device__ __forceinline__ void arrival_quiet(u32 *flag_word, u32 flagged, u64 *group, u64 add) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_store_dword %0, %1, off sc1\n\tglobal_atomic_add_x2 %2, %3, off"
+                 :
+                 : "v"(flag_word), "v"(flagged), "v"(group), "v"(add)
+                 : "memory");
+#else
+    *flag_word = flagged;
+    *group += add;
+#endif
+}
+
+/* a value that is the same in every lane, as a scalar */
+__device__ __forceinline__ u32 uniform32(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readfirstlane(x);
+#else
+    return __shfl(x, 0);
+#endif
+}
+
+__device__ __forceinline__ u64 uniform64(u64 x) {
+    return ((u64)uniform32((u32)(x >> 32)) << 32) | uniform32((u32)x);
+}
+
 /* lanes of a wave take turns in program order (what one lane wrote to LDS, another reads behind this): nothing on the GPU
  * but a line the compiler does not move LDS accesses across, a rendezvous of the wave's fibers under tests/emu */
 __device__ __forceinline__ void wave_step() {

@@ -62,6 +62,13 @@ rounds = [
     ("plans_made_on_the_device", lambda s: pc.plans_made_on_the_device(w, seed=s, engine=eng, big=600_000 + 1013 * (s % 60), n_small=200 + s % 120)
      if s % 3 == 0 else None),
     ("streams_with_two_last_chunks", lambda s: pc.streams_with_two_last_chunks(w, seed=s, engine=eng, modes=(None,)) if s % 3 == 1 else None),
+    # round 6: a few stream ends folded into the sync kernel's grid (the stream's last symbols followed by the workgroup), quiet
+    # plans (no kernels for listed chunks until a fetch says chunks were listed), the encoder's way back by ticket
+    ("few_ends_among_many_chunks", lambda s: pc.few_ends_among_many_chunks(w, n=330_000 + 1017 * (s % 70), seed=s, engine=eng, modes=(None,))
+     if s % 2 == 0 else None),
+    ("quiet_plans", lambda s: pc.quiet_plans(w, n=300_000 + 997 * (s % 50), seed=s, engine=eng) if s % 3 == 2 else None),
+    ("encode_roads", lambda s: pc.encode_roads(w, sizes=(200_000 + 1021 * (s % 30), 16384, 40_000 + s % 999, 1_000_000 + 4099 * (s % 20)), seed=s)
+     if s % 4 == 3 else None),
 ]
 rounds = [r for r in rounds if only in r[0]]
 t0 = time.time()

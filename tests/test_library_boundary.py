@@ -228,6 +228,20 @@ def test_kernel_census(kernel_listing):
     assert not [n for n in names if "dec_onepass" in n or "dec_sync_bank" in n or "dec_sync_resident" in n or "dec_sync_fast" in n]
 
 
+def test_kernels_spell_nothing_differently_for_the_cpu_build():
+    """What the GPU build and the CPU test build (tests/emu) spell differently -- inline assembly, address-space casts,
+    scalar broadcasts -- is in the two headers of primitives (kernels_common.hpp, decode_common.hpp), each with a plain C++
+    twin beside it: no kernel source has an arm of its own for the emulator."""
+    hip = os.path.join(harness.REPO, "aws-c-compression_amd", "csrc", "hip")
+    for name in sorted(n for n in os.listdir(hip) if n.endswith((".hip", ".hpp", ".h", ".inc"))):
+        text = open(os.path.join(hip, name)).read()
+        arms = text.count("__HIP_DEVICE_COMPILE__")
+        if name in ("kernels_common.hpp", "decode_common.hpp"):
+            assert arms >= 1, name
+        else:
+            assert arms == 0, (name, arms)
+
+
 def test_no_kernel_spills_vector_registers(kernel_listing):
     """No kernel of the library has scratch memory or a spilled vector register (profiles/tools/spill_census.py prints
     the same table): a value spilled inside these kernels' divergent walks once came back wrong, and a spill in a
