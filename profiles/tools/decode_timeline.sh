@@ -18,7 +18,7 @@ import re
 def short(n):
     m = re.search(r"(\w+_kernel(<[^>]*>)?)", n)
     return m.group(1) if m else n[:60]
-last = max(i for i, n in enumerate(names) if short(n).startswith("dec_sync_one_kernel") and "false" in short(n))
+last = max(i for i, n in enumerate(names) if short(n).startswith("dec_sync_one_mixed_kernel") or (short(n).startswith("dec_sync_one_kernel") and "false" in short(n)))
 t0 = int(rows[last]["Start_Timestamp"]); prev_end = t0
 out = open(sys.argv[1] + "/timeline.txt", "w")
 for r in rows[last:]:

@@ -33,7 +33,7 @@ GROUPS = [  # bench kernel name <- substrings of the device kernel names it cove
     ("enc_count", ["enc_count_kernel"]),
     ("enc_scan", ["enc_scan_small_kernel", "enc_scan_large_kernel"]),
     ("enc_pack", ["enc_pack_wave_kernel", "enc_pack_stream_kernel", "enc_pack_kernel"]),
-    ("dec_sync", ["dec_sync_one_kernel", "dec_sync_pack_kernel", "dec_sync_guess_kernel", "dec_sync_few_kernel", "dec_sync_tail_kernel",
+    ("dec_sync", ["dec_sync_one_kernel", "dec_sync_one_mixed_kernel", "dec_sync_pack_kernel", "dec_sync_guess_kernel", "dec_sync_few_kernel", "dec_sync_tail_kernel",
                   "dec_sync_kernel"]),
     ("dec_scan", ["dec_scan_small_kernel", "dec_scan_runs_kernel", "dec_scan_apply_kernel",
                   "dec_sync_true_kernel", "dec_tiny_kernel", "dec_deep_kernel"]),
