@@ -16,6 +16,7 @@ namespace {
 
 constexpr u32 kPlanThreads = 256;
 constexpr u32 kPlanVec = 8; /* counters per item that are scanned into positions */
+constexpr u32 kPlanStatsBlocks = 128; /* workgroups of the statistics pass at most (each adds its findings to one record) */
 /* the longest encode item a plan made here takes: its segments fit 32 bits with room to spare (the host's loop refuses
  * a plan of 0xFFFFFFFF segments or more, csrc/host/engine.c enc_plan_fill) */
 constexpr u64 kEncItemMaxBytes = (u64)(0xFFFFFFFEull - 1) * HUFD_ENC_SEG_BYTES;
@@ -97,22 +98,60 @@ __global__ __launch_bounds__(kPlanThreads) void plan_stats_kernel(hufd_item_sour
     }
     __syncthreads();
     const u32 i = blockIdx.x * kPlanThreads + threadIdx.x;
-    if (i < n_items) {
-        const raw_item r = load_item<ENC>(src, i);
+    /* a thread's item as the sums and maxima it adds to; the wave folds them first and ONE lane adds to the workgroup's
+     * record -- eleven LDS atomics a thread on the same seven words were 0.40 ms for a million items (the whole of a fresh
+     * plan's pass was this kernel), a wave's worth of them 0.03 */
+    u64 count[2] = {0, 0}, longest_in[2] = {0, 0}, not_shortest = 0, longest = 0, out_cap = 0, bits = 0, invalid = 0;
+    /* (a workgroup takes items in turn: what it has to say goes into ONE record of the device with nine atomics on one
+     * memory line -- from a workgroup per 256 items those were 37 000 of them for a million items, one after the other at
+     * the memory side: 0.39 ms, the whole of the pass; from at most kPlanStatsBlocks workgroups 1 200) */
+    for (u64 at = i; at < n_items; at += (u64)gridDim.x * kPlanThreads) {
+        const raw_item r = load_item<ENC>(src, (u32)at);
         const u64 classes[2] = {class0, class1};
         for (u32 c = 0; c < 2; ++c) {
             if (r.in_len <= classes[c]) {
-                atomicAdd(&local->count[c], (u64)1);
-                atomicMax(&local->longest_in_class[c], r.in_len);
+                count[c] += 1;
+                longest_in[c] = r.in_len > longest_in[c] ? r.in_len : longest_in[c];
             }
         }
-        atomicMax(&local->not_shortest, ~r.in_len);
-        atomicMax(&local->longest, r.in_len);
-        atomicMax(&local->largest_out_cap, r.out_cap);
-        atomicMax(&local->worst_bits, (u64)r.bits);
+        not_shortest = ~r.in_len > not_shortest ? ~r.in_len : not_shortest;
+        longest = r.in_len > longest ? r.in_len : longest;
+        out_cap = r.out_cap > out_cap ? r.out_cap : out_cap;
+        bits = r.bits > bits ? r.bits : bits;
         /* (an item is refused where the host's loop refuses it: a decode item holds less than 4 GiB; an encode item's
          *  segments must be a number the 32-bit counts below can hold -- more of them than that is no plan either way) */
-        if (ENC ? (r.bits > 32 || r.in_len > kEncItemMaxBytes) : (r.bits > 7 || r.in_len > 0xFFFFFFFFull)) {
+        invalid |= (ENC ? (r.bits > 32 || r.in_len > kEncItemMaxBytes) : (r.bits > 7 || r.in_len > 0xFFFFFFFFull)) ? 1u : 0u;
+    }
+#pragma unroll
+    for (u32 d = kWave / 2; d > 0; d >>= 1) {
+#pragma unroll
+        for (u32 c = 0; c < 2; ++c) {
+            count[c] += __shfl_xor(count[c], d);
+            const u64 o = __shfl_xor(longest_in[c], d);
+            longest_in[c] = o > longest_in[c] ? o : longest_in[c];
+        }
+        u64 o = __shfl_xor(not_shortest, d);
+        not_shortest = o > not_shortest ? o : not_shortest;
+        o = __shfl_xor(longest, d);
+        longest = o > longest ? o : longest;
+        o = __shfl_xor(out_cap, d);
+        out_cap = o > out_cap ? o : out_cap;
+        o = __shfl_xor(bits, d);
+        bits = o > bits ? o : bits;
+        invalid |= __shfl_xor(invalid, d);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        for (u32 c = 0; c < 2; ++c) {
+            if (count[c]) {
+                atomicAdd(&local->count[c], count[c]);
+                atomicMax(&local->longest_in_class[c], longest_in[c]);
+            }
+        }
+        atomicMax(&local->not_shortest, not_shortest);
+        atomicMax(&local->longest, longest);
+        atomicMax(&local->largest_out_cap, out_cap);
+        atomicMax(&local->worst_bits, bits);
+        if (invalid) {
             atomicMax(&local->invalid, (u64)1);
         }
     }
@@ -317,33 +356,42 @@ __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(
     }
 }
 
-/* one workgroup: the sums of the workgroups in front of each (in place), and the totals */
+/* one workgroup: the sums of the workgroups in front of each (in place), and the totals.  A thread takes a stretch of
+ * consecutive workgroups (its eight sums in registers), the threads' sums are scanned once a counter, and the thread writes
+ * its stretch's positions: eight scans of the workgroup whatever the batch -- a scan a counter and 256 workgroups of the
+ * batch was 128 of them for a million items, 83 us */
 __global__ __launch_bounds__(kPlanThreads) void plan_scan_blocks_kernel(u32 *block_sums, u32 n_blocks, plan_decision *decision) {
     u32 *slots = reinterpret_cast<u32 *>(dyn_lds); /* [kPlanThreads / 64] */
-    u64 *carry = reinterpret_cast<u64 *>(dyn_lds + 64); /* [kPlanVec] */
-    if (threadIdx.x < kPlanVec) {
-        carry[threadIdx.x] = 0;
+    const u32 per = (n_blocks + kPlanThreads - 1) / kPlanThreads;
+    const u32 lo = threadIdx.x * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
+    u32 mine[kPlanVec];
+#pragma unroll
+    for (u32 k = 0; k < kPlanVec; ++k) {
+        mine[k] = 0;
     }
-    __syncthreads();
-    for (u32 base = 0; base < n_blocks; base += kPlanThreads) {
-        const u32 b = base + threadIdx.x;
+    for (u32 b = lo; b < hi; ++b) {
 #pragma unroll
         for (u32 k = 0; k < kPlanVec; ++k) {
-            const u32 mine = b < n_blocks ? block_sums[(u64)b * kPlanVec + k] : 0u;
-            u32 total = 0;
-            const u32 before = block_exclusive_sum<kPlanThreads>(mine, slots, total);
-            if (b < n_blocks) {
-                block_sums[(u64)b * kPlanVec + k] = (u32)carry[k] + before;
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                carry[k] += total;
-            }
-            __syncthreads();
+            mine[k] += block_sums[(u64)b * kPlanVec + k];
         }
     }
-    if (threadIdx.x < kPlanVec) {
-        decision->totals[threadIdx.x] = carry[threadIdx.x];
+    u32 before[kPlanVec];
+#pragma unroll
+    for (u32 k = 0; k < kPlanVec; ++k) {
+        u32 total = 0;
+        before[k] = block_exclusive_sum<kPlanThreads>(mine[k], slots, total);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            decision->totals[k] = total;
+        }
+    }
+    for (u32 b = lo; b < hi; ++b) {
+#pragma unroll
+        for (u32 k = 0; k < kPlanVec; ++k) {
+            const u32 here = block_sums[(u64)b * kPlanVec + k];
+            block_sums[(u64)b * kPlanVec + k] = before[k];
+            before[k] += here;
+        }
     }
 }
 
@@ -509,7 +557,9 @@ int plan_count(
     if (e != hipSuccess) {
         return (int)e;
     }
-    hipLaunchKernelGGL((plan_stats_kernel<ENC>), dim3(blocks), dim3(kPlanThreads), sizeof(plan_stats), st, *src, n_items, class0, class1, stats);
+    hipLaunchKernelGGL(
+        (plan_stats_kernel<ENC>), dim3(blocks < kPlanStatsBlocks ? blocks : kPlanStatsBlocks), dim3(kPlanThreads), sizeof(plan_stats), st, *src,
+        n_items, class0, class1, stats);
     hipLaunchKernelGGL(plan_decide_kernel, dim3(1), dim3(64), 0, st, stats, class0, class1, per_byte, decision);
     hipLaunchKernelGGL((plan_count_kernel<ENC>), dim3(blocks), dim3(kPlanThreads), 128, st, *src, n_items, decision, shortest_code, solo_limit, stats, block_sums);
     hipLaunchKernelGGL(plan_scan_blocks_kernel, dim3(1), dim3(kPlanThreads), 128, st, block_sums, blocks, decision);
