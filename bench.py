@@ -335,7 +335,10 @@ def run_stream(args, ranks, lib, eng):
     eng.fill_splitmix64(d_in, n, seed)
     enc_plan = eng.encode_plan([dict(in_offset=0, in_len=n, out_offset=0, out_capacity=worst)])
 
-    # untimed first pass: learn the encoded length, build the decode plan, check the round trip
+    # untimed first pass: learn the encoded length, build the decode plan, check both record sets.  The digests of what
+    # the passes wrote are taken AFTER the timed steps (hashing three GiB on the host leaves the GPU idle for seconds, and
+    # its clocks need ~13 steps to settle after that -- profiles/tools/step_ramp.py: the set-up would put that ramp into
+    # the timed steps); a stream that differs from the pinned one still ends the run without a line.
     eng.encode_launch(enc_plan, d_in, d_enc)
     (rc, err, consumed, e_len, _, _), = eng.encode_results(enc_plan, 1)
     assert rc == 0 and consumed == n, (rc, err, consumed)
@@ -343,20 +346,16 @@ def run_stream(args, ranks, lib, eng):
     eng.decode_launch(dec_plan, d_enc, d_back)
     (rc, err, symbols, _), = eng.decode_results(dec_plan, 1)
     assert rc == 0 and symbols == n, (rc, err, symbols)
-    in_digest = digest_of(eng, d_in, n)
-    assert digest_of(eng, d_back, n) == in_digest, "round trip is not bit-exact"
-    enc_digest = digest_of(eng, d_enc, e_len)
-    pinned_by = None
+    pinned, pinned_by = None, None
     if n == GIB and seed == 5:
         pinned = harness.load_json("survey_probe_records.json")["streams"]["G1G"]
-        assert (e_len, enc_digest) == (pinned["encoded_len"], pinned["sha256_encoded"]), "encoded stream differs from the reference's"
         pinned_by = "the survey's record of the real reference (tests/golden/survey_probe_records.json)"
     elif n == GIB and str(seed) in harness.load_json("config5_stream_pins.json")["streams"]:
         # configs[4]: rank g's stream is seed 5 + g; seeds 6 .. 12 are pinned by the oracle (tests/golden/make_config5_pins.py)
         pinned = harness.load_json("config5_stream_pins.json")["streams"][str(seed)]
-        assert in_digest == pinned["sha256_input"], "rank %d: input stream differs from the pinned one" % ranks.rank
-        assert (e_len, enc_digest) == (pinned["encoded_len"], pinned["sha256_encoded"]), "rank %d: encoded stream differs from the oracle's" % ranks.rank
         pinned_by = "the pinned oracle's record (tests/golden/config5_stream_pins.json)"
+    if pinned:
+        assert e_len == pinned["encoded_len"], "rank %d: encoded length differs from the pinned one" % ranks.rank
 
     names_e, names_d = stage_names(lib, eng)
     stages = Stages(eng, args.steps, names_e, names_d)
@@ -384,9 +383,12 @@ def run_stream(args, ranks, lib, eng):
     # what the TIMED steps left behind: both record sets, both digests, the roads taken (untimed)
     (rc, err, consumed, e_after, _, _), = eng.encode_results(enc_plan, 1)
     (rc2, err2, symbols, _), = eng.decode_results(dec_plan, 1)
-    bit_exact = ((rc, consumed, e_after) == (0, n, e_len) and (rc2, symbols) == (0, n) and
-                 digest_of(eng, d_enc, e_len) == enc_digest and digest_of(eng, d_back, n) == in_digest)
-    assert bit_exact, "the timed steps did not leave the pinned stream and its round trip"
+    in_digest, enc_digest = digest_of(eng, d_in, n), digest_of(eng, d_enc, e_len)
+    if pinned:
+        assert in_digest == pinned.get("sha256_input", in_digest), "rank %d: input stream differs from the pinned one" % ranks.rank
+        assert enc_digest == pinned["sha256_encoded"], "rank %d: encoded stream differs from the pinned one" % ranks.rank
+    bit_exact = ((rc, consumed, e_after) == (0, n, e_len) and (rc2, symbols) == (0, n) and digest_of(eng, d_back, n) == in_digest)
+    assert bit_exact, "the timed steps did not leave the stream's round trip"
     roads = {0: "two-pass", 1: "one-pass", 2: "one-pass gave up, two-pass did the launch over"}
 
     kernel_ms, t_enc_ms, t_dec_ms = stages.medians()
