@@ -580,7 +580,7 @@ __device__ __forceinline__ u32 lean_row(u32 state, u32 hi, u32 lo, u32 table, co
  * stage, the state on.  Written out for the GPU as lean_row is: what the compiler makes of the loop in C is eight vector
  * instructions a trip (shift, address, a copy of the store address, that address + 1, + the record's base, the state's add, a
  * compare through SDWA) and two scalar ones that fold the compare into the exec mask; here five and a branch -- the compare is
- * v_cmpx_lt_u16 on the state's low half, straight into exec.  2.2 of a row's 5.2 trips are such trips, for either chain.
+ * v_cmpx_lt_u16 on the state's low half, straight into exec.  1.3 of a row's 4.3 trips are such trips, for either chain.
  * `at`: where the chain's next symbol goes, as an LDS address.  v62 / v63 are the block's own temporaries.
  */
 __device__ __forceinline__ void emit_uncertain_codes(u32 &state, u32 &at, u64 pair, u32 table, const row_walk &rw) {
