@@ -576,6 +576,42 @@ __device__ __forceinline__ u32 lean_row(u32 state, u32 hi, u32 lo, u32 table, co
 }
 
 /*
+ * The codes of a row behind the certain ones for a walk whose position is the state's low BYTE and whose row is two words
+ * shifted for a 32-bit funnel (dec_sync_one's one_walk): while the byte is above `thr`, the entry of the window at the
+ * position's low five bits, added.  Written out for the GPU: the compiler's loop is five vector instructions a trip (funnel,
+ * and, add, an AND that cuts the byte out, compare) and two scalar ones that fold the compare into the exec mask; here four
+ * and a branch -- the compare looks at the byte by itself (SDWA) and writes exec.
+ */
+__device__ __forceinline__ u32 byte_rows_uncertain(u32 state, u32 xh, u32 xl, u32 table, u32 mask, u32 thr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 saved_exec;
+    u32 t;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_gt_u32_sdwa vcc, %[st], %[thr] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+        "s_cbranch_execz 2f\n"
+        "1:\n\t"
+        "v_alignbit_b32 %[t], %[xh], %[xl], %[st]\n\t"
+        "v_and_or_b32 %[t], %[t], %[mask], %[tab]\n\t"
+        "ds_read_b32 %[t], %[t]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_add_u32_e32 %[st], %[st], %[t]\n\t"
+        "v_cmpx_gt_u32_sdwa vcc, %[st], %[thr] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+        "s_cbranch_execnz 1b\n"
+        "2:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [st] "+v"(state), [t] "=&v"(t), [sv] "=&s"(saved_exec)
+        : [xh] "v"(xh), [xl] "v"(xl), [mask] "s"(mask), [tab] "v"(table), [thr] "s"(thr)
+        : "vcc");
+#else
+    while ((state & 0xFFu) > thr) {
+        state += lds_word_at((funnel_by_low5(xh, xl, state) & mask) | table);
+    }
+#endif
+    return state;
+}
+
+/*
  * The codes of a row behind the certain ones, one chain: while a code starts in the row, its table entry, its symbol to the
  * stage, the state on.  Written out for the GPU as lean_row is: what the compiler makes of the loop in C is eight vector
  * instructions a trip (shift, address, a copy of the store address, that address + 1, + the record's base, the state's add, a

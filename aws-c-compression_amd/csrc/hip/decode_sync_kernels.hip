@@ -302,40 +302,57 @@ __device__ __host__ constexpr u32 one_rec_index(u32 row) {
     return at;
 }
 
-/* state = symbols << 21 | windows without a code << 10 | position (as row_walk's low half: thr + 32 - bits into the row) */
+/*
+ * state = symbols << 19 | windows without a code << 8 | position, a byte: thr + 32 - bits into the row.
+ *
+ * The rows of this kernel are not taken from the sub-chunk's words as they lie but from words SHIFTED by 31 - LB bits
+ * (`shifted`: row r's first word starts 31 - LB bits in front of word r): the window of a code that starts k bits into row
+ * r then stands at bits 2 .. LB + 1 of (xh:xl) >> (31 - k), a shift below 32 for every k of the row -- ONE 32-bit funnel
+ * shift (v_alignbit_b32) of two registers that need not be a pair, its amount the position's low five bits as they stand.
+ * With the words as they lie the shift runs to 62 - LB: a 64-bit shift of an aligned register pair, which the compiler put
+ * together anew for every row (two v_perm a row: the byte swap fused with the copy), and the position was ten bits with the
+ * other counts on top of it -- an AND in front of every compare where a byte compares by itself (SDWA).  A row's ~20
+ * vector instructions became ~16, and these kernels' vector units are busy 80 % of their time (`SQ_ACTIVE_INST_VALU`).
+ */
 struct one_walk {
     u32 thr, mask;
+    static constexpr u32 kPos = 0xFFu;
     __device__ __forceinline__ one_walk(u32 lut_bits) {
-        thr = 512 + (32 - lut_bits) - 2;
+        thr = 64 + 31;
         mask = ((1u << lut_bits) - 1u) << 2;
     }
     __device__ __forceinline__ u32 state_at(u32 k) const {
         return thr + 32 - k;
     }
     __device__ __forceinline__ u32 offset_of(u32 state) const {
-        return thr + 32 - (state & 0x3FFu);
+        return thr + 32 - (state & kPos);
     }
     static __device__ __forceinline__ u32 count_of(u32 state) {
-        return state >> 21;
+        return state >> 19;
     }
     static __device__ __forceinline__ u32 dead_of(u32 state) {
-        return (state >> 10) & 0x7FFu;
+        return (state >> 8) & 0x7FFu;
     }
     static __device__ __forceinline__ u32 entry_of(u32 len) { /* a code: a symbol more, `len` bits on; none: a mark more, one bit on */
-        return len ? (1u << 21) - len : (1u << 10) - 1u;
+        return len ? (1u << 19) - len : (1u << 8) - 1u;
     }
-    /* every code of the walk that starts in the row whose words are hi:lo (SURE of them without asking) */
+    /* a row's first word, from the stream's word in front of the row's (big-endian, as bswap gives it) and the row's own */
+    template <u32 LB>
+    static __device__ __forceinline__ u32 shifted(u32 before, u32 word) {
+        return funnel(before, word, 31u - LB);
+    }
+    /* the table entry of the code the walk stands at, in the row whose shifted words are xh:xl */
+    __device__ __forceinline__ u32 look(u32 state, u32 xh, u32 xl, u32 table) const {
+        return lds_word_at((funnel_by_low5(xh, xl, state) & mask) | table);
+    }
+    /* every code of the walk that starts in that row (SURE of them without asking) */
     template <u32 SURE>
-    __device__ __forceinline__ u32 row(u32 state, u32 hi, u32 lo, u32 table) const {
-        const u64 pair = ((u64)hi << 32) | lo;
+    __device__ __forceinline__ u32 row(u32 state, u32 xh, u32 xl, u32 table) const {
 #pragma unroll
         for (u32 i = 0; i < SURE; ++i) {
-            state += lds_word_at(((u32)(pair >> (state & 63u)) & mask) | table);
+            state += look(state, xh, xl, table);
         }
-        while ((state & 0x3FFu) > thr) {
-            state += lds_word_at(((u32)(pair >> (state & 63u)) & mask) | table);
-        }
-        return state;
+        return byte_rows_uncertain(state, xh, xl, table, mask, thr);
     }
 };
 

@@ -198,6 +198,16 @@ __device__ __forceinline__ u32 funnel(u32 hi, u32 lo, u32 shift /* 0..31 */) {
 #endif
 }
 
+/* the same with the shift taken from the low five bits of a word that holds other things above them (v_alignbit_b32 looks at
+ * those five bits only: no AND in front of it) */
+__device__ __forceinline__ u32 funnel_by_low5(u32 hi, u32 lo, u32 word) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, word);
+#else
+    return (u32)(((((u64)hi) << 32) | lo) >> (word & 31u));
+#endif
+}
+
 /*
  * The same loads for a poll loop: load and wait in one piece of assembly, so that the compiler sees a value, not a
  * load in flight.  (A load it knows of inside the loop makes every wait behind the loop a wait for everything --
