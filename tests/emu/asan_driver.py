@@ -2,7 +2,7 @@
 of UBSan (tests/test_emulated_asan.py builds it and runs this with libasan preloaded): the roads that index by what a
 stream says -- one-launch calls, long-code items across blocks (settled and by transfer functions), fixed-length coders,
 the ways back, the chunks whose walks never become one, the packed end-of-stream chunks, plans chained on the device, the
-encoder's wave-per-item road --
+encoder's wave-per-item road, a long stream's end inside the sync kernel's grid, the encoder's way back by ticket --
 with every access of the kernels' code checked."""
 import os
 import sys
@@ -26,7 +26,11 @@ for run in (lambda: pc.block_decode_calls(w, wants=(130, 513, 8192, 8193, 16385,
             # wave, staged through the image's LDS)
             lambda: pc.walks_that_never_meet(w, runs=(130, 420)),
             lambda: pc.tiny_encode_items(w, n_items=270, seed=161, max_len=20000, edge_lens=False, more_lens=(4095, 4096, 4097, 16383, 16384, 16385)),
-            lambda: pc.tiny_encode_items(w, n_items=90, seed=162, max_len=9000, edge_lens=False, more_lens=(4095, 4096, 4097))):
+            lambda: pc.tiny_encode_items(w, n_items=90, seed=162, max_len=9000, edge_lens=False, more_lens=(4095, 4096, 4097)),
+            # round 6: a few stream ends as workgroups of the sync kernel's own grid (the stream's last symbols followed there),
+            # the encoder's way back by ticket, dec_sync_one's rows through shifted words
+            lambda: pc.few_ends_among_many_chunks(w, modes=(None,)),
+            lambda: pc.encode_roads(w, sizes=(200_000, 16384, 40_000))):
     t0 = time.time()
     run()
     print("%.0f s" % (time.time() - t0), flush=True)
