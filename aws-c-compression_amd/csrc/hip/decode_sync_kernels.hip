@@ -361,10 +361,9 @@ struct one_shared {
     u32 wlut[1u << LB]; /* one_walk::entry_of(length); at a multiple of its own size */
     u32 exit_state[HUFD_DEC_LANES];
     u32 sub0[kSubWords + 4]; /* sub-chunk 0's rows, for the threads that try its entry states */
-    /* every lane's guessed walk at the kept boundaries, and at the quarter boundaries behind them: written and read by the lane
-     * itself (and lane 0's by the threads that try sub-chunk 0's entry states) -- in LDS because 33 words of stream are what a
-     * lane's registers hold at eight waves a SIMD: with these twelve beside them the kernel spilled, and took twice as long */
-    u32 kept[kOneRecs + kQuarters - 1][HUFD_DEC_LANES];
+    /* (every lane's guessed walk at the kept boundaries lived here in round 5, 12 KiB: the states are in registers now) */
+    u32 last0;             /* lane 0's guessed walk at the sub-chunk's end: what the candidates of sub-chunk 0 ask of it */
+    u32 tiny[kTailWords];  /* FOLLOW, a chunk of fewer than 136 bytes: its words for the one thread that follows the stream */
     u32 wave_sum[HUFD_DEC_LANES / 64];
     u32 bad;
     u32 decided0; /* every entry state of sub-chunk 0 died or met lane 0's walk: what dec_sync_guess needs of a chunk */
